@@ -1,0 +1,270 @@
+/* vpt.h — C-ABI of the MI355X wavefront render backend.
+ *
+ * Drop-in boundary for the hot path of Zydak/Vulkan-Path-Tracer.
+ * The reference has no FFI; the seam is the C++ class surface its Editor calls:
+ *   PathTracer     (PathTracer/PathTracer.h:83-183)
+ *   PostProcessor  (PathTracer/PostProcessor.h:8-33)
+ * Each entry point below names the reference member(s) it replaces.  The C++
+ * facade in vulkan-path-tracer_amd/host/ (class PathTracer / PostProcessor /
+ * FlyCamera with the reference's method names) is a thin shim over these calls;
+ * INTEGRATION.md shows the binding a maintainer would add upstream.
+ *
+ * Conventions: plain pointers and sizes only; return 0 or a negative VPT_ERR_*;
+ * never aborts; device memory is owned by the context, host buffers by the
+ * caller; one host thread per context; matrices are float[16] column-major
+ * exactly as glm stores a mat4; all struct layouts are the reference's scalar
+ * layouts (Bindings.slang) so existing host data can be passed through.
+ */
+#ifndef VPT_H
+#define VPT_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VPT_OK 0
+#define VPT_ERR_INVALID_ARGUMENT (-1)
+#define VPT_ERR_NO_DEVICE (-2)     /* HIP device/runtime missing: the backend never falls back to a CPU path */
+#define VPT_ERR_OUT_OF_MEMORY (-3)
+#define VPT_ERR_NO_SCENE (-4)
+#define VPT_ERR_DEVICE (-5)        /* a HIP call failed; see vpt_last_error() */
+#define VPT_ERR_UNSUPPORTED (-6)
+#define VPT_ERR_LIMIT (-7)         /* MAX_ENTITIES / MAX_INSTANCES / MAX_EMISSIVE_MESHES, PathTracer.h:192-195 */
+
+/* Limits, PathTracer.h:192-195 (asserts PathTracer.cpp:182-184). */
+#define VPT_MAX_ENTITIES 10000u
+#define VPT_MAX_INSTANCES 100000u
+#define VPT_MAX_EMISSIVE_MESHES 10000u
+
+/* Feature flags == the Slang #define set assembled at PathTracer.cpp:621-654. */
+#define VPT_FLAG_SKY_MIS (1u << 0)             /* ENABLE_SKY_MIS            SetSkyMIS            */
+#define VPT_FLAG_MESH_MIS (1u << 1)            /* ENABLE_MESH_MIS           SetMeshMIS           */
+#define VPT_FLAG_SHOW_ENV_DIRECTLY (1u << 2)   /* SHOW_ENV_MAP_DIRECTLY     SetEnvMapShownDirectly */
+#define VPT_FLAG_GEOMETRY_NORMALS (1u << 3)    /* USE_ONLY_GEOMETRY_NORMALS SetUseOnlyGeometryNormals */
+#define VPT_FLAG_ENERGY_COMPENSATION (1u << 4) /* USE_ENERGY_COMPENSATION   SetUseEnergyCompensation */
+#define VPT_FLAG_FURNACE (1u << 5)             /* FURNACE_TEST_MODE         SetFurnaceTestMode   */
+#define VPT_FLAG_RAY_QUERIES (1u << 6)         /* USE_RAY_QUERIES (only mode implemented)        */
+/* Tonemap.slang:170 samples the bloom image with a sampler whose filter is VulkanHelper's
+ * default (PostProcessor.cpp:67, unpinned): set = LINEAR (default), clear = NEAREST. */
+#define VPT_FLAG_TONEMAP_LINEAR_BLOOM_TAP (1u << 7)
+#define VPT_FLAGS_DEFAULT                                                                                   \
+    (VPT_FLAG_SKY_MIS | VPT_FLAG_MESH_MIS | VPT_FLAG_SHOW_ENV_DIRECTLY | VPT_FLAG_ENERGY_COMPENSATION |    \
+     VPT_FLAG_RAY_QUERIES | VPT_FLAG_TONEMAP_LINEAR_BLOOM_TAP) /* PathTracer.h:211-221 */
+
+/* == PathTracer::Material (PathTracer.h:12-34) == CPUMaterial (Bindings.slang:55-77); 112 bytes. */
+typedef struct vpt_material {
+    float base_color[3];
+    float emissive_color[3];
+    float specular_color[3];
+    float medium_color[3];
+    float medium_emissive_color[3];
+    float metallic;
+    float roughness;
+    float ior;
+    float transmission;
+    float anisotropy;
+    float anisotropy_rotation;
+    float medium_density;
+    float medium_anisotropy;
+    uint32_t base_color_texture;
+    uint32_t normal_texture;
+    uint32_t roughness_texture;
+    uint32_t metallic_texture;
+    uint32_t emissive_texture;
+} vpt_material;
+
+/* == Vertex (Bindings.slang:7-12) == VulkanHelper::LoadedMeshVertex (PathTracer.cpp:190-194); 32 bytes. */
+typedef struct vpt_vertex {
+    float position[3];
+    float normal[3];
+    float texcoord[2];
+} vpt_vertex;
+
+/* == VulkanHelper Mesh as used at PathTracer.cpp:204-225. */
+typedef struct vpt_mesh {
+    const vpt_vertex* vertices;
+    uint32_t vertex_count;
+    const uint32_t* indices;
+    uint32_t index_count;
+} vpt_mesh;
+
+/* == VulkanHelper::MeshInstance as used at PathTracer.cpp:449-481. */
+typedef struct vpt_instance {
+    uint32_t mesh_index;
+    uint32_t material_index;
+    float transform[16];
+} vpt_instance;
+
+/* == TextureAsset, PathTracer.cpp:815-836: channels 4 = RGBA8 UNORM, 1 = R8 UNORM. */
+typedef struct vpt_texture {
+    uint32_t width;
+    uint32_t height;
+    uint32_t channels;
+    const uint8_t* data;
+} vpt_texture;
+
+/* Scene as PathTracer::SetScene assembles it (PathTracer.cpp:158-676).  Texture indices in the
+ * materials index `textures`.  `env_rgba` is the RGBA32F environment image (alpha is ignored;
+ * importance, alias table and the per-texel pdf in alpha are derived by the backend exactly as
+ * LoadEnvironmentMap does, PathTracer.cpp:1137-1332).  The three energy-compensation tables are
+ * the contents of Assets/LookupTables/ (.bin files; 64x64x32, 128x128x32, 128x128x32 floats). */
+typedef struct vpt_scene_desc {
+    const vpt_mesh* meshes;
+    uint32_t mesh_count;
+    const vpt_material* materials;
+    uint32_t material_count;
+    const vpt_instance* instances;
+    uint32_t instance_count;
+    const vpt_texture* textures;
+    uint32_t texture_count;
+    const float* env_rgba;
+    uint32_t env_width;
+    uint32_t env_height;
+    const float* lut_reflection;
+    const float* lut_refraction_outside;
+    const float* lut_refraction_inside;
+} vpt_scene_desc;
+
+/* Scalar state of PathTracer (PathTracer.h:197-233) that reaches the shaders through
+ * PathTracerUniform (PathTracer.h:271-302) plus the feature-flag set, plus the one thing the
+ * reference does not expose: the seed.  Reference: Seed = PCGHash(wall-clock ms)
+ * (PathTracer.cpp:127-140); here Seed(dispatch k) = PCGHash(base_seed + k). */
+typedef struct vpt_params {
+    uint32_t samples_per_frame; /* SetSamplesPerFrame, default 1 */
+    uint32_t max_samples;       /* SetMaxSamplesAccumulated, default 5000 */
+    uint32_t max_depth;         /* SetMaxDepth, default 200 */
+    float max_luminance;        /* SetMaxLuminance, default 500 */
+    float focus_distance;       /* SetFocusDistance, default 1 */
+    float dof_strength;         /* SetDepthOfFieldStrength, default 0 */
+    float sky_azimuth;          /* SetSkyAzimuth, degrees */
+    float sky_altitude;         /* SetSkyAltitude, degrees */
+    float sky_intensity;        /* SetSkyIntensity, default 1 */
+    uint32_t screen_chunk_count;/* SetSplitScreenCount, default 1 */
+    float emissive_pdf_bias;    /* SetEmissiveMeshSamplingPDFBias, default 0 */
+    uint32_t flags;             /* VPT_FLAG_* */
+    uint32_t base_seed;
+} vpt_params;
+
+/* PostProcessor::TonemappingData + BloomData (PostProcessor.h:8-21). */
+typedef struct vpt_post_params {
+    float exposure;        /* 1.0 */
+    float gamma;           /* 2.2 */
+    float bloom_threshold; /* 2.0 */
+    float bloom_strength;  /* 1.0 */
+    uint32_t mip_count;    /* 10 */
+    float falloff_range;   /* 5.0 */
+} vpt_post_params;
+
+typedef struct vpt_config {
+    int device;          /* HIP device ordinal */
+    uint32_t width;      /* output image, RGBA32F (PathTracer.cpp:507-512, 698) */
+    uint32_t height;
+    uint32_t shard_rank; /* this context renders rows y with y % shard_count == shard_rank */
+    uint32_t shard_count;/* 1 = whole image */
+    uint32_t frames_in_flight; /* 0 = choose so that ~4M paths are resident */
+    uint32_t profile;    /* 1 = bracket every kernel launch with hipEvents (vpt_get_stats kernel times) */
+    uint32_t count_traversal; /* 1 = count BVH node/triangle visits (slower; for the roofline's algorithmic bytes) */
+} vpt_config;
+
+#define VPT_KERNEL_COUNT 8
+enum vpt_kernel_id {
+    VPT_K_RAYGEN = 0,
+    VPT_K_EXTEND = 1,
+    VPT_K_SHADE = 2,
+    VPT_K_SHADOW = 3,
+    VPT_K_ACCUMULATE = 4,
+    VPT_K_RESOLVE = 5,
+    VPT_K_BLOOM = 6,
+    VPT_K_TONEMAP = 7
+};
+
+typedef struct vpt_stats {
+    uint64_t samples;          /* camera paths finished (GetSamplesAccumulated * pixels) */
+    uint64_t frames;           /* m_FrameCount */
+    uint64_t dispatches;       /* m_DispatchCount */
+    uint64_t closest_rays;     /* rays traced by the extend kernel */
+    uint64_t shadow_rays;      /* rays traced by the shadow kernel */
+    uint64_t nodes_visited;    /* only when count_traversal */
+    uint64_t tris_tested;      /* only when count_traversal */
+    uint64_t kernel_launches[VPT_KERNEL_COUNT];
+    double kernel_ms[VPT_KERNEL_COUNT]; /* only when profile */
+    uint64_t total_vertex_count; /* GetTotalVertexCount */
+    uint64_t total_index_count;  /* GetTotalIndexCount */
+    uint32_t bvh_nodes;
+    uint32_t bvh_triangles;
+    uint32_t bvh_node_bytes;
+    uint32_t bvh_tri_bytes;
+    uint32_t emissive_mesh_count;
+    uint32_t emissive_triangle_count;
+    uint32_t frames_in_flight;
+    uint32_t shard_pixels;
+} vpt_stats;
+
+typedef struct vpt_ctx vpt_ctx;
+
+/* PathTracer::New (PathTracer.cpp:21-120) + CreateOutputImageView (692-710). NULL on failure;
+ * *err (if non-NULL) receives the VPT_ERR_* code.  Fails with VPT_ERR_NO_DEVICE when no HIP
+ * device is usable: there is no CPU fallback behind this API. */
+vpt_ctx* vpt_create(const vpt_config* cfg, int* err);
+void vpt_destroy(vpt_ctx* ctx);
+const char* vpt_last_error(const vpt_ctx* ctx);
+
+/* PathTracer::SetScene (PathTracer.cpp:158-676): uploads geometry/materials/textures, derives the
+ * emissive-mesh list (449-469) and the env importance/alias tables (1137-1332), builds the BVH
+ * (replaces BLASBuilder/TLAS, 488-505), resets accumulation. Arrays are borrowed for the call only. */
+int vpt_set_scene(vpt_ctx* ctx, const vpt_scene_desc* scene);
+/* PathTracer::SetMaterial (PathTracer.cpp:712-810): patches one material, rebuilds the emissive list
+ * if emission changed, resets accumulation. */
+int vpt_set_material(vpt_ctx* ctx, uint32_t index, const vpt_material* material);
+int vpt_get_material(const vpt_ctx* ctx, uint32_t index, vpt_material* out);
+/* SetCameraViewInverse / SetCameraProjectionInverse. */
+int vpt_set_camera(vpt_ctx* ctx, const float view_inverse[16], const float projection_inverse[16]);
+/* All scalar setters + the #define toggles (PathTracer.cpp:1010-1015, 1623-1716). Resets accumulation. */
+int vpt_set_params(vpt_ctx* ctx, const vpt_params* params);
+void vpt_default_params(vpt_params* params);
+void vpt_default_post_params(vpt_post_params* params);
+/* PathTracer::ResizeImage. */
+int vpt_resize(vpt_ctx* ctx, uint32_t width, uint32_t height);
+/* PathTracer::ResetPathTracing (PathTracer.h:183). */
+int vpt_reset(vpt_ctx* ctx);
+
+/* PathTracer::PathTrace x dispatches (PathTracer.cpp:122-156); blocking. *done (if non-NULL) is
+ * PathTrace's return value: 1 once samples accumulated >= max_samples (then nothing is launched). */
+int vpt_render(vpt_ctx* ctx, uint32_t dispatches, int* done);
+
+/* GetOutputImage(): the RGBA32F accumulation image (alpha 1). Whole image (shard_count==1, or after
+ * vpt_assemble_shards) to a caller-owned host / device buffer of width*height*4 floats. */
+int vpt_get_radiance(vpt_ctx* ctx, float* rgba_host);
+int vpt_get_radiance_device(vpt_ctx* ctx, void* rgba_device);
+/* Checkpoint/resume hook: overwrite the accumulation image and frame counter. */
+int vpt_set_radiance(vpt_ctx* ctx, const float* rgba_host, uint32_t frame_count);
+
+/* Multi-GPU: this context's rows (y % shard_count == shard_rank), packed in increasing y, as
+ * rows*width*4 floats in device memory (the buffer handed to the RCCL gather), and the inverse on
+ * the gathering rank: `gathered` holds shard_count shards back to back, each padded to
+ * vpt_shard_floats(ctx) floats. */
+size_t vpt_shard_floats(const vpt_ctx* ctx);
+int vpt_get_shard_device(vpt_ctx* ctx, void* shard_device);
+int vpt_assemble_shards(vpt_ctx* ctx, const void* gathered_device, uint32_t shard_count);
+
+/* PostProcessor::SetTonemappingData/SetBloomData + PostProcess (PostProcessor.cpp:193-246) on the
+ * accumulation image: threshold -> (mip-1)x down -> (mip-1)x up -> tonemap. rgba8_host receives
+ * GetOutputImageView() (RGBA8 UNORM, width*height*4 bytes); bloom0_host (optional) receives bloom
+ * mip 0 after the up-sample chain (RGBA32F) for testing. */
+int vpt_postprocess(vpt_ctx* ctx, const vpt_post_params* params, uint8_t* rgba8_host, float* bloom0_host);
+
+int vpt_get_stats(vpt_ctx* ctx, vpt_stats* out);
+int vpt_reset_stats(vpt_ctx* ctx);
+
+/* Test hook on the extend kernel alone: closest hit of n rays (origin xyz, tmin, dir xyz, tmax —
+ * 32 B each, host memory) -> n hits {t, u, v, primitive, instance} (20 B each). */
+typedef struct vpt_ray { float origin[3]; float tmin; float direction[3]; float tmax; } vpt_ray;
+typedef struct vpt_hit { float t; float u; float v; uint32_t primitive; uint32_t instance; } vpt_hit;
+int vpt_trace_rays(vpt_ctx* ctx, const vpt_ray* rays_host, uint32_t n, vpt_hit* hits_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VPT_H */

@@ -1,0 +1,159 @@
+"""ctypes mirror of include/vpt.h (struct layouts and prototypes). Plumbing only."""
+import ctypes as C
+
+VPT_OK = 0
+ERR_NAMES = {
+    -1: "VPT_ERR_INVALID_ARGUMENT", -2: "VPT_ERR_NO_DEVICE", -3: "VPT_ERR_OUT_OF_MEMORY", -4: "VPT_ERR_NO_SCENE",
+    -5: "VPT_ERR_DEVICE", -6: "VPT_ERR_UNSUPPORTED", -7: "VPT_ERR_LIMIT",
+}
+
+FLAG_SKY_MIS = 1 << 0
+FLAG_MESH_MIS = 1 << 1
+FLAG_SHOW_ENV_DIRECTLY = 1 << 2
+FLAG_GEOMETRY_NORMALS = 1 << 3
+FLAG_ENERGY_COMPENSATION = 1 << 4
+FLAG_FURNACE = 1 << 5
+FLAG_RAY_QUERIES = 1 << 6
+FLAG_TONEMAP_LINEAR_BLOOM_TAP = 1 << 7
+FLAGS_DEFAULT = (FLAG_SKY_MIS | FLAG_MESH_MIS | FLAG_SHOW_ENV_DIRECTLY | FLAG_ENERGY_COMPENSATION |
+                 FLAG_RAY_QUERIES | FLAG_TONEMAP_LINEAR_BLOOM_TAP)
+
+KERNEL_NAMES = ["raygen", "extend", "shade", "shadow", "accumulate", "resolve", "bloom", "tonemap"]
+KERNEL_COUNT = 8
+
+
+class Material(C.Structure):
+    _fields_ = [
+        ("base_color", C.c_float * 3), ("emissive_color", C.c_float * 3), ("specular_color", C.c_float * 3),
+        ("medium_color", C.c_float * 3), ("medium_emissive_color", C.c_float * 3),
+        ("metallic", C.c_float), ("roughness", C.c_float), ("ior", C.c_float), ("transmission", C.c_float),
+        ("anisotropy", C.c_float), ("anisotropy_rotation", C.c_float), ("medium_density", C.c_float),
+        ("medium_anisotropy", C.c_float),
+        ("base_color_texture", C.c_uint32), ("normal_texture", C.c_uint32), ("roughness_texture", C.c_uint32),
+        ("metallic_texture", C.c_uint32), ("emissive_texture", C.c_uint32),
+    ]
+
+
+assert C.sizeof(Material) == 112
+
+
+class Mesh(C.Structure):
+    _fields_ = [("vertices", C.c_void_p), ("vertex_count", C.c_uint32), ("indices", C.c_void_p),
+                ("index_count", C.c_uint32)]
+
+
+class Instance(C.Structure):
+    _fields_ = [("mesh_index", C.c_uint32), ("material_index", C.c_uint32), ("transform", C.c_float * 16)]
+
+
+class Texture(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("channels", C.c_uint32), ("data", C.c_void_p)]
+
+
+class SceneDesc(C.Structure):
+    _fields_ = [
+        ("meshes", C.POINTER(Mesh)), ("mesh_count", C.c_uint32),
+        ("materials", C.POINTER(Material)), ("material_count", C.c_uint32),
+        ("instances", C.POINTER(Instance)), ("instance_count", C.c_uint32),
+        ("textures", C.POINTER(Texture)), ("texture_count", C.c_uint32),
+        ("env_rgba", C.c_void_p), ("env_width", C.c_uint32), ("env_height", C.c_uint32),
+        ("lut_reflection", C.c_void_p), ("lut_refraction_outside", C.c_void_p), ("lut_refraction_inside", C.c_void_p),
+    ]
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("samples_per_frame", C.c_uint32), ("max_samples", C.c_uint32), ("max_depth", C.c_uint32),
+        ("max_luminance", C.c_float), ("focus_distance", C.c_float), ("dof_strength", C.c_float),
+        ("sky_azimuth", C.c_float), ("sky_altitude", C.c_float), ("sky_intensity", C.c_float),
+        ("screen_chunk_count", C.c_uint32), ("emissive_pdf_bias", C.c_float), ("flags", C.c_uint32),
+        ("base_seed", C.c_uint32),
+    ]
+
+
+def default_params(**kw):
+    """PathTracer.h:197-233 defaults."""
+    p = Params(1, 5000, 200, 500.0, 1.0, 0.0, 0.0, 0.0, 1.0, 1, 0.0, FLAGS_DEFAULT, 1)
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise AttributeError(k)
+        setattr(p, k, v)
+    return p
+
+
+class PostParams(C.Structure):
+    _fields_ = [("exposure", C.c_float), ("gamma", C.c_float), ("bloom_threshold", C.c_float),
+                ("bloom_strength", C.c_float), ("mip_count", C.c_uint32), ("falloff_range", C.c_float)]
+
+
+def default_post_params(**kw):
+    """PostProcessor.h:8-21 defaults."""
+    p = PostParams(1.0, 2.2, 2.0, 1.0, 10, 5.0)
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise AttributeError(k)
+        setattr(p, k, v)
+    return p
+
+
+class Config(C.Structure):
+    _fields_ = [("device", C.c_int), ("width", C.c_uint32), ("height", C.c_uint32), ("shard_rank", C.c_uint32),
+                ("shard_count", C.c_uint32), ("frames_in_flight", C.c_uint32), ("profile", C.c_uint32),
+                ("count_traversal", C.c_uint32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("samples", C.c_uint64), ("frames", C.c_uint64), ("dispatches", C.c_uint64), ("closest_rays", C.c_uint64),
+        ("shadow_rays", C.c_uint64), ("nodes_visited", C.c_uint64), ("tris_tested", C.c_uint64),
+        ("kernel_launches", C.c_uint64 * KERNEL_COUNT), ("kernel_ms", C.c_double * KERNEL_COUNT),
+        ("total_vertex_count", C.c_uint64), ("total_index_count", C.c_uint64),
+        ("bvh_nodes", C.c_uint32), ("bvh_triangles", C.c_uint32), ("bvh_node_bytes", C.c_uint32),
+        ("bvh_tri_bytes", C.c_uint32), ("emissive_mesh_count", C.c_uint32), ("emissive_triangle_count", C.c_uint32),
+        ("frames_in_flight", C.c_uint32), ("shard_pixels", C.c_uint32),
+    ]
+
+
+class Ray(C.Structure):
+    _fields_ = [("origin", C.c_float * 3), ("tmin", C.c_float), ("direction", C.c_float * 3), ("tmax", C.c_float)]
+
+
+class Hit(C.Structure):
+    _fields_ = [("t", C.c_float), ("u", C.c_float), ("v", C.c_float), ("primitive", C.c_uint32),
+                ("instance", C.c_uint32)]
+
+
+# every symbol include/vpt.h declares, with (restype, argtypes)
+PROTOTYPES = {
+    "vpt_create": (C.c_void_p, [C.POINTER(Config), C.POINTER(C.c_int)]),
+    "vpt_destroy": (None, [C.c_void_p]),
+    "vpt_last_error": (C.c_char_p, [C.c_void_p]),
+    "vpt_set_scene": (C.c_int, [C.c_void_p, C.POINTER(SceneDesc)]),
+    "vpt_set_material": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(Material)]),
+    "vpt_get_material": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(Material)]),
+    "vpt_set_camera": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "vpt_set_params": (C.c_int, [C.c_void_p, C.POINTER(Params)]),
+    "vpt_default_params": (None, [C.POINTER(Params)]),
+    "vpt_default_post_params": (None, [C.POINTER(PostParams)]),
+    "vpt_resize": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),
+    "vpt_reset": (C.c_int, [C.c_void_p]),
+    "vpt_render": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_int)]),
+    "vpt_get_radiance": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "vpt_get_radiance_device": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "vpt_set_radiance": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32]),
+    "vpt_shard_floats": (C.c_size_t, [C.c_void_p]),
+    "vpt_get_shard_device": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "vpt_assemble_shards": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32]),
+    "vpt_postprocess": (C.c_int, [C.c_void_p, C.POINTER(PostParams), C.c_void_p, C.c_void_p]),
+    "vpt_get_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
+    "vpt_reset_stats": (C.c_int, [C.c_void_p]),
+    "vpt_trace_rays": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
+}
+
+
+def bind(lib):
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    return lib
