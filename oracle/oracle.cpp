@@ -1053,7 +1053,7 @@ void orc_postprocess(const float* rgba, uint32_t w, uint32_t h, const vpt_post_p
                 for (int a = -2; a < 2; a++)
                     for (int b = -2; b < 2; b++)
                         c = c + ld3(src, iclamp(x * 2 + a, 0, src.w - 1), iclamp(y * 2 + b, 0, src.h - 1));
-                c = c / pow_(5.0f, 2.0f);
+                c = c / 25.0f;  // pow(range*2+1, 2) with range = 2 folds to 25
                 c = c * pp->bloom_strength;
                 st4(dst, x, y, c);
             }
@@ -1067,7 +1067,7 @@ void orc_postprocess(const float* rgba, uint32_t w, uint32_t h, const vpt_post_p
                 for (int a = -2; a < 2; a++)
                     for (int b = -2; b < 2; b++)
                         c = c + ld3(src, iclamp(x / 2 + a + 1, 0, src.w - 1), iclamp(y / 2 + b + 1, 0, src.h - 1));
-                c = c / pow_(5.0f, 2.0f);
+                c = c / 25.0f;  // pow(range*2+1, 2) with range = 2 folds to 25
                 c = c * pp->bloom_strength;
                 st4(dst, x, y, c + ld3(dst, x, y));
             }

@@ -1,0 +1,159 @@
+"""MI355X wavefront render backend for the Vulkan-Path-Tracer hot path.
+
+This package is a thin ctypes shim over the C-ABI in include/vpt.h (libvpt_hip.so, hand-written HIP for
+gfx950).  All compute happens in the library; there is no Python or CPU fallback: if the library or a
+HIP device is missing, loading / vpt_create fail loudly.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _abi, scenes  # noqa: F401
+from ._abi import default_params, default_post_params  # noqa: F401
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class VptError(RuntimeError):
+    pass
+
+
+def library_path():
+    return os.path.join(_HERE, "libvpt_hip.so")
+
+
+def build(force=False, verbose=False):
+    from . import build as _b
+    return _b.build(force=force, verbose=verbose)
+
+
+def load_library():
+    """Loads libvpt_hip.so (building it first when hipcc is available and sources are newer)."""
+    global _LIB
+    if _LIB is None:
+        path = library_path()
+        try:
+            path = build()
+        except Exception as e:  # no hipcc on this box: the prebuilt in-tree .so must exist
+            if not os.path.exists(path):
+                raise VptError("libvpt_hip.so is missing and cannot be built: %s" % e)
+        _LIB = _abi.bind(C.CDLL(path))
+    return _LIB
+
+
+def _check(lib, ctx, rc, what):
+    if rc != 0:
+        msg = lib.vpt_last_error(ctx).decode() if ctx else ""
+        raise VptError("%s failed: %s %s" % (what, _abi.ERR_NAMES.get(rc, rc), msg))
+
+
+class PathTracer:
+    """Mirror of the reference's PathTracer + PostProcessor call surface over the C-ABI."""
+
+    def __init__(self, width, height, device=0, shard_rank=0, shard_count=1, frames_in_flight=0, profile=False,
+                 count_traversal=False):
+        self.lib = load_library()
+        cfg = _abi.Config(device, width, height, shard_rank, shard_count, frames_in_flight, int(profile), int(count_traversal))
+        err = C.c_int(0)
+        self.ctx = self.lib.vpt_create(C.byref(cfg), C.byref(err))
+        if not self.ctx:
+            raise VptError("vpt_create failed: %s (no CPU fallback exists)" % _abi.ERR_NAMES.get(err.value, err.value))
+        self.width, self.height = width, height
+        self.shard_rank, self.shard_count = shard_rank, shard_count
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.vpt_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- PathTracer API
+    def set_scene(self, scene, set_camera=True):
+        desc, keep = scene.to_desc()
+        _check(self.lib, self.ctx, self.lib.vpt_set_scene(self.ctx, C.byref(desc)), "vpt_set_scene")
+        del keep
+        if set_camera:
+            self.set_camera(scene.view_inverse, scene.projection_inverse(self.width / self.height))
+
+    def set_camera(self, view_inverse, projection_inverse):
+        _check(self.lib, self.ctx, self.lib.vpt_set_camera(self.ctx, scenes.colmajor(view_inverse), scenes.colmajor(projection_inverse)), "vpt_set_camera")
+
+    def set_params(self, params):
+        _check(self.lib, self.ctx, self.lib.vpt_set_params(self.ctx, C.byref(params)), "vpt_set_params")
+
+    def set_material(self, index, mat):
+        _check(self.lib, self.ctx, self.lib.vpt_set_material(self.ctx, index, C.byref(mat)), "vpt_set_material")
+
+    def get_material(self, index):
+        m = _abi.Material()
+        _check(self.lib, self.ctx, self.lib.vpt_get_material(self.ctx, index, C.byref(m)), "vpt_get_material")
+        return m
+
+    def resize(self, w, h):
+        _check(self.lib, self.ctx, self.lib.vpt_resize(self.ctx, w, h), "vpt_resize")
+        self.width, self.height = w, h
+
+    def reset(self):
+        _check(self.lib, self.ctx, self.lib.vpt_reset(self.ctx), "vpt_reset")
+
+    def render(self, dispatches):
+        done = C.c_int(0)
+        _check(self.lib, self.ctx, self.lib.vpt_render(self.ctx, dispatches, C.byref(done)), "vpt_render")
+        return bool(done.value)
+
+    def radiance(self):
+        out = np.empty((self.height, self.width, 4), np.float32)
+        _check(self.lib, self.ctx, self.lib.vpt_get_radiance(self.ctx, out.ctypes.data), "vpt_get_radiance")
+        return out
+
+    def radiance_to_device(self, ptr):
+        _check(self.lib, self.ctx, self.lib.vpt_get_radiance_device(self.ctx, ptr), "vpt_get_radiance_device")
+
+    def set_radiance(self, img, frame_count):
+        img = np.ascontiguousarray(img, np.float32)
+        assert img.shape == (self.height, self.width, 4)
+        _check(self.lib, self.ctx, self.lib.vpt_set_radiance(self.ctx, img.ctypes.data, frame_count), "vpt_set_radiance")
+
+    def shard_floats(self):
+        return int(self.lib.vpt_shard_floats(self.ctx))
+
+    def shard_to_device(self, ptr):
+        _check(self.lib, self.ctx, self.lib.vpt_get_shard_device(self.ctx, ptr), "vpt_get_shard_device")
+
+    def assemble_shards(self, gathered_ptr, shard_count):
+        _check(self.lib, self.ctx, self.lib.vpt_assemble_shards(self.ctx, gathered_ptr, shard_count), "vpt_assemble_shards")
+
+    # ---- PostProcessor API
+    def postprocess(self, post_params=None, want_bloom=False):
+        pp = post_params or default_post_params()
+        out = np.empty((self.height, self.width, 4), np.uint8)
+        bloom = np.empty((self.height, self.width, 4), np.float32) if want_bloom else None
+        _check(self.lib, self.ctx, self.lib.vpt_postprocess(self.ctx, C.byref(pp), out.ctypes.data, bloom.ctypes.data if want_bloom else None), "vpt_postprocess")
+        return (out, bloom) if want_bloom else out
+
+    def stats(self):
+        s = _abi.Stats()
+        _check(self.lib, self.ctx, self.lib.vpt_get_stats(self.ctx, C.byref(s)), "vpt_get_stats")
+        d = {k: getattr(s, k) for k, _ in _abi.Stats._fields_ if k not in ("kernel_launches", "kernel_ms")}
+        d["kernel_launches"] = {n: int(s.kernel_launches[i]) for i, n in enumerate(_abi.KERNEL_NAMES)}
+        d["kernel_ms"] = {n: float(s.kernel_ms[i]) for i, n in enumerate(_abi.KERNEL_NAMES)}
+        return d
+
+    def reset_stats(self):
+        _check(self.lib, self.ctx, self.lib.vpt_reset_stats(self.ctx), "vpt_reset_stats")
+
+    def trace_rays(self, rays):
+        rays = np.ascontiguousarray(rays, np.float32)
+        hits = np.zeros(len(rays), HIT_DTYPE)
+        _check(self.lib, self.ctx, self.lib.vpt_trace_rays(self.ctx, rays.ctypes.data, len(rays), hits.ctypes.data), "vpt_trace_rays")
+        return hits
+
+
+HIT_DTYPE = np.dtype([("t", "<f4"), ("u", "<f4"), ("v", "<f4"), ("primitive", "<u4"), ("instance", "<u4")])

@@ -1,0 +1,174 @@
+// bvh_build.cpp — deterministic binned-SAH BVH2 over the flattened world-space triangles.
+// Replaces BLASBuilder::Build + TLAS::New (reference PathTracer.cpp:488-505; the reference's BVH lives
+// in the Vulkan driver).  Every reference instance gets its own BLAS (PathTracer.cpp:471-479) and is
+// placed once, so instances are flattened into one world-space tree.
+//
+// Output layout (device_types.hpp): 64 B nodes that hold BOTH child boxes, 48 B triangles in leaf
+// order, leaves of <= 4 triangles, depth bounded by kMaxDepth (the traversal stack size).
+#include "bvh_build.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace vpt {
+
+namespace {
+constexpr int kLeafSize = 4;
+constexpr int kBins = 16;
+constexpr int kMaxDepth = 30;  // < kStackDepth (32)
+
+struct Box {
+    float lo[3], hi[3];
+    void reset() { for (int a = 0; a < 3; a++) { lo[a] = 3.0e38f; hi[a] = -3.0e38f; } }
+    void grow(const Box& b) { for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], b.lo[a]); hi[a] = std::max(hi[a], b.hi[a]); } }
+    void grow(const float* p) { for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], p[a]); hi[a] = std::max(hi[a], p[a]); } }
+    float half_area() const {
+        float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        if (dx < 0 || dy < 0 || dz < 0) return 0.0f;
+        return dx * dy + dy * dz + dz * dx;
+    }
+};
+struct Ref { Box b; float c[3]; uint32_t tri; };
+struct TmpNode { Box b; int left, right; int first, count; };
+
+struct Builder {
+    std::vector<Ref> refs;
+    std::vector<TmpNode> nodes;
+
+    int build(int first, int count, int depth) {
+        TmpNode n; n.b.reset(); n.left = n.right = -1; n.first = first; n.count = count;
+        Box cb; cb.reset();
+        for (int i = first; i < first + count; i++) { n.b.grow(refs[i].b); cb.grow(refs[i].c); }
+        int id = (int)nodes.size();
+        nodes.push_back(n);
+        if (count <= kLeafSize) return id;
+        int need = 0; { int c = (count + kLeafSize - 1) / kLeafSize; while ((1 << need) < c) need++; }
+        bool force_median = depth + need + 1 >= kMaxDepth;
+        int best_axis = -1, best_bin = -1; float best_cost = 3.0e38f;
+        if (!force_median) {
+            for (int a = 0; a < 3; a++) {
+                float ext = cb.hi[a] - cb.lo[a];
+                if (!(ext > 0.0f)) continue;
+                Box bb[kBins]; int bc[kBins];
+                for (int k = 0; k < kBins; k++) { bb[k].reset(); bc[k] = 0; }
+                float scale = (float)kBins / ext;
+                for (int i = first; i < first + count; i++) {
+                    int k = (int)((refs[i].c[a] - cb.lo[a]) * scale);
+                    k = k < 0 ? 0 : (k >= kBins ? kBins - 1 : k);
+                    bb[k].grow(refs[i].b); bc[k]++;
+                }
+                float la[kBins]; int lc[kBins];
+                Box acc; acc.reset(); int cnt = 0;
+                for (int k = 0; k < kBins - 1; k++) { acc.grow(bb[k]); cnt += bc[k]; la[k] = acc.half_area(); lc[k] = cnt; }
+                acc.reset(); cnt = 0;
+                for (int k = kBins - 1; k > 0; k--) {
+                    acc.grow(bb[k]); cnt += bc[k];
+                    if (lc[k - 1] == 0 || cnt == 0) continue;
+                    float cost = la[k - 1] * (float)lc[k - 1] + acc.half_area() * (float)cnt;
+                    if (cost < best_cost) { best_cost = cost; best_axis = a; best_bin = k; }
+                }
+            }
+        }
+        int mid;
+        if (best_axis >= 0) {
+            int a = best_axis;
+            float ext = cb.hi[a] - cb.lo[a], scale = (float)kBins / ext, lo = cb.lo[a];
+            int bin = best_bin;
+            auto it = std::stable_partition(refs.begin() + first, refs.begin() + first + count, [&](const Ref& r) {
+                int k = (int)((r.c[a] - lo) * scale);
+                k = k < 0 ? 0 : (k >= kBins ? kBins - 1 : k);
+                return k < bin;
+            });
+            mid = (int)(it - refs.begin());
+        } else {
+            // object-median split on the widest centroid axis (also the depth-bounding fallback)
+            int a = 0; float e = -1.0f;
+            for (int k = 0; k < 3; k++) { float x = cb.hi[k] - cb.lo[k]; if (x > e) { e = x; a = k; } }
+            mid = first + count / 2;
+            std::nth_element(refs.begin() + first, refs.begin() + mid, refs.begin() + first + count,
+                             [a](const Ref& x, const Ref& y) { return x.c[a] < y.c[a] || (x.c[a] == y.c[a] && x.tri < y.tri); });
+        }
+        if (mid == first || mid == first + count) mid = first + count / 2;
+        int l = build(first, mid - first, depth + 1);
+        int r = build(mid, first + count - mid, depth + 1);
+        nodes[id].left = l; nodes[id].right = r; nodes[id].count = 0;
+        return id;
+    }
+};
+
+inline int32_t leaf_code(int first, int count) { return ~(int32_t)(((uint32_t)first << 3) | (uint32_t)(count - 1)); }
+}  // namespace
+
+void build_bvh(const std::vector<BvhTri>& tris_in, std::vector<BvhNode>& nodes_out, std::vector<BvhTri>& tris_out, int* depth_out) {
+    nodes_out.clear(); tris_out.clear();
+    Builder b;
+    b.refs.resize(tris_in.size());
+    float maxabs = 0.0f;
+    for (size_t i = 0; i < tris_in.size(); i++) {
+        const BvhTri& t = tris_in[i];
+        float p[3][3];
+        for (int a = 0; a < 3; a++) { p[0][a] = t.v0[a]; p[1][a] = t.v0[a] + t.e1[a]; p[2][a] = t.v0[a] + t.e2[a]; }
+        Ref& r = b.refs[i];
+        r.b.reset(); r.b.grow(p[0]); r.b.grow(p[1]); r.b.grow(p[2]);
+        for (int a = 0; a < 3; a++) { r.c[a] = 0.5f * (r.b.lo[a] + r.b.hi[a]); maxabs = std::max(maxabs, std::max(std::fabs(r.b.lo[a]), std::fabs(r.b.hi[a]))); }
+        r.tri = (uint32_t)i;
+    }
+    // Conservative padding so a box test can never cull a triangle the shared ray_triangle() accepts.
+    const float pad = 2.0e-5f * maxabs + 1.0e-6f;
+    if (tris_in.empty()) {
+        BvhNode n; std::memset(&n, 0, sizeof(n));
+        for (int a = 0; a < 3; a++) { n.lmin[a] = n.rmin[a] = 1.0e30f; n.lmax[a] = n.rmax[a] = 1.0e30f; }  // unreachable point boxes
+        n.left = n.right = leaf_code(0, 1);
+        nodes_out.push_back(n);
+        if (depth_out) *depth_out = 0;
+        return;
+    }
+    b.build(0, (int)b.refs.size(), 0);
+    tris_out.resize(tris_in.size());
+    for (size_t i = 0; i < b.refs.size(); i++) tris_out[i] = tris_in[b.refs[i].tri];
+
+    // emit: inner tmp nodes -> 64 B nodes in depth-first order; a leaf root gets a wrapper node.
+    std::vector<int> inner_index(b.nodes.size(), -1);
+    int max_depth = 0;
+    auto child_code = [&](int tn) -> int32_t {
+        const TmpNode& c = b.nodes[tn];
+        return c.left < 0 ? leaf_code(c.first, c.count) : inner_index[tn];
+    };
+    // assign indices depth-first
+    {
+        std::vector<std::pair<int, int>> st; st.push_back({0, 0});
+        int next = 0;
+        while (!st.empty()) {
+            auto [tn, d] = st.back(); st.pop_back();
+            max_depth = std::max(max_depth, d);
+            if (b.nodes[tn].left < 0) continue;
+            inner_index[tn] = next++;
+            st.push_back({b.nodes[tn].right, d + 1});
+            st.push_back({b.nodes[tn].left, d + 1});
+        }
+        nodes_out.resize(next > 0 ? next : 1);
+    }
+    auto put_box = [&](const Box& bx, float* mn, float* mx) { for (int a = 0; a < 3; a++) { mn[a] = bx.lo[a] - pad; mx[a] = bx.hi[a] + pad; } };
+    if (b.nodes[0].left < 0) {
+        BvhNode n; std::memset(&n, 0, sizeof(n));
+        put_box(b.nodes[0].b, n.lmin, n.lmax);
+        for (int a = 0; a < 3; a++) { n.rmin[a] = 1.0e30f; n.rmax[a] = 1.0e30f; }  // unreachable point box
+        n.left = leaf_code(b.nodes[0].first, b.nodes[0].count);
+        n.right = n.left;  // never entered: its box is empty
+        nodes_out[0] = n;
+    } else {
+        for (size_t tn = 0; tn < b.nodes.size(); tn++) {
+            if (inner_index[tn] < 0) continue;
+            const TmpNode& t = b.nodes[tn];
+            BvhNode n; std::memset(&n, 0, sizeof(n));
+            put_box(b.nodes[t.left].b, n.lmin, n.lmax);
+            put_box(b.nodes[t.right].b, n.rmin, n.rmax);
+            n.left = child_code(t.left); n.right = child_code(t.right);
+            nodes_out[inner_index[tn]] = n;
+        }
+    }
+    if (depth_out) *depth_out = max_depth;
+}
+
+}  // namespace vpt

@@ -1,0 +1,393 @@
+// shading.hpp — device-side surface / material / sampling routines of the shade stage.
+// Reference semantics: Shaders/Surface.slang, Material.slang, Sampler.slang, RTCommon.slang
+// (file:line cited per function).  All arithmetic goes through include/vpt_fp32.h and is compiled
+// with -ffp-contract=off, so expression order here is part of the parity contract.
+#pragma once
+#include "device_types.hpp"
+
+namespace vpt {
+using namespace vptfp;
+
+// Defines.slang:1-7 (as fp32)
+#define VPT_PI 3.1415926535897F
+#define VPT_2PI 6.2831853071795F
+#define VPT_1_OVER_PI 0.3183098861837F
+constexpr uint32_t kMaxDepthMarker = 1000000u;  // Defines.slang:16 MAX_DEPTH
+
+struct Rng {  // Sampler.slang:21-43
+    uint32_t s;
+    __device__ inline float uf() { s = pcg_hash(s); return u32_to_unit(s); }
+};
+
+__device__ inline V3 ld3(const float* p) { return v3(p[0], p[1], p[2]); }
+__device__ inline V4 v4(float x, float y, float z, float w) { V4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
+__device__ inline V4 lerp4(V4 a, V4 b, float t) { return v4(lerp(a.x, b.x, t), lerp(a.y, b.y, t), lerp(a.z, b.z, t), lerp(a.w, b.w, t)); }
+
+// ------------------------------------------------------------------ software samplers (LINEAR, mip 0)
+__device__ inline V4 tex_fetch(const uint8_t* texels, const TexDesc& t, int x, int y) {
+    if (t.c == 4) {
+        uchar4 p = *reinterpret_cast<const uchar4*>(texels + t.offset + ((size_t)y * t.w + x) * 4);
+        return v4((float)p.x / 255.0f, (float)p.y / 255.0f, (float)p.z / 255.0f, (float)p.w / 255.0f);
+    }
+    float v = (float)texels[t.offset + (size_t)y * t.w + x] / 255.0f;
+    return v4(v, 0.0f, 0.0f, 1.0f);
+}
+// uTextureSampler: LINEAR / REPEAT (PathTracer.cpp:84-91)
+__device__ inline V4 tex_sample(const DeviceScene& sc, uint32_t ti, float u, float v) {
+    TexDesc t = sc.textures[ti];
+    if (t.w == 1 && t.h == 1) return tex_fetch(sc.texels, t, 0, 0);  // == the filtered result, bit for bit
+    int x0, x1, y0, y1; float fx, fy;
+    texel_coords(u, (int)t.w, true, &x0, &x1, &fx);
+    texel_coords(v, (int)t.h, true, &y0, &y1, &fy);
+    V4 a = lerp4(tex_fetch(sc.texels, t, x0, y0), tex_fetch(sc.texels, t, x1, y0), fx);
+    V4 b = lerp4(tex_fetch(sc.texels, t, x0, y1), tex_fetch(sc.texels, t, x1, y1), fx);
+    return lerp4(a, b, fy);
+}
+__device__ inline V4 env_sample(const DeviceScene& sc, float u, float v) {
+    int w = (int)sc.env_w, h = (int)sc.env_h;
+    const float4* e = reinterpret_cast<const float4*>(sc.env);
+    int x0, x1, y0, y1; float fx, fy;
+    texel_coords(u, w, true, &x0, &x1, &fx);
+    texel_coords(v, h, true, &y0, &y1, &fy);
+    float4 p00 = e[(size_t)y0 * w + x0], p10 = e[(size_t)y0 * w + x1], p01 = e[(size_t)y1 * w + x0], p11 = e[(size_t)y1 * w + x1];
+    V4 a = lerp4(v4(p00.x, p00.y, p00.z, p00.w), v4(p10.x, p10.y, p10.z, p10.w), fx);
+    V4 b = lerp4(v4(p01.x, p01.y, p01.z, p01.w), v4(p11.x, p11.y, p11.z, p11.w), fx);
+    return lerp4(a, b, fy);
+}
+// uLookupTableSampler: LINEAR / CLAMP_TO_EDGE on an R32F 2D array (PathTracer.cpp:93-94)
+__device__ inline float lut_sample(const float* lut, int sx, int sy, int sz, float u, float v, float layer) {
+    int x0, x1, y0, y1; float fx, fy;
+    texel_coords(u, sx, false, &x0, &x1, &fx);
+    texel_coords(v, sy, false, &y0, &y1, &fy);
+    const float* p = lut + (size_t)lut_layer(layer, sz) * sx * sy;
+    float a = lerp(p[y0 * sx + x0], p[y0 * sx + x1], fx);
+    float b = lerp(p[y1 * sx + x0], p[y1 * sx + x1], fx);
+    return lerp(a, b, fy);
+}
+
+// ------------------------------------------------------------------ RTCommon.slang
+__device__ inline float power_heuristics(float a, float b) {  // :124-127
+    float a2 = pow_(a, 2.0f);
+    return a2 / (a2 + pow_(b, 2.0f));
+}
+__device__ inline V2 direction_to_uv(V3 v) {  // :129-136
+    float gamma = asin_(clamp_(v.y, -1.0f, 1.0f));
+    float theta = atan2_(v.x, -v.z);
+    V2 uv; uv.x = theta * VPT_1_OVER_PI * 0.5f + 0.5f; uv.y = gamma * VPT_1_OVER_PI + 0.5f;
+    return uv;
+}
+
+// ------------------------------------------------------------------ Surface.slang:26-147
+struct SurfaceFrame {
+    V3 pos, N, T, B, Ng;
+    V2 uv;
+    V3 p1, p2, p3;  // object-space positions of the hit triangle (light-MIS area, ClosestHit.slang:276-287)
+    bool inside;
+    __device__ inline V3 tangent_to_world(V3 v) const { return normalize((v.x * T + v.y * B) + v.z * N); }
+    __device__ inline V3 world_to_tangent(V3 v) const { return normalize(v3(dot(v, T), dot(v, B), dot(v, N))); }
+};
+
+__device__ inline void surface_init(const DeviceScene& sc, SurfaceFrame& s, const InstanceDesc& in, uint32_t prim, float hu,
+                                    float hv, V3 raydir, uint32_t normal_tex, bool geo_only) {
+    const MeshDesc me = sc.meshes[in.mesh];
+    const uint32_t* idx = sc.indices + me.index_offset + prim * 3;
+    const vpt_vertex* vb = sc.vertices + me.vertex_offset;
+    const float4* q1 = reinterpret_cast<const float4*>(vb + idx[0]);
+    const float4* q2 = reinterpret_cast<const float4*>(vb + idx[1]);
+    const float4* q3 = reinterpret_cast<const float4*>(vb + idx[2]);
+    float4 a0 = q1[0], a1 = q1[1], b0 = q2[0], b1 = q2[1], c0 = q3[0], c1 = q3[1];
+    s.p1 = v3(a0.x, a0.y, a0.z); s.p2 = v3(b0.x, b0.y, b0.z); s.p3 = v3(c0.x, c0.y, c0.z);
+    V3 n1 = v3(a0.w, a1.x, a1.y), n2 = v3(b0.w, b1.x, b1.y), n3 = v3(c0.w, c1.x, c1.y);
+    float bx = 1.0f - hu - hv, by = hu, bz = hv;  // ClosestHit.slang:45
+    s.pos = mat_point(in.xform, (s.p1 * bx + s.p2 * by) + s.p3 * bz);
+    s.uv.x = (a1.z * bx + b1.z * by) + c1.z * bz;
+    s.uv.y = (a1.w * bx + b1.w * by) + c1.w * bz;
+    s.Ng = normalize(cross(s.p2 - s.p1, s.p3 - s.p1));
+    s.Ng = normalize(rowvec_mat3(s.Ng, in.inv3));
+    if (geo_only) {
+        s.N = s.Ng;
+    } else {
+        s.N = normalize((n1 * bx + n2 * by) + n3 * bz);
+        s.N = normalize(rowvec_mat3(s.N, in.inv3));
+    }
+    V3 view = -raydir;
+    if (dot(s.Ng, view) < 0.0f) { s.N = -s.N; s.Ng = -s.Ng; s.inside = true; } else { s.inside = false; }
+    V3 up = fabs_(s.N.z) < 0.9999999f ? v3(0.0f, 0.0f, 1.0f) : v3(1.0f, 0.0f, 0.0f);
+    s.T = normalize(cross(up, s.N));
+    s.B = normalize(cross(s.N, s.T));
+    if (!geo_only) {
+        V4 nm = tex_sample(sc, normal_tex, s.uv.x, s.uv.y);
+        s.N = s.tangent_to_world(v3(nm.x * 2.0f - 1.0f, nm.y * 2.0f - 1.0f, nm.z * 2.0f - 1.0f));
+    }
+    float nv = dot(s.N, view);
+    if (nv < 0.0f) s.N = normalize(s.N - view * (nv - 0.01f));
+    V3 pr = normalize(reflect(-view, s.N));
+    if (dot(pr, s.Ng) < 0.0f) s.N = normalize(s.N + s.Ng * (0.1f + dot(s.N, s.Ng)));
+    s.T = normalize(cross(s.N, up));
+    s.B = normalize(cross(s.N, s.T));
+}
+__device__ inline void rotate_tangents(SurfaceFrame& s, float deg) {  // Surface.slang:129-136
+    float sn, cs;
+    sincos_(deg * (VPT_PI / 180.0f), &sn, &cs);
+    s.T = (s.T * cs + cross(s.N, s.T) * sn) + (s.N * dot(s.N, s.T)) * (1.0f - cs);
+    s.B = cross(s.T, s.N);
+}
+
+// ------------------------------------------------------------------ Material.slang
+struct Eval { V3 f; float pdf; };
+
+struct Bsdf {
+    V3 base, spec, emissive;
+    float metallic, roughness, ior, transmission, anisotropy;
+    float eta, ax, ay;
+    float pm, pd, pg;  // normalised lobe probabilities (Material.slang:97-106 == 170-179)
+    const float *lut_r, *lut_o, *lut_i;
+    bool ec;
+
+    __device__ inline float fresnel(float c) const {  // :434-449
+        float st2 = eta * eta * (1.0f - c * c);
+        if (st2 > 1.0f) return 1.0f;
+        float ct = sqrt_(max_(1.0f - st2, 0.0f));
+        float rs = (eta * ct - c) / (eta * ct + c);
+        float rp = (eta * c - ct) / (eta * c + ct);
+        return 0.5f * (rs * rs + rp * rp);
+    }
+    __device__ inline float ggx_d(V3 h) const {  // :394-404
+        float ax2 = ax * ax, ay2 = ay * ay;
+        return 1.0f / (VPT_PI * ax * ay * pow_((h.x * h.x) / ax2 + (h.y * h.y) / ay2 + h.z * h.z, 2.0f));
+    }
+    __device__ inline float smith(V3 v) const {  // :406-423
+        float vz2 = fabs_(v.z) * fabs_(v.z);
+        float lam = (-1.0f + sqrt_(1.0f + ((ax * ax) * (v.x * v.x) + (ay * ay) * (v.y * v.y)) / vz2)) / 2.0f;
+        return 1.0f / (1.0f + lam);
+    }
+    // :331-351. D, GV are shared by every reflection lobe of one direction pair.
+    __device__ inline Eval reflection(V3 V, V3 L, V3 F) const {
+        Eval e; e.f = v3s(0.0f); e.pdf = 0.0f;
+        if (L.z <= 1e-5f) return e;
+        V3 H = normalize(V + L);
+        float VdotH = dot(V, H);
+        float D = ggx_d(H);
+        float GV = smith(V), GL = smith(L);
+        e.pdf = (GV * max_(VdotH, 0.0f) * D / V.z) / (4.0f * VdotH);
+        e.f = ((F * D) * GV) * GL / (4.0f * V.z);
+        return e;
+    }
+    __device__ inline Eval refraction(V3 V, V3 L, V3 F) const {  // :359-387
+        Eval e; e.f = v3s(0.0f); e.pdf = 0.0f;
+        if (L.z >= 1e-5f) return e;
+        V3 H = normalize(V * eta + L);
+        if (H.z < 0.0f) H = -H;
+        float VdotH = dot(V, H), LdotH = dot(L, H);
+        float D = ggx_d(H);
+        float GV = smith(V), GL = smith(L);
+        float G = GV * GL;
+        float den = LdotH + eta * VdotH;
+        float den2 = den * den, eta2 = eta * eta;
+        float jac = (eta2 * fabs_(LdotH)) / den2;
+        e.pdf = (GV * fabs_(VdotH) * D / V.z) * jac;
+        e.f = (((F * D) * G) * eta2 / den2) * (fabs_(VdotH) * fabs_(LdotH) / fabs_(V.z));
+        return e;
+    }
+    // EvaluateBSDF, :167-254.  ec_r / ec_g: the two LUT taps depend on V only, so the caller
+    // fetches them once per hit and passes them to all (up to three) evaluations.
+    __device__ inline Eval eval(V3 V, V3 L, float ec_r, float ec_g) const {
+        bool refracted = L.z < 0.0f;
+        V3 H; bool valid_refr = false;
+        if (refracted) {
+            H = normalize(V * eta + L);
+            if (H.z < 0.0f) H = -H;
+            float VdotH = dot(V, H), LdotH = dot(L, H);
+            valid_refr = (VdotH > 0.0f && LdotH < 0.0f) || (VdotH < 0.0f && LdotH > 0.0f);
+        } else {
+            H = normalize(V + L);
+        }
+        float F = fresnel(fabs_(dot(V, H)));
+        Eval r; r.f = v3s(0.0f); r.pdf = 0.0f;
+        if (!refracted) {
+            // metallic (:266-283)
+            {
+                float m = clamp_(1.0f - dot(V, H), 0.0f, 1.0f);
+                float m2 = m * m;
+                V3 Fm = lerp(base, spec, m2 * m2 * m);
+                Eval e = reflection(V, L, Fm);
+                if (ec) { float c = (1.0f - ec_r) / ec_r; e.f = (v3s(1.0f) + base * c) * e.f; }
+                r.f = r.f + e.f * pm; r.pdf += e.pdf * pm;
+            }
+            // diffuse (:256-264)
+            {
+                float dpdf = (L.z * VPT_1_OVER_PI) * (L.z > 0.0f ? 1.0f : 0.0f);
+                V3 df = (base * VPT_1_OVER_PI) * L.z;
+                r.f = r.f + df * pd * (1.0f - F); r.pdf += dpdf * pd * (1.0f - F);
+            }
+            // dielectric specular (:285-298) and glass reflection (:225-238) share EvaluateReflection(SpecularColor)
+            {
+                Eval e = reflection(V, L, spec);
+                V3 sf = e.f;
+                if (ec) sf = sf / ec_r;
+                r.f = r.f + sf * pd * F; r.pdf += e.pdf * pd * F;
+                V3 gf = e.f;
+                if (ec && ec_g > 0.01f) gf = gf / ec_g;
+                r.f = r.f + gf * pg * F; r.pdf += e.pdf * pg * F;
+            }
+        }
+        if (refracted && valid_refr) {  // :240-252
+            Eval e = refraction(V, L, base);
+            if (ec && ec_g > 0.01f) e.f = e.f / ec_g;
+            r.f = r.f + e.f * pg * (1.0f - F); r.pdf += e.pdf * pg * (1.0f - F);
+        }
+        return r;
+    }
+};
+
+// Material.Initialize, :39-87 (+ FURNACE_TEST_MODE override :78-86)
+__device__ inline void bsdf_init(const DeviceScene& sc, Bsdf& b, const vpt_material& m, V2 uv, bool inside, uint32_t flags,
+                                 V3& medium_color, float& medium_density, float& medium_aniso, float& aniso_rotation) {
+    V4 tb = tex_sample(sc, m.base_color_texture, uv.x, uv.y);
+    b.ior = max_(m.ior, 1.000001f);
+    b.base = v3(m.base_color[0] * pow_(tb.x, 2.2f), m.base_color[1] * pow_(tb.y, 2.2f), m.base_color[2] * pow_(tb.z, 2.2f));
+    b.roughness = m.roughness * tex_sample(sc, m.roughness_texture, uv.x, uv.y).x;
+    b.metallic = m.metallic * tex_sample(sc, m.metallic_texture, uv.x, uv.y).x;
+    V4 te = tex_sample(sc, m.emissive_texture, uv.x, uv.y);
+    b.emissive = v3(m.emissive_color[0] * te.x, m.emissive_color[1] * te.y, m.emissive_color[2] * te.z);
+    b.spec = ld3(m.specular_color);
+    b.transmission = m.transmission;
+    b.anisotropy = m.anisotropy;
+    float aspect = sqrt_(1.0f - sqrt_(m.anisotropy) * 0.9f);
+    b.ax = max_(0.00001f, b.roughness / aspect);
+    b.ay = max_(0.00001f, b.roughness * aspect);
+    b.eta = inside ? b.ior : 1.0f / b.ior;
+    medium_color = ld3(m.medium_color);
+    medium_density = m.medium_density; medium_aniso = m.medium_anisotropy; aniso_rotation = m.anisotropy_rotation;
+    if (flags & VPT_FLAG_FURNACE) { b.base = v3s(1.0f); b.emissive = v3s(0.0f); b.spec = v3s(1.0f); medium_color = v3s(1.0f); }
+    b.ec = (flags & VPT_FLAG_ENERGY_COMPENSATION) != 0;
+    b.lut_r = sc.lut_r; b.lut_o = sc.lut_o; b.lut_i = sc.lut_i;
+    b.pm = b.metallic;
+    b.pd = (1.0f - b.metallic) * (1.0f - b.transmission);
+    b.pg = (1.0f - b.metallic) * b.transmission;
+    float sum = b.pm + b.pd + b.pg;
+    b.pm /= sum; b.pd /= sum; b.pg /= sum;
+}
+
+// ------------------------------------------------------------------ Sampler.slang
+__device__ inline V2 random_circle(Rng& r) {  // :102-112
+    float u1 = r.uf(), u2 = r.uf();
+    float s, c; sincos_(2.0f * VPT_PI * u1, &s, &c);
+    float rad = sqrt_(u2);
+    V2 o; o.x = rad * c; o.y = rad * s; return o;
+}
+__device__ inline V3 random_sphere(Rng& r) {  // :114-133
+    float u1 = r.uf(), u2 = r.uf();
+    float s, c; sincos_(2.0f * VPT_PI * u1, &s, &c);
+    float z = 1.0f - 2.0f * u2;
+    float rad = sqrt_(1.0f - z * z);
+    return v3(rad * c, rad * s, z);
+}
+__device__ inline V3 ggx_sample(Rng& r, V3 Ve, float ax, float ay) {  // :141-166 (Heitz 2018 VNDF)
+    float u1 = r.uf(), u2 = r.uf();
+    V3 Vh = normalize(v3(ax * Ve.x, ay * Ve.y, fabs_(Ve.z)));
+    float lensq = Vh.x * Vh.x + Vh.y * Vh.y;
+    V3 T1 = lensq > 0.0f ? v3(-Vh.y, Vh.x, 0.0f) * (1.0f / sqrt_(lensq)) : v3(1.0f, 0.0f, 0.0f);
+    V3 T2 = cross(Vh, T1);
+    float rad = sqrt_(u1);
+    float sp, cp; sincos_(2.0f * VPT_PI * u2, &sp, &cp);
+    float t1 = rad * cp, t2 = rad * sp;
+    float s = 0.5f * (1.0f + Vh.z);
+    t2 = (1.0f - s) * sqrt_(1.0f - t1 * t1) + s * t2;
+    V3 Nh = (t1 * T1 + t2 * T2) + sqrt_(max_(0.0f, 1.0f - t1 * t1 - t2 * t2)) * Vh;
+    return normalize(v3(ax * Nh.x, ay * Nh.y, max_(0.0f, Nh.z)));
+}
+__device__ inline V3 sample_hg(Rng& r, V3 dir, float G) {  // :168-193
+    float r1 = r.uf(), r2 = r.uf();
+    float ct;
+    if (fabs_(G) < 1e-5f) ct = 2.0f * r1 - 1.0f;
+    else { float sq = (1.0f - G * G) / (1.0f - G + 2.0f * G * r1); ct = (1.0f + G * G - sq * sq) / (2.0f * G); }
+    float sp, cp; sincos_(2.0f * VPT_PI * r2, &sp, &cp);
+    float st = sqrt_(1.0f - ct * ct);
+    V3 nd = v3(st * cp, st * sp, ct);
+    V3 up = fabs_(dir.y) < 0.9999999f ? v3(0.0f, 1.0f, 0.0f) : v3(0.0f, 0.0f, 1.0f);
+    V3 t = normalize(cross(up, dir));
+    V3 b = cross(dir, t);
+    return normalize((nd.x * t + nd.y * b) + nd.z * dir);
+}
+// ImportanceSampleEnvMap, :286-346 (3 draws)
+__device__ inline void sample_env(const DeviceScene& sc, const RenderParams& P, Rng& r, V3& to_light, V4& out) {
+    float x0 = r.uf(), x1 = r.uf(), x2 = r.uf();
+    uint32_t w = sc.env_w, h = sc.env_h, size = w * h;
+    uint32_t idx = (uint32_t)(x0 * (float)size);
+    idx = idx < size - 1 ? idx : size - 1;
+    AliasEntry e = sc.alias[idx];
+    uint32_t ei;
+    if (x1 < e.importance) { ei = idx; x1 /= e.importance; }
+    else { ei = e.alias; x1 = (x1 - e.importance) / (1.0f - e.importance); }
+    uint32_t px = ei % w, py = ei / w;
+    float u = ((float)px + x1) / (float)w;
+    float sp, cp; sincos_(u * (2.0f * VPT_PI) - VPT_PI, &sp, &cp);
+    float step = VPT_PI / (float)h;
+    float theta0 = (float)py * step;
+    float ct = cos_(theta0) * (1.0f - x2) + cos_(theta0 + step) * x2;
+    float theta = acos_(clamp_(ct, -1.0f, 1.0f));
+    float st = sin_(theta);
+    float v = theta * VPT_1_OVER_PI;
+    to_light = v3(sp * st, -ct, (-cp) * st);
+    to_light = rotate(to_light, v3(0.0f, 1.0f, 0.0f), P.sky_azimuth / 180.0f * VPT_PI);
+    to_light = rotate(to_light, v3(1.0f, 0.0f, 0.0f), P.sky_altitude / 180.0f * VPT_PI);
+    out = env_sample(sc, u, v);
+    out.x *= P.sky_intensity; out.y *= P.sky_intensity; out.z *= P.sky_intensity;
+}
+// SampleEmissiveTriangle, :348-422 (1+1+2 draws; none if there is no emissive mesh)
+__device__ inline void sample_emissive(const DeviceScene& sc, Rng& r, V3 pos, V3& to_light, V4& cpdf, uint32_t& gid) {
+    gid = 0xffffffffu;
+    uint32_t n = sc.emissive_count;
+    if (n == 0) { to_light = v3s(0.0f); cpdf = v4(0.0f, 0.0f, 0.0f, 0.0f); return; }
+    uint32_t mi = (uint32_t)floor_(r.uf() * (float)n);
+    mi = mi < n - 1 ? mi : n - 1;
+    const EmissiveDesc& em = sc.emissive[mi];
+    uint32_t tc = em.tri_count;
+    uint32_t ti = (uint32_t)floor_(r.uf() * (float)tc);
+    ti = ti < tc - 1 ? ti : tc - 1;
+    gid = sc.instances[em.instance].tri_offset + ti;
+    const MeshDesc me = sc.meshes[em.mesh];
+    const uint32_t* idx = sc.indices + me.index_offset + ti * 3;
+    const vpt_vertex* vb = sc.vertices + me.vertex_offset;
+    const vpt_vertex &a = vb[idx[0]], &b = vb[idx[1]], &c = vb[idx[2]];
+    V3 p0 = mat_point(em.xform, ld3(a.position)), p1 = mat_point(em.xform, ld3(b.position)), p2 = mat_point(em.xform, ld3(c.position));
+    float x0 = r.uf(), x1 = r.uf();
+    float su = sqrt_(x0);
+    float b0 = 1.0f - su, b1 = x1 * su, b2 = 1.0f - b0 - b1;
+    V3 tp = (b0 * p0 + b1 * p1) + b2 * p2;
+    float uu = (b0 * a.texcoord[0] + b1 * b.texcoord[0]) + b2 * c.texcoord[0];
+    float vv = (b0 * a.texcoord[1] + b1 * b.texcoord[1]) + b2 * c.texcoord[1];
+    to_light = normalize(tp - pos);
+    V3 nrm = normalize(cross(p2 - p0, p1 - p0));
+    float area = length(cross(p1 - p0, p2 - p0)) * 0.5f;
+    float d2 = dot(tp - pos, tp - pos);
+    float ct = fabs_(dot(nrm, to_light));
+    cpdf.w = d2 / ((float)n * (float)tc * area * ct);
+    const vpt_material& m = sc.materials[em.material];
+    V4 te = tex_sample(sc, m.emissive_texture, uu, vv);
+    cpdf.x = m.emissive_color[0] * te.x; cpdf.y = m.emissive_color[1] * te.y; cpdf.z = m.emissive_color[2] * te.z;
+}
+
+// Camera ray + AA jitter + DOF, RayGen.slang:35-50 (4 draws, the DOF pair always drawn).
+__device__ inline void camera_ray(const RenderParams& P, Rng& r, uint32_t x, uint32_t y, V3& origin, V3& direction) {
+    float j0 = r.uf(), j1 = r.uf();
+    float cx = ((float)x + 0.5f) + (j0 * (0.5f - -0.5f) + -0.5f);
+    float cy = ((float)y + 0.5f) + (j1 * (0.5f - -0.5f) + -0.5f);
+    float dx = (cx / (float)P.width) * 2.0f - 1.0f, dy = (cy / (float)P.height) * 2.0f - 1.0f;
+    V4 o4 = mat_v4(P.view_inv, v4(0.0f, 0.0f, 0.0f, 1.0f));
+    origin = v3(o4.x, o4.y, o4.z);
+    V4 tg = mat_v4(P.proj_inv, v4(dx, dy, 1.0f, 1.0f));
+    V3 tn = normalize(v3(tg.x, tg.y, tg.z));
+    V4 dd = mat_v4(P.view_inv, v4(tn.x, tn.y, tn.z, 0.0f));
+    direction = v3(dd.x, dd.y, dd.z);
+    V3 focus = origin + direction * max_(P.focus_distance, 0.001f);
+    V2 rc = random_circle(r);
+    float rox = rc.x * 0.5f * P.dof_strength, roy = rc.y * 0.5f * P.dof_strength;
+    V3 right = v3(P.view_inv[0], P.view_inv[1], P.view_inv[2]);
+    V3 upv = v3(P.view_inv[4], P.view_inv[5], P.view_inv[6]);
+    origin = origin + (rox * right + roy * upv);
+    direction = normalize(focus - origin);
+}
+
+}  // namespace vpt

@@ -1,0 +1,691 @@
+// vpt_api.hip — implementation of the C-ABI in include/vpt.h: context, scene preparation (host
+// arithmetic of PathTracer.cpp restated), the wavefront render loop, sharding, post-process schedule.
+// There is no CPU fallback in this file: without a HIP device vpt_create() fails.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "bvh_build.hpp"
+#include "kernels.hpp"
+
+using namespace vpt;
+
+struct vpt_ctx {
+    vpt_config cfg{};
+    hipStream_t stream = nullptr;
+    std::string err;
+    int cu_count = 256;
+
+    // host copies (SetMaterial / emissive list maintenance / stats)
+    bool has_scene = false;
+    std::vector<vpt_material> materials;
+    std::vector<MeshDesc> meshes;
+    std::vector<InstanceDesc> instances;
+    std::vector<EmissiveDesc> emissive;
+    uint32_t emissive_tris = 0;
+    uint64_t total_vertices = 0, total_indices = 0;
+    uint32_t bvh_depth = 0;
+
+    DeviceScene dsc{};
+    std::vector<void*> scene_allocs;
+    vpt_material* d_materials = nullptr;
+    EmissiveDesc* d_emissive = nullptr;
+    bool lds_scene = false;
+    int trav_blocks = 1024;
+
+    vpt_params params{};
+    RenderParams P{};
+    uint32_t frames_in_flight = 1;
+
+    void* ps_block = nullptr;
+    PathState ps{};
+    uint32_t* queue[2] = {nullptr, nullptr};
+    ShadowRay* shadow = nullptr;
+    Counters* ctr = nullptr;
+    float* image = nullptr;       // this shard's rows, RGBA32F
+    float* full_image = nullptr;  // whole image when shard_count > 1 (after vpt_assemble_shards)
+    bool full_valid = false;
+
+    uint64_t dispatch_count = 0;
+    uint32_t frame_count = 0, samples_accum = 0;
+    vpt_stats stats{};
+
+    // post
+    std::vector<float*> mips;
+    std::vector<std::pair<uint32_t, uint32_t>> mip_sizes;
+    uint8_t* post_out = nullptr;
+    uint32_t post_w = 0, post_h = 0;
+
+    // profiling events
+    std::vector<hipEvent_t> ev_pool;
+    struct Pending { int kernel; hipEvent_t a, b; };
+    std::vector<Pending> pending;
+    size_t ev_next = 0;
+};
+
+namespace {
+
+#define HIPCHK(ctx, call)                                                                                      \
+    do {                                                                                                       \
+        hipError_t e_ = (call);                                                                                \
+        if (e_ != hipSuccess) {                                                                                \
+            char buf_[512];                                                                                    \
+            snprintf(buf_, sizeof(buf_), "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            (ctx)->err = buf_;                                                                                 \
+            return (e_ == hipErrorOutOfMemory) ? VPT_ERR_OUT_OF_MEMORY : VPT_ERR_DEVICE;                       \
+        }                                                                                                      \
+    } while (0)
+
+int fail(vpt_ctx* c, int code, const char* msg) { c->err = msg; return code; }
+
+template <class T>
+int upload(vpt_ctx* c, const std::vector<T>& v, const T** out, size_t min_elems = 1) {
+    size_t n = std::max(v.size(), min_elems);
+    void* d = nullptr;
+    HIPCHK(c, hipMalloc(&d, n * sizeof(T)));
+    c->scene_allocs.push_back(d);
+    HIPCHK(c, hipMemset(d, 0, n * sizeof(T)));
+    if (!v.empty()) HIPCHK(c, hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    *out = (const T*)d;
+    return VPT_OK;
+}
+
+void free_scene(vpt_ctx* c) {
+    for (void* p : c->scene_allocs) (void)hipFree(p);
+    c->scene_allocs.clear();
+    c->has_scene = false;
+    c->d_materials = nullptr; c->d_emissive = nullptr;
+}
+void free_render_buffers(vpt_ctx* c) {
+    if (c->ps_block) (void)hipFree(c->ps_block);
+    c->ps_block = nullptr;
+    for (int i = 0; i < 2; i++) { if (c->queue[i]) (void)hipFree(c->queue[i]); c->queue[i] = nullptr; }
+    if (c->shadow) (void)hipFree(c->shadow);
+    c->shadow = nullptr;
+    if (c->image) (void)hipFree(c->image);
+    c->image = nullptr;
+    if (c->full_image) (void)hipFree(c->full_image);
+    c->full_image = nullptr;
+    for (float* m : c->mips) (void)hipFree(m);
+    c->mips.clear(); c->mip_sizes.clear();
+    if (c->post_out) (void)hipFree(c->post_out);
+    c->post_out = nullptr; c->post_w = c->post_h = 0;
+}
+
+uint32_t shard_rows_of(uint32_t height, uint32_t rank, uint32_t count) { return rank < height ? (height - rank + count - 1) / count : 0; }
+
+int alloc_render_buffers(vpt_ctx* c) {
+    free_render_buffers(c);
+    RenderParams& P = c->P;
+    P.width = c->cfg.width; P.height = c->cfg.height;
+    P.shard_rank = c->cfg.shard_rank; P.shard_count = c->cfg.shard_count;
+    P.shard_rows = shard_rows_of(P.height, P.shard_rank, P.shard_count);
+    P.shard_pixels = P.shard_rows * P.width;
+    if (P.shard_pixels == 0) return fail(c, VPT_ERR_INVALID_ARGUMENT, "empty shard");
+    uint32_t F = c->cfg.frames_in_flight;
+    if (F == 0) { F = (4u << 20) / P.shard_pixels; F = std::max(1u, std::min(F, 64u)); }
+    c->frames_in_flight = F;
+    uint64_t cap64 = (uint64_t)P.shard_pixels * F;
+    if (cap64 >= (1ull << 31)) return fail(c, VPT_ERR_INVALID_ARGUMENT, "too many paths in flight");
+    uint32_t cap = (uint32_t)cap64;
+    const int kWords = 47;
+    size_t stride = ((size_t)cap + 63) & ~(size_t)63;
+    HIPCHK(c, hipMalloc(&c->ps_block, stride * 4 * kWords));
+    uint32_t* base = (uint32_t*)c->ps_block;
+    int k = 0;
+    auto nextf = [&]() { return (float*)(base + stride * (k++)); };
+    auto nextu = [&]() { return (uint32_t*)(base + stride * (k++)); };
+    PathState& s = c->ps;
+    s.capacity = cap;
+    s.rng = nextu();
+    s.ox = nextf(); s.oy = nextf(); s.oz = nextf();
+    s.dx = nextf(); s.dy = nextf(); s.dz = nextf();
+    s.tx = nextf(); s.ty = nextf(); s.tz = nextf();
+    s.lx = nextf(); s.ly = nextf(); s.lz = nextf();
+    s.bx = nextf(); s.by = nextf(); s.bz = nextf();
+    s.pdf = nextf();
+    s.depth = nextu(); s.medium_flag = nextu();
+    s.mdensity = nextf(); s.maniso = nextf(); s.mcr = nextf(); s.mcg = nextf(); s.mcb = nextf();
+    s.ht = nextf(); s.hu = nextf(); s.hv = nextf(); s.hprim = nextu(); s.hinst = nextu();
+    s.ex = nextf(); s.ey = nextf(); s.ez = nextf();
+    s.skx = nextf(); s.sky = nextf(); s.skz = nextf();
+    s.lgx = nextf(); s.lgy = nextf(); s.lgz = nextf();
+    s.vis = nextu();
+    s.ax = nextf(); s.ay = nextf(); s.az = nextf();
+    if (k > kWords) return fail(c, VPT_ERR_DEVICE, "internal: path state carve overflow");
+    for (int i = 0; i < 2; i++) HIPCHK(c, hipMalloc((void**)&c->queue[i], (size_t)cap * 4));
+    HIPCHK(c, hipMalloc((void**)&c->shadow, (size_t)cap * 2 * sizeof(ShadowRay)));
+    HIPCHK(c, hipMalloc((void**)&c->image, (size_t)P.shard_pixels * 16));
+    HIPCHK(c, hipMemset(c->image, 0, (size_t)P.shard_pixels * 16));
+    if (P.shard_count > 1) {
+        HIPCHK(c, hipMalloc((void**)&c->full_image, (size_t)P.width * P.height * 16));
+        HIPCHK(c, hipMemset(c->full_image, 0, (size_t)P.width * P.height * 16));
+    }
+    c->full_valid = false;
+    return VPT_OK;
+}
+
+void sync_params(vpt_ctx* c) {
+    RenderParams& P = c->P;
+    const vpt_params& p = c->params;
+    P.samples_per_frame = p.samples_per_frame; P.max_depth = p.max_depth;
+    P.max_luminance = p.max_luminance; P.focus_distance = p.focus_distance; P.dof_strength = p.dof_strength;
+    P.sky_azimuth = p.sky_azimuth; P.sky_altitude = p.sky_altitude; P.sky_intensity = p.sky_intensity;
+    P.emissive_pdf_bias = p.emissive_pdf_bias; P.flags = p.flags; P.base_seed = p.base_seed;
+}
+
+void reset_accum(vpt_ctx* c) { c->frame_count = 0; c->dispatch_count = 0; c->samples_accum = 0; }  // PathTracer.h:183
+
+// Emissive-mesh list, PathTracer.cpp:449-469 (and SetMaterial's rebuild, 712-794: same resulting order
+// only for additions at the end; we rebuild from instance order, which is what SetScene produces).
+void build_emissive(vpt_ctx* c) {
+    c->emissive.clear(); c->emissive_tris = 0;
+    for (uint32_t i = 0; i < c->instances.size(); i++) {
+        const vpt_material& m = c->materials[c->instances[i].material];
+        if (m.emissive_color[0] != 0.0f || m.emissive_color[1] != 0.0f || m.emissive_color[2] != 0.0f) {
+            EmissiveDesc e;
+            e.mesh = c->instances[i].mesh; e.material = c->instances[i].material;
+            e.tri_count = c->meshes[e.mesh].tri_count; e.instance = i;
+            memcpy(e.xform, c->instances[i].xform, 64);
+            c->emissive.push_back(e); c->emissive_tris += e.tri_count;
+        }
+    }
+}
+int upload_emissive(vpt_ctx* c) {
+    if (c->emissive.size() > VPT_MAX_EMISSIVE_MESHES) return fail(c, VPT_ERR_LIMIT, "too many emissive meshes");
+    if (!c->emissive.empty())
+        HIPCHK(c, hipMemcpy(c->d_emissive, c->emissive.data(), c->emissive.size() * sizeof(EmissiveDesc), hipMemcpyHostToDevice));
+    c->dsc.emissive_count = (uint32_t)c->emissive.size();
+    c->dsc.emissive_tris = c->emissive_tris;
+    return VPT_OK;
+}
+
+// LoadEnvironmentMap, PathTracer.cpp:1161-1296: per-texel importance = solid angle * max(rgb), alias
+// table (Vose-style pairing with the reference's pre-increment partition quirk), pdf into alpha.
+void build_env_tables(const float* rgba, uint32_t w, uint32_t h, std::vector<float>& env, std::vector<AliasEntry>& alias) {
+    const uint64_t size = (uint64_t)w * h;
+    env.assign(rgba, rgba + size * 4);
+    std::vector<float> importance(size);
+    float cos_prev = 1.0f;
+    const float step_phi = 2.0f * 3.14159265358979323846f / (float)w;
+    const float step_theta = 3.14159265358979323846f / (float)h;
+    for (uint32_t y = 0; y < h; y++) {
+        float cos_next = vptfp::cos_((float)(y + 1) * step_theta);
+        float area = (cos_prev - cos_next) * step_phi;
+        cos_prev = cos_next;
+        const float* row = &env[(size_t)y * w * 4];
+        for (uint32_t x = 0; x < w; x++) importance[(size_t)y * w + x] = area * std::max(row[x * 4], std::max(row[x * 4 + 1], row[x * 4 + 2]));
+    }
+    float sum = 0.0f;
+    for (uint64_t i = 0; i < size; i++) sum = sum + importance[i];  // std::accumulate in fp32, in order
+    const float average = sum / (float)size;
+    alias.resize(size);
+    for (uint64_t i = 0; i < size; i++) { alias[i].importance = (average == 0.0f) ? 0.0f : importance[i] / average; alias[i].alias = (uint32_t)i; }
+    std::vector<uint32_t> table(size + 1, 0u);
+    uint32_t lo = 0, hi = (uint32_t)size;
+    for (uint32_t i = 0; i < size; i++) {
+        if (alias[i].importance < 1.0f) table[++lo] = i;  // upstream pre-increments: slot 0 stays 0
+        else table[--hi] = i;
+    }
+    for (lo = 0; lo < hi && hi < size; lo++) {
+        const uint32_t l = table[lo], g = table[hi];
+        alias[l].alias = g;
+        alias[g].importance -= 1.0f - alias[l].importance;
+        if (alias[g].importance < 1.0f) hi++;
+    }
+    for (uint64_t i = 0; i < size; i++) {
+        float m = std::max(env[i * 4], std::max(env[i * 4 + 1], env[i * 4 + 2]));
+        env[i * 4 + 3] = (sum == 0.0f) ? 0.0f : m / sum;
+    }
+}
+
+void begin_timing(vpt_ctx* c, int kernel, hipEvent_t* a, hipEvent_t* b) {
+    *a = *b = nullptr;
+    c->stats.kernel_launches[kernel]++;
+    if (!c->cfg.profile) return;
+    if (c->ev_next + 2 > c->ev_pool.size()) {
+        for (int i = 0; i < 64; i++) { hipEvent_t e; (void)hipEventCreate(&e); c->ev_pool.push_back(e); }
+    }
+    *a = c->ev_pool[c->ev_next++]; *b = c->ev_pool[c->ev_next++];
+    (void)hipEventRecord(*a, c->stream);
+    c->pending.push_back({kernel, *a, *b});
+}
+void end_timing(vpt_ctx* c, hipEvent_t b) { if (b) (void)hipEventRecord(b, c->stream); }
+void collect_timing(vpt_ctx* c) {  // call after a stream sync
+    for (auto& p : c->pending) { float ms = 0.0f; if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) c->stats.kernel_ms[p.kernel] += ms; }
+    c->pending.clear(); c->ev_next = 0;
+}
+#define TIMED(ctx, kid, launch_expr)            \
+    do {                                        \
+        hipEvent_t ea_, eb_;                    \
+        begin_timing(ctx, kid, &ea_, &eb_);     \
+        launch_expr;                            \
+        end_timing(ctx, eb_);                   \
+    } while (0)
+
+// One batch of `frames` consecutive dispatches (frame_base = index of the first).
+int render_batch(vpt_ctx* c, uint32_t frames, uint32_t dispatch_base, uint32_t frame_base) {
+    const uint32_t n_slots = frames * c->P.shard_pixels;
+    hipStream_t s = c->stream;
+    Counters init{};
+    init.ray_count[0] = n_slots;
+    HIPCHK(c, hipMemcpyAsync(c->ctr, &init, 32, hipMemcpyHostToDevice, s));  // counters only, keep stat_* running
+    TIMED(c, VPT_K_RAYGEN, launch_raygen(s, c->P, c->ps, c->queue[0], n_slots, dispatch_base));
+    uint32_t parity = 0, n = n_slots;
+    const bool count = c->cfg.count_traversal != 0;
+    uint64_t iter = 0;
+    const uint64_t iter_cap = (uint64_t)c->P.max_depth * c->P.samples_per_frame * 4ull + 1024ull;
+    while (n > 0) {
+        launch_prepare(s, c->ctr, parity);
+        TIMED(c, VPT_K_EXTEND, launch_extend(s, (uint32_t)c->trav_blocks, c->lds_scene, count, c->dsc, c->ps, c->queue[parity], c->ctr, parity));
+        TIMED(c, VPT_K_SHADE, launch_shade(s, n, c->dsc, c->P, c->ps, c->queue[parity], c->shadow, c->ctr, parity));
+        TIMED(c, VPT_K_SHADOW, launch_shadow(s, (uint32_t)c->trav_blocks, c->lds_scene, count, c->dsc, c->ps, c->shadow, c->ctr));
+        TIMED(c, VPT_K_ACCUMULATE, launch_accumulate(s, n, c->P, c->ps, c->queue[parity], c->queue[parity ^ 1u], c->ctr, parity));
+        Counters h{};
+        HIPCHK(c, hipMemcpyAsync(&h, c->ctr, sizeof(Counters), hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        collect_timing(c);
+        c->stats.closest_rays += n;
+        c->stats.shadow_rays += h.shadow_count;
+        c->stats.nodes_visited = h.stat_nodes;
+        c->stats.tris_tested = h.stat_tris;
+        parity ^= 1u;
+        n = h.ray_count[parity];
+        if (n > n_slots) return fail(c, VPT_ERR_DEVICE, "internal: queue overflow");
+        if (++iter > iter_cap) return fail(c, VPT_ERR_DEVICE, "internal: bounce loop did not terminate");
+    }
+    TIMED(c, VPT_K_RESOLVE, launch_resolve(s, c->P, c->ps, c->image, frames, frame_base));
+    HIPCHK(c, hipStreamSynchronize(s));
+    collect_timing(c);
+    HIPCHK(c, hipGetLastError());
+    c->stats.samples += (uint64_t)n_slots * c->P.samples_per_frame;
+    return VPT_OK;
+}
+
+int ensure_post_buffers(vpt_ctx* c) {
+    const uint32_t w = c->P.width, h = c->P.height;
+    if (c->post_w == w && c->post_h == h && !c->mips.empty()) return VPT_OK;
+    for (float* m : c->mips) (void)hipFree(m);
+    c->mips.clear(); c->mip_sizes.clear();
+    if (c->post_out) (void)hipFree(c->post_out);
+    c->post_out = nullptr;
+    uint32_t cw = w, ch = h;
+    for (int i = 0; i < 10; i++) {  // PostProcessor.cpp:136-157 (MAX_BLOOM_LEVELS = 10)
+        float* m = nullptr;
+        HIPCHK(c, hipMalloc((void**)&m, (size_t)cw * ch * 16));
+        c->mips.push_back(m); c->mip_sizes.push_back({cw, ch});
+        if (cw % 2 != 0) cw -= 1;
+        if (ch % 2 != 0) ch -= 1;
+        cw /= 2; ch /= 2;
+        if (cw < 2 || ch < 2) break;
+    }
+    HIPCHK(c, hipMalloc((void**)&c->post_out, (size_t)w * h * 4));
+    c->post_w = w; c->post_h = h;
+    return VPT_OK;
+}
+
+const float* whole_image(vpt_ctx* c) { return c->P.shard_count > 1 ? c->full_image : c->image; }
+
+}  // namespace
+
+extern "C" {
+
+void vpt_default_params(vpt_params* p) {  // PathTracer.h:197-233
+    p->samples_per_frame = 1; p->max_samples = 5000; p->max_depth = 200; p->max_luminance = 500.0f;
+    p->focus_distance = 1.0f; p->dof_strength = 0.0f; p->sky_azimuth = 0.0f; p->sky_altitude = 0.0f; p->sky_intensity = 1.0f;
+    p->screen_chunk_count = 1; p->emissive_pdf_bias = 0.0f; p->flags = VPT_FLAGS_DEFAULT; p->base_seed = 1;
+}
+void vpt_default_post_params(vpt_post_params* p) {  // PostProcessor.h:8-21
+    p->exposure = 1.0f; p->gamma = 2.2f; p->bloom_threshold = 2.0f; p->bloom_strength = 1.0f; p->mip_count = 10; p->falloff_range = 5.0f;
+}
+
+vpt_ctx* vpt_create(const vpt_config* cfg, int* err) {
+    auto set = [&](int e) { if (err) *err = e; };
+    if (!cfg || cfg->width == 0 || cfg->height == 0 || cfg->shard_count == 0 || cfg->shard_rank >= cfg->shard_count) { set(VPT_ERR_INVALID_ARGUMENT); return nullptr; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev) { set(VPT_ERR_NO_DEVICE); return nullptr; }
+    if (hipSetDevice(cfg->device) != hipSuccess) { set(VPT_ERR_NO_DEVICE); return nullptr; }
+    vpt_ctx* c = new vpt_ctx();
+    c->cfg = *cfg;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess) c->cu_count = prop.multiProcessorCount;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipMalloc((void**)&c->ctr, sizeof(Counters)) != hipSuccess) {
+        set(VPT_ERR_DEVICE); delete c; return nullptr;
+    }
+    (void)hipMemset(c->ctr, 0, sizeof(Counters));
+    vpt_default_params(&c->params);
+    const float id[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    memcpy(c->P.view_inv, id, 64); memcpy(c->P.proj_inv, id, 64);
+    sync_params(c);
+    int rc = alloc_render_buffers(c);
+    if (rc != VPT_OK) { set(rc); vpt_destroy(c); return nullptr; }
+    set(VPT_OK);
+    return c;
+}
+
+void vpt_destroy(vpt_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->cfg.device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    free_scene(c);
+    free_render_buffers(c);
+    if (c->ctr) (void)hipFree(c->ctr);
+    for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* vpt_last_error(const vpt_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int vpt_set_scene(vpt_ctx* c, const vpt_scene_desc* sd) {
+    if (!c || !sd) return VPT_ERR_INVALID_ARGUMENT;
+    if (sd->mesh_count == 0 || !sd->meshes) return fail(c, VPT_ERR_INVALID_ARGUMENT, "No meshes found in scene");  // PathTracer.cpp:180
+    if (sd->mesh_count >= VPT_MAX_ENTITIES || sd->material_count >= VPT_MAX_ENTITIES) return fail(c, VPT_ERR_LIMIT, "too many meshes/materials");
+    if (sd->instance_count >= VPT_MAX_INSTANCES) return fail(c, VPT_ERR_LIMIT, "too many mesh instances");
+    if (!sd->materials || sd->material_count == 0 || !sd->instances || !sd->textures || sd->texture_count == 0 || !sd->env_rgba ||
+        sd->env_width == 0 || sd->env_height == 0 || !sd->lut_reflection || !sd->lut_refraction_outside || !sd->lut_refraction_inside)
+        return fail(c, VPT_ERR_INVALID_ARGUMENT, "incomplete scene description");
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    free_scene(c);
+    reset_accum(c);
+    // ---- geometry pools
+    std::vector<vpt_vertex> verts; std::vector<uint32_t> idx;
+    c->meshes.clear(); c->total_vertices = 0; c->total_indices = 0;
+    for (uint32_t m = 0; m < sd->mesh_count; m++) {
+        const vpt_mesh& me = sd->meshes[m];
+        if (!me.vertices || !me.indices || me.index_count % 3 != 0) return fail(c, VPT_ERR_INVALID_ARGUMENT, "bad mesh");
+        for (uint32_t k = 0; k < me.index_count; k++) if (me.indices[k] >= me.vertex_count) return fail(c, VPT_ERR_INVALID_ARGUMENT, "mesh index out of range");
+        MeshDesc d; d.vertex_offset = (uint32_t)verts.size(); d.index_offset = (uint32_t)idx.size(); d.tri_count = me.index_count / 3; d.pad = 0;
+        verts.insert(verts.end(), me.vertices, me.vertices + me.vertex_count);
+        idx.insert(idx.end(), me.indices, me.indices + me.index_count);
+        c->meshes.push_back(d);
+        c->total_vertices += me.vertex_count; c->total_indices += me.index_count;
+    }
+    c->materials.assign(sd->materials, sd->materials + sd->material_count);
+    for (const vpt_material& m : c->materials)
+        if (m.base_color_texture >= sd->texture_count || m.normal_texture >= sd->texture_count || m.roughness_texture >= sd->texture_count ||
+            m.metallic_texture >= sd->texture_count || m.emissive_texture >= sd->texture_count)
+            return fail(c, VPT_ERR_INVALID_ARGUMENT, "material texture index out of range");
+    // ---- instances, flattened world-space triangles (instance-major global ids)
+    c->instances.clear();
+    std::vector<BvhTri> tris;
+    for (uint32_t i = 0; i < sd->instance_count; i++) {
+        const vpt_instance& in = sd->instances[i];
+        if (in.mesh_index >= sd->mesh_count) return fail(c, VPT_ERR_INVALID_ARGUMENT, "instance mesh index out of range");
+        if (in.material_index >= sd->material_count) return fail(c, VPT_ERR_INVALID_ARGUMENT, "Mesh instance has invalid material index");  // PathTracer.cpp:454
+        InstanceDesc d; memset(&d, 0, sizeof(d));
+        d.mesh = in.mesh_index; d.material = in.material_index; d.tri_offset = (uint32_t)tris.size();
+        memcpy(d.xform, in.transform, 64);
+        vptfp::inverse3x3_from_mat4(in.transform, d.inv3);
+        c->instances.push_back(d);
+        const MeshDesc& me = c->meshes[d.mesh];
+        for (uint32_t t = 0; t < me.tri_count; t++) {
+            const uint32_t* ii = &idx[me.index_offset + t * 3];
+            vptfp::V3 p[3];
+            for (int k = 0; k < 3; k++) {
+                const vpt_vertex& v = verts[me.vertex_offset + ii[k]];
+                p[k] = vptfp::mat_point(d.xform, vptfp::v3(v.position[0], v.position[1], v.position[2]));
+            }
+            vptfp::V3 e1 = p[1] - p[0], e2 = p[2] - p[0];
+            BvhTri bt;
+            bt.v0[0] = p[0].x; bt.v0[1] = p[0].y; bt.v0[2] = p[0].z;
+            bt.e1[0] = e1.x; bt.e1[1] = e1.y; bt.e1[2] = e1.z;
+            bt.e2[0] = e2.x; bt.e2[1] = e2.y; bt.e2[2] = e2.z;
+            bt.prim = t; bt.inst = i; bt.gid = (uint32_t)tris.size();
+            tris.push_back(bt);
+        }
+    }
+    std::vector<BvhNode> nodes; std::vector<BvhTri> leaf_tris; int depth = 0;
+    build_bvh(tris, nodes, leaf_tris, &depth);
+    c->bvh_depth = (uint32_t)depth;
+    // ---- textures
+    std::vector<TexDesc> tds; std::vector<uint8_t> texels;
+    for (uint32_t t = 0; t < sd->texture_count; t++) {
+        const vpt_texture& tx = sd->textures[t];
+        if (!tx.data || tx.width == 0 || tx.height == 0 || (tx.channels != 1 && tx.channels != 4)) return fail(c, VPT_ERR_INVALID_ARGUMENT, "bad texture");
+        while (texels.size() % 4) texels.push_back(0);
+        TexDesc d; d.offset = (uint32_t)texels.size(); d.w = tx.width; d.h = tx.height; d.c = tx.channels;
+        texels.insert(texels.end(), tx.data, tx.data + (size_t)tx.width * tx.height * tx.channels);
+        tds.push_back(d);
+    }
+    // ---- environment + tables
+    std::vector<float> env; std::vector<AliasEntry> alias;
+    build_env_tables(sd->env_rgba, sd->env_width, sd->env_height, env, alias);
+    std::vector<float> lr(sd->lut_reflection, sd->lut_reflection + 64 * 64 * 32);
+    std::vector<float> lo(sd->lut_refraction_outside, sd->lut_refraction_outside + 128 * 128 * 32);
+    std::vector<float> li(sd->lut_refraction_inside, sd->lut_refraction_inside + 128 * 128 * 32);
+    build_emissive(c);
+    // ---- upload
+    DeviceScene& D = c->dsc;
+    int rc;
+    if ((rc = upload(c, nodes, &D.nodes))) return rc;
+    if ((rc = upload(c, leaf_tris, &D.tris))) return rc;
+    D.node_count = (uint32_t)nodes.size(); D.tri_count = (uint32_t)leaf_tris.size();
+    if ((rc = upload(c, verts, &D.vertices))) return rc;
+    if ((rc = upload(c, idx, &D.indices))) return rc;
+    if ((rc = upload(c, c->meshes, &D.meshes))) return rc;
+    if ((rc = upload(c, c->instances, &D.instances))) return rc;
+    const vpt_material* dm = nullptr;
+    if ((rc = upload(c, c->materials, &dm))) return rc;
+    D.materials = dm; c->d_materials = const_cast<vpt_material*>(dm);
+    if ((rc = upload(c, tds, &D.textures))) return rc;
+    if ((rc = upload(c, texels, &D.texels, 4))) return rc;
+    {
+        void* d = nullptr;
+        HIPCHK(c, hipMalloc(&d, sizeof(EmissiveDesc) * std::max<size_t>(1, c->instances.size())));
+        c->scene_allocs.push_back(d);
+        c->d_emissive = (EmissiveDesc*)d; D.emissive = c->d_emissive;
+    }
+    if ((rc = upload_emissive(c))) return rc;
+    if ((rc = upload(c, env, &D.env))) return rc;
+    if ((rc = upload(c, alias, &D.alias))) return rc;
+    D.env_w = sd->env_width; D.env_h = sd->env_height;
+    if ((rc = upload(c, lr, &D.lut_r))) return rc;
+    if ((rc = upload(c, lo, &D.lut_o))) return rc;
+    if ((rc = upload(c, li, &D.lut_i))) return rc;
+    // small scenes ride in LDS next to the traversal stacks
+    c->lds_scene = ((size_t)D.node_count * 64 + (size_t)D.tri_count * 48) <= 16384;
+    c->trav_blocks = traverse_blocks_per_cu(c->lds_scene, D) * c->cu_count;
+    c->has_scene = true;
+    HIPCHK(c, hipMemset(c->image, 0, (size_t)c->P.shard_pixels * 16));
+    return VPT_OK;
+}
+
+int vpt_set_material(vpt_ctx* c, uint32_t index, const vpt_material* m) {
+    if (!c || !m) return VPT_ERR_INVALID_ARGUMENT;
+    if (!c->has_scene) return fail(c, VPT_ERR_NO_SCENE, "no scene");
+    if (index >= c->materials.size()) return fail(c, VPT_ERR_INVALID_ARGUMENT, "material index out of range");
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    const vpt_material& old = c->materials[index];
+    bool emissive_changed = old.emissive_color[0] != m->emissive_color[0] || old.emissive_color[1] != m->emissive_color[1] || old.emissive_color[2] != m->emissive_color[2];
+    c->materials[index] = *m;
+    HIPCHK(c, hipMemcpy(c->d_materials + index, m, sizeof(vpt_material), hipMemcpyHostToDevice));
+    if (emissive_changed) { build_emissive(c); int rc = upload_emissive(c); if (rc) return rc; }
+    reset_accum(c);
+    return VPT_OK;
+}
+int vpt_get_material(const vpt_ctx* c, uint32_t index, vpt_material* out) {
+    if (!c || !out || index >= c->materials.size()) return VPT_ERR_INVALID_ARGUMENT;
+    *out = c->materials[index];
+    return VPT_OK;
+}
+
+int vpt_set_camera(vpt_ctx* c, const float* vi, const float* pi) {
+    if (!c || !vi || !pi) return VPT_ERR_INVALID_ARGUMENT;
+    memcpy(c->P.view_inv, vi, 64); memcpy(c->P.proj_inv, pi, 64);
+    reset_accum(c);
+    return VPT_OK;
+}
+
+int vpt_set_params(vpt_ctx* c, const vpt_params* p) {
+    if (!c || !p) return VPT_ERR_INVALID_ARGUMENT;
+    if (p->samples_per_frame == 0 || p->samples_per_frame > 0xffffffu) return fail(c, VPT_ERR_INVALID_ARGUMENT, "samples_per_frame must be >= 1");
+    if (p->screen_chunk_count != 1) return fail(c, VPT_ERR_UNSUPPORTED, "split-screen dispatch (screen_chunk_count > 1) is not implemented in the HIP backend yet");
+    if (!(p->flags & VPT_FLAG_RAY_QUERIES)) return fail(c, VPT_ERR_UNSUPPORTED, "only the USE_RAY_QUERIES semantics are implemented");
+    c->params = *p;
+    sync_params(c);
+    reset_accum(c);
+    return VPT_OK;
+}
+
+int vpt_resize(vpt_ctx* c, uint32_t w, uint32_t h) {
+    if (!c || w == 0 || h == 0) return VPT_ERR_INVALID_ARGUMENT;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    c->cfg.width = w; c->cfg.height = h;
+    reset_accum(c);
+    return alloc_render_buffers(c);
+}
+
+int vpt_reset(vpt_ctx* c) { if (!c) return VPT_ERR_INVALID_ARGUMENT; reset_accum(c); return VPT_OK; }
+
+int vpt_render(vpt_ctx* c, uint32_t dispatches, int* done) {
+    if (!c) return VPT_ERR_INVALID_ARGUMENT;
+    if (!c->has_scene) return fail(c, VPT_ERR_NO_SCENE, "vpt_render before vpt_set_scene");
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    if (done) *done = 0;
+    uint32_t left = dispatches;
+    while (left > 0) {
+        if (c->samples_accum >= c->params.max_samples) { if (done) *done = 1; break; }  // PathTracer.cpp:124-125
+        uint32_t frames_left = (c->params.max_samples - c->samples_accum + c->params.samples_per_frame - 1) / c->params.samples_per_frame;
+        uint32_t nf = std::min(std::min(left, c->frames_in_flight), frames_left);
+        int rc = render_batch(c, nf, (uint32_t)c->dispatch_count, c->frame_count);
+        if (rc) return rc;
+        c->dispatch_count += nf;                              // PathTracer.cpp:151-153 with ScreenChunkCount == 1
+        c->frame_count = (uint32_t)c->dispatch_count;
+        c->samples_accum = c->frame_count * c->params.samples_per_frame;
+        left -= nf;
+        c->full_valid = false;
+    }
+    if (done && c->samples_accum >= c->params.max_samples && left == 0) *done = c->samples_accum >= c->params.max_samples ? *done : 0;
+    return VPT_OK;
+}
+
+int vpt_get_radiance_device(vpt_ctx* c, void* dst) {
+    if (!c || !dst) return VPT_ERR_INVALID_ARGUMENT;
+    if (c->P.shard_count > 1 && !c->full_valid) return fail(c, VPT_ERR_INVALID_ARGUMENT, "sharded context: call vpt_assemble_shards first");
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    HIPCHK(c, hipMemcpyAsync(dst, whole_image(c), (size_t)c->P.width * c->P.height * 16, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return VPT_OK;
+}
+int vpt_get_radiance(vpt_ctx* c, float* dst) {
+    if (!c || !dst) return VPT_ERR_INVALID_ARGUMENT;
+    if (c->P.shard_count > 1 && !c->full_valid) return fail(c, VPT_ERR_INVALID_ARGUMENT, "sharded context: call vpt_assemble_shards first");
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    HIPCHK(c, hipMemcpy(dst, whole_image(c), (size_t)c->P.width * c->P.height * 16, hipMemcpyDeviceToHost));
+    return VPT_OK;
+}
+int vpt_set_radiance(vpt_ctx* c, const float* src, uint32_t frame_count) {
+    if (!c || !src) return VPT_ERR_INVALID_ARGUMENT;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    const uint32_t W = c->P.width;
+    if (c->P.shard_count == 1) {
+        HIPCHK(c, hipMemcpy(c->image, src, (size_t)W * c->P.height * 16, hipMemcpyHostToDevice));
+    } else {
+        HIPCHK(c, hipMemcpy(c->full_image, src, (size_t)W * c->P.height * 16, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy2D(c->image, (size_t)W * 16, src + (size_t)c->P.shard_rank * W * 4, (size_t)W * 16 * c->P.shard_count, (size_t)W * 16,
+                              c->P.shard_rows, hipMemcpyHostToDevice));
+        c->full_valid = true;
+    }
+    c->frame_count = frame_count; c->dispatch_count = frame_count; c->samples_accum = frame_count * c->params.samples_per_frame;
+    return VPT_OK;
+}
+
+size_t vpt_shard_floats(const vpt_ctx* c) {
+    if (!c) return 0;
+    uint32_t max_rows = shard_rows_of(c->P.height, 0, c->P.shard_count);
+    return (size_t)max_rows * c->P.width * 4;
+}
+int vpt_get_shard_device(vpt_ctx* c, void* dst) {
+    if (!c || !dst) return VPT_ERR_INVALID_ARGUMENT;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    size_t bytes = (size_t)c->P.shard_pixels * 16, padded = vpt_shard_floats(c) * 4;
+    HIPCHK(c, hipMemcpyAsync(dst, c->image, bytes, hipMemcpyDeviceToDevice, c->stream));
+    if (padded > bytes) HIPCHK(c, hipMemsetAsync((char*)dst + bytes, 0, padded - bytes, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return VPT_OK;
+}
+int vpt_assemble_shards(vpt_ctx* c, const void* gathered, uint32_t shard_count) {
+    if (!c || !gathered) return VPT_ERR_INVALID_ARGUMENT;
+    if (shard_count != c->P.shard_count) return fail(c, VPT_ERR_INVALID_ARGUMENT, "shard_count mismatch");
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    float* dst = c->P.shard_count > 1 ? c->full_image : c->image;
+    launch_scatter_rows(c->stream, (const float*)gathered, dst, c->P.width, c->P.height, shard_count, (uint32_t)(vpt_shard_floats(c) / 4));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipGetLastError());
+    c->full_valid = true;
+    return VPT_OK;
+}
+
+// PostProcessor::PostProcess, PostProcessor.cpp:193-246.
+int vpt_postprocess(vpt_ctx* c, const vpt_post_params* pp, uint8_t* out8, float* bloom0) {
+    if (!c || !pp || !out8) return VPT_ERR_INVALID_ARGUMENT;
+    if (c->P.shard_count > 1 && !c->full_valid) return fail(c, VPT_ERR_INVALID_ARGUMENT, "sharded context: call vpt_assemble_shards first");
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    int rc = ensure_post_buffers(c);
+    if (rc) return rc;
+    hipStream_t s = c->stream;
+    const float* hdr = whole_image(c);
+    const uint32_t W = c->P.width, H = c->P.height;
+    uint32_t mip_count = std::max(1u, std::min(pp->mip_count, (uint32_t)c->mips.size()));
+    TIMED(c, VPT_K_BLOOM, launch_bloom_threshold(s, hdr, c->mips[0], W, H, pp->bloom_threshold, pp->falloff_range));
+    for (uint32_t i = 1; i < mip_count; i++)
+        TIMED(c, VPT_K_BLOOM, launch_bloom_down(s, c->mips[i - 1], c->mip_sizes[i - 1].first, c->mip_sizes[i - 1].second, c->mips[i],
+                                                c->mip_sizes[i].first, c->mip_sizes[i].second, pp->bloom_strength));
+    for (uint32_t i = mip_count - 1; i > 0; i--)
+        TIMED(c, VPT_K_BLOOM, launch_bloom_up(s, c->mips[i], c->mip_sizes[i].first, c->mip_sizes[i].second, c->mips[i - 1],
+                                              c->mip_sizes[i - 1].first, c->mip_sizes[i - 1].second, pp->bloom_strength));
+    TIMED(c, VPT_K_TONEMAP, launch_tonemap(s, hdr, c->mips[0], c->post_out, W, H, pp->exposure, pp->gamma,
+                                           (c->params.flags & VPT_FLAG_TONEMAP_LINEAR_BLOOM_TAP) != 0));
+    HIPCHK(c, hipStreamSynchronize(s));
+    collect_timing(c);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpy(out8, c->post_out, (size_t)W * H * 4, hipMemcpyDeviceToHost));
+    if (bloom0) HIPCHK(c, hipMemcpy(bloom0, c->mips[0], (size_t)W * H * 16, hipMemcpyDeviceToHost));
+    return VPT_OK;
+}
+
+int vpt_get_stats(vpt_ctx* c, vpt_stats* out) {
+    if (!c || !out) return VPT_ERR_INVALID_ARGUMENT;
+    vpt_stats s = c->stats;
+    s.frames = c->frame_count; s.dispatches = c->dispatch_count;
+    s.total_vertex_count = c->total_vertices; s.total_index_count = c->total_indices;
+    s.bvh_nodes = c->dsc.node_count; s.bvh_triangles = c->dsc.tri_count;
+    s.bvh_node_bytes = sizeof(BvhNode); s.bvh_tri_bytes = sizeof(BvhTri);
+    s.emissive_mesh_count = (uint32_t)c->emissive.size(); s.emissive_triangle_count = c->emissive_tris;
+    s.frames_in_flight = c->frames_in_flight; s.shard_pixels = c->P.shard_pixels;
+    *out = s;
+    return VPT_OK;
+}
+int vpt_reset_stats(vpt_ctx* c) {
+    if (!c) return VPT_ERR_INVALID_ARGUMENT;
+    c->stats = vpt_stats{};
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    HIPCHK(c, hipMemset(c->ctr, 0, sizeof(Counters)));
+    return VPT_OK;
+}
+
+int vpt_trace_rays(vpt_ctx* c, const vpt_ray* rays, uint32_t n, vpt_hit* hits) {
+    if (!c || (n && (!rays || !hits))) return VPT_ERR_INVALID_ARGUMENT;
+    if (!c->has_scene) return fail(c, VPT_ERR_NO_SCENE, "no scene");
+    if (n == 0) return VPT_OK;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    vpt_ray* dr = nullptr; vpt_hit* dh = nullptr;
+    HIPCHK(c, hipMalloc((void**)&dr, (size_t)n * sizeof(vpt_ray)));
+    if (hipMalloc((void**)&dh, (size_t)n * sizeof(vpt_hit)) != hipSuccess) { (void)hipFree(dr); return fail(c, VPT_ERR_OUT_OF_MEMORY, "hipMalloc hits"); }
+    int rc = VPT_OK;
+    if (hipMemcpy(dr, rays, (size_t)n * sizeof(vpt_ray), hipMemcpyHostToDevice) != hipSuccess) rc = VPT_ERR_DEVICE;
+    if (!rc) {
+        launch_trace_rays(c->stream, c->dsc, dr, n, dh);
+        if (hipStreamSynchronize(c->stream) != hipSuccess || hipGetLastError() != hipSuccess) rc = VPT_ERR_DEVICE;
+    }
+    if (!rc && hipMemcpy(hits, dh, (size_t)n * sizeof(vpt_hit), hipMemcpyDeviceToHost) != hipSuccess) rc = VPT_ERR_DEVICE;
+    (void)hipFree(dr); (void)hipFree(dh);
+    if (rc) c->err = "vpt_trace_rays: device error";
+    return rc;
+}
+
+}  // extern "C"
