@@ -1,0 +1,204 @@
+#!/usr/bin/env python
+"""bench.py — Msamples/s of the wavefront path tracer on BASELINE.json's metric config.
+
+Workload (config.workload = "cornell_1080p_d8"): BASELINE.json configs[1] — Assets/CornellBox as shipped
+(diffuse walls + emissive quad, strength 50), black environment, 1920x1080, max depth 8, 1 sample per
+pixel per frame, base seed 1.  A *step* is one wavefront batch of the hot path:
+every rank renders `frames_per_step` consecutive frames of its own rows (raygen -> [extend, shade,
+shadow, accumulate] until the ray queue is empty -> resolve).  Rows are dealt round-robin over ranks, each
+rank keeps ~4M paths resident, so per-GPU work per step is fixed (weak scaling) and
+
+    value = (samples all ranks traced in the K timed steps) / (max over ranks of the wall time)
+
+with scene, BVH, path state and accumulation image resident in HBM before the timed region.  The timed
+region ends with the single collective of the path: one gather of the finished row shards (RCCL, backend
+"nccl") and the row re-interleave on rank 0.
+
+Extra JSON objects (see DESIGN.md §6 for the byte accounting):
+  roofline     — for the kernel with the largest share of GPU time in the timed region: algorithmic HBM
+                 bytes per launch / mean launch duration (HIP events recorded by the library on the stream
+                 it launches on), against the 8 TB/s HBM3E peak.  `kernels` lists every stage.
+  cpu_baseline — the CPU oracle (oracle/, a port of the reference shaders; the reference has no CPU path)
+                 on this box's host cores, on a bounded sample of the same workload.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 GB/s measured copy
+WIDTH, HEIGHT, MAX_DEPTH, BASE_SEED = 1920, 1080, 8, 1
+
+# Algorithmic bytes per unit for each stage: state words actually read/written per path or
+# ray by the algorithm with this build's struct sizes; BVH node/triangle visits are measured, not assumed.
+NODE_BYTES, TRI_BYTES = 64, 48
+EXTEND_FIXED = 4 + 24 + 20          # queue id, origin+direction in, hit record out
+SHADOW_FIXED = 32 + 4               # compacted shadow ray in, visibility word out
+SHADE_FIXED = (4 + 4 + 24 + 4 + 4 + 20 + 4) + (4 + 24 + 12 + 4 + 4 + 4 + 36 + 4)   # path state in / out
+SHADE_SCENE = 8 + 48 + 36 + 12 + 96 + 112 + 5 * 4 + (8 + 64) + (80 + 12 + 96 + 12 + 4) + 2 * 16  # instance, indices, 3 vertices, material, 5 1x1 texels, env alias+4 texels, light mesh entry+triangle, 2 LUT taps
+SHADE_SHADOW_OUT = 32               # per shadow ray emitted
+ACCUM_BYTES = (4 + 4 + 36 + 12 + 12 + 4 + 12 + 4 + 4) + (12 + 12 + 4 + 4)
+RAYGEN_BYTES = 4 * 22               # path state initialised per slot
+RESOLVE_BYTES = 12 + 32             # per (pixel, frame) sample sum in, plus image read+write amortised per frame
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=48)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the oracle sample")
+    return ap.parse_args()
+
+
+def cpu_baseline(vpt, scene, seconds):
+    """Oracle on the host cores: bounded sample of the same workload (whole 1080p frames, depth 8)."""
+    from oracle import oracle_py
+    cores = os.cpu_count() or 1
+    o = oracle_py.Oracle(scene, WIDTH, HEIGHT, threads=cores)
+    o.set_params(vpt.default_params(max_depth=MAX_DEPTH, base_seed=BASE_SEED))
+    t0 = time.perf_counter()
+    o.render(1)
+    t1 = time.perf_counter() - t0
+    frames = max(1, min(32, int(seconds / max(t1, 1e-3)) - 1))
+    t0 = time.perf_counter()
+    o.render(frames)
+    dt = time.perf_counter() - t0
+    c = o.counters()
+    o.close()
+    return {"value": round(WIDTH * HEIGHT * frames / dt / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "sample": "%d full 1920x1080 frames (1 spp each, depth %d) of the same Cornell workload, OpenMP over rows" % (frames, MAX_DEPTH),
+            "mrays_per_s": round((c["closest"] + c["shadow"]) * frames / (frames + 1) / dt / 1e6, 3)}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the backend has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    vpt = importlib.import_module("vulkan-path-tracer_amd")
+    sharding = importlib.import_module("vulkan-path-tracer_amd.sharding")
+    scene = vpt.scenes.Scene.load(os.path.join(ROOT, "tests", "golden", "cornell_box.npz"))
+    params = vpt.default_params(max_depth=MAX_DEPTH, base_seed=BASE_SEED, max_samples=0x7fffffff)
+
+    # traversal visit counts (algorithmic bytes of extend / shadow) from a short counting pass
+    cnt = vpt.PathTracer(WIDTH, HEIGHT, device=local_rank, shard_rank=rank, shard_count=world, count_traversal=True)
+    cnt.set_scene(scene); cnt.set_params(params); cnt.render(2)
+    cs = cnt.stats(); cnt.close()
+    nodes_per_ray = cs["nodes_visited"] / max(cs["closest_rays"], 1)
+    tris_per_ray = cs["tris_tested"] / max(cs["closest_rays"], 1)
+    snodes_per_ray = cs["shadow_nodes_visited"] / max(cs["shadow_rays"], 1)
+    stris_per_ray = cs["shadow_tris_tested"] / max(cs["shadow_rays"], 1)
+
+    pt = vpt.PathTracer(WIDTH, HEIGHT, device=local_rank, shard_rank=rank, shard_count=world, profile=True)
+    pt.set_scene(scene); pt.set_params(params)
+    F = pt.stats()["frames_in_flight"]
+    shard = torch.empty(pt.shard_floats(), dtype=torch.float32, device="cuda")
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        pt.render(F)
+    if world > 1:  # warm the communicator outside the timed region
+        pt.shard_to_device(shard.data_ptr())
+        sharding.gather_shards(shard, world)
+    pt.reset_stats()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pt.render(F)
+    pt.shard_to_device(shard.data_ptr())
+    gathered = sharding.gather_shards(shard, world)
+    if rank == 0:
+        pt.assemble_shards(gathered.data_ptr(), world)
+    sync()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    st = pt.stats()
+    local_samples = st["samples"]
+    tot = torch.tensor([float(local_samples), float(st["closest_rays"]), float(st["shadow_rays"])], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    samples, closest, shadow = (float(x) for x in tot.tolist())
+
+    if rank == 0:
+        # ---- per-kernel algorithmic bytes / measured HIP-event time (this rank's launches)
+        n_paths = st["closest_rays"]          # path-bounces shaded == rays extended
+        units = {
+            "raygen": (st["samples"], RAYGEN_BYTES),
+            "extend": (st["closest_rays"], EXTEND_FIXED + nodes_per_ray * NODE_BYTES + tris_per_ray * TRI_BYTES),
+            "shade": (n_paths, SHADE_FIXED + SHADE_SCENE + SHADE_SHADOW_OUT * st["shadow_rays"] / max(n_paths, 1)),
+            "shadow": (st["shadow_rays"], SHADOW_FIXED + snodes_per_ray * NODE_BYTES + stris_per_ray * TRI_BYTES),
+            "accumulate": (n_paths, ACCUM_BYTES),
+            "resolve": (st["samples"], RESOLVE_BYTES),
+        }
+        kernels = {}
+        for name, (n, bpu) in units.items():
+            ms, launches = st["kernel_ms"][name], st["kernel_launches"][name]
+            if launches == 0 or ms <= 0:
+                continue
+            kernels[name] = {"launches": launches, "avg_ms": round(ms / launches, 5), "share": 0.0,
+                             "bytes_per_unit": round(bpu, 1), "units_per_launch": round(n / launches, 1),
+                             "achieved_GBs": round(n * bpu / (ms * 1e-3) / 1e9, 2)}
+        tot_ms = sum(st["kernel_ms"][k] for k in kernels)
+        for k in kernels:
+            kernels[k]["share"] = round(st["kernel_ms"][k] / tot_ms, 4)
+        dom = max(kernels, key=lambda k: kernels[k]["share"])
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")   # written from rocprofv3 --pmc passes (see profiles/README.md)
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(dom, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roof = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(kernels[dom]["achieved_GBs"] / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "avg_launch_ms": kernels[dom]["avg_ms"],
+                "algorithmic_bytes_per_launch": round(kernels[dom]["bytes_per_unit"] * kernels[dom]["units_per_launch"], 0),
+                "traversal": {"nodes_per_closest_ray": round(nodes_per_ray, 3), "tris_per_closest_ray": round(tris_per_ray, 3),
+                              "nodes_per_shadow_ray": round(snodes_per_ray, 3), "tris_per_shadow_ray": round(stris_per_ray, 3)},
+                "kernels": kernels}
+        line = {
+            "metric": "Msamples/s at 1920x1080", "value": round(samples / dt / 1e6, 3), "unit": "Msamples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "cornell_1080p_d8", "scene": "CornellBox (12 triangles, emissive quad 50), black env",
+                       "width": WIDTH, "height": HEIGHT, "max_depth": MAX_DEPTH, "samples_per_frame": 1,
+                       "frames_per_step_per_gpu": F, "paths_in_flight_per_gpu": st["shard_pixels"] * F,
+                       "partition": "rows y % N == rank, one gather at the end", "base_seed": BASE_SEED},
+            "mrays_per_s": round((closest + shadow) / dt / 1e6, 2),
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(vpt, scene, args.cpu_seconds)
+        print(json.dumps(line), flush=True)
+    pt.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -186,8 +186,10 @@ typedef struct vpt_stats {
     uint64_t dispatches;       /* m_DispatchCount */
     uint64_t closest_rays;     /* rays traced by the extend kernel */
     uint64_t shadow_rays;      /* rays traced by the shadow kernel */
-    uint64_t nodes_visited;    /* only when count_traversal */
-    uint64_t tris_tested;      /* only when count_traversal */
+    uint64_t nodes_visited;    /* extend kernel, only when count_traversal */
+    uint64_t tris_tested;      /* extend kernel, only when count_traversal */
+    uint64_t shadow_nodes_visited; /* shadow kernel, only when count_traversal */
+    uint64_t shadow_tris_tested;   /* shadow kernel, only when count_traversal */
     uint64_t kernel_launches[VPT_KERNEL_COUNT];
     double kernel_ms[VPT_KERNEL_COUNT]; /* only when profile */
     uint64_t total_vertex_count; /* GetTotalVertexCount */

@@ -1,0 +1,73 @@
+"""N > 1 host path on CPU: world_size-2 gloo run of the shard -> gather -> assemble logic bench.py uses."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, w, h, out_path):
+    sys.path.insert(0, ROOT)
+    import importlib
+    sharding = importlib.import_module("vulkan-path-tracer_amd.sharding")
+    vpt = importlib.import_module("vulkan-path-tracer_amd")
+    from oracle import oracle_py
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # every rank renders the same deterministic image with the oracle and keeps only its own rows,
+    # exactly the rows a sharded HIP context would own
+    sc = vpt.scenes.Scene.load(os.path.join(ROOT, "tests", "golden", "cornell_box.npz"))
+    o = oracle_py.Oracle(sc, w, h, threads=1)
+    o.set_params(vpt.default_params(max_depth=3))
+    o.render(2)
+    full = torch.from_numpy(o.radiance())
+    o.close()
+    local = sharding.extract_rows(full, rank, world)
+    assert local.numel() == sharding.shard_floats(w, h, world)
+    gathered = sharding.gather_shards(local, world)
+    img = sharding.assemble_rows(gathered, w, h, world)
+    t = torch.tensor([float(rank + 1)])
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)  # bench.py's max-over-ranks timing reduction
+    if rank == 0:
+        np.save(out_path, np.stack([img.numpy(), full.numpy()]))
+        assert t.item() == world
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("w,h", [(24, 13), (16, 8)])
+def test_gloo_world2_gather_assemble(tmp_path, w, h):
+    out = str(tmp_path / "img.npy")
+    mp.spawn(_worker, args=(2, _free_port(), w, h, out), nprocs=2, join=True)
+    img, full = np.load(out)
+    assert np.array_equal(img, full)
+
+
+def test_shard_arithmetic():
+    import importlib
+    sys.path.insert(0, ROOT)
+    sharding = importlib.import_module("vulkan-path-tracer_amd.sharding")
+    for h in (1080, 2160, 37, 7):
+        for world in (1, 2, 3, 4, 8):
+            rows = [sharding.shard_rows(h, r, world) for r in range(world)]
+            assert sum(rows) == h and max(rows) == rows[0]
+            assert sharding.shard_floats(10, h, world) == rows[0] * 40
+    assert [sharding.shard_rows(1080, r, 8) for r in range(8)] == [135] * 8   # 1080p splits evenly over 8 GPUs
+    full = torch.arange(5 * 3 * 4, dtype=torch.float32).reshape(5, 3, 4)
+    g = torch.stack([sharding.extract_rows(full, r, 2) for r in range(2)])
+    assert torch.equal(sharding.assemble_rows(g, 3, 5, 2), full)

@@ -1,0 +1,66 @@
+"""The extend kernel alone (vpt_trace_rays) against the oracle's brute-force closest hit: (t,u,v) bit-exact,
+primitive/instance identical, ties and degenerate rays included."""
+import numpy as np
+import pytest
+
+from test_oracle_kat import random_rays
+
+pytestmark = pytest.mark.gpu
+
+
+def compare(vpt, oracle, sc, rays):
+    o = oracle.Oracle(sc, 8, 8)
+    o.set_brute_force(True)
+    ref = o.trace_rays(rays)
+    o.close()
+    g = vpt.PathTracer(8, 8)
+    g.set_scene(sc)
+    got = g.trace_rays(rays)
+    st = g.stats()
+    g.close()
+    for k in ("t", "u", "v", "primitive", "instance"):
+        assert np.array_equal(got[k], ref[k]), k
+    return ref, st
+
+
+@pytest.mark.parametrize("name,scale,n", [("cornell_box", 8.0, 400000), ("cornell_box_glass", 8.0, 200000), ("viking_room", 2.0, 60000)])
+def test_random_rays(vpt, oracle, scenes, name, scale, n):
+    ref, st = compare(vpt, oracle, scenes(name), random_rays(n, 5, scale))
+    assert (ref["t"] >= 0).mean() > 0.05
+    assert st["bvh_triangles"] == scenes(name).triangle_count()
+    assert st["bvh_node_bytes"] == 64 and st["bvh_tri_bytes"] == 48
+
+
+def test_axis_aligned_and_degenerate_rays(vpt, oracle, scenes):
+    """Zero direction components (0 * inf in slab tests), origins on walls, rays along box edges."""
+    sc = scenes("cornell_box")
+    rays = []
+    for ax in range(3):
+        for sgn in (-1.0, 1.0):
+            for ox in np.linspace(-6, 6, 25):
+                for oy in np.linspace(-6, 6, 25):
+                    o = [ox, oy, -5.8]
+                    d = [0.0, 0.0, 0.0]
+                    d[ax] = sgn
+                    rays.append(o + [1e-4] + d + [1e6])
+    rays = np.array(rays, np.float32)
+    # exact wall coordinates as origins (coplanar rays) and exact corner directions
+    extra = rays.copy()
+    extra[:, 0] = np.float32(5.709264755249023)
+    compare(vpt, oracle, sc, np.concatenate([rays, extra]))
+
+
+def test_tmin_tmax_window(vpt, oracle, scenes):
+    rays = random_rays(50000, 8, 6.0)
+    rays[:, 3] = 2.0   # tmin beyond near hits
+    rays[:, 7] = 9.0   # tmax before far hits
+    ref, _ = compare(vpt, oracle, scenes("cornell_box_glass"), rays)
+    hit = ref["t"] >= 0
+    assert hit.any() and (ref["t"][hit] > 2.0).all() and (ref["t"][hit] < 9.0).all()
+
+
+def test_empty_ray_list(vpt, scenes):
+    g = vpt.PathTracer(8, 8)
+    g.set_scene(scenes("cornell_box"))
+    assert len(g.trace_rays(np.zeros((0, 8), np.float32))) == 0
+    g.close()

@@ -25,7 +25,7 @@ def library_path():
 
 
 def build(force=False, verbose=False):
-    from . import build as _b
+    from . import _build as _b
     return _b.build(force=force, verbose=verbose)
 
 

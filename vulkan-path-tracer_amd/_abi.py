@@ -106,6 +106,7 @@ class Stats(C.Structure):
     _fields_ = [
         ("samples", C.c_uint64), ("frames", C.c_uint64), ("dispatches", C.c_uint64), ("closest_rays", C.c_uint64),
         ("shadow_rays", C.c_uint64), ("nodes_visited", C.c_uint64), ("tris_tested", C.c_uint64),
+        ("shadow_nodes_visited", C.c_uint64), ("shadow_tris_tested", C.c_uint64),
         ("kernel_launches", C.c_uint64 * KERNEL_COUNT), ("kernel_ms", C.c_double * KERNEL_COUNT),
         ("total_vertex_count", C.c_uint64), ("total_index_count", C.c_uint64),
         ("bvh_nodes", C.c_uint32), ("bvh_triangles", C.c_uint32), ("bvh_node_bytes", C.c_uint32),

@@ -128,7 +128,9 @@ struct Counters {
     uint32_t shadow_count;
     uint32_t extend_head, shadow_head;  // persistent-kernel work cursors
     uint32_t pad[3];
-    unsigned long long stat_closest, stat_shadow, stat_nodes, stat_tris, stat_samples;
+    unsigned long long stat_nodes, stat_tris;          // extend kernel (count_traversal builds only)
+    unsigned long long stat_shadow_nodes, stat_shadow_tris;  // shadow kernel
+    unsigned long long stat_pad;
 };
 
 }  // namespace vpt

@@ -139,8 +139,8 @@ __global__ __launch_bounds__(kTraverseBlock) void k_shadow(DeviceScene sc, PathS
         }
     }
     if (COUNT) {
-        atomicAdd(&ctr->stat_nodes, (unsigned long long)st.nodes);
-        atomicAdd(&ctr->stat_tris, (unsigned long long)st.tris);
+        atomicAdd(&ctr->stat_shadow_nodes, (unsigned long long)st.nodes);
+        atomicAdd(&ctr->stat_shadow_tris, (unsigned long long)st.tris);
     }
 }
 

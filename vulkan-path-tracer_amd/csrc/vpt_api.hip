@@ -292,6 +292,8 @@ int render_batch(vpt_ctx* c, uint32_t frames, uint32_t dispatch_base, uint32_t f
         c->stats.shadow_rays += h.shadow_count;
         c->stats.nodes_visited = h.stat_nodes;
         c->stats.tris_tested = h.stat_tris;
+        c->stats.shadow_nodes_visited = h.stat_shadow_nodes;
+        c->stats.shadow_tris_tested = h.stat_shadow_tris;
         parity ^= 1u;
         n = h.ray_count[parity];
         if (n > n_slots) return fail(c, VPT_ERR_DEVICE, "internal: queue overflow");
