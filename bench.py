@@ -38,13 +38,16 @@ WIDTH, HEIGHT, MAX_DEPTH, BASE_SEED = 1920, 1080, 8, 1
 # ray by the algorithm with this build's struct sizes; BVH node/triangle visits are measured, not assumed.
 NODE_BYTES, TRI_BYTES = 64, 48
 EXTEND_FIXED = 4 + 24 + 20          # queue id, origin+direction in, hit record out
-SHADOW_FIXED = 32 + 4               # compacted shadow ray in, visibility word out
-SHADE_FIXED = (4 + 4 + 24 + 4 + 4 + 20 + 4) + (4 + 24 + 12 + 4 + 4 + 4 + 36 + 4)   # path state in / out
-SHADE_SCENE = 8 + 48 + 36 + 12 + 96 + 112 + 5 * 4 + (8 + 64) + (80 + 12 + 96 + 12 + 4) + 2 * 16  # instance, indices, 3 vertices, material, 5 1x1 texels, env alias+4 texels, light mesh entry+triangle, 2 LUT taps
-SHADE_SHADOW_OUT = 32               # per shadow ray emitted
-ACCUM_BYTES = (4 + 4 + 36 + 12 + 12 + 4 + 12 + 4 + 4) + (12 + 12 + 4 + 4)
-RAYGEN_BYTES = 4 * 22               # path state initialised per slot
-RESOLVE_BYTES = 12 + 32             # per (pixel, frame) sample sum in, plus image read+write amortised per frame
+SHADE_IN = 4 + 16 + 16 + 16 + 20    # queue id, records A (origin|rng), B (dir|depth), T (throughput|pdf), hit record
+SHADE_ALIVE_OUT = 16 + 16 + 16 + 4  # A, B, T of the surviving path + next-queue id
+SHADE_PENDING_OUT = 16 + 4          # CE (emission|flags) + connect-queue id
+SHADE_RAY_OUT = 48                  # contribution|gid, origin|dir.x, dir.yz per queued shadow ray
+SHADE_SCENE = 8 + 48 + 36 + 12 + 96 + 112 + 5 * 4 + (8 + 64) + (80 + 12 + 96 + 12 + 4) + 2 * 16  # instance, indices, 3 vertices, material, 5 1x1 texels, env alias + 4 texels, light entry + triangle, 2 LUT taps
+CONNECT_FIXED = 4 + 16 + 16 + 16 + 16   # queue id, CE, T (pre-update throughput), pathLight read + write
+CONNECT_RAY = 48                    # per shadow ray: the three records shade queued
+CONNECT_FINAL = 32                  # frame-sum read + write at the end of a sample
+RAYGEN_BYTES = 16 * 5 + 4           # records A, B, T, L, ACC + queue id
+RESOLVE_BYTES = 16 + 32             # per (pixel, frame) sum in, plus image read+write (amortised over the frames of a batch)
 
 
 def parse():
@@ -53,6 +56,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=48)
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--frames-in-flight", type=int, default=0, help="frames per step per GPU (0 = backend default, ~4M resident paths)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the oracle sample")
     return ap.parse_args()
 
@@ -106,7 +110,8 @@ def main():
     snodes_per_ray = cs["shadow_nodes_visited"] / max(cs["shadow_rays"], 1)
     stris_per_ray = cs["shadow_tris_tested"] / max(cs["shadow_rays"], 1)
 
-    pt = vpt.PathTracer(WIDTH, HEIGHT, device=local_rank, shard_rank=rank, shard_count=world, profile=True)
+    pt = vpt.PathTracer(WIDTH, HEIGHT, device=local_rank, shard_rank=rank, shard_count=world, profile=True,
+                        frames_in_flight=args.frames_in_flight)
     pt.set_scene(scene); pt.set_params(params)
     F = pt.stats()["frames_in_flight"]
     shard = torch.empty(pt.shard_floats(), dtype=torch.float32, device="cuda")
@@ -146,12 +151,14 @@ def main():
     if rank == 0:
         # ---- per-kernel algorithmic bytes / measured HIP-event time (this rank's launches)
         n_paths = st["closest_rays"]          # path-bounces shaded == rays extended
+        alive_frac = 1.0 - st["samples"] / max(n_paths, 1)      # every sample ends exactly once
         units = {
             "raygen": (st["samples"], RAYGEN_BYTES),
-            "extend": (st["closest_rays"], EXTEND_FIXED + nodes_per_ray * NODE_BYTES + tris_per_ray * TRI_BYTES),
-            "shade": (n_paths, SHADE_FIXED + SHADE_SCENE + SHADE_SHADOW_OUT * st["shadow_rays"] / max(n_paths, 1)),
-            "shadow": (st["shadow_rays"], SHADOW_FIXED + snodes_per_ray * NODE_BYTES + stris_per_ray * TRI_BYTES),
-            "accumulate": (n_paths, ACCUM_BYTES),
+            "extend": (n_paths, EXTEND_FIXED + nodes_per_ray * NODE_BYTES + tris_per_ray * TRI_BYTES),
+            "shade": (n_paths, SHADE_IN + SHADE_SCENE + SHADE_ALIVE_OUT * alive_frac + SHADE_PENDING_OUT * st["connect_paths"] / max(n_paths, 1)
+                      + SHADE_RAY_OUT * st["shadow_rays"] / max(n_paths, 1)),
+            "connect": (st["connect_paths"], CONNECT_FIXED + CONNECT_FINAL * st["samples"] / max(st["connect_paths"], 1)
+                        + (CONNECT_RAY + snodes_per_ray * NODE_BYTES + stris_per_ray * TRI_BYTES) * st["shadow_rays"] / max(st["connect_paths"], 1)),
             "resolve": (st["samples"], RESOLVE_BYTES),
         }
         kernels = {}

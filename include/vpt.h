@@ -163,7 +163,7 @@ typedef struct vpt_config {
     uint32_t height;
     uint32_t shard_rank; /* this context renders rows y with y % shard_count == shard_rank */
     uint32_t shard_count;/* 1 = whole image */
-    uint32_t frames_in_flight; /* 0 = choose so that ~4M paths are resident */
+    uint32_t frames_in_flight; /* 0 = choose so that ~32M paths are resident (at most 64 frames) */
     uint32_t profile;    /* 1 = bracket every kernel launch with hipEvents (vpt_get_stats kernel times) */
     uint32_t count_traversal; /* 1 = count BVH node/triangle visits (slower; for the roofline's algorithmic bytes) */
 } vpt_config;
@@ -173,8 +173,8 @@ enum vpt_kernel_id {
     VPT_K_RAYGEN = 0,
     VPT_K_EXTEND = 1,
     VPT_K_SHADE = 2,
-    VPT_K_SHADOW = 3,
-    VPT_K_ACCUMULATE = 4,
+    VPT_K_CONNECT = 3,  /* shadow rays + light accumulation + end-of-sample */
+    VPT_K_RESERVED = 4,
     VPT_K_RESOLVE = 5,
     VPT_K_BLOOM = 6,
     VPT_K_TONEMAP = 7
@@ -185,11 +185,12 @@ typedef struct vpt_stats {
     uint64_t frames;           /* m_FrameCount */
     uint64_t dispatches;       /* m_DispatchCount */
     uint64_t closest_rays;     /* rays traced by the extend kernel */
-    uint64_t shadow_rays;      /* rays traced by the shadow kernel */
+    uint64_t shadow_rays;      /* rays traced by the connect kernel */
+    uint64_t connect_paths;    /* path-bounces that went through the connect kernel */
     uint64_t nodes_visited;    /* extend kernel, only when count_traversal */
     uint64_t tris_tested;      /* extend kernel, only when count_traversal */
-    uint64_t shadow_nodes_visited; /* shadow kernel, only when count_traversal */
-    uint64_t shadow_tris_tested;   /* shadow kernel, only when count_traversal */
+    uint64_t shadow_nodes_visited; /* connect kernel, only when count_traversal */
+    uint64_t shadow_tris_tested;   /* connect kernel, only when count_traversal */
     uint64_t kernel_launches[VPT_KERNEL_COUNT];
     double kernel_ms[VPT_KERNEL_COUNT]; /* only when profile */
     uint64_t total_vertex_count; /* GetTotalVertexCount */

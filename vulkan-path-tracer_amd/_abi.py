@@ -18,7 +18,7 @@ FLAG_TONEMAP_LINEAR_BLOOM_TAP = 1 << 7
 FLAGS_DEFAULT = (FLAG_SKY_MIS | FLAG_MESH_MIS | FLAG_SHOW_ENV_DIRECTLY | FLAG_ENERGY_COMPENSATION |
                  FLAG_RAY_QUERIES | FLAG_TONEMAP_LINEAR_BLOOM_TAP)
 
-KERNEL_NAMES = ["raygen", "extend", "shade", "shadow", "accumulate", "resolve", "bloom", "tonemap"]
+KERNEL_NAMES = ["raygen", "extend", "shade", "connect", "reserved", "resolve", "bloom", "tonemap"]
 KERNEL_COUNT = 8
 
 
@@ -105,7 +105,7 @@ class Config(C.Structure):
 class Stats(C.Structure):
     _fields_ = [
         ("samples", C.c_uint64), ("frames", C.c_uint64), ("dispatches", C.c_uint64), ("closest_rays", C.c_uint64),
-        ("shadow_rays", C.c_uint64), ("nodes_visited", C.c_uint64), ("tris_tested", C.c_uint64),
+        ("shadow_rays", C.c_uint64), ("connect_paths", C.c_uint64), ("nodes_visited", C.c_uint64), ("tris_tested", C.c_uint64),
         ("shadow_nodes_visited", C.c_uint64), ("shadow_tris_tested", C.c_uint64),
         ("kernel_launches", C.c_uint64 * KERNEL_COUNT), ("kernel_ms", C.c_double * KERNEL_COUNT),
         ("total_vertex_count", C.c_uint64), ("total_index_count", C.c_uint64),

@@ -86,51 +86,46 @@ struct RenderParams {
     uint32_t flags, base_seed;
 };
 
-// ---- Wavefront path state, structure-of-arrays over `capacity` slots
-// (slot = frame_in_flight * shard_pixels + shard_pixel).  All arrays are indexed by slot so a path
-// never moves; queues hold slot ids.
+// ---- Wavefront path state: 16-byte records per slot (slot = frame_in_flight * shard_pixels +
+// shard_pixel).  A path never moves; queues hold slot ids, so results cannot depend on queue order.
+// Records are grouped by which stage touches them, so every access is one dwordx4 per lane: after
+// compaction neighbouring lanes hold non-adjacent slots, and a 16 B record uses a fetched sector 4x
+// better than 4 B structure-of-arrays gathers (and needs a quarter of the memory instructions).
 struct PathState {
     uint32_t capacity;
-    // payload (RTCommon.slang:5-35, surface subset) + raygen locals
-    uint32_t* rng;
-    float *ox, *oy, *oz;     // payload.Origin
-    float *dx, *dy, *dz;     // payload.Direction
-    float *tx, *ty, *tz;     // pathThroughput
-    float *lx, *ly, *lz;     // pathLight
-    float *bx, *by, *bz;     // payload.BxDF
-    float* pdf;              // payload.PDF
-    uint32_t* depth;         // payload.Depth
-    uint32_t* medium_flag;   // payload.InMedium (bit 0) | sample index within the frame << 8
-    float *mdensity, *maniso, *mcr, *mcg, *mcb;  // medium state
-    // hit record written by extend (20 B)
-    float *ht, *hu, *hv;
-    uint32_t *hprim, *hinst;
-    // pending contributions of the current bounce, joined in accumulate before the luminance clamp
-    float *ex, *ey, *ez;     // emission / miss radiance
-    float *skx, *sky, *skz;  // sky NEE contribution (if visible)
-    float *lgx, *lgy, *lgz;  // light NEE contribution (if visible)
-    uint32_t* vis;           // bit0 sky ray unoccluded, bit1 light ray reached the sampled triangle
-    // per-slot sum over the samples of the frame (accumulatedLight)
-    float *ax, *ay, *az;
+    float4* A;       // payload.Origin.xyz | RNG state                        extend R, shade RW
+    float4* B;       // payload.Direction.xyz | payload.Depth, bit31 = InMedium extend R, shade RW
+    float4* T[2];    // pathThroughput.xyz | payload.PDF   ping-pong by bounce parity: shade(k) reads
+                     // T[k&1] and writes T[(k+1)&1]; connect(k) still finds the pre-update throughput in T[k&1]
+    float4* H;       // hit record t,u,v | PrimitiveIndex                      extend W, shade R
+    uint32_t* hinst; // hit record InstanceIndex
+    float4* CE;      // pending: emission / miss radiance .xyz | connect flags shade W, connect R
+    float4* CS;      // pending: sky NEE contribution .xyz                     (only when a sky ray is queued)
+    float4* CSO;     //          sky ray origin.xyz | dir.x
+    float4* CSD;     //          sky ray dir.yz
+    float4* CL;      // pending: light NEE contribution .xyz | global id of the sampled triangle
+    float4* CLO;     //          light ray origin.xyz | dir.x
+    float4* CLD;     //          light ray dir.yz
+    float4* L;       // pathLight.xyz                                          connect RW
+    float4* ACC;     // accumulatedLight of the frame (sum over samples_per_frame)  connect RW at path end
+    float4* M;       // medium colour.rgb | density (only glass)               shade RW when refracting
+    float* maniso;   // medium anisotropy
+    uint32_t* sidx;  // sample index within the frame (samples_per_frame > 1 only)
 };
 
-// Compacted shadow ray, 32 B: one coalesced dwordx4 pair per lane.
-struct ShadowRay {
-    float ox, oy, oz;
-    uint32_t slot_kind;  // slot | kind<<31 (0 sky, 1 light)
-    float dx, dy, dz;
-    uint32_t expect_gid;  // light: global id of the sampled triangle
-};
-static_assert(sizeof(ShadowRay) == 32, "shadow ray is 32 B");
+// connect flags (CE.w)
+constexpr uint32_t kCF_Sky = 1u, kCF_Light = 2u, kCF_Finalize = 4u, kCF_Clamp = 8u;
 
 struct Counters {
-    uint32_t ray_count[2];   // active-path queue sizes (ping-pong)
-    uint32_t shadow_count;
-    uint32_t extend_head, shadow_head;  // persistent-kernel work cursors
-    uint32_t pad[3];
-    unsigned long long stat_nodes, stat_tris;          // extend kernel (count_traversal builds only)
-    unsigned long long stat_shadow_nodes, stat_shadow_tris;  // shadow kernel
-    unsigned long long stat_pad;
+    uint32_t ray_count[2];    // active-path queue sizes (ping-pong by bounce parity)
+    uint32_t connect_front;   // connect queue: entries with shadow rays grow from the front,
+    uint32_t connect_back;    //                emission/finalize-only entries from the back
+    uint32_t extend_head, connect_head;  // persistent-kernel work cursors
+    uint32_t shadow_rays;     // shadow rays queued by shade this bounce
+    uint32_t pad;
+    unsigned long long stat_closest, stat_shadow, stat_connect;  // folded per bounce by k_prepare / k_fold
+    unsigned long long stat_nodes, stat_tris;                // extend kernel (count_traversal builds only)
+    unsigned long long stat_shadow_nodes, stat_shadow_tris;  // connect kernel
 };
 
 }  // namespace vpt

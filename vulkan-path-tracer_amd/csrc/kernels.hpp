@@ -6,19 +6,19 @@ namespace vpt {
 
 void launch_raygen(hipStream_t s, const RenderParams& P, const PathState& ps, uint32_t* queue, uint32_t n_slots, uint32_t dispatch_base);
 void launch_prepare(hipStream_t s, Counters* ctr, uint32_t parity);
+void launch_fold(hipStream_t s, Counters* ctr);
 void launch_extend(hipStream_t s, uint32_t blocks, bool lds_scene, bool count, const DeviceScene& sc, const PathState& ps,
                    const uint32_t* queue, Counters* ctr, uint32_t parity);
-void launch_shadow(hipStream_t s, uint32_t blocks, bool lds_scene, bool count, const DeviceScene& sc, const PathState& ps,
-                   const ShadowRay* rays, Counters* ctr);
-void launch_shade(hipStream_t s, uint32_t n_upper, const DeviceScene& sc, const RenderParams& P, const PathState& ps,
-                  const uint32_t* queue, ShadowRay* shadow, Counters* ctr, uint32_t parity);
-void launch_accumulate(hipStream_t s, uint32_t n_upper, const RenderParams& P, const PathState& ps, const uint32_t* qin,
-                       uint32_t* qout, Counters* ctr, uint32_t parity);
+void launch_shade(hipStream_t s, uint32_t blocks, const DeviceScene& sc, const RenderParams& P, const PathState& ps,
+                  const uint32_t* queue, uint32_t* queue_next, uint32_t* cqueue, Counters* ctr, uint32_t parity);
+void launch_connect(hipStream_t s, uint32_t blocks, bool lds_scene, bool count, const DeviceScene& sc, const RenderParams& P,
+                    const PathState& ps, const uint32_t* cqueue, Counters* ctr, uint32_t parity);
 void launch_resolve(hipStream_t s, const RenderParams& P, const PathState& ps, float* image, uint32_t frames, uint32_t frame_base);
 void launch_trace_rays(hipStream_t s, const DeviceScene& sc, const vpt_ray* rays, uint32_t n, vpt_hit* hits);
 void launch_scatter_rows(hipStream_t s, const float* gathered, float* full, uint32_t w, uint32_t h, uint32_t shard_count, uint32_t stride_px);
 size_t traverse_lds_bytes(const DeviceScene& sc, bool lds_scene);
 int traverse_blocks_per_cu(bool lds_scene, const DeviceScene& sc);
+int shade_blocks_per_cu();
 
 // post-process chain (kernels_post.hip)
 void launch_bloom_threshold(hipStream_t s, const float* in, float* out, uint32_t w, uint32_t h, float threshold, float falloff);

@@ -33,33 +33,46 @@ __device__ inline uint32_t wave_append(bool pred, uint32_t* counter) {
     return base + lanes_below(mask);
 }
 
+// ------------------------------------------------------------------ small helpers
+__device__ inline float4 f4(V3 v, float w) { return make_float4(v.x, v.y, v.z, w); }
+__device__ inline float4 f4u(V3 v, uint32_t w) { return make_float4(v.x, v.y, v.z, __uint_as_float(w)); }
+__device__ inline V3 xyz(float4 v) { return v3(v.x, v.y, v.z); }
+__device__ inline void pixel_of_slot(const RenderParams& P, uint32_t slot, uint32_t& x, uint32_t& y, uint32_t& f) {
+    f = slot / P.shard_pixels;
+    uint32_t sp = slot - f * P.shard_pixels;
+    uint32_t ys = sp / P.width;
+    x = sp - ys * P.width;
+    y = P.shard_rank + P.shard_count * ys;
+}
+
 // ------------------------------------------------------------------ raygen
 __global__ __launch_bounds__(256) void k_raygen(RenderParams P, PathState ps, uint32_t* queue, uint32_t n_slots,
                                                 uint32_t dispatch_base) {
     uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= n_slots) return;
-    uint32_t f = slot / P.shard_pixels, sp = slot - f * P.shard_pixels;
-    uint32_t ys = sp / P.width, x = sp - ys * P.width;
-    uint32_t y = P.shard_rank + P.shard_count * ys;
+    uint32_t x, y, f;
+    pixel_of_slot(P, slot, x, y, f);
     uint32_t seed = pcg_hash(P.base_seed + dispatch_base + f);  // PathTracer.cpp:139 with an explicit seed
     Rng r; r.s = y + P.width * x + seed;                        // RayGen.slang:28
     V3 o, d;
     camera_ray(P, r, x, y, o, d);
-    ps.rng[slot] = r.s;
-    ps.ox[slot] = o.x; ps.oy[slot] = o.y; ps.oz[slot] = o.z;
-    ps.dx[slot] = d.x; ps.dy[slot] = d.y; ps.dz[slot] = d.z;
-    ps.tx[slot] = 1.0f; ps.ty[slot] = 1.0f; ps.tz[slot] = 1.0f;
-    ps.lx[slot] = 0.0f; ps.ly[slot] = 0.0f; ps.lz[slot] = 0.0f;
-    ps.bx[slot] = 1.0f; ps.by[slot] = 1.0f; ps.bz[slot] = 1.0f;
-    ps.pdf[slot] = 1.0f;
-    ps.depth[slot] = 0u;
-    ps.medium_flag[slot] = 0u;
-    ps.ax[slot] = 0.0f; ps.ay[slot] = 0.0f; ps.az[slot] = 0.0f;
+    ps.A[slot] = f4u(o, r.s);
+    ps.B[slot] = f4u(d, 0u);
+    ps.T[0][slot] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);  // pathThroughput = 1, payload.PDF = 1
+    ps.L[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    ps.ACC[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (P.samples_per_frame > 1) ps.sidx[slot] = 0u;
     queue[slot] = slot;
 }
 
-// ------------------------------------------------------------------ persistent traversal kernels
-constexpr uint32_t kFetch = 256;  // rays per queue fetch per wave (4 x 64): one atomic per 256 rays
+// ------------------------------------------------------------------ persistent work fetch
+// One atomic on a single word costs ~11 ns under contention (MI355X_MICROARCH.md 'dequeue': a head word
+// saturates at ~88 dequeues/us), so the number of fetches per launch is kept near 8k: a wave takes
+// n/8192 queue entries per fetch, rounded up to whole waves, between 64 and 1024.
+__device__ inline uint32_t fetch_chunk(uint32_t n) {
+    uint32_t c = ((n >> 13) + 63u) & ~63u;
+    return c < 64u ? 64u : (c > 1024u ? 1024u : c);
+}
 
 template <bool LDS_SCENE>
 __device__ inline void stage_scene(const DeviceScene& sc, float4* lds_nodes, float4* lds_tris) {
@@ -71,7 +84,15 @@ __device__ inline void stage_scene(const DeviceScene& sc, float4* lds_nodes, flo
         __syncthreads();
     }
 }
+template <bool LDS_SCENE, bool COUNT>
+__device__ inline bool trace_any(const DeviceScene& sc, const float4* lds_nodes, const float4* lds_tris, V3 o, V3 d, float tmin,
+                                 float tmax, uint32_t* stack, HitRec& h, TravStats& st) {
+    if (LDS_SCENE) { LdsSceneSrc src{lds_nodes, lds_tris}; return trace_closest<COUNT>(src, o, d, tmin, tmax, stack, kTraverseBlock, h, st); }
+    GlobalSceneSrc src{sc.nodes, sc.tris};
+    return trace_closest<COUNT>(src, o, d, tmin, tmax, stack, kTraverseBlock, h, st);
+}
 
+// ------------------------------------------------------------------ extend: closest hit of every queued path
 template <bool LDS_SCENE, bool COUNT>
 __global__ __launch_bounds__(kTraverseBlock) void k_extend(DeviceScene sc, PathState ps, const uint32_t* queue,
                                                           Counters* ctr, uint32_t parity) {
@@ -81,66 +102,28 @@ __global__ __launch_bounds__(kTraverseBlock) void k_extend(DeviceScene sc, PathS
     float4* lds_tris = lds_nodes + sc.node_count * 4;
     stage_scene<LDS_SCENE>(sc, lds_nodes, lds_tris);
     const uint32_t n = ctr->ray_count[parity];
+    const uint32_t chunk = fetch_chunk(n);
     TravStats st; st.nodes = 0; st.tris = 0;
     while (true) {
         uint32_t base = 0;
-        if (lane_id() == 0) base = atomicAdd(&ctr->extend_head, kFetch);
+        if (lane_id() == 0) base = atomicAdd(&ctr->extend_head, chunk);
         base = __shfl(base, 0);
         if (base >= n) break;
-        for (uint32_t k = 0; k < kFetch; k += 64) {
+        for (uint32_t k = 0; k < chunk; k += 64) {
             uint32_t i = base + k + lane_id();
             if (i >= n) break;
             uint32_t slot = queue[i];
-            V3 o = v3(ps.ox[slot], ps.oy[slot], ps.oz[slot]);
-            V3 d = normalize(v3(ps.dx[slot], ps.dy[slot], ps.dz[slot]));  // RayGen.slang:70
+            float4 a = ps.A[slot], b = ps.B[slot];
+            V3 d = normalize(xyz(b));  // RayGen.slang:70
             HitRec h;
-            bool found;
-            if (LDS_SCENE) { LdsSceneSrc src{lds_nodes, lds_tris}; found = trace_closest<COUNT>(src, o, d, 0.01f, 100000.0f, stack, kTraverseBlock, h, st); }
-            else { GlobalSceneSrc src{sc.nodes, sc.tris}; found = trace_closest<COUNT>(src, o, d, 0.01f, 100000.0f, stack, kTraverseBlock, h, st); }
-            ps.ht[slot] = found ? h.t : -1.0f;
-            ps.hu[slot] = h.u; ps.hv[slot] = h.v;
-            ps.hprim[slot] = h.prim; ps.hinst[slot] = h.inst;
+            bool found = trace_any<LDS_SCENE, COUNT>(sc, lds_nodes, lds_tris, xyz(a), d, 0.01f, 100000.0f, stack, h, st);
+            ps.H[slot] = make_float4(found ? h.t : -1.0f, h.u, h.v, __uint_as_float(h.prim));
+            ps.hinst[slot] = h.inst;
         }
     }
     if (COUNT) {
         atomicAdd(&ctr->stat_nodes, (unsigned long long)st.nodes);
         atomicAdd(&ctr->stat_tris, (unsigned long long)st.tris);
-    }
-}
-
-template <bool LDS_SCENE, bool COUNT>
-__global__ __launch_bounds__(kTraverseBlock) void k_shadow(DeviceScene sc, PathState ps, const ShadowRay* rays, Counters* ctr) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    uint32_t* stack = reinterpret_cast<uint32_t*>(smem) + threadIdx.x;
-    float4* lds_nodes = reinterpret_cast<float4*>(smem + kStackDepth * kTraverseBlock * 4);
-    float4* lds_tris = lds_nodes + sc.node_count * 4;
-    stage_scene<LDS_SCENE>(sc, lds_nodes, lds_tris);
-    const uint32_t n = ctr->shadow_count;
-    TravStats st; st.nodes = 0; st.tris = 0;
-    while (true) {
-        uint32_t base = 0;
-        if (lane_id() == 0) base = atomicAdd(&ctr->shadow_head, kFetch);
-        base = __shfl(base, 0);
-        if (base >= n) break;
-        for (uint32_t k = 0; k < kFetch; k += 64) {
-            uint32_t i = base + k + lane_id();
-            if (i >= n) break;
-            const float4* rp = reinterpret_cast<const float4*>(rays + i);
-            float4 r0 = rp[0], r1 = rp[1];
-            uint32_t sk = __float_as_uint(r0.w), expect = __float_as_uint(r1.w);
-            V3 o = v3(r0.x, r0.y, r0.z), d = v3(r1.x, r1.y, r1.z);  // direction not re-normalised (RTCommon.slang:55)
-            HitRec h;
-            bool found;
-            if (LDS_SCENE) { LdsSceneSrc src{lds_nodes, lds_tris}; found = trace_closest<COUNT>(src, o, d, 0.0001f, 1000000.0f, stack, kTraverseBlock, h, st); }
-            else { GlobalSceneSrc src{sc.nodes, sc.tris}; found = trace_closest<COUNT>(src, o, d, 0.0001f, 1000000.0f, stack, kTraverseBlock, h, st); }
-            uint32_t slot = sk & 0x7fffffffu;
-            if (sk >> 31) { if (found && h.gid == expect) atomicOr(ps.vis + slot, 2u); }  // ClosestHit.slang:173-176
-            else { if (!found) atomicOr(ps.vis + slot, 1u); }                              // ClosestHit.slang:139
-        }
-    }
-    if (COUNT) {
-        atomicAdd(&ctr->stat_shadow_nodes, (unsigned long long)st.nodes);
-        atomicAdd(&ctr->stat_shadow_tris, (unsigned long long)st.tris);
     }
 }
 
@@ -160,235 +143,324 @@ __global__ __launch_bounds__(kTraverseBlock) void k_trace_rays(DeviceScene sc, c
 }
 
 // ------------------------------------------------------------------ shade
-__global__ __launch_bounds__(256) void k_shade(DeviceScene sc, RenderParams P, PathState ps, const uint32_t* queue,
-                                               ShadowRay* shadow, Counters* ctr, uint32_t parity) {
-    const uint32_t n = ctr->ray_count[parity];
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    bool active = i < n;
-    uint32_t slot = active ? queue[i] : 0u;
-    bool want_sky = false, want_light = false;
+// One path per lane: miss shader or closest-hit shader, then the tail of the reference's bounce loop that
+// does not depend on visibility (throughput update, Russian roulette, termination, next-sample
+// regeneration).  Survivors are ballot-compacted into the next ray queue; paths with anything pending
+// (emission, NEE candidates, end of sample) are compacted into the connect queue — entries that carry
+// shadow rays from the front, the others from the back, so a wave of the connect kernel is homogeneous.
+// Result bits of shade_path()
+constexpr uint32_t kSP_Alive = 1u, kSP_Front = 2u, kSP_Back = 4u;  // bits 3-4: number of shadow rays queued
+
+__device__ __forceinline__ uint32_t shade_path(const DeviceScene& sc, const RenderParams& P, const PathState& ps,
+                                               const float4* Tin, float4* Tout, uint32_t slot) {
+    bool alive = false, want_sky = false, want_light = false, pending = false;
+    float4 a = ps.A[slot], b = ps.B[slot], t = Tin[slot], h = ps.H[slot];
+    Rng rng; rng.s = __float_as_uint(a.w);
+    V3 porg = xyz(a), pdir = xyz(b);           // payload.Origin / payload.Direction
+    uint32_t dw = __float_as_uint(b.w);
+    uint32_t depth = dw & 0x7fffffffu;         // payload.Depth
+    bool in_medium = (dw >> 31) != 0u;         // payload.InMedium
+    V3 thr_prev = xyz(t);                      // pathThroughput before this bounce
+    float prev_pdf = t.w;                      // payload.PDF of the previous bounce
+    V3 emitted = v3s(0.0f), csky = v3s(0.0f), clight = v3s(0.0f);
     V3 sky_o = v3s(0.0f), sky_d = v3s(0.0f), light_o = v3s(0.0f), light_d = v3s(0.0f);
     uint32_t light_gid = 0xffffffffu;
-    if (active) {
-        Rng rng; rng.s = ps.rng[slot];
-        V3 porg = v3(ps.ox[slot], ps.oy[slot], ps.oz[slot]);  // payload.Origin (previous vertex)
-        V3 pdir = v3(ps.dx[slot], ps.dy[slot], ps.dz[slot]);  // payload.Direction
-        uint32_t depth = ps.depth[slot];
-        float prev_pdf = ps.pdf[slot];
-        float ht = ps.ht[slot];
-        V3 emitted = v3s(0.0f), csky = v3s(0.0f), clight = v3s(0.0f);
-        if (ht < 0.0f) {
-            // ---- Miss.slang:8-77
-            V4 cp = v4(0.0f, 0.0f, 0.0f, 1.0f);
-            if ((P.flags & VPT_FLAG_SHOW_ENV_DIRECTLY) || depth > 0) {
-                V3 d = rotate(pdir, v3(1.0f, 0.0f, 0.0f), -(P.sky_altitude / 180.0f * VPT_PI));
-                d = rotate(d, v3(0.0f, 1.0f, 0.0f), -(P.sky_azimuth / 180.0f * VPT_PI));
-                V2 uv = direction_to_uv(d);
-                cp = env_sample(sc, uv.x, uv.y);
-            }
-            emitted = v3(cp.x, cp.y, cp.z) * P.sky_intensity;
-            if (P.flags & VPT_FLAG_FURNACE) emitted = v3s(1.0f);
-            if ((P.flags & VPT_FLAG_SKY_MIS) && depth > 0) emitted = emitted * power_heuristics(prev_pdf, cp.w);
-            ps.depth[slot] = kMaxDepthMarker;
-        } else {
-            // ---- ClosestHit.slang:20-378
-            V3 rd = normalize(pdir);  // WorldRayDirection()
-            uint32_t inst_id = ps.hinst[slot];
-            const InstanceDesc& in = sc.instances[inst_id];
-            const vpt_material& mat = sc.materials[in.material];
-            SurfaceFrame s;
-            surface_init(sc, s, in, ps.hprim[slot], ps.hu[slot], ps.hv[slot], rd, mat.normal_texture,
-                         (P.flags & VPT_FLAG_GEOMETRY_NORMALS) != 0);
-            Bsdf b; V3 mcol; float mdens, maniso, arot;
-            bsdf_init(sc, b, mat, s.uv, s.inside, P.flags, mcol, mdens, maniso, arot);
-            bool is_light = b.emissive.x > 0.0f || b.emissive.y > 0.0f || b.emissive.z > 0.0f;
-            rotate_tangents(s, arot);
-            uint32_t mflag = ps.medium_flag[slot];
-            bool scattered = false;
-            if (mflag & 1u) {  // :80-116
-                float pm_aniso = ps.maniso[slot];
-                if (pm_aniso != 1.0f) {
-                    float gd = length(porg - s.pos);
-                    float sd = -log_(rng.uf()) / ps.mdensity[slot];
-                    if (sd < gd) {
-                        V3 no = porg + (sd * pdir);
-                        V3 nd = sample_hg(rng, pdir, pm_aniso);
-                        ps.ox[slot] = no.x; ps.oy[slot] = no.y; ps.oz[slot] = no.z;
-                        ps.dx[slot] = nd.x; ps.dy[slot] = nd.y; ps.dz[slot] = nd.z;
-                        ps.bx[slot] = ps.mcr[slot]; ps.by[slot] = ps.mcg[slot]; ps.bz[slot] = ps.mcb[slot];
-                        scattered = true;  // PDF stays stale, depth unchanged, nothing emitted
-                    }
+    V3 new_o = porg, new_d = pdir, bxdf = v3s(1.0f);
+    float new_pdf = prev_pdf;
+    uint32_t new_depth = depth;
+    if (h.x < 0.0f) {
+        // ---- Miss.slang:8-77
+        V4 cp = v4(0.0f, 0.0f, 0.0f, 1.0f);
+        if ((P.flags & VPT_FLAG_SHOW_ENV_DIRECTLY) || depth > 0) {
+            V3 d = rotate(pdir, v3(1.0f, 0.0f, 0.0f), -(P.sky_altitude / 180.0f * VPT_PI));
+            d = rotate(d, v3(0.0f, 1.0f, 0.0f), -(P.sky_azimuth / 180.0f * VPT_PI));
+            V2 uv = direction_to_uv(d);
+            cp = env_sample(sc, uv.x, uv.y);
+        }
+        emitted = v3(cp.x, cp.y, cp.z) * P.sky_intensity;
+        if (P.flags & VPT_FLAG_FURNACE) emitted = v3s(1.0f);
+        if ((P.flags & VPT_FLAG_SKY_MIS) && depth > 0) emitted = emitted * power_heuristics(prev_pdf, cp.w);
+        new_depth = kMaxDepthMarker;  // payload.BxDF / PDF stay stale; the path ends here
+    } else {
+        // ---- ClosestHit.slang:20-378
+        V3 rd = normalize(pdir);  // WorldRayDirection()
+        uint32_t inst_id = ps.hinst[slot];
+        const InstanceDesc& in = sc.instances[inst_id];
+        const vpt_material& mat = sc.materials[in.material];
+        SurfaceFrame s;
+        surface_init(sc, s, in, __float_as_uint(h.w), h.y, h.z, rd, mat.normal_texture, (P.flags & VPT_FLAG_GEOMETRY_NORMALS) != 0);
+        Bsdf bs; V3 mcol; float mdens, maniso, arot;
+        bsdf_init(sc, bs, mat, s.uv, s.inside, P.flags, mcol, mdens, maniso, arot);
+        bool is_light = bs.emissive.x > 0.0f || bs.emissive.y > 0.0f || bs.emissive.z > 0.0f;
+        rotate_tangents(s, arot);
+        bool scattered = false;
+        if (in_medium) {  // :80-116
+            float pm_aniso = ps.maniso[slot];
+            if (pm_aniso != 1.0f) {
+                float4 m = ps.M[slot];
+                float gd = length(porg - s.pos);
+                float sd = -log_(rng.uf()) / m.w;
+                if (sd < gd) {
+                    new_o = porg + (sd * pdir);
+                    new_d = sample_hg(rng, pdir, pm_aniso);
+                    bxdf = xyz(m);     // payload.BxDF = MediumColor; PDF stays stale, depth unchanged
+                    scattered = true;
                 }
-            }
-            if (!scattered) {
-                // sky NEE sample (:125-148) — 3 draws
-                V3 to_sky = v3s(0.0f); V4 sky = v4(0.0f, 0.0f, 0.0f, 0.0f);
-                if (P.flags & VPT_FLAG_SKY_MIS) {
-                    sample_env(sc, P, rng, to_sky, sky);
-                    sky.x *= P.sky_intensity; sky.y *= P.sky_intensity; sky.z *= P.sky_intensity;  // applied twice upstream (quirk 1)
-                }
-                // emissive-mesh NEE sample (:155-184) — 4 draws unless this is an emitter
-                V3 to_light = v3s(0.0f); V4 lc = v4(0.0f, 0.0f, 0.0f, 0.0f);
-                if ((P.flags & VPT_FLAG_MESH_MIS) && !is_light) sample_emissive(sc, rng, s.pos, to_light, lc, light_gid);
-                // BSDF sampling (:190-201; Material.slang:94-165)
-                V3 V = s.world_to_tangent(normalize(-rd));
-                V3 H = ggx_sample(rng, V, b.ax, b.ay);
-                float Fs = b.fresnel(dot(V, H));
-                float x1 = rng.uf();
-                V3 L; bool refr = false;
-                if (x1 < b.pm) { L = normalize(reflect(-V, H)); }
-                else if (x1 < b.pm + b.pd) {
-                    if (rng.uf() < Fs) L = normalize(reflect(-V, H));
-                    else L = normalize(random_sphere(rng) + v3(0.0f, 0.0f, 1.0f));
-                } else {
-                    if (rng.uf() < Fs) L = normalize(reflect(-V, H));
-                    else { L = normalize(refract(-V, H, b.eta)); refr = true; }
-                }
-                bool valid_dir = !((L.z < 0.0f && !refr) || (refr && L.z >= 0.0f));
-                // the two energy-compensation taps depend on V only: fetch once for all evaluations
-                float ec_r = 1.0f, ec_g = 1.0f;
-                if (b.ec) {
-                    ec_r = lut_sample(b.lut_r, 64, 64, 32, V.z, b.roughness, b.anisotropy * 32.0f);
-                    ec_g = lut_sample(b.eta > 1.0f ? b.lut_i : b.lut_o, 128, 128, 32, pow_(V.z, 1.0f / 2.0f), b.roughness,
-                                      (clamp_(b.ior, 1.0001f, 2.0f) - 1.0f) * 32.0f);
-                }
-                Eval se; se.f = v3s(0.0f); se.pdf = 0.0f;
-                V3 Ls = v3s(0.0f);
-                if (valid_dir) { se = b.eval(V, L, ec_r, ec_g); Ls = L; }
-                bool was_refracted = Ls.z < 0.0f;
-                V3 scatter_world = s.tangent_to_world(Ls);
-                if (!was_refracted && dot(scatter_world, s.Ng) < 0.0f) { se.pdf = 0.0f; se.f = v3s(0.0f); }
-                if (was_refracted && s.inside) { mflag &= ~1u; }
-                else if (was_refracted && !s.inside) {
-                    mflag |= 1u;
-                    ps.mcr[slot] = mcol.x; ps.mcg[slot] = mcol.y; ps.mcb[slot] = mcol.z;
-                    ps.maniso[slot] = maniso; ps.mdensity[slot] = mdens;
-                }
-                // emission with MIS against light sampling (:265-317)
-                if (P.flags & VPT_FLAG_MESH_MIS) {
-                    if (depth == 0 && is_light) emitted = emitted + b.emissive;
-                    else if (is_light) {
-                        V3 a = mat_point(in.xform, s.p1), bb = mat_point(in.xform, s.p2), cc = mat_point(in.xform, s.p3);
-                        float area = length(cross(bb - a, cc - a)) * 0.5f;
-                        float d2 = dot(s.pos - porg, s.pos - porg);
-                        float ct = fabs_(dot(s.N, normalize(porg - s.pos)));
-                        uint32_t tc = 0;
-                        for (uint32_t k = 0; k < sc.emissive_count; k++)
-                            if (sc.emissive[k].instance == inst_id) { tc = sc.emissive[k].tri_count; break; }
-                        float lp = (1.0f / (float)sc.emissive_count) * (1.0f / (float)tc) * (1.0f / area) * (d2 / ct);
-                        lp = max_(lp, P.emissive_pdf_bias);
-                        emitted = emitted + b.emissive * power_heuristics(prev_pdf, lp);
-                    }
-                } else {
-                    emitted = emitted + b.emissive;
-                }
-                // NEE contributions, evaluated speculatively; the shadow stage decides whether they count
-                // (EvaluateBSDF draws no random numbers, so evaluating before the visibility test is equivalent)
-                if ((P.flags & VPT_FLAG_SKY_MIS) && sky.w > 0.0f) {
-                    Eval e = b.eval(V, s.world_to_tangent(to_sky), ec_r, ec_g);
-                    if (e.pdf > 0.0f) {
-                        csky = (e.f * v3(sky.x, sky.y, sky.z) / sky.w) * power_heuristics(sky.w, e.pdf);
-                        want_sky = true; sky_o = s.pos + s.N * 1e-5f; sky_d = to_sky;
-                    }
-                }
-                if ((P.flags & VPT_FLAG_MESH_MIS) && !is_light && lc.w > 0.0f) {
-                    Eval e = b.eval(V, s.world_to_tangent(to_light), ec_r, ec_g);
-                    if (e.pdf > 0.0f) {
-                        clight = (e.f * v3(lc.x, lc.y, lc.z) / lc.w) * power_heuristics(lc.w, e.pdf);
-                        want_light = true; light_o = s.pos + to_light * 1e-2f; light_d = to_light;
-                    }
-                }
-                V3 no = s.pos + s.N * (was_refracted ? -1e-3f : 1e-3f);
-                ps.ox[slot] = no.x; ps.oy[slot] = no.y; ps.oz[slot] = no.z;
-                ps.dx[slot] = scatter_world.x; ps.dy[slot] = scatter_world.y; ps.dz[slot] = scatter_world.z;
-                ps.bx[slot] = se.f.x; ps.by[slot] = se.f.y; ps.bz[slot] = se.f.z;
-                ps.pdf[slot] = se.pdf;
-                ps.medium_flag[slot] = mflag;
-                ps.depth[slot] = (se.pdf <= 0.0f) ? (kMaxDepthMarker + depth) : (depth + 1u);  // :374-376
             }
         }
-        ps.rng[slot] = rng.s;
-        ps.ex[slot] = emitted.x; ps.ey[slot] = emitted.y; ps.ez[slot] = emitted.z;
-        ps.skx[slot] = csky.x; ps.sky[slot] = csky.y; ps.skz[slot] = csky.z;
-        ps.lgx[slot] = clight.x; ps.lgy[slot] = clight.y; ps.lgz[slot] = clight.z;
-        ps.vis[slot] = 0u;
-    }
-    // wave-level compaction of the (<=2 per path) shadow rays into one stream
-    uint32_t is = wave_append(want_sky, &ctr->shadow_count);
-    if (want_sky) {
-        float4* q = reinterpret_cast<float4*>(shadow + is);
-        q[0] = make_float4(sky_o.x, sky_o.y, sky_o.z, __uint_as_float(slot));
-        q[1] = make_float4(sky_d.x, sky_d.y, sky_d.z, __uint_as_float(0u));
-    }
-    uint32_t il = wave_append(want_light, &ctr->shadow_count);
-    if (want_light) {
-        float4* q = reinterpret_cast<float4*>(shadow + il);
-        q[0] = make_float4(light_o.x, light_o.y, light_o.z, __uint_as_float(slot | 0x80000000u));
-        q[1] = make_float4(light_d.x, light_d.y, light_d.z, __uint_as_float(light_gid));
-    }
-}
-
-// ------------------------------------------------------------------ accumulate (+ compaction, + path regeneration)
-__global__ __launch_bounds__(256) void k_accumulate(RenderParams P, PathState ps, const uint32_t* queue_in, uint32_t* queue_out,
-                                                    Counters* ctr, uint32_t parity) {
-    const uint32_t n = ctr->ray_count[parity];
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    bool active = i < n;
-    uint32_t slot = active ? queue_in[i] : 0u;
-    bool alive = false;
-    if (active) {
-        uint32_t vis = ps.vis[slot];
-        V3 E = v3(ps.ex[slot], ps.ey[slot], ps.ez[slot]);
-        if (vis & 1u) E = E + v3(ps.skx[slot], ps.sky[slot], ps.skz[slot]);  // ClosestHit.slang:344-353
-        if (vis & 2u) E = E + v3(ps.lgx[slot], ps.lgy[slot], ps.lgz[slot]);  // ClosestHit.slang:358-370
-        V3 thr = v3(ps.tx[slot], ps.ty[slot], ps.tz[slot]);
-        V3 light = v3(ps.lx[slot], ps.ly[slot], ps.lz[slot]);
-        uint32_t depth = ps.depth[slot];
-        V3 contrib = E * thr;  // RayGen.slang:92
-        if (depth != 1u) {
-            float lum = dot(contrib, v3(0.212671f, 0.715160f, 0.072169f));
-            contrib = contrib * (P.max_luminance / max_(lum, P.max_luminance));
+        if (!scattered) {
+            // sky NEE sample (:125-148) — 3 draws
+            V3 to_sky = v3s(0.0f); V4 sky = v4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (P.flags & VPT_FLAG_SKY_MIS) {
+                sample_env(sc, P, rng, to_sky, sky);
+                sky.x *= P.sky_intensity; sky.y *= P.sky_intensity; sky.z *= P.sky_intensity;  // applied twice upstream (quirk 1)
+            }
+            // emissive-mesh NEE sample (:155-184) — 4 draws unless this is an emitter
+            V3 to_light = v3s(0.0f); V4 lc = v4(0.0f, 0.0f, 0.0f, 0.0f);
+            if ((P.flags & VPT_FLAG_MESH_MIS) && !is_light) sample_emissive(sc, rng, s.pos, to_light, lc, light_gid);
+            // BSDF sampling (:190-201; Material.slang:94-165)
+            V3 V = s.world_to_tangent(normalize(-rd));
+            V3 H = ggx_sample(rng, V, bs.ax, bs.ay);
+            float Fs = bs.fresnel(dot(V, H));
+            float x1 = rng.uf();
+            V3 L; bool refr = false;
+            if (x1 < bs.pm) { L = normalize(reflect(-V, H)); }
+            else if (x1 < bs.pm + bs.pd) {
+                if (rng.uf() < Fs) L = normalize(reflect(-V, H));
+                else L = normalize(random_sphere(rng) + v3(0.0f, 0.0f, 1.0f));
+            } else {
+                if (rng.uf() < Fs) L = normalize(reflect(-V, H));
+                else { L = normalize(refract(-V, H, bs.eta)); refr = true; }
+            }
+            bool valid_dir = !((L.z < 0.0f && !refr) || (refr && L.z >= 0.0f));
+            // the two energy-compensation taps depend on V only: fetch once for all evaluations
+            float ec_r = 1.0f, ec_g = 1.0f;
+            if (bs.ec) {
+                ec_r = lut_sample(bs.lut_r, 64, 64, 32, V.z, bs.roughness, bs.anisotropy * 32.0f);
+                ec_g = lut_sample(bs.eta > 1.0f ? bs.lut_i : bs.lut_o, 128, 128, 32, pow_(V.z, 1.0f / 2.0f), bs.roughness,
+                                  (clamp_(bs.ior, 1.0001f, 2.0f) - 1.0f) * 32.0f);
+            }
+            Eval se; se.f = v3s(0.0f); se.pdf = 0.0f;
+            V3 Ls = v3s(0.0f);
+            const float gv = bs.smith(V);  // G1(V): shared by every evaluation of this hit
+    if (valid_dir) { se = bs.eval(V, L, ec_r, ec_g, gv); Ls = L; }
+            bool was_refracted = Ls.z < 0.0f;
+            V3 scatter_world = s.tangent_to_world(Ls);
+            if (!was_refracted && dot(scatter_world, s.Ng) < 0.0f) { se.pdf = 0.0f; se.f = v3s(0.0f); }
+            if (was_refracted && s.inside) { in_medium = false; }
+            else if (was_refracted && !s.inside) {
+                in_medium = true;
+                ps.M[slot] = make_float4(mcol.x, mcol.y, mcol.z, mdens);
+                ps.maniso[slot] = maniso;
+            }
+            // emission with MIS against light sampling (:265-317)
+            if (P.flags & VPT_FLAG_MESH_MIS) {
+                if (depth == 0 && is_light) emitted = emitted + bs.emissive;
+                else if (is_light) {
+                    V3 pa = mat_point(in.xform, s.p1), pb = mat_point(in.xform, s.p2), pc = mat_point(in.xform, s.p3);
+                    float area = length(cross(pb - pa, pc - pa)) * 0.5f;
+                    float d2 = dot(s.pos - porg, s.pos - porg);
+                    float ct = fabs_(dot(s.N, normalize(porg - s.pos)));
+                    uint32_t tc = 0;
+                    for (uint32_t k = 0; k < sc.emissive_count; k++)
+                        if (sc.emissive[k].instance == inst_id) { tc = sc.emissive[k].tri_count; break; }
+                    float lp = (1.0f / (float)sc.emissive_count) * (1.0f / (float)tc) * (1.0f / area) * (d2 / ct);
+                    lp = max_(lp, P.emissive_pdf_bias);
+                    emitted = emitted + bs.emissive * power_heuristics(prev_pdf, lp);
+                }
+            } else {
+                emitted = emitted + bs.emissive;
+            }
+            // NEE contributions, evaluated speculatively; the connect stage decides whether they count
+            // (EvaluateBSDF draws no random numbers, so evaluating before the visibility test is equivalent)
+            if ((P.flags & VPT_FLAG_SKY_MIS) && sky.w > 0.0f) {
+                Eval e = bs.eval(V, s.world_to_tangent(to_sky), ec_r, ec_g, gv);
+                if (e.pdf > 0.0f) {
+                    csky = (e.f * v3(sky.x, sky.y, sky.z) / sky.w) * power_heuristics(sky.w, e.pdf);
+                    want_sky = true; sky_o = s.pos + s.N * 1e-5f; sky_d = to_sky;
+                }
+            }
+            if ((P.flags & VPT_FLAG_MESH_MIS) && !is_light && lc.w > 0.0f) {
+                Eval e = bs.eval(V, s.world_to_tangent(to_light), ec_r, ec_g, gv);
+                if (e.pdf > 0.0f) {
+                    clight = (e.f * v3(lc.x, lc.y, lc.z) / lc.w) * power_heuristics(lc.w, e.pdf);
+                    want_light = true; light_o = s.pos + to_light * 1e-2f; light_d = to_light;
+                }
+            }
+            new_o = s.pos + s.N * (was_refracted ? -1e-3f : 1e-3f);
+            new_d = scatter_world;
+            bxdf = se.f; new_pdf = se.pdf;
+            new_depth = (se.pdf <= 0.0f) ? (kMaxDepthMarker + depth) : (depth + 1u);  // :374-376
         }
-        light = light + contrib;
-        thr = thr * (v3(ps.bx[slot], ps.by[slot], ps.bz[slot]) / ps.pdf[slot]);
-        float p = min_(max_(thr.x, max_(thr.y, thr.z)), 1.0f);
-        Rng rng; rng.s = ps.rng[slot];
-        float u = rng.uf();  // drawn on every iteration, terminal ones included
-        bool terminated = (p < u);
-        if (!terminated) thr = thr / p;
-        if (!(depth < P.max_depth)) terminated = true;
-        if (!terminated) {
-            alive = true;
-            ps.tx[slot] = thr.x; ps.ty[slot] = thr.y; ps.tz[slot] = thr.z;
-            ps.lx[slot] = light.x; ps.ly[slot] = light.y; ps.lz[slot] = light.z;
-        } else {
-            // sample finished: NaN/Inf guard, per-frame sum (RayGen.slang:116-128)
-            bool ok = !isinf_(light.x) && !isinf_(light.y) && !isinf_(light.z) && !isnan_(light.x) && !isnan_(light.y) && !isnan_(light.z);
-            if (ok) { ps.ax[slot] += light.x; ps.ay[slot] += light.y; ps.az[slot] += light.z; }
-            uint32_t mflag = ps.medium_flag[slot];
-            uint32_t sample = (mflag >> 8) + 1u;
-            if (sample < P.samples_per_frame) {
-                // next sample of the same pixel continues the same RNG stream (RayGen.slang:33)
-                uint32_t sp = slot % P.shard_pixels;
-                uint32_t ys = sp / P.width, x = sp - ys * P.width;
-                uint32_t y = P.shard_rank + P.shard_count * ys;
-                V3 o, d;
-                camera_ray(P, rng, x, y, o, d);
-                ps.ox[slot] = o.x; ps.oy[slot] = o.y; ps.oz[slot] = o.z;
-                ps.dx[slot] = d.x; ps.dy[slot] = d.y; ps.dz[slot] = d.z;
-                ps.tx[slot] = 1.0f; ps.ty[slot] = 1.0f; ps.tz[slot] = 1.0f;
-                ps.lx[slot] = 0.0f; ps.ly[slot] = 0.0f; ps.lz[slot] = 0.0f;
-                ps.bx[slot] = 1.0f; ps.by[slot] = 1.0f; ps.bz[slot] = 1.0f;
-                ps.pdf[slot] = 1.0f;
-                ps.depth[slot] = 0u;
-                ps.medium_flag[slot] = sample << 8;
+    }
+    // ---- RayGen.slang:104-113: throughput, Russian roulette (drawn on every iteration), loop condition
+    V3 thr = thr_prev * (bxdf / new_pdf);
+    float p = min_(max_(thr.x, max_(thr.y, thr.z)), 1.0f);
+    float u = rng.uf();
+    bool terminated = p < u;
+    if (!terminated) thr = thr / p;
+    if (!(new_depth < P.max_depth)) terminated = true;
+    uint32_t cflags = (want_sky ? kCF_Sky : 0u) | (want_light ? kCF_Light : 0u) | (new_depth != 1u ? kCF_Clamp : 0u);
+    if (terminated) {
+        cflags |= kCF_Finalize;
+        if (P.samples_per_frame > 1) {
+            uint32_t sample = ps.sidx[slot] + 1u;
+            if (sample < P.samples_per_frame) {  // next sample of the pixel continues the RNG stream (RayGen.slang:33)
+                uint32_t x, y, f;
+                pixel_of_slot(P, slot, x, y, f);
+                camera_ray(P, rng, x, y, new_o, new_d);
+                thr = v3s(1.0f); new_pdf = 1.0f; new_depth = 0u; in_medium = false;
+                ps.sidx[slot] = sample;
                 alive = true;
             }
         }
-        ps.rng[slot] = rng.s;
+    } else {
+        alive = true;
     }
-    uint32_t o = wave_append(alive, &ctr->ray_count[parity ^ 1u]);
-    if (alive) queue_out[o] = slot;
+    if (alive) {
+        ps.A[slot] = f4u(new_o, rng.s);
+        ps.B[slot] = f4u(new_d, new_depth | (in_medium ? 0x80000000u : 0u));
+        Tout[slot] = f4(thr, new_pdf);
+    }
+    bool thr_finite = !isinf_(thr_prev.x) && !isinf_(thr_prev.y) && !isinf_(thr_prev.z) && !isnan_(thr_prev.x) && !isnan_(thr_prev.y) && !isnan_(thr_prev.z);
+    pending = want_sky || want_light || terminated || emitted.x != 0.0f || emitted.y != 0.0f || emitted.z != 0.0f || !thr_finite;
+    if (pending) {
+        ps.CE[slot] = f4u(emitted, cflags);
+        if (want_sky) {
+            ps.CS[slot] = f4(csky, 0.0f);
+            ps.CSO[slot] = f4(sky_o, sky_d.x);
+            ps.CSD[slot] = make_float4(sky_d.y, sky_d.z, 0.0f, 0.0f);
+        }
+        if (want_light) {
+            ps.CL[slot] = f4u(clight, light_gid);
+            ps.CLO[slot] = f4(light_o, light_d.x);
+            ps.CLD[slot] = make_float4(light_d.y, light_d.z, 0.0f, 0.0f);
+        }
+    }
+    bool has_rays = want_sky || want_light;
+    return (alive ? kSP_Alive : 0u) | ((pending && has_rays) ? kSP_Front : 0u) | ((pending && !has_rays) ? kSP_Back : 0u) |
+           (((want_sky ? 1u : 0u) + (want_light ? 1u : 0u)) << 3);
+}
+
+// A block shades tiles of cpt x 256 paths (cpt = 1..4 per thread) and reserves queue space with ONE atomic
+// per counter per tile; cpt grows with the queue so a launch issues at most ~8k atomics per counter.
+
+__global__ __launch_bounds__(256, 3) void k_shade(DeviceScene sc, RenderParams P, PathState ps, const uint32_t* queue,
+                                               uint32_t* queue_next, uint32_t* cqueue, Counters* ctr, uint32_t parity) {
+    __shared__ uint32_t s_cnt[4][4];
+    __shared__ uint32_t s_base[4][3];
+    const uint32_t n = ctr->ray_count[parity];
+    const float4* Tin = ps.T[parity];
+    float4* Tout = ps.T[parity ^ 1u];
+    const uint32_t wave = threadIdx.x >> 6;
+    uint32_t cpt = (n + (1u << 21) - 1u) >> 21;
+    cpt = cpt < 1u ? 1u : (cpt > 4u ? 4u : cpt);
+    const uint32_t tile_size = cpt * 256u;
+    for (uint32_t tile = blockIdx.x * tile_size; tile < n; tile += gridDim.x * tile_size) {
+        uint32_t s0 = 0u, s1 = 0u, s2 = 0u, s3 = 0u, res = 0u;  // slots and 5-bit results of this lane's 4 paths
+        uint32_t tot_alive = 0u, tot_front = 0u, tot_back = 0u, tot_rays = 0u;  // wave totals
+#pragma unroll 1
+        for (uint32_t c = 0; c < cpt; c++) {
+            uint32_t i = tile + c * 256u + threadIdx.x;
+            uint32_t r = 0u, slot = 0u;
+            if (i < n) {
+                slot = queue[i];
+                r = shade_path(sc, P, ps, Tin, Tout, slot);
+            }
+            s0 = (c == 0u) ? slot : s0; s1 = (c == 1u) ? slot : s1; s2 = (c == 2u) ? slot : s2; s3 = (c == 3u) ? slot : s3;
+            res |= r << (c * 5u);
+            tot_alive += (uint32_t)__popcll(__ballot((r & kSP_Alive) != 0u));
+            tot_front += (uint32_t)__popcll(__ballot((r & kSP_Front) != 0u));
+            tot_back += (uint32_t)__popcll(__ballot((r & kSP_Back) != 0u));
+            tot_rays += (uint32_t)__popcll(__ballot((r & 8u) != 0u)) + 2u * (uint32_t)__popcll(__ballot((r & 16u) != 0u));
+        }
+        // block-level reservation: one atomic per counter per 1024 paths
+        if (lane_id() == 0) { s_cnt[wave][0] = tot_alive; s_cnt[wave][1] = tot_front; s_cnt[wave][2] = tot_back; s_cnt[wave][3] = tot_rays; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t sum[4] = {0u, 0u, 0u, 0u};
+            uint32_t pre[4][3];
+            for (uint32_t w = 0; w < 4; w++)
+                for (uint32_t q = 0; q < 4; q++) { if (q < 3) pre[w][q] = sum[q]; sum[q] += s_cnt[w][q]; }
+            uint32_t b_alive = sum[0] ? atomicAdd(&ctr->ray_count[parity ^ 1u], sum[0]) : 0u;
+            uint32_t b_front = sum[1] ? atomicAdd(&ctr->connect_front, sum[1]) : 0u;
+            uint32_t b_back = sum[2] ? atomicAdd(&ctr->connect_back, sum[2]) : 0u;
+            if (sum[3]) atomicAdd(&ctr->shadow_rays, sum[3]);
+            for (uint32_t w = 0; w < 4; w++) { s_base[w][0] = b_alive + pre[w][0]; s_base[w][1] = b_front + pre[w][1]; s_base[w][2] = b_back + pre[w][2]; }
+        }
+        __syncthreads();
+        uint32_t o_alive = s_base[wave][0], o_front = s_base[wave][1], o_back = s_base[wave][2];
+#pragma unroll
+        for (uint32_t c = 0; c < 4; c++) {
+            uint32_t r = (res >> (c * 5u)) & 31u;
+            uint32_t slot = c == 0u ? s0 : (c == 1u ? s1 : (c == 2u ? s2 : s3));
+            unsigned long long ma = __ballot((r & kSP_Alive) != 0u), mf = __ballot((r & kSP_Front) != 0u), mb = __ballot((r & kSP_Back) != 0u);
+            if (r & kSP_Alive) queue_next[o_alive + lanes_below(ma)] = slot;
+            if (r & kSP_Front) cqueue[o_front + lanes_below(mf)] = slot;
+            if (r & kSP_Back) cqueue[ps.capacity - 1u - (o_back + lanes_below(mb))] = slot;
+            o_alive += (uint32_t)__popcll(ma); o_front += (uint32_t)__popcll(mf); o_back += (uint32_t)__popcll(mb);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ connect
+// Per pending path: trace its (<= 2) shadow rays (RTCommon.slang:47-64: closest committed hit), join the
+// visible NEE contributions with the emission BEFORE the luminance clamp (RayGen.slang:92-102), add to
+// pathLight, and at the end of a sample apply the NaN/Inf guard and add to the frame sum (:116-128).
+template <bool LDS_SCENE, bool COUNT>
+__global__ __launch_bounds__(kTraverseBlock) void k_connect(DeviceScene sc, RenderParams P, PathState ps, const uint32_t* cqueue,
+                                                           Counters* ctr, uint32_t parity) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint32_t* stack = reinterpret_cast<uint32_t*>(smem) + threadIdx.x;
+    float4* lds_nodes = reinterpret_cast<float4*>(smem + kStackDepth * kTraverseBlock * 4);
+    float4* lds_tris = lds_nodes + sc.node_count * 4;
+    stage_scene<LDS_SCENE>(sc, lds_nodes, lds_tris);
+    const uint32_t nf = ctr->connect_front, nb = ctr->connect_back, n = nf + nb;
+    const float4* Tprev = ps.T[parity];
+    const uint32_t chunk = fetch_chunk(n);
+    TravStats st; st.nodes = 0; st.tris = 0;
+    while (true) {
+        uint32_t base = 0;
+        if (lane_id() == 0) base = atomicAdd(&ctr->connect_head, chunk);
+        base = __shfl(base, 0);
+        if (base >= n) break;
+        for (uint32_t k = 0; k < chunk; k += 64) {
+            uint32_t i = base + k + lane_id();
+            if (i >= n) break;
+            uint32_t slot = (i < nf) ? cqueue[i] : cqueue[ps.capacity - 1u - (i - nf)];
+            float4 ce = ps.CE[slot];
+            uint32_t flags = __float_as_uint(ce.w);
+            V3 E = xyz(ce);
+            if (flags & kCF_Sky) {  // ClosestHit.slang:139, 344-353
+                float4 so = ps.CSO[slot], sd = ps.CSD[slot];
+                HitRec h;
+                bool found = trace_any<LDS_SCENE, COUNT>(sc, lds_nodes, lds_tris, xyz(so), v3(so.w, sd.x, sd.y), 0.0001f, 1000000.0f, stack, h, st);
+                if (!found) E = E + xyz(ps.CS[slot]);
+            }
+            if (flags & kCF_Light) {  // ClosestHit.slang:171-176, 358-370
+                float4 lo = ps.CLO[slot], ld = ps.CLD[slot], cl = ps.CL[slot];
+                HitRec h;
+                bool found = trace_any<LDS_SCENE, COUNT>(sc, lds_nodes, lds_tris, xyz(lo), v3(lo.w, ld.x, ld.y), 0.0001f, 1000000.0f, stack, h, st);
+                if (found && h.gid == __float_as_uint(cl.w)) E = E + xyz(cl);
+            }
+            V3 contrib = E * xyz(Tprev[slot]);  // RayGen.slang:92
+            if (flags & kCF_Clamp) {
+                float lum = dot(contrib, v3(0.212671f, 0.715160f, 0.072169f));
+                contrib = contrib * (P.max_luminance / max_(lum, P.max_luminance));
+            }
+            V3 light = xyz(ps.L[slot]) + contrib;
+            if (flags & kCF_Finalize) {
+                bool ok = !isinf_(light.x) && !isinf_(light.y) && !isinf_(light.z) && !isnan_(light.x) && !isnan_(light.y) && !isnan_(light.z);
+                if (ok) { float4 acc = ps.ACC[slot]; ps.ACC[slot] = f4(xyz(acc) + light, 0.0f); }
+                light = v3s(0.0f);  // a regenerated sample starts from pathLight = 0
+            }
+            ps.L[slot] = f4(light, 0.0f);
+        }
+    }
+    if (COUNT) {
+        atomicAdd(&ctr->stat_shadow_nodes, (unsigned long long)st.nodes);
+        atomicAdd(&ctr->stat_shadow_tris, (unsigned long long)st.tris);
+    }
 }
 
 // ------------------------------------------------------------------ resolve: running mean, frames applied in order
@@ -398,8 +470,7 @@ __global__ __launch_bounds__(256) void k_resolve(RenderParams P, PathState ps, f
     float4 px = image[sp];
     V3 color = v3(px.x, px.y, px.z);
     for (uint32_t f = 0; f < frames; f++) {
-        uint32_t slot = f * P.shard_pixels + sp;
-        V3 acc = v3(ps.ax[slot], ps.ay[slot], ps.az[slot]) / (float)P.samples_per_frame;
+        V3 acc = xyz(ps.ACC[f * P.shard_pixels + sp]) / (float)P.samples_per_frame;
         uint32_t fc = frame_base + f;
         if (fc > 0) color = lerp(color, acc, 1.0f / (float)(fc + 1u));
         else color = acc;
@@ -407,8 +478,18 @@ __global__ __launch_bounds__(256) void k_resolve(RenderParams P, PathState ps, f
     image[sp] = make_float4(color.x, color.y, color.z, 1.0f);
 }
 
+// Start of a bounce: fold the statistics of the previous one, reset cursors and the output queue sizes.
 __global__ void k_prepare(Counters* ctr, uint32_t parity) {
-    ctr->extend_head = 0u; ctr->shadow_head = 0u; ctr->shadow_count = 0u; ctr->ray_count[parity ^ 1u] = 0u;
+    ctr->stat_closest += ctr->ray_count[parity];
+    ctr->stat_shadow += ctr->shadow_rays;
+    ctr->stat_connect += ctr->connect_front + ctr->connect_back;
+    ctr->shadow_rays = 0u;
+    ctr->extend_head = 0u; ctr->connect_head = 0u; ctr->connect_front = 0u; ctr->connect_back = 0u;
+    ctr->ray_count[parity ^ 1u] = 0u;
+}
+__global__ void k_fold(Counters* ctr) {
+    ctr->stat_shadow += ctr->shadow_rays; ctr->shadow_rays = 0u;
+    ctr->stat_connect += ctr->connect_front + ctr->connect_back; ctr->connect_front = 0u; ctr->connect_back = 0u;
 }
 
 // shard rows <-> full image
@@ -428,6 +509,7 @@ void launch_raygen(hipStream_t s, const RenderParams& P, const PathState& ps, ui
     hipLaunchKernelGGL(k_raygen, dim3(cdiv(n_slots, 256)), dim3(256), 0, s, P, ps, queue, n_slots, dispatch_base);
 }
 void launch_prepare(hipStream_t s, Counters* ctr, uint32_t parity) { hipLaunchKernelGGL(k_prepare, dim3(1), dim3(1), 0, s, ctr, parity); }
+void launch_fold(hipStream_t s, Counters* ctr) { hipLaunchKernelGGL(k_fold, dim3(1), dim3(1), 0, s, ctr); }
 
 size_t traverse_lds_bytes(const DeviceScene& sc, bool lds_scene) {
     size_t b = (size_t)kStackDepth * kTraverseBlock * 4;
@@ -445,24 +527,20 @@ void launch_extend(hipStream_t s, uint32_t blocks, bool lds_scene, bool count, c
         else hipLaunchKernelGGL((k_extend<false, false>), dim3(blocks), dim3(kTraverseBlock), lds, s, sc, ps, queue, ctr, parity);
     }
 }
-void launch_shadow(hipStream_t s, uint32_t blocks, bool lds_scene, bool count, const DeviceScene& sc, const PathState& ps,
-                   const ShadowRay* rays, Counters* ctr) {
+void launch_connect(hipStream_t s, uint32_t blocks, bool lds_scene, bool count, const DeviceScene& sc, const RenderParams& P,
+                    const PathState& ps, const uint32_t* cqueue, Counters* ctr, uint32_t parity) {
     size_t lds = traverse_lds_bytes(sc, lds_scene);
     if (lds_scene) {
-        if (count) hipLaunchKernelGGL((k_shadow<true, true>), dim3(blocks), dim3(kTraverseBlock), lds, s, sc, ps, rays, ctr);
-        else hipLaunchKernelGGL((k_shadow<true, false>), dim3(blocks), dim3(kTraverseBlock), lds, s, sc, ps, rays, ctr);
+        if (count) hipLaunchKernelGGL((k_connect<true, true>), dim3(blocks), dim3(kTraverseBlock), lds, s, sc, P, ps, cqueue, ctr, parity);
+        else hipLaunchKernelGGL((k_connect<true, false>), dim3(blocks), dim3(kTraverseBlock), lds, s, sc, P, ps, cqueue, ctr, parity);
     } else {
-        if (count) hipLaunchKernelGGL((k_shadow<false, true>), dim3(blocks), dim3(kTraverseBlock), lds, s, sc, ps, rays, ctr);
-        else hipLaunchKernelGGL((k_shadow<false, false>), dim3(blocks), dim3(kTraverseBlock), lds, s, sc, ps, rays, ctr);
+        if (count) hipLaunchKernelGGL((k_connect<false, true>), dim3(blocks), dim3(kTraverseBlock), lds, s, sc, P, ps, cqueue, ctr, parity);
+        else hipLaunchKernelGGL((k_connect<false, false>), dim3(blocks), dim3(kTraverseBlock), lds, s, sc, P, ps, cqueue, ctr, parity);
     }
 }
-void launch_shade(hipStream_t s, uint32_t n_upper, const DeviceScene& sc, const RenderParams& P, const PathState& ps,
-                  const uint32_t* queue, ShadowRay* shadow, Counters* ctr, uint32_t parity) {
-    hipLaunchKernelGGL(k_shade, dim3(cdiv(n_upper, 256)), dim3(256), 0, s, sc, P, ps, queue, shadow, ctr, parity);
-}
-void launch_accumulate(hipStream_t s, uint32_t n_upper, const RenderParams& P, const PathState& ps, const uint32_t* qin,
-                       uint32_t* qout, Counters* ctr, uint32_t parity) {
-    hipLaunchKernelGGL(k_accumulate, dim3(cdiv(n_upper, 256)), dim3(256), 0, s, P, ps, qin, qout, ctr, parity);
+void launch_shade(hipStream_t s, uint32_t blocks, const DeviceScene& sc, const RenderParams& P, const PathState& ps,
+                  const uint32_t* queue, uint32_t* queue_next, uint32_t* cqueue, Counters* ctr, uint32_t parity) {
+    hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(256), 0, s, sc, P, ps, queue, queue_next, cqueue, ctr, parity);
 }
 void launch_resolve(hipStream_t s, const RenderParams& P, const PathState& ps, float* image, uint32_t frames, uint32_t frame_base) {
     hipLaunchKernelGGL(k_resolve, dim3(cdiv(P.shard_pixels, 256)), dim3(256), 0, s, P, ps, reinterpret_cast<float4*>(image), frames, frame_base);
@@ -477,8 +555,13 @@ void launch_scatter_rows(hipStream_t s, const float* gathered, float* full, uint
 int traverse_blocks_per_cu(bool lds_scene, const DeviceScene& sc) {
     int nb = 0;
     size_t lds = traverse_lds_bytes(sc, lds_scene);
-    if (lds_scene) hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_extend<true, false>, kTraverseBlock, lds);
-    else hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_extend<false, false>, kTraverseBlock, lds);
+    if (lds_scene) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_connect<true, false>, kTraverseBlock, lds);
+    else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_connect<false, false>, kTraverseBlock, lds);
+    return nb > 0 ? nb : 1;
+}
+int shade_blocks_per_cu() {
+    int nb = 0;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_shade, 256, 0);
     return nb > 0 ? nb : 1;
 }
 

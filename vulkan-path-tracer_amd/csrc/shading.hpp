@@ -161,37 +161,43 @@ struct Bsdf {
         float lam = (-1.0f + sqrt_(1.0f + ((ax * ax) * (v.x * v.x) + (ay * ay) * (v.y * v.y)) / vz2)) / 2.0f;
         return 1.0f / (1.0f + lam);
     }
-    // :331-351. D, GV are shared by every reflection lobe of one direction pair.
-    __device__ inline Eval reflection(V3 V, V3 L, V3 F) const {
-        Eval e; e.f = v3s(0.0f); e.pdf = 0.0f;
-        if (L.z <= 1e-5f) return e;
-        V3 H = normalize(V + L);
+    // EvaluateReflection, :331-351, split into the part that does not depend on the Fresnel colour
+    // (H, D, G1(L), pdf — identical for the metallic, dielectric-specular and glass-reflection lobes of one
+    // direction pair) and the colour part.  gv = G1(V) depends on V only and is shared by every
+    // evaluation of a hit.  Each expression is evaluated exactly as upstream writes it, just once.
+    struct ReflCommon { float D, GL, pdf; bool valid; };
+    __device__ inline ReflCommon reflection_common(V3 V, V3 L, V3 H, float gv) const {
+        ReflCommon c; c.D = 0.0f; c.GL = 0.0f; c.pdf = 0.0f; c.valid = !(L.z <= 1e-5f);
+        if (!c.valid) return c;
         float VdotH = dot(V, H);
-        float D = ggx_d(H);
-        float GV = smith(V), GL = smith(L);
-        e.pdf = (GV * max_(VdotH, 0.0f) * D / V.z) / (4.0f * VdotH);
-        e.f = ((F * D) * GV) * GL / (4.0f * V.z);
-        return e;
+        c.D = ggx_d(H);
+        c.GL = smith(L);
+        c.pdf = (gv * max_(VdotH, 0.0f) * c.D / V.z) / (4.0f * VdotH);
+        return c;
     }
-    __device__ inline Eval refraction(V3 V, V3 L, V3 F) const {  // :359-387
+    __device__ inline V3 reflection_f(const ReflCommon& c, V3 V, V3 F, float gv) const {
+        if (!c.valid) return v3s(0.0f);
+        return ((F * c.D) * gv) * c.GL / (4.0f * V.z);
+    }
+    __device__ inline Eval refraction(V3 V, V3 L, V3 F, float gv) const {  // :359-387
         Eval e; e.f = v3s(0.0f); e.pdf = 0.0f;
         if (L.z >= 1e-5f) return e;
         V3 H = normalize(V * eta + L);
         if (H.z < 0.0f) H = -H;
         float VdotH = dot(V, H), LdotH = dot(L, H);
         float D = ggx_d(H);
-        float GV = smith(V), GL = smith(L);
-        float G = GV * GL;
+        float GL = smith(L);
+        float G = gv * GL;
         float den = LdotH + eta * VdotH;
         float den2 = den * den, eta2 = eta * eta;
         float jac = (eta2 * fabs_(LdotH)) / den2;
-        e.pdf = (GV * fabs_(VdotH) * D / V.z) * jac;
+        e.pdf = (gv * fabs_(VdotH) * D / V.z) * jac;
         e.f = (((F * D) * G) * eta2 / den2) * (fabs_(VdotH) * fabs_(LdotH) / fabs_(V.z));
         return e;
     }
-    // EvaluateBSDF, :167-254.  ec_r / ec_g: the two LUT taps depend on V only, so the caller
-    // fetches them once per hit and passes them to all (up to three) evaluations.
-    __device__ inline Eval eval(V3 V, V3 L, float ec_r, float ec_g) const {
+    // EvaluateBSDF, :167-254.  ec_r / ec_g (the two LUT taps) and gv = G1(V) depend on V only, so the
+    // caller computes them once per hit and passes them to all (up to three) evaluations.
+    __device__ inline Eval eval(V3 V, V3 L, float ec_r, float ec_g, float gv) const {
         bool refracted = L.z < 0.0f;
         V3 H; bool valid_refr = false;
         if (refracted) {
@@ -205,14 +211,14 @@ struct Bsdf {
         float F = fresnel(fabs_(dot(V, H)));
         Eval r; r.f = v3s(0.0f); r.pdf = 0.0f;
         if (!refracted) {
+            ReflCommon rc = reflection_common(V, L, H, gv);  // H == normalize(V + L) in every reflection lobe
             // metallic (:266-283)
             {
                 float m = clamp_(1.0f - dot(V, H), 0.0f, 1.0f);
                 float m2 = m * m;
-                V3 Fm = lerp(base, spec, m2 * m2 * m);
-                Eval e = reflection(V, L, Fm);
-                if (ec) { float c = (1.0f - ec_r) / ec_r; e.f = (v3s(1.0f) + base * c) * e.f; }
-                r.f = r.f + e.f * pm; r.pdf += e.pdf * pm;
+                V3 ef = reflection_f(rc, V, lerp(base, spec, m2 * m2 * m), gv);
+                if (ec) { float c = (1.0f - ec_r) / ec_r; ef = (v3s(1.0f) + base * c) * ef; }
+                r.f = r.f + ef * pm; r.pdf += rc.pdf * pm;
             }
             // diffuse (:256-264)
             {
@@ -220,19 +226,19 @@ struct Bsdf {
                 V3 df = (base * VPT_1_OVER_PI) * L.z;
                 r.f = r.f + df * pd * (1.0f - F); r.pdf += dpdf * pd * (1.0f - F);
             }
-            // dielectric specular (:285-298) and glass reflection (:225-238) share EvaluateReflection(SpecularColor)
+            // dielectric specular (:285-298) and glass reflection (:225-238): both EvaluateReflection(SpecularColor)
             {
-                Eval e = reflection(V, L, spec);
-                V3 sf = e.f;
+                V3 ef = reflection_f(rc, V, spec, gv);
+                V3 sf = ef;
                 if (ec) sf = sf / ec_r;
-                r.f = r.f + sf * pd * F; r.pdf += e.pdf * pd * F;
-                V3 gf = e.f;
+                r.f = r.f + sf * pd * F; r.pdf += rc.pdf * pd * F;
+                V3 gf = ef;
                 if (ec && ec_g > 0.01f) gf = gf / ec_g;
-                r.f = r.f + gf * pg * F; r.pdf += e.pdf * pg * F;
+                r.f = r.f + gf * pg * F; r.pdf += rc.pdf * pg * F;
             }
         }
         if (refracted && valid_refr) {  // :240-252
-            Eval e = refraction(V, L, base);
+            Eval e = refraction(V, L, base, gv);
             if (ec && ec_g > 0.01f) e.f = e.f / ec_g;
             r.f = r.f + e.f * pg * (1.0f - F); r.pdf += e.pdf * pg * (1.0f - F);
         }

@@ -43,7 +43,8 @@ struct vpt_ctx {
     void* ps_block = nullptr;
     PathState ps{};
     uint32_t* queue[2] = {nullptr, nullptr};
-    ShadowRay* shadow = nullptr;
+    uint32_t* cqueue = nullptr;  // connect queue (two-ended)
+    int shade_blocks = 1024;
     Counters* ctr = nullptr;
     float* image = nullptr;       // this shard's rows, RGBA32F
     float* full_image = nullptr;  // whole image when shard_count > 1 (after vpt_assemble_shards)
@@ -103,8 +104,8 @@ void free_render_buffers(vpt_ctx* c) {
     if (c->ps_block) (void)hipFree(c->ps_block);
     c->ps_block = nullptr;
     for (int i = 0; i < 2; i++) { if (c->queue[i]) (void)hipFree(c->queue[i]); c->queue[i] = nullptr; }
-    if (c->shadow) (void)hipFree(c->shadow);
-    c->shadow = nullptr;
+    if (c->cqueue) (void)hipFree(c->cqueue);
+    c->cqueue = nullptr;
     if (c->image) (void)hipFree(c->image);
     c->image = nullptr;
     if (c->full_image) (void)hipFree(c->full_image);
@@ -126,38 +127,28 @@ int alloc_render_buffers(vpt_ctx* c) {
     P.shard_pixels = P.shard_rows * P.width;
     if (P.shard_pixels == 0) return fail(c, VPT_ERR_INVALID_ARGUMENT, "empty shard");
     uint32_t F = c->cfg.frames_in_flight;
-    if (F == 0) { F = (4u << 20) / P.shard_pixels; F = std::max(1u, std::min(F, 64u)); }
+    if (F == 0) { F = (32u << 20) / P.shard_pixels; F = std::max(1u, std::min(F, 64u)); }  // ~32M resident paths (8.4 GB of records)
     c->frames_in_flight = F;
     uint64_t cap64 = (uint64_t)P.shard_pixels * F;
     if (cap64 >= (1ull << 31)) return fail(c, VPT_ERR_INVALID_ARGUMENT, "too many paths in flight");
     uint32_t cap = (uint32_t)cap64;
-    const int kWords = 47;
+    // 15 float4 records + 3 dword arrays per slot (device_types.hpp PathState)
+    const size_t kRecords = 15, kWords = 3;
     size_t stride = ((size_t)cap + 63) & ~(size_t)63;
-    HIPCHK(c, hipMalloc(&c->ps_block, stride * 4 * kWords));
-    uint32_t* base = (uint32_t*)c->ps_block;
-    int k = 0;
-    auto nextf = [&]() { return (float*)(base + stride * (k++)); };
-    auto nextu = [&]() { return (uint32_t*)(base + stride * (k++)); };
+    HIPCHK(c, hipMalloc(&c->ps_block, stride * (16 * kRecords + 4 * kWords)));
+    float4* rb = (float4*)c->ps_block;
+    size_t k = 0;
+    auto next4 = [&]() { return rb + stride * (k++); };
     PathState& s = c->ps;
     s.capacity = cap;
-    s.rng = nextu();
-    s.ox = nextf(); s.oy = nextf(); s.oz = nextf();
-    s.dx = nextf(); s.dy = nextf(); s.dz = nextf();
-    s.tx = nextf(); s.ty = nextf(); s.tz = nextf();
-    s.lx = nextf(); s.ly = nextf(); s.lz = nextf();
-    s.bx = nextf(); s.by = nextf(); s.bz = nextf();
-    s.pdf = nextf();
-    s.depth = nextu(); s.medium_flag = nextu();
-    s.mdensity = nextf(); s.maniso = nextf(); s.mcr = nextf(); s.mcg = nextf(); s.mcb = nextf();
-    s.ht = nextf(); s.hu = nextf(); s.hv = nextf(); s.hprim = nextu(); s.hinst = nextu();
-    s.ex = nextf(); s.ey = nextf(); s.ez = nextf();
-    s.skx = nextf(); s.sky = nextf(); s.skz = nextf();
-    s.lgx = nextf(); s.lgy = nextf(); s.lgz = nextf();
-    s.vis = nextu();
-    s.ax = nextf(); s.ay = nextf(); s.az = nextf();
-    if (k > kWords) return fail(c, VPT_ERR_DEVICE, "internal: path state carve overflow");
+    s.A = next4(); s.B = next4(); s.T[0] = next4(); s.T[1] = next4(); s.H = next4();
+    s.CE = next4(); s.CS = next4(); s.CSO = next4(); s.CSD = next4(); s.CL = next4(); s.CLO = next4(); s.CLD = next4();
+    s.L = next4(); s.ACC = next4(); s.M = next4();
+    if (k != kRecords) return fail(c, VPT_ERR_DEVICE, "internal: path state carve mismatch");
+    uint32_t* wb = (uint32_t*)(rb + stride * kRecords);
+    s.hinst = wb; s.maniso = (float*)(wb + stride); s.sidx = wb + stride * 2;
     for (int i = 0; i < 2; i++) HIPCHK(c, hipMalloc((void**)&c->queue[i], (size_t)cap * 4));
-    HIPCHK(c, hipMalloc((void**)&c->shadow, (size_t)cap * 2 * sizeof(ShadowRay)));
+    HIPCHK(c, hipMalloc((void**)&c->cqueue, (size_t)cap * 4));
     HIPCHK(c, hipMalloc((void**)&c->image, (size_t)P.shard_pixels * 16));
     HIPCHK(c, hipMemset(c->image, 0, (size_t)P.shard_pixels * 16));
     if (P.shard_count > 1) {
@@ -266,38 +257,48 @@ void collect_timing(vpt_ctx* c) {  // call after a stream sync
         end_timing(ctx, eb_);                   \
     } while (0)
 
-// One batch of `frames` consecutive dispatches (frame_base = index of the first).
+// One batch of `frames` consecutive dispatches (frame_base = index of the first).  The bounce loop runs
+// without host round-trips: every stage reads its queue size from device memory, so the host only
+// checks the queue every few bounces (and right after max_depth bounces, when a surface-only batch is done).
 int render_batch(vpt_ctx* c, uint32_t frames, uint32_t dispatch_base, uint32_t frame_base) {
     const uint32_t n_slots = frames * c->P.shard_pixels;
     hipStream_t s = c->stream;
     Counters init{};
     init.ray_count[0] = n_slots;
-    HIPCHK(c, hipMemcpyAsync(c->ctr, &init, 32, hipMemcpyHostToDevice, s));  // counters only, keep stat_* running
+    HIPCHK(c, hipMemcpyAsync(c->ctr, &init, 32, hipMemcpyHostToDevice, s));  // queue words only, stat_* keep running
     TIMED(c, VPT_K_RAYGEN, launch_raygen(s, c->P, c->ps, c->queue[0], n_slots, dispatch_base));
-    uint32_t parity = 0, n = n_slots;
+    uint32_t parity = 0;
     const bool count = c->cfg.count_traversal != 0;
+    const uint64_t min_bounces = (uint64_t)c->P.max_depth * c->P.samples_per_frame;
+    const uint64_t iter_cap = min_bounces * 4ull + 1024ull;
     uint64_t iter = 0;
-    const uint64_t iter_cap = (uint64_t)c->P.max_depth * c->P.samples_per_frame * 4ull + 1024ull;
-    while (n > 0) {
-        launch_prepare(s, c->ctr, parity);
-        TIMED(c, VPT_K_EXTEND, launch_extend(s, (uint32_t)c->trav_blocks, c->lds_scene, count, c->dsc, c->ps, c->queue[parity], c->ctr, parity));
-        TIMED(c, VPT_K_SHADE, launch_shade(s, n, c->dsc, c->P, c->ps, c->queue[parity], c->shadow, c->ctr, parity));
-        TIMED(c, VPT_K_SHADOW, launch_shadow(s, (uint32_t)c->trav_blocks, c->lds_scene, count, c->dsc, c->ps, c->shadow, c->ctr));
-        TIMED(c, VPT_K_ACCUMULATE, launch_accumulate(s, n, c->P, c->ps, c->queue[parity], c->queue[parity ^ 1u], c->ctr, parity));
+    uint32_t chunk = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(min_bounces, 1), 8);
+    while (true) {
+        for (uint32_t j = 0; j < chunk; j++) {
+            launch_prepare(s, c->ctr, parity);
+            TIMED(c, VPT_K_EXTEND, launch_extend(s, (uint32_t)c->trav_blocks, c->lds_scene, count, c->dsc, c->ps, c->queue[parity], c->ctr, parity));
+            TIMED(c, VPT_K_SHADE, launch_shade(s, (uint32_t)c->shade_blocks, c->dsc, c->P, c->ps, c->queue[parity], c->queue[parity ^ 1u], c->cqueue, c->ctr, parity));
+            TIMED(c, VPT_K_CONNECT, launch_connect(s, (uint32_t)c->trav_blocks, c->lds_scene, count, c->dsc, c->P, c->ps, c->cqueue, c->ctr, parity));
+            parity ^= 1u;
+        }
+        iter += chunk;
+        launch_fold(s, c->ctr);
         Counters h{};
         HIPCHK(c, hipMemcpyAsync(&h, c->ctr, sizeof(Counters), hipMemcpyDeviceToHost, s));
         HIPCHK(c, hipStreamSynchronize(s));
         collect_timing(c);
-        c->stats.closest_rays += n;
-        c->stats.shadow_rays += h.shadow_count;
+        c->stats.closest_rays = h.stat_closest;
+        c->stats.shadow_rays = h.stat_shadow;
+        c->stats.connect_paths = h.stat_connect;
         c->stats.nodes_visited = h.stat_nodes;
         c->stats.tris_tested = h.stat_tris;
         c->stats.shadow_nodes_visited = h.stat_shadow_nodes;
         c->stats.shadow_tris_tested = h.stat_shadow_tris;
-        parity ^= 1u;
-        n = h.ray_count[parity];
+        uint32_t n = h.ray_count[parity];
         if (n > n_slots) return fail(c, VPT_ERR_DEVICE, "internal: queue overflow");
-        if (++iter > iter_cap) return fail(c, VPT_ERR_DEVICE, "internal: bounce loop did not terminate");
+        if (n == 0) break;
+        if (iter > iter_cap) return fail(c, VPT_ERR_DEVICE, "internal: bounce loop did not terminate");
+        chunk = 4;
     }
     TIMED(c, VPT_K_RESOLVE, launch_resolve(s, c->P, c->ps, c->image, frames, frame_base));
     HIPCHK(c, hipStreamSynchronize(s));
@@ -491,6 +492,7 @@ int vpt_set_scene(vpt_ctx* c, const vpt_scene_desc* sd) {
     // small scenes ride in LDS next to the traversal stacks
     c->lds_scene = ((size_t)D.node_count * 64 + (size_t)D.tri_count * 48) <= 16384;
     c->trav_blocks = traverse_blocks_per_cu(c->lds_scene, D) * c->cu_count;
+    c->shade_blocks = shade_blocks_per_cu() * c->cu_count;
     c->has_scene = true;
     HIPCHK(c, hipMemset(c->image, 0, (size_t)c->P.shard_pixels * 16));
     return VPT_OK;
@@ -525,6 +527,8 @@ int vpt_set_camera(vpt_ctx* c, const float* vi, const float* pi) {
 int vpt_set_params(vpt_ctx* c, const vpt_params* p) {
     if (!c || !p) return VPT_ERR_INVALID_ARGUMENT;
     if (p->samples_per_frame == 0 || p->samples_per_frame > 0xffffffu) return fail(c, VPT_ERR_INVALID_ARGUMENT, "samples_per_frame must be >= 1");
+    // MAX_DEPTH (Defines.slang:16) marks a finished path; a larger MaxDepth would make the reference loop forever on a miss
+    if (p->max_depth == 0 || p->max_depth > 1000000u) return fail(c, VPT_ERR_INVALID_ARGUMENT, "max_depth must be in [1, 1000000]");
     if (p->screen_chunk_count != 1) return fail(c, VPT_ERR_UNSUPPORTED, "split-screen dispatch (screen_chunk_count > 1) is not implemented in the HIP backend yet");
     if (!(p->flags & VPT_FLAG_RAY_QUERIES)) return fail(c, VPT_ERR_UNSUPPORTED, "only the USE_RAY_QUERIES semantics are implemented");
     c->params = *p;
