@@ -4,9 +4,10 @@
 Workload (config.workload = "cornell_1080p_d8"): BASELINE.json configs[1] — Assets/CornellBox as shipped
 (diffuse walls + emissive quad, strength 50), black environment, 1920x1080, max depth 8, 1 sample per
 pixel per frame, base seed 1.  A *step* is one wavefront batch of the hot path:
-every rank renders `frames_per_step` consecutive frames of its own rows (raygen -> [extend, shade,
-shadow, accumulate] until the ray queue is empty -> resolve).  Rows are dealt round-robin over ranks, each
-rank keeps ~4M paths resident, so per-GPU work per step is fixed (weak scaling) and
+every rank renders `frames_per_step` consecutive frames of its own rows (fused primary bounce, then one
+fused bounce kernel — or extend/shade/connect for scenes too big for LDS — per bounce until the ray queue is
+empty, then resolve).  Rows are dealt round-robin over ranks, each rank keeps ~32M paths resident, so
+per-GPU work per step is fixed (weak scaling) and
 
     value = (samples all ranks traced in the K timed steps) / (max over ranks of the wall time)
 
@@ -45,8 +46,9 @@ SHADE_RAY_OUT = 48                  # contribution|gid, origin|dir.x, dir.yz per
 SHADE_SCENE = 8 + 48 + 36 + 12 + 96 + 112 + 5 * 4 + (8 + 64) + (80 + 12 + 96 + 12 + 4) + 2 * 16  # instance, indices, 3 vertices, material, 5 1x1 texels, env alias + 4 texels, light entry + triangle, 2 LUT taps
 CONNECT_FIXED = 4 + 16 + 16 + 16 + 16   # queue id, CE, T (pre-update throughput), pathLight read + write
 CONNECT_RAY = 48                    # per shadow ray: the three records shade queued
-CONNECT_FINAL = 32                  # frame-sum read + write at the end of a sample
-RAYGEN_BYTES = 16 * 5 + 4           # records A, B, T, L, ACC + queue id
+CONNECT_FINAL = 16                  # frame-sum write at the end of a sample (samples_per_frame == 1)
+PRIMARY_DONE = 16                   # a path that ends at bounce 0 writes only its frame sum
+PRIMARY_ALIVE = 16 * 4 + 4          # a survivor writes records A, B, T, L and its queue id
 RESOLVE_BYTES = 16 + 32             # per (pixel, frame) sum in, plus image read+write (amortised over the frames of a batch)
 
 
@@ -150,15 +152,23 @@ def main():
 
     if rank == 0:
         # ---- per-kernel algorithmic bytes / measured HIP-event time (this rank's launches)
-        n_paths = st["closest_rays"]          # path-bounces shaded == rays extended
-        alive_frac = 1.0 - st["samples"] / max(n_paths, 1)      # every sample ends exactly once
+        n0 = st["samples"] // 1                # bounce 0 of every slot runs in the fused primary kernel
+        n_later = st["closest_rays"] - n0      # path-bounces that went through extend / shade
+        hits0, alive0, rays0 = st["primary_hits"], st["primary_survivors"], st["primary_shadow_rays"]
+        later_rays = st["shadow_rays"] - rays0
+        alive_later = max(n_later - alive0, 0)  # paths leaving bounce k >= 1 alive == paths entering bounce k+1
+        trav = nodes_per_ray * NODE_BYTES + tris_per_ray * TRI_BYTES
+        strav = snodes_per_ray * NODE_BYTES + stris_per_ray * TRI_BYTES
         units = {
-            "raygen": (st["samples"], RAYGEN_BYTES),
-            "extend": (n_paths, EXTEND_FIXED + nodes_per_ray * NODE_BYTES + tris_per_ray * TRI_BYTES),
-            "shade": (n_paths, SHADE_IN + SHADE_SCENE + SHADE_ALIVE_OUT * alive_frac + SHADE_PENDING_OUT * st["connect_paths"] / max(n_paths, 1)
-                      + SHADE_RAY_OUT * st["shadow_rays"] / max(n_paths, 1)),
-            "connect": (st["connect_paths"], CONNECT_FIXED + CONNECT_FINAL * st["samples"] / max(st["connect_paths"], 1)
-                        + (CONNECT_RAY + snodes_per_ray * NODE_BYTES + stris_per_ray * TRI_BYTES) * st["shadow_rays"] / max(st["connect_paths"], 1)),
+            # per slot: frame sum out for paths that end, records A,B,T,L + queue id for survivors, scene gathers
+            # per hit, node/triangle visits of the camera ray and of the bounce-0 shadow rays
+            "primary": (n0, (PRIMARY_DONE * (n0 - alive0) + PRIMARY_ALIVE * alive0 + SHADE_SCENE * hits0 + strav * rays0) / max(n0, 1) + trav),
+            # fused later bounce: records A,B,T,L in, the same out for survivors, frame sum for paths that end
+            "bounce": (n_later, 4 + 64 + SHADE_SCENE + trav + (PRIMARY_ALIVE * alive_later + PRIMARY_DONE * alive0 + strav * later_rays) / max(n_later, 1)),
+            "extend": (n_later, EXTEND_FIXED + trav),
+            "shade": (n_later, SHADE_IN + SHADE_SCENE + (SHADE_ALIVE_OUT * alive_later + SHADE_PENDING_OUT * st["connect_paths"]
+                                                         + SHADE_RAY_OUT * later_rays) / max(n_later, 1)),
+            "connect": (st["connect_paths"], CONNECT_FIXED + (CONNECT_FINAL * alive0 + (CONNECT_RAY + strav) * later_rays) / max(st["connect_paths"], 1)),
             "resolve": (st["samples"], RESOLVE_BYTES),
         }
         kernels = {}

@@ -166,15 +166,21 @@ typedef struct vpt_config {
     uint32_t frames_in_flight; /* 0 = choose so that ~32M paths are resident (at most 64 frames) */
     uint32_t profile;    /* 1 = bracket every kernel launch with hipEvents (vpt_get_stats kernel times) */
     uint32_t count_traversal; /* 1 = count BVH node/triangle visits (slower; for the roofline's algorithmic bytes) */
+    uint32_t pipeline;   /* VPT_PIPELINE_*: how bounces >= 1 run (bounce 0 is always the fused primary kernel) */
 } vpt_config;
+
+/* Bounces >= 1: AUTO = FUSED when the BVH fits in LDS next to the traversal stacks, else STAGED. Results are identical. */
+#define VPT_PIPELINE_AUTO 0u
+#define VPT_PIPELINE_FUSED 1u   /* one kernel per bounce */
+#define VPT_PIPELINE_STAGED 2u  /* extend -> shade -> connect with compacted queues */
 
 #define VPT_KERNEL_COUNT 8
 enum vpt_kernel_id {
-    VPT_K_RAYGEN = 0,
+    VPT_K_PRIMARY = 0,  /* bounce 0 fused: camera ray + extend + shade + connect */
     VPT_K_EXTEND = 1,
     VPT_K_SHADE = 2,
     VPT_K_CONNECT = 3,  /* shadow rays + light accumulation + end-of-sample */
-    VPT_K_RESERVED = 4,
+    VPT_K_BOUNCE = 4,   /* bounce >= 1 fused (LDS-resident scenes): extend + shade + connect in one kernel */
     VPT_K_RESOLVE = 5,
     VPT_K_BLOOM = 6,
     VPT_K_TONEMAP = 7
@@ -187,6 +193,9 @@ typedef struct vpt_stats {
     uint64_t closest_rays;     /* rays traced by the extend kernel */
     uint64_t shadow_rays;      /* rays traced by the connect kernel */
     uint64_t connect_paths;    /* path-bounces that went through the connect kernel */
+    uint64_t primary_hits;     /* camera rays that hit geometry */
+    uint64_t primary_survivors;   /* paths that continue after bounce 0 */
+    uint64_t primary_shadow_rays; /* shadow rays traced inside the primary kernel */
     uint64_t nodes_visited;    /* extend kernel, only when count_traversal */
     uint64_t tris_tested;      /* extend kernel, only when count_traversal */
     uint64_t shadow_nodes_visited; /* connect kernel, only when count_traversal */

@@ -143,8 +143,12 @@ VPT_HD float exp_(float x) {
     return y * pow2i_(a) * pow2i_(b);
 }
 
-// pow as the GPU drivers do it: exp(y*log(x)); x<0 -> NaN, pow(0,y>0)=0.
+// pow as the GPU drivers do it: exp(y*log(x)); x<0 -> NaN, pow(0,y>0)=0.  The two constant exponents the
+// path uses all over (pow(pdf, 2.0f) in PowerHeuristics, pow(., 2.0f) in the GGX distribution, pow(V.z, 1/2)
+// for the refraction table) fold to a multiply / a square root, as shader compilers fold them.
 VPT_HD float pow_(float x, float y) {
+    if (y == 2.0f) return x * x;
+    if (y == 0.5f) return sqrt_(x);
     if (y == 0.0f) return 1.0f;
     if (x == 0.0f) return (y > 0.0f) ? 0.0f : u2f(0x7f800000u);
     return exp_(y * log_(x));
@@ -214,7 +218,8 @@ VPT_HD V3 operator*(V3 a, V3 b) { return v3(a.x * b.x, a.y * b.y, a.z * b.z); }
 VPT_HD V3 operator*(V3 a, float s) { return v3(a.x * s, a.y * s, a.z * s); }
 VPT_HD V3 operator*(float s, V3 a) { return v3(a.x * s, a.y * s, a.z * s); }
 VPT_HD V3 operator/(V3 a, V3 b) { return v3(a.x / b.x, a.y / b.y, a.z / b.z); }
-VPT_HD V3 operator/(V3 a, float s) { return v3(a.x / s, a.y / s, a.z / s); }
+// vector / scalar: one IEEE reciprocal, three multiplies (how the shader compilers lower a splat divide)
+VPT_HD V3 operator/(V3 a, float s) { float r = 1.0f / s; return v3(a.x * r, a.y * r, a.z * r); }
 VPT_HD float dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 VPT_HD V3 cross(V3 a, V3 b) {
     return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);

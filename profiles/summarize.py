@@ -15,12 +15,14 @@ from collections import defaultdict
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 G = os.path.join(ROOT, "gpurun_out")
-STAGES = ["raygen", "extend", "shade", "shadow", "accumulate", "resolve", "connect", "bloom", "tonemap"]
+STAGES = ["primary", "bounce", "extend", "shade", "connect", "resolve", "bloom", "tonemap"]
 
 
 def stage_of(name):
-    if "<true, true>" in name or "<false, true>" in name:
+    if "<true, true" in name or "<false, true" in name:
         return None  # traversal-counting variants (short pre-pass of bench.py)
+    if "k_bounce" in name:
+        return "primary" if ", true>" in name else "bounce"  # k_bounce<LDS, COUNT, FIRST>
     for s in STAGES:
         if "k_" + s in name:
             return s

@@ -54,7 +54,7 @@ def test_bad_arguments_return_error_codes(vpt):
     lib = vpt.load_library()
     err = C.c_int(0)
     assert not lib.vpt_create(None, C.byref(err)) and err.value == -1
-    cfg = vpt._abi.Config(0, 0, 0, 0, 1, 0, 0, 0)
+    cfg = vpt._abi.Config(0, 0, 0, 0, 1, 0, 0, 0, 0)
     assert not lib.vpt_create(C.byref(cfg), C.byref(err)) and err.value == -1
     assert lib.vpt_render(None, 1, None) == -1
     assert lib.vpt_get_stats(None, None) == -1

@@ -57,9 +57,13 @@ def test_atan2_and_pow(oracle):
         got = oracle.fp32_eval("pow", b, np.full_like(b, e))
         ref = b.astype(np.float64) ** e
         assert (np.abs(got - ref) / ref).max() < 2e-6, e
-    # edge semantics used by the path: pow(0,y>0)=0, pow(x,0)=1, pow(<0)=NaN, overflow -> inf
-    edge = oracle.fp32_eval("pow", np.array([0, 3, -1, 1e20, 1], np.float32), np.array([2.2, 0, 2, 2, 7], np.float32))
+    # edge semantics used by the path: pow(0,y>0)=0, pow(x,0)=1, pow(<0, non-folded)=NaN, overflow -> inf
+    edge = oracle.fp32_eval("pow", np.array([0, 3, -1, 1e20, 1], np.float32), np.array([2.2, 0, 3, 2, 7], np.float32))
     assert edge[0] == 0 and edge[1] == 1 and np.isnan(edge[2]) and np.isinf(edge[3]) and edge[4] == 1
+    # constant exponents 2 and 0.5 fold to x*x and sqrt(x) exactly
+    x = np.array([3.0, -1.5, 0.3, 1e-20], np.float32)
+    assert np.array_equal(oracle.fp32_eval("pow", x, np.full_like(x, 2.0)), x * x)
+    assert np.array_equal(oracle.fp32_eval("pow", np.abs(x), np.full_like(x, 0.5)), np.sqrt(np.abs(x)))
 
 
 def test_special_values(oracle):

@@ -123,6 +123,21 @@ def test_material_classes(vpt, oracle, scenes):
     assert_parity(img, ref)
 
 
+@pytest.mark.parametrize("name", ["cornell_box", "cornell_box_glass", "viking_room"])
+@pytest.mark.parametrize("pipeline", [1, 2])
+def test_both_pipelines_match_the_oracle(vpt, oracle, scenes, name, pipeline):
+    """Bounces >= 1 run either fused (one kernel per bounce) or staged (extend / shade / connect with compacted
+    queues); AUTO picks by BVH size, so both are forced here on small and large scenes alike."""
+    sc = copy.deepcopy(scenes(name))
+    sc.env = vpt.scenes.sun_sky_env(64, 32, seed=4, sun_peak=80.0)
+    p = vpt.default_params(max_depth=10, samples_per_frame=2)
+    img, ref, st, ctr = render_both(vpt, oracle, sc, 144, 81, p, 3, pipeline=pipeline)
+    assert_parity(img, ref)
+    assert st["closest_rays"] == ctr["closest"]
+    launched = st["kernel_launches"]
+    assert (launched["bounce"] > 0) == (pipeline == 1) and (launched["extend"] > 0) == (pipeline == 2)
+
+
 def test_frames_in_flight_do_not_change_the_image(vpt, oracle, scenes):
     """Several frames share one wavefront batch; the running mean is still applied in frame order."""
     sc = scenes("cornell_box")

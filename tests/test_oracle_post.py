@@ -40,7 +40,7 @@ def np_post(img, pp, linear=True):
         for a in range(-2, 2):
             for b in range(-2, 2):
                 acc = acc + src[np.clip(2 * ys + b, 0, ih - 1), np.clip(2 * xs + a, 0, iw - 1)]
-        mips.append(acc / f(25) * f(pp.bloom_strength))
+        mips.append(acc * (f(1) / f(25)) * f(pp.bloom_strength))  # float3 / float == multiply by the reciprocal (fp32 contract)
     for i in range(mc - 1, 0, -1):
         src, dst = mips[i], mips[i - 1]
         ih, iw = src.shape[:2]
@@ -50,7 +50,7 @@ def np_post(img, pp, linear=True):
         for a in range(-2, 2):
             for b in range(-2, 2):
                 acc = acc + src[np.clip(ys // 2 + b + 1, 0, ih - 1), np.clip(xs // 2 + a + 1, 0, iw - 1)]
-        mips[i - 1] = acc / f(25) * f(pp.bloom_strength) + dst
+        mips[i - 1] = acc * (f(1) / f(25)) * f(pp.bloom_strength) + dst
     return mips[0]
 
 

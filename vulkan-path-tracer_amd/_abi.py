@@ -18,8 +18,9 @@ FLAG_TONEMAP_LINEAR_BLOOM_TAP = 1 << 7
 FLAGS_DEFAULT = (FLAG_SKY_MIS | FLAG_MESH_MIS | FLAG_SHOW_ENV_DIRECTLY | FLAG_ENERGY_COMPENSATION |
                  FLAG_RAY_QUERIES | FLAG_TONEMAP_LINEAR_BLOOM_TAP)
 
-KERNEL_NAMES = ["raygen", "extend", "shade", "connect", "reserved", "resolve", "bloom", "tonemap"]
+KERNEL_NAMES = ["primary", "extend", "shade", "connect", "bounce", "resolve", "bloom", "tonemap"]
 KERNEL_COUNT = 8
+PIPELINE_AUTO, PIPELINE_FUSED, PIPELINE_STAGED = 0, 1, 2
 
 
 class Material(C.Structure):
@@ -99,13 +100,13 @@ def default_post_params(**kw):
 class Config(C.Structure):
     _fields_ = [("device", C.c_int), ("width", C.c_uint32), ("height", C.c_uint32), ("shard_rank", C.c_uint32),
                 ("shard_count", C.c_uint32), ("frames_in_flight", C.c_uint32), ("profile", C.c_uint32),
-                ("count_traversal", C.c_uint32)]
+                ("count_traversal", C.c_uint32), ("pipeline", C.c_uint32)]
 
 
 class Stats(C.Structure):
     _fields_ = [
         ("samples", C.c_uint64), ("frames", C.c_uint64), ("dispatches", C.c_uint64), ("closest_rays", C.c_uint64),
-        ("shadow_rays", C.c_uint64), ("connect_paths", C.c_uint64), ("nodes_visited", C.c_uint64), ("tris_tested", C.c_uint64),
+        ("shadow_rays", C.c_uint64), ("connect_paths", C.c_uint64), ("primary_hits", C.c_uint64), ("primary_survivors", C.c_uint64), ("primary_shadow_rays", C.c_uint64), ("nodes_visited", C.c_uint64), ("tris_tested", C.c_uint64),
         ("shadow_nodes_visited", C.c_uint64), ("shadow_tris_tested", C.c_uint64),
         ("kernel_launches", C.c_uint64 * KERNEL_COUNT), ("kernel_ms", C.c_double * KERNEL_COUNT),
         ("total_vertex_count", C.c_uint64), ("total_index_count", C.c_uint64),

@@ -126,6 +126,7 @@ struct Counters {
     unsigned long long stat_closest, stat_shadow, stat_connect;  // folded per bounce by k_prepare / k_fold
     unsigned long long stat_nodes, stat_tris;                // extend kernel (count_traversal builds only)
     unsigned long long stat_shadow_nodes, stat_shadow_tris;  // connect kernel
+    unsigned long long stat_primary_hits, stat_primary_alive, stat_primary_rays;  // bounce 0: hits, survivors, shadow rays
 };
 
 }  // namespace vpt

@@ -1,6 +1,6 @@
 // kernels_path.hip — wavefront integrator stages for gfx950.
 //
-//   raygen     RayGen.slang:12-64     pixel/frame -> camera ray, path state, full queue
+//   primary    bounce 0 fused: camera ray (RayGen.slang:12-64) + everything below for the first hit
 //   extend     RayGen.slang:90        persistent-threads closest-hit traversal over the ray queue
 //   shade      ClosestHit.slang + Miss.slang: surface, material, NEE sampling, BSDF sampling;
 //              emits <=2 shadow rays per path into a wave-compacted shadow queue
@@ -43,26 +43,6 @@ __device__ inline void pixel_of_slot(const RenderParams& P, uint32_t slot, uint3
     uint32_t ys = sp / P.width;
     x = sp - ys * P.width;
     y = P.shard_rank + P.shard_count * ys;
-}
-
-// ------------------------------------------------------------------ raygen
-__global__ __launch_bounds__(256) void k_raygen(RenderParams P, PathState ps, uint32_t* queue, uint32_t n_slots,
-                                                uint32_t dispatch_base) {
-    uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
-    if (slot >= n_slots) return;
-    uint32_t x, y, f;
-    pixel_of_slot(P, slot, x, y, f);
-    uint32_t seed = pcg_hash(P.base_seed + dispatch_base + f);  // PathTracer.cpp:139 with an explicit seed
-    Rng r; r.s = y + P.width * x + seed;                        // RayGen.slang:28
-    V3 o, d;
-    camera_ray(P, r, x, y, o, d);
-    ps.A[slot] = f4u(o, r.s);
-    ps.B[slot] = f4u(d, 0u);
-    ps.T[0][slot] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);  // pathThroughput = 1, payload.PDF = 1
-    ps.L[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    ps.ACC[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    if (P.samples_per_frame > 1) ps.sidx[slot] = 0u;
-    queue[slot] = slot;
 }
 
 // ------------------------------------------------------------------ persistent work fetch
@@ -151,17 +131,36 @@ __global__ __launch_bounds__(kTraverseBlock) void k_trace_rays(DeviceScene sc, c
 // Result bits of shade_path()
 constexpr uint32_t kSP_Alive = 1u, kSP_Front = 2u, kSP_Back = 4u;  // bits 3-4: number of shadow rays queued
 
-__device__ __forceinline__ uint32_t shade_path(const DeviceScene& sc, const RenderParams& P, const PathState& ps,
-                                               const float4* Tin, float4* Tout, uint32_t slot) {
-    bool alive = false, want_sky = false, want_light = false, pending = false;
-    float4 a = ps.A[slot], b = ps.B[slot], t = Tin[slot], h = ps.H[slot];
-    Rng rng; rng.s = __float_as_uint(a.w);
-    V3 porg = xyz(a), pdir = xyz(b);           // payload.Origin / payload.Direction
-    uint32_t dw = __float_as_uint(b.w);
-    uint32_t depth = dw & 0x7fffffffu;         // payload.Depth
-    bool in_medium = (dw >> 31) != 0u;         // payload.InMedium
-    V3 thr_prev = xyz(t);                      // pathThroughput before this bounce
-    float prev_pdf = t.w;                      // payload.PDF of the previous bounce
+struct ShadeIn {
+    uint32_t rng;
+    V3 porg, pdir;      // payload.Origin / payload.Direction
+    uint32_t depth;     // payload.Depth
+    bool in_medium;     // payload.InMedium
+    V3 thr_prev;        // pathThroughput before this bounce
+    float prev_pdf;     // payload.PDF of the previous bounce
+    float4 h;           // hit record t,u,v | PrimitiveIndex (t < 0: miss)
+    uint32_t inst;      // InstanceIndex
+};
+struct ShadeOut {
+    bool alive, terminated, want_sky, want_light, in_medium;
+    uint32_t rng, new_depth, cflags, light_gid;
+    V3 new_o, new_d, thr;
+    float new_pdf;
+    V3 emitted, csky, clight, sky_o, sky_d, light_o, light_d;
+};
+
+// The miss / closest-hit shader and the visibility-independent tail of the bounce loop for ONE path, on
+// values held in registers (the callers own every load/store of the path records).
+__device__ __forceinline__ void shade_core(const DeviceScene& sc, const RenderParams& P, const PathState& ps, uint32_t slot,
+                                           const ShadeIn& in_, ShadeOut& out) {
+    bool alive = false, want_sky = false, want_light = false;
+    const float4 h = in_.h;
+    Rng rng; rng.s = in_.rng;
+    const V3 porg = in_.porg, pdir = in_.pdir;
+    const uint32_t depth = in_.depth;
+    bool in_medium = in_.in_medium;
+    const V3 thr_prev = in_.thr_prev;
+    const float prev_pdf = in_.prev_pdf;
     V3 emitted = v3s(0.0f), csky = v3s(0.0f), clight = v3s(0.0f);
     V3 sky_o = v3s(0.0f), sky_d = v3s(0.0f), light_o = v3s(0.0f), light_d = v3s(0.0f);
     uint32_t light_gid = 0xffffffffu;
@@ -184,7 +183,7 @@ __device__ __forceinline__ uint32_t shade_path(const DeviceScene& sc, const Rend
     } else {
         // ---- ClosestHit.slang:20-378
         V3 rd = normalize(pdir);  // WorldRayDirection()
-        uint32_t inst_id = ps.hinst[slot];
+        uint32_t inst_id = in_.inst;
         const InstanceDesc& in = sc.instances[inst_id];
         const vpt_material& mat = sc.materials[in.material];
         SurfaceFrame s;
@@ -317,29 +316,51 @@ __device__ __forceinline__ uint32_t shade_path(const DeviceScene& sc, const Rend
     } else {
         alive = true;
     }
-    if (alive) {
-        ps.A[slot] = f4u(new_o, rng.s);
-        ps.B[slot] = f4u(new_d, new_depth | (in_medium ? 0x80000000u : 0u));
-        Tout[slot] = f4(thr, new_pdf);
+    out.alive = alive; out.terminated = terminated; out.want_sky = want_sky; out.want_light = want_light; out.in_medium = in_medium;
+    out.rng = rng.s; out.new_depth = new_depth; out.cflags = cflags; out.light_gid = light_gid;
+    out.new_o = new_o; out.new_d = new_d; out.thr = thr; out.new_pdf = new_pdf;
+    out.emitted = emitted; out.csky = csky; out.clight = clight;
+    out.sky_o = sky_o; out.sky_d = sky_d; out.light_o = light_o; out.light_d = light_d;
+}
+
+__device__ __forceinline__ uint32_t shade_path(const DeviceScene& sc, const RenderParams& P, const PathState& ps,
+                                               const float4* Tin, float4* Tout, uint32_t slot) {
+    float4 a = ps.A[slot], b = ps.B[slot], t = Tin[slot];
+    ShadeIn in_;
+    in_.h = ps.H[slot];
+    in_.inst = in_.h.x < 0.0f ? 0u : ps.hinst[slot];
+    in_.rng = __float_as_uint(a.w);
+    in_.porg = xyz(a); in_.pdir = xyz(b);
+    uint32_t dw = __float_as_uint(b.w);
+    in_.depth = dw & 0x7fffffffu; in_.in_medium = (dw >> 31) != 0u;
+    in_.thr_prev = xyz(t); in_.prev_pdf = t.w;
+    ShadeOut o;
+    shade_core(sc, P, ps, slot, in_, o);
+    if (o.alive) {
+        ps.A[slot] = f4u(o.new_o, o.rng);
+        ps.B[slot] = f4u(o.new_d, o.new_depth | (o.in_medium ? 0x80000000u : 0u));
+        Tout[slot] = f4(o.thr, o.new_pdf);
     }
-    bool thr_finite = !isinf_(thr_prev.x) && !isinf_(thr_prev.y) && !isinf_(thr_prev.z) && !isnan_(thr_prev.x) && !isnan_(thr_prev.y) && !isnan_(thr_prev.z);
-    pending = want_sky || want_light || terminated || emitted.x != 0.0f || emitted.y != 0.0f || emitted.z != 0.0f || !thr_finite;
+    const V3 tp = in_.thr_prev;
+    bool thr_finite = !isinf_(tp.x) && !isinf_(tp.y) && !isinf_(tp.z) && !isnan_(tp.x) && !isnan_(tp.y) && !isnan_(tp.z);
+    // 0 * inf = NaN must still reach pathLight, so a non-finite throughput always goes through connect
+    bool pending = o.want_sky || o.want_light || o.terminated || o.emitted.x != 0.0f || o.emitted.y != 0.0f || o.emitted.z != 0.0f || !thr_finite;
     if (pending) {
-        ps.CE[slot] = f4u(emitted, cflags);
-        if (want_sky) {
-            ps.CS[slot] = f4(csky, 0.0f);
-            ps.CSO[slot] = f4(sky_o, sky_d.x);
-            ps.CSD[slot] = make_float4(sky_d.y, sky_d.z, 0.0f, 0.0f);
+        ps.CE[slot] = f4u(o.emitted, o.cflags);
+        if (o.want_sky) {
+            ps.CS[slot] = f4(o.csky, 0.0f);
+            ps.CSO[slot] = f4(o.sky_o, o.sky_d.x);
+            ps.CSD[slot] = make_float4(o.sky_d.y, o.sky_d.z, 0.0f, 0.0f);
         }
-        if (want_light) {
-            ps.CL[slot] = f4u(clight, light_gid);
-            ps.CLO[slot] = f4(light_o, light_d.x);
-            ps.CLD[slot] = make_float4(light_d.y, light_d.z, 0.0f, 0.0f);
+        if (o.want_light) {
+            ps.CL[slot] = f4u(o.clight, o.light_gid);
+            ps.CLO[slot] = f4(o.light_o, o.light_d.x);
+            ps.CLD[slot] = make_float4(o.light_d.y, o.light_d.z, 0.0f, 0.0f);
         }
     }
-    bool has_rays = want_sky || want_light;
-    return (alive ? kSP_Alive : 0u) | ((pending && has_rays) ? kSP_Front : 0u) | ((pending && !has_rays) ? kSP_Back : 0u) |
-           (((want_sky ? 1u : 0u) + (want_light ? 1u : 0u)) << 3);
+    bool has_rays = o.want_sky || o.want_light;
+    return (o.alive ? kSP_Alive : 0u) | ((pending && has_rays) ? kSP_Front : 0u) | ((pending && !has_rays) ? kSP_Back : 0u) |
+           (((o.want_sky ? 1u : 0u) + (o.want_light ? 1u : 0u)) << 3);
 }
 
 // A block shades tiles of cpt x 256 paths (cpt = 1..4 per thread) and reserves queue space with ONE atomic
@@ -403,6 +424,150 @@ __global__ __launch_bounds__(256, 3) void k_shade(DeviceScene sc, RenderParams P
     }
 }
 
+// ------------------------------------------------------------------ primary: bounce 0, fully fused
+// Bounce 0 is ~60 % of all path-bounces of a frame (every pixel has one; later bounces only see the
+// survivors), its rays are coherent, and nothing about it has to be read from memory: the slot id gives
+// pixel and frame, hence seed, RNG state and camera ray (RayGen.slang:12-64).  So the first bounce runs as one
+// kernel — camera ray, closest hit, miss/closest-hit shader, the <= 2 shadow rays, contribution, Russian
+// roulette — and only survivors write their records (A, B, T, L) and enter the wavefront queues.
+// Finished paths write just the frame sum.  pathThroughput is 1 and pathLight is 0 on entry.
+// The same kernel with FIRST = false runs every later bounce of scenes whose BVH rides in LDS (traversal is
+// then a handful of LDS reads, so a separate extend/connect stage would only move records through HBM):
+// it reads a queued path's records A, B, T, L, does the whole bounce, and writes them back for survivors.
+template <bool LDS_SCENE, bool COUNT, bool FIRST>
+__global__ __launch_bounds__(kTraverseBlock, 3) void k_bounce(DeviceScene sc, RenderParams P, PathState ps, const uint32_t* queue,
+                                                             uint32_t* queue_next, Counters* ctr, uint32_t parity, uint32_t n_slots,
+                                                             uint32_t dispatch_base) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ uint32_t s_cnt[4][3];
+    __shared__ uint32_t s_base[4];
+    uint32_t* stack = reinterpret_cast<uint32_t*>(smem) + threadIdx.x;
+    float4* lds_nodes = reinterpret_cast<float4*>(smem + kStackDepth * kTraverseBlock * 4);
+    float4* lds_tris = lds_nodes + sc.node_count * 4;
+    stage_scene<LDS_SCENE>(sc, lds_nodes, lds_tris);
+    const uint32_t n = FIRST ? n_slots : ctr->ray_count[parity];
+    const float4* Tin = ps.T[parity];
+    float4* Tout = ps.T[parity ^ 1u];
+    const uint32_t wave = threadIdx.x >> 6;
+    uint32_t cpt = (n + (1u << 21) - 1u) >> 21;
+    cpt = cpt < 1u ? 1u : (cpt > 4u ? 4u : cpt);
+    const uint32_t tile_size = cpt * 256u;
+    TravStats st, sst; st.nodes = 0; st.tris = 0; sst.nodes = 0; sst.tris = 0;
+    if (FIRST && blockIdx.x == 0 && threadIdx.x == 0) ctr->stat_closest += n;
+    for (uint32_t tile = blockIdx.x * tile_size; tile < n; tile += gridDim.x * tile_size) {
+        uint32_t res = 0u;  // bit c: path c of this lane survives
+        uint32_t s0 = 0u, s1 = 0u, s2 = 0u, s3 = 0u;
+        uint32_t tot_alive = 0u, tot_rays = 0u, tot_hits = 0u;
+#pragma unroll 1
+        for (uint32_t c = 0; c < cpt; c++) {
+            uint32_t idx = tile + c * 256u + threadIdx.x;
+            uint32_t slot = idx;
+            bool alive = false, hit = false;
+            uint32_t nrays = 0u;
+            if (idx < n) {
+                ShadeIn in_;
+                V3 light_prev = v3s(0.0f);
+                if (FIRST) {
+                    uint32_t x, y, f;
+                    pixel_of_slot(P, slot, x, y, f);
+                    uint32_t seed = pcg_hash(P.base_seed + dispatch_base + f);  // PathTracer.cpp:139 with an explicit seed
+                    Rng r; r.s = y + P.width * x + seed;                        // RayGen.slang:28
+                    camera_ray(P, r, x, y, in_.porg, in_.pdir);
+                    in_.rng = r.s; in_.depth = 0u; in_.in_medium = false; in_.thr_prev = v3s(1.0f); in_.prev_pdf = 1.0f;
+                    if (P.samples_per_frame > 1) ps.sidx[slot] = 0u;
+                } else {
+                    slot = queue[idx];
+                    float4 a = ps.A[slot], b = ps.B[slot], t = Tin[slot];
+                    in_.rng = __float_as_uint(a.w);
+                    in_.porg = xyz(a); in_.pdir = xyz(b);
+                    uint32_t dw = __float_as_uint(b.w);
+                    in_.depth = dw & 0x7fffffffu; in_.in_medium = (dw >> 31) != 0u;
+                    in_.thr_prev = xyz(t); in_.prev_pdf = t.w;
+                    light_prev = xyz(ps.L[slot]);
+                }
+                HitRec hr;
+                hit = trace_any<LDS_SCENE, COUNT>(sc, lds_nodes, lds_tris, in_.porg, normalize(in_.pdir), 0.01f, 100000.0f, stack, hr, st);
+                in_.h = make_float4(hit ? hr.t : -1.0f, hr.u, hr.v, __uint_as_float(hr.prim));
+                in_.inst = hr.inst;
+                ShadeOut o;
+                shade_core(sc, P, ps, slot, in_, o);
+                // connect, inline (RayGen.slang:92-102; FIRST: pathThroughput == 1, pathLight == 0)
+                V3 E = o.emitted;
+                if (o.want_sky) {
+                    HitRec h2;
+                    bool found = trace_any<LDS_SCENE, COUNT>(sc, lds_nodes, lds_tris, o.sky_o, o.sky_d, 0.0001f, 1000000.0f, stack, h2, sst);
+                    if (!found) E = E + o.csky;
+                    nrays++;
+                }
+                if (o.want_light) {
+                    HitRec h2;
+                    bool found = trace_any<LDS_SCENE, COUNT>(sc, lds_nodes, lds_tris, o.light_o, o.light_d, 0.0001f, 1000000.0f, stack, h2, sst);
+                    if (found && h2.gid == o.light_gid) E = E + o.clight;
+                    nrays++;
+                }
+                V3 contrib = E * in_.thr_prev;
+                if (o.cflags & kCF_Clamp) {
+                    float lum = dot(contrib, v3(0.212671f, 0.715160f, 0.072169f));
+                    contrib = contrib * (P.max_luminance / max_(lum, P.max_luminance));
+                }
+                V3 light = light_prev + contrib;
+                if (o.terminated) {  // end of a sample: NaN/Inf guard, frame sum (RayGen.slang:116-128)
+                    bool ok = !isinf_(light.x) && !isinf_(light.y) && !isinf_(light.z) && !isnan_(light.x) && !isnan_(light.y) && !isnan_(light.z);
+                    if (FIRST || P.samples_per_frame == 1) {  // first (or only) finalisation of the slot: 0 + pathLight
+                        ps.ACC[slot] = ok ? f4(v3s(0.0f) + light, 0.0f) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    } else if (ok) {
+                        float4 acc = ps.ACC[slot]; ps.ACC[slot] = f4(xyz(acc) + light, 0.0f);
+                    }
+                    light = v3s(0.0f);
+                } else if (FIRST && P.samples_per_frame > 1) {
+                    ps.ACC[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // later finalisations add to it
+                }
+                alive = o.alive;
+                if (alive) {
+                    ps.A[slot] = f4u(o.new_o, o.rng);
+                    ps.B[slot] = f4u(o.new_d, o.new_depth | (o.in_medium ? 0x80000000u : 0u));
+                    Tout[slot] = f4(o.thr, o.new_pdf);
+                    ps.L[slot] = f4(light, 0.0f);
+                }
+            }
+            s0 = (c == 0u) ? slot : s0; s1 = (c == 1u) ? slot : s1; s2 = (c == 2u) ? slot : s2; s3 = (c == 3u) ? slot : s3;
+            res |= (alive ? 1u : 0u) << c;
+            tot_alive += (uint32_t)__popcll(__ballot(alive));
+            tot_rays += (uint32_t)__popcll(__ballot(nrays >= 1u)) + (uint32_t)__popcll(__ballot(nrays >= 2u));
+            tot_hits += (uint32_t)__popcll(__ballot(hit));
+        }
+        if (lane_id() == 0) { s_cnt[wave][0] = tot_alive; s_cnt[wave][1] = tot_rays; s_cnt[wave][2] = tot_hits; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t sum = 0u, rays = 0u, hits = 0u, pre[4];
+            for (uint32_t w = 0; w < 4; w++) { pre[w] = sum; sum += s_cnt[w][0]; rays += s_cnt[w][1]; hits += s_cnt[w][2]; }
+            uint32_t b = sum ? atomicAdd(&ctr->ray_count[parity ^ 1u], sum) : 0u;
+            if (rays) atomicAdd(&ctr->shadow_rays, rays);
+            if (FIRST) {
+                if (hits) atomicAdd(&ctr->stat_primary_hits, (unsigned long long)hits);
+                if (sum) atomicAdd(&ctr->stat_primary_alive, (unsigned long long)sum);
+                if (rays) atomicAdd(&ctr->stat_primary_rays, (unsigned long long)rays);
+            }
+            for (uint32_t w = 0; w < 4; w++) s_base[w] = b + pre[w];
+        }
+        __syncthreads();
+        uint32_t o_alive = s_base[wave];
+#pragma unroll
+        for (uint32_t c = 0; c < 4; c++) {
+            bool alive = ((res >> c) & 1u) != 0u;
+            unsigned long long ma = __ballot(alive);
+            if (alive) queue_next[o_alive + lanes_below(ma)] = c == 0u ? s0 : (c == 1u ? s1 : (c == 2u ? s2 : s3));
+            o_alive += (uint32_t)__popcll(ma);
+        }
+    }
+    if (COUNT) {
+        atomicAdd(&ctr->stat_nodes, (unsigned long long)st.nodes);
+        atomicAdd(&ctr->stat_tris, (unsigned long long)st.tris);
+        atomicAdd(&ctr->stat_shadow_nodes, (unsigned long long)sst.nodes);
+        atomicAdd(&ctr->stat_shadow_tris, (unsigned long long)sst.tris);
+    }
+}
+
 // ------------------------------------------------------------------ connect
 // Per pending path: trace its (<= 2) shadow rays (RTCommon.slang:47-64: closest committed hit), join the
 // visible NEE contributions with the emission BEFORE the luminance clamp (RayGen.slang:92-102), add to
@@ -451,7 +616,11 @@ __global__ __launch_bounds__(kTraverseBlock) void k_connect(DeviceScene sc, Rend
             V3 light = xyz(ps.L[slot]) + contrib;
             if (flags & kCF_Finalize) {
                 bool ok = !isinf_(light.x) && !isinf_(light.y) && !isinf_(light.z) && !isnan_(light.x) && !isnan_(light.y) && !isnan_(light.z);
-                if (ok) { float4 acc = ps.ACC[slot]; ps.ACC[slot] = f4(xyz(acc) + light, 0.0f); }
+                if (P.samples_per_frame == 1) {  // the only finalisation of this slot: 0 + pathLight
+                    ps.ACC[slot] = ok ? f4(v3s(0.0f) + light, 0.0f) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                } else if (ok) {
+                    float4 acc = ps.ACC[slot]; ps.ACC[slot] = f4(xyz(acc) + light, 0.0f);
+                }
                 light = v3s(0.0f);  // a regenerated sample starts from pathLight = 0
             }
             ps.L[slot] = f4(light, 0.0f);
@@ -505,8 +674,28 @@ __global__ __launch_bounds__(256) void k_scatter_rows(const float4* gathered, fl
 // ------------------------------------------------------------------ launch wrappers
 static inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
-void launch_raygen(hipStream_t s, const RenderParams& P, const PathState& ps, uint32_t* queue, uint32_t n_slots, uint32_t dispatch_base) {
-    hipLaunchKernelGGL(k_raygen, dim3(cdiv(n_slots, 256)), dim3(256), 0, s, P, ps, queue, n_slots, dispatch_base);
+// first == true: bounce 0 of n_slots fresh slots (queue unused); otherwise one fused bounce of queue[parity].
+void launch_bounce(hipStream_t s, uint32_t blocks, bool lds_scene, bool count, bool first, const DeviceScene& sc, const RenderParams& P,
+                   const PathState& ps, const uint32_t* queue, uint32_t* queue_next, Counters* ctr, uint32_t parity, uint32_t n_slots,
+                   uint32_t dispatch_base) {
+    size_t lds = traverse_lds_bytes(sc, lds_scene);
+    dim3 g(blocks), b(kTraverseBlock);
+#define VPT_LAUNCH_BOUNCE(L, C, F) hipLaunchKernelGGL((k_bounce<L, C, F>), g, b, lds, s, sc, P, ps, queue, queue_next, ctr, parity, n_slots, dispatch_base)
+    if (lds_scene) {
+        if (count) { if (first) VPT_LAUNCH_BOUNCE(true, true, true); else VPT_LAUNCH_BOUNCE(true, true, false); }
+        else { if (first) VPT_LAUNCH_BOUNCE(true, false, true); else VPT_LAUNCH_BOUNCE(true, false, false); }
+    } else {
+        if (count) { if (first) VPT_LAUNCH_BOUNCE(false, true, true); else VPT_LAUNCH_BOUNCE(false, true, false); }
+        else { if (first) VPT_LAUNCH_BOUNCE(false, false, true); else VPT_LAUNCH_BOUNCE(false, false, false); }
+    }
+#undef VPT_LAUNCH_BOUNCE
+}
+int bounce_blocks_per_cu(bool lds_scene, const DeviceScene& sc) {
+    int nb = 0;
+    size_t lds = traverse_lds_bytes(sc, lds_scene);
+    if (lds_scene) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_bounce<true, false, false>, kTraverseBlock, lds);
+    else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_bounce<false, false, false>, kTraverseBlock, lds);
+    return nb > 0 ? nb : 1;
 }
 void launch_prepare(hipStream_t s, Counters* ctr, uint32_t parity) { hipLaunchKernelGGL(k_prepare, dim3(1), dim3(1), 0, s, ctr, parity); }
 void launch_fold(hipStream_t s, Counters* ctr) { hipLaunchKernelGGL(k_fold, dim3(1), dim3(1), 0, s, ctr); }

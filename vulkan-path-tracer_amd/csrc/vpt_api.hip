@@ -44,7 +44,7 @@ struct vpt_ctx {
     PathState ps{};
     uint32_t* queue[2] = {nullptr, nullptr};
     uint32_t* cqueue = nullptr;  // connect queue (two-ended)
-    int shade_blocks = 1024;
+    int shade_blocks = 1024, primary_blocks = 768;
     Counters* ctr = nullptr;
     float* image = nullptr;       // this shard's rows, RGBA32F
     float* full_image = nullptr;  // whole image when shard_count > 1 (after vpt_assemble_shards)
@@ -263,19 +263,26 @@ void collect_timing(vpt_ctx* c) {  // call after a stream sync
 int render_batch(vpt_ctx* c, uint32_t frames, uint32_t dispatch_base, uint32_t frame_base) {
     const uint32_t n_slots = frames * c->P.shard_pixels;
     hipStream_t s = c->stream;
-    Counters init{};
-    init.ray_count[0] = n_slots;
-    HIPCHK(c, hipMemcpyAsync(c->ctr, &init, 32, hipMemcpyHostToDevice, s));  // queue words only, stat_* keep running
-    TIMED(c, VPT_K_RAYGEN, launch_raygen(s, c->P, c->ps, c->queue[0], n_slots, dispatch_base));
-    uint32_t parity = 0;
     const bool count = c->cfg.count_traversal != 0;
+    Counters init{};
+    HIPCHK(c, hipMemcpyAsync(c->ctr, &init, 32, hipMemcpyHostToDevice, s));  // queue words only, stat_* keep running
+    // bounce 0 of every slot, fused; survivors land in queue[1]
+    TIMED(c, VPT_K_PRIMARY, launch_bounce(s, (uint32_t)c->primary_blocks, c->lds_scene, count, true, c->dsc, c->P, c->ps, nullptr, c->queue[1], c->ctr, 0u, n_slots, dispatch_base));
+    // later bounces: fused when the BVH rides in LDS, staged (extend / shade / connect) otherwise
+    const bool fused = c->cfg.pipeline == VPT_PIPELINE_FUSED || (c->cfg.pipeline == VPT_PIPELINE_AUTO && c->lds_scene);
+    uint32_t parity = 1;
     const uint64_t min_bounces = (uint64_t)c->P.max_depth * c->P.samples_per_frame;
     const uint64_t iter_cap = min_bounces * 4ull + 1024ull;
     uint64_t iter = 0;
-    uint32_t chunk = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(min_bounces, 1), 8);
+    uint32_t chunk = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(min_bounces - 1, 1), 8);
     while (true) {
         for (uint32_t j = 0; j < chunk; j++) {
             launch_prepare(s, c->ctr, parity);
+            if (fused) {
+                TIMED(c, VPT_K_BOUNCE, launch_bounce(s, (uint32_t)c->primary_blocks, c->lds_scene, count, false, c->dsc, c->P, c->ps, c->queue[parity], c->queue[parity ^ 1u], c->ctr, parity, 0u, 0u));
+                parity ^= 1u;
+                continue;
+            }
             TIMED(c, VPT_K_EXTEND, launch_extend(s, (uint32_t)c->trav_blocks, c->lds_scene, count, c->dsc, c->ps, c->queue[parity], c->ctr, parity));
             TIMED(c, VPT_K_SHADE, launch_shade(s, (uint32_t)c->shade_blocks, c->dsc, c->P, c->ps, c->queue[parity], c->queue[parity ^ 1u], c->cqueue, c->ctr, parity));
             TIMED(c, VPT_K_CONNECT, launch_connect(s, (uint32_t)c->trav_blocks, c->lds_scene, count, c->dsc, c->P, c->ps, c->cqueue, c->ctr, parity));
@@ -290,6 +297,9 @@ int render_batch(vpt_ctx* c, uint32_t frames, uint32_t dispatch_base, uint32_t f
         c->stats.closest_rays = h.stat_closest;
         c->stats.shadow_rays = h.stat_shadow;
         c->stats.connect_paths = h.stat_connect;
+        c->stats.primary_hits = h.stat_primary_hits;
+        c->stats.primary_survivors = h.stat_primary_alive;
+        c->stats.primary_shadow_rays = h.stat_primary_rays;
         c->stats.nodes_visited = h.stat_nodes;
         c->stats.tris_tested = h.stat_tris;
         c->stats.shadow_nodes_visited = h.stat_shadow_nodes;
@@ -347,7 +357,7 @@ void vpt_default_post_params(vpt_post_params* p) {  // PostProcessor.h:8-21
 
 vpt_ctx* vpt_create(const vpt_config* cfg, int* err) {
     auto set = [&](int e) { if (err) *err = e; };
-    if (!cfg || cfg->width == 0 || cfg->height == 0 || cfg->shard_count == 0 || cfg->shard_rank >= cfg->shard_count) { set(VPT_ERR_INVALID_ARGUMENT); return nullptr; }
+    if (!cfg || cfg->width == 0 || cfg->height == 0 || cfg->shard_count == 0 || cfg->shard_rank >= cfg->shard_count || cfg->pipeline > VPT_PIPELINE_STAGED) { set(VPT_ERR_INVALID_ARGUMENT); return nullptr; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev) { set(VPT_ERR_NO_DEVICE); return nullptr; }
     if (hipSetDevice(cfg->device) != hipSuccess) { set(VPT_ERR_NO_DEVICE); return nullptr; }
@@ -493,6 +503,7 @@ int vpt_set_scene(vpt_ctx* c, const vpt_scene_desc* sd) {
     c->lds_scene = ((size_t)D.node_count * 64 + (size_t)D.tri_count * 48) <= 16384;
     c->trav_blocks = traverse_blocks_per_cu(c->lds_scene, D) * c->cu_count;
     c->shade_blocks = shade_blocks_per_cu() * c->cu_count;
+    c->primary_blocks = bounce_blocks_per_cu(c->lds_scene, D) * c->cu_count;
     c->has_scene = true;
     HIPCHK(c, hipMemset(c->image, 0, (size_t)c->P.shard_pixels * 16));
     return VPT_OK;
