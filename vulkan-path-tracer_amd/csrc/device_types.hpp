@@ -50,6 +50,26 @@ struct EmissiveDesc {  // == EmissiveMeshEntry (PathTracer.h:321-328), 80 B
     uint32_t mesh, material, tri_count, instance;
     float xform[16];
 };
+// Derived tables, filled on the device by the same expressions the shade stage would otherwise evaluate
+// per hit (kernels_path.hip k_precompute_*), so using them cannot change a bit of the result.
+struct MatResolved {  // Material.Initialize (Material.slang:39-87) for a material whose value textures are all 1x1
+    float base[3], roughness;
+    float emissive[3], metallic;
+    float ax, ay, ior, inv_ior;
+    float pm, pd, pg;
+    uint32_t flags;   // bit0: base/roughness/metallic/emissive textures are 1x1 -> fields valid; bit1: normal map 1x1 -> nmap valid
+    float nmap[3], pad;
+};
+static_assert(sizeof(MatResolved) == 80, "MatResolved is 80 B");
+struct EmissiveTri {  // world-space light triangle as SampleEmissiveTriangle (Sampler.slang:375-404) derives it per sample
+    float p0[3], area;
+    float p1[3], u0;
+    float p2[3], v0;
+    float nrm[3], u1;
+    float v1, u2, v2, pad;
+};
+static_assert(sizeof(EmissiveTri) == 80, "EmissiveTri is 80 B");
+
 struct AliasEntry {  // == AliasMapEntry (Bindings.slang:1-5)
     uint32_t alias;
     float importance;
@@ -74,6 +94,10 @@ struct DeviceScene {
     const float* lut_r;  // 64x64x32
     const float* lut_o;  // 128x128x32
     const float* lut_i;  // 128x128x32
+    const MatResolved* mat_resolved;        // per material
+    const float4* tri_ng;                   // per global triangle id: world-space geometric normal (Surface.slang:48-49)
+    const EmissiveTri* emissive_tri;        // per emissive triangle
+    const uint32_t* emissive_tri_offset;    // per emissive mesh: first entry in emissive_tri
 };
 
 struct RenderParams {

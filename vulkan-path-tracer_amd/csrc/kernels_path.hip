@@ -186,10 +186,11 @@ __device__ __forceinline__ void shade_core(const DeviceScene& sc, const RenderPa
         uint32_t inst_id = in_.inst;
         const InstanceDesc& in = sc.instances[inst_id];
         const vpt_material& mat = sc.materials[in.material];
+        const MatResolved mr = sc.mat_resolved[in.material];
         SurfaceFrame s;
-        surface_init(sc, s, in, __float_as_uint(h.w), h.y, h.z, rd, mat.normal_texture, (P.flags & VPT_FLAG_GEOMETRY_NORMALS) != 0);
+        surface_init(sc, s, in, __float_as_uint(h.w), h.y, h.z, rd, mat.normal_texture, (P.flags & VPT_FLAG_GEOMETRY_NORMALS) != 0, mr);
         Bsdf bs; V3 mcol; float mdens, maniso, arot;
-        bsdf_init(sc, bs, mat, s.uv, s.inside, P.flags, mcol, mdens, maniso, arot);
+        bsdf_init(sc, bs, mat, mr, s.uv, s.inside, P.flags, mcol, mdens, maniso, arot);
         bool is_light = bs.emissive.x > 0.0f || bs.emissive.y > 0.0f || bs.emissive.z > 0.0f;
         rotate_tangents(s, arot);
         bool scattered = false;
@@ -256,13 +257,16 @@ __device__ __forceinline__ void shade_core(const DeviceScene& sc, const RenderPa
             if (P.flags & VPT_FLAG_MESH_MIS) {
                 if (depth == 0 && is_light) emitted = emitted + bs.emissive;
                 else if (is_light) {
-                    V3 pa = mat_point(in.xform, s.p1), pb = mat_point(in.xform, s.p2), pc = mat_point(in.xform, s.p3);
-                    float area = length(cross(pb - pa, pc - pa)) * 0.5f;
                     float d2 = dot(s.pos - porg, s.pos - porg);
                     float ct = fabs_(dot(s.N, normalize(porg - s.pos)));
                     uint32_t tc = 0;
+                    float area = 0.0f;  // of the hit triangle in world space: the light table holds exactly that value
                     for (uint32_t k = 0; k < sc.emissive_count; k++)
-                        if (sc.emissive[k].instance == inst_id) { tc = sc.emissive[k].tri_count; break; }
+                        if (sc.emissive[k].instance == inst_id) {
+                            tc = sc.emissive[k].tri_count;
+                            area = sc.emissive_tri[sc.emissive_tri_offset[k] + __float_as_uint(h.w)].area;
+                            break;
+                        }
                     float lp = (1.0f / (float)sc.emissive_count) * (1.0f / (float)tc) * (1.0f / area) * (d2 / ct);
                     lp = max_(lp, P.emissive_pdf_bias);
                     emitted = emitted + bs.emissive * power_heuristics(prev_pdf, lp);
@@ -669,6 +673,50 @@ __global__ __launch_bounds__(256) void k_scatter_rows(const float4* gathered, fl
     uint32_t y = i / width, x = i - y * width;
     uint32_t r = y % shard_count, ys = y / shard_count;
     full[i] = gathered[(size_t)r * shard_stride_px + (size_t)ys * width + x];
+}
+
+// ------------------------------------------------------------------ derived scene tables
+__global__ __launch_bounds__(256) void k_precompute_materials(DeviceScene sc, uint32_t flags, MatResolved* out, uint32_t n) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const vpt_material& m = sc.materials[i];
+    MatResolved r;
+    V2 uv; uv.x = 0.0f; uv.y = 0.0f;
+    material_resolve(sc, m, uv, flags, r);
+    auto one = [&](uint32_t t) { return sc.textures[t].w == 1 && sc.textures[t].h == 1; };
+    r.flags = (one(m.base_color_texture) && one(m.roughness_texture) && one(m.metallic_texture) && one(m.emissive_texture)) ? 1u : 0u;
+    if (one(m.normal_texture)) {
+        V4 nm = tex_sample(sc, m.normal_texture, 0.0f, 0.0f);
+        r.nmap[0] = nm.x * 2.0f - 1.0f; r.nmap[1] = nm.y * 2.0f - 1.0f; r.nmap[2] = nm.z * 2.0f - 1.0f;
+        r.flags |= 2u;
+    } else { r.nmap[0] = r.nmap[1] = r.nmap[2] = 0.0f; }
+    r.pad = 0.0f;
+    out[i] = r;
+}
+__global__ __launch_bounds__(256) void k_precompute_tri_ng(DeviceScene sc, float4* out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= sc.tri_count) return;
+    const BvhTri& t = sc.tris[i];
+    V3 ng = triangle_ng(sc, sc.instances[t.inst], t.prim);
+    out[t.gid] = make_float4(ng.x, ng.y, ng.z, 0.0f);
+}
+__global__ __launch_bounds__(256) void k_precompute_emissive(DeviceScene sc, EmissiveTri* out, uint32_t total) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    uint32_t k = 0;
+    while (k + 1 < sc.emissive_count && sc.emissive_tri_offset[k + 1] <= i) k++;
+    EmissiveTri t;
+    emissive_tri_compute(sc, sc.emissive[k], i - sc.emissive_tri_offset[k], t);
+    out[i] = t;
+}
+void launch_precompute_materials(hipStream_t s, const DeviceScene& sc, uint32_t flags, MatResolved* out, uint32_t n) {
+    if (n) hipLaunchKernelGGL(k_precompute_materials, dim3((n + 255) / 256), dim3(256), 0, s, sc, flags, out, n);
+}
+void launch_precompute_tri_ng(hipStream_t s, const DeviceScene& sc, float4* out) {
+    if (sc.tri_count) hipLaunchKernelGGL(k_precompute_tri_ng, dim3((sc.tri_count + 255) / 256), dim3(256), 0, s, sc, out);
+}
+void launch_precompute_emissive(hipStream_t s, const DeviceScene& sc, EmissiveTri* out, uint32_t total) {
+    if (total) hipLaunchKernelGGL(k_precompute_emissive, dim3((total + 255) / 256), dim3(256), 0, s, sc, out, total);
 }
 
 // ------------------------------------------------------------------ launch wrappers

@@ -87,8 +87,21 @@ struct SurfaceFrame {
     __device__ inline V3 world_to_tangent(V3 v) const { return normalize(v3(dot(v, T), dot(v, B), dot(v, N))); }
 };
 
+// Geometric normal of one triangle in world space (Surface.slang:48-49); evaluated once per triangle by
+// k_precompute_tri_ng and read back per hit.
+__device__ inline V3 triangle_ng(const DeviceScene& sc, const InstanceDesc& in, uint32_t prim) {
+    const MeshDesc me = sc.meshes[in.mesh];
+    const uint32_t* idx = sc.indices + me.index_offset + prim * 3;
+    const vpt_vertex* vb = sc.vertices + me.vertex_offset;
+    V3 p1 = v3(vb[idx[0]].position[0], vb[idx[0]].position[1], vb[idx[0]].position[2]);
+    V3 p2 = v3(vb[idx[1]].position[0], vb[idx[1]].position[1], vb[idx[1]].position[2]);
+    V3 p3 = v3(vb[idx[2]].position[0], vb[idx[2]].position[1], vb[idx[2]].position[2]);
+    V3 ng = normalize(cross(p2 - p1, p3 - p1));
+    return normalize(rowvec_mat3(ng, in.inv3));
+}
+
 __device__ inline void surface_init(const DeviceScene& sc, SurfaceFrame& s, const InstanceDesc& in, uint32_t prim, float hu,
-                                    float hv, V3 raydir, uint32_t normal_tex, bool geo_only) {
+                                    float hv, V3 raydir, uint32_t normal_tex, bool geo_only, const MatResolved& mr) {
     const MeshDesc me = sc.meshes[in.mesh];
     const uint32_t* idx = sc.indices + me.index_offset + prim * 3;
     const vpt_vertex* vb = sc.vertices + me.vertex_offset;
@@ -102,8 +115,7 @@ __device__ inline void surface_init(const DeviceScene& sc, SurfaceFrame& s, cons
     s.pos = mat_point(in.xform, (s.p1 * bx + s.p2 * by) + s.p3 * bz);
     s.uv.x = (a1.z * bx + b1.z * by) + c1.z * bz;
     s.uv.y = (a1.w * bx + b1.w * by) + c1.w * bz;
-    s.Ng = normalize(cross(s.p2 - s.p1, s.p3 - s.p1));
-    s.Ng = normalize(rowvec_mat3(s.Ng, in.inv3));
+    { float4 g = sc.tri_ng[in.tri_offset + prim]; s.Ng = v3(g.x, g.y, g.z); }
     if (geo_only) {
         s.N = s.Ng;
     } else {
@@ -116,8 +128,10 @@ __device__ inline void surface_init(const DeviceScene& sc, SurfaceFrame& s, cons
     s.T = normalize(cross(up, s.N));
     s.B = normalize(cross(s.N, s.T));
     if (!geo_only) {
-        V4 nm = tex_sample(sc, normal_tex, s.uv.x, s.uv.y);
-        s.N = s.tangent_to_world(v3(nm.x * 2.0f - 1.0f, nm.y * 2.0f - 1.0f, nm.z * 2.0f - 1.0f));
+        V3 nv;
+        if (mr.flags & 2u) nv = v3(mr.nmap[0], mr.nmap[1], mr.nmap[2]);
+        else { V4 nm = tex_sample(sc, normal_tex, s.uv.x, s.uv.y); nv = v3(nm.x * 2.0f - 1.0f, nm.y * 2.0f - 1.0f, nm.z * 2.0f - 1.0f); }
+        s.N = s.tangent_to_world(nv);
     }
     float nv = dot(s.N, view);
     if (nv < 0.0f) s.N = normalize(s.N - view * (nv - 0.01f));
@@ -246,33 +260,47 @@ struct Bsdf {
     }
 };
 
-// Material.Initialize, :39-87 (+ FURNACE_TEST_MODE override :78-86)
-__device__ inline void bsdf_init(const DeviceScene& sc, Bsdf& b, const vpt_material& m, V2 uv, bool inside, uint32_t flags,
-                                 V3& medium_color, float& medium_density, float& medium_aniso, float& aniso_rotation) {
+// Material.Initialize, :39-87 (+ FURNACE_TEST_MODE override :78-86): the texture-dependent part.  Called per
+// hit with the hit's uv, or once per material (uv irrelevant) by k_precompute_materials when every value
+// texture is 1x1.
+__device__ inline void material_resolve(const DeviceScene& sc, const vpt_material& m, V2 uv, uint32_t flags, MatResolved& r) {
     V4 tb = tex_sample(sc, m.base_color_texture, uv.x, uv.y);
-    b.ior = max_(m.ior, 1.000001f);
-    b.base = v3(m.base_color[0] * pow_(tb.x, 2.2f), m.base_color[1] * pow_(tb.y, 2.2f), m.base_color[2] * pow_(tb.z, 2.2f));
-    b.roughness = m.roughness * tex_sample(sc, m.roughness_texture, uv.x, uv.y).x;
-    b.metallic = m.metallic * tex_sample(sc, m.metallic_texture, uv.x, uv.y).x;
+    r.ior = max_(m.ior, 1.000001f);
+    r.inv_ior = 1.0f / r.ior;
+    r.base[0] = m.base_color[0] * pow_(tb.x, 2.2f); r.base[1] = m.base_color[1] * pow_(tb.y, 2.2f); r.base[2] = m.base_color[2] * pow_(tb.z, 2.2f);
+    r.roughness = m.roughness * tex_sample(sc, m.roughness_texture, uv.x, uv.y).x;
+    r.metallic = m.metallic * tex_sample(sc, m.metallic_texture, uv.x, uv.y).x;
     V4 te = tex_sample(sc, m.emissive_texture, uv.x, uv.y);
-    b.emissive = v3(m.emissive_color[0] * te.x, m.emissive_color[1] * te.y, m.emissive_color[2] * te.z);
+    r.emissive[0] = m.emissive_color[0] * te.x; r.emissive[1] = m.emissive_color[1] * te.y; r.emissive[2] = m.emissive_color[2] * te.z;
+    float aspect = sqrt_(1.0f - sqrt_(m.anisotropy) * 0.9f);
+    r.ax = max_(0.00001f, r.roughness / aspect);
+    r.ay = max_(0.00001f, r.roughness * aspect);
+    if (flags & VPT_FLAG_FURNACE) { r.base[0] = r.base[1] = r.base[2] = 1.0f; r.emissive[0] = r.emissive[1] = r.emissive[2] = 0.0f; }
+    r.pm = r.metallic;
+    r.pd = (1.0f - r.metallic) * (1.0f - m.transmission);
+    r.pg = (1.0f - r.metallic) * m.transmission;
+    float sum = r.pm + r.pd + r.pg;
+    r.pm /= sum; r.pd /= sum; r.pg /= sum;
+}
+__device__ inline void bsdf_init(const DeviceScene& sc, Bsdf& b, const vpt_material& m, const MatResolved& pre, V2 uv, bool inside,
+                                 uint32_t flags, V3& medium_color, float& medium_density, float& medium_aniso, float& aniso_rotation) {
+    MatResolved r = pre;
+    if (!(pre.flags & 1u)) material_resolve(sc, m, uv, flags, r);
+    b.ior = r.ior;
+    b.base = v3(r.base[0], r.base[1], r.base[2]);
+    b.roughness = r.roughness; b.metallic = r.metallic;
+    b.emissive = v3(r.emissive[0], r.emissive[1], r.emissive[2]);
     b.spec = ld3(m.specular_color);
     b.transmission = m.transmission;
     b.anisotropy = m.anisotropy;
-    float aspect = sqrt_(1.0f - sqrt_(m.anisotropy) * 0.9f);
-    b.ax = max_(0.00001f, b.roughness / aspect);
-    b.ay = max_(0.00001f, b.roughness * aspect);
-    b.eta = inside ? b.ior : 1.0f / b.ior;
+    b.ax = r.ax; b.ay = r.ay;
+    b.eta = inside ? r.ior : r.inv_ior;
     medium_color = ld3(m.medium_color);
     medium_density = m.medium_density; medium_aniso = m.medium_anisotropy; aniso_rotation = m.anisotropy_rotation;
-    if (flags & VPT_FLAG_FURNACE) { b.base = v3s(1.0f); b.emissive = v3s(0.0f); b.spec = v3s(1.0f); medium_color = v3s(1.0f); }
+    if (flags & VPT_FLAG_FURNACE) { b.spec = v3s(1.0f); medium_color = v3s(1.0f); }
     b.ec = (flags & VPT_FLAG_ENERGY_COMPENSATION) != 0;
     b.lut_r = sc.lut_r; b.lut_o = sc.lut_o; b.lut_i = sc.lut_i;
-    b.pm = b.metallic;
-    b.pd = (1.0f - b.metallic) * (1.0f - b.transmission);
-    b.pg = (1.0f - b.metallic) * b.transmission;
-    float sum = b.pm + b.pd + b.pg;
-    b.pm /= sum; b.pd /= sum; b.pg /= sum;
+    b.pm = r.pm; b.pd = r.pd; b.pg = r.pg;
 }
 
 // ------------------------------------------------------------------ Sampler.slang
@@ -341,6 +369,21 @@ __device__ inline void sample_env(const DeviceScene& sc, const RenderParams& P, 
     out = env_sample(sc, u, v);
     out.x *= P.sky_intensity; out.y *= P.sky_intensity; out.z *= P.sky_intensity;
 }
+// World-space data of one light triangle (Sampler.slang:375-404), evaluated once per emissive triangle by
+// k_precompute_emissive; `area` is also the area ClosestHit.slang:276-287 recomputes when a path hits the light.
+__device__ inline void emissive_tri_compute(const DeviceScene& sc, const EmissiveDesc& em, uint32_t ti, EmissiveTri& t) {
+    const MeshDesc me = sc.meshes[em.mesh];
+    const uint32_t* idx = sc.indices + me.index_offset + ti * 3;
+    const vpt_vertex* vb = sc.vertices + me.vertex_offset;
+    const vpt_vertex &a = vb[idx[0]], &b = vb[idx[1]], &c = vb[idx[2]];
+    V3 p0 = mat_point(em.xform, ld3(a.position)), p1 = mat_point(em.xform, ld3(b.position)), p2 = mat_point(em.xform, ld3(c.position));
+    V3 nrm = normalize(cross(p2 - p0, p1 - p0));
+    t.area = length(cross(p1 - p0, p2 - p0)) * 0.5f;
+    t.p0[0] = p0.x; t.p0[1] = p0.y; t.p0[2] = p0.z; t.p1[0] = p1.x; t.p1[1] = p1.y; t.p1[2] = p1.z; t.p2[0] = p2.x; t.p2[1] = p2.y; t.p2[2] = p2.z;
+    t.nrm[0] = nrm.x; t.nrm[1] = nrm.y; t.nrm[2] = nrm.z;
+    t.u0 = a.texcoord[0]; t.v0 = a.texcoord[1]; t.u1 = b.texcoord[0]; t.v1 = b.texcoord[1]; t.u2 = c.texcoord[0]; t.v2 = c.texcoord[1]; t.pad = 0.0f;
+}
+
 // SampleEmissiveTriangle, :348-422 (1+1+2 draws; none if there is no emissive mesh)
 __device__ inline void sample_emissive(const DeviceScene& sc, Rng& r, V3 pos, V3& to_light, V4& cpdf, uint32_t& gid) {
     gid = 0xffffffffu;
@@ -353,20 +396,17 @@ __device__ inline void sample_emissive(const DeviceScene& sc, Rng& r, V3 pos, V3
     uint32_t ti = (uint32_t)floor_(r.uf() * (float)tc);
     ti = ti < tc - 1 ? ti : tc - 1;
     gid = sc.instances[em.instance].tri_offset + ti;
-    const MeshDesc me = sc.meshes[em.mesh];
-    const uint32_t* idx = sc.indices + me.index_offset + ti * 3;
-    const vpt_vertex* vb = sc.vertices + me.vertex_offset;
-    const vpt_vertex &a = vb[idx[0]], &b = vb[idx[1]], &c = vb[idx[2]];
-    V3 p0 = mat_point(em.xform, ld3(a.position)), p1 = mat_point(em.xform, ld3(b.position)), p2 = mat_point(em.xform, ld3(c.position));
+    const float4* tq = reinterpret_cast<const float4*>(sc.emissive_tri + sc.emissive_tri_offset[mi] + ti);
+    float4 q0 = tq[0], q1 = tq[1], q2 = tq[2], q3 = tq[3], q4 = tq[4];
+    V3 p0 = v3(q0.x, q0.y, q0.z), p1 = v3(q1.x, q1.y, q1.z), p2 = v3(q2.x, q2.y, q2.z), nrm = v3(q3.x, q3.y, q3.z);
+    float area = q0.w;
     float x0 = r.uf(), x1 = r.uf();
     float su = sqrt_(x0);
     float b0 = 1.0f - su, b1 = x1 * su, b2 = 1.0f - b0 - b1;
     V3 tp = (b0 * p0 + b1 * p1) + b2 * p2;
-    float uu = (b0 * a.texcoord[0] + b1 * b.texcoord[0]) + b2 * c.texcoord[0];
-    float vv = (b0 * a.texcoord[1] + b1 * b.texcoord[1]) + b2 * c.texcoord[1];
+    float uu = (b0 * q1.w + b1 * q3.w) + b2 * q4.y;
+    float vv = (b0 * q2.w + b1 * q4.x) + b2 * q4.z;
     to_light = normalize(tp - pos);
-    V3 nrm = normalize(cross(p2 - p0, p1 - p0));
-    float area = length(cross(p1 - p0, p2 - p0)) * 0.5f;
     float d2 = dot(tp - pos, tp - pos);
     float ct = fabs_(dot(nrm, to_light));
     cpdf.w = d2 / ((float)n * (float)tc * area * ct);

@@ -33,6 +33,10 @@ struct vpt_ctx {
     std::vector<void*> scene_allocs;
     vpt_material* d_materials = nullptr;
     EmissiveDesc* d_emissive = nullptr;
+    MatResolved* d_mat_resolved = nullptr;
+    EmissiveTri* d_emissive_tri = nullptr;
+    uint32_t* d_emissive_tri_offset = nullptr;
+    float4* d_tri_ng = nullptr;
     bool lds_scene = false;
     int trav_blocks = 1024;
 
@@ -191,6 +195,13 @@ int upload_emissive(vpt_ctx* c) {
         HIPCHK(c, hipMemcpy(c->d_emissive, c->emissive.data(), c->emissive.size() * sizeof(EmissiveDesc), hipMemcpyHostToDevice));
     c->dsc.emissive_count = (uint32_t)c->emissive.size();
     c->dsc.emissive_tris = c->emissive_tris;
+    // per-light-triangle table (world-space corners, normal, area)
+    std::vector<uint32_t> off(std::max<size_t>(1, c->emissive.size()), 0u);
+    uint32_t total = 0;
+    for (size_t k = 0; k < c->emissive.size(); k++) { off[k] = total; total += c->emissive[k].tri_count; }
+    HIPCHK(c, hipMemcpy(c->d_emissive_tri_offset, off.data(), off.size() * 4, hipMemcpyHostToDevice));
+    launch_precompute_emissive(c->stream, c->dsc, c->d_emissive_tri, total);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return VPT_OK;
 }
 
@@ -492,6 +503,15 @@ int vpt_set_scene(vpt_ctx* c, const vpt_scene_desc* sd) {
         c->scene_allocs.push_back(d);
         c->d_emissive = (EmissiveDesc*)d; D.emissive = c->d_emissive;
     }
+    {
+        void *d1 = nullptr, *d2 = nullptr, *d3 = nullptr, *d4 = nullptr;
+        HIPCHK(c, hipMalloc(&d1, sizeof(MatResolved) * c->materials.size())); c->scene_allocs.push_back(d1);
+        HIPCHK(c, hipMalloc(&d2, sizeof(EmissiveTri) * std::max<size_t>(1, leaf_tris.size()))); c->scene_allocs.push_back(d2);
+        HIPCHK(c, hipMalloc(&d3, 4 * std::max<size_t>(1, c->instances.size()))); c->scene_allocs.push_back(d3);
+        HIPCHK(c, hipMalloc(&d4, 16 * std::max<size_t>(1, leaf_tris.size()))); c->scene_allocs.push_back(d4);
+        c->d_mat_resolved = (MatResolved*)d1; c->d_emissive_tri = (EmissiveTri*)d2; c->d_emissive_tri_offset = (uint32_t*)d3; c->d_tri_ng = (float4*)d4;
+        D.mat_resolved = c->d_mat_resolved; D.emissive_tri = c->d_emissive_tri; D.emissive_tri_offset = c->d_emissive_tri_offset; D.tri_ng = c->d_tri_ng;
+    }
     if ((rc = upload_emissive(c))) return rc;
     if ((rc = upload(c, env, &D.env))) return rc;
     if ((rc = upload(c, alias, &D.alias))) return rc;
@@ -504,6 +524,10 @@ int vpt_set_scene(vpt_ctx* c, const vpt_scene_desc* sd) {
     c->trav_blocks = traverse_blocks_per_cu(c->lds_scene, D) * c->cu_count;
     c->shade_blocks = shade_blocks_per_cu() * c->cu_count;
     c->primary_blocks = bounce_blocks_per_cu(c->lds_scene, D) * c->cu_count;
+    launch_precompute_tri_ng(c->stream, D, c->d_tri_ng);
+    launch_precompute_materials(c->stream, D, c->params.flags, c->d_mat_resolved, (uint32_t)c->materials.size());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipGetLastError());
     c->has_scene = true;
     HIPCHK(c, hipMemset(c->image, 0, (size_t)c->P.shard_pixels * 16));
     return VPT_OK;
@@ -519,6 +543,8 @@ int vpt_set_material(vpt_ctx* c, uint32_t index, const vpt_material* m) {
     c->materials[index] = *m;
     HIPCHK(c, hipMemcpy(c->d_materials + index, m, sizeof(vpt_material), hipMemcpyHostToDevice));
     if (emissive_changed) { build_emissive(c); int rc = upload_emissive(c); if (rc) return rc; }
+    launch_precompute_materials(c->stream, c->dsc, c->params.flags, c->d_mat_resolved, (uint32_t)c->materials.size());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     reset_accum(c);
     return VPT_OK;
 }
@@ -542,9 +568,15 @@ int vpt_set_params(vpt_ctx* c, const vpt_params* p) {
     if (p->max_depth == 0 || p->max_depth > 1000000u) return fail(c, VPT_ERR_INVALID_ARGUMENT, "max_depth must be in [1, 1000000]");
     if (p->screen_chunk_count != 1) return fail(c, VPT_ERR_UNSUPPORTED, "split-screen dispatch (screen_chunk_count > 1) is not implemented in the HIP backend yet");
     if (!(p->flags & VPT_FLAG_RAY_QUERIES)) return fail(c, VPT_ERR_UNSUPPORTED, "only the USE_RAY_QUERIES semantics are implemented");
+    const bool flags_changed = c->params.flags != p->flags;
     c->params = *p;
     sync_params(c);
     reset_accum(c);
+    if (flags_changed && c->has_scene) {  // FURNACE_TEST_MODE is baked into the resolved-material table
+        HIPCHK(c, hipSetDevice(c->cfg.device));
+        launch_precompute_materials(c->stream, c->dsc, c->params.flags, c->d_mat_resolved, (uint32_t)c->materials.size());
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
     return VPT_OK;
 }
 
