@@ -17,6 +17,7 @@ namespace {
 constexpr int kLeafSize = 4;
 constexpr int kBins = 16;
 constexpr int kMaxDepth = 30;  // < kStackDepth (32)
+constexpr float kNodeCost = 0.7f;  // one two-box node test relative to one triangle test
 
 struct Box {
     float lo[3], hi[3];
@@ -42,7 +43,8 @@ struct Builder {
         for (int i = first; i < first + count; i++) { n.b.grow(refs[i].b); cb.grow(refs[i].c); }
         int id = (int)nodes.size();
         nodes.push_back(n);
-        if (count <= kLeafSize) return id;
+        if (count == 1) return id;
+        const bool small = count <= kLeafSize;  // may stay a leaf; split only if SAH says the split is cheaper
         int need = 0; { int c = (count + kLeafSize - 1) / kLeafSize; while ((1 << need) < c) need++; }
         bool force_median = depth + need + 1 >= kMaxDepth;
         int best_axis = -1, best_bin = -1; float best_cost = 3.0e38f;
@@ -69,6 +71,11 @@ struct Builder {
                     if (cost < best_cost) { best_cost = cost; best_axis = a; best_bin = k; }
                 }
             }
+        }
+        if (small) {
+            // leaf cost = count triangle tests; split cost = one node visit + area-weighted child tests
+            float pa = n.b.half_area();
+            if (best_axis < 0 || !(pa > 0.0f) || kNodeCost + best_cost / pa >= (float)count) return id;
         }
         int mid;
         if (best_axis >= 0) {

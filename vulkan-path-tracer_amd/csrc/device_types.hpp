@@ -59,8 +59,9 @@ struct MatResolved {  // Material.Initialize (Material.slang:39-87) for a materi
     float pm, pd, pg;
     uint32_t flags;   // bit0: base/roughness/metallic/emissive textures are 1x1 -> fields valid; bit1: normal map 1x1 -> nmap valid
     float nmap[3], pad;
+    float rot_sin, rot_cos, pad1, pad2;  // sincos(AnisotropyRotation in radians), Surface.slang:129-136
 };
-static_assert(sizeof(MatResolved) == 80, "MatResolved is 80 B");
+static_assert(sizeof(MatResolved) == 96, "MatResolved is 96 B");
 struct EmissiveTri {  // world-space light triangle as SampleEmissiveTriangle (Sampler.slang:375-404) derives it per sample
     float p0[3], area;
     float p1[3], u0;
@@ -91,6 +92,7 @@ struct DeviceScene {
     const float* env;  // RGBA32F, alpha = pdf
     const AliasEntry* alias;
     uint32_t env_w, env_h;
+    uint32_t env_black, env_pad;  // 1: every env texel (and so its pdf) is exactly 0 -> lookups return 0 without fetching
     const float* lut_r;  // 64x64x32
     const float* lut_o;  // 128x128x32
     const float* lut_i;  // 128x128x32

@@ -170,7 +170,9 @@ __device__ __forceinline__ void shade_core(const DeviceScene& sc, const RenderPa
     if (h.x < 0.0f) {
         // ---- Miss.slang:8-77
         V4 cp = v4(0.0f, 0.0f, 0.0f, 1.0f);
-        if ((P.flags & VPT_FLAG_SHOW_ENV_DIRECTLY) || depth > 0) {
+        if (((P.flags & VPT_FLAG_SHOW_ENV_DIRECTLY) || depth > 0) && sc.env_black) {
+            cp = v4(0.0f, 0.0f, 0.0f, 0.0f);  // an all-zero env map returns exactly 0 (pdf included) for any direction
+        } else if ((P.flags & VPT_FLAG_SHOW_ENV_DIRECTLY) || depth > 0) {
             V3 d = rotate(pdir, v3(1.0f, 0.0f, 0.0f), -(P.sky_altitude / 180.0f * VPT_PI));
             d = rotate(d, v3(0.0f, 1.0f, 0.0f), -(P.sky_azimuth / 180.0f * VPT_PI));
             V2 uv = direction_to_uv(d);
@@ -192,7 +194,7 @@ __device__ __forceinline__ void shade_core(const DeviceScene& sc, const RenderPa
         Bsdf bs; V3 mcol; float mdens, maniso, arot;
         bsdf_init(sc, bs, mat, mr, s.uv, s.inside, P.flags, mcol, mdens, maniso, arot);
         bool is_light = bs.emissive.x > 0.0f || bs.emissive.y > 0.0f || bs.emissive.z > 0.0f;
-        rotate_tangents(s, arot);
+        rotate_tangents(s, mr.rot_sin, mr.rot_cos);  // AnisotropyRotation has no texture: the table entry is always valid
         bool scattered = false;
         if (in_medium) {  // :80-116
             float pm_aniso = ps.maniso[slot];
@@ -237,8 +239,11 @@ __device__ __forceinline__ void shade_core(const DeviceScene& sc, const RenderPa
             float ec_r = 1.0f, ec_g = 1.0f;
             if (bs.ec) {
                 ec_r = lut_sample(bs.lut_r, 64, 64, 32, V.z, bs.roughness, bs.anisotropy * 32.0f);
-                ec_g = lut_sample(bs.eta > 1.0f ? bs.lut_i : bs.lut_o, 128, 128, 32, pow_(V.z, 1.0f / 2.0f), bs.roughness,
-                                  (clamp_(bs.ior, 1.0001f, 2.0f) - 1.0f) * 32.0f);
+                // the glass tap only ever scales terms weighted by pg; with pg == 0 those terms are (finite)*0 = 0
+                // whatever the tap is, so it is skipped (tables are finite)
+                if (bs.pg != 0.0f)
+                    ec_g = lut_sample(bs.eta > 1.0f ? bs.lut_i : bs.lut_o, 128, 128, 32, pow_(V.z, 1.0f / 2.0f), bs.roughness,
+                                      (clamp_(bs.ior, 1.0001f, 2.0f) - 1.0f) * 32.0f);
             }
             Eval se; se.f = v3s(0.0f); se.pdf = 0.0f;
             V3 Ls = v3s(0.0f);

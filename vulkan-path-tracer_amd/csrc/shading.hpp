@@ -140,9 +140,7 @@ __device__ inline void surface_init(const DeviceScene& sc, SurfaceFrame& s, cons
     s.T = normalize(cross(s.N, up));
     s.B = normalize(cross(s.N, s.T));
 }
-__device__ inline void rotate_tangents(SurfaceFrame& s, float deg) {  // Surface.slang:129-136
-    float sn, cs;
-    sincos_(deg * (VPT_PI / 180.0f), &sn, &cs);
+__device__ inline void rotate_tangents(SurfaceFrame& s, float sn, float cs) {  // Surface.slang:129-136, sincos per material
     s.T = (s.T * cs + cross(s.N, s.T) * sn) + (s.N * dot(s.N, s.T)) * (1.0f - cs);
     s.B = cross(s.T, s.N);
 }
@@ -281,6 +279,7 @@ __device__ inline void material_resolve(const DeviceScene& sc, const vpt_materia
     r.pg = (1.0f - r.metallic) * m.transmission;
     float sum = r.pm + r.pd + r.pg;
     r.pm /= sum; r.pd /= sum; r.pg /= sum;
+    sincos_(m.anisotropy_rotation * (VPT_PI / 180.0f), &r.rot_sin, &r.rot_cos);
 }
 __device__ inline void bsdf_init(const DeviceScene& sc, Bsdf& b, const vpt_material& m, const MatResolved& pre, V2 uv, bool inside,
                                  uint32_t flags, V3& medium_color, float& medium_density, float& medium_aniso, float& aniso_rotation) {
@@ -346,6 +345,13 @@ __device__ inline V3 sample_hg(Rng& r, V3 dir, float G) {  // :168-193
 }
 // ImportanceSampleEnvMap, :286-346 (3 draws)
 __device__ inline void sample_env(const DeviceScene& sc, const RenderParams& P, Rng& r, V3& to_light, V4& out) {
+    if (sc.env_black) {
+        // every texel and every pdf is exactly 0: the bilinear result is +0 for any direction, so only the
+        // three draws (Sampler.slang:289) have an effect
+        r.s = pcg_hash(pcg_hash(pcg_hash(r.s)));
+        to_light = v3s(0.0f); out = v4(0.0f, 0.0f, 0.0f, 0.0f);
+        return;
+    }
     float x0 = r.uf(), x1 = r.uf(), x2 = r.uf();
     uint32_t w = sc.env_w, h = sc.env_h, size = w * h;
     uint32_t idx = (uint32_t)(x0 * (float)size);

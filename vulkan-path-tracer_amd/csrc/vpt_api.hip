@@ -516,6 +516,8 @@ int vpt_set_scene(vpt_ctx* c, const vpt_scene_desc* sd) {
     if ((rc = upload(c, env, &D.env))) return rc;
     if ((rc = upload(c, alias, &D.alias))) return rc;
     D.env_w = sd->env_width; D.env_h = sd->env_height;
+    D.env_black = 1u;
+    for (size_t i = 0; i < env.size(); i++) if (env[i] != 0.0f) { D.env_black = 0u; break; }
     if ((rc = upload(c, lr, &D.lut_r))) return rc;
     if ((rc = upload(c, lo, &D.lut_o))) return rc;
     if ((rc = upload(c, li, &D.lut_i))) return rc;
