@@ -166,17 +166,17 @@ typedef struct vpt_config {
     uint32_t frames_in_flight; /* 0 = choose so that ~32M paths are resident (at most 64 frames) */
     uint32_t profile;    /* 1 = bracket every kernel launch with hipEvents (vpt_get_stats kernel times) */
     uint32_t count_traversal; /* 1 = count BVH node/triangle visits (slower; for the roofline's algorithmic bytes) */
-    uint32_t pipeline;   /* VPT_PIPELINE_*: how bounces >= 1 run (bounce 0 is always the fused primary kernel) */
+    uint32_t pipeline;   /* VPT_PIPELINE_* */
 } vpt_config;
 
-/* Bounces >= 1: AUTO = FUSED when the BVH fits in LDS next to the traversal stacks, else STAGED. Results are identical. */
+/* AUTO = FUSED when the BVH fits in LDS next to the traversal stacks, else STAGED. Results are identical. */
 #define VPT_PIPELINE_AUTO 0u
 #define VPT_PIPELINE_FUSED 1u   /* one kernel per bounce */
 #define VPT_PIPELINE_STAGED 2u  /* extend -> shade -> connect with compacted queues */
 
 #define VPT_KERNEL_COUNT 8
 enum vpt_kernel_id {
-    VPT_K_PRIMARY = 0,  /* bounce 0 fused: camera ray + extend + shade + connect */
+    VPT_K_PRIMARY = 0,  /* fused pipeline: bounce 0 (camera ray + extend + shade + connect); staged pipeline: raygen */
     VPT_K_EXTEND = 1,
     VPT_K_SHADE = 2,
     VPT_K_CONNECT = 3,  /* shadow rays + light accumulation + end-of-sample */

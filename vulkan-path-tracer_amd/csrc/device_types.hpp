@@ -100,6 +100,7 @@ struct DeviceScene {
     const float4* tri_ng;                   // per global triangle id: world-space geometric normal (Surface.slang:48-49)
     const EmissiveTri* emissive_tri;        // per emissive triangle
     const uint32_t* emissive_tri_offset;    // per emissive mesh: first entry in emissive_tri
+    const uint32_t* tri_slot_of_gid;        // per global triangle id: position in the leaf-ordered triangle array
 };
 
 struct RenderParams {

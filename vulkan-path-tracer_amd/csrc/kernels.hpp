@@ -8,6 +8,7 @@ void launch_bounce(hipStream_t s, uint32_t blocks, bool lds_scene, bool count, b
                    const PathState& ps, const uint32_t* queue, uint32_t* queue_next, Counters* ctr, uint32_t parity, uint32_t n_slots,
                    uint32_t dispatch_base);
 int bounce_blocks_per_cu(bool lds_scene, const DeviceScene& sc);
+void launch_raygen(hipStream_t s, const RenderParams& P, const PathState& ps, uint32_t* queue, uint32_t n_slots, uint32_t dispatch_base);
 void launch_prepare(hipStream_t s, Counters* ctr, uint32_t parity);
 void launch_fold(hipStream_t s, Counters* ctr);
 void launch_extend(hipStream_t s, uint32_t blocks, bool lds_scene, bool count, const DeviceScene& sc, const PathState& ps,

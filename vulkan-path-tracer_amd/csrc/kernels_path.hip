@@ -45,6 +45,26 @@ __device__ inline void pixel_of_slot(const RenderParams& P, uint32_t slot, uint3
     y = P.shard_rank + P.shard_count * ys;
 }
 
+// ------------------------------------------------------------------ raygen (staged pipeline only)
+// Scenes whose BVH does not fit in LDS run bounce 0 through the same extend / shade / connect stages as every
+// other bounce, so the camera rays are written out as ordinary path records.
+__global__ __launch_bounds__(256) void k_raygen(RenderParams P, PathState ps, uint32_t* queue, uint32_t n_slots, uint32_t dispatch_base) {
+    uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= n_slots) return;
+    uint32_t x, y, f;
+    pixel_of_slot(P, slot, x, y, f);
+    uint32_t seed = pcg_hash(P.base_seed + dispatch_base + f);  // PathTracer.cpp:139 with an explicit seed
+    Rng r; r.s = y + P.width * x + seed;                        // RayGen.slang:28
+    V3 o, d;
+    camera_ray(P, r, x, y, o, d);
+    ps.A[slot] = f4u(o, r.s);
+    ps.B[slot] = f4u(d, 0u);
+    ps.T[0][slot] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);  // pathThroughput = 1, payload.PDF = 1
+    ps.L[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (P.samples_per_frame > 1) { ps.ACC[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); ps.sidx[slot] = 0u; }
+    queue[slot] = slot;
+}
+
 // ------------------------------------------------------------------ persistent work fetch
 // One atomic on a single word costs ~11 ns under contention (MI355X_MICROARCH.md 'dequeue': a head word
 // saturates at ~88 dequeues/us), so the number of fetches per launch is kept near 8k: a wave takes
@@ -70,6 +90,21 @@ __device__ inline bool trace_any(const DeviceScene& sc, const float4* lds_nodes,
     if (LDS_SCENE) { LdsSceneSrc src{lds_nodes, lds_tris}; return trace_closest<COUNT>(src, o, d, tmin, tmax, stack, kTraverseBlock, h, st); }
     GlobalSceneSrc src{sc.nodes, sc.tris};
     return trace_closest<COUNT>(src, o, d, tmin, tmax, stack, kTraverseBlock, h, st);
+}
+
+// Sky visibility / light identity as exact any-hit queries (traverse.hpp).
+template <bool LDS_SCENE, bool COUNT>
+__device__ inline bool sky_visible(const DeviceScene& sc, const float4* lds_nodes, const float4* lds_tris, V3 o, V3 d, uint32_t* stack, TravStats& st) {
+    if (LDS_SCENE) { LdsSceneSrc src{lds_nodes, lds_tris}; return !trace_occluded<COUNT, false>(src, o, d, 0.0001f, 1000000.0f, 0.0f, 0u, stack, kTraverseBlock, st); }
+    GlobalSceneSrc src{sc.nodes, sc.tris};
+    return !trace_occluded<COUNT, false>(src, o, d, 0.0001f, 1000000.0f, 0.0f, 0u, stack, kTraverseBlock, st);
+}
+template <bool LDS_SCENE, bool COUNT>
+__device__ inline bool light_visible(const DeviceScene& sc, const float4* lds_nodes, const float4* lds_tris, V3 o, V3 d, uint32_t gid, uint32_t* stack, TravStats& st) {
+    uint32_t slot = sc.tri_slot_of_gid[gid];
+    if (LDS_SCENE) { LdsSceneSrc src{lds_nodes, lds_tris}; return closest_is<COUNT>(src, o, d, 0.0001f, 1000000.0f, gid, slot, stack, kTraverseBlock, st); }
+    GlobalSceneSrc src{sc.nodes, sc.tris};
+    return closest_is<COUNT>(src, o, d, 0.0001f, 1000000.0f, gid, slot, stack, kTraverseBlock, st);
 }
 
 // ------------------------------------------------------------------ extend: closest hit of every queued path
@@ -503,15 +538,11 @@ __global__ __launch_bounds__(kTraverseBlock, 3) void k_bounce(DeviceScene sc, Re
                 // connect, inline (RayGen.slang:92-102; FIRST: pathThroughput == 1, pathLight == 0)
                 V3 E = o.emitted;
                 if (o.want_sky) {
-                    HitRec h2;
-                    bool found = trace_any<LDS_SCENE, COUNT>(sc, lds_nodes, lds_tris, o.sky_o, o.sky_d, 0.0001f, 1000000.0f, stack, h2, sst);
-                    if (!found) E = E + o.csky;
+                    if (sky_visible<LDS_SCENE, COUNT>(sc, lds_nodes, lds_tris, o.sky_o, o.sky_d, stack, sst)) E = E + o.csky;
                     nrays++;
                 }
                 if (o.want_light) {
-                    HitRec h2;
-                    bool found = trace_any<LDS_SCENE, COUNT>(sc, lds_nodes, lds_tris, o.light_o, o.light_d, 0.0001f, 1000000.0f, stack, h2, sst);
-                    if (found && h2.gid == o.light_gid) E = E + o.clight;
+                    if (light_visible<LDS_SCENE, COUNT>(sc, lds_nodes, lds_tris, o.light_o, o.light_d, o.light_gid, stack, sst)) E = E + o.clight;
                     nrays++;
                 }
                 V3 contrib = E * in_.thr_prev;
@@ -607,15 +638,11 @@ __global__ __launch_bounds__(kTraverseBlock) void k_connect(DeviceScene sc, Rend
             V3 E = xyz(ce);
             if (flags & kCF_Sky) {  // ClosestHit.slang:139, 344-353
                 float4 so = ps.CSO[slot], sd = ps.CSD[slot];
-                HitRec h;
-                bool found = trace_any<LDS_SCENE, COUNT>(sc, lds_nodes, lds_tris, xyz(so), v3(so.w, sd.x, sd.y), 0.0001f, 1000000.0f, stack, h, st);
-                if (!found) E = E + xyz(ps.CS[slot]);
+                if (sky_visible<LDS_SCENE, COUNT>(sc, lds_nodes, lds_tris, xyz(so), v3(so.w, sd.x, sd.y), stack, st)) E = E + xyz(ps.CS[slot]);
             }
             if (flags & kCF_Light) {  // ClosestHit.slang:171-176, 358-370
                 float4 lo = ps.CLO[slot], ld = ps.CLD[slot], cl = ps.CL[slot];
-                HitRec h;
-                bool found = trace_any<LDS_SCENE, COUNT>(sc, lds_nodes, lds_tris, xyz(lo), v3(lo.w, ld.x, ld.y), 0.0001f, 1000000.0f, stack, h, st);
-                if (found && h.gid == __float_as_uint(cl.w)) E = E + xyz(cl);
+                if (light_visible<LDS_SCENE, COUNT>(sc, lds_nodes, lds_tris, xyz(lo), v3(lo.w, ld.x, ld.y), __float_as_uint(cl.w), stack, st)) E = E + xyz(cl);
             }
             V3 contrib = E * xyz(Tprev[slot]);  // RayGen.slang:92
             if (flags & kCF_Clamp) {
@@ -749,6 +776,9 @@ int bounce_blocks_per_cu(bool lds_scene, const DeviceScene& sc) {
     if (lds_scene) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_bounce<true, false, false>, kTraverseBlock, lds);
     else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_bounce<false, false, false>, kTraverseBlock, lds);
     return nb > 0 ? nb : 1;
+}
+void launch_raygen(hipStream_t s, const RenderParams& P, const PathState& ps, uint32_t* queue, uint32_t n_slots, uint32_t dispatch_base) {
+    hipLaunchKernelGGL(k_raygen, dim3(cdiv(n_slots, 256)), dim3(256), 0, s, P, ps, queue, n_slots, dispatch_base);
 }
 void launch_prepare(hipStream_t s, Counters* ctr, uint32_t parity) { hipLaunchKernelGGL(k_prepare, dim3(1), dim3(1), 0, s, ctr, parity); }
 void launch_fold(hipStream_t s, Counters* ctr) { hipLaunchKernelGGL(k_fold, dim3(1), dim3(1), 0, s, ctr); }

@@ -124,4 +124,73 @@ __device__ inline bool trace_closest(const Src& src, V3 o, V3 d, float tmin, flo
     return found;
 }
 
+// Shadow queries.  The reference asks for the CLOSEST committed hit and then only looks at (a) whether there
+// is one (sky visibility, ClosestHit.slang:139) or (b) whether it is the sampled light triangle
+// (ClosestHit.slang:171-176).  Both are decided exactly by an any-hit search:
+//   (a) occluded  <=>  some triangle is hit with tmin < t < tmax;
+//   (b) closest == expected  <=>  the expected triangle is hit at t_e (tested first, by its own record) and no
+//       other triangle beats it under the closest-hit order used everywhere here (smaller t, ties to the
+//       smaller global id), i.e. no hit with t < t_e or (t == t_e and gid < expected).
+// The search stops at the first such triangle and never looks beyond t_e, so it visits far fewer nodes than a
+// closest-hit traversal.  LIGHT = false: (a); LIGHT = true: (b) with `t_e`, `expect`.
+template <bool COUNT, bool LIGHT, class Src>
+__device__ inline bool trace_occluded(const Src& src, V3 o, V3 d, float tmin, float tmax, float t_e, uint32_t expect, uint32_t* stack,
+                                      int stride, TravStats& st) {
+    const float tlimit = LIGHT ? t_e : tmax;
+    V3 inv;
+    inv.x = (vptfp::fabs_(d.x) > 1e-30f) ? 1.0f / d.x : (vptfp::f2u(d.x) >> 31 ? -1e30f : 1e30f);
+    inv.y = (vptfp::fabs_(d.y) > 1e-30f) ? 1.0f / d.y : (vptfp::f2u(d.y) >> 31 ? -1e30f : 1e30f);
+    inv.z = (vptfp::fabs_(d.z) > 1e-30f) ? 1.0f / d.z : (vptfp::f2u(d.z) >> 31 ? -1e30f : 1e30f);
+    int sp = 0;
+    int cur = 0;
+    while (true) {
+        if (cur >= 0) {
+            float4 a, b, c; int l, r;
+            src.node(cur, a, b, c, l, r);
+            if (COUNT) st.nodes++;
+            float tl = box_entry(a.x, a.y, a.z, a.w, b.x, b.y, o, inv, tmin, tlimit);
+            float tr = box_entry(b.z, b.w, c.x, c.y, c.z, c.w, o, inv, tmin, tlimit);
+            bool hl = tl >= 0.0f, hr = tr >= 0.0f;
+            if (hl && hr) {
+                bool lfirst = tl <= tr;
+                int nearc = lfirst ? l : r, farc = lfirst ? r : l;
+                if (sp < kStackDepth) { stack[sp * stride] = (uint32_t)farc; sp++; }
+                cur = nearc;
+                continue;
+            } else if (hl) { cur = l; continue; }
+            else if (hr) { cur = r; continue; }
+        } else {
+            uint32_t enc = (uint32_t)(~cur);
+            int first = (int)(enc >> 3), cnt = (int)(enc & 7u) + 1;
+            for (int k = 0; k < cnt; k++) {
+                float4 a, b, c;
+                src.tri(first + k, a, b, c);
+                if (COUNT) st.tris++;
+                float t, u, v;
+                if (vptfp::ray_triangle(o, d, vptfp::v3(a.x, a.y, a.z), vptfp::v3(a.w, b.x, b.y), vptfp::v3(b.z, b.w, c.x), tmin, tmax, &t, &u, &v)) {
+                    if (!LIGHT) return true;
+                    if (t < t_e || (t == t_e && __float_as_uint(c.w) < expect)) return true;
+                }
+            }
+        }
+        if (sp == 0) break;
+        sp--;
+        cur = (int)stack[sp * stride];
+    }
+    return false;
+}
+
+// (b) in full: is the closest hit of the ray the triangle with global id `expect`?  `slot` is that triangle's
+// position in the leaf-ordered triangle array.
+template <bool COUNT, class Src>
+__device__ inline bool closest_is(const Src& src, V3 o, V3 d, float tmin, float tmax, uint32_t expect, uint32_t slot, uint32_t* stack,
+                                  int stride, TravStats& st) {
+    float4 a, b, c;
+    src.tri((int)slot, a, b, c);
+    if (COUNT) st.tris++;
+    float t_e, u, v;
+    if (!vptfp::ray_triangle(o, d, vptfp::v3(a.x, a.y, a.z), vptfp::v3(a.w, b.x, b.y), vptfp::v3(b.z, b.w, c.x), tmin, tmax, &t_e, &u, &v)) return false;
+    return !trace_occluded<COUNT, true>(src, o, d, tmin, tmax, t_e, expect, stack, stride, st);
+}
+
 }  // namespace vpt

@@ -275,17 +275,23 @@ int render_batch(vpt_ctx* c, uint32_t frames, uint32_t dispatch_base, uint32_t f
     const uint32_t n_slots = frames * c->P.shard_pixels;
     hipStream_t s = c->stream;
     const bool count = c->cfg.count_traversal != 0;
-    Counters init{};
-    HIPCHK(c, hipMemcpyAsync(c->ctr, &init, 32, hipMemcpyHostToDevice, s));  // queue words only, stat_* keep running
-    // bounce 0 of every slot, fused; survivors land in queue[1]
-    TIMED(c, VPT_K_PRIMARY, launch_bounce(s, (uint32_t)c->primary_blocks, c->lds_scene, count, true, c->dsc, c->P, c->ps, nullptr, c->queue[1], c->ctr, 0u, n_slots, dispatch_base));
-    // later bounces: fused when the BVH rides in LDS, staged (extend / shade / connect) otherwise
+    // fused (one kernel per bounce, bounce 0 included) when the BVH rides in LDS; staged otherwise
     const bool fused = c->cfg.pipeline == VPT_PIPELINE_FUSED || (c->cfg.pipeline == VPT_PIPELINE_AUTO && c->lds_scene);
-    uint32_t parity = 1;
+    Counters init{};
+    if (!fused) init.ray_count[0] = n_slots;
+    HIPCHK(c, hipMemcpyAsync(c->ctr, &init, 32, hipMemcpyHostToDevice, s));  // queue words only, stat_* keep running
+    uint32_t parity;
+    if (fused) {  // bounce 0 of every slot needs no input records; survivors land in queue[1]
+        TIMED(c, VPT_K_PRIMARY, launch_bounce(s, (uint32_t)c->primary_blocks, c->lds_scene, count, true, c->dsc, c->P, c->ps, nullptr, c->queue[1], c->ctr, 0u, n_slots, dispatch_base));
+        parity = 1;
+    } else {
+        TIMED(c, VPT_K_PRIMARY, launch_raygen(s, c->P, c->ps, c->queue[0], n_slots, dispatch_base));
+        parity = 0;
+    }
     const uint64_t min_bounces = (uint64_t)c->P.max_depth * c->P.samples_per_frame;
     const uint64_t iter_cap = min_bounces * 4ull + 1024ull;
     uint64_t iter = 0;
-    uint32_t chunk = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(min_bounces - 1, 1), 8);
+    uint32_t chunk = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(min_bounces - (fused ? 1 : 0), 1), 8);
     while (true) {
         for (uint32_t j = 0; j < chunk; j++) {
             launch_prepare(s, c->ctr, parity);
@@ -488,6 +494,11 @@ int vpt_set_scene(vpt_ctx* c, const vpt_scene_desc* sd) {
     if ((rc = upload(c, nodes, &D.nodes))) return rc;
     if ((rc = upload(c, leaf_tris, &D.tris))) return rc;
     D.node_count = (uint32_t)nodes.size(); D.tri_count = (uint32_t)leaf_tris.size();
+    {
+        std::vector<uint32_t> slot_of(leaf_tris.size(), 0u);
+        for (size_t i = 0; i < leaf_tris.size(); i++) slot_of[leaf_tris[i].gid] = (uint32_t)i;
+        if ((rc = upload(c, slot_of, &D.tri_slot_of_gid))) return rc;
+    }
     if ((rc = upload(c, verts, &D.vertices))) return rc;
     if ((rc = upload(c, idx, &D.indices))) return rc;
     if ((rc = upload(c, c->meshes, &D.meshes))) return rc;

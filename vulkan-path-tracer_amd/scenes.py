@@ -366,3 +366,198 @@ def sun_sky_env(w, h, seed=7, sun_peak=5.0e4):
     e = np.zeros((h, w, 4), np.float32)
     e[:, :, :3] = img
     return e
+
+
+# ------------------------------------------------------------------ procedural scenes (BASELINE configs 3-5)
+def _grid_mesh(nu, nv, fn):
+    """Tessellated parametric surface: fn(u, v) -> (pos[...,3], nrm[...,3]); u, v in [0,1]."""
+    u, v = np.meshgrid(np.linspace(0, 1, nu + 1), np.linspace(0, 1, nv + 1), indexing="ij")
+    pos, nrm = fn(u, v)
+    uv = np.stack([u, v], -1)
+    idx = np.arange((nu + 1) * (nv + 1)).reshape(nu + 1, nv + 1)
+    a, b, c, d = idx[:-1, :-1], idx[1:, :-1], idx[1:, 1:], idx[:-1, 1:]
+    tris = np.concatenate([np.stack([a, b, c], -1).reshape(-1, 3), np.stack([a, c, d], -1).reshape(-1, 3)])
+    return pos.reshape(-1, 3).astype(np.float32), nrm.reshape(-1, 3).astype(np.float32), uv.reshape(-1, 2).astype(np.float32), tris.astype(np.uint32)
+
+
+def _xform(t=(0, 0, 0), s=(1, 1, 1), ry=0.0):
+    m = np.eye(4)
+    c, sn = np.cos(ry), np.sin(ry)
+    r = np.array([[c, 0, sn], [0, 1, 0], [-sn, 0, c]])
+    m[:3, :3] = r @ np.diag(s)
+    m[:3, 3] = t
+    return m.astype(np.float32)
+
+
+def _fix_normals(pos, nrm, tris):
+    """Make the winding agree with the vertex normals (the backend derives `hit from inside` from the winding)."""
+    p = pos[tris]
+    g = np.cross(p[:, 1] - p[:, 0], p[:, 2] - p[:, 0])
+    n = nrm[tris].sum(1)
+    flip = (g * n).sum(1) < 0
+    tris = tris.copy()
+    tris[flip] = tris[flip][:, [0, 2, 1]]
+    return tris
+
+
+def _tex_checker(rng, n=1024, cells=16, c0=(0.8, 0.75, 0.7), c1=(0.35, 0.3, 0.28), noise=0.08):
+    y, x = np.mgrid[0:n, 0:n]
+    m = (((x * cells // n) + (y * cells // n)) % 2)[..., None]
+    img = np.where(m == 0, np.array(c0), np.array(c1)) + rng.randn(n, n, 1) * noise
+    out = np.empty((n, n, 4), np.uint8)
+    out[..., :3] = np.clip(img, 0, 1) * 255
+    out[..., 3] = 255
+    return out
+
+
+def _tex_noise_r8(rng, n=1024, lo=0.2, hi=0.9, cells=32):
+    coarse = rng.rand(cells + 1, cells + 1)
+    t = np.linspace(0, cells, n, endpoint=False)
+    i = t.astype(int)
+    f = t - i
+    a = coarse[i][:, i] * (1 - f)[None, :] + coarse[i][:, i + 1] * f[None, :]
+    b = coarse[i + 1][:, i] * (1 - f)[None, :] + coarse[i + 1][:, i + 1] * f[None, :]
+    v = a * (1 - f)[:, None] + b * f[:, None]
+    return (np.clip(lo + (hi - lo) * v, 0, 1) * 255).astype(np.uint8)[..., None]
+
+
+def atrium(seed=7, detail=1.0, env_size=(2048, 1024), tex_size=1024):
+    """Sponza-class procedural atrium (SURVEY §8d config 3): two-storey colonnade with arches, drapes, spheres;
+    ~250k triangles at detail=1, ~25 materials (metallic in {0,1}, roughness U[0.1,0.9]), 8 RGBA8 base-colour
+    textures + 4 R8 roughness textures, sun-and-sky env.  World is Y-down (up = -Y) like every scene here."""
+    rng = np.random.RandomState(seed)
+    s = Scene()
+    s.name = "atrium"
+    d = lambda n: max(2, int(round(n * np.sqrt(detail))))
+    base_tex = [s.add_texture(_tex_checker(rng, tex_size, cells=int(rng.choice([8, 16, 32])), c0=tuple(0.5 + 0.45 * rng.rand(3)), c1=tuple(0.15 + 0.3 * rng.rand(3)))) for _ in range(8)]
+    rough_tex = [s.add_texture(_tex_noise_r8(rng, tex_size)) for _ in range(4)]
+    for k in range(25):
+        metal = 1.0 if k % 5 == 4 else 0.0
+        m = material(name="m%d" % k, base_color=tuple(0.4 + 0.55 * rng.rand(3)), metallic=metal, roughness=float(0.1 + 0.8 * rng.rand()))
+        if k % 3 != 2:
+            m["base_color_texture"] = base_tex[k % 8]
+        if k % 4 == 1:
+            m["roughness_texture"] = rough_tex[k % 4]
+        s.materials.append(m)
+
+    def add(fn, nu, nv, mat, xf=None, fix=True):
+        pos, nrm, uv, tris = _grid_mesh(nu, nv, fn)
+        if fix:
+            tris = _fix_normals(pos, nrm, tris)
+        me = s.add_mesh(pos, nrm, uv * 4.0, tris)
+        s.add_instance(me, mat, xf)
+        return me
+
+    L, Wd, Hh = 24.0, 10.0, 9.0   # length (z), half-width (x), height
+    up = -1.0                      # up direction in y
+    # floor + two side walls + back wall + upper gallery slabs
+    add(lambda u, v: (np.stack([(u - 0.5) * 2 * Wd, 0 * u, (v - 0.5) * L], -1), np.stack([0 * u, up + 0 * u, 0 * u], -1)), d(120), d(140), 0)
+    for sx in (-1, 1):
+        add(lambda u, v, sx=sx: (np.stack([sx * Wd + 0 * u, up * v * Hh, (u - 0.5) * L], -1), np.stack([-sx + 0 * u, 0 * u, 0 * u], -1)), d(100), d(40), 1 + (sx > 0))
+        add(lambda u, v, sx=sx: (np.stack([sx * (Wd - 1.5 - 2.0 * u), up * 4.5 + 0 * u, (v - 0.5) * L], -1), np.stack([0 * u, up + 0 * u, 0 * u], -1)), d(12), d(100), 3)
+    add(lambda u, v: (np.stack([(u - 0.5) * 2 * Wd, up * v * Hh, -0.5 * L + 0 * u], -1), np.stack([0 * u, 0 * u, 1 + 0 * u], -1)), d(60), d(30), 5)
+    # one column mesh, instanced along both sides and both storeys
+    def column(u, v):
+        th = u * 2 * np.pi
+        r = 0.32 * (1.0 + 0.12 * np.cos(12 * th)) * (1.0 - 0.15 * v)
+        return np.stack([r * np.cos(th), up * v * 4.2, r * np.sin(th)], -1), np.stack([np.cos(th), 0 * th, np.sin(th)], -1)
+    pos, nrm, uv, tris = _grid_mesh(d(40), d(24), column)
+    col = s.add_mesh(pos, nrm, uv, _fix_normals(pos, nrm, tris))
+    zs = np.linspace(-0.42 * L, 0.42 * L, 10)
+    for storey in range(2):
+        for sx in (-1, 1):
+            for k, z in enumerate(zs):
+                s.add_instance(col, 6 + (k + storey) % 4, _xform((sx * (Wd - 3.5), up * 4.5 * storey, z), (1, 1, 1), ry=0.3 * k))
+    # arches between neighbouring columns (half tori)
+    def arch(u, v):
+        a, b = u * np.pi, v * 2 * np.pi
+        R, r = 0.5 * (zs[1] - zs[0]), 0.18
+        cz, cy = R * np.cos(a), R * np.sin(a)
+        n = np.stack([np.cos(b) + 0 * a, np.sin(b) * np.sin(a), np.sin(b) * np.cos(a)], -1)
+        p = np.stack([0 * a, up * cy, cz], -1) + r * np.stack([n[..., 0], up * n[..., 1], n[..., 2]], -1)
+        return p, np.stack([n[..., 0], up * n[..., 1], n[..., 2]], -1)
+    pos, nrm, uv, tris = _grid_mesh(d(28), d(14), arch)
+    arc = s.add_mesh(pos, nrm, uv, _fix_normals(pos, nrm, tris))
+    for storey in range(2):
+        for sx in (-1, 1):
+            for k in range(len(zs) - 1):
+                s.add_instance(arc, 10 + k % 3, _xform((sx * (Wd - 3.5), up * (4.2 + 4.5 * storey), 0.5 * (zs[k] + zs[k + 1]))))
+    # drapes: wavy cloth sheets hanging across the nave
+    for k in range(8):
+        ph, amp = rng.rand() * 6, 0.25 + 0.2 * rng.rand()
+        z0 = -0.4 * L + k * 0.1 * L
+        def drape(u, v, ph=ph, amp=amp, z0=z0):
+            x = (u - 0.5) * 9.0
+            sag = 1.2 * (1 - (2 * u - 1) ** 2)
+            y = up * (7.5 - sag - 2.5 * v)
+            z = z0 + amp * np.sin(9 * u + ph) * (0.3 + v) + 0.1 * np.sin(23 * v + ph)
+            dz_du = amp * 9 * np.cos(9 * u + ph) * (0.3 + v)
+            n = np.stack([-dz_du / 9.0, 0 * u, 1 + 0 * u], -1)
+            n /= np.linalg.norm(n, axis=-1, keepdims=True)
+            return np.stack([x, y, z], -1), n
+        add(drape, d(64), d(56), 13 + k % 5, fix=True)
+    # spheres on plinths down the nave (metal and dielectric)
+    def sphere(u, v):
+        th, ph_ = u * 2 * np.pi, v * np.pi
+        n = np.stack([np.sin(ph_) * np.cos(th), np.cos(ph_), np.sin(ph_) * np.sin(th)], -1)
+        return n, n
+    pos, nrm, uv, tris = _grid_mesh(d(96), d(48), sphere)
+    sph = s.add_mesh(pos, nrm, uv, _fix_normals(pos, nrm, tris))
+    for k in range(6):
+        r = 0.6 + 0.25 * rng.rand()
+        s.add_instance(sph, 18 + k, _xform(((k % 2 * 2 - 1) * 2.2, up * (r + 0.02), -0.35 * L + k * 0.13 * L), (r, r, r)))
+    s.materials[18].update(metallic=1.0, roughness=0.15)
+    s.materials[20].update(transmission=1.0, roughness=0.05, ior=1.5, base_color=(1, 1, 1))
+    s.materials[24].update(emissive_color=(30.0, 24.0, 15.0), base_color_texture=0)  # a warm lamp
+    lamp_r = 0.35
+    s.add_instance(sph, 24, _xform((0.0, up * 6.5, 0.15 * L), (lamp_r, lamp_r, lamp_r)))
+    s.env = sun_sky_env(env_size[0], env_size[1], seed=seed, sun_peak=5.0e4)
+    eye, at = (0.0, up * 2.2, 0.47 * L), (0.5, up * 3.2, -0.3 * L)
+    s.view_inverse = np.linalg.inv(look_at(eye, at, (0, up, 0)))
+    # camera space is y-down as well (see load_gltf): flip the camera's x/y axes handedness-consistently
+    s.view_inverse = (s.view_inverse @ np.diag([1.0, -1.0, 1.0, 1.0])).astype(np.float32)
+    s.aspect = 16.0 / 9.0
+    return s
+
+
+def glass_bust(seed=11, detail=1.0, env_size=(4096, 2048)):
+    """Glass 'bust' on a plinth: displaced sphere ~500k triangles at detail=1, transmission 1,
+    roughness 0.05, IOR 1.5; diffuse floor; sun-and-sky HDR env."""
+    rng = np.random.RandomState(seed)
+    s = Scene()
+    s.name = "glass_bust"
+    up = -1.0
+    s.materials.append(material(name="glass", transmission=1.0, roughness=0.05, ior=1.5, base_color=(1, 1, 1)))
+    s.materials.append(material(name="floor", base_color=(0.6, 0.58, 0.55), roughness=0.9))
+    s.materials.append(material(name="plinth", base_color=(0.25, 0.25, 0.28), roughness=0.4))
+    ph = rng.rand(6) * 6.28
+    def bust(u, v):
+        th, p = u * 2 * np.pi, v * np.pi
+        n = np.stack([np.sin(p) * np.cos(th), np.cos(p), np.sin(p) * np.sin(th)], -1)
+        r = 1.0 + 0.18 * np.sin(3 * th + ph[0]) * np.sin(2 * p + ph[1]) + 0.07 * np.sin(9 * th + ph[2]) * np.sin(7 * p + ph[3]) + 0.25 * np.exp(-((p - 0.9) ** 2) * 6) * np.cos(th + ph[4])
+        pos = n * r[..., None] * np.array([0.8, 1.15, 0.8])
+        return pos * np.array([1, up, 1]), n * np.array([1, up, 1])
+    n_u = max(8, int(round(708 * np.sqrt(detail))))
+    pos, nrm, uv, tris = _grid_mesh(n_u, n_u // 2, bust)
+    # smooth normals from geometry (the analytic ones ignore the displacement)
+    p = pos[tris]
+    g = np.cross(p[:, 1] - p[:, 0], p[:, 2] - p[:, 0])
+    vn = np.zeros_like(pos)
+    for k in range(3):
+        np.add.at(vn, tris[:, k], g)
+    flip = (vn * nrm).sum(1) < 0
+    vn[flip] *= -1
+    vn /= np.maximum(np.linalg.norm(vn, axis=1, keepdims=True), 1e-20)
+    me = s.add_mesh(pos, vn.astype(np.float32), uv, _fix_normals(pos, vn, tris))
+    s.add_instance(me, 0, _xform((0, up * 2.0, 0)))
+    fpos, fnrm, fuv, ftris = _grid_mesh(64, 64, lambda u, v: (np.stack([(u - 0.5) * 30, 0 * u, (v - 0.5) * 30], -1), np.stack([0 * u, up + 0 * u, 0 * u], -1)))
+    s.add_instance(s.add_mesh(fpos, fnrm, fuv, _fix_normals(fpos, fnrm, ftris)), 1)
+    def cyl(u, v):
+        th = u * 2 * np.pi
+        return np.stack([0.9 * np.cos(th), up * v * 0.8, 0.9 * np.sin(th)], -1), np.stack([np.cos(th), 0 * th, np.sin(th)], -1)
+    cp, cn, cuv, ct = _grid_mesh(96, 8, cyl)
+    s.add_instance(s.add_mesh(cp, cn, cuv, _fix_normals(cp, cn, ct)), 2)
+    s.env = sun_sky_env(env_size[0], env_size[1], seed=seed, sun_peak=5.0e4)
+    s.view_inverse = (np.linalg.inv(look_at((0.0, up * 2.4, 5.2), (0.0, up * 1.9, 0.0), (0, up, 0))) @ np.diag([1.0, -1.0, 1.0, 1.0])).astype(np.float32)
+    s.aspect = 16.0 / 9.0
+    return s
