@@ -159,26 +159,31 @@ def main():
         alive_later = max(n_later - alive0, 0)  # paths leaving bounce k >= 1 alive == paths entering bounce k+1
         trav = nodes_per_ray * NODE_BYTES + tris_per_ray * TRI_BYTES
         strav = snodes_per_ray * NODE_BYTES + stris_per_ray * TRI_BYTES
+        # per stage: (units, algorithmic bytes per unit by SURVEY 8d's formula = path records + scene gathers + BVH visits,
+        #             of which bytes per unit that are path records / queues / frame sums, i.e. unique per path and bound for HBM)
+        scene_hit = SHADE_SCENE
         units = {
-            # per slot: frame sum out for paths that end, records A,B,T,L + queue id for survivors, scene gathers
-            # per hit, node/triangle visits of the camera ray and of the bounce-0 shadow rays
-            "primary": (n0, (PRIMARY_DONE * (n0 - alive0) + PRIMARY_ALIVE * alive0 + SHADE_SCENE * hits0 + strav * rays0) / max(n0, 1) + trav),
+            # fused bounce 0, per slot: frame sum out for paths that end, records A,B,T,L + queue id for survivors
+            "primary": (n0, (PRIMARY_DONE * (n0 - alive0) + PRIMARY_ALIVE * alive0 + scene_hit * hits0 + strav * rays0) / max(n0, 1) + trav,
+                        (PRIMARY_DONE * (n0 - alive0) + PRIMARY_ALIVE * alive0) / max(n0, 1)),
             # fused later bounce: records A,B,T,L in, the same out for survivors, frame sum for paths that end
-            "bounce": (n_later, 4 + 64 + SHADE_SCENE + trav + (PRIMARY_ALIVE * alive_later + PRIMARY_DONE * alive0 + strav * later_rays) / max(n_later, 1)),
-            "extend": (n_later, EXTEND_FIXED + trav),
-            "shade": (n_later, SHADE_IN + SHADE_SCENE + (SHADE_ALIVE_OUT * alive_later + SHADE_PENDING_OUT * st["connect_paths"]
-                                                         + SHADE_RAY_OUT * later_rays) / max(n_later, 1)),
-            "connect": (st["connect_paths"], CONNECT_FIXED + (CONNECT_FINAL * alive0 + (CONNECT_RAY + strav) * later_rays) / max(st["connect_paths"], 1)),
-            "resolve": (st["samples"], RESOLVE_BYTES),
+            "bounce": (n_later, 4 + 64 + scene_hit + trav + (PRIMARY_ALIVE * alive_later + PRIMARY_DONE * alive0 + strav * later_rays) / max(n_later, 1),
+                       4 + 64 + (PRIMARY_ALIVE * alive_later + PRIMARY_DONE * alive0) / max(n_later, 1)),
+            "extend": (n_later, EXTEND_FIXED + trav, EXTEND_FIXED),
+            "shade": (n_later, SHADE_IN + scene_hit + (SHADE_ALIVE_OUT * alive_later + SHADE_PENDING_OUT * st["connect_paths"] + SHADE_RAY_OUT * later_rays) / max(n_later, 1),
+                      SHADE_IN + (SHADE_ALIVE_OUT * alive_later + SHADE_PENDING_OUT * st["connect_paths"] + SHADE_RAY_OUT * later_rays) / max(n_later, 1)),
+            "connect": (st["connect_paths"], CONNECT_FIXED + (CONNECT_FINAL * alive0 + (CONNECT_RAY + strav) * later_rays) / max(st["connect_paths"], 1),
+                        CONNECT_FIXED + (CONNECT_FINAL * alive0 + CONNECT_RAY * later_rays) / max(st["connect_paths"], 1)),
+            "resolve": (st["samples"], RESOLVE_BYTES, RESOLVE_BYTES),
         }
         kernels = {}
-        for name, (n, bpu) in units.items():
+        for name, (n, bpu, spu) in units.items():
             ms, launches = st["kernel_ms"][name], st["kernel_launches"][name]
             if launches == 0 or ms <= 0:
                 continue
             kernels[name] = {"launches": launches, "avg_ms": round(ms / launches, 5), "share": 0.0,
-                             "bytes_per_unit": round(bpu, 1), "units_per_launch": round(n / launches, 1),
-                             "achieved_GBs": round(n * bpu / (ms * 1e-3) / 1e9, 2)}
+                             "bytes_per_unit": round(bpu, 1), "record_bytes_per_unit": round(spu, 1), "units_per_launch": round(n / launches, 1),
+                             "achieved_GBs": round(n * bpu / (ms * 1e-3) / 1e9, 2), "achieved_records_only_GBs": round(n * spu / (ms * 1e-3) / 1e9, 2)}
         tot_ms = sum(st["kernel_ms"][k] for k in kernels)
         for k in kernels:
             kernels[k]["share"] = round(st["kernel_ms"][k] / tot_ms, 4)
@@ -192,6 +197,8 @@ def main():
                 traffic = None
         roof = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(kernels[dom]["achieved_GBs"] / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "achieved_records_only": kernels[dom]["achieved_records_only_GBs"],
+                "note": "achieved counts scene/BVH gathers that this 12-triangle scene serves from LDS/L1; records_only is the part that must cross HBM; traffic is the PMC measurement",
                 "avg_launch_ms": kernels[dom]["avg_ms"],
                 "algorithmic_bytes_per_launch": round(kernels[dom]["bytes_per_unit"] * kernels[dom]["units_per_launch"], 0),
                 "traversal": {"nodes_per_closest_ray": round(nodes_per_ray, 3), "tris_per_closest_ray": round(tris_per_ray, 3),
