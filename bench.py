@@ -37,7 +37,7 @@ WIDTH, HEIGHT, MAX_DEPTH, BASE_SEED = 1920, 1080, 8, 1
 
 # Algorithmic bytes per unit for each stage: state words actually read/written per path or
 # ray by the algorithm with this build's struct sizes; BVH node/triangle visits are measured, not assumed.
-NODE_BYTES, TRI_BYTES = 64, 48
+NODE_BYTES, TRI_BYTES = 128, 48   # BVH4 node = one 128 B line, triangle = 48 B
 EXTEND_FIXED = 4 + 24 + 20          # queue id, origin+direction in, hit record out
 SHADE_IN = 4 + 16 + 16 + 16 + 20    # queue id, records A (origin|rng), B (dir|depth), T (throughput|pdf), hit record
 SHADE_ALIVE_OUT = 16 + 16 + 16 + 4  # A, B, T of the surviving path + next-queue id

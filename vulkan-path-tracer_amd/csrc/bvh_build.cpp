@@ -3,8 +3,8 @@
 // in the Vulkan driver).  Every reference instance gets its own BLAS (PathTracer.cpp:471-479) and is
 // placed once, so instances are flattened into one world-space tree.
 //
-// Output layout (device_types.hpp): 64 B nodes that hold BOTH child boxes, 48 B triangles in leaf
-// order, leaves of <= 4 triangles, depth bounded by kMaxDepth (the traversal stack size).
+// Output layout (device_types.hpp): 128 B four-wide nodes (collapsed from the binary SAH tree), 48 B triangles
+// in leaf order, leaves of <= 4 triangles, binary depth bounded by kMaxDepth (bounds the traversal stack).
 #include "bvh_build.hpp"
 
 #include <algorithm>
@@ -125,8 +125,7 @@ void build_bvh(const std::vector<BvhTri>& tris_in, std::vector<BvhNode>& nodes_o
     const float pad = 2.0e-5f * maxabs + 1.0e-6f;
     if (tris_in.empty()) {
         BvhNode n; std::memset(&n, 0, sizeof(n));
-        for (int a = 0; a < 3; a++) { n.lmin[a] = n.rmin[a] = 1.0e30f; n.lmax[a] = n.rmax[a] = 1.0e30f; }  // unreachable point boxes
-        n.left = n.right = leaf_code(0, 1);
+        for (int k = 0; k < 4; k++) { n.minx[k] = n.miny[k] = n.minz[k] = n.maxx[k] = n.maxy[k] = n.maxz[k] = 1.0e30f; n.child[k] = leaf_code(0, 1); }
         nodes_out.push_back(n);
         if (depth_out) *depth_out = 0;
         return;
@@ -135,44 +134,54 @@ void build_bvh(const std::vector<BvhTri>& tris_in, std::vector<BvhNode>& nodes_o
     tris_out.resize(tris_in.size());
     for (size_t i = 0; i < b.refs.size(); i++) tris_out[i] = tris_in[b.refs[i].tri];
 
-    // emit: inner tmp nodes -> 64 B nodes in depth-first order; a leaf root gets a wrapper node.
-    std::vector<int> inner_index(b.nodes.size(), -1);
+    // emit: collapse the binary tree into 4-wide nodes (a node adopts its grandchildren, largest box first),
+    // depth-first order; a leaf root gets a wrapper node.
     int max_depth = 0;
-    auto child_code = [&](int tn) -> int32_t {
-        const TmpNode& c = b.nodes[tn];
-        return c.left < 0 ? leaf_code(c.first, c.count) : inner_index[tn];
+    auto put_box = [&](BvhNode& n, int k, const Box& bx) {
+        n.minx[k] = bx.lo[0] - pad; n.miny[k] = bx.lo[1] - pad; n.minz[k] = bx.lo[2] - pad;
+        n.maxx[k] = bx.hi[0] + pad; n.maxy[k] = bx.hi[1] + pad; n.maxz[k] = bx.hi[2] + pad;
     };
-    // assign indices depth-first
-    {
-        std::vector<std::pair<int, int>> st; st.push_back({0, 0});
-        int next = 0;
-        while (!st.empty()) {
-            auto [tn, d] = st.back(); st.pop_back();
-            max_depth = std::max(max_depth, d);
-            if (b.nodes[tn].left < 0) continue;
-            inner_index[tn] = next++;
-            st.push_back({b.nodes[tn].right, d + 1});
-            st.push_back({b.nodes[tn].left, d + 1});
-        }
-        nodes_out.resize(next > 0 ? next : 1);
-    }
-    auto put_box = [&](const Box& bx, float* mn, float* mx) { for (int a = 0; a < 3; a++) { mn[a] = bx.lo[a] - pad; mx[a] = bx.hi[a] + pad; } };
-    if (b.nodes[0].left < 0) {
+    auto empty_node = [&]() {
         BvhNode n; std::memset(&n, 0, sizeof(n));
-        put_box(b.nodes[0].b, n.lmin, n.lmax);
-        for (int a = 0; a < 3; a++) { n.rmin[a] = 1.0e30f; n.rmax[a] = 1.0e30f; }  // unreachable point box
-        n.left = leaf_code(b.nodes[0].first, b.nodes[0].count);
-        n.right = n.left;  // never entered: its box is empty
-        nodes_out[0] = n;
+        for (int k = 0; k < 4; k++) {
+            n.minx[k] = n.miny[k] = n.minz[k] = n.maxx[k] = n.maxy[k] = n.maxz[k] = 1.0e30f;  // unreachable point box
+            n.child[k] = leaf_code(0, 1);
+        }
+        return n;
+    };
+    struct Item { int tmp; int out; int depth; };
+    std::vector<Item> work;
+    nodes_out.push_back(empty_node());
+    if (b.nodes[0].left < 0) {
+        put_box(nodes_out[0], 0, b.nodes[0].b);
+        nodes_out[0].child[0] = leaf_code(b.nodes[0].first, b.nodes[0].count);
     } else {
-        for (size_t tn = 0; tn < b.nodes.size(); tn++) {
-            if (inner_index[tn] < 0) continue;
-            const TmpNode& t = b.nodes[tn];
-            BvhNode n; std::memset(&n, 0, sizeof(n));
-            put_box(b.nodes[t.left].b, n.lmin, n.lmax);
-            put_box(b.nodes[t.right].b, n.rmin, n.rmax);
-            n.left = child_code(t.left); n.right = child_code(t.right);
-            nodes_out[inner_index[tn]] = n;
+        work.push_back({0, 0, 0});
+    }
+    while (!work.empty()) {
+        Item it = work.back(); work.pop_back();
+        max_depth = std::max(max_depth, it.depth);
+        int kids[4]; int nk = 0;
+        kids[nk++] = b.nodes[it.tmp].left; kids[nk++] = b.nodes[it.tmp].right;
+        while (nk < 4) {
+            int best = -1; float ba = -1.0f;
+            for (int k = 0; k < nk; k++)
+                if (b.nodes[kids[k]].left >= 0) { float a = b.nodes[kids[k]].b.half_area(); if (a > ba) { ba = a; best = k; } }
+            if (best < 0) break;
+            int t = kids[best];
+            kids[best] = b.nodes[t].left; kids[nk++] = b.nodes[t].right;
+        }
+        for (int k = 0; k < nk; k++) {
+            const TmpNode& c = b.nodes[kids[k]];
+            put_box(nodes_out[it.out], k, c.b);
+            if (c.left < 0) {
+                nodes_out[it.out].child[k] = leaf_code(c.first, c.count);
+            } else {
+                int idx = (int)nodes_out.size();
+                nodes_out.push_back(empty_node());
+                nodes_out[it.out].child[k] = idx;
+                work.push_back({kids[k], idx, it.depth + 1});
+            }
         }
     }
     if (depth_out) *depth_out = max_depth;

@@ -12,15 +12,17 @@ using vptfp::V2;
 using vptfp::V3;
 using vptfp::V4;
 
-// ---- BVH2, 64-byte nodes: both child boxes live in the parent so one 64 B fetch (4 x dwordx4)
-// decides both children.  child >= 0: inner node index; child < 0: leaf, ~child = first<<3 | (count-1).
+// ---- BVH4, 128-byte nodes = one cache line: the four child boxes in SoA form (6 x dwordx4) + four child
+// codes, so ONE fetch decides four children and a ray needs about half the dependent memory round-trips
+// of a binary tree.  child >= 0: inner node index; child < 0: leaf, ~child = first<<3 | (count-1).
+// Unused child slots hold an unreachable point box at 1e30.
 struct BvhNode {
-    float lmin[3], lmax[3];
-    float rmin[3], rmax[3];
-    int32_t left, right;
-    uint32_t pad0, pad1;
+    float minx[4], miny[4], minz[4];
+    float maxx[4], maxy[4], maxz[4];
+    int32_t child[4];
+    uint32_t pad[4];
 };
-static_assert(sizeof(BvhNode) == 64, "node is 64 B");
+static_assert(sizeof(BvhNode) == 128, "node is 128 B");
 
 // World-space triangle, 48 bytes (3 x dwordx4), stored in BVH leaf order.
 struct BvhTri {
@@ -101,6 +103,7 @@ struct DeviceScene {
     const EmissiveTri* emissive_tri;        // per emissive triangle
     const uint32_t* emissive_tri_offset;    // per emissive mesh: first entry in emissive_tri
     const uint32_t* tri_slot_of_gid;        // per global triangle id: position in the leaf-ordered triangle array
+    uint32_t* stack_overflow;               // traversal stack entries beyond the LDS part, kStackOverflow per resident thread
 };
 
 struct RenderParams {

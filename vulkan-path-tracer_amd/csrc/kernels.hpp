@@ -18,12 +18,13 @@ void launch_shade(hipStream_t s, uint32_t blocks, const DeviceScene& sc, const R
 void launch_connect(hipStream_t s, uint32_t blocks, bool lds_scene, bool count, const DeviceScene& sc, const RenderParams& P,
                     const PathState& ps, const uint32_t* cqueue, Counters* ctr, uint32_t parity);
 void launch_resolve(hipStream_t s, const RenderParams& P, const PathState& ps, float* image, uint32_t frames, uint32_t frame_base);
-void launch_trace_rays(hipStream_t s, const DeviceScene& sc, const vpt_ray* rays, uint32_t n, vpt_hit* hits);
+void launch_trace_rays(hipStream_t s, uint32_t blocks, const DeviceScene& sc, const vpt_ray* rays, uint32_t n, vpt_hit* hits);
 void launch_scatter_rows(hipStream_t s, const float* gathered, float* full, uint32_t w, uint32_t h, uint32_t shard_count, uint32_t stride_px);
 void launch_precompute_materials(hipStream_t s, const DeviceScene& sc, uint32_t flags, MatResolved* out, uint32_t n);
 void launch_precompute_tri_ng(hipStream_t s, const DeviceScene& sc, float4* out);
 void launch_precompute_emissive(hipStream_t s, const DeviceScene& sc, EmissiveTri* out, uint32_t total);
 size_t traverse_lds_bytes(const DeviceScene& sc, bool lds_scene);
+size_t stack_overflow_bytes(uint32_t blocks);  // per-thread spill region of the traversal stacks for a grid of `blocks`
 int traverse_blocks_per_cu(bool lds_scene, const DeviceScene& sc);
 int shade_blocks_per_cu();
 

@@ -79,32 +79,32 @@ __device__ inline void stage_scene(const DeviceScene& sc, float4* lds_nodes, flo
     if (LDS_SCENE) {
         const float4* gn = reinterpret_cast<const float4*>(sc.nodes);
         const float4* gt = reinterpret_cast<const float4*>(sc.tris);
-        for (uint32_t i = threadIdx.x; i < sc.node_count * 4; i += blockDim.x) lds_nodes[i] = gn[i];
+        for (uint32_t i = threadIdx.x; i < sc.node_count * 8; i += blockDim.x) lds_nodes[i] = gn[i];
         for (uint32_t i = threadIdx.x; i < sc.tri_count * 3; i += blockDim.x) lds_tris[i] = gt[i];
         __syncthreads();
     }
 }
 template <bool LDS_SCENE, bool COUNT>
 __device__ inline bool trace_any(const DeviceScene& sc, const float4* lds_nodes, const float4* lds_tris, V3 o, V3 d, float tmin,
-                                 float tmax, uint32_t* stack, HitRec& h, TravStats& st) {
-    if (LDS_SCENE) { LdsSceneSrc src{lds_nodes, lds_tris}; return trace_closest<COUNT>(src, o, d, tmin, tmax, stack, kTraverseBlock, h, st); }
+                                 float tmax, const TravStack& stack, HitRec& h, TravStats& st) {
+    if (LDS_SCENE) { LdsSceneSrc src{lds_nodes, lds_tris}; return trace_closest<COUNT>(src, o, d, tmin, tmax, stack, h, st); }
     GlobalSceneSrc src{sc.nodes, sc.tris};
-    return trace_closest<COUNT>(src, o, d, tmin, tmax, stack, kTraverseBlock, h, st);
+    return trace_closest<COUNT>(src, o, d, tmin, tmax, stack, h, st);
 }
 
 // Sky visibility / light identity as exact any-hit queries (traverse.hpp).
 template <bool LDS_SCENE, bool COUNT>
-__device__ inline bool sky_visible(const DeviceScene& sc, const float4* lds_nodes, const float4* lds_tris, V3 o, V3 d, uint32_t* stack, TravStats& st) {
-    if (LDS_SCENE) { LdsSceneSrc src{lds_nodes, lds_tris}; return !trace_occluded<COUNT, false>(src, o, d, 0.0001f, 1000000.0f, 0.0f, 0u, stack, kTraverseBlock, st); }
+__device__ inline bool sky_visible(const DeviceScene& sc, const float4* lds_nodes, const float4* lds_tris, V3 o, V3 d, const TravStack& stack, TravStats& st) {
+    if (LDS_SCENE) { LdsSceneSrc src{lds_nodes, lds_tris}; return !trace_occluded<COUNT, false>(src, o, d, 0.0001f, 1000000.0f, 0.0f, 0u, stack, st); }
     GlobalSceneSrc src{sc.nodes, sc.tris};
-    return !trace_occluded<COUNT, false>(src, o, d, 0.0001f, 1000000.0f, 0.0f, 0u, stack, kTraverseBlock, st);
+    return !trace_occluded<COUNT, false>(src, o, d, 0.0001f, 1000000.0f, 0.0f, 0u, stack, st);
 }
 template <bool LDS_SCENE, bool COUNT>
-__device__ inline bool light_visible(const DeviceScene& sc, const float4* lds_nodes, const float4* lds_tris, V3 o, V3 d, uint32_t gid, uint32_t* stack, TravStats& st) {
+__device__ inline bool light_visible(const DeviceScene& sc, const float4* lds_nodes, const float4* lds_tris, V3 o, V3 d, uint32_t gid, const TravStack& stack, TravStats& st) {
     uint32_t slot = sc.tri_slot_of_gid[gid];
-    if (LDS_SCENE) { LdsSceneSrc src{lds_nodes, lds_tris}; return closest_is<COUNT>(src, o, d, 0.0001f, 1000000.0f, gid, slot, stack, kTraverseBlock, st); }
+    if (LDS_SCENE) { LdsSceneSrc src{lds_nodes, lds_tris}; return closest_is<COUNT>(src, o, d, 0.0001f, 1000000.0f, gid, slot, stack, st); }
     GlobalSceneSrc src{sc.nodes, sc.tris};
-    return closest_is<COUNT>(src, o, d, 0.0001f, 1000000.0f, gid, slot, stack, kTraverseBlock, st);
+    return closest_is<COUNT>(src, o, d, 0.0001f, 1000000.0f, gid, slot, stack, st);
 }
 
 // ------------------------------------------------------------------ extend: closest hit of every queued path
@@ -112,9 +112,9 @@ template <bool LDS_SCENE, bool COUNT>
 __global__ __launch_bounds__(kTraverseBlock) void k_extend(DeviceScene sc, PathState ps, const uint32_t* queue,
                                                           Counters* ctr, uint32_t parity) {
     extern __shared__ __align__(16) unsigned char smem[];
-    uint32_t* stack = reinterpret_cast<uint32_t*>(smem) + threadIdx.x;
+    const TravStack stack = make_stack(smem, sc.stack_overflow);
     float4* lds_nodes = reinterpret_cast<float4*>(smem + kStackDepth * kTraverseBlock * 4);
-    float4* lds_tris = lds_nodes + sc.node_count * 4;
+    float4* lds_tris = lds_nodes + sc.node_count * 8;
     stage_scene<LDS_SCENE>(sc, lds_nodes, lds_tris);
     const uint32_t n = ctr->ray_count[parity];
     const uint32_t chunk = fetch_chunk(n);
@@ -145,16 +145,16 @@ __global__ __launch_bounds__(kTraverseBlock) void k_extend(DeviceScene sc, PathS
 // Test hook: the extend traversal on caller-supplied rays.
 __global__ __launch_bounds__(kTraverseBlock) void k_trace_rays(DeviceScene sc, const vpt_ray* rays, uint32_t n, vpt_hit* hits) {
     extern __shared__ __align__(16) unsigned char smem[];
-    uint32_t* stack = reinterpret_cast<uint32_t*>(smem) + threadIdx.x;
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    vpt_ray r = rays[i];
-    HitRec h; TravStats st;
+    const TravStack stack = make_stack(smem, sc.stack_overflow);
     GlobalSceneSrc src{sc.nodes, sc.tris};
-    bool found = trace_closest<false>(src, v3(r.origin[0], r.origin[1], r.origin[2]), v3(r.direction[0], r.direction[1], r.direction[2]),
-                                      r.tmin, r.tmax, stack, kTraverseBlock, h, st);
-    vpt_hit o; o.t = found ? h.t : -1.0f; o.u = found ? h.u : 0.0f; o.v = found ? h.v : 0.0f; o.primitive = h.prim; o.instance = h.inst;
-    hits[i] = o;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        vpt_ray r = rays[i];
+        HitRec h; TravStats st;
+        bool found = trace_closest<false>(src, v3(r.origin[0], r.origin[1], r.origin[2]), v3(r.direction[0], r.direction[1], r.direction[2]),
+                                          r.tmin, r.tmax, stack, h, st);
+        vpt_hit o; o.t = found ? h.t : -1.0f; o.u = found ? h.u : 0.0f; o.v = found ? h.v : 0.0f; o.primitive = h.prim; o.instance = h.inst;
+        hits[i] = o;
+    }
 }
 
 // ------------------------------------------------------------------ shade
@@ -485,9 +485,9 @@ __global__ __launch_bounds__(kTraverseBlock, 3) void k_bounce(DeviceScene sc, Re
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ uint32_t s_cnt[4][3];
     __shared__ uint32_t s_base[4];
-    uint32_t* stack = reinterpret_cast<uint32_t*>(smem) + threadIdx.x;
+    const TravStack stack = make_stack(smem, sc.stack_overflow);
     float4* lds_nodes = reinterpret_cast<float4*>(smem + kStackDepth * kTraverseBlock * 4);
-    float4* lds_tris = lds_nodes + sc.node_count * 4;
+    float4* lds_tris = lds_nodes + sc.node_count * 8;
     stage_scene<LDS_SCENE>(sc, lds_nodes, lds_tris);
     const uint32_t n = FIRST ? n_slots : ctr->ray_count[parity];
     const float4* Tin = ps.T[parity];
@@ -616,9 +616,9 @@ template <bool LDS_SCENE, bool COUNT>
 __global__ __launch_bounds__(kTraverseBlock) void k_connect(DeviceScene sc, RenderParams P, PathState ps, const uint32_t* cqueue,
                                                            Counters* ctr, uint32_t parity) {
     extern __shared__ __align__(16) unsigned char smem[];
-    uint32_t* stack = reinterpret_cast<uint32_t*>(smem) + threadIdx.x;
+    const TravStack stack = make_stack(smem, sc.stack_overflow);
     float4* lds_nodes = reinterpret_cast<float4*>(smem + kStackDepth * kTraverseBlock * 4);
-    float4* lds_tris = lds_nodes + sc.node_count * 4;
+    float4* lds_tris = lds_nodes + sc.node_count * 8;
     stage_scene<LDS_SCENE>(sc, lds_nodes, lds_tris);
     const uint32_t nf = ctr->connect_front, nb = ctr->connect_back, n = nf + nb;
     const float4* Tprev = ps.T[parity];
@@ -785,7 +785,7 @@ void launch_fold(hipStream_t s, Counters* ctr) { hipLaunchKernelGGL(k_fold, dim3
 
 size_t traverse_lds_bytes(const DeviceScene& sc, bool lds_scene) {
     size_t b = (size_t)kStackDepth * kTraverseBlock * 4;
-    if (lds_scene) b += (size_t)sc.node_count * 64 + (size_t)sc.tri_count * 48;
+    if (lds_scene) b += (size_t)sc.node_count * sizeof(BvhNode) + (size_t)sc.tri_count * sizeof(BvhTri);
     return b;
 }
 void launch_extend(hipStream_t s, uint32_t blocks, bool lds_scene, bool count, const DeviceScene& sc, const PathState& ps,
@@ -817,13 +817,15 @@ void launch_shade(hipStream_t s, uint32_t blocks, const DeviceScene& sc, const R
 void launch_resolve(hipStream_t s, const RenderParams& P, const PathState& ps, float* image, uint32_t frames, uint32_t frame_base) {
     hipLaunchKernelGGL(k_resolve, dim3(cdiv(P.shard_pixels, 256)), dim3(256), 0, s, P, ps, reinterpret_cast<float4*>(image), frames, frame_base);
 }
-void launch_trace_rays(hipStream_t s, const DeviceScene& sc, const vpt_ray* rays, uint32_t n, vpt_hit* hits) {
-    hipLaunchKernelGGL(k_trace_rays, dim3(cdiv(n, kTraverseBlock)), dim3(kTraverseBlock), (size_t)kStackDepth * kTraverseBlock * 4, s, sc, rays, n, hits);
+void launch_trace_rays(hipStream_t s, uint32_t blocks, const DeviceScene& sc, const vpt_ray* rays, uint32_t n, vpt_hit* hits) {
+    uint32_t g = cdiv(n, kTraverseBlock);
+    hipLaunchKernelGGL(k_trace_rays, dim3(g < blocks ? g : blocks), dim3(kTraverseBlock), (size_t)kStackDepth * kTraverseBlock * 4, s, sc, rays, n, hits);
 }
 void launch_scatter_rows(hipStream_t s, const float* gathered, float* full, uint32_t w, uint32_t h, uint32_t shard_count, uint32_t stride_px) {
     hipLaunchKernelGGL(k_scatter_rows, dim3(cdiv(w * h, 256)), dim3(256), 0, s, reinterpret_cast<const float4*>(gathered),
                        reinterpret_cast<float4*>(full), w, h, shard_count, stride_px);
 }
+size_t stack_overflow_bytes(uint32_t blocks) { return (size_t)blocks * kTraverseBlock * kStackOverflow * 4; }
 int traverse_blocks_per_cu(bool lds_scene, const DeviceScene& sc) {
     int nb = 0;
     size_t lds = traverse_lds_bytes(sc, lds_scene);

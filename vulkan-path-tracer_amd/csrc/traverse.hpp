@@ -1,19 +1,23 @@
-// traverse.hpp — closest-hit BVH2 traversal for one ray per lane (replaces the driver-side
-// TraceRay / RayQuery of RayGen.slang:90 and RTCommon.slang:54-63).
+// traverse.hpp — BVH4 traversal for one ray per lane (replaces the driver-side TraceRay / RayQuery of
+// RayGen.slang:90 and RTCommon.slang:54-63).
 //
-// * nodes are 64 B (both child boxes in the parent), triangles 48 B; near child first, far child
-//   pushed on a per-lane stack that lives in LDS as stack[depth][lane] (bank = lane, conflict-free);
-// * the triangle test is the shared fp32 contract vptfp::ray_triangle(), so (t,u,v) are bit-identical
-//   to the oracle's; ties in t go to the smaller global triangle id, so the result does not depend
-//   on traversal order or tree shape;
-// * box tests are conservative (boxes are padded at build time; the interval test carries a 4-ulp
-//   slack) — a box test only ever prunes, it never decides a hit.
+// * nodes are 128 B (four child boxes in SoA form + four child codes: one cache line, 7 x dwordx4),
+//   triangles 48 B; closest-hit search visits the hit children nearest first (4-element sorting network on the
+//   entry distances), any-hit search takes them in slot order;
+// * the per-lane stack lives in LDS as stack[depth][lane] (bank = lane, conflict-free) for the first
+//   kStackDepth entries and spills to a per-thread global region beyond that (rare: 3 pushes per level);
+// * the triangle test is the shared fp32 contract vptfp::ray_triangle(), so (t,u,v) are bit-identical to the
+//   oracle's; ties in t go to the smaller global triangle id, so the result does not depend on traversal
+//   order or tree shape;
+// * box tests are conservative (boxes are padded at build time; the interval test carries a 4-ulp slack) — a
+//   box test only ever prunes, it never decides a hit.
 #pragma once
 #include "device_types.hpp"
 
 namespace vpt {
 
-constexpr int kStackDepth = 32;  // the builder bounds the tree depth to this
+constexpr int kStackDepth = 24;      // LDS entries per lane
+constexpr int kStackOverflow = 72;   // global entries per lane: 3 pushes per level x binary depth bound 30, minus the LDS part
 constexpr int kTraverseBlock = 256;
 
 struct HitRec {
@@ -25,15 +29,42 @@ struct TravStats {
     uint32_t nodes, tris;
 };
 
+struct TravStack {
+    uint32_t* lds;    // this lane's column: entry k at lds[k * kTraverseBlock]
+    uint32_t* glob;   // this thread's overflow region
+    int sp;
+    __device__ inline void push(uint32_t v) {
+        if (sp < kStackDepth) lds[sp * kTraverseBlock] = v;
+        else if (sp < kStackDepth + kStackOverflow) glob[sp - kStackDepth] = v;
+        sp++;
+    }
+    __device__ inline uint32_t pop() {
+        sp--;
+        return sp < kStackDepth ? lds[sp * kTraverseBlock] : glob[sp - kStackDepth];
+    }
+};
+__device__ inline TravStack make_stack(unsigned char* smem, uint32_t* overflow) {
+    TravStack s;
+    s.lds = reinterpret_cast<uint32_t*>(smem) + threadIdx.x;
+    s.glob = overflow + (size_t)(blockIdx.x * blockDim.x + threadIdx.x) * kStackOverflow;
+    s.sp = 0;
+    return s;
+}
+
+struct NodeData {
+    float4 minx, miny, minz, maxx, maxy, maxz;
+    int c0, c1, c2, c3;
+};
+
 // Scene access either from global memory or from an LDS copy (small scenes).
 struct GlobalSceneSrc {
     const BvhNode* nodes;
     const BvhTri* tris;
-    __device__ inline void node(int i, float4& a, float4& b, float4& c, int& l, int& r) const {
+    __device__ inline void node(int i, NodeData& n) const {
         const float4* p = reinterpret_cast<const float4*>(nodes + i);
-        a = p[0]; b = p[1]; c = p[2];
-        float4 d = p[3];
-        l = __float_as_int(d.x); r = __float_as_int(d.y);
+        n.minx = p[0]; n.miny = p[1]; n.minz = p[2]; n.maxx = p[3]; n.maxy = p[4]; n.maxz = p[5];
+        float4 c = p[6];
+        n.c0 = __float_as_int(c.x); n.c1 = __float_as_int(c.y); n.c2 = __float_as_int(c.z); n.c3 = __float_as_int(c.w);
     }
     __device__ inline void tri(int i, float4& a, float4& b, float4& c) const {
         const float4* p = reinterpret_cast<const float4*>(tris + i);
@@ -43,11 +74,11 @@ struct GlobalSceneSrc {
 struct LdsSceneSrc {
     const float4* nodes;  // LDS
     const float4* tris;   // LDS
-    __device__ inline void node(int i, float4& a, float4& b, float4& c, int& l, int& r) const {
-        const float4* p = nodes + i * 4;
-        a = p[0]; b = p[1]; c = p[2];
-        float4 d = p[3];
-        l = __float_as_int(d.x); r = __float_as_int(d.y);
+    __device__ inline void node(int i, NodeData& n) const {
+        const float4* p = nodes + i * 8;
+        n.minx = p[0]; n.miny = p[1]; n.minz = p[2]; n.maxx = p[3]; n.maxy = p[4]; n.maxz = p[5];
+        float4 c = p[6];
+        n.c0 = __float_as_int(c.x); n.c1 = __float_as_int(c.y); n.c2 = __float_as_int(c.z); n.c3 = __float_as_int(c.w);
     }
     __device__ inline void tri(int i, float4& a, float4& b, float4& c) const {
         const float4* p = tris + i * 3;
@@ -57,8 +88,9 @@ struct LdsSceneSrc {
 
 __device__ inline float fmin_(float a, float b) { return __builtin_fminf(a, b); }
 __device__ inline float fmax_(float a, float b) { return __builtin_fmaxf(a, b); }
+constexpr float kMissT = 3.0e38f;
 
-// Entry distance of the ray into a box, or a negative value if it misses [tmin, tlimit].
+// Entry distance of the ray into a box, or kMissT if it misses [tmin, tlimit].
 __device__ inline float box_entry(float bx0, float by0, float bz0, float bx1, float by1, float bz1, V3 o, V3 inv,
                                   float tmin, float tlimit) {
     float t0x = (bx0 - o.x) * inv.x, t1x = (bx1 - o.x) * inv.x;
@@ -66,38 +98,53 @@ __device__ inline float box_entry(float bx0, float by0, float bz0, float bx1, fl
     float t0z = (bz0 - o.z) * inv.z, t1z = (bz1 - o.z) * inv.z;
     float tn = fmax_(fmax_(fmin_(t0x, t1x), fmin_(t0y, t1y)), fmax_(fmin_(t0z, t1z), tmin));
     float tf = fmin_(fmin_(fmax_(t0x, t1x), fmax_(t0y, t1y)), fmin_(fmax_(t0z, t1z), tlimit));
-    return (tn <= tf * 1.0000005f) ? tn : -1.0f;
+    return (tn <= tf * 1.0000005f) ? tn : kMissT;
 }
-
-// stack: this lane's column, entries at stack[k * stride].
-template <bool COUNT, class Src>
-__device__ inline bool trace_closest(const Src& src, V3 o, V3 d, float tmin, float tmax, uint32_t* stack, int stride,
-                                     HitRec& best, TravStats& st) {
-    best.t = tmax; best.u = 0.0f; best.v = 0.0f; best.prim = 0xffffffffu; best.inst = 0xffffffffu; best.gid = 0xffffffffu;
-    bool found = false;
-    V3 inv;
+__device__ inline V3 safe_inverse(V3 d) {
     // a zero component would give 0*inf = NaN in the slab test: clamp its reciprocal to +-1e30
+    V3 inv;
     inv.x = (vptfp::fabs_(d.x) > 1e-30f) ? 1.0f / d.x : (vptfp::f2u(d.x) >> 31 ? -1e30f : 1e30f);
     inv.y = (vptfp::fabs_(d.y) > 1e-30f) ? 1.0f / d.y : (vptfp::f2u(d.y) >> 31 ? -1e30f : 1e30f);
     inv.z = (vptfp::fabs_(d.z) > 1e-30f) ? 1.0f / d.z : (vptfp::f2u(d.z) >> 31 ? -1e30f : 1e30f);
-    int sp = 0;
+    return inv;
+}
+__device__ inline void node_entries(const NodeData& n, V3 o, V3 inv, float tmin, float tlimit, float& t0, float& t1, float& t2, float& t3) {
+    t0 = box_entry(n.minx.x, n.miny.x, n.minz.x, n.maxx.x, n.maxy.x, n.maxz.x, o, inv, tmin, tlimit);
+    t1 = box_entry(n.minx.y, n.miny.y, n.minz.y, n.maxx.y, n.maxy.y, n.maxz.y, o, inv, tmin, tlimit);
+    t2 = box_entry(n.minx.z, n.miny.z, n.minz.z, n.maxx.z, n.maxy.z, n.maxz.z, o, inv, tmin, tlimit);
+    t3 = box_entry(n.minx.w, n.miny.w, n.minz.w, n.maxx.w, n.maxy.w, n.maxz.w, o, inv, tmin, tlimit);
+}
+__device__ inline void cswap(float& ta, int& ca, float& tb, int& cb) {
+    bool sw = tb < ta;
+    float tt = sw ? tb : ta; int ct = sw ? cb : ca;
+    tb = sw ? ta : tb; cb = sw ? ca : cb;
+    ta = tt; ca = ct;
+}
+
+// Closest hit with tmin < t < tmax; ties -> smaller global triangle id.
+template <bool COUNT, class Src>
+__device__ inline bool trace_closest(const Src& src, V3 o, V3 d, float tmin, float tmax, TravStack stack, HitRec& best, TravStats& st) {
+    best.t = tmax; best.u = 0.0f; best.v = 0.0f; best.prim = 0xffffffffu; best.inst = 0xffffffffu; best.gid = 0xffffffffu;
+    bool found = false;
+    const V3 inv = safe_inverse(d);
+    stack.sp = 0;
     int cur = 0;  // root is inner node 0
     while (true) {
         if (cur >= 0) {
-            float4 a, b, c; int l, r;
-            src.node(cur, a, b, c, l, r);
+            NodeData n;
+            src.node(cur, n);
             if (COUNT) st.nodes++;
-            float tl = box_entry(a.x, a.y, a.z, a.w, b.x, b.y, o, inv, tmin, best.t);
-            float tr = box_entry(b.z, b.w, c.x, c.y, c.z, c.w, o, inv, tmin, best.t);
-            bool hl = tl >= 0.0f, hr = tr >= 0.0f;
-            if (hl && hr) {
-                bool lfirst = tl <= tr;
-                int nearc = lfirst ? l : r, farc = lfirst ? r : l;
-                if (sp < kStackDepth) { stack[sp * stride] = (uint32_t)farc; sp++; }
-                cur = nearc;
+            float t0, t1, t2, t3;
+            node_entries(n, o, inv, tmin, best.t, t0, t1, t2, t3);
+            int c0 = n.c0, c1 = n.c1, c2 = n.c2, c3 = n.c3;
+            cswap(t0, c0, t1, c1); cswap(t2, c2, t3, c3); cswap(t0, c0, t2, c2); cswap(t1, c1, t3, c3); cswap(t1, c1, t2, c2);
+            if (t0 < kMissT) {  // nearest child next, the others pushed far -> near
+                if (t3 < kMissT) stack.push((uint32_t)c3);
+                if (t2 < kMissT) stack.push((uint32_t)c2);
+                if (t1 < kMissT) stack.push((uint32_t)c1);
+                cur = c0;
                 continue;
-            } else if (hl) { cur = l; continue; }
-            else if (hr) { cur = r; continue; }
+            }
         } else {
             uint32_t enc = (uint32_t)(~cur);
             int first = (int)(enc >> 3), cnt = (int)(enc & 7u) + 1;
@@ -117,9 +164,8 @@ __device__ inline bool trace_closest(const Src& src, V3 o, V3 d, float tmin, flo
                 }
             }
         }
-        if (sp == 0) break;
-        sp--;
-        cur = (int)stack[sp * stride];
+        if (stack.sp == 0) break;
+        cur = (int)stack.pop();
     }
     return found;
 }
@@ -134,31 +180,25 @@ __device__ inline bool trace_closest(const Src& src, V3 o, V3 d, float tmin, flo
 // The search stops at the first such triangle and never looks beyond t_e, so it visits far fewer nodes than a
 // closest-hit traversal.  LIGHT = false: (a); LIGHT = true: (b) with `t_e`, `expect`.
 template <bool COUNT, bool LIGHT, class Src>
-__device__ inline bool trace_occluded(const Src& src, V3 o, V3 d, float tmin, float tmax, float t_e, uint32_t expect, uint32_t* stack,
-                                      int stride, TravStats& st) {
+__device__ inline bool trace_occluded(const Src& src, V3 o, V3 d, float tmin, float tmax, float t_e, uint32_t expect, TravStack stack,
+                                      TravStats& st) {
     const float tlimit = LIGHT ? t_e : tmax;
-    V3 inv;
-    inv.x = (vptfp::fabs_(d.x) > 1e-30f) ? 1.0f / d.x : (vptfp::f2u(d.x) >> 31 ? -1e30f : 1e30f);
-    inv.y = (vptfp::fabs_(d.y) > 1e-30f) ? 1.0f / d.y : (vptfp::f2u(d.y) >> 31 ? -1e30f : 1e30f);
-    inv.z = (vptfp::fabs_(d.z) > 1e-30f) ? 1.0f / d.z : (vptfp::f2u(d.z) >> 31 ? -1e30f : 1e30f);
-    int sp = 0;
+    const V3 inv = safe_inverse(d);
+    stack.sp = 0;
     int cur = 0;
     while (true) {
         if (cur >= 0) {
-            float4 a, b, c; int l, r;
-            src.node(cur, a, b, c, l, r);
+            NodeData n;
+            src.node(cur, n);
             if (COUNT) st.nodes++;
-            float tl = box_entry(a.x, a.y, a.z, a.w, b.x, b.y, o, inv, tmin, tlimit);
-            float tr = box_entry(b.z, b.w, c.x, c.y, c.z, c.w, o, inv, tmin, tlimit);
-            bool hl = tl >= 0.0f, hr = tr >= 0.0f;
-            if (hl && hr) {
-                bool lfirst = tl <= tr;
-                int nearc = lfirst ? l : r, farc = lfirst ? r : l;
-                if (sp < kStackDepth) { stack[sp * stride] = (uint32_t)farc; sp++; }
-                cur = nearc;
-                continue;
-            } else if (hl) { cur = l; continue; }
-            else if (hr) { cur = r; continue; }
+            float t0, t1, t2, t3;
+            node_entries(n, o, inv, tmin, tlimit, t0, t1, t2, t3);
+            int next = 0x7fffffff;  // order is irrelevant for an any-hit search: take hit children in slot order
+            if (t3 < kMissT) next = n.c3;
+            if (t2 < kMissT) { if (next != 0x7fffffff) stack.push((uint32_t)next); next = n.c2; }
+            if (t1 < kMissT) { if (next != 0x7fffffff) stack.push((uint32_t)next); next = n.c1; }
+            if (t0 < kMissT) { if (next != 0x7fffffff) stack.push((uint32_t)next); next = n.c0; }
+            if (next != 0x7fffffff) { cur = next; continue; }
         } else {
             uint32_t enc = (uint32_t)(~cur);
             int first = (int)(enc >> 3), cnt = (int)(enc & 7u) + 1;
@@ -173,9 +213,8 @@ __device__ inline bool trace_occluded(const Src& src, V3 o, V3 d, float tmin, fl
                 }
             }
         }
-        if (sp == 0) break;
-        sp--;
-        cur = (int)stack[sp * stride];
+        if (stack.sp == 0) break;
+        cur = (int)stack.pop();
     }
     return false;
 }
@@ -183,14 +222,14 @@ __device__ inline bool trace_occluded(const Src& src, V3 o, V3 d, float tmin, fl
 // (b) in full: is the closest hit of the ray the triangle with global id `expect`?  `slot` is that triangle's
 // position in the leaf-ordered triangle array.
 template <bool COUNT, class Src>
-__device__ inline bool closest_is(const Src& src, V3 o, V3 d, float tmin, float tmax, uint32_t expect, uint32_t slot, uint32_t* stack,
-                                  int stride, TravStats& st) {
+__device__ inline bool closest_is(const Src& src, V3 o, V3 d, float tmin, float tmax, uint32_t expect, uint32_t slot, TravStack stack,
+                                  TravStats& st) {
     float4 a, b, c;
     src.tri((int)slot, a, b, c);
     if (COUNT) st.tris++;
     float t_e, u, v;
     if (!vptfp::ray_triangle(o, d, vptfp::v3(a.x, a.y, a.z), vptfp::v3(a.w, b.x, b.y), vptfp::v3(b.z, b.w, c.x), tmin, tmax, &t_e, &u, &v)) return false;
-    return !trace_occluded<COUNT, true>(src, o, d, tmin, tmax, t_e, expect, stack, stride, st);
+    return !trace_occluded<COUNT, true>(src, o, d, tmin, tmax, t_e, expect, stack, st);
 }
 
 }  // namespace vpt

@@ -48,7 +48,7 @@ struct vpt_ctx {
     PathState ps{};
     uint32_t* queue[2] = {nullptr, nullptr};
     uint32_t* cqueue = nullptr;  // connect queue (two-ended)
-    int shade_blocks = 1024, primary_blocks = 768;
+    int shade_blocks = 1024, primary_blocks = 768, max_blocks = 1536;
     Counters* ctr = nullptr;
     float* image = nullptr;       // this shard's rows, RGBA32F
     float* full_image = nullptr;  // whole image when shard_count > 1 (after vpt_assemble_shards)
@@ -533,10 +533,17 @@ int vpt_set_scene(vpt_ctx* c, const vpt_scene_desc* sd) {
     if ((rc = upload(c, lo, &D.lut_o))) return rc;
     if ((rc = upload(c, li, &D.lut_i))) return rc;
     // small scenes ride in LDS next to the traversal stacks
-    c->lds_scene = ((size_t)D.node_count * 64 + (size_t)D.tri_count * 48) <= 16384;
+    c->lds_scene = ((size_t)D.node_count * sizeof(BvhNode) + (size_t)D.tri_count * sizeof(BvhTri)) <= 16384;
     c->trav_blocks = traverse_blocks_per_cu(c->lds_scene, D) * c->cu_count;
     c->shade_blocks = shade_blocks_per_cu() * c->cu_count;
     c->primary_blocks = bounce_blocks_per_cu(c->lds_scene, D) * c->cu_count;
+    {   // per-thread overflow region of the traversal stacks, for the largest persistent grid launched
+        c->max_blocks = std::max(std::max(c->trav_blocks, c->shade_blocks), c->primary_blocks);
+        void* d = nullptr;
+        HIPCHK(c, hipMalloc(&d, stack_overflow_bytes((uint32_t)c->max_blocks)));
+        c->scene_allocs.push_back(d);
+        D.stack_overflow = (uint32_t*)d;
+    }
     launch_precompute_tri_ng(c->stream, D, c->d_tri_ng);
     launch_precompute_materials(c->stream, D, c->params.flags, c->d_mat_resolved, (uint32_t)c->materials.size());
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -741,7 +748,7 @@ int vpt_trace_rays(vpt_ctx* c, const vpt_ray* rays, uint32_t n, vpt_hit* hits) {
     int rc = VPT_OK;
     if (hipMemcpy(dr, rays, (size_t)n * sizeof(vpt_ray), hipMemcpyHostToDevice) != hipSuccess) rc = VPT_ERR_DEVICE;
     if (!rc) {
-        launch_trace_rays(c->stream, c->dsc, dr, n, dh);
+        launch_trace_rays(c->stream, (uint32_t)c->max_blocks, c->dsc, dr, n, dh);
         if (hipStreamSynchronize(c->stream) != hipSuccess || hipGetLastError() != hipSuccess) rc = VPT_ERR_DEVICE;
     }
     if (!rc && hipMemcpy(hits, dh, (size_t)n * sizeof(vpt_hit), hipMemcpyDeviceToHost) != hipSuccess) rc = VPT_ERR_DEVICE;
