@@ -138,6 +138,24 @@ def test_both_pipelines_match_the_oracle(vpt, oracle, scenes, name, pipeline):
     assert (launched["bounce"] > 0) == (pipeline == 1) and (launched["extend"] > 0) == (pipeline == 2)
 
 
+@pytest.mark.parametrize("S,w,h", [(2, 64, 36), (3, 50, 31)])
+@pytest.mark.parametrize("pipeline", [1, 2])
+def test_split_screen_dispatch(vpt, oracle, scenes, S, w, h, pipeline):
+    """SetSplitScreenCount (RayGen.slang:16-25, PathTracer.cpp:141-153): S^2 interleaved dispatches per frame, the first
+    one filling whole S x S cells; the image must match after EVERY dispatch count, mid-frame included."""
+    sc = scenes("cornell_box")
+    p = vpt.default_params(max_depth=4, screen_chunk_count=S, samples_per_frame=2)
+    o = oracle.Oracle(sc, w, h); o.set_params(p)
+    g = vpt.PathTracer(w, h, pipeline=pipeline, frames_in_flight=5); g.set_scene(sc); g.set_params(p)
+    for n in (1, 2, S * S - 3 if S > 2 else 1, S * S + 2, 7):
+        o.render(n); g.render(n)
+        assert np.array_equal(g.radiance(), o.radiance()), n
+    st = g.stats()
+    total = 1 + 2 + (S * S - 3 if S > 2 else 1) + S * S + 2 + 7
+    assert st["dispatches"] == total and st["frames"] == total // (S * S)
+    o.close(); g.close()
+
+
 def test_frames_in_flight_do_not_change_the_image(vpt, oracle, scenes):
     """Several frames share one wavefront batch; the running mean is still applied in frame order."""
     sc = scenes("cornell_box")
@@ -225,8 +243,14 @@ def test_errors(vpt, scenes):
     g = vpt.PathTracer(32, 32)
     with pytest.raises(vpt.VptError, match="NO_SCENE"):
         g.render(1)
+    with pytest.raises(vpt.VptError, match="INVALID_ARGUMENT"):
+        g.set_params(vpt.default_params(screen_chunk_count=0))
+    with pytest.raises(vpt.VptError, match="INVALID_ARGUMENT"):
+        g.set_params(vpt.default_params(max_depth=0))
+    s2 = vpt.PathTracer(32, 32, shard_rank=0, shard_count=2)
     with pytest.raises(vpt.VptError, match="UNSUPPORTED"):
-        g.set_params(vpt.default_params(screen_chunk_count=2))
+        s2.set_params(vpt.default_params(screen_chunk_count=2))  # split-screen copies pixels across rows: one context only
+    s2.close()
     bad = copy.deepcopy(scenes("cornell_box"))
     bad.materials[0]["base_color_texture"] = 99
     with pytest.raises(vpt.VptError, match="INVALID_ARGUMENT"):

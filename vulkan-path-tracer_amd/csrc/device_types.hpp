@@ -111,6 +111,8 @@ struct RenderParams {
     uint32_t width, height;
     uint32_t shard_rank, shard_count, shard_rows, shard_pixels;
     uint32_t samples_per_frame, max_depth;
+    uint32_t split;                // ScreenSplitCount (RayGen.slang:16-25); 1 = every dispatch covers every pixel
+    const uint32_t* launch_off;    // split > 1: prefix sums of the launch-grid sizes of the dispatches in the batch
     float max_luminance, focus_distance, dof_strength;
     float sky_azimuth, sky_altitude, sky_intensity, emissive_pdf_bias;
     uint32_t flags, base_seed;

@@ -45,14 +45,31 @@ __device__ inline void pixel_of_slot(const RenderParams& P, uint32_t slot, uint3
     y = P.shard_rank + P.shard_count * ys;
 }
 
+// Launch index -> (slot, pixel, dispatch-in-batch).  With ScreenSplitCount S == 1 a dispatch covers the whole shard
+// and the launch index IS the slot.  With S > 1 dispatch k of the batch covers the pixels of chunk
+// c = (dispatch_base + k) % S^2 only: LaunchID * S + (c % S, c / S)  (RayGen.slang:16-25); its launch grid is
+// exactly the in-bounds part, and P.launch_off[k] is where it starts in the batch-wide launch index space.
+__device__ inline void launch_pixel(const RenderParams& P, uint32_t li, uint32_t dispatch_base, uint32_t& slot, uint32_t& x, uint32_t& y, uint32_t& f) {
+    if (P.split == 1u) { slot = li; pixel_of_slot(P, li, x, y, f); return; }
+    uint32_t k = 0;
+    while (P.launch_off[k + 1] <= li) k++;
+    uint32_t r = li - P.launch_off[k];
+    uint32_t c = (dispatch_base + k) % (P.split * P.split);
+    uint32_t cx = c % P.split, cy = c / P.split;
+    uint32_t lw = (P.width - cx + P.split - 1u) / P.split;
+    uint32_t ly = r / lw, lx = r - ly * lw;
+    x = lx * P.split + cx; y = ly * P.split + cy; f = k;
+    slot = k * P.shard_pixels + y * P.width + x;
+}
+
 // ------------------------------------------------------------------ raygen (staged pipeline only)
 // Scenes whose BVH does not fit in LDS run bounce 0 through the same extend / shade / connect stages as every
 // other bounce, so the camera rays are written out as ordinary path records.
 __global__ __launch_bounds__(256) void k_raygen(RenderParams P, PathState ps, uint32_t* queue, uint32_t n_slots, uint32_t dispatch_base) {
-    uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
-    if (slot >= n_slots) return;
-    uint32_t x, y, f;
-    pixel_of_slot(P, slot, x, y, f);
+    uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
+    if (li >= n_slots) return;
+    uint32_t slot, x, y, f;
+    launch_pixel(P, li, dispatch_base, slot, x, y, f);
     uint32_t seed = pcg_hash(P.base_seed + dispatch_base + f);  // PathTracer.cpp:139 with an explicit seed
     Rng r; r.s = y + P.width * x + seed;                        // RayGen.slang:28
     V3 o, d;
@@ -62,7 +79,7 @@ __global__ __launch_bounds__(256) void k_raygen(RenderParams P, PathState ps, ui
     ps.T[0][slot] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);  // pathThroughput = 1, payload.PDF = 1
     ps.L[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     if (P.samples_per_frame > 1) { ps.ACC[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); ps.sidx[slot] = 0u; }
-    queue[slot] = slot;
+    queue[li] = slot;
 }
 
 // ------------------------------------------------------------------ persistent work fetch
@@ -513,7 +530,7 @@ __global__ __launch_bounds__(kTraverseBlock, 3) void k_bounce(DeviceScene sc, Re
                 V3 light_prev = v3s(0.0f);
                 if (FIRST) {
                     uint32_t x, y, f;
-                    pixel_of_slot(P, slot, x, y, f);
+                    launch_pixel(P, idx, dispatch_base, slot, x, y, f);
                     uint32_t seed = pcg_hash(P.base_seed + dispatch_base + f);  // PathTracer.cpp:139 with an explicit seed
                     Rng r; r.s = y + P.width * x + seed;                        // RayGen.slang:28
                     camera_ray(P, r, x, y, in_.porg, in_.pdir);
@@ -669,16 +686,34 @@ __global__ __launch_bounds__(kTraverseBlock) void k_connect(DeviceScene sc, Rend
 }
 
 // ------------------------------------------------------------------ resolve: running mean, frames applied in order
+// frame_base = index of the first dispatch of the batch (== FrameCount when ScreenSplitCount is 1).
 __global__ __launch_bounds__(256) void k_resolve(RenderParams P, PathState ps, float4* image, uint32_t frames, uint32_t frame_base) {
     uint32_t sp = blockIdx.x * blockDim.x + threadIdx.x;
     if (sp >= P.shard_pixels) return;
     float4 px = image[sp];
     V3 color = v3(px.x, px.y, px.z);
-    for (uint32_t f = 0; f < frames; f++) {
-        V3 acc = xyz(ps.ACC[f * P.shard_pixels + sp]) / (float)P.samples_per_frame;
-        uint32_t fc = frame_base + f;
-        if (fc > 0) color = lerp(color, acc, 1.0f / (float)(fc + 1u));
-        else color = acc;
+    if (P.split == 1u) {
+        for (uint32_t f = 0; f < frames; f++) {
+            V3 acc = xyz(ps.ACC[f * P.shard_pixels + sp]) / (float)P.samples_per_frame;
+            uint32_t fc = frame_base + f;
+            if (fc > 0) color = lerp(color, acc, 1.0f / (float)(fc + 1u));
+            else color = acc;
+        }
+    } else {
+        // split-screen (RayGen.slang:16-25, 143-157): dispatch d touches only the pixels of its chunk; the very
+        // first dispatch also copies each rendered pixel into its whole S x S cell ("pixels that aren't rendered")
+        const uint32_t S = P.split, y = sp / P.width, x = sp - y * P.width;
+        for (uint32_t f = 0; f < frames; f++) {
+            uint32_t d = frame_base + f, c = d % (S * S), fc = d / (S * S);
+            if (x % S == c % S && y % S == c / S) {
+                V3 acc = xyz(ps.ACC[f * P.shard_pixels + sp]) / (float)P.samples_per_frame;
+                if (fc > 0) color = lerp(color, acc, 1.0f / (float)(fc + 1u));
+                else color = acc;
+            } else if (d == 0u) {
+                uint32_t ax = x - x % S, ay = y - y % S;
+                color = xyz(ps.ACC[f * P.shard_pixels + ay * P.width + ax]) / (float)P.samples_per_frame;
+            }
+        }
     }
     image[sp] = make_float4(color.x, color.y, color.z, 1.0f);
 }

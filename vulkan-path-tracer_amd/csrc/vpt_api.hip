@@ -48,6 +48,7 @@ struct vpt_ctx {
     PathState ps{};
     uint32_t* queue[2] = {nullptr, nullptr};
     uint32_t* cqueue = nullptr;  // connect queue (two-ended)
+    uint32_t* d_launch_off = nullptr;  // split-screen: launch-grid prefix sums of the dispatches of a batch
     int shade_blocks = 1024, primary_blocks = 768, max_blocks = 1536;
     Counters* ctr = nullptr;
     float* image = nullptr;       // this shard's rows, RGBA32F
@@ -170,6 +171,7 @@ void sync_params(vpt_ctx* c) {
     P.max_luminance = p.max_luminance; P.focus_distance = p.focus_distance; P.dof_strength = p.dof_strength;
     P.sky_azimuth = p.sky_azimuth; P.sky_altitude = p.sky_altitude; P.sky_intensity = p.sky_intensity;
     P.emissive_pdf_bias = p.emissive_pdf_bias; P.flags = p.flags; P.base_seed = p.base_seed;
+    P.split = p.screen_chunk_count; P.launch_off = c->d_launch_off;
 }
 
 void reset_accum(vpt_ctx* c) { c->frame_count = 0; c->dispatch_count = 0; c->samples_accum = 0; }  // PathTracer.h:183
@@ -268,12 +270,25 @@ void collect_timing(vpt_ctx* c) {  // call after a stream sync
         end_timing(ctx, eb_);                   \
     } while (0)
 
-// One batch of `frames` consecutive dispatches (frame_base = index of the first).  The bounce loop runs
+// One batch of `frames` consecutive dispatches starting at dispatch index `dispatch_base`.  The bounce loop runs
 // without host round-trips: every stage reads its queue size from device memory, so the host only
 // checks the queue every few bounces (and right after max_depth bounces, when a surface-only batch is done).
-int render_batch(vpt_ctx* c, uint32_t frames, uint32_t dispatch_base, uint32_t frame_base) {
-    const uint32_t n_slots = frames * c->P.shard_pixels;
+int render_batch(vpt_ctx* c, uint32_t frames, uint32_t dispatch_base) {
     hipStream_t s = c->stream;
+    uint32_t n_slots = frames * c->P.shard_pixels;  // launch-grid size of the batch
+    const uint32_t S = c->P.split;
+    if (S > 1) {  // RayTrace(ceil(W/S), ceil(H/S)) per dispatch, in-bounds part only (PathTracer.cpp:145-150, RayGen.slang:24)
+        std::vector<uint32_t> off(frames + 1, 0u);
+        for (uint32_t k = 0; k < frames; k++) {
+            uint32_t ch = (dispatch_base + k) % (S * S), cx = ch % S, cy = ch / S;
+            uint32_t lw = cx < c->P.width ? (c->P.width - cx + S - 1) / S : 0, lh = cy < c->P.height ? (c->P.height - cy + S - 1) / S : 0;
+            off[k + 1] = off[k] + lw * lh;
+        }
+        n_slots = off[frames];
+        HIPCHK(c, hipMemcpyAsync(c->d_launch_off, off.data(), off.size() * 4, hipMemcpyHostToDevice, s));
+        HIPCHK(c, hipStreamSynchronize(s));  // `off` is a stack-lifetime staging buffer
+    }
+    if (n_slots == 0) return VPT_OK;
     const bool count = c->cfg.count_traversal != 0;
     // fused (one kernel per bounce, bounce 0 included) when the BVH rides in LDS; staged otherwise
     const bool fused = c->cfg.pipeline == VPT_PIPELINE_FUSED || (c->cfg.pipeline == VPT_PIPELINE_AUTO && c->lds_scene);
@@ -327,7 +342,7 @@ int render_batch(vpt_ctx* c, uint32_t frames, uint32_t dispatch_base, uint32_t f
         if (iter > iter_cap) return fail(c, VPT_ERR_DEVICE, "internal: bounce loop did not terminate");
         chunk = 4;
     }
-    TIMED(c, VPT_K_RESOLVE, launch_resolve(s, c->P, c->ps, c->image, frames, frame_base));
+    TIMED(c, VPT_K_RESOLVE, launch_resolve(s, c->P, c->ps, c->image, frames, dispatch_base));
     HIPCHK(c, hipStreamSynchronize(s));
     collect_timing(c);
     HIPCHK(c, hipGetLastError());
@@ -386,6 +401,7 @@ vpt_ctx* vpt_create(const vpt_config* cfg, int* err) {
         set(VPT_ERR_DEVICE); delete c; return nullptr;
     }
     (void)hipMemset(c->ctr, 0, sizeof(Counters));
+    if (hipMalloc((void**)&c->d_launch_off, 65 * 4) != hipSuccess) { set(VPT_ERR_DEVICE); vpt_destroy(c); return nullptr; }
     vpt_default_params(&c->params);
     const float id[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
     memcpy(c->P.view_inv, id, 64); memcpy(c->P.proj_inv, id, 64);
@@ -403,6 +419,7 @@ void vpt_destroy(vpt_ctx* c) {
     free_scene(c);
     free_render_buffers(c);
     if (c->ctr) (void)hipFree(c->ctr);
+    if (c->d_launch_off) (void)hipFree(c->d_launch_off);
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -586,7 +603,8 @@ int vpt_set_params(vpt_ctx* c, const vpt_params* p) {
     if (p->samples_per_frame == 0 || p->samples_per_frame > 0xffffffu) return fail(c, VPT_ERR_INVALID_ARGUMENT, "samples_per_frame must be >= 1");
     // MAX_DEPTH (Defines.slang:16) marks a finished path; a larger MaxDepth would make the reference loop forever on a miss
     if (p->max_depth == 0 || p->max_depth > 1000000u) return fail(c, VPT_ERR_INVALID_ARGUMENT, "max_depth must be in [1, 1000000]");
-    if (p->screen_chunk_count != 1) return fail(c, VPT_ERR_UNSUPPORTED, "split-screen dispatch (screen_chunk_count > 1) is not implemented in the HIP backend yet");
+    if (p->screen_chunk_count == 0 || p->screen_chunk_count > 64) return fail(c, VPT_ERR_INVALID_ARGUMENT, "screen_chunk_count must be in [1, 64]");
+    if (p->screen_chunk_count != 1 && c->P.shard_count != 1) return fail(c, VPT_ERR_UNSUPPORTED, "split-screen dispatch needs the whole image in one context (shard_count == 1): its first dispatch copies pixels across rows");
     if (!(p->flags & VPT_FLAG_RAY_QUERIES)) return fail(c, VPT_ERR_UNSUPPORTED, "only the USE_RAY_QUERIES semantics are implemented");
     const bool flags_changed = c->params.flags != p->flags;
     c->params = *p;
@@ -618,12 +636,15 @@ int vpt_render(vpt_ctx* c, uint32_t dispatches, int* done) {
     uint32_t left = dispatches;
     while (left > 0) {
         if (c->samples_accum >= c->params.max_samples) { if (done) *done = 1; break; }  // PathTracer.cpp:124-125
-        uint32_t frames_left = (c->params.max_samples - c->samples_accum + c->params.samples_per_frame - 1) / c->params.samples_per_frame;
-        uint32_t nf = std::min(std::min(left, c->frames_in_flight), frames_left);
-        int rc = render_batch(c, nf, (uint32_t)c->dispatch_count, c->frame_count);
+        // dispatches until PathTrace would return true: samples = floor(dispatches / S^2) * spp (PathTracer.cpp:151-153)
+        const uint64_t S2 = (uint64_t)c->params.screen_chunk_count * c->params.screen_chunk_count;
+        uint64_t frames_needed = ((uint64_t)c->params.max_samples + c->params.samples_per_frame - 1) / c->params.samples_per_frame;
+        uint64_t disp_left = frames_needed * S2 - c->dispatch_count;
+        uint32_t nf = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(left, c->frames_in_flight), disp_left);
+        int rc = render_batch(c, nf, (uint32_t)c->dispatch_count);
         if (rc) return rc;
-        c->dispatch_count += nf;                              // PathTracer.cpp:151-153 with ScreenChunkCount == 1
-        c->frame_count = (uint32_t)c->dispatch_count;
+        c->dispatch_count += nf;
+        c->frame_count = (uint32_t)(c->dispatch_count / S2);
         c->samples_accum = c->frame_count * c->params.samples_per_frame;
         left -= nf;
         c->full_valid = false;
@@ -659,7 +680,9 @@ int vpt_set_radiance(vpt_ctx* c, const float* src, uint32_t frame_count) {
                               c->P.shard_rows, hipMemcpyHostToDevice));
         c->full_valid = true;
     }
-    c->frame_count = frame_count; c->dispatch_count = frame_count; c->samples_accum = frame_count * c->params.samples_per_frame;
+    c->frame_count = frame_count;
+    c->dispatch_count = (uint64_t)frame_count * c->params.screen_chunk_count * c->params.screen_chunk_count;
+    c->samples_accum = frame_count * c->params.samples_per_frame;
     return VPT_OK;
 }
 
