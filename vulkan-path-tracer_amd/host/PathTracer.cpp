@@ -1,0 +1,150 @@
+// PathTracer.cpp — forwards the reference's PathTracer members to the C-ABI (see PathTracer.h).
+#include "PathTracer.h"
+
+#include <cstring>
+#include <stdexcept>
+#include <utility>
+
+namespace vpthost {
+
+void PathTracer::Check(int rc, const char* what) const {
+    if (rc != VPT_OK) throw std::runtime_error(std::string(what) + " failed (" + std::to_string(rc) + "): " + (m_Ctx ? vpt_last_error(m_Ctx) : ""));
+}
+
+PathTracer PathTracer::New(int device) {
+    PathTracer pt;
+    pt.m_Device = device;
+    vpt_default_params(&pt.m_Params);
+    pt.m_Env.assign(4, 0.0f);  // black 1x1 environment until SetEnvironmentMap (the reference's default .hdr is not redistributable)
+    return pt;
+}
+PathTracer::PathTracer(PathTracer&& o) noexcept { *this = std::move(o); }
+PathTracer& PathTracer::operator=(PathTracer&& o) noexcept {
+    if (this != &o) {
+        if (m_Ctx) vpt_destroy(m_Ctx);
+        m_Device = o.m_Device; m_Ctx = o.m_Ctx; o.m_Ctx = nullptr; m_Params = o.m_Params; m_Width = o.m_Width; m_Height = o.m_Height;
+        m_SamplesAccumulated = o.m_SamplesAccumulated; m_DispatchCount = o.m_DispatchCount;
+        m_TotalVertexCount = o.m_TotalVertexCount; m_TotalIndexCount = o.m_TotalIndexCount;
+        m_CameraViewInverse = o.m_CameraViewInverse; m_CameraProjectionInverse = o.m_CameraProjectionInverse;
+        m_Materials = std::move(o.m_Materials); m_MaterialNames = std::move(o.m_MaterialNames); m_Scene = std::move(o.m_Scene);
+        m_Env = std::move(o.m_Env); m_EnvW = o.m_EnvW; m_EnvH = o.m_EnvH;
+        m_LutR = std::move(o.m_LutR); m_LutO = std::move(o.m_LutO); m_LutI = std::move(o.m_LutI);
+        m_LookupTablePath = std::move(o.m_LookupTablePath); m_Output = std::move(o.m_Output);
+    }
+    return *this;
+}
+PathTracer::~PathTracer() { if (m_Ctx) vpt_destroy(m_Ctx); }
+
+void PathTracer::SetScene(const std::string& sceneFilePath) {
+    SceneAsset scene; std::string err;
+    if (!ImportScene(sceneFilePath, scene, err)) throw std::runtime_error("Failed to import scene! " + err);  // PathTracer.cpp:168
+    SetScene(scene);
+}
+
+void PathTracer::SetScene(const SceneAsset& sceneIn) {
+    ResetPathTracing();
+    m_Scene = sceneIn;
+    if (m_Scene.Cameras.empty()) {  // PathTracer.cpp:171-178
+        CameraAsset cam;
+        cam.AspectRatio = 16.0f / 9.0f; cam.FOV = 45.0f;
+        cam.ViewMatrix = lookAt(Vec3(0.0f, 0.0f, 5.0f), Vec3(0.0f, 0.0f, 0.0f), Vec3(0.0f, 1.0f, 0.0f));
+        m_Scene.Cameras.push_back(cam);
+    }
+    if (m_Scene.Meshes.empty()) throw std::runtime_error("No meshes found in scene! Please load a scene that contains meshes!");
+    if (m_Scene.Meshes.size() >= VPT_MAX_ENTITIES || m_Scene.Materials.size() >= VPT_MAX_ENTITIES || m_Scene.MeshInstances.size() >= VPT_MAX_INSTANCES)
+        throw std::runtime_error("Too many meshes / materials / mesh instances in the scene");  // PathTracer.cpp:182-184
+    const float aspectRatio = m_Scene.Cameras[0].AspectRatio;
+    m_CameraViewInverse = inverse(m_Scene.Cameras[0].ViewMatrix);                             // PathTracer.cpp:188
+    m_CameraProjectionInverse = inverse(perspective(radians(45.0f), aspectRatio, 0.1f, 100.0f));  // PathTracer.cpp:578: the camera's own FOV is ignored
+    if (m_LutR.empty()) {
+        std::string err;
+        if (m_LookupTablePath.empty()) throw std::runtime_error("SetLookupTablePath() must name the energy-compensation tables before SetScene()");
+        if (!LoadLookupTables(m_LookupTablePath, m_LutR, m_LutO, m_LutI, err)) throw std::runtime_error(err);
+    }
+    m_Materials = m_Scene.Materials; m_MaterialNames = m_Scene.MaterialNames;
+    m_TotalVertexCount = 0; m_TotalIndexCount = 0;
+    for (const auto& m : m_Scene.Meshes) { m_TotalVertexCount += m.Vertices.size(); m_TotalIndexCount += m.Indices.size(); }
+    const uint32_t w = (uint32_t)(1080.0f * aspectRatio), h = 1080;  // PathTracer.cpp:509-511
+    if (m_Width == 0) { m_Width = w; m_Height = h; }  // unless ResizeImage already chose a size
+    if (!m_Ctx) {
+        vpt_config cfg{}; cfg.device = m_Device; cfg.width = m_Width; cfg.height = m_Height; cfg.shard_rank = 0; cfg.shard_count = 1;
+        int err = 0;
+        m_Ctx = vpt_create(&cfg, &err);
+        if (!m_Ctx) throw std::runtime_error("vpt_create failed (" + std::to_string(err) + "): no usable HIP device; this backend has no CPU fallback");
+    }
+    UploadScene();
+    Check(vpt_set_params(m_Ctx, &m_Params), "vpt_set_params");
+    Check(vpt_set_camera(m_Ctx, m_CameraViewInverse.m, m_CameraProjectionInverse.m), "vpt_set_camera");
+}
+
+void PathTracer::UploadScene() {
+    std::vector<vpt_mesh> meshes; std::vector<vpt_instance> inst; std::vector<vpt_texture> tex;
+    for (const auto& m : m_Scene.Meshes) meshes.push_back({m.Vertices.data(), (uint32_t)m.Vertices.size(), m.Indices.data(), (uint32_t)m.Indices.size()});
+    for (const auto& i : m_Scene.MeshInstances) { vpt_instance v; v.mesh_index = i.MeshIndex; v.material_index = i.MaterialIndex; std::memcpy(v.transform, i.Transform.m, 64); inst.push_back(v); }
+    for (const auto& t : m_Scene.Textures) tex.push_back({t.Width, t.Height, t.Channels, t.Data.data()});
+    vpt_scene_desc d{};
+    d.meshes = meshes.data(); d.mesh_count = (uint32_t)meshes.size();
+    d.materials = m_Materials.data(); d.material_count = (uint32_t)m_Materials.size();
+    d.instances = inst.data(); d.instance_count = (uint32_t)inst.size();
+    d.textures = tex.data(); d.texture_count = (uint32_t)tex.size();
+    d.env_rgba = m_Env.data(); d.env_width = m_EnvW; d.env_height = m_EnvH;
+    d.lut_reflection = m_LutR.data(); d.lut_refraction_outside = m_LutO.data(); d.lut_refraction_inside = m_LutI.data();
+    Check(vpt_set_scene(m_Ctx, &d), "vpt_set_scene");
+}
+
+bool PathTracer::PathTrace(uint32_t dispatches) {
+    if (!m_Ctx) throw std::runtime_error("PathTrace before SetScene");
+    int done = 0;
+    Check(vpt_render(m_Ctx, dispatches, &done), "vpt_render");
+    vpt_stats st; Check(vpt_get_stats(m_Ctx, &st), "vpt_get_stats");
+    m_DispatchCount = st.dispatches;
+    m_SamplesAccumulated = (uint32_t)st.frames * m_Params.samples_per_frame;  // PathTracer.cpp:151-153
+    return done != 0;
+}
+
+void PathTracer::ResizeImage(uint32_t width, uint32_t height) {
+    m_Width = width; m_Height = height;
+    if (m_Ctx) Check(vpt_resize(m_Ctx, width, height), "vpt_resize");
+    ResetPathTracing();
+}
+
+const std::vector<float>& PathTracer::GetOutputImage() {
+    m_Output.resize((size_t)m_Width * m_Height * 4);
+    Check(vpt_get_radiance(m_Ctx, m_Output.data()), "vpt_get_radiance");
+    return m_Output;
+}
+
+void PathTracer::SetMaterial(uint32_t index, const Material& material) {  // PathTracer.cpp:712-810
+    if (index >= m_Materials.size()) throw std::runtime_error("SetMaterial: index out of range");
+    Check(vpt_set_material(m_Ctx, index, &material), "vpt_set_material");
+    m_Materials[index] = material;
+    ResetPathTracing();
+}
+
+void PathTracer::SetUseRayQueries(bool value) { if (!value) throw std::runtime_error("only the USE_RAY_QUERIES semantics are implemented"); }
+void PathTracer::SetCameraViewInverse(const Mat4& view) { m_CameraViewInverse = view; if (m_Ctx) Check(vpt_set_camera(m_Ctx, m_CameraViewInverse.m, m_CameraProjectionInverse.m), "vpt_set_camera"); ResetPathTracing(); }
+void PathTracer::SetCameraProjectionInverse(const Mat4& p) { m_CameraProjectionInverse = p; if (m_Ctx) Check(vpt_set_camera(m_Ctx, m_CameraViewInverse.m, m_CameraProjectionInverse.m), "vpt_set_camera"); ResetPathTracing(); }
+void PathTracer::SetFlag(uint32_t bit, bool value) { m_Params.flags = value ? (m_Params.flags | bit) : (m_Params.flags & ~bit); Push(true); }
+void PathTracer::Push(bool resets) {
+    if (m_Ctx) {
+        if (resets) Check(vpt_set_params(m_Ctx, &m_Params), "vpt_set_params");
+        else {  // SetMaxSamplesAccumulated does not reset the accumulation upstream (PathTracer.cpp:1003-1006): keep the image
+            std::vector<float> img((size_t)m_Width * m_Height * 4);
+            vpt_stats st; Check(vpt_get_stats(m_Ctx, &st), "vpt_get_stats");
+            Check(vpt_get_radiance(m_Ctx, img.data()), "vpt_get_radiance");
+            Check(vpt_set_params(m_Ctx, &m_Params), "vpt_set_params");
+            Check(vpt_set_radiance(m_Ctx, img.data(), (uint32_t)st.frames), "vpt_set_radiance");
+            return;
+        }
+    }
+    if (resets) { m_SamplesAccumulated = 0; m_DispatchCount = 0; }
+}
+void PathTracer::SetEnvironmentMap(const std::vector<float>& rgba, uint32_t width, uint32_t height) {
+    if (rgba.size() != (size_t)width * height * 4 || width == 0 || height == 0) throw std::runtime_error("SetEnvironmentMap: bad size");
+    m_Env = rgba; m_EnvW = width; m_EnvH = height;
+    if (m_Ctx) { UploadScene(); Check(vpt_set_camera(m_Ctx, m_CameraViewInverse.m, m_CameraProjectionInverse.m), "vpt_set_camera"); }
+    ResetPathTracing();
+}
+void PathTracer::ResetPathTracing() { m_SamplesAccumulated = 0; m_DispatchCount = 0; if (m_Ctx) vpt_reset(m_Ctx); }
+
+}  // namespace vpthost

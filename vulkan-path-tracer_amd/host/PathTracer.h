@@ -1,0 +1,125 @@
+// PathTracer.h — the reference's render API (PathTracer/PathTracer.h:83-183) over the MI355X backend's C-ABI
+// (include/vpt.h).  Same member names and meanings; what changes is what the Vulkan types carried:
+//   * New(device ordinal) instead of New(VulkanHelper::Device, ThreadPool*);
+//   * no CommandBuffer arguments — every call completes before it returns;
+//   * GetOutputImage() hands back the RGBA32F accumulation image as host floats;
+//   * the seed is explicit (SetSeed): the reference draws it from the wall clock (PathTracer.cpp:127-140);
+//   * errors throw std::runtime_error where the reference VH_ASSERT-aborts.
+// Volumes and atmosphere members are absent: that half of the integrator is out of scope.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/vpt.h"
+#include "Math.h"
+#include "SceneLoader.h"
+
+namespace vpthost {
+
+class PathTracer {
+public:
+    using Material = vpt_material;  // byte-identical to PathTracer::Material (PathTracer.h:12-34)
+
+    [[nodiscard]] static PathTracer New(int device = 0);
+    PathTracer() = default;
+    PathTracer(PathTracer&& o) noexcept;
+    PathTracer& operator=(PathTracer&& o) noexcept;
+    PathTracer(const PathTracer&) = delete;
+    PathTracer& operator=(const PathTracer&) = delete;
+    ~PathTracer();
+
+    // PathTracer.cpp:158-676. `lookupTablePath`: the three energy-compensation tables as one raw file.
+    void SetScene(const std::string& sceneFilePath);
+    void SetScene(const SceneAsset& scene);
+    void SetLookupTablePath(const std::string& path) { m_LookupTablePath = path; }
+    // True when all samples were accumulated (PathTracer.cpp:122-156). `dispatches` > 1 lets the backend keep
+    // several frames in flight; PathTrace() == one reference call.
+    bool PathTrace(uint32_t dispatches = 1);
+    void ResizeImage(uint32_t width, uint32_t height);
+
+    [[nodiscard]] const std::vector<float>& GetOutputImage();  // RGBA32F, width*height*4
+    [[nodiscard]] uint32_t GetWidth() const { return m_Width; }
+    [[nodiscard]] uint32_t GetHeight() const { return m_Height; }
+
+    [[nodiscard]] const std::vector<Material>& GetMaterials() const { return m_Materials; }
+    [[nodiscard]] const Material& GetMaterial(uint32_t index) const { return m_Materials[index]; }
+    [[nodiscard]] const std::string& GetMaterialName(uint32_t index) const { return m_MaterialNames[index]; }
+    void SetMaterial(uint32_t index, const Material& material);
+
+    void SetSkyMIS(bool value) { SetFlag(VPT_FLAG_SKY_MIS, value); }
+    void SetMeshMIS(bool value) { SetFlag(VPT_FLAG_MESH_MIS, value); }
+    void SetEnvMapShownDirectly(bool value) { SetFlag(VPT_FLAG_SHOW_ENV_DIRECTLY, value); }
+    void SetUseOnlyGeometryNormals(bool value) { SetFlag(VPT_FLAG_GEOMETRY_NORMALS, value); }
+    void SetUseEnergyCompensation(bool value) { SetFlag(VPT_FLAG_ENERGY_COMPENSATION, value); }
+    void SetFurnaceTestMode(bool value) { SetFlag(VPT_FLAG_FURNACE, value); }
+    void SetUseRayQueries(bool value);
+    void SetCameraViewInverse(const Mat4& view);
+    void SetCameraProjectionInverse(const Mat4& projection);
+    void SetMaxSamplesAccumulated(uint32_t v) { m_Params.max_samples = v; Push(false); }
+    void SetMaxDepth(uint32_t v) { m_Params.max_depth = v; Push(true); }
+    void SetSamplesPerFrame(uint32_t v) { m_Params.samples_per_frame = v; Push(true); }
+    void SetMaxLuminance(float v) { m_Params.max_luminance = v; Push(true); }
+    void SetFocusDistance(float v) { m_Params.focus_distance = v; Push(true); }
+    void SetDepthOfFieldStrength(float v) { m_Params.dof_strength = v; Push(true); }
+    void SetSkyAzimuth(float v) { m_Params.sky_azimuth = v; Push(true); }
+    void SetSkyAltitude(float v) { m_Params.sky_altitude = v; Push(true); }
+    void SetSkyIntensity(float v) { m_Params.sky_intensity = v; Push(true); }
+    void SetSplitScreenCount(uint32_t v) { m_Params.screen_chunk_count = v; Push(true); }
+    void SetEmissiveMeshSamplingPDFBias(float v) { m_Params.emissive_pdf_bias = v; Push(true); }
+    void SetSeed(uint32_t v) { m_Params.base_seed = v; Push(true); }
+    // RGBA32F, width*height*4 floats (the reference loads a .hdr file: SetEnvMapFilepath, PathTracer.cpp:1137-1164)
+    void SetEnvironmentMap(const std::vector<float>& rgba, uint32_t width, uint32_t height);
+
+    [[nodiscard]] uint32_t GetSamplesAccumulated() const { return m_SamplesAccumulated; }
+    [[nodiscard]] uint32_t GetSamplesPerFrame() const { return m_Params.samples_per_frame; }
+    [[nodiscard]] uint32_t GetMaxSamplesAccumulated() const { return m_Params.max_samples; }
+    [[nodiscard]] uint32_t GetMaxDepth() const { return m_Params.max_depth; }
+    [[nodiscard]] float GetMaxLuminance() const { return m_Params.max_luminance; }
+    [[nodiscard]] float GetFocusDistance() const { return m_Params.focus_distance; }
+    [[nodiscard]] float GetDepthOfFieldStrength() const { return m_Params.dof_strength; }
+    [[nodiscard]] float GetSkyRotationAzimuth() const { return m_Params.sky_azimuth; }
+    [[nodiscard]] float GetSkyRotationAltitude() const { return m_Params.sky_altitude; }
+    [[nodiscard]] float GetSkyIntensity() const { return m_Params.sky_intensity; }
+    [[nodiscard]] bool IsSkyMISEnabled() const { return m_Params.flags & VPT_FLAG_SKY_MIS; }
+    [[nodiscard]] bool IsMeshMISEnabled() const { return m_Params.flags & VPT_FLAG_MESH_MIS; }
+    [[nodiscard]] bool IsEnvMapShownDirectly() const { return m_Params.flags & VPT_FLAG_SHOW_ENV_DIRECTLY; }
+    [[nodiscard]] bool UseOnlyGeometryNormals() const { return m_Params.flags & VPT_FLAG_GEOMETRY_NORMALS; }
+    [[nodiscard]] bool UseEnergyCompensation() const { return m_Params.flags & VPT_FLAG_ENERGY_COMPENSATION; }
+    [[nodiscard]] bool IsInFurnaceTestMode() const { return m_Params.flags & VPT_FLAG_FURNACE; }
+    [[nodiscard]] bool UseRayQueries() const { return true; }
+    [[nodiscard]] uint32_t GetSplitScreenCount() const { return m_Params.screen_chunk_count; }
+    [[nodiscard]] float GetEmissiveMeshSamplingPDFBias() const { return m_Params.emissive_pdf_bias; }
+    [[nodiscard]] const Mat4& GetCameraViewInverse() const { return m_CameraViewInverse; }
+    [[nodiscard]] const Mat4& GetCameraProjectionInverse() const { return m_CameraProjectionInverse; }
+    [[nodiscard]] uint64_t GetTotalVertexCount() const { return m_TotalVertexCount; }
+    [[nodiscard]] uint64_t GetTotalIndexCount() const { return m_TotalIndexCount; }
+
+    void ResetPathTracing();  // PathTracer.h:183
+
+    [[nodiscard]] vpt_ctx* Context() const { return m_Ctx; }  // for PostProcessor
+
+private:
+    void Check(int rc, const char* what) const;
+    void SetFlag(uint32_t bit, bool value);
+    void Push(bool resets);
+    void UploadScene();
+
+    int m_Device = 0;
+    vpt_ctx* m_Ctx = nullptr;
+    vpt_params m_Params{};
+    uint32_t m_Width = 0, m_Height = 0;
+    uint32_t m_SamplesAccumulated = 0;
+    uint64_t m_DispatchCount = 0;
+    uint64_t m_TotalVertexCount = 0, m_TotalIndexCount = 0;
+    Mat4 m_CameraViewInverse, m_CameraProjectionInverse;
+    std::vector<Material> m_Materials;
+    std::vector<std::string> m_MaterialNames;
+    SceneAsset m_Scene;
+    std::vector<float> m_Env; uint32_t m_EnvW = 1, m_EnvH = 1;
+    std::vector<float> m_LutR, m_LutO, m_LutI;
+    std::string m_LookupTablePath;
+    std::vector<float> m_Output;
+};
+
+}  // namespace vpthost

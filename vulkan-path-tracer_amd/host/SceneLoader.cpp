@@ -1,0 +1,353 @@
+// SceneLoader.cpp — minimal JSON + glTF 2.0 + PNG readers (see SceneLoader.h).
+#include "SceneLoader.h"
+
+#include <zlib.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <map>
+#include <memory>
+#include <sstream>
+
+namespace vpthost {
+namespace {
+
+// ---------------------------------------------------------------- JSON
+struct JVal;
+using JPtr = std::shared_ptr<JVal>;
+struct JVal {
+    enum Type { Null, Bool, Num, Str, Arr, Obj } type = Null;
+    double num = 0;
+    bool b = false;
+    std::string str;
+    std::vector<JPtr> arr;
+    std::map<std::string, JPtr> obj;
+    const JVal* get(const std::string& k) const { auto it = obj.find(k); return it == obj.end() ? nullptr : it->second.get(); }
+    bool has(const std::string& k) const { return obj.count(k) != 0; }
+    double number(const std::string& k, double def) const { const JVal* v = get(k); return v && v->type == Num ? v->num : def; }
+    size_t size() const { return arr.size(); }
+    const JVal& operator[](size_t i) const { return *arr[i]; }
+};
+struct JParser {
+    const std::string& s; size_t p = 0; bool ok = true;
+    explicit JParser(const std::string& t) : s(t) {}
+    void ws() { while (p < s.size() && (s[p] == ' ' || s[p] == '\n' || s[p] == '\t' || s[p] == '\r')) p++; }
+    JPtr parse() {
+        ws();
+        auto v = std::make_shared<JVal>();
+        if (p >= s.size()) { ok = false; return v; }
+        char c = s[p];
+        if (c == '{') {
+            v->type = JVal::Obj; p++; ws();
+            if (p < s.size() && s[p] == '}') { p++; return v; }
+            while (ok) {
+                ws(); JPtr k = parse(); ws();
+                if (!ok || k->type != JVal::Str || p >= s.size() || s[p] != ':') { ok = false; break; }
+                p++;
+                v->obj[k->str] = parse(); ws();
+                if (p < s.size() && s[p] == ',') { p++; continue; }
+                if (p < s.size() && s[p] == '}') { p++; break; }
+                ok = false;
+            }
+        } else if (c == '[') {
+            v->type = JVal::Arr; p++; ws();
+            if (p < s.size() && s[p] == ']') { p++; return v; }
+            while (ok) {
+                v->arr.push_back(parse()); ws();
+                if (p < s.size() && s[p] == ',') { p++; continue; }
+                if (p < s.size() && s[p] == ']') { p++; break; }
+                ok = false;
+            }
+        } else if (c == '"') {
+            v->type = JVal::Str; p++;
+            while (p < s.size() && s[p] != '"') {
+                if (s[p] == '\\' && p + 1 < s.size()) {
+                    char e = s[p + 1];
+                    v->str += e == 'n' ? '\n' : e == 't' ? '\t' : e;  // \uXXXX is not needed for the asset paths we read
+                    p += 2;
+                } else v->str += s[p++];
+            }
+            p++;
+        } else if (s.compare(p, 4, "true") == 0) { v->type = JVal::Bool; v->b = true; p += 4; }
+        else if (s.compare(p, 5, "false") == 0) { v->type = JVal::Bool; p += 5; }
+        else if (s.compare(p, 4, "null") == 0) { p += 4; }
+        else {
+            char* end = nullptr;
+            v->type = JVal::Num; v->num = std::strtod(s.c_str() + p, &end);
+            if (end == s.c_str() + p) ok = false;
+            p = (size_t)(end - s.c_str());
+        }
+        return v;
+    }
+};
+
+bool read_file(const std::string& path, std::string& out) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) return false;
+    std::ostringstream ss; ss << f.rdbuf(); out = ss.str();
+    return true;
+}
+std::string dir_of(const std::string& path) { size_t k = path.find_last_of("/\\"); return k == std::string::npos ? std::string(".") : path.substr(0, k); }
+
+Mat4 from_rows(const double r[4][4]) { Mat4 m; for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) m.at(i, j) = (float)r[i][j]; return m; }
+
+// node local matrix in double (TRS or explicit matrix)
+void node_matrix(const JVal& n, double M[4][4]) {
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) M[i][j] = i == j;
+    if (const JVal* m = n.get("matrix")) { for (int c = 0; c < 4; c++) for (int r = 0; r < 4; r++) M[r][c] = (*m)[c * 4 + r].num; return; }
+    double T[4][4], R[4][4], S[4][4];
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) T[i][j] = R[i][j] = S[i][j] = i == j;
+    if (const JVal* t = n.get("translation")) for (int i = 0; i < 3; i++) T[i][3] = (*t)[i].num;
+    if (const JVal* q = n.get("rotation")) {
+        double x = (*q)[0].num, y = (*q)[1].num, z = (*q)[2].num, w = (*q)[3].num;
+        double r[3][3] = {{1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)},
+                          {2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)},
+                          {2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)}};
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) R[i][j] = r[i][j];
+    }
+    if (const JVal* sc = n.get("scale")) for (int i = 0; i < 3; i++) S[i][i] = (*sc)[i].num;
+    double TR[4][4];
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) { TR[i][j] = 0; for (int k = 0; k < 4; k++) TR[i][j] += T[i][k] * R[k][j]; }
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) { M[i][j] = 0; for (int k = 0; k < 4; k++) M[i][j] += TR[i][k] * S[k][j]; }
+}
+void matmul(const double A[4][4], const double B[4][4], double C[4][4]) {
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) { double s = 0; for (int k = 0; k < 4; k++) s += A[i][k] * B[k][j]; C[i][j] = s; }
+}
+// F * M * F with F = diag(1,-1,1,1): glTF is Y-up, the reference's world is Y-down
+void flip_y(double M[4][4]) { for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) if ((i == 1) != (j == 1)) M[i][j] = -M[i][j]; }
+
+void default_material(vpt_material& m) {  // PathTracer.h:14-33
+    std::memset(&m, 0, sizeof(m));
+    for (int i = 0; i < 3; i++) { m.base_color[i] = 1; m.specular_color[i] = 1; m.medium_color[i] = 1; }
+    m.roughness = 1.0f; m.ior = 1.5f;
+    m.base_color_texture = 0; m.normal_texture = 1; m.roughness_texture = 2; m.metallic_texture = 3; m.emissive_texture = 4;
+}
+
+uint8_t paeth(int a, int b, int c) { int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c); return (uint8_t)(pa <= pb && pa <= pc ? a : (pb <= pc ? b : c)); }
+
+}  // namespace
+
+bool LoadPNG(const std::string& path, TextureAsset& out, std::string& error) {
+    std::string f;
+    if (!read_file(path, f)) { error = "cannot open " + path; return false; }
+    static const unsigned char sig[8] = {137, 80, 78, 71, 13, 10, 26, 10};
+    if (f.size() < 33 || std::memcmp(f.data(), sig, 8) != 0) { error = "not a PNG: " + path; return false; }
+    auto be32 = [&](size_t o) { return ((uint32_t)(uint8_t)f[o] << 24) | ((uint32_t)(uint8_t)f[o + 1] << 16) | ((uint32_t)(uint8_t)f[o + 2] << 8) | (uint8_t)f[o + 3]; };
+    uint32_t w = 0, h = 0; int depth = 0, ctype = 0, interlace = 0;
+    std::string idat;
+    for (size_t p = 8; p + 12 <= f.size();) {
+        uint32_t len = be32(p); std::string type = f.substr(p + 4, 4);
+        if (p + 12 + len > f.size()) break;
+        if (type == "IHDR") { w = be32(p + 8); h = be32(p + 12); depth = (uint8_t)f[p + 16]; ctype = (uint8_t)f[p + 17]; interlace = (uint8_t)f[p + 20]; }
+        else if (type == "IDAT") idat.append(f, p + 8, len);
+        else if (type == "IEND") break;
+        p += 12 + len;
+    }
+    int ch = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
+    if (depth != 8 || ch == 0 || interlace != 0 || w == 0 || h == 0) { error = "unsupported PNG format (need 8-bit gray/RGB/RGBA, non-interlaced): " + path; return false; }
+    const size_t stride = (size_t)w * ch;
+    std::vector<uint8_t> raw((stride + 1) * h);
+    uLongf dl = (uLongf)raw.size();
+    if (uncompress(raw.data(), &dl, (const Bytef*)idat.data(), (uLong)idat.size()) != Z_OK || dl != raw.size()) { error = "PNG inflate failed: " + path; return false; }
+    std::vector<uint8_t> img(stride * h);
+    for (uint32_t y = 0; y < h; y++) {
+        const uint8_t* src = &raw[(stride + 1) * y]; uint8_t ft = src[0]; src++;
+        uint8_t* dst = &img[stride * y]; const uint8_t* up = y ? &img[stride * (y - 1)] : nullptr;
+        for (size_t x = 0; x < stride; x++) {
+            int a = x >= (size_t)ch ? dst[x - ch] : 0, b = up ? up[x] : 0, c = (up && x >= (size_t)ch) ? up[x - ch] : 0;
+            int v = src[x];
+            switch (ft) { case 1: v += a; break; case 2: v += b; break; case 3: v += (a + b) / 2; break; case 4: v += paeth(a, b, c); break; default: break; }
+            dst[x] = (uint8_t)v;
+        }
+    }
+    out.Width = w; out.Height = h; out.Channels = 4; out.Data.resize((size_t)w * h * 4);
+    for (size_t i = 0; i < (size_t)w * h; i++) {
+        const uint8_t* s = &img[i * ch]; uint8_t* d = &out.Data[i * 4];
+        if (ch == 1) { d[0] = d[1] = d[2] = s[0]; d[3] = 255; }
+        else if (ch == 2) { d[0] = d[1] = d[2] = s[0]; d[3] = s[1]; }
+        else if (ch == 3) { d[0] = s[0]; d[1] = s[1]; d[2] = s[2]; d[3] = 255; }
+        else { d[0] = s[0]; d[1] = s[1]; d[2] = s[2]; d[3] = s[3]; }
+    }
+    return true;
+}
+
+bool LoadLookupTables(const std::string& path, std::vector<float>& r, std::vector<float>& o, std::vector<float>& i, std::string& error) {
+    std::string f;
+    const size_t n0 = 64 * 64 * 32, n1 = 128 * 128 * 32;
+    if (!read_file(path, f) || f.size() != (n0 + 2 * n1) * 4) { error = "bad lookup table file " + path; return false; }
+    const float* p = reinterpret_cast<const float*>(f.data());
+    r.assign(p, p + n0); o.assign(p + n0, p + n0 + n1); i.assign(p + n0 + n1, p + n0 + 2 * n1);
+    return true;
+}
+
+bool ImportScene(const std::string& gltfPath, SceneAsset& sc, std::string& error) {
+    std::string text;
+    if (!read_file(gltfPath, text)) { error = "cannot open " + gltfPath; return false; }
+    JParser jp(text);
+    JPtr root = jp.parse();
+    if (!jp.ok || root->type != JVal::Obj) { error = "JSON parse error in " + gltfPath; return false; }
+    const JVal& g = *root;
+    const std::string base = dir_of(gltfPath);
+    std::vector<std::string> bufs;
+    if (const JVal* bs = g.get("buffers"))
+        for (size_t i = 0; i < bs->size(); i++) {
+            std::string d;
+            const JVal* uri = (*bs)[i].get("uri");
+            if (!uri || !read_file(base + "/" + uri->str, d)) { error = "cannot read glTF buffer"; return false; }
+            bufs.push_back(std::move(d));
+        }
+    auto accessor = [&](int idx, std::vector<double>& out, int& ncomp) -> bool {
+        const JVal& a = (*g.get("accessors"))[(size_t)idx];
+        const JVal& bv = (*g.get("bufferViews"))[(size_t)a.number("bufferView", 0)];
+        int ct = (int)a.number("componentType", 5126);
+        const std::string& ty = a.get("type")->str;
+        ncomp = ty == "SCALAR" ? 1 : ty == "VEC2" ? 2 : ty == "VEC3" ? 3 : ty == "VEC4" ? 4 : 16;
+        size_t count = (size_t)a.number("count", 0);
+        size_t csz = ct == 5126 || ct == 5125 ? 4 : (ct == 5123 || ct == 5122 ? 2 : 1);
+        size_t off = (size_t)bv.number("byteOffset", 0) + (size_t)a.number("byteOffset", 0);
+        size_t stride = (size_t)bv.number("byteStride", 0);
+        if (!stride) stride = csz * ncomp;
+        const std::string& buf = bufs[(size_t)bv.number("buffer", 0)];
+        if (off + (count ? (count - 1) * stride + csz * ncomp : 0) > buf.size()) return false;
+        out.resize(count * ncomp);
+        for (size_t k = 0; k < count; k++)
+            for (int c = 0; c < ncomp; c++) {
+                const char* p = buf.data() + off + k * stride + c * csz;
+                double v;
+                if (ct == 5126) { float x; std::memcpy(&x, p, 4); v = x; }
+                else if (ct == 5125) { uint32_t x; std::memcpy(&x, p, 4); v = x; }
+                else if (ct == 5123) { uint16_t x; std::memcpy(&x, p, 2); v = x; }
+                else if (ct == 5122) { int16_t x; std::memcpy(&x, p, 2); v = x; }
+                else if (ct == 5121) { v = (uint8_t)*p; }
+                else { v = (int8_t)*p; }
+                out[k * ncomp + c] = v;
+            }
+        return true;
+    };
+
+    // default textures in LoadDefaultTexture order (PathTracer.cpp:1557-1582): base, normal, roughness R8, metallic R8, emissive
+    sc = SceneAsset();
+    auto deftex = [&](std::vector<uint8_t> d, uint32_t ch) { TextureAsset t; t.Width = t.Height = 1; t.Channels = ch; t.Data = std::move(d); sc.Textures.push_back(t); };
+    deftex({255, 255, 255, 255}, 4); deftex({128, 128, 255, 255}, 4); deftex({255}, 1); deftex({255}, 1); deftex({255, 255, 255, 255}, 4);
+    std::map<std::string, uint32_t> texCache;
+    auto textureIndex = [&](const JVal* ref, bool single, uint32_t& outIdx) -> bool {
+        if (!ref) return true;
+        const JVal& tex = (*g.get("textures"))[(size_t)ref->number("index", 0)];
+        const JVal& img = (*g.get("images"))[(size_t)tex.number("source", 0)];
+        std::string key = img.get("uri")->str + (single ? "#r" : "");
+        auto it = texCache.find(key);
+        if (it == texCache.end()) {
+            TextureAsset t;
+            if (!LoadPNG(base + "/" + img.get("uri")->str, t, error)) return false;
+            if (single) {  // LoadTexture(..., onlySingleChannel=true) keeps R (PathTracer.cpp:826-836)
+                std::vector<uint8_t> r((size_t)t.Width * t.Height);
+                for (size_t i = 0; i < r.size(); i++) r[i] = t.Data[i * 4];
+                t.Data = std::move(r); t.Channels = 1;
+            }
+            sc.Textures.push_back(std::move(t));
+            it = texCache.emplace(key, (uint32_t)sc.Textures.size() - 1).first;
+        }
+        outIdx = it->second;
+        return true;
+    };
+
+    if (const JVal* mats = g.get("materials"))
+        for (size_t i = 0; i < mats->size(); i++) {
+            const JVal& m = (*mats)[i];
+            vpt_material pm; default_material(pm);
+            const JVal* pbr = m.get("pbrMetallicRoughness");
+            const JVal* ext = m.get("extensions");
+            auto extObj = [&](const char* name) -> const JVal* { return ext ? ext->get(name) : nullptr; };
+            if (pbr) {
+                if (const JVal* bc = pbr->get("baseColorFactor")) for (int k = 0; k < 3; k++) pm.base_color[k] = (float)(*bc)[k].num;
+                pm.metallic = (float)pbr->number("metallicFactor", 1.0);
+                pm.roughness = (float)pbr->number("roughnessFactor", 1.0);
+            } else { pm.metallic = 1.0f; }
+            double strength = 1.0;
+            if (const JVal* es = extObj("KHR_materials_emissive_strength")) strength = es->number("emissiveStrength", 1.0);
+            if (const JVal* ef = m.get("emissiveFactor")) for (int k = 0; k < 3; k++) pm.emissive_color[k] = (float)((*ef)[k].num * strength);
+            if (const JVal* e = extObj("KHR_materials_ior")) pm.ior = (float)e->number("ior", 1.5);
+            if (const JVal* e = extObj("KHR_materials_transmission")) pm.transmission = (float)e->number("transmissionFactor", 0.0);
+            if (const JVal* e = extObj("KHR_materials_specular")) if (const JVal* c = e->get("specularColorFactor")) for (int k = 0; k < 3; k++) pm.specular_color[k] = (float)(*c)[k].num;
+            if (!textureIndex(pbr ? pbr->get("baseColorTexture") : nullptr, false, pm.base_color_texture)) return false;
+            if (!textureIndex(m.get("normalTexture"), false, pm.normal_texture)) return false;
+            if (!textureIndex(pbr ? pbr->get("metallicRoughnessTexture") : nullptr, true, pm.roughness_texture)) return false;
+            if (!textureIndex(pbr ? pbr->get("metallicRoughnessTexture") : nullptr, true, pm.metallic_texture)) return false;
+            if (!textureIndex(m.get("emissiveTexture"), false, pm.emissive_texture)) return false;
+            sc.Materials.push_back(pm);
+            const JVal* nm = m.get("name");
+            sc.MaterialNames.push_back(nm ? nm->str : std::string());
+        }
+    if (sc.Materials.empty()) { vpt_material pm; default_material(pm); sc.Materials.push_back(pm); sc.MaterialNames.push_back("default"); }
+
+    // meshes: one MeshAsset per primitive
+    std::map<std::pair<int, int>, std::pair<uint32_t, uint32_t>> primMesh;
+    if (const JVal* meshes = g.get("meshes"))
+        for (size_t mi = 0; mi < meshes->size(); mi++) {
+            const JVal& prims = *(*meshes)[mi].get("primitives");
+            for (size_t pi = 0; pi < prims.size(); pi++) {
+                const JVal& p = prims[pi];
+                const JVal& attr = *p.get("attributes");
+                std::vector<double> pos, nrm, uv, idx; int nc;
+                if (!attr.has("POSITION") || !accessor((int)attr.number("POSITION", 0), pos, nc)) { error = "primitive without POSITION"; return false; }
+                size_t nv = pos.size() / 3;
+                if (attr.has("NORMAL")) accessor((int)attr.number("NORMAL", 0), nrm, nc);
+                if (attr.has("TEXCOORD_0")) accessor((int)attr.number("TEXCOORD_0", 0), uv, nc);
+                MeshAsset me; me.Vertices.resize(nv);
+                for (size_t v = 0; v < nv; v++) {
+                    vpt_vertex& o = me.Vertices[v];
+                    o.position[0] = (float)pos[v * 3]; o.position[1] = -(float)pos[v * 3 + 1]; o.position[2] = (float)pos[v * 3 + 2];
+                    if (nrm.size() == nv * 3) { o.normal[0] = (float)nrm[v * 3]; o.normal[1] = -(float)nrm[v * 3 + 1]; o.normal[2] = (float)nrm[v * 3 + 2]; }
+                    else { o.normal[0] = o.normal[1] = o.normal[2] = 0; }
+                    if (uv.size() == nv * 2) { o.texcoord[0] = (float)uv[v * 2]; o.texcoord[1] = (float)uv[v * 2 + 1]; } else { o.texcoord[0] = o.texcoord[1] = 0; }
+                }
+                if (p.has("indices")) { accessor((int)p.number("indices", 0), idx, nc); } else { idx.resize(nv); for (size_t k = 0; k < nv; k++) idx[k] = (double)k; }
+                me.Indices.resize(idx.size() / 3 * 3);
+                for (size_t t = 0; t + 2 < idx.size(); t += 3) {  // mirror => swap the winding so geometric and vertex normals agree
+                    me.Indices[t] = (uint32_t)idx[t]; me.Indices[t + 1] = (uint32_t)idx[t + 2]; me.Indices[t + 2] = (uint32_t)idx[t + 1];
+                }
+                sc.Meshes.push_back(std::move(me));
+                primMesh[{(int)mi, (int)pi}] = {(uint32_t)sc.Meshes.size() - 1, (uint32_t)p.number("material", 0)};
+            }
+        }
+
+    // node hierarchy
+    struct Walk { size_t node; double M[4][4]; };
+    std::vector<Walk> stack;
+    const JVal* nodes = g.get("nodes");
+    const JVal* scenes = g.get("scenes");
+    if (nodes && scenes && scenes->size()) {
+        const JVal& roots = *(*scenes)[(size_t)g.number("scene", 0)].get("nodes");
+        for (size_t i = roots.size(); i-- > 0;) { Walk w; w.node = (size_t)roots[i].num; for (int a = 0; a < 4; a++) for (int b = 0; b < 4; b++) w.M[a][b] = a == b; stack.push_back(w); }
+    }
+    while (!stack.empty()) {
+        Walk w = stack.back(); stack.pop_back();
+        const JVal& n = (*nodes)[w.node];
+        double L[4][4], M[4][4];
+        node_matrix(n, L); matmul(w.M, L, M);
+        double F[4][4]; std::memcpy(F, M, sizeof(F)); flip_y(F);
+        if (n.has("mesh")) {
+            int mi = (int)n.number("mesh", 0);
+            const JVal& prims = *(*g.get("meshes"))[(size_t)mi].get("primitives");
+            for (size_t pi = 0; pi < prims.size(); pi++) {
+                auto pm = primMesh[{mi, (int)pi}];
+                MeshInstance inst; inst.MeshIndex = pm.first; inst.MaterialIndex = pm.second; inst.Transform = from_rows(F);
+                sc.MeshInstances.push_back(inst);
+            }
+        }
+        if (n.has("camera") && sc.Cameras.empty()) {
+            const JVal& c = (*g.get("cameras"))[(size_t)n.number("camera", 0)];
+            CameraAsset cam;
+            if (const JVal* p = c.get("perspective")) { cam.AspectRatio = (float)p->number("aspectRatio", 16.0 / 9.0); cam.FOV = degrees((float)p->number("yfov", 0.7853981633974483)); }
+            cam.ViewMatrix = inverse(from_rows(F));
+            sc.Cameras.push_back(cam);
+        }
+        if (const JVal* ch = n.get("children"))
+            for (size_t i = ch->size(); i-- > 0;) { Walk c; c.node = (size_t)(*ch)[i].num; std::memcpy(c.M, M, sizeof(M)); stack.push_back(c); }
+    }
+    if (sc.Meshes.empty()) { error = "No meshes found in scene"; return false; }  // PathTracer.cpp:180
+    return true;
+}
+
+}  // namespace vpthost

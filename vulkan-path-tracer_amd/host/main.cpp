@@ -1,0 +1,122 @@
+// vpt_render — headless driver in place of Application / Editor (Application.cpp:81-99, Editor.cpp:81-143):
+// load a glTF scene, run PathTrace() until the sample budget is spent, post-process, write the images.
+//   vpt_render --scene S.gltf --luts lookup_tables.bin [--size WxH] [--spp N] [--depth D] [--seed K] [--split S]
+//              [--env-constant r,g,b] [--radiance out.f32] [--camera out.f32] [--ppm out.ppm] [--info] [--dump-scene out.bin]
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <stdexcept>
+#include <string>
+
+#include "FlyCamera.h"
+#include "PathTracer.h"
+#include "PostProcessor.h"
+
+using namespace vpthost;
+
+static void write_file(const std::string& path, const void* data, size_t bytes) {
+    std::ofstream f(path, std::ios::binary);
+    if (!f) throw std::runtime_error("cannot write " + path);
+    f.write((const char*)data, (std::streamsize)bytes);
+}
+
+int main(int argc, char** argv) {
+    std::string scene, luts, radiance, camera, ppm, dump;
+    uint32_t w = 0, h = 0, spp = 16, depth = 8, seed = 1, split = 1;
+    bool info = false, selftest = false; float env[3] = {0, 0, 0}; bool haveEnv = false;
+    for (int i = 1; i < argc; i++) {
+        std::string a = argv[i];
+        auto next = [&]() -> std::string { if (i + 1 >= argc) { fprintf(stderr, "missing value for %s\n", a.c_str()); exit(2); } return argv[++i]; };
+        if (a == "--scene") scene = next();
+        else if (a == "--luts") luts = next();
+        else if (a == "--size") { std::string s = next(); if (sscanf(s.c_str(), "%ux%u", &w, &h) != 2) { fprintf(stderr, "--size WxH\n"); return 2; } }
+        else if (a == "--spp") spp = (uint32_t)atoi(next().c_str());
+        else if (a == "--depth") depth = (uint32_t)atoi(next().c_str());
+        else if (a == "--seed") seed = (uint32_t)strtoul(next().c_str(), nullptr, 10);
+        else if (a == "--split") split = (uint32_t)atoi(next().c_str());
+        else if (a == "--env-constant") { std::string s = next(); if (sscanf(s.c_str(), "%f,%f,%f", &env[0], &env[1], &env[2]) != 3) return 2; haveEnv = true; }
+        else if (a == "--radiance") radiance = next();
+        else if (a == "--camera") camera = next();
+        else if (a == "--ppm") ppm = next();
+        else if (a == "--info") info = true;
+        else if (a == "--selftest") selftest = true;
+        else if (a == "--dump-scene") { dump = next(); info = true; }
+        else { fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
+    }
+    if (selftest) {  // host-side arithmetic only (no device): FlyCamera <-> matrices, Mat4 inverse
+        Mat4 view = lookAt(Vec3(1.0f, -2.0f, 6.0f), Vec3(0.2f, -0.5f, 0.0f), Vec3(0.0f, 1.0f, 0.0f));
+        Mat4 proj = perspective(radians(45.0f), 16.0f / 9.0f, 0.1f, 1000.0f);
+        FlyCamera cam(view, proj);
+        Mat4 v2 = cam.GetViewMatrix(), p2 = cam.GetProjectionMatrix(), id = multiply(view, inverse(view));
+        double ev = 0, ep = 0, ei = 0;
+        for (int i = 0; i < 16; i++) { ev = std::fmax(ev, std::fabs(v2.m[i] - view.m[i])); ep = std::fmax(ep, std::fabs(p2.m[i] - proj.m[i])); ei = std::fmax(ei, std::fabs(id.m[i] - (i % 5 == 0 ? 1.0f : 0.0f))); }
+        cam.ProcessKeyboard(FlyCamera::Direction::UP, 1.0f);  // UP moves against m_Up (FlyCamera.cpp:47-49)
+        printf("{\"view_err\": %.3g, \"proj_err\": %.3g, \"inverse_err\": %.3g, \"fov\": %.4f, \"aspect\": %.5f, \"up_dy\": %.4f}\n", ev, ep, ei, cam.GetFov(), cam.GetAspectRatio(),
+               cam.GetPosition().y - (-2.0f));
+        return (ev < 1e-4 && ep < 1e-5 && ei < 1e-5) ? 0 : 1;
+    }
+    if (scene.empty()) { fprintf(stderr, "usage: vpt_render --scene S.gltf --luts lookup_tables.bin [--size WxH] [--spp N] [--depth D] ...\n"); return 2; }
+    try {
+        if (info) {  // scene import only: no device needed
+            SceneAsset sc; std::string err;
+            if (!ImportScene(scene, sc, err)) throw std::runtime_error(err);
+            if (!dump.empty()) {  // flat binary image of the imported scene, for comparison with the Python loader
+                std::string b;
+                auto put = [&](const void* p, size_t n) { b.append((const char*)p, n); };
+                auto u32 = [&](uint32_t v) { put(&v, 4); };
+                u32((uint32_t)sc.Meshes.size());
+                for (auto& m : sc.Meshes) { u32((uint32_t)m.Vertices.size()); u32((uint32_t)m.Indices.size()); put(m.Vertices.data(), m.Vertices.size() * sizeof(vpt_vertex)); put(m.Indices.data(), m.Indices.size() * 4); }
+                u32((uint32_t)sc.Materials.size()); put(sc.Materials.data(), sc.Materials.size() * sizeof(vpt_material));
+                u32((uint32_t)sc.MeshInstances.size());
+                for (auto& i : sc.MeshInstances) { u32(i.MeshIndex); u32(i.MaterialIndex); put(i.Transform.m, 64); }
+                u32((uint32_t)sc.Textures.size());
+                for (auto& t : sc.Textures) { u32(t.Width); u32(t.Height); u32(t.Channels); put(t.Data.data(), t.Data.size()); }
+                u32((uint32_t)sc.Cameras.size());
+                for (auto& c : sc.Cameras) { put(&c.AspectRatio, 4); Mat4 vi = inverse(c.ViewMatrix); put(vi.m, 64); }
+                write_file(dump, b.data(), b.size());
+            }
+            size_t tris = 0, verts = 0;
+            for (auto& i : sc.MeshInstances) tris += sc.Meshes[i.MeshIndex].Indices.size() / 3;
+            for (auto& m : sc.Meshes) verts += m.Vertices.size();
+            printf("{\"meshes\": %zu, \"instances\": %zu, \"materials\": %zu, \"textures\": %zu, \"triangles\": %zu, \"vertices\": %zu, \"cameras\": %zu}\n",
+                   sc.Meshes.size(), sc.MeshInstances.size(), sc.Materials.size(), sc.Textures.size(), tris, verts, sc.Cameras.size());
+            return 0;
+        }
+        PathTracer pt = PathTracer::New(0);
+        pt.SetLookupTablePath(luts);
+        if (haveEnv) { std::vector<float> e(64 * 32 * 4, 0.0f); for (size_t i = 0; i < 64 * 32; i++) { e[i * 4] = env[0]; e[i * 4 + 1] = env[1]; e[i * 4 + 2] = env[2]; } pt.SetEnvironmentMap(e, 64, 32); }
+        if (w && h) pt.ResizeImage(w, h);
+        pt.SetScene(scene);
+        if (w && h) {  // the window was resized: Editor.cpp:203-211 rebuilds the projection from the new aspect ratio
+            FlyCamera cam(inverse(pt.GetCameraViewInverse()), inverse(pt.GetCameraProjectionInverse()));
+            cam.SetAspectRatio((float)w / (float)h); cam.SetNearFar(0.1f, 100.0f);
+            pt.SetCameraProjectionInverse(inverse(cam.GetProjectionMatrix()));
+        }
+        pt.SetMaxDepth(depth); pt.SetSeed(seed); pt.SetSplitScreenCount(split); pt.SetMaxSamplesAccumulated(spp);
+        auto t0 = std::chrono::steady_clock::now();
+        while (!pt.PathTrace(64)) {}
+        double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        const std::vector<float>& img = pt.GetOutputImage();
+        PostProcessor post = PostProcessor::New();
+        post.SetInputImage(pt);
+        post.PostProcess();
+        if (!radiance.empty()) write_file(radiance, img.data(), img.size() * 4);
+        if (!camera.empty()) { float m[32]; memcpy(m, pt.GetCameraViewInverse().m, 64); memcpy(m + 16, pt.GetCameraProjectionInverse().m, 64); write_file(camera, m, sizeof(m)); }
+        if (!ppm.empty()) {
+            const std::vector<uint8_t>& o = post.GetOutputImage();
+            std::string out = "P6\n" + std::to_string(pt.GetWidth()) + " " + std::to_string(pt.GetHeight()) + "\n255\n";
+            for (size_t i = 0; i < (size_t)pt.GetWidth() * pt.GetHeight(); i++) out.append((const char*)&o[i * 4], 3);
+            write_file(ppm, out.data(), out.size());
+        }
+        printf("{\"width\": %u, \"height\": %u, \"samples\": %u, \"seconds\": %.4f, \"msamples_per_s\": %.2f, \"vertices\": %llu, \"indices\": %llu}\n", pt.GetWidth(), pt.GetHeight(),
+               pt.GetSamplesAccumulated(), sec, (double)pt.GetWidth() * pt.GetHeight() * pt.GetSamplesAccumulated() / sec / 1e6,
+               (unsigned long long)pt.GetTotalVertexCount(), (unsigned long long)pt.GetTotalIndexCount());
+    } catch (const std::exception& e) {
+        fprintf(stderr, "vpt_render: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}

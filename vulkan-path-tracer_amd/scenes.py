@@ -52,12 +52,15 @@ _LUT_CACHE = {}
 
 
 def load_luts():
-    """The three reference tables (Assets/LookupTables/*.bin), shipped as a data asset."""
+    """The three reference tables (Assets/LookupTables/*.bin) shipped as one raw fp32 file: reflection
+    64x64x32, refraction-from-outside 128x128x32, refraction-from-inside 128x128x32, index x + y*SX + z*SX*SY."""
     if not _LUT_CACHE:
-        z = np.load(os.path.join(ASSET_DIR, "lookup_tables.npz"))
-        _LUT_CACHE["r"] = np.ascontiguousarray(z["reflection"], np.float32)
-        _LUT_CACHE["o"] = np.ascontiguousarray(z["refraction_outside"], np.float32)
-        _LUT_CACHE["i"] = np.ascontiguousarray(z["refraction_inside"], np.float32)
+        a = np.fromfile(os.path.join(ASSET_DIR, "lookup_tables.bin"), "<f4")
+        n0, n1 = 64 * 64 * 32, 128 * 128 * 32
+        assert a.size == n0 + 2 * n1
+        _LUT_CACHE["r"] = np.ascontiguousarray(a[:n0].reshape(32, 64, 64))
+        _LUT_CACHE["o"] = np.ascontiguousarray(a[n0:n0 + n1].reshape(32, 128, 128))
+        _LUT_CACHE["i"] = np.ascontiguousarray(a[n0 + n1:].reshape(32, 128, 128))
     return _LUT_CACHE["r"], _LUT_CACHE["o"], _LUT_CACHE["i"]
 
 
