@@ -1,7 +1,8 @@
 // kernels_post.hip — bloom chain + ACES tonemap (reference Shaders/PostProcess/*.slang,
 // schedule PostProcessor.cpp:193-246).  HBM-bound streaming kernels: one float4 (16 B) per lane per
-// access, rows contiguous across the wave.  Tap summation order is the reference's (x offset outer,
-// y offset inner) so results are bit-identical to the scalar restatement.
+// access, rows contiguous across the wave; the two 4x4 box blurs stage their input tile in LDS.  Tap
+// summation order is the reference's (x offset outer, y offset inner) so results are bit-identical to
+// the scalar restatement.
 #include "kernels.hpp"
 
 namespace vpt {
@@ -22,19 +23,33 @@ __global__ __launch_bounds__(256) void k_bloom_threshold(const float4* in, float
     out[i] = make_float4(c.x, c.y, c.z, 1.0f);
 }
 
+// Tile geometry shared by the two blur kernels: a block of 256 threads produces 64 x 4 output texels from an
+// input tile staged in LDS (coalesced float4 rows, edge texels clamped while loading, which is exactly the
+// reference's clamp(samplePos)), then every thread sums its 16 taps from LDS in the reference's order
+// (x offset outer, y offset inner) so the result stays bit-identical to the scalar restatement.
+constexpr int kTileW = 64, kTileH = 4;
+constexpr int kDownW = 2 * kTileW + 2, kDownH = 2 * kTileH + 2;   // 130 x 10 input texels per down-sample tile
+constexpr int kUpW = kTileW / 2 + 3, kUpH = kTileH / 2 + 3;       // 35 x 5 input texels per up-sample tile
+
 // BloomDownSample.slang:46-63: 16 taps around 2*xy, divided by 25 (pow(range*2+1, 2)), times strength.
 __global__ __launch_bounds__(256) void k_bloom_down(const float4* in, int iw, int ih, float4* out, int ow, int oh, float strength) {
-    int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    __shared__ float4 tile[kDownH][kDownW];
+    const int x0 = blockIdx.x * kTileW, y0 = blockIdx.y * kTileH;
+    const int sx0 = 2 * x0 - 2, sy0 = 2 * y0 - 2;
+    for (int i = threadIdx.x; i < kDownW * kDownH; i += 256) {
+        int ty = i / kDownW, tx = i - ty * kDownW;
+        tile[ty][tx] = in[(size_t)iclamp(sy0 + ty, 0, ih - 1) * iw + iclamp(sx0 + tx, 0, iw - 1)];
+    }
+    __syncthreads();
+    const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
+    const int x = x0 + lx, y = y0 + ly;
     if (x >= ow || y >= oh) return;
     V3 c = v3s(0.0f);
-    for (int a = -2; a < 2; a++) {
-        int sx = iclamp(2 * x + a, 0, iw - 1);
+    for (int a = -2; a < 2; a++)
         for (int b = -2; b < 2; b++) {
-            int sy = iclamp(2 * y + b, 0, ih - 1);
-            float4 p = in[(size_t)sy * iw + sx];
+            float4 p = tile[2 * ly + b + 2][2 * lx + a + 2];
             c = c + v3(p.x, p.y, p.z);
         }
-    }
     c = c / 25.0f;
     c = c * strength;
     out[(size_t)y * ow + x] = make_float4(c.x, c.y, c.z, 1.0f);
@@ -42,17 +57,23 @@ __global__ __launch_bounds__(256) void k_bloom_down(const float4* in, int iw, in
 
 // BloomUpSample.slang:30-48: 16 taps around xy/2 + 1 of the coarser mip, /25, *strength, added to the finer mip.
 __global__ __launch_bounds__(256) void k_bloom_up(const float4* in, int iw, int ih, float4* out, int ow, int oh, float strength) {
-    int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    __shared__ float4 tile[kUpH][kUpW];
+    const int x0 = blockIdx.x * kTileW, y0 = blockIdx.y * kTileH;
+    const int sx0 = x0 / 2 - 1, sy0 = y0 / 2 - 1;
+    for (int i = threadIdx.x; i < kUpW * kUpH; i += 256) {
+        int ty = i / kUpW, tx = i - ty * kUpW;
+        tile[ty][tx] = in[(size_t)iclamp(sy0 + ty, 0, ih - 1) * iw + iclamp(sx0 + tx, 0, iw - 1)];
+    }
+    __syncthreads();
+    const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
+    const int x = x0 + lx, y = y0 + ly;
     if (x >= ow || y >= oh) return;
     V3 c = v3s(0.0f);
-    for (int a = -2; a < 2; a++) {
-        int sx = iclamp(x / 2 + a + 1, 0, iw - 1);
+    for (int a = -2; a < 2; a++)
         for (int b = -2; b < 2; b++) {
-            int sy = iclamp(y / 2 + b + 1, 0, ih - 1);
-            float4 p = in[(size_t)sy * iw + sx];
+            float4 p = tile[y / 2 + b + 1 - sy0][x / 2 + a + 1 - sx0];
             c = c + v3(p.x, p.y, p.z);
         }
-    }
     c = c / 25.0f;
     c = c * strength;
     float4 cur = out[(size_t)y * ow + x];
