@@ -37,7 +37,7 @@ WIDTH, HEIGHT, MAX_DEPTH, BASE_SEED = 1920, 1080, 8, 1
 
 # Algorithmic bytes per unit for each stage: state words actually read/written per path or
 # ray by the algorithm with this build's struct sizes; BVH node/triangle visits are measured, not assumed.
-NODE_BYTES, TRI_BYTES = 128, 48   # BVH4 node = one 128 B line, triangle = 48 B
+TRI_BYTES = 48   # triangle record; the node size (64 B quantised, 128 B fp32 when the BVH rides in LDS) comes from vpt_stats
 EXTEND_FIXED = 4 + 24 + 20          # queue id, origin+direction in, hit record out
 SHADE_IN = 4 + 16 + 16 + 16 + 20    # queue id, records A (origin|rng), B (dir|depth), T (throughput|pdf), hit record
 SHADE_ALIVE_OUT = 16 + 16 + 16 + 4  # A, B, T of the surviving path + next-queue id
@@ -157,6 +157,7 @@ def main():
         hits0, alive0, rays0 = st["primary_hits"], st["primary_survivors"], st["primary_shadow_rays"]
         later_rays = st["shadow_rays"] - rays0
         alive_later = max(n_later - alive0, 0)  # paths leaving bounce k >= 1 alive == paths entering bounce k+1
+        NODE_BYTES = st["bvh_node_bytes"]
         trav = nodes_per_ray * NODE_BYTES + tris_per_ray * TRI_BYTES
         strav = snodes_per_ray * NODE_BYTES + stris_per_ray * TRI_BYTES
         # per stage: (units, algorithmic bytes per unit by SURVEY 8d's formula = path records + scene gathers + BVH visits,

@@ -32,5 +32,9 @@ def main():
               "shadow", round(cs["shadow_nodes_visited"] / max(cs["shadow_rays"], 1), 1), round(cs["shadow_tris_tested"] / max(cs["shadow_rays"], 1), 2))
         print("   ms", {k: round(v, 2) for k, v in st["kernel_ms"].items() if v > 0}, "launches", {k: v for k, v in st["kernel_launches"].items() if v})
 
+    g = vpt.PathTracer(1920, 1080, pipeline=0, frames_in_flight=8); g.set_scene(sc); g.set_params(P)
+    g.render(32); g.reset_stats(); t = time.time(); g.render(16); dt = time.time() - t; st = g.stats(); g.close()
+    print("pipeline AUTO Msamples/s", round(st["samples"] / dt / 1e6, 1), "launches", {k: v for k, v in st["kernel_launches"].items() if v})
+
 if __name__ == "__main__":
     main()

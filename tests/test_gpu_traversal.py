@@ -28,7 +28,8 @@ def test_random_rays(vpt, oracle, scenes, name, scale, n):
     ref, st = compare(vpt, oracle, scenes(name), random_rays(n, 5, scale))
     assert (ref["t"] >= 0).mean() > 0.05
     assert st["bvh_triangles"] == scenes(name).triangle_count()
-    assert st["bvh_node_bytes"] == 128 and st["bvh_tri_bytes"] == 48  # BVH4 node = one cache line
+    # vpt_trace_rays always walks the 64 B quantised nodes; the render kernels of an LDS-resident scene use 128 B fp32 ones
+    assert st["bvh_node_bytes"] in (64, 128) and st["bvh_tri_bytes"] == 48
 
 
 def test_axis_aligned_and_degenerate_rays(vpt, oracle, scenes):

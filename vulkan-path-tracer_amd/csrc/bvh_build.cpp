@@ -3,7 +3,7 @@
 // in the Vulkan driver).  Every reference instance gets its own BLAS (PathTracer.cpp:471-479) and is
 // placed once, so instances are flattened into one world-space tree.
 //
-// Output layout (device_types.hpp): 128 B four-wide nodes (collapsed from the binary SAH tree), 48 B triangles
+// Output layout (device_types.hpp): 64 B four-wide quantised nodes (collapsed from the binary SAH tree), 48 B triangles
 // in leaf order, leaves of <= 4 triangles, binary depth bounded by kMaxDepth (bounds the traversal stack).
 #include "bvh_build.hpp"
 
@@ -107,8 +107,8 @@ struct Builder {
 inline int32_t leaf_code(int first, int count) { return ~(int32_t)(((uint32_t)first << 3) | (uint32_t)(count - 1)); }
 }  // namespace
 
-void build_bvh(const std::vector<BvhTri>& tris_in, std::vector<BvhNode>& nodes_out, std::vector<BvhTri>& tris_out, int* depth_out) {
-    nodes_out.clear(); tris_out.clear();
+void build_bvh(const std::vector<BvhTri>& tris_in, std::vector<BvhNode>& nodes_out, std::vector<BvhNodeWide>& wide_out, std::vector<BvhTri>& tris_out, int* depth_out) {
+    nodes_out.clear(); wide_out.clear(); tris_out.clear();
     Builder b;
     b.refs.resize(tris_in.size());
     float maxabs = 0.0f;
@@ -123,10 +123,23 @@ void build_bvh(const std::vector<BvhTri>& tris_in, std::vector<BvhNode>& nodes_o
     }
     // Conservative padding so a box test can never cull a triangle the shared ray_triangle() accepts.
     const float pad = 2.0e-5f * maxabs + 1.0e-6f;
-    if (tris_in.empty()) {
+    auto empty_node = [&]() {
         BvhNode n; std::memset(&n, 0, sizeof(n));
-        for (int k = 0; k < 4; k++) { n.minx[k] = n.miny[k] = n.minz[k] = n.maxx[k] = n.maxy[k] = n.maxz[k] = 1.0e30f; n.child[k] = leaf_code(0, 1); }
-        nodes_out.push_back(n);
+        n.exps = 1u | 1u << 8 | 1u << 16;
+        for (int a = 0; a < 3; a++) { n.lo[a] = 0xffffffffu; n.hi[a] = 0u; }  // inverted: never entered
+        for (int k = 0; k < 4; k++) n.child[k] = leaf_code(0, 1);
+        return n;
+    };
+    auto empty_wide = [&]() {
+        BvhNodeWide n; std::memset(&n, 0, sizeof(n));
+        for (int k = 0; k < 4; k++) {
+            n.minx[k] = n.miny[k] = n.minz[k] = n.maxx[k] = n.maxy[k] = n.maxz[k] = 1.0e30f;  // unreachable point box
+            n.child[k] = leaf_code(0, 1);
+        }
+        return n;
+    };
+    if (tris_in.empty()) {
+        nodes_out.push_back(empty_node()); wide_out.push_back(empty_wide());
         if (depth_out) *depth_out = 0;
         return;
     }
@@ -137,24 +150,44 @@ void build_bvh(const std::vector<BvhTri>& tris_in, std::vector<BvhNode>& nodes_o
     // emit: collapse the binary tree into 4-wide nodes (a node adopts its grandchildren, largest box first),
     // depth-first order; a leaf root gets a wrapper node.
     int max_depth = 0;
-    auto put_box = [&](BvhNode& n, int k, const Box& bx) {
-        n.minx[k] = bx.lo[0] - pad; n.miny[k] = bx.lo[1] - pad; n.minz[k] = bx.lo[2] - pad;
-        n.maxx[k] = bx.hi[0] + pad; n.maxy[k] = bx.hi[1] + pad; n.maxz[k] = bx.hi[2] + pad;
-    };
-    auto empty_node = [&]() {
-        BvhNode n; std::memset(&n, 0, sizeof(n));
-        for (int k = 0; k < 4; k++) {
-            n.minx[k] = n.miny[k] = n.minz[k] = n.maxx[k] = n.maxy[k] = n.maxz[k] = 1.0e30f;  // unreachable point box
-            n.child[k] = leaf_code(0, 1);
+    // Quantise the (padded) child boxes of one node: origin = their common lower corner, step = the smallest
+    // power of two whose 255 steps span them; lower planes round down, upper planes round up, checked in double
+    // (origin + q * step is exact there) so the decoded box is a superset of the fp32 one.
+    auto put_boxes = [&](BvhNode& n, BvhNodeWide& w, const Box* bx, int nk) {
+        for (int k = 0; k < nk; k++) {
+            w.minx[k] = bx[k].lo[0] - pad; w.miny[k] = bx[k].lo[1] - pad; w.minz[k] = bx[k].lo[2] - pad;
+            w.maxx[k] = bx[k].hi[0] + pad; w.maxy[k] = bx[k].hi[1] + pad; w.maxz[k] = bx[k].hi[2] + pad;
         }
-        return n;
+        for (int a = 0; a < 3; a++) {
+            float lo = bx[0].lo[a] - pad, hi = bx[0].hi[a] + pad;
+            for (int k = 1; k < nk; k++) { lo = std::min(lo, bx[k].lo[a] - pad); hi = std::max(hi, bx[k].hi[a] + pad); }
+            const double org = lo, ext = (double)hi - (double)lo;
+            int e = 1;  // biased exponent, step = 2^(e-127)
+            if (ext > 0.0) { int ex; std::frexp(ext / 255.0, &ex); e = std::min(std::max(ex + 127, 1), 254); }
+            while (e < 254 && org + 255.0 * std::ldexp(1.0, e - 127) < (double)hi) e++;
+            const double step = std::ldexp(1.0, e - 127);
+            n.origin[a] = lo;
+            n.exps |= (uint32_t)e << (8 * a);
+            uint32_t wl = 0xffffffffu, wh = 0u;
+            for (int k = 0; k < nk; k++) {
+                const double cl = (double)(bx[k].lo[a] - pad), ch = (double)(bx[k].hi[a] + pad);
+                int ql = (int)std::floor((cl - org) / step), qh = (int)std::ceil((ch - org) / step);
+                ql = std::min(std::max(ql, 0), 255); qh = std::min(std::max(qh, 0), 255);
+                while (ql > 0 && org + ql * step > cl) ql--;
+                while (qh < 255 && org + qh * step < ch) qh++;
+                wl = (wl & ~(0xffu << (8 * k))) | (uint32_t)ql << (8 * k);
+                wh = (wh & ~(0xffu << (8 * k))) | (uint32_t)qh << (8 * k);
+            }
+            n.lo[a] = wl; n.hi[a] = wh;
+        }
     };
     struct Item { int tmp; int out; int depth; };
     std::vector<Item> work;
-    nodes_out.push_back(empty_node());
+    nodes_out.push_back(empty_node()); wide_out.push_back(empty_wide());
     if (b.nodes[0].left < 0) {
-        put_box(nodes_out[0], 0, b.nodes[0].b);
-        nodes_out[0].child[0] = leaf_code(b.nodes[0].first, b.nodes[0].count);
+        nodes_out[0].exps = 0;
+        put_boxes(nodes_out[0], wide_out[0], &b.nodes[0].b, 1);
+        nodes_out[0].child[0] = wide_out[0].child[0] = leaf_code(b.nodes[0].first, b.nodes[0].count);
     } else {
         work.push_back({0, 0, 0});
     }
@@ -171,15 +204,18 @@ void build_bvh(const std::vector<BvhTri>& tris_in, std::vector<BvhNode>& nodes_o
             int t = kids[best];
             kids[best] = b.nodes[t].left; kids[nk++] = b.nodes[t].right;
         }
+        Box boxes[4];
+        for (int k = 0; k < nk; k++) boxes[k] = b.nodes[kids[k]].b;
+        nodes_out[it.out].exps = 0;
+        put_boxes(nodes_out[it.out], wide_out[it.out], boxes, nk);
         for (int k = 0; k < nk; k++) {
             const TmpNode& c = b.nodes[kids[k]];
-            put_box(nodes_out[it.out], k, c.b);
             if (c.left < 0) {
-                nodes_out[it.out].child[k] = leaf_code(c.first, c.count);
+                nodes_out[it.out].child[k] = wide_out[it.out].child[k] = leaf_code(c.first, c.count);
             } else {
                 int idx = (int)nodes_out.size();
-                nodes_out.push_back(empty_node());
-                nodes_out[it.out].child[k] = idx;
+                nodes_out.push_back(empty_node()); wide_out.push_back(empty_wide());
+                nodes_out[it.out].child[k] = wide_out[it.out].child[k] = idx;
                 work.push_back({kids[k], idx, it.depth + 1});
             }
         }

@@ -12,17 +12,31 @@ using vptfp::V2;
 using vptfp::V3;
 using vptfp::V4;
 
-// ---- BVH4, 128-byte nodes = one cache line: the four child boxes in SoA form (6 x dwordx4) + four child
-// codes, so ONE fetch decides four children and a ray needs about half the dependent memory round-trips
-// of a binary tree.  child >= 0: inner node index; child < 0: leaf, ~child = first<<3 | (count-1).
-// Unused child slots hold an unreachable point box at 1e30.
+// ---- BVH4, 64-byte nodes (two per cache line, 4 x dwordx4): the four child boxes are 8-bit offsets on a
+// per-node grid, plane = origin + q * 2^(e-127) per axis, rounded OUTWARD at build time so a decoded box always
+// contains the (already padded) fp32 child box.  One fetch decides four children.
+//   child >= 0: inner node index; child < 0: leaf, ~child = first<<3 | (count-1).
+// Unused slots hold the inverted box lo = 255, hi = 0 (empty interval on every axis) and a harmless leaf code.
 struct BvhNode {
+    float origin[3];
+    uint32_t exps;     // biased exponents of the grid steps: ex | ey << 8 | ez << 16
+    uint32_t lo[3];    // per axis: byte k = lower plane of child k
+    uint32_t hi[3];    // per axis: byte k = upper plane of child k
+    uint32_t pad[2];
+    int32_t child[4];
+};
+static_assert(sizeof(BvhNode) == 64, "node is 64 B");
+
+// The same tree with fp32 child boxes in SoA form (128 B), used only when the whole BVH is staged into LDS
+// (scenes of a few dozen triangles): there the bytes are free and the plain slab test costs fewer VALU ops than
+// decoding the grid.  Unused slots hold an unreachable point box at 1e30.
+struct BvhNodeWide {
     float minx[4], miny[4], minz[4];
     float maxx[4], maxy[4], maxz[4];
     int32_t child[4];
     uint32_t pad[4];
 };
-static_assert(sizeof(BvhNode) == 128, "node is 128 B");
+static_assert(sizeof(BvhNodeWide) == 128, "wide node is 128 B");
 
 // World-space triangle, 48 bytes (3 x dwordx4), stored in BVH leaf order.
 struct BvhTri {
@@ -80,6 +94,7 @@ struct AliasEntry {  // == AliasMapEntry (Bindings.slang:1-5)
 
 struct DeviceScene {
     const BvhNode* nodes;
+    const BvhNodeWide* nodes_wide;  // non-null only for LDS-resident scenes
     const BvhTri* tris;
     uint32_t node_count, tri_count;
     const vpt_vertex* vertices;

@@ -94,7 +94,7 @@ __device__ inline uint32_t fetch_chunk(uint32_t n) {
 template <bool LDS_SCENE>
 __device__ inline void stage_scene(const DeviceScene& sc, float4* lds_nodes, float4* lds_tris) {
     if (LDS_SCENE) {
-        const float4* gn = reinterpret_cast<const float4*>(sc.nodes);
+        const float4* gn = reinterpret_cast<const float4*>(sc.nodes_wide);
         const float4* gt = reinterpret_cast<const float4*>(sc.tris);
         for (uint32_t i = threadIdx.x; i < sc.node_count * 8; i += blockDim.x) lds_nodes[i] = gn[i];
         for (uint32_t i = threadIdx.x; i < sc.tri_count * 3; i += blockDim.x) lds_tris[i] = gt[i];
@@ -629,54 +629,97 @@ __global__ __launch_bounds__(kTraverseBlock, 3) void k_bounce(DeviceScene sc, Re
 // Per pending path: trace its (<= 2) shadow rays (RTCommon.slang:47-64: closest committed hit), join the
 // visible NEE contributions with the emission BEFORE the luminance clamp (RayGen.slang:92-102), add to
 // pathLight, and at the end of a sample apply the NaN/Inf guard and add to the frame sum (:116-128).
+//
+// A block works on tiles of up to kConnectTile paths.  The shadow rays of a tile are first listed in LDS (sky
+// rays from the front, light rays from the back, one entry = owning path of the tile), then traced ONE RAY PER
+// LANE — a path with two rays does not hold a lane twice as long while its neighbours idle, and waves see one
+// ray kind — and the visibility bits go back to the owners through LDS, which add the contributions in the
+// reference's order.
+constexpr uint32_t kConnectTile = 512;
+constexpr uint32_t kConnectScratch = kConnectTile * 4 + kConnectTile * 2 * 2 + kConnectTile * 2 + 16;  // slots, ray list, visibility, counters
+__device__ inline uint32_t connect_tile(uint32_t n) { return n >= (1u << 19) ? 512u : n >= (1u << 17) ? 256u : n >= (1u << 15) ? 128u : 64u; }
+
 template <bool LDS_SCENE, bool COUNT>
 __global__ __launch_bounds__(kTraverseBlock) void k_connect(DeviceScene sc, RenderParams P, PathState ps, const uint32_t* cqueue,
                                                            Counters* ctr, uint32_t parity) {
     extern __shared__ __align__(16) unsigned char smem[];
     const TravStack stack = make_stack(smem, sc.stack_overflow);
-    float4* lds_nodes = reinterpret_cast<float4*>(smem + kStackDepth * kTraverseBlock * 4);
+    unsigned char* scratch = smem + kStackDepth * kTraverseBlock * 4;
+    uint32_t* t_slot = reinterpret_cast<uint32_t*>(scratch);                                   // [kConnectTile]
+    uint16_t* t_list = reinterpret_cast<uint16_t*>(scratch + kConnectTile * 4);                // [2 * kConnectTile]
+    unsigned char* t_vis = scratch + kConnectTile * 8;                                         // [2 * kConnectTile]
+    uint32_t* t_misc = reinterpret_cast<uint32_t*>(scratch + kConnectTile * 10);               // tile base, #sky, #light
+    float4* lds_nodes = reinterpret_cast<float4*>(scratch + kConnectScratch);
     float4* lds_tris = lds_nodes + sc.node_count * 8;
     stage_scene<LDS_SCENE>(sc, lds_nodes, lds_tris);
     const uint32_t nf = ctr->connect_front, nb = ctr->connect_back, n = nf + nb;
     const float4* Tprev = ps.T[parity];
-    const uint32_t chunk = fetch_chunk(n);
+    const uint32_t tile = connect_tile(n);
+    const uint32_t tid = threadIdx.x;
+    constexpr uint32_t kOwn = kConnectTile / kTraverseBlock;  // paths a thread owns per tile
     TravStats st; st.nodes = 0; st.tris = 0;
     while (true) {
-        uint32_t base = 0;
-        if (lane_id() == 0) base = atomicAdd(&ctr->connect_head, chunk);
-        base = __shfl(base, 0);
+        __syncthreads();  // the previous tile is fully consumed
+        if (tid == 0) { t_misc[0] = atomicAdd(&ctr->connect_head, tile); t_misc[1] = 0u; t_misc[2] = 0u; }
+        __syncthreads();
+        const uint32_t base = t_misc[0];
         if (base >= n) break;
-        for (uint32_t k = 0; k < chunk; k += 64) {
-            uint32_t i = base + k + lane_id();
-            if (i >= n) break;
-            uint32_t slot = (i < nf) ? cqueue[i] : cqueue[ps.capacity - 1u - (i - nf)];
-            float4 ce = ps.CE[slot];
-            uint32_t flags = __float_as_uint(ce.w);
-            V3 E = xyz(ce);
-            if (flags & kCF_Sky) {  // ClosestHit.slang:139, 344-353
-                float4 so = ps.CSO[slot], sd = ps.CSD[slot];
-                if (sky_visible<LDS_SCENE, COUNT>(sc, lds_nodes, lds_tris, xyz(so), v3(so.w, sd.x, sd.y), stack, st)) E = E + xyz(ps.CS[slot]);
+        uint32_t slot[kOwn], flags[kOwn];
+#pragma unroll
+        for (uint32_t q = 0; q < kOwn; q++) {
+            const uint32_t j = tid + q * kTraverseBlock, i = base + j;
+            const bool valid = j < tile && i < n;
+            slot[q] = 0u; flags[q] = 0u;
+            if (valid) {
+                slot[q] = (i < nf) ? cqueue[i] : cqueue[ps.capacity - 1u - (i - nf)];
+                flags[q] = __float_as_uint(ps.CE[slot[q]].w) | 0x80000000u;  // bit 31: this thread owns a path here
+                t_slot[j] = slot[q];
             }
-            if (flags & kCF_Light) {  // ClosestHit.slang:171-176, 358-370
-                float4 lo = ps.CLO[slot], ld = ps.CLD[slot], cl = ps.CL[slot];
-                if (light_visible<LDS_SCENE, COUNT>(sc, lds_nodes, lds_tris, xyz(lo), v3(lo.w, ld.x, ld.y), __float_as_uint(cl.w), stack, st)) E = E + xyz(cl);
+            const bool sky = (flags[q] & kCF_Sky) != 0u, light = (flags[q] & kCF_Light) != 0u;
+            const uint32_t ps_ = wave_append(sky, &t_misc[1]);
+            if (sky) t_list[ps_] = (uint16_t)j;
+            const uint32_t pl_ = wave_append(light, &t_misc[2]);
+            if (light) t_list[2u * kConnectTile - 1u - pl_] = (uint16_t)j;
+        }
+        __syncthreads();
+        const uint32_t ns = t_misc[1], nr = ns + t_misc[2];
+        for (uint32_t r = tid; r < nr; r += kTraverseBlock) {
+            if (r < ns) {  // ClosestHit.slang:139, 344-353
+                const uint32_t j = t_list[r], sl = t_slot[j];
+                float4 so = ps.CSO[sl], sd = ps.CSD[sl];
+                t_vis[2u * j] = sky_visible<LDS_SCENE, COUNT>(sc, lds_nodes, lds_tris, xyz(so), v3(so.w, sd.x, sd.y), stack, st) ? 1 : 0;
+            } else {       // ClosestHit.slang:171-176, 358-370
+                const uint32_t j = t_list[2u * kConnectTile - 1u - (r - ns)], sl = t_slot[j];
+                float4 lo = ps.CLO[sl], ld = ps.CLD[sl];
+                const uint32_t expect = __float_as_uint(ps.CL[sl].w);
+                t_vis[2u * j + 1u] = light_visible<LDS_SCENE, COUNT>(sc, lds_nodes, lds_tris, xyz(lo), v3(lo.w, ld.x, ld.y), expect, stack, st) ? 1 : 0;
             }
-            V3 contrib = E * xyz(Tprev[slot]);  // RayGen.slang:92
-            if (flags & kCF_Clamp) {
-                float lum = dot(contrib, v3(0.212671f, 0.715160f, 0.072169f));
-                contrib = contrib * (P.max_luminance / max_(lum, P.max_luminance));
-            }
-            V3 light = xyz(ps.L[slot]) + contrib;
-            if (flags & kCF_Finalize) {
-                bool ok = !isinf_(light.x) && !isinf_(light.y) && !isinf_(light.z) && !isnan_(light.x) && !isnan_(light.y) && !isnan_(light.z);
-                if (P.samples_per_frame == 1) {  // the only finalisation of this slot: 0 + pathLight
-                    ps.ACC[slot] = ok ? f4(v3s(0.0f) + light, 0.0f) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                } else if (ok) {
-                    float4 acc = ps.ACC[slot]; ps.ACC[slot] = f4(xyz(acc) + light, 0.0f);
+        }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t q = 0; q < kOwn; q++) {
+            if (flags[q] & 0x80000000u) {
+                const uint32_t j = tid + q * kTraverseBlock, sl = slot[q], fl = flags[q];
+                V3 E = xyz(ps.CE[sl]);
+                if ((fl & kCF_Sky) && t_vis[2u * j]) E = E + xyz(ps.CS[sl]);
+                if ((fl & kCF_Light) && t_vis[2u * j + 1u]) E = E + xyz(ps.CL[sl]);
+                V3 contrib = E * xyz(Tprev[sl]);  // RayGen.slang:92
+                if (fl & kCF_Clamp) {
+                    float lum = dot(contrib, v3(0.212671f, 0.715160f, 0.072169f));
+                    contrib = contrib * (P.max_luminance / max_(lum, P.max_luminance));
                 }
-                light = v3s(0.0f);  // a regenerated sample starts from pathLight = 0
+                V3 light = xyz(ps.L[sl]) + contrib;
+                if (fl & kCF_Finalize) {
+                    bool ok = !isinf_(light.x) && !isinf_(light.y) && !isinf_(light.z) && !isnan_(light.x) && !isnan_(light.y) && !isnan_(light.z);
+                    if (P.samples_per_frame == 1) {  // the only finalisation of this slot: 0 + pathLight
+                        ps.ACC[sl] = ok ? f4(v3s(0.0f) + light, 0.0f) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    } else if (ok) {
+                        float4 acc = ps.ACC[sl]; ps.ACC[sl] = f4(xyz(acc) + light, 0.0f);
+                    }
+                    light = v3s(0.0f);  // a regenerated sample starts from pathLight = 0
+                }
+                ps.L[sl] = f4(light, 0.0f);
             }
-            ps.L[slot] = f4(light, 0.0f);
         }
     }
     if (COUNT) {
@@ -820,7 +863,7 @@ void launch_fold(hipStream_t s, Counters* ctr) { hipLaunchKernelGGL(k_fold, dim3
 
 size_t traverse_lds_bytes(const DeviceScene& sc, bool lds_scene) {
     size_t b = (size_t)kStackDepth * kTraverseBlock * 4;
-    if (lds_scene) b += (size_t)sc.node_count * sizeof(BvhNode) + (size_t)sc.tri_count * sizeof(BvhTri);
+    if (lds_scene) b += (size_t)sc.node_count * sizeof(BvhNodeWide) + (size_t)sc.tri_count * sizeof(BvhTri);
     return b;
 }
 void launch_extend(hipStream_t s, uint32_t blocks, bool lds_scene, bool count, const DeviceScene& sc, const PathState& ps,
@@ -836,7 +879,7 @@ void launch_extend(hipStream_t s, uint32_t blocks, bool lds_scene, bool count, c
 }
 void launch_connect(hipStream_t s, uint32_t blocks, bool lds_scene, bool count, const DeviceScene& sc, const RenderParams& P,
                     const PathState& ps, const uint32_t* cqueue, Counters* ctr, uint32_t parity) {
-    size_t lds = traverse_lds_bytes(sc, lds_scene);
+    size_t lds = traverse_lds_bytes(sc, lds_scene) + kConnectScratch;
     if (lds_scene) {
         if (count) hipLaunchKernelGGL((k_connect<true, true>), dim3(blocks), dim3(kTraverseBlock), lds, s, sc, P, ps, cqueue, ctr, parity);
         else hipLaunchKernelGGL((k_connect<true, false>), dim3(blocks), dim3(kTraverseBlock), lds, s, sc, P, ps, cqueue, ctr, parity);
@@ -863,7 +906,7 @@ void launch_scatter_rows(hipStream_t s, const float* gathered, float* full, uint
 size_t stack_overflow_bytes(uint32_t blocks) { return (size_t)blocks * kTraverseBlock * kStackOverflow * 4; }
 int traverse_blocks_per_cu(bool lds_scene, const DeviceScene& sc) {
     int nb = 0;
-    size_t lds = traverse_lds_bytes(sc, lds_scene);
+    size_t lds = traverse_lds_bytes(sc, lds_scene) + kConnectScratch;
     if (lds_scene) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_connect<true, false>, kTraverseBlock, lds);
     else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_connect<false, false>, kTraverseBlock, lds);
     return nb > 0 ? nb : 1;

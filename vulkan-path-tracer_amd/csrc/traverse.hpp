@@ -1,16 +1,17 @@
 // traverse.hpp — BVH4 traversal for one ray per lane (replaces the driver-side TraceRay / RayQuery of
 // RayGen.slang:90 and RTCommon.slang:54-63).
 //
-// * nodes are 128 B (four child boxes in SoA form + four child codes: one cache line, 7 x dwordx4),
-//   triangles 48 B; closest-hit search visits the hit children nearest first (4-element sorting network on the
+// * nodes in global memory are 64 B (four child boxes as 8-bit offsets on a per-node power-of-two grid + four
+//   child codes: 4 x dwordx4, two nodes per cache line); a scene small enough to be staged into LDS uses the
+//   same tree with fp32 boxes (128 B nodes: no decode, fewer VALU ops); triangles 48 B; closest-hit search visits the hit children nearest first (4-element sorting network on the
 //   entry distances), any-hit search takes them in slot order;
 // * the per-lane stack lives in LDS as stack[depth][lane] (bank = lane, conflict-free) for the first
 //   kStackDepth entries and spills to a per-thread global region beyond that (rare: 3 pushes per level);
 // * the triangle test is the shared fp32 contract vptfp::ray_triangle(), so (t,u,v) are bit-identical to the
 //   oracle's; ties in t go to the smaller global triangle id, so the result does not depend on traversal
 //   order or tree shape;
-// * box tests are conservative (boxes are padded at build time; the interval test carries a 4-ulp slack) — a
-//   box test only ever prunes, it never decides a hit.
+// * box tests are conservative (boxes are padded at build time and quantised outward; the interval test
+//   carries a 4-ulp slack) — a box test only ever prunes, it never decides a hit.
 #pragma once
 #include "device_types.hpp"
 
@@ -52,19 +53,30 @@ __device__ inline TravStack make_stack(unsigned char* smem, uint32_t* overflow) 
 }
 
 struct NodeData {
+    float ox, oy, oz;
+    uint32_t exps;
+    uint32_t lox, loy, loz, hix, hiy, hiz;
+    int c0, c1, c2, c3;
+};
+__device__ inline void unpack_node(const uint4& w0, const uint4& w1, const uint4& w2, const uint4& w3, NodeData& n) {
+    n.ox = __uint_as_float(w0.x); n.oy = __uint_as_float(w0.y); n.oz = __uint_as_float(w0.z); n.exps = w0.w;
+    n.lox = w1.x; n.loy = w1.y; n.loz = w1.z; n.hix = w1.w; n.hiy = w2.x; n.hiz = w2.y;
+    n.c0 = (int)w3.x; n.c1 = (int)w3.y; n.c2 = (int)w3.z; n.c3 = (int)w3.w;
+}
+
+struct NodeDataWide {
     float4 minx, miny, minz, maxx, maxy, maxz;
     int c0, c1, c2, c3;
 };
 
-// Scene access either from global memory or from an LDS copy (small scenes).
+// Scene access either from global memory (quantised nodes) or from an LDS copy (small scenes, fp32 nodes).
 struct GlobalSceneSrc {
+    using Node = NodeData;
     const BvhNode* nodes;
     const BvhTri* tris;
     __device__ inline void node(int i, NodeData& n) const {
-        const float4* p = reinterpret_cast<const float4*>(nodes + i);
-        n.minx = p[0]; n.miny = p[1]; n.minz = p[2]; n.maxx = p[3]; n.maxy = p[4]; n.maxz = p[5];
-        float4 c = p[6];
-        n.c0 = __float_as_int(c.x); n.c1 = __float_as_int(c.y); n.c2 = __float_as_int(c.z); n.c3 = __float_as_int(c.w);
+        const uint4* p = reinterpret_cast<const uint4*>(nodes + i);
+        unpack_node(p[0], p[1], p[2], p[3], n);
     }
     __device__ inline void tri(int i, float4& a, float4& b, float4& c) const {
         const float4* p = reinterpret_cast<const float4*>(tris + i);
@@ -72,9 +84,10 @@ struct GlobalSceneSrc {
     }
 };
 struct LdsSceneSrc {
-    const float4* nodes;  // LDS
+    using Node = NodeDataWide;
+    const float4* nodes;  // LDS, BvhNodeWide
     const float4* tris;   // LDS
-    __device__ inline void node(int i, NodeData& n) const {
+    __device__ inline void node(int i, NodeDataWide& n) const {
         const float4* p = nodes + i * 8;
         n.minx = p[0]; n.miny = p[1]; n.minz = p[2]; n.maxx = p[3]; n.maxy = p[4]; n.maxz = p[5];
         float4 c = p[6];
@@ -90,16 +103,6 @@ __device__ inline float fmin_(float a, float b) { return __builtin_fminf(a, b); 
 __device__ inline float fmax_(float a, float b) { return __builtin_fmaxf(a, b); }
 constexpr float kMissT = 3.0e38f;
 
-// Entry distance of the ray into a box, or kMissT if it misses [tmin, tlimit].
-__device__ inline float box_entry(float bx0, float by0, float bz0, float bx1, float by1, float bz1, V3 o, V3 inv,
-                                  float tmin, float tlimit) {
-    float t0x = (bx0 - o.x) * inv.x, t1x = (bx1 - o.x) * inv.x;
-    float t0y = (by0 - o.y) * inv.y, t1y = (by1 - o.y) * inv.y;
-    float t0z = (bz0 - o.z) * inv.z, t1z = (bz1 - o.z) * inv.z;
-    float tn = fmax_(fmax_(fmin_(t0x, t1x), fmin_(t0y, t1y)), fmax_(fmin_(t0z, t1z), tmin));
-    float tf = fmin_(fmin_(fmax_(t0x, t1x), fmax_(t0y, t1y)), fmin_(fmax_(t0z, t1z), tlimit));
-    return (tn <= tf * 1.0000005f) ? tn : kMissT;
-}
 __device__ inline V3 safe_inverse(V3 d) {
     // a zero component would give 0*inf = NaN in the slab test: clamp its reciprocal to +-1e30
     V3 inv;
@@ -108,11 +111,58 @@ __device__ inline V3 safe_inverse(V3 d) {
     inv.z = (vptfp::fabs_(d.z) > 1e-30f) ? 1.0f / d.z : (vptfp::f2u(d.z) >> 31 ? -1e30f : 1e30f);
     return inv;
 }
-__device__ inline void node_entries(const NodeData& n, V3 o, V3 inv, float tmin, float tlimit, float& t0, float& t1, float& t2, float& t3) {
-    t0 = box_entry(n.minx.x, n.miny.x, n.minz.x, n.maxx.x, n.maxy.x, n.maxz.x, o, inv, tmin, tlimit);
-    t1 = box_entry(n.minx.y, n.miny.y, n.minz.y, n.maxx.y, n.maxy.y, n.maxz.y, o, inv, tmin, tlimit);
-    t2 = box_entry(n.minx.z, n.miny.z, n.minz.z, n.maxx.z, n.maxy.z, n.maxz.z, o, inv, tmin, tlimit);
-    t3 = box_entry(n.minx.w, n.miny.w, n.minz.w, n.maxx.w, n.maxy.w, n.maxz.w, o, inv, tmin, tlimit);
+
+// Per-ray constants of the slab test: reciprocal direction and which plane byte is the near one per axis.
+struct RaySlab {
+    V3 o, inv;
+    bool negx, negy, negz;
+};
+__device__ inline RaySlab make_slab(V3 o, V3 d) {
+    RaySlab r;
+    r.o = o; r.inv = safe_inverse(d);
+    r.negx = r.inv.x < 0.0f; r.negy = r.inv.y < 0.0f; r.negz = r.inv.z < 0.0f;
+    return r;
+}
+template <int K> __device__ inline float byte_f(uint32_t w) { return (float)((w >> (8 * K)) & 0xffu); }  // v_cvt_f32_ubyteK
+
+// Entry distances of the ray into the four child boxes ([tmin, tlimit] clipped), kMissT for a miss.
+// plane distance = (origin + q*step - o) * inv = q * (step*inv) + (origin - o)*inv: one fma per plane (step is a
+// power of two, so step*inv is exact); the rounding of the second term moves a plane by a few ulp of the
+// ray-to-node distance, which the build-time padding of every box covers.  The near/far byte is picked by the
+// sign of the direction, so an inverted (unused) slot gives near > far on every axis and is never entered.
+__device__ inline void node_entries(const NodeData& n, const RaySlab& r, float tmin, float tlimit, float& t0, float& t1, float& t2, float& t3) {
+    const float ax = __uint_as_float((n.exps & 0xffu) << 23) * r.inv.x;
+    const float ay = __uint_as_float(((n.exps >> 8) & 0xffu) << 23) * r.inv.y;
+    const float az = __uint_as_float(((n.exps >> 16) & 0xffu) << 23) * r.inv.z;
+    const float bx = (n.ox - r.o.x) * r.inv.x, by = (n.oy - r.o.y) * r.inv.y, bz = (n.oz - r.o.z) * r.inv.z;
+    const uint32_t nx = r.negx ? n.hix : n.lox, fx = r.negx ? n.lox : n.hix;
+    const uint32_t ny = r.negy ? n.hiy : n.loy, fy = r.negy ? n.loy : n.hiy;
+    const uint32_t nz = r.negz ? n.hiz : n.loz, fz = r.negz ? n.loz : n.hiz;
+#define VPT_CHILD(K, T)                                                                                                     \
+    {                                                                                                                       \
+        float tn = fmax_(fmax_(__builtin_fmaf(byte_f<K>(nx), ax, bx), __builtin_fmaf(byte_f<K>(ny), ay, by)),               \
+                         fmax_(__builtin_fmaf(byte_f<K>(nz), az, bz), tmin));                                               \
+        float tf = fmin_(fmin_(__builtin_fmaf(byte_f<K>(fx), ax, bx), __builtin_fmaf(byte_f<K>(fy), ay, by)),               \
+                         fmin_(__builtin_fmaf(byte_f<K>(fz), az, bz), tlimit));                                             \
+        T = (tn <= tf * 1.0000005f) ? tn : kMissT;                                                                          \
+    }
+    VPT_CHILD(0, t0) VPT_CHILD(1, t1) VPT_CHILD(2, t2) VPT_CHILD(3, t3)
+#undef VPT_CHILD
+}
+// fp32 nodes: the plain slab test.
+__device__ inline float box_entry(float bx0, float by0, float bz0, float bx1, float by1, float bz1, V3 o, V3 inv, float tmin, float tlimit) {
+    float t0x = (bx0 - o.x) * inv.x, t1x = (bx1 - o.x) * inv.x;
+    float t0y = (by0 - o.y) * inv.y, t1y = (by1 - o.y) * inv.y;
+    float t0z = (bz0 - o.z) * inv.z, t1z = (bz1 - o.z) * inv.z;
+    float tn = fmax_(fmax_(fmin_(t0x, t1x), fmin_(t0y, t1y)), fmax_(fmin_(t0z, t1z), tmin));
+    float tf = fmin_(fmin_(fmax_(t0x, t1x), fmax_(t0y, t1y)), fmin_(fmax_(t0z, t1z), tlimit));
+    return (tn <= tf * 1.0000005f) ? tn : kMissT;
+}
+__device__ inline void node_entries(const NodeDataWide& n, const RaySlab& r, float tmin, float tlimit, float& t0, float& t1, float& t2, float& t3) {
+    t0 = box_entry(n.minx.x, n.miny.x, n.minz.x, n.maxx.x, n.maxy.x, n.maxz.x, r.o, r.inv, tmin, tlimit);
+    t1 = box_entry(n.minx.y, n.miny.y, n.minz.y, n.maxx.y, n.maxy.y, n.maxz.y, r.o, r.inv, tmin, tlimit);
+    t2 = box_entry(n.minx.z, n.miny.z, n.minz.z, n.maxx.z, n.maxy.z, n.maxz.z, r.o, r.inv, tmin, tlimit);
+    t3 = box_entry(n.minx.w, n.miny.w, n.minz.w, n.maxx.w, n.maxy.w, n.maxz.w, r.o, r.inv, tmin, tlimit);
 }
 __device__ inline void cswap(float& ta, int& ca, float& tb, int& cb) {
     bool sw = tb < ta;
@@ -126,16 +176,16 @@ template <bool COUNT, class Src>
 __device__ inline bool trace_closest(const Src& src, V3 o, V3 d, float tmin, float tmax, TravStack stack, HitRec& best, TravStats& st) {
     best.t = tmax; best.u = 0.0f; best.v = 0.0f; best.prim = 0xffffffffu; best.inst = 0xffffffffu; best.gid = 0xffffffffu;
     bool found = false;
-    const V3 inv = safe_inverse(d);
+    const RaySlab slab = make_slab(o, d);
     stack.sp = 0;
     int cur = 0;  // root is inner node 0
     while (true) {
         if (cur >= 0) {
-            NodeData n;
+            typename Src::Node n;
             src.node(cur, n);
             if (COUNT) st.nodes++;
             float t0, t1, t2, t3;
-            node_entries(n, o, inv, tmin, best.t, t0, t1, t2, t3);
+            node_entries(n, slab, tmin, best.t, t0, t1, t2, t3);
             int c0 = n.c0, c1 = n.c1, c2 = n.c2, c3 = n.c3;
             cswap(t0, c0, t1, c1); cswap(t2, c2, t3, c3); cswap(t0, c0, t2, c2); cswap(t1, c1, t3, c3); cswap(t1, c1, t2, c2);
             if (t0 < kMissT) {  // nearest child next, the others pushed far -> near
@@ -183,16 +233,16 @@ template <bool COUNT, bool LIGHT, class Src>
 __device__ inline bool trace_occluded(const Src& src, V3 o, V3 d, float tmin, float tmax, float t_e, uint32_t expect, TravStack stack,
                                       TravStats& st) {
     const float tlimit = LIGHT ? t_e : tmax;
-    const V3 inv = safe_inverse(d);
+    const RaySlab slab = make_slab(o, d);
     stack.sp = 0;
     int cur = 0;
     while (true) {
         if (cur >= 0) {
-            NodeData n;
+            typename Src::Node n;
             src.node(cur, n);
             if (COUNT) st.nodes++;
             float t0, t1, t2, t3;
-            node_entries(n, o, inv, tmin, tlimit, t0, t1, t2, t3);
+            node_entries(n, slab, tmin, tlimit, t0, t1, t2, t3);
             int next = 0x7fffffff;  // order is irrelevant for an any-hit search: take hit children in slot order
             if (t3 < kMissT) next = n.c3;
             if (t2 < kMissT) { if (next != 0x7fffffff) stack.push((uint32_t)next); next = n.c2; }

@@ -2,6 +2,7 @@
 // arithmetic of PathTracer.cpp restated), the wavefront render loop, sharding, post-process schedule.
 // There is no CPU fallback in this file: without a HIP device vpt_create() fails.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -48,6 +49,12 @@ struct vpt_ctx {
     PathState ps{};
     uint32_t* queue[2] = {nullptr, nullptr};
     uint32_t* cqueue = nullptr;  // connect queue (two-ended)
+    // AUTO pipeline on a scene whose BVH does not fit LDS: the first four full batches are timed, staged and fused
+    // alternating (both produce identical bits; the first of each also pays its kernels' one-time load), and the
+    // pipeline with the smaller minimum is kept until the scene, size or params change.
+    int tune_state = 0;  // batches timed so far (even: staged next, odd: fused next); kTuneBatches = decided
+    bool auto_fused = false;
+    double tune_ms[2] = {1e30, 1e30};
     uint32_t* d_launch_off = nullptr;  // split-screen: launch-grid prefix sums of the dispatches of a batch
     int shade_blocks = 1024, primary_blocks = 768, max_blocks = 1536;
     Counters* ctr = nullptr;
@@ -132,7 +139,8 @@ int alloc_render_buffers(vpt_ctx* c) {
     P.shard_pixels = P.shard_rows * P.width;
     if (P.shard_pixels == 0) return fail(c, VPT_ERR_INVALID_ARGUMENT, "empty shard");
     uint32_t F = c->cfg.frames_in_flight;
-    if (F == 0) { F = (32u << 20) / P.shard_pixels; F = std::max(1u, std::min(F, 64u)); }  // ~32M resident paths (8.4 GB of records)
+    if (F == 0) F = (32u << 20) / P.shard_pixels;  // ~32M resident paths (8.4 GB of records) whatever the shard size
+    F = std::max(1u, std::min(F, 256u));
     c->frames_in_flight = F;
     uint64_t cap64 = (uint64_t)P.shard_pixels * F;
     if (cap64 >= (1ull << 31)) return fail(c, VPT_ERR_INVALID_ARGUMENT, "too many paths in flight");
@@ -291,7 +299,7 @@ int render_batch(vpt_ctx* c, uint32_t frames, uint32_t dispatch_base) {
     if (n_slots == 0) return VPT_OK;
     const bool count = c->cfg.count_traversal != 0;
     // fused (one kernel per bounce, bounce 0 included) when the BVH rides in LDS; staged otherwise
-    const bool fused = c->cfg.pipeline == VPT_PIPELINE_FUSED || (c->cfg.pipeline == VPT_PIPELINE_AUTO && c->lds_scene);
+    const bool fused = c->cfg.pipeline == VPT_PIPELINE_FUSED || (c->cfg.pipeline == VPT_PIPELINE_AUTO && (c->lds_scene || c->auto_fused));
     Counters init{};
     if (!fused) init.ray_count[0] = n_slots;
     HIPCHK(c, hipMemcpyAsync(c->ctr, &init, 32, hipMemcpyHostToDevice, s));  // queue words only, stat_* keep running
@@ -401,7 +409,7 @@ vpt_ctx* vpt_create(const vpt_config* cfg, int* err) {
         set(VPT_ERR_DEVICE); delete c; return nullptr;
     }
     (void)hipMemset(c->ctr, 0, sizeof(Counters));
-    if (hipMalloc((void**)&c->d_launch_off, 65 * 4) != hipSuccess) { set(VPT_ERR_DEVICE); vpt_destroy(c); return nullptr; }
+    if (hipMalloc((void**)&c->d_launch_off, 257 * 4) != hipSuccess) { set(VPT_ERR_DEVICE); vpt_destroy(c); return nullptr; }
     vpt_default_params(&c->params);
     const float id[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
     memcpy(c->P.view_inv, id, 64); memcpy(c->P.proj_inv, id, 64);
@@ -485,8 +493,8 @@ int vpt_set_scene(vpt_ctx* c, const vpt_scene_desc* sd) {
             tris.push_back(bt);
         }
     }
-    std::vector<BvhNode> nodes; std::vector<BvhTri> leaf_tris; int depth = 0;
-    build_bvh(tris, nodes, leaf_tris, &depth);
+    std::vector<BvhNode> nodes; std::vector<BvhNodeWide> wide; std::vector<BvhTri> leaf_tris; int depth = 0;
+    build_bvh(tris, nodes, wide, leaf_tris, &depth);
     c->bvh_depth = (uint32_t)depth;
     // ---- textures
     std::vector<TexDesc> tds; std::vector<uint8_t> texels;
@@ -509,6 +517,10 @@ int vpt_set_scene(vpt_ctx* c, const vpt_scene_desc* sd) {
     DeviceScene& D = c->dsc;
     int rc;
     if ((rc = upload(c, nodes, &D.nodes))) return rc;
+    // small scenes ride in LDS next to the traversal stacks, in the fp32 node form
+    c->lds_scene = (nodes.size() * sizeof(BvhNodeWide) + leaf_tris.size() * sizeof(BvhTri)) <= 16384;
+    D.nodes_wide = nullptr;
+    if (c->lds_scene && (rc = upload(c, wide, &D.nodes_wide))) return rc;
     if ((rc = upload(c, leaf_tris, &D.tris))) return rc;
     D.node_count = (uint32_t)nodes.size(); D.tri_count = (uint32_t)leaf_tris.size();
     {
@@ -549,8 +561,7 @@ int vpt_set_scene(vpt_ctx* c, const vpt_scene_desc* sd) {
     if ((rc = upload(c, lr, &D.lut_r))) return rc;
     if ((rc = upload(c, lo, &D.lut_o))) return rc;
     if ((rc = upload(c, li, &D.lut_i))) return rc;
-    // small scenes ride in LDS next to the traversal stacks
-    c->lds_scene = ((size_t)D.node_count * sizeof(BvhNode) + (size_t)D.tri_count * sizeof(BvhTri)) <= 16384;
+    c->tune_state = 0; c->auto_fused = false; c->tune_ms[0] = c->tune_ms[1] = 1e30;
     c->trav_blocks = traverse_blocks_per_cu(c->lds_scene, D) * c->cu_count;
     c->shade_blocks = shade_blocks_per_cu() * c->cu_count;
     c->primary_blocks = bounce_blocks_per_cu(c->lds_scene, D) * c->cu_count;
@@ -607,6 +618,7 @@ int vpt_set_params(vpt_ctx* c, const vpt_params* p) {
     if (p->screen_chunk_count != 1 && c->P.shard_count != 1) return fail(c, VPT_ERR_UNSUPPORTED, "split-screen dispatch needs the whole image in one context (shard_count == 1): its first dispatch copies pixels across rows");
     if (!(p->flags & VPT_FLAG_RAY_QUERIES)) return fail(c, VPT_ERR_UNSUPPORTED, "only the USE_RAY_QUERIES semantics are implemented");
     const bool flags_changed = c->params.flags != p->flags;
+    if (flags_changed || c->params.max_depth != p->max_depth) { c->tune_state = 0; c->auto_fused = false; c->tune_ms[0] = c->tune_ms[1] = 1e30; }
     c->params = *p;
     sync_params(c);
     reset_accum(c);
@@ -641,8 +653,17 @@ int vpt_render(vpt_ctx* c, uint32_t dispatches, int* done) {
         uint64_t frames_needed = ((uint64_t)c->params.max_samples + c->params.samples_per_frame - 1) / c->params.samples_per_frame;
         uint64_t disp_left = frames_needed * S2 - c->dispatch_count;
         uint32_t nf = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(left, c->frames_in_flight), disp_left);
-        int rc = render_batch(c, nf, (uint32_t)c->dispatch_count);
+        constexpr int kTuneBatches = 4;
+        const bool tune = c->cfg.pipeline == VPT_PIPELINE_AUTO && !c->lds_scene && c->tune_state < kTuneBatches && nf == c->frames_in_flight;
+        if (tune) c->auto_fused = (c->tune_state & 1) != 0;
+        const auto t0 = std::chrono::steady_clock::now();
+        int rc = render_batch(c, nf, (uint32_t)c->dispatch_count);  // returns with the stream drained
         if (rc) return rc;
+        if (tune) {
+            double& best = c->tune_ms[c->tune_state & 1];
+            best = std::min(best, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+            c->auto_fused = ++c->tune_state == kTuneBatches && c->tune_ms[1] < c->tune_ms[0];
+        }
         c->dispatch_count += nf;
         c->frame_count = (uint32_t)(c->dispatch_count / S2);
         c->samples_accum = c->frame_count * c->params.samples_per_frame;
@@ -746,7 +767,7 @@ int vpt_get_stats(vpt_ctx* c, vpt_stats* out) {
     s.frames = c->frame_count; s.dispatches = c->dispatch_count;
     s.total_vertex_count = c->total_vertices; s.total_index_count = c->total_indices;
     s.bvh_nodes = c->dsc.node_count; s.bvh_triangles = c->dsc.tri_count;
-    s.bvh_node_bytes = sizeof(BvhNode); s.bvh_tri_bytes = sizeof(BvhTri);
+    s.bvh_node_bytes = c->lds_scene ? sizeof(BvhNodeWide) : sizeof(BvhNode); s.bvh_tri_bytes = sizeof(BvhTri);
     s.emissive_mesh_count = (uint32_t)c->emissive.size(); s.emissive_triangle_count = c->emissive_tris;
     s.frames_in_flight = c->frames_in_flight; s.shard_pixels = c->P.shard_pixels;
     *out = s;
