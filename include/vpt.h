@@ -276,6 +276,20 @@ typedef struct vpt_ray { float origin[3]; float tmin; float direction[3]; float 
 typedef struct vpt_hit { float t; float u; float v; uint32_t primitive; uint32_t instance; } vpt_hit;
 int vpt_trace_rays(vpt_ctx* ctx, const vpt_ray* rays_host, uint32_t n, vpt_hit* hits_host);
 
+/* ---- energy-compensation lookup tables -------------------------------------------
+ * Replaces LookupTableCalculator::CalculateTable(tableSize, sampleCount) (LookupTableCalculator.cpp:44-157)
+ * with its shaders LookupReflect.slang / LookupRefract.slang (+ ABOVE_SURFACE / BELOW_SURFACE): sampleCount/20
+ * passes of 20 samples per cell, pass i seeded with PCG(i*2 + sampleCount + PCG(time_ms)), summed in pass
+ * order and divided by the pass count.  The reference puts wall-clock milliseconds into time_ms (one reading
+ * per pass); here it is one caller-chosen value, so a table is reproducible.  Application.cpp:41,54,67 use
+ * sizes 64x64x32 (reflect) and 128x128x32 (refract) with 10'000'000 samples.
+ * out_host receives size_x*size_y*size_z floats, x fastest.  Needs no context (runs on `device`). */
+#define VPT_LUT_REFLECT 0
+#define VPT_LUT_REFRACT_ABOVE 1
+#define VPT_LUT_REFRACT_BELOW 2
+int vpt_lut_calculate(int device, uint32_t kind, uint32_t size_x, uint32_t size_y, uint32_t size_z, uint32_t sample_count,
+                      uint32_t time_ms, float* out_host);
+
 #ifdef __cplusplus
 }
 #endif

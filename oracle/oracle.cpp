@@ -1169,4 +1169,67 @@ float orc_lut_refract_cell(uint32_t x, uint32_t y, uint32_t z, uint32_t sx, uint
     return (float)(fin / (double)nsamples);
 }
 
+// LookupTableCalculator::CalculateTable (LookupTableCalculator.cpp:44-157) for a list of cells, with the exact
+// arithmetic structure of the reference: sampleCount/20 passes; pass i reseeds the cell with
+// Sampler(y + x*x + PCG(i*2 + sampleCount + PCG(time_ms))) (:99-103; the reference's time_ms is a wall-clock
+// reading per pass, here one fixed value), adds finalValue/20 (fp32, LookupReflect.slang:60-89 /
+// LookupRefract.slang:53-102) and the sum is divided by the pass count at the end (:152-155).
+// kind 0 reflect, 1 refract ABOVE_SURFACE, 2 refract BELOW_SURFACE.  cells[i] = x + y*sx + z*sx*sy.
+void orc_lut_cells(uint32_t kind, uint32_t sx, uint32_t sy, uint32_t sz, uint32_t sample_count, uint32_t time_ms,
+                   const uint32_t* cells, uint32_t n, float* out, int threads) {
+    const uint32_t passes = sample_count / 20u, th = pcg_hash(time_ms);
+#pragma omp parallel for schedule(dynamic, 16) num_threads(threads > 0 ? threads : 1)
+    for (int64_t ci = 0; ci < (int64_t)n; ci++) {
+        const uint32_t index = cells[ci], x = index % sx, y = (index / sx) % sy, z = index / (sx * sy);
+        Mat m; memset(&m.p, 0, sizeof(m.p)); m.o = nullptr; m.ec = false;
+        float vc;
+        if (kind == 0) {
+            vc = clamp_((float)x / (float)sx, 0.05f, 0.999f);
+            float rough = clamp_((float)y / (float)sy, 0.0001f, 1.0f);
+            float aniso = (float)z / (float)sz;
+            float aspect = sqrt_(1.0f - sqrt_(aniso) * 0.9f);
+            m.ax = max_(0.0001f, rough / aspect); m.ay = max_(0.0001f, rough * aspect);
+            m.p.anisotropy = aniso; m.p.roughness = rough; m.eta = 1.0f;
+        } else {
+            vc = clamp_(pow_((float)x / ((float)sx - 1.0f), 2.0f), 0.01f, 0.9999f);
+            float rough = clamp_((float)y / ((float)sy - 1.0f), 0.01f, 1.0f);
+            float ior = 1.0f + clamp_((float)z / ((float)sz - 1.0f), 0.0001f, 1.0f);
+            m.ax = rough; m.ay = rough; m.p.roughness = rough; m.p.ior = ior; m.eta = kind == 1 ? (1.0f / ior) : ior;
+        }
+        float cell = 0.0f;
+        for (uint32_t i = 0; i < passes; i++) {
+            Rng r; r.s = y + x * x + pcg_hash(i * 2u + sample_count + th);
+            float fin = 0.0f;
+            for (uint32_t k = 0; k < 20u; k++) {
+                float mag = sqrt_(1.0f - vc * vc);
+                float phi = r.uf() * M_2_PI_F;
+                float s, c; sincos_(phi, &s, &c);
+                V3 V = normalize(v3(mag * c, mag * s, vc));
+                V3 H = ggx_sample(r, V, m.ax, m.ay);
+                if (kind == 0) {
+                    V3 L = normalize(reflect(-V, H));
+                    if (L.z <= 0.0f) continue;
+                    Eval e = m.eval_reflection(V, L, v3s(1.0f));
+                    if (e.pdf <= 0.0f) continue;
+                    if (isnan_(e.bxdf.x) || isinf_(e.bxdf.x)) continue;
+                    fin += e.bxdf.x / e.pdf;
+                } else {
+                    float F = m.dielectric_fresnel(fabs_(dot(V, H)));
+                    float val = 0.0f;
+                    if (r.uf() < F) {
+                        V3 L = normalize(reflect(-V, H));
+                        if (L.z > 0.0f) { Eval e = m.eval_reflection(V, L, v3s(1.0f)); if (e.pdf > 0.0f && !isnan_(e.bxdf.x) && !isinf_(e.bxdf.x)) val += e.bxdf.x / e.pdf; }
+                    } else {
+                        V3 L = normalize(refract(-V, H, m.eta));
+                        if (L.z < 0.0f) { Eval e = m.eval_refraction(V, L, v3s(1.0f)); if (e.pdf > 0.0f && !isnan_(e.bxdf.x) && !isinf_(e.bxdf.x)) val += e.bxdf.x / e.pdf; }
+                    }
+                    if (!isnan_(val) && !isinf_(val)) fin += val;
+                }
+            }
+            cell += fin / 20.0f;
+        }
+        out[ci] = cell / (float)passes;
+    }
+}
+
 }  // extern "C"

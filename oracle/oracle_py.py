@@ -50,8 +50,19 @@ def lib():
         L.orc_lut_reflect_cell.argtypes = [C.c_uint32] * 8
         L.orc_lut_refract_cell.restype = C.c_float
         L.orc_lut_refract_cell.argtypes = [C.c_uint32] * 6 + [C.c_int, C.c_uint32, C.c_uint32]
+        L.orc_lut_cells.restype = None
+        L.orc_lut_cells.argtypes = [C.c_uint32] * 6 + [C.c_void_p, C.c_uint32, C.c_void_p, C.c_int]
         _lib = L
     return _lib
+
+
+def lut_cells(kind, size, sample_count, time_ms, cells, threads=None):
+    """LookupTableCalculator::CalculateTable restated, for the listed cell indices (x + y*sx + z*sx*sy)."""
+    cells = np.ascontiguousarray(cells, np.uint32)
+    out = np.zeros(len(cells), np.float32)
+    lib().orc_lut_cells(kind, size[0], size[1], size[2], sample_count, time_ms, cells.ctypes.data, len(cells), out.ctypes.data,
+                        threads or os.cpu_count() or 1)
+    return out
 
 
 class Oracle:

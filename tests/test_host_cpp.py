@@ -100,3 +100,17 @@ def test_render_through_the_cpp_facade_matches_the_oracle(cli, vpt, oracle, tmp_
     ref8, _ = oracle.postprocess(ref, vpt.default_post_params())
     body = open(ppm, "rb").read().split(b"\n255\n", 1)[1]
     assert np.array_equal(np.frombuffer(body, np.uint8).reshape(h, w, 3), ref8[..., :3])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which,kind,size", [("reflect", 0, (64, 64, 32)), ("refract-above", 1, (32, 32, 8)), ("refract-below", 2, (32, 32, 8))])
+def test_lookup_table_calculator_facade(cli, vpt, tmp_path, which, kind, size):
+    """LookupTableCalculator::New(shader, defines).CalculateTable(size, samples) through the CLI == vpt_lut_calculate."""
+    path = str(tmp_path / "t.bin")
+    out = json.loads(subprocess.check_output([cli, "--make-lut", which, "--lut-samples", "400", "--lut-time-seed", "9", "--lut-size", "%dx%dx%d" % size,
+                                              "--lut-out", path]))
+    assert out["size"] == list(size) and out["samples_per_cell"] == 400
+    got = np.fromfile(path, "<f4")
+    assert np.array_equal(got, vpt.calculate_lut(kind, size, 400, time_ms=9).reshape(-1))
+    p = subprocess.run([cli, "--make-lut", which, "--lut-samples", "5", "--lut-out", path], capture_output=True)
+    assert p.returncode == 1 and b"vpt_lut_calculate" in p.stderr

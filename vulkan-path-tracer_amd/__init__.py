@@ -49,6 +49,19 @@ def _check(lib, ctx, rc, what):
         raise VptError("%s failed: %s %s" % (what, _abi.ERR_NAMES.get(rc, rc), msg))
 
 
+LUT_REFLECT, LUT_REFRACT_ABOVE, LUT_REFRACT_BELOW = 0, 1, 2
+
+
+def calculate_lut(kind, size, sample_count, time_ms=0, device=0):
+    """LookupTableCalculator::CalculateTable (LookupTableCalculator.cpp:44) on the GPU: returns float32 [z, y, x].
+    kind: LUT_REFLECT (LookupReflect.slang), LUT_REFRACT_ABOVE / _BELOW (LookupRefract.slang + define)."""
+    lib = load_library()
+    sx, sy, sz = (int(v) for v in size)
+    out = np.zeros((sz, sy, sx), np.float32)
+    _check(lib, None, lib.vpt_lut_calculate(device, kind, sx, sy, sz, sample_count, time_ms, out.ctypes.data), "vpt_lut_calculate")
+    return out
+
+
 class PathTracer:
     """Mirror of the reference's PathTracer + PostProcessor call surface over the C-ABI."""
 

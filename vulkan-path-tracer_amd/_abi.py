@@ -150,6 +150,7 @@ PROTOTYPES = {
     "vpt_get_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
     "vpt_reset_stats": (C.c_int, [C.c_void_p]),
     "vpt_trace_rays": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
+    "vpt_lut_calculate": (C.c_int, [C.c_int] + [C.c_uint32] * 6 + [C.c_void_p]),
 }
 
 

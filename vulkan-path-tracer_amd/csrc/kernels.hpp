@@ -28,6 +28,10 @@ size_t stack_overflow_bytes(uint32_t blocks);  // per-thread spill region of the
 int traverse_blocks_per_cu(bool lds_scene, const DeviceScene& sc);
 int shade_blocks_per_cu();
 
+// lookup-table generator (kernels_lut.hip)
+void launch_lut(hipStream_t s, int kind, float* table, uint32_t sx, uint32_t sy, uint32_t sz, uint32_t sample_count, uint32_t time_hash,
+                uint32_t first_dispatch, uint32_t n_dispatches);
+
 // post-process chain (kernels_post.hip)
 void launch_bloom_threshold(hipStream_t s, const float* in, float* out, uint32_t w, uint32_t h, float threshold, float falloff);
 void launch_bloom_down(hipStream_t s, const float* in, uint32_t iw, uint32_t ih, float* out, uint32_t ow, uint32_t oh, float strength);

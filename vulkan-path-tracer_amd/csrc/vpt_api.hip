@@ -801,4 +801,28 @@ int vpt_trace_rays(vpt_ctx* c, const vpt_ray* rays, uint32_t n, vpt_hit* hits) {
     return rc;
 }
 
+int vpt_lut_calculate(int device, uint32_t kind, uint32_t sx, uint32_t sy, uint32_t sz, uint32_t sample_count, uint32_t time_ms, float* out) {
+    // sampleCount / 20 passes (LookupTableCalculator.cpp:97); fewer than one pass would divide the table by zero
+    if (!out || kind > VPT_LUT_REFRACT_BELOW || sx == 0 || sy == 0 || sz == 0 || (uint64_t)sx * sy * sz > (1u << 28) || sample_count < 20u)
+        return VPT_ERR_INVALID_ARGUMENT;
+    if (hipSetDevice(device) != hipSuccess) return VPT_ERR_DEVICE;
+    const size_t cells = (size_t)sx * sy * sz;
+    float* d = nullptr;
+    if (hipMalloc((void**)&d, cells * 4) != hipSuccess) return VPT_ERR_OUT_OF_MEMORY;
+    hipStream_t s = nullptr;
+    int rc = VPT_OK;
+    if (hipStreamCreate(&s) != hipSuccess || hipMemsetAsync(d, 0, cells * 4, s) != hipSuccess) rc = VPT_ERR_DEVICE;
+    const uint32_t passes = sample_count / 20u, time_hash = vptfp::pcg_hash(time_ms);
+    const uint32_t per_launch = 4096;  // bounds one launch to ~80k samples per cell
+    for (uint32_t first = 0; !rc && first < passes; first += per_launch) {
+        launch_lut(s, (int)kind, d, sx, sy, sz, sample_count, time_hash, first, std::min(per_launch, passes - first));
+        if (hipStreamSynchronize(s) != hipSuccess || hipGetLastError() != hipSuccess) rc = VPT_ERR_DEVICE;
+    }
+    if (!rc && hipMemcpy(out, d, cells * 4, hipMemcpyDeviceToHost) != hipSuccess) rc = VPT_ERR_DEVICE;
+    if (!rc) for (size_t i = 0; i < cells; i++) out[i] /= (float)passes;  // LookupTableCalculator.cpp:152-155
+    if (s) (void)hipStreamDestroy(s);
+    (void)hipFree(d);
+    return rc;
+}
+
 }  // extern "C"

@@ -2,6 +2,8 @@
 // load a glTF scene, run PathTrace() until the sample budget is spent, post-process, write the images.
 //   vpt_render --scene S.gltf --luts lookup_tables.bin [--size WxH] [--spp N] [--depth D] [--seed K] [--split S]
 //              [--env-constant r,g,b] [--radiance out.f32] [--camera out.f32] [--ppm out.ppm] [--info] [--dump-scene out.bin]
+//   vpt_render --make-lut reflect|refract-above|refract-below --lut-samples N [--lut-size XxYxZ] [--lut-time-seed T] --lut-out table.bin
+//              (Application.cpp:38-77: the three tables the reference regenerates with 10'000'000 samples)
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -12,6 +14,7 @@
 #include <string>
 
 #include "FlyCamera.h"
+#include "LookupTableCalculator.h"
 #include "PathTracer.h"
 #include "PostProcessor.h"
 
@@ -24,7 +27,8 @@ static void write_file(const std::string& path, const void* data, size_t bytes) 
 }
 
 int main(int argc, char** argv) {
-    std::string scene, luts, radiance, camera, ppm, dump;
+    std::string scene, luts, radiance, camera, ppm, dump, makeLut, lutOut;
+    uint32_t lutSamples = 10000000u, lutTime = 0; UVec3 lutSize{0, 0, 0};
     uint32_t w = 0, h = 0, spp = 16, depth = 8, seed = 1, split = 1;
     bool info = false, selftest = false; float env[3] = {0, 0, 0}; bool haveEnv = false;
     for (int i = 1; i < argc; i++) {
@@ -44,6 +48,11 @@ int main(int argc, char** argv) {
         else if (a == "--info") info = true;
         else if (a == "--selftest") selftest = true;
         else if (a == "--dump-scene") { dump = next(); info = true; }
+        else if (a == "--make-lut") makeLut = next();
+        else if (a == "--lut-samples") lutSamples = (uint32_t)strtoul(next().c_str(), nullptr, 10);
+        else if (a == "--lut-time-seed") lutTime = (uint32_t)strtoul(next().c_str(), nullptr, 10);
+        else if (a == "--lut-out") lutOut = next();
+        else if (a == "--lut-size") { std::string s = next(); if (sscanf(s.c_str(), "%ux%ux%u", &lutSize.x, &lutSize.y, &lutSize.z) != 3) { fprintf(stderr, "--lut-size XxYxZ\n"); return 2; } }
         else { fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
     }
     if (selftest) {  // host-side arithmetic only (no device): FlyCamera <-> matrices, Mat4 inverse
@@ -57,6 +66,25 @@ int main(int argc, char** argv) {
         printf("{\"view_err\": %.3g, \"proj_err\": %.3g, \"inverse_err\": %.3g, \"fov\": %.4f, \"aspect\": %.5f, \"up_dy\": %.4f}\n", ev, ep, ei, cam.GetFov(), cam.GetAspectRatio(),
                cam.GetPosition().y - (-2.0f));
         return (ev < 1e-4 && ep < 1e-5 && ei < 1e-5) ? 0 : 1;
+    }
+    if (!makeLut.empty()) {
+        try {
+            const bool reflect = makeLut == "reflect";
+            if (!reflect && makeLut != "refract-above" && makeLut != "refract-below") throw std::runtime_error("--make-lut reflect|refract-above|refract-below");
+            if (lutOut.empty()) throw std::runtime_error("--lut-out is required");
+            std::vector<ShaderDefine> defs;
+            if (!reflect) defs.push_back({makeLut == "refract-above" ? "ABOVE_SURFACE" : "BELOW_SURFACE", ""});
+            LookupTableCalculator calc = LookupTableCalculator::New(0, reflect ? "LookupReflect.slang" : "LookupRefract.slang", defs);
+            calc.SetTimeSeed(lutTime);
+            if (lutSize.x == 0) lutSize = reflect ? UVec3{64, 64, 32} : UVec3{128, 128, 32};  // Application.cpp:41,54,67
+            auto t0 = std::chrono::steady_clock::now();
+            std::vector<float> table = calc.CalculateTable(lutSize, lutSamples);
+            double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            write_file(lutOut, table.data(), table.size() * 4);
+            printf("{\"table\": \"%s\", \"size\": [%u, %u, %u], \"samples_per_cell\": %u, \"seconds\": %.3f, \"gsamples_per_s\": %.2f}\n", makeLut.c_str(), lutSize.x,
+                   lutSize.y, lutSize.z, lutSamples, sec, (double)table.size() * (lutSamples / 20u * 20u) / sec * 1e-9);
+            return 0;
+        } catch (const std::exception& e) { fprintf(stderr, "error: %s\n", e.what()); return 1; }
     }
     if (scene.empty()) { fprintf(stderr, "usage: vpt_render --scene S.gltf --luts lookup_tables.bin [--size WxH] [--spp N] [--depth D] ...\n"); return 2; }
     try {
