@@ -231,6 +231,35 @@ int vpt_set_scene(vpt_ctx* ctx, const vpt_scene_desc* scene);
  * if emission changed, resets accumulation. */
 int vpt_set_material(vpt_ctx* ctx, uint32_t index, const vpt_material* material);
 int vpt_get_material(const vpt_ctx* ctx, uint32_t index, vpt_material* out);
+/* ---- participating media: homogeneous box volumes ---------------------------------
+ * PathTracer::Volume / VolumeGPU (PathTracer.h:36-74, 341-400) as the shaders read it (Volume.slang:19-52).
+ * corner_min / corner_max are the WORLD-space box, i.e. Position + Corner * Scale already applied
+ * (PathTracer.h:395-396).  Heterogeneous (NanoVDB) density / temperature grids are not implemented:
+ * density_data_index must be -1.  The integrator side is RayGen.slang:162-380 (free-flight sampling per box,
+ * nearest scatter vs. distance to geometry, NEE towards sky and emissive meshes through every box's Beer-Lambert
+ * transmittance, phase-function scattering) and ClosestHit.slang:332-333,364 (volumes shadow surface NEE). */
+typedef struct vpt_volume {
+    float corner_min[3];
+    float corner_max[3];
+    float color[3];              /* single-scattering albedo */
+    float emissive_color[3];
+    float density;               /* extinction per unit length */
+    float anisotropy;            /* g of Henyey-Greenstein / Draine */
+    float alpha;                 /* Draine alpha */
+    float droplet_size;          /* HG+Draine fit parameter d (micrometres) */
+    int32_t density_data_index;  /* -1: homogeneous (the only supported value) */
+    int32_t approximated_scattering;          /* ApproximatedScatteringForClouds: g^(1+depth) */
+    float approximated_scattering_falloff;
+} vpt_volume;
+#define VPT_MAX_VOLUMES 32       /* the reference sorts into fixed float[100] / int[100] arrays (RayGen.slang:165-166) */
+#define VPT_PHASE_HENYEY_GREENSTEIN 0        /* PathTracer.h:76-81 PhaseFunction */
+#define VPT_PHASE_DRAINE 1
+#define VPT_PHASE_HENYEY_GREENSTEIN_PLUS_DRAINE 2
+/* AddVolume / RemoveVolume / SetVolume (PathTracer.h:157-159): the whole list is replaced; count 0 removes all
+ * volumes.  Resets accumulation. */
+int vpt_set_volumes(vpt_ctx* ctx, const vpt_volume* volumes, uint32_t count);
+/* SetPhaseFunction (PathTracer.h:106); default VPT_PHASE_HENYEY_GREENSTEIN (PathTracer.h:219).  Resets accumulation. */
+int vpt_set_phase_function(vpt_ctx* ctx, uint32_t phase_function);
 /* SetCameraViewInverse / SetCameraProjectionInverse. */
 int vpt_set_camera(vpt_ctx* ctx, const float view_inverse[16], const float projection_inverse[16]);
 /* All scalar setters + the #define toggles (PathTracer.cpp:1010-1015, 1623-1716). Resets accumulation. */

@@ -106,6 +106,8 @@ struct Oracle {
     uint32_t frame_count = 0, samples_accum = 0;
     bool brute_force = false;
     Counters ctr;
+    std::vector<vpt_volume> volumes;  // uVolumes (Volume.slang:9), homogeneous only
+    uint32_t phase = VPT_PHASE_HENYEY_GREENSTEIN;  // PHASE_FUNCTION_* define (PathTracer.h:219)
 };
 
 // ------------------------------------------------------------------ software samplers
@@ -271,6 +273,7 @@ struct Payload {
     bool in_medium;
     float medium_density, medium_anisotropy;
     V3 medium_color, medium_emissive;
+    uint32_t volume_depth;  // RTCommon.slang:34
 };
 
 float power_heuristics(float a, float b) {  // RTCommon.slang:124-127
@@ -598,6 +601,185 @@ void sample_emissive(const Oracle& o, Rng& r, V3 pos, V3& to_light, V4& cpdf, ui
     cpdf.x = m.emissive_color[0] * te.x; cpdf.y = m.emissive_color[1] * te.y; cpdf.z = m.emissive_color[2] * te.z;
 }
 
+// ------------------------------------------------------------------ Volumes (Volume.slang / RayGen.slang:162-380, homogeneous boxes)
+V3 sample_draine(Rng& r, V3 dir, float g, float a) {  // Sampler.slang:217-266
+    float r1 = r.uf(), r2 = r.uf();
+    float ct;
+    if (fabs_(g) < 1e-5f) {
+        ct = 2.0f * r1 - 1.0f;
+    } else if (fabs_(a) < 1e-5f) {
+        float sq = (1.0f - g * g) / (1.0f - g + 2.0f * g * r1);
+        ct = (1.0f + g * g - sq * sq) / (2.0f * g);
+    } else {
+        const float g2 = g * g, g3 = g * g2, g4 = g2 * g2, g6 = g2 * g4;
+        const float pgp1_2 = (1.0f + g2) * (1.0f + g2);
+        const float T1a = -a + a * g4;
+        const float T1a3 = T1a * T1a * T1a;
+        const float T2 = -1296.0f * (-1.0f + g2) * (a - a * g2) * (T1a) * (4.0f * g2 + a * pgp1_2);
+        const float T3 = 3.0f * g2 * (1.0f + g * (-1.0f + 2.0f * r1)) + a * (2.0f + g2 + g3 * (1.0f + 2.0f * g2) * (-1.0f + 2.0f * r1));
+        const float T4a = 432.0f * T1a3 + T2 + 432.0f * (a - a * g2) * T3 * T3;
+        const float T4b = -144.0f * a * g2 + 288.0f * a * g4 - 144.0f * a * g6;
+        const float T4b3 = T4b * T4b * T4b;
+        const float T4 = T4a + sqrt_(-4.0f * T4b3 + T4a * T4a);
+        const float T4p3 = pow_(T4, 1.0f / 3.0f);
+        const float T6 = (2.0f * T1a + (48.0f * pow_(2.0f, 1.0f / 3.0f) * (-(a * g2) + 2.0f * a * g4 - a * g6)) / T4p3 + T4p3 / (3.0f * pow_(2.0f, 1.0f / 3.0f))) / (a - a * g2);
+        const float T5 = 6.0f * (1.0f + g2) + T6;
+        ct = (1.0f + g2 - pow_(-0.5f * sqrt_(T5) + sqrt_(6.0f * (1.0f + g2) - (8.0f * T3) / (a * (-1.0f + g2) * sqrt_(T5)) - T6) / 2.0f, 2.0f)) / (2.0f * g);
+    }
+    float phi = 2.0f * M_PI_F * r2;
+    float st = sqrt_(1.0f - ct * ct);
+    float sp, cp; sincos_(phi, &sp, &cp);
+    V3 nd = v3(st * cp, st * sp, ct);
+    V3 up = fabs_(dir.y) < 0.9999999f ? v3(0, 1, 0) : v3(0, 0, 1);
+    V3 t = normalize(cross(up, dir));
+    V3 b = cross(dir, t);
+    return normalize((nd.x * t + nd.y * b) + nd.z * dir);
+}
+struct HgDraineFit { float ghg, gd, alpha_d, w_d; };
+HgDraineFit hg_draine_fit(float d) {  // Sampler.slang:271-274 == Volume.slang:397-400
+    HgDraineFit f;
+    f.ghg = exp_(-(0.0990567f / (d - 1.67154f)));
+    f.gd = exp_(-(2.20679f / (d + 3.91029f)) - 0.428934f);
+    f.alpha_d = exp_(3.62489f - (8.29288f / (d + 5.52825f)));
+    f.w_d = exp_(-(0.599085f / (d - 0.641583f)) - 0.665888f);
+    return f;
+}
+V3 sample_hg_plus_draine(Rng& r, V3 dir, float d, uint32_t depth) {  // Sampler.slang:268-284
+    HgDraineFit f = hg_draine_fit(d);
+    float ghg = pow_(max_(f.ghg, 0.0f), 1.0f + (float)depth);
+    float gd = pow_(max_(f.gd, 0.0f), 1.0f + (float)depth);
+    float u = r.uf();
+    if (u < f.w_d) return sample_hg(r, dir, ghg);
+    return sample_draine(r, dir, gd, f.alpha_d);
+}
+float phase_hg(V3 V, V3 L, float g) {  // RTCommon.slang:213-220
+    if (g == 0.0f) return 1.0f / (4.0f * M_PI_F);
+    float ct = dot(V, L);
+    return (1.0f / (4.0f * M_PI_F)) * ((1.0f - g * g) / pow_(1.0f + g * g - 2.0f * g * ct, 1.5f));
+}
+float phase_draine(V3 V, V3 L, float g, float a) {  // RTCommon.slang:222-227
+    float ct = dot(V, L);
+    return ((1.0f - g * g) * (1.0f + a * ct * ct)) / (4.0f * (1.0f + (a * (1.0f + 2.0f * g * g)) / 3.0f) * M_PI_F * pow_(1.0f + g * g - 2.0f * g * ct, 1.5f));
+}
+struct VolIsect { float tn, tf; };
+VolIsect ray_aabb(V3 org, V3 dir, const float* bmin, const float* bmax) {  // Volume.slang:183-207
+    V3 inv = v3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+    V3 t0 = (P3(bmin) - org) * inv, t1 = (P3(bmax) - org) * inv;
+    V3 ts = v3(min_(t0.x, t1.x), min_(t0.y, t1.y), min_(t0.z, t1.z));
+    V3 tb = v3(max_(t0.x, t1.x), max_(t0.y, t1.y), max_(t0.z, t1.z));
+    VolIsect r;
+    r.tn = max_(max_(ts.x, ts.y), max_(ts.x, ts.z));
+    r.tf = min_(min_(tb.x, tb.y), min_(tb.x, tb.z));
+    if (r.tf < 0.0f || r.tn > r.tf) { r.tn = -1.0f; r.tf = -1.0f; }
+    return r;
+}
+float effective_anisotropy(const vpt_volume& v, float depth) {  // Volume.slang:141-147
+    if (v.approximated_scattering != 0) {
+        float s = v.anisotropy > 0.0f ? 1.0f : (v.anisotropy < 0.0f ? -1.0f : 0.0f);
+        return pow_(fabs_(v.anisotropy), 1.0f + depth) * s;
+    }
+    return v.anisotropy;
+}
+V3 volume_scatter_direction(const Oracle& o, const vpt_volume& v, V3 dir, Rng& r, uint32_t depth) {  // Volume.slang:350-368
+    if (o.phase == VPT_PHASE_HENYEY_GREENSTEIN) return sample_hg(r, dir, effective_anisotropy(v, (float)depth));
+    if (o.phase == VPT_PHASE_DRAINE) return sample_draine(r, dir, effective_anisotropy(v, (float)depth), v.alpha);
+    return sample_hg_plus_draine(r, dir, v.droplet_size, depth);
+}
+float volume_phase(const Oracle& o, const vpt_volume& v, V3 V, V3 L, uint32_t depth) {  // Volume.slang:370-388, 395-406
+    if (o.phase == VPT_PHASE_HENYEY_GREENSTEIN) return phase_hg(V, L, effective_anisotropy(v, (float)depth));
+    if (o.phase == VPT_PHASE_DRAINE) return phase_draine(V, L, effective_anisotropy(v, (float)depth), v.alpha);
+    HgDraineFit f = hg_draine_fit(v.droplet_size);
+    return lerp(phase_hg(V, L, f.ghg), phase_draine(V, L, f.gd, f.alpha_d), f.w_d);
+}
+// Volume::CalculateVolumesTransmittance, Volume.slang:419-446 (homogeneous branch: Beer-Lambert per box)
+float volumes_transmittance(const Oracle& o, V3 org, V3 dir) {
+    float tr = 1.0f;
+    for (const vpt_volume& v : o.volumes) {
+        VolIsect is = ray_aabb(org, dir, v.corner_min, v.corner_max);
+        is.tn = max_(is.tn, 0.0f);
+        float len = is.tf - is.tn;
+        if (len > 0.0f) tr *= exp_(-v.density * len);
+    }
+    return clamp_(tr, 0.0f, 1.0f);
+}
+// Volume::DoesRayScatterInVolume, Volume.slang:261-297 (homogeneous branch)
+float does_ray_scatter(const vpt_volume& v, V3 org, V3 dir, Rng& r, float ignore_if_farther) {
+    VolIsect is = ray_aabb(org, dir, v.corner_min, v.corner_max);
+    if (is.tf < 0.0f) return -1.0f;
+    if (ignore_if_farther >= 0.0f && is.tn > ignore_if_farther) return -1.0f;
+    float inside = is.tf - max_(is.tn, 0.0f);
+    if (inside <= 0.0f) return -1.0f;
+    float sd = -log_(r.uf()) / v.density;  // Sampler.slang:425-428
+    if (sd < inside) return max_(is.tn, 0.0f) + sd;
+    return -1.0f;
+}
+void sample_emissive(const Oracle& o, Rng& r, V3 pos, V3& to_light, V4& cpdf, uint32_t& tri, uint32_t& inst);
+void importance_sample_env(const Oracle& o, Rng& r, V3& to_light, V4& out);
+// EvaluateVolumeScatteringEvent, RayGen.slang:265-380
+void volume_scatter_event(const Oracle& o, Payload& p, float sd, int vi, Counters* c) {
+    const vpt_volume& v = o.volumes[vi];
+    p.origin = p.origin + p.direction * sd;
+    p.emitted = P3(v.emissive_color);  // + GetEmissionFromTemperatureAtPoint == 0 without temperature data
+    V3 to_sky = v3s(0.0f); V4 sky; sky.x = sky.y = sky.z = sky.w = 0.0f;
+    if (o.P.flags & VPT_FLAG_SKY_MIS) {
+        importance_sample_env(o, p.rng, to_sky, sky);
+        sky.x *= o.P.sky_intensity; sky.y *= o.P.sky_intensity; sky.z *= o.P.sky_intensity;
+        uint32_t t0, t1;
+        if (does_ray_intersect(o, p.origin, to_sky, t0, t1, c)) sky.x = sky.y = sky.z = sky.w = 0.0f;
+    }
+    V3 to_light = v3s(0.0f); V4 lc; lc.x = lc.y = lc.z = lc.w = 0.0f;
+    if (o.P.flags & VPT_FLAG_MESH_MIS) {
+        uint32_t lt, li;
+        sample_emissive(o, p.rng, p.origin, to_light, lc, lt, li);
+        if (lc.w > 0.0f) {  // with pdf 0 the sample is discarded at :354 whatever the visibility test says
+            uint32_t ht, hi;
+            does_ray_intersect(o, p.origin, to_light, ht, hi, c);  // a miss reports (0, 0), which is compared like a hit (:296-299)
+            if (ht != lt || hi != li) lc.x = lc.y = lc.z = lc.w = 0.0f;
+        }
+    }
+    V3 nd = volume_scatter_direction(o, v, p.direction, p.rng, p.volume_depth);
+    float ph = volume_phase(o, v, p.direction, nd, p.volume_depth);
+    V3 sbxdf = P3(v.color) * ph;
+    if ((o.P.flags & VPT_FLAG_SKY_MIS) && sky.w > 0.0f) {
+        float ps = volume_phase(o, v, p.direction, to_sky, p.volume_depth);
+        V3 tr = v3s(volumes_transmittance(o, p.origin, to_sky));
+        V3 bx = P3(v.color) * ps;
+        if (ps > 0.0f) p.emitted = p.emitted + ((tr * bx) * (v3(sky.x, sky.y, sky.z) / sky.w)) * power_heuristics(sky.w, ps);
+    }
+    if ((o.P.flags & VPT_FLAG_MESH_MIS) && lc.w > 0.0f) {
+        float pl = volume_phase(o, v, p.direction, to_light, p.volume_depth);
+        V3 tr = v3s(volumes_transmittance(o, p.origin, to_light));
+        V3 bx = P3(v.color) * pl;
+        if (pl > 0.0f) p.emitted = p.emitted + ((tr * bx) * (v3(lc.x, lc.y, lc.z) / lc.w)) * power_heuristics(lc.w, pl);
+    }
+    p.direction = nd;
+    p.bxdf = sbxdf; p.pdf = ph;
+    p.depth++;
+    p.volume_depth++;
+}
+// ScatteredInVolume, RayGen.slang:162-263 (no atmosphere)
+bool scattered_in_volume(const Oracle& o, Payload& p, Counters* c) {
+    const int n = (int)o.volumes.size();
+    float dist[VPT_MAX_VOLUMES]; int idx[VPT_MAX_VOLUMES];
+    for (int i = 0; i < n; i++) {
+        VolIsect is = ray_aabb(p.origin, p.direction, o.volumes[i].corner_min, o.volumes[i].corner_max);
+        dist[i] = max_(0.0f, is.tn); idx[i] = i;
+    }
+    for (int i = 0; i < n; i++)
+        for (int j = i + 1; j < n; j++)
+            if (dist[j] < dist[i]) { std::swap(dist[i], dist[j]); std::swap(idx[i], idx[j]); }
+    float dgeo = -1.0f;  // GetDistanceToGeometry, RTCommon.slang:86-101: the payload direction as is
+    Hit h;
+    if (closest_hit(o, p.origin, p.direction, 0.00001f, 1000000.0f, h, c)) dgeo = h.t;
+    float sd = -1.0f; int sv = -1;
+    for (int i = 0; i < n; i++) {
+        float t = does_ray_scatter(o.volumes[idx[i]], p.origin, p.direction, p.rng, sd);
+        if (t >= 0.0f && (t < sd || sd < 0.0f)) { sd = t; sv = idx[i]; }
+    }
+    if (sd >= 0.0f && (dgeo < 0.0f || sd < dgeo)) { volume_scatter_event(o, p, sd, sv, c); return true; }
+    return false;
+}
+
 // ------------------------------------------------------------------ SampleBSDF (Material.slang:94-165)
 struct BSample { V3 L, bxdf; float pdf; };
 BSample sample_bsdf(const Mat& m, Rng& r, V3 V, V3 H) {
@@ -734,11 +916,16 @@ void closest_hit_shader(const Oracle& o, Payload& p, V3 raydir, const Hit& hit, 
     p.direction = scatter_world;
     p.bxdf = bs.bxdf; p.pdf = bs.pdf;
     if (o.P.flags & VPT_FLAG_SKY_MIS) {  // 323-355
-        if (can_sky && sky.w > 0.0f && sky_e.pdf > 0.0f)
-            p.emitted = p.emitted + (sky_e.bxdf * v3(sky.x, sky.y, sky.z) / sky.w) * power_heuristics(sky.w, sky_e.pdf);
+        if (can_sky) {
+            V3 tr = v3s(volumes_transmittance(o, p.origin, to_sky));  // :332-333, from the NEW origin; 1 without volumes
+            if (sky.w > 0.0f && sky_e.pdf > 0.0f)
+                p.emitted = p.emitted + (sky_e.bxdf * tr * v3(sky.x, sky.y, sky.z) / sky.w) * power_heuristics(sky.w, sky_e.pdf);
+        }
     }
-    if ((o.P.flags & VPT_FLAG_MESH_MIS) && !is_light && can_light && lc.w > 0.0f && light_e.pdf > 0.0f)
-        p.emitted = p.emitted + (light_e.bxdf * v3(lc.x, lc.y, lc.z) / lc.w) * power_heuristics(lc.w, light_e.pdf);
+    if ((o.P.flags & VPT_FLAG_MESH_MIS) && !is_light && can_light && lc.w > 0.0f && light_e.pdf > 0.0f) {
+        V3 tr = v3s(volumes_transmittance(o, p.origin, to_light));  // :364
+        p.emitted = p.emitted + (light_e.bxdf * tr * v3(lc.x, lc.y, lc.z) / lc.w) * power_heuristics(lc.w, light_e.pdf);
+    }
     bool invalid = bs.pdf <= 0.0f;
     p.depth = invalid ? (MAX_DEPTH_C + p.depth) : (p.depth + 1);
 }
@@ -777,15 +964,18 @@ void raygen_pixel(Oracle& o, uint32_t lx, uint32_t ly, uint32_t frame_count, uin
         direction = normalize(focus - origin);
 
         p.depth = 0; p.origin = origin; p.direction = direction; p.bxdf = v3s(1.0f); p.pdf = 1.0f;
-        p.emitted = v3s(0.0f); p.in_medium = false;
+        p.emitted = v3s(0.0f); p.in_medium = false; p.volume_depth = 0;
         p.medium_density = 0.0f; p.medium_anisotropy = 0.0f; p.medium_color = v3s(0.0f); p.medium_emissive = v3s(0.0f);
         V3 thr = v3s(1.0f), light = v3s(0.0f);
         for (; p.depth < o.P.max_depth;) {
             V3 rd = normalize(p.direction);
             p.emitted = v3s(0.0f);
             Hit h;
-            c.closest++;
-            if (closest_hit(o, p.origin, rd, 0.01f, 100000.0f, h, &c)) closest_hit_shader(o, p, rd, h, &c);
+            c.closest++;  // one per loop iteration (the GPU counts path-bounces)
+            // RayGen.slang:86-90; without volumes ScatteredInVolume only makes the unused distance query (a9: dropped)
+            bool scattered = !o.volumes.empty() && scattered_in_volume(o, p, &c);
+            if (scattered) {}
+            else if (closest_hit(o, p.origin, rd, 0.01f, 100000.0f, h, &c)) closest_hit_shader(o, p, rd, h, &c);
             else miss_shader(o, p);
             V3 contrib = p.emitted * thr;
             if (p.depth != 1) {
@@ -963,6 +1153,14 @@ void orc_set_camera(void* h, const float* vi, const float* pi) { Oracle* o = (Or
 void orc_reset(void* h) { Oracle* o = (Oracle*)h; o->frame_count = 0; o->dispatch_count = 0; o->samples_accum = 0; }
 void orc_set_params(void* h, const vpt_params* p) { Oracle* o = (Oracle*)h; o->P = *p; orc_reset(h); }
 void orc_set_material(void* h, uint32_t idx, const vpt_material* m) { Oracle* o = (Oracle*)h; o->materials[idx] = *m; build_emissive(*o); orc_reset(h); }
+int orc_set_volumes(void* h, const vpt_volume* v, uint32_t n) {
+    Oracle* o = (Oracle*)h;
+    if (n > VPT_MAX_VOLUMES) return -1;
+    for (uint32_t i = 0; i < n; i++) if (v[i].density_data_index != -1) return -1;
+    o->volumes.assign(v, v + n); orc_reset(h);
+    return 0;
+}
+void orc_set_phase_function(void* h, uint32_t phase) { Oracle* o = (Oracle*)h; o->phase = phase; orc_reset(h); }
 void orc_set_brute_force(void* h, int on) { ((Oracle*)h)->brute_force = on != 0; }
 
 // PathTracer::PathTrace x dispatches (PathTracer.cpp:122-156) with Seed = PCGHash(base_seed + dispatch).

@@ -32,6 +32,9 @@ def lib():
         L.orc_set_params.argtypes = [C.c_void_p, C.POINTER(_abi.Params)]
         L.orc_set_material.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(_abi.Material)]
         L.orc_set_brute_force.argtypes = [C.c_void_p, C.c_int]
+        L.orc_set_volumes.restype = C.c_int
+        L.orc_set_volumes.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+        L.orc_set_phase_function.argtypes = [C.c_void_p, C.c_uint32]
         L.orc_render.restype = C.c_int
         L.orc_render.argtypes = [C.c_void_p, C.c_uint32, C.c_int]
         L.orc_get_radiance.argtypes = [C.c_void_p, C.c_void_p]
@@ -97,6 +100,14 @@ class Oracle:
 
     def set_material(self, idx, mat):
         self.L.orc_set_material(self.h_, idx, C.byref(mat))
+
+    def set_volumes(self, volumes):
+        arr = (_abi.Volume * max(len(volumes), 1))(*volumes)
+        if self.L.orc_set_volumes(self.h_, arr, len(volumes)) != 0:
+            raise ValueError("orc_set_volumes: too many volumes or heterogeneous volume")
+
+    def set_phase_function(self, phase):
+        self.L.orc_set_phase_function(self.h_, phase)
 
     def set_brute_force(self, on):
         self.L.orc_set_brute_force(self.h_, int(on))

@@ -114,3 +114,25 @@ def test_lookup_table_calculator_facade(cli, vpt, tmp_path, which, kind, size):
     assert np.array_equal(got, vpt.calculate_lut(kind, size, 400, time_ms=9).reshape(-1))
     p = subprocess.run([cli, "--make-lut", which, "--lut-samples", "5", "--lut-out", path], capture_output=True)
     assert p.returncode == 1 and b"vpt_lut_calculate" in p.stderr
+
+
+@pytest.mark.gpu
+def test_volumes_through_the_cpp_facade(cli, vpt, oracle, tmp_path):
+    """AddVolume / SetPhaseFunction on the facade == vpt_set_volumes / vpt_set_phase_function == the oracle."""
+    gltf = os.path.join(GOLDEN, "cornell_box.gltf")
+    rad, cam = str(tmp_path / "r.f32"), str(tmp_path / "c.f32")
+    w, h, spp, depth = 128, 72, 3, 6
+    subprocess.check_output([cli, "--scene", gltf, "--luts", LUTS, "--size", "%dx%d" % (w, h), "--spp", str(spp), "--depth", str(depth), "--radiance", rad,
+                             "--camera", cam, "--volume", "-5,-10.5,-5,5,-0.5,5,0.15,0.4,0.9,0.8,0.7", "--volume", "-1,-4,-1,1,-2,1,2.0,-0.3,0.2,0.3,0.4",
+                             "--phase", "draine"])
+    img = np.fromfile(rad, "<f4").reshape(h, w, 4)
+    m = np.fromfile(cam, "<f4").reshape(2, 4, 4)
+    o = oracle.Oracle(vpt.scenes.load_gltf(gltf), w, h)
+    o.set_camera(m[0].T, m[1].T)
+    o.set_params(vpt.default_params(max_depth=depth, base_seed=1, max_samples=spp))
+    o.set_volumes([vpt.volume(corner_min=(-5, -10.5, -5), corner_max=(5, -0.5, 5), density=0.15, anisotropy=0.4, color=(0.9, 0.8, 0.7)),
+                   vpt.volume(corner_min=(-1, -4, -1), corner_max=(1, -2, 1), density=2.0, anisotropy=-0.3, color=(0.2, 0.3, 0.4))])
+    o.set_phase_function(vpt.PHASE_DRAINE)
+    o.render(spp)
+    ref = o.radiance(); o.close()
+    assert np.array_equal(img, ref)

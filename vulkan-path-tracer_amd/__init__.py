@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 from . import _abi, scenes  # noqa: F401
-from ._abi import default_params, default_post_params  # noqa: F401
+from ._abi import default_params, default_post_params, volume  # noqa: F401
+from ._abi import PHASE_HENYEY_GREENSTEIN, PHASE_DRAINE, PHASE_HENYEY_GREENSTEIN_PLUS_DRAINE  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
@@ -100,6 +101,14 @@ class PathTracer:
 
     def set_params(self, params):
         _check(self.lib, self.ctx, self.lib.vpt_set_params(self.ctx, C.byref(params)), "vpt_set_params")
+
+    def set_volumes(self, volumes):
+        """AddVolume / RemoveVolume / SetVolume (PathTracer.h:157-159): replaces the whole list."""
+        arr = (_abi.Volume * max(len(volumes), 1))(*volumes)
+        _check(self.lib, self.ctx, self.lib.vpt_set_volumes(self.ctx, arr, len(volumes)), "vpt_set_volumes")
+
+    def set_phase_function(self, phase):
+        _check(self.lib, self.ctx, self.lib.vpt_set_phase_function(self.ctx, phase), "vpt_set_phase_function")
 
     def set_material(self, index, mat):
         _check(self.lib, self.ctx, self.lib.vpt_set_material(self.ctx, index, C.byref(mat)), "vpt_set_material")

@@ -38,6 +38,29 @@ class Material(C.Structure):
 assert C.sizeof(Material) == 112
 
 
+class Volume(C.Structure):  # vpt_volume
+    _fields_ = [
+        ("corner_min", C.c_float * 3), ("corner_max", C.c_float * 3), ("color", C.c_float * 3), ("emissive_color", C.c_float * 3),
+        ("density", C.c_float), ("anisotropy", C.c_float), ("alpha", C.c_float), ("droplet_size", C.c_float),
+        ("density_data_index", C.c_int32), ("approximated_scattering", C.c_int32), ("approximated_scattering_falloff", C.c_float),
+    ]
+
+
+assert C.sizeof(Volume) == 76
+PHASE_HENYEY_GREENSTEIN, PHASE_DRAINE, PHASE_HENYEY_GREENSTEIN_PLUS_DRAINE = 0, 1, 2
+
+
+def volume(corner_min=(-1, -1, -1), corner_max=(1, 1, 1), color=(0.8, 0.8, 0.8), emissive_color=(0, 0, 0), density=1.0, anisotropy=0.0,
+           alpha=1.0, droplet_size=20.0, approximated_scattering=0, approximated_scattering_falloff=0.8):
+    """PathTracer::Volume defaults (PathTracer.h:36-74); corners are world space (Position + Corner * Scale applied)."""
+    v = Volume()
+    v.corner_min[:] = corner_min; v.corner_max[:] = corner_max; v.color[:] = color; v.emissive_color[:] = emissive_color
+    v.density, v.anisotropy, v.alpha, v.droplet_size = density, anisotropy, alpha, droplet_size
+    v.density_data_index = -1
+    v.approximated_scattering, v.approximated_scattering_falloff = approximated_scattering, approximated_scattering_falloff
+    return v
+
+
 class Mesh(C.Structure):
     _fields_ = [("vertices", C.c_void_p), ("vertex_count", C.c_uint32), ("indices", C.c_void_p),
                 ("index_count", C.c_uint32)]
@@ -134,6 +157,8 @@ PROTOTYPES = {
     "vpt_set_material": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(Material)]),
     "vpt_get_material": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(Material)]),
     "vpt_set_camera": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "vpt_set_volumes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32]),
+    "vpt_set_phase_function": (C.c_int, [C.c_void_p, C.c_uint32]),
     "vpt_set_params": (C.c_int, [C.c_void_p, C.POINTER(Params)]),
     "vpt_default_params": (None, [C.POINTER(Params)]),
     "vpt_default_post_params": (None, [C.POINTER(PostParams)]),

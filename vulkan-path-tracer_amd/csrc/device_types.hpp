@@ -119,6 +119,8 @@ struct DeviceScene {
     const uint32_t* emissive_tri_offset;    // per emissive mesh: first entry in emissive_tri
     const uint32_t* tri_slot_of_gid;        // per global triangle id: position in the leaf-ordered triangle array
     uint32_t* stack_overflow;               // traversal stack entries beyond the LDS part, kStackOverflow per resident thread
+    const vpt_volume* volumes;              // uVolumes (Volume.slang:9); volume_count == 0: none
+    uint32_t volume_count, phase;           // PHASE_FUNCTION_* (PathTracer.h:76-81)
 };
 
 struct RenderParams {
@@ -158,6 +160,7 @@ struct PathState {
     float4* M;       // medium colour.rgb | density (only glass)               shade RW when refracting
     float* maniso;   // medium anisotropy
     uint32_t* sidx;  // sample index within the frame (samples_per_frame > 1 only)
+    uint32_t* vdepth;  // payload.VolumeDepth (only touched while volumes are set)
 };
 
 // connect flags (CE.w)

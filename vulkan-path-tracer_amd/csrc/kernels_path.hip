@@ -12,6 +12,7 @@
 // A "wave" is 64 lanes; compaction uses one 64-bit ballot + mbcnt prefix and a single atomic per wave.
 #include "kernels.hpp"
 #include "shading.hpp"
+#include "volume.hpp"
 #include "traverse.hpp"
 
 namespace vpt {
@@ -192,10 +193,14 @@ struct ShadeIn {
     float prev_pdf;     // payload.PDF of the previous bounce
     float4 h;           // hit record t,u,v | PrimitiveIndex (t < 0: miss)
     uint32_t inst;      // InstanceIndex
+    int vol_index;      // >= 0: the path scattered in this box before reaching the geometry (volumes only)
+    float vol_t;        //       at this distance along payload.Direction
+    uint32_t vdepth;    // payload.VolumeDepth
 };
 struct ShadeOut {
     bool alive, terminated, want_sky, want_light, in_medium;
-    uint32_t rng, new_depth, cflags, light_gid;
+    bool light_miss_ok;  // volume NEE compares a MISS as "hit (0, 0)" (RayGen.slang:296-299): visible if nothing is hit and the sample is triangle 0
+    uint32_t rng, new_depth, cflags, light_gid, vdepth;
     V3 new_o, new_d, thr;
     float new_pdf;
     V3 emitted, csky, clight, sky_o, sky_d, light_o, light_d;
@@ -203,9 +208,11 @@ struct ShadeOut {
 
 // The miss / closest-hit shader and the visibility-independent tail of the bounce loop for ONE path, on
 // values held in registers (the callers own every load/store of the path records).
+template <bool VOL>
 __device__ __forceinline__ void shade_core(const DeviceScene& sc, const RenderParams& P, const PathState& ps, uint32_t slot,
                                            const ShadeIn& in_, ShadeOut& out) {
-    bool alive = false, want_sky = false, want_light = false;
+    bool alive = false, want_sky = false, want_light = false, light_miss_ok = false;
+    uint32_t vdepth = VOL ? in_.vdepth : 0u;
     const float4 h = in_.h;
     Rng rng; rng.s = in_.rng;
     const V3 porg = in_.porg, pdir = in_.pdir;
@@ -219,7 +226,43 @@ __device__ __forceinline__ void shade_core(const DeviceScene& sc, const RenderPa
     V3 new_o = porg, new_d = pdir, bxdf = v3s(1.0f);
     float new_pdf = prev_pdf;
     uint32_t new_depth = depth;
-    if (h.x < 0.0f) {
+    if (VOL && in_.vol_index >= 0) {
+        // ---- EvaluateVolumeScatteringEvent, RayGen.slang:265-380 (no atmosphere, no temperature grid)
+        const vpt_volume& v = sc.volumes[in_.vol_index];
+        new_o = porg + pdir * in_.vol_t;
+        emitted = ld3(v.emissive_color);
+        V3 to_sky = v3s(0.0f); V4 sky = v4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (P.flags & VPT_FLAG_SKY_MIS) {
+            sample_env(sc, P, rng, to_sky, sky);
+            sky.x *= P.sky_intensity; sky.y *= P.sky_intensity; sky.z *= P.sky_intensity;
+        }
+        V3 to_light = v3s(0.0f); V4 lc = v4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (P.flags & VPT_FLAG_MESH_MIS) sample_emissive(sc, rng, new_o, to_light, lc, light_gid);
+        const V3 nd = volume_scatter_direction(sc.phase, v, pdir, rng, vdepth);
+        const float ph = volume_phase(sc.phase, v, pdir, nd, vdepth);
+        // NEE, speculative like the surface case: the shadow rays start AT the scatter point (no offset)
+        if ((P.flags & VPT_FLAG_SKY_MIS) && sky.w > 0.0f) {
+            float ps_ = volume_phase(sc.phase, v, pdir, to_sky, vdepth);
+            if (ps_ > 0.0f) {
+                V3 tr = v3s(volumes_transmittance(sc, new_o, to_sky));
+                csky = ((tr * (ld3(v.color) * ps_)) * (v3(sky.x, sky.y, sky.z) / sky.w)) * power_heuristics(sky.w, ps_);
+                want_sky = true; sky_o = new_o; sky_d = to_sky;
+            }
+        }
+        if ((P.flags & VPT_FLAG_MESH_MIS) && lc.w > 0.0f) {
+            float pl = volume_phase(sc.phase, v, pdir, to_light, vdepth);
+            if (pl > 0.0f) {
+                V3 tr = v3s(volumes_transmittance(sc, new_o, to_light));
+                clight = ((tr * (ld3(v.color) * pl)) * (v3(lc.x, lc.y, lc.z) / lc.w)) * power_heuristics(lc.w, pl);
+                want_light = true; light_o = new_o; light_d = to_light;
+                light_miss_ok = light_gid == 0u;
+            }
+        }
+        new_d = nd;
+        bxdf = ld3(v.color) * ph; new_pdf = ph;
+        new_depth = depth + 1u;
+        vdepth = vdepth + 1u;
+    } else if (h.x < 0.0f) {
         // ---- Miss.slang:8-77
         V4 cp = v4(0.0f, 0.0f, 0.0f, 1.0f);
         if (((P.flags & VPT_FLAG_SHOW_ENV_DIRECTLY) || depth > 0) && sc.env_black) {
@@ -333,9 +376,11 @@ __device__ __forceinline__ void shade_core(const DeviceScene& sc, const RenderPa
             }
             // NEE contributions, evaluated speculatively; the connect stage decides whether they count
             // (EvaluateBSDF draws no random numbers, so evaluating before the visibility test is equivalent)
+            new_o = s.pos + s.N * (was_refracted ? -1e-3f : 1e-3f);  // volumes shadow NEE from the NEW origin (:332-333, 364)
             if ((P.flags & VPT_FLAG_SKY_MIS) && sky.w > 0.0f) {
                 Eval e = bs.eval(V, s.world_to_tangent(to_sky), ec_r, ec_g, gv);
                 if (e.pdf > 0.0f) {
+                    if (VOL) e.f = e.f * v3s(volumes_transmittance(sc, new_o, to_sky));
                     csky = (e.f * v3(sky.x, sky.y, sky.z) / sky.w) * power_heuristics(sky.w, e.pdf);
                     want_sky = true; sky_o = s.pos + s.N * 1e-5f; sky_d = to_sky;
                 }
@@ -343,11 +388,11 @@ __device__ __forceinline__ void shade_core(const DeviceScene& sc, const RenderPa
             if ((P.flags & VPT_FLAG_MESH_MIS) && !is_light && lc.w > 0.0f) {
                 Eval e = bs.eval(V, s.world_to_tangent(to_light), ec_r, ec_g, gv);
                 if (e.pdf > 0.0f) {
+                    if (VOL) e.f = e.f * v3s(volumes_transmittance(sc, new_o, to_light));
                     clight = (e.f * v3(lc.x, lc.y, lc.z) / lc.w) * power_heuristics(lc.w, e.pdf);
                     want_light = true; light_o = s.pos + to_light * 1e-2f; light_d = to_light;
                 }
             }
-            new_o = s.pos + s.N * (was_refracted ? -1e-3f : 1e-3f);
             new_d = scatter_world;
             bxdf = se.f; new_pdf = se.pdf;
             new_depth = (se.pdf <= 0.0f) ? (kMaxDepthMarker + depth) : (depth + 1u);  // :374-376
@@ -369,7 +414,7 @@ __device__ __forceinline__ void shade_core(const DeviceScene& sc, const RenderPa
                 uint32_t x, y, f;
                 pixel_of_slot(P, slot, x, y, f);
                 camera_ray(P, rng, x, y, new_o, new_d);
-                thr = v3s(1.0f); new_pdf = 1.0f; new_depth = 0u; in_medium = false;
+                thr = v3s(1.0f); new_pdf = 1.0f; new_depth = 0u; in_medium = false; vdepth = 0u;
                 ps.sidx[slot] = sample;
                 alive = true;
             }
@@ -379,6 +424,7 @@ __device__ __forceinline__ void shade_core(const DeviceScene& sc, const RenderPa
     }
     out.alive = alive; out.terminated = terminated; out.want_sky = want_sky; out.want_light = want_light; out.in_medium = in_medium;
     out.rng = rng.s; out.new_depth = new_depth; out.cflags = cflags; out.light_gid = light_gid;
+    out.light_miss_ok = light_miss_ok; out.vdepth = vdepth;
     out.new_o = new_o; out.new_d = new_d; out.thr = thr; out.new_pdf = new_pdf;
     out.emitted = emitted; out.csky = csky; out.clight = clight;
     out.sky_o = sky_o; out.sky_d = sky_d; out.light_o = light_o; out.light_d = light_d;
@@ -395,8 +441,9 @@ __device__ __forceinline__ uint32_t shade_path(const DeviceScene& sc, const Rend
     uint32_t dw = __float_as_uint(b.w);
     in_.depth = dw & 0x7fffffffu; in_.in_medium = (dw >> 31) != 0u;
     in_.thr_prev = xyz(t); in_.prev_pdf = t.w;
+    in_.vol_index = -1; in_.vol_t = 0.0f; in_.vdepth = 0u;
     ShadeOut o;
-    shade_core(sc, P, ps, slot, in_, o);
+    shade_core<false>(sc, P, ps, slot, in_, o);
     if (o.alive) {
         ps.A[slot] = f4u(o.new_o, o.rng);
         ps.B[slot] = f4u(o.new_d, o.new_depth | (o.in_medium ? 0x80000000u : 0u));
@@ -495,7 +542,7 @@ __global__ __launch_bounds__(256, 3) void k_shade(DeviceScene sc, RenderParams P
 // The same kernel with FIRST = false runs every later bounce of scenes whose BVH rides in LDS (traversal is
 // then a handful of LDS reads, so a separate extend/connect stage would only move records through HBM):
 // it reads a queued path's records A, B, T, L, does the whole bounce, and writes them back for survivors.
-template <bool LDS_SCENE, bool COUNT, bool FIRST>
+template <bool LDS_SCENE, bool COUNT, bool FIRST, bool VOL>
 __global__ __launch_bounds__(kTraverseBlock, 3) void k_bounce(DeviceScene sc, RenderParams P, PathState ps, const uint32_t* queue,
                                                              uint32_t* queue_next, Counters* ctr, uint32_t parity, uint32_t n_slots,
                                                              uint32_t dispatch_base) {
@@ -535,6 +582,7 @@ __global__ __launch_bounds__(kTraverseBlock, 3) void k_bounce(DeviceScene sc, Re
                     Rng r; r.s = y + P.width * x + seed;                        // RayGen.slang:28
                     camera_ray(P, r, x, y, in_.porg, in_.pdir);
                     in_.rng = r.s; in_.depth = 0u; in_.in_medium = false; in_.thr_prev = v3s(1.0f); in_.prev_pdf = 1.0f;
+                    in_.vdepth = 0u;
                     if (P.samples_per_frame > 1) ps.sidx[slot] = 0u;
                 } else {
                     slot = queue[idx];
@@ -544,14 +592,24 @@ __global__ __launch_bounds__(kTraverseBlock, 3) void k_bounce(DeviceScene sc, Re
                     uint32_t dw = __float_as_uint(b.w);
                     in_.depth = dw & 0x7fffffffu; in_.in_medium = (dw >> 31) != 0u;
                     in_.thr_prev = xyz(t); in_.prev_pdf = t.w;
+                    in_.vdepth = VOL ? ps.vdepth[slot] : 0u;
                     light_prev = xyz(ps.L[slot]);
                 }
                 HitRec hr;
-                hit = trace_any<LDS_SCENE, COUNT>(sc, lds_nodes, lds_tris, in_.porg, normalize(in_.pdir), 0.01f, 100000.0f, stack, hr, st);
+                in_.vol_index = -1; in_.vol_t = 0.0f;
+                if (VOL) {  // ScatteredInVolume (RayGen.slang:86): GetDistanceToGeometry uses the payload direction as is,
+                            // TMin 1e-5, TMax 1e6 (RTCommon.slang:86-101)
+                    bool g = trace_any<LDS_SCENE, COUNT>(sc, lds_nodes, lds_tris, in_.porg, in_.pdir, 0.00001f, 1000000.0f, stack, hr, st);
+                    Rng vr; vr.s = in_.rng;
+                    in_.vol_index = scattered_in_volume(sc, in_.porg, in_.pdir, vr, g ? hr.t : -1.0f, in_.vol_t);
+                    in_.rng = vr.s;
+                }
+                if (!VOL || in_.vol_index < 0)
+                    hit = trace_any<LDS_SCENE, COUNT>(sc, lds_nodes, lds_tris, in_.porg, normalize(in_.pdir), 0.01f, 100000.0f, stack, hr, st);
                 in_.h = make_float4(hit ? hr.t : -1.0f, hr.u, hr.v, __uint_as_float(hr.prim));
                 in_.inst = hr.inst;
                 ShadeOut o;
-                shade_core(sc, P, ps, slot, in_, o);
+                shade_core<VOL>(sc, P, ps, slot, in_, o);
                 // connect, inline (RayGen.slang:92-102; FIRST: pathThroughput == 1, pathLight == 0)
                 V3 E = o.emitted;
                 if (o.want_sky) {
@@ -559,7 +617,9 @@ __global__ __launch_bounds__(kTraverseBlock, 3) void k_bounce(DeviceScene sc, Re
                     nrays++;
                 }
                 if (o.want_light) {
-                    if (light_visible<LDS_SCENE, COUNT>(sc, lds_nodes, lds_tris, o.light_o, o.light_d, o.light_gid, stack, sst)) E = E + o.clight;
+                    bool vis = light_visible<LDS_SCENE, COUNT>(sc, lds_nodes, lds_tris, o.light_o, o.light_d, o.light_gid, stack, sst);
+                    if (VOL && !vis && o.light_miss_ok) vis = sky_visible<LDS_SCENE, COUNT>(sc, lds_nodes, lds_tris, o.light_o, o.light_d, stack, sst);
+                    if (vis) E = E + o.clight;
                     nrays++;
                 }
                 V3 contrib = E * in_.thr_prev;
@@ -585,6 +645,7 @@ __global__ __launch_bounds__(kTraverseBlock, 3) void k_bounce(DeviceScene sc, Re
                     ps.B[slot] = f4u(o.new_d, o.new_depth | (o.in_medium ? 0x80000000u : 0u));
                     Tout[slot] = f4(o.thr, o.new_pdf);
                     ps.L[slot] = f4(light, 0.0f);
+                    if (VOL) ps.vdepth[slot] = o.vdepth;
                 }
             }
             s0 = (c == 0u) ? slot : s0; s1 = (c == 1u) ? slot : s1; s2 = (c == 2u) ? slot : s2; s3 = (c == 3u) ? slot : s3;
@@ -838,8 +899,12 @@ void launch_bounce(hipStream_t s, uint32_t blocks, bool lds_scene, bool count, b
                    uint32_t dispatch_base) {
     size_t lds = traverse_lds_bytes(sc, lds_scene);
     dim3 g(blocks), b(kTraverseBlock);
-#define VPT_LAUNCH_BOUNCE(L, C, F) hipLaunchKernelGGL((k_bounce<L, C, F>), g, b, lds, s, sc, P, ps, queue, queue_next, ctr, parity, n_slots, dispatch_base)
-    if (lds_scene) {
+#define VPT_LAUNCH_BOUNCE_V(L, C, F, V) hipLaunchKernelGGL((k_bounce<L, C, F, V>), g, b, lds, s, sc, P, ps, queue, queue_next, ctr, parity, n_slots, dispatch_base)
+#define VPT_LAUNCH_BOUNCE(L, C, F) VPT_LAUNCH_BOUNCE_V(L, C, F, false)
+    if (sc.volume_count > 0u) {  // the volume variants carry no traversal counters
+        if (lds_scene) { if (first) VPT_LAUNCH_BOUNCE_V(true, false, true, true); else VPT_LAUNCH_BOUNCE_V(true, false, false, true); }
+        else { if (first) VPT_LAUNCH_BOUNCE_V(false, false, true, true); else VPT_LAUNCH_BOUNCE_V(false, false, false, true); }
+    } else if (lds_scene) {
         if (count) { if (first) VPT_LAUNCH_BOUNCE(true, true, true); else VPT_LAUNCH_BOUNCE(true, true, false); }
         else { if (first) VPT_LAUNCH_BOUNCE(true, false, true); else VPT_LAUNCH_BOUNCE(true, false, false); }
     } else {
@@ -847,12 +912,13 @@ void launch_bounce(hipStream_t s, uint32_t blocks, bool lds_scene, bool count, b
         else { if (first) VPT_LAUNCH_BOUNCE(false, false, true); else VPT_LAUNCH_BOUNCE(false, false, false); }
     }
 #undef VPT_LAUNCH_BOUNCE
+#undef VPT_LAUNCH_BOUNCE_V
 }
 int bounce_blocks_per_cu(bool lds_scene, const DeviceScene& sc) {
     int nb = 0;
     size_t lds = traverse_lds_bytes(sc, lds_scene);
-    if (lds_scene) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_bounce<true, false, false>, kTraverseBlock, lds);
-    else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_bounce<false, false, false>, kTraverseBlock, lds);
+    if (lds_scene) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_bounce<true, false, false, false>, kTraverseBlock, lds);
+    else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_bounce<false, false, false, false>, kTraverseBlock, lds);
     return nb > 0 ? nb : 1;
 }
 void launch_raygen(hipStream_t s, const RenderParams& P, const PathState& ps, uint32_t* queue, uint32_t n_slots, uint32_t dispatch_base) {

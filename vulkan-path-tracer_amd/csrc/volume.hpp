@@ -1,0 +1,142 @@
+// volume.hpp — homogeneous box volumes on the device.
+// Reference semantics: Volume.slang:183-207 (ray/box), 141-147 (depth-dependent anisotropy), 261-297 (free-flight
+// sampling, homogeneous branch), 350-406 (phase functions), 419-446 (Beer-Lambert transmittance through every box);
+// Sampler.slang:168-284 (HG / Draine / HG+Draine sampling), RTCommon.slang:213-227 (phase pdfs).
+// Expression order is part of the parity contract (compiled with -ffp-contract=off, vpt_fp32.h math).
+#pragma once
+#include "shading.hpp"
+
+namespace vpt {
+
+__device__ inline V3 sample_draine(Rng& r, V3 dir, float g, float a) {  // Sampler.slang:217-266
+    float r1 = r.uf(), r2 = r.uf();
+    float ct;
+    if (fabs_(g) < 1e-5f) {
+        ct = 2.0f * r1 - 1.0f;
+    } else if (fabs_(a) < 1e-5f) {
+        float sq = (1.0f - g * g) / (1.0f - g + 2.0f * g * r1);
+        ct = (1.0f + g * g - sq * sq) / (2.0f * g);
+    } else {
+        const float g2 = g * g, g3 = g * g2, g4 = g2 * g2, g6 = g2 * g4;
+        const float pgp1_2 = (1.0f + g2) * (1.0f + g2);
+        const float T1a = -a + a * g4;
+        const float T1a3 = T1a * T1a * T1a;
+        const float T2 = -1296.0f * (-1.0f + g2) * (a - a * g2) * (T1a) * (4.0f * g2 + a * pgp1_2);
+        const float T3 = 3.0f * g2 * (1.0f + g * (-1.0f + 2.0f * r1)) + a * (2.0f + g2 + g3 * (1.0f + 2.0f * g2) * (-1.0f + 2.0f * r1));
+        const float T4a = 432.0f * T1a3 + T2 + 432.0f * (a - a * g2) * T3 * T3;
+        const float T4b = -144.0f * a * g2 + 288.0f * a * g4 - 144.0f * a * g6;
+        const float T4b3 = T4b * T4b * T4b;
+        const float T4 = T4a + sqrt_(-4.0f * T4b3 + T4a * T4a);
+        const float T4p3 = pow_(T4, 1.0f / 3.0f);
+        const float T6 = (2.0f * T1a + (48.0f * pow_(2.0f, 1.0f / 3.0f) * (-(a * g2) + 2.0f * a * g4 - a * g6)) / T4p3 + T4p3 / (3.0f * pow_(2.0f, 1.0f / 3.0f))) / (a - a * g2);
+        const float T5 = 6.0f * (1.0f + g2) + T6;
+        ct = (1.0f + g2 - pow_(-0.5f * sqrt_(T5) + sqrt_(6.0f * (1.0f + g2) - (8.0f * T3) / (a * (-1.0f + g2) * sqrt_(T5)) - T6) / 2.0f, 2.0f)) / (2.0f * g);
+    }
+    float sp, cp; sincos_(2.0f * VPT_PI * r2, &sp, &cp);
+    float st = sqrt_(1.0f - ct * ct);
+    V3 nd = v3(st * cp, st * sp, ct);
+    V3 up = fabs_(dir.y) < 0.9999999f ? v3(0.0f, 1.0f, 0.0f) : v3(0.0f, 0.0f, 1.0f);
+    V3 t = normalize(cross(up, dir));
+    V3 b = cross(dir, t);
+    return normalize((nd.x * t + nd.y * b) + nd.z * dir);
+}
+struct HgDraineFit { float ghg, gd, alpha_d, w_d; };
+__device__ inline HgDraineFit hg_draine_fit(float d) {  // Sampler.slang:271-274 == Volume.slang:397-400
+    HgDraineFit f;
+    f.ghg = exp_(-(0.0990567f / (d - 1.67154f)));
+    f.gd = exp_(-(2.20679f / (d + 3.91029f)) - 0.428934f);
+    f.alpha_d = exp_(3.62489f - (8.29288f / (d + 5.52825f)));
+    f.w_d = exp_(-(0.599085f / (d - 0.641583f)) - 0.665888f);
+    return f;
+}
+__device__ inline float phase_hg(V3 V, V3 L, float g) {  // RTCommon.slang:213-220
+    if (g == 0.0f) return 1.0f / (4.0f * VPT_PI);
+    float ct = dot(V, L);
+    return (1.0f / (4.0f * VPT_PI)) * ((1.0f - g * g) / pow_(1.0f + g * g - 2.0f * g * ct, 1.5f));
+}
+__device__ inline float phase_draine(V3 V, V3 L, float g, float a) {  // RTCommon.slang:222-227
+    float ct = dot(V, L);
+    return ((1.0f - g * g) * (1.0f + a * ct * ct)) / (4.0f * (1.0f + (a * (1.0f + 2.0f * g * g)) / 3.0f) * VPT_PI * pow_(1.0f + g * g - 2.0f * g * ct, 1.5f));
+}
+struct VolIsect { float tn, tf; };
+__device__ inline VolIsect ray_aabb(V3 org, V3 dir, const float* bmin, const float* bmax) {  // Volume.slang:183-207
+    V3 inv = v3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+    V3 t0 = (ld3(bmin) - org) * inv, t1 = (ld3(bmax) - org) * inv;
+    V3 ts = v3(min_(t0.x, t1.x), min_(t0.y, t1.y), min_(t0.z, t1.z));
+    V3 tb = v3(max_(t0.x, t1.x), max_(t0.y, t1.y), max_(t0.z, t1.z));
+    VolIsect r;
+    r.tn = max_(max_(ts.x, ts.y), max_(ts.x, ts.z));
+    r.tf = min_(min_(tb.x, tb.y), min_(tb.x, tb.z));
+    if (r.tf < 0.0f || r.tn > r.tf) { r.tn = -1.0f; r.tf = -1.0f; }
+    return r;
+}
+__device__ inline float effective_anisotropy(const vpt_volume& v, float depth) {  // Volume.slang:141-147
+    if (v.approximated_scattering != 0) {
+        float s = v.anisotropy > 0.0f ? 1.0f : (v.anisotropy < 0.0f ? -1.0f : 0.0f);
+        return pow_(fabs_(v.anisotropy), 1.0f + depth) * s;
+    }
+    return v.anisotropy;
+}
+__device__ inline V3 volume_scatter_direction(uint32_t phase, const vpt_volume& v, V3 dir, Rng& r, uint32_t depth) {  // Volume.slang:350-368
+    if (phase == VPT_PHASE_HENYEY_GREENSTEIN) return sample_hg(r, dir, effective_anisotropy(v, (float)depth));
+    if (phase == VPT_PHASE_DRAINE) return sample_draine(r, dir, effective_anisotropy(v, (float)depth), v.alpha);
+    HgDraineFit f = hg_draine_fit(v.droplet_size);  // Sampler.slang:268-284
+    float ghg = pow_(max_(f.ghg, 0.0f), 1.0f + (float)depth);
+    float gd = pow_(max_(f.gd, 0.0f), 1.0f + (float)depth);
+    float u = r.uf();
+    if (u < f.w_d) return sample_hg(r, dir, ghg);
+    return sample_draine(r, dir, gd, f.alpha_d);
+}
+__device__ inline float volume_phase(uint32_t phase, const vpt_volume& v, V3 V, V3 L, uint32_t depth) {  // Volume.slang:370-406
+    if (phase == VPT_PHASE_HENYEY_GREENSTEIN) return phase_hg(V, L, effective_anisotropy(v, (float)depth));
+    if (phase == VPT_PHASE_DRAINE) return phase_draine(V, L, effective_anisotropy(v, (float)depth), v.alpha);
+    HgDraineFit f = hg_draine_fit(v.droplet_size);
+    return lerp(phase_hg(V, L, f.ghg), phase_draine(V, L, f.gd, f.alpha_d), f.w_d);
+}
+// Volume::CalculateVolumesTransmittance, Volume.slang:419-446 (homogeneous branch)
+__device__ inline float volumes_transmittance(const DeviceScene& sc, V3 org, V3 dir) {
+    float tr = 1.0f;
+    for (uint32_t i = 0; i < sc.volume_count; i++) {
+        const vpt_volume& v = sc.volumes[i];
+        VolIsect is = ray_aabb(org, dir, v.corner_min, v.corner_max);
+        is.tn = max_(is.tn, 0.0f);
+        float len = is.tf - is.tn;
+        if (len > 0.0f) tr *= exp_(-v.density * len);
+    }
+    return clamp_(tr, 0.0f, 1.0f);
+}
+// Volume::DoesRayScatterInVolume, Volume.slang:261-297 (homogeneous branch; one draw when the ray crosses the box)
+__device__ inline float does_ray_scatter(const vpt_volume& v, V3 org, V3 dir, Rng& r, float ignore_if_farther) {
+    VolIsect is = ray_aabb(org, dir, v.corner_min, v.corner_max);
+    if (is.tf < 0.0f) return -1.0f;
+    if (ignore_if_farther >= 0.0f && is.tn > ignore_if_farther) return -1.0f;
+    float inside = is.tf - max_(is.tn, 0.0f);
+    if (inside <= 0.0f) return -1.0f;
+    float sd = -log_(r.uf()) / v.density;  // Sampler.slang:425-428
+    if (sd < inside) return max_(is.tn, 0.0f) + sd;
+    return -1.0f;
+}
+// ScatteredInVolume, RayGen.slang:162-263 without the atmosphere: boxes in order of entry distance (the
+// reference's exchange sort, reproduced literally because ties are common and it is not stable), each crossed
+// box draws a free-flight distance, the nearest scatter wins if it lies before the geometry (`dgeo` =
+// GetDistanceToGeometry, < 0: none).  Returns the box index or -1; `sd` = scatter distance.
+__device__ inline int scattered_in_volume(const DeviceScene& sc, V3 org, V3 dir, Rng& r, float dgeo, float& sd) {
+    const int n = (int)sc.volume_count;
+    float dist[VPT_MAX_VOLUMES]; int idx[VPT_MAX_VOLUMES];
+    for (int i = 0; i < n; i++) {
+        VolIsect is = ray_aabb(org, dir, sc.volumes[i].corner_min, sc.volumes[i].corner_max);
+        dist[i] = max_(0.0f, is.tn); idx[i] = i;
+    }
+    for (int i = 0; i < n; i++)
+        for (int j = i + 1; j < n; j++)
+            if (dist[j] < dist[i]) { float td = dist[i]; int ti = idx[i]; dist[i] = dist[j]; idx[i] = idx[j]; dist[j] = td; idx[j] = ti; }
+    sd = -1.0f; int sv = -1;
+    for (int i = 0; i < n; i++) {
+        float t = does_ray_scatter(sc.volumes[idx[i]], org, dir, r, sd);
+        if (t >= 0.0f && (t < sd || sd < 0.0f)) { sd = t; sv = idx[i]; }
+    }
+    if (sd >= 0.0f && (dgeo < 0.0f || sd < dgeo)) return sv;
+    return -1;
+}
+
+}  // namespace vpt

@@ -52,6 +52,9 @@ struct vpt_ctx {
     // AUTO pipeline on a scene whose BVH does not fit LDS: the first four full batches are timed, staged and fused
     // alternating (both produce identical bits; the first of each also pays its kernels' one-time load), and the
     // pipeline with the smaller minimum is kept until the scene, size or params change.
+    std::vector<vpt_volume> volumes;       // homogeneous box volumes (vpt_set_volumes)
+    vpt_volume* d_volumes = nullptr;
+    uint32_t phase = VPT_PHASE_HENYEY_GREENSTEIN;
     int tune_state = 0;  // batches timed so far (even: staged next, odd: fused next); kTuneBatches = decided
     bool auto_fused = false;
     double tune_ms[2] = {1e30, 1e30};
@@ -145,8 +148,8 @@ int alloc_render_buffers(vpt_ctx* c) {
     uint64_t cap64 = (uint64_t)P.shard_pixels * F;
     if (cap64 >= (1ull << 31)) return fail(c, VPT_ERR_INVALID_ARGUMENT, "too many paths in flight");
     uint32_t cap = (uint32_t)cap64;
-    // 15 float4 records + 3 dword arrays per slot (device_types.hpp PathState)
-    const size_t kRecords = 15, kWords = 3;
+    // 15 float4 records + 4 dword arrays per slot (device_types.hpp PathState)
+    const size_t kRecords = 15, kWords = 4;
     size_t stride = ((size_t)cap + 63) & ~(size_t)63;
     HIPCHK(c, hipMalloc(&c->ps_block, stride * (16 * kRecords + 4 * kWords)));
     float4* rb = (float4*)c->ps_block;
@@ -159,7 +162,7 @@ int alloc_render_buffers(vpt_ctx* c) {
     s.L = next4(); s.ACC = next4(); s.M = next4();
     if (k != kRecords) return fail(c, VPT_ERR_DEVICE, "internal: path state carve mismatch");
     uint32_t* wb = (uint32_t*)(rb + stride * kRecords);
-    s.hinst = wb; s.maniso = (float*)(wb + stride); s.sidx = wb + stride * 2;
+    s.hinst = wb; s.maniso = (float*)(wb + stride); s.sidx = wb + stride * 2; s.vdepth = wb + stride * 3;
     for (int i = 0; i < 2; i++) HIPCHK(c, hipMalloc((void**)&c->queue[i], (size_t)cap * 4));
     HIPCHK(c, hipMalloc((void**)&c->cqueue, (size_t)cap * 4));
     HIPCHK(c, hipMalloc((void**)&c->image, (size_t)P.shard_pixels * 16));
@@ -299,7 +302,9 @@ int render_batch(vpt_ctx* c, uint32_t frames, uint32_t dispatch_base) {
     if (n_slots == 0) return VPT_OK;
     const bool count = c->cfg.count_traversal != 0;
     // fused (one kernel per bounce, bounce 0 included) when the BVH rides in LDS; staged otherwise
-    const bool fused = c->cfg.pipeline == VPT_PIPELINE_FUSED || (c->cfg.pipeline == VPT_PIPELINE_AUTO && (c->lds_scene || c->auto_fused));
+    // volumes are integrated in the fused per-bounce kernel only
+    const bool vol = !c->volumes.empty();
+    const bool fused = vol || c->cfg.pipeline == VPT_PIPELINE_FUSED || (c->cfg.pipeline == VPT_PIPELINE_AUTO && (c->lds_scene || c->auto_fused));
     Counters init{};
     if (!fused) init.ray_count[0] = n_slots;
     HIPCHK(c, hipMemcpyAsync(c->ctr, &init, 32, hipMemcpyHostToDevice, s));  // queue words only, stat_* keep running
@@ -428,6 +433,7 @@ void vpt_destroy(vpt_ctx* c) {
     free_render_buffers(c);
     if (c->ctr) (void)hipFree(c->ctr);
     if (c->d_launch_off) (void)hipFree(c->d_launch_off);
+    if (c->d_volumes) (void)hipFree(c->d_volumes);
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -627,6 +633,34 @@ int vpt_set_params(vpt_ctx* c, const vpt_params* p) {
         launch_precompute_materials(c->stream, c->dsc, c->params.flags, c->d_mat_resolved, (uint32_t)c->materials.size());
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
+    return VPT_OK;
+}
+
+int vpt_set_volumes(vpt_ctx* c, const vpt_volume* v, uint32_t count) {
+    if (!c || (count && !v)) return VPT_ERR_INVALID_ARGUMENT;
+    if (count > VPT_MAX_VOLUMES) return fail(c, VPT_ERR_LIMIT, "more than VPT_MAX_VOLUMES volumes");
+    if (count && c->cfg.pipeline == VPT_PIPELINE_STAGED) return fail(c, VPT_ERR_UNSUPPORTED, "volumes run on the fused pipeline (use VPT_PIPELINE_AUTO or _FUSED)");
+    for (uint32_t i = 0; i < count; i++) {
+        if (v[i].density_data_index != -1) return fail(c, VPT_ERR_UNSUPPORTED, "heterogeneous (NanoVDB) volumes are not implemented: density_data_index must be -1");
+        if (!(v[i].density > 0.0f)) return fail(c, VPT_ERR_INVALID_ARGUMENT, "volume density must be > 0");  // -log(u)/0 (Sampler.slang:427)
+    }
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->d_volumes) { (void)hipFree(c->d_volumes); c->d_volumes = nullptr; }
+    c->volumes.assign(v, v + count);
+    if (count) {
+        HIPCHK(c, hipMalloc((void**)&c->d_volumes, (size_t)count * sizeof(vpt_volume)));
+        HIPCHK(c, hipMemcpy(c->d_volumes, v, (size_t)count * sizeof(vpt_volume), hipMemcpyHostToDevice));
+    }
+    c->dsc.volumes = c->d_volumes; c->dsc.volume_count = count; c->dsc.phase = c->phase;
+    reset_accum(c);
+    return VPT_OK;
+}
+int vpt_set_phase_function(vpt_ctx* c, uint32_t phase) {
+    if (!c) return VPT_ERR_INVALID_ARGUMENT;
+    if (phase > VPT_PHASE_HENYEY_GREENSTEIN_PLUS_DRAINE) return fail(c, VPT_ERR_INVALID_ARGUMENT, "unknown phase function");
+    c->phase = phase; c->dsc.phase = phase;
+    reset_accum(c);
     return VPT_OK;
 }
 

@@ -75,7 +75,39 @@ void PathTracer::SetScene(const SceneAsset& sceneIn) {
     UploadScene();
     Check(vpt_set_params(m_Ctx, &m_Params), "vpt_set_params");
     Check(vpt_set_camera(m_Ctx, m_CameraViewInverse.m, m_CameraProjectionInverse.m), "vpt_set_camera");
+    UploadVolumes();
 }
+
+// VolumeGPU(const Volume&), PathTracer.h:374-399: the box goes to world space on upload.
+void PathTracer::UploadVolumes() {
+    if (!m_Ctx) return;
+    std::vector<vpt_volume> g;
+    for (const Volume& v : m_Volumes) {
+        vpt_volume o{};
+        const float mn[3] = {v.Position.x + v.CornerMin.x * v.Scale.x, v.Position.y + v.CornerMin.y * v.Scale.y, v.Position.z + v.CornerMin.z * v.Scale.z};
+        const float mx[3] = {v.Position.x + v.CornerMax.x * v.Scale.x, v.Position.y + v.CornerMax.y * v.Scale.y, v.Position.z + v.CornerMax.z * v.Scale.z};
+        std::memcpy(o.corner_min, mn, 12); std::memcpy(o.corner_max, mx, 12);
+        o.color[0] = v.Color.x; o.color[1] = v.Color.y; o.color[2] = v.Color.z;
+        o.emissive_color[0] = v.EmissiveColor.x; o.emissive_color[1] = v.EmissiveColor.y; o.emissive_color[2] = v.EmissiveColor.z;
+        o.density = v.Density; o.anisotropy = v.Anisotropy; o.alpha = v.Alpha; o.droplet_size = v.DropletSize;
+        o.density_data_index = -1;
+        o.approximated_scattering = v.ApproximatedScatteringForClouds; o.approximated_scattering_falloff = v.ApproximatedScatteringFalloff;
+        g.push_back(o);
+    }
+    Check(vpt_set_phase_function(m_Ctx, (uint32_t)m_PhaseFunction), "vpt_set_phase_function");
+    Check(vpt_set_volumes(m_Ctx, g.data(), (uint32_t)g.size()), "vpt_set_volumes");
+    m_SamplesAccumulated = 0; m_DispatchCount = 0;
+}
+void PathTracer::AddVolume(const Volume& volume) { m_Volumes.push_back(volume); UploadVolumes(); }
+void PathTracer::RemoveVolume(uint32_t index) {
+    if (index >= m_Volumes.size()) throw std::runtime_error("RemoveVolume: index out of range");
+    m_Volumes.erase(m_Volumes.begin() + index); UploadVolumes();
+}
+void PathTracer::SetVolume(uint32_t index, const Volume& volume) {
+    if (index >= m_Volumes.size()) throw std::runtime_error("SetVolume: index out of range");
+    m_Volumes[index] = volume; UploadVolumes();
+}
+void PathTracer::SetPhaseFunction(PhaseFunction phaseFunction) { m_PhaseFunction = phaseFunction; UploadVolumes(); }
 
 void PathTracer::UploadScene() {
     std::vector<vpt_mesh> meshes; std::vector<vpt_instance> inst; std::vector<vpt_texture> tex;

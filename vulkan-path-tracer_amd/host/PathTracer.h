@@ -5,7 +5,8 @@
 //   * GetOutputImage() hands back the RGBA32F accumulation image as host floats;
 //   * the seed is explicit (SetSeed): the reference draws it from the wall clock (PathTracer.cpp:127-140);
 //   * errors throw std::runtime_error where the reference VH_ASSERT-aborts.
-// Volumes and atmosphere members are absent: that half of the integrator is out of scope.
+// Homogeneous box volumes are in (AddVolume / SetVolume / RemoveVolume / SetPhaseFunction); NanoVDB density grids
+// (AddDensityDataToVolume) and the atmosphere members are absent.
 #pragma once
 #include <cstdint>
 #include <string>
@@ -20,6 +21,14 @@ namespace vpthost {
 class PathTracer {
 public:
     using Material = vpt_material;  // byte-identical to PathTracer::Material (PathTracer.h:12-34)
+    struct Volume {  // PathTracer.h:36-74 without the NanoVDB buffers
+        Vec3 CornerMin{-1.0f, -1.0f, -1.0f}, CornerMax{1.0f, 1.0f, 1.0f}, Position{0.0f, 0.0f, 0.0f}, Scale{1.0f, 1.0f, 1.0f};
+        Vec3 Color{0.8f, 0.8f, 0.8f}, EmissiveColor{0.0f, 0.0f, 0.0f};
+        float Density = 1.0f, Anisotropy = 0.0f, Alpha = 1.0f, DropletSize = 20.0f;
+        int ApproximatedScatteringForClouds = 0;
+        float ApproximatedScatteringFalloff = 0.8f;
+    };
+    enum class PhaseFunction { HENYEY_GREENSTEIN = 0, DRAINE = 1, HENYEY_GREENSTEIN_PLUS_DRAINE = 2 };  // PathTracer.h:76-81
 
     [[nodiscard]] static PathTracer New(int device = 0);
     PathTracer() = default;
@@ -54,6 +63,14 @@ public:
     void SetUseEnergyCompensation(bool value) { SetFlag(VPT_FLAG_ENERGY_COMPENSATION, value); }
     void SetFurnaceTestMode(bool value) { SetFlag(VPT_FLAG_FURNACE, value); }
     void SetUseRayQueries(bool value);
+    // PathTracer.h:106,157-159.  Volumes survive SetScene, like m_Volumes upstream.
+    void AddVolume(const Volume& volume);
+    void RemoveVolume(uint32_t index);
+    void SetVolume(uint32_t index, const Volume& volume);
+    void SetPhaseFunction(PhaseFunction phaseFunction);
+    [[nodiscard]] uint32_t GetVolumesCount() const { return (uint32_t)m_Volumes.size(); }
+    [[nodiscard]] const std::vector<Volume>& GetVolumes() const { return m_Volumes; }
+    [[nodiscard]] PhaseFunction GetPhaseFunction() const { return m_PhaseFunction; }
     void SetCameraViewInverse(const Mat4& view);
     void SetCameraProjectionInverse(const Mat4& projection);
     void SetMaxSamplesAccumulated(uint32_t v) { m_Params.max_samples = v; Push(false); }
@@ -104,6 +121,7 @@ private:
     void SetFlag(uint32_t bit, bool value);
     void Push(bool resets);
     void UploadScene();
+    void UploadVolumes();
 
     int m_Device = 0;
     vpt_ctx* m_Ctx = nullptr;
@@ -120,6 +138,8 @@ private:
     std::vector<float> m_LutR, m_LutO, m_LutI;
     std::string m_LookupTablePath;
     std::vector<float> m_Output;
+    std::vector<Volume> m_Volumes;
+    PhaseFunction m_PhaseFunction = PhaseFunction::HENYEY_GREENSTEIN;  // PathTracer.h:219
 };
 
 }  // namespace vpthost
