@@ -136,3 +136,65 @@ def test_volumes_through_the_cpp_facade(cli, vpt, oracle, tmp_path):
     o.render(spp)
     ref = o.radiance(); o.close()
     assert np.array_equal(img, ref)
+
+
+def test_hdr_reader_and_png_writer_agree_between_cpp_and_python(cli, vpt, tmp_path):
+    """the .hdr env-map reader (flat and RLE scanlines) and the PNG writer, C++ vs Python, byte for byte."""
+    rng = np.random.default_rng(4)
+    sky = vpt.scenes.sun_sky_env(96, 48, seed=9, sun_peak=3.0e4)[..., :3].copy()
+    sky[5:9, 10:40] = 0.0                       # exponent-0 texels and long runs
+    sky[20, :] = sky[20, 0]                      # a constant scanline: one run per component
+    sky[30:34] *= rng.uniform(1e-6, 1e3, (4, 96, 1)).astype(np.float32)
+    for rle in (True, False):
+        path = str(tmp_path / ("sky_%d.hdr" % rle))
+        vpt.imagefiles.save_hdr(path, sky, rle=rle)
+        py = vpt.imagefiles.load_hdr(path)
+        dump = str(tmp_path / "env.f32")
+        out = json.loads(subprocess.check_output([cli, "--env-hdr", path, "--dump-env", dump]))
+        assert (out["width"], out["height"]) == (96, 48)
+        cpp = np.fromfile(dump, "<f4").reshape(48, 96, 4)
+        assert np.array_equal(cpp, py)
+        # RGBE keeps 8 mantissa bits of the brightest channel
+        big = sky.max(axis=2) > 1e-30
+        assert np.all(np.abs(py[..., :3][big] - sky[big]) <= sky.max(axis=2)[big][:, None] / 128.0 + 1e-30)
+        assert np.all(py[..., 3] == 1.0)
+    narrow = str(tmp_path / "narrow.hdr")       # width < 8: flat scanlines even when RLE is asked for
+    vpt.imagefiles.save_hdr(narrow, sky[:3, :5], rle=True)
+    assert vpt.imagefiles.load_hdr(narrow).shape == (3, 5, 4)
+    p = subprocess.run([cli, "--env-hdr", os.path.join(GOLDEN, "cornell_box.gltf"), "--dump-env", str(tmp_path / "x")], capture_output=True)
+    assert p.returncode == 1 and b"not a Radiance HDR" in p.stderr
+    # PNG: C++ writer -> C++ reader (inside the CLI) and -> Python reader; Python writer -> same pixels
+    png = str(tmp_path / "t.png")
+    assert json.loads(subprocess.check_output([cli, "--png-roundtrip", png]))["png_roundtrip"] is True
+    a = vpt.imagefiles.load_png(png)
+    assert a.shape == (21, 37, 4)
+    png2 = str(tmp_path / "t2.png")
+    vpt.imagefiles.save_png(png2, a)
+    assert np.array_equal(vpt.imagefiles.load_png(png2), a)
+    for name in ("textured_boxes_base.png", "textured_boxes_rough.png"):
+        f = os.path.join(GOLDEN, name)
+        if os.path.exists(f):
+            assert vpt.imagefiles.load_png(f).shape[2] == 4
+
+
+@pytest.mark.gpu
+def test_hdr_env_and_png_export_through_the_cli(cli, vpt, oracle, tmp_path):
+    """SetEnvMapFilepath(.hdr) + Editor::SaveToFile(.png) end to end: radiance == oracle with the decoded env, PNG == oracle post."""
+    gltf = os.path.join(GOLDEN, "cornell_box.gltf")
+    hdr, rad, cam, png = (str(tmp_path / n) for n in ("sky.hdr", "r.f32", "c.f32", "o.png"))
+    vpt.imagefiles.save_hdr(hdr, vpt.scenes.sun_sky_env(64, 32, seed=2, sun_peak=500.0)[..., :3])
+    w, h, spp, depth = 96, 54, 3, 5
+    subprocess.check_output([cli, "--scene", gltf, "--luts", LUTS, "--size", "%dx%d" % (w, h), "--spp", str(spp), "--depth", str(depth), "--radiance", rad,
+                             "--camera", cam, "--env-hdr", hdr, "--png", png])
+    img = np.fromfile(rad, "<f4").reshape(h, w, 4)
+    m = np.fromfile(cam, "<f4").reshape(2, 4, 4)
+    sc = vpt.scenes.load_gltf(gltf)
+    sc.env = vpt.imagefiles.load_hdr(hdr)
+    o = oracle.Oracle(sc, w, h)
+    o.set_camera(m[0].T, m[1].T)
+    o.set_params(vpt.default_params(max_depth=depth, base_seed=1, max_samples=spp))
+    o.render(spp)
+    ref = o.radiance(); o.close()
+    assert np.array_equal(img, ref)
+    ref8, _ = oracle.postprocess(ref, vpt.default_post_params())
+    assert np.array_equal(vpt.imagefiles.load_png(png), ref8)

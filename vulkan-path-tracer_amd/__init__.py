@@ -9,7 +9,7 @@ import os
 
 import numpy as np
 
-from . import _abi, scenes  # noqa: F401
+from . import _abi, imagefiles, scenes  # noqa: F401
 from ._abi import default_params, default_post_params, volume  # noqa: F401
 from ._abi import PHASE_HENYEY_GREENSTEIN, PHASE_DRAINE, PHASE_HENYEY_GREENSTEIN_PLUS_DRAINE  # noqa: F401
 

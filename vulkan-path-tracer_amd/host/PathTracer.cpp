@@ -177,6 +177,12 @@ void PathTracer::SetEnvironmentMap(const std::vector<float>& rgba, uint32_t widt
     if (m_Ctx) { UploadScene(); Check(vpt_set_camera(m_Ctx, m_CameraViewInverse.m, m_CameraProjectionInverse.m), "vpt_set_camera"); }
     ResetPathTracing();
 }
+void PathTracer::SetEnvMapFilepath(const std::string& filePath) {  // PathTracer.cpp:1137-1164 (ImportTexture of an .hdr)
+    std::vector<float> rgba; uint32_t w = 0, h = 0; std::string err;
+    if (!LoadHDR(filePath, rgba, w, h, err)) throw std::runtime_error(err);
+    m_EnvMapFilepath = filePath;
+    SetEnvironmentMap(rgba, w, h);
+}
 void PathTracer::ResetPathTracing() { m_SamplesAccumulated = 0; m_DispatchCount = 0; if (m_Ctx) vpt_reset(m_Ctx); }
 
 }  // namespace vpthost

@@ -87,6 +87,8 @@ public:
     void SetSeed(uint32_t v) { m_Params.base_seed = v; Push(true); }
     // RGBA32F, width*height*4 floats (the reference loads a .hdr file: SetEnvMapFilepath, PathTracer.cpp:1137-1164)
     void SetEnvironmentMap(const std::vector<float>& rgba, uint32_t width, uint32_t height);
+    void SetEnvMapFilepath(const std::string& filePath);  // PathTracer.h:154: a Radiance .hdr file
+    [[nodiscard]] const std::string& GetEnvMapFilepath() const { return m_EnvMapFilepath; }
 
     [[nodiscard]] uint32_t GetSamplesAccumulated() const { return m_SamplesAccumulated; }
     [[nodiscard]] uint32_t GetSamplesPerFrame() const { return m_Params.samples_per_frame; }
@@ -137,6 +139,7 @@ private:
     std::vector<float> m_Env; uint32_t m_EnvW = 1, m_EnvH = 1;
     std::vector<float> m_LutR, m_LutO, m_LutI;
     std::string m_LookupTablePath;
+    std::string m_EnvMapFilepath;
     std::vector<float> m_Output;
     std::vector<Volume> m_Volumes;
     PhaseFunction m_PhaseFunction = PhaseFunction::HENYEY_GREENSTEIN;  // PathTracer.h:219

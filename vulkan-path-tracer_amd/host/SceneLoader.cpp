@@ -1,5 +1,6 @@
 // SceneLoader.cpp — minimal JSON + glTF 2.0 + PNG readers (see SceneLoader.h).
 #include "SceneLoader.h"
+#include <cmath>
 
 #include <zlib.h>
 
@@ -170,6 +171,86 @@ bool LoadPNG(const std::string& path, TextureAsset& out, std::string& error) {
         else { d[0] = s[0]; d[1] = s[1]; d[2] = s[2]; d[3] = s[3]; }
     }
     return true;
+}
+
+bool LoadHDR(const std::string& path, std::vector<float>& rgba, uint32_t& width, uint32_t& height, std::string& error) {
+    std::string f;
+    if (!read_file(path, f)) { error = "cannot open " + path; return false; }
+    size_t p = 0;
+    auto line = [&](std::string& out) { out.clear(); while (p < f.size() && f[p] != '\n') out.push_back(f[p++]); if (p < f.size()) p++; return true; };
+    std::string ln;
+    line(ln);
+    if (ln.rfind("#?RADIANCE", 0) != 0 && ln.rfind("#?RGBE", 0) != 0) { error = "not a Radiance HDR file: " + path; return false; }
+    bool fmt = false;
+    while (p < f.size()) { line(ln); if (ln.empty()) break; if (ln == "FORMAT=32-bit_rle_rgbe") fmt = true; }
+    if (!fmt) { error = "unsupported HDR format (need 32-bit_rle_rgbe): " + path; return false; }
+    line(ln);
+    int h = 0, w = 0;
+    if (sscanf(ln.c_str(), "-Y %d +X %d", &h, &w) != 2 || w <= 0 || h <= 0) { error = "unsupported HDR orientation (need -Y h +X w): " + path; return false; }
+    width = (uint32_t)w; height = (uint32_t)h;
+    rgba.assign((size_t)w * h * 4, 1.0f);
+    std::vector<uint8_t> scan((size_t)w * 4);
+    auto put = [&](int y) {
+        for (int x = 0; x < w; x++) {
+            const uint8_t* s = &scan[(size_t)x * 4]; float* d = &rgba[((size_t)y * w + x) * 4];
+            if (s[3] == 0) { d[0] = d[1] = d[2] = 0.0f; }
+            else { float sc = std::ldexp(1.0f, (int)s[3] - 136); d[0] = (float)s[0] * sc; d[1] = (float)s[1] * sc; d[2] = (float)s[2] * sc; }
+        }
+    };
+    for (int y = 0; y < h; y++) {
+        if (p + 4 > f.size()) { error = "truncated HDR: " + path; return false; }
+        const uint8_t b0 = (uint8_t)f[p], b1 = (uint8_t)f[p + 1], b2 = (uint8_t)f[p + 2], b3 = (uint8_t)f[p + 3];
+        if (w < 8 || w >= 32768 || b0 != 2 || b1 != 2 || (b2 & 0x80)) {  // flat scanline
+            if (p + (size_t)w * 4 > f.size()) { error = "truncated HDR: " + path; return false; }
+            std::memcpy(scan.data(), f.data() + p, (size_t)w * 4); p += (size_t)w * 4;
+        } else {  // new RLE: the four components of the scanline stored one after another
+            if ((((int)b2 << 8) | b3) != w) { error = "bad HDR scanline width: " + path; return false; }
+            p += 4;
+            for (int c = 0; c < 4; c++)
+                for (int x = 0; x < w;) {
+                    if (p >= f.size()) { error = "truncated HDR: " + path; return false; }
+                    int n = (uint8_t)f[p++];
+                    if (n > 128) {
+                        n -= 128;
+                        if (n == 0 || x + n > w || p >= f.size()) { error = "bad HDR run: " + path; return false; }
+                        uint8_t v = (uint8_t)f[p++];
+                        for (int k = 0; k < n; k++) scan[(size_t)(x++) * 4 + c] = v;
+                    } else {
+                        if (n == 0 || x + n > w || p + n > f.size()) { error = "bad HDR run: " + path; return false; }
+                        for (int k = 0; k < n; k++) scan[(size_t)(x++) * 4 + c] = (uint8_t)f[p++];
+                    }
+                }
+        }
+        put(y);
+    }
+    return true;
+}
+
+bool SavePNG(const std::string& path, const uint8_t* rgba, uint32_t w, uint32_t h, std::string& error) {
+    if (!rgba || w == 0 || h == 0) { error = "SavePNG: empty image"; return false; }
+    std::vector<uint8_t> raw(((size_t)w * 4 + 1) * h);
+    for (uint32_t y = 0; y < h; y++) { raw[((size_t)w * 4 + 1) * y] = 0; std::memcpy(&raw[((size_t)w * 4 + 1) * y + 1], rgba + (size_t)y * w * 4, (size_t)w * 4); }
+    uLongf cl = compressBound((uLong)raw.size());
+    std::vector<uint8_t> comp(cl);
+    if (compress2(comp.data(), &cl, raw.data(), (uLong)raw.size(), 6) != Z_OK) { error = "SavePNG: deflate failed"; return false; }
+    std::string out("\x89PNG\r\n\x1a\n", 8);
+    auto chunk = [&](const char* type, const uint8_t* d, uint32_t n) {
+        uint8_t len[4] = {(uint8_t)(n >> 24), (uint8_t)(n >> 16), (uint8_t)(n >> 8), (uint8_t)n};
+        out.append((const char*)len, 4);
+        std::string body(type, 4); body.append((const char*)d, n);
+        out += body;
+        uint32_t c = (uint32_t)crc32(0L, (const Bytef*)body.data(), (uInt)body.size());
+        uint8_t cb[4] = {(uint8_t)(c >> 24), (uint8_t)(c >> 16), (uint8_t)(c >> 8), (uint8_t)c};
+        out.append((const char*)cb, 4);
+    };
+    uint8_t ihdr[13] = {(uint8_t)(w >> 24), (uint8_t)(w >> 16), (uint8_t)(w >> 8), (uint8_t)w, (uint8_t)(h >> 24), (uint8_t)(h >> 16), (uint8_t)(h >> 8), (uint8_t)h, 8, 6, 0, 0, 0};
+    chunk("IHDR", ihdr, 13);
+    chunk("IDAT", comp.data(), (uint32_t)cl);
+    chunk("IEND", nullptr, 0);
+    std::ofstream o(path, std::ios::binary);
+    if (!o) { error = "cannot write " + path; return false; }
+    o.write(out.data(), (std::streamsize)out.size());
+    return (bool)o;
 }
 
 bool LoadLookupTables(const std::string& path, std::vector<float>& r, std::vector<float>& o, std::vector<float>& i, std::string& error) {

@@ -40,6 +40,12 @@ struct SceneAsset {
 // Returns false and fills `error` on failure (the reference aborts via VH_ASSERT, PathTracer.cpp:168).
 bool ImportScene(const std::string& gltfPath, SceneAsset& out, std::string& error);
 bool LoadPNG(const std::string& path, TextureAsset& out, std::string& error);  // 8-bit gray/RGB/RGBA, non-interlaced
+// Radiance .hdr (RGBE; flat or new-style RLE scanlines; "-Y h +X w" orientation) -> RGBA32F rows top to bottom, A = 1:
+// what ImportTexture hands LoadEnvironmentMap for the default env map (PathTracer.cpp:1137-1164, PathTracer.h:208).
+// value = mantissa * 2^(e - 136), 0 when e == 0 (the stb_image convention the reference's importer follows).
+bool LoadHDR(const std::string& path, std::vector<float>& rgba, uint32_t& width, uint32_t& height, std::string& error);
+// 8-bit RGBA PNG (Editor::SaveToFile -> stbi_write_png, Editor.cpp:815-843): filter 0 rows, one zlib stream.
+bool SavePNG(const std::string& path, const uint8_t* rgba, uint32_t width, uint32_t height, std::string& error);
 // Assets/LookupTables as one raw fp32 file (reflection 64x64x32, refraction outside/inside 128x128x32).
 bool LoadLookupTables(const std::string& path, std::vector<float>& reflection, std::vector<float>& outside, std::vector<float>& inside, std::string& error);
 

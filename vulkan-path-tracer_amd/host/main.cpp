@@ -2,6 +2,7 @@
 // load a glTF scene, run PathTrace() until the sample budget is spent, post-process, write the images.
 //   vpt_render --scene S.gltf --luts lookup_tables.bin [--size WxH] [--spp N] [--depth D] [--seed K] [--split S]
 //              [--env-constant r,g,b] [--radiance out.f32] [--camera out.f32] [--ppm out.ppm] [--info] [--dump-scene out.bin]
+//              [--env-hdr sky.hdr] [--png out.png]
 //              [--volume minx,miny,minz,maxx,maxy,maxz,density,g,r,g,b]... [--phase hg|draine|hg+draine]
 //   vpt_render --make-lut reflect|refract-above|refract-below --lut-samples N [--lut-size XxYxZ] [--lut-time-seed T] --lut-out table.bin
 //              (Application.cpp:38-77: the three tables the reference regenerates with 10'000'000 samples)
@@ -28,7 +29,7 @@ static void write_file(const std::string& path, const void* data, size_t bytes) 
 }
 
 int main(int argc, char** argv) {
-    std::string scene, luts, radiance, camera, ppm, dump, makeLut, lutOut;
+    std::string scene, luts, radiance, camera, ppm, png, envHdr, dumpEnv, pngTest, dump, makeLut, lutOut;
     std::vector<PathTracer::Volume> volumes; int phase = 0;
     uint32_t lutSamples = 10000000u, lutTime = 0; UVec3 lutSize{0, 0, 0};
     uint32_t w = 0, h = 0, spp = 16, depth = 8, seed = 1, split = 1;
@@ -47,6 +48,10 @@ int main(int argc, char** argv) {
         else if (a == "--radiance") radiance = next();
         else if (a == "--camera") camera = next();
         else if (a == "--ppm") ppm = next();
+        else if (a == "--png") png = next();                 // Editor::SaveToFile
+        else if (a == "--env-hdr") envHdr = next();          // SetEnvMapFilepath
+        else if (a == "--dump-env") dumpEnv = next();        // with --env-hdr: decoded RGBA32F (no device needed)
+        else if (a == "--png-roundtrip") pngTest = next();   // with --dump-env unused: writes a test pattern PNG and reads it back (no device needed)
         else if (a == "--info") info = true;
         else if (a == "--selftest") selftest = true;
         else if (a == "--dump-scene") { dump = next(); info = true; }
@@ -75,6 +80,28 @@ int main(int argc, char** argv) {
         printf("{\"view_err\": %.3g, \"proj_err\": %.3g, \"inverse_err\": %.3g, \"fov\": %.4f, \"aspect\": %.5f, \"up_dy\": %.4f}\n", ev, ep, ei, cam.GetFov(), cam.GetAspectRatio(),
                cam.GetPosition().y - (-2.0f));
         return (ev < 1e-4 && ep < 1e-5 && ei < 1e-5) ? 0 : 1;
+    }
+    if (!dumpEnv.empty() || !pngTest.empty()) {  // host-side file formats only
+        try {
+            std::string err;
+            if (!dumpEnv.empty()) {
+                std::vector<float> rgba; uint32_t ew = 0, eh = 0;
+                if (!LoadHDR(envHdr, rgba, ew, eh, err)) throw std::runtime_error(err);
+                write_file(dumpEnv, rgba.data(), rgba.size() * 4);
+                printf("{\"width\": %u, \"height\": %u}\n", ew, eh);
+            }
+            if (!pngTest.empty()) {
+                const uint32_t pw = 37, ph = 21;
+                std::vector<uint8_t> px((size_t)pw * ph * 4);
+                for (size_t i = 0; i < px.size(); i++) px[i] = (uint8_t)((i * 2654435761u) >> 13);
+                if (!SavePNG(pngTest, px.data(), pw, ph, err)) throw std::runtime_error(err);
+                TextureAsset back;
+                if (!LoadPNG(pngTest, back, err)) throw std::runtime_error(err);
+                if (back.Width != pw || back.Height != ph || back.Data != px) throw std::runtime_error("PNG round trip differs");
+                printf("{\"png_roundtrip\": true}\n");
+            }
+            return 0;
+        } catch (const std::exception& e) { fprintf(stderr, "error: %s\n", e.what()); return 1; }
     }
     if (!makeLut.empty()) {
         try {
@@ -126,6 +153,7 @@ int main(int argc, char** argv) {
         pt.SetLookupTablePath(luts);
         if (haveEnv) { std::vector<float> e(64 * 32 * 4, 0.0f); for (size_t i = 0; i < 64 * 32; i++) { e[i * 4] = env[0]; e[i * 4 + 1] = env[1]; e[i * 4 + 2] = env[2]; } pt.SetEnvironmentMap(e, 64, 32); }
         if (w && h) pt.ResizeImage(w, h);
+        if (!envHdr.empty()) pt.SetEnvMapFilepath(envHdr);
         pt.SetScene(scene);
         if (w && h) {  // the window was resized: Editor.cpp:203-211 rebuilds the projection from the new aspect ratio
             FlyCamera cam(inverse(pt.GetCameraViewInverse()), inverse(pt.GetCameraProjectionInverse()));
@@ -149,6 +177,10 @@ int main(int argc, char** argv) {
             std::string out = "P6\n" + std::to_string(pt.GetWidth()) + " " + std::to_string(pt.GetHeight()) + "\n255\n";
             for (size_t i = 0; i < (size_t)pt.GetWidth() * pt.GetHeight(); i++) out.append((const char*)&o[i * 4], 3);
             write_file(ppm, out.data(), out.size());
+        }
+        if (!png.empty()) {
+            std::string err;
+            if (!SavePNG(png, post.GetOutputImage().data(), pt.GetWidth(), pt.GetHeight(), err)) throw std::runtime_error(err);
         }
         printf("{\"width\": %u, \"height\": %u, \"samples\": %u, \"seconds\": %.4f, \"msamples_per_s\": %.2f, \"vertices\": %llu, \"indices\": %llu}\n", pt.GetWidth(), pt.GetHeight(),
                pt.GetSamplesAccumulated(), sec, (double)pt.GetWidth() * pt.GetHeight() * pt.GetSamplesAccumulated() / sec / 1e6,

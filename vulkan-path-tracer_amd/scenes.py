@@ -274,8 +274,8 @@ def load_gltf(path, image_loader=None):
         key = (img["uri"], single_channel)
         if key not in tex_cache:
             if image_loader is None:
-                from PIL import Image
-                arr = np.array(Image.open(os.path.join(base, img["uri"])).convert("RGBA"), np.uint8)
+                from . import imagefiles
+                arr = imagefiles.load_png(os.path.join(base, img["uri"]))
             else:
                 arr = image_loader(os.path.join(base, img["uri"]))
             if single_channel:  # LoadTexture(..., onlySingleChannel=true) keeps R (PathTracer.cpp:826-836)
