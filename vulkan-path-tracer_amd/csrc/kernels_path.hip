@@ -127,7 +127,7 @@ __device__ inline bool light_visible(const DeviceScene& sc, const float4* lds_no
 
 // ------------------------------------------------------------------ extend: closest hit of every queued path
 template <bool LDS_SCENE, bool COUNT>
-__global__ __launch_bounds__(kTraverseBlock) void k_extend(DeviceScene sc, PathState ps, const uint32_t* queue,
+__global__ __launch_bounds__(kTraverseBlock, 8) void k_extend(DeviceScene sc, PathState ps, const uint32_t* queue,
                                                           Counters* ctr, uint32_t parity) {
     extern __shared__ __align__(16) unsigned char smem[];
     const TravStack stack = make_stack(smem, sc.stack_overflow);
@@ -701,7 +701,7 @@ constexpr uint32_t kConnectScratch = kConnectTile * 4 + kConnectTile * 2 * 2 + k
 __device__ inline uint32_t connect_tile(uint32_t n) { return n >= (1u << 19) ? 512u : n >= (1u << 17) ? 256u : n >= (1u << 15) ? 128u : 64u; }
 
 template <bool LDS_SCENE, bool COUNT>
-__global__ __launch_bounds__(kTraverseBlock) void k_connect(DeviceScene sc, RenderParams P, PathState ps, const uint32_t* cqueue,
+__global__ __launch_bounds__(kTraverseBlock, 8) void k_connect(DeviceScene sc, RenderParams P, PathState ps, const uint32_t* cqueue,
                                                            Counters* ctr, uint32_t parity) {
     extern __shared__ __align__(16) unsigned char smem[];
     const TravStack stack = make_stack(smem, sc.stack_overflow);

@@ -17,8 +17,8 @@
 
 namespace vpt {
 
-constexpr int kStackDepth = 24;      // LDS entries per lane
-constexpr int kStackOverflow = 72;   // global entries per lane: 3 pushes per level x binary depth bound 30, minus the LDS part
+constexpr int kStackDepth = 14;      // LDS entries per lane
+constexpr int kStackOverflow = 82;   // global entries per lane: 3 pushes per level x binary depth bound 30, minus the LDS part
 constexpr int kTraverseBlock = 256;
 
 struct HitRec {
