@@ -8,6 +8,7 @@ HBM bytes follow MI355X_MICROARCH.md §HBM: FETCH_SIZE / WRITE_SIZE are in KiB, 
 import csv
 import json
 import os
+import re
 import shutil
 import sys
 from collections import defaultdict
@@ -18,11 +19,17 @@ G = os.path.join(ROOT, "gpurun_out")
 STAGES = ["primary", "bounce", "extend", "shade", "connect", "resolve", "bloom", "tonemap"]
 
 
+def template_args(name):
+    m = re.search(r"<([^>]*)>", name)
+    return [a.strip() for a in m.group(1).split(",")] if m else []
+
+
 def stage_of(name):
-    if "<true, true" in name or "<false, true" in name:
-        return None  # traversal-counting variants (short pre-pass of bench.py)
+    a = template_args(name)
+    if len(a) >= 2 and a[1] == "true":
+        return None  # traversal-counting variants (short pre-pass of bench.py): k_*<LDS, COUNT, ...>
     if "k_bounce" in name:
-        return "primary" if ", true>" in name else "bounce"  # k_bounce<LDS, COUNT, FIRST>
+        return "primary" if len(a) >= 3 and a[2] == "true" else "bounce"  # k_bounce<LDS, COUNT, FIRST, VOL>
     for s in STAGES:
         if "k_" + s in name:
             return s

@@ -2,6 +2,7 @@
 VALU busy = SQ_ACTIVE_INST_VALU (quad-cycles) * 4 / (1024 SIMDs * kernel cycles); kernel cycles = GRBM_GUI_ACTIVE / 8 XCDs."""
 import collections
 import csv
+import re
 import os
 import sys
 
@@ -11,11 +12,12 @@ acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
 for f in ("prof_sq/sq_counter_collection.csv", "prof_sq2/sq2_counter_collection.csv"):
     for r in csv.DictReader(open(os.path.join(ROOT, "gpurun_out", f))):
         k = r["Kernel_Name"]
-        if "<true, true" in k or "<false, true" in k:
+        a = [x.strip() for x in re.search(r"<([^>]*)>", k).group(1).split(",")] if "<" in k else []
+        if len(a) >= 2 and a[1] == "true":
             continue
         name = None
         if "k_bounce" in k:
-            name = "primary" if ", true>" in k else "bounce"
+            name = "primary" if len(a) >= 3 and a[2] == "true" else "bounce"
         else:
             for s in ("extend", "shade", "connect", "resolve", "raygen"):
                 if "k_" + s in k:
