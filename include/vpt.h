@@ -260,6 +260,26 @@ typedef struct vpt_volume {
 int vpt_set_volumes(vpt_ctx* ctx, const vpt_volume* volumes, uint32_t count);
 /* SetPhaseFunction (PathTracer.h:106); default VPT_PHASE_HENYEY_GREENSTEIN (PathTracer.h:219).  Resets accumulation. */
 int vpt_set_phase_function(vpt_ctx* ctx, uint32_t phase_function);
+/* ---- atmosphere ----------------------------------------------------------------------
+ * SetEnableAtmosphere + the planet / density setters (PathTracer.h:168-179; defaults :221-232; UBO fields
+ * :276-288).  With an atmosphere the sky is no environment map: rays that leave the scene return black
+ * (Miss.slang:11-14) and all sky light is in-scattered sunlight — delta-tracked scatter events on Rayleigh / Mie /
+ * ozone profiles (Atmosphere.slang:131-201, RayGen.slang:212-262,382-470), ONE colour channel per path once it has
+ * scattered (ColorChannel, RayGen.slang:120-129), sun-disk NEE (Sampler.slang:431-462; its direction comes from
+ * sky_azimuth / sky_altitude) through ratio-tracked transmittance (Atmosphere.slang:33-107).  Units are metres.
+ * Runs on the fused pipeline. */
+typedef struct vpt_atmosphere {
+    float planet_position[3];
+    float planet_radius;
+    float atmosphere_height;
+    float rayleigh_density_falloff, mie_density_falloff, ozone_density_falloff, ozone_peak;
+    float rayleigh_multiplier[3];   /* RayleighScatteringCoefficientMultiplier */
+    float mie_multiplier[3];        /* MieScatteringCoefficientMultiplier */
+    float ozone_multiplier[3];      /* OzoneAbsorptionCoefficientMultiplier */
+    float sun_color[3];
+} vpt_atmosphere;
+void vpt_default_atmosphere(vpt_atmosphere* out);                       /* PathTracer.h:222-232 */
+int vpt_set_atmosphere(vpt_ctx* ctx, const vpt_atmosphere* atmosphere); /* NULL: SetEnableAtmosphere(false). Resets accumulation. */
 /* SetCameraViewInverse / SetCameraProjectionInverse. */
 int vpt_set_camera(vpt_ctx* ctx, const float view_inverse[16], const float projection_inverse[16]);
 /* All scalar setters + the #define toggles (PathTracer.cpp:1010-1015, 1623-1716). Resets accumulation. */

@@ -107,6 +107,8 @@ struct Oracle {
     bool brute_force = false;
     Counters ctr;
     std::vector<vpt_volume> volumes;  // uVolumes (Volume.slang:9), homogeneous only
+    bool atm_on = false;              // ENABLE_ATMOSPHERE
+    vpt_atmosphere atm;
     uint32_t phase = VPT_PHASE_HENYEY_GREENSTEIN;  // PHASE_FUNCTION_* define (PathTracer.h:219)
 };
 
@@ -274,6 +276,7 @@ struct Payload {
     float medium_density, medium_anisotropy;
     V3 medium_color, medium_emissive;
     uint32_t volume_depth;  // RTCommon.slang:34
+    int color_channel;      // RTCommon.slang:31: -1 until the path scatters in the atmosphere
 };
 
 float power_heuristics(float a, float b) {  // RTCommon.slang:124-127
@@ -601,6 +604,146 @@ void sample_emissive(const Oracle& o, Rng& r, V3 pos, V3& to_light, V4& cpdf, ui
     cpdf.x = m.emissive_color[0] * te.x; cpdf.y = m.emissive_color[1] * te.y; cpdf.z = m.emissive_color[2] * te.z;
 }
 
+// ------------------------------------------------------------------ Atmosphere (Atmosphere.slang, Sampler.slang:431-462, RTCommon.slang:174-211)
+const float C_RAYLEIGH[3] = {5.802f * 1e-6f, 13.558f * 1e-6f, 33.100f * 1e-6f};  // Atmosphere.slang:7-11
+const float C_MIE_SCATTERING = 3.996f * 1e-6f, C_MIE_ABSORPTION = 4.40f * 1e-6f;
+const float C_MIE = C_MIE_SCATTERING + C_MIE_ABSORPTION;
+const float C_OZONE[3] = {0.650f * 1e-6f, 1.881f * 1e-6f, 0.085f * 1e-6f};
+V2 intersect_sphere(V3 org, V3 dir, V3 center, float radius) {  // RTCommon.slang:174-192
+    org = org - center;
+    float a = dot(dir, dir);
+    float b = 2.0f * dot(org, dir);
+    float c = dot(org, org) - radius * radius;
+    float disc = b * b - 4.0f * a * c;
+    V2 r;
+    if (disc < 0.0f) { r.x = -1.0f; r.y = -1.0f; return r; }
+    r.x = (-b - sqrt_(disc)) / (2.0f * a);
+    r.y = (-b + sqrt_(disc)) / (2.0f * a);
+    return r;
+}
+float rayleigh_phase(V3 V, V3 L) { float ct = dot(V, L); return (3.0f / (16.0f * M_PI_F)) * (1.0f + ct * ct); }  // RTCommon.slang:197-201
+float phase_mie(V3 V, V3 L) {  // RTCommon.slang:204-211 with g = 0.85
+    float ct = dot(V, L);
+    float g = min_(0.85f, 0.9381f);
+    float k = 1.55f * g - 0.55f * g * g * g;
+    float kc = k * ct;
+    return (1.0f - k * k) / ((4.0f * M_PI_F) * (1.0f - kc) * (1.0f - kc));
+}
+V3 sample_rayleigh(Rng& r, V3 dir) {  // Sampler.slang:195-215
+    float r1 = r.uf(), r2 = r.uf();
+    float u = -pow_(2.0f * (2.0f * r1 - 1.0f) + sqrt_(4.0f * pow_(2.0f * r1 - 1.0f, 2.0f) + 1.0f), 1.0f / 3.0f);
+    float ct = u - (1.0f / u);
+    float phi = 2.0f * M_PI_F * r2;
+    float st = sqrt_(1.0f - ct * ct);
+    float sp, cp; sincos_(phi, &sp, &cp);
+    V3 nd = v3(st * cp, st * sp, ct);
+    V3 up = fabs_(dir.y) < 0.9999999f ? v3(0, 1, 0) : v3(0, 0, 1);
+    V3 t = normalize(cross(up, dir));
+    V3 b = cross(dir, t);
+    return normalize((nd.x * t + nd.y * b) + nd.z * dir);
+}
+void sample_sun_disk(const Oracle& o, Rng& r, float sun_theta, V3& to_light, V4& cpdf) {  // Sampler.slang:431-462
+    float az = o.P.sky_azimuth / 180.0f * M_PI_F, al = o.P.sky_altitude / 180.0f * M_PI_F;
+    V3 sun = rotate(v3(0.0f, 0.0f, -1.0f), v3(1.0f, 0.0f, 0.0f), al);
+    sun = rotate(sun, v3(0.0f, 1.0f, 0.0f), az);
+    float ctm = cos_(sun_theta);
+    float phi = 2.0f * M_PI_F * r.uf();
+    float ct = lerp(ctm, 1.0f, r.uf());
+    float st = sqrt_(1.0f - ct * ct);
+    float sp, cp; sincos_(phi, &sp, &cp);
+    V3 local = v3(cp * st, sp * st, ct);
+    V3 w = normalize(sun);
+    V3 up = fabs_(w.z) < 0.999f ? v3(0, 0, 1) : v3(1, 0, 0);
+    V3 u = normalize(cross(up, w));
+    V3 v = cross(w, u);
+    to_light = (u * local.x + v * local.y) + w * local.z;
+    float solid = 2.0f * M_PI_F * (1.0f - ctm);
+    cpdf.w = 1.0f / solid;
+    V3 c = (2e5f * P3(o.atm.sun_color)) * o.P.sky_intensity;
+    cpdf.x = c.x; cpdf.y = c.y; cpdf.z = c.z;
+}
+// Sampler::ImportanceSampleSky, Sampler.slang:464-476
+void importance_sample_sky(const Oracle& o, Rng& r, V3& to_light, V4& out) {
+    if (o.atm_on) sample_sun_disk(o, r, 0.004675f, to_light, out);
+    else importance_sample_env(o, r, to_light, out);
+}
+float atmosphere_height(const Oracle& o, V3 p) { return length(p - P3(o.atm.planet_position)) - o.atm.planet_radius; }  // Atmosphere.slang:13-16
+float rayleigh_density(const Oracle& o, float h) { return exp_(-h / o.atm.rayleigh_density_falloff); }
+float mie_density(const Oracle& o, float h) { return exp_(-h / o.atm.mie_density_falloff); }
+float ozone_density(const Oracle& o, float h) { return exp_(-(fabs_(h - o.atm.ozone_peak) / o.atm.ozone_density_falloff)); }
+struct AtmCoef { float ray, mie, ozo, majorant; };
+AtmCoef atmosphere_coefficients(const Oracle& o, int ch) {  // Atmosphere.slang:52-60 == 151-155
+    AtmCoef k;
+    k.ray = C_RAYLEIGH[ch] * o.atm.rayleigh_multiplier[ch];
+    k.mie = C_MIE * o.atm.mie_multiplier[ch];
+    k.ozo = C_OZONE[ch] * o.atm.ozone_multiplier[ch];
+    k.majorant = (rayleigh_density(o, 0.0f) * k.ray + mie_density(o, 0.0f) * k.mie) + ozone_density(o, o.atm.ozone_peak) * k.ozo;
+    return k;
+}
+// CalculateTransmittanceThroughAtmosphere, Atmosphere.slang:33-107: float3 with only `ch` set (ratio tracking + roulette)
+V3 atmosphere_transmittance(const Oracle& o, Rng& r, V3 org, V3 dir, int ch) {
+    V2 planet = intersect_sphere(org, dir, P3(o.atm.planet_position), o.atm.planet_radius);
+    if (planet.y > 0.0f) return v3s(0.0f);
+    V2 at = intersect_sphere(org, dir, P3(o.atm.planet_position), o.atm.planet_radius + o.atm.atmosphere_height);
+    float tmin = max_(at.x, 0.0f), tmax = at.y;
+    if (tmax < 0.0f) return v3s(1.0f);
+    AtmCoef k = atmosphere_coefficients(o, ch);
+    if (k.majorant <= 0.0f) return v3s(1.0f);
+    float t = 0.0f, tr = 1.0f;
+    for (int i = 0; i < 1000; i++) {
+        float dt = -log_(1.0f - r.uf()) / k.majorant;
+        t += dt;
+        if (t >= tmax - tmin) break;
+        float h = atmosphere_height(o, org + dir * (t + tmin));
+        if (h < 0.0f) break;
+        float dr = rayleigh_density(o, h) * k.ray, dm = mie_density(o, h) * k.mie, dz = ozone_density(o, h) * k.ozo;
+        tr *= 1.0f - (dr + dm + dz) / k.majorant;
+        float p = tr;
+        if (r.uf() > p) { tr = 0.0f; break; }
+        tr /= p;
+    }
+    V3 out = v3s(0.0f);
+    if (ch == 0) out.x = tr; else if (ch == 1) out.y = tr; else out.z = tr;
+    return out;
+}
+// SampleAtmosphereScatterDistance, Atmosphere.slang:117-201: delta tracking; comp 0 Rayleigh, 1 Mie, 2 ozone, -1 none
+float atmosphere_scatter_distance(const Oracle& o, Rng& r, V3 org, V3 dir, int ch, int& comp) {
+    V2 at = intersect_sphere(org, dir, P3(o.atm.planet_position), o.atm.planet_radius + o.atm.atmosphere_height);
+    float tmin_a = max_(at.x, 0.0f), tmax_a = at.y;
+    comp = -1;
+    V2 planet = intersect_sphere(org, dir, P3(o.atm.planet_position), o.atm.planet_radius);
+    float tmin_p = planet.x;
+    if (tmax_a < 0.0f) return -1.0f;
+    AtmCoef k = atmosphere_coefficients(o, ch);
+    if (k.majorant <= 0.0f) return -1.0f;
+    float t = tmin_a;
+    for (int i = 0; i < 1000; i++) {
+        float dt = -log_(1.0f - r.uf()) / k.majorant;
+        t += dt;
+        if (t >= tmax_a) break;
+        if (tmin_p > 0.0f && t >= tmin_p) break;
+        float h = atmosphere_height(o, org + dir * t);
+        float dr = rayleigh_density(o, h) * k.ray, dm = mie_density(o, h) * k.mie, dz = ozone_density(o, h) * k.ozo;
+        float dens = (dr + dm) + dz;
+        if (dens / k.majorant < r.uf()) continue;
+        float pr = dr / dens, pm = dm / dens;
+        float x = r.uf();
+        if (x <= pr) comp = 0; else if (x <= pr + pm) comp = 1; else comp = 2;
+        return t;
+    }
+    return -1.0f;
+}
+// The per-channel product the surface / volume NEE applies to a sky sample (ClosestHit.slang:335-349 == RayGen.slang:328-343)
+V3 nee_atmosphere_transmittance(const Oracle& o, Rng& r, V3 tr, V3 org, V3 dir, int color_channel) {
+    if (color_channel == -1) {
+        tr.x *= atmosphere_transmittance(o, r, org, dir, 0).x;
+        tr.y *= atmosphere_transmittance(o, r, org, dir, 1).y;
+        tr.z *= atmosphere_transmittance(o, r, org, dir, 2).z;
+        return tr;
+    }
+    return tr * atmosphere_transmittance(o, r, org, dir, color_channel);
+}
+
 // ------------------------------------------------------------------ Volumes (Volume.slang / RayGen.slang:162-380, homogeneous boxes)
 V3 sample_draine(Rng& r, V3 dir, float g, float a) {  // Sampler.slang:217-266
     float r1 = r.uf(), r2 = r.uf();
@@ -722,7 +865,7 @@ void volume_scatter_event(const Oracle& o, Payload& p, float sd, int vi, Counter
     p.emitted = P3(v.emissive_color);  // + GetEmissionFromTemperatureAtPoint == 0 without temperature data
     V3 to_sky = v3s(0.0f); V4 sky; sky.x = sky.y = sky.z = sky.w = 0.0f;
     if (o.P.flags & VPT_FLAG_SKY_MIS) {
-        importance_sample_env(o, p.rng, to_sky, sky);
+        importance_sample_sky(o, p.rng, to_sky, sky);
         sky.x *= o.P.sky_intensity; sky.y *= o.P.sky_intensity; sky.z *= o.P.sky_intensity;
         uint32_t t0, t1;
         if (does_ray_intersect(o, p.origin, to_sky, t0, t1, c)) sky.x = sky.y = sky.z = sky.w = 0.0f;
@@ -743,6 +886,7 @@ void volume_scatter_event(const Oracle& o, Payload& p, float sd, int vi, Counter
     if ((o.P.flags & VPT_FLAG_SKY_MIS) && sky.w > 0.0f) {
         float ps = volume_phase(o, v, p.direction, to_sky, p.volume_depth);
         V3 tr = v3s(volumes_transmittance(o, p.origin, to_sky));
+        if (o.atm_on) tr = nee_atmosphere_transmittance(o, p.rng, tr, p.origin, to_sky, p.color_channel);  // :328-343
         V3 bx = P3(v.color) * ps;
         if (ps > 0.0f) p.emitted = p.emitted + ((tr * bx) * (v3(sky.x, sky.y, sky.z) / sky.w)) * power_heuristics(sky.w, ps);
     }
@@ -757,7 +901,49 @@ void volume_scatter_event(const Oracle& o, Payload& p, float sd, int vi, Counter
     p.depth++;
     p.volume_depth++;
 }
-// ScatteredInVolume, RayGen.slang:162-263 (no atmosphere)
+// EvaluateAtmosphereScatteringEvent, RayGen.slang:382-470
+void atmosphere_scatter_event(const Oracle& o, Payload& p, float sd, int comp, Counters* c) {
+    p.origin = p.origin + sd * p.direction;
+    V3 nd;
+    if (comp == 0) nd = sample_rayleigh(p.rng, p.direction);
+    else if (comp == 1) nd = sample_hg(p.rng, p.direction, 0.85f);
+    else nd = p.direction;
+    if (o.P.flags & VPT_FLAG_SKY_MIS) {
+        V3 to_sky; V4 cp;
+        importance_sample_sky(o, p.rng, to_sky, cp);
+        cp.x *= o.P.sky_intensity; cp.y *= o.P.sky_intensity; cp.z *= o.P.sky_intensity;
+        uint32_t t0, t1;
+        bool obscured = does_ray_intersect(o, p.origin, to_sky, t0, t1, c);
+        V3 tr = v3s(1.0f);
+        if (!obscured) {
+            tr = atmosphere_transmittance(o, p.rng, p.origin, to_sky, p.color_channel);
+            tr = tr * volumes_transmittance(o, p.origin, to_sky);
+        } else {
+            tr = v3s(0.0f);
+        }
+        V3 sun = v3(cp.x, cp.y, cp.z) / cp.w;
+        if (comp == 0) {
+            p.emitted = p.emitted + (rayleigh_phase(p.direction, to_sky) * tr) * sun;
+            p.bxdf = v3s(rayleigh_phase(p.direction, nd)); p.pdf = rayleigh_phase(p.direction, nd);
+        } else if (comp == 1) {
+            p.emitted = p.emitted + (phase_hg(p.direction, to_sky, 0.85f) * tr) * sun;
+            float att = C_MIE_ABSORPTION / C_MIE;
+            p.bxdf = v3s(phase_hg(p.direction, nd, 0.85f) * (1.0f - att)); p.pdf = phase_hg(p.direction, nd, 0.85f);
+        } else {
+            p.bxdf = v3s(0.0f); p.pdf = 1.0f;
+        }
+    } else {
+        if (comp == 0) {
+            p.bxdf = v3s(rayleigh_phase(p.direction, nd)); p.pdf = rayleigh_phase(p.direction, nd);
+        } else {  // Mie AND ozone (quirk: `componentHit == 0 ... else`)
+            float att = C_MIE_ABSORPTION / C_MIE;
+            p.bxdf = v3s(phase_mie(p.direction, nd) * att); p.pdf = phase_hg(p.direction, nd, 0.85f);
+        }
+    }
+    p.direction = nd;
+    p.depth++;
+}
+// ScatteredInVolume, RayGen.slang:162-263
 bool scattered_in_volume(const Oracle& o, Payload& p, Counters* c) {
     const int n = (int)o.volumes.size();
     float dist[VPT_MAX_VOLUMES]; int idx[VPT_MAX_VOLUMES];
@@ -776,7 +962,17 @@ bool scattered_in_volume(const Oracle& o, Payload& p, Counters* c) {
         float t = does_ray_scatter(o.volumes[idx[i]], p.origin, p.direction, p.rng, sd);
         if (t >= 0.0f && (t < sd || sd < 0.0f)) { sd = t; sv = idx[i]; }
     }
-    if (sd >= 0.0f && (dgeo < 0.0f || sd < dgeo)) { volume_scatter_event(o, p, sd, sv, c); return true; }
+    int cc = p.color_channel, comp = -1;
+    if (o.atm_on) {  // :212-236
+        if (cc == -1) { float pick = p.rng.uf(); cc = pick < 0.33333f ? 0 : (pick < 0.66666f ? 1 : 2); }
+        float ad = atmosphere_scatter_distance(o, p.rng, p.origin, p.direction, cc, comp);
+        if (ad >= 0.0f && (ad < sd || sd < 0.0f)) { sd = ad; sv = -2; }
+    }
+    if (sd >= 0.0f && (dgeo < 0.0f || sd < dgeo)) {
+        if (sv == -2) { p.color_channel = cc; atmosphere_scatter_event(o, p, sd, comp, c); }
+        else volume_scatter_event(o, p, sd, sv, c);
+        return true;
+    }
     return false;
 }
 
@@ -805,6 +1001,7 @@ BSample sample_bsdf(const Mat& m, Rng& r, V3 V, V3 H) {
 
 // ------------------------------------------------------------------ Miss (Miss.slang:8-77)
 void miss_shader(const Oracle& o, Payload& p) {
+    if (o.atm_on) { p.depth = MAX_DEPTH_C; return; }  // Miss.slang:11-14: the sky is in-scattered sunlight only
     V4 cp;
     bool show = (o.P.flags & VPT_FLAG_SHOW_ENV_DIRECTLY) != 0;
     if (show || p.depth > 0) {
@@ -853,7 +1050,7 @@ void closest_hit_shader(const Oracle& o, Payload& p, V3 raydir, const Hit& hit, 
     V3 to_sky, to_sky_t = v3s(0.0f); V4 sky; sky.x = sky.y = sky.z = sky.w = 0.0f;
     bool can_sky = false;
     if (o.P.flags & VPT_FLAG_SKY_MIS) {  // 125-148
-        importance_sample_env(o, p.rng, to_sky, sky);
+        importance_sample_sky(o, p.rng, to_sky, sky);
         sky.x *= o.P.sky_intensity; sky.y *= o.P.sky_intensity; sky.z *= o.P.sky_intensity;
         to_sky_t = s.world_to_tangent(to_sky);
         uint32_t t0, t1;
@@ -918,6 +1115,7 @@ void closest_hit_shader(const Oracle& o, Payload& p, V3 raydir, const Hit& hit, 
     if (o.P.flags & VPT_FLAG_SKY_MIS) {  // 323-355
         if (can_sky) {
             V3 tr = v3s(volumes_transmittance(o, p.origin, to_sky));  // :332-333, from the NEW origin; 1 without volumes
+            if (o.atm_on) tr = nee_atmosphere_transmittance(o, p.rng, tr, p.origin, to_sky, p.color_channel);  // :335-349
             if (sky.w > 0.0f && sky_e.pdf > 0.0f)
                 p.emitted = p.emitted + (sky_e.bxdf * tr * v3(sky.x, sky.y, sky.z) / sky.w) * power_heuristics(sky.w, sky_e.pdf);
         }
@@ -964,7 +1162,7 @@ void raygen_pixel(Oracle& o, uint32_t lx, uint32_t ly, uint32_t frame_count, uin
         direction = normalize(focus - origin);
 
         p.depth = 0; p.origin = origin; p.direction = direction; p.bxdf = v3s(1.0f); p.pdf = 1.0f;
-        p.emitted = v3s(0.0f); p.in_medium = false; p.volume_depth = 0;
+        p.emitted = v3s(0.0f); p.in_medium = false; p.volume_depth = 0; p.color_channel = -1;
         p.medium_density = 0.0f; p.medium_anisotropy = 0.0f; p.medium_color = v3s(0.0f); p.medium_emissive = v3s(0.0f);
         V3 thr = v3s(1.0f), light = v3s(0.0f);
         for (; p.depth < o.P.max_depth;) {
@@ -973,7 +1171,8 @@ void raygen_pixel(Oracle& o, uint32_t lx, uint32_t ly, uint32_t frame_count, uin
             Hit h;
             c.closest++;  // one per loop iteration (the GPU counts path-bounces)
             // RayGen.slang:86-90; without volumes ScatteredInVolume only makes the unused distance query (a9: dropped)
-            bool scattered = !o.volumes.empty() && scattered_in_volume(o, p, &c);
+            if (o.atm_on && atmosphere_height(o, p.origin) < 0.0f) break;  // RayGen.slang:76-84: below the planet's surface
+            bool scattered = (!o.volumes.empty() || o.atm_on) && scattered_in_volume(o, p, &c);
             if (scattered) {}
             else if (closest_hit(o, p.origin, rd, 0.01f, 100000.0f, h, &c)) closest_hit_shader(o, p, rd, h, &c);
             else miss_shader(o, p);
@@ -992,7 +1191,12 @@ void raygen_pixel(Oracle& o, uint32_t lx, uint32_t ly, uint32_t frame_count, uin
         }
         c.samples++;
         bool ok = !isinf_(light.x) && !isinf_(light.y) && !isinf_(light.z) && !isnan_(light.x) && !isnan_(light.y) && !isnan_(light.z);
-        if (ok) acc = acc + light;
+        if (ok) {  // RayGen.slang:116-129: a split path carries one colour channel
+            if (p.color_channel == -1) acc = acc + light;
+            else if (p.color_channel == 0) acc.x += light.x;
+            else if (p.color_channel == 1) acc.y += light.y;
+            else acc.z += light.z;
+        }
     }
     acc = acc / (float)o.P.samples_per_frame;
     V3 color;
@@ -1159,6 +1363,12 @@ int orc_set_volumes(void* h, const vpt_volume* v, uint32_t n) {
     for (uint32_t i = 0; i < n; i++) if (v[i].density_data_index != -1) return -1;
     o->volumes.assign(v, v + n); orc_reset(h);
     return 0;
+}
+void orc_set_atmosphere(void* h, const vpt_atmosphere* a) {
+    Oracle* o = (Oracle*)h;
+    o->atm_on = a != nullptr;
+    if (a) o->atm = *a;
+    orc_reset(h);
 }
 void orc_set_phase_function(void* h, uint32_t phase) { Oracle* o = (Oracle*)h; o->phase = phase; orc_reset(h); }
 void orc_set_brute_force(void* h, int on) { ((Oracle*)h)->brute_force = on != 0; }
@@ -1428,6 +1638,22 @@ void orc_lut_cells(uint32_t kind, uint32_t sx, uint32_t sy, uint32_t sz, uint32_
         }
         out[ci] = cell / (float)passes;
     }
+}
+
+// Monte-Carlo means of the two atmosphere estimators for one ray (test hook): out[0] = E[ratio-tracked
+// transmittance of channel ch] (Atmosphere.slang:33-107), out[1] = fraction of delta-tracking runs that leave the
+// atmosphere without a collision (:117-201).  Both estimate exp(-optical depth) of the same ray.
+void orc_atmosphere_estimators(const vpt_atmosphere* a, const float* org, const float* dir, int ch, uint32_t seed, uint32_t n, float* out) {
+    Oracle o; o.atm_on = true; o.atm = *a;
+    Rng r; r.s = seed;
+    double tr = 0.0, esc = 0.0;
+    for (uint32_t i = 0; i < n; i++) {
+        V3 t = atmosphere_transmittance(o, r, P3(org), P3(dir), ch);
+        tr += ch == 0 ? t.x : (ch == 1 ? t.y : t.z);
+        int comp;
+        if (atmosphere_scatter_distance(o, r, P3(org), P3(dir), ch, comp) < 0.0f) esc += 1.0;
+    }
+    out[0] = (float)(tr / n); out[1] = (float)(esc / n);
 }
 
 }  // extern "C"

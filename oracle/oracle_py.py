@@ -35,6 +35,8 @@ def lib():
         L.orc_set_volumes.restype = C.c_int
         L.orc_set_volumes.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
         L.orc_set_phase_function.argtypes = [C.c_void_p, C.c_uint32]
+        L.orc_set_atmosphere.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_atmosphere_estimators.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_void_p]
         L.orc_render.restype = C.c_int
         L.orc_render.argtypes = [C.c_void_p, C.c_uint32, C.c_int]
         L.orc_get_radiance.argtypes = [C.c_void_p, C.c_void_p]
@@ -58,6 +60,12 @@ def lib():
         _lib = L
     return _lib
 
+
+def atmosphere_estimators(atm, origin, direction, channel, seed=1, n=20000):
+    """(E[ratio-tracked transmittance], P[delta tracking escapes]) for one ray: both estimate exp(-optical depth)."""
+    o = np.asarray(origin, np.float32); d = np.asarray(direction, np.float32); out = np.zeros(2, np.float32)
+    lib().orc_atmosphere_estimators(C.byref(atm), o.ctypes.data, d.ctypes.data, channel, seed, n, out.ctypes.data)
+    return float(out[0]), float(out[1])
 
 def lut_cells(kind, size, sample_count, time_ms, cells, threads=None):
     """LookupTableCalculator::CalculateTable restated, for the listed cell indices (x + y*sx + z*sx*sy)."""
@@ -105,6 +113,9 @@ class Oracle:
         arr = (_abi.Volume * max(len(volumes), 1))(*volumes)
         if self.L.orc_set_volumes(self.h_, arr, len(volumes)) != 0:
             raise ValueError("orc_set_volumes: too many volumes or heterogeneous volume")
+
+    def set_atmosphere(self, atm):
+        self.L.orc_set_atmosphere(self.h_, C.byref(atm) if atm is not None else None)
 
     def set_phase_function(self, phase):
         self.L.orc_set_phase_function(self.h_, phase)

@@ -198,3 +198,22 @@ def test_hdr_env_and_png_export_through_the_cli(cli, vpt, oracle, tmp_path):
     assert np.array_equal(img, ref)
     ref8, _ = oracle.postprocess(ref, vpt.default_post_params())
     assert np.array_equal(vpt.imagefiles.load_png(png), ref8)
+
+
+@pytest.mark.gpu
+def test_atmosphere_through_the_cpp_facade(cli, vpt, oracle, tmp_path):
+    """SetEnableAtmosphere + SetSkyAltitude/Azimuth on the facade == vpt_set_atmosphere == the oracle."""
+    gltf = os.path.join(GOLDEN, "cornell_box.gltf")
+    rad, cam = str(tmp_path / "r.f32"), str(tmp_path / "c.f32")
+    w, h, spp, depth = 96, 54, 3, 6
+    subprocess.check_output([cli, "--scene", gltf, "--luts", LUTS, "--size", "%dx%d" % (w, h), "--spp", str(spp), "--depth", str(depth), "--radiance", rad,
+                             "--camera", cam, "--atmosphere", "--sun", "-35,120"])
+    img = np.fromfile(rad, "<f4").reshape(h, w, 4)
+    m = np.fromfile(cam, "<f4").reshape(2, 4, 4)
+    o = oracle.Oracle(vpt.scenes.load_gltf(gltf), w, h)
+    o.set_camera(m[0].T, m[1].T)
+    o.set_params(vpt.default_params(max_depth=depth, base_seed=1, max_samples=spp, sky_altitude=-35.0, sky_azimuth=120.0))
+    o.set_atmosphere(vpt.atmosphere())
+    o.render(spp)
+    ref = o.radiance(); o.close()
+    assert np.array_equal(img, ref)

@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 from . import _abi, imagefiles, scenes  # noqa: F401
-from ._abi import default_params, default_post_params, volume  # noqa: F401
+from ._abi import default_params, default_post_params, volume, atmosphere  # noqa: F401
 from ._abi import PHASE_HENYEY_GREENSTEIN, PHASE_DRAINE, PHASE_HENYEY_GREENSTEIN_PLUS_DRAINE  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -106,6 +106,10 @@ class PathTracer:
         """AddVolume / RemoveVolume / SetVolume (PathTracer.h:157-159): replaces the whole list."""
         arr = (_abi.Volume * max(len(volumes), 1))(*volumes)
         _check(self.lib, self.ctx, self.lib.vpt_set_volumes(self.ctx, arr, len(volumes)), "vpt_set_volumes")
+
+    def set_atmosphere(self, atm):
+        """SetEnableAtmosphere(True) + the planet/density setters; None disables (PathTracer.h:168-179)."""
+        _check(self.lib, self.ctx, self.lib.vpt_set_atmosphere(self.ctx, C.byref(atm) if atm is not None else None), "vpt_set_atmosphere")
 
     def set_phase_function(self, phase):
         _check(self.lib, self.ctx, self.lib.vpt_set_phase_function(self.ctx, phase), "vpt_set_phase_function")

@@ -47,6 +47,34 @@ class Volume(C.Structure):  # vpt_volume
 
 
 assert C.sizeof(Volume) == 76
+
+
+class Atmosphere(C.Structure):  # vpt_atmosphere
+    _fields_ = [
+        ("planet_position", C.c_float * 3), ("planet_radius", C.c_float), ("atmosphere_height", C.c_float),
+        ("rayleigh_density_falloff", C.c_float), ("mie_density_falloff", C.c_float), ("ozone_density_falloff", C.c_float),
+        ("ozone_peak", C.c_float),
+        ("rayleigh_multiplier", C.c_float * 3), ("mie_multiplier", C.c_float * 3), ("ozone_multiplier", C.c_float * 3),
+        ("sun_color", C.c_float * 3),
+    ]
+
+
+assert C.sizeof(Atmosphere) == 84
+
+
+def atmosphere(**kw):
+    """PathTracer.h:222-232 defaults (metres; the planet centre sits 1 km + one radius along +Y, i.e. below a Y-down world)."""
+    a = Atmosphere()
+    d = dict(planet_position=(0.0, 6360e3 + 1000.0, 0.0), planet_radius=6360e3, atmosphere_height=100e3, rayleigh_density_falloff=8000.0,
+             mie_density_falloff=1200.0, ozone_density_falloff=5000.0, ozone_peak=22000.0, rayleigh_multiplier=(1, 1, 1), mie_multiplier=(1, 1, 1),
+             ozone_multiplier=(1, 1, 1), sun_color=(1.0, 0.956, 0.88))
+    d.update(kw)
+    for k, v in d.items():
+        if isinstance(v, (tuple, list)):
+            getattr(a, k)[:] = v
+        else:
+            setattr(a, k, v)
+    return a
 PHASE_HENYEY_GREENSTEIN, PHASE_DRAINE, PHASE_HENYEY_GREENSTEIN_PLUS_DRAINE = 0, 1, 2
 
 
@@ -157,6 +185,8 @@ PROTOTYPES = {
     "vpt_set_material": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(Material)]),
     "vpt_get_material": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(Material)]),
     "vpt_set_camera": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "vpt_default_atmosphere": (None, [C.POINTER(Atmosphere)]),
+    "vpt_set_atmosphere": (C.c_int, [C.c_void_p, C.c_void_p]),
     "vpt_set_volumes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32]),
     "vpt_set_phase_function": (C.c_int, [C.c_void_p, C.c_uint32]),
     "vpt_set_params": (C.c_int, [C.c_void_p, C.POINTER(Params)]),

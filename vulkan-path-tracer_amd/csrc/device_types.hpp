@@ -121,6 +121,8 @@ struct DeviceScene {
     uint32_t* stack_overflow;               // traversal stack entries beyond the LDS part, kStackOverflow per resident thread
     const vpt_volume* volumes;              // uVolumes (Volume.slang:9); volume_count == 0: none
     uint32_t volume_count, phase;           // PHASE_FUNCTION_* (PathTracer.h:76-81)
+    uint32_t atm_on;                        // ENABLE_ATMOSPHERE
+    vpt_atmosphere atm;
 };
 
 struct RenderParams {
@@ -161,6 +163,7 @@ struct PathState {
     float* maniso;   // medium anisotropy
     uint32_t* sidx;  // sample index within the frame (samples_per_frame > 1 only)
     uint32_t* vdepth;  // payload.VolumeDepth (only touched while volumes are set)
+    int32_t* cchan;    // payload.ColorChannel (only touched while the atmosphere is on)
 };
 
 // connect flags (CE.w)

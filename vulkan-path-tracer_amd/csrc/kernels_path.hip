@@ -13,6 +13,7 @@
 #include "kernels.hpp"
 #include "shading.hpp"
 #include "volume.hpp"
+#include "atmosphere.hpp"
 #include "traverse.hpp"
 
 namespace vpt {
@@ -193,9 +194,11 @@ struct ShadeIn {
     float prev_pdf;     // payload.PDF of the previous bounce
     float4 h;           // hit record t,u,v | PrimitiveIndex (t < 0: miss)
     uint32_t inst;      // InstanceIndex
-    int vol_index;      // >= 0: the path scattered in this box before reaching the geometry (volumes only)
+    int vol_index;      // >= 0: the path scattered in this box before reaching the geometry; -2: in the atmosphere (media kernels only)
     float vol_t;        //       at this distance along payload.Direction
     uint32_t vdepth;    // payload.VolumeDepth
+    int cchan;          // payload.ColorChannel (for an atmosphere event: the channel the collision was sampled for)
+    int atm_comp;       // atmosphere event: 0 Rayleigh, 1 Mie, 2 ozone
 };
 struct ShadeOut {
     bool alive, terminated, want_sky, want_light, in_medium;
@@ -204,6 +207,14 @@ struct ShadeOut {
     V3 new_o, new_d, thr;
     float new_pdf;
     V3 emitted, csky, clight, sky_o, sky_d, light_o, light_d;
+    // media kernels only: shade_core<true> stops before the throughput / roulette tail, because with an atmosphere the
+    // sky sample's transmittance is tracked (draws random numbers) only once the shadow ray is known to be clear
+    V3 bxdf;            // payload.BxDF
+    V3 sky_f, sky_rgb;  // sky NEE ingredients: BSDF or colour*phase towards the sample, sample radiance
+    float sky_tvol, sky_w, sky_mis;  // box transmittance, sample pdf, MIS weight (1 for the atmosphere event)
+    int sky_kind;       // 0 surface, 1 box scatter event, 2 atmosphere scatter event (the three expressions differ in association)
+    bool sky_add;       // false: trace and track (the draws count) but add nothing (ozone collision)
+    int cchan;          // payload.ColorChannel after this bounce
 };
 
 // The miss / closest-hit shader and the visibility-independent tail of the bounce loop for ONE path, on
@@ -212,6 +223,7 @@ template <bool VOL>
 __device__ __forceinline__ void shade_core(const DeviceScene& sc, const RenderParams& P, const PathState& ps, uint32_t slot,
                                            const ShadeIn& in_, ShadeOut& out) {
     bool alive = false, want_sky = false, want_light = false, light_miss_ok = false;
+    if (VOL) { out.sky_add = true; out.sky_kind = 0; out.sky_tvol = 1.0f; out.sky_w = 1.0f; out.sky_mis = 1.0f; out.sky_f = v3s(0.0f); out.sky_rgb = v3s(0.0f); }
     uint32_t vdepth = VOL ? in_.vdepth : 0u;
     const float4 h = in_.h;
     Rng rng; rng.s = in_.rng;
@@ -233,19 +245,20 @@ __device__ __forceinline__ void shade_core(const DeviceScene& sc, const RenderPa
         emitted = ld3(v.emissive_color);
         V3 to_sky = v3s(0.0f); V4 sky = v4(0.0f, 0.0f, 0.0f, 0.0f);
         if (P.flags & VPT_FLAG_SKY_MIS) {
-            sample_env(sc, P, rng, to_sky, sky);
+            sample_sky(sc, P, rng, to_sky, sky);
             sky.x *= P.sky_intensity; sky.y *= P.sky_intensity; sky.z *= P.sky_intensity;
         }
         V3 to_light = v3s(0.0f); V4 lc = v4(0.0f, 0.0f, 0.0f, 0.0f);
         if (P.flags & VPT_FLAG_MESH_MIS) sample_emissive(sc, rng, new_o, to_light, lc, light_gid);
         const V3 nd = volume_scatter_direction(sc.phase, v, pdir, rng, vdepth);
         const float ph = volume_phase(sc.phase, v, pdir, nd, vdepth);
-        // NEE, speculative like the surface case: the shadow rays start AT the scatter point (no offset)
+        // NEE: the shadow rays start AT the scatter point (no offset); the sky term is assembled after the visibility test
         if ((P.flags & VPT_FLAG_SKY_MIS) && sky.w > 0.0f) {
             float ps_ = volume_phase(sc.phase, v, pdir, to_sky, vdepth);
-            if (ps_ > 0.0f) {
-                V3 tr = v3s(volumes_transmittance(sc, new_o, to_sky));
-                csky = ((tr * (ld3(v.color) * ps_)) * (v3(sky.x, sky.y, sky.z) / sky.w)) * power_heuristics(sky.w, ps_);
+            if (ps_ > 0.0f || sc.atm_on) {  // with an atmosphere the transmittance is tracked (draws) whenever the sample is unobscured (:316-343)
+                out.sky_f = ld3(v.color) * ps_; out.sky_tvol = volumes_transmittance(sc, new_o, to_sky);
+                out.sky_rgb = v3(sky.x, sky.y, sky.z); out.sky_w = sky.w; out.sky_mis = power_heuristics(sky.w, ps_); out.sky_kind = 1;
+                out.sky_add = ps_ > 0.0f;
                 want_sky = true; sky_o = new_o; sky_d = to_sky;
             }
         }
@@ -262,6 +275,45 @@ __device__ __forceinline__ void shade_core(const DeviceScene& sc, const RenderPa
         bxdf = ld3(v.color) * ph; new_pdf = ph;
         new_depth = depth + 1u;
         vdepth = vdepth + 1u;
+    } else if (VOL && in_.vol_index == -2) {
+        // ---- EvaluateAtmosphereScatteringEvent, RayGen.slang:382-470
+        const int comp = in_.atm_comp;
+        new_o = porg + in_.vol_t * pdir;
+        V3 nd;
+        if (comp == 0) nd = sample_rayleigh(rng, pdir);
+        else if (comp == 1) nd = sample_hg(rng, pdir, 0.85f);
+        else nd = pdir;
+        if (P.flags & VPT_FLAG_SKY_MIS) {
+            V3 to_sky; V4 cp;
+            sample_sky(sc, P, rng, to_sky, cp);
+            cp.x *= P.sky_intensity; cp.y *= P.sky_intensity; cp.z *= P.sky_intensity;
+            // the sun term needs the shadow ray first: its transmittance is tracked only when the ray is clear (:398-409)
+            out.sky_rgb = v3(cp.x, cp.y, cp.z); out.sky_w = cp.w; out.sky_mis = 1.0f; out.sky_kind = 2;
+            out.sky_tvol = 1.0f;  // the box transmittance is evaluated with the atmosphere's, after the visibility test
+            sky_o = new_o; sky_d = to_sky;
+            if (comp == 0) {
+                out.sky_f = v3s(rayleigh_phase(pdir, to_sky)); want_sky = true;
+                bxdf = v3s(rayleigh_phase(pdir, nd)); new_pdf = rayleigh_phase(pdir, nd);
+            } else if (comp == 1) {
+                out.sky_f = v3s(phase_hg(pdir, to_sky, 0.85f)); want_sky = true;
+                float att = VPT_C_MIE_ABSORPTION / VPT_C_MIE;
+                bxdf = v3s(phase_hg(pdir, nd, 0.85f) * (1.0f - att)); new_pdf = phase_hg(pdir, nd, 0.85f);
+            } else {
+                // ozone only absorbs; the reference still traces the shadow ray and tracks the transmittance (random draws)
+                out.sky_f = v3s(0.0f); want_sky = true; out.sky_add = false;
+                bxdf = v3s(0.0f); new_pdf = 1.0f;
+            }
+        } else {
+            if (comp == 0) { bxdf = v3s(rayleigh_phase(pdir, nd)); new_pdf = rayleigh_phase(pdir, nd); }
+            else {  // Mie AND ozone (`componentHit == 0 ... else`, :455-466)
+                float att = VPT_C_MIE_ABSORPTION / VPT_C_MIE;
+                bxdf = v3s(phase_mie(pdir, nd) * att); new_pdf = phase_hg(pdir, nd, 0.85f);
+            }
+        }
+        new_d = nd;
+        new_depth = depth + 1u;
+    } else if (VOL && sc.atm_on && h.x < 0.0f) {
+        new_depth = kMaxDepthMarker;  // Miss.slang:11-14: with an atmosphere the sky is in-scattered sunlight only
     } else if (h.x < 0.0f) {
         // ---- Miss.slang:8-77
         V4 cp = v4(0.0f, 0.0f, 0.0f, 1.0f);
@@ -309,7 +361,7 @@ __device__ __forceinline__ void shade_core(const DeviceScene& sc, const RenderPa
             // sky NEE sample (:125-148) — 3 draws
             V3 to_sky = v3s(0.0f); V4 sky = v4(0.0f, 0.0f, 0.0f, 0.0f);
             if (P.flags & VPT_FLAG_SKY_MIS) {
-                sample_env(sc, P, rng, to_sky, sky);
+                if (VOL) sample_sky(sc, P, rng, to_sky, sky); else sample_env(sc, P, rng, to_sky, sky);
                 sky.x *= P.sky_intensity; sky.y *= P.sky_intensity; sky.z *= P.sky_intensity;  // applied twice upstream (quirk 1)
             }
             // emissive-mesh NEE sample (:155-184) — 4 draws unless this is an emitter
@@ -377,11 +429,17 @@ __device__ __forceinline__ void shade_core(const DeviceScene& sc, const RenderPa
             // NEE contributions, evaluated speculatively; the connect stage decides whether they count
             // (EvaluateBSDF draws no random numbers, so evaluating before the visibility test is equivalent)
             new_o = s.pos + s.N * (was_refracted ? -1e-3f : 1e-3f);  // volumes shadow NEE from the NEW origin (:332-333, 364)
-            if ((P.flags & VPT_FLAG_SKY_MIS) && sky.w > 0.0f) {
+            // with an atmosphere every unobscured sky sample has its transmittance tracked (draws), used or not (ClosestHit.slang:330-349)
+            if ((P.flags & VPT_FLAG_SKY_MIS) && (sky.w > 0.0f || (VOL && sc.atm_on))) {
                 Eval e = bs.eval(V, s.world_to_tangent(to_sky), ec_r, ec_g, gv);
-                if (e.pdf > 0.0f) {
-                    if (VOL) e.f = e.f * v3s(volumes_transmittance(sc, new_o, to_sky));
-                    csky = (e.f * v3(sky.x, sky.y, sky.z) / sky.w) * power_heuristics(sky.w, e.pdf);
+                if (e.pdf > 0.0f || (VOL && sc.atm_on)) {
+                    if (VOL) {  // assembled after the visibility test
+                        out.sky_f = e.f; out.sky_tvol = volumes_transmittance(sc, new_o, to_sky);
+                        out.sky_rgb = v3(sky.x, sky.y, sky.z); out.sky_w = sky.w; out.sky_mis = power_heuristics(sky.w, e.pdf); out.sky_kind = 0;
+                        out.sky_add = sky.w > 0.0f && e.pdf > 0.0f;
+                    } else {
+                        csky = (e.f * v3(sky.x, sky.y, sky.z) / sky.w) * power_heuristics(sky.w, e.pdf);
+                    }
                     want_sky = true; sky_o = s.pos + s.N * 1e-5f; sky_d = to_sky;
                 }
             }
@@ -397,6 +455,14 @@ __device__ __forceinline__ void shade_core(const DeviceScene& sc, const RenderPa
             bxdf = se.f; new_pdf = se.pdf;
             new_depth = (se.pdf <= 0.0f) ? (kMaxDepthMarker + depth) : (depth + 1u);  // :374-376
         }
+    }
+    if (VOL) {  // media kernels: the caller resolves visibility, then runs shade_tail_media()
+        out.want_sky = want_sky; out.want_light = want_light; out.in_medium = in_medium;
+        out.rng = rng.s; out.new_depth = new_depth; out.light_gid = light_gid; out.light_miss_ok = light_miss_ok; out.vdepth = vdepth;
+        out.new_o = new_o; out.new_d = new_d; out.new_pdf = new_pdf; out.bxdf = bxdf; out.cchan = in_.cchan;
+        out.emitted = emitted; out.csky = csky; out.clight = clight;
+        out.sky_o = sky_o; out.sky_d = sky_d; out.light_o = light_o; out.light_d = light_d;
+        return;
     }
     // ---- RayGen.slang:104-113: throughput, Russian roulette (drawn on every iteration), loop condition
     V3 thr = thr_prev * (bxdf / new_pdf);
@@ -430,6 +496,41 @@ __device__ __forceinline__ void shade_core(const DeviceScene& sc, const RenderPa
     out.sky_o = sky_o; out.sky_d = sky_d; out.light_o = light_o; out.light_d = light_d;
 }
 
+// The tail of the bounce loop for the media kernels (RayGen.slang:104-129), on the state shade_core<true> left in `o`.
+// `aborted`: the loop was left by `break` before anything happened (origin below the planet's surface, :76-84).
+__device__ __forceinline__ void shade_tail_media(const RenderParams& P, const PathState& ps, uint32_t slot, V3 thr_prev, bool aborted, ShadeOut& o) {
+    Rng rng; rng.s = o.rng;
+    V3 thr = thr_prev;
+    bool terminated = true;
+    if (!aborted) {
+        thr = thr_prev * (o.bxdf / o.new_pdf);
+        float p = min_(max_(thr.x, max_(thr.y, thr.z)), 1.0f);
+        float u = rng.uf();
+        terminated = p < u;
+        if (!terminated) thr = thr / p;
+        if (!(o.new_depth < P.max_depth)) terminated = true;
+    }
+    bool alive = false;
+    uint32_t cflags = (o.new_depth != 1u ? kCF_Clamp : 0u);
+    if (terminated) {
+        cflags |= kCF_Finalize;
+        if (P.samples_per_frame > 1) {
+            uint32_t sample = ps.sidx[slot] + 1u;
+            if (sample < P.samples_per_frame) {
+                uint32_t x, y, f;
+                pixel_of_slot(P, slot, x, y, f);
+                camera_ray(P, rng, x, y, o.new_o, o.new_d);
+                thr = v3s(1.0f); o.new_pdf = 1.0f; o.new_depth = 0u; o.in_medium = false; o.vdepth = 0u; o.cchan = -1;
+                ps.sidx[slot] = sample;
+                alive = true;
+            }
+        }
+    } else {
+        alive = true;
+    }
+    o.alive = alive; o.terminated = terminated; o.cflags = cflags; o.rng = rng.s; o.thr = thr;
+}
+
 __device__ __forceinline__ uint32_t shade_path(const DeviceScene& sc, const RenderParams& P, const PathState& ps,
                                                const float4* Tin, float4* Tout, uint32_t slot) {
     float4 a = ps.A[slot], b = ps.B[slot], t = Tin[slot];
@@ -441,7 +542,7 @@ __device__ __forceinline__ uint32_t shade_path(const DeviceScene& sc, const Rend
     uint32_t dw = __float_as_uint(b.w);
     in_.depth = dw & 0x7fffffffu; in_.in_medium = (dw >> 31) != 0u;
     in_.thr_prev = xyz(t); in_.prev_pdf = t.w;
-    in_.vol_index = -1; in_.vol_t = 0.0f; in_.vdepth = 0u;
+    in_.vol_index = -1; in_.vol_t = 0.0f; in_.vdepth = 0u; in_.cchan = -1; in_.atm_comp = -1;
     ShadeOut o;
     shade_core<false>(sc, P, ps, slot, in_, o);
     if (o.alive) {
@@ -582,7 +683,7 @@ __global__ __launch_bounds__(kTraverseBlock, 3) void k_bounce(DeviceScene sc, Re
                     Rng r; r.s = y + P.width * x + seed;                        // RayGen.slang:28
                     camera_ray(P, r, x, y, in_.porg, in_.pdir);
                     in_.rng = r.s; in_.depth = 0u; in_.in_medium = false; in_.thr_prev = v3s(1.0f); in_.prev_pdf = 1.0f;
-                    in_.vdepth = 0u;
+                    in_.vdepth = 0u; in_.cchan = -1;
                     if (P.samples_per_frame > 1) ps.sidx[slot] = 0u;
                 } else {
                     slot = queue[idx];
@@ -593,28 +694,58 @@ __global__ __launch_bounds__(kTraverseBlock, 3) void k_bounce(DeviceScene sc, Re
                     in_.depth = dw & 0x7fffffffu; in_.in_medium = (dw >> 31) != 0u;
                     in_.thr_prev = xyz(t); in_.prev_pdf = t.w;
                     in_.vdepth = VOL ? ps.vdepth[slot] : 0u;
+                    in_.cchan = (VOL && sc.atm_on) ? ps.cchan[slot] : -1;
                     light_prev = xyz(ps.L[slot]);
                 }
                 HitRec hr;
-                in_.vol_index = -1; in_.vol_t = 0.0f;
-                if (VOL) {  // ScatteredInVolume (RayGen.slang:86): GetDistanceToGeometry uses the payload direction as is,
-                            // TMin 1e-5, TMax 1e6 (RTCommon.slang:86-101)
+                in_.vol_index = -1; in_.vol_t = 0.0f; in_.atm_comp = -1;
+                // RayGen.slang:76-84: a path whose origin is below the planet's surface leaves the loop at once
+                const bool aborted = VOL && sc.atm_on && atmosphere_height(sc, in_.porg) < 0.0f;
+                ShadeOut o;
+                if (VOL && !aborted) {  // ScatteredInVolume (RayGen.slang:86): GetDistanceToGeometry uses the payload direction as is,
+                                        // TMin 1e-5, TMax 1e6 (RTCommon.slang:86-101)
                     bool g = trace_any<LDS_SCENE, COUNT>(sc, lds_nodes, lds_tris, in_.porg, in_.pdir, 0.00001f, 1000000.0f, stack, hr, st);
                     Rng vr; vr.s = in_.rng;
-                    in_.vol_index = scattered_in_volume(sc, in_.porg, in_.pdir, vr, g ? hr.t : -1.0f, in_.vol_t);
+                    int cc;
+                    in_.vol_index = scattered_in_media(sc, in_.porg, in_.pdir, vr, g ? hr.t : -1.0f, in_.cchan, in_.vol_t, in_.atm_comp, cc);
+                    if (in_.vol_index == -2) in_.cchan = cc;  // the path now tracks this colour channel only (:242-247)
                     in_.rng = vr.s;
                 }
-                if (!VOL || in_.vol_index < 0)
+                if (!VOL || (!aborted && in_.vol_index == -1))
                     hit = trace_any<LDS_SCENE, COUNT>(sc, lds_nodes, lds_tris, in_.porg, normalize(in_.pdir), 0.01f, 100000.0f, stack, hr, st);
                 in_.h = make_float4(hit ? hr.t : -1.0f, hr.u, hr.v, __uint_as_float(hr.prim));
                 in_.inst = hr.inst;
-                ShadeOut o;
-                shade_core<VOL>(sc, P, ps, slot, in_, o);
+                if (VOL && aborted) {
+                    o.want_sky = false; o.want_light = false; o.emitted = v3s(0.0f); o.csky = v3s(0.0f); o.clight = v3s(0.0f);
+                    o.rng = in_.rng; o.new_depth = in_.depth; o.new_o = in_.porg; o.new_d = in_.pdir; o.new_pdf = in_.prev_pdf; o.bxdf = v3s(1.0f);
+                    o.in_medium = in_.in_medium; o.vdepth = in_.vdepth; o.cchan = in_.cchan; o.light_gid = 0xffffffffu; o.light_miss_ok = false;
+                } else {
+                    shade_core<VOL>(sc, P, ps, slot, in_, o);
+                }
                 // connect, inline (RayGen.slang:92-102; FIRST: pathThroughput == 1, pathLight == 0)
                 V3 E = o.emitted;
-                if (o.want_sky) {
+                if (!VOL && o.want_sky) {
                     if (sky_visible<LDS_SCENE, COUNT>(sc, lds_nodes, lds_tris, o.sky_o, o.sky_d, stack, sst)) E = E + o.csky;
                     nrays++;
+                }
+                if (VOL && o.want_sky) {  // the sky term is assembled now: its transmittance draws come after the visibility test
+                    nrays++;
+                    if (sky_visible<LDS_SCENE, COUNT>(sc, lds_nodes, lds_tris, o.sky_o, o.sky_d, stack, sst)) {
+                        Rng tr_rng; tr_rng.s = o.rng;
+                        V3 csky;
+                        if (o.sky_kind == 2) {        // RayGen.slang:405-424: (phase * T_atm * T_boxes) * (sun / pdf)
+                            V3 tr = atmosphere_transmittance(sc, tr_rng, o.sky_o, o.sky_d, o.cchan);
+                            tr = tr * volumes_transmittance(sc, o.sky_o, o.sky_d);
+                            csky = (o.sky_f * tr) * (o.sky_rgb / o.sky_w);
+                        } else {
+                            V3 tr = v3s(o.sky_tvol);  // from the new origin (ClosestHit.slang:332-349, RayGen.slang:325-343)
+                            if (sc.atm_on) tr = nee_atmosphere_transmittance(sc, tr_rng, tr, o.new_o, o.sky_d, o.cchan);
+                            if (o.sky_kind == 0) csky = ((o.sky_f * tr) * o.sky_rgb / o.sky_w) * o.sky_mis;
+                            else csky = ((tr * o.sky_f) * (o.sky_rgb / o.sky_w)) * o.sky_mis;
+                        }
+                        o.rng = tr_rng.s;
+                        if (o.sky_add) E = E + csky;
+                    }
                 }
                 if (o.want_light) {
                     bool vis = light_visible<LDS_SCENE, COUNT>(sc, lds_nodes, lds_tris, o.light_o, o.light_d, o.light_gid, stack, sst);
@@ -622,14 +753,18 @@ __global__ __launch_bounds__(kTraverseBlock, 3) void k_bounce(DeviceScene sc, Re
                     if (vis) E = E + o.clight;
                     nrays++;
                 }
+                const int fin_chan = VOL ? o.cchan : -1;  // the channel this sample is accumulated in (RayGen.slang:118-128)
+                if (VOL) shade_tail_media(P, ps, slot, in_.thr_prev, aborted, o);
                 V3 contrib = E * in_.thr_prev;
                 if (o.cflags & kCF_Clamp) {
                     float lum = dot(contrib, v3(0.212671f, 0.715160f, 0.072169f));
                     contrib = contrib * (P.max_luminance / max_(lum, P.max_luminance));
                 }
                 V3 light = light_prev + contrib;
+                if (VOL && aborted) light = light_prev;  // the loop was left before anything was added
                 if (o.terminated) {  // end of a sample: NaN/Inf guard, frame sum (RayGen.slang:116-128)
                     bool ok = !isinf_(light.x) && !isinf_(light.y) && !isinf_(light.z) && !isnan_(light.x) && !isnan_(light.y) && !isnan_(light.z);
+                    if (VOL && fin_chan != -1) light = v3(fin_chan == 0 ? light.x : 0.0f, fin_chan == 1 ? light.y : 0.0f, fin_chan == 2 ? light.z : 0.0f);
                     if (FIRST || P.samples_per_frame == 1) {  // first (or only) finalisation of the slot: 0 + pathLight
                         ps.ACC[slot] = ok ? f4(v3s(0.0f) + light, 0.0f) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                     } else if (ok) {
@@ -645,7 +780,7 @@ __global__ __launch_bounds__(kTraverseBlock, 3) void k_bounce(DeviceScene sc, Re
                     ps.B[slot] = f4u(o.new_d, o.new_depth | (o.in_medium ? 0x80000000u : 0u));
                     Tout[slot] = f4(o.thr, o.new_pdf);
                     ps.L[slot] = f4(light, 0.0f);
-                    if (VOL) ps.vdepth[slot] = o.vdepth;
+                    if (VOL) { ps.vdepth[slot] = o.vdepth; if (sc.atm_on) ps.cchan[slot] = o.cchan; }
                 }
             }
             s0 = (c == 0u) ? slot : s0; s1 = (c == 1u) ? slot : s1; s2 = (c == 2u) ? slot : s2; s3 = (c == 3u) ? slot : s3;
@@ -901,7 +1036,7 @@ void launch_bounce(hipStream_t s, uint32_t blocks, bool lds_scene, bool count, b
     dim3 g(blocks), b(kTraverseBlock);
 #define VPT_LAUNCH_BOUNCE_V(L, C, F, V) hipLaunchKernelGGL((k_bounce<L, C, F, V>), g, b, lds, s, sc, P, ps, queue, queue_next, ctr, parity, n_slots, dispatch_base)
 #define VPT_LAUNCH_BOUNCE(L, C, F) VPT_LAUNCH_BOUNCE_V(L, C, F, false)
-    if (sc.volume_count > 0u) {  // the volume variants carry no traversal counters
+    if (sc.volume_count > 0u || sc.atm_on) {  // the media variants carry no traversal counters
         if (lds_scene) { if (first) VPT_LAUNCH_BOUNCE_V(true, false, true, true); else VPT_LAUNCH_BOUNCE_V(true, false, false, true); }
         else { if (first) VPT_LAUNCH_BOUNCE_V(false, false, true, true); else VPT_LAUNCH_BOUNCE_V(false, false, false, true); }
     } else if (lds_scene) {

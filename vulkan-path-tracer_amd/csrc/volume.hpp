@@ -116,11 +116,10 @@ __device__ inline float does_ray_scatter(const vpt_volume& v, V3 org, V3 dir, Rn
     if (sd < inside) return max_(is.tn, 0.0f) + sd;
     return -1.0f;
 }
-// ScatteredInVolume, RayGen.slang:162-263 without the atmosphere: boxes in order of entry distance (the
-// reference's exchange sort, reproduced literally because ties are common and it is not stable), each crossed
-// box draws a free-flight distance, the nearest scatter wins if it lies before the geometry (`dgeo` =
-// GetDistanceToGeometry, < 0: none).  Returns the box index or -1; `sd` = scatter distance.
-__device__ inline int scattered_in_volume(const DeviceScene& sc, V3 org, V3 dir, Rng& r, float dgeo, float& sd) {
+// The box part of ScatteredInVolume, RayGen.slang:162-210: boxes in order of entry distance (the reference's
+// exchange sort, reproduced literally because ties are common and it is not stable), each crossed box draws a
+// free-flight distance, the nearest scatter wins.  Returns the box index or -1; `sd` = its distance (-1: none).
+__device__ inline int nearest_box_scatter(const DeviceScene& sc, V3 org, V3 dir, Rng& r, float& sd) {
     const int n = (int)sc.volume_count;
     float dist[VPT_MAX_VOLUMES]; int idx[VPT_MAX_VOLUMES];
     for (int i = 0; i < n; i++) {
@@ -135,8 +134,7 @@ __device__ inline int scattered_in_volume(const DeviceScene& sc, V3 org, V3 dir,
         float t = does_ray_scatter(sc.volumes[idx[i]], org, dir, r, sd);
         if (t >= 0.0f && (t < sd || sd < 0.0f)) { sd = t; sv = idx[i]; }
     }
-    if (sd >= 0.0f && (dgeo < 0.0f || sd < dgeo)) return sv;
-    return -1;
+    return sv;
 }
 
 }  // namespace vpt

@@ -149,7 +149,7 @@ int alloc_render_buffers(vpt_ctx* c) {
     if (cap64 >= (1ull << 31)) return fail(c, VPT_ERR_INVALID_ARGUMENT, "too many paths in flight");
     uint32_t cap = (uint32_t)cap64;
     // 15 float4 records + 4 dword arrays per slot (device_types.hpp PathState)
-    const size_t kRecords = 15, kWords = 4;
+    const size_t kRecords = 15, kWords = 5;
     size_t stride = ((size_t)cap + 63) & ~(size_t)63;
     HIPCHK(c, hipMalloc(&c->ps_block, stride * (16 * kRecords + 4 * kWords)));
     float4* rb = (float4*)c->ps_block;
@@ -162,7 +162,7 @@ int alloc_render_buffers(vpt_ctx* c) {
     s.L = next4(); s.ACC = next4(); s.M = next4();
     if (k != kRecords) return fail(c, VPT_ERR_DEVICE, "internal: path state carve mismatch");
     uint32_t* wb = (uint32_t*)(rb + stride * kRecords);
-    s.hinst = wb; s.maniso = (float*)(wb + stride); s.sidx = wb + stride * 2; s.vdepth = wb + stride * 3;
+    s.hinst = wb; s.maniso = (float*)(wb + stride); s.sidx = wb + stride * 2; s.vdepth = wb + stride * 3; s.cchan = (int32_t*)(wb + stride * 4);
     for (int i = 0; i < 2; i++) HIPCHK(c, hipMalloc((void**)&c->queue[i], (size_t)cap * 4));
     HIPCHK(c, hipMalloc((void**)&c->cqueue, (size_t)cap * 4));
     HIPCHK(c, hipMalloc((void**)&c->image, (size_t)P.shard_pixels * 16));
@@ -303,7 +303,7 @@ int render_batch(vpt_ctx* c, uint32_t frames, uint32_t dispatch_base) {
     const bool count = c->cfg.count_traversal != 0;
     // fused (one kernel per bounce, bounce 0 included) when the BVH rides in LDS; staged otherwise
     // volumes are integrated in the fused per-bounce kernel only
-    const bool vol = !c->volumes.empty();
+    const bool vol = !c->volumes.empty() || c->dsc.atm_on;
     const bool fused = vol || c->cfg.pipeline == VPT_PIPELINE_FUSED || (c->cfg.pipeline == VPT_PIPELINE_AUTO && (c->lds_scene || c->auto_fused));
     Counters init{};
     if (!fused) init.ray_count[0] = n_slots;
@@ -653,6 +653,25 @@ int vpt_set_volumes(vpt_ctx* c, const vpt_volume* v, uint32_t count) {
         HIPCHK(c, hipMemcpy(c->d_volumes, v, (size_t)count * sizeof(vpt_volume), hipMemcpyHostToDevice));
     }
     c->dsc.volumes = c->d_volumes; c->dsc.volume_count = count; c->dsc.phase = c->phase;
+    reset_accum(c);
+    return VPT_OK;
+}
+void vpt_default_atmosphere(vpt_atmosphere* a) {  // PathTracer.h:222-232
+    if (!a) return;
+    a->planet_position[0] = 0.0f; a->planet_position[1] = 6360e3f + 1000.0f; a->planet_position[2] = 0.0f;
+    a->planet_radius = 6360e3f; a->atmosphere_height = 100e3f;
+    a->rayleigh_density_falloff = 8000.0f; a->mie_density_falloff = 1200.0f; a->ozone_density_falloff = 5000.0f; a->ozone_peak = 22000.0f;
+    for (int k = 0; k < 3; k++) { a->rayleigh_multiplier[k] = 1.0f; a->mie_multiplier[k] = 1.0f; a->ozone_multiplier[k] = 1.0f; }
+    a->sun_color[0] = 1.0f; a->sun_color[1] = 0.956f; a->sun_color[2] = 0.88f;
+}
+int vpt_set_atmosphere(vpt_ctx* c, const vpt_atmosphere* a) {
+    if (!c) return VPT_ERR_INVALID_ARGUMENT;
+    if (a && c->cfg.pipeline == VPT_PIPELINE_STAGED) return fail(c, VPT_ERR_UNSUPPORTED, "the atmosphere runs on the fused pipeline (use VPT_PIPELINE_AUTO or _FUSED)");
+    if (a && (!(a->planet_radius > 0.0f) || !(a->atmosphere_height > 0.0f) || !(a->rayleigh_density_falloff > 0.0f) || !(a->mie_density_falloff > 0.0f) ||
+              !(a->ozone_density_falloff > 0.0f)))
+        return fail(c, VPT_ERR_INVALID_ARGUMENT, "planet radius, atmosphere height and the density falloffs must be > 0");
+    c->dsc.atm_on = a ? 1u : 0u;
+    if (a) c->dsc.atm = *a;
     reset_accum(c);
     return VPT_OK;
 }

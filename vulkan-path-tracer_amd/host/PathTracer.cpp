@@ -76,6 +76,7 @@ void PathTracer::SetScene(const SceneAsset& sceneIn) {
     Check(vpt_set_params(m_Ctx, &m_Params), "vpt_set_params");
     Check(vpt_set_camera(m_Ctx, m_CameraViewInverse.m, m_CameraProjectionInverse.m), "vpt_set_camera");
     UploadVolumes();
+    UploadAtmosphere();
 }
 
 // VolumeGPU(const Volume&), PathTracer.h:374-399: the box goes to world space on upload.
@@ -96,6 +97,11 @@ void PathTracer::UploadVolumes() {
     }
     Check(vpt_set_phase_function(m_Ctx, (uint32_t)m_PhaseFunction), "vpt_set_phase_function");
     Check(vpt_set_volumes(m_Ctx, g.data(), (uint32_t)g.size()), "vpt_set_volumes");
+    m_SamplesAccumulated = 0; m_DispatchCount = 0;
+}
+void PathTracer::UploadAtmosphere() {
+    if (!m_Ctx) return;
+    Check(vpt_set_atmosphere(m_Ctx, m_EnableAtmosphere ? &m_Atmosphere : nullptr), "vpt_set_atmosphere");
     m_SamplesAccumulated = 0; m_DispatchCount = 0;
 }
 void PathTracer::AddVolume(const Volume& volume) { m_Volumes.push_back(volume); UploadVolumes(); }

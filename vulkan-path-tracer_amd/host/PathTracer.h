@@ -71,6 +71,21 @@ public:
     [[nodiscard]] uint32_t GetVolumesCount() const { return (uint32_t)m_Volumes.size(); }
     [[nodiscard]] const std::vector<Volume>& GetVolumes() const { return m_Volumes; }
     [[nodiscard]] PhaseFunction GetPhaseFunction() const { return m_PhaseFunction; }
+    // Atmosphere (PathTracer.h:133-144, 168-179; defaults :221-232).  The sun direction is SkyAzimuth / SkyAltitude.
+    void SetEnableAtmosphere(bool enable) { m_EnableAtmosphere = enable; UploadAtmosphere(); }
+    void SetPlanetPosition(Vec3 p) { m_Atmosphere.planet_position[0] = p.x; m_Atmosphere.planet_position[1] = p.y; m_Atmosphere.planet_position[2] = p.z; UploadAtmosphere(); }
+    void SetPlanetRadius(float v) { m_Atmosphere.planet_radius = v; UploadAtmosphere(); }
+    void SetAtmosphereHeight(float v) { m_Atmosphere.atmosphere_height = v; UploadAtmosphere(); }
+    void SetRayleighScatteringCoefficientMultiplier(Vec3 m) { Set3(m_Atmosphere.rayleigh_multiplier, m); }
+    void SetMieScatteringCoefficientMultiplier(Vec3 m) { Set3(m_Atmosphere.mie_multiplier, m); }
+    void SetOzoneAbsorptionCoefficientMultiplier(Vec3 m) { Set3(m_Atmosphere.ozone_multiplier, m); }
+    void SetRayleighDensityFalloff(float v) { m_Atmosphere.rayleigh_density_falloff = v; UploadAtmosphere(); }
+    void SetMieDensityFalloff(float v) { m_Atmosphere.mie_density_falloff = v; UploadAtmosphere(); }
+    void SetOzoneDensityFalloff(float v) { m_Atmosphere.ozone_density_falloff = v; UploadAtmosphere(); }
+    void SetOzonePeak(float v) { m_Atmosphere.ozone_peak = v; UploadAtmosphere(); }
+    void SetSunColor(Vec3 c) { Set3(m_Atmosphere.sun_color, c); }
+    [[nodiscard]] bool IsAtmosphereEnabled() const { return m_EnableAtmosphere; }
+    [[nodiscard]] const vpt_atmosphere& GetAtmosphere() const { return m_Atmosphere; }
     void SetCameraViewInverse(const Mat4& view);
     void SetCameraProjectionInverse(const Mat4& projection);
     void SetMaxSamplesAccumulated(uint32_t v) { m_Params.max_samples = v; Push(false); }
@@ -124,6 +139,8 @@ private:
     void Push(bool resets);
     void UploadScene();
     void UploadVolumes();
+    void UploadAtmosphere();
+    void Set3(float* dst, Vec3 v) { dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; UploadAtmosphere(); }
 
     int m_Device = 0;
     vpt_ctx* m_Ctx = nullptr;
@@ -142,6 +159,8 @@ private:
     std::string m_EnvMapFilepath;
     std::vector<float> m_Output;
     std::vector<Volume> m_Volumes;
+    bool m_EnableAtmosphere = false;  // PathTracer.h:221
+    vpt_atmosphere m_Atmosphere = [] { vpt_atmosphere a; vpt_default_atmosphere(&a); return a; }();
     PhaseFunction m_PhaseFunction = PhaseFunction::HENYEY_GREENSTEIN;  // PathTracer.h:219
 };
 

@@ -2,7 +2,7 @@
 // load a glTF scene, run PathTrace() until the sample budget is spent, post-process, write the images.
 //   vpt_render --scene S.gltf --luts lookup_tables.bin [--size WxH] [--spp N] [--depth D] [--seed K] [--split S]
 //              [--env-constant r,g,b] [--radiance out.f32] [--camera out.f32] [--ppm out.ppm] [--info] [--dump-scene out.bin]
-//              [--env-hdr sky.hdr] [--png out.png]
+//              [--env-hdr sky.hdr] [--png out.png] [--atmosphere] [--sun altitude,azimuth]
 //              [--volume minx,miny,minz,maxx,maxy,maxz,density,g,r,g,b]... [--phase hg|draine|hg+draine]
 //   vpt_render --make-lut reflect|refract-above|refract-below --lut-samples N [--lut-size XxYxZ] [--lut-time-seed T] --lut-out table.bin
 //              (Application.cpp:38-77: the three tables the reference regenerates with 10'000'000 samples)
@@ -30,7 +30,7 @@ static void write_file(const std::string& path, const void* data, size_t bytes) 
 
 int main(int argc, char** argv) {
     std::string scene, luts, radiance, camera, ppm, png, envHdr, dumpEnv, pngTest, dump, makeLut, lutOut;
-    std::vector<PathTracer::Volume> volumes; int phase = 0;
+    std::vector<PathTracer::Volume> volumes; int phase = 0; bool atmosphere = false; float sunAlt = 0.0f, sunAz = 0.0f;
     uint32_t lutSamples = 10000000u, lutTime = 0; UVec3 lutSize{0, 0, 0};
     uint32_t w = 0, h = 0, spp = 16, depth = 8, seed = 1, split = 1;
     bool info = false, selftest = false; float env[3] = {0, 0, 0}; bool haveEnv = false;
@@ -62,6 +62,8 @@ int main(int argc, char** argv) {
             volumes.push_back(v);
         }
         else if (a == "--phase") { std::string s = next(); phase = s == "hg" ? 0 : s == "draine" ? 1 : s == "hg+draine" ? 2 : -1; if (phase < 0) { fprintf(stderr, "--phase hg|draine|hg+draine\n"); return 2; } }
+        else if (a == "--atmosphere") atmosphere = true;
+        else if (a == "--sun") { std::string s = next(); if (sscanf(s.c_str(), "%f,%f", &sunAlt, &sunAz) != 2) { fprintf(stderr, "--sun altitude,azimuth\n"); return 2; } }
         else if (a == "--make-lut") makeLut = next();
         else if (a == "--lut-samples") lutSamples = (uint32_t)strtoul(next().c_str(), nullptr, 10);
         else if (a == "--lut-time-seed") lutTime = (uint32_t)strtoul(next().c_str(), nullptr, 10);
@@ -163,6 +165,8 @@ int main(int argc, char** argv) {
         pt.SetMaxDepth(depth); pt.SetSeed(seed); pt.SetSplitScreenCount(split); pt.SetMaxSamplesAccumulated(spp);
         if (phase != 0) pt.SetPhaseFunction((PathTracer::PhaseFunction)phase);
         for (const auto& v : volumes) pt.AddVolume(v);
+        if (sunAlt != 0.0f || sunAz != 0.0f) { pt.SetSkyAltitude(sunAlt); pt.SetSkyAzimuth(sunAz); }
+        if (atmosphere) pt.SetEnableAtmosphere(true);
         auto t0 = std::chrono::steady_clock::now();
         while (!pt.PathTrace(64)) {}
         double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
