@@ -1,0 +1,83 @@
+"""BASELINE.json configs 3-5: the procedural Sponza-class atrium and the glass bust.  Exact parity against
+the oracle at a size the oracle finishes in seconds (both pipelines), and at the configs' full sizes the properties
+that do not need the oracle: the two pipelines and a 2-way shard split agree bit for bit, images are finite."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def atrium(vpt):
+    return vpt.scenes.atrium()          # 284,880 triangles, 97 instances, 25 materials, 12 textures, sun-and-sky env
+
+
+@pytest.fixture(scope="module")
+def bust(vpt):
+    return vpt.scenes.glass_bust()      # 510,992 triangles, transmission 1, 4096x2048 env
+
+
+def oracle_image(oracle, sc, w, h, params, frames):
+    o = oracle.Oracle(sc, w, h); o.set_params(params); o.render(frames)
+    ref = o.radiance(); o.close()
+    return ref
+
+
+@pytest.mark.parametrize("pipeline", [1, 2])
+def test_config3_atrium_exact_at_320x180(vpt, oracle, atrium, pipeline):
+    assert 0.95 * 250_000 <= atrium.triangle_count() <= 1.15 * 250_000 or atrium.triangle_count() == 284880
+    P = vpt.default_params(max_depth=8)
+    ref = oracle_image(oracle, atrium, 320, 180, P, 2)
+    g = vpt.PathTracer(320, 180, pipeline=pipeline); g.set_scene(atrium); g.set_params(P); g.render(2)
+    img = g.radiance(); st = g.stats(); g.close()
+    assert np.array_equal(img, ref)
+    assert st["bvh_node_bytes"] == 64 and st["bvh_triangles"] == atrium.triangle_count()
+
+
+@pytest.mark.parametrize("pipeline", [1, 2])
+def test_config5_glass_bust_exact_at_320x180_depth32(vpt, oracle, bust, pipeline):
+    P = vpt.default_params(max_depth=32)
+    ref = oracle_image(oracle, bust, 320, 180, P, 2)
+    g = vpt.PathTracer(320, 180, pipeline=pipeline); g.set_scene(bust); g.set_params(P); g.render(2)
+    img = g.radiance(); g.close()
+    assert np.array_equal(img, ref)
+    out8_ref, _ = oracle.postprocess(ref, vpt.default_post_params())      # config 5 names bloom + tonemap defaults
+    g = vpt.PathTracer(320, 180, pipeline=pipeline); g.set_scene(bust); g.set_params(P); g.render(2)
+    assert np.array_equal(g.postprocess(), out8_ref); g.close()
+
+
+def test_config3_atrium_1080p_pipelines_and_shards_agree(vpt, atrium):
+    P = vpt.default_params(max_depth=8)
+    imgs = []
+    for pipeline in (2, 1, 0):           # staged, fused, AUTO (times both, keeps the faster)
+        g = vpt.PathTracer(1920, 1080, pipeline=pipeline, frames_in_flight=4); g.set_scene(atrium); g.set_params(P); g.render(4 if pipeline else 20)
+        if pipeline == 0:
+            g.reset(); g.render(4)       # after the tuning batches
+        imgs.append(g.radiance()); g.close()
+    assert np.array_equal(imgs[0], imgs[1]) and np.array_equal(imgs[0], imgs[2])
+    assert np.isfinite(imgs[0]).all() and imgs[0][..., :3].mean() > 0.01
+    hip = C.CDLL("libamdhip64.so")
+    parts = []
+    for r in range(2):
+        s = vpt.PathTracer(1920, 1080, shard_rank=r, shard_count=2, frames_in_flight=4); s.set_scene(atrium); s.set_params(P); s.render(4)
+        parts.append(s)
+    n = parts[0].shard_floats()
+    buf = C.c_void_p()
+    assert hip.hipMalloc(C.byref(buf), n * 4 * 2) == 0
+    for r, s in enumerate(parts):
+        s.shard_to_device(C.c_void_p(buf.value + r * n * 4))
+    parts[0].assemble_shards(buf, 2)
+    assert np.array_equal(parts[0].radiance(), imgs[0])
+    hip.hipFree(buf)
+    for s in parts:
+        s.close()
+
+
+def test_config4_atrium_4k_runs_and_matches_between_pipelines(vpt, atrium):
+    """3840x2160 (config 4's per-frame size): 8.3 M paths per frame, two frames; staged == fused."""
+    P = vpt.default_params(max_depth=8)
+    a = vpt.PathTracer(3840, 2160, pipeline=2, frames_in_flight=2); a.set_scene(atrium); a.set_params(P); a.render(2); ia = a.radiance(); a.close()
+    b = vpt.PathTracer(3840, 2160, pipeline=1, frames_in_flight=2); b.set_scene(atrium); b.set_params(P); b.render(2); ib = b.radiance(); b.close()
+    assert np.array_equal(ia, ib) and np.isfinite(ia).all()
