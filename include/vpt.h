@@ -234,8 +234,9 @@ int vpt_get_material(const vpt_ctx* ctx, uint32_t index, vpt_material* out);
 /* ---- participating media: homogeneous box volumes ---------------------------------
  * PathTracer::Volume / VolumeGPU (PathTracer.h:36-74, 341-400) as the shaders read it (Volume.slang:19-52).
  * corner_min / corner_max are the WORLD-space box, i.e. Position + Corner * Scale already applied
- * (PathTracer.h:395-396).  Heterogeneous (NanoVDB) density / temperature grids are not implemented:
- * density_data_index must be -1.  The integrator side is RayGen.slang:162-380 (free-flight sampling per box,
+ * (PathTracer.h:395-396).  Heterogeneous volumes take their density from a DENSE grid (vpt_add_density_grid below:
+ * the OpenVDB / NanoVDB tree of the reference, densified); temperature grids / blackbody emission are not implemented.
+ * The integrator side is RayGen.slang:162-380 (free-flight sampling per box,
  * nearest scatter vs. distance to geometry, NEE towards sky and emissive meshes through every box's Beer-Lambert
  * transmittance, phase-function scattering) and ClosestHit.slang:332-333,364 (volumes shadow surface NEE). */
 typedef struct vpt_volume {
@@ -247,9 +248,10 @@ typedef struct vpt_volume {
     float anisotropy;            /* g of Henyey-Greenstein / Draine */
     float alpha;                 /* Draine alpha */
     float droplet_size;          /* HG+Draine fit parameter d (micrometres) */
-    int32_t density_data_index;  /* -1: homogeneous (the only supported value) */
-    int32_t approximated_scattering;          /* ApproximatedScatteringForClouds: g^(1+depth) */
+    int32_t density_data_index;  /* -1: homogeneous; >= 0: a grid added with vpt_add_density_grid */
+    int32_t approximated_scattering;          /* ApproximatedScatteringForClouds: g^(1+depth), density * falloff^depth */
     float approximated_scattering_falloff;
+    float grid_sharpness;                     /* GridSharpness (heterogeneous only) */
 } vpt_volume;
 #define VPT_MAX_VOLUMES 32       /* the reference sorts into fixed float[100] / int[100] arrays (RayGen.slang:165-166) */
 #define VPT_PHASE_HENYEY_GREENSTEIN 0        /* PathTracer.h:76-81 PhaseFunction */
@@ -258,6 +260,16 @@ typedef struct vpt_volume {
 /* AddVolume / RemoveVolume / SetVolume (PathTracer.h:157-159): the whole list is replaced; count 0 removes all
  * volumes.  Resets accumulation. */
 int vpt_set_volumes(vpt_ctx* ctx, const vpt_volume* volumes, uint32_t count);
+/* AddDensityDataToVolume (PathTracer.cpp:1347-1516) with the .vdb file already decoded by the caller: a dense grid of
+ * raw densities over the active-voxel bounding box (x fastest, then y, then z, in the file's index order).  The library
+ * does what the reference does after reading the file: MaxDensityInTheGrid, the 32x32x32 table of per-block maxima of
+ * density / max used for empty-space skipping (y flipped "for Vulkan", :1425-1442), upload.  Lookups mirror
+ * SampleNanoVDBBuffer (Volume.slang:69-117): position normalised in the box, y flipped, floor to a voxel, +-1 voxel
+ * of random jitter per axis (three PCG draws), clamp to the grid.  Returns the grid's index (the value to put in
+ * vpt_volume.density_data_index) or a negative VPT_ERR_*.  At most VPT_MAX_DENSITY_GRIDS grids. */
+#define VPT_MAX_DENSITY_GRIDS 16
+int vpt_add_density_grid(vpt_ctx* ctx, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z, const float* density);
+int vpt_clear_density_grids(vpt_ctx* ctx);   /* RemoveDensityDataFromVolume for all; volumes must not reference grids afterwards */
 /* SetPhaseFunction (PathTracer.h:106); default VPT_PHASE_HENYEY_GREENSTEIN (PathTracer.h:219).  Resets accumulation. */
 int vpt_set_phase_function(vpt_ctx* ctx, uint32_t phase_function);
 /* ---- atmosphere ----------------------------------------------------------------------

@@ -45,6 +45,8 @@ VPT_HD float min_(float a, float b) { return (b < a) ? b : a; }
 VPT_HD float max_(float a, float b) { return (a < b) ? b : a; }
 VPT_HD float clamp_(float x, float lo, float hi) { return min_(max_(x, lo), hi); }
 VPT_HD float saturate_(float x) { return clamp_(x, 0.0f, 1.0f); }
+// float -> int with the out-of-range cases pinned (a bare cast differs between x86 and gfx950 there): NaN and x < lo give lo
+VPT_HD int f2i_clamped(float x, int lo, int hi) { if (!(x >= (float)lo)) return lo; if (x >= (float)hi) return hi; return (int)x; }
 
 // ---------------------------------------------------------------- RNG
 // PCG hash, reference Sampler.slang:4-9 == PathTracer.cpp:130-134.

@@ -108,6 +108,8 @@ struct Oracle {
     Counters ctr;
     std::vector<vpt_volume> volumes;  // uVolumes (Volume.slang:9), homogeneous only
     bool atm_on = false;              // ENABLE_ATMOSPHERE
+    struct DensityGrid { uint32_t dim[3]; float max_density; std::vector<float> values, block_max; };
+    std::vector<DensityGrid> grids;   // uNanoVDBBuffersDensity / uVolumeMaxDensities, densified
     vpt_atmosphere atm;
     uint32_t phase = VPT_PHASE_HENYEY_GREENSTEIN;  // PHASE_FUNCTION_* define (PathTracer.h:219)
 };
@@ -834,24 +836,140 @@ float volume_phase(const Oracle& o, const vpt_volume& v, V3 V, V3 L, uint32_t de
     HgDraineFit f = hg_draine_fit(v.droplet_size);
     return lerp(phase_hg(V, L, f.ghg), phase_draine(V, L, f.gd, f.alpha_d), f.w_d);
 }
-// Volume::CalculateVolumesTransmittance, Volume.slang:419-446 (homogeneous branch: Beer-Lambert per box)
-float volumes_transmittance(const Oracle& o, V3 org, V3 dir) {
+// ---- heterogeneous boxes: density from a dense grid (the reference's NanoVDB tree, densified) --------------------
+float effective_density(const vpt_volume& v, float base, float depth) {  // Volume.slang:149-156
+    if (v.approximated_scattering != 0) return base * pow_(v.approximated_scattering_falloff, depth);
+    return base;
+}
+// SampleNanoVDBBuffer, Volume.slang:69-117, on a dense grid whose index box is [0, dim): normalise in the box, flip y,
+// floor to a voxel, jitter by -1..1 voxels per axis (three raw PCG draws), clamp, value / max * sharpness in [0, 1].
+float sample_density_grid(const Oracle& o, const vpt_volume& v, Rng& r, V3 x) {
+    const Oracle::DensityGrid& g = o.grids[v.density_data_index];
+    V3 n = (x - P3(v.corner_min)) / (P3(v.corner_max) - P3(v.corner_min));
+    n.y = 1.0f - n.y;
+    V3 gp = n * v3((float)g.dim[0], (float)g.dim[1], (float)g.dim[2]);
+    int cx = f2i_clamped(floor_(gp.x), -1, (int)g.dim[0]), cy = f2i_clamped(floor_(gp.y), -1, (int)g.dim[1]), cz = f2i_clamped(floor_(gp.z), -1, (int)g.dim[2]);
+    r.s = pcg_hash(r.s); cx += (int)(r.s % 3u) - 1;
+    r.s = pcg_hash(r.s); cy += (int)(r.s % 3u) - 1;
+    r.s = pcg_hash(r.s); cz += (int)(r.s % 3u) - 1;
+    cx = std::min(std::max(cx, 0), (int)g.dim[0] - 1); cy = std::min(std::max(cy, 0), (int)g.dim[1] - 1); cz = std::min(std::max(cz, 0), (int)g.dim[2] - 1);
+    float value = g.values[(size_t)cx + (size_t)cy * g.dim[0] + (size_t)cz * g.dim[0] * g.dim[1]];
+    return clamp_(value / g.max_density * v.grid_sharpness, 0.0f, 1.0f);
+}
+struct VolBlock { int index; V3 lo, hi; };
+struct VolTrav { V3 block_size; float eps, t_enter, t_exit; };
+VolTrav make_traversal(const vpt_volume& v, VolIsect is) {  // Volume.slang:119-127
+    VolTrav c;
+    V3 ext = P3(v.corner_max) - P3(v.corner_min);
+    c.block_size = ext / v3s(32.0f);
+    c.eps = 0.0001f * max_(ext.x, max_(ext.y, ext.z));
+    c.t_enter = max_(is.tn, 0.0f);
+    c.t_exit = is.tf;
+    return c;
+}
+VolBlock block_info(const vpt_volume& v, V3 pos, const VolTrav& c) {  // Volume.slang:129-147
+    V3 rel = (pos - P3(v.corner_min)) / (P3(v.corner_max) - P3(v.corner_min));
+    int ix = f2i_clamped(rel.x * 32.0f, 0, 31), iy = f2i_clamped(rel.y * 32.0f, 0, 31), iz = f2i_clamped(rel.z * 32.0f, 0, 31);
+    VolBlock b;
+    b.index = ix + iy * 32 + iz * 32 * 32;
+    b.lo = P3(v.corner_min) + c.block_size * v3((float)ix, (float)iy, (float)iz);
+    b.hi = b.lo + c.block_size;
+    return b;
+}
+VolIsect ray_aabb3(V3 org, V3 dir, V3 lo, V3 hi) { float a[3] = {lo.x, lo.y, lo.z}, b[3] = {hi.x, hi.y, hi.z}; return ray_aabb(org, dir, a, b); }
+// ProcessHeterogeneousVolumeScattering, Volume.slang:299-348: delta tracking block by block
+float heterogeneous_scatter(const Oracle& o, const vpt_volume& v, V3 org, V3 dir, Rng& r, float depth, VolIsect is) {
+    const Oracle::DensityGrid& g = o.grids[v.density_data_index];
+    VolTrav c = make_traversal(v, is);
+    VolBlock b = block_info(v, org + dir * (c.t_enter + c.eps), c);
+    float t = 0.0f;
+    for (int i = 0; i < 10000; i++) {
+        V3 cur = org + dir * (c.t_enter + t + c.eps);
+        VolIsect bi = ray_aabb3(cur, dir, b.lo, b.hi);
+        float maxd = effective_density(v, g.block_max[b.index] * v.density, depth);
+        float sd = -log_(r.uf()) / maxd;
+        if (bi.tf <= 0.0f) {
+            t += c.eps;
+            if (c.t_enter + t > c.t_exit) return -1.0f;
+            b = block_info(v, org + dir * (c.t_enter + t + c.eps), c);
+            continue;
+        }
+        float to_exit = bi.tf - max_(bi.tn, 0.0f);
+        if (sd > to_exit) {
+            t += to_exit + c.eps;
+            if (c.t_enter + t > c.t_exit) return -1.0f;
+            b = block_info(v, org + dir * (c.t_enter + t + c.eps), c);
+            continue;
+        }
+        t += sd;
+        if (c.t_enter + t > c.t_exit) return -1.0f;
+        V3 pos = org + dir * (c.t_enter + t);
+        float dens = effective_density(v, sample_density_grid(o, v, r, pos) * v.density, depth);
+        if (dens / maxd < r.uf()) continue;
+        return c.t_enter + t;
+    }
+    return -1.0f;
+}
+// ProcessHeterogeneousVolumeTransmittance, Volume.slang:448-520: ratio tracking + roulette, block by block
+float heterogeneous_transmittance(const Oracle& o, const vpt_volume& v, Rng& r, V3 org, V3 dir, float depth, VolIsect is) {
+    const Oracle::DensityGrid& g = o.grids[v.density_data_index];
+    VolTrav c = make_traversal(v, is);
+    VolBlock b = block_info(v, org + dir * (c.t_enter + c.eps), c);
+    float tr = 1.0f, t = 0.0f;
+    for (int j = 0; j < 1000; j++) {
+        V3 cur = org + dir * (c.t_enter + t + c.eps);
+        VolIsect bi = ray_aabb3(cur, dir, b.lo, b.hi);
+        float maxd = effective_density(v, g.block_max[b.index] * v.density, depth);
+        float sd = -log_(r.uf()) / maxd;
+        if (bi.tf <= 0.0f) {
+            t += c.eps;
+            if (c.t_enter + t > c.t_exit) break;
+            b = block_info(v, org + dir * (c.t_enter + t + c.eps), c);
+            continue;
+        }
+        float to_exit = bi.tf - max_(bi.tn, 0.0f);
+        if (sd > to_exit) {
+            t += to_exit + c.eps;
+            if (c.t_enter + t > c.t_exit) break;
+            b = block_info(v, org + dir * (c.t_enter + t + c.eps), c);
+            continue;
+        }
+        t += sd;
+        if (c.t_enter + t > c.t_exit) break;
+        V3 pos = org + dir * (c.t_enter + t);
+        float dens = effective_density(v, sample_density_grid(o, v, r, pos) * v.density, depth);
+        tr *= 1.0f - (dens / maxd);
+        float p = tr;
+        if (r.uf() > p) return 0.0f;
+        tr /= p;
+    }
+    return tr;
+}
+// Volume::CalculateVolumesTransmittance, Volume.slang:419-446: Beer-Lambert for homogeneous boxes, tracked (random
+// draws) for heterogeneous ones
+float volumes_transmittance(const Oracle& o, Rng& r, V3 org, V3 dir, float depth) {
     float tr = 1.0f;
     for (const vpt_volume& v : o.volumes) {
         VolIsect is = ray_aabb(org, dir, v.corner_min, v.corner_max);
         is.tn = max_(is.tn, 0.0f);
-        float len = is.tf - is.tn;
-        if (len > 0.0f) tr *= exp_(-v.density * len);
+        if (v.density_data_index >= 0 && is.tf >= 0.0f) {
+            tr *= heterogeneous_transmittance(o, v, r, org, dir, depth, is);
+            if (tr <= 0.0f) return 0.0f;
+        } else {
+            float len = is.tf - is.tn;
+            if (len > 0.0f) tr *= exp_(-v.density * len);
+        }
     }
     return clamp_(tr, 0.0f, 1.0f);
 }
-// Volume::DoesRayScatterInVolume, Volume.slang:261-297 (homogeneous branch)
-float does_ray_scatter(const vpt_volume& v, V3 org, V3 dir, Rng& r, float ignore_if_farther) {
+// Volume::DoesRayScatterInVolume, Volume.slang:261-297
+float does_ray_scatter(const Oracle& o, const vpt_volume& v, V3 org, V3 dir, Rng& r, float depth, float ignore_if_farther) {
     VolIsect is = ray_aabb(org, dir, v.corner_min, v.corner_max);
     if (is.tf < 0.0f) return -1.0f;
     if (ignore_if_farther >= 0.0f && is.tn > ignore_if_farther) return -1.0f;
     float inside = is.tf - max_(is.tn, 0.0f);
     if (inside <= 0.0f) return -1.0f;
+    if (v.density_data_index >= 0) return heterogeneous_scatter(o, v, org, dir, r, depth, is);
     float sd = -log_(r.uf()) / v.density;  // Sampler.slang:425-428
     if (sd < inside) return max_(is.tn, 0.0f) + sd;
     return -1.0f;
@@ -885,14 +1003,14 @@ void volume_scatter_event(const Oracle& o, Payload& p, float sd, int vi, Counter
     V3 sbxdf = P3(v.color) * ph;
     if ((o.P.flags & VPT_FLAG_SKY_MIS) && sky.w > 0.0f) {
         float ps = volume_phase(o, v, p.direction, to_sky, p.volume_depth);
-        V3 tr = v3s(volumes_transmittance(o, p.origin, to_sky));
+        V3 tr = v3s(volumes_transmittance(o, p.rng, p.origin, to_sky, (float)p.volume_depth));
         if (o.atm_on) tr = nee_atmosphere_transmittance(o, p.rng, tr, p.origin, to_sky, p.color_channel);  // :328-343
         V3 bx = P3(v.color) * ps;
         if (ps > 0.0f) p.emitted = p.emitted + ((tr * bx) * (v3(sky.x, sky.y, sky.z) / sky.w)) * power_heuristics(sky.w, ps);
     }
     if ((o.P.flags & VPT_FLAG_MESH_MIS) && lc.w > 0.0f) {
         float pl = volume_phase(o, v, p.direction, to_light, p.volume_depth);
-        V3 tr = v3s(volumes_transmittance(o, p.origin, to_light));
+        V3 tr = v3s(volumes_transmittance(o, p.rng, p.origin, to_light, (float)(p.volume_depth + 1u)));
         V3 bx = P3(v.color) * pl;
         if (pl > 0.0f) p.emitted = p.emitted + ((tr * bx) * (v3(lc.x, lc.y, lc.z) / lc.w)) * power_heuristics(lc.w, pl);
     }
@@ -917,7 +1035,7 @@ void atmosphere_scatter_event(const Oracle& o, Payload& p, float sd, int comp, C
         V3 tr = v3s(1.0f);
         if (!obscured) {
             tr = atmosphere_transmittance(o, p.rng, p.origin, to_sky, p.color_channel);
-            tr = tr * volumes_transmittance(o, p.origin, to_sky);
+            tr = tr * volumes_transmittance(o, p.rng, p.origin, to_sky, (float)p.volume_depth);
         } else {
             tr = v3s(0.0f);
         }
@@ -959,7 +1077,7 @@ bool scattered_in_volume(const Oracle& o, Payload& p, Counters* c) {
     if (closest_hit(o, p.origin, p.direction, 0.00001f, 1000000.0f, h, c)) dgeo = h.t;
     float sd = -1.0f; int sv = -1;
     for (int i = 0; i < n; i++) {
-        float t = does_ray_scatter(o.volumes[idx[i]], p.origin, p.direction, p.rng, sd);
+        float t = does_ray_scatter(o, o.volumes[idx[i]], p.origin, p.direction, p.rng, (float)p.depth, sd);
         if (t >= 0.0f && (t < sd || sd < 0.0f)) { sd = t; sv = idx[i]; }
     }
     int cc = p.color_channel, comp = -1;
@@ -1114,14 +1232,14 @@ void closest_hit_shader(const Oracle& o, Payload& p, V3 raydir, const Hit& hit, 
     p.bxdf = bs.bxdf; p.pdf = bs.pdf;
     if (o.P.flags & VPT_FLAG_SKY_MIS) {  // 323-355
         if (can_sky) {
-            V3 tr = v3s(volumes_transmittance(o, p.origin, to_sky));  // :332-333, from the NEW origin; 1 without volumes
+            V3 tr = v3s(volumes_transmittance(o, p.rng, p.origin, to_sky, 0.0f));  // :332-333, from the NEW origin; 1 without volumes
             if (o.atm_on) tr = nee_atmosphere_transmittance(o, p.rng, tr, p.origin, to_sky, p.color_channel);  // :335-349
             if (sky.w > 0.0f && sky_e.pdf > 0.0f)
                 p.emitted = p.emitted + (sky_e.bxdf * tr * v3(sky.x, sky.y, sky.z) / sky.w) * power_heuristics(sky.w, sky_e.pdf);
         }
     }
     if ((o.P.flags & VPT_FLAG_MESH_MIS) && !is_light && can_light && lc.w > 0.0f && light_e.pdf > 0.0f) {
-        V3 tr = v3s(volumes_transmittance(o, p.origin, to_light));  // :364
+        V3 tr = v3s(volumes_transmittance(o, p.rng, p.origin, to_light, 0.0f));  // :364
         p.emitted = p.emitted + (light_e.bxdf * tr * v3(lc.x, lc.y, lc.z) / lc.w) * power_heuristics(lc.w, light_e.pdf);
     }
     bool invalid = bs.pdf <= 0.0f;
@@ -1360,10 +1478,32 @@ void orc_set_material(void* h, uint32_t idx, const vpt_material* m) { Oracle* o 
 int orc_set_volumes(void* h, const vpt_volume* v, uint32_t n) {
     Oracle* o = (Oracle*)h;
     if (n > VPT_MAX_VOLUMES) return -1;
-    for (uint32_t i = 0; i < n; i++) if (v[i].density_data_index != -1) return -1;
+    for (uint32_t i = 0; i < n; i++) if (v[i].density_data_index < -1 || v[i].density_data_index >= (int)o->grids.size()) return -1;
     o->volumes.assign(v, v + n); orc_reset(h);
     return 0;
 }
+// AddDensityDataToVolume, PathTracer.cpp:1390-1442 on a dense grid: max density, 32^3 block maxima of density/max (y flipped)
+int orc_add_density_grid(void* h, uint32_t dx, uint32_t dy, uint32_t dz, const float* d) {
+    Oracle* o = (Oracle*)h;
+    Oracle::DensityGrid g;
+    g.dim[0] = dx; g.dim[1] = dy; g.dim[2] = dz;
+    g.values.assign(d, d + (size_t)dx * dy * dz);
+    float mx = 0.0f;
+    for (float v : g.values) mx = std::max(mx, v);
+    g.max_density = mx;
+    g.block_max.assign(32768, 0.0f);
+    for (uint32_t z = 0; z < dz; z++)
+        for (uint32_t y = 0; y < dy; y++)
+            for (uint32_t x = 0; x < dx; x++) {
+                float raw = g.values[(size_t)x + (size_t)(dy - 1 - y) * dx + (size_t)z * dx * dy];
+                float dens = clamp_(raw / mx, 0.0f, 1.0f);
+                uint32_t bi = ((x * 32u) / dx) + ((y * 32u) / dy) * 32u + ((z * 32u) / dz) * 1024u;
+                if (g.block_max[bi] < dens) g.block_max[bi] = dens;
+            }
+    o->grids.push_back(std::move(g));
+    return (int)o->grids.size() - 1;
+}
+void orc_clear_density_grids(void* h) { Oracle* o = (Oracle*)h; o->grids.clear(); orc_reset(h); }
 void orc_set_atmosphere(void* h, const vpt_atmosphere* a) {
     Oracle* o = (Oracle*)h;
     o->atm_on = a != nullptr;

@@ -36,6 +36,9 @@ def lib():
         L.orc_set_volumes.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
         L.orc_set_phase_function.argtypes = [C.c_void_p, C.c_uint32]
         L.orc_set_atmosphere.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_add_density_grid.restype = C.c_int
+        L.orc_add_density_grid.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.orc_clear_density_grids.argtypes = [C.c_void_p]
         L.orc_atmosphere_estimators.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_void_p]
         L.orc_render.restype = C.c_int
         L.orc_render.argtypes = [C.c_void_p, C.c_uint32, C.c_int]
@@ -113,6 +116,14 @@ class Oracle:
         arr = (_abi.Volume * max(len(volumes), 1))(*volumes)
         if self.L.orc_set_volumes(self.h_, arr, len(volumes)) != 0:
             raise ValueError("orc_set_volumes: too many volumes or heterogeneous volume")
+
+    def add_density_grid(self, grid):
+        """grid: float32 [z, y, x] raw densities -> index for volume(density_data_index=...)."""
+        g = np.ascontiguousarray(grid, np.float32)
+        return self.L.orc_add_density_grid(self.h_, g.shape[2], g.shape[1], g.shape[0], g.ctypes.data)
+
+    def clear_density_grids(self):
+        self.L.orc_clear_density_grids(self.h_)
 
     def set_atmosphere(self, atm):
         self.L.orc_set_atmosphere(self.h_, C.byref(atm) if atm is not None else None)

@@ -107,8 +107,8 @@ def test_camera_inside_volume_glass_scene_multisample_and_shards(vpt, oracle, sc
 
 def test_volume_argument_errors(vpt, scenes):
     g = vpt.PathTracer(32, 18); g.set_scene(scenes("cornell_box"))
-    with pytest.raises(vpt.VptError, match="UNSUPPORTED"):
-        v = vpt.volume(); v.density_data_index = 0
+    with pytest.raises(vpt.VptError, match="INVALID"):
+        v = vpt.volume(); v.density_data_index = 0   # no grid was added
         g.set_volumes([v])
     with pytest.raises(vpt.VptError, match="LIMIT"):
         g.set_volumes([vpt.volume()] * 33)
@@ -121,3 +121,44 @@ def test_volume_argument_errors(vpt, scenes):
     with pytest.raises(vpt.VptError, match="UNSUPPORTED"):
         s.set_volumes([vpt.volume()])
     s.close()
+
+
+@pytest.mark.parametrize("approx", [0, 1])
+def test_heterogeneous_cloud_in_cornell(vpt, oracle, scenes, approx):
+    """A dense-grid smoke cloud (delta-tracked scattering, ratio-tracked NEE transmittance — both draw random numbers,
+    the latter only for unobscured samples) next to a homogeneous fog box, under a lit env."""
+    from test_oracle_volumes import cloud_grid
+    sc = lit_env_scene(vpt, scenes)
+    grid = cloud_grid()
+    P = vpt.default_params(max_depth=10)
+    o = oracle.Oracle(sc, 160, 90); o.set_params(P)
+    gi = o.add_density_grid(grid)
+    g = vpt.PathTracer(160, 90); g.set_scene(sc); g.set_params(P)
+    assert g.add_density_grid(grid) == gi == 0
+    vols = [vpt.volume(corner_min=(-3.5, -8.0, -3.0), corner_max=(3.0, -1.0, 3.5), color=(0.85, 0.85, 0.9), density=1.6, anisotropy=0.5,
+                       density_data_index=gi, grid_sharpness=1.3, approximated_scattering=approx, approximated_scattering_falloff=0.7),
+            fog(vpt, density=0.05)]
+    o.set_volumes(vols); g.set_volumes(vols)
+    o.render(4); g.render(4)
+    ref = o.radiance(); img = g.radiance(); o.close()
+    assert_parity(img, ref)
+    with pytest.raises(vpt.VptError, match="INVALID"):
+        g.clear_density_grids()                      # still referenced
+    g.set_volumes([fog(vpt)]); g.clear_density_grids()
+    with pytest.raises(vpt.VptError, match="INVALID"):
+        g.set_volumes([vpt.volume(density_data_index=0)])   # no such grid any more
+    g.close()
+
+
+def test_heterogeneous_cloud_under_the_atmosphere(vpt, oracle, scenes):
+    """Everything that tracks at once: atmosphere collisions + sun NEE, a grid cloud, the Cornell room."""
+    from test_oracle_volumes import cloud_grid
+    sc = scenes("cornell_box")
+    P = vpt.default_params(max_depth=8, sky_altitude=-50.0, sky_azimuth=150.0)
+    o = oracle.Oracle(sc, 128, 72); o.set_params(P); gi = o.add_density_grid(cloud_grid(seed=5))
+    g = vpt.PathTracer(128, 72); g.set_scene(sc); g.set_params(P); g.add_density_grid(cloud_grid(seed=5))
+    vols = [vpt.volume(corner_min=(-4.0, -9.0, -4.0), corner_max=(4.0, -2.0, 4.0), color=(0.9, 0.9, 0.9), density=1.0, density_data_index=gi)]
+    for x in (o, g):
+        x.set_volumes(vols); x.set_atmosphere(vpt.atmosphere()); x.render(3)
+    ref = o.radiance(); img = g.radiance(); o.close(); g.close()
+    assert_parity(img, ref)

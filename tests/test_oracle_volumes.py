@@ -67,3 +67,35 @@ def test_no_volumes_is_the_plain_integrator(vpt, oracle, scenes):
     o.set_volumes([vpt.volume(corner_min=(900, 900, 900), corner_max=(901, 901, 901))]); o.render(2)
     far = o.radiance(); o.close()
     assert np.array_equal(base, far)
+
+
+def cloud_grid(shape=(40, 36, 48), seed=2):
+    """A smooth procedural 'smoke' density [z, y, x] (sum of Gaussian puffs), every axis >= 32 voxels so that the
+    reference's 32^3 block-maxima table has no holes (it is filled through `x * 32 / dim`, PathTracer.cpp:1439)."""
+    rng = np.random.default_rng(seed)
+    z, y, x = np.meshgrid(*[np.linspace(-1, 1, n) for n in shape], indexing="ij")
+    d = np.zeros(shape, np.float64)
+    for _ in range(7):
+        c = rng.uniform(-0.6, 0.6, 3); r = rng.uniform(0.2, 0.5)
+        d += rng.uniform(0.5, 2.0) * np.exp(-((x - c[0]) ** 2 + (y - c[1]) ** 2 + (z - c[2]) ** 2) / (r * r))
+    return d.astype(np.float32)
+
+
+def test_heterogeneous_slab_beer_lambert_and_furnace(vpt, oracle):
+    """Dense-grid volumes (the reference's NanoVDB path, densified): a constant grid behaves like the homogeneous box,
+    a half-filled grid like half the thickness, and an albedo-1 cloud in a white env stays white."""
+    sc = empty_scene(vpt)
+
+    def centre(grid, sigma, color, frames):
+        o = oracle.Oracle(sc, 64, 36)
+        o.set_params(vpt.default_params(max_depth=64, max_samples=1 << 30))
+        gi = o.add_density_grid(grid)
+        o.set_volumes([vpt.volume(corner_min=(-1, -1, -1), corner_max=(1, 1, 1), color=color, density=sigma, density_data_index=gi)])
+        o.render(frames)
+        img = o.radiance(); o.close()
+        return img[16:20, 30:34, :3].mean()
+    tol = 4 * np.sqrt(0.25 / (16 * 256)) + 0.01   # MC error + the epsilon steps between blocks (Volume.slang:124)
+    assert abs(centre(np.full((32, 32, 32), 3.0, np.float32), 0.7, (0, 0, 0), 256) - np.exp(-0.7 * 2)) < tol
+    half = np.zeros((64, 32, 32), np.float32); half[:32] = 2.0
+    assert abs(centre(half, 0.7, (0, 0, 0), 256) - np.exp(-0.7 * 1)) < tol + 0.01   # + the +-1 voxel jitter at the interface
+    assert abs(centre(cloud_grid(), 3.0, (1, 1, 1), 96) - 1.0) < 0.03

@@ -107,6 +107,17 @@ class PathTracer:
         arr = (_abi.Volume * max(len(volumes), 1))(*volumes)
         _check(self.lib, self.ctx, self.lib.vpt_set_volumes(self.ctx, arr, len(volumes)), "vpt_set_volumes")
 
+    def add_density_grid(self, grid):
+        """AddDensityDataToVolume with the .vdb already decoded: float32 [z, y, x] raw densities -> grid index."""
+        g = np.ascontiguousarray(grid, np.float32)
+        rc = self.lib.vpt_add_density_grid(self.ctx, g.shape[2], g.shape[1], g.shape[0], g.ctypes.data)
+        if rc < 0:
+            _check(self.lib, self.ctx, rc, "vpt_add_density_grid")
+        return rc
+
+    def clear_density_grids(self):
+        _check(self.lib, self.ctx, self.lib.vpt_clear_density_grids(self.ctx), "vpt_clear_density_grids")
+
     def set_atmosphere(self, atm):
         """SetEnableAtmosphere(True) + the planet/density setters; None disables (PathTracer.h:168-179)."""
         _check(self.lib, self.ctx, self.lib.vpt_set_atmosphere(self.ctx, C.byref(atm) if atm is not None else None), "vpt_set_atmosphere")

@@ -43,10 +43,11 @@ class Volume(C.Structure):  # vpt_volume
         ("corner_min", C.c_float * 3), ("corner_max", C.c_float * 3), ("color", C.c_float * 3), ("emissive_color", C.c_float * 3),
         ("density", C.c_float), ("anisotropy", C.c_float), ("alpha", C.c_float), ("droplet_size", C.c_float),
         ("density_data_index", C.c_int32), ("approximated_scattering", C.c_int32), ("approximated_scattering_falloff", C.c_float),
+        ("grid_sharpness", C.c_float),
     ]
 
 
-assert C.sizeof(Volume) == 76
+assert C.sizeof(Volume) == 80
 
 
 class Atmosphere(C.Structure):  # vpt_atmosphere
@@ -79,12 +80,13 @@ PHASE_HENYEY_GREENSTEIN, PHASE_DRAINE, PHASE_HENYEY_GREENSTEIN_PLUS_DRAINE = 0, 
 
 
 def volume(corner_min=(-1, -1, -1), corner_max=(1, 1, 1), color=(0.8, 0.8, 0.8), emissive_color=(0, 0, 0), density=1.0, anisotropy=0.0,
-           alpha=1.0, droplet_size=20.0, approximated_scattering=0, approximated_scattering_falloff=0.8):
+           alpha=1.0, droplet_size=20.0, approximated_scattering=0, approximated_scattering_falloff=0.8, density_data_index=-1, grid_sharpness=1.0):
     """PathTracer::Volume defaults (PathTracer.h:36-74); corners are world space (Position + Corner * Scale applied)."""
     v = Volume()
     v.corner_min[:] = corner_min; v.corner_max[:] = corner_max; v.color[:] = color; v.emissive_color[:] = emissive_color
     v.density, v.anisotropy, v.alpha, v.droplet_size = density, anisotropy, alpha, droplet_size
-    v.density_data_index = -1
+    v.density_data_index = density_data_index
+    v.grid_sharpness = grid_sharpness
     v.approximated_scattering, v.approximated_scattering_falloff = approximated_scattering, approximated_scattering_falloff
     return v
 
@@ -187,6 +189,8 @@ PROTOTYPES = {
     "vpt_set_camera": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "vpt_default_atmosphere": (None, [C.POINTER(Atmosphere)]),
     "vpt_set_atmosphere": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "vpt_add_density_grid": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]),
+    "vpt_clear_density_grids": (C.c_int, [C.c_void_p]),
     "vpt_set_volumes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32]),
     "vpt_set_phase_function": (C.c_int, [C.c_void_p, C.c_uint32]),
     "vpt_set_params": (C.c_int, [C.c_void_p, C.POINTER(Params)]),

@@ -150,8 +150,8 @@ __device__ inline V3 nee_atmosphere_transmittance(const DeviceScene& sc, Rng& r,
 // delta-tracked atmosphere collision — which first fixes the colour channel the collision is sampled for — wins if it
 // lies before the geometry (`dgeo` = GetDistanceToGeometry, < 0: none).
 // Returns -1: no scatter, -2: atmosphere (component `comp`, channel `cc`), >= 0: box index; `sd` = distance.
-__device__ inline int scattered_in_media(const DeviceScene& sc, V3 org, V3 dir, Rng& r, float dgeo, int cc_in, float& sd, int& comp, int& cc) {
-    int sv = nearest_box_scatter(sc, org, dir, r, sd);
+__device__ inline int scattered_in_media(const DeviceScene& sc, V3 org, V3 dir, Rng& r, float dgeo, float depth, int cc_in, float& sd, int& comp, int& cc) {
+    int sv = nearest_box_scatter(sc, org, dir, r, depth, sd);
     cc = cc_in; comp = -1;
     if (sc.atm_on) {
         if (cc == -1) { float pick = r.uf(); cc = pick < 0.33333f ? 0 : (pick < 0.66666f ? 1 : 2); }

@@ -92,6 +92,14 @@ struct AliasEntry {  // == AliasMapEntry (Bindings.slang:1-5)
     float importance;
 };
 
+// A heterogeneous volume's density: dense raw values (x fastest) + the 32^3 table of per-block maxima of value/max.
+struct DensityGrid {
+    const float* values;
+    const float* block_max;
+    uint32_t dim[3];
+    float max_density;
+};
+
 struct DeviceScene {
     const BvhNode* nodes;
     const BvhNodeWide* nodes_wide;  // non-null only for LDS-resident scenes
@@ -122,6 +130,8 @@ struct DeviceScene {
     const vpt_volume* volumes;              // uVolumes (Volume.slang:9); volume_count == 0: none
     uint32_t volume_count, phase;           // PHASE_FUNCTION_* (PathTracer.h:76-81)
     uint32_t atm_on;                        // ENABLE_ATMOSPHERE
+    uint32_t hetero;                        // some volume takes its density from a grid (its transmittance is tracked, not evaluated)
+    const struct DensityGrid* grids;        // uNanoVDBBuffersDensity / uVolumeMaxDensities, densified (vpt_add_density_grid)
     vpt_atmosphere atm;
 };
 

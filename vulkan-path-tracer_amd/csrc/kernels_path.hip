@@ -211,7 +211,11 @@ struct ShadeOut {
     // sky sample's transmittance is tracked (draws random numbers) only once the shadow ray is known to be clear
     V3 bxdf;            // payload.BxDF
     V3 sky_f, sky_rgb;  // sky NEE ingredients: BSDF or colour*phase towards the sample, sample radiance
-    float sky_tvol, sky_w, sky_mis;  // box transmittance, sample pdf, MIS weight (1 for the atmosphere event)
+    float sky_tdepth, sky_w, sky_mis;  // rayDepth argument of the box transmittance, sample pdf, MIS weight (1 for the atmosphere event)
+    V3 light_f, light_rgb;           // the same for the emissive-mesh sample (its transmittance may draw too: heterogeneous boxes)
+    float light_tdepth, light_w, light_mis;
+    int light_kind;                  // 0 surface, 1 box scatter event
+    bool light_add;
     int sky_kind;       // 0 surface, 1 box scatter event, 2 atmosphere scatter event (the three expressions differ in association)
     bool sky_add;       // false: trace and track (the draws count) but add nothing (ozone collision)
     int cchan;          // payload.ColorChannel after this bounce
@@ -223,7 +227,12 @@ template <bool VOL>
 __device__ __forceinline__ void shade_core(const DeviceScene& sc, const RenderParams& P, const PathState& ps, uint32_t slot,
                                            const ShadeIn& in_, ShadeOut& out) {
     bool alive = false, want_sky = false, want_light = false, light_miss_ok = false;
-    if (VOL) { out.sky_add = true; out.sky_kind = 0; out.sky_tvol = 1.0f; out.sky_w = 1.0f; out.sky_mis = 1.0f; out.sky_f = v3s(0.0f); out.sky_rgb = v3s(0.0f); }
+    if (VOL) {
+        out.sky_add = true; out.sky_kind = 0; out.sky_tdepth = 0.0f; out.sky_w = 1.0f; out.sky_mis = 1.0f; out.sky_f = v3s(0.0f); out.sky_rgb = v3s(0.0f);
+        out.light_add = true; out.light_kind = 0; out.light_tdepth = 0.0f; out.light_w = 1.0f; out.light_mis = 1.0f; out.light_f = v3s(0.0f); out.light_rgb = v3s(0.0f);
+    }
+    // media whose transmittance is TRACKED (random draws) rather than evaluated: every unobscured NEE sample is tracked, used or not
+    const bool tracked = VOL && (sc.atm_on || sc.hetero);
     uint32_t vdepth = VOL ? in_.vdepth : 0u;
     const float4 h = in_.h;
     Rng rng; rng.s = in_.rng;
@@ -255,8 +264,8 @@ __device__ __forceinline__ void shade_core(const DeviceScene& sc, const RenderPa
         // NEE: the shadow rays start AT the scatter point (no offset); the sky term is assembled after the visibility test
         if ((P.flags & VPT_FLAG_SKY_MIS) && sky.w > 0.0f) {
             float ps_ = volume_phase(sc.phase, v, pdir, to_sky, vdepth);
-            if (ps_ > 0.0f || sc.atm_on) {  // with an atmosphere the transmittance is tracked (draws) whenever the sample is unobscured (:316-343)
-                out.sky_f = ld3(v.color) * ps_; out.sky_tvol = volumes_transmittance(sc, new_o, to_sky);
+            if (ps_ > 0.0f || tracked) {  // tracked transmittance draws whenever the sample is unobscured (:316-343)
+                out.sky_f = ld3(v.color) * ps_; out.sky_tdepth = (float)vdepth;
                 out.sky_rgb = v3(sky.x, sky.y, sky.z); out.sky_w = sky.w; out.sky_mis = power_heuristics(sky.w, ps_); out.sky_kind = 1;
                 out.sky_add = ps_ > 0.0f;
                 want_sky = true; sky_o = new_o; sky_d = to_sky;
@@ -264,9 +273,10 @@ __device__ __forceinline__ void shade_core(const DeviceScene& sc, const RenderPa
         }
         if ((P.flags & VPT_FLAG_MESH_MIS) && lc.w > 0.0f) {
             float pl = volume_phase(sc.phase, v, pdir, to_light, vdepth);
-            if (pl > 0.0f) {
-                V3 tr = v3s(volumes_transmittance(sc, new_o, to_light));
-                clight = ((tr * (ld3(v.color) * pl)) * (v3(lc.x, lc.y, lc.z) / lc.w)) * power_heuristics(lc.w, pl);
+            if (pl > 0.0f || tracked) {
+                out.light_f = ld3(v.color) * pl; out.light_tdepth = (float)(vdepth + 1u);  // :353 passes VolumeDepth + 1
+                out.light_rgb = v3(lc.x, lc.y, lc.z); out.light_w = lc.w; out.light_mis = power_heuristics(lc.w, pl); out.light_kind = 1;
+                out.light_add = pl > 0.0f;
                 want_light = true; light_o = new_o; light_d = to_light;
                 light_miss_ok = light_gid == 0u;
             }
@@ -289,7 +299,7 @@ __device__ __forceinline__ void shade_core(const DeviceScene& sc, const RenderPa
             cp.x *= P.sky_intensity; cp.y *= P.sky_intensity; cp.z *= P.sky_intensity;
             // the sun term needs the shadow ray first: its transmittance is tracked only when the ray is clear (:398-409)
             out.sky_rgb = v3(cp.x, cp.y, cp.z); out.sky_w = cp.w; out.sky_mis = 1.0f; out.sky_kind = 2;
-            out.sky_tvol = 1.0f;  // the box transmittance is evaluated with the atmosphere's, after the visibility test
+            out.sky_tdepth = (float)vdepth;
             sky_o = new_o; sky_d = to_sky;
             if (comp == 0) {
                 out.sky_f = v3s(rayleigh_phase(pdir, to_sky)); want_sky = true;
@@ -430,11 +440,11 @@ __device__ __forceinline__ void shade_core(const DeviceScene& sc, const RenderPa
             // (EvaluateBSDF draws no random numbers, so evaluating before the visibility test is equivalent)
             new_o = s.pos + s.N * (was_refracted ? -1e-3f : 1e-3f);  // volumes shadow NEE from the NEW origin (:332-333, 364)
             // with an atmosphere every unobscured sky sample has its transmittance tracked (draws), used or not (ClosestHit.slang:330-349)
-            if ((P.flags & VPT_FLAG_SKY_MIS) && (sky.w > 0.0f || (VOL && sc.atm_on))) {
+            if ((P.flags & VPT_FLAG_SKY_MIS) && (sky.w > 0.0f || tracked)) {
                 Eval e = bs.eval(V, s.world_to_tangent(to_sky), ec_r, ec_g, gv);
-                if (e.pdf > 0.0f || (VOL && sc.atm_on)) {
+                if (e.pdf > 0.0f || tracked) {
                     if (VOL) {  // assembled after the visibility test
-                        out.sky_f = e.f; out.sky_tvol = volumes_transmittance(sc, new_o, to_sky);
+                        out.sky_f = e.f; out.sky_tdepth = 0.0f;
                         out.sky_rgb = v3(sky.x, sky.y, sky.z); out.sky_w = sky.w; out.sky_mis = power_heuristics(sky.w, e.pdf); out.sky_kind = 0;
                         out.sky_add = sky.w > 0.0f && e.pdf > 0.0f;
                     } else {
@@ -446,8 +456,12 @@ __device__ __forceinline__ void shade_core(const DeviceScene& sc, const RenderPa
             if ((P.flags & VPT_FLAG_MESH_MIS) && !is_light && lc.w > 0.0f) {
                 Eval e = bs.eval(V, s.world_to_tangent(to_light), ec_r, ec_g, gv);
                 if (e.pdf > 0.0f) {
-                    if (VOL) e.f = e.f * v3s(volumes_transmittance(sc, new_o, to_light));
-                    clight = (e.f * v3(lc.x, lc.y, lc.z) / lc.w) * power_heuristics(lc.w, e.pdf);
+                    if (VOL) {
+                        out.light_f = e.f; out.light_tdepth = 0.0f; out.light_rgb = v3(lc.x, lc.y, lc.z); out.light_w = lc.w;
+                        out.light_mis = power_heuristics(lc.w, e.pdf); out.light_kind = 0;
+                    } else {
+                        clight = (e.f * v3(lc.x, lc.y, lc.z) / lc.w) * power_heuristics(lc.w, e.pdf);
+                    }
                     want_light = true; light_o = s.pos + to_light * 1e-2f; light_d = to_light;
                 }
             }
@@ -707,7 +721,7 @@ __global__ __launch_bounds__(kTraverseBlock, 3) void k_bounce(DeviceScene sc, Re
                     bool g = trace_any<LDS_SCENE, COUNT>(sc, lds_nodes, lds_tris, in_.porg, in_.pdir, 0.00001f, 1000000.0f, stack, hr, st);
                     Rng vr; vr.s = in_.rng;
                     int cc;
-                    in_.vol_index = scattered_in_media(sc, in_.porg, in_.pdir, vr, g ? hr.t : -1.0f, in_.cchan, in_.vol_t, in_.atm_comp, cc);
+                    in_.vol_index = scattered_in_media(sc, in_.porg, in_.pdir, vr, g ? hr.t : -1.0f, (float)in_.depth, in_.cchan, in_.vol_t, in_.atm_comp, cc);
                     if (in_.vol_index == -2) in_.cchan = cc;  // the path now tracks this colour channel only (:242-247)
                     in_.rng = vr.s;
                 }
@@ -735,10 +749,10 @@ __global__ __launch_bounds__(kTraverseBlock, 3) void k_bounce(DeviceScene sc, Re
                         V3 csky;
                         if (o.sky_kind == 2) {        // RayGen.slang:405-424: (phase * T_atm * T_boxes) * (sun / pdf)
                             V3 tr = atmosphere_transmittance(sc, tr_rng, o.sky_o, o.sky_d, o.cchan);
-                            tr = tr * volumes_transmittance(sc, o.sky_o, o.sky_d);
+                            tr = tr * volumes_transmittance(sc, tr_rng, o.sky_o, o.sky_d, o.sky_tdepth);
                             csky = (o.sky_f * tr) * (o.sky_rgb / o.sky_w);
                         } else {
-                            V3 tr = v3s(o.sky_tvol);  // from the new origin (ClosestHit.slang:332-349, RayGen.slang:325-343)
+                            V3 tr = v3s(volumes_transmittance(sc, tr_rng, o.new_o, o.sky_d, o.sky_tdepth));  // from the new origin (ClosestHit.slang:332-349, RayGen.slang:325-343)
                             if (sc.atm_on) tr = nee_atmosphere_transmittance(sc, tr_rng, tr, o.new_o, o.sky_d, o.cchan);
                             if (o.sky_kind == 0) csky = ((o.sky_f * tr) * o.sky_rgb / o.sky_w) * o.sky_mis;
                             else csky = ((tr * o.sky_f) * (o.sky_rgb / o.sky_w)) * o.sky_mis;
@@ -750,7 +764,18 @@ __global__ __launch_bounds__(kTraverseBlock, 3) void k_bounce(DeviceScene sc, Re
                 if (o.want_light) {
                     bool vis = light_visible<LDS_SCENE, COUNT>(sc, lds_nodes, lds_tris, o.light_o, o.light_d, o.light_gid, stack, sst);
                     if (VOL && !vis && o.light_miss_ok) vis = sky_visible<LDS_SCENE, COUNT>(sc, lds_nodes, lds_tris, o.light_o, o.light_d, stack, sst);
-                    if (vis) E = E + o.clight;
+                    if (VOL) {
+                        if (vis) {  // ClosestHit.slang:361-370, RayGen.slang:348-361: the light term with the box transmittance
+                            Rng tr_rng; tr_rng.s = o.rng;
+                            V3 tr = v3s(volumes_transmittance(sc, tr_rng, o.new_o, o.light_d, o.light_tdepth));
+                            o.rng = tr_rng.s;
+                            V3 cl = o.light_kind == 0 ? ((o.light_f * tr) * o.light_rgb / o.light_w) * o.light_mis
+                                                      : ((tr * o.light_f) * (o.light_rgb / o.light_w)) * o.light_mis;
+                            if (o.light_add) E = E + cl;
+                        }
+                    } else if (vis) {
+                        E = E + o.clight;
+                    }
                     nrays++;
                 }
                 const int fin_chan = VOL ? o.cchan : -1;  // the channel this sample is accumulated in (RayGen.slang:118-128)

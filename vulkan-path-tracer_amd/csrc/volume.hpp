@@ -93,25 +93,140 @@ __device__ inline float volume_phase(uint32_t phase, const vpt_volume& v, V3 V, 
     HgDraineFit f = hg_draine_fit(v.droplet_size);
     return lerp(phase_hg(V, L, f.ghg), phase_draine(V, L, f.gd, f.alpha_d), f.w_d);
 }
-// Volume::CalculateVolumesTransmittance, Volume.slang:419-446 (homogeneous branch)
-__device__ inline float volumes_transmittance(const DeviceScene& sc, V3 org, V3 dir) {
+// ---- heterogeneous boxes: density from a dense grid (the reference's NanoVDB tree, densified) --------------------
+__device__ inline float effective_density(const vpt_volume& v, float base, float depth) {  // Volume.slang:149-156
+    if (v.approximated_scattering != 0) return base * pow_(v.approximated_scattering_falloff, depth);
+    return base;
+}
+// SampleNanoVDBBuffer, Volume.slang:69-117, on a dense grid whose index box is [0, dim)
+__device__ inline float sample_density_grid(const DeviceScene& sc, const vpt_volume& v, Rng& r, V3 x) {
+    const DensityGrid& g = sc.grids[v.density_data_index];
+    V3 n = (x - ld3(v.corner_min)) / (ld3(v.corner_max) - ld3(v.corner_min));
+    n.y = 1.0f - n.y;
+    V3 gp = n * v3((float)g.dim[0], (float)g.dim[1], (float)g.dim[2]);
+    int cx = f2i_clamped(floor_(gp.x), -1, (int)g.dim[0]), cy = f2i_clamped(floor_(gp.y), -1, (int)g.dim[1]), cz = f2i_clamped(floor_(gp.z), -1, (int)g.dim[2]);
+    r.s = pcg_hash(r.s); cx += (int)(r.s % 3u) - 1;
+    r.s = pcg_hash(r.s); cy += (int)(r.s % 3u) - 1;
+    r.s = pcg_hash(r.s); cz += (int)(r.s % 3u) - 1;
+    cx = min(max(cx, 0), (int)g.dim[0] - 1); cy = min(max(cy, 0), (int)g.dim[1] - 1); cz = min(max(cz, 0), (int)g.dim[2] - 1);
+    float value = g.values[(size_t)cx + (size_t)cy * g.dim[0] + (size_t)cz * g.dim[0] * g.dim[1]];
+    return clamp_(value / g.max_density * v.grid_sharpness, 0.0f, 1.0f);
+}
+struct VolBlock { int index; V3 lo, hi; };
+struct VolTrav { V3 block_size; float eps, t_enter, t_exit; };
+__device__ inline VolTrav make_traversal(const vpt_volume& v, VolIsect is) {  // Volume.slang:119-127
+    VolTrav c;
+    V3 ext = ld3(v.corner_max) - ld3(v.corner_min);
+    c.block_size = ext / v3s(32.0f);
+    c.eps = 0.0001f * max_(ext.x, max_(ext.y, ext.z));
+    c.t_enter = max_(is.tn, 0.0f);
+    c.t_exit = is.tf;
+    return c;
+}
+__device__ inline VolBlock block_info(const vpt_volume& v, V3 pos, const VolTrav& c) {  // Volume.slang:129-147
+    V3 rel = (pos - ld3(v.corner_min)) / (ld3(v.corner_max) - ld3(v.corner_min));
+    int ix = f2i_clamped(rel.x * 32.0f, 0, 31), iy = f2i_clamped(rel.y * 32.0f, 0, 31), iz = f2i_clamped(rel.z * 32.0f, 0, 31);
+    VolBlock b;
+    b.index = ix + iy * 32 + iz * 32 * 32;
+    b.lo = ld3(v.corner_min) + c.block_size * v3((float)ix, (float)iy, (float)iz);
+    b.hi = b.lo + c.block_size;
+    return b;
+}
+__device__ inline VolIsect ray_aabb3(V3 org, V3 dir, V3 lo, V3 hi) { float a[3] = {lo.x, lo.y, lo.z}, b[3] = {hi.x, hi.y, hi.z}; return ray_aabb(org, dir, a, b); }
+// ProcessHeterogeneousVolumeScattering, Volume.slang:299-348: delta tracking block by block
+__device__ inline float heterogeneous_scatter(const DeviceScene& sc, const vpt_volume& v, V3 org, V3 dir, Rng& r, float depth, VolIsect is) {
+    const DensityGrid& g = sc.grids[v.density_data_index];
+    VolTrav c = make_traversal(v, is);
+    VolBlock b = block_info(v, org + dir * (c.t_enter + c.eps), c);
+    float t = 0.0f;
+    for (int i = 0; i < 10000; i++) {
+        V3 cur = org + dir * (c.t_enter + t + c.eps);
+        VolIsect bi = ray_aabb3(cur, dir, b.lo, b.hi);
+        float maxd = effective_density(v, g.block_max[b.index] * v.density, depth);
+        float sd = -log_(r.uf()) / maxd;
+        if (bi.tf <= 0.0f) {
+            t += c.eps;
+            if (c.t_enter + t > c.t_exit) return -1.0f;
+            b = block_info(v, org + dir * (c.t_enter + t + c.eps), c);
+            continue;
+        }
+        float to_exit = bi.tf - max_(bi.tn, 0.0f);
+        if (sd > to_exit) {
+            t += to_exit + c.eps;
+            if (c.t_enter + t > c.t_exit) return -1.0f;
+            b = block_info(v, org + dir * (c.t_enter + t + c.eps), c);
+            continue;
+        }
+        t += sd;
+        if (c.t_enter + t > c.t_exit) return -1.0f;
+        V3 pos = org + dir * (c.t_enter + t);
+        float dens = effective_density(v, sample_density_grid(sc, v, r, pos) * v.density, depth);
+        if (dens / maxd < r.uf()) continue;
+        return c.t_enter + t;
+    }
+    return -1.0f;
+}
+// ProcessHeterogeneousVolumeTransmittance, Volume.slang:448-520: ratio tracking + roulette, block by block
+__device__ inline float heterogeneous_transmittance(const DeviceScene& sc, const vpt_volume& v, Rng& r, V3 org, V3 dir, float depth, VolIsect is) {
+    const DensityGrid& g = sc.grids[v.density_data_index];
+    VolTrav c = make_traversal(v, is);
+    VolBlock b = block_info(v, org + dir * (c.t_enter + c.eps), c);
+    float tr = 1.0f, t = 0.0f;
+    for (int j = 0; j < 1000; j++) {
+        V3 cur = org + dir * (c.t_enter + t + c.eps);
+        VolIsect bi = ray_aabb3(cur, dir, b.lo, b.hi);
+        float maxd = effective_density(v, g.block_max[b.index] * v.density, depth);
+        float sd = -log_(r.uf()) / maxd;
+        if (bi.tf <= 0.0f) {
+            t += c.eps;
+            if (c.t_enter + t > c.t_exit) break;
+            b = block_info(v, org + dir * (c.t_enter + t + c.eps), c);
+            continue;
+        }
+        float to_exit = bi.tf - max_(bi.tn, 0.0f);
+        if (sd > to_exit) {
+            t += to_exit + c.eps;
+            if (c.t_enter + t > c.t_exit) break;
+            b = block_info(v, org + dir * (c.t_enter + t + c.eps), c);
+            continue;
+        }
+        t += sd;
+        if (c.t_enter + t > c.t_exit) break;
+        V3 pos = org + dir * (c.t_enter + t);
+        float dens = effective_density(v, sample_density_grid(sc, v, r, pos) * v.density, depth);
+        tr *= 1.0f - (dens / maxd);
+        float p = tr;
+        if (r.uf() > p) return 0.0f;
+        tr /= p;
+    }
+    return tr;
+}
+// Volume::CalculateVolumesTransmittance, Volume.slang:419-446: Beer-Lambert for homogeneous boxes, tracked (random
+// draws) for heterogeneous ones — which is why callers evaluate it only after the shadow ray is known to be clear
+__device__ inline float volumes_transmittance(const DeviceScene& sc, Rng& r, V3 org, V3 dir, float depth) {
     float tr = 1.0f;
     for (uint32_t i = 0; i < sc.volume_count; i++) {
         const vpt_volume& v = sc.volumes[i];
         VolIsect is = ray_aabb(org, dir, v.corner_min, v.corner_max);
         is.tn = max_(is.tn, 0.0f);
-        float len = is.tf - is.tn;
-        if (len > 0.0f) tr *= exp_(-v.density * len);
+        if (v.density_data_index >= 0 && is.tf >= 0.0f) {
+            tr *= heterogeneous_transmittance(sc, v, r, org, dir, depth, is);
+            if (tr <= 0.0f) return 0.0f;
+        } else {
+            float len = is.tf - is.tn;
+            if (len > 0.0f) tr *= exp_(-v.density * len);
+        }
     }
     return clamp_(tr, 0.0f, 1.0f);
 }
-// Volume::DoesRayScatterInVolume, Volume.slang:261-297 (homogeneous branch; one draw when the ray crosses the box)
-__device__ inline float does_ray_scatter(const vpt_volume& v, V3 org, V3 dir, Rng& r, float ignore_if_farther) {
+// Volume::DoesRayScatterInVolume, Volume.slang:261-297
+__device__ inline float does_ray_scatter(const DeviceScene& sc, const vpt_volume& v, V3 org, V3 dir, Rng& r, float depth, float ignore_if_farther) {
     VolIsect is = ray_aabb(org, dir, v.corner_min, v.corner_max);
     if (is.tf < 0.0f) return -1.0f;
     if (ignore_if_farther >= 0.0f && is.tn > ignore_if_farther) return -1.0f;
     float inside = is.tf - max_(is.tn, 0.0f);
     if (inside <= 0.0f) return -1.0f;
+    if (v.density_data_index >= 0) return heterogeneous_scatter(sc, v, org, dir, r, depth, is);
     float sd = -log_(r.uf()) / v.density;  // Sampler.slang:425-428
     if (sd < inside) return max_(is.tn, 0.0f) + sd;
     return -1.0f;
@@ -119,7 +234,7 @@ __device__ inline float does_ray_scatter(const vpt_volume& v, V3 org, V3 dir, Rn
 // The box part of ScatteredInVolume, RayGen.slang:162-210: boxes in order of entry distance (the reference's
 // exchange sort, reproduced literally because ties are common and it is not stable), each crossed box draws a
 // free-flight distance, the nearest scatter wins.  Returns the box index or -1; `sd` = its distance (-1: none).
-__device__ inline int nearest_box_scatter(const DeviceScene& sc, V3 org, V3 dir, Rng& r, float& sd) {
+__device__ inline int nearest_box_scatter(const DeviceScene& sc, V3 org, V3 dir, Rng& r, float depth, float& sd) {
     const int n = (int)sc.volume_count;
     float dist[VPT_MAX_VOLUMES]; int idx[VPT_MAX_VOLUMES];
     for (int i = 0; i < n; i++) {
@@ -131,7 +246,7 @@ __device__ inline int nearest_box_scatter(const DeviceScene& sc, V3 org, V3 dir,
             if (dist[j] < dist[i]) { float td = dist[i]; int ti = idx[i]; dist[i] = dist[j]; idx[i] = idx[j]; dist[j] = td; idx[j] = ti; }
     sd = -1.0f; int sv = -1;
     for (int i = 0; i < n; i++) {
-        float t = does_ray_scatter(sc.volumes[idx[i]], org, dir, r, sd);
+        float t = does_ray_scatter(sc, sc.volumes[idx[i]], org, dir, r, depth, sd);
         if (t >= 0.0f && (t < sd || sd < 0.0f)) { sd = t; sv = idx[i]; }
     }
     return sv;

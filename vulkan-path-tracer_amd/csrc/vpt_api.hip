@@ -54,6 +54,8 @@ struct vpt_ctx {
     // pipeline with the smaller minimum is kept until the scene, size or params change.
     std::vector<vpt_volume> volumes;       // homogeneous box volumes (vpt_set_volumes)
     vpt_volume* d_volumes = nullptr;
+    std::vector<DensityGrid> grids;        // device pointers inside (vpt_add_density_grid)
+    DensityGrid* d_grids = nullptr;
     uint32_t phase = VPT_PHASE_HENYEY_GREENSTEIN;
     int tune_state = 0;  // batches timed so far (even: staged next, odd: fused next); kTuneBatches = decided
     bool auto_fused = false;
@@ -434,6 +436,8 @@ void vpt_destroy(vpt_ctx* c) {
     if (c->ctr) (void)hipFree(c->ctr);
     if (c->d_launch_off) (void)hipFree(c->d_launch_off);
     if (c->d_volumes) (void)hipFree(c->d_volumes);
+    for (DensityGrid& g : c->grids) { (void)hipFree((void*)g.values); (void)hipFree((void*)g.block_max); }
+    if (c->d_grids) (void)hipFree(c->d_grids);
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -641,7 +645,8 @@ int vpt_set_volumes(vpt_ctx* c, const vpt_volume* v, uint32_t count) {
     if (count > VPT_MAX_VOLUMES) return fail(c, VPT_ERR_LIMIT, "more than VPT_MAX_VOLUMES volumes");
     if (count && c->cfg.pipeline == VPT_PIPELINE_STAGED) return fail(c, VPT_ERR_UNSUPPORTED, "volumes run on the fused pipeline (use VPT_PIPELINE_AUTO or _FUSED)");
     for (uint32_t i = 0; i < count; i++) {
-        if (v[i].density_data_index != -1) return fail(c, VPT_ERR_UNSUPPORTED, "heterogeneous (NanoVDB) volumes are not implemented: density_data_index must be -1");
+        if (v[i].density_data_index < -1 || v[i].density_data_index >= (int)c->grids.size())
+            return fail(c, VPT_ERR_INVALID_ARGUMENT, "density_data_index must be -1 or an index returned by vpt_add_density_grid");
         if (!(v[i].density > 0.0f)) return fail(c, VPT_ERR_INVALID_ARGUMENT, "volume density must be > 0");  // -log(u)/0 (Sampler.slang:427)
     }
     HIPCHK(c, hipSetDevice(c->cfg.device));
@@ -653,7 +658,53 @@ int vpt_set_volumes(vpt_ctx* c, const vpt_volume* v, uint32_t count) {
         HIPCHK(c, hipMemcpy(c->d_volumes, v, (size_t)count * sizeof(vpt_volume), hipMemcpyHostToDevice));
     }
     c->dsc.volumes = c->d_volumes; c->dsc.volume_count = count; c->dsc.phase = c->phase;
+    c->dsc.hetero = 0u;
+    for (uint32_t i = 0; i < count; i++) if (v[i].density_data_index >= 0) c->dsc.hetero = 1u;
     reset_accum(c);
+    return VPT_OK;
+}
+// AddDensityDataToVolume, PathTracer.cpp:1390-1442, on a dense grid
+int vpt_add_density_grid(vpt_ctx* c, uint32_t dx, uint32_t dy, uint32_t dz, const float* d) {
+    if (!c || !d || dx == 0 || dy == 0 || dz == 0 || (uint64_t)dx * dy * dz > (1ull << 31)) return VPT_ERR_INVALID_ARGUMENT;
+    if (c->grids.size() >= VPT_MAX_DENSITY_GRIDS) return fail(c, VPT_ERR_LIMIT, "more than VPT_MAX_DENSITY_GRIDS density grids");
+    const size_t n = (size_t)dx * dy * dz;
+    float mx = 0.0f;
+    for (size_t i = 0; i < n; i++) mx = std::max(mx, d[i]);
+    if (!(mx > 0.0f)) return fail(c, VPT_ERR_INVALID_ARGUMENT, "density grid has no positive value");
+    std::vector<float> block_max(32768, 0.0f);
+    for (uint32_t z = 0; z < dz; z++)
+        for (uint32_t y = 0; y < dy; y++)
+            for (uint32_t x = 0; x < dx; x++) {
+                const float raw = d[(size_t)x + (size_t)(dy - 1 - y) * dx + (size_t)z * dx * dy];  // "Y has to be flipped for vulkan" (:1435)
+                const float dens = vptfp::clamp_(raw / mx, 0.0f, 1.0f);
+                const uint32_t bi = ((x * 32u) / dx) + ((y * 32u) / dy) * 32u + ((z * 32u) / dz) * 1024u;
+                if (block_max[bi] < dens) block_max[bi] = dens;
+            }
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    DensityGrid g{};
+    float *dv = nullptr, *db = nullptr;
+    HIPCHK(c, hipMalloc((void**)&dv, n * 4));
+    if (hipMalloc((void**)&db, 32768 * 4) != hipSuccess) { (void)hipFree(dv); return fail(c, VPT_ERR_OUT_OF_MEMORY, "hipMalloc block maxima"); }
+    HIPCHK(c, hipMemcpy(dv, d, n * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(db, block_max.data(), 32768 * 4, hipMemcpyHostToDevice));
+    g.values = dv; g.block_max = db; g.dim[0] = dx; g.dim[1] = dy; g.dim[2] = dz; g.max_density = mx;
+    c->grids.push_back(g);
+    if (c->d_grids) (void)hipFree(c->d_grids);
+    HIPCHK(c, hipMalloc((void**)&c->d_grids, c->grids.size() * sizeof(DensityGrid)));
+    HIPCHK(c, hipMemcpy(c->d_grids, c->grids.data(), c->grids.size() * sizeof(DensityGrid), hipMemcpyHostToDevice));
+    c->dsc.grids = c->d_grids;
+    return (int)c->grids.size() - 1;
+}
+int vpt_clear_density_grids(vpt_ctx* c) {
+    if (!c) return VPT_ERR_INVALID_ARGUMENT;
+    for (const vpt_volume& v : c->volumes) if (v.density_data_index >= 0) return fail(c, VPT_ERR_INVALID_ARGUMENT, "a volume still references a density grid");
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (DensityGrid& g : c->grids) { (void)hipFree((void*)g.values); (void)hipFree((void*)g.block_max); }
+    c->grids.clear();
+    if (c->d_grids) { (void)hipFree(c->d_grids); c->d_grids = nullptr; }
+    c->dsc.grids = nullptr;
     return VPT_OK;
 }
 void vpt_default_atmosphere(vpt_atmosphere* a) {  // PathTracer.h:222-232

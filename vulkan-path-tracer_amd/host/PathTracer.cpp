@@ -91,7 +91,7 @@ void PathTracer::UploadVolumes() {
         o.color[0] = v.Color.x; o.color[1] = v.Color.y; o.color[2] = v.Color.z;
         o.emissive_color[0] = v.EmissiveColor.x; o.emissive_color[1] = v.EmissiveColor.y; o.emissive_color[2] = v.EmissiveColor.z;
         o.density = v.Density; o.anisotropy = v.Anisotropy; o.alpha = v.Alpha; o.droplet_size = v.DropletSize;
-        o.density_data_index = -1;
+        o.density_data_index = v.DensityDataIndex; o.grid_sharpness = v.GridSharpness;
         o.approximated_scattering = v.ApproximatedScatteringForClouds; o.approximated_scattering_falloff = v.ApproximatedScatteringFalloff;
         g.push_back(o);
     }
@@ -112,6 +112,19 @@ void PathTracer::RemoveVolume(uint32_t index) {
 void PathTracer::SetVolume(uint32_t index, const Volume& volume) {
     if (index >= m_Volumes.size()) throw std::runtime_error("SetVolume: index out of range");
     m_Volumes[index] = volume; UploadVolumes();
+}
+void PathTracer::AddDensityDataToVolume(uint32_t volumeIndex, uint32_t dx, uint32_t dy, uint32_t dz, const float* density) {
+    if (volumeIndex >= m_Volumes.size()) throw std::runtime_error("AddDensityDataToVolume: index out of range");
+    if (!m_Ctx) throw std::runtime_error("AddDensityDataToVolume before SetScene");
+    int idx = vpt_add_density_grid(m_Ctx, dx, dy, dz, density);
+    if (idx < 0) Check(idx, "vpt_add_density_grid");
+    m_Volumes[volumeIndex].DensityDataIndex = idx;
+    UploadVolumes();
+}
+void PathTracer::RemoveDensityDataFromVolume(uint32_t volumeIndex) {  // the grid itself stays allocated until the context goes
+    if (volumeIndex >= m_Volumes.size()) throw std::runtime_error("RemoveDensityDataFromVolume: index out of range");
+    m_Volumes[volumeIndex].DensityDataIndex = -1;
+    UploadVolumes();
 }
 void PathTracer::SetPhaseFunction(PhaseFunction phaseFunction) { m_PhaseFunction = phaseFunction; UploadVolumes(); }
 

@@ -27,6 +27,8 @@ public:
         float Density = 1.0f, Anisotropy = 0.0f, Alpha = 1.0f, DropletSize = 20.0f;
         int ApproximatedScatteringForClouds = 0;
         float ApproximatedScatteringFalloff = 0.8f;
+        int DensityDataIndex = -1;   // set by AddDensityDataToVolume
+        float GridSharpness = 1.0f;
     };
     enum class PhaseFunction { HENYEY_GREENSTEIN = 0, DRAINE = 1, HENYEY_GREENSTEIN_PLUS_DRAINE = 2 };  // PathTracer.h:76-81
 
@@ -68,6 +70,10 @@ public:
     void RemoveVolume(uint32_t index);
     void SetVolume(uint32_t index, const Volume& volume);
     void SetPhaseFunction(PhaseFunction phaseFunction);
+    // AddDensityDataToVolume (PathTracer.h:165, PathTracer.cpp:1347-1516) with the .vdb already decoded into a dense grid of
+    // raw densities (x fastest, file index order).  The box corners stay as the caller set them.
+    void AddDensityDataToVolume(uint32_t volumeIndex, uint32_t dimX, uint32_t dimY, uint32_t dimZ, const float* density);
+    void RemoveDensityDataFromVolume(uint32_t volumeIndex);
     [[nodiscard]] uint32_t GetVolumesCount() const { return (uint32_t)m_Volumes.size(); }
     [[nodiscard]] const std::vector<Volume>& GetVolumes() const { return m_Volumes; }
     [[nodiscard]] PhaseFunction GetPhaseFunction() const { return m_PhaseFunction; }
