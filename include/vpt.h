@@ -235,7 +235,7 @@ int vpt_get_material(const vpt_ctx* ctx, uint32_t index, vpt_material* out);
  * PathTracer::Volume / VolumeGPU (PathTracer.h:36-74, 341-400) as the shaders read it (Volume.slang:19-52).
  * corner_min / corner_max are the WORLD-space box, i.e. Position + Corner * Scale already applied
  * (PathTracer.h:395-396).  Heterogeneous volumes take their density from a DENSE grid (vpt_add_density_grid below:
- * the OpenVDB / NanoVDB tree of the reference, densified); temperature grids / blackbody emission are not implemented.
+ * the OpenVDB / NanoVDB tree of the reference, densified), including emission from temperature / blackbody.
  * The integrator side is RayGen.slang:162-380 (free-flight sampling per box,
  * nearest scatter vs. distance to geometry, NEE towards sky and emissive meshes through every box's Beer-Lambert
  * transmittance, phase-function scattering) and ClosestHit.slang:332-333,364 (volumes shadow surface NEE). */
@@ -252,6 +252,14 @@ typedef struct vpt_volume {
     int32_t approximated_scattering;          /* ApproximatedScatteringForClouds: g^(1+depth), density * falloff^depth */
     float approximated_scattering_falloff;
     float grid_sharpness;                     /* GridSharpness (heterogeneous only) */
+    /* Emission from temperature (Volume.slang:233-258).  Upstream the host writes the normalised temperature INTO the
+     * density grid wherever it is positive (PathTracer.cpp:1444-1454) and the shader reads that same grid
+     * (Volume.slang:238): has_temperature_data = 1 means "the grid attached to this volume is that merged grid". */
+    int32_t has_temperature_data;
+    int32_t use_blackbody;                    /* 1: Blackbody(kelvin), 0: temperature_color */
+    float temperature_color[3];
+    float temperature_gamma, temperature_scale, emissive_color_gamma;
+    int32_t kelvin_min, kelvin_max;
 } vpt_volume;
 #define VPT_MAX_VOLUMES 32       /* the reference sorts into fixed float[100] / int[100] arrays (RayGen.slang:165-166) */
 #define VPT_PHASE_HENYEY_GREENSTEIN 0        /* PathTracer.h:76-81 PhaseFunction */

@@ -877,6 +877,25 @@ VolBlock block_info(const vpt_volume& v, V3 pos, const VolTrav& c) {  // Volume.
     return b;
 }
 VolIsect ray_aabb3(V3 org, V3 dir, V3 lo, V3 hi) { float a[3] = {lo.x, lo.y, lo.z}, b[3] = {hi.x, hi.y, hi.z}; return ray_aabb(org, dir, a, b); }
+V3 blackbody(float kelvin) {  // RTCommon.slang:139-172
+    float temp = kelvin / 100.0f;
+    float r, g, b;
+    if (temp <= 66.0f) r = 255.0f; else r = 329.698727446f * pow_(temp - 60.0f, -0.1332047592f);
+    if (temp <= 66.0f) g = 99.4708025861f * log_(temp) - 161.1195681661f; else g = 288.1221695283f * pow_(temp - 60.0f, -0.0755148492f);
+    if (temp >= 66.0f) b = 255.0f; else if (temp <= 19.0f) b = 0.0f; else b = 138.5177312231f * log_(temp - 10.0f) - 305.0447927307f;
+    V3 c = v3(r, g, b) / 255.0f;
+    return v3(clamp_(c.x, 0.0f, 1.0f), clamp_(c.y, 0.0f, 1.0f), clamp_(c.z, 0.0f, 1.0f));
+}
+// GetEmissionFromTemperatureAtPoint, Volume.slang:233-258 (reads the volume's density grid: see vpt.h)
+V3 temperature_emission(const Oracle& o, const vpt_volume& v, Rng& r, V3 x) {
+    if (!v.has_temperature_data) return v3s(0.0f);
+    float tn = sample_density_grid(o, v, r, x);
+    V3 color;
+    if (v.use_blackbody) color = blackbody(tn * (float)(v.kelvin_max - v.kelvin_min) + (float)v.kelvin_min);
+    else color = P3(v.temperature_color);
+    float intensity = pow_(tn, v.temperature_gamma) * v.temperature_scale;
+    return intensity * v3(pow_(color.x, v.emissive_color_gamma), pow_(color.y, v.emissive_color_gamma), pow_(color.z, v.emissive_color_gamma));
+}
 // ProcessHeterogeneousVolumeScattering, Volume.slang:299-348: delta tracking block by block
 float heterogeneous_scatter(const Oracle& o, const vpt_volume& v, V3 org, V3 dir, Rng& r, float depth, VolIsect is) {
     const Oracle::DensityGrid& g = o.grids[v.density_data_index];
@@ -980,7 +999,7 @@ void importance_sample_env(const Oracle& o, Rng& r, V3& to_light, V4& out);
 void volume_scatter_event(const Oracle& o, Payload& p, float sd, int vi, Counters* c) {
     const vpt_volume& v = o.volumes[vi];
     p.origin = p.origin + p.direction * sd;
-    p.emitted = P3(v.emissive_color);  // + GetEmissionFromTemperatureAtPoint == 0 without temperature data
+    p.emitted = P3(v.emissive_color) + temperature_emission(o, v, p.rng, p.origin);  // :268
     V3 to_sky = v3s(0.0f); V4 sky; sky.x = sky.y = sky.z = sky.w = 0.0f;
     if (o.P.flags & VPT_FLAG_SKY_MIS) {
         importance_sample_sky(o, p.rng, to_sky, sky);
@@ -1478,7 +1497,7 @@ void orc_set_material(void* h, uint32_t idx, const vpt_material* m) { Oracle* o 
 int orc_set_volumes(void* h, const vpt_volume* v, uint32_t n) {
     Oracle* o = (Oracle*)h;
     if (n > VPT_MAX_VOLUMES) return -1;
-    for (uint32_t i = 0; i < n; i++) if (v[i].density_data_index < -1 || v[i].density_data_index >= (int)o->grids.size()) return -1;
+    for (uint32_t i = 0; i < n; i++) if (v[i].density_data_index < -1 || v[i].density_data_index >= (int)o->grids.size() || (v[i].has_temperature_data && v[i].density_data_index < 0)) return -1;
     o->volumes.assign(v, v + n); orc_reset(h);
     return 0;
 }

@@ -162,3 +162,27 @@ def test_heterogeneous_cloud_under_the_atmosphere(vpt, oracle, scenes):
         x.set_volumes(vols); x.set_atmosphere(vpt.atmosphere()); x.render(3)
     ref = o.radiance(); img = g.radiance(); o.close(); g.close()
     assert_parity(img, ref)
+
+
+@pytest.mark.parametrize("blackbody", [1, 0])
+def test_fire_volume_temperature_emission(vpt, oracle, scenes, blackbody):
+    """Emission from temperature (Volume.slang:233-258): blackbody colour ramp or a fixed colour, intensity
+    temperature^gamma * scale, read from the volume's (merged) grid with the jittered lookup."""
+    from test_oracle_volumes import cloud_grid
+    sc = scenes("cornell_box")
+    P = vpt.default_params(max_depth=6)
+    o = oracle.Oracle(sc, 128, 72); o.set_params(P); gi = o.add_density_grid(cloud_grid(seed=9))
+    g = vpt.PathTracer(128, 72); g.set_scene(sc); g.set_params(P); g.add_density_grid(cloud_grid(seed=9))
+    fire = vpt.volume(corner_min=(-3.0, -7.0, -3.0), corner_max=(3.0, -0.5, 3.0), color=(0.2, 0.2, 0.2), density=1.2, density_data_index=gi,
+                      has_temperature_data=1, use_blackbody=blackbody, temperature_color=(1.0, 0.4, 0.1), temperature_gamma=1.7, temperature_scale=6.0,
+                      emissive_color_gamma=2.2, kelvin_min=800, kelvin_max=7000)
+    for x in (o, g):
+        x.set_volumes([fire]); x.render(3)
+    ref = o.radiance(); img = g.radiance()
+    assert_parity(img, ref)
+    cold = vpt.volume(corner_min=(-3.0, -7.0, -3.0), corner_max=(3.0, -0.5, 3.0), color=(0.2, 0.2, 0.2), density=1.2, density_data_index=gi)
+    g.set_volumes([cold]); g.render(3)
+    assert g.radiance()[..., :3].sum() < img[..., :3].sum()      # the fire adds light
+    with pytest.raises(vpt.VptError, match="INVALID"):
+        g.set_volumes([vpt.volume(has_temperature_data=1)])     # temperature without a grid
+    o.close(); g.close()

@@ -43,11 +43,13 @@ class Volume(C.Structure):  # vpt_volume
         ("corner_min", C.c_float * 3), ("corner_max", C.c_float * 3), ("color", C.c_float * 3), ("emissive_color", C.c_float * 3),
         ("density", C.c_float), ("anisotropy", C.c_float), ("alpha", C.c_float), ("droplet_size", C.c_float),
         ("density_data_index", C.c_int32), ("approximated_scattering", C.c_int32), ("approximated_scattering_falloff", C.c_float),
-        ("grid_sharpness", C.c_float),
+        ("grid_sharpness", C.c_float), ("has_temperature_data", C.c_int32), ("use_blackbody", C.c_int32), ("temperature_color", C.c_float * 3),
+        ("temperature_gamma", C.c_float), ("temperature_scale", C.c_float), ("emissive_color_gamma", C.c_float),
+        ("kelvin_min", C.c_int32), ("kelvin_max", C.c_int32),
     ]
 
 
-assert C.sizeof(Volume) == 80
+assert C.sizeof(Volume) == 120
 
 
 class Atmosphere(C.Structure):  # vpt_atmosphere
@@ -80,13 +82,19 @@ PHASE_HENYEY_GREENSTEIN, PHASE_DRAINE, PHASE_HENYEY_GREENSTEIN_PLUS_DRAINE = 0, 
 
 
 def volume(corner_min=(-1, -1, -1), corner_max=(1, 1, 1), color=(0.8, 0.8, 0.8), emissive_color=(0, 0, 0), density=1.0, anisotropy=0.0,
-           alpha=1.0, droplet_size=20.0, approximated_scattering=0, approximated_scattering_falloff=0.8, density_data_index=-1, grid_sharpness=1.0):
+           alpha=1.0, droplet_size=20.0, approximated_scattering=0, approximated_scattering_falloff=0.8, density_data_index=-1, grid_sharpness=1.0,
+           has_temperature_data=0, use_blackbody=1, temperature_color=(1.0, 0.5, 0.0), temperature_gamma=1.0, temperature_scale=1.0,
+           emissive_color_gamma=1.0, kelvin_min=500, kelvin_max=8000):
     """PathTracer::Volume defaults (PathTracer.h:36-74); corners are world space (Position + Corner * Scale applied)."""
     v = Volume()
     v.corner_min[:] = corner_min; v.corner_max[:] = corner_max; v.color[:] = color; v.emissive_color[:] = emissive_color
     v.density, v.anisotropy, v.alpha, v.droplet_size = density, anisotropy, alpha, droplet_size
     v.density_data_index = density_data_index
     v.grid_sharpness = grid_sharpness
+    v.has_temperature_data, v.use_blackbody = has_temperature_data, use_blackbody
+    v.temperature_color[:] = temperature_color
+    v.temperature_gamma, v.temperature_scale, v.emissive_color_gamma = temperature_gamma, temperature_scale, emissive_color_gamma
+    v.kelvin_min, v.kelvin_max = kelvin_min, kelvin_max
     v.approximated_scattering, v.approximated_scattering_falloff = approximated_scattering, approximated_scattering_falloff
     return v
 

@@ -67,7 +67,7 @@ __device__ inline void sample_sun_disk(const DeviceScene& sc, const RenderParams
 // Sampler::ImportanceSampleSky, Sampler.slang:464-476
 __device__ inline void sample_sky(const DeviceScene& sc, const RenderParams& P, Rng& r, V3& to_light, V4& out) {
     if (sc.atm_on) sample_sun_disk(sc, P, r, 0.004675f, to_light, out);
-    else sample_env(sc, P, r, to_light, out);
+    else sample_env(sc, P, r, to_light, out, sc.hetero != 0u);
 }
 __device__ inline float atmosphere_height(const DeviceScene& sc, V3 p) { return length(p - ld3(sc.atm.planet_position)) - sc.atm.planet_radius; }
 __device__ inline float rayleigh_density(const DeviceScene& sc, float h) { return exp_(-h / sc.atm.rayleigh_density_falloff); }

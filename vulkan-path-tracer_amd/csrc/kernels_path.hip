@@ -251,7 +251,7 @@ __device__ __forceinline__ void shade_core(const DeviceScene& sc, const RenderPa
         // ---- EvaluateVolumeScatteringEvent, RayGen.slang:265-380 (no atmosphere, no temperature grid)
         const vpt_volume& v = sc.volumes[in_.vol_index];
         new_o = porg + pdir * in_.vol_t;
-        emitted = ld3(v.emissive_color);
+        emitted = ld3(v.emissive_color) + temperature_emission(sc, v, rng, new_o);  // RayGen.slang:268
         V3 to_sky = v3s(0.0f); V4 sky = v4(0.0f, 0.0f, 0.0f, 0.0f);
         if (P.flags & VPT_FLAG_SKY_MIS) {
             sample_sky(sc, P, rng, to_sky, sky);

@@ -344,8 +344,10 @@ __device__ inline V3 sample_hg(Rng& r, V3 dir, float G) {  // :168-193
     return normalize((nd.x * t + nd.y * b) + nd.z * dir);
 }
 // ImportanceSampleEnvMap, :286-346 (3 draws)
-__device__ inline void sample_env(const DeviceScene& sc, const RenderParams& P, Rng& r, V3& to_light, V4& out) {
-    if (sc.env_black) {
+// `need_direction`: the caller uses to_light even when the sample carries no light (media whose transmittance is tracked
+// along the shadow ray), so the all-black shortcut does not apply
+__device__ inline void sample_env(const DeviceScene& sc, const RenderParams& P, Rng& r, V3& to_light, V4& out, bool need_direction = false) {
+    if (sc.env_black && !need_direction) {
         // every texel and every pdf is exactly 0: the bilinear result is +0 for any direction, so only the
         // three draws (Sampler.slang:289) have an effect
         r.s = pcg_hash(pcg_hash(pcg_hash(r.s)));

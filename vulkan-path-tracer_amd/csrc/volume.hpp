@@ -133,6 +133,25 @@ __device__ inline VolBlock block_info(const vpt_volume& v, V3 pos, const VolTrav
     return b;
 }
 __device__ inline VolIsect ray_aabb3(V3 org, V3 dir, V3 lo, V3 hi) { float a[3] = {lo.x, lo.y, lo.z}, b[3] = {hi.x, hi.y, hi.z}; return ray_aabb(org, dir, a, b); }
+__device__ inline V3 blackbody(float kelvin) {  // RTCommon.slang:139-172
+    float temp = kelvin / 100.0f;
+    float r, g, b;
+    if (temp <= 66.0f) r = 255.0f; else r = 329.698727446f * pow_(temp - 60.0f, -0.1332047592f);
+    if (temp <= 66.0f) g = 99.4708025861f * log_(temp) - 161.1195681661f; else g = 288.1221695283f * pow_(temp - 60.0f, -0.0755148492f);
+    if (temp >= 66.0f) b = 255.0f; else if (temp <= 19.0f) b = 0.0f; else b = 138.5177312231f * log_(temp - 10.0f) - 305.0447927307f;
+    V3 c = v3(r, g, b) / 255.0f;
+    return v3(clamp_(c.x, 0.0f, 1.0f), clamp_(c.y, 0.0f, 1.0f), clamp_(c.z, 0.0f, 1.0f));
+}
+// GetEmissionFromTemperatureAtPoint, Volume.slang:233-258 (reads the volume's density grid: see vpt.h)
+__device__ inline V3 temperature_emission(const DeviceScene& sc, const vpt_volume& v, Rng& r, V3 x) {
+    if (!v.has_temperature_data) return v3s(0.0f);
+    float tn = sample_density_grid(sc, v, r, x);
+    V3 color;
+    if (v.use_blackbody) color = blackbody(tn * (float)(v.kelvin_max - v.kelvin_min) + (float)v.kelvin_min);
+    else color = ld3(v.temperature_color);
+    float intensity = pow_(tn, v.temperature_gamma) * v.temperature_scale;
+    return intensity * v3(pow_(color.x, v.emissive_color_gamma), pow_(color.y, v.emissive_color_gamma), pow_(color.z, v.emissive_color_gamma));
+}
 // ProcessHeterogeneousVolumeScattering, Volume.slang:299-348: delta tracking block by block
 __device__ inline float heterogeneous_scatter(const DeviceScene& sc, const vpt_volume& v, V3 org, V3 dir, Rng& r, float depth, VolIsect is) {
     const DensityGrid& g = sc.grids[v.density_data_index];

@@ -647,6 +647,7 @@ int vpt_set_volumes(vpt_ctx* c, const vpt_volume* v, uint32_t count) {
     for (uint32_t i = 0; i < count; i++) {
         if (v[i].density_data_index < -1 || v[i].density_data_index >= (int)c->grids.size())
             return fail(c, VPT_ERR_INVALID_ARGUMENT, "density_data_index must be -1 or an index returned by vpt_add_density_grid");
+        if (v[i].has_temperature_data && v[i].density_data_index < 0) return fail(c, VPT_ERR_INVALID_ARGUMENT, "has_temperature_data needs a density grid");
         if (!(v[i].density > 0.0f)) return fail(c, VPT_ERR_INVALID_ARGUMENT, "volume density must be > 0");  // -log(u)/0 (Sampler.slang:427)
     }
     HIPCHK(c, hipSetDevice(c->cfg.device));

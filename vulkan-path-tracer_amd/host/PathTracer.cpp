@@ -92,6 +92,10 @@ void PathTracer::UploadVolumes() {
         o.emissive_color[0] = v.EmissiveColor.x; o.emissive_color[1] = v.EmissiveColor.y; o.emissive_color[2] = v.EmissiveColor.z;
         o.density = v.Density; o.anisotropy = v.Anisotropy; o.alpha = v.Alpha; o.droplet_size = v.DropletSize;
         o.density_data_index = v.DensityDataIndex; o.grid_sharpness = v.GridSharpness;
+        o.has_temperature_data = v.HasTemperatureData; o.use_blackbody = v.UseBlackbody;
+        o.temperature_color[0] = v.TemperatureColor.x; o.temperature_color[1] = v.TemperatureColor.y; o.temperature_color[2] = v.TemperatureColor.z;
+        o.temperature_gamma = v.TemperatureGamma; o.temperature_scale = v.TemperatureScale; o.emissive_color_gamma = v.EmissiveColorGamma;
+        o.kelvin_min = v.KelvinMin; o.kelvin_max = v.KelvinMax;
         o.approximated_scattering = v.ApproximatedScatteringForClouds; o.approximated_scattering_falloff = v.ApproximatedScatteringFalloff;
         g.push_back(o);
     }

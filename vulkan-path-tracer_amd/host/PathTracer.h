@@ -29,6 +29,9 @@ public:
         float ApproximatedScatteringFalloff = 0.8f;
         int DensityDataIndex = -1;   // set by AddDensityDataToVolume
         float GridSharpness = 1.0f;
+        Vec3 TemperatureColor{1.0f, 0.5f, 0.0f};
+        int UseBlackbody = 1, HasTemperatureData = 0, KelvinMin = 500, KelvinMax = 8000;
+        float TemperatureGamma = 1.0f, TemperatureScale = 1.0f, EmissiveColorGamma = 1.0f;
     };
     enum class PhaseFunction { HENYEY_GREENSTEIN = 0, DRAINE = 1, HENYEY_GREENSTEIN_PLUS_DRAINE = 2 };  // PathTracer.h:76-81
 
