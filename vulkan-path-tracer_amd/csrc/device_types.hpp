@@ -186,6 +186,9 @@ struct Counters {
     uint32_t extend_head, connect_head;  // persistent-kernel work cursors
     uint32_t shadow_rays;     // shadow rays queued by shade this bounce
     uint32_t pad;
+    // fused pipeline: three rotating queue sizes — bounce k reads rc3[k % 3], appends to rc3[(k + 1) % 3] and zeroes
+    // rc3[(k + 2) % 3] (idle during bounce k), so no separate reset kernel sits between two bounces
+    uint32_t rc3[4];
     unsigned long long stat_closest, stat_shadow, stat_connect;  // folded per bounce by k_prepare / k_fold
     unsigned long long stat_nodes, stat_tris;                // extend kernel (count_traversal builds only)
     unsigned long long stat_shadow_nodes, stat_shadow_tris;  // connect kernel

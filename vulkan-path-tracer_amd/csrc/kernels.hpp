@@ -6,9 +6,9 @@ namespace vpt {
 
 void launch_bounce(hipStream_t s, uint32_t blocks, bool lds_scene, bool count, bool first, const DeviceScene& sc, const RenderParams& P,
                    const PathState& ps, const uint32_t* queue, uint32_t* queue_next, Counters* ctr, uint32_t parity, uint32_t n_slots,
-                   uint32_t dispatch_base);
+                   uint32_t dispatch_base, uint32_t k3);
 int bounce_blocks_per_cu(bool lds_scene, const DeviceScene& sc);
-void launch_raygen(hipStream_t s, const RenderParams& P, const PathState& ps, uint32_t* queue, uint32_t n_slots, uint32_t dispatch_base);
+void launch_raygen(hipStream_t s, const RenderParams& P, const PathState& ps, uint32_t* queue, Counters* ctr, uint32_t n_slots, uint32_t dispatch_base);
 void launch_prepare(hipStream_t s, Counters* ctr, uint32_t parity);
 void launch_fold(hipStream_t s, Counters* ctr);
 void launch_extend(hipStream_t s, uint32_t blocks, bool lds_scene, bool count, const DeviceScene& sc, const PathState& ps,
@@ -17,7 +17,7 @@ void launch_shade(hipStream_t s, uint32_t blocks, const DeviceScene& sc, const R
                   const uint32_t* queue, uint32_t* queue_next, uint32_t* cqueue, Counters* ctr, uint32_t parity);
 void launch_connect(hipStream_t s, uint32_t blocks, bool lds_scene, bool count, const DeviceScene& sc, const RenderParams& P,
                     const PathState& ps, const uint32_t* cqueue, Counters* ctr, uint32_t parity);
-void launch_resolve(hipStream_t s, const RenderParams& P, const PathState& ps, float* image, uint32_t frames, uint32_t frame_base);
+void launch_resolve(hipStream_t s, const RenderParams& P, const PathState& ps, float* image, uint32_t frames, uint32_t frame_base, const uint32_t* guard);
 void launch_trace_rays(hipStream_t s, uint32_t blocks, const DeviceScene& sc, const vpt_ray* rays, uint32_t n, vpt_hit* hits);
 void launch_scatter_rows(hipStream_t s, const float* gathered, float* full, uint32_t w, uint32_t h, uint32_t shard_count, uint32_t stride_px);
 void launch_precompute_materials(hipStream_t s, const DeviceScene& sc, uint32_t flags, MatResolved* out, uint32_t n);

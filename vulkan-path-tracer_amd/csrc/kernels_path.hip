@@ -67,8 +67,9 @@ __device__ inline void launch_pixel(const RenderParams& P, uint32_t li, uint32_t
 // ------------------------------------------------------------------ raygen (staged pipeline only)
 // Scenes whose BVH does not fit in LDS run bounce 0 through the same extend / shade / connect stages as every
 // other bounce, so the camera rays are written out as ordinary path records.
-__global__ __launch_bounds__(256) void k_raygen(RenderParams P, PathState ps, uint32_t* queue, uint32_t n_slots, uint32_t dispatch_base) {
+__global__ __launch_bounds__(256) void k_raygen(RenderParams P, PathState ps, uint32_t* queue, Counters* ctr, uint32_t n_slots, uint32_t dispatch_base) {
     uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
+    if (li == 0u) ctr->ray_count[0] = n_slots;  // the counters were zeroed at the start of the batch
     if (li >= n_slots) return;
     uint32_t slot, x, y, f;
     launch_pixel(P, li, dispatch_base, slot, x, y, f);
@@ -660,7 +661,7 @@ __global__ __launch_bounds__(256, 3) void k_shade(DeviceScene sc, RenderParams P
 template <bool LDS_SCENE, bool COUNT, bool FIRST, bool VOL>
 __global__ __launch_bounds__(kTraverseBlock, 3) void k_bounce(DeviceScene sc, RenderParams P, PathState ps, const uint32_t* queue,
                                                              uint32_t* queue_next, Counters* ctr, uint32_t parity, uint32_t n_slots,
-                                                             uint32_t dispatch_base) {
+                                                             uint32_t dispatch_base, uint32_t k3) {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ uint32_t s_cnt[4][3];
     __shared__ uint32_t s_base[4];
@@ -668,7 +669,8 @@ __global__ __launch_bounds__(kTraverseBlock, 3) void k_bounce(DeviceScene sc, Re
     float4* lds_nodes = reinterpret_cast<float4*>(smem + kStackDepth * kTraverseBlock * 4);
     float4* lds_tris = lds_nodes + sc.node_count * 8;
     stage_scene<LDS_SCENE>(sc, lds_nodes, lds_tris);
-    const uint32_t n = FIRST ? n_slots : ctr->ray_count[parity];
+    const uint32_t n = FIRST ? n_slots : ctr->rc3[k3];  // k3 = bounce index % 3 (Counters::rc3)
+    uint32_t* const n_next = &ctr->rc3[(k3 + 1u) % 3u];
     const float4* Tin = ps.T[parity];
     float4* Tout = ps.T[parity ^ 1u];
     const uint32_t wave = threadIdx.x >> 6;
@@ -676,7 +678,7 @@ __global__ __launch_bounds__(kTraverseBlock, 3) void k_bounce(DeviceScene sc, Re
     cpt = cpt < 1u ? 1u : (cpt > 4u ? 4u : cpt);
     const uint32_t tile_size = cpt * 256u;
     TravStats st, sst; st.nodes = 0; st.tris = 0; sst.nodes = 0; sst.tris = 0;
-    if (FIRST && blockIdx.x == 0 && threadIdx.x == 0) ctr->stat_closest += n;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { ctr->stat_closest += n; ctr->rc3[(k3 + 2u) % 3u] = 0u; }
     for (uint32_t tile = blockIdx.x * tile_size; tile < n; tile += gridDim.x * tile_size) {
         uint32_t res = 0u;  // bit c: path c of this lane survives
         uint32_t s0 = 0u, s1 = 0u, s2 = 0u, s3 = 0u;
@@ -819,8 +821,8 @@ __global__ __launch_bounds__(kTraverseBlock, 3) void k_bounce(DeviceScene sc, Re
         if (threadIdx.x == 0) {
             uint32_t sum = 0u, rays = 0u, hits = 0u, pre[4];
             for (uint32_t w = 0; w < 4; w++) { pre[w] = sum; sum += s_cnt[w][0]; rays += s_cnt[w][1]; hits += s_cnt[w][2]; }
-            uint32_t b = sum ? atomicAdd(&ctr->ray_count[parity ^ 1u], sum) : 0u;
-            if (rays) atomicAdd(&ctr->shadow_rays, rays);
+            uint32_t b = sum ? atomicAdd(n_next, sum) : 0u;
+            if (rays) atomicAdd(&ctr->stat_shadow, (unsigned long long)rays);
             if (FIRST) {
                 if (hits) atomicAdd(&ctr->stat_primary_hits, (unsigned long long)hits);
                 if (sum) atomicAdd(&ctr->stat_primary_alive, (unsigned long long)sum);
@@ -951,7 +953,11 @@ __global__ __launch_bounds__(kTraverseBlock, 8) void k_connect(DeviceScene sc, R
 
 // ------------------------------------------------------------------ resolve: running mean, frames applied in order
 // frame_base = index of the first dispatch of the batch (== FrameCount when ScreenSplitCount is 1).
-__global__ __launch_bounds__(256) void k_resolve(RenderParams P, PathState ps, float4* image, uint32_t frames, uint32_t frame_base) {
+// `guard`: queue size word that must be 0 (every path of the batch has finished) — the host enqueues the resolve right
+// behind the bounces it expects to be the last ones and only then looks at the counter; if paths were still alive the
+// launch does nothing and is repeated after more bounces.
+__global__ __launch_bounds__(256) void k_resolve(RenderParams P, PathState ps, float4* image, uint32_t frames, uint32_t frame_base, const uint32_t* guard) {
+    if (guard && *guard != 0u) return;
     uint32_t sp = blockIdx.x * blockDim.x + threadIdx.x;
     if (sp >= P.shard_pixels) return;
     float4 px = image[sp];
@@ -1056,10 +1062,10 @@ static inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 // first == true: bounce 0 of n_slots fresh slots (queue unused); otherwise one fused bounce of queue[parity].
 void launch_bounce(hipStream_t s, uint32_t blocks, bool lds_scene, bool count, bool first, const DeviceScene& sc, const RenderParams& P,
                    const PathState& ps, const uint32_t* queue, uint32_t* queue_next, Counters* ctr, uint32_t parity, uint32_t n_slots,
-                   uint32_t dispatch_base) {
+                   uint32_t dispatch_base, uint32_t k3) {
     size_t lds = traverse_lds_bytes(sc, lds_scene);
     dim3 g(blocks), b(kTraverseBlock);
-#define VPT_LAUNCH_BOUNCE_V(L, C, F, V) hipLaunchKernelGGL((k_bounce<L, C, F, V>), g, b, lds, s, sc, P, ps, queue, queue_next, ctr, parity, n_slots, dispatch_base)
+#define VPT_LAUNCH_BOUNCE_V(L, C, F, V) hipLaunchKernelGGL((k_bounce<L, C, F, V>), g, b, lds, s, sc, P, ps, queue, queue_next, ctr, parity, n_slots, dispatch_base, k3)
 #define VPT_LAUNCH_BOUNCE(L, C, F) VPT_LAUNCH_BOUNCE_V(L, C, F, false)
     if (sc.volume_count > 0u || sc.atm_on) {  // the media variants carry no traversal counters
         if (lds_scene) { if (first) VPT_LAUNCH_BOUNCE_V(true, false, true, true); else VPT_LAUNCH_BOUNCE_V(true, false, false, true); }
@@ -1081,8 +1087,8 @@ int bounce_blocks_per_cu(bool lds_scene, const DeviceScene& sc) {
     else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_bounce<false, false, false, false>, kTraverseBlock, lds);
     return nb > 0 ? nb : 1;
 }
-void launch_raygen(hipStream_t s, const RenderParams& P, const PathState& ps, uint32_t* queue, uint32_t n_slots, uint32_t dispatch_base) {
-    hipLaunchKernelGGL(k_raygen, dim3(cdiv(n_slots, 256)), dim3(256), 0, s, P, ps, queue, n_slots, dispatch_base);
+void launch_raygen(hipStream_t s, const RenderParams& P, const PathState& ps, uint32_t* queue, Counters* ctr, uint32_t n_slots, uint32_t dispatch_base) {
+    hipLaunchKernelGGL(k_raygen, dim3(cdiv(n_slots, 256)), dim3(256), 0, s, P, ps, queue, ctr, n_slots, dispatch_base);
 }
 void launch_prepare(hipStream_t s, Counters* ctr, uint32_t parity) { hipLaunchKernelGGL(k_prepare, dim3(1), dim3(1), 0, s, ctr, parity); }
 void launch_fold(hipStream_t s, Counters* ctr) { hipLaunchKernelGGL(k_fold, dim3(1), dim3(1), 0, s, ctr); }
@@ -1118,8 +1124,8 @@ void launch_shade(hipStream_t s, uint32_t blocks, const DeviceScene& sc, const R
                   const uint32_t* queue, uint32_t* queue_next, uint32_t* cqueue, Counters* ctr, uint32_t parity) {
     hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(256), 0, s, sc, P, ps, queue, queue_next, cqueue, ctr, parity);
 }
-void launch_resolve(hipStream_t s, const RenderParams& P, const PathState& ps, float* image, uint32_t frames, uint32_t frame_base) {
-    hipLaunchKernelGGL(k_resolve, dim3(cdiv(P.shard_pixels, 256)), dim3(256), 0, s, P, ps, reinterpret_cast<float4*>(image), frames, frame_base);
+void launch_resolve(hipStream_t s, const RenderParams& P, const PathState& ps, float* image, uint32_t frames, uint32_t frame_base, const uint32_t* guard) {
+    hipLaunchKernelGGL(k_resolve, dim3(cdiv(P.shard_pixels, 256)), dim3(256), 0, s, P, ps, reinterpret_cast<float4*>(image), frames, frame_base, guard);
 }
 void launch_trace_rays(hipStream_t s, uint32_t blocks, const DeviceScene& sc, const vpt_ray* rays, uint32_t n, vpt_hit* hits) {
     uint32_t g = cdiv(n, kTraverseBlock);

@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstddef>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -307,15 +308,14 @@ int render_batch(vpt_ctx* c, uint32_t frames, uint32_t dispatch_base) {
     // volumes are integrated in the fused per-bounce kernel only
     const bool vol = !c->volumes.empty() || c->dsc.atm_on;
     const bool fused = vol || c->cfg.pipeline == VPT_PIPELINE_FUSED || (c->cfg.pipeline == VPT_PIPELINE_AUTO && (c->lds_scene || c->auto_fused));
-    Counters init{};
-    if (!fused) init.ray_count[0] = n_slots;
-    HIPCHK(c, hipMemcpyAsync(c->ctr, &init, 32, hipMemcpyHostToDevice, s));  // queue words only, stat_* keep running
+    HIPCHK(c, hipMemsetAsync(c->ctr, 0, offsetof(Counters, stat_closest), s));  // queue words only, stat_* keep running
     uint32_t parity;
+    uint32_t k3 = 0;  // fused: bounce index % 3 (Counters::rc3)
     if (fused) {  // bounce 0 of every slot needs no input records; survivors land in queue[1]
-        TIMED(c, VPT_K_PRIMARY, launch_bounce(s, (uint32_t)c->primary_blocks, c->lds_scene, count, true, c->dsc, c->P, c->ps, nullptr, c->queue[1], c->ctr, 0u, n_slots, dispatch_base));
-        parity = 1;
+        TIMED(c, VPT_K_PRIMARY, launch_bounce(s, (uint32_t)c->primary_blocks, c->lds_scene, count, true, c->dsc, c->P, c->ps, nullptr, c->queue[1], c->ctr, 0u, n_slots, dispatch_base, 0u));
+        parity = 1; k3 = 1;
     } else {
-        TIMED(c, VPT_K_PRIMARY, launch_raygen(s, c->P, c->ps, c->queue[0], n_slots, dispatch_base));
+        TIMED(c, VPT_K_PRIMARY, launch_raygen(s, c->P, c->ps, c->queue[0], c->ctr, n_slots, dispatch_base));
         parity = 0;
     }
     const uint64_t min_bounces = (uint64_t)c->P.max_depth * c->P.samples_per_frame;
@@ -324,19 +324,23 @@ int render_batch(vpt_ctx* c, uint32_t frames, uint32_t dispatch_base) {
     uint32_t chunk = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(min_bounces - (fused ? 1 : 0), 1), 8);
     while (true) {
         for (uint32_t j = 0; j < chunk; j++) {
-            launch_prepare(s, c->ctr, parity);
-            if (fused) {
-                TIMED(c, VPT_K_BOUNCE, launch_bounce(s, (uint32_t)c->primary_blocks, c->lds_scene, count, false, c->dsc, c->P, c->ps, c->queue[parity], c->queue[parity ^ 1u], c->ctr, parity, 0u, 0u));
-                parity ^= 1u;
+            if (fused) {  // no reset kernel in between: the bounce kernels rotate three queue-size words
+                TIMED(c, VPT_K_BOUNCE, launch_bounce(s, (uint32_t)c->primary_blocks, c->lds_scene, count, false, c->dsc, c->P, c->ps, c->queue[parity], c->queue[parity ^ 1u], c->ctr, parity, 0u, 0u, k3));
+                parity ^= 1u; k3 = (k3 + 1u) % 3u;
                 continue;
             }
+            launch_prepare(s, c->ctr, parity);
             TIMED(c, VPT_K_EXTEND, launch_extend(s, (uint32_t)c->trav_blocks, c->lds_scene, count, c->dsc, c->ps, c->queue[parity], c->ctr, parity));
             TIMED(c, VPT_K_SHADE, launch_shade(s, (uint32_t)c->shade_blocks, c->dsc, c->P, c->ps, c->queue[parity], c->queue[parity ^ 1u], c->cqueue, c->ctr, parity));
             TIMED(c, VPT_K_CONNECT, launch_connect(s, (uint32_t)c->trav_blocks, c->lds_scene, count, c->dsc, c->P, c->ps, c->cqueue, c->ctr, parity));
             parity ^= 1u;
         }
         iter += chunk;
-        launch_fold(s, c->ctr);
+        if (!fused) launch_fold(s, c->ctr);
+        // the resolve rides right behind the bounces that are expected to be the last ones; it does nothing if a path is
+        // still alive (in-medium walks do not consume depth), in which case more bounces and another resolve follow
+        const uint32_t* guard = fused ? &c->ctr->rc3[k3] : &c->ctr->ray_count[parity];
+        TIMED(c, VPT_K_RESOLVE, launch_resolve(s, c->P, c->ps, c->image, frames, dispatch_base, guard));
         Counters h{};
         HIPCHK(c, hipMemcpyAsync(&h, c->ctr, sizeof(Counters), hipMemcpyDeviceToHost, s));
         HIPCHK(c, hipStreamSynchronize(s));
@@ -351,15 +355,12 @@ int render_batch(vpt_ctx* c, uint32_t frames, uint32_t dispatch_base) {
         c->stats.tris_tested = h.stat_tris;
         c->stats.shadow_nodes_visited = h.stat_shadow_nodes;
         c->stats.shadow_tris_tested = h.stat_shadow_tris;
-        uint32_t n = h.ray_count[parity];
+        uint32_t n = fused ? h.rc3[k3] : h.ray_count[parity];
         if (n > n_slots) return fail(c, VPT_ERR_DEVICE, "internal: queue overflow");
         if (n == 0) break;
         if (iter > iter_cap) return fail(c, VPT_ERR_DEVICE, "internal: bounce loop did not terminate");
         chunk = 4;
     }
-    TIMED(c, VPT_K_RESOLVE, launch_resolve(s, c->P, c->ps, c->image, frames, dispatch_base));
-    HIPCHK(c, hipStreamSynchronize(s));
-    collect_timing(c);
     HIPCHK(c, hipGetLastError());
     c->stats.samples += (uint64_t)n_slots * c->P.samples_per_frame;
     return VPT_OK;
