@@ -95,6 +95,19 @@ public:
     void SetSunColor(Vec3 c) { Set3(m_Atmosphere.sun_color, c); }
     [[nodiscard]] bool IsAtmosphereEnabled() const { return m_EnableAtmosphere; }
     [[nodiscard]] const vpt_atmosphere& GetAtmosphere() const { return m_Atmosphere; }
+    [[nodiscard]] Vec3 GetPlanetPosition() const { return Vec3(m_Atmosphere.planet_position[0], m_Atmosphere.planet_position[1], m_Atmosphere.planet_position[2]); }
+    [[nodiscard]] float GetPlanetRadius() const { return m_Atmosphere.planet_radius; }
+    [[nodiscard]] float GetAtmosphereHeight() const { return m_Atmosphere.atmosphere_height; }
+    [[nodiscard]] Vec3 GetRayleighScatteringCoefficientMultiplier() const { return Vec3(m_Atmosphere.rayleigh_multiplier[0], m_Atmosphere.rayleigh_multiplier[1], m_Atmosphere.rayleigh_multiplier[2]); }
+    [[nodiscard]] Vec3 GetMieScatteringCoefficientMultiplier() const { return Vec3(m_Atmosphere.mie_multiplier[0], m_Atmosphere.mie_multiplier[1], m_Atmosphere.mie_multiplier[2]); }
+    [[nodiscard]] Vec3 GetOzoneAbsorptionCoefficientMultiplier() const { return Vec3(m_Atmosphere.ozone_multiplier[0], m_Atmosphere.ozone_multiplier[1], m_Atmosphere.ozone_multiplier[2]); }
+    [[nodiscard]] float GetRayleighDensityFalloff() const { return m_Atmosphere.rayleigh_density_falloff; }
+    [[nodiscard]] float GetMieDensityFalloff() const { return m_Atmosphere.mie_density_falloff; }
+    [[nodiscard]] float GetOzoneDensityFalloff() const { return m_Atmosphere.ozone_density_falloff; }
+    [[nodiscard]] float GetOzonePeak() const { return m_Atmosphere.ozone_peak; }
+    [[nodiscard]] Vec3 GetSunColor() const { return Vec3(m_Atmosphere.sun_color[0], m_Atmosphere.sun_color[1], m_Atmosphere.sun_color[2]); }
+    // GetOutputImageView() (PathTracer.h:112) is a Vulkan image view upstream; here GetOutputImage() returns the RGBA32F host copy.
+    // ReloadShaders() (PathTracer.h:185) has no counterpart: feature toggles are flag bits, nothing is recompiled.
     void SetCameraViewInverse(const Mat4& view);
     void SetCameraProjectionInverse(const Mat4& projection);
     void SetMaxSamplesAccumulated(uint32_t v) { m_Params.max_samples = v; Push(false); }
