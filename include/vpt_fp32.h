@@ -342,6 +342,15 @@ VPT_HD uint8_t unorm8(float c) {
 // (e1 = v1 - v0, e2 = v2 - v0 computed in fp32 from mat_point()-transformed
 // vertices). Moller-Trumbore, two-sided, no culling (FORCE_OPAQUE, no cull
 // flags: RayGen.slang:90, RTCommon.slang:54). Returns true and (t,u,v) if the
+// Sliver triangles (edges parallel to within 1e-5 rad, or a zero edge) are not part of the scene's geometry for
+// intersection purposes, like the degenerate primitives a hardware BVH builder drops: their determinant is a rounding
+// residue for EVERY ray, so u and v land in range at arbitrary t, far from the triangle — results would depend on the
+// order an acceleration structure happens to visit its leaves in.  Both BVH builders and the brute-force loop skip them.
+VPT_HD bool triangle_degenerate(V3 e1, V3 e2) {
+    V3 n = cross(e1, e2);
+    return !(dot(n, n) > 1.0e-10f * (dot(e1, e1) * dot(e2, e2)));
+}
+
 // ray hits with tmin < t < tmax; u,v are the barycentrics of v1,v2
 // (ClosestHit.slang:45). Ties between triangles are resolved by the caller
 // (smaller global triangle id wins) so the result is traversal-order free.
@@ -359,6 +368,26 @@ VPT_HD bool ray_triangle(V3 o, V3 d, V3 v0, V3 e1, V3 e2, float tmin, float tmax
     if (!(v >= 0.0f && u + v <= 1.0f)) return false;
     float t = dot(e2, q) * inv;
     if (!(t > tmin && t < tmax)) return false;
+#ifdef VPT_RT_LOCALITY_CHECK  // diagnostic build only: flags hits that lie outside the triangle's own bounding box
+    {
+        const float ox[3] = {o.x, o.y, o.z}, dx[3] = {d.x, d.y, d.z};
+        const float ax[3] = {v0.x, v0.y, v0.z}, bx[3] = {v0.x + e1.x, v0.y + e1.y, v0.z + e1.z}, cx[3] = {v0.x + e2.x, v0.y + e2.y, v0.z + e2.z};
+        float tn = -3.0e38f, tf = 3.0e38f;
+        for (int k = 0; k < 3; k++) {
+            float lo = min_(ax[k], min_(bx[k], cx[k])), hi = max_(ax[k], max_(bx[k], cx[k]));
+            const float pad = 1.0e-5f * max_(fabs_(lo), fabs_(hi)) + 1.0e-6f;
+            lo -= pad; hi += pad;
+            if (dx[k] != 0.0f) {
+                const float id = 1.0f / dx[k];
+                const float t0 = (lo - ox[k]) * id, t1 = (hi - ox[k]) * id;
+                tn = max_(tn, min_(t0, t1)); tf = min_(tf, max_(t0, t1));
+            } else if (ox[k] < lo || ox[k] > hi) {
+                return false;
+            }
+        }
+        if (!(t * 1.000002f >= tn && t * 0.999998f <= tf)) return false;
+    }
+#endif
     *t_out = t;
     *u_out = u;
     *v_out = v;

@@ -63,6 +63,7 @@ struct Tex {
 struct Tri {  // world-space triangle for intersection only
     V3 v0, e1, e2;
     uint32_t prim, inst;
+    bool skip;  // sliver (vpt_fp32.h triangle_degenerate): never intersected
 };
 
 struct Node {
@@ -214,6 +215,7 @@ int build_node(Oracle& o, int first, int count) {
 
 inline void consider(const Oracle& o, int gid, V3 org, V3 dir, float tmin, float tmax, Hit& best, Counters* c) {
     const Tri& tr = o.tris[gid];
+    if (tr.skip) return;  // sliver: not intersectable (vpt_fp32.h triangle_degenerate)
     float t, u, v;
     if (c) c->tris++;
     if (ray_triangle(org, dir, tr.v0, tr.e1, tr.e2, tmin, tmax, &t, &u, &v)) {
@@ -223,8 +225,17 @@ inline void consider(const Oracle& o, int gid, V3 org, V3 dir, float tmin, float
     }
 }
 
+// Debug ray log (orc_ray_log_*): every closest_hit() call of the calling thread while enabled.
+struct LoggedRay { float o[3], tmin, d[3], tmax; float t; int gid; };
+static thread_local std::vector<LoggedRay>* g_ray_log = nullptr;
+bool closest_hit_impl(const Oracle& o, V3 org, V3 dir, float tmin, float tmax, Hit& best, Counters* c);
 // Closest hit with tmin < t < tmax; ties -> smaller global triangle id.
 bool closest_hit(const Oracle& o, V3 org, V3 dir, float tmin, float tmax, Hit& best, Counters* c) {
+    bool r = closest_hit_impl(o, org, dir, tmin, tmax, best, c);
+    if (g_ray_log) g_ray_log->push_back({{org.x, org.y, org.z}, tmin, {dir.x, dir.y, dir.z}, tmax, r ? best.t : -1.0f, r ? best.gid : -1});
+    return r;
+}
+bool closest_hit_impl(const Oracle& o, V3 org, V3 dir, float tmin, float tmax, Hit& best, Counters* c) {
     best.gid = -1; best.t = tmax;
     if (o.brute_force || o.nodes.empty()) {
         for (int g = 0; g < (int)o.tris.size(); g++) consider(o, g, org, dir, tmin, tmax, best, c);
@@ -1426,7 +1437,7 @@ void build_tris(Oracle& o) {
             V3 a = mat_point(M, P3(o.mverts[mesh][o.mindices[mesh][t * 3]].position));
             V3 b = mat_point(M, P3(o.mverts[mesh][o.mindices[mesh][t * 3 + 1]].position));
             V3 c = mat_point(M, P3(o.mverts[mesh][o.mindices[mesh][t * 3 + 2]].position));
-            Tri tr; tr.v0 = a; tr.e1 = b - a; tr.e2 = c - a; tr.prim = t; tr.inst = i;
+            Tri tr; tr.v0 = a; tr.e1 = b - a; tr.e2 = c - a; tr.prim = t; tr.inst = i; tr.skip = triangle_degenerate(tr.e1, tr.e2);
             o.tris.push_back(tr);
         }
     }
@@ -1813,6 +1824,54 @@ void orc_atmosphere_estimators(const vpt_atmosphere* a, const float* org, const 
         if (atmosphere_scatter_distance(o, r, P3(org), P3(dir), ch, comp) < 0.0f) esc += 1.0;
     }
     out[0] = (float)(tr / n); out[1] = (float)(esc / n);
+}
+
+// Debug hook: the frame sample (accumulatedLight / SampleCount) of single pixels for frames first..first+n-1, i.e. what
+// dispatch k alone contributes to pixel (x, y); seeds as in orc_render.  out[(p * n + k) * 3 + c].
+void orc_pixel_samples(void* h, const uint32_t* xs, const uint32_t* ys, uint32_t npix, uint32_t first, uint32_t n, float* out) {
+    Oracle* o = (Oracle*)h;
+    Counters c{};
+    for (uint32_t p = 0; p < npix; p++)
+        for (uint32_t k = 0; k < n; k++) {
+            float* px = &o->image[((size_t)ys[p] * o->W + xs[p]) * 4];
+            float keep[4] = {px[0], px[1], px[2], px[3]};
+            raygen_pixel(*o, xs[p], ys[p], 0u, pcg_hash(o->P.base_seed + first + k), 0u, c);  // frame_count 0: the pixel becomes the sample itself
+            for (int q = 0; q < 3; q++) out[((size_t)p * n + k) * 3 + q] = px[q];
+            for (int q = 0; q < 4; q++) px[q] = keep[q];
+        }
+}
+
+// Debug hook: all rays (closest and shadow queries, in call order) of one pixel's sample of dispatch `frame`:
+// 10 floats per ray {o.xyz, tmin, d.xyz, tmax, t or -1, global triangle id or -1}; returns the ray count (<= cap).
+uint32_t orc_pixel_rays(void* h, uint32_t x, uint32_t y, uint32_t frame, float* out, uint32_t cap) {
+    Oracle* o = (Oracle*)h;
+    std::vector<LoggedRay> log;
+    g_ray_log = &log;
+    float rgb[3];
+    orc_pixel_samples(h, &x, &y, 1, frame, 1, rgb);
+    g_ray_log = nullptr;
+    uint32_t n = (uint32_t)std::min<size_t>(log.size(), cap);
+    for (uint32_t i = 0; i < n; i++) {
+        const LoggedRay& r = log[i];
+        float* q = out + (size_t)i * 10;
+        q[0] = r.o[0]; q[1] = r.o[1]; q[2] = r.o[2]; q[3] = r.tmin; q[4] = r.d[0]; q[5] = r.d[1]; q[6] = r.d[2]; q[7] = r.tmax; q[8] = r.t; q[9] = (float)r.gid;
+    }
+    (void)o;
+    return n;
+}
+
+// Debug hook: the flattened world-space triangles {v0, e1, e2, prim, inst, gid} (12 dwords each), as the BVH builders see them.
+uint32_t orc_get_triangles(void* h, float* out, uint32_t cap) {
+    Oracle* o = (Oracle*)h;
+    uint32_t n = (uint32_t)std::min<size_t>(o->tris.size(), cap);
+    for (uint32_t i = 0; out && i < n; i++) {
+        const Tri& t = o->tris[i];
+        float* q = out + (size_t)i * 12;
+        q[0] = t.v0.x; q[1] = t.v0.y; q[2] = t.v0.z; q[3] = t.e1.x; q[4] = t.e1.y; q[5] = t.e1.z; q[6] = t.e2.x; q[7] = t.e2.y; q[8] = t.e2.z;
+        uint32_t ids[3] = {t.prim, t.inst, i};
+        memcpy(q + 9, ids, 12);
+    }
+    return (uint32_t)o->tris.size();
 }
 
 }  // extern "C"

@@ -36,6 +36,11 @@ def lib():
         L.orc_set_volumes.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
         L.orc_set_phase_function.argtypes = [C.c_void_p, C.c_uint32]
         L.orc_set_atmosphere.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_get_triangles.restype = C.c_uint32
+        L.orc_get_triangles.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+        L.orc_pixel_rays.restype = C.c_uint32
+        L.orc_pixel_rays.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32]
+        L.orc_pixel_samples.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
         L.orc_add_density_grid.restype = C.c_int
         L.orc_add_density_grid.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
         L.orc_clear_density_grids.argtypes = [C.c_void_p]
@@ -124,6 +129,26 @@ class Oracle:
 
     def clear_density_grids(self):
         self.L.orc_clear_density_grids(self.h_)
+
+    def pixel_samples(self, xs, ys, first, n):
+        """Per-dispatch samples of single pixels (debug): float32 [npix, n, 3]."""
+        xs = np.ascontiguousarray(xs, np.uint32); ys = np.ascontiguousarray(ys, np.uint32)
+        out = np.zeros((len(xs), n, 3), np.float32)
+        self.L.orc_pixel_samples(self.h_, xs.ctypes.data, ys.ctypes.data, len(xs), first, n, out.ctypes.data)
+        return out
+
+    def pixel_rays(self, x, y, frame, cap=4096):
+        """Every ray of one pixel's sample of dispatch `frame` (debug): float32 [n, 10] = o, tmin, d, tmax, t|-1, gid|-1."""
+        out = np.zeros((cap, 10), np.float32)
+        n = self.L.orc_pixel_rays(self.h_, x, y, frame, out.ctypes.data, cap)
+        return out[:n]
+
+    def triangles(self):
+        """Flattened world-space triangles (debug): float32 [n, 12] = v0, e1, e2, then prim / inst / gid as uint32 bits."""
+        n = self.L.orc_get_triangles(self.h_, None, 0)
+        out = np.zeros((n, 12), np.float32)
+        self.L.orc_get_triangles(self.h_, out.ctypes.data, n)
+        return out
 
     def set_atmosphere(self, atm):
         self.L.orc_set_atmosphere(self.h_, C.byref(atm) if atm is not None else None)

@@ -1,0 +1,44 @@
+"""The product BVH (csrc/bvh_build.cpp: binned SAH -> BVH4 -> 8-bit quantised boxes) checked on the host: tests/tools/bvh_debug
+restates the device's slab test operation for operation, walks rays through the tree and compares with brute force.
+Regression: 39 rays of four atrium samples (found by the full-size config-3 parity run) two of which "hit" a degenerate
+sliver triangle (e1 == e2) at t = 2 and t = 4 — far outside its box — through a rounding-residue determinant.  Slivers
+(vpt_fp32.h triangle_degenerate) are no longer intersectable on either side, which makes the result independent of the tree."""
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def build_tool(tmp_path):
+    exe = str(tmp_path / "bvh_debug")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-march=x86-64-v3", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                           "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "tools", "bvh_debug.cpp"),
+                           os.path.join(ROOT, "vulkan-path-tracer_amd", "csrc", "bvh_build.cpp"), "-o", exe])
+    return exe
+
+
+def test_quantised_bvh_equals_brute_force_on_the_host(vpt, oracle, tmp_path):
+    exe = build_tool(tmp_path)
+    sc = vpt.scenes.atrium()
+    o = oracle.Oracle(sc, 8, 8); tris = o.triangles(); o.close()
+    e1, e2 = tris[:, 3:6], tris[:, 6:9]
+    assert (np.abs(np.cross(e1, e2)).max(axis=1) == 0).sum() > 0          # the generator does emit exact slivers
+    tris.tofile(str(tmp_path / "tris.bin"))
+    logged = np.load(os.path.join(ROOT, "tests", "golden", "atrium_degenerate_rays.npy"))[:, :8]
+    rng = np.random.default_rng(5)
+    n = 1500                                                               # brute force on the host: 1500 x 285k triangle tests
+    rnd = np.zeros((n, 8), np.float32)
+    rnd[:, 0:3] = rng.uniform(-9, 9, (n, 3)) * np.array([1, 0.4, 1]) + np.array([0, -5, 0])
+    d = rng.normal(size=(n, 3)); rnd[:, 4:7] = d / np.linalg.norm(d, axis=1, keepdims=True)
+    rnd[:, 3] = 1e-4; rnd[:, 7] = 1e6
+    np.concatenate([logged, rnd]).astype(np.float32).tofile(str(tmp_path / "rays.bin"))
+    p = subprocess.run([exe, str(tmp_path / "tris.bin"), str(tmp_path / "rays.bin")], capture_output=True, text=True)
+    assert p.returncode == 0 and "mismatches 0 of %d" % (len(logged) + n) in p.stdout, p.stdout[-2000:]
+    assert "slivers dropped 0" not in p.stdout
+    # the oracle skips them too: its closest hits for the logged rays equal brute force over the remaining triangles
+    o = oracle.Oracle(sc, 8, 8); a = o.trace_rays(logged.astype(np.float32)); o.set_brute_force(True); b = o.trace_rays(logged.astype(np.float32)); o.close()
+    for f in ("t", "primitive", "instance"):
+        assert np.array_equal(a[f], b[f])
+    assert a["t"][11] != 4.0 and a["t"][30] != 2.0          # the two spurious sliver hits are gone

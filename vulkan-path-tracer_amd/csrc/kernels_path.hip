@@ -122,6 +122,7 @@ __device__ inline bool sky_visible(const DeviceScene& sc, const float4* lds_node
 template <bool LDS_SCENE, bool COUNT>
 __device__ inline bool light_visible(const DeviceScene& sc, const float4* lds_nodes, const float4* lds_tris, V3 o, V3 d, uint32_t gid, const TravStack& stack, TravStats& st) {
     uint32_t slot = sc.tri_slot_of_gid[gid];
+    if (slot == 0xffffffffu) return false;  // the sampled light triangle is a sliver: nothing can hit it
     if (LDS_SCENE) { LdsSceneSrc src{lds_nodes, lds_tris}; return closest_is<COUNT>(src, o, d, 0.0001f, 1000000.0f, gid, slot, stack, st); }
     GlobalSceneSrc src{sc.nodes, sc.tris};
     return closest_is<COUNT>(src, o, d, 0.0001f, 1000000.0f, gid, slot, stack, st);

@@ -478,12 +478,13 @@ int vpt_set_scene(vpt_ctx* c, const vpt_scene_desc* sd) {
     // ---- instances, flattened world-space triangles (instance-major global ids)
     c->instances.clear();
     std::vector<BvhTri> tris;
+    uint32_t total_tris = 0;
     for (uint32_t i = 0; i < sd->instance_count; i++) {
         const vpt_instance& in = sd->instances[i];
         if (in.mesh_index >= sd->mesh_count) return fail(c, VPT_ERR_INVALID_ARGUMENT, "instance mesh index out of range");
         if (in.material_index >= sd->material_count) return fail(c, VPT_ERR_INVALID_ARGUMENT, "Mesh instance has invalid material index");  // PathTracer.cpp:454
         InstanceDesc d; memset(&d, 0, sizeof(d));
-        d.mesh = in.mesh_index; d.material = in.material_index; d.tri_offset = (uint32_t)tris.size();
+        d.mesh = in.mesh_index; d.material = in.material_index; d.tri_offset = total_tris;
         memcpy(d.xform, in.transform, 64);
         vptfp::inverse3x3_from_mat4(in.transform, d.inv3);
         c->instances.push_back(d);
@@ -500,8 +501,8 @@ int vpt_set_scene(vpt_ctx* c, const vpt_scene_desc* sd) {
             bt.v0[0] = p[0].x; bt.v0[1] = p[0].y; bt.v0[2] = p[0].z;
             bt.e1[0] = e1.x; bt.e1[1] = e1.y; bt.e1[2] = e1.z;
             bt.e2[0] = e2.x; bt.e2[1] = e2.y; bt.e2[2] = e2.z;
-            bt.prim = t; bt.inst = i; bt.gid = (uint32_t)tris.size();
-            tris.push_back(bt);
+            bt.prim = t; bt.inst = i; bt.gid = total_tris++;  // instance-major id over ALL triangles (tie-break key)
+            if (!vptfp::triangle_degenerate(e1, e2)) tris.push_back(bt);  // slivers are not intersectable (vpt_fp32.h)
         }
     }
     std::vector<BvhNode> nodes; std::vector<BvhNodeWide> wide; std::vector<BvhTri> leaf_tris; int depth = 0;
@@ -535,7 +536,7 @@ int vpt_set_scene(vpt_ctx* c, const vpt_scene_desc* sd) {
     if ((rc = upload(c, leaf_tris, &D.tris))) return rc;
     D.node_count = (uint32_t)nodes.size(); D.tri_count = (uint32_t)leaf_tris.size();
     {
-        std::vector<uint32_t> slot_of(leaf_tris.size(), 0u);
+        std::vector<uint32_t> slot_of(total_tris, 0xffffffffu);  // 0xffffffff: a sliver, in no leaf
         for (size_t i = 0; i < leaf_tris.size(); i++) slot_of[leaf_tris[i].gid] = (uint32_t)i;
         if ((rc = upload(c, slot_of, &D.tri_slot_of_gid))) return rc;
     }
@@ -557,9 +558,9 @@ int vpt_set_scene(vpt_ctx* c, const vpt_scene_desc* sd) {
     {
         void *d1 = nullptr, *d2 = nullptr, *d3 = nullptr, *d4 = nullptr;
         HIPCHK(c, hipMalloc(&d1, sizeof(MatResolved) * c->materials.size())); c->scene_allocs.push_back(d1);
-        HIPCHK(c, hipMalloc(&d2, sizeof(EmissiveTri) * std::max<size_t>(1, leaf_tris.size()))); c->scene_allocs.push_back(d2);
+        HIPCHK(c, hipMalloc(&d2, sizeof(EmissiveTri) * std::max<size_t>(1, total_tris))); c->scene_allocs.push_back(d2);
         HIPCHK(c, hipMalloc(&d3, 4 * std::max<size_t>(1, c->instances.size()))); c->scene_allocs.push_back(d3);
-        HIPCHK(c, hipMalloc(&d4, 16 * std::max<size_t>(1, leaf_tris.size()))); c->scene_allocs.push_back(d4);
+        HIPCHK(c, hipMalloc(&d4, 16 * std::max<size_t>(1, total_tris))); c->scene_allocs.push_back(d4);
         c->d_mat_resolved = (MatResolved*)d1; c->d_emissive_tri = (EmissiveTri*)d2; c->d_emissive_tri_offset = (uint32_t*)d3; c->d_tri_ng = (float4*)d4;
         D.mat_resolved = c->d_mat_resolved; D.emissive_tri = c->d_emissive_tri; D.emissive_tri_offset = c->d_emissive_tri_offset; D.tri_ng = c->d_tri_ng;
     }
