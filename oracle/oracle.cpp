@@ -218,7 +218,8 @@ inline void consider(const Oracle& o, int gid, V3 org, V3 dir, float tmin, float
     if (tr.skip) return;  // sliver: not intersectable (vpt_fp32.h triangle_degenerate)
     float t, u, v;
     if (c) c->tris++;
-    if (ray_triangle(org, dir, tr.v0, tr.e1, tr.e2, tmin, tmax, &t, &u, &v)) {
+    if (ray_triangle(org, dir, tr.v0, tr.e1, tr.e2, tmin, tmax, &t, &u, &v) &&
+        (!(o.P.flags & VPT_FLAG_LOCAL_HITS) || hit_is_local(org, dir, tr.v0, tr.e1, tr.e2, t))) {
         if (best.gid < 0 || t < best.t || (t == best.t && gid < best.gid)) {
             best.t = t; best.u = u; best.v = v; best.prim = tr.prim; best.inst = tr.inst; best.gid = gid;
         }

@@ -52,7 +52,10 @@ int main(int argc, char** argv) {
         const float* q = &rays[ri * 8];
         V3 o = vptfp::v3(q[0], q[1], q[2]), d = vptfp::v3(q[4], q[5], q[6]); float tmin = q[3], tmax = q[7];
         Slab s; s.o = o; s.inv = vptfp::v3(sinv(d.x), sinv(d.y), sinv(d.z)); s.nx = s.inv.x < 0; s.ny = s.inv.y < 0; s.nz = s.inv.z < 0;
-        auto tri_hit = [&](const BvhTri& t, float& tt) { float u, v; return vptfp::ray_triangle(o, d, vptfp::v3(t.v0[0], t.v0[1], t.v0[2]), vptfp::v3(t.e1[0], t.e1[1], t.e1[2]), vptfp::v3(t.e2[0], t.e2[1], t.e2[2]), tmin, tmax, &tt, &u, &v); };
+        // a hit = accepted by the shared triangle test AND local to the triangle's own box (vpt_fp32.h hit_is_local); the device
+        // reaches the same set by validating the winning candidate after the search and searching again without it
+        auto tri_hit = [&](const BvhTri& t, float& tt) { float u, v; vptfp::V3 a = vptfp::v3(t.v0[0], t.v0[1], t.v0[2]), b = vptfp::v3(t.e1[0], t.e1[1], t.e1[2]), c = vptfp::v3(t.e2[0], t.e2[1], t.e2[2]);
+            return vptfp::ray_triangle(o, d, a, b, c, tmin, tmax, &tt, &u, &v) && vptfp::hit_is_local(o, d, a, b, c, tt); };
         float bt = tmax; int bg = -1;
         for (const BvhTri& t : leaf) { float tt; if (tri_hit(t, tt) && (bg < 0 || tt < bt || (tt == bt && (int)t.gid < bg))) { bt = tt; bg = (int)t.gid; } }
         float best = tmax; int gid = -1; std::vector<int> st; int cur = 0;

@@ -9,6 +9,7 @@ ERR_NAMES = {
 
 FLAG_SKY_MIS = 1 << 0
 FLAG_MESH_MIS = 1 << 1
+FLAG_LOCAL_HITS = 1 << 8
 FLAG_SHOW_ENV_DIRECTLY = 1 << 2
 FLAG_GEOMETRY_NORMALS = 1 << 3
 FLAG_ENERGY_COMPENSATION = 1 << 4

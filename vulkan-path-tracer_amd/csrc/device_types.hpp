@@ -130,6 +130,7 @@ struct DeviceScene {
     const vpt_volume* volumes;              // uVolumes (Volume.slang:9); volume_count == 0: none
     uint32_t volume_count, phase;           // PHASE_FUNCTION_* (PathTracer.h:76-81)
     uint32_t atm_on;                        // ENABLE_ATMOSPHERE
+    uint32_t strict_hits;                   // VPT_FLAG_LOCAL_HITS: validate the winning hit's locality (traverse.hpp)
     uint32_t hetero;                        // some volume takes its density from a grid (its transmittance is tracked, not evaluated)
     const struct DensityGrid* grids;        // uNanoVDBBuffersDensity / uVolumeMaxDensities, densified (vpt_add_density_grid)
     vpt_atmosphere atm;

@@ -107,31 +107,32 @@ __device__ inline void stage_scene(const DeviceScene& sc, float4* lds_nodes, flo
 template <bool LDS_SCENE, bool COUNT>
 __device__ inline bool trace_any(const DeviceScene& sc, const float4* lds_nodes, const float4* lds_tris, V3 o, V3 d, float tmin,
                                  float tmax, const TravStack& stack, HitRec& h, TravStats& st) {
-    if (LDS_SCENE) { LdsSceneSrc src{lds_nodes, lds_tris}; return trace_closest<COUNT>(src, o, d, tmin, tmax, stack, h, st); }
-    GlobalSceneSrc src{sc.nodes, sc.tris};
+    if (LDS_SCENE) { LdsSceneSrc src{lds_nodes, lds_tris, sc.strict_hits != 0u}; return trace_closest<COUNT>(src, o, d, tmin, tmax, stack, h, st); }
+    GlobalSceneSrc src{sc.nodes, sc.tris, sc.strict_hits != 0u};
     return trace_closest<COUNT>(src, o, d, tmin, tmax, stack, h, st);
 }
 
 // Sky visibility / light identity as exact any-hit queries (traverse.hpp).
 template <bool LDS_SCENE, bool COUNT>
 __device__ inline bool sky_visible(const DeviceScene& sc, const float4* lds_nodes, const float4* lds_tris, V3 o, V3 d, const TravStack& stack, TravStats& st) {
-    if (LDS_SCENE) { LdsSceneSrc src{lds_nodes, lds_tris}; return !trace_occluded<COUNT, false>(src, o, d, 0.0001f, 1000000.0f, 0.0f, 0u, stack, st); }
-    GlobalSceneSrc src{sc.nodes, sc.tris};
+    if (LDS_SCENE) { LdsSceneSrc src{lds_nodes, lds_tris, sc.strict_hits != 0u}; return !trace_occluded<COUNT, false>(src, o, d, 0.0001f, 1000000.0f, 0.0f, 0u, stack, st); }
+    GlobalSceneSrc src{sc.nodes, sc.tris, sc.strict_hits != 0u};
     return !trace_occluded<COUNT, false>(src, o, d, 0.0001f, 1000000.0f, 0.0f, 0u, stack, st);
 }
 template <bool LDS_SCENE, bool COUNT>
 __device__ inline bool light_visible(const DeviceScene& sc, const float4* lds_nodes, const float4* lds_tris, V3 o, V3 d, uint32_t gid, const TravStack& stack, TravStats& st) {
     uint32_t slot = sc.tri_slot_of_gid[gid];
     if (slot == 0xffffffffu) return false;  // the sampled light triangle is a sliver: nothing can hit it
-    if (LDS_SCENE) { LdsSceneSrc src{lds_nodes, lds_tris}; return closest_is<COUNT>(src, o, d, 0.0001f, 1000000.0f, gid, slot, stack, st); }
-    GlobalSceneSrc src{sc.nodes, sc.tris};
+    if (LDS_SCENE) { LdsSceneSrc src{lds_nodes, lds_tris, sc.strict_hits != 0u}; return closest_is<COUNT>(src, o, d, 0.0001f, 1000000.0f, gid, slot, stack, st); }
+    GlobalSceneSrc src{sc.nodes, sc.tris, sc.strict_hits != 0u};
     return closest_is<COUNT>(src, o, d, 0.0001f, 1000000.0f, gid, slot, stack, st);
 }
 
 // ------------------------------------------------------------------ extend: closest hit of every queued path
-template <bool LDS_SCENE, bool COUNT>
+template <bool LDS_SCENE, bool COUNT, bool STRICT>
 __global__ __launch_bounds__(kTraverseBlock, 8) void k_extend(DeviceScene sc, PathState ps, const uint32_t* queue,
                                                           Counters* ctr, uint32_t parity) {
+    sc.strict_hits = STRICT ? 1u : 0u;  // compile-time constant from here on (VPT_FLAG_LOCAL_HITS picks the instantiation)
     extern __shared__ __align__(16) unsigned char smem[];
     const TravStack stack = make_stack(smem, sc.stack_overflow);
     float4* lds_nodes = reinterpret_cast<float4*>(smem + kStackDepth * kTraverseBlock * 4);
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(kTraverseBlock, 8) void k_extend(DeviceScene sc, Pa
 __global__ __launch_bounds__(kTraverseBlock) void k_trace_rays(DeviceScene sc, const vpt_ray* rays, uint32_t n, vpt_hit* hits) {
     extern __shared__ __align__(16) unsigned char smem[];
     const TravStack stack = make_stack(smem, sc.stack_overflow);
-    GlobalSceneSrc src{sc.nodes, sc.tris};
+    GlobalSceneSrc src{sc.nodes, sc.tris, sc.strict_hits != 0u};
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         vpt_ray r = rays[i];
         HitRec h; TravStats st;
@@ -659,10 +660,11 @@ __global__ __launch_bounds__(256, 3) void k_shade(DeviceScene sc, RenderParams P
 // The same kernel with FIRST = false runs every later bounce of scenes whose BVH rides in LDS (traversal is
 // then a handful of LDS reads, so a separate extend/connect stage would only move records through HBM):
 // it reads a queued path's records A, B, T, L, does the whole bounce, and writes them back for survivors.
-template <bool LDS_SCENE, bool COUNT, bool FIRST, bool VOL>
+template <bool LDS_SCENE, bool COUNT, bool FIRST, bool VOL, bool STRICT>
 __global__ __launch_bounds__(kTraverseBlock, 3) void k_bounce(DeviceScene sc, RenderParams P, PathState ps, const uint32_t* queue,
                                                              uint32_t* queue_next, Counters* ctr, uint32_t parity, uint32_t n_slots,
                                                              uint32_t dispatch_base, uint32_t k3) {
+    sc.strict_hits = STRICT ? 1u : 0u;  // compile-time constant from here on (VPT_FLAG_LOCAL_HITS picks the instantiation)
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ uint32_t s_cnt[4][3];
     __shared__ uint32_t s_base[4];
@@ -863,9 +865,10 @@ constexpr uint32_t kConnectTile = 512;
 constexpr uint32_t kConnectScratch = kConnectTile * 4 + kConnectTile * 2 * 2 + kConnectTile * 2 + 16;  // slots, ray list, visibility, counters
 __device__ inline uint32_t connect_tile(uint32_t n) { return n >= (1u << 19) ? 512u : n >= (1u << 17) ? 256u : n >= (1u << 15) ? 128u : 64u; }
 
-template <bool LDS_SCENE, bool COUNT>
+template <bool LDS_SCENE, bool COUNT, bool STRICT>
 __global__ __launch_bounds__(kTraverseBlock, 8) void k_connect(DeviceScene sc, RenderParams P, PathState ps, const uint32_t* cqueue,
                                                            Counters* ctr, uint32_t parity) {
+    sc.strict_hits = STRICT ? 1u : 0u;
     extern __shared__ __align__(16) unsigned char smem[];
     const TravStack stack = make_stack(smem, sc.stack_overflow);
     unsigned char* scratch = smem + kStackDepth * kTraverseBlock * 4;
@@ -1066,7 +1069,8 @@ void launch_bounce(hipStream_t s, uint32_t blocks, bool lds_scene, bool count, b
                    uint32_t dispatch_base, uint32_t k3) {
     size_t lds = traverse_lds_bytes(sc, lds_scene);
     dim3 g(blocks), b(kTraverseBlock);
-#define VPT_LAUNCH_BOUNCE_V(L, C, F, V) hipLaunchKernelGGL((k_bounce<L, C, F, V>), g, b, lds, s, sc, P, ps, queue, queue_next, ctr, parity, n_slots, dispatch_base, k3)
+#define VPT_LAUNCH_BOUNCE_V(L, C, F, V) do { if (sc.strict_hits) hipLaunchKernelGGL((k_bounce<L, C, F, V, true>), g, b, lds, s, sc, P, ps, queue, queue_next, ctr, parity, n_slots, dispatch_base, k3); \
+        else hipLaunchKernelGGL((k_bounce<L, C, F, V, false>), g, b, lds, s, sc, P, ps, queue, queue_next, ctr, parity, n_slots, dispatch_base, k3); } while (0)
 #define VPT_LAUNCH_BOUNCE(L, C, F) VPT_LAUNCH_BOUNCE_V(L, C, F, false)
     if (sc.volume_count > 0u || sc.atm_on) {  // the media variants carry no traversal counters
         if (lds_scene) { if (first) VPT_LAUNCH_BOUNCE_V(true, false, true, true); else VPT_LAUNCH_BOUNCE_V(true, false, false, true); }
@@ -1084,8 +1088,8 @@ void launch_bounce(hipStream_t s, uint32_t blocks, bool lds_scene, bool count, b
 int bounce_blocks_per_cu(bool lds_scene, const DeviceScene& sc) {
     int nb = 0;
     size_t lds = traverse_lds_bytes(sc, lds_scene);
-    if (lds_scene) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_bounce<true, false, false, false>, kTraverseBlock, lds);
-    else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_bounce<false, false, false, false>, kTraverseBlock, lds);
+    if (lds_scene) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_bounce<true, false, false, false, false>, kTraverseBlock, lds);
+    else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_bounce<false, false, false, false, false>, kTraverseBlock, lds);
     return nb > 0 ? nb : 1;
 }
 void launch_raygen(hipStream_t s, const RenderParams& P, const PathState& ps, uint32_t* queue, Counters* ctr, uint32_t n_slots, uint32_t dispatch_base) {
@@ -1103,22 +1107,22 @@ void launch_extend(hipStream_t s, uint32_t blocks, bool lds_scene, bool count, c
                    const uint32_t* queue, Counters* ctr, uint32_t parity) {
     size_t lds = traverse_lds_bytes(sc, lds_scene);
     if (lds_scene) {
-        if (count) hipLaunchKernelGGL((k_extend<true, true>), dim3(blocks), dim3(kTraverseBlock), lds, s, sc, ps, queue, ctr, parity);
-        else hipLaunchKernelGGL((k_extend<true, false>), dim3(blocks), dim3(kTraverseBlock), lds, s, sc, ps, queue, ctr, parity);
+        if (count) { if (sc.strict_hits) hipLaunchKernelGGL((k_extend<true, true, true>), dim3(blocks), dim3(kTraverseBlock), lds, s, sc, ps, queue, ctr, parity); else hipLaunchKernelGGL((k_extend<true, true, false>), dim3(blocks), dim3(kTraverseBlock), lds, s, sc, ps, queue, ctr, parity); }
+        else { if (sc.strict_hits) hipLaunchKernelGGL((k_extend<true, false, true>), dim3(blocks), dim3(kTraverseBlock), lds, s, sc, ps, queue, ctr, parity); else hipLaunchKernelGGL((k_extend<true, false, false>), dim3(blocks), dim3(kTraverseBlock), lds, s, sc, ps, queue, ctr, parity); }
     } else {
-        if (count) hipLaunchKernelGGL((k_extend<false, true>), dim3(blocks), dim3(kTraverseBlock), lds, s, sc, ps, queue, ctr, parity);
-        else hipLaunchKernelGGL((k_extend<false, false>), dim3(blocks), dim3(kTraverseBlock), lds, s, sc, ps, queue, ctr, parity);
+        if (count) { if (sc.strict_hits) hipLaunchKernelGGL((k_extend<false, true, true>), dim3(blocks), dim3(kTraverseBlock), lds, s, sc, ps, queue, ctr, parity); else hipLaunchKernelGGL((k_extend<false, true, false>), dim3(blocks), dim3(kTraverseBlock), lds, s, sc, ps, queue, ctr, parity); }
+        else { if (sc.strict_hits) hipLaunchKernelGGL((k_extend<false, false, true>), dim3(blocks), dim3(kTraverseBlock), lds, s, sc, ps, queue, ctr, parity); else hipLaunchKernelGGL((k_extend<false, false, false>), dim3(blocks), dim3(kTraverseBlock), lds, s, sc, ps, queue, ctr, parity); }
     }
 }
 void launch_connect(hipStream_t s, uint32_t blocks, bool lds_scene, bool count, const DeviceScene& sc, const RenderParams& P,
                     const PathState& ps, const uint32_t* cqueue, Counters* ctr, uint32_t parity) {
     size_t lds = traverse_lds_bytes(sc, lds_scene) + kConnectScratch;
     if (lds_scene) {
-        if (count) hipLaunchKernelGGL((k_connect<true, true>), dim3(blocks), dim3(kTraverseBlock), lds, s, sc, P, ps, cqueue, ctr, parity);
-        else hipLaunchKernelGGL((k_connect<true, false>), dim3(blocks), dim3(kTraverseBlock), lds, s, sc, P, ps, cqueue, ctr, parity);
+        if (count) { if (sc.strict_hits) hipLaunchKernelGGL((k_connect<true, true, true>), dim3(blocks), dim3(kTraverseBlock), lds, s, sc, P, ps, cqueue, ctr, parity); else hipLaunchKernelGGL((k_connect<true, true, false>), dim3(blocks), dim3(kTraverseBlock), lds, s, sc, P, ps, cqueue, ctr, parity); }
+        else { if (sc.strict_hits) hipLaunchKernelGGL((k_connect<true, false, true>), dim3(blocks), dim3(kTraverseBlock), lds, s, sc, P, ps, cqueue, ctr, parity); else hipLaunchKernelGGL((k_connect<true, false, false>), dim3(blocks), dim3(kTraverseBlock), lds, s, sc, P, ps, cqueue, ctr, parity); }
     } else {
-        if (count) hipLaunchKernelGGL((k_connect<false, true>), dim3(blocks), dim3(kTraverseBlock), lds, s, sc, P, ps, cqueue, ctr, parity);
-        else hipLaunchKernelGGL((k_connect<false, false>), dim3(blocks), dim3(kTraverseBlock), lds, s, sc, P, ps, cqueue, ctr, parity);
+        if (count) { if (sc.strict_hits) hipLaunchKernelGGL((k_connect<false, true, true>), dim3(blocks), dim3(kTraverseBlock), lds, s, sc, P, ps, cqueue, ctr, parity); else hipLaunchKernelGGL((k_connect<false, true, false>), dim3(blocks), dim3(kTraverseBlock), lds, s, sc, P, ps, cqueue, ctr, parity); }
+        else { if (sc.strict_hits) hipLaunchKernelGGL((k_connect<false, false, true>), dim3(blocks), dim3(kTraverseBlock), lds, s, sc, P, ps, cqueue, ctr, parity); else hipLaunchKernelGGL((k_connect<false, false, false>), dim3(blocks), dim3(kTraverseBlock), lds, s, sc, P, ps, cqueue, ctr, parity); }
     }
 }
 void launch_shade(hipStream_t s, uint32_t blocks, const DeviceScene& sc, const RenderParams& P, const PathState& ps,
@@ -1140,8 +1144,8 @@ size_t stack_overflow_bytes(uint32_t blocks) { return (size_t)blocks * kTraverse
 int traverse_blocks_per_cu(bool lds_scene, const DeviceScene& sc) {
     int nb = 0;
     size_t lds = traverse_lds_bytes(sc, lds_scene) + kConnectScratch;
-    if (lds_scene) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_connect<true, false>, kTraverseBlock, lds);
-    else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_connect<false, false>, kTraverseBlock, lds);
+    if (lds_scene) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_connect<true, false, false>, kTraverseBlock, lds);
+    else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_connect<false, false, false>, kTraverseBlock, lds);
     return nb > 0 ? nb : 1;
 }
 int shade_blocks_per_cu() {

@@ -24,6 +24,7 @@ constexpr int kTraverseBlock = 256;
 struct HitRec {
     float t, u, v;
     uint32_t prim, inst, gid;
+    int slot;  // position of the triangle in the leaf-ordered array (to validate the winner, see trace_closest)
 };
 
 struct TravStats {
@@ -74,6 +75,7 @@ struct GlobalSceneSrc {
     using Node = NodeData;
     const BvhNode* nodes;
     const BvhTri* tris;
+    bool strict;  // DeviceScene::strict_hits
     __device__ inline void node(int i, NodeData& n) const {
         const uint4* p = reinterpret_cast<const uint4*>(nodes + i);
         unpack_node(p[0], p[1], p[2], p[3], n);
@@ -87,6 +89,7 @@ struct LdsSceneSrc {
     using Node = NodeDataWide;
     const float4* nodes;  // LDS, BvhNodeWide
     const float4* tris;   // LDS
+    bool strict;          // DeviceScene::strict_hits
     __device__ inline void node(int i, NodeDataWide& n) const {
         const float4* p = nodes + i * 8;
         n.minx = p[0]; n.miny = p[1]; n.minz = p[2]; n.maxx = p[3]; n.maxy = p[4]; n.maxz = p[5];
@@ -171,10 +174,11 @@ __device__ inline void cswap(float& ta, int& ca, float& tb, int& cb) {
     ta = tt; ca = ct;
 }
 
-// Closest hit with tmin < t < tmax; ties -> smaller global triangle id.
-template <bool COUNT, class Src>
-__device__ inline bool trace_closest(const Src& src, V3 o, V3 d, float tmin, float tmax, TravStack stack, HitRec& best, TravStats& st) {
-    best.t = tmax; best.u = 0.0f; best.v = 0.0f; best.prim = 0xffffffffu; best.inst = 0xffffffffu; best.gid = 0xffffffffu;
+// One closest-hit search (tmin < t < tmax; ties -> smaller global triangle id) that ignores triangles ex0 / ex1.
+template <bool COUNT, bool STRICT, class Src>
+__device__ inline bool trace_closest_pass(const Src& src, V3 o, V3 d, float tmin, float tmax, TravStack stack, HitRec& best, TravStats& st,
+                                          uint32_t ex0, uint32_t ex1) {
+    best.t = tmax; best.u = 0.0f; best.v = 0.0f; best.prim = 0xffffffffu; best.inst = 0xffffffffu; best.gid = 0xffffffffu; best.slot = 0;
     bool found = false;
     const RaySlab slab = make_slab(o, d);
     stack.sp = 0;
@@ -206,9 +210,10 @@ __device__ inline bool trace_closest(const Src& src, V3 o, V3 d, float tmin, flo
                 if (vptfp::ray_triangle(o, d, vptfp::v3(a.x, a.y, a.z), vptfp::v3(a.w, b.x, b.y), vptfp::v3(b.z, b.w, c.x),
                                         tmin, tmax, &t, &u, &v)) {
                     uint32_t gid = __float_as_uint(c.w);
-                    if (!found || t < best.t || (t == best.t && gid < best.gid)) {
+                    if ((!STRICT || (gid != ex0 && gid != ex1)) && (!found || t < best.t || (t == best.t && gid < best.gid))) {
                         best.t = t; best.u = u; best.v = v;
                         best.prim = __float_as_uint(c.y); best.inst = __float_as_uint(c.z); best.gid = gid;
+                        if (STRICT) best.slot = first + k;
                         found = true;
                     }
                 }
@@ -220,6 +225,36 @@ __device__ inline bool trace_closest(const Src& src, V3 o, V3 d, float tmin, flo
     return found;
 }
 
+template <class Src>
+__device__ inline bool slot_hit_is_local(const Src& src, int slot, V3 o, V3 d, float t) {
+    float4 a, b, c;
+    src.tri(slot, a, b, c);
+    return vptfp::hit_is_local(o, d, vptfp::v3(a.x, a.y, a.z), vptfp::v3(a.w, b.x, b.y), vptfp::v3(b.z, b.w, c.x), t);
+}
+// Closest hit among the hits that are LOCAL to their triangle (vpt_fp32.h hit_is_local: for a ray numerically inside a
+// triangle's plane fp32 can place the hit outside the triangle's own box, where a box hierarchy would or would not see it
+// depending on its shape).  The guard is too expensive per candidate in SIMT form (it would run whenever any lane of the
+// wave has a candidate), so the search runs unguarded, the WINNER is validated once, and in the ~1e-9 case that it fails
+// the search is repeated without that triangle.  Even so it costs ~11 % of the Cornell throughput (about four validations
+// of ~70 VALU per bounce), so it is a run-time option (VPT_FLAG_LOCAL_HITS); off, the unguarded winner is returned.  Candidates that are not the winner cannot matter: best.t only shrinks,
+// and a local hit closer than the final winner is never pruned (boxes contain the triangle boxes).
+// The path kernels are instantiated twice (STRICT template flag): the default instantiation sees strict == false as a
+// compile-time constant and carries none of this code (the fused bounce kernel is instruction-cache sensitive).
+template <bool COUNT, class Src>
+__device__ inline bool trace_closest_strict(const Src& src, V3 o, V3 d, float tmin, float tmax, TravStack stack, HitRec& best, TravStats& st) {
+    uint32_t ex0 = 0xffffffffu, ex1 = 0xffffffffu;
+    while (true) {
+        if (!trace_closest_pass<COUNT, true>(src, o, d, tmin, tmax, stack, best, st, ex0, ex1)) return false;
+        if (slot_hit_is_local(src, best.slot, o, d, best.t)) return true;
+        ex1 = ex0; ex0 = best.gid;
+    }
+}
+template <bool COUNT, class Src>
+__device__ inline bool trace_closest(const Src& src, V3 o, V3 d, float tmin, float tmax, TravStack stack, HitRec& best, TravStats& st) {
+    if (!src.strict) return trace_closest_pass<COUNT, false>(src, o, d, tmin, tmax, stack, best, st, 0xffffffffu, 0xffffffffu);  // default: the unguarded winner
+    return trace_closest_strict<COUNT>(src, o, d, tmin, tmax, stack, best, st);
+}
+
 // Shadow queries.  The reference asks for the CLOSEST committed hit and then only looks at (a) whether there
 // is one (sky visibility, ClosestHit.slang:139) or (b) whether it is the sampled light triangle
 // (ClosestHit.slang:171-176).  Both are decided exactly by an any-hit search:
@@ -229,9 +264,10 @@ __device__ inline bool trace_closest(const Src& src, V3 o, V3 d, float tmin, flo
 //       smaller global id), i.e. no hit with t < t_e or (t == t_e and gid < expected).
 // The search stops at the first such triangle and never looks beyond t_e, so it visits far fewer nodes than a
 // closest-hit traversal.  LIGHT = false: (a); LIGHT = true: (b) with `t_e`, `expect`.
-template <bool COUNT, bool LIGHT, class Src>
-__device__ inline bool trace_occluded(const Src& src, V3 o, V3 d, float tmin, float tmax, float t_e, uint32_t expect, TravStack stack,
-                                      TravStats& st) {
+// One any-hit search ignoring triangles ex0 / ex1; reports the triangle that stopped it (cand_slot, cand_t, cand_gid).
+template <bool COUNT, bool LIGHT, bool STRICT, class Src>
+__device__ inline bool trace_occluded_pass(const Src& src, V3 o, V3 d, float tmin, float tmax, float t_e, uint32_t expect, TravStack stack,
+                                           TravStats& st, uint32_t ex0, uint32_t ex1, int& cand_slot, float& cand_t, uint32_t& cand_gid) {
     const float tlimit = LIGHT ? t_e : tmax;
     const RaySlab slab = make_slab(o, d);
     stack.sp = 0;
@@ -258,8 +294,11 @@ __device__ inline bool trace_occluded(const Src& src, V3 o, V3 d, float tmin, fl
                 if (COUNT) st.tris++;
                 float t, u, v;
                 if (vptfp::ray_triangle(o, d, vptfp::v3(a.x, a.y, a.z), vptfp::v3(a.w, b.x, b.y), vptfp::v3(b.z, b.w, c.x), tmin, tmax, &t, &u, &v)) {
-                    if (!LIGHT) return true;
-                    if (t < t_e || (t == t_e && __float_as_uint(c.w) < expect)) return true;
+                    const uint32_t gid = __float_as_uint(c.w);
+                    if ((!STRICT || (gid != ex0 && gid != ex1)) && (!LIGHT || t < t_e || (t == t_e && gid < expect))) {
+                        if (STRICT) { cand_slot = first + k; cand_t = t; cand_gid = gid; }
+                        return true;
+                    }
                 }
             }
         }
@@ -267,6 +306,26 @@ __device__ inline bool trace_occluded(const Src& src, V3 o, V3 d, float tmin, fl
         cur = (int)stack.pop();
     }
     return false;
+}
+
+// Any-hit search over LOCAL hits only: the triangle that stops a pass is validated afterwards (see trace_closest).
+template <bool COUNT, bool LIGHT, class Src>
+__device__ inline bool trace_occluded_strict(const Src& src, V3 o, V3 d, float tmin, float tmax, float t_e, uint32_t expect, TravStack stack,
+                                                   TravStats& st) {
+    int slot = 0; float t = 0.0f; uint32_t gid = 0xffffffffu;
+    uint32_t ex0 = 0xffffffffu, ex1 = 0xffffffffu;
+    while (true) {
+        if (!trace_occluded_pass<COUNT, LIGHT, true>(src, o, d, tmin, tmax, t_e, expect, stack, st, ex0, ex1, slot, t, gid)) return false;
+        if (slot_hit_is_local(src, slot, o, d, t)) return true;
+        ex1 = ex0; ex0 = gid;
+    }
+}
+template <bool COUNT, bool LIGHT, class Src>
+__device__ inline bool trace_occluded(const Src& src, V3 o, V3 d, float tmin, float tmax, float t_e, uint32_t expect, TravStack stack,
+                                      TravStats& st) {
+    int slot = 0; float t = 0.0f; uint32_t gid = 0xffffffffu;
+    if (!src.strict) return trace_occluded_pass<COUNT, LIGHT, false>(src, o, d, tmin, tmax, t_e, expect, stack, st, 0xffffffffu, 0xffffffffu, slot, t, gid);
+    return trace_occluded_strict<COUNT, LIGHT>(src, o, d, tmin, tmax, t_e, expect, stack, st);
 }
 
 // (b) in full: is the closest hit of the ray the triangle with global id `expect`?  `slot` is that triangle's
@@ -279,6 +338,7 @@ __device__ inline bool closest_is(const Src& src, V3 o, V3 d, float tmin, float 
     if (COUNT) st.tris++;
     float t_e, u, v;
     if (!vptfp::ray_triangle(o, d, vptfp::v3(a.x, a.y, a.z), vptfp::v3(a.w, b.x, b.y), vptfp::v3(b.z, b.w, c.x), tmin, tmax, &t_e, &u, &v)) return false;
+    if (src.strict && !vptfp::hit_is_local(o, d, vptfp::v3(a.x, a.y, a.z), vptfp::v3(a.w, b.x, b.y), vptfp::v3(b.z, b.w, c.x), t_e)) return false;
     return !trace_occluded<COUNT, true>(src, o, d, tmin, tmax, t_e, expect, stack, st);
 }
 

@@ -630,6 +630,7 @@ int vpt_set_params(vpt_ctx* c, const vpt_params* p) {
     if (p->screen_chunk_count != 1 && c->P.shard_count != 1) return fail(c, VPT_ERR_UNSUPPORTED, "split-screen dispatch needs the whole image in one context (shard_count == 1): its first dispatch copies pixels across rows");
     if (!(p->flags & VPT_FLAG_RAY_QUERIES)) return fail(c, VPT_ERR_UNSUPPORTED, "only the USE_RAY_QUERIES semantics are implemented");
     const bool flags_changed = c->params.flags != p->flags;
+    c->dsc.strict_hits = (p->flags & VPT_FLAG_LOCAL_HITS) ? 1u : 0u;
     if (flags_changed || c->params.max_depth != p->max_depth) { c->tune_state = 0; c->auto_fused = false; c->tune_ms[0] = c->tune_ms[1] = 1e30; }
     c->params = *p;
     sync_params(c);
