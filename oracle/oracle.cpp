@@ -1875,4 +1875,41 @@ uint32_t orc_get_triangles(void* h, float* out, uint32_t cap) {
     return (uint32_t)o->tris.size();
 }
 
+// Test hooks on the BSDF restatement (Material.slang:94-449), for closed-form pins.  The material is taken as is (no
+// textures: Material.Initialize with all-white 1x1 textures), hit from outside; energy compensation off (it needs a scene's LUTs).
+static void hook_material(Mat& m, const vpt_material* src) {
+    m.p = *src; m.o = nullptr; m.ec = false;
+    m.p.ior = max_(m.p.ior, 1.000001f);
+    float aspect = sqrt_(1.0f - sqrt_(m.p.anisotropy) * 0.9f);
+    m.ax = max_(0.00001f, m.p.roughness / aspect);
+    m.ay = max_(0.00001f, m.p.roughness * aspect);
+    m.eta = 1.0f / m.p.ior;
+}
+// D(h) of GGXDistributionAnisotropic (Material.slang:394-404) for n directions h (xyz triples)
+void orc_ggx_d(const vpt_material* mat, const float* h, uint32_t n, float* out) {
+    Mat m; hook_material(m, mat);
+    for (uint32_t i = 0; i < n; i++) out[i] = m.ggx_d(v3(h[i * 3], h[i * 3 + 1], h[i * 3 + 2]));
+}
+// EvaluateBSDF(V, L) (Material.slang:167-254) for n directions L: out[i*4..] = f.rgb (cos included), pdf
+void orc_bsdf_eval(const vpt_material* mat, const float* V, const float* L, uint32_t n, float* out) {
+    Mat m; hook_material(m, mat);
+    V3 v = v3(V[0], V[1], V[2]);
+    for (uint32_t i = 0; i < n; i++) {
+        Eval e = m.eval_bsdf(v, v3(L[i * 3], L[i * 3 + 1], L[i * 3 + 2]));
+        out[i * 4] = e.bxdf.x; out[i * 4 + 1] = e.bxdf.y; out[i * 4 + 2] = e.bxdf.z; out[i * 4 + 3] = e.pdf;
+    }
+}
+// n draws of the VNDF + SampleBSDF (Sampler.slang:141-166, Material.slang:94-165) from one RNG stream: out[i*7..] = L.xyz, f.rgb, pdf
+void orc_bsdf_sample(const vpt_material* mat, const float* V, uint32_t seed, uint32_t n, float* out) {
+    Mat m; hook_material(m, mat);
+    V3 v = v3(V[0], V[1], V[2]);
+    Rng r; r.s = seed;
+    for (uint32_t i = 0; i < n; i++) {
+        V3 H = ggx_sample(r, v, m.ax, m.ay);
+        BSample b = sample_bsdf(m, r, v, H);
+        float* q = out + (size_t)i * 7;
+        q[0] = b.L.x; q[1] = b.L.y; q[2] = b.L.z; q[3] = b.bxdf.x; q[4] = b.bxdf.y; q[5] = b.bxdf.z; q[6] = b.pdf;
+    }
+}
+
 }  // extern "C"

@@ -36,6 +36,9 @@ def lib():
         L.orc_set_volumes.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
         L.orc_set_phase_function.argtypes = [C.c_void_p, C.c_uint32]
         L.orc_set_atmosphere.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_ggx_d.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+        L.orc_bsdf_eval.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+        L.orc_bsdf_sample.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
         L.orc_get_triangles.restype = C.c_uint32
         L.orc_get_triangles.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
         L.orc_pixel_rays.restype = C.c_uint32
@@ -74,6 +77,26 @@ def atmosphere_estimators(atm, origin, direction, channel, seed=1, n=20000):
     o = np.asarray(origin, np.float32); d = np.asarray(direction, np.float32); out = np.zeros(2, np.float32)
     lib().orc_atmosphere_estimators(C.byref(atm), o.ctypes.data, d.ctypes.data, channel, seed, n, out.ctypes.data)
     return float(out[0]), float(out[1])
+
+def ggx_d(mat, h):
+    h = np.ascontiguousarray(h, np.float32); out = np.zeros(len(h), np.float32)
+    lib().orc_ggx_d(C.byref(mat), h.ctypes.data, len(h), out.ctypes.data)
+    return out
+
+
+def bsdf_eval(mat, V, L):
+    """EvaluateBSDF(V, L) for an array of L: (f [n, 3] with the cosine included, pdf [n])."""
+    V = np.ascontiguousarray(V, np.float32); L = np.ascontiguousarray(L, np.float32); out = np.zeros((len(L), 4), np.float32)
+    lib().orc_bsdf_eval(C.byref(mat), V.ctypes.data, L.ctypes.data, len(L), out.ctypes.data)
+    return out[:, :3], out[:, 3]
+
+
+def bsdf_sample(mat, V, seed, n):
+    """n draws of VNDF + SampleBSDF: (L [n, 3], f [n, 3], pdf [n])."""
+    V = np.ascontiguousarray(V, np.float32); out = np.zeros((n, 7), np.float32)
+    lib().orc_bsdf_sample(C.byref(mat), V.ctypes.data, seed, n, out.ctypes.data)
+    return out[:, :3], out[:, 3:6], out[:, 6]
+
 
 def lut_cells(kind, size, sample_count, time_ms, cells, threads=None):
     """LookupTableCalculator::CalculateTable restated, for the listed cell indices (x + y*sx + z*sx*sy)."""
