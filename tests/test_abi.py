@@ -71,3 +71,34 @@ def test_no_device_means_failure_not_fallback(vpt):
         pytest.skip("GPU present")
     with pytest.raises(vpt.VptError, match="NO_DEVICE"):
         vpt.PathTracer(16, 16)
+
+
+def test_ctypes_mirror_matches_the_compiled_header(vpt, tmp_path):
+    """sizeof and every field offset of each C struct, as gcc lays out include/vpt.h, against the ctypes mirror."""
+    import subprocess
+    a = vpt._abi
+    pairs = [("vpt_material", a.Material), ("vpt_volume", a.Volume), ("vpt_atmosphere", a.Atmosphere), ("vpt_mesh", a.Mesh), ("vpt_instance", a.Instance),
+             ("vpt_texture", a.Texture), ("vpt_scene_desc", a.SceneDesc), ("vpt_params", a.Params), ("vpt_post_params", a.PostParams),
+             ("vpt_config", a.Config), ("vpt_stats", a.Stats), ("vpt_ray", a.Ray), ("vpt_hit", a.Hit)]
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "vpt.h"', 'int main(void) {']
+    for cname, cls in pairs:
+        lines.append('printf("%s %%zu", sizeof(%s));' % (cname, cname))
+        for fname, _ in cls._fields_:
+            lines.append('printf(" %%zu", offsetof(%s, %s));' % (cname, fname))
+        lines.append('printf("\\n");')
+    lines += ['return 0; }']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = str(tmp_path / "layout")
+    subprocess.check_call(["gcc", "-I" + os.path.join(ROOT, "include"), str(src), "-o", exe])
+    out = subprocess.check_output([exe], text=True).strip().splitlines()
+    for (cname, cls), line in zip(pairs, out):
+        tok = line.split()
+        assert tok[0] == cname and int(tok[1]) == C.sizeof(cls), (cname, tok[1], C.sizeof(cls))
+        for (fname, _), off in zip(cls._fields_, tok[2:]):
+            assert getattr(cls, fname).offset == int(off), (cname, fname)
+    # the flag bits the Python side names
+    hdr = open(os.path.join(ROOT, "include", "vpt.h")).read()
+    for name, val in (("VPT_FLAG_SKY_MIS", a.FLAG_SKY_MIS), ("VPT_FLAG_MESH_MIS", a.FLAG_MESH_MIS), ("VPT_FLAG_LOCAL_HITS", a.FLAG_LOCAL_HITS)):
+        m = re.search(r"#define %s \(1u << (\d+)\)" % name, hdr)
+        assert m and (1 << int(m.group(1))) == val, name
