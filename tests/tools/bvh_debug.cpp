@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstring>
 #include <functional>
+#include <string>
 #include <vector>
 #include "../../vulkan-path-tracer_amd/csrc/bvh_build.hpp"
 using namespace vpt;
@@ -48,6 +49,8 @@ int main(int argc, char** argv) {
     std::vector<int> slot_of((size_t)max_gid + 1);
     for (size_t i = 0; i < leaf.size(); i++) slot_of[leaf[i].gid] = (int)i;
     int bad = 0;
+    const bool stats_only = argc > 3 && std::string(argv[3]) == "--stats";  // skip brute force, report visit counts
+    double n_nodes = 0, n_tris = 0, a_nodes = 0, a_tris = 0;
     for (size_t ri = 0; ri < rays.size() / 8; ri++) {
         const float* q = &rays[ri * 8];
         V3 o = vptfp::v3(q[0], q[1], q[2]), d = vptfp::v3(q[4], q[5], q[6]); float tmin = q[3], tmax = q[7];
@@ -57,17 +60,17 @@ int main(int argc, char** argv) {
         auto tri_hit = [&](const BvhTri& t, float& tt) { float u, v; vptfp::V3 a = vptfp::v3(t.v0[0], t.v0[1], t.v0[2]), b = vptfp::v3(t.e1[0], t.e1[1], t.e1[2]), c = vptfp::v3(t.e2[0], t.e2[1], t.e2[2]);
             return vptfp::ray_triangle(o, d, a, b, c, tmin, tmax, &tt, &u, &v) && vptfp::hit_is_local(o, d, a, b, c, tt); };
         float bt = tmax; int bg = -1;
-        for (const BvhTri& t : leaf) { float tt; if (tri_hit(t, tt) && (bg < 0 || tt < bt || (tt == bt && (int)t.gid < bg))) { bt = tt; bg = (int)t.gid; } }
+        if (!stats_only) for (const BvhTri& t : leaf) { float tt; if (tri_hit(t, tt) && (bg < 0 || tt < bt || (tt == bt && (int)t.gid < bg))) { bt = tt; bg = (int)t.gid; } }
         float best = tmax; int gid = -1; std::vector<int> st; int cur = 0;
         while (true) {
             if (cur >= 0) {
-                float t[4], a[4], b[4]; entries(nodes[cur], s, tmin, best, t, a, b);
+                float t[4], a[4], b[4]; entries(nodes[cur], s, tmin, best, t, a, b); n_nodes++;
                 int c[4] = {nodes[cur].child[0], nodes[cur].child[1], nodes[cur].child[2], nodes[cur].child[3]};
                 for (int i = 0; i < 4; i++) for (int j = i + 1; j < 4; j++) if (t[j] < t[i]) { std::swap(t[i], t[j]); std::swap(c[i], c[j]); }
                 if (t[0] < kMiss) { if (t[3] < kMiss) st.push_back(c[3]); if (t[2] < kMiss) st.push_back(c[2]); if (t[1] < kMiss) st.push_back(c[1]); cur = c[0]; continue; }
             } else {
                 uint32_t enc = (uint32_t)(~cur); int first = (int)(enc >> 3), cnt = (int)(enc & 7u) + 1;
-                for (int k = 0; k < cnt; k++) { float tt; const BvhTri& tr = leaf[first + k]; if (tri_hit(tr, tt) && (gid < 0 || tt < best || (tt == best && (int)tr.gid < gid))) { best = tt; gid = (int)tr.gid; } }
+                for (int k = 0; k < cnt; k++) { float tt; const BvhTri& tr = leaf[first + k]; n_tris++; if (tri_hit(tr, tt) && (gid < 0 || tt < best || (tt == best && (int)tr.gid < gid))) { best = tt; gid = (int)tr.gid; } }
             }
             if (st.empty()) break;
             cur = st.back(); st.pop_back();
@@ -77,24 +80,24 @@ int main(int argc, char** argv) {
             std::vector<int> st2; int c2 = 0;
             while (!tree_any) {
                 if (c2 >= 0) {
-                    float t[4], a[4], b[4]; entries(nodes[c2], s, tmin, tmax, t, a, b);
+                    float t[4], a[4], b[4]; entries(nodes[c2], s, tmin, tmax, t, a, b); a_nodes++;
                     int next = 0x7fffffff;
                     for (int k = 3; k >= 0; k--) if (t[k] < kMiss) { if (next != 0x7fffffff) st2.push_back(next); next = nodes[c2].child[k]; }
                     if (next != 0x7fffffff) { c2 = next; continue; }
                 } else {
                     uint32_t enc = (uint32_t)(~c2); int first = (int)(enc >> 3), cnt = (int)(enc & 7u) + 1;
-                    for (int k = 0; k < cnt; k++) { float tt; if (tri_hit(leaf[first + k], tt)) tree_any = true; }
+                    for (int k = 0; k < cnt && !tree_any; k++) { float tt; a_tris++; if (tri_hit(leaf[first + k], tt)) tree_any = true; }
                 }
                 if (st2.empty()) break;
                 c2 = st2.back(); st2.pop_back();
             }
-            if (brute_any != tree_any) {
+            if (!stats_only && brute_any != tree_any) {
                 bad++;
                 for (const BvhTri& t : leaf) { float tt; if (tri_hit(t, tt)) { lost = (int)t.gid; printf("ray %zu ANY-HIT: brute finds gid %d at t %.9g, tree finds nothing\n", ri, lost, tt);
                     printf("  triangle v0 %.9g %.9g %.9g e1 %.9g %.9g %.9g e2 %.9g %.9g %.9g\n", t.v0[0], t.v0[1], t.v0[2], t.e1[0], t.e1[1], t.e1[2], t.e2[0], t.e2[1], t.e2[2]); } }
             }
         }
-        if (gid != bg) {
+        if (!stats_only && gid != bg) {
             bad++;
             printf("ray %zu: brute t %.9g gid %d | tree t %.9g gid %d\n", ri, bt, bg, best, gid);
             if (bg >= 0) {  // chain of nodes down to the lost triangle's leaf
@@ -122,6 +125,8 @@ int main(int argc, char** argv) {
             }
         }
     }
+    const double nr = (double)(rays.size() / 8);
+    printf("visits per ray: closest %.2f nodes %.2f tris | any-hit %.2f nodes %.2f tris | nodes %zu\n", n_nodes / nr, n_tris / nr, a_nodes / nr, a_tris / nr, nodes.size());
     printf("mismatches %d of %zu\n", bad, rays.size() / 8);
     return bad ? 1 : 0;
 }
