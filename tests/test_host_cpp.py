@@ -217,3 +217,58 @@ def test_atmosphere_through_the_cpp_facade(cli, vpt, oracle, tmp_path):
     o.render(spp)
     ref = o.radiance(); o.close()
     assert np.array_equal(img, ref)
+
+
+def _repack(src_gltf, dst, mode):
+    """Rewrite a .gltf + .bin + PNG scene as (mode 'glb') one binary container with the images embedded as bufferViews, or
+    (mode 'data') a .gltf whose buffer and images are base64 data: URIs."""
+    import base64, struct
+    base = os.path.dirname(src_gltf)
+    g = json.load(open(src_gltf))
+    blob = bytearray(open(os.path.join(base, g["buffers"][0]["uri"]), "rb").read())
+    assert len(g["buffers"]) == 1
+    if mode == "glb":
+        for img in g.get("images", []):
+            png = open(os.path.join(base, img.pop("uri")), "rb").read()
+            while len(blob) % 4:
+                blob.append(0)
+            g["bufferViews"].append({"buffer": 0, "byteOffset": len(blob), "byteLength": len(png)})
+            img["bufferView"] = len(g["bufferViews"]) - 1; img["mimeType"] = "image/png"
+            blob += png
+        while len(blob) % 4:
+            blob.append(0)
+        g["buffers"][0] = {"byteLength": len(blob)}
+        js = json.dumps(g).encode()
+        js += b" " * (-len(js) % 4)
+        body = struct.pack("<II", len(js), 0x4E4F534A) + js + struct.pack("<II", len(blob), 0x004E4942) + bytes(blob)
+        open(dst, "wb").write(struct.pack("<4sII", b"glTF", 2, 12 + len(body)) + body)
+    else:
+        g["buffers"][0]["uri"] = "data:application/octet-stream;base64," + base64.b64encode(bytes(blob)).decode()
+        for img in g.get("images", []):
+            img["uri"] = "data:image/png;base64," + base64.b64encode(open(os.path.join(base, img["uri"]), "rb").read()).decode()
+        json.dump(g, open(dst, "w"))
+
+
+@pytest.mark.parametrize("mode", ["glb", "data"])
+def test_glb_container_and_data_uris(cli, vpt, tmp_path, mode):
+    """SURVEY 8f-3 loader breadth: the binary .glb container (JSON + BIN chunks, images as bufferViews) and base64 data: URIs
+    import to exactly the scene of the plain .gltf + .bin + .png form, in the C++ importer and in the Python loader."""
+    src = os.path.join(GOLDEN, "textured_boxes.gltf")
+    dst = str(tmp_path / ("scene.glb" if mode == "glb" else "scene_inline.gltf"))
+    _repack(src, dst, mode)
+    a, b = vpt.scenes.load_gltf(src), vpt.scenes.load_gltf(dst)
+    assert len(a.meshes) == len(b.meshes) and len(a.textures) == len(b.textures) and len(a.textures) > 5
+    for (va, ia), (vb, ib) in zip(a.meshes, b.meshes):
+        assert np.array_equal(va, vb) and np.array_equal(ia, ib)
+    for ta, tb in zip(a.textures, b.textures):
+        assert np.array_equal(ta, tb)
+    assert [{k: v for k, v in m.items() if k != "name"} for m in a.materials] == [{k: v for k, v in m.items() if k != "name"} for m in b.materials]
+    for name, path in (("a", src), ("b", dst)):
+        subprocess.check_output([cli, "--scene", path, "--dump-scene", str(tmp_path / (name + ".bin"))])
+    assert open(tmp_path / "a.bin", "rb").read() == open(tmp_path / "b.bin", "rb").read()
+    # a truncated container is an error, not a crash
+    if mode == "glb":
+        bad = str(tmp_path / "bad.glb")
+        open(bad, "wb").write(open(dst, "rb").read()[:200])
+        p = subprocess.run([cli, "--scene", bad, "--info"], capture_output=True)
+        assert p.returncode == 1 and b"glb" in p.stderr

@@ -129,9 +129,29 @@ uint8_t paeth(int a, int b, int c) { int p = a + b - c, pa = std::abs(p - a), pb
 
 }  // namespace
 
+bool DecodePNG(const std::string& f, const std::string& path, TextureAsset& out, std::string& error);
 bool LoadPNG(const std::string& path, TextureAsset& out, std::string& error) {
     std::string f;
     if (!read_file(path, f)) { error = "cannot open " + path; return false; }
+    return DecodePNG(f, path, out, error);
+}
+// base64 payload of a "data:<mime>;base64,<payload>" URI (glTF 2.0 section 2.6); false if `uri` is not one
+static bool decode_data_uri(const std::string& uri, std::string& out) {
+    if (uri.compare(0, 5, "data:") != 0) return false;
+    size_t comma = uri.find(',');
+    if (comma == std::string::npos || uri.find(";base64") == std::string::npos || uri.find(";base64") > comma) return false;
+    out.clear();
+    uint32_t acc = 0; int bits = 0;
+    for (size_t i = comma + 1; i < uri.size(); i++) {
+        const char ch = uri[i];
+        int v = (ch >= 'A' && ch <= 'Z') ? ch - 'A' : (ch >= 'a' && ch <= 'z') ? ch - 'a' + 26 : (ch >= '0' && ch <= '9') ? ch - '0' + 52 : ch == '+' ? 62 : ch == '/' ? 63 : -1;
+        if (v < 0) continue;  // '=' padding, whitespace
+        acc = (acc << 6) | (uint32_t)v; bits += 6;
+        if (bits >= 8) { bits -= 8; out.push_back((char)((acc >> bits) & 0xffu)); }
+    }
+    return true;
+}
+bool DecodePNG(const std::string& f, const std::string& path, TextureAsset& out, std::string& error) {
     static const unsigned char sig[8] = {137, 80, 78, 71, 13, 10, 26, 10};
     if (f.size() < 33 || std::memcmp(f.data(), sig, 8) != 0) { error = "not a PNG: " + path; return false; }
     auto be32 = [&](size_t o) { return ((uint32_t)(uint8_t)f[o] << 24) | ((uint32_t)(uint8_t)f[o + 1] << 16) | ((uint32_t)(uint8_t)f[o + 2] << 8) | (uint8_t)f[o + 3]; };
@@ -263,8 +283,22 @@ bool LoadLookupTables(const std::string& path, std::vector<float>& r, std::vecto
 }
 
 bool ImportScene(const std::string& gltfPath, SceneAsset& sc, std::string& error) {
-    std::string text;
+    std::string text, glbBin;
     if (!read_file(gltfPath, text)) { error = "cannot open " + gltfPath; return false; }
+    if (text.size() >= 20 && text.compare(0, 4, "glTF") == 0) {  // binary container (.glb): 12-byte header, JSON chunk, optional BIN chunk
+        auto le32 = [&](size_t o) { return (uint32_t)(uint8_t)text[o] | ((uint32_t)(uint8_t)text[o + 1] << 8) | ((uint32_t)(uint8_t)text[o + 2] << 16) | ((uint32_t)(uint8_t)text[o + 3] << 24); };
+        if (le32(4) != 2u) { error = "unsupported .glb version in " + gltfPath; return false; }
+        std::string json;
+        for (size_t p = 12; p + 8 <= text.size();) {
+            const uint32_t len = le32(p), type = le32(p + 4);
+            if (p + 8 + len > text.size()) { error = "truncated .glb: " + gltfPath; return false; }
+            if (type == 0x4E4F534Au) json = text.substr(p + 8, len);          // "JSON"
+            else if (type == 0x004E4942u && glbBin.empty()) glbBin = text.substr(p + 8, len);  // "BIN\0"
+            p += 8 + ((len + 3u) & ~3u);
+        }
+        if (json.empty()) { error = "no JSON chunk in " + gltfPath; return false; }
+        text.swap(json);
+    }
     JParser jp(text);
     JPtr root = jp.parse();
     if (!jp.ok || root->type != JVal::Obj) { error = "JSON parse error in " + gltfPath; return false; }
@@ -275,7 +309,8 @@ bool ImportScene(const std::string& gltfPath, SceneAsset& sc, std::string& error
         for (size_t i = 0; i < bs->size(); i++) {
             std::string d;
             const JVal* uri = (*bs)[i].get("uri");
-            if (!uri || !read_file(base + "/" + uri->str, d)) { error = "cannot read glTF buffer"; return false; }
+            if (!uri) { if (i != 0 || glbBin.empty()) { error = "glTF buffer without uri"; return false; } d = glbBin; }  // the .glb BIN chunk
+            else if (!decode_data_uri(uri->str, d) && !read_file(base + "/" + uri->str, d)) { error = "cannot read glTF buffer " + uri->str; return false; }
             bufs.push_back(std::move(d));
         }
     auto accessor = [&](int idx, std::vector<double>& out, int& ncomp) -> bool {
@@ -316,11 +351,25 @@ bool ImportScene(const std::string& gltfPath, SceneAsset& sc, std::string& error
         if (!ref) return true;
         const JVal& tex = (*g.get("textures"))[(size_t)ref->number("index", 0)];
         const JVal& img = (*g.get("images"))[(size_t)tex.number("source", 0)];
-        std::string key = img.get("uri")->str + (single ? "#r" : "");
+        // image source: external file, data: URI, or a bufferView (embedded PNG, the usual .glb form)
+        const JVal* iuri = img.get("uri");
+        std::string key = (iuri ? iuri->str : "bufferView:" + std::to_string((long long)img.number("bufferView", -1))) + (single ? "#r" : "");
         auto it = texCache.find(key);
         if (it == texCache.end()) {
             TextureAsset t;
-            if (!LoadPNG(base + "/" + img.get("uri")->str, t, error)) return false;
+            std::string bytes;
+            if (!iuri) {
+                const JVal* bvs = g.get("bufferViews");
+                const long long bi = (long long)img.number("bufferView", -1);
+                if (!bvs || bi < 0 || (size_t)bi >= bvs->size()) { error = "glTF image without uri or bufferView"; return false; }
+                const JVal& bv = (*bvs)[(size_t)bi];
+                const size_t bidx = (size_t)bv.number("buffer", 0), off = (size_t)bv.number("byteOffset", 0), len = (size_t)bv.number("byteLength", 0);
+                if (bidx >= bufs.size() || off + len > bufs[bidx].size()) { error = "glTF image bufferView out of range"; return false; }
+                bytes = bufs[bidx].substr(off, len);
+                if (!DecodePNG(bytes, key, t, error)) return false;
+            } else if (decode_data_uri(iuri->str, bytes)) {
+                if (!DecodePNG(bytes, "data URI", t, error)) return false;
+            } else if (!LoadPNG(base + "/" + iuri->str, t, error)) return false;
             if (single) {  // LoadTexture(..., onlySingleChannel=true) keeps R (PathTracer.cpp:826-836)
                 std::vector<uint8_t> r((size_t)t.Width * t.Height);
                 for (size_t i = 0; i < r.size(); i++) r[i] = t.Data[i * 4];

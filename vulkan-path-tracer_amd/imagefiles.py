@@ -105,7 +105,10 @@ def save_hdr(path, rgb, rle=True):
 
 def load_png(path):
     """8-bit gray / gray+alpha / RGB / RGBA, non-interlaced -> uint8 [h, w, 4]."""
-    b = open(path, "rb").read()
+    return decode_png(open(path, "rb").read(), path)
+
+
+def decode_png(b, path="<memory>"):
     if b[:8] != _PNG_SIG:
         raise ValueError("not a PNG: %s" % path)
     p, idat, hdr = 8, b"", None

@@ -244,8 +244,40 @@ def _node_matrix(n):
 
 def load_gltf(path, image_loader=None):
     base = os.path.dirname(path)
-    g = json.load(open(path))
-    bufs = [open(os.path.join(base, b["uri"]), "rb").read() for b in g["buffers"]]
+    raw_file = open(path, "rb").read()
+    glb_bin = None
+    if raw_file[:4] == b"glTF":  # binary container (.glb): 12-byte header, JSON chunk, optional BIN chunk
+        import struct
+        if struct.unpack_from("<I", raw_file, 4)[0] != 2:
+            raise ValueError("unsupported .glb version in %s" % path)
+        p, text = 12, None
+        while p + 8 <= len(raw_file):
+            n, typ = struct.unpack_from("<II", raw_file, p)
+            if typ == 0x4E4F534A:
+                text = raw_file[p + 8:p + 8 + n]
+            elif typ == 0x004E4942 and glb_bin is None:
+                glb_bin = raw_file[p + 8:p + 8 + n]
+            p += 8 + ((n + 3) & ~3)
+        g = json.loads(text)
+    else:
+        g = json.loads(raw_file)
+
+    def data_uri(uri):
+        """Payload of a data:...;base64,... URI (glTF 2.0 section 2.6) or None."""
+        if not uri.startswith("data:") or ";base64" not in uri.split(",", 1)[0]:
+            return None
+        import base64
+        return base64.b64decode(uri.split(",", 1)[1])
+
+    bufs = []
+    for i, b in enumerate(g.get("buffers", [])):
+        if "uri" not in b:
+            if i != 0 or glb_bin is None:
+                raise ValueError("glTF buffer without uri")
+            bufs.append(glb_bin)
+        else:
+            d = data_uri(b["uri"])
+            bufs.append(d if d is not None else open(os.path.join(base, b["uri"]), "rb").read())
 
     def accessor(i):
         a = g["accessors"][i]
@@ -271,10 +303,16 @@ def load_gltf(path, image_loader=None):
         if tex_ref is None:
             return None
         img = g["images"][g["textures"][tex_ref["index"]]["source"]]
-        key = (img["uri"], single_channel)
+        key = (img.get("uri", "bufferView:%d" % img.get("bufferView", -1)), single_channel)
         if key not in tex_cache:
-            if image_loader is None:
-                from . import imagefiles
+            from . import imagefiles
+            if "uri" not in img:      # embedded PNG (the usual .glb form)
+                bv = g["bufferViews"][img["bufferView"]]
+                off = bv.get("byteOffset", 0)
+                arr = imagefiles.decode_png(bufs[bv["buffer"]][off:off + bv["byteLength"]])
+            elif data_uri(img["uri"]) is not None:
+                arr = imagefiles.decode_png(data_uri(img["uri"]))
+            elif image_loader is None:
                 arr = imagefiles.load_png(os.path.join(base, img["uri"]))
             else:
                 arr = image_loader(os.path.join(base, img["uri"]))
