@@ -1,26 +1,36 @@
 #!/usr/bin/env python
 """bench.py — Msamples/s of the wavefront path tracer on BASELINE.json's metric config.
 
-Workload (config.workload = "cornell_1080p_d8"): BASELINE.json configs[1] — Assets/CornellBox as shipped
-(diffuse walls + emissive quad, strength 50), black environment, 1920x1080, max depth 8, 1 sample per
-pixel per frame, base seed 1.  A *step* is one wavefront batch of the hot path:
-every rank renders `frames_per_step` consecutive frames of its own rows (fused primary bounce, then one
-fused bounce kernel — or extend/shade/connect for scenes too big for LDS — per bounce until the ray queue is
-empty, then resolve).  Rows are dealt round-robin over ranks, each rank keeps ~32M paths resident, so
-per-GPU work per step is fixed (weak scaling) and
+Headline workload (config.workload = "cornell_1080p_d8"): BASELINE.json configs[1] — Assets/CornellBox as shipped
+(diffuse walls + emissive quad, strength 50), black environment, 1920x1080, max depth 8, 1 sample per pixel per
+frame, base seed 1.  A *step* is one wavefront batch of the hot path: every rank renders
+`frames_per_step` consecutive frames of its own rows (all bounces until the ray queue is empty, then resolve).
+Rows are dealt round-robin over ranks, each rank keeps ~32M paths resident, so per-GPU work per step is fixed
+(weak scaling) and
 
     value = (samples all ranks traced in the K timed steps) / (max over ranks of the wall time)
 
-with scene, BVH, path state and accumulation image resident in HBM before the timed region.  The timed
-region ends with the single collective of the path: one gather of the finished row shards (RCCL, backend
-"nccl") and the row re-interleave on rank 0.
+with scene, BVH, path state and accumulation image resident in HBM before the timed region, and with the library's
+per-launch event profiling OFF.  The timed region ends with the single collective of the path: one RCCL gather of the
+finished row shards issued by the library itself (vpt_comm_gather_shards, include/vpt.h) and the row re-interleave on
+rank 0.  torch.distributed is only the launcher / control plane (rendezvous, barrier, max-over-ranks).
 
-Extra JSON objects (see DESIGN.md §6 for the byte accounting):
-  roofline     — for the kernel with the largest share of GPU time in the timed region: algorithmic HBM
-                 bytes per launch / mean launch duration (HIP events recorded by the library on the stream
-                 it launches on), against the 8 TB/s HBM3E peak.  `kernels` lists every stage.
-  cpu_baseline — the CPU oracle (oracle/, a port of the reference shaders; the reference has no CPU path)
-                 on this box's host cores, on a bounded sample of the same workload.
+After the timed region the same workload runs a few more steps with profiling ON (HIP events the library records
+around every launch on its own stream) and with traversal counters, which feed
+
+  roofline     — for the kernel with the largest share of GPU time: `bound` says what limits it ("valu" for the fused
+                 Cornell kernels: 74-82 % VALU-busy in profiles/, their BVH rides in LDS; "hbm" only where the
+                 bytes really cross HBM).  `achieved` = bytes that MUST cross HBM per launch (path records, queue
+                 words, frame sums) / mean launch duration, so frac <= 1 by construction; `traffic` = the PMC
+                 measurement (profiles/traffic.json); `algorithmic_GBs` is SURVEY §8d's figure (records + scene
+                 gathers + measured BVH visits), which on an LDS/L2-resident scene exceeds what HBM moves and is
+                 therefore reported beside the fraction, not as it.
+  workloads    — (N=1 only) the two scenes whose traversal touches memory, BASELINE configs 3 and 5 at their own
+                 resolution and depth ("atrium_1080p_d8", "glass_bust_1080p_d32"): Msamples/s and per-kernel
+                 algorithmic bytes from MEASURED node / triangle visits, with the traversal kernels' fraction of
+                 the 8 TB/s roofline.
+  cpu_baseline — the CPU oracle (oracle/, a port of the reference shaders; the reference has no CPU path) on this
+                 box's host cores, on a bounded sample of the headline workload.
 """
 import argparse
 import importlib
@@ -33,17 +43,22 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 GB/s measured copy
-WIDTH, HEIGHT, MAX_DEPTH, BASE_SEED = 1920, 1080, 8, 1
+WIDTH, HEIGHT, BASE_SEED = 1920, 1080, 1
+WORKLOADS = {   # name -> (max depth, scene description)
+    "cornell_1080p_d8": (8, "CornellBox (12 triangles, emissive quad 50), black env"),
+    "atrium_1080p_d8": (8, "procedural Sponza-class atrium, 253,002 triangles, 25 PBR materials, 12 textures, sun-and-sky env 2048x1024"),
+    "glass_bust_1080p_d32": (32, "glass bust 510,992 triangles (transmission 1, roughness 0.05, IOR 1.5) on a plinth, sun-and-sky env 4096x2048"),
+}
 
 # Algorithmic bytes per unit for each stage: state words actually read/written per path or
 # ray by the algorithm with this build's struct sizes; BVH node/triangle visits are measured, not assumed.
-TRI_BYTES = 48   # triangle record; the node size (64 B quantised, 128 B fp32 when the BVH rides in LDS) comes from vpt_stats
+TRI_BYTES = 48   # triangle record; the node size comes from vpt_stats (64 B quantised BVH4, 128 B fp32 when the BVH rides in LDS)
 EXTEND_FIXED = 4 + 24 + 20          # queue id, origin+direction in, hit record out
 SHADE_IN = 4 + 16 + 16 + 16 + 20    # queue id, records A (origin|rng), B (dir|depth), T (throughput|pdf), hit record
 SHADE_ALIVE_OUT = 16 + 16 + 16 + 4  # A, B, T of the surviving path + next-queue id
 SHADE_PENDING_OUT = 16 + 4          # CE (emission|flags) + connect-queue id
 SHADE_RAY_OUT = 48                  # contribution|gid, origin|dir.x, dir.yz per queued shadow ray
-SHADE_SCENE = 8 + 48 + 36 + 12 + 96 + 112 + 5 * 4 + (8 + 64) + (80 + 12 + 96 + 12 + 4) + 2 * 16  # instance, indices, 3 vertices, material, 5 1x1 texels, env alias + 4 texels, light entry + triangle, 2 LUT taps
+SHADE_SCENE = 8 + 48 + 36 + 12 + 96 + 112 + 5 * 4 + (8 + 64) + (80 + 12 + 96 + 12 + 4) + 2 * 16  # instance, indices, 3 vertices, material, 5 texels, env alias + 4 texels, light entry + triangle, 2 LUT taps
 CONNECT_FIXED = 4 + 16 + 16 + 16 + 16   # queue id, CE, T (pre-update throughput), pathLight read + write
 CONNECT_RAY = 48                    # per shadow ray: the three records shade queued
 CONNECT_FINAL = 16                  # frame-sum write at the end of a sample (samples_per_frame == 1)
@@ -57,18 +72,29 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=48)
     ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--workload", default="cornell_1080p_d8", choices=sorted(WORKLOADS), help="headline workload (the default is BASELINE's metric config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--frames-in-flight", type=int, default=0, help="frames per step per GPU (0 = backend default, ~4M resident paths)")
+    ap.add_argument("--no-extra-workloads", action="store_true", help="skip the atrium / glass-bust blocks")
+    ap.add_argument("--frames-in-flight", type=int, default=0, help="frames per step per GPU (0 = backend default, ~32M resident paths)")
+    ap.add_argument("--pipeline", type=int, default=0, help="vpt_config.pipeline (0 AUTO)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the oracle sample")
     return ap.parse_args()
 
 
-def cpu_baseline(vpt, scene, seconds):
-    """Oracle on the host cores: bounded sample of the same workload (whole 1080p frames, depth 8)."""
+def load_scene(vpt, name):
+    if name == "cornell_1080p_d8":
+        return vpt.scenes.Scene.load(os.path.join(ROOT, "tests", "golden", "cornell_box.npz"))
+    if name == "atrium_1080p_d8":
+        return vpt.scenes.atrium()
+    return vpt.scenes.glass_bust()
+
+
+def cpu_baseline(vpt, scene, depth, seconds):
+    """Oracle on the host cores: bounded sample of the same workload (whole 1080p frames)."""
     from oracle import oracle_py
     cores = os.cpu_count() or 1
     o = oracle_py.Oracle(scene, WIDTH, HEIGHT, threads=cores)
-    o.set_params(vpt.default_params(max_depth=MAX_DEPTH, base_seed=BASE_SEED))
+    o.set_params(vpt.default_params(max_depth=depth, base_seed=BASE_SEED))
     t0 = time.perf_counter()
     o.render(1)
     t1 = time.perf_counter() - t0
@@ -79,8 +105,130 @@ def cpu_baseline(vpt, scene, seconds):
     c = o.counters()
     o.close()
     return {"value": round(WIDTH * HEIGHT * frames / dt / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
-            "sample": "%d full 1920x1080 frames (1 spp each, depth %d) of the same Cornell workload, OpenMP over rows" % (frames, MAX_DEPTH),
+            "sample": "%d full 1920x1080 frames (1 spp each, depth %d) of the same workload, OpenMP over rows" % (frames, depth),
             "mrays_per_s": round((c["closest"] + c["shadow"]) * frames / (frames + 1) / dt / 1e6, 3)}
+
+
+def traversal_counts(vpt, scene, params, device, rank, world, pipeline, frames):
+    """Mean BVH nodes / triangles visited per closest-hit and per shadow ray, from the counting kernel variants."""
+    cnt = vpt.PathTracer(WIDTH, HEIGHT, device=device, shard_rank=rank, shard_count=world, count_traversal=True, pipeline=pipeline,
+                         frames_in_flight=frames)
+    cnt.set_scene(scene); cnt.set_params(params); cnt.render(frames)
+    cs = cnt.stats(); cnt.close()
+    return {"nodes_per_closest_ray": cs["nodes_visited"] / max(cs["closest_rays"], 1), "tris_per_closest_ray": cs["tris_tested"] / max(cs["closest_rays"], 1),
+            "nodes_per_shadow_ray": cs["shadow_nodes_visited"] / max(cs["shadow_rays"], 1), "tris_per_shadow_ray": cs["shadow_tris_tested"] / max(cs["shadow_rays"], 1),
+            "closest_rays": cs["closest_rays"], "shadow_rays": cs["shadow_rays"], "samples": cs["samples"]}
+
+
+def kernel_table(st, tc):
+    """Per stage: launches, mean ms, units, algorithmic bytes per unit (records + scene gathers + measured BVH visits) and
+    the part of them that is unique per path (records / queue words / frame sums) and therefore has to cross HBM."""
+    n0 = st["samples"]
+    fused0 = st["kernel_launches"]["bounce"] > 0 or st["kernel_launches"]["extend"] == 0   # bounce 0 ran in the fused primary kernel
+    n_later = st["closest_rays"] - (n0 if fused0 else 0)
+    hits0, alive0, rays0 = st["primary_hits"], st["primary_survivors"], st["primary_shadow_rays"]
+    later_rays = st["shadow_rays"] - rays0
+    alive_later = max(n_later - alive0, 0) if fused0 else max(st["closest_rays"] - n0, 0)
+    node_b = st["bvh_node_bytes"]
+    trav = tc["nodes_per_closest_ray"] * node_b + tc["tris_per_closest_ray"] * TRI_BYTES
+    strav = tc["nodes_per_shadow_ray"] * node_b + tc["tris_per_shadow_ray"] * TRI_BYTES
+    fin = alive0 if fused0 else n0     # frame-sum writes by the connect stage
+    units = {
+        "primary": (n0, (PRIMARY_DONE * (n0 - alive0) + PRIMARY_ALIVE * alive0 + SHADE_SCENE * hits0 + strav * rays0) / max(n0, 1) + trav,
+                    (PRIMARY_DONE * (n0 - alive0) + PRIMARY_ALIVE * alive0) / max(n0, 1)) if fused0 else (n0, 68.0, 68.0),
+        "bounce": (n_later, 4 + 64 + SHADE_SCENE + trav + (PRIMARY_ALIVE * alive_later + PRIMARY_DONE * alive0 + strav * later_rays) / max(n_later, 1),
+                   4 + 64 + (PRIMARY_ALIVE * alive_later + PRIMARY_DONE * alive0) / max(n_later, 1)),
+        "extend": (n_later, EXTEND_FIXED + trav, EXTEND_FIXED),
+        "shade": (n_later, SHADE_IN + SHADE_SCENE + (SHADE_ALIVE_OUT * alive_later + SHADE_PENDING_OUT * st["connect_paths"] + SHADE_RAY_OUT * later_rays) / max(n_later, 1),
+                  SHADE_IN + (SHADE_ALIVE_OUT * alive_later + SHADE_PENDING_OUT * st["connect_paths"] + SHADE_RAY_OUT * later_rays) / max(n_later, 1)),
+        "connect": (st["connect_paths"], CONNECT_FIXED + (CONNECT_FINAL * fin + (CONNECT_RAY + strav) * later_rays) / max(st["connect_paths"], 1),
+                    CONNECT_FIXED + (CONNECT_FINAL * fin + CONNECT_RAY * later_rays) / max(st["connect_paths"], 1)),
+        "resolve": (st["samples"], RESOLVE_BYTES, RESOLVE_BYTES),
+    }
+    kernels = {}
+    for name, (n, bpu, spu) in units.items():
+        ms, launches = st["kernel_ms"][name], st["kernel_launches"][name]
+        if launches == 0 or ms <= 0:
+            continue
+        kernels[name] = {"launches": launches, "avg_ms": round(ms / launches, 5), "total_ms": round(ms, 3), "share": 0.0,
+                         "units_per_launch": round(n / launches, 1), "algorithmic_bytes_per_unit": round(bpu, 1), "record_bytes_per_unit": round(spu, 1),
+                         "algorithmic_GBs": round(n * bpu / (ms * 1e-3) / 1e9, 1), "records_GBs": round(n * spu / (ms * 1e-3) / 1e9, 1),
+                         "algorithmic_frac_of_hbm_peak": round(n * bpu / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    tot_ms = sum(st["kernel_ms"][k] for k in kernels)
+    for k in kernels:
+        kernels[k]["share"] = round(st["kernel_ms"][k] / tot_ms, 4)
+    return kernels
+
+
+def load_json(path):
+    try:
+        return json.load(open(path))
+    except Exception:
+        return {}
+
+
+def profile_workload(vpt, name, scene, device, rank, world, pipeline, frames_in_flight, steps, warmup):
+    """Un-profiled throughput, then profiled per-kernel times, then traversal counts, for one workload on this rank."""
+    depth = WORKLOADS[name][0]
+    params = vpt.default_params(max_depth=depth, base_seed=BASE_SEED, max_samples=0x7fffffff)
+    pt = vpt.PathTracer(WIDTH, HEIGHT, device=device, shard_rank=rank, shard_count=world, pipeline=pipeline, frames_in_flight=frames_in_flight)
+    pt.set_scene(scene); pt.set_params(params)
+    F = pt.stats()["frames_in_flight"]
+    for _ in range(warmup):
+        pt.render(F)
+    pt.reset_stats()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        pt.render(F)          # vpt_render returns with the stream drained
+    dt = time.perf_counter() - t0
+    st = pt.stats(); pt.close()
+    out = {"value": round(st["samples"] / dt / 1e6, 2), "unit": "Msamples/s", "steps": steps, "frames_per_step": F, "ms_per_step": round(dt / steps * 1e3, 3),
+           "mrays_per_s": round((st["closest_rays"] + st["shadow_rays"]) / dt / 1e6, 1), "scene": WORKLOADS[name][1], "max_depth": depth,
+           "rays_per_sample": round((st["closest_rays"] + st["shadow_rays"]) / max(st["samples"], 1), 3)}
+    out.update(kernel_profile(vpt, name, scene, device, rank, world, pipeline, frames_in_flight, max(2, min(steps, 4))))
+    return out
+
+
+def kernel_profile(vpt, name, scene, device, rank, world, pipeline, frames_in_flight, steps):
+    depth = WORKLOADS[name][0]
+    params = vpt.default_params(max_depth=depth, base_seed=BASE_SEED, max_samples=0x7fffffff)
+    pp = vpt.PathTracer(WIDTH, HEIGHT, device=device, shard_rank=rank, shard_count=world, pipeline=pipeline, frames_in_flight=frames_in_flight, profile=True)
+    pp.set_scene(scene); pp.set_params(params)
+    F = pp.stats()["frames_in_flight"]
+    for _ in range(4):        # AUTO times both pipelines over the first four full batches
+        pp.render(F)
+    pp.reset_stats()
+    for _ in range(steps):
+        pp.render(F)
+    st = pp.stats(); pp.close()
+    used = 1 if st["kernel_launches"]["bounce"] > 0 else 2    # the pipeline AUTO settled on: count with the same one
+    tc = traversal_counts(vpt, scene, params, device, rank, world, used if pipeline == 0 else pipeline, min(F, 4))
+    kernels = kernel_table(st, tc)
+    return {"pipeline": "fused" if used == 1 else "staged", "bvh": {"nodes": st["bvh_nodes"], "triangles": st["bvh_triangles"], "node_bytes": st["bvh_node_bytes"], "tri_bytes": st["bvh_tri_bytes"]},
+            "traversal": {k: round(v, 3) for k, v in tc.items() if k.endswith("_ray")}, "kernels": kernels}
+
+
+def roofline_for(name, prof):
+    """The roofline object of the bench line, for the kernel with the largest share of GPU time."""
+    kernels = prof["kernels"]
+    dom = max(kernels, key=lambda k: kernels[k]["share"])
+    k = kernels[dom]
+    pmc = load_json(os.path.join(ROOT, "profiles", "traffic.json")).get(name, {})   # written from rocprofv3 --pmc passes (profiles/README.md)
+    traffic = pmc.get(dom, {}).get("hbm_bytes_per_launch")
+    valu_busy = pmc.get(dom, {}).get("valu_busy")
+    lds_scene = prof["bvh"]["node_bytes"] == 128
+    # the fused kernels of an LDS-resident scene are VALU-bound (profiles/*_pmc_sq.md); traversal of a memory-resident BVH is
+    # bounded by divergent VALU issue and dependent-fetch latency, shading by gathers: none of them is a streaming HBM kernel,
+    # so the HBM fraction below is what they leave of the memory roofline, not a claim that HBM is the limiter
+    bound = "valu" if lds_scene or dom in ("extend", "connect", "trace") else "hbm"
+    return {"bound": bound, "kernel": dom, "achieved": k["records_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(k["records_GBs"] / HBM_PEAK_GBS, 5),
+            "traffic": traffic, "valu_busy": valu_busy, "avg_launch_ms": k["avg_ms"],
+            "record_bytes_per_launch": round(k["record_bytes_per_unit"] * k["units_per_launch"], 0),
+            "algorithmic_bytes_per_launch": round(k["algorithmic_bytes_per_unit"] * k["units_per_launch"], 0),
+            "algorithmic_GBs": k["algorithmic_GBs"], "algorithmic_frac_of_hbm_peak": k["algorithmic_frac_of_hbm_peak"],
+            "note": "achieved = path records / queue words / frame sums (must cross HBM) per launch / mean launch time; algorithmic_* adds scene gathers and measured "
+                    "BVH visits by SURVEY 8d's formula, which LDS / L1 / L2 serve on a resident scene; traffic and valu_busy are rocprofv3 PMC passes (profiles/)",
+            "traversal": prof["traversal"], "kernels": kernels}
 
 
 def main():
@@ -94,35 +242,28 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the backend has no CPU fallback")
-    # Test hooks for a 1-GPU box (the N > 1 path is otherwise only ever run by the driver): VPT_BENCH_DEVICE pins every
-    # rank to one device, VPT_BENCH_BACKEND=gloo routes the two collectives through host memory.  Never set by default.
-    backend = os.environ.get("VPT_BENCH_BACKEND", "nccl")
-    if "VPT_BENCH_DEVICE" in os.environ:
+    # Test hook for a 1-GPU box (the N > 1 path is otherwise only ever run by the driver): VPT_BENCH_DEVICE pins every rank to
+    # one device and the shard gather then goes through host memory (RCCL refuses two ranks on one device).  Never set by default.
+    one_device = "VPT_BENCH_DEVICE" in os.environ
+    if one_device:
         local_rank = int(os.environ["VPT_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
-    cdev = "cuda" if backend == "nccl" else "cpu"  # where collective operands live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend, rank=rank, world_size=world)
+        dist.init_process_group("gloo", rank=rank, world_size=world)   # control plane only: the data-path gather is the library's RCCL call
     vpt = importlib.import_module("vulkan-path-tracer_amd")
     sharding = importlib.import_module("vulkan-path-tracer_amd.sharding")
-    scene = vpt.scenes.Scene.load(os.path.join(ROOT, "tests", "golden", "cornell_box.npz"))
-    params = vpt.default_params(max_depth=MAX_DEPTH, base_seed=BASE_SEED, max_samples=0x7fffffff)
+    name = args.workload
+    depth = WORKLOADS[name][0]
+    scene = load_scene(vpt, name)
+    params = vpt.default_params(max_depth=depth, base_seed=BASE_SEED, max_samples=0x7fffffff)
 
-    # traversal visit counts (algorithmic bytes of extend / shadow) from a short counting pass
-    cnt = vpt.PathTracer(WIDTH, HEIGHT, device=local_rank, shard_rank=rank, shard_count=world, count_traversal=True)
-    cnt.set_scene(scene); cnt.set_params(params); cnt.render(2)
-    cs = cnt.stats(); cnt.close()
-    nodes_per_ray = cs["nodes_visited"] / max(cs["closest_rays"], 1)
-    tris_per_ray = cs["tris_tested"] / max(cs["closest_rays"], 1)
-    snodes_per_ray = cs["shadow_nodes_visited"] / max(cs["shadow_rays"], 1)
-    stris_per_ray = cs["shadow_tris_tested"] / max(cs["shadow_rays"], 1)
-
-    pt = vpt.PathTracer(WIDTH, HEIGHT, device=local_rank, shard_rank=rank, shard_count=world, profile=True,
-                        frames_in_flight=args.frames_in_flight)
+    pt = vpt.PathTracer(WIDTH, HEIGHT, device=local_rank, shard_rank=rank, shard_count=world, pipeline=args.pipeline, frames_in_flight=args.frames_in_flight)
     pt.set_scene(scene); pt.set_params(params)
     F = pt.stats()["frames_in_flight"]
-    shard = torch.empty(pt.shard_floats(), dtype=torch.float32, device="cuda")
+    comm = None
+    if world > 1:
+        comm = sharding.ShardComm(pt, rank, world, host_staged=one_device)   # ncclCommInitRank inside libvpt_hip.so; the id travels over gloo
 
     def sync():
         if world > 1:
@@ -131,105 +272,62 @@ def main():
 
     for _ in range(args.warmup):
         pt.render(F)
-    def gather():
-        pt.shard_to_device(shard.data_ptr())
-        return sharding.gather_shards(shard.to(cdev), world).to("cuda")
-
-    if world > 1:  # warm the communicator outside the timed region
-        gather()
+    if comm:
+        comm.gather_and_assemble()   # warm the communicator outside the timed region
     pt.reset_stats()
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         pt.render(F)
-    gathered = gather()
-    if rank == 0:
-        pt.assemble_shards(gathered.data_ptr(), world)
+    if comm:
+        comm.gather_and_assemble()   # one ncclGather of the row shards to rank 0 + row re-interleave there
     sync()
     dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
+    tmax = torch.tensor([dt], dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     st = pt.stats()
-    local_samples = st["samples"]
-    tot = torch.tensor([float(local_samples), float(st["closest_rays"]), float(st["shadow_rays"])], dtype=torch.float64, device=cdev)
+    tot = torch.tensor([float(st["samples"]), float(st["closest_rays"]), float(st["shadow_rays"])], dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
     samples, closest, shadow = (float(x) for x in tot.tolist())
+    shard_pixels = st["shard_pixels"]
+    pt.close()
 
     if rank == 0:
-        # ---- per-kernel algorithmic bytes / measured HIP-event time (this rank's launches)
-        n0 = st["samples"] // 1                # bounce 0 of every slot runs in the fused primary kernel
-        n_later = st["closest_rays"] - n0      # path-bounces that went through extend / shade
-        hits0, alive0, rays0 = st["primary_hits"], st["primary_survivors"], st["primary_shadow_rays"]
-        later_rays = st["shadow_rays"] - rays0
-        alive_later = max(n_later - alive0, 0)  # paths leaving bounce k >= 1 alive == paths entering bounce k+1
-        NODE_BYTES = st["bvh_node_bytes"]
-        trav = nodes_per_ray * NODE_BYTES + tris_per_ray * TRI_BYTES
-        strav = snodes_per_ray * NODE_BYTES + stris_per_ray * TRI_BYTES
-        # per stage: (units, algorithmic bytes per unit by SURVEY 8d's formula = path records + scene gathers + BVH visits,
-        #             of which bytes per unit that are path records / queues / frame sums, i.e. unique per path and bound for HBM)
-        scene_hit = SHADE_SCENE
-        units = {
-            # fused bounce 0, per slot: frame sum out for paths that end, records A,B,T,L + queue id for survivors
-            "primary": (n0, (PRIMARY_DONE * (n0 - alive0) + PRIMARY_ALIVE * alive0 + scene_hit * hits0 + strav * rays0) / max(n0, 1) + trav,
-                        (PRIMARY_DONE * (n0 - alive0) + PRIMARY_ALIVE * alive0) / max(n0, 1)),
-            # fused later bounce: records A,B,T,L in, the same out for survivors, frame sum for paths that end
-            "bounce": (n_later, 4 + 64 + scene_hit + trav + (PRIMARY_ALIVE * alive_later + PRIMARY_DONE * alive0 + strav * later_rays) / max(n_later, 1),
-                       4 + 64 + (PRIMARY_ALIVE * alive_later + PRIMARY_DONE * alive0) / max(n_later, 1)),
-            "extend": (n_later, EXTEND_FIXED + trav, EXTEND_FIXED),
-            "shade": (n_later, SHADE_IN + scene_hit + (SHADE_ALIVE_OUT * alive_later + SHADE_PENDING_OUT * st["connect_paths"] + SHADE_RAY_OUT * later_rays) / max(n_later, 1),
-                      SHADE_IN + (SHADE_ALIVE_OUT * alive_later + SHADE_PENDING_OUT * st["connect_paths"] + SHADE_RAY_OUT * later_rays) / max(n_later, 1)),
-            "connect": (st["connect_paths"], CONNECT_FIXED + (CONNECT_FINAL * alive0 + (CONNECT_RAY + strav) * later_rays) / max(st["connect_paths"], 1),
-                        CONNECT_FIXED + (CONNECT_FINAL * alive0 + CONNECT_RAY * later_rays) / max(st["connect_paths"], 1)),
-            "resolve": (st["samples"], RESOLVE_BYTES, RESOLVE_BYTES),
-        }
-        kernels = {}
-        for name, (n, bpu, spu) in units.items():
-            ms, launches = st["kernel_ms"][name], st["kernel_launches"][name]
-            if launches == 0 or ms <= 0:
-                continue
-            kernels[name] = {"launches": launches, "avg_ms": round(ms / launches, 5), "share": 0.0,
-                             "bytes_per_unit": round(bpu, 1), "record_bytes_per_unit": round(spu, 1), "units_per_launch": round(n / launches, 1),
-                             "achieved_GBs": round(n * bpu / (ms * 1e-3) / 1e9, 2), "achieved_records_only_GBs": round(n * spu / (ms * 1e-3) / 1e9, 2)}
-        tot_ms = sum(st["kernel_ms"][k] for k in kernels)
-        for k in kernels:
-            kernels[k]["share"] = round(st["kernel_ms"][k] / tot_ms, 4)
-        dom = max(kernels, key=lambda k: kernels[k]["share"])
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")   # written from rocprofv3 --pmc passes (see profiles/README.md)
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get(dom, {}).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        roof = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(kernels[dom]["achieved_GBs"] / HBM_PEAK_GBS, 5), "traffic": traffic,
-                "achieved_records_only": kernels[dom]["achieved_records_only_GBs"],
-                "note": "achieved counts scene/BVH gathers that this 12-triangle scene serves from LDS/L1; records_only is the part that must cross HBM; traffic is the PMC measurement",
-                "avg_launch_ms": kernels[dom]["avg_ms"],
-                "algorithmic_bytes_per_launch": round(kernels[dom]["bytes_per_unit"] * kernels[dom]["units_per_launch"], 0),
-                "traversal": {"nodes_per_closest_ray": round(nodes_per_ray, 3), "tris_per_closest_ray": round(tris_per_ray, 3),
-                              "nodes_per_shadow_ray": round(snodes_per_ray, 3), "tris_per_shadow_ray": round(stris_per_ray, 3)},
-                "kernels": kernels}
+        prof = kernel_profile(vpt, name, scene, local_rank, rank, world, args.pipeline, args.frames_in_flight, 4)
         line = {
             "metric": "Msamples/s at 1920x1080", "value": round(samples / dt / 1e6, 3), "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "cornell_1080p_d8", "scene": "CornellBox (12 triangles, emissive quad 50), black env",
-                       "width": WIDTH, "height": HEIGHT, "max_depth": MAX_DEPTH, "samples_per_frame": 1,
-                       "frames_per_step_per_gpu": F, "paths_in_flight_per_gpu": st["shard_pixels"] * F,
-                       "partition": "rows y % N == rank, one gather at the end", "base_seed": BASE_SEED},
+            "config": {"workload": name, "scene": WORKLOADS[name][1],
+                       "width": WIDTH, "height": HEIGHT, "max_depth": depth, "samples_per_frame": 1,
+                       "frames_per_step_per_gpu": F, "paths_in_flight_per_gpu": shard_pixels * F,
+                       "timed_samples_per_pixel": round(samples / (WIDTH * HEIGHT), 1),
+                       "note": "a rate metric: the timed region is steps x frames_per_step frames of the 1024-spp job, not all 1024 (full run: profiles/*_config2_full_parity.json)",
+                       "partition": "rows y % N == rank, one ncclGather at the end", "base_seed": BASE_SEED, "pipeline": prof["pipeline"]},
             "mrays_per_s": round((closest + shadow) / dt / 1e6, 2),
-            "roofline": roof,
+            "roofline": roofline_for(name, prof),
         }
+        if world == 1 and not args.no_extra_workloads:
+            extra = {}
+            for other in ("atrium_1080p_d8", "glass_bust_1080p_d32"):
+                if other == name:
+                    continue
+                sc2 = load_scene(vpt, other)
+                w = profile_workload(vpt, other, sc2, local_rank, 0, 1, 0, 0, steps=6, warmup=5)
+                r = roofline_for(other, w)
+                w["roofline"] = {k: r[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "valu_busy", "algorithmic_GBs", "algorithmic_frac_of_hbm_peak")}
+                extra[other] = w
+            line["workloads"] = extra
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(vpt, scene, args.cpu_seconds)
+            line["cpu_baseline"] = cpu_baseline(vpt, scene, depth, args.cpu_seconds)
         print(json.dumps(line), flush=True)
-    pt.close()
     if world > 1:
         dist.barrier()
+        if comm:
+            comm.close()
         dist.destroy_process_group()
 
 

@@ -336,6 +336,24 @@ size_t vpt_shard_floats(const vpt_ctx* ctx);
 int vpt_get_shard_device(vpt_ctx* ctx, void* shard_device);
 int vpt_assemble_shards(vpt_ctx* ctx, const void* gathered_device, uint32_t shard_count);
 
+/* The one collective of the path.  The reference's only image partition is the interleaved
+ * split-screen chunking of RayGen.slang:16-25 / PathTracer.cpp:141-153; here shard r owns rows y % N == r and
+ * the finished shards meet ONCE, on `root`, over xGMI.  Nothing else ever crosses devices.
+ *   process per GPU (torchrun / mpirun launch): vpt_comm_unique_id() on one rank, the 128 bytes handed to the
+ *     others out of band (any control plane), vpt_comm_init() = ncclCommInitRank on the context's device,
+ *     vpt_comm_gather_shards() = ncclGather of the padded shards (vpt_shard_floats each) on the context's stream
+ *     followed, on root, by the row re-interleave: root's vpt_get_radiance / vpt_postprocess then see the whole
+ *     image.  rank must equal the context's shard_rank and world its shard_count.
+ *   one process driving N devices (the C++ host, `vpt_render --gpus N`): vpt_multi_gather_shards() over the N
+ *     contexts, shard k at index k: peer copies (hipMemcpyPeerAsync, direct xGMI links) into root + re-interleave.
+ * Both return VPT_ERR_DEVICE with the RCCL / HIP message in vpt_last_error() on failure. */
+#define VPT_COMM_ID_BYTES 128
+int vpt_comm_unique_id(void* id_out);
+int vpt_comm_init(vpt_ctx* ctx, const void* id, int rank, int world);
+int vpt_comm_gather_shards(vpt_ctx* ctx, int root);
+int vpt_comm_destroy(vpt_ctx* ctx);
+int vpt_multi_gather_shards(vpt_ctx* const* ctxs, uint32_t count, uint32_t root);
+
 /* PostProcessor::SetTonemappingData/SetBloomData + PostProcess (PostProcessor.cpp:193-246) on the
  * accumulation image: threshold -> (mip-1)x down -> (mip-1)x up -> tonemap. rgba8_host receives
  * GetOutputImageView() (RGBA8 UNORM, width*height*4 bytes); bloom0_host (optional) receives bloom

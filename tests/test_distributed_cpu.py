@@ -71,3 +71,50 @@ def test_shard_arithmetic():
     full = torch.arange(5 * 3 * 4, dtype=torch.float32).reshape(5, 3, 4)
     g = torch.stack([sharding.extract_rows(full, r, 2) for r in range(2)])
     assert torch.equal(sharding.assemble_rows(g, 3, 5, 2), full)
+
+
+class _FakeLib:
+    """Stands in for libvpt_hip.so in the control-plane test below (no device here): records what ShardComm hands to
+    vpt_comm_init."""
+    def __init__(self, rank):
+        self.rank, self.got = rank, None
+
+    def vpt_comm_unique_id(self, buf):
+        for i in range(128):
+            buf[i] = (i * 7 + 3) & 0xff
+        return 0
+
+    def vpt_comm_init(self, ctx, raw, rank, world):
+        self.got = (bytes(raw), rank, world)
+        return 0
+
+    def vpt_comm_destroy(self, ctx):
+        return 0
+
+
+class _FakePt:
+    def __init__(self, rank):
+        self.lib, self.ctx = _FakeLib(rank), None
+
+
+def _id_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import importlib
+    sharding = importlib.import_module("vulkan-path-tracer_amd.sharding")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pt = _FakePt(rank)
+    comm = sharding.ShardComm(pt, rank, world)          # rank 0 makes the id, gloo carries it, every rank inits with it
+    raw, r, w = pt.lib.got
+    open(os.path.join(out_dir, "id%d.bin" % rank), "wb").write(raw + bytes([r, w]))
+    comm.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_comm_id_reaches_every_rank_over_the_control_plane(tmp_path):
+    mp.spawn(_id_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    a, b = (open(str(tmp_path / ("id%d.bin" % r)), "rb").read() for r in range(2))
+    assert a[:128] == b[:128] == bytes((i * 7 + 3) & 0xff for i in range(128))
+    assert (a[128], a[129]) == (0, 2) and (b[128], b[129]) == (1, 2)

@@ -1,0 +1,110 @@
+"""The one collective of the path through the C-ABI (include/vpt.h vpt_comm_* / vpt_multi_gather_shards), the bench's N > 1
+path on one device, and the error paths that must leave a context usable.  RCCL refuses two ranks on one device, so on
+a one-GPU box the communicator is exercised with world 1 (ncclCommInitRank + ncclGather do run) and the N-shard logic
+through the single-process peer-copy form; the torchrun launch of bench.py runs the same Python as an 8-GPU node with the
+shards staged through host memory (VPT_BENCH_DEVICE hook)."""
+import ctypes as C
+import importlib
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def render_whole(vpt, sc, w, h, P, frames):
+    g = vpt.PathTracer(w, h); g.set_scene(sc); g.set_params(P); g.render(frames)
+    img = g.radiance(); g.close()
+    return img
+
+
+def test_rccl_communicator_world1(vpt, scenes):
+    sc = scenes("cornell_box")
+    P = vpt.default_params(max_depth=4)
+    ref = render_whole(vpt, sc, 96, 54, P, 3)
+    g = vpt.PathTracer(96, 54); g.set_scene(sc); g.set_params(P)
+    ident = (C.c_ubyte * 128)()
+    assert g.lib.vpt_comm_unique_id(ident) == 0 and any(ident)
+    assert g.lib.vpt_comm_gather_shards(g.ctx, 0) == -1                      # before init
+    assert g.lib.vpt_comm_init(g.ctx, bytes(ident), 1, 2) == -1              # rank / world must match the context's shard
+    assert g.lib.vpt_comm_init(g.ctx, bytes(ident), 0, 1) == 0, g.lib.vpt_last_error(g.ctx)
+    g.render(3)
+    assert g.lib.vpt_comm_gather_shards(g.ctx, 0) == 0, g.lib.vpt_last_error(g.ctx)
+    assert np.array_equal(g.radiance(), ref)
+    assert g.lib.vpt_comm_destroy(g.ctx) == 0
+    g.close()
+
+
+@pytest.mark.parametrize("n,h", [(2, 54), (3, 55), (8, 61)])
+def test_multi_gather_shards_equals_one_context(vpt, scenes, n, h):
+    sc = scenes("cornell_box_glass")
+    P = vpt.default_params(max_depth=5)
+    ref = render_whole(vpt, sc, 80, h, P, 2)
+    parts = []
+    for r in range(n):
+        s = vpt.PathTracer(80, h, shard_rank=r, shard_count=n); s.set_scene(sc); s.set_params(P); s.render(2)
+        parts.append(s)
+    arr = (C.c_void_p * n)(*[p.ctx for p in parts])
+    root = n - 1                                                            # any shard can be the root
+    assert parts[0].lib.vpt_multi_gather_shards(arr, n, root) == 0, parts[root].lib.vpt_last_error(parts[root].ctx)
+    assert np.array_equal(parts[root].radiance(), ref)
+    out8 = parts[root].postprocess()
+    g = vpt.PathTracer(80, h); g.set_scene(sc); g.set_params(P); g.render(2)
+    assert np.array_equal(out8, g.postprocess()); g.close()
+    assert parts[0].lib.vpt_multi_gather_shards(arr, n - 1, 0) == -1         # count must equal shard_count
+    for p in parts:
+        p.close()
+
+
+def test_failed_resize_and_bad_material_leave_the_context_usable(vpt, scenes):
+    abi = importlib.import_module("vulkan-path-tracer_amd._abi")
+    sc = scenes("cornell_box")
+    P = vpt.default_params(max_depth=3)
+    ref = render_whole(vpt, sc, 64, 36, P, 2)
+    g = vpt.PathTracer(64, 36); g.set_scene(sc); g.set_params(P)
+    assert g.lib.vpt_resize(g.ctx, 70000, 70000) == -1                       # rejected before anything is freed
+    g.render(2)
+    assert np.array_equal(g.radiance(), ref)
+    m = g.get_material(0)
+    bad = abi.Material.from_buffer_copy(bytes(m)); bad.base_color_texture = 9999
+    assert g.lib.vpt_set_material(g.ctx, 0, C.byref(bad)) == -1              # texture index out of range: nothing changes
+    assert bytes(g.get_material(0)) == bytes(m)
+    g.reset(); g.render(2)
+    assert np.array_equal(g.radiance(), ref)
+    g.close()
+
+
+def test_rejected_scene_keeps_the_current_one(vpt, scenes):
+    sc = scenes("cornell_box")
+    P = vpt.default_params(max_depth=3)
+    ref = render_whole(vpt, sc, 64, 36, P, 2)
+    g = vpt.PathTracer(64, 36); g.set_scene(sc); g.set_params(P)
+    desc, keep = sc.to_desc()
+    desc.materials[0].base_color_texture = 12345                            # invalid description
+    assert g.lib.vpt_set_scene(g.ctx, C.byref(desc)) == -1
+    del keep
+    g.render(2)                                                             # the old scene is still there
+    assert np.array_equal(g.radiance(), ref)
+    g.close()
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def test_bench_two_ranks_on_one_device():
+    env = dict(os.environ, VPT_BENCH_DEVICE="0", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--frames-in-flight", "2"]
+    p = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["scaling"] == "weak" and line["config"]["workload"] == "cornell_1080p_d8"
+    assert line["roofline"]["frac"] <= 1.0 and line["roofline"]["bound"] in ("valu", "hbm")

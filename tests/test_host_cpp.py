@@ -71,11 +71,29 @@ def test_cpp_camera_and_matrix_restatements(cli):
     assert r["view_err"] < 1e-4 and r["proj_err"] < 1e-5 and r["inverse_err"] < 1e-5
     assert abs(r["fov"] - 45.0) < 1e-3 and abs(r["aspect"] - 16 / 9) < 1e-4
     assert r["up_dy"] != 0.0
+    assert r["move_keeps_state"] is True      # volumes, phase function, atmosphere, shard identity all travel with a move
 
 
 def test_cli_reports_errors_without_crashing(cli, tmp_path):
     p = subprocess.run([cli, "--scene", str(tmp_path / "missing.gltf"), "--info"], capture_output=True)
     assert p.returncode == 1 and b"cannot open" in p.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gpus", [2, 3])
+def test_multi_gpu_cli_is_bit_identical_to_one_device(cli, tmp_path, gpus):
+    """vpt_render --gpus N: N shard contexts (one host thread each), vpt_multi_gather_shards into shard 0, post there.
+    On a one-GPU box every shard is pinned to device 0 (--devices): the gather is then a same-device peer copy, the rest
+    of the path (partition, threads, gather into root, re-interleave, post on root) is the one an 8-GPU node runs."""
+    gltf = os.path.join(GOLDEN, "textured_boxes.gltf")
+    outs = []
+    for n in (1, gpus):
+        rad, ppm = str(tmp_path / ("r%d.f32" % n)), str(tmp_path / ("o%d.ppm" % n))
+        out = json.loads(subprocess.check_output([cli, "--scene", gltf, "--luts", LUTS, "--size", "161x91", "--spp", "6", "--depth", "5", "--radiance", rad, "--ppm", ppm,
+                                                  "--gpus", str(n), "--devices", ",".join(["0"] * n)]))
+        assert out["gpus"] == n and out["samples"] == 6
+        outs.append((np.fromfile(rad, "<f4"), open(ppm, "rb").read()))
+    assert np.array_equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1]
 
 
 @pytest.mark.gpu

@@ -214,12 +214,20 @@ PROTOTYPES = {
     "vpt_shard_floats": (C.c_size_t, [C.c_void_p]),
     "vpt_get_shard_device": (C.c_int, [C.c_void_p, C.c_void_p]),
     "vpt_assemble_shards": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32]),
+    "vpt_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "vpt_comm_init": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    "vpt_comm_gather_shards": (C.c_int, [C.c_void_p, C.c_int]),
+    "vpt_comm_destroy": (C.c_int, [C.c_void_p]),
+    "vpt_multi_gather_shards": (C.c_int, [C.POINTER(C.c_void_p), C.c_uint32, C.c_uint32]),
     "vpt_postprocess": (C.c_int, [C.c_void_p, C.POINTER(PostParams), C.c_void_p, C.c_void_p]),
     "vpt_get_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
     "vpt_reset_stats": (C.c_int, [C.c_void_p]),
     "vpt_trace_rays": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     "vpt_lut_calculate": (C.c_int, [C.c_int] + [C.c_uint32] * 6 + [C.c_void_p]),
 }
+
+
+COMM_ID_BYTES = 128
 
 
 def bind(lib):

@@ -37,20 +37,23 @@ def build(force=False, verbose=False):
     objs = []
     procs = []
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    newest_header = max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS)
     for src in SOURCES:
         obj = os.path.join(HERE, "build", src + ".o")
+        objs.append(obj)
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(newest_header, os.path.getmtime(os.path.join(CSRC, src))):
+            continue   # this object is newer than its source and every header
         cmd = [hipcc()] + FLAGS + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
-        objs.append(obj)
     for src, p in procs:
         out = p.communicate()[0].decode()
         if p.returncode != 0:
             raise RuntimeError("hipcc failed on %s:\n%s" % (src, out))
         if verbose and out.strip():
             print(out)
-    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
     subprocess.check_call(cmd)
     return LIB
 

@@ -10,6 +10,8 @@
 #include <string>
 #include <vector>
 
+#include <rccl/rccl.h>
+
 #include "bvh_build.hpp"
 #include "kernels.hpp"
 
@@ -23,6 +25,11 @@ struct vpt_ctx {
 
     // host copies (SetMaterial / emissive list maintenance / stats)
     bool has_scene = false;
+    bool buffers_ok = false;     // render buffers allocated for the current size (false after a failed vpt_resize)
+    uint32_t texture_count = 0;  // of the current scene: vpt_set_material validates texture indices against it
+    ncclComm_t comm = nullptr;   // vpt_comm_init: one rank per process
+    int comm_rank = -1, comm_world = 0;
+    float* gather_buf = nullptr; // root: shard_count padded shards back to back
     std::vector<vpt_material> materials;
     std::vector<MeshDesc> meshes;
     std::vector<InstanceDesc> instances;
@@ -128,6 +135,8 @@ void free_render_buffers(vpt_ctx* c) {
     c->image = nullptr;
     if (c->full_image) (void)hipFree(c->full_image);
     c->full_image = nullptr;
+    if (c->gather_buf) (void)hipFree(c->gather_buf);
+    c->gather_buf = nullptr;
     for (float* m : c->mips) (void)hipFree(m);
     c->mips.clear(); c->mip_sizes.clear();
     if (c->post_out) (void)hipFree(c->post_out);
@@ -136,21 +145,43 @@ void free_render_buffers(vpt_ctx* c) {
 
 uint32_t shard_rows_of(uint32_t height, uint32_t rank, uint32_t count) { return rank < height ? (height - rank + count - 1) / count : 0; }
 
+// Size checks of a (width, height) before anything is freed or changed.
+int check_render_size(vpt_ctx* c, uint32_t width, uint32_t height, uint32_t* frames_out) {
+    const uint64_t rows = shard_rows_of(height, c->cfg.shard_rank, c->cfg.shard_count);
+    const uint64_t px = rows * width;
+    if (px == 0) return fail(c, VPT_ERR_INVALID_ARGUMENT, "empty shard");
+    if (px >= (1ull << 31) || (uint64_t)width * height >= (1ull << 31)) return fail(c, VPT_ERR_INVALID_ARGUMENT, "image too large");
+    uint64_t F = c->cfg.frames_in_flight;
+    if (F == 0) F = (32ull << 20) / px;  // ~32M resident paths (8.4 GB of records) whatever the shard size
+    F = std::max<uint64_t>(1, std::min<uint64_t>(F, 256));
+    if (px * F >= (1ull << 31)) return fail(c, VPT_ERR_INVALID_ARGUMENT, "too many paths in flight");
+    *frames_out = (uint32_t)F;
+    return VPT_OK;
+}
+
+int alloc_render_buffers_impl(vpt_ctx* c);
+// (Re)allocates everything that depends on the image size.  On failure the context keeps NO render buffers and says so
+// (buffers_ok == false): vpt_render / vpt_get_* / vpt_postprocess then return an error instead of touching freed memory.
 int alloc_render_buffers(vpt_ctx* c) {
+    c->buffers_ok = false;
+    int rc = alloc_render_buffers_impl(c);
+    if (rc != VPT_OK) { std::string keep = c->err; free_render_buffers(c); c->err = keep; return rc; }
+    c->buffers_ok = true;
+    return VPT_OK;
+}
+
+int alloc_render_buffers_impl(vpt_ctx* c) {
+    uint32_t F = 1;
+    int rcs = check_render_size(c, c->cfg.width, c->cfg.height, &F);
+    if (rcs != VPT_OK) return rcs;
     free_render_buffers(c);
     RenderParams& P = c->P;
     P.width = c->cfg.width; P.height = c->cfg.height;
     P.shard_rank = c->cfg.shard_rank; P.shard_count = c->cfg.shard_count;
     P.shard_rows = shard_rows_of(P.height, P.shard_rank, P.shard_count);
     P.shard_pixels = P.shard_rows * P.width;
-    if (P.shard_pixels == 0) return fail(c, VPT_ERR_INVALID_ARGUMENT, "empty shard");
-    uint32_t F = c->cfg.frames_in_flight;
-    if (F == 0) F = (32u << 20) / P.shard_pixels;  // ~32M resident paths (8.4 GB of records) whatever the shard size
-    F = std::max(1u, std::min(F, 256u));
     c->frames_in_flight = F;
-    uint64_t cap64 = (uint64_t)P.shard_pixels * F;
-    if (cap64 >= (1ull << 31)) return fail(c, VPT_ERR_INVALID_ARGUMENT, "too many paths in flight");
-    uint32_t cap = (uint32_t)cap64;
+    uint32_t cap = P.shard_pixels * F;
     // 15 float4 records + 4 dword arrays per slot (device_types.hpp PathState)
     const size_t kRecords = 15, kWords = 5;
     size_t stride = ((size_t)cap + 63) & ~(size_t)63;
@@ -168,8 +199,10 @@ int alloc_render_buffers(vpt_ctx* c) {
     s.hinst = wb; s.maniso = (float*)(wb + stride); s.sidx = wb + stride * 2; s.vdepth = wb + stride * 3; s.cchan = (int32_t*)(wb + stride * 4);
     for (int i = 0; i < 2; i++) HIPCHK(c, hipMalloc((void**)&c->queue[i], (size_t)cap * 4));
     HIPCHK(c, hipMalloc((void**)&c->cqueue, (size_t)cap * 4));
-    HIPCHK(c, hipMalloc((void**)&c->image, (size_t)P.shard_pixels * 16));
-    HIPCHK(c, hipMemset(c->image, 0, (size_t)P.shard_pixels * 16));
+    // padded to the largest shard's row count (vpt_shard_floats): the buffer is handed to ncclGather as it is
+    const size_t image_bytes = (size_t)shard_rows_of(P.height, 0, P.shard_count) * P.width * 16;
+    HIPCHK(c, hipMalloc((void**)&c->image, image_bytes));
+    HIPCHK(c, hipMemset(c->image, 0, image_bytes));
     if (P.shard_count > 1) {
         HIPCHK(c, hipMalloc((void**)&c->full_image, (size_t)P.width * P.height * 16));
         HIPCHK(c, hipMemset(c->full_image, 0, (size_t)P.width * P.height * 16));
@@ -432,6 +465,7 @@ void vpt_destroy(vpt_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->comm) { (void)ncclCommDestroy(c->comm); c->comm = nullptr; }
     free_scene(c);
     free_render_buffers(c);
     if (c->ctr) (void)hipFree(c->ctr);
@@ -455,6 +489,33 @@ int vpt_set_scene(vpt_ctx* c, const vpt_scene_desc* sd) {
         sd->env_width == 0 || sd->env_height == 0 || !sd->lut_reflection || !sd->lut_refraction_outside || !sd->lut_refraction_inside)
         return fail(c, VPT_ERR_INVALID_ARGUMENT, "incomplete scene description");
     HIPCHK(c, hipSetDevice(c->cfg.device));
+    // ---- validate the whole description first: a rejected scene leaves the current one untouched
+    {
+        uint64_t nv = 0, ni = 0, texel_bytes = 0;
+        for (uint32_t m = 0; m < sd->mesh_count; m++) {
+            const vpt_mesh& me = sd->meshes[m];
+            if (!me.vertices || !me.indices || me.index_count % 3 != 0) return fail(c, VPT_ERR_INVALID_ARGUMENT, "bad mesh");
+            for (uint32_t k = 0; k < me.index_count; k++) if (me.indices[k] >= me.vertex_count) return fail(c, VPT_ERR_INVALID_ARGUMENT, "mesh index out of range");
+            nv += me.vertex_count; ni += me.index_count;
+        }
+        if (nv > 0xffffffffull || ni > 0xffffffffull) return fail(c, VPT_ERR_LIMIT, "more than 2^32 pooled vertices / indices");
+        for (uint32_t i = 0; i < sd->material_count; i++) {
+            const vpt_material& m = sd->materials[i];
+            if (m.base_color_texture >= sd->texture_count || m.normal_texture >= sd->texture_count || m.roughness_texture >= sd->texture_count ||
+                m.metallic_texture >= sd->texture_count || m.emissive_texture >= sd->texture_count)
+                return fail(c, VPT_ERR_INVALID_ARGUMENT, "material texture index out of range");
+        }
+        for (uint32_t i = 0; i < sd->instance_count; i++) {
+            if (sd->instances[i].mesh_index >= sd->mesh_count) return fail(c, VPT_ERR_INVALID_ARGUMENT, "instance mesh index out of range");
+            if (sd->instances[i].material_index >= sd->material_count) return fail(c, VPT_ERR_INVALID_ARGUMENT, "Mesh instance has invalid material index");  // PathTracer.cpp:454
+        }
+        for (uint32_t t = 0; t < sd->texture_count; t++) {
+            const vpt_texture& tx = sd->textures[t];
+            if (!tx.data || tx.width == 0 || tx.height == 0 || (tx.channels != 1 && tx.channels != 4)) return fail(c, VPT_ERR_INVALID_ARGUMENT, "bad texture");
+            texel_bytes += (uint64_t)tx.width * tx.height * tx.channels + 3;
+        }
+        if (texel_bytes > 0xffffffffull) return fail(c, VPT_ERR_LIMIT, "texel pool over 4 GiB (TexDesc offsets are 32-bit)");
+    }
     free_scene(c);
     reset_accum(c);
     // ---- geometry pools
@@ -462,8 +523,6 @@ int vpt_set_scene(vpt_ctx* c, const vpt_scene_desc* sd) {
     c->meshes.clear(); c->total_vertices = 0; c->total_indices = 0;
     for (uint32_t m = 0; m < sd->mesh_count; m++) {
         const vpt_mesh& me = sd->meshes[m];
-        if (!me.vertices || !me.indices || me.index_count % 3 != 0) return fail(c, VPT_ERR_INVALID_ARGUMENT, "bad mesh");
-        for (uint32_t k = 0; k < me.index_count; k++) if (me.indices[k] >= me.vertex_count) return fail(c, VPT_ERR_INVALID_ARGUMENT, "mesh index out of range");
         MeshDesc d; d.vertex_offset = (uint32_t)verts.size(); d.index_offset = (uint32_t)idx.size(); d.tri_count = me.index_count / 3; d.pad = 0;
         verts.insert(verts.end(), me.vertices, me.vertices + me.vertex_count);
         idx.insert(idx.end(), me.indices, me.indices + me.index_count);
@@ -471,18 +530,13 @@ int vpt_set_scene(vpt_ctx* c, const vpt_scene_desc* sd) {
         c->total_vertices += me.vertex_count; c->total_indices += me.index_count;
     }
     c->materials.assign(sd->materials, sd->materials + sd->material_count);
-    for (const vpt_material& m : c->materials)
-        if (m.base_color_texture >= sd->texture_count || m.normal_texture >= sd->texture_count || m.roughness_texture >= sd->texture_count ||
-            m.metallic_texture >= sd->texture_count || m.emissive_texture >= sd->texture_count)
-            return fail(c, VPT_ERR_INVALID_ARGUMENT, "material texture index out of range");
+    c->texture_count = sd->texture_count;
     // ---- instances, flattened world-space triangles (instance-major global ids)
     c->instances.clear();
     std::vector<BvhTri> tris;
     uint32_t total_tris = 0;
     for (uint32_t i = 0; i < sd->instance_count; i++) {
         const vpt_instance& in = sd->instances[i];
-        if (in.mesh_index >= sd->mesh_count) return fail(c, VPT_ERR_INVALID_ARGUMENT, "instance mesh index out of range");
-        if (in.material_index >= sd->material_count) return fail(c, VPT_ERR_INVALID_ARGUMENT, "Mesh instance has invalid material index");  // PathTracer.cpp:454
         InstanceDesc d; memset(&d, 0, sizeof(d));
         d.mesh = in.mesh_index; d.material = in.material_index; d.tri_offset = total_tris;
         memcpy(d.xform, in.transform, 64);
@@ -512,7 +566,6 @@ int vpt_set_scene(vpt_ctx* c, const vpt_scene_desc* sd) {
     std::vector<TexDesc> tds; std::vector<uint8_t> texels;
     for (uint32_t t = 0; t < sd->texture_count; t++) {
         const vpt_texture& tx = sd->textures[t];
-        if (!tx.data || tx.width == 0 || tx.height == 0 || (tx.channels != 1 && tx.channels != 4)) return fail(c, VPT_ERR_INVALID_ARGUMENT, "bad texture");
         while (texels.size() % 4) texels.push_back(0);
         TexDesc d; d.offset = (uint32_t)texels.size(); d.w = tx.width; d.h = tx.height; d.c = tx.channels;
         texels.insert(texels.end(), tx.data, tx.data + (size_t)tx.width * tx.height * tx.channels);
@@ -597,6 +650,9 @@ int vpt_set_material(vpt_ctx* c, uint32_t index, const vpt_material* m) {
     if (!c || !m) return VPT_ERR_INVALID_ARGUMENT;
     if (!c->has_scene) return fail(c, VPT_ERR_NO_SCENE, "no scene");
     if (index >= c->materials.size()) return fail(c, VPT_ERR_INVALID_ARGUMENT, "material index out of range");
+    if (m->base_color_texture >= c->texture_count || m->normal_texture >= c->texture_count || m->roughness_texture >= c->texture_count ||
+        m->metallic_texture >= c->texture_count || m->emissive_texture >= c->texture_count)
+        return fail(c, VPT_ERR_INVALID_ARGUMENT, "material texture index out of range");   // the shade stage indexes textures[] unchecked
     HIPCHK(c, hipSetDevice(c->cfg.device));
     const vpt_material& old = c->materials[index];
     bool emissive_changed = old.emissive_color[0] != m->emissive_color[0] || old.emissive_color[1] != m->emissive_color[1] || old.emissive_color[2] != m->emissive_color[2];
@@ -741,6 +797,9 @@ int vpt_set_phase_function(vpt_ctx* c, uint32_t phase) {
 int vpt_resize(vpt_ctx* c, uint32_t w, uint32_t h) {
     if (!c || w == 0 || h == 0) return VPT_ERR_INVALID_ARGUMENT;
     HIPCHK(c, hipSetDevice(c->cfg.device));
+    uint32_t F = 1;
+    int rc = check_render_size(c, w, h, &F);   // nothing is freed or changed for a size this context cannot hold
+    if (rc != VPT_OK) return rc;
     c->cfg.width = w; c->cfg.height = h;
     reset_accum(c);
     return alloc_render_buffers(c);
@@ -751,6 +810,7 @@ int vpt_reset(vpt_ctx* c) { if (!c) return VPT_ERR_INVALID_ARGUMENT; reset_accum
 int vpt_render(vpt_ctx* c, uint32_t dispatches, int* done) {
     if (!c) return VPT_ERR_INVALID_ARGUMENT;
     if (!c->has_scene) return fail(c, VPT_ERR_NO_SCENE, "vpt_render before vpt_set_scene");
+    if (!c->buffers_ok) return fail(c, VPT_ERR_DEVICE, "no render buffers: the last vpt_resize failed");
     HIPCHK(c, hipSetDevice(c->cfg.device));
     if (done) *done = 0;
     uint32_t left = dispatches;
@@ -784,6 +844,7 @@ int vpt_render(vpt_ctx* c, uint32_t dispatches, int* done) {
 
 int vpt_get_radiance_device(vpt_ctx* c, void* dst) {
     if (!c || !dst) return VPT_ERR_INVALID_ARGUMENT;
+    if (!c->buffers_ok) return fail(c, VPT_ERR_DEVICE, "no render buffers: the last vpt_resize failed");
     if (c->P.shard_count > 1 && !c->full_valid) return fail(c, VPT_ERR_INVALID_ARGUMENT, "sharded context: call vpt_assemble_shards first");
     HIPCHK(c, hipSetDevice(c->cfg.device));
     HIPCHK(c, hipMemcpyAsync(dst, whole_image(c), (size_t)c->P.width * c->P.height * 16, hipMemcpyDeviceToDevice, c->stream));
@@ -792,6 +853,7 @@ int vpt_get_radiance_device(vpt_ctx* c, void* dst) {
 }
 int vpt_get_radiance(vpt_ctx* c, float* dst) {
     if (!c || !dst) return VPT_ERR_INVALID_ARGUMENT;
+    if (!c->buffers_ok) return fail(c, VPT_ERR_DEVICE, "no render buffers: the last vpt_resize failed");
     if (c->P.shard_count > 1 && !c->full_valid) return fail(c, VPT_ERR_INVALID_ARGUMENT, "sharded context: call vpt_assemble_shards first");
     HIPCHK(c, hipSetDevice(c->cfg.device));
     HIPCHK(c, hipMemcpy(dst, whole_image(c), (size_t)c->P.width * c->P.height * 16, hipMemcpyDeviceToHost));
@@ -799,6 +861,7 @@ int vpt_get_radiance(vpt_ctx* c, float* dst) {
 }
 int vpt_set_radiance(vpt_ctx* c, const float* src, uint32_t frame_count) {
     if (!c || !src) return VPT_ERR_INVALID_ARGUMENT;
+    if (!c->buffers_ok) return fail(c, VPT_ERR_DEVICE, "no render buffers: the last vpt_resize failed");
     HIPCHK(c, hipSetDevice(c->cfg.device));
     const uint32_t W = c->P.width;
     if (c->P.shard_count == 1) {
@@ -822,6 +885,7 @@ size_t vpt_shard_floats(const vpt_ctx* c) {
 }
 int vpt_get_shard_device(vpt_ctx* c, void* dst) {
     if (!c || !dst) return VPT_ERR_INVALID_ARGUMENT;
+    if (!c->buffers_ok) return fail(c, VPT_ERR_DEVICE, "no render buffers: the last vpt_resize failed");
     HIPCHK(c, hipSetDevice(c->cfg.device));
     size_t bytes = (size_t)c->P.shard_pixels * 16, padded = vpt_shard_floats(c) * 4;
     HIPCHK(c, hipMemcpyAsync(dst, c->image, bytes, hipMemcpyDeviceToDevice, c->stream));
@@ -832,6 +896,7 @@ int vpt_get_shard_device(vpt_ctx* c, void* dst) {
 int vpt_assemble_shards(vpt_ctx* c, const void* gathered, uint32_t shard_count) {
     if (!c || !gathered) return VPT_ERR_INVALID_ARGUMENT;
     if (shard_count != c->P.shard_count) return fail(c, VPT_ERR_INVALID_ARGUMENT, "shard_count mismatch");
+    if (!c->buffers_ok) return fail(c, VPT_ERR_DEVICE, "no render buffers: the last vpt_resize failed");
     HIPCHK(c, hipSetDevice(c->cfg.device));
     float* dst = c->P.shard_count > 1 ? c->full_image : c->image;
     launch_scatter_rows(c->stream, (const float*)gathered, dst, c->P.width, c->P.height, shard_count, (uint32_t)(vpt_shard_floats(c) / 4));
@@ -844,6 +909,7 @@ int vpt_assemble_shards(vpt_ctx* c, const void* gathered, uint32_t shard_count) 
 // PostProcessor::PostProcess, PostProcessor.cpp:193-246.
 int vpt_postprocess(vpt_ctx* c, const vpt_post_params* pp, uint8_t* out8, float* bloom0) {
     if (!c || !pp || !out8) return VPT_ERR_INVALID_ARGUMENT;
+    if (!c->buffers_ok) return fail(c, VPT_ERR_DEVICE, "no render buffers: the last vpt_resize failed");
     if (c->P.shard_count > 1 && !c->full_valid) return fail(c, VPT_ERR_INVALID_ARGUMENT, "sharded context: call vpt_assemble_shards first");
     HIPCHK(c, hipSetDevice(c->cfg.device));
     int rc = ensure_post_buffers(c);
@@ -907,6 +973,105 @@ int vpt_trace_rays(vpt_ctx* c, const vpt_ray* rays, uint32_t n, vpt_hit* hits) {
     (void)hipFree(dr); (void)hipFree(dh);
     if (rc) c->err = "vpt_trace_rays: device error";
     return rc;
+}
+
+
+// ---- the one collective of the path (include/vpt.h) ----
+namespace {
+int ensure_gather_buf(vpt_ctx* c) {
+    if (c->gather_buf) return VPT_OK;
+    HIPCHK(c, hipMalloc((void**)&c->gather_buf, vpt_shard_floats(c) * 4 * (size_t)c->P.shard_count));
+    return VPT_OK;
+}
+int nccl_fail(vpt_ctx* c, const char* what, ncclResult_t r) {
+    c->err = std::string(what) + " failed: " + ncclGetErrorString(r);
+    return VPT_ERR_DEVICE;
+}
+// root: gather_buf -> full image (rows re-interleaved); shard_count == 1: the image already is the whole image
+int assemble_from_gather_buf(vpt_ctx* c) {
+    if (c->P.shard_count == 1) return VPT_OK;
+    launch_scatter_rows(c->stream, c->gather_buf, c->full_image, c->P.width, c->P.height, c->P.shard_count, (uint32_t)(vpt_shard_floats(c) / 4));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipGetLastError());
+    c->full_valid = true;
+    return VPT_OK;
+}
+}  // namespace
+
+int vpt_comm_unique_id(void* id_out) {
+    if (!id_out) return VPT_ERR_INVALID_ARGUMENT;
+    static_assert(sizeof(ncclUniqueId) == VPT_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
+    ncclUniqueId id;
+    if (ncclGetUniqueId(&id) != ncclSuccess) return VPT_ERR_DEVICE;
+    memcpy(id_out, &id, sizeof(id));
+    return VPT_OK;
+}
+int vpt_comm_init(vpt_ctx* c, const void* id, int rank, int world) {
+    if (!c || !id) return VPT_ERR_INVALID_ARGUMENT;
+    if (world < 1 || rank < 0 || rank >= world || (uint32_t)rank != c->P.shard_rank || (uint32_t)world != c->P.shard_count)
+        return fail(c, VPT_ERR_INVALID_ARGUMENT, "vpt_comm_init: rank / world must equal the context's shard_rank / shard_count");
+    if (c->comm) return fail(c, VPT_ERR_INVALID_ARGUMENT, "vpt_comm_init: the context already has a communicator");
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    ncclUniqueId uid; memcpy(&uid, id, sizeof(uid));
+    ncclResult_t r = ncclCommInitRank(&c->comm, world, uid, rank);
+    if (r != ncclSuccess) { c->comm = nullptr; return nccl_fail(c, "ncclCommInitRank", r); }
+    c->comm_rank = rank; c->comm_world = world;
+    return VPT_OK;
+}
+int vpt_comm_gather_shards(vpt_ctx* c, int root) {
+    if (!c) return VPT_ERR_INVALID_ARGUMENT;
+    if (!c->comm) return fail(c, VPT_ERR_INVALID_ARGUMENT, "vpt_comm_gather_shards before vpt_comm_init");
+    if (root < 0 || root >= c->comm_world) return fail(c, VPT_ERR_INVALID_ARGUMENT, "root out of range");
+    if (!c->buffers_ok) return fail(c, VPT_ERR_DEVICE, "no render buffers: the last vpt_resize failed");
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    const bool is_root = c->comm_rank == root;
+    if (is_root) { int rc = ensure_gather_buf(c); if (rc) return rc; }
+    // every rank contributes its rows padded to the largest shard (the image buffer is allocated at that size);
+    // the launch is ordered behind the renders already on the context's stream
+    ncclResult_t r = ncclGather(c->image, is_root ? c->gather_buf : nullptr, vpt_shard_floats(c), ncclFloat32, root, c->comm, c->stream);
+    if (r != ncclSuccess) return nccl_fail(c, "ncclGather", r);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return is_root ? assemble_from_gather_buf(c) : VPT_OK;
+}
+int vpt_comm_destroy(vpt_ctx* c) {
+    if (!c) return VPT_ERR_INVALID_ARGUMENT;
+    if (c->comm) {
+        (void)hipSetDevice(c->cfg.device);
+        ncclResult_t r = ncclCommDestroy(c->comm);
+        c->comm = nullptr; c->comm_rank = -1; c->comm_world = 0;
+        if (r != ncclSuccess) return nccl_fail(c, "ncclCommDestroy", r);
+    }
+    return VPT_OK;
+}
+int vpt_multi_gather_shards(vpt_ctx* const* ctxs, uint32_t count, uint32_t root) {
+    if (!ctxs || count == 0 || root >= count || !ctxs[root]) return VPT_ERR_INVALID_ARGUMENT;
+    vpt_ctx* R = ctxs[root];
+    if (R->P.shard_count != count) return fail(R, VPT_ERR_INVALID_ARGUMENT, "vpt_multi_gather_shards: count must equal shard_count");
+    for (uint32_t k = 0; k < count; k++) {
+        vpt_ctx* c = ctxs[k];
+        if (!c || c->P.shard_rank != k || c->P.shard_count != count || c->P.width != R->P.width || c->P.height != R->P.height || !c->buffers_ok)
+            return fail(R, VPT_ERR_INVALID_ARGUMENT, "vpt_multi_gather_shards: context k must be shard k of the same image");
+    }
+    HIPCHK(R, hipSetDevice(R->cfg.device));
+    int rc = ensure_gather_buf(R);
+    if (rc) return rc;
+    const size_t stride = vpt_shard_floats(R) * 4;
+    for (uint32_t k = 0; k < count; k++) {   // direct peer copies: xGMI is point to point, every shard takes its own link into root
+        vpt_ctx* c = ctxs[k];
+        HIPCHK(R, hipSetDevice(c->cfg.device));
+        if (c->cfg.device != R->cfg.device) {
+            hipError_t e = hipDeviceEnablePeerAccess(R->cfg.device, 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { (void)hipGetLastError(); }  // the copy below then stages through the host
+            else (void)hipGetLastError();
+        }
+        HIPCHK(R, hipMemcpyPeerAsync((char*)R->gather_buf + (size_t)k * stride, R->cfg.device, c->image, c->cfg.device, stride, c->stream));
+    }
+    for (uint32_t k = 0; k < count; k++) {
+        HIPCHK(R, hipSetDevice(ctxs[k]->cfg.device));
+        HIPCHK(R, hipStreamSynchronize(ctxs[k]->stream));
+    }
+    HIPCHK(R, hipSetDevice(R->cfg.device));
+    return assemble_from_gather_buf(R);
 }
 
 int vpt_lut_calculate(int device, uint32_t kind, uint32_t sx, uint32_t sy, uint32_t sz, uint32_t sample_count, uint32_t time_ms, float* out) {

@@ -18,18 +18,40 @@ PathTracer PathTracer::New(int device) {
     pt.m_Env.assign(4, 0.0f);  // black 1x1 environment until SetEnvironmentMap (the reference's default .hdr is not redistributable)
     return pt;
 }
-PathTracer::PathTracer(PathTracer&& o) noexcept { *this = std::move(o); }
+PathTracer PathTracer::New(int device, uint32_t shardRank, uint32_t shardCount) {
+    if (shardCount == 0 || shardRank >= shardCount) throw std::runtime_error("PathTracer::New: shardRank must be < shardCount");
+    PathTracer pt = New(device);
+    pt.m_ShardRank = shardRank; pt.m_ShardCount = shardCount;
+    return pt;
+}
+void PathTracer::GatherShards(const std::vector<PathTracer*>& shards, uint32_t root) {
+    if (shards.empty() || root >= shards.size()) throw std::runtime_error("GatherShards: bad arguments");
+    std::vector<vpt_ctx*> ctxs;
+    for (PathTracer* p : shards) { if (!p || !p->m_Ctx) throw std::runtime_error("GatherShards before SetScene"); ctxs.push_back(p->m_Ctx); }
+    shards[root]->Check(vpt_multi_gather_shards(ctxs.data(), (uint32_t)ctxs.size(), root), "vpt_multi_gather_shards");
+}
+// Member-wise swap of EVERY member (a hand-written member list once forgot the volume / atmosphere state): the moved-from
+// object ends up with the target's old state and releases it in its own destructor.
+void PathTracer::Swap(PathTracer& o) noexcept {
+    using std::swap;
+    swap(m_Device, o.m_Device); swap(m_ShardRank, o.m_ShardRank); swap(m_ShardCount, o.m_ShardCount); swap(m_Ctx, o.m_Ctx);
+    swap(m_Params, o.m_Params); swap(m_Width, o.m_Width); swap(m_Height, o.m_Height);
+    swap(m_SamplesAccumulated, o.m_SamplesAccumulated); swap(m_DispatchCount, o.m_DispatchCount);
+    swap(m_TotalVertexCount, o.m_TotalVertexCount); swap(m_TotalIndexCount, o.m_TotalIndexCount);
+    swap(m_CameraViewInverse, o.m_CameraViewInverse); swap(m_CameraProjectionInverse, o.m_CameraProjectionInverse);
+    swap(m_Materials, o.m_Materials); swap(m_MaterialNames, o.m_MaterialNames); swap(m_Scene, o.m_Scene);
+    swap(m_Env, o.m_Env); swap(m_EnvW, o.m_EnvW); swap(m_EnvH, o.m_EnvH);
+    swap(m_LutR, o.m_LutR); swap(m_LutO, o.m_LutO); swap(m_LutI, o.m_LutI);
+    swap(m_LookupTablePath, o.m_LookupTablePath); swap(m_EnvMapFilepath, o.m_EnvMapFilepath); swap(m_Output, o.m_Output);
+    swap(m_Volumes, o.m_Volumes); swap(m_EnableAtmosphere, o.m_EnableAtmosphere); swap(m_Atmosphere, o.m_Atmosphere);
+    swap(m_PhaseFunction, o.m_PhaseFunction);
+}
+PathTracer::PathTracer(PathTracer&& o) noexcept { Swap(o); }
 PathTracer& PathTracer::operator=(PathTracer&& o) noexcept {
     if (this != &o) {
-        if (m_Ctx) vpt_destroy(m_Ctx);
-        m_Device = o.m_Device; m_Ctx = o.m_Ctx; o.m_Ctx = nullptr; m_Params = o.m_Params; m_Width = o.m_Width; m_Height = o.m_Height;
-        m_SamplesAccumulated = o.m_SamplesAccumulated; m_DispatchCount = o.m_DispatchCount;
-        m_TotalVertexCount = o.m_TotalVertexCount; m_TotalIndexCount = o.m_TotalIndexCount;
-        m_CameraViewInverse = o.m_CameraViewInverse; m_CameraProjectionInverse = o.m_CameraProjectionInverse;
-        m_Materials = std::move(o.m_Materials); m_MaterialNames = std::move(o.m_MaterialNames); m_Scene = std::move(o.m_Scene);
-        m_Env = std::move(o.m_Env); m_EnvW = o.m_EnvW; m_EnvH = o.m_EnvH;
-        m_LutR = std::move(o.m_LutR); m_LutO = std::move(o.m_LutO); m_LutI = std::move(o.m_LutI);
-        m_LookupTablePath = std::move(o.m_LookupTablePath); m_Output = std::move(o.m_Output);
+        PathTracer released;   // takes this object's old state (context included) and frees it on scope exit
+        Swap(released);
+        Swap(o);
     }
     return *this;
 }
@@ -67,7 +89,7 @@ void PathTracer::SetScene(const SceneAsset& sceneIn) {
     const uint32_t w = (uint32_t)(1080.0f * aspectRatio), h = 1080;  // PathTracer.cpp:509-511
     if (m_Width == 0) { m_Width = w; m_Height = h; }  // unless ResizeImage already chose a size
     if (!m_Ctx) {
-        vpt_config cfg{}; cfg.device = m_Device; cfg.width = m_Width; cfg.height = m_Height; cfg.shard_rank = 0; cfg.shard_count = 1;
+        vpt_config cfg{}; cfg.device = m_Device; cfg.width = m_Width; cfg.height = m_Height; cfg.shard_rank = m_ShardRank; cfg.shard_count = m_ShardCount;
         int err = 0;
         m_Ctx = vpt_create(&cfg, &err);
         if (!m_Ctx) throw std::runtime_error("vpt_create failed (" + std::to_string(err) + "): no usable HIP device; this backend has no CPU fallback");

@@ -36,6 +36,14 @@ public:
     enum class PhaseFunction { HENYEY_GREENSTEIN = 0, DRAINE = 1, HENYEY_GREENSTEIN_PLUS_DRAINE = 2 };  // PathTracer.h:76-81
 
     [[nodiscard]] static PathTracer New(int device = 0);
+    // Multi-GPU: shard `shardRank` of `shardCount` renders rows y % shardCount == shardRank on `device` (the
+    // reference's interleaved split-screen partition, RayGen.slang:16-25, along one axis).  GatherShards() is the one
+    // collective of the path: every shard's rows go to shards[root] over xGMI (vpt_multi_gather_shards), after which
+    // shards[root].GetOutputImage() / PostProcessor see the whole image — bit-identical to a single-device render.
+    [[nodiscard]] static PathTracer New(int device, uint32_t shardRank, uint32_t shardCount);
+    static void GatherShards(const std::vector<PathTracer*>& shards, uint32_t root = 0);
+    [[nodiscard]] uint32_t GetShardRank() const { return m_ShardRank; }
+    [[nodiscard]] uint32_t GetShardCount() const { return m_ShardCount; }
     PathTracer() = default;
     PathTracer(PathTracer&& o) noexcept;
     PathTracer& operator=(PathTracer&& o) noexcept;
@@ -156,6 +164,7 @@ public:
     [[nodiscard]] vpt_ctx* Context() const { return m_Ctx; }  // for PostProcessor
 
 private:
+    void Swap(PathTracer& o) noexcept;
     void Check(int rc, const char* what) const;
     void SetFlag(uint32_t bit, bool value);
     void Push(bool resets);
@@ -165,6 +174,7 @@ private:
     void Set3(float* dst, Vec3 v) { dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; UploadAtmosphere(); }
 
     int m_Device = 0;
+    uint32_t m_ShardRank = 0, m_ShardCount = 1;
     vpt_ctx* m_Ctx = nullptr;
     vpt_params m_Params{};
     uint32_t m_Width = 0, m_Height = 0;

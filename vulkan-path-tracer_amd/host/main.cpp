@@ -4,6 +4,9 @@
 //              [--env-constant r,g,b] [--radiance out.f32] [--camera out.f32] [--ppm out.ppm] [--info] [--dump-scene out.bin]
 //              [--env-hdr sky.hdr] [--png out.png] [--atmosphere] [--sun altitude,azimuth]
 //              [--volume minx,miny,minz,maxx,maxy,maxz,density,g,r,g,b]... [--phase hg|draine|hg+draine]
+//              [--gpus N [--devices d0,d1,...]]   rows y % N == k rendered on device k (one host thread each), one gather of
+//                                                 the shards into device 0 over xGMI, post-process there; the image is
+//                                                 bit-identical for every N (a device may be listed more than once)
 //   vpt_render --make-lut reflect|refract-above|refract-below --lut-samples N [--lut-size XxYxZ] [--lut-time-seed T] --lut-out table.bin
 //              (Application.cpp:38-77: the three tables the reference regenerates with 10'000'000 samples)
 #include <chrono>
@@ -14,6 +17,7 @@
 #include <fstream>
 #include <stdexcept>
 #include <string>
+#include <thread>
 
 #include "FlyCamera.h"
 #include "LookupTableCalculator.h"
@@ -32,7 +36,7 @@ int main(int argc, char** argv) {
     std::string scene, luts, radiance, camera, ppm, png, envHdr, dumpEnv, pngTest, dump, makeLut, lutOut;
     std::vector<PathTracer::Volume> volumes; int phase = 0; bool atmosphere = false; float sunAlt = 0.0f, sunAz = 0.0f;
     uint32_t lutSamples = 10000000u, lutTime = 0; UVec3 lutSize{0, 0, 0};
-    uint32_t w = 0, h = 0, spp = 16, depth = 8, seed = 1, split = 1;
+    uint32_t w = 0, h = 0, spp = 16, depth = 8, seed = 1, split = 1, gpus = 1; std::vector<int> devices;
     bool info = false, selftest = false; float env[3] = {0, 0, 0}; bool haveEnv = false;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
@@ -44,6 +48,8 @@ int main(int argc, char** argv) {
         else if (a == "--depth") depth = (uint32_t)atoi(next().c_str());
         else if (a == "--seed") seed = (uint32_t)strtoul(next().c_str(), nullptr, 10);
         else if (a == "--split") split = (uint32_t)atoi(next().c_str());
+        else if (a == "--gpus") { gpus = (uint32_t)atoi(next().c_str()); if (gpus == 0 || gpus > 64) { fprintf(stderr, "--gpus 1..64\n"); return 2; } }
+        else if (a == "--devices") { std::string v = next(); size_t p0 = 0; while (p0 <= v.size()) { size_t q = v.find(',', p0); if (q == std::string::npos) q = v.size(); devices.push_back(atoi(v.substr(p0, q - p0).c_str())); p0 = q + 1; } }
         else if (a == "--env-constant") { std::string s = next(); if (sscanf(s.c_str(), "%f,%f,%f", &env[0], &env[1], &env[2]) != 3) return 2; haveEnv = true; }
         else if (a == "--radiance") radiance = next();
         else if (a == "--camera") camera = next();
@@ -79,9 +85,19 @@ int main(int argc, char** argv) {
         double ev = 0, ep = 0, ei = 0;
         for (int i = 0; i < 16; i++) { ev = std::fmax(ev, std::fabs(v2.m[i] - view.m[i])); ep = std::fmax(ep, std::fabs(p2.m[i] - proj.m[i])); ei = std::fmax(ei, std::fabs(id.m[i] - (i % 5 == 0 ? 1.0f : 0.0f))); }
         cam.ProcessKeyboard(FlyCamera::Direction::UP, 1.0f);  // UP moves against m_Up (FlyCamera.cpp:47-49)
-        printf("{\"view_err\": %.3g, \"proj_err\": %.3g, \"inverse_err\": %.3g, \"fov\": %.4f, \"aspect\": %.5f, \"up_dy\": %.4f}\n", ev, ep, ei, cam.GetFov(), cam.GetAspectRatio(),
-               cam.GetPosition().y - (-2.0f));
-        return (ev < 1e-4 && ep < 1e-5 && ei < 1e-5) ? 0 : 1;
+        // a moved PathTracer carries ALL of its state (volumes, phase function, atmosphere, env path, shard identity)
+        PathTracer a = PathTracer::New(0, 1, 4), b = PathTracer::New(0);
+        PathTracer::Volume vol; vol.Density = 3.0f;
+        a.AddVolume(vol); a.AddVolume(vol); a.SetPhaseFunction(PathTracer::PhaseFunction::DRAINE); a.SetPlanetRadius(1234.0f); a.SetEnableAtmosphere(true);
+        a.SetMaxDepth(7);
+        b = std::move(a);
+        PathTracer c2(std::move(b));
+        const bool moveOk = c2.GetVolumesCount() == 2 && c2.GetVolumes()[1].Density == 3.0f && c2.GetPhaseFunction() == PathTracer::PhaseFunction::DRAINE &&
+                            c2.IsAtmosphereEnabled() && c2.GetPlanetRadius() == 1234.0f && c2.GetMaxDepth() == 7 && c2.GetShardRank() == 1 && c2.GetShardCount() == 4 &&
+                            b.GetVolumesCount() == 0 && !b.IsAtmosphereEnabled();
+        printf("{\"view_err\": %.3g, \"proj_err\": %.3g, \"inverse_err\": %.3g, \"fov\": %.4f, \"aspect\": %.5f, \"up_dy\": %.4f, \"move_keeps_state\": %s}\n", ev, ep, ei, cam.GetFov(), cam.GetAspectRatio(),
+               cam.GetPosition().y - (-2.0f), moveOk ? "true" : "false");
+        return (ev < 1e-4 && ep < 1e-5 && ei < 1e-5 && moveOk) ? 0 : 1;
     }
     if (!dumpEnv.empty() || !pngTest.empty()) {  // host-side file formats only
         try {
@@ -151,24 +167,39 @@ int main(int argc, char** argv) {
                    sc.Meshes.size(), sc.MeshInstances.size(), sc.Materials.size(), sc.Textures.size(), tris, verts, sc.Cameras.size());
             return 0;
         }
-        PathTracer pt = PathTracer::New(0);
-        pt.SetLookupTablePath(luts);
-        if (haveEnv) { std::vector<float> e(64 * 32 * 4, 0.0f); for (size_t i = 0; i < 64 * 32; i++) { e[i * 4] = env[0]; e[i * 4 + 1] = env[1]; e[i * 4 + 2] = env[2]; } pt.SetEnvironmentMap(e, 64, 32); }
-        if (w && h) pt.ResizeImage(w, h);
-        if (!envHdr.empty()) pt.SetEnvMapFilepath(envHdr);
-        pt.SetScene(scene);
-        if (w && h) {  // the window was resized: Editor.cpp:203-211 rebuilds the projection from the new aspect ratio
-            FlyCamera cam(inverse(pt.GetCameraViewInverse()), inverse(pt.GetCameraProjectionInverse()));
-            cam.SetAspectRatio((float)w / (float)h); cam.SetNearFar(0.1f, 100.0f);
-            pt.SetCameraProjectionInverse(inverse(cam.GetProjectionMatrix()));
+        while (devices.size() < gpus) devices.push_back((int)devices.size());
+        std::vector<PathTracer> shards;
+        for (uint32_t k = 0; k < gpus; k++) shards.push_back(PathTracer::New(devices[k], k, gpus));
+        for (PathTracer& pt : shards) {   // every shard holds a replica of the scene and the same settings
+            pt.SetLookupTablePath(luts);
+            if (haveEnv) { std::vector<float> e(64 * 32 * 4, 0.0f); for (size_t i = 0; i < 64 * 32; i++) { e[i * 4] = env[0]; e[i * 4 + 1] = env[1]; e[i * 4 + 2] = env[2]; } pt.SetEnvironmentMap(e, 64, 32); }
+            if (w && h) pt.ResizeImage(w, h);
+            if (!envHdr.empty()) pt.SetEnvMapFilepath(envHdr);
+            pt.SetScene(scene);
+            if (w && h) {  // the window was resized: Editor.cpp:203-211 rebuilds the projection from the new aspect ratio
+                FlyCamera cam(inverse(pt.GetCameraViewInverse()), inverse(pt.GetCameraProjectionInverse()));
+                cam.SetAspectRatio((float)w / (float)h); cam.SetNearFar(0.1f, 100.0f);
+                pt.SetCameraProjectionInverse(inverse(cam.GetProjectionMatrix()));
+            }
+            pt.SetMaxDepth(depth); pt.SetSeed(seed); pt.SetSplitScreenCount(split); pt.SetMaxSamplesAccumulated(spp);
+            if (phase != 0) pt.SetPhaseFunction((PathTracer::PhaseFunction)phase);
+            for (const auto& v : volumes) pt.AddVolume(v);
+            if (sunAlt != 0.0f || sunAz != 0.0f) { pt.SetSkyAltitude(sunAlt); pt.SetSkyAzimuth(sunAz); }
+            if (atmosphere) pt.SetEnableAtmosphere(true);
         }
-        pt.SetMaxDepth(depth); pt.SetSeed(seed); pt.SetSplitScreenCount(split); pt.SetMaxSamplesAccumulated(spp);
-        if (phase != 0) pt.SetPhaseFunction((PathTracer::PhaseFunction)phase);
-        for (const auto& v : volumes) pt.AddVolume(v);
-        if (sunAlt != 0.0f || sunAz != 0.0f) { pt.SetSkyAltitude(sunAlt); pt.SetSkyAzimuth(sunAz); }
-        if (atmosphere) pt.SetEnableAtmosphere(true);
+        PathTracer& pt = shards[0];
         auto t0 = std::chrono::steady_clock::now();
-        while (!pt.PathTrace(64)) {}
+        if (gpus == 1) {
+            while (!pt.PathTrace(64)) {}
+        } else {  // one host thread per device; the shards never talk to each other until the gather
+            std::vector<std::thread> th; std::vector<std::string> errs(gpus);
+            for (uint32_t k = 0; k < gpus; k++)
+                th.emplace_back([&, k] { try { while (!shards[k].PathTrace(64)) {} } catch (const std::exception& e) { errs[k] = e.what(); } });
+            for (auto& t : th) t.join();
+            for (const std::string& e : errs) if (!e.empty()) throw std::runtime_error(e);
+            std::vector<PathTracer*> ps; for (PathTracer& p : shards) ps.push_back(&p);
+            PathTracer::GatherShards(ps, 0);
+        }
         double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         const std::vector<float>& img = pt.GetOutputImage();
         PostProcessor post = PostProcessor::New();
@@ -186,8 +217,8 @@ int main(int argc, char** argv) {
             std::string err;
             if (!SavePNG(png, post.GetOutputImage().data(), pt.GetWidth(), pt.GetHeight(), err)) throw std::runtime_error(err);
         }
-        printf("{\"width\": %u, \"height\": %u, \"samples\": %u, \"seconds\": %.4f, \"msamples_per_s\": %.2f, \"vertices\": %llu, \"indices\": %llu}\n", pt.GetWidth(), pt.GetHeight(),
-               pt.GetSamplesAccumulated(), sec, (double)pt.GetWidth() * pt.GetHeight() * pt.GetSamplesAccumulated() / sec / 1e6,
+        printf("{\"width\": %u, \"height\": %u, \"gpus\": %u, \"samples\": %u, \"seconds\": %.4f, \"msamples_per_s\": %.2f, \"vertices\": %llu, \"indices\": %llu}\n", pt.GetWidth(), pt.GetHeight(),
+               gpus, pt.GetSamplesAccumulated(), sec, (double)pt.GetWidth() * pt.GetHeight() * pt.GetSamplesAccumulated() / sec / 1e6,
                (unsigned long long)pt.GetTotalVertexCount(), (unsigned long long)pt.GetTotalIndexCount());
     } catch (const std::exception& e) {
         fprintf(stderr, "vpt_render: %s\n", e.what());

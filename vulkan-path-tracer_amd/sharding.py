@@ -2,10 +2,64 @@
 
 Rows are dealt round-robin: row y belongs to rank y % world (the reference's interleaved split-screen
 scheme, RayGen.slang:16-25, along one axis).  Seeds depend on (pixel, frame) only, so the assembled image
-is bit-identical for any world size.  The only data-path collective is one gather of the finished shards
-(RCCL over xGMI with backend "nccl"; gloo in the CPU tests)."""
+is bit-identical for any world size.  The only data-path collective is one gather of the finished shards.  In the
+product it is issued by the library (include/vpt.h vpt_comm_gather_shards: ncclGather over xGMI on the context's own
+stream; vpt_multi_gather_shards when one process drives all devices); ShardComm below wires it to a process-per-GPU
+launch, where torch.distributed is only the control plane that carries the 128-byte communicator id.  The torch
+functions further down restate the same partition for the CPU tests (gloo, world_size 2)."""
+import ctypes as C
+
 import torch
 import torch.distributed as dist
+
+from . import _abi
+
+
+class ShardComm:
+    """One rank's end of the shard gather.  host_staged=False (the product path): ncclCommInitRank inside
+    libvpt_hip.so, ncclGather on the render stream, row re-interleave on the root.  host_staged=True is a test hook for
+    boxes with fewer devices than ranks (RCCL refuses two ranks on one device): the shards travel through host memory
+    over the torch process group instead and the root assembles them with the same library call."""
+
+    def __init__(self, pt, rank, world, root=0, host_staged=False, group=None):
+        self.pt, self.rank, self.world, self.root, self.host_staged, self.group = pt, rank, world, root, host_staged, group
+        self.ready = False
+        if world > 1 and not host_staged:
+            ident = torch.zeros(_abi.COMM_ID_BYTES, dtype=torch.uint8)
+            if rank == root:
+                buf = (C.c_ubyte * _abi.COMM_ID_BYTES)()
+                rc = pt.lib.vpt_comm_unique_id(buf)
+                if rc != 0:
+                    raise RuntimeError("vpt_comm_unique_id failed: %d" % rc)
+                ident = torch.tensor(list(buf), dtype=torch.uint8)
+            dist.broadcast(ident, src=root, group=group)     # control plane: 128 bytes, once
+            raw = bytes(ident.tolist())
+            rc = pt.lib.vpt_comm_init(pt.ctx, raw, rank, world)
+            if rc != 0:
+                raise RuntimeError("vpt_comm_init failed: %s" % pt.lib.vpt_last_error(pt.ctx).decode())
+            self.ready = True
+
+    def gather_and_assemble(self):
+        """After this call the root context holds the whole image (radiance() / postprocess() work there)."""
+        pt = self.pt
+        if self.world == 1:
+            return
+        if not self.host_staged:
+            rc = pt.lib.vpt_comm_gather_shards(pt.ctx, self.root)
+            if rc != 0:
+                raise RuntimeError("vpt_comm_gather_shards failed: %s" % pt.lib.vpt_last_error(pt.ctx).decode())
+            return
+        shard = torch.empty(pt.shard_floats(), dtype=torch.float32, device="cuda")
+        pt.shard_to_device(shard.data_ptr())
+        gathered = gather_shards(shard.cpu(), self.world, group=self.group)
+        if self.rank == self.root:
+            g = gathered.to("cuda")
+            pt.assemble_shards(g.data_ptr(), self.world)
+
+    def close(self):
+        if self.ready:
+            self.pt.lib.vpt_comm_destroy(self.pt.ctx)
+            self.ready = False
 
 
 def shard_rows(height, rank, world):
