@@ -64,7 +64,7 @@ CONNECT_RAY = 48                    # per shadow ray: the three records shade qu
 CONNECT_FINAL = 16                  # frame-sum write at the end of a sample (samples_per_frame == 1)
 PRIMARY_DONE = 16                   # a path that ends at bounce 0 writes only its frame sum
 PRIMARY_ALIVE = 16 * 4 + 4          # a survivor writes records A, B, T, L and its queue id
-RESOLVE_BYTES = 16 + 32             # per (pixel, frame) sum in, plus image read+write (amortised over the frames of a batch)
+# resolve: 16 B frame sum per (pixel, frame) in, plus one 32 B image read+write per pixel per batch
 
 
 def parse():
@@ -143,7 +143,7 @@ def kernel_table(st, tc):
                   SHADE_IN + (SHADE_ALIVE_OUT * alive_later + SHADE_PENDING_OUT * st["connect_paths"] + SHADE_RAY_OUT * later_rays) / max(n_later, 1)),
         "connect": (st["connect_paths"], CONNECT_FIXED + (CONNECT_FINAL * fin + (CONNECT_RAY + strav) * later_rays) / max(st["connect_paths"], 1),
                     CONNECT_FIXED + (CONNECT_FINAL * fin + CONNECT_RAY * later_rays) / max(st["connect_paths"], 1)),
-        "resolve": (st["samples"], RESOLVE_BYTES, RESOLVE_BYTES),
+        "resolve": (st["samples"], 16 + 32.0 / max(st["frames_in_flight"], 1), 16 + 32.0 / max(st["frames_in_flight"], 1)),
     }
     kernels = {}
     for name, (n, bpu, spu) in units.items():

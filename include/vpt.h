@@ -308,7 +308,8 @@ void vpt_default_atmosphere(vpt_atmosphere* out);                       /* PathT
 int vpt_set_atmosphere(vpt_ctx* ctx, const vpt_atmosphere* atmosphere); /* NULL: SetEnableAtmosphere(false). Resets accumulation. */
 /* SetCameraViewInverse / SetCameraProjectionInverse. */
 int vpt_set_camera(vpt_ctx* ctx, const float view_inverse[16], const float projection_inverse[16]);
-/* All scalar setters + the #define toggles (PathTracer.cpp:1010-1015, 1623-1716). Resets accumulation. */
+/* All scalar setters + the #define toggles (PathTracer.cpp:1010-1015, 1623-1716). Resets accumulation — except when
+ * max_samples is the only field that changed (SetMaxSamplesAccumulated keeps the image, PathTracer.cpp:1003-1006). */
 int vpt_set_params(vpt_ctx* ctx, const vpt_params* params);
 void vpt_default_params(vpt_params* params);
 void vpt_default_post_params(vpt_post_params* params);
@@ -368,6 +369,18 @@ int vpt_reset_stats(vpt_ctx* ctx);
 typedef struct vpt_ray { float origin[3]; float tmin; float direction[3]; float tmax; } vpt_ray;
 typedef struct vpt_hit { float t; float u; float v; uint32_t primitive; uint32_t instance; } vpt_hit;
 int vpt_trace_rays(vpt_ctx* ctx, const vpt_ray* rays_host, uint32_t n, vpt_hit* hits_host);
+
+/* Measurement hook on the ray-stream traversal kernels alone (the "trace lab"): keep a ray set resident on the device,
+ * then time kernel variants on exactly those rays, optionally visiting them in a caller-given order (a permutation of
+ * 0..n-1: e.g. sorted by origin cell and direction octant).  All rays of a set share ray 0's tmin / tmax.  Results are
+ * per ray whatever the variant or order: hits_host (optional, n entries; any-hit: t = 1 occluded / -1 clear).
+ * best_ms = fastest of `reps` launches (HIP events on the context's stream); visits (optional) = {nodes, triangles}
+ * visited, from one extra counting launch. */
+#define VPT_TRACE_BASE 0u  /* one ray per lane, 64 rays per wave at a time (round 1's extend / shadow loop) */
+#define VPT_TRACE_VOTE 1u  /* persistent lanes, wave-level vote between node / triangle / fetch steps, ray replacement */
+int vpt_lab_set_rays(vpt_ctx* ctx, const vpt_ray* rays_host, uint32_t n);
+int vpt_lab_trace(vpt_ctx* ctx, uint32_t variant, uint32_t any_hit, const uint32_t* order_host, uint32_t param, uint32_t reps,
+                  vpt_hit* hits_host, float* best_ms, uint64_t* visits);
 
 /* ---- energy-compensation lookup tables -------------------------------------------
  * Replaces LookupTableCalculator::CalculateTable(tableSize, sampleCount) (LookupTableCalculator.cpp:44-157)

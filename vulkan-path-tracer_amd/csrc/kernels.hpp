@@ -28,6 +28,21 @@ size_t stack_overflow_bytes(uint32_t blocks);  // per-thread spill region of the
 int traverse_blocks_per_cu(bool lds_scene, const DeviceScene& sc);
 int shade_blocks_per_cu();
 
+// ray-stream traversal kernels (kernels_trace.hip)
+struct TraceArgs {
+    const float4* ro;       // origin.xyz | -
+    const float4* rd;       // direction.xyz | -
+    const uint32_t* order;  // optional: entry i of the stream is ray order[i]
+    float4* hit;            // closest: t (< 0 miss), u, v | primitive; any-hit: x = 1 occluded / -1 clear
+    uint32_t* hinst;        // closest: instance
+    uint32_t n;
+    float tmin, tmax;
+    uint32_t normalize_dir; // RayGen.slang:70 normalises the payload direction before tracing
+    uint32_t param;         // variant parameter (vote: idle lanes that trigger a fetch step; 0 = default)
+};
+void launch_trace(hipStream_t s, uint32_t blocks, uint32_t variant, bool any, bool count, const DeviceScene& sc, const TraceArgs& a, Counters* ctr);
+int trace_blocks_per_cu(uint32_t variant, bool any);
+
 // lookup-table generator (kernels_lut.hip)
 void launch_lut(hipStream_t s, int kind, float* table, uint32_t sx, uint32_t sy, uint32_t sz, uint32_t sample_count, uint32_t time_hash,
                 uint32_t first_dispatch, uint32_t n_dispatches);

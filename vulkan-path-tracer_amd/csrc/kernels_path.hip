@@ -15,25 +15,9 @@
 #include "volume.hpp"
 #include "atmosphere.hpp"
 #include "traverse.hpp"
+#include "wave.hpp"
 
 namespace vpt {
-
-__device__ inline uint32_t lane_id() { return threadIdx.x & 63u; }
-__device__ inline uint32_t lanes_below(unsigned long long mask) {  // popcount of mask bits below this lane
-    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-}
-// One atomic per wave: returns this lane's slot in the output stream (valid where pred).
-__device__ inline uint32_t wave_append(bool pred, uint32_t* counter) {
-    unsigned long long mask = __ballot(pred);
-    uint32_t total = (uint32_t)__popcll(mask);
-    uint32_t base = 0;
-    if (total) {
-        uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
-        if (lane_id() == leader) base = atomicAdd(counter, total);
-        base = __shfl(base, (int)leader);
-    }
-    return base + lanes_below(mask);
-}
 
 // ------------------------------------------------------------------ small helpers
 __device__ inline float4 f4(V3 v, float w) { return make_float4(v.x, v.y, v.z, w); }
@@ -86,14 +70,6 @@ __global__ __launch_bounds__(256) void k_raygen(RenderParams P, PathState ps, ui
 }
 
 // ------------------------------------------------------------------ persistent work fetch
-// One atomic on a single word costs ~11 ns under contention (MI355X_MICROARCH.md 'dequeue': a head word
-// saturates at ~88 dequeues/us), so the number of fetches per launch is kept near 8k: a wave takes
-// n/8192 queue entries per fetch, rounded up to whole waves, between 64 and 1024.
-__device__ inline uint32_t fetch_chunk(uint32_t n) {
-    uint32_t c = ((n >> 13) + 63u) & ~63u;
-    return c < 64u ? 64u : (c > 1024u ? 1024u : c);
-}
-
 template <bool LDS_SCENE>
 __device__ inline void stage_scene(const DeviceScene& sc, float4* lds_nodes, float4* lds_tris) {
     if (LDS_SCENE) {

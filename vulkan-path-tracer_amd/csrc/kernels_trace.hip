@@ -1,0 +1,238 @@
+// kernels_trace.hip — ray-stream traversal kernels (replace the driver-side TraceRay / RayQuery of RayGen.slang:90 and
+// RTCommon.slang:54-63 for ray streams that live in HBM) and the trace lab that times them on identical rays.
+//
+//   k_trace_base   one ray per lane, a wave works through 64 rays at a time until the slowest lane is done
+//                  (the structure of round 1's extend kernel, kept as the measured baseline)
+//   k_trace_vote   persistent lanes with a wave-level vote: every iteration the wave executes ONE kind of step for the
+//                  lanes that want it — an inner-node step (fetch 64 B, four slab tests, order, push), a triangle step
+//                  (ONE triangle of the lane's current leaf) or a fetch step (retire finished rays, load new ones into
+//                  the idle lanes) — chosen by ballot/popcount as the kind most lanes are waiting for.  A lane that
+//                  reached a leaf no longer drags the whole wave through the triangle code while its neighbours sit at
+//                  inner nodes, a leaf of four triangles no longer makes one-triangle lanes wait, and a finished lane is
+//                  refilled instead of idling until the slowest ray of its 64 is done.  Results are per ray, so the
+//                  order rays are worked on cannot change a bit of them.
+//
+// Closest-hit search: ties in t go to the smaller global triangle id (traverse.hpp), so every kernel here returns the
+// same (t, u, v, primitive, instance) for a ray whatever it visits first.
+#include "kernels.hpp"
+#include "traverse.hpp"
+#include "wave.hpp"
+
+namespace vpt {
+
+namespace {
+
+constexpr int kLaneIdle = 0x7fffffff;  // the lane holds no ray
+constexpr int kLaneDone = 0x7ffffffe;  // the lane's ray is finished, its result not yet written
+
+__device__ inline V3 xyz4(float4 v) { return vptfp::v3(v.x, v.y, v.z); }
+
+__device__ inline void load_ray(const TraceArgs& a, uint32_t i, uint32_t& rid, V3& o, V3& d) {
+    rid = a.order ? a.order[i] : i;
+    o = xyz4(a.ro[rid]);
+    d = xyz4(a.rd[rid]);
+    if (a.normalize_dir) d = vptfp::normalize(d);  // RayGen.slang:70
+}
+
+// hit record of a finished closest-hit search: prim / inst come from the winning triangle's record
+__device__ inline void store_closest(const TraceArgs& a, const BvhTri* tris, uint32_t rid, bool found, float t, float u, float v, uint32_t slot) {
+    uint32_t prim = 0xffffffffu, inst = 0xffffffffu;
+    if (found) { prim = tris[slot].prim; inst = tris[slot].inst; }
+    a.hit[rid] = make_float4(found ? t : -1.0f, found ? u : 0.0f, found ? v : 0.0f, __uint_as_float(prim));
+    a.hinst[rid] = inst;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ baseline: 64 rays per wave at a time
+template <bool ANY, bool COUNT>
+__global__ __launch_bounds__(kTraverseBlock, 8) void k_trace_base(DeviceScene sc, TraceArgs a, Counters* ctr) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const TravStack stack = make_stack(smem, sc.stack_overflow);
+    GlobalSceneSrc src{sc.nodes, sc.tris, false};
+    const uint32_t chunk = fetch_chunk(a.n);
+    TravStats st; st.nodes = 0; st.tris = 0;
+    while (true) {
+        uint32_t base = 0;
+        if (lane_id() == 0) base = atomicAdd(&ctr->extend_head, chunk);
+        base = __shfl(base, 0);
+        if (base >= a.n) break;
+        for (uint32_t k = 0; k < chunk; k += 64) {
+            uint32_t i = base + k + lane_id();
+            if (i >= a.n) break;
+            uint32_t rid; V3 o, d;
+            load_ray(a, i, rid, o, d);
+            if (ANY) {
+                int slot = 0; float t = 0.0f; uint32_t gid = 0;
+                bool occ = trace_occluded_pass<COUNT, false, false>(src, o, d, a.tmin, a.tmax, 0.0f, 0u, stack, st, 0xffffffffu, 0xffffffffu, slot, t, gid);
+                a.hit[rid] = make_float4(occ ? 1.0f : -1.0f, 0.0f, 0.0f, 0.0f);
+            } else {
+                HitRec h;
+                bool found = trace_closest_pass<COUNT, false>(src, o, d, a.tmin, a.tmax, stack, h, st, 0xffffffffu, 0xffffffffu);
+                a.hit[rid] = make_float4(found ? h.t : -1.0f, found ? h.u : 0.0f, found ? h.v : 0.0f, __uint_as_float(h.prim));
+                a.hinst[rid] = h.inst;
+            }
+        }
+    }
+    if (COUNT) {
+        atomicAdd(&ctr->stat_nodes, (unsigned long long)st.nodes);
+        atomicAdd(&ctr->stat_tris, (unsigned long long)st.tris);
+    }
+}
+
+// ------------------------------------------------------------------ vote-scheduled persistent lanes
+// Lane state: `cur` >= 0 inner node to visit; < 0 leaf code ~(first << 3 | count - 1) with `first` advancing as the
+// triangles are consumed; kLaneDone / kLaneIdle.  The wave owns a chunk [w_next, w_end) of the ray stream (one atomic per
+// chunk) and deals its entries to idle lanes in fetch steps.
+template <bool ANY, bool COUNT>
+__global__ __launch_bounds__(kTraverseBlock, 8) void k_trace_vote(DeviceScene sc, TraceArgs a, Counters* ctr) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint32_t* const stk = reinterpret_cast<uint32_t*>(smem) + threadIdx.x;  // entry k of this lane at stk[k * kTraverseBlock]
+    uint32_t* const ovf = sc.stack_overflow + (size_t)(blockIdx.x * blockDim.x + threadIdx.x) * kStackOverflow;
+    const BvhNode* const nodes = sc.nodes;
+    const BvhTri* const tris = sc.tris;
+    const uint32_t chunk = fetch_chunk(a.n);
+    const uint32_t fetch_at = (a.param & 0xffu) ? (a.param & 0xffu) : 16u;  // idle lanes that trigger a fetch step (64: only when all are idle)
+    const bool weighted = ((a.param >> 8) & 1u) != 0u;  // vote by lanes served per instruction issued: a triangle step costs about half a node step
+    uint32_t w_next = 0, w_end = 0;
+    bool exhausted = false;
+    int cur = kLaneIdle, sp = 0;
+    uint32_t rid = 0, bslot = 0xffffffffu, bgid = 0xffffffffu;
+    V3 o = vptfp::v3(0.0f, 0.0f, 0.0f), d = o, inv = o;
+    float best_t = 0.0f, bu = 0.0f, bv = 0.0f;
+    uint32_t st_nodes = 0, st_tris = 0;
+
+#define VPT_PUSH(V)                                                                                       \
+    do {                                                                                                  \
+        if (sp < kStackDepth) stk[sp * kTraverseBlock] = (uint32_t)(V);                                   \
+        else if (sp < kStackDepth + kStackOverflow) ovf[sp - kStackDepth] = (uint32_t)(V);                \
+        sp++;                                                                                             \
+    } while (0)
+#define VPT_POP_OR_DONE()                                                                                 \
+    do {                                                                                                  \
+        if (sp == 0) cur = kLaneDone;                                                                     \
+        else { sp--; cur = (int)(sp < kStackDepth ? stk[sp * kTraverseBlock] : ovf[sp - kStackDepth]); }  \
+    } while (0)
+
+    while (true) {
+        const bool busy = cur < kLaneDone;
+        const bool at_node = busy && cur >= 0;
+        const bool at_leaf = busy && cur < 0;
+        const uint32_t nn = (uint32_t)__popcll(__ballot(at_node)), nl = (uint32_t)__popcll(__ballot(at_leaf));
+        if (!exhausted && (64u - nn - nl >= fetch_at || nn + nl == 0u)) {
+            // ---- fetch step: retire finished rays, deal new ones to the idle lanes
+            if (cur == kLaneDone) {
+                if (ANY) a.hit[rid] = make_float4(bslot != 0xffffffffu ? 1.0f : -1.0f, 0.0f, 0.0f, 0.0f);
+                else store_closest(a, tris, rid, bslot != 0xffffffffu, best_t, bu, bv, bslot);
+                cur = kLaneIdle;
+            }
+            if (w_next >= w_end) {
+                uint32_t base = 0;
+                if (lane_id() == 0) base = atomicAdd(&ctr->extend_head, chunk);
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (base >= a.n) exhausted = true;
+                else { w_next = base; w_end = base + chunk < a.n ? base + chunk : a.n; }
+            }
+            if (!exhausted) {
+                const unsigned long long m_idle = __ballot(cur == kLaneIdle);
+                const uint32_t i = w_next + lanes_below(m_idle);
+                if (cur == kLaneIdle && i < w_end) {
+                    load_ray(a, i, rid, o, d);
+                    inv = safe_inverse(d);
+                    best_t = a.tmax; bslot = 0xffffffffu; bgid = 0xffffffffu;
+                    sp = 0; cur = 0;  // root
+                }
+                const uint32_t want = (uint32_t)__popcll(m_idle), left = w_end - w_next;
+                w_next += want < left ? want : left;
+            }
+        } else if (nn + nl == 0u) {
+            break;
+        } else if (weighted ? nn > 2u * nl : nn >= nl) {
+            // ---- inner-node step
+            if (at_node) {
+                const uint4* p = reinterpret_cast<const uint4*>(nodes + cur);
+                NodeData n;
+                unpack_node(p[0], p[1], p[2], p[3], n);
+                if (COUNT) st_nodes++;
+                RaySlab slab; slab.o = o; slab.inv = inv;
+                slab.negx = inv.x < 0.0f; slab.negy = inv.y < 0.0f; slab.negz = inv.z < 0.0f;
+                float t0, t1, t2, t3;
+                node_entries(n, slab, a.tmin, best_t, t0, t1, t2, t3);
+                int c0 = n.c0, c1 = n.c1, c2 = n.c2, c3 = n.c3;
+                if (ANY) {  // order is irrelevant for an any-hit search: hit children in slot order
+                    int next = kLaneIdle;
+                    if (t3 < kMissT) next = c3;
+                    if (t2 < kMissT) { if (next != kLaneIdle) VPT_PUSH(next); next = c2; }
+                    if (t1 < kMissT) { if (next != kLaneIdle) VPT_PUSH(next); next = c1; }
+                    if (t0 < kMissT) { if (next != kLaneIdle) VPT_PUSH(next); next = c0; }
+                    if (next != kLaneIdle) cur = next; else VPT_POP_OR_DONE();
+                } else {
+                    cswap(t0, c0, t1, c1); cswap(t2, c2, t3, c3); cswap(t0, c0, t2, c2); cswap(t1, c1, t3, c3); cswap(t1, c1, t2, c2);
+                    if (t0 < kMissT) {  // nearest child next, the others pushed far -> near
+                        if (t3 < kMissT) VPT_PUSH(c3);
+                        if (t2 < kMissT) VPT_PUSH(c2);
+                        if (t1 < kMissT) VPT_PUSH(c1);
+                        cur = c0;
+                    } else {
+                        VPT_POP_OR_DONE();
+                    }
+                }
+            }
+        } else {
+            // ---- triangle step: ONE triangle of the lane's leaf
+            if (at_leaf) {
+                const uint32_t enc = (uint32_t)(~cur);
+                const int first = (int)(enc >> 3);
+                const uint32_t more = enc & 7u;  // triangles left after this one
+                const float4* q = reinterpret_cast<const float4*>(tris + first);
+                const float4 ta = q[0], tb = q[1], tc = q[2];
+                if (COUNT) st_tris++;
+                float t, u, v;
+                bool stop = false;
+                if (vptfp::ray_triangle(o, d, vptfp::v3(ta.x, ta.y, ta.z), vptfp::v3(ta.w, tb.x, tb.y), vptfp::v3(tb.z, tb.w, tc.x), a.tmin, a.tmax, &t, &u, &v)) {
+                    const uint32_t gid = __float_as_uint(tc.w);
+                    if (ANY) { bslot = (uint32_t)first; stop = true; }
+                    else if (bslot == 0xffffffffu || t < best_t || (t == best_t && gid < bgid)) { best_t = t; bu = u; bv = v; bslot = (uint32_t)first; bgid = gid; }
+                }
+                if (stop) cur = kLaneDone;
+                else if (more) cur = ~(int)((((uint32_t)first + 1u) << 3) | (more - 1u));
+                else VPT_POP_OR_DONE();
+            }
+        }
+    }
+    if (cur == kLaneDone) {  // rays that finished after the stream ran dry
+        if (ANY) a.hit[rid] = make_float4(bslot != 0xffffffffu ? 1.0f : -1.0f, 0.0f, 0.0f, 0.0f);
+        else store_closest(a, tris, rid, bslot != 0xffffffffu, best_t, bu, bv, bslot);
+    }
+#undef VPT_PUSH
+#undef VPT_POP_OR_DONE
+    if (COUNT) {
+        atomicAdd(&ctr->stat_nodes, (unsigned long long)st_nodes);
+        atomicAdd(&ctr->stat_tris, (unsigned long long)st_tris);
+    }
+}
+
+// ------------------------------------------------------------------ launch
+int trace_blocks_per_cu(uint32_t variant, bool any) {
+    int nb = 0;
+    const size_t lds = (size_t)kStackDepth * kTraverseBlock * 4;
+    if (variant == VPT_TRACE_BASE) {
+        if (any) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_base<true, false>, kTraverseBlock, lds);
+        else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_base<false, false>, kTraverseBlock, lds);
+    } else {
+        if (any) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_vote<true, false>, kTraverseBlock, lds);
+        else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_vote<false, false>, kTraverseBlock, lds);
+    }
+    return nb > 0 ? nb : 1;
+}
+
+void launch_trace(hipStream_t s, uint32_t blocks, uint32_t variant, bool any, bool count, const DeviceScene& sc, const TraceArgs& a, Counters* ctr) {
+    const size_t lds = (size_t)kStackDepth * kTraverseBlock * 4;
+    const dim3 g(blocks), b(kTraverseBlock);
+#define VPT_LT(K) do { if (any) { if (count) hipLaunchKernelGGL((K<true, true>), g, b, lds, s, sc, a, ctr); else hipLaunchKernelGGL((K<true, false>), g, b, lds, s, sc, a, ctr); } \
+                       else { if (count) hipLaunchKernelGGL((K<false, true>), g, b, lds, s, sc, a, ctr); else hipLaunchKernelGGL((K<false, false>), g, b, lds, s, sc, a, ctr); } } while (0)
+    if (variant == VPT_TRACE_BASE) VPT_LT(k_trace_base); else VPT_LT(k_trace_vote);
+#undef VPT_LT
+}
+
+}  // namespace vpt

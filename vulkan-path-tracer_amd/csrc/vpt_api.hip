@@ -30,6 +30,10 @@ struct vpt_ctx {
     ncclComm_t comm = nullptr;   // vpt_comm_init: one rank per process
     int comm_rank = -1, comm_world = 0;
     float* gather_buf = nullptr; // root: shard_count padded shards back to back
+    // trace lab (vpt_lab_*): a resident ray set
+    float4 *lab_ro = nullptr, *lab_rd = nullptr, *lab_hit = nullptr;
+    uint32_t *lab_hinst = nullptr, *lab_order = nullptr;
+    uint32_t lab_n = 0; float lab_tmin = 0.0f, lab_tmax = 0.0f;
     std::vector<vpt_material> materials;
     std::vector<MeshDesc> meshes;
     std::vector<InstanceDesc> instances;
@@ -124,6 +128,10 @@ void free_scene(vpt_ctx* c) {
     c->scene_allocs.clear();
     c->has_scene = false;
     c->d_materials = nullptr; c->d_emissive = nullptr;
+}
+void free_lab(vpt_ctx* c) {
+    for (void* p : {(void*)c->lab_ro, (void*)c->lab_rd, (void*)c->lab_hit, (void*)c->lab_hinst, (void*)c->lab_order}) if (p) (void)hipFree(p);
+    c->lab_ro = c->lab_rd = c->lab_hit = nullptr; c->lab_hinst = c->lab_order = nullptr; c->lab_n = 0;
 }
 void free_render_buffers(vpt_ctx* c) {
     if (c->ps_block) (void)hipFree(c->ps_block);
@@ -466,6 +474,7 @@ void vpt_destroy(vpt_ctx* c) {
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->comm) { (void)ncclCommDestroy(c->comm); c->comm = nullptr; }
+    free_lab(c);
     free_scene(c);
     free_render_buffers(c);
     if (c->ctr) (void)hipFree(c->ctr);
@@ -685,6 +694,10 @@ int vpt_set_params(vpt_ctx* c, const vpt_params* p) {
     if (p->screen_chunk_count == 0 || p->screen_chunk_count > 64) return fail(c, VPT_ERR_INVALID_ARGUMENT, "screen_chunk_count must be in [1, 64]");
     if (p->screen_chunk_count != 1 && c->P.shard_count != 1) return fail(c, VPT_ERR_UNSUPPORTED, "split-screen dispatch needs the whole image in one context (shard_count == 1): its first dispatch copies pixels across rows");
     if (!(p->flags & VPT_FLAG_RAY_QUERIES)) return fail(c, VPT_ERR_UNSUPPORTED, "only the USE_RAY_QUERIES semantics are implemented");
+    {   // SetMaxSamplesAccumulated alone keeps the accumulated image (PathTracer.cpp:1003-1006 does not reset)
+        vpt_params same = *p; same.max_samples = c->params.max_samples;
+        if (p->max_samples != c->params.max_samples && memcmp(&same, &c->params, sizeof(vpt_params)) == 0) { c->params.max_samples = p->max_samples; return VPT_OK; }
+    }
     const bool flags_changed = c->params.flags != p->flags;
     c->dsc.strict_hits = (p->flags & VPT_FLAG_LOCAL_HITS) ? 1u : 0u;
     if (flags_changed || c->params.max_depth != p->max_depth) { c->tune_state = 0; c->auto_fused = false; c->tune_ms[0] = c->tune_ms[1] = 1e30; }
@@ -1072,6 +1085,72 @@ int vpt_multi_gather_shards(vpt_ctx* const* ctxs, uint32_t count, uint32_t root)
     }
     HIPCHK(R, hipSetDevice(R->cfg.device));
     return assemble_from_gather_buf(R);
+}
+
+int vpt_lab_set_rays(vpt_ctx* c, const vpt_ray* rays, uint32_t n) {
+    if (!c || !rays || n == 0) return VPT_ERR_INVALID_ARGUMENT;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    free_lab(c);
+    std::vector<float4> ro(n), rd(n);
+    for (uint32_t i = 0; i < n; i++) {
+        ro[i] = make_float4(rays[i].origin[0], rays[i].origin[1], rays[i].origin[2], 0.0f);
+        rd[i] = make_float4(rays[i].direction[0], rays[i].direction[1], rays[i].direction[2], 0.0f);
+    }
+    HIPCHK(c, hipMalloc((void**)&c->lab_ro, (size_t)n * 16)); HIPCHK(c, hipMalloc((void**)&c->lab_rd, (size_t)n * 16));
+    HIPCHK(c, hipMalloc((void**)&c->lab_hit, (size_t)n * 16)); HIPCHK(c, hipMalloc((void**)&c->lab_hinst, (size_t)n * 4));
+    HIPCHK(c, hipMalloc((void**)&c->lab_order, (size_t)n * 4));
+    HIPCHK(c, hipMemcpy(c->lab_ro, ro.data(), (size_t)n * 16, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->lab_rd, rd.data(), (size_t)n * 16, hipMemcpyHostToDevice));
+    c->lab_n = n; c->lab_tmin = rays[0].tmin; c->lab_tmax = rays[0].tmax;
+    return VPT_OK;
+}
+int vpt_lab_trace(vpt_ctx* c, uint32_t variant, uint32_t any_hit, const uint32_t* order, uint32_t param, uint32_t reps, vpt_hit* hits, float* best_ms,
+                  uint64_t* visits) {
+    if (!c || variant > VPT_TRACE_VOTE || reps == 0) return VPT_ERR_INVALID_ARGUMENT;
+    if (!c->has_scene) return fail(c, VPT_ERR_NO_SCENE, "no scene");
+    if (c->lds_scene) return fail(c, VPT_ERR_UNSUPPORTED, "the trace lab runs on scenes whose BVH lives in memory");
+    if (c->lab_n == 0) return fail(c, VPT_ERR_INVALID_ARGUMENT, "vpt_lab_trace before vpt_lab_set_rays");
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    const uint32_t n = c->lab_n;
+    if (order) HIPCHK(c, hipMemcpy(c->lab_order, order, (size_t)n * 4, hipMemcpyHostToDevice));
+    TraceArgs a{};
+    a.ro = c->lab_ro; a.rd = c->lab_rd; a.order = order ? c->lab_order : nullptr; a.hit = c->lab_hit; a.hinst = c->lab_hinst;
+    a.n = n; a.tmin = c->lab_tmin; a.tmax = c->lab_tmax; a.normalize_dir = 0u; a.param = param;
+    const uint32_t blocks = (uint32_t)std::min(trace_blocks_per_cu(variant, any_hit != 0) * c->cu_count, c->max_blocks);
+    hipEvent_t e0, e1;
+    HIPCHK(c, hipEventCreate(&e0)); HIPCHK(c, hipEventCreate(&e1));
+    float best = 1e30f;
+    for (uint32_t r = 0; r < reps + (visits ? 1u : 0u); r++) {
+        const bool count = visits && r == reps;
+        HIPCHK(c, hipMemsetAsync(c->ctr, 0, sizeof(Counters), c->stream));
+        HIPCHK(c, hipEventRecord(e0, c->stream));
+        launch_trace(c->stream, blocks, variant, any_hit != 0, count, c->dsc, a, c->ctr);
+        HIPCHK(c, hipEventRecord(e1, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipGetLastError());
+        float ms = 0.0f;
+        HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
+        if (!count) best = std::min(best, ms);
+        else {
+            Counters h{};
+            HIPCHK(c, hipMemcpy(&h, c->ctr, sizeof(Counters), hipMemcpyDeviceToHost));
+            visits[0] = h.stat_nodes; visits[1] = h.stat_tris;
+        }
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    HIPCHK(c, hipMemset(c->ctr, 0, sizeof(Counters)));
+    if (best_ms) *best_ms = best;
+    if (hits) {
+        std::vector<float4> h4(n); std::vector<uint32_t> hi(n, 0xffffffffu);
+        HIPCHK(c, hipMemcpy(h4.data(), c->lab_hit, (size_t)n * 16, hipMemcpyDeviceToHost));
+        if (!any_hit) HIPCHK(c, hipMemcpy(hi.data(), c->lab_hinst, (size_t)n * 4, hipMemcpyDeviceToHost));
+        for (uint32_t i = 0; i < n; i++) {
+            hits[i].t = h4[i].x; hits[i].u = h4[i].y; hits[i].v = h4[i].z;
+            uint32_t prim; memcpy(&prim, &h4[i].w, 4);
+            hits[i].primitive = any_hit ? 0xffffffffu : prim; hits[i].instance = hi[i];
+        }
+    }
+    return VPT_OK;
 }
 
 int vpt_lut_calculate(int device, uint32_t kind, uint32_t sx, uint32_t sy, uint32_t sz, uint32_t sample_count, uint32_t time_ms, float* out) {

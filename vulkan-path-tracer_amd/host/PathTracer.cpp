@@ -203,17 +203,9 @@ void PathTracer::SetCameraViewInverse(const Mat4& view) { m_CameraViewInverse = 
 void PathTracer::SetCameraProjectionInverse(const Mat4& p) { m_CameraProjectionInverse = p; if (m_Ctx) Check(vpt_set_camera(m_Ctx, m_CameraViewInverse.m, m_CameraProjectionInverse.m), "vpt_set_camera"); ResetPathTracing(); }
 void PathTracer::SetFlag(uint32_t bit, bool value) { m_Params.flags = value ? (m_Params.flags | bit) : (m_Params.flags & ~bit); Push(true); }
 void PathTracer::Push(bool resets) {
-    if (m_Ctx) {
-        if (resets) Check(vpt_set_params(m_Ctx, &m_Params), "vpt_set_params");
-        else {  // SetMaxSamplesAccumulated does not reset the accumulation upstream (PathTracer.cpp:1003-1006): keep the image
-            std::vector<float> img((size_t)m_Width * m_Height * 4);
-            vpt_stats st; Check(vpt_get_stats(m_Ctx, &st), "vpt_get_stats");
-            Check(vpt_get_radiance(m_Ctx, img.data()), "vpt_get_radiance");
-            Check(vpt_set_params(m_Ctx, &m_Params), "vpt_set_params");
-            Check(vpt_set_radiance(m_Ctx, img.data(), (uint32_t)st.frames), "vpt_set_radiance");
-            return;
-        }
-    }
+    // vpt_set_params keeps the accumulated image when only max_samples changes (SetMaxSamplesAccumulated does not reset
+    // upstream, PathTracer.cpp:1003-1006) and resets it for every other field
+    if (m_Ctx) Check(vpt_set_params(m_Ctx, &m_Params), "vpt_set_params");
     if (resets) { m_SamplesAccumulated = 0; m_DispatchCount = 0; }
 }
 void PathTracer::SetEnvironmentMap(const std::vector<float>& rgba, uint32_t width, uint32_t height) {
