@@ -31,15 +31,20 @@ def test_lut_reproduces_shipped_tables(vpt, kind, size):
     assert got.shape == shipped.shape
     err = np.abs(got - shipped)
     assert np.isfinite(got).all()
-    # Rows of near-mirror roughness (refract tables: y < 8, roughness <= 0.055) are limited by fp32 cancellation in
-    # the VNDF sample and the GGX D term, not by sample count: this generator is reproducible there to 1e-3 between
-    # seeds yet sits up to 0.08 away from the shipped table, which was computed with the Vulkan driver's own
-    # sin/cos/sqrt/fma choices.  Everything else agrees to Monte-Carlo error.
-    y0 = 8 if kind else 0
-    body, mirror = err[:, y0:, :], err[:, :y0, :]
-    assert body.mean() < 1.5e-3 and np.quantile(body, 0.999) < 0.02, (body.mean(), float(np.quantile(body, 0.999)), body.max())
-    if y0:
-        assert mirror.mean() < 0.02 and mirror.max() < 0.15, (mirror.mean(), mirror.max())
+    # The refraction tables disagree with this generator in one corner only: near-mirror rows (y <= 4, alpha <= 0.032) seen
+    # at grazing angles (x <= 31, V.z <= 0.06) — up to 0.09 — and layer z = 0 (IOR 1.0001).  A float64 evaluation of those cells sides
+    # with this generator (tests/test_oracle_lut_fp64.py): the shipped values are the outlier, so the corner is excluded
+    # and everything else, the other near-mirror cells included, has to agree to Monte-Carlo error.
+    disputed = np.zeros(err.shape, bool)
+    if kind:
+        disputed[:, :5, :32] = True
+        disputed[0, :, :] = True
+    ok = err[~disputed]
+    assert ok.mean() < 1.5e-3 and np.quantile(ok, 0.999) < 0.012, (ok.mean(), float(np.quantile(ok, 0.999)), ok.max())
+    if kind:
+        mirror = np.where(disputed, 0.0, err)[1:, :8, :]                     # near-mirror rows outside the corner: the rows config 5 reads
+        assert mirror.max() < 0.012, mirror.max()
+        assert (got - shipped)[1:, :2, :13].mean() > 0.05   # in the corner the shipped table is LOW by ~0.08
 
 
 def test_lut_argument_errors(vpt):

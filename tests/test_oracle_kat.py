@@ -164,10 +164,14 @@ def test_lut_generator_restatement_reproduces_shipped_tables(oracle, vpt, kind, 
     """orc_lut_cells restates LookupTableCalculator::CalculateTable pass by pass (20-sample passes, per-pass
     reseed, fp32 sums); at 40k samples a cell lands within Monte-Carlo error of the shipped 10M-sample table."""
     table = vpt.scenes.load_luts()[kind].reshape(-1)
-    cells = np.random.default_rng(kind).integers(0, table.size, 64).astype(np.uint32)
+    cells = np.random.default_rng(kind).integers(0, table.size, 96).astype(np.uint32)
+    if kind:  # the grazing near-mirror corner and the IOR-1.0001 layer, where a float64 evaluation shows the SHIPPED values
+              # to be the outlier (tests/test_oracle_lut_fp64.py), are compared there, not here
+        x, y, z = cells % size[0], (cells // size[0]) % size[1], cells // (size[0] * size[1])
+        cells = cells[~(((y < 5) & (x < 32)) | (z == 0))]
     got = oracle.lut_cells(kind, size, 40000, 7, cells)
     err = np.abs(got - table[cells])
-    assert err.mean() < 4e-3 and err.max() < 0.04, (err.mean(), err.max())
+    assert err.mean() < 4e-3 and err.max() < 0.02, (err.mean(), err.max())
     # the pass structure matters: the same cells with another time seed differ in the low bits but agree statistically
     other = oracle.lut_cells(kind, size, 40000, 8, cells)
     assert not np.array_equal(got, other) and np.abs(got - other).mean() < 6e-3
