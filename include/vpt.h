@@ -178,18 +178,21 @@ typedef struct vpt_config {
 /* AUTO = FUSED when the BVH fits in LDS next to the traversal stacks, else STAGED. Results are identical. */
 #define VPT_PIPELINE_AUTO 0u
 #define VPT_PIPELINE_FUSED 1u   /* one kernel per bounce */
-#define VPT_PIPELINE_STAGED 2u  /* extend -> shade -> connect with compacted queues */
+#define VPT_PIPELINE_STAGED 2u  /* extend -> shade -> connect with compacted queues; traversal on the vote-scheduled persistent kernels */
+#define VPT_PIPELINE_STAGED_R1 3u /* the same stages with round 1's traversal loops (64 rays per wave at a time): kept as the measured baseline */
 
-#define VPT_KERNEL_COUNT 8
+#define VPT_KERNEL_COUNT 10
 enum vpt_kernel_id {
     VPT_K_PRIMARY = 0,  /* fused pipeline: bounce 0 (camera ray + extend + shade + connect); staged pipeline: raygen */
     VPT_K_EXTEND = 1,
     VPT_K_SHADE = 2,
-    VPT_K_CONNECT = 3,  /* shadow rays + light accumulation + end-of-sample */
+    VPT_K_CONNECT = 3,  /* shadow rays + light accumulation + end-of-sample in one kernel (VPT_PIPELINE_STAGED_R1) */
     VPT_K_BOUNCE = 4,   /* bounce >= 1 fused (LDS-resident scenes): extend + shade + connect in one kernel */
     VPT_K_RESOLVE = 5,
     VPT_K_BLOOM = 6,
-    VPT_K_TONEMAP = 7
+    VPT_K_TONEMAP = 7,
+    VPT_K_SHADOW = 8,   /* staged pipeline: shadow-ray streams (sky rays, light rays) traced as any-hit searches */
+    VPT_K_JOIN = 9      /* staged pipeline: NEE contributions joined with the emission, pathLight, end of sample */
 };
 
 typedef struct vpt_stats {

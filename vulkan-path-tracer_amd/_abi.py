@@ -19,8 +19,8 @@ FLAG_TONEMAP_LINEAR_BLOOM_TAP = 1 << 7
 FLAGS_DEFAULT = (FLAG_SKY_MIS | FLAG_MESH_MIS | FLAG_SHOW_ENV_DIRECTLY | FLAG_ENERGY_COMPENSATION |
                  FLAG_RAY_QUERIES | FLAG_TONEMAP_LINEAR_BLOOM_TAP)
 
-KERNEL_NAMES = ["primary", "extend", "shade", "connect", "bounce", "resolve", "bloom", "tonemap"]
-KERNEL_COUNT = 8
+KERNEL_NAMES = ["primary", "extend", "shade", "connect", "bounce", "resolve", "bloom", "tonemap", "shadow", "join"]
+KERNEL_COUNT = 10
 PIPELINE_AUTO, PIPELINE_FUSED, PIPELINE_STAGED = 0, 1, 2
 
 

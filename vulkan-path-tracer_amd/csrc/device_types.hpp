@@ -177,6 +177,39 @@ struct PathState {
     int32_t* cchan;    // payload.ColorChannel (only touched while the atmosphere is on)
 };
 
+// ---- Streams of the staged pipeline (kernels_stream.hip): records in the order the shade stage produced them, written by
+// wave-private chunked appends (vote.hpp), so every read and write of them is coalesced.
+struct StreamState {
+    // pending paths of this bounce (anything to join: emission, NEE candidates, end of sample)
+    float4* PE;   // emission / miss radiance .xyz | connect flags
+    float4* PS;   // sky NEE contribution .xyz | index of its ray in the sky-ray stream
+    float4* PL;   // light NEE contribution .xyz | index of its ray in the light-ray stream
+    float4* PT;   // pathThroughput before this bounce .xyz | slot (kHole: nobody wrote this entry)
+    // shadow rays
+    float4* SKO;  // sky rays: origin.xyz | dir.x
+    float4* SKD;  //           dir.y, dir.z, 0xffffffff (0xfffffffe: hole), -
+    float4* LTO;  // light rays: origin.xyz | dir.x
+    float4* LTD;  //           dir.y, dir.z, global id of the sampled triangle (0xfffffffe: hole), -
+    unsigned char* vis_sky;    // per sky ray: 1 = nothing hit
+    unsigned char* vis_light;  // per light ray: 1 = the closest hit is the sampled triangle
+    uint32_t cap;              // entries allocated per stream
+};
+
+// Counters of the stream pipeline.  Every word several hundred waves hit with atomics sits in its OWN 256-byte block:
+// atomics on one line serialise at ~11 ns each whichever word they address (MI355X_MICROARCH.md 'dequeue'), and the first
+// version, with four stream lengths in one line, paid ~0.15 ms per launch for it.
+struct alignas(256) HotWord {
+    uint32_t v;
+    uint32_t pad[63];
+};
+struct StreamCounters {
+    HotWord queue_len[2];   // ray queue lengths, holes included (ping-pong by bounce parity)
+    HotWord alive[2];       // exact number of live paths in queue[p]: what the host and the resolve guard look at
+    HotWord pend_len, sky_len, light_len;                // stream lengths, holes included
+    HotWord extend_head, shade_head, sky_head, light_head;  // dynamic work cursors (work beyond each wave's static first 64 entries)
+    uint32_t shade_active;  // waves of the shade grid that take part in this bounce (each owns a static first chunk of every stream)
+};
+
 // connect flags (CE.w)
 constexpr uint32_t kCF_Sky = 1u, kCF_Light = 2u, kCF_Finalize = 4u, kCF_Clamp = 8u;
 

@@ -36,12 +36,25 @@ struct TraceArgs {
     float4* hit;            // closest: t (< 0 miss), u, v | primitive; any-hit: x = 1 occluded / -1 clear
     uint32_t* hinst;        // closest: instance
     uint32_t n;
+    const uint32_t* n_dev;  // optional: the stream length lives in device memory (a queue size word); overrides n
+    uint32_t* head;         // work cursor for entries beyond the waves' static first 64 (zeroed before the launch)
     float tmin, tmax;
     uint32_t normalize_dir; // RayGen.slang:70 normalises the payload direction before tracing
     uint32_t param;         // variant parameter (vote: idle lanes that trigger a fetch step; 0 = default)
 };
 void launch_trace(hipStream_t s, uint32_t blocks, uint32_t variant, bool any, bool count, const DeviceScene& sc, const TraceArgs& a, Counters* ctr);
 int trace_blocks_per_cu(uint32_t variant, bool any);
+
+// staged pipeline on compact streams (kernels_stream.hip)
+void launch_stream_begin(hipStream_t s, StreamCounters* sc, uint32_t n_slots);
+void launch_prepare_stream(hipStream_t s, StreamCounters* sc, uint32_t parity, uint32_t shade_waves);
+void launch_shade_stream(hipStream_t s, uint32_t blocks, const DeviceScene& sc, const RenderParams& P, const PathState& ps, const StreamState& ss,
+                         const uint32_t* queue, uint32_t* queue_next, Counters* ctr, StreamCounters* sctr, uint32_t parity);
+void launch_trace_shadow(hipStream_t s, uint32_t blocks, bool light, bool count, const DeviceScene& sc, const StreamState& ss, Counters* ctr,
+                         StreamCounters* sctr, uint32_t param);
+void launch_join(hipStream_t s, uint32_t blocks, const RenderParams& P, const PathState& ps, const StreamState& ss, const StreamCounters* sctr);
+int shade_stream_blocks_per_cu();
+int trace_shadow_blocks_per_cu();
 
 // lookup-table generator (kernels_lut.hip)
 void launch_lut(hipStream_t s, int kind, float* table, uint32_t sx, uint32_t sy, uint32_t sz, uint32_t sample_count, uint32_t time_hash,

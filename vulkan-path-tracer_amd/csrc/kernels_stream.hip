@@ -1,0 +1,293 @@
+// kernels_stream.hip — the staged pipeline's shade / shadow / join stages on compact streams.
+//
+//   shade   ClosestHit.slang + Miss.slang + the visibility-independent tail of the bounce loop (shade_core.hpp), one path
+//           per lane, persistent.  What a path leaves behind goes into streams by wave-private chunked appends (vote.hpp):
+//           its slot into the next ray queue if it lives on, a pending record (emission | flags, the two NEE contributions,
+//           the pre-update throughput) if anything has to be joined, and its <= 2 shadow rays into the sky-ray and
+//           light-ray streams — so a wave of the shadow stage sees rays of ONE kind, read as coalesced 32-byte records.
+//   shadow  RTCommon.slang:47-64 as exact any-hit searches (traverse.hpp) on the vote scheduler (vote.hpp), one ray per
+//           lane job; the answer is one byte per ray.
+//   join    RayGen.slang:92-128: visible NEE contributions joined with the emission BEFORE the luminance clamp, pathLight,
+//           NaN guard and frame sum at the end of a sample.
+//
+// Path records A, B, T, L, H stay addressed by slot (a path never moves), so nothing here can change a bit of the image.
+#include "kernels.hpp"
+#include "shade_core.hpp"
+#include "vote.hpp"
+
+namespace vpt {
+
+constexpr uint32_t kRayHole = 0xfffffffeu;  // SKD.z / LTD.z of an entry nobody wrote
+
+// ------------------------------------------------------------------ shade
+__global__ __launch_bounds__(256, 3) void k_shade_stream(DeviceScene sc, RenderParams P, PathState ps, StreamState ss, const uint32_t* queue,
+                                                         uint32_t* queue_next, Counters* ctr, StreamCounters* sctr, uint32_t parity) {
+    const uint32_t n = sctr->queue_len[parity].v;
+    const uint32_t active = sctr->shade_active;   // min(waves of the grid, ceil(n / 64)), set by k_prepare_stream
+    const uint32_t gw = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (gw >= active) return;                     // this wave owns no chunk of any stream and takes no work
+    const float4* Tin = ps.T[parity];
+    float4* Tout = ps.T[parity ^ 1u];
+    const uint32_t chunk = fetch_chunk(n);
+    WaveAppender a_next, a_pend, a_sky, a_light;
+    const bool exact = n < kAppendExactBelow;     // as k_prepare_stream decided when it preset the stream lengths
+    a_next.init(gw, exact); a_pend.init(gw, exact); a_sky.init(gw, exact); a_light.init(gw, exact);
+    uint32_t w_paths = 0u, w_rays = 0u, w_pend = 0u, w_alive = 0u;  // wave totals (uniform)
+    uint32_t base = gw * 64u, span = 64u;          // the wave's static first 64 entries, then chunks through the cursor
+    while (true) {
+        for (uint32_t k = 0u; k < span; k += 64u) {
+            const uint32_t i = base + k + lane_id();
+            if (base + k >= n) break;
+            const uint32_t slot = i < n ? queue[i] : kHole;
+            const bool valid = slot != kHole;
+            bool alive = false, pending = false, want_sky = false, want_light = false;
+            ShadeOut o;
+            V3 thr_prev = v3s(0.0f);
+            if (valid) {
+                const float4 a = ps.A[slot], b = ps.B[slot], t = Tin[slot];
+                ShadeIn in_;
+                in_.h = ps.H[slot];
+                in_.inst = in_.h.x < 0.0f ? 0u : ps.hinst[slot];
+                in_.rng = __float_as_uint(a.w);
+                in_.porg = xyz(a); in_.pdir = xyz(b);
+                const uint32_t dw = __float_as_uint(b.w);
+                in_.depth = dw & 0x7fffffffu; in_.in_medium = (dw >> 31) != 0u;
+                in_.thr_prev = xyz(t); in_.prev_pdf = t.w;
+                in_.vol_index = -1; in_.vol_t = 0.0f; in_.vdepth = 0u; in_.cchan = -1; in_.atm_comp = -1;
+                shade_core<false>(sc, P, ps, slot, in_, o);
+                thr_prev = in_.thr_prev;
+                alive = o.alive; want_sky = o.want_sky; want_light = o.want_light;
+                if (alive) {
+                    ps.A[slot] = f4u(o.new_o, o.rng);
+                    ps.B[slot] = f4u(o.new_d, o.new_depth | (o.in_medium ? 0x80000000u : 0u));
+                    Tout[slot] = f4(o.thr, o.new_pdf);
+                }
+                const bool thr_finite = !isinf_(thr_prev.x) && !isinf_(thr_prev.y) && !isinf_(thr_prev.z) && !isnan_(thr_prev.x) && !isnan_(thr_prev.y) && !isnan_(thr_prev.z);
+                // 0 * inf = NaN must still reach pathLight, so a non-finite throughput always goes through the join
+                pending = want_sky || want_light || o.terminated || o.emitted.x != 0.0f || o.emitted.y != 0.0f || o.emitted.z != 0.0f || !thr_finite;
+            }
+            const uint32_t p_next = a_next.append(alive, &sctr->queue_len[parity ^ 1u].v);
+            if (alive) queue_next[p_next] = slot;
+            const uint32_t p_sky = a_sky.append(want_sky, &sctr->sky_len.v);
+            if (want_sky) {
+                ss.SKO[p_sky] = f4(o.sky_o, o.sky_d.x);
+                ss.SKD[p_sky] = make_float4(o.sky_d.y, o.sky_d.z, __uint_as_float(0xffffffffu), 0.0f);
+            }
+            const uint32_t p_light = a_light.append(want_light, &sctr->light_len.v);
+            if (want_light) {
+                ss.LTO[p_light] = f4(o.light_o, o.light_d.x);
+                ss.LTD[p_light] = make_float4(o.light_d.y, o.light_d.z, __uint_as_float(o.light_gid), 0.0f);
+            }
+            const uint32_t p_pend = a_pend.append(pending, &sctr->pend_len.v);
+            if (pending) {
+                ss.PE[p_pend] = f4u(o.emitted, o.cflags);
+                ss.PS[p_pend] = f4u(o.csky, p_sky);
+                ss.PL[p_pend] = f4u(o.clight, p_light);
+                ss.PT[p_pend] = f4u(thr_prev, slot);
+            }
+            w_paths += (uint32_t)__popcll(__ballot(valid));
+            w_alive += (uint32_t)__popcll(__ballot(alive));
+            w_rays += (uint32_t)__popcll(__ballot(want_sky)) + (uint32_t)__popcll(__ballot(want_light));
+            w_pend += (uint32_t)__popcll(__ballot(pending));
+        }
+        if (active * 64u >= n) break;
+        uint32_t nb = 0u;
+        if (lane_id() == 0u) nb = atomicAdd(&sctr->shade_head.v, chunk);
+        base = active * 64u + __builtin_amdgcn_readfirstlane(nb);
+        span = chunk;
+        if (base >= n) break;
+    }
+    // the unwritten tails of this wave's last chunks become holes
+    for (uint32_t j = lane_id(); j < a_next.tail_count(); j += 64u) queue_next[a_next.tail_first() + j] = kHole;
+    for (uint32_t j = lane_id(); j < a_pend.tail_count(); j += 64u) ss.PT[a_pend.tail_first() + j] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(kHole));
+    for (uint32_t j = lane_id(); j < a_sky.tail_count(); j += 64u) ss.SKD[a_sky.tail_first() + j] = make_float4(0.0f, 0.0f, __uint_as_float(kRayHole), 0.0f);
+    for (uint32_t j = lane_id(); j < a_light.tail_count(); j += 64u) ss.LTD[a_light.tail_first() + j] = make_float4(0.0f, 0.0f, __uint_as_float(kRayHole), 0.0f);
+    if (lane_id() == 0u) {
+        if (w_alive) atomicAdd(&sctr->alive[parity ^ 1u].v, w_alive);
+        if (w_paths) atomicAdd(&ctr->stat_closest, (unsigned long long)w_paths);
+        if (w_rays) atomicAdd(&ctr->stat_shadow, (unsigned long long)w_rays);
+        if (w_pend) atomicAdd(&ctr->stat_connect, (unsigned long long)w_pend);
+    }
+}
+
+// ------------------------------------------------------------------ shadow rays
+// LIGHT = false: visible <=> nothing is hit (ClosestHit.slang:139, 344-353).  LIGHT = true: visible <=> the closest hit is
+// the sampled triangle (ClosestHit.slang:171-176, 358-370): that triangle is tested first by its own record, then the search
+// looks for anything that beats it (traverse.hpp closest_is).
+template <bool LIGHT, bool COUNT>
+__global__ __launch_bounds__(kTraverseBlock, 8) void k_trace_shadow(DeviceScene sc, const float4* RO, const float4* RD, unsigned char* vis, const uint32_t* n_dev,
+                                                                  uint32_t* head, Counters* ctr, uint32_t param) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const LaneStack S = make_lane_stack(smem, sc.stack_overflow);
+    const BvhNode* const nodes = sc.nodes;
+    const BvhTri* const tris = sc.tris;
+    const uint32_t n = *n_dev;
+    const uint32_t chunk = fetch_chunk(n);
+    const uint32_t fetch_at = (param & 0xffu) ? (param & 0xffu) : 16u;
+    const bool weighted = ((param >> 8) & 1u) != 0u;
+    const float tmin = 0.0001f, tmax = 1000000.0f;  // RTCommon.slang:47-64
+    const uint32_t n_static = gridDim.x * (kTraverseBlock / 64u) * 64u;  // every wave starts on its own 64 entries, no atomic
+    uint32_t w_next = (blockIdx.x * (kTraverseBlock / 64u) + (threadIdx.x >> 6)) * 64u, w_end = w_next + 64u < n ? w_next + 64u : n;
+    if (w_next >= n) { w_next = 0u; w_end = 0u; }
+    bool exhausted = false;
+    int cur = kLaneIdle, sp = 0;
+    uint32_t rid = 0u, expect = 0xffffffffu;
+    bool visible = false;
+    V3 o = vptfp::v3(0.0f, 0.0f, 0.0f), d = o, inv = o;
+    float tlim = tmax;
+    uint32_t st_nodes = 0u, st_tris = 0u;
+    while (true) {
+        const bool busy = cur < kLaneDone;
+        const bool at_node = busy && cur >= 0;
+        const bool at_leaf = busy && cur < 0;
+        const uint32_t nn = (uint32_t)__popcll(__ballot(at_node)), nl = (uint32_t)__popcll(__ballot(at_leaf));
+        if (!exhausted && (64u - nn - nl >= fetch_at || nn + nl == 0u)) {
+            if (cur == kLaneDone) { vis[rid] = visible ? 1 : 0; cur = kLaneIdle; }
+            if (w_next >= w_end) {
+                if (n_static >= n) exhausted = true;
+                else {
+                    uint32_t base = 0u;
+                    if (lane_id() == 0u) base = atomicAdd(head, chunk);
+                    base = n_static + __builtin_amdgcn_readfirstlane(base);
+                    if (base >= n) exhausted = true;
+                    else { w_next = base; w_end = base + chunk < n ? base + chunk : n; }
+                }
+            }
+            if (!exhausted) {
+                const unsigned long long m_idle = __ballot(cur == kLaneIdle);
+                const uint32_t i = w_next + lanes_below(m_idle);
+                if (cur == kLaneIdle && i < w_end) {
+                    const float4 rd = RD[i];
+                    expect = __float_as_uint(rd.z);
+                    if (expect != kRayHole) {
+                        const float4 ro = RO[i];
+                        rid = i;
+                        o = vptfp::v3(ro.x, ro.y, ro.z); d = vptfp::v3(ro.w, rd.x, rd.y); inv = safe_inverse(d);
+                        tlim = tmax; visible = true;  // until an occluder / a closer triangle is found
+                        sp = 0; cur = 0;
+                        if (LIGHT) {
+                            const uint32_t slot = sc.tri_slot_of_gid[expect];
+                            bool hit_it = false;
+                            if (slot != 0xffffffffu) {  // 0xffffffff: the sampled light triangle is a sliver, nothing can hit it
+                                const float4* q = reinterpret_cast<const float4*>(tris + slot);
+                                const float4 ta = q[0], tb = q[1], tc = q[2];
+                                if (COUNT) st_tris++;
+                                float u, v;
+                                hit_it = vptfp::ray_triangle(o, d, vptfp::v3(ta.x, ta.y, ta.z), vptfp::v3(ta.w, tb.x, tb.y), vptfp::v3(tb.z, tb.w, tc.x), tmin, tmax, &tlim, &u, &v);
+                            }
+                            if (!hit_it) { visible = false; cur = kLaneDone; }
+                        }
+                    }
+                }
+                const uint32_t want = (uint32_t)__popcll(m_idle), left = w_end - w_next;
+                w_next += want < left ? want : left;
+            }
+        } else if (nn + nl == 0u) {
+            break;
+        } else if (weighted ? nn > 2u * nl : nn >= nl) {
+            if (at_node) {
+                if (COUNT) st_nodes++;
+                vote_node_step<true>(nodes, S, cur, sp, o, inv, tmin, tlim);
+            }
+        } else {
+            if (at_leaf) {
+                if (COUNT) st_tris++;
+                if (vote_tri_step_any(tris, S, cur, sp, o, d, tmin, tmax, tlim, expect)) visible = false;
+            }
+        }
+    }
+    if (cur == kLaneDone) vis[rid] = visible ? 1 : 0;
+    if (COUNT) {
+        atomicAdd(&ctr->stat_shadow_nodes, (unsigned long long)st_nodes);
+        atomicAdd(&ctr->stat_shadow_tris, (unsigned long long)st_tris);
+    }
+}
+
+// ------------------------------------------------------------------ join
+__global__ __launch_bounds__(256) void k_join(RenderParams P, PathState ps, StreamState ss, const StreamCounters* sctr) {
+    const uint32_t n = sctr->pend_len.v;
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+        const float4 pt = ss.PT[j];
+        const uint32_t sl = __float_as_uint(pt.w);
+        if (sl == kHole) continue;
+        const float4 pe = ss.PE[j];
+        const uint32_t fl = __float_as_uint(pe.w);
+        V3 E = xyz(pe);
+        if (fl & kCF_Sky) { const float4 s4 = ss.PS[j]; if (ss.vis_sky[__float_as_uint(s4.w)]) E = E + xyz(s4); }
+        if (fl & kCF_Light) { const float4 l4 = ss.PL[j]; if (ss.vis_light[__float_as_uint(l4.w)]) E = E + xyz(l4); }
+        V3 contrib = E * xyz(pt);  // RayGen.slang:92
+        if (fl & kCF_Clamp) {
+            float lum = dot(contrib, v3(0.212671f, 0.715160f, 0.072169f));
+            contrib = contrib * (P.max_luminance / max_(lum, P.max_luminance));
+        }
+        V3 light = xyz(ps.L[sl]) + contrib;
+        if (fl & kCF_Finalize) {  // end of a sample: NaN/Inf guard, frame sum (RayGen.slang:116-128)
+            bool ok = !isinf_(light.x) && !isinf_(light.y) && !isinf_(light.z) && !isnan_(light.x) && !isnan_(light.y) && !isnan_(light.z);
+            if (P.samples_per_frame == 1) {  // the only finalisation of this slot: 0 + pathLight
+                ps.ACC[sl] = ok ? f4(v3s(0.0f) + light, 0.0f) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            } else if (ok) {
+                float4 acc = ps.ACC[sl]; ps.ACC[sl] = f4(xyz(acc) + light, 0.0f);
+            }
+            light = v3s(0.0f);  // a regenerated sample starts from pathLight = 0
+        }
+        ps.L[sl] = f4(light, 0.0f);
+    }
+}
+
+// Start of a batch: the ray queue raygen filled.
+__global__ void k_stream_begin(StreamCounters* sc, uint32_t n_slots) {
+    sc->queue_len[0].v = n_slots; sc->alive[0].v = n_slots;
+    sc->queue_len[1].v = 0u; sc->alive[1].v = 0u;
+}
+// Start of a bounce: how many waves of the shade grid take part (each owns a static first chunk of every stream it appends
+// to, so the streams start at that length), cursors to zero.
+__global__ void k_prepare_stream(StreamCounters* sc, uint32_t parity, uint32_t shade_waves) {
+    const uint32_t n = sc->queue_len[parity].v;
+    const uint32_t need = (n + 63u) / 64u;
+    const uint32_t active = need < shade_waves ? need : shade_waves;
+    sc->shade_active = active;
+    // long streams: every participating wave owns a static first chunk; short ones are appended to exactly (vote.hpp)
+    sc->pend_len.v = sc->sky_len.v = sc->light_len.v = sc->queue_len[parity ^ 1u].v = n < kAppendExactBelow ? 0u : active * kAppendChunk;
+    sc->alive[parity ^ 1u].v = 0u;
+    sc->extend_head.v = 0u; sc->shade_head.v = 0u; sc->sky_head.v = 0u; sc->light_head.v = 0u;
+}
+
+// ------------------------------------------------------------------ launch
+void launch_stream_begin(hipStream_t s, StreamCounters* sc, uint32_t n_slots) { hipLaunchKernelGGL(k_stream_begin, dim3(1), dim3(1), 0, s, sc, n_slots); }
+void launch_prepare_stream(hipStream_t s, StreamCounters* sc, uint32_t parity, uint32_t shade_waves) {
+    hipLaunchKernelGGL(k_prepare_stream, dim3(1), dim3(1), 0, s, sc, parity, shade_waves);
+}
+void launch_shade_stream(hipStream_t s, uint32_t blocks, const DeviceScene& sc, const RenderParams& P, const PathState& ps, const StreamState& ss,
+                         const uint32_t* queue, uint32_t* queue_next, Counters* ctr, StreamCounters* sctr, uint32_t parity) {
+    hipLaunchKernelGGL(k_shade_stream, dim3(blocks), dim3(256), 0, s, sc, P, ps, ss, queue, queue_next, ctr, sctr, parity);
+}
+void launch_trace_shadow(hipStream_t s, uint32_t blocks, bool light, bool count, const DeviceScene& sc, const StreamState& ss, Counters* ctr,
+                         StreamCounters* sctr, uint32_t param) {
+    const size_t lds = (size_t)kStackDepth * kTraverseBlock * 4;
+    const dim3 g(blocks), b(kTraverseBlock);
+    if (light) {
+        if (count) hipLaunchKernelGGL((k_trace_shadow<true, true>), g, b, lds, s, sc, ss.LTO, ss.LTD, ss.vis_light, &sctr->light_len.v, &sctr->light_head.v, ctr, param);
+        else hipLaunchKernelGGL((k_trace_shadow<true, false>), g, b, lds, s, sc, ss.LTO, ss.LTD, ss.vis_light, &sctr->light_len.v, &sctr->light_head.v, ctr, param);
+    } else {
+        if (count) hipLaunchKernelGGL((k_trace_shadow<false, true>), g, b, lds, s, sc, ss.SKO, ss.SKD, ss.vis_sky, &sctr->sky_len.v, &sctr->sky_head.v, ctr, param);
+        else hipLaunchKernelGGL((k_trace_shadow<false, false>), g, b, lds, s, sc, ss.SKO, ss.SKD, ss.vis_sky, &sctr->sky_len.v, &sctr->sky_head.v, ctr, param);
+    }
+}
+void launch_join(hipStream_t s, uint32_t blocks, const RenderParams& P, const PathState& ps, const StreamState& ss, const StreamCounters* sctr) {
+    hipLaunchKernelGGL(k_join, dim3(blocks), dim3(256), 0, s, P, ps, ss, sctr);
+}
+int shade_stream_blocks_per_cu() {
+    int nb = 0;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_shade_stream, 256, 0);
+    return nb > 0 ? nb : 1;
+}
+int trace_shadow_blocks_per_cu() {
+    int a = 0, b = 0;
+    const size_t lds = (size_t)kStackDepth * kTraverseBlock * 4;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_trace_shadow<true, false>, kTraverseBlock, lds);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_trace_shadow<false, false>, kTraverseBlock, lds);
+    int nb = a < b ? a : b;
+    return nb > 0 ? nb : 1;
+}
+
+}  // namespace vpt

@@ -17,13 +17,11 @@
 #include "kernels.hpp"
 #include "traverse.hpp"
 #include "wave.hpp"
+#include "vote.hpp"
 
 namespace vpt {
 
 namespace {
-
-constexpr int kLaneIdle = 0x7fffffff;  // the lane holds no ray
-constexpr int kLaneDone = 0x7ffffffe;  // the lane's ray is finished, its result not yet written
 
 __device__ inline V3 xyz4(float4 v) { return vptfp::v3(v.x, v.y, v.z); }
 
@@ -50,16 +48,17 @@ __global__ __launch_bounds__(kTraverseBlock, 8) void k_trace_base(DeviceScene sc
     extern __shared__ __align__(16) unsigned char smem[];
     const TravStack stack = make_stack(smem, sc.stack_overflow);
     GlobalSceneSrc src{sc.nodes, sc.tris, false};
-    const uint32_t chunk = fetch_chunk(a.n);
+    const uint32_t n = a.n_dev ? *a.n_dev : a.n;
+    const uint32_t chunk = fetch_chunk(n);
     TravStats st; st.nodes = 0; st.tris = 0;
     while (true) {
         uint32_t base = 0;
-        if (lane_id() == 0) base = atomicAdd(&ctr->extend_head, chunk);
+        if (lane_id() == 0) base = atomicAdd(a.head, chunk);
         base = __shfl(base, 0);
-        if (base >= a.n) break;
+        if (base >= n) break;
         for (uint32_t k = 0; k < chunk; k += 64) {
             uint32_t i = base + k + lane_id();
-            if (i >= a.n) break;
+            if (i >= n) break;
             uint32_t rid; V3 o, d;
             load_ray(a, i, rid, o, d);
             if (ANY) {
@@ -82,38 +81,29 @@ __global__ __launch_bounds__(kTraverseBlock, 8) void k_trace_base(DeviceScene sc
 
 // ------------------------------------------------------------------ vote-scheduled persistent lanes
 // Lane state: `cur` >= 0 inner node to visit; < 0 leaf code ~(first << 3 | count - 1) with `first` advancing as the
-// triangles are consumed; kLaneDone / kLaneIdle.  The wave owns a chunk [w_next, w_end) of the ray stream (one atomic per
+// triangles are consumed; kLaneDone / kLaneIdle.  The wave owns a chunk [w_next, w_end) of the stream (one atomic per
 // chunk) and deals its entries to idle lanes in fetch steps.
 template <bool ANY, bool COUNT>
 __global__ __launch_bounds__(kTraverseBlock, 8) void k_trace_vote(DeviceScene sc, TraceArgs a, Counters* ctr) {
     extern __shared__ __align__(16) unsigned char smem[];
-    uint32_t* const stk = reinterpret_cast<uint32_t*>(smem) + threadIdx.x;  // entry k of this lane at stk[k * kTraverseBlock]
-    uint32_t* const ovf = sc.stack_overflow + (size_t)(blockIdx.x * blockDim.x + threadIdx.x) * kStackOverflow;
+    const LaneStack S = make_lane_stack(smem, sc.stack_overflow);
     const BvhNode* const nodes = sc.nodes;
     const BvhTri* const tris = sc.tris;
-    const uint32_t chunk = fetch_chunk(a.n);
+    const uint32_t n = a.n_dev ? *a.n_dev : a.n;
+    const uint32_t chunk = fetch_chunk(n);
     const uint32_t fetch_at = (a.param & 0xffu) ? (a.param & 0xffu) : 16u;  // idle lanes that trigger a fetch step (64: only when all are idle)
     const bool weighted = ((a.param >> 8) & 1u) != 0u;  // vote by lanes served per instruction issued: a triangle step costs about half a node step
-    uint32_t w_next = 0, w_end = 0;
+    // every wave starts on its own 64 entries without an atomic (8192 waves fetching at once would queue ~90 us on the cursor);
+    // entries beyond the grid's static part are fetched chunk-wise through the cursor
+    const uint32_t n_static = gridDim.x * (kTraverseBlock / 64u) * 64u;
+    uint32_t w_next = (blockIdx.x * (kTraverseBlock / 64u) + (threadIdx.x >> 6)) * 64u, w_end = w_next + 64u < n ? w_next + 64u : n;
+    if (w_next >= n) { w_next = 0u; w_end = 0u; }
     bool exhausted = false;
     int cur = kLaneIdle, sp = 0;
     uint32_t rid = 0, bslot = 0xffffffffu, bgid = 0xffffffffu;
     V3 o = vptfp::v3(0.0f, 0.0f, 0.0f), d = o, inv = o;
     float best_t = 0.0f, bu = 0.0f, bv = 0.0f;
     uint32_t st_nodes = 0, st_tris = 0;
-
-#define VPT_PUSH(V)                                                                                       \
-    do {                                                                                                  \
-        if (sp < kStackDepth) stk[sp * kTraverseBlock] = (uint32_t)(V);                                   \
-        else if (sp < kStackDepth + kStackOverflow) ovf[sp - kStackDepth] = (uint32_t)(V);                \
-        sp++;                                                                                             \
-    } while (0)
-#define VPT_POP_OR_DONE()                                                                                 \
-    do {                                                                                                  \
-        if (sp == 0) cur = kLaneDone;                                                                     \
-        else { sp--; cur = (int)(sp < kStackDepth ? stk[sp * kTraverseBlock] : ovf[sp - kStackDepth]); }  \
-    } while (0)
-
     while (true) {
         const bool busy = cur < kLaneDone;
         const bool at_node = busy && cur >= 0;
@@ -127,20 +117,28 @@ __global__ __launch_bounds__(kTraverseBlock, 8) void k_trace_vote(DeviceScene sc
                 cur = kLaneIdle;
             }
             if (w_next >= w_end) {
-                uint32_t base = 0;
-                if (lane_id() == 0) base = atomicAdd(&ctr->extend_head, chunk);
-                base = __builtin_amdgcn_readfirstlane(base);
-                if (base >= a.n) exhausted = true;
-                else { w_next = base; w_end = base + chunk < a.n ? base + chunk : a.n; }
+                if (n_static >= n) exhausted = true;
+                else {
+                    uint32_t base = 0;
+                    if (lane_id() == 0) base = atomicAdd(a.head, chunk);
+                    base = n_static + __builtin_amdgcn_readfirstlane(base);
+                    if (base >= n) exhausted = true;
+                    else { w_next = base; w_end = base + chunk < n ? base + chunk : n; }
+                }
             }
             if (!exhausted) {
                 const unsigned long long m_idle = __ballot(cur == kLaneIdle);
                 const uint32_t i = w_next + lanes_below(m_idle);
                 if (cur == kLaneIdle && i < w_end) {
-                    load_ray(a, i, rid, o, d);
-                    inv = safe_inverse(d);
-                    best_t = a.tmax; bslot = 0xffffffffu; bgid = 0xffffffffu;
-                    sp = 0; cur = 0;  // root
+                    rid = a.order ? a.order[i] : i;
+                    if (rid != kHole) {  // a hole: the tail of some wave's last chunk of the queue (vote.hpp WaveAppender)
+                        o = xyz4(a.ro[rid]);
+                        d = xyz4(a.rd[rid]);
+                        if (a.normalize_dir) d = vptfp::normalize(d);  // RayGen.slang:70
+                        inv = safe_inverse(d);
+                        best_t = a.tmax; bslot = 0xffffffffu; bgid = 0xffffffffu;
+                        sp = 0; cur = 0;  // root
+                    }
                 }
                 const uint32_t want = (uint32_t)__popcll(m_idle), left = w_end - w_next;
                 w_next += want < left ? want : left;
@@ -148,55 +146,15 @@ __global__ __launch_bounds__(kTraverseBlock, 8) void k_trace_vote(DeviceScene sc
         } else if (nn + nl == 0u) {
             break;
         } else if (weighted ? nn > 2u * nl : nn >= nl) {
-            // ---- inner-node step
             if (at_node) {
-                const uint4* p = reinterpret_cast<const uint4*>(nodes + cur);
-                NodeData n;
-                unpack_node(p[0], p[1], p[2], p[3], n);
                 if (COUNT) st_nodes++;
-                RaySlab slab; slab.o = o; slab.inv = inv;
-                slab.negx = inv.x < 0.0f; slab.negy = inv.y < 0.0f; slab.negz = inv.z < 0.0f;
-                float t0, t1, t2, t3;
-                node_entries(n, slab, a.tmin, best_t, t0, t1, t2, t3);
-                int c0 = n.c0, c1 = n.c1, c2 = n.c2, c3 = n.c3;
-                if (ANY) {  // order is irrelevant for an any-hit search: hit children in slot order
-                    int next = kLaneIdle;
-                    if (t3 < kMissT) next = c3;
-                    if (t2 < kMissT) { if (next != kLaneIdle) VPT_PUSH(next); next = c2; }
-                    if (t1 < kMissT) { if (next != kLaneIdle) VPT_PUSH(next); next = c1; }
-                    if (t0 < kMissT) { if (next != kLaneIdle) VPT_PUSH(next); next = c0; }
-                    if (next != kLaneIdle) cur = next; else VPT_POP_OR_DONE();
-                } else {
-                    cswap(t0, c0, t1, c1); cswap(t2, c2, t3, c3); cswap(t0, c0, t2, c2); cswap(t1, c1, t3, c3); cswap(t1, c1, t2, c2);
-                    if (t0 < kMissT) {  // nearest child next, the others pushed far -> near
-                        if (t3 < kMissT) VPT_PUSH(c3);
-                        if (t2 < kMissT) VPT_PUSH(c2);
-                        if (t1 < kMissT) VPT_PUSH(c1);
-                        cur = c0;
-                    } else {
-                        VPT_POP_OR_DONE();
-                    }
-                }
+                vote_node_step<ANY>(nodes, S, cur, sp, o, inv, a.tmin, best_t);
             }
         } else {
-            // ---- triangle step: ONE triangle of the lane's leaf
             if (at_leaf) {
-                const uint32_t enc = (uint32_t)(~cur);
-                const int first = (int)(enc >> 3);
-                const uint32_t more = enc & 7u;  // triangles left after this one
-                const float4* q = reinterpret_cast<const float4*>(tris + first);
-                const float4 ta = q[0], tb = q[1], tc = q[2];
                 if (COUNT) st_tris++;
-                float t, u, v;
-                bool stop = false;
-                if (vptfp::ray_triangle(o, d, vptfp::v3(ta.x, ta.y, ta.z), vptfp::v3(ta.w, tb.x, tb.y), vptfp::v3(tb.z, tb.w, tc.x), a.tmin, a.tmax, &t, &u, &v)) {
-                    const uint32_t gid = __float_as_uint(tc.w);
-                    if (ANY) { bslot = (uint32_t)first; stop = true; }
-                    else if (bslot == 0xffffffffu || t < best_t || (t == best_t && gid < bgid)) { best_t = t; bu = u; bv = v; bslot = (uint32_t)first; bgid = gid; }
-                }
-                if (stop) cur = kLaneDone;
-                else if (more) cur = ~(int)((((uint32_t)first + 1u) << 3) | (more - 1u));
-                else VPT_POP_OR_DONE();
+                if (ANY) { if (vote_tri_step_any(tris, S, cur, sp, o, d, a.tmin, a.tmax, a.tmax, 0xffffffffu)) bslot = 0u; }
+                else vote_tri_step_closest(tris, S, cur, sp, o, d, a.tmin, a.tmax, best_t, bu, bv, bslot, bgid);
             }
         }
     }
@@ -204,8 +162,6 @@ __global__ __launch_bounds__(kTraverseBlock, 8) void k_trace_vote(DeviceScene sc
         if (ANY) a.hit[rid] = make_float4(bslot != 0xffffffffu ? 1.0f : -1.0f, 0.0f, 0.0f, 0.0f);
         else store_closest(a, tris, rid, bslot != 0xffffffffu, best_t, bu, bv, bslot);
     }
-#undef VPT_PUSH
-#undef VPT_POP_OR_DONE
     if (COUNT) {
         atomicAdd(&ctr->stat_nodes, (unsigned long long)st_nodes);
         atomicAdd(&ctr->stat_tris, (unsigned long long)st_tris);

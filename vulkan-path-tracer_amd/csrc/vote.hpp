@@ -1,0 +1,150 @@
+// vote.hpp — building blocks of the vote-scheduled persistent traversal kernels (kernels_trace.hip, kernels_stream.hip):
+// the per-lane stack and ONE inner-node visit / ONE triangle test of a lane's ray, written so that a wave can execute a
+// single kind of step per iteration for the lanes that want it.
+#pragma once
+#include "traverse.hpp"
+#include "wave.hpp"
+
+namespace vpt {
+
+constexpr int kLaneIdle = 0x7fffffff;  // the lane holds no ray
+constexpr int kLaneDone = 0x7ffffffe;  // the lane's ray is finished, its result not yet written
+constexpr uint32_t kHole = 0xffffffffu;  // a stream entry nobody wrote (tail of a wave's last chunk, see WaveAppender)
+
+struct LaneStack {
+    uint32_t* stk;  // LDS: entry k of this lane at stk[k * kTraverseBlock]
+    uint32_t* ovf;  // global: entries beyond kStackDepth
+    __device__ __forceinline__ void push(int& sp, int v) const {
+        if (sp < kStackDepth) stk[sp * kTraverseBlock] = (uint32_t)v;
+        else if (sp < kStackDepth + kStackOverflow) ovf[sp - kStackDepth] = (uint32_t)v;
+        sp++;
+    }
+    __device__ __forceinline__ void pop_or_done(int& sp, int& cur) const {
+        if (sp == 0) cur = kLaneDone;
+        else { sp--; cur = (int)(sp < kStackDepth ? stk[sp * kTraverseBlock] : ovf[sp - kStackDepth]); }
+    }
+};
+__device__ __forceinline__ LaneStack make_lane_stack(unsigned char* smem, uint32_t* overflow) {
+    LaneStack S;
+    S.stk = reinterpret_cast<uint32_t*>(smem) + threadIdx.x;
+    S.ovf = overflow + (size_t)(blockIdx.x * blockDim.x + threadIdx.x) * kStackOverflow;
+    return S;
+}
+
+// One inner-node visit: 64 B fetch, four slab tests against [tmin, tlimit], then either the nearest hit child with the
+// others pushed far -> near (closest-hit search) or the hit children in slot order (any-hit search).
+template <bool ANY>
+__device__ __forceinline__ void vote_node_step(const BvhNode* nodes, const LaneStack& S, int& cur, int& sp, V3 o, V3 inv, float tmin, float tlimit) {
+    const uint4* p = reinterpret_cast<const uint4*>(nodes + cur);
+    NodeData n;
+    unpack_node(p[0], p[1], p[2], p[3], n);
+    RaySlab slab; slab.o = o; slab.inv = inv;
+    slab.negx = inv.x < 0.0f; slab.negy = inv.y < 0.0f; slab.negz = inv.z < 0.0f;
+    float t0, t1, t2, t3;
+    node_entries(n, slab, tmin, tlimit, t0, t1, t2, t3);
+    int c0 = n.c0, c1 = n.c1, c2 = n.c2, c3 = n.c3;
+    if (ANY) {
+        int next = kLaneIdle;
+        if (t3 < kMissT) next = c3;
+        if (t2 < kMissT) { if (next != kLaneIdle) S.push(sp, next); next = c2; }
+        if (t1 < kMissT) { if (next != kLaneIdle) S.push(sp, next); next = c1; }
+        if (t0 < kMissT) { if (next != kLaneIdle) S.push(sp, next); next = c0; }
+        if (next != kLaneIdle) cur = next; else S.pop_or_done(sp, cur);
+    } else {
+        cswap(t0, c0, t1, c1); cswap(t2, c2, t3, c3); cswap(t0, c0, t2, c2); cswap(t1, c1, t3, c3); cswap(t1, c1, t2, c2);
+        if (t0 < kMissT) {
+            if (t3 < kMissT) S.push(sp, c3);
+            if (t2 < kMissT) S.push(sp, c2);
+            if (t1 < kMissT) S.push(sp, c1);
+            cur = c0;
+        } else {
+            S.pop_or_done(sp, cur);
+        }
+    }
+}
+// One triangle of the lane's leaf, closest-hit search (ties in t -> smaller global id).
+__device__ __forceinline__ void vote_tri_step_closest(const BvhTri* tris, const LaneStack& S, int& cur, int& sp, V3 o, V3 d, float tmin, float tmax,
+                                                      float& best_t, float& bu, float& bv, uint32_t& bslot, uint32_t& bgid) {
+    const uint32_t enc = (uint32_t)(~cur);
+    const int first = (int)(enc >> 3);
+    const uint32_t more = enc & 7u;  // triangles left after this one
+    const float4* q = reinterpret_cast<const float4*>(tris + first);
+    const float4 ta = q[0], tb = q[1], tc = q[2];
+    float t, u, v;
+    if (vptfp::ray_triangle(o, d, vptfp::v3(ta.x, ta.y, ta.z), vptfp::v3(ta.w, tb.x, tb.y), vptfp::v3(tb.z, tb.w, tc.x), tmin, tmax, &t, &u, &v)) {
+        const uint32_t gid = __float_as_uint(tc.w);
+        if (bslot == 0xffffffffu || t < best_t || (t == best_t && gid < bgid)) { best_t = t; bu = u; bv = v; bslot = (uint32_t)first; bgid = gid; }
+    }
+    if (more) cur = ~(int)((((uint32_t)first + 1u) << 3) | (more - 1u));
+    else S.pop_or_done(sp, cur);
+}
+// One triangle of the lane's leaf, any-hit search: stops at the first triangle hit with t < tlim, or t == tlim and a
+// smaller global id than `expect` (traverse.hpp: with tlim = tmax this is plain occlusion; with tlim = t_e of the sampled
+// light triangle it decides "is the closest hit that triangle").  Returns true when the search is over.
+__device__ __forceinline__ bool vote_tri_step_any(const BvhTri* tris, const LaneStack& S, int& cur, int& sp, V3 o, V3 d, float tmin, float tmax,
+                                                  float tlim, uint32_t expect) {
+    const uint32_t enc = (uint32_t)(~cur);
+    const int first = (int)(enc >> 3);
+    const uint32_t more = enc & 7u;
+    const float4* q = reinterpret_cast<const float4*>(tris + first);
+    const float4 ta = q[0], tb = q[1], tc = q[2];
+    float t, u, v;
+    if (vptfp::ray_triangle(o, d, vptfp::v3(ta.x, ta.y, ta.z), vptfp::v3(ta.w, tb.x, tb.y), vptfp::v3(tb.z, tb.w, tc.x), tmin, tmax, &t, &u, &v)) {
+        const uint32_t gid = __float_as_uint(tc.w);
+        if (t < tlim || (t == tlim && gid < expect)) { cur = kLaneDone; return true; }
+    }
+    if (more) cur = ~(int)((((uint32_t)first + 1u) << 3) | (more - 1u));
+    else S.pop_or_done(sp, cur);
+    return false;
+}
+
+
+// Wave-private chunked append to a stream in global memory.  A wave owns a STATIC first chunk (its index in the grid picks it:
+// no atomic, so thousands of waves starting together do not queue on the stream counter) and reserves further chunks of
+// kAppendChunk entries with ONE atomic each; lanes get their entries by ballot prefix, and an append may straddle two chunks.
+// The only unwritten entries of a stream are therefore the tail of each participating wave's LAST chunk, which the wave marks
+// as holes when it is done (consumers skip them).  The stream counter, preset to waves x kAppendChunk, holds the stream's
+// LENGTH (holes included); every write lands in a 256-entry run owned by one wave.
+constexpr uint32_t kAppendChunk = 256;
+// Short streams are appended to EXACTLY instead (one atomic per wave per append, no holes at all): with fewer than
+// kAppendExactBelow entries to process a launch issues at most ~30 k such atomics per stream, while chunk tails of several
+// thousand waves would outnumber the entries themselves.
+constexpr uint32_t kAppendExactBelow = 1u << 21;
+struct WaveAppender {
+    uint32_t base, used;  // wave-uniform
+    bool exact;
+    __device__ __forceinline__ void init(uint32_t wave_in_grid, bool exact_mode) {
+        exact = exact_mode;
+        base = exact_mode ? 0u : wave_in_grid * kAppendChunk;
+        used = exact_mode ? kAppendChunk : 0u;   // exact mode owns no chunk: tail_count() == 0
+    }
+    // every lane of the wave calls; returns the entry index for lanes with pred
+    __device__ __forceinline__ uint32_t append(bool pred, uint32_t* counter) {
+        const unsigned long long m = __ballot(pred);
+        const uint32_t cnt = (uint32_t)__popcll(m), off = lanes_below(m);
+        if (exact) {
+            uint32_t nb = 0u;
+            if (cnt) {
+                if (lane_id() == 0u) nb = atomicAdd(counter, cnt);
+                nb = __builtin_amdgcn_readfirstlane(nb);
+            }
+            return nb + off;
+        }
+        const uint32_t room = kAppendChunk - used;
+        uint32_t pos;
+        if (cnt <= room) { pos = base + used + off; used += cnt; }
+        else {
+            uint32_t nb = 0u;
+            if (lane_id() == 0u) nb = atomicAdd(counter, kAppendChunk);
+            nb = __builtin_amdgcn_readfirstlane(nb);
+            pos = off < room ? base + used + off : nb + (off - room);
+            base = nb; used = cnt - room;
+        }
+        return pos;
+    }
+    // entries [tail_first(), tail_first() + tail_count()) of the wave's last chunk were never written
+    __device__ __forceinline__ uint32_t tail_first() const { return base + used; }
+    __device__ __forceinline__ uint32_t tail_count() const { return kAppendChunk - used; }
+};
+
+}  // namespace vpt

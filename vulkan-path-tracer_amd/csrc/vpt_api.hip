@@ -61,6 +61,10 @@ struct vpt_ctx {
     PathState ps{};
     uint32_t* queue[2] = {nullptr, nullptr};
     uint32_t* cqueue = nullptr;  // connect queue (two-ended)
+    void* ss_block = nullptr;    // stream records of the staged pipeline (kernels_stream.hip)
+    StreamState ss{};
+    uint32_t stream_slack = 0;   // entries a stream may hold beyond its true count: unwritten chunk tails (vote.hpp WaveAppender)
+    int shade_stream_blocks = 768, shadow_blocks = 2048;
     // AUTO pipeline on a scene whose BVH does not fit LDS: the first four full batches are timed, staged and fused
     // alternating (both produce identical bits; the first of each also pays its kernels' one-time load), and the
     // pipeline with the smaller minimum is kept until the scene, size or params change.
@@ -74,7 +78,10 @@ struct vpt_ctx {
     double tune_ms[2] = {1e30, 1e30};
     uint32_t* d_launch_off = nullptr;  // split-screen: launch-grid prefix sums of the dispatches of a batch
     int shade_blocks = 1024, primary_blocks = 768, max_blocks = 1536;
+    int vote_blocks = 2048;   // persistent grid of the vote-scheduled traversal kernels
+    uint32_t vote_param = 256u + 16u;  // weighted vote, fetch step at 16 idle lanes (profiles/r02_trace_lab_*.json)
     Counters* ctr = nullptr;
+    StreamCounters* sctr = nullptr;   // stream pipeline: lengths, exact live counts and work cursors, one cache line each
     float* image = nullptr;       // this shard's rows, RGBA32F
     float* full_image = nullptr;  // whole image when shard_count > 1 (after vpt_assemble_shards)
     bool full_valid = false;
@@ -139,6 +146,8 @@ void free_render_buffers(vpt_ctx* c) {
     for (int i = 0; i < 2; i++) { if (c->queue[i]) (void)hipFree(c->queue[i]); c->queue[i] = nullptr; }
     if (c->cqueue) (void)hipFree(c->cqueue);
     c->cqueue = nullptr;
+    if (c->ss_block) (void)hipFree(c->ss_block);
+    c->ss_block = nullptr;
     if (c->image) (void)hipFree(c->image);
     c->image = nullptr;
     if (c->full_image) (void)hipFree(c->full_image);
@@ -205,8 +214,21 @@ int alloc_render_buffers_impl(vpt_ctx* c) {
     if (k != kRecords) return fail(c, VPT_ERR_DEVICE, "internal: path state carve mismatch");
     uint32_t* wb = (uint32_t*)(rb + stride * kRecords);
     s.hinst = wb; s.maniso = (float*)(wb + stride); s.sidx = wb + stride * 2; s.vdepth = wb + stride * 3; s.cchan = (int32_t*)(wb + stride * 4);
-    for (int i = 0; i < 2; i++) HIPCHK(c, hipMalloc((void**)&c->queue[i], (size_t)cap * 4));
+    // streams written by chunked appends hold up to one unwritten chunk tail per wave that appended to them: at most
+    // 256 entries per 64 items processed, and never more than one per resident wave of the largest persistent grid
+    c->stream_slack = (uint32_t)std::min<uint64_t>((uint64_t)cap * 4 + 256, (uint64_t)8192 * 4 * 256);
+    const size_t scap = (size_t)cap + c->stream_slack;
+    for (int i = 0; i < 2; i++) HIPCHK(c, hipMalloc((void**)&c->queue[i], scap * 4));
     HIPCHK(c, hipMalloc((void**)&c->cqueue, (size_t)cap * 4));
+    {
+        const size_t sst = (scap + 63) & ~(size_t)63;
+        HIPCHK(c, hipMalloc(&c->ss_block, sst * (16 * 8 + 2)));
+        float4* q = (float4*)c->ss_block;
+        StreamState& t = c->ss;
+        t.PE = q; t.PS = q + sst; t.PL = q + 2 * sst; t.PT = q + 3 * sst; t.SKO = q + 4 * sst; t.SKD = q + 5 * sst; t.LTO = q + 6 * sst; t.LTD = q + 7 * sst;
+        t.vis_sky = (unsigned char*)(q + 8 * sst); t.vis_light = t.vis_sky + sst;
+        t.cap = (uint32_t)scap;
+    }
     // padded to the largest shard's row count (vpt_shard_floats): the buffer is handed to ncclGather as it is
     const size_t image_bytes = (size_t)shard_rows_of(P.height, 0, P.shard_count) * P.width * 16;
     HIPCHK(c, hipMalloc((void**)&c->image, image_bytes));
@@ -359,6 +381,8 @@ int render_batch(vpt_ctx* c, uint32_t frames, uint32_t dispatch_base) {
         TIMED(c, VPT_K_PRIMARY, launch_raygen(s, c->P, c->ps, c->queue[0], c->ctr, n_slots, dispatch_base));
         parity = 0;
     }
+    const bool stream = !fused && !c->lds_scene && !c->dsc.strict_hits && c->cfg.pipeline != VPT_PIPELINE_STAGED_R1;
+    if (stream) launch_stream_begin(s, c->sctr, n_slots);
     const uint64_t min_bounces = (uint64_t)c->P.max_depth * c->P.samples_per_frame;
     const uint64_t iter_cap = min_bounces * 4ull + 1024ull;
     uint64_t iter = 0;
@@ -370,6 +394,23 @@ int render_batch(vpt_ctx* c, uint32_t frames, uint32_t dispatch_base) {
                 parity ^= 1u; k3 = (k3 + 1u) % 3u;
                 continue;
             }
+            // a memory-resident BVH runs the staged pipeline on the vote-scheduled traversal kernels and compact streams
+            // (kernels_trace.hip, kernels_stream.hip); round 1's stage kernels serve LDS-resident scenes forced into the staged
+            // pipeline, VPT_FLAG_LOCAL_HITS and VPT_PIPELINE_STAGED_R1
+            if (stream) {   // stream pipeline: extend -> shade (streams out) -> sky rays, light rays -> join
+                launch_prepare_stream(s, c->sctr, parity, (uint32_t)c->shade_stream_blocks * 4u);
+                TraceArgs a{};
+                a.ro = c->ps.A; a.rd = c->ps.B; a.order = c->queue[parity]; a.hit = c->ps.H; a.hinst = c->ps.hinst;
+                a.n = 0; a.n_dev = &c->sctr->queue_len[parity].v; a.head = &c->sctr->extend_head.v;
+                a.tmin = 0.01f; a.tmax = 100000.0f; a.normalize_dir = 1u; a.param = c->vote_param;
+                TIMED(c, VPT_K_EXTEND, launch_trace(s, (uint32_t)c->vote_blocks, VPT_TRACE_VOTE, false, count, c->dsc, a, c->ctr));
+                TIMED(c, VPT_K_SHADE, launch_shade_stream(s, (uint32_t)c->shade_stream_blocks, c->dsc, c->P, c->ps, c->ss, c->queue[parity], c->queue[parity ^ 1u], c->ctr, c->sctr, parity));
+                TIMED(c, VPT_K_SHADOW, launch_trace_shadow(s, (uint32_t)c->shadow_blocks, false, count, c->dsc, c->ss, c->ctr, c->sctr, c->vote_param));
+                TIMED(c, VPT_K_SHADOW, launch_trace_shadow(s, (uint32_t)c->shadow_blocks, true, count, c->dsc, c->ss, c->ctr, c->sctr, c->vote_param));
+                TIMED(c, VPT_K_JOIN, launch_join(s, (uint32_t)c->shade_blocks, c->P, c->ps, c->ss, c->sctr));
+                parity ^= 1u;
+                continue;
+            }
             launch_prepare(s, c->ctr, parity);
             TIMED(c, VPT_K_EXTEND, launch_extend(s, (uint32_t)c->trav_blocks, c->lds_scene, count, c->dsc, c->ps, c->queue[parity], c->ctr, parity));
             TIMED(c, VPT_K_SHADE, launch_shade(s, (uint32_t)c->shade_blocks, c->dsc, c->P, c->ps, c->queue[parity], c->queue[parity ^ 1u], c->cqueue, c->ctr, parity));
@@ -377,10 +418,10 @@ int render_batch(vpt_ctx* c, uint32_t frames, uint32_t dispatch_base) {
             parity ^= 1u;
         }
         iter += chunk;
-        if (!fused) launch_fold(s, c->ctr);
+        if (!fused && !stream) launch_fold(s, c->ctr);
         // the resolve rides right behind the bounces that are expected to be the last ones; it does nothing if a path is
         // still alive (in-medium walks do not consume depth), in which case more bounces and another resolve follow
-        const uint32_t* guard = fused ? &c->ctr->rc3[k3] : &c->ctr->ray_count[parity];
+        const uint32_t* guard = fused ? &c->ctr->rc3[k3] : stream ? &c->sctr->alive[parity].v : &c->ctr->ray_count[parity];
         TIMED(c, VPT_K_RESOLVE, launch_resolve(s, c->P, c->ps, c->image, frames, dispatch_base, guard));
         Counters h{};
         HIPCHK(c, hipMemcpyAsync(&h, c->ctr, sizeof(Counters), hipMemcpyDeviceToHost, s));
@@ -397,6 +438,12 @@ int render_batch(vpt_ctx* c, uint32_t frames, uint32_t dispatch_base) {
         c->stats.shadow_nodes_visited = h.stat_shadow_nodes;
         c->stats.shadow_tris_tested = h.stat_shadow_tris;
         uint32_t n = fused ? h.rc3[k3] : h.ray_count[parity];
+        if (stream) {  // the exact number of live paths; the queue length (holes included) must fit the queue allocation
+            uint32_t len = 0;
+            HIPCHK(c, hipMemcpy(&n, &c->sctr->alive[parity].v, 4, hipMemcpyDeviceToHost));
+            HIPCHK(c, hipMemcpy(&len, &c->sctr->queue_len[parity].v, 4, hipMemcpyDeviceToHost));
+            if ((uint64_t)len > (uint64_t)c->ps.capacity + c->stream_slack) return fail(c, VPT_ERR_DEVICE, "internal: stream overflow");
+        }
         if (n > n_slots) return fail(c, VPT_ERR_DEVICE, "internal: queue overflow");
         if (n == 0) break;
         if (iter > iter_cap) return fail(c, VPT_ERR_DEVICE, "internal: bounce loop did not terminate");
@@ -446,7 +493,7 @@ void vpt_default_post_params(vpt_post_params* p) {  // PostProcessor.h:8-21
 
 vpt_ctx* vpt_create(const vpt_config* cfg, int* err) {
     auto set = [&](int e) { if (err) *err = e; };
-    if (!cfg || cfg->width == 0 || cfg->height == 0 || cfg->shard_count == 0 || cfg->shard_rank >= cfg->shard_count || cfg->pipeline > VPT_PIPELINE_STAGED) { set(VPT_ERR_INVALID_ARGUMENT); return nullptr; }
+    if (!cfg || cfg->width == 0 || cfg->height == 0 || cfg->shard_count == 0 || cfg->shard_rank >= cfg->shard_count || cfg->pipeline > VPT_PIPELINE_STAGED_R1) { set(VPT_ERR_INVALID_ARGUMENT); return nullptr; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev) { set(VPT_ERR_NO_DEVICE); return nullptr; }
     if (hipSetDevice(cfg->device) != hipSuccess) { set(VPT_ERR_NO_DEVICE); return nullptr; }
@@ -458,6 +505,8 @@ vpt_ctx* vpt_create(const vpt_config* cfg, int* err) {
         set(VPT_ERR_DEVICE); delete c; return nullptr;
     }
     (void)hipMemset(c->ctr, 0, sizeof(Counters));
+    if (hipMalloc((void**)&c->sctr, sizeof(StreamCounters)) != hipSuccess) { set(VPT_ERR_DEVICE); vpt_destroy(c); return nullptr; }
+    (void)hipMemset(c->sctr, 0, sizeof(StreamCounters));
     if (hipMalloc((void**)&c->d_launch_off, 257 * 4) != hipSuccess) { set(VPT_ERR_DEVICE); vpt_destroy(c); return nullptr; }
     vpt_default_params(&c->params);
     const float id[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
@@ -478,6 +527,7 @@ void vpt_destroy(vpt_ctx* c) {
     free_scene(c);
     free_render_buffers(c);
     if (c->ctr) (void)hipFree(c->ctr);
+    if (c->sctr) (void)hipFree(c->sctr);
     if (c->d_launch_off) (void)hipFree(c->d_launch_off);
     if (c->d_volumes) (void)hipFree(c->d_volumes);
     for (DensityGrid& g : c->grids) { (void)hipFree((void*)g.values); (void)hipFree((void*)g.block_max); }
@@ -639,8 +689,11 @@ int vpt_set_scene(vpt_ctx* c, const vpt_scene_desc* sd) {
     c->trav_blocks = traverse_blocks_per_cu(c->lds_scene, D) * c->cu_count;
     c->shade_blocks = shade_blocks_per_cu() * c->cu_count;
     c->primary_blocks = bounce_blocks_per_cu(c->lds_scene, D) * c->cu_count;
+    c->shade_stream_blocks = shade_stream_blocks_per_cu() * c->cu_count;
+    c->shadow_blocks = trace_shadow_blocks_per_cu() * c->cu_count;
+    c->vote_blocks = std::min(trace_blocks_per_cu(VPT_TRACE_VOTE, false), trace_blocks_per_cu(VPT_TRACE_VOTE, true)) * c->cu_count;
     {   // per-thread overflow region of the traversal stacks, for the largest persistent grid launched
-        c->max_blocks = std::max(std::max(c->trav_blocks, c->shade_blocks), c->primary_blocks);
+        c->max_blocks = std::max(std::max(std::max(std::max(c->trav_blocks, c->shade_blocks), c->primary_blocks), c->vote_blocks), std::max(c->shade_stream_blocks, c->shadow_blocks));
         void* d = nullptr;
         HIPCHK(c, hipMalloc(&d, stack_overflow_bytes((uint32_t)c->max_blocks)));
         c->scene_allocs.push_back(d);
@@ -715,7 +768,7 @@ int vpt_set_params(vpt_ctx* c, const vpt_params* p) {
 int vpt_set_volumes(vpt_ctx* c, const vpt_volume* v, uint32_t count) {
     if (!c || (count && !v)) return VPT_ERR_INVALID_ARGUMENT;
     if (count > VPT_MAX_VOLUMES) return fail(c, VPT_ERR_LIMIT, "more than VPT_MAX_VOLUMES volumes");
-    if (count && c->cfg.pipeline == VPT_PIPELINE_STAGED) return fail(c, VPT_ERR_UNSUPPORTED, "volumes run on the fused pipeline (use VPT_PIPELINE_AUTO or _FUSED)");
+    if (count && c->cfg.pipeline >= VPT_PIPELINE_STAGED) return fail(c, VPT_ERR_UNSUPPORTED, "volumes run on the fused pipeline (use VPT_PIPELINE_AUTO or _FUSED)");
     for (uint32_t i = 0; i < count; i++) {
         if (v[i].density_data_index < -1 || v[i].density_data_index >= (int)c->grids.size())
             return fail(c, VPT_ERR_INVALID_ARGUMENT, "density_data_index must be -1 or an index returned by vpt_add_density_grid");
@@ -790,7 +843,7 @@ void vpt_default_atmosphere(vpt_atmosphere* a) {  // PathTracer.h:222-232
 }
 int vpt_set_atmosphere(vpt_ctx* c, const vpt_atmosphere* a) {
     if (!c) return VPT_ERR_INVALID_ARGUMENT;
-    if (a && c->cfg.pipeline == VPT_PIPELINE_STAGED) return fail(c, VPT_ERR_UNSUPPORTED, "the atmosphere runs on the fused pipeline (use VPT_PIPELINE_AUTO or _FUSED)");
+    if (a && c->cfg.pipeline >= VPT_PIPELINE_STAGED) return fail(c, VPT_ERR_UNSUPPORTED, "the atmosphere runs on the fused pipeline (use VPT_PIPELINE_AUTO or _FUSED)");
     if (a && (!(a->planet_radius > 0.0f) || !(a->atmosphere_height > 0.0f) || !(a->rayleigh_density_falloff > 0.0f) || !(a->mie_density_falloff > 0.0f) ||
               !(a->ozone_density_falloff > 0.0f)))
         return fail(c, VPT_ERR_INVALID_ARGUMENT, "planet radius, atmosphere height and the density falloffs must be > 0");
@@ -1115,7 +1168,7 @@ int vpt_lab_trace(vpt_ctx* c, uint32_t variant, uint32_t any_hit, const uint32_t
     if (order) HIPCHK(c, hipMemcpy(c->lab_order, order, (size_t)n * 4, hipMemcpyHostToDevice));
     TraceArgs a{};
     a.ro = c->lab_ro; a.rd = c->lab_rd; a.order = order ? c->lab_order : nullptr; a.hit = c->lab_hit; a.hinst = c->lab_hinst;
-    a.n = n; a.tmin = c->lab_tmin; a.tmax = c->lab_tmax; a.normalize_dir = 0u; a.param = param;
+    a.n = n; a.head = &c->ctr->extend_head; a.tmin = c->lab_tmin; a.tmax = c->lab_tmax; a.normalize_dir = 0u; a.param = param;
     const uint32_t blocks = (uint32_t)std::min(trace_blocks_per_cu(variant, any_hit != 0) * c->cu_count, c->max_blocks);
     hipEvent_t e0, e1;
     HIPCHK(c, hipEventCreate(&e0)); HIPCHK(c, hipEventCreate(&e1));
