@@ -179,6 +179,9 @@ typedef struct vpt_config {
 #define VPT_PIPELINE_AUTO 0u
 #define VPT_PIPELINE_FUSED 1u   /* one kernel per bounce */
 #define VPT_PIPELINE_STAGED 2u  /* extend -> shade -> connect with compacted queues; traversal on the vote-scheduled persistent kernels */
+#define VPT_PIPELINE_STAGED_SORTED 4u /* STAGED with the shade queue sorted by material class (miss | plain | textured | glass | emissive),
+                                       * one shade launch per class, the miss and plain ones specialised.  Bit-identical; measured
+                                       * 10-14 % SLOWER than STAGED on the BASELINE scenes, so AUTO never picks it */
 #define VPT_PIPELINE_STAGED_R1 3u /* the same stages with round 1's traversal loops (64 rays per wave at a time): kept as the measured baseline */
 
 #define VPT_KERNEL_COUNT 10

@@ -25,7 +25,7 @@ def oracle_image(oracle, sc, w, h, params, frames):
     return ref
 
 
-@pytest.mark.parametrize("pipeline", [1, 2, 3])   # fused, staged (vote-scheduled traversal), staged with round 1's traversal loops
+@pytest.mark.parametrize("pipeline", [1, 2, 3, 4])   # fused, staged (streams + vote-scheduled traversal), round 1's stage kernels, staged + shade queue sorted by material class
 def test_config3_atrium_exact_at_320x180(vpt, oracle, atrium, pipeline):
     assert 0.95 * 250_000 <= atrium.triangle_count() <= 1.05 * 250_000   # 250 k +- 5 %
     P = vpt.default_params(max_depth=8)
@@ -37,7 +37,7 @@ def test_config3_atrium_exact_at_320x180(vpt, oracle, atrium, pipeline):
     assert 0.99 * atrium.triangle_count() <= st["bvh_triangles"] < atrium.triangle_count()   # the generator emits a few exact slivers; they are dropped
 
 
-@pytest.mark.parametrize("pipeline", [1, 2, 3])
+@pytest.mark.parametrize("pipeline", [1, 2, 3, 4])
 def test_config5_glass_bust_exact_at_320x180_depth32(vpt, oracle, bust, pipeline):
     P = vpt.default_params(max_depth=32)
     ref = oracle_image(oracle, bust, 320, 180, P, 2)
@@ -52,12 +52,12 @@ def test_config5_glass_bust_exact_at_320x180_depth32(vpt, oracle, bust, pipeline
 def test_config3_atrium_1080p_pipelines_and_shards_agree(vpt, atrium):
     P = vpt.default_params(max_depth=8)
     imgs = []
-    for pipeline in (2, 1, 3, 0):        # staged, fused, staged with round 1's traversal, AUTO (times both, keeps the faster)
+    for pipeline in (2, 1, 3, 4, 0):     # staged, fused, round 1's stage kernels, staged + class sort, AUTO (times both, keeps the faster)
         g = vpt.PathTracer(1920, 1080, pipeline=pipeline, frames_in_flight=4); g.set_scene(atrium); g.set_params(P); g.render(4 if pipeline else 20)
         if pipeline == 0:
             g.reset(); g.render(4)       # after the tuning batches
         imgs.append(g.radiance()); g.close()
-    assert np.array_equal(imgs[0], imgs[1]) and np.array_equal(imgs[0], imgs[2]) and np.array_equal(imgs[0], imgs[3])
+    assert all(np.array_equal(imgs[0], im) for im in imgs[1:])
     assert np.isfinite(imgs[0]).all() and imgs[0][..., :3].mean() > 0.01
     hip = C.CDLL("libamdhip64.so")
     parts = []

@@ -126,6 +126,7 @@ struct DeviceScene {
     const EmissiveTri* emissive_tri;        // per emissive triangle
     const uint32_t* emissive_tri_offset;    // per emissive mesh: first entry in emissive_tri
     const uint32_t* tri_slot_of_gid;        // per global triangle id: position in the leaf-ordered triangle array
+    const unsigned char* inst_class;        // per instance: shade class of its material (kShade*), the sort key of the shade queues
     uint32_t* stack_overflow;               // traversal stack entries beyond the LDS part, kStackOverflow per resident thread
     const vpt_volume* volumes;              // uVolumes (Volume.slang:9); volume_count == 0: none
     uint32_t volume_count, phase;           // PHASE_FUNCTION_* (PathTracer.h:76-81)
@@ -202,12 +203,26 @@ struct alignas(256) HotWord {
     uint32_t v;
     uint32_t pad[63];
 };
+// Shade classes: the key the staged pipeline sorts its shade queue by (one queue and one shade launch per class, so a wave
+// shades paths of ONE class).  The reference gets this grouping from hit-group / miss-shader dispatch
+// (ClosestHit.slang:20, Miss.slang:8).  kShadePlain promises what its kernel instantiation relies on: every value texture
+// and the normal map of the material are 1x1 (MatResolved.flags == 3), so no texel is ever fetched; the other hit classes
+// run the general closest-hit code and differ only in what their waves have in common.
+constexpr uint32_t kShadeMiss = 0, kShadePlain = 1, kShadeTextured = 2, kShadeGlass = 3, kShadeEmissive = 4, kShadeClasses = 5;
+constexpr int kShadeAny = -1;  // template value: no class knowledge (fused kernels, round-1 shade stage)
+
 struct StreamCounters {
     HotWord queue_len[2];   // ray queue lengths, holes included (ping-pong by bounce parity)
     HotWord alive[2];       // exact number of live paths in queue[p]: what the host and the resolve guard look at
     HotWord pend_len, sky_len, light_len;                // stream lengths, holes included
     HotWord extend_head, shade_head, sky_head, light_head;  // dynamic work cursors (work beyond each wave's static first 64 entries)
-    uint32_t shade_active;  // waves of the shade grid that take part in this bounce (each owns a static first chunk of every stream)
+    // per shade class (filled by the extend stage's retire step, laid out by k_prepare_classes)
+    HotWord class_len[kShadeClasses];    // class queue lengths (dense: the classify step writes no holes)
+    HotWord class_head[kShadeClasses];   // shade work cursors
+    uint32_t class_active[kShadeClasses];   // waves of the shade grid that take part in the class's launch
+    uint32_t class_exact[kShadeClasses];    // 1: the launch appends exactly (short queue), 0: chunked with static first chunks
+    uint32_t class_base[kShadeClasses];     // first entry of the launch's static chunks in every stream it appends to
+    uint32_t classify_done;                 // blocks of the classify launch that have finished (the last one lays the streams out)
 };
 
 // connect flags (CE.w)

@@ -41,15 +41,19 @@ struct TraceArgs {
     float tmin, tmax;
     uint32_t normalize_dir; // RayGen.slang:70 normalises the payload direction before tracing
     uint32_t param;         // variant parameter (vote: idle lanes that trigger a fetch step; 0 = default)
+    unsigned char* cls;     // closest-hit only, optional: per queue entry, the shade class of what the ray hit (kShade*; 0xff for a hole)
 };
 void launch_trace(hipStream_t s, uint32_t blocks, uint32_t variant, bool any, bool count, const DeviceScene& sc, const TraceArgs& a, Counters* ctr);
 int trace_blocks_per_cu(uint32_t variant, bool any);
 
 // staged pipeline on compact streams (kernels_stream.hip)
 void launch_stream_begin(hipStream_t s, StreamCounters* sc, uint32_t n_slots);
-void launch_prepare_stream(hipStream_t s, StreamCounters* sc, uint32_t parity, uint32_t shade_waves);
-void launch_shade_stream(hipStream_t s, uint32_t blocks, const DeviceScene& sc, const RenderParams& P, const PathState& ps, const StreamState& ss,
+void launch_prepare_stream(hipStream_t s, StreamCounters* sc, uint32_t parity);
+void launch_classify(hipStream_t s, const uint32_t* queue, const unsigned char* cls, uint32_t* const* class_queue, StreamCounters* sc, uint32_t parity, uint32_t max_entries, uint32_t shade_waves);
+void launch_layout_single(hipStream_t s, StreamCounters* sc, uint32_t parity, uint32_t shade_waves);
+void launch_shade_stream(hipStream_t s, uint32_t blocks, uint32_t cls, bool sorted, const DeviceScene& sc, const RenderParams& P, const PathState& ps, const StreamState& ss,
                          const uint32_t* queue, uint32_t* queue_next, Counters* ctr, StreamCounters* sctr, uint32_t parity);
+void launch_classify_instances(hipStream_t s, const DeviceScene& sc, unsigned char* out, uint32_t n);
 void launch_trace_shadow(hipStream_t s, uint32_t blocks, bool light, bool count, const DeviceScene& sc, const StreamState& ss, Counters* ctr,
                          StreamCounters* sctr, uint32_t param);
 void launch_join(hipStream_t s, uint32_t blocks, const RenderParams& P, const PathState& ps, const StreamState& ss, const StreamCounters* sctr);

@@ -638,6 +638,24 @@ __global__ __launch_bounds__(256) void k_precompute_emissive(DeviceScene sc, Emi
     emissive_tri_compute(sc, sc.emissive[k], i - sc.emissive_tri_offset[k], t);
     out[i] = t;
 }
+// Shade class of every instance (device_types.hpp kShade*), from the resolved material table.
+__global__ __launch_bounds__(256) void k_classify_instances(DeviceScene sc, unsigned char* out, uint32_t n) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t mi = sc.instances[i].material;
+    const vpt_material& m = sc.materials[mi];
+    const MatResolved& r = sc.mat_resolved[mi];
+    const bool emissive = (r.flags & 1u) ? (r.emissive[0] > 0.0f || r.emissive[1] > 0.0f || r.emissive[2] > 0.0f)
+                                         : (m.emissive_color[0] != 0.0f || m.emissive_color[1] != 0.0f || m.emissive_color[2] != 0.0f);
+    uint32_t c = kShadeTextured;
+    if (emissive) c = kShadeEmissive;
+    else if (m.transmission > 0.0f) c = kShadeGlass;
+    else if ((r.flags & 3u) == 3u) c = kShadePlain;   // the promise k_shade_stream<kShadePlain> relies on: no texture of this material is ever sampled
+    out[i] = (unsigned char)c;
+}
+void launch_classify_instances(hipStream_t s, const DeviceScene& sc, unsigned char* out, uint32_t n) {
+    if (n) hipLaunchKernelGGL(k_classify_instances, dim3((n + 255) / 256), dim3(256), 0, s, sc, out, n);
+}
 void launch_precompute_materials(hipStream_t s, const DeviceScene& sc, uint32_t flags, MatResolved* out, uint32_t n) {
     if (n) hipLaunchKernelGGL(k_precompute_materials, dim3((n + 255) / 256), dim3(256), 0, s, sc, flags, out, n);
 }

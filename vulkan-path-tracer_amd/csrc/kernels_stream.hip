@@ -19,19 +19,96 @@ namespace vpt {
 
 constexpr uint32_t kRayHole = 0xfffffffeu;  // SKD.z / LTD.z of an entry nobody wrote
 
+// ------------------------------------------------------------------ classify: the shade queue, sorted by shade class
+// The extend stage leaves one class byte per queue entry (kShade*: miss | plain | textured | glass | emissive; 0xff for a
+// hole).  Each block takes tiles of 4096 entries, counts the classes with wave ballots, reserves its part of every class queue
+// with ONE atomic per class, and writes the entries out in order: dense queues, one per class, in which a wave of the shade
+// stage finds paths of one class only.  The last block to finish lays out the streams the class launches append to.
+constexpr uint32_t kClassifyItems = 16, kClassifyTile = 256 * kClassifyItems;
+
+struct ClassQueues { uint32_t* q[kShadeClasses]; };
+
+__global__ __launch_bounds__(256) void k_classify(const uint32_t* queue, const unsigned char* cls, ClassQueues cq, StreamCounters* sc, uint32_t parity, uint32_t shade_waves) {
+    __shared__ uint32_t s_cnt[4][kShadeClasses];
+    __shared__ uint32_t s_base[4][kShadeClasses];
+    const uint32_t n = sc->queue_len[parity].v;
+    const uint32_t wave = threadIdx.x >> 6;
+    for (uint32_t tile = blockIdx.x * kClassifyTile; tile < n; tile += gridDim.x * kClassifyTile) {
+        uint32_t slot[kClassifyItems], kc[kClassifyItems];
+        uint32_t cnt[kShadeClasses];
+#pragma unroll
+        for (uint32_t c = 0; c < kShadeClasses; c++) cnt[c] = 0u;
+#pragma unroll
+        for (uint32_t it = 0; it < kClassifyItems; it++) {
+            const uint32_t i = tile + it * 256u + threadIdx.x;
+            slot[it] = i < n ? queue[i] : kHole;
+            kc[it] = (i < n && slot[it] != kHole) ? (uint32_t)cls[i] : 0xffu;
+#pragma unroll
+            for (uint32_t c = 0; c < kShadeClasses; c++) cnt[c] += (uint32_t)__popcll(__ballot(kc[it] == c));  // wave-uniform
+        }
+        __syncthreads();  // the previous tile's s_base is consumed
+        if (lane_id() == 0u) {
+#pragma unroll
+            for (uint32_t c = 0; c < kShadeClasses; c++) s_cnt[wave][c] = cnt[c];
+        }
+        __syncthreads();
+        if (threadIdx.x < kShadeClasses) {
+            const uint32_t c = threadIdx.x;
+            const uint32_t t0 = s_cnt[0][c], t1 = s_cnt[1][c], t2 = s_cnt[2][c], t3 = s_cnt[3][c], tot = t0 + t1 + t2 + t3;
+            const uint32_t b = tot ? atomicAdd(&sc->class_len[c].v, tot) : 0u;
+            s_base[0][c] = b; s_base[1][c] = b + t0; s_base[2][c] = b + t0 + t1; s_base[3][c] = b + t0 + t1 + t2;
+        }
+        __syncthreads();
+        uint32_t run[kShadeClasses];
+#pragma unroll
+        for (uint32_t c = 0; c < kShadeClasses; c++) run[c] = s_base[wave][c];
+#pragma unroll
+        for (uint32_t it = 0; it < kClassifyItems; it++) {
+#pragma unroll
+            for (uint32_t c = 0; c < kShadeClasses; c++) {
+                const unsigned long long m = __ballot(kc[it] == c);
+                if (kc[it] == c) cq.q[c][run[c] + lanes_below(m)] = slot[it];
+                run[c] += (uint32_t)__popcll(m);
+            }
+        }
+    }
+    // ---- the last block to get here lays out the class launches' appends (class_len is final then)
+    __shared__ uint32_t s_last;
+    __syncthreads();
+    if (threadIdx.x == 0u) {
+        __threadfence();
+        s_last = atomicAdd(&sc->classify_done, 1u) == gridDim.x - 1u ? 1u : 0u;
+    }
+    __syncthreads();
+    if (s_last && threadIdx.x == 0u) {
+        uint32_t reserved = 0u;  // every stream the shade launches append to starts with the static chunks of the chunked launches
+        for (uint32_t c = 0; c < kShadeClasses; c++) {
+            const uint32_t nc = atomicAdd(&sc->class_len[c].v, 0u);
+            const uint32_t need = (nc + 63u) / 64u, active = need < shade_waves ? need : shade_waves;
+            const uint32_t exact = nc < kAppendExactBelow ? 1u : 0u;
+            sc->class_active[c] = active; sc->class_exact[c] = exact; sc->class_base[c] = reserved;
+            if (!exact) reserved += active * kAppendChunk;
+        }
+        sc->queue_len[parity ^ 1u].v = reserved; sc->pend_len.v = reserved; sc->sky_len.v = reserved; sc->light_len.v = reserved;
+        __threadfence();
+    }
+}
+
 // ------------------------------------------------------------------ shade
+template <int CLS>
 __global__ __launch_bounds__(256, 3) void k_shade_stream(DeviceScene sc, RenderParams P, PathState ps, StreamState ss, const uint32_t* queue,
-                                                         uint32_t* queue_next, Counters* ctr, StreamCounters* sctr, uint32_t parity) {
-    const uint32_t n = sctr->queue_len[parity].v;
-    const uint32_t active = sctr->shade_active;   // min(waves of the grid, ceil(n / 64)), set by k_prepare_stream
+                                                         uint32_t* queue_next, Counters* ctr, StreamCounters* sctr, uint32_t parity, uint32_t cls) {
+    const uint32_t n = sctr->class_len[cls].v;    // this class's queue: dense, written by k_classify
+    const uint32_t active = sctr->class_active[cls];   // min(waves of the grid, ceil(n / 64))
     const uint32_t gw = blockIdx.x * 4u + (threadIdx.x >> 6);
     if (gw >= active) return;                     // this wave owns no chunk of any stream and takes no work
     const float4* Tin = ps.T[parity];
     float4* Tout = ps.T[parity ^ 1u];
     const uint32_t chunk = fetch_chunk(n);
     WaveAppender a_next, a_pend, a_sky, a_light;
-    const bool exact = n < kAppendExactBelow;     // as k_prepare_stream decided when it preset the stream lengths
-    a_next.init(gw, exact); a_pend.init(gw, exact); a_sky.init(gw, exact); a_light.init(gw, exact);
+    const bool exact = sctr->class_exact[cls] != 0u;
+    const uint32_t first_chunk = sctr->class_base[cls] / kAppendChunk + gw;   // this launch's static chunks follow the earlier launches'
+    a_next.init(first_chunk, exact); a_pend.init(first_chunk, exact); a_sky.init(first_chunk, exact); a_light.init(first_chunk, exact);
     uint32_t w_paths = 0u, w_rays = 0u, w_pend = 0u, w_alive = 0u;  // wave totals (uniform)
     uint32_t base = gw * 64u, span = 64u;          // the wave's static first 64 entries, then chunks through the cursor
     while (true) {
@@ -54,7 +131,7 @@ __global__ __launch_bounds__(256, 3) void k_shade_stream(DeviceScene sc, RenderP
                 in_.depth = dw & 0x7fffffffu; in_.in_medium = (dw >> 31) != 0u;
                 in_.thr_prev = xyz(t); in_.prev_pdf = t.w;
                 in_.vol_index = -1; in_.vol_t = 0.0f; in_.vdepth = 0u; in_.cchan = -1; in_.atm_comp = -1;
-                shade_core<false>(sc, P, ps, slot, in_, o);
+                shade_core<false, CLS>(sc, P, ps, slot, in_, o);
                 thr_prev = in_.thr_prev;
                 alive = o.alive; want_sky = o.want_sky; want_light = o.want_light;
                 if (alive) {
@@ -92,7 +169,7 @@ __global__ __launch_bounds__(256, 3) void k_shade_stream(DeviceScene sc, RenderP
         }
         if (active * 64u >= n) break;
         uint32_t nb = 0u;
-        if (lane_id() == 0u) nb = atomicAdd(&sctr->shade_head.v, chunk);
+        if (lane_id() == 0u) nb = atomicAdd(&sctr->class_head[cls].v, chunk);
         base = active * 64u + __builtin_amdgcn_readfirstlane(nb);
         span = chunk;
         if (base >= n) break;
@@ -136,11 +213,9 @@ __global__ __launch_bounds__(kTraverseBlock, 8) void k_trace_shadow(DeviceScene 
     V3 o = vptfp::v3(0.0f, 0.0f, 0.0f), d = o, inv = o;
     float tlim = tmax;
     uint32_t st_nodes = 0u, st_tris = 0u;
+    // one inner loop per kind of step (kernels_trace.hip k_trace_vote explains why)
     while (true) {
-        const bool busy = cur < kLaneDone;
-        const bool at_node = busy && cur >= 0;
-        const bool at_leaf = busy && cur < 0;
-        const uint32_t nn = (uint32_t)__popcll(__ballot(at_node)), nl = (uint32_t)__popcll(__ballot(at_leaf));
+        uint32_t nn = (uint32_t)__popcll(__ballot(cur >= 0 && cur < kLaneDone)), nl = (uint32_t)__popcll(__ballot(cur < 0));
         if (!exhausted && (64u - nn - nl >= fetch_at || nn + nl == 0u)) {
             if (cur == kLaneDone) { vis[rid] = visible ? 1 : 0; cur = kLaneIdle; }
             if (w_next >= w_end) {
@@ -182,18 +257,26 @@ __global__ __launch_bounds__(kTraverseBlock, 8) void k_trace_shadow(DeviceScene 
                 const uint32_t want = (uint32_t)__popcll(m_idle), left = w_end - w_next;
                 w_next += want < left ? want : left;
             }
-        } else if (nn + nl == 0u) {
-            break;
-        } else if (weighted ? nn > 2u * nl : nn >= nl) {
-            if (at_node) {
-                if (COUNT) st_nodes++;
-                vote_node_step<true>(nodes, S, cur, sp, o, inv, tmin, tlim);
-            }
+            continue;
+        }
+        if (nn + nl == 0u) break;
+        const uint32_t refill = exhausted ? 65u : fetch_at;
+        if (weighted ? nn > 2u * nl : nn >= nl) {
+            do {
+                if (cur >= 0 && cur < kLaneDone) {
+                    if (COUNT) st_nodes++;
+                    vote_node_step<true>(nodes, S, cur, sp, o, inv, tmin, tlim);
+                }
+                nn = (uint32_t)__popcll(__ballot(cur >= 0 && cur < kLaneDone)); nl = (uint32_t)__popcll(__ballot(cur < 0));
+            } while (nn != 0u && (weighted ? nn > 2u * nl : nn >= nl) && 64u - nn - nl < refill);
         } else {
-            if (at_leaf) {
-                if (COUNT) st_tris++;
-                if (vote_tri_step_any(tris, S, cur, sp, o, d, tmin, tmax, tlim, expect)) visible = false;
-            }
+            do {
+                if (cur < 0) {
+                    if (COUNT) st_tris++;
+                    if (vote_tri_step_any(tris, S, cur, sp, o, d, tmin, tmax, tlim, expect)) visible = false;
+                }
+                nn = (uint32_t)__popcll(__ballot(cur >= 0 && cur < kLaneDone)); nl = (uint32_t)__popcll(__ballot(cur < 0));
+            } while (nl != 0u && !(weighted ? nn > 2u * nl : nn >= nl) && 64u - nn - nl < refill);
         }
     }
     if (cur == kLaneDone) vis[rid] = visible ? 1 : 0;
@@ -239,27 +322,45 @@ __global__ void k_stream_begin(StreamCounters* sc, uint32_t n_slots) {
     sc->queue_len[0].v = n_slots; sc->alive[0].v = n_slots;
     sc->queue_len[1].v = 0u; sc->alive[1].v = 0u;
 }
-// Start of a bounce: how many waves of the shade grid take part (each owns a static first chunk of every stream it appends
-// to, so the streams start at that length), cursors to zero.
-__global__ void k_prepare_stream(StreamCounters* sc, uint32_t parity, uint32_t shade_waves) {
+// Unsorted mode: the whole ray queue is "class 0" of one shade launch running the general code (k_shade_stream<kShadeAny>).
+__global__ void k_layout_single(StreamCounters* sc, uint32_t parity, uint32_t shade_waves) {
     const uint32_t n = sc->queue_len[parity].v;
-    const uint32_t need = (n + 63u) / 64u;
-    const uint32_t active = need < shade_waves ? need : shade_waves;
-    sc->shade_active = active;
-    // long streams: every participating wave owns a static first chunk; short ones are appended to exactly (vote.hpp)
-    sc->pend_len.v = sc->sky_len.v = sc->light_len.v = sc->queue_len[parity ^ 1u].v = n < kAppendExactBelow ? 0u : active * kAppendChunk;
+    const uint32_t need = (n + 63u) / 64u, active = need < shade_waves ? need : shade_waves;
+    const uint32_t exact = n < kAppendExactBelow ? 1u : 0u;
+    sc->class_len[0].v = n; sc->class_active[0] = active; sc->class_exact[0] = exact; sc->class_base[0] = 0u;
+    const uint32_t reserved = exact ? 0u : active * kAppendChunk;
+    sc->queue_len[parity ^ 1u].v = reserved; sc->pend_len.v = reserved; sc->sky_len.v = reserved; sc->light_len.v = reserved;
+}
+
+// Start of a bounce: cursors and class queue lengths to zero (the stream lengths are set by k_classify's last block).
+__global__ void k_prepare_stream(StreamCounters* sc, uint32_t parity) {
     sc->alive[parity ^ 1u].v = 0u;
-    sc->extend_head.v = 0u; sc->shade_head.v = 0u; sc->sky_head.v = 0u; sc->light_head.v = 0u;
+    sc->extend_head.v = 0u; sc->sky_head.v = 0u; sc->light_head.v = 0u;
+    for (uint32_t c = 0; c < kShadeClasses; c++) { sc->class_len[c].v = 0u; sc->class_head[c].v = 0u; }
+    sc->classify_done = 0u;
 }
 
 // ------------------------------------------------------------------ launch
 void launch_stream_begin(hipStream_t s, StreamCounters* sc, uint32_t n_slots) { hipLaunchKernelGGL(k_stream_begin, dim3(1), dim3(1), 0, s, sc, n_slots); }
-void launch_prepare_stream(hipStream_t s, StreamCounters* sc, uint32_t parity, uint32_t shade_waves) {
-    hipLaunchKernelGGL(k_prepare_stream, dim3(1), dim3(1), 0, s, sc, parity, shade_waves);
+void launch_prepare_stream(hipStream_t s, StreamCounters* sc, uint32_t parity) { hipLaunchKernelGGL(k_prepare_stream, dim3(1), dim3(1), 0, s, sc, parity); }
+void launch_classify(hipStream_t s, const uint32_t* queue, const unsigned char* cls, uint32_t* const* class_queue, StreamCounters* sc, uint32_t parity,
+                     uint32_t max_entries, uint32_t shade_waves) {
+    ClassQueues cq;
+    for (uint32_t c = 0; c < kShadeClasses; c++) cq.q[c] = class_queue[c];
+    uint32_t blocks = (max_entries + kClassifyTile - 1u) / kClassifyTile;
+    blocks = blocks < 1u ? 1u : (blocks > 2048u ? 2048u : blocks);
+    hipLaunchKernelGGL(k_classify, dim3(blocks), dim3(256), 0, s, queue, cls, cq, sc, parity, shade_waves);
 }
-void launch_shade_stream(hipStream_t s, uint32_t blocks, const DeviceScene& sc, const RenderParams& P, const PathState& ps, const StreamState& ss,
+void launch_layout_single(hipStream_t s, StreamCounters* sc, uint32_t parity, uint32_t shade_waves) {
+    hipLaunchKernelGGL(k_layout_single, dim3(1), dim3(1), 0, s, sc, parity, shade_waves);
+}
+void launch_shade_stream(hipStream_t s, uint32_t blocks, uint32_t cls, bool sorted, const DeviceScene& sc, const RenderParams& P, const PathState& ps, const StreamState& ss,
                          const uint32_t* queue, uint32_t* queue_next, Counters* ctr, StreamCounters* sctr, uint32_t parity) {
-    hipLaunchKernelGGL(k_shade_stream, dim3(blocks), dim3(256), 0, s, sc, P, ps, ss, queue, queue_next, ctr, sctr, parity);
+    const dim3 g(blocks), b(256);
+    if (!sorted) hipLaunchKernelGGL((k_shade_stream<kShadeAny>), g, b, 0, s, sc, P, ps, ss, queue, queue_next, ctr, sctr, parity, 0u);
+    else if (cls == kShadeMiss) hipLaunchKernelGGL((k_shade_stream<(int)kShadeMiss>), g, b, 0, s, sc, P, ps, ss, queue, queue_next, ctr, sctr, parity, cls);
+    else if (cls == kShadePlain) hipLaunchKernelGGL((k_shade_stream<(int)kShadePlain>), g, b, 0, s, sc, P, ps, ss, queue, queue_next, ctr, sctr, parity, cls);
+    else hipLaunchKernelGGL((k_shade_stream<(int)kShadeTextured>), g, b, 0, s, sc, P, ps, ss, queue, queue_next, ctr, sctr, parity, cls);  // textured, glass, emissive: the general hit code
 }
 void launch_trace_shadow(hipStream_t s, uint32_t blocks, bool light, bool count, const DeviceScene& sc, const StreamState& ss, Counters* ctr,
                          StreamCounters* sctr, uint32_t param) {
@@ -278,7 +379,7 @@ void launch_join(hipStream_t s, uint32_t blocks, const RenderParams& P, const Pa
 }
 int shade_stream_blocks_per_cu() {
     int nb = 0;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_shade_stream, 256, 0);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_shade_stream<kShadeAny>, 256, 0);
     return nb > 0 ? nb : 1;
 }
 int trace_shadow_blocks_per_cu() {

@@ -32,14 +32,14 @@ __device__ inline void load_ray(const TraceArgs& a, uint32_t i, uint32_t& rid, V
     if (a.normalize_dir) d = vptfp::normalize(d);  // RayGen.slang:70
 }
 
-// hit record of a finished closest-hit search: prim / inst come from the winning triangle's record
-__device__ inline void store_closest(const TraceArgs& a, const BvhTri* tris, uint32_t rid, bool found, float t, float u, float v, uint32_t slot) {
+// hit record of a finished closest-hit search: prim / inst come from the winning triangle's record; returns the instance
+__device__ inline uint32_t store_closest(const TraceArgs& a, const BvhTri* tris, uint32_t rid, bool found, float t, float u, float v, uint32_t slot) {
     uint32_t prim = 0xffffffffu, inst = 0xffffffffu;
     if (found) { prim = tris[slot].prim; inst = tris[slot].inst; }
     a.hit[rid] = make_float4(found ? t : -1.0f, found ? u : 0.0f, found ? v : 0.0f, __uint_as_float(prim));
     a.hinst[rid] = inst;
+    return inst;
 }
-
 }  // namespace
 
 // ------------------------------------------------------------------ baseline: 64 rays per wave at a time
@@ -104,16 +104,20 @@ __global__ __launch_bounds__(kTraverseBlock, 8) void k_trace_vote(DeviceScene sc
     V3 o = vptfp::v3(0.0f, 0.0f, 0.0f), d = o, inv = o;
     float best_t = 0.0f, bu = 0.0f, bv = 0.0f;
     uint32_t st_nodes = 0, st_tris = 0;
+    uint32_t qi = 0u;  // the ray's position in the queue: where its shade class goes (a.cls)
+    // Vote loop.  Each kind of step runs in its OWN inner loop for as long as it stays the kind most lanes wait for: the
+    // lane state then lives in fixed registers across the back edge (a flat three-way state machine made the compiler copy
+    // ~30 registers per iteration at the merge point, a third of all VALU work).
     while (true) {
-        const bool busy = cur < kLaneDone;
-        const bool at_node = busy && cur >= 0;
-        const bool at_leaf = busy && cur < 0;
-        const uint32_t nn = (uint32_t)__popcll(__ballot(at_node)), nl = (uint32_t)__popcll(__ballot(at_leaf));
+        uint32_t nn = (uint32_t)__popcll(__ballot(cur >= 0 && cur < kLaneDone)), nl = (uint32_t)__popcll(__ballot(cur < 0));
         if (!exhausted && (64u - nn - nl >= fetch_at || nn + nl == 0u)) {
             // ---- fetch step: retire finished rays, deal new ones to the idle lanes
             if (cur == kLaneDone) {
                 if (ANY) a.hit[rid] = make_float4(bslot != 0xffffffffu ? 1.0f : -1.0f, 0.0f, 0.0f, 0.0f);
-                else store_closest(a, tris, rid, bslot != 0xffffffffu, best_t, bu, bv, bslot);
+                else {
+                    const uint32_t inst = store_closest(a, tris, rid, bslot != 0xffffffffu, best_t, bu, bv, bslot);
+                    if (a.cls) a.cls[qi] = bslot != 0xffffffffu ? sc.inst_class[inst] : (unsigned char)kShadeMiss;  // the shade-queue sort key
+                }
                 cur = kLaneIdle;
             }
             if (w_next >= w_end) {
@@ -131,6 +135,8 @@ __global__ __launch_bounds__(kTraverseBlock, 8) void k_trace_vote(DeviceScene sc
                 const uint32_t i = w_next + lanes_below(m_idle);
                 if (cur == kLaneIdle && i < w_end) {
                     rid = a.order ? a.order[i] : i;
+                    qi = i;
+                    if (rid == kHole) { if (a.cls) a.cls[i] = 0xffu; }   // a hole has no class: the classify step drops it
                     if (rid != kHole) {  // a hole: the tail of some wave's last chunk of the queue (vote.hpp WaveAppender)
                         o = xyz4(a.ro[rid]);
                         d = xyz4(a.rd[rid]);
@@ -143,24 +149,35 @@ __global__ __launch_bounds__(kTraverseBlock, 8) void k_trace_vote(DeviceScene sc
                 const uint32_t want = (uint32_t)__popcll(m_idle), left = w_end - w_next;
                 w_next += want < left ? want : left;
             }
-        } else if (nn + nl == 0u) {
-            break;
-        } else if (weighted ? nn > 2u * nl : nn >= nl) {
-            if (at_node) {
-                if (COUNT) st_nodes++;
-                vote_node_step<ANY>(nodes, S, cur, sp, o, inv, a.tmin, best_t);
-            }
+            continue;
+        }
+        if (nn + nl == 0u) break;
+        const uint32_t refill = exhausted ? 65u : fetch_at;   // idle lanes that send the wave back to the fetch step
+        if (weighted ? nn > 2u * nl : nn >= nl) {
+            do {  // ---- inner-node steps
+                if (cur >= 0 && cur < kLaneDone) {
+                    if (COUNT) st_nodes++;
+                    vote_node_step<ANY>(nodes, S, cur, sp, o, inv, a.tmin, best_t);
+                }
+                nn = (uint32_t)__popcll(__ballot(cur >= 0 && cur < kLaneDone)); nl = (uint32_t)__popcll(__ballot(cur < 0));
+            } while (nn != 0u && (weighted ? nn > 2u * nl : nn >= nl) && 64u - nn - nl < refill);
         } else {
-            if (at_leaf) {
-                if (COUNT) st_tris++;
-                if (ANY) { if (vote_tri_step_any(tris, S, cur, sp, o, d, a.tmin, a.tmax, a.tmax, 0xffffffffu)) bslot = 0u; }
-                else vote_tri_step_closest(tris, S, cur, sp, o, d, a.tmin, a.tmax, best_t, bu, bv, bslot, bgid);
-            }
+            do {  // ---- triangle steps: ONE triangle of each participating lane's leaf
+                if (cur < 0) {
+                    if (COUNT) st_tris++;
+                    if (ANY) { if (vote_tri_step_any(tris, S, cur, sp, o, d, a.tmin, a.tmax, a.tmax, 0xffffffffu)) bslot = 0u; }
+                    else vote_tri_step_closest(tris, S, cur, sp, o, d, a.tmin, a.tmax, best_t, bu, bv, bslot, bgid);
+                }
+                nn = (uint32_t)__popcll(__ballot(cur >= 0 && cur < kLaneDone)); nl = (uint32_t)__popcll(__ballot(cur < 0));
+            } while (nl != 0u && !(weighted ? nn > 2u * nl : nn >= nl) && 64u - nn - nl < refill);
         }
     }
     if (cur == kLaneDone) {  // rays that finished after the stream ran dry
         if (ANY) a.hit[rid] = make_float4(bslot != 0xffffffffu ? 1.0f : -1.0f, 0.0f, 0.0f, 0.0f);
-        else store_closest(a, tris, rid, bslot != 0xffffffffu, best_t, bu, bv, bslot);
+        else {
+            const uint32_t inst = store_closest(a, tris, rid, bslot != 0xffffffffu, best_t, bu, bv, bslot);
+            if (a.cls) a.cls[qi] = bslot != 0xffffffffu ? sc.inst_class[inst] : (unsigned char)kShadeMiss;
+        }
     }
     if (COUNT) {
         atomicAdd(&ctr->stat_nodes, (unsigned long long)st_nodes);

@@ -76,7 +76,10 @@ struct ShadeOut {
 
 // The miss / closest-hit shader and the visibility-independent tail of the bounce loop for ONE path, on
 // values held in registers (the callers own every load/store of the path records).
-template <bool VOL>
+// CLS: what the caller knows about every path it hands over (device_types.hpp kShade*): kShadeMiss — none hit anything;
+// kShadePlain — all hit a material whose textures are all 1x1 (the texture code drops out; results are those of the general
+// code, which would take the same branches); any other hit class — all hit something; kShadeAny — nothing.
+template <bool VOL, int CLS = kShadeAny>
 __device__ __forceinline__ void shade_core(const DeviceScene& sc, const RenderParams& P, const PathState& ps, uint32_t slot,
                                            const ShadeIn& in_, ShadeOut& out) {
     bool alive = false, want_sky = false, want_light = false, light_miss_ok = false;
@@ -177,7 +180,7 @@ __device__ __forceinline__ void shade_core(const DeviceScene& sc, const RenderPa
         new_depth = depth + 1u;
     } else if (VOL && sc.atm_on && h.x < 0.0f) {
         new_depth = kMaxDepthMarker;  // Miss.slang:11-14: with an atmosphere the sky is in-scattered sunlight only
-    } else if (h.x < 0.0f) {
+    } else if (CLS == kShadeMiss || (CLS == kShadeAny && h.x < 0.0f)) {
         // ---- Miss.slang:8-77
         V4 cp = v4(0.0f, 0.0f, 0.0f, 1.0f);
         if (((P.flags & VPT_FLAG_SHOW_ENV_DIRECTLY) || depth > 0) && sc.env_black) {
@@ -198,7 +201,8 @@ __device__ __forceinline__ void shade_core(const DeviceScene& sc, const RenderPa
         uint32_t inst_id = in_.inst;
         const InstanceDesc& in = sc.instances[inst_id];
         const vpt_material& mat = sc.materials[in.material];
-        const MatResolved mr = sc.mat_resolved[in.material];
+        MatResolved mr = sc.mat_resolved[in.material];
+        if (CLS == (int)kShadePlain) mr.flags = 3u;  // what the class promises, as a compile-time fact: no texel fetch is compiled in
         SurfaceFrame s;
         surface_init(sc, s, in, __float_as_uint(h.w), h.y, h.z, rd, mat.normal_texture, (P.flags & VPT_FLAG_GEOMETRY_NORMALS) != 0, mr);
         Bsdf bs; V3 mcol; float mdens, maniso, arot;

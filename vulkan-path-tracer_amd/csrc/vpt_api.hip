@@ -50,6 +50,7 @@ struct vpt_ctx {
     EmissiveTri* d_emissive_tri = nullptr;
     uint32_t* d_emissive_tri_offset = nullptr;
     float4* d_tri_ng = nullptr;
+    unsigned char* d_inst_class = nullptr;   // shade class per instance (kernels_path.hip k_classify_instances)
     bool lds_scene = false;
     int trav_blocks = 1024;
 
@@ -62,7 +63,10 @@ struct vpt_ctx {
     uint32_t* queue[2] = {nullptr, nullptr};
     uint32_t* cqueue = nullptr;  // connect queue (two-ended)
     void* ss_block = nullptr;    // stream records of the staged pipeline (kernels_stream.hip)
+    uint32_t* class_queue[kShadeClasses] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // the shade queue sorted by class
+    unsigned char* cls_q = nullptr;          // shade class per ray-queue entry, written by the extend stage
     StreamState ss{};
+    uint32_t class_present = 0x1fu;   // shade classes some instance of the scene belongs to (bit kShadeMiss always set): the others get no launch
     uint32_t stream_slack = 0;   // entries a stream may hold beyond its true count: unwritten chunk tails (vote.hpp WaveAppender)
     int shade_stream_blocks = 768, shadow_blocks = 2048;
     // AUTO pipeline on a scene whose BVH does not fit LDS: the first four full batches are timed, staged and fused
@@ -148,6 +152,9 @@ void free_render_buffers(vpt_ctx* c) {
     c->cqueue = nullptr;
     if (c->ss_block) (void)hipFree(c->ss_block);
     c->ss_block = nullptr;
+    for (uint32_t k = 0; k < kShadeClasses; k++) { if (c->class_queue[k]) (void)hipFree(c->class_queue[k]); c->class_queue[k] = nullptr; }
+    if (c->cls_q) (void)hipFree(c->cls_q);
+    c->cls_q = nullptr;
     if (c->image) (void)hipFree(c->image);
     c->image = nullptr;
     if (c->full_image) (void)hipFree(c->full_image);
@@ -228,6 +235,8 @@ int alloc_render_buffers_impl(vpt_ctx* c) {
         t.PE = q; t.PS = q + sst; t.PL = q + 2 * sst; t.PT = q + 3 * sst; t.SKO = q + 4 * sst; t.SKD = q + 5 * sst; t.LTO = q + 6 * sst; t.LTD = q + 7 * sst;
         t.vis_sky = (unsigned char*)(q + 8 * sst); t.vis_light = t.vis_sky + sst;
         t.cap = (uint32_t)scap;
+        for (uint32_t k = 0; k < kShadeClasses; k++) HIPCHK(c, hipMalloc((void**)&c->class_queue[k], scap * 4));
+        HIPCHK(c, hipMalloc((void**)&c->cls_q, scap));
     }
     // padded to the largest shard's row count (vpt_shard_floats): the buffer is handed to ncclGather as it is
     const size_t image_bytes = (size_t)shard_rows_of(P.height, 0, P.shard_count) * P.width * 16;
@@ -323,6 +332,15 @@ void build_env_tables(const float* rgba, uint32_t w, uint32_t h, std::vector<flo
     }
 }
 
+// Which shade classes occur in the scene: the staged pipeline launches the shade stage once per class that does.
+int update_class_present(vpt_ctx* c) {
+    std::vector<unsigned char> cls(c->instances.size());
+    if (!cls.empty()) HIPCHK(c, hipMemcpy(cls.data(), c->d_inst_class, cls.size(), hipMemcpyDeviceToHost));
+    c->class_present = 1u << kShadeMiss;
+    for (unsigned char k : cls) if (k < kShadeClasses) c->class_present |= 1u << k;
+    return VPT_OK;
+}
+
 void begin_timing(vpt_ctx* c, int kernel, hipEvent_t* a, hipEvent_t* b) {
     *a = *b = nullptr;
     c->stats.kernel_launches[kernel]++;
@@ -397,14 +415,24 @@ int render_batch(vpt_ctx* c, uint32_t frames, uint32_t dispatch_base) {
             // a memory-resident BVH runs the staged pipeline on the vote-scheduled traversal kernels and compact streams
             // (kernels_trace.hip, kernels_stream.hip); round 1's stage kernels serve LDS-resident scenes forced into the staged
             // pipeline, VPT_FLAG_LOCAL_HITS and VPT_PIPELINE_STAGED_R1
-            if (stream) {   // stream pipeline: extend -> shade (streams out) -> sky rays, light rays -> join
-                launch_prepare_stream(s, c->sctr, parity, (uint32_t)c->shade_stream_blocks * 4u);
+            if (stream) {   // stream pipeline: extend -> classify -> shade per class (streams out) -> sky rays, light rays -> join
+                launch_prepare_stream(s, c->sctr, parity);
                 TraceArgs a{};
-                a.ro = c->ps.A; a.rd = c->ps.B; a.order = c->queue[parity]; a.hit = c->ps.H; a.hinst = c->ps.hinst;
+                a.ro = c->ps.A; a.rd = c->ps.B; a.order = c->queue[parity]; a.hit = c->ps.H; a.hinst = c->ps.hinst; a.cls = c->cls_q;
                 a.n = 0; a.n_dev = &c->sctr->queue_len[parity].v; a.head = &c->sctr->extend_head.v;
                 a.tmin = 0.01f; a.tmax = 100000.0f; a.normalize_dir = 1u; a.param = c->vote_param;
+                const bool sorted = c->cfg.pipeline == VPT_PIPELINE_STAGED_SORTED;
+                if (!sorted) a.cls = nullptr;
                 TIMED(c, VPT_K_EXTEND, launch_trace(s, (uint32_t)c->vote_blocks, VPT_TRACE_VOTE, false, count, c->dsc, a, c->ctr));
-                TIMED(c, VPT_K_SHADE, launch_shade_stream(s, (uint32_t)c->shade_stream_blocks, c->dsc, c->P, c->ps, c->ss, c->queue[parity], c->queue[parity ^ 1u], c->ctr, c->sctr, parity));
+                if (sorted) {   // the shade queue sorted by material class: one dense queue and one launch per class present in the scene
+                    TIMED(c, VPT_K_SHADE, launch_classify(s, c->queue[parity], c->cls_q, c->class_queue, c->sctr, parity, n_slots + c->stream_slack, (uint32_t)c->shade_stream_blocks * 4u));
+                    for (uint32_t k = 0; k < kShadeClasses; k++)
+                        if (c->class_present & (1u << k))
+                            TIMED(c, VPT_K_SHADE, launch_shade_stream(s, (uint32_t)c->shade_stream_blocks, k, true, c->dsc, c->P, c->ps, c->ss, c->class_queue[k], c->queue[parity ^ 1u], c->ctr, c->sctr, parity));
+                } else {
+                    launch_layout_single(s, c->sctr, parity, (uint32_t)c->shade_stream_blocks * 4u);
+                    TIMED(c, VPT_K_SHADE, launch_shade_stream(s, (uint32_t)c->shade_stream_blocks, 0u, false, c->dsc, c->P, c->ps, c->ss, c->queue[parity], c->queue[parity ^ 1u], c->ctr, c->sctr, parity));
+                }
                 TIMED(c, VPT_K_SHADOW, launch_trace_shadow(s, (uint32_t)c->shadow_blocks, false, count, c->dsc, c->ss, c->ctr, c->sctr, c->vote_param));
                 TIMED(c, VPT_K_SHADOW, launch_trace_shadow(s, (uint32_t)c->shadow_blocks, true, count, c->dsc, c->ss, c->ctr, c->sctr, c->vote_param));
                 TIMED(c, VPT_K_JOIN, launch_join(s, (uint32_t)c->shade_blocks, c->P, c->ps, c->ss, c->sctr));
@@ -493,7 +521,7 @@ void vpt_default_post_params(vpt_post_params* p) {  // PostProcessor.h:8-21
 
 vpt_ctx* vpt_create(const vpt_config* cfg, int* err) {
     auto set = [&](int e) { if (err) *err = e; };
-    if (!cfg || cfg->width == 0 || cfg->height == 0 || cfg->shard_count == 0 || cfg->shard_rank >= cfg->shard_count || cfg->pipeline > VPT_PIPELINE_STAGED_R1) { set(VPT_ERR_INVALID_ARGUMENT); return nullptr; }
+    if (!cfg || cfg->width == 0 || cfg->height == 0 || cfg->shard_count == 0 || cfg->shard_rank >= cfg->shard_count || cfg->pipeline > VPT_PIPELINE_STAGED_SORTED) { set(VPT_ERR_INVALID_ARGUMENT); return nullptr; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev) { set(VPT_ERR_NO_DEVICE); return nullptr; }
     if (hipSetDevice(cfg->device) != hipSuccess) { set(VPT_ERR_NO_DEVICE); return nullptr; }
@@ -673,6 +701,9 @@ int vpt_set_scene(vpt_ctx* c, const vpt_scene_desc* sd) {
         HIPCHK(c, hipMalloc(&d2, sizeof(EmissiveTri) * std::max<size_t>(1, total_tris))); c->scene_allocs.push_back(d2);
         HIPCHK(c, hipMalloc(&d3, 4 * std::max<size_t>(1, c->instances.size()))); c->scene_allocs.push_back(d3);
         HIPCHK(c, hipMalloc(&d4, 16 * std::max<size_t>(1, total_tris))); c->scene_allocs.push_back(d4);
+        void* d5 = nullptr;
+        HIPCHK(c, hipMalloc(&d5, std::max<size_t>(1, c->instances.size()))); c->scene_allocs.push_back(d5);
+        c->d_inst_class = (unsigned char*)d5; D.inst_class = c->d_inst_class;
         c->d_mat_resolved = (MatResolved*)d1; c->d_emissive_tri = (EmissiveTri*)d2; c->d_emissive_tri_offset = (uint32_t*)d3; c->d_tri_ng = (float4*)d4;
         D.mat_resolved = c->d_mat_resolved; D.emissive_tri = c->d_emissive_tri; D.emissive_tri_offset = c->d_emissive_tri_offset; D.tri_ng = c->d_tri_ng;
     }
@@ -701,7 +732,9 @@ int vpt_set_scene(vpt_ctx* c, const vpt_scene_desc* sd) {
     }
     launch_precompute_tri_ng(c->stream, D, c->d_tri_ng);
     launch_precompute_materials(c->stream, D, c->params.flags, c->d_mat_resolved, (uint32_t)c->materials.size());
+    launch_classify_instances(c->stream, D, c->d_inst_class, (uint32_t)c->instances.size());
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if ((rc = update_class_present(c))) return rc;
     HIPCHK(c, hipGetLastError());
     c->has_scene = true;
     HIPCHK(c, hipMemset(c->image, 0, (size_t)c->P.shard_pixels * 16));
@@ -722,7 +755,9 @@ int vpt_set_material(vpt_ctx* c, uint32_t index, const vpt_material* m) {
     HIPCHK(c, hipMemcpy(c->d_materials + index, m, sizeof(vpt_material), hipMemcpyHostToDevice));
     if (emissive_changed) { build_emissive(c); int rc = upload_emissive(c); if (rc) return rc; }
     launch_precompute_materials(c->stream, c->dsc, c->params.flags, c->d_mat_resolved, (uint32_t)c->materials.size());
+    launch_classify_instances(c->stream, c->dsc, c->d_inst_class, (uint32_t)c->instances.size());
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    { int rc2 = update_class_present(c); if (rc2) return rc2; }
     reset_accum(c);
     return VPT_OK;
 }
@@ -760,7 +795,9 @@ int vpt_set_params(vpt_ctx* c, const vpt_params* p) {
     if (flags_changed && c->has_scene) {  // FURNACE_TEST_MODE is baked into the resolved-material table
         HIPCHK(c, hipSetDevice(c->cfg.device));
         launch_precompute_materials(c->stream, c->dsc, c->params.flags, c->d_mat_resolved, (uint32_t)c->materials.size());
+        launch_classify_instances(c->stream, c->dsc, c->d_inst_class, (uint32_t)c->instances.size());
         HIPCHK(c, hipStreamSynchronize(c->stream));
+        int rc2 = update_class_present(c); if (rc2) return rc2;
     }
     return VPT_OK;
 }
