@@ -213,9 +213,11 @@ __global__ __launch_bounds__(kTraverseBlock, 8) void k_trace_shadow(DeviceScene 
     V3 o = vptfp::v3(0.0f, 0.0f, 0.0f), d = o, inv = o;
     float tlim = tmax;
     uint32_t st_nodes = 0u, st_tris = 0u;
-    // one inner loop per kind of step (kernels_trace.hip k_trace_vote explains why)
-    while (true) {
-        uint32_t nn = (uint32_t)__popcll(__ballot(cur >= 0 && cur < kLaneDone)), nl = (uint32_t)__popcll(__ballot(cur < 0));
+    while (true) {   // one kind of step per iteration (kernels_trace.hip k_trace_vote)
+        const bool busy = cur < kLaneDone;
+        const bool at_node = busy && cur >= 0;
+        const bool at_leaf = busy && cur < 0;
+        const uint32_t nn = (uint32_t)__popcll(__ballot(at_node)), nl = (uint32_t)__popcll(__ballot(at_leaf));
         if (!exhausted && (64u - nn - nl >= fetch_at || nn + nl == 0u)) {
             if (cur == kLaneDone) { vis[rid] = visible ? 1 : 0; cur = kLaneIdle; }
             if (w_next >= w_end) {
@@ -257,26 +259,18 @@ __global__ __launch_bounds__(kTraverseBlock, 8) void k_trace_shadow(DeviceScene 
                 const uint32_t want = (uint32_t)__popcll(m_idle), left = w_end - w_next;
                 w_next += want < left ? want : left;
             }
-            continue;
-        }
-        if (nn + nl == 0u) break;
-        const uint32_t refill = exhausted ? 65u : fetch_at;
-        if (weighted ? nn > 2u * nl : nn >= nl) {
-            do {
-                if (cur >= 0 && cur < kLaneDone) {
-                    if (COUNT) st_nodes++;
-                    vote_node_step<true>(nodes, S, cur, sp, o, inv, tmin, tlim);
-                }
-                nn = (uint32_t)__popcll(__ballot(cur >= 0 && cur < kLaneDone)); nl = (uint32_t)__popcll(__ballot(cur < 0));
-            } while (nn != 0u && (weighted ? nn > 2u * nl : nn >= nl) && 64u - nn - nl < refill);
+        } else if (nn + nl == 0u) {
+            break;
+        } else if (weighted ? nn > 2u * nl : nn >= nl) {
+            if (at_node) {
+                if (COUNT) st_nodes++;
+                vote_node_step<true>(nodes, S, cur, sp, o, inv, tmin, tlim);
+            }
         } else {
-            do {
-                if (cur < 0) {
-                    if (COUNT) st_tris++;
-                    if (vote_tri_step_any(tris, S, cur, sp, o, d, tmin, tmax, tlim, expect)) visible = false;
-                }
-                nn = (uint32_t)__popcll(__ballot(cur >= 0 && cur < kLaneDone)); nl = (uint32_t)__popcll(__ballot(cur < 0));
-            } while (nl != 0u && !(weighted ? nn > 2u * nl : nn >= nl) && 64u - nn - nl < refill);
+            if (at_leaf) {
+                if (COUNT) st_tris++;
+                if (vote_tri_step_any(tris, S, cur, sp, o, d, tmin, tmax, tlim, expect)) visible = false;
+            }
         }
     }
     if (cur == kLaneDone) vis[rid] = visible ? 1 : 0;
@@ -364,7 +358,7 @@ void launch_shade_stream(hipStream_t s, uint32_t blocks, uint32_t cls, bool sort
 }
 void launch_trace_shadow(hipStream_t s, uint32_t blocks, bool light, bool count, const DeviceScene& sc, const StreamState& ss, Counters* ctr,
                          StreamCounters* sctr, uint32_t param) {
-    const size_t lds = (size_t)kStackDepth * kTraverseBlock * 4;
+    const size_t lds = kVoteStackBytes;
     const dim3 g(blocks), b(kTraverseBlock);
     if (light) {
         if (count) hipLaunchKernelGGL((k_trace_shadow<true, true>), g, b, lds, s, sc, ss.LTO, ss.LTD, ss.vis_light, &sctr->light_len.v, &sctr->light_head.v, ctr, param);
@@ -384,7 +378,7 @@ int shade_stream_blocks_per_cu() {
 }
 int trace_shadow_blocks_per_cu() {
     int a = 0, b = 0;
-    const size_t lds = (size_t)kStackDepth * kTraverseBlock * 4;
+    const size_t lds = kVoteStackBytes;
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_trace_shadow<true, false>, kTraverseBlock, lds);
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_trace_shadow<false, false>, kTraverseBlock, lds);
     int nb = a < b ? a : b;

@@ -105,11 +105,13 @@ __global__ __launch_bounds__(kTraverseBlock, 8) void k_trace_vote(DeviceScene sc
     float best_t = 0.0f, bu = 0.0f, bv = 0.0f;
     uint32_t st_nodes = 0, st_tris = 0;
     uint32_t qi = 0u;  // the ray's position in the queue: where its shade class goes (a.cls)
-    // Vote loop.  Each kind of step runs in its OWN inner loop for as long as it stays the kind most lanes wait for: the
-    // lane state then lives in fixed registers across the back edge (a flat three-way state machine made the compiler copy
-    // ~30 registers per iteration at the merge point, a third of all VALU work).
+    // Vote loop: one kind of step per iteration.  (Giving each kind its own inner loop, which lets the lane state stay in fixed
+    // registers across the back edge, was measured 5-7 % slower on closest-hit rays: the vote then sticks to a kind for too long.)
     while (true) {
-        uint32_t nn = (uint32_t)__popcll(__ballot(cur >= 0 && cur < kLaneDone)), nl = (uint32_t)__popcll(__ballot(cur < 0));
+        const bool busy = cur < kLaneDone;
+        const bool at_node = busy && cur >= 0;
+        const bool at_leaf = busy && cur < 0;
+        const uint32_t nn = (uint32_t)__popcll(__ballot(at_node)), nl = (uint32_t)__popcll(__ballot(at_leaf));
         if (!exhausted && (64u - nn - nl >= fetch_at || nn + nl == 0u)) {
             // ---- fetch step: retire finished rays, deal new ones to the idle lanes
             if (cur == kLaneDone) {
@@ -149,27 +151,19 @@ __global__ __launch_bounds__(kTraverseBlock, 8) void k_trace_vote(DeviceScene sc
                 const uint32_t want = (uint32_t)__popcll(m_idle), left = w_end - w_next;
                 w_next += want < left ? want : left;
             }
-            continue;
-        }
-        if (nn + nl == 0u) break;
-        const uint32_t refill = exhausted ? 65u : fetch_at;   // idle lanes that send the wave back to the fetch step
-        if (weighted ? nn > 2u * nl : nn >= nl) {
-            do {  // ---- inner-node steps
-                if (cur >= 0 && cur < kLaneDone) {
-                    if (COUNT) st_nodes++;
-                    vote_node_step<ANY>(nodes, S, cur, sp, o, inv, a.tmin, best_t);
-                }
-                nn = (uint32_t)__popcll(__ballot(cur >= 0 && cur < kLaneDone)); nl = (uint32_t)__popcll(__ballot(cur < 0));
-            } while (nn != 0u && (weighted ? nn > 2u * nl : nn >= nl) && 64u - nn - nl < refill);
+        } else if (nn + nl == 0u) {
+            break;
+        } else if (weighted ? nn > 2u * nl : nn >= nl) {
+            if (at_node) {  // ---- inner-node step
+                if (COUNT) st_nodes++;
+                vote_node_step<ANY>(nodes, S, cur, sp, o, inv, a.tmin, best_t);
+            }
         } else {
-            do {  // ---- triangle steps: ONE triangle of each participating lane's leaf
-                if (cur < 0) {
-                    if (COUNT) st_tris++;
-                    if (ANY) { if (vote_tri_step_any(tris, S, cur, sp, o, d, a.tmin, a.tmax, a.tmax, 0xffffffffu)) bslot = 0u; }
-                    else vote_tri_step_closest(tris, S, cur, sp, o, d, a.tmin, a.tmax, best_t, bu, bv, bslot, bgid);
-                }
-                nn = (uint32_t)__popcll(__ballot(cur >= 0 && cur < kLaneDone)); nl = (uint32_t)__popcll(__ballot(cur < 0));
-            } while (nl != 0u && !(weighted ? nn > 2u * nl : nn >= nl) && 64u - nn - nl < refill);
+            if (at_leaf) {  // ---- triangle step: ONE triangle of the lane's leaf
+                if (COUNT) st_tris++;
+                if (ANY) { if (vote_tri_step_any(tris, S, cur, sp, o, d, a.tmin, a.tmax, a.tmax, 0xffffffffu)) bslot = 0u; }
+                else vote_tri_step_closest(tris, S, cur, sp, o, d, a.tmin, a.tmax, best_t, bu, bv, bslot, bgid);
+            }
         }
     }
     if (cur == kLaneDone) {  // rays that finished after the stream ran dry
@@ -188,7 +182,7 @@ __global__ __launch_bounds__(kTraverseBlock, 8) void k_trace_vote(DeviceScene sc
 // ------------------------------------------------------------------ launch
 int trace_blocks_per_cu(uint32_t variant, bool any) {
     int nb = 0;
-    const size_t lds = (size_t)kStackDepth * kTraverseBlock * 4;
+    const size_t lds = kVoteStackBytes;
     if (variant == VPT_TRACE_BASE) {
         if (any) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_base<true, false>, kTraverseBlock, lds);
         else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_base<false, false>, kTraverseBlock, lds);
@@ -200,7 +194,7 @@ int trace_blocks_per_cu(uint32_t variant, bool any) {
 }
 
 void launch_trace(hipStream_t s, uint32_t blocks, uint32_t variant, bool any, bool count, const DeviceScene& sc, const TraceArgs& a, Counters* ctr) {
-    const size_t lds = (size_t)kStackDepth * kTraverseBlock * 4;
+    const size_t lds = kVoteStackBytes;
     const dim3 g(blocks), b(kTraverseBlock);
 #define VPT_LT(K) do { if (any) { if (count) hipLaunchKernelGGL((K<true, true>), g, b, lds, s, sc, a, ctr); else hipLaunchKernelGGL((K<true, false>), g, b, lds, s, sc, a, ctr); } \
                        else { if (count) hipLaunchKernelGGL((K<false, true>), g, b, lds, s, sc, a, ctr); else hipLaunchKernelGGL((K<false, false>), g, b, lds, s, sc, a, ctr); } } while (0)
