@@ -181,6 +181,14 @@ struct PathState {
 // ---- Streams of the staged pipeline (kernels_stream.hip): records in the order the shade stage produced them, written by
 // wave-private chunked appends (vote.hpp), so every read and write of them is coalesced.
 struct StreamState {
+    // path records in queue order, ping-pong by bounce parity: entry i of queue[p] is the path whose records are R*[p][i], so the
+    // extend and shade stages read them as coalesced 16-byte streams (a surviving path's records MOVE to where its queue
+    // entry goes; its frame sum, pathLight and medium stay addressed by slot)
+    float4* RA[2];  // payload.Origin.xyz | RNG state
+    float4* RB[2];  // payload.Direction.xyz | payload.Depth, bit31 = InMedium
+    float4* RT[2];  // pathThroughput.xyz | payload.PDF
+    float4* SH;     // hit record t,u,v | PrimitiveIndex of queue entry i (extend W, shade R)
+    uint32_t* SHI;  // hit record InstanceIndex
     // pending paths of this bounce (anything to join: emission, NEE candidates, end of sample)
     float4* PE;   // emission / miss radiance .xyz | connect flags
     float4* PS;   // sky NEE contribution .xyz | index of its ray in the sky-ray stream

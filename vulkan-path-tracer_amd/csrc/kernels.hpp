@@ -33,6 +33,7 @@ struct TraceArgs {
     const float4* ro;       // origin.xyz | -
     const float4* rd;       // direction.xyz | -
     const uint32_t* order;  // optional: entry i of the stream is ray order[i]
+    const uint32_t* valid;  // optional (with order == nullptr): entry i is a hole when valid[i] == 0xffffffff
     float4* hit;            // closest: t (< 0 miss), u, v | primitive; any-hit: x = 1 occluded / -1 clear
     uint32_t* hinst;        // closest: instance
     uint32_t n;
@@ -48,11 +49,12 @@ int trace_blocks_per_cu(uint32_t variant, bool any);
 
 // staged pipeline on compact streams (kernels_stream.hip)
 void launch_stream_begin(hipStream_t s, StreamCounters* sc, uint32_t n_slots);
+void launch_raygen_stream(hipStream_t s, const RenderParams& P, const PathState& ps, const StreamState& ss, uint32_t* queue, uint32_t n_slots, uint32_t dispatch_base);
 void launch_prepare_stream(hipStream_t s, StreamCounters* sc, uint32_t parity);
 void launch_classify(hipStream_t s, const uint32_t* queue, const unsigned char* cls, uint32_t* const* class_queue, StreamCounters* sc, uint32_t parity, uint32_t max_entries, uint32_t shade_waves);
 void launch_layout_single(hipStream_t s, StreamCounters* sc, uint32_t parity, uint32_t shade_waves);
 void launch_shade_stream(hipStream_t s, uint32_t blocks, uint32_t cls, bool sorted, const DeviceScene& sc, const RenderParams& P, const PathState& ps, const StreamState& ss,
-                         const uint32_t* queue, uint32_t* queue_next, Counters* ctr, StreamCounters* sctr, uint32_t parity);
+                         const uint32_t* queue, const uint32_t* order, uint32_t* queue_next, Counters* ctr, StreamCounters* sctr, uint32_t parity);
 void launch_classify_instances(hipStream_t s, const DeviceScene& sc, unsigned char* out, uint32_t n);
 void launch_trace_shadow(hipStream_t s, uint32_t blocks, bool light, bool count, const DeviceScene& sc, const StreamState& ss, Counters* ctr,
                          StreamCounters* sctr, uint32_t param);

@@ -34,15 +34,14 @@ __global__ __launch_bounds__(256) void k_classify(const uint32_t* queue, const u
     const uint32_t n = sc->queue_len[parity].v;
     const uint32_t wave = threadIdx.x >> 6;
     for (uint32_t tile = blockIdx.x * kClassifyTile; tile < n; tile += gridDim.x * kClassifyTile) {
-        uint32_t slot[kClassifyItems], kc[kClassifyItems];
+        uint32_t kc[kClassifyItems];
         uint32_t cnt[kShadeClasses];
 #pragma unroll
         for (uint32_t c = 0; c < kShadeClasses; c++) cnt[c] = 0u;
 #pragma unroll
         for (uint32_t it = 0; it < kClassifyItems; it++) {
             const uint32_t i = tile + it * 256u + threadIdx.x;
-            slot[it] = i < n ? queue[i] : kHole;
-            kc[it] = (i < n && slot[it] != kHole) ? (uint32_t)cls[i] : 0xffu;
+            kc[it] = (i < n && queue[i] != kHole) ? (uint32_t)cls[i] : 0xffu;
 #pragma unroll
             for (uint32_t c = 0; c < kShadeClasses; c++) cnt[c] += (uint32_t)__popcll(__ballot(kc[it] == c));  // wave-uniform
         }
@@ -67,7 +66,7 @@ __global__ __launch_bounds__(256) void k_classify(const uint32_t* queue, const u
 #pragma unroll
             for (uint32_t c = 0; c < kShadeClasses; c++) {
                 const unsigned long long m = __ballot(kc[it] == c);
-                if (kc[it] == c) cq.q[c][run[c] + lanes_below(m)] = slot[it];
+                if (kc[it] == c) cq.q[c][run[c] + lanes_below(m)] = tile + it * 256u + threadIdx.x;   // the entry's POSITION in the ray queue
                 run[c] += (uint32_t)__popcll(m);
             }
         }
@@ -96,14 +95,12 @@ __global__ __launch_bounds__(256) void k_classify(const uint32_t* queue, const u
 
 // ------------------------------------------------------------------ shade
 template <int CLS>
-__global__ __launch_bounds__(256, 3) void k_shade_stream(DeviceScene sc, RenderParams P, PathState ps, StreamState ss, const uint32_t* queue,
+__global__ __launch_bounds__(256, 3) void k_shade_stream(DeviceScene sc, RenderParams P, PathState ps, StreamState ss, const uint32_t* queue, const uint32_t* order,
                                                          uint32_t* queue_next, Counters* ctr, StreamCounters* sctr, uint32_t parity, uint32_t cls) {
     const uint32_t n = sctr->class_len[cls].v;    // this class's queue: dense, written by k_classify
     const uint32_t active = sctr->class_active[cls];   // min(waves of the grid, ceil(n / 64))
     const uint32_t gw = blockIdx.x * 4u + (threadIdx.x >> 6);
     if (gw >= active) return;                     // this wave owns no chunk of any stream and takes no work
-    const float4* Tin = ps.T[parity];
-    float4* Tout = ps.T[parity ^ 1u];
     const uint32_t chunk = fetch_chunk(n);
     WaveAppender a_next, a_pend, a_sky, a_light;
     const bool exact = sctr->class_exact[cls] != 0u;
@@ -115,16 +112,18 @@ __global__ __launch_bounds__(256, 3) void k_shade_stream(DeviceScene sc, RenderP
         for (uint32_t k = 0u; k < span; k += 64u) {
             const uint32_t i = base + k + lane_id();
             if (base + k >= n) break;
-            const uint32_t slot = i < n ? queue[i] : kHole;
+            // sorted mode: `order` holds positions in the ray queue (k_classify); unsorted: the queue is worked through in order
+            const uint32_t qi = i < n ? (order ? order[i] : i) : 0u;
+            const uint32_t slot = i < n ? queue[qi] : kHole;
             const bool valid = slot != kHole;
             bool alive = false, pending = false, want_sky = false, want_light = false;
             ShadeOut o;
             V3 thr_prev = v3s(0.0f);
             if (valid) {
-                const float4 a = ps.A[slot], b = ps.B[slot], t = Tin[slot];
+                const float4 a = ss.RA[parity][qi], b = ss.RB[parity][qi], t = ss.RT[parity][qi];
                 ShadeIn in_;
-                in_.h = ps.H[slot];
-                in_.inst = in_.h.x < 0.0f ? 0u : ps.hinst[slot];
+                in_.h = ss.SH[qi];
+                in_.inst = in_.h.x < 0.0f ? 0u : ss.SHI[qi];
                 in_.rng = __float_as_uint(a.w);
                 in_.porg = xyz(a); in_.pdir = xyz(b);
                 const uint32_t dw = __float_as_uint(b.w);
@@ -134,17 +133,17 @@ __global__ __launch_bounds__(256, 3) void k_shade_stream(DeviceScene sc, RenderP
                 shade_core<false, CLS>(sc, P, ps, slot, in_, o);
                 thr_prev = in_.thr_prev;
                 alive = o.alive; want_sky = o.want_sky; want_light = o.want_light;
-                if (alive) {
-                    ps.A[slot] = f4u(o.new_o, o.rng);
-                    ps.B[slot] = f4u(o.new_d, o.new_depth | (o.in_medium ? 0x80000000u : 0u));
-                    Tout[slot] = f4(o.thr, o.new_pdf);
-                }
                 const bool thr_finite = !isinf_(thr_prev.x) && !isinf_(thr_prev.y) && !isinf_(thr_prev.z) && !isnan_(thr_prev.x) && !isnan_(thr_prev.y) && !isnan_(thr_prev.z);
                 // 0 * inf = NaN must still reach pathLight, so a non-finite throughput always goes through the join
                 pending = want_sky || want_light || o.terminated || o.emitted.x != 0.0f || o.emitted.y != 0.0f || o.emitted.z != 0.0f || !thr_finite;
             }
             const uint32_t p_next = a_next.append(alive, &sctr->queue_len[parity ^ 1u].v);
-            if (alive) queue_next[p_next] = slot;
+            if (alive) {   // the survivor's records move to where its queue entry goes
+                queue_next[p_next] = slot;
+                ss.RA[parity ^ 1u][p_next] = f4u(o.new_o, o.rng);
+                ss.RB[parity ^ 1u][p_next] = f4u(o.new_d, o.new_depth | (o.in_medium ? 0x80000000u : 0u));
+                ss.RT[parity ^ 1u][p_next] = f4(o.thr, o.new_pdf);
+            }
             const uint32_t p_sky = a_sky.append(want_sky, &sctr->sky_len.v);
             if (want_sky) {
                 ss.SKO[p_sky] = f4(o.sky_o, o.sky_d.x);
@@ -311,6 +310,28 @@ __global__ __launch_bounds__(256) void k_join(RenderParams P, PathState ps, Stre
     }
 }
 
+// Camera rays of a batch as the first ray queue and its records (RayGen.slang:12-64; the staged pipeline runs bounce 0 through
+// the same stages as every other bounce).
+__global__ __launch_bounds__(256) void k_raygen_stream(RenderParams P, PathState ps, StreamState ss, uint32_t* queue, uint32_t n_slots, uint32_t dispatch_base) {
+    const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
+    if (li >= n_slots) return;
+    uint32_t slot, x, y, f;
+    launch_pixel(P, li, dispatch_base, slot, x, y, f);
+    const uint32_t seed = pcg_hash(P.base_seed + dispatch_base + f);  // PathTracer.cpp:139 with an explicit seed
+    Rng r; r.s = y + P.width * x + seed;                              // RayGen.slang:28
+    V3 o, d;
+    camera_ray(P, r, x, y, o, d);
+    ss.RA[0][li] = f4u(o, r.s);
+    ss.RB[0][li] = f4u(d, 0u);
+    ss.RT[0][li] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);  // pathThroughput = 1, payload.PDF = 1
+    ps.L[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (P.samples_per_frame > 1) { ps.ACC[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); ps.sidx[slot] = 0u; }
+    queue[li] = slot;
+}
+void launch_raygen_stream(hipStream_t s, const RenderParams& P, const PathState& ps, const StreamState& ss, uint32_t* queue, uint32_t n_slots, uint32_t dispatch_base) {
+    hipLaunchKernelGGL(k_raygen_stream, dim3((n_slots + 255u) / 256u), dim3(256), 0, s, P, ps, ss, queue, n_slots, dispatch_base);
+}
+
 // Start of a batch: the ray queue raygen filled.
 __global__ void k_stream_begin(StreamCounters* sc, uint32_t n_slots) {
     sc->queue_len[0].v = n_slots; sc->alive[0].v = n_slots;
@@ -349,12 +370,12 @@ void launch_layout_single(hipStream_t s, StreamCounters* sc, uint32_t parity, ui
     hipLaunchKernelGGL(k_layout_single, dim3(1), dim3(1), 0, s, sc, parity, shade_waves);
 }
 void launch_shade_stream(hipStream_t s, uint32_t blocks, uint32_t cls, bool sorted, const DeviceScene& sc, const RenderParams& P, const PathState& ps, const StreamState& ss,
-                         const uint32_t* queue, uint32_t* queue_next, Counters* ctr, StreamCounters* sctr, uint32_t parity) {
+                         const uint32_t* queue, const uint32_t* order, uint32_t* queue_next, Counters* ctr, StreamCounters* sctr, uint32_t parity) {
     const dim3 g(blocks), b(256);
-    if (!sorted) hipLaunchKernelGGL((k_shade_stream<kShadeAny>), g, b, 0, s, sc, P, ps, ss, queue, queue_next, ctr, sctr, parity, 0u);
-    else if (cls == kShadeMiss) hipLaunchKernelGGL((k_shade_stream<(int)kShadeMiss>), g, b, 0, s, sc, P, ps, ss, queue, queue_next, ctr, sctr, parity, cls);
-    else if (cls == kShadePlain) hipLaunchKernelGGL((k_shade_stream<(int)kShadePlain>), g, b, 0, s, sc, P, ps, ss, queue, queue_next, ctr, sctr, parity, cls);
-    else hipLaunchKernelGGL((k_shade_stream<(int)kShadeTextured>), g, b, 0, s, sc, P, ps, ss, queue, queue_next, ctr, sctr, parity, cls);  // textured, glass, emissive: the general hit code
+    if (!sorted) hipLaunchKernelGGL((k_shade_stream<kShadeAny>), g, b, 0, s, sc, P, ps, ss, queue, nullptr, queue_next, ctr, sctr, parity, 0u);
+    else if (cls == kShadeMiss) hipLaunchKernelGGL((k_shade_stream<(int)kShadeMiss>), g, b, 0, s, sc, P, ps, ss, queue, order, queue_next, ctr, sctr, parity, cls);
+    else if (cls == kShadePlain) hipLaunchKernelGGL((k_shade_stream<(int)kShadePlain>), g, b, 0, s, sc, P, ps, ss, queue, order, queue_next, ctr, sctr, parity, cls);
+    else hipLaunchKernelGGL((k_shade_stream<(int)kShadeTextured>), g, b, 0, s, sc, P, ps, ss, queue, order, queue_next, ctr, sctr, parity, cls);  // textured, glass, emissive: the general hit code
 }
 void launch_trace_shadow(hipStream_t s, uint32_t blocks, bool light, bool count, const DeviceScene& sc, const StreamState& ss, Counters* ctr,
                          StreamCounters* sctr, uint32_t param) {

@@ -136,7 +136,7 @@ __global__ __launch_bounds__(kTraverseBlock, 8) void k_trace_vote(DeviceScene sc
                 const unsigned long long m_idle = __ballot(cur == kLaneIdle);
                 const uint32_t i = w_next + lanes_below(m_idle);
                 if (cur == kLaneIdle && i < w_end) {
-                    rid = a.order ? a.order[i] : i;
+                    rid = a.order ? a.order[i] : (a.valid && a.valid[i] == kHole) ? kHole : i;
                     qi = i;
                     if (rid == kHole) { if (a.cls) a.cls[i] = 0xffu; }   // a hole has no class: the classify step drops it
                     if (rid != kHole) {  // a hole: the tail of some wave's last chunk of the queue (vote.hpp WaveAppender)

@@ -34,8 +34,8 @@ __device__ __forceinline__ LaneStack make_lane_stack(unsigned char* smem, uint32
 constexpr size_t kVoteStackBytes = (size_t)kVoteStackRows * kTraverseBlock * 4;
 
 // One inner-node visit: 64 B fetch, four slab tests against [tmin, tlimit], then either the nearest hit child with the
-// others pushed far -> near (closest-hit search) or the hit children in slot order (any-hit search).  (Branch-free pushes through
-// a trash row were measured: closest-hit -8 %, any-hit +2 %; not kept.)
+// others pushed far -> near (closest-hit search) or the hit children in slot order (any-hit search).  (Measured and not kept: branch-free pushes through
+// a trash row — closest-hit -8 %, any-hit +2 %; farthest-child-first for the light-identity queries — shadow stage -25 %.)
 template <bool ANY>
 __device__ __forceinline__ void vote_node_step(const BvhNode* nodes, const LaneStack& S, int& cur, int& sp, V3 o, V3 inv, float tmin, float tlimit) {
     const uint4* p = reinterpret_cast<const uint4*>(nodes + cur);

@@ -229,11 +229,13 @@ int alloc_render_buffers_impl(vpt_ctx* c) {
     HIPCHK(c, hipMalloc((void**)&c->cqueue, (size_t)cap * 4));
     {
         const size_t sst = (scap + 63) & ~(size_t)63;
-        HIPCHK(c, hipMalloc(&c->ss_block, sst * (16 * 8 + 2)));
+        HIPCHK(c, hipMalloc(&c->ss_block, sst * (16 * 15 + 4 + 2)));
         float4* q = (float4*)c->ss_block;
         StreamState& t = c->ss;
         t.PE = q; t.PS = q + sst; t.PL = q + 2 * sst; t.PT = q + 3 * sst; t.SKO = q + 4 * sst; t.SKD = q + 5 * sst; t.LTO = q + 6 * sst; t.LTD = q + 7 * sst;
-        t.vis_sky = (unsigned char*)(q + 8 * sst); t.vis_light = t.vis_sky + sst;
+        t.RA[0] = q + 8 * sst; t.RA[1] = q + 9 * sst; t.RB[0] = q + 10 * sst; t.RB[1] = q + 11 * sst; t.RT[0] = q + 12 * sst; t.RT[1] = q + 13 * sst;
+        t.SH = q + 14 * sst; t.SHI = (uint32_t*)(q + 15 * sst);
+        t.vis_sky = (unsigned char*)(t.SHI + sst); t.vis_light = t.vis_sky + sst;
         t.cap = (uint32_t)scap;
         for (uint32_t k = 0; k < kShadeClasses; k++) HIPCHK(c, hipMalloc((void**)&c->class_queue[k], scap * 4));
         HIPCHK(c, hipMalloc((void**)&c->cls_q, scap));
@@ -389,18 +391,21 @@ int render_batch(vpt_ctx* c, uint32_t frames, uint32_t dispatch_base) {
     // volumes are integrated in the fused per-bounce kernel only
     const bool vol = !c->volumes.empty() || c->dsc.atm_on;
     const bool fused = vol || c->cfg.pipeline == VPT_PIPELINE_FUSED || (c->cfg.pipeline == VPT_PIPELINE_AUTO && (c->lds_scene || c->auto_fused));
+    const bool stream = !fused && !c->lds_scene && !c->dsc.strict_hits && c->cfg.pipeline != VPT_PIPELINE_STAGED_R1;
     HIPCHK(c, hipMemsetAsync(c->ctr, 0, offsetof(Counters, stat_closest), s));  // queue words only, stat_* keep running
     uint32_t parity;
     uint32_t k3 = 0;  // fused: bounce index % 3 (Counters::rc3)
     if (fused) {  // bounce 0 of every slot needs no input records; survivors land in queue[1]
         TIMED(c, VPT_K_PRIMARY, launch_bounce(s, (uint32_t)c->primary_blocks, c->lds_scene, count, true, c->dsc, c->P, c->ps, nullptr, c->queue[1], c->ctr, 0u, n_slots, dispatch_base, 0u));
         parity = 1; k3 = 1;
+    } else if (stream) {
+        TIMED(c, VPT_K_PRIMARY, launch_raygen_stream(s, c->P, c->ps, c->ss, c->queue[0], n_slots, dispatch_base));
+        launch_stream_begin(s, c->sctr, n_slots);
+        parity = 0;
     } else {
         TIMED(c, VPT_K_PRIMARY, launch_raygen(s, c->P, c->ps, c->queue[0], c->ctr, n_slots, dispatch_base));
         parity = 0;
     }
-    const bool stream = !fused && !c->lds_scene && !c->dsc.strict_hits && c->cfg.pipeline != VPT_PIPELINE_STAGED_R1;
-    if (stream) launch_stream_begin(s, c->sctr, n_slots);
     const uint64_t min_bounces = (uint64_t)c->P.max_depth * c->P.samples_per_frame;
     const uint64_t iter_cap = min_bounces * 4ull + 1024ull;
     uint64_t iter = 0;
@@ -418,7 +423,7 @@ int render_batch(vpt_ctx* c, uint32_t frames, uint32_t dispatch_base) {
             if (stream) {   // stream pipeline: extend -> classify -> shade per class (streams out) -> sky rays, light rays -> join
                 launch_prepare_stream(s, c->sctr, parity);
                 TraceArgs a{};
-                a.ro = c->ps.A; a.rd = c->ps.B; a.order = c->queue[parity]; a.hit = c->ps.H; a.hinst = c->ps.hinst; a.cls = c->cls_q;
+                a.ro = c->ss.RA[parity]; a.rd = c->ss.RB[parity]; a.order = nullptr; a.valid = c->queue[parity]; a.hit = c->ss.SH; a.hinst = c->ss.SHI; a.cls = c->cls_q;
                 a.n = 0; a.n_dev = &c->sctr->queue_len[parity].v; a.head = &c->sctr->extend_head.v;
                 a.tmin = 0.01f; a.tmax = 100000.0f; a.normalize_dir = 1u; a.param = c->vote_param;
                 const bool sorted = c->cfg.pipeline == VPT_PIPELINE_STAGED_SORTED;
@@ -428,10 +433,10 @@ int render_batch(vpt_ctx* c, uint32_t frames, uint32_t dispatch_base) {
                     TIMED(c, VPT_K_SHADE, launch_classify(s, c->queue[parity], c->cls_q, c->class_queue, c->sctr, parity, n_slots + c->stream_slack, (uint32_t)c->shade_stream_blocks * 4u));
                     for (uint32_t k = 0; k < kShadeClasses; k++)
                         if (c->class_present & (1u << k))
-                            TIMED(c, VPT_K_SHADE, launch_shade_stream(s, (uint32_t)c->shade_stream_blocks, k, true, c->dsc, c->P, c->ps, c->ss, c->class_queue[k], c->queue[parity ^ 1u], c->ctr, c->sctr, parity));
+                            TIMED(c, VPT_K_SHADE, launch_shade_stream(s, (uint32_t)c->shade_stream_blocks, k, true, c->dsc, c->P, c->ps, c->ss, c->queue[parity], c->class_queue[k], c->queue[parity ^ 1u], c->ctr, c->sctr, parity));
                 } else {
                     launch_layout_single(s, c->sctr, parity, (uint32_t)c->shade_stream_blocks * 4u);
-                    TIMED(c, VPT_K_SHADE, launch_shade_stream(s, (uint32_t)c->shade_stream_blocks, 0u, false, c->dsc, c->P, c->ps, c->ss, c->queue[parity], c->queue[parity ^ 1u], c->ctr, c->sctr, parity));
+                    TIMED(c, VPT_K_SHADE, launch_shade_stream(s, (uint32_t)c->shade_stream_blocks, 0u, false, c->dsc, c->P, c->ps, c->ss, c->queue[parity], nullptr, c->queue[parity ^ 1u], c->ctr, c->sctr, parity));
                 }
                 TIMED(c, VPT_K_SHADOW, launch_trace_shadow(s, (uint32_t)c->shadow_blocks, false, count, c->dsc, c->ss, c->ctr, c->sctr, c->vote_param));
                 TIMED(c, VPT_K_SHADOW, launch_trace_shadow(s, (uint32_t)c->shadow_blocks, true, count, c->dsc, c->ss, c->ctr, c->sctr, c->vote_param));
