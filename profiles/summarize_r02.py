@@ -1,6 +1,6 @@
 """gpurun_out/prof_<scene>_p<pipe>/ (profiles/collect_r02.sh) -> profiles/r02_<scene>_p<pipe>_kernel_stats.csv + _summary.md.
 SQ counters are quad-cycle based; wait = SQ_WAIT_ANY / SQ_WAVE_CYCLES; VALU busy = SQ_ACTIVE_INST_VALU * 4 / (1024 SIMDs x
-GRBM_GUI_ACTIVE / 8) as in r01; lane use = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU x 4) when the counter exists;
+GRBM_GUI_ACTIVE / 8) as in r01; lane use = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU): mean fraction of the 64 lanes active per VALU instruction;
 FETCH_SIZE / WRITE_SIZE in KiB, FETCH doubled (gfx950 note in MI355X_MICROARCH.md)."""
 import collections, csv, glob, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -38,7 +38,7 @@ for s, (calls, tot) in sorted(dur.items(), key=lambda kv: -kv[1][1]):
     wait = div(a["SQ_WAIT_ANY"], a["SQ_WAVE_CYCLES"])
     l2 = div(a["TCC_HIT_sum"], a["TCC_HIT_sum"] + a["TCC_MISS_sum"])
     busy = div(a["SQ_ACTIVE_INST_VALU"] * 4, 1024 * a["GRBM_GUI_ACTIVE"] / 8)
-    lane = div(a["SQ_THREAD_CYCLES_VALU"], 64 * 4 * a["SQ_ACTIVE_INST_VALU"])
+    lane = div(a["SQ_THREAD_CYCLES_VALU"], 64 * a["SQ_ACTIVE_INST_VALU"])
     rows[s] = {"launches": calls, "total_ms": tot / 1e6, "wait": wait, "valu_busy": busy, "lane_use": lane, "valu_wave_instr": a["SQ_INSTS_VALU"], "l2_hit": l2,
                "fetched_GB": 2 * a["FETCH_SIZE"] * 1024 / 1e9, "written_GB": a["WRITE_SIZE"] * 1024 / 1e9, "raw": dict(a)}
     lines.append("| %s | %d | %.2f | %.0f %% | %.0f %% | %.0f %% | %.3g | %.0f %% | %.2f | %.2f |" % (s, calls, tot / 1e6, 100 * wait, 100 * busy, 100 * lane, a["SQ_INSTS_VALU"], 100 * l2, rows[s]["fetched_GB"], rows[s]["written_GB"]))

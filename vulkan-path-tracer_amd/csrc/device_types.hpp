@@ -187,6 +187,7 @@ struct StreamState {
     float4* RA[2];  // payload.Origin.xyz | RNG state
     float4* RB[2];  // payload.Direction.xyz | payload.Depth, bit31 = InMedium
     float4* RT[2];  // pathThroughput.xyz | payload.PDF
+    float4* RL[2];  // pathLight.xyz (fused pipeline only: the staged one keeps pathLight by slot, where the join stage adds to it)
     float4* SH;     // hit record t,u,v | PrimitiveIndex of queue entry i (extend W, shade R)
     uint32_t* SHI;  // hit record InstanceIndex
     // pending paths of this bounce (anything to join: emission, NEE candidates, end of sample)
@@ -245,7 +246,9 @@ struct Counters {
     uint32_t pad;
     // fused pipeline: three rotating queue sizes — bounce k reads rc3[k % 3], appends to rc3[(k + 1) % 3] and zeroes
     // rc3[(k + 2) % 3] (idle during bounce k), so no separate reset kernel sits between two bounces
-    uint32_t rc3[4];
+    uint32_t rc3[4];          // dynamically reserved part of the three rotating queues' lengths
+    uint32_t rc3_static[4];   // static part: one chunk per wave of the producing launch (0 when it appended exactly)
+    uint32_t alive3[4];       // exact number of live paths in each of the three queues
     unsigned long long stat_closest, stat_shadow, stat_connect;  // folded per bounce by k_prepare / k_fold
     unsigned long long stat_nodes, stat_tris;                // extend kernel (count_traversal builds only)
     unsigned long long stat_shadow_nodes, stat_shadow_tris;  // connect kernel

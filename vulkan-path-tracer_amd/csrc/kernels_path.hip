@@ -17,6 +17,7 @@
 #include "traverse.hpp"
 #include "wave.hpp"
 #include "shade_core.hpp"
+#include "vote.hpp"
 
 namespace vpt {
 
@@ -249,38 +250,49 @@ __global__ __launch_bounds__(256, 3) void k_shade(DeviceScene sc, RenderParams P
 // then a handful of LDS reads, so a separate extend/connect stage would only move records through HBM):
 // it reads a queued path's records A, B, T, L, does the whole bounce, and writes them back for survivors.
 template <bool LDS_SCENE, bool COUNT, bool FIRST, bool VOL, bool STRICT>
-__global__ __launch_bounds__(kTraverseBlock, 3) void k_bounce(DeviceScene sc, RenderParams P, PathState ps, const uint32_t* queue,
+__global__ __launch_bounds__(kTraverseBlock, 3) void k_bounce(DeviceScene sc, RenderParams P, PathState ps, StreamState ss, const uint32_t* queue,
                                                              uint32_t* queue_next, Counters* ctr, uint32_t parity, uint32_t n_slots,
                                                              uint32_t dispatch_base, uint32_t k3) {
     sc.strict_hits = STRICT ? 1u : 0u;  // compile-time constant from here on (VPT_FLAG_LOCAL_HITS picks the instantiation)
     extern __shared__ __align__(16) unsigned char smem[];
-    __shared__ uint32_t s_cnt[4][3];
-    __shared__ uint32_t s_base[4];
     const TravStack stack = make_stack(smem, sc.stack_overflow);
     float4* lds_nodes = reinterpret_cast<float4*>(smem + kStackDepth * kTraverseBlock * 4);
     float4* lds_tris = lds_nodes + sc.node_count * 8;
     stage_scene<LDS_SCENE>(sc, lds_nodes, lds_tris);
-    const uint32_t n = FIRST ? n_slots : ctr->rc3[k3];  // k3 = bounce index % 3 (Counters::rc3)
-    uint32_t* const n_next = &ctr->rc3[(k3 + 1u) % 3u];
-    const float4* Tin = ps.T[parity];
-    float4* Tout = ps.T[parity ^ 1u];
+    // Queue k3 (= bounce index % 3) is read, queue k3 + 1 appended to, the words of queue k3 + 2 zeroed for the bounce after the
+    // next: no reset kernel between two bounces.  A queue's length (holes included) is its static part — one chunk per wave
+    // that took part in the producing launch, or nothing when that launch appended exactly — plus the dynamically reserved part.
+    const uint32_t kn = (k3 + 1u) % 3u, kz = (k3 + 2u) % 3u;
+    const uint32_t n = FIRST ? n_slots : ctr->rc3_static[k3] + ctr->rc3[k3];
+    const uint32_t waves = gridDim.x * (kTraverseBlock / 64u);
+    const uint32_t need = (n + 63u) / 64u, active = need < waves ? need : waves;
+    const bool exact = n < kAppendExactBelow;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        ctr->rc3_static[kn] = exact ? 0u : active * kAppendChunk;
+        ctr->rc3[kz] = 0u; ctr->alive3[kz] = 0u;
+    }
+    // Long queues: wave-private chunked appends (vote.hpp).  Short ones (< kAppendExactBelow entries): the block's four waves
+    // add up their survivors in LDS and reserve them with ONE atomic per 256 paths, exactly — no holes, and few enough atomics
+    // for a kernel whose whole launch takes ~0.1 ms at that size (one per wave would saturate the counter, ~88 / us).
+    __shared__ uint32_t s_cnt[kTraverseBlock / 64u];
+    __shared__ uint32_t s_base[kTraverseBlock / 64u];
     const uint32_t wave = threadIdx.x >> 6;
-    uint32_t cpt = (n + (1u << 21) - 1u) >> 21;
-    cpt = cpt < 1u ? 1u : (cpt > 4u ? 4u : cpt);
-    const uint32_t tile_size = cpt * 256u;
+    const uint32_t gw = blockIdx.x * (kTraverseBlock / 64u) + wave;
+    if (!exact && gw >= active) return;   // (after the block-wide staging above) this wave owns no chunk and no work
+    WaveAppender a_next;
+    a_next.init(gw, false, active * kAppendChunk);   // chunked mode: the counter rc3[kn] counts what is reserved beyond the static chunks
     TravStats st, sst; st.nodes = 0; st.tris = 0; sst.nodes = 0; sst.tris = 0;
-    if (blockIdx.x == 0 && threadIdx.x == 0) { ctr->stat_closest += n; ctr->rc3[(k3 + 2u) % 3u] = 0u; }
-    for (uint32_t tile = blockIdx.x * tile_size; tile < n; tile += gridDim.x * tile_size) {
-        uint32_t res = 0u;  // bit c: path c of this lane survives
-        uint32_t s0 = 0u, s1 = 0u, s2 = 0u, s3 = 0u;
-        uint32_t tot_alive = 0u, tot_rays = 0u, tot_hits = 0u;
-#pragma unroll 1
-        for (uint32_t c = 0; c < cpt; c++) {
-            uint32_t idx = tile + c * 256u + threadIdx.x;
-            uint32_t slot = idx;
+    uint32_t w_paths = 0u, w_alive = 0u, w_rays = 0u, w_hits = 0u;  // wave totals (uniform)
+    for (uint32_t tile = blockIdx.x; tile * kTraverseBlock < n; tile += gridDim.x) {
+        {
+            const uint32_t idx = tile * kTraverseBlock + threadIdx.x;
+            uint32_t slot = FIRST ? idx : (idx < n ? queue[idx] : kHole);
             bool alive = false, hit = false;
             uint32_t nrays = 0u;
-            if (idx < n) {
+            ShadeOut o;
+            V3 light = v3s(0.0f);
+            const bool valid = idx < n && slot != kHole;
+            if (valid) {
                 ShadeIn in_;
                 V3 light_prev = v3s(0.0f);
                 if (FIRST) {
@@ -292,9 +304,8 @@ __global__ __launch_bounds__(kTraverseBlock, 3) void k_bounce(DeviceScene sc, Re
                     in_.rng = r.s; in_.depth = 0u; in_.in_medium = false; in_.thr_prev = v3s(1.0f); in_.prev_pdf = 1.0f;
                     in_.vdepth = 0u; in_.cchan = -1;
                     if (P.samples_per_frame > 1) ps.sidx[slot] = 0u;
-                } else {
-                    slot = queue[idx];
-                    float4 a = ps.A[slot], b = ps.B[slot], t = Tin[slot];
+                } else {   // the path's records, in queue order
+                    float4 a = ss.RA[parity][idx], b = ss.RB[parity][idx], t = ss.RT[parity][idx];
                     in_.rng = __float_as_uint(a.w);
                     in_.porg = xyz(a); in_.pdir = xyz(b);
                     uint32_t dw = __float_as_uint(b.w);
@@ -302,13 +313,12 @@ __global__ __launch_bounds__(kTraverseBlock, 3) void k_bounce(DeviceScene sc, Re
                     in_.thr_prev = xyz(t); in_.prev_pdf = t.w;
                     in_.vdepth = VOL ? ps.vdepth[slot] : 0u;
                     in_.cchan = (VOL && sc.atm_on) ? ps.cchan[slot] : -1;
-                    light_prev = xyz(ps.L[slot]);
+                    light_prev = xyz(ss.RL[parity][idx]);
                 }
                 HitRec hr;
                 in_.vol_index = -1; in_.vol_t = 0.0f; in_.atm_comp = -1;
                 // RayGen.slang:76-84: a path whose origin is below the planet's surface leaves the loop at once
                 const bool aborted = VOL && sc.atm_on && atmosphere_height(sc, in_.porg) < 0.0f;
-                ShadeOut o;
                 if (VOL && !aborted) {  // ScatteredInVolume (RayGen.slang:86): GetDistanceToGeometry uses the payload direction as is,
                                         // TMin 1e-5, TMax 1e6 (RTCommon.slang:86-101)
                     bool g = trace_any<LDS_SCENE, COUNT>(sc, lds_nodes, lds_tris, in_.porg, in_.pdir, 0.00001f, 1000000.0f, stack, hr, st);
@@ -378,7 +388,7 @@ __global__ __launch_bounds__(kTraverseBlock, 3) void k_bounce(DeviceScene sc, Re
                     float lum = dot(contrib, v3(0.212671f, 0.715160f, 0.072169f));
                     contrib = contrib * (P.max_luminance / max_(lum, P.max_luminance));
                 }
-                V3 light = light_prev + contrib;
+                light = light_prev + contrib;
                 if (VOL && aborted) light = light_prev;  // the loop was left before anything was added
                 if (o.terminated) {  // end of a sample: NaN/Inf guard, frame sum (RayGen.slang:116-128)
                     bool ok = !isinf_(light.x) && !isinf_(light.y) && !isinf_(light.z) && !isnan_(light.x) && !isnan_(light.y) && !isnan_(light.z);
@@ -393,42 +403,46 @@ __global__ __launch_bounds__(kTraverseBlock, 3) void k_bounce(DeviceScene sc, Re
                     ps.ACC[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // later finalisations add to it
                 }
                 alive = o.alive;
-                if (alive) {
-                    ps.A[slot] = f4u(o.new_o, o.rng);
-                    ps.B[slot] = f4u(o.new_d, o.new_depth | (o.in_medium ? 0x80000000u : 0u));
-                    Tout[slot] = f4(o.thr, o.new_pdf);
-                    ps.L[slot] = f4(light, 0.0f);
-                    if (VOL) { ps.vdepth[slot] = o.vdepth; if (sc.atm_on) ps.cchan[slot] = o.cchan; }
+                if (alive && VOL) { ps.vdepth[slot] = o.vdepth; if (sc.atm_on) ps.cchan[slot] = o.cchan; }
+            }
+            // survivors: the queue entry and, with it, the path's records go to the next queue (wave-private chunked append)
+            uint32_t pn;
+            if (!exact) pn = a_next.append(alive, &ctr->rc3[kn]);
+            else {
+                const unsigned long long ma = __ballot(alive);
+                if (lane_id() == 0) s_cnt[wave] = (uint32_t)__popcll(ma);
+                __syncthreads();
+                if (threadIdx.x == 0) {
+                    uint32_t sum = 0u, pre[kTraverseBlock / 64u];
+                    for (uint32_t w = 0; w < kTraverseBlock / 64u; w++) { pre[w] = sum; sum += s_cnt[w]; }
+                    const uint32_t b = sum ? atomicAdd(&ctr->rc3[kn], sum) : 0u;
+                    for (uint32_t w = 0; w < kTraverseBlock / 64u; w++) s_base[w] = b + pre[w];
                 }
+                __syncthreads();
+                pn = s_base[wave] + lanes_below(ma);
             }
-            s0 = (c == 0u) ? slot : s0; s1 = (c == 1u) ? slot : s1; s2 = (c == 2u) ? slot : s2; s3 = (c == 3u) ? slot : s3;
-            res |= (alive ? 1u : 0u) << c;
-            tot_alive += (uint32_t)__popcll(__ballot(alive));
-            tot_rays += (uint32_t)__popcll(__ballot(nrays >= 1u)) + (uint32_t)__popcll(__ballot(nrays >= 2u));
-            tot_hits += (uint32_t)__popcll(__ballot(hit));
-        }
-        if (lane_id() == 0) { s_cnt[wave][0] = tot_alive; s_cnt[wave][1] = tot_rays; s_cnt[wave][2] = tot_hits; }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            uint32_t sum = 0u, rays = 0u, hits = 0u, pre[4];
-            for (uint32_t w = 0; w < 4; w++) { pre[w] = sum; sum += s_cnt[w][0]; rays += s_cnt[w][1]; hits += s_cnt[w][2]; }
-            uint32_t b = sum ? atomicAdd(n_next, sum) : 0u;
-            if (rays) atomicAdd(&ctr->stat_shadow, (unsigned long long)rays);
-            if (FIRST) {
-                if (hits) atomicAdd(&ctr->stat_primary_hits, (unsigned long long)hits);
-                if (sum) atomicAdd(&ctr->stat_primary_alive, (unsigned long long)sum);
-                if (rays) atomicAdd(&ctr->stat_primary_rays, (unsigned long long)rays);
+            if (alive) {
+                queue_next[pn] = slot;
+                ss.RA[parity ^ 1u][pn] = f4u(o.new_o, o.rng);
+                ss.RB[parity ^ 1u][pn] = f4u(o.new_d, o.new_depth | (o.in_medium ? 0x80000000u : 0u));
+                ss.RT[parity ^ 1u][pn] = f4(o.thr, o.new_pdf);
+                ss.RL[parity ^ 1u][pn] = f4(light, 0.0f);
             }
-            for (uint32_t w = 0; w < 4; w++) s_base[w] = b + pre[w];
+            w_paths += (uint32_t)__popcll(__ballot(valid));
+            w_alive += (uint32_t)__popcll(__ballot(alive));
+            w_rays += (uint32_t)__popcll(__ballot(nrays >= 1u)) + (uint32_t)__popcll(__ballot(nrays >= 2u));
+            w_hits += (uint32_t)__popcll(__ballot(hit));
         }
-        __syncthreads();
-        uint32_t o_alive = s_base[wave];
-#pragma unroll
-        for (uint32_t c = 0; c < 4; c++) {
-            bool alive = ((res >> c) & 1u) != 0u;
-            unsigned long long ma = __ballot(alive);
-            if (alive) queue_next[o_alive + lanes_below(ma)] = c == 0u ? s0 : (c == 1u ? s1 : (c == 2u ? s2 : s3));
-            o_alive += (uint32_t)__popcll(ma);
+    }
+    if (!exact) for (uint32_t j = lane_id(); j < a_next.tail_count(); j += 64u) queue_next[a_next.tail_first() + j] = kHole;  // the unwritten tail of the wave's last chunk
+    if (lane_id() == 0) {
+        if (w_alive) atomicAdd(&ctr->alive3[kn], w_alive);
+        if (w_paths) atomicAdd(&ctr->stat_closest, (unsigned long long)w_paths);
+        if (w_rays) atomicAdd(&ctr->stat_shadow, (unsigned long long)w_rays);
+        if (FIRST) {
+            if (w_hits) atomicAdd(&ctr->stat_primary_hits, (unsigned long long)w_hits);
+            if (w_alive) atomicAdd(&ctr->stat_primary_alive, (unsigned long long)w_alive);
+            if (w_rays) atomicAdd(&ctr->stat_primary_rays, (unsigned long long)w_rays);
         }
     }
     if (COUNT) {
@@ -671,12 +685,12 @@ static inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
 // first == true: bounce 0 of n_slots fresh slots (queue unused); otherwise one fused bounce of queue[parity].
 void launch_bounce(hipStream_t s, uint32_t blocks, bool lds_scene, bool count, bool first, const DeviceScene& sc, const RenderParams& P,
-                   const PathState& ps, const uint32_t* queue, uint32_t* queue_next, Counters* ctr, uint32_t parity, uint32_t n_slots,
+                   const PathState& ps, const StreamState& ss, const uint32_t* queue, uint32_t* queue_next, Counters* ctr, uint32_t parity, uint32_t n_slots,
                    uint32_t dispatch_base, uint32_t k3) {
     size_t lds = traverse_lds_bytes(sc, lds_scene);
     dim3 g(blocks), b(kTraverseBlock);
-#define VPT_LAUNCH_BOUNCE_V(L, C, F, V) do { if (sc.strict_hits) hipLaunchKernelGGL((k_bounce<L, C, F, V, true>), g, b, lds, s, sc, P, ps, queue, queue_next, ctr, parity, n_slots, dispatch_base, k3); \
-        else hipLaunchKernelGGL((k_bounce<L, C, F, V, false>), g, b, lds, s, sc, P, ps, queue, queue_next, ctr, parity, n_slots, dispatch_base, k3); } while (0)
+#define VPT_LAUNCH_BOUNCE_V(L, C, F, V) do { if (sc.strict_hits) hipLaunchKernelGGL((k_bounce<L, C, F, V, true>), g, b, lds, s, sc, P, ps, ss, queue, queue_next, ctr, parity, n_slots, dispatch_base, k3); \
+        else hipLaunchKernelGGL((k_bounce<L, C, F, V, false>), g, b, lds, s, sc, P, ps, ss, queue, queue_next, ctr, parity, n_slots, dispatch_base, k3); } while (0)
 #define VPT_LAUNCH_BOUNCE(L, C, F) VPT_LAUNCH_BOUNCE_V(L, C, F, false)
     if (sc.volume_count > 0u || sc.atm_on) {  // the media variants carry no traversal counters
         if (lds_scene) { if (first) VPT_LAUNCH_BOUNCE_V(true, false, true, true); else VPT_LAUNCH_BOUNCE_V(true, false, false, true); }

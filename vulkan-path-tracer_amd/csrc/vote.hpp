@@ -115,9 +115,10 @@ constexpr uint32_t kAppendChunk = 256;
 constexpr uint32_t kAppendExactBelow = 1u << 21;
 struct WaveAppender {
     uint32_t base, used;  // wave-uniform
+    uint32_t dyn_base;    // where the counter's reservations start in the stream (0 when the counter was preset to the static part)
     bool exact;
-    __device__ __forceinline__ void init(uint32_t wave_in_grid, bool exact_mode) {
-        exact = exact_mode;
+    __device__ __forceinline__ void init(uint32_t wave_in_grid, bool exact_mode, uint32_t dynamic_base = 0u) {
+        exact = exact_mode; dyn_base = dynamic_base;
         base = exact_mode ? 0u : wave_in_grid * kAppendChunk;
         used = exact_mode ? kAppendChunk : 0u;   // exact mode owns no chunk: tail_count() == 0
     }
@@ -139,7 +140,7 @@ struct WaveAppender {
         else {
             uint32_t nb = 0u;
             if (lane_id() == 0u) nb = atomicAdd(counter, kAppendChunk);
-            nb = __builtin_amdgcn_readfirstlane(nb);
+            nb = dyn_base + __builtin_amdgcn_readfirstlane(nb);
             pos = off < room ? base + used + off : nb + (off - room);
             base = nb; used = cnt - room;
         }

@@ -229,12 +229,13 @@ int alloc_render_buffers_impl(vpt_ctx* c) {
     HIPCHK(c, hipMalloc((void**)&c->cqueue, (size_t)cap * 4));
     {
         const size_t sst = (scap + 63) & ~(size_t)63;
-        HIPCHK(c, hipMalloc(&c->ss_block, sst * (16 * 15 + 4 + 2)));
+        HIPCHK(c, hipMalloc(&c->ss_block, sst * (16 * 17 + 4 + 2)));
         float4* q = (float4*)c->ss_block;
         StreamState& t = c->ss;
         t.PE = q; t.PS = q + sst; t.PL = q + 2 * sst; t.PT = q + 3 * sst; t.SKO = q + 4 * sst; t.SKD = q + 5 * sst; t.LTO = q + 6 * sst; t.LTD = q + 7 * sst;
         t.RA[0] = q + 8 * sst; t.RA[1] = q + 9 * sst; t.RB[0] = q + 10 * sst; t.RB[1] = q + 11 * sst; t.RT[0] = q + 12 * sst; t.RT[1] = q + 13 * sst;
-        t.SH = q + 14 * sst; t.SHI = (uint32_t*)(q + 15 * sst);
+        t.RL[0] = q + 14 * sst; t.RL[1] = q + 15 * sst;
+        t.SH = q + 16 * sst; t.SHI = (uint32_t*)(q + 17 * sst);
         t.vis_sky = (unsigned char*)(t.SHI + sst); t.vis_light = t.vis_sky + sst;
         t.cap = (uint32_t)scap;
         for (uint32_t k = 0; k < kShadeClasses; k++) HIPCHK(c, hipMalloc((void**)&c->class_queue[k], scap * 4));
@@ -396,7 +397,7 @@ int render_batch(vpt_ctx* c, uint32_t frames, uint32_t dispatch_base) {
     uint32_t parity;
     uint32_t k3 = 0;  // fused: bounce index % 3 (Counters::rc3)
     if (fused) {  // bounce 0 of every slot needs no input records; survivors land in queue[1]
-        TIMED(c, VPT_K_PRIMARY, launch_bounce(s, (uint32_t)c->primary_blocks, c->lds_scene, count, true, c->dsc, c->P, c->ps, nullptr, c->queue[1], c->ctr, 0u, n_slots, dispatch_base, 0u));
+        TIMED(c, VPT_K_PRIMARY, launch_bounce(s, (uint32_t)c->primary_blocks, c->lds_scene, count, true, c->dsc, c->P, c->ps, c->ss, nullptr, c->queue[1], c->ctr, 0u, n_slots, dispatch_base, 0u));
         parity = 1; k3 = 1;
     } else if (stream) {
         TIMED(c, VPT_K_PRIMARY, launch_raygen_stream(s, c->P, c->ps, c->ss, c->queue[0], n_slots, dispatch_base));
@@ -413,7 +414,7 @@ int render_batch(vpt_ctx* c, uint32_t frames, uint32_t dispatch_base) {
     while (true) {
         for (uint32_t j = 0; j < chunk; j++) {
             if (fused) {  // no reset kernel in between: the bounce kernels rotate three queue-size words
-                TIMED(c, VPT_K_BOUNCE, launch_bounce(s, (uint32_t)c->primary_blocks, c->lds_scene, count, false, c->dsc, c->P, c->ps, c->queue[parity], c->queue[parity ^ 1u], c->ctr, parity, 0u, 0u, k3));
+                TIMED(c, VPT_K_BOUNCE, launch_bounce(s, (uint32_t)c->primary_blocks, c->lds_scene, count, false, c->dsc, c->P, c->ps, c->ss, c->queue[parity], c->queue[parity ^ 1u], c->ctr, parity, 0u, 0u, k3));
                 parity ^= 1u; k3 = (k3 + 1u) % 3u;
                 continue;
             }
@@ -454,7 +455,7 @@ int render_batch(vpt_ctx* c, uint32_t frames, uint32_t dispatch_base) {
         if (!fused && !stream) launch_fold(s, c->ctr);
         // the resolve rides right behind the bounces that are expected to be the last ones; it does nothing if a path is
         // still alive (in-medium walks do not consume depth), in which case more bounces and another resolve follow
-        const uint32_t* guard = fused ? &c->ctr->rc3[k3] : stream ? &c->sctr->alive[parity].v : &c->ctr->ray_count[parity];
+        const uint32_t* guard = fused ? &c->ctr->alive3[k3] : stream ? &c->sctr->alive[parity].v : &c->ctr->ray_count[parity];
         TIMED(c, VPT_K_RESOLVE, launch_resolve(s, c->P, c->ps, c->image, frames, dispatch_base, guard));
         Counters h{};
         HIPCHK(c, hipMemcpyAsync(&h, c->ctr, sizeof(Counters), hipMemcpyDeviceToHost, s));
@@ -470,7 +471,7 @@ int render_batch(vpt_ctx* c, uint32_t frames, uint32_t dispatch_base) {
         c->stats.tris_tested = h.stat_tris;
         c->stats.shadow_nodes_visited = h.stat_shadow_nodes;
         c->stats.shadow_tris_tested = h.stat_shadow_tris;
-        uint32_t n = fused ? h.rc3[k3] : h.ray_count[parity];
+        uint32_t n = fused ? h.alive3[k3] : h.ray_count[parity];
         if (stream) {  // the exact number of live paths; the queue length (holes included) must fit the queue allocation
             uint32_t len = 0;
             HIPCHK(c, hipMemcpy(&n, &c->sctr->alive[parity].v, 4, hipMemcpyDeviceToHost));
