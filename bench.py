@@ -120,11 +120,20 @@ def traversal_counts(vpt, scene, params, device, rank, world, pipeline, frames):
             "closest_rays": cs["closest_rays"], "shadow_rays": cs["shadow_rays"], "samples": cs["samples"]}
 
 
+# stream pipeline (kernels_stream.hip): records in queue order, compact pending / shadow-ray streams
+SHADE_STREAM_IN = 4 + 16 + 16 + 16 + 20     # queue entry (slot), records RA, RB, RT, hit record: coalesced
+SHADE_STREAM_ALIVE = 4 + 48                 # survivor: queue entry + RA, RB, RT at its new position
+SHADE_STREAM_PENDING = 64                   # pending record PE, PS, PL, PT
+SHADOW_RAY = 32 + 1                         # ray record in, visibility byte out
+JOIN_FIXED = 64 + 16 + 16                   # pending record in, pathLight read + write (by slot)
+
+
 def kernel_table(st, tc):
     """Per stage: launches, mean ms, units, algorithmic bytes per unit (records + scene gathers + measured BVH visits) and
     the part of them that is unique per path (records / queue words / frame sums) and therefore has to cross HBM."""
     n0 = st["samples"]
     fused0 = st["kernel_launches"]["bounce"] > 0 or st["kernel_launches"]["extend"] == 0   # bounce 0 ran in the fused primary kernel
+    streams = st["kernel_launches"]["join"] > 0                                            # staged pipeline on compact streams
     n_later = st["closest_rays"] - (n0 if fused0 else 0)
     hits0, alive0, rays0 = st["primary_hits"], st["primary_survivors"], st["primary_shadow_rays"]
     later_rays = st["shadow_rays"] - rays0
@@ -132,19 +141,26 @@ def kernel_table(st, tc):
     node_b = st["bvh_node_bytes"]
     trav = tc["nodes_per_closest_ray"] * node_b + tc["tris_per_closest_ray"] * TRI_BYTES
     strav = tc["nodes_per_shadow_ray"] * node_b + tc["tris_per_shadow_ray"] * TRI_BYTES
-    fin = alive0 if fused0 else n0     # frame-sum writes by the connect stage
+    fin = alive0 if fused0 else n0     # frame-sum writes by the connect / join stage
+    pend = st["connect_paths"]
     units = {
         "primary": (n0, (PRIMARY_DONE * (n0 - alive0) + PRIMARY_ALIVE * alive0 + SHADE_SCENE * hits0 + strav * rays0) / max(n0, 1) + trav,
-                    (PRIMARY_DONE * (n0 - alive0) + PRIMARY_ALIVE * alive0) / max(n0, 1)) if fused0 else (n0, 68.0, 68.0),
+                    (PRIMARY_DONE * (n0 - alive0) + PRIMARY_ALIVE * alive0) / max(n0, 1)) if fused0 else (n0, 52.0 + 16.0, 52.0 + 16.0),
         "bounce": (n_later, 4 + 64 + SHADE_SCENE + trav + (PRIMARY_ALIVE * alive_later + PRIMARY_DONE * alive0 + strav * later_rays) / max(n_later, 1),
                    4 + 64 + (PRIMARY_ALIVE * alive_later + PRIMARY_DONE * alive0) / max(n_later, 1)),
         "extend": (n_later, EXTEND_FIXED + trav, EXTEND_FIXED),
-        "shade": (n_later, SHADE_IN + SHADE_SCENE + (SHADE_ALIVE_OUT * alive_later + SHADE_PENDING_OUT * st["connect_paths"] + SHADE_RAY_OUT * later_rays) / max(n_later, 1),
-                  SHADE_IN + (SHADE_ALIVE_OUT * alive_later + SHADE_PENDING_OUT * st["connect_paths"] + SHADE_RAY_OUT * later_rays) / max(n_later, 1)),
-        "connect": (st["connect_paths"], CONNECT_FIXED + (CONNECT_FINAL * fin + (CONNECT_RAY + strav) * later_rays) / max(st["connect_paths"], 1),
-                    CONNECT_FIXED + (CONNECT_FINAL * fin + CONNECT_RAY * later_rays) / max(st["connect_paths"], 1)),
         "resolve": (st["samples"], 16 + 32.0 / max(st["frames_in_flight"], 1), 16 + 32.0 / max(st["frames_in_flight"], 1)),
     }
+    if streams:
+        rec = SHADE_STREAM_IN + (SHADE_STREAM_ALIVE * alive_later + SHADE_STREAM_PENDING * pend + 32 * later_rays) / max(n_later, 1)
+        units["shade"] = (n_later, rec + SHADE_SCENE, rec)
+        units["shadow"] = (later_rays, SHADOW_RAY + strav, SHADOW_RAY)
+        units["join"] = (pend, JOIN_FIXED + (CONNECT_FINAL * fin) / max(pend, 1), JOIN_FIXED + (CONNECT_FINAL * fin) / max(pend, 1))
+    else:
+        units["shade"] = (n_later, SHADE_IN + SHADE_SCENE + (SHADE_ALIVE_OUT * alive_later + SHADE_PENDING_OUT * pend + SHADE_RAY_OUT * later_rays) / max(n_later, 1),
+                          SHADE_IN + (SHADE_ALIVE_OUT * alive_later + SHADE_PENDING_OUT * pend + SHADE_RAY_OUT * later_rays) / max(n_later, 1))
+        units["connect"] = (pend, CONNECT_FIXED + (CONNECT_FINAL * fin + (CONNECT_RAY + strav) * later_rays) / max(pend, 1),
+                            CONNECT_FIXED + (CONNECT_FINAL * fin + CONNECT_RAY * later_rays) / max(pend, 1))
     kernels = {}
     for name, (n, bpu, spu) in units.items():
         ms, launches = st["kernel_ms"][name], st["kernel_launches"][name]
@@ -204,7 +220,7 @@ def kernel_profile(vpt, name, scene, device, rank, world, pipeline, frames_in_fl
     used = 1 if st["kernel_launches"]["bounce"] > 0 else 2    # the pipeline AUTO settled on: count with the same one
     tc = traversal_counts(vpt, scene, params, device, rank, world, used if pipeline == 0 else pipeline, min(F, 4))
     kernels = kernel_table(st, tc)
-    return {"pipeline": "fused" if used == 1 else "staged", "bvh": {"nodes": st["bvh_nodes"], "triangles": st["bvh_triangles"], "node_bytes": st["bvh_node_bytes"], "tri_bytes": st["bvh_tri_bytes"]},
+    return {"pipeline": "fused" if used == 1 else ("staged (streams)" if st["kernel_launches"]["join"] > 0 else "staged (round-1 kernels)"), "bvh": {"nodes": st["bvh_nodes"], "triangles": st["bvh_triangles"], "node_bytes": st["bvh_node_bytes"], "tri_bytes": st["bvh_tri_bytes"]},
             "traversal": {k: round(v, 3) for k, v in tc.items() if k.endswith("_ray")}, "kernels": kernels}
 
 
@@ -220,7 +236,7 @@ def roofline_for(name, prof):
     # the fused kernels of an LDS-resident scene are VALU-bound (profiles/*_pmc_sq.md); traversal of a memory-resident BVH is
     # bounded by divergent VALU issue and dependent-fetch latency, shading by gathers: none of them is a streaming HBM kernel,
     # so the HBM fraction below is what they leave of the memory roofline, not a claim that HBM is the limiter
-    bound = "valu" if lds_scene or dom in ("extend", "connect", "trace") else "hbm"
+    bound = "valu" if lds_scene or dom in ("extend", "connect", "shadow", "shade") else "hbm"
     return {"bound": bound, "kernel": dom, "achieved": k["records_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(k["records_GBs"] / HBM_PEAK_GBS, 5),
             "traffic": traffic, "valu_busy": valu_busy, "avg_launch_ms": k["avg_ms"],
             "record_bytes_per_launch": round(k["record_bytes_per_unit"] * k["units_per_launch"], 0),

@@ -290,3 +290,60 @@ def test_glb_container_and_data_uris(cli, vpt, tmp_path, mode):
         open(bad, "wb").write(open(dst, "rb").read()[:200])
         p = subprocess.run([cli, "--scene", bad, "--info"], capture_output=True)
         assert p.returncode == 1 and b"glb" in p.stderr
+
+
+def _gltf(tmp_path, name, doc, bin_bytes=b"\x00" * 64):
+    import json as _json
+    (tmp_path / "b.bin").write_bytes(bin_bytes)
+    p = tmp_path / name
+    p.write_text(doc if isinstance(doc, str) else _json.dumps(doc))
+    return str(p)
+
+
+def _minimal():
+    import struct
+    tri = struct.pack("<9f", 0, 0, 0, 1, 0, 0, 0, 1, 0) + struct.pack("<3H", 0, 1, 2) + b"\x00\x00"
+    doc = {"asset": {"version": "2.0"}, "buffers": [{"uri": "b.bin", "byteLength": len(tri)}],
+           "bufferViews": [{"buffer": 0, "byteOffset": 0, "byteLength": 36}, {"buffer": 0, "byteOffset": 36, "byteLength": 6}],
+           "accessors": [{"bufferView": 0, "componentType": 5126, "count": 3, "type": "VEC3"}, {"bufferView": 1, "componentType": 5123, "count": 3, "type": "SCALAR"}],
+           "meshes": [{"primitives": [{"attributes": {"POSITION": 0}, "indices": 1}]}], "nodes": [{"mesh": 0}], "scenes": [{"nodes": [0]}], "scene": 0}
+    return doc, tri
+
+
+def test_cpp_importer_rejects_malformed_files_without_crashing(cli, tmp_path):
+    """the C++ glTF / PNG readers must treat file contents as untrusted (the Python twin raises in these cases)."""
+    import copy
+    doc, tri = _minimal()
+    ok = subprocess.run([cli, "--scene", _gltf(tmp_path, "ok.gltf", doc, tri), "--info"], capture_output=True)
+    assert ok.returncode == 0 and json.loads(ok.stdout)["triangles"] == 1
+    bad = {}
+    d = copy.deepcopy(doc); d["accessors"][0]["count"] = 2 ** 62; bad["huge_count"] = d
+    d = copy.deepcopy(doc); d["accessors"][0]["count"] = 2 ** 40; d["bufferViews"][0]["byteStride"] = 2 ** 40; bad["stride_overflow"] = d
+    d = copy.deepcopy(doc); d["accessors"][0]["bufferView"] = 7; bad["bufferview_index"] = d
+    d = copy.deepcopy(doc); d["bufferViews"][0]["buffer"] = 3; bad["buffer_index"] = d
+    d = copy.deepcopy(doc); del d["accessors"]; bad["no_accessors"] = d
+    d = copy.deepcopy(doc); del d["accessors"][0]["type"]; bad["no_type"] = d
+    d = copy.deepcopy(doc); d["accessors"][0]["byteOffset"] = -5; bad["negative_offset"] = d
+    d = copy.deepcopy(doc); d["nodes"] = [{"children": [1]}, {"children": [0], "mesh": 0}]; bad["node_cycle"] = d
+    d = copy.deepcopy(doc); d["nodes"][0]["mesh"] = 9; bad["mesh_index"] = d
+    d = copy.deepcopy(doc); d["scenes"][0]["nodes"] = [5]; bad["root_index"] = d
+    d = copy.deepcopy(doc); d["materials"] = [{"pbrMetallicRoughness": {"baseColorTexture": {"index": 4}}}]; bad["texture_index"] = d
+    d = copy.deepcopy(doc); d["nodes"][0]["matrix"] = [1, 0, 0]; bad["short_matrix"] = d
+    for name, dd in bad.items():
+        p = subprocess.run([cli, "--scene", _gltf(tmp_path, name + ".gltf", dd, tri), "--info"], capture_output=True, timeout=30)
+        assert p.returncode == 1 and p.stderr, (name, p.returncode, p.stderr[-200:])
+    deep = "[" * 5000 + "]" * 5000
+    p = subprocess.run([cli, "--scene", _gltf(tmp_path, "deep.gltf", '{"x": %s}' % deep, tri), "--info"], capture_output=True, timeout=30)
+    assert p.returncode == 1
+    # PNG readers: a short IHDR chunk and absurd dimensions
+    import struct, zlib
+    def chunk(t, d): return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d))
+    sig = b"\x89PNG\r\n\x1a\n"
+    pngs = {"short_ihdr": sig + chunk(b"IHDR", b"\0" * 4) + chunk(b"IDAT", zlib.compress(b"\0" * 16)) + chunk(b"IEND", b""),
+            "huge": sig + chunk(b"IHDR", struct.pack(">IIBBBBB", 2 ** 31 - 1, 2 ** 31 - 1, 8, 6, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(b"\0" * 16)) + chunk(b"IEND", b"")}
+    for name, data in pngs.items():
+        (tmp_path / (name + ".png")).write_bytes(data)
+        d = copy.deepcopy(doc); d["images"] = [{"uri": name + ".png"}]; d["textures"] = [{"source": 0}]
+        d["materials"] = [{"pbrMetallicRoughness": {"baseColorTexture": {"index": 0}}}]
+        p = subprocess.run([cli, "--scene", _gltf(tmp_path, name + ".gltf", d, tri), "--info"], capture_output=True, timeout=30)
+        assert p.returncode == 1 and b"PNG" in p.stderr, (name, p.returncode, p.stderr[-200:])

@@ -17,6 +17,9 @@ namespace {
 // ---------------------------------------------------------------- JSON
 struct JVal;
 using JPtr = std::shared_ptr<JVal>;
+// Files are untrusted: every array index and every required key goes through accessors that never touch memory they should not.
+// A bad access yields a shared Null value and raises g_malformed, which ImportScene turns into an error.
+thread_local bool g_malformed = false;
 struct JVal {
     enum Type { Null, Bool, Num, Str, Arr, Obj } type = Null;
     double num = 0;
@@ -24,29 +27,36 @@ struct JVal {
     std::string str;
     std::vector<JPtr> arr;
     std::map<std::string, JPtr> obj;
+    static const JVal& null_value() { static const JVal v; return v; }
     const JVal* get(const std::string& k) const { auto it = obj.find(k); return it == obj.end() ? nullptr : it->second.get(); }
     bool has(const std::string& k) const { return obj.count(k) != 0; }
     double number(const std::string& k, double def) const { const JVal* v = get(k); return v && v->type == Num ? v->num : def; }
     size_t size() const { return arr.size(); }
-    const JVal& operator[](size_t i) const { return *arr[i]; }
+    const JVal& operator[](size_t i) const { if (i >= arr.size() || !arr[i]) { g_malformed = true; return null_value(); } return *arr[i]; }
+    // required member: the shared Null (and the malformed flag) when it is missing
+    const JVal& req(const std::string& k) const { const JVal* v = get(k); if (!v) { g_malformed = true; return null_value(); } return *v; }
+    // array index stored as a JSON number: SIZE_MAX (always out of range) for anything that is not a non-negative integer
+    size_t index(const std::string& k, double def) const { const double d = number(k, def); return (d >= 0.0 && d < 9.0e15) ? (size_t)d : (size_t)-1; }
+    size_t as_index() const { return (type == Num && num >= 0.0 && num < 9.0e15) ? (size_t)num : (size_t)-1; }
 };
+constexpr int kMaxJsonDepth = 256;
 struct JParser {
     const std::string& s; size_t p = 0; bool ok = true;
     explicit JParser(const std::string& t) : s(t) {}
     void ws() { while (p < s.size() && (s[p] == ' ' || s[p] == '\n' || s[p] == '\t' || s[p] == '\r')) p++; }
-    JPtr parse() {
+    JPtr parse(int depth = 0) {
         ws();
         auto v = std::make_shared<JVal>();
-        if (p >= s.size()) { ok = false; return v; }
+        if (p >= s.size() || depth > kMaxJsonDepth) { ok = false; return v; }   // nesting is bounded: the parser recurses
         char c = s[p];
         if (c == '{') {
             v->type = JVal::Obj; p++; ws();
             if (p < s.size() && s[p] == '}') { p++; return v; }
             while (ok) {
-                ws(); JPtr k = parse(); ws();
+                ws(); JPtr k = parse(depth + 1); ws();
                 if (!ok || k->type != JVal::Str || p >= s.size() || s[p] != ':') { ok = false; break; }
                 p++;
-                v->obj[k->str] = parse(); ws();
+                v->obj[k->str] = parse(depth + 1); ws();
                 if (p < s.size() && s[p] == ',') { p++; continue; }
                 if (p < s.size() && s[p] == '}') { p++; break; }
                 ok = false;
@@ -55,7 +65,7 @@ struct JParser {
             v->type = JVal::Arr; p++; ws();
             if (p < s.size() && s[p] == ']') { p++; return v; }
             while (ok) {
-                v->arr.push_back(parse()); ws();
+                v->arr.push_back(parse(depth + 1)); ws();
                 if (p < s.size() && s[p] == ',') { p++; continue; }
                 if (p < s.size() && s[p] == ']') { p++; break; }
                 ok = false;
@@ -160,13 +170,17 @@ bool DecodePNG(const std::string& f, const std::string& path, TextureAsset& out,
     for (size_t p = 8; p + 12 <= f.size();) {
         uint32_t len = be32(p); std::string type = f.substr(p + 4, 4);
         if (p + 12 + len > f.size()) break;
-        if (type == "IHDR") { w = be32(p + 8); h = be32(p + 12); depth = (uint8_t)f[p + 16]; ctype = (uint8_t)f[p + 17]; interlace = (uint8_t)f[p + 20]; }
+        if (type == "IHDR") {
+            if (len < 13) { error = "bad PNG header: " + path; return false; }
+            w = be32(p + 8); h = be32(p + 12); depth = (uint8_t)f[p + 16]; ctype = (uint8_t)f[p + 17]; interlace = (uint8_t)f[p + 20];
+        }
         else if (type == "IDAT") idat.append(f, p + 8, len);
         else if (type == "IEND") break;
         p += 12 + len;
     }
     int ch = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
     if (depth != 8 || ch == 0 || interlace != 0 || w == 0 || h == 0) { error = "unsupported PNG format (need 8-bit gray/RGB/RGBA, non-interlaced): " + path; return false; }
+    if (w > 32768u || h > 32768u) { error = "PNG larger than 32768 x 32768: " + path; return false; }   // bounds every size computed below (< 2^32 bytes)
     const size_t stride = (size_t)w * ch;
     std::vector<uint8_t> raw((stride + 1) * h);
     uLongf dl = (uLongf)raw.size();
@@ -299,6 +313,7 @@ bool ImportScene(const std::string& gltfPath, SceneAsset& sc, std::string& error
         if (json.empty()) { error = "no JSON chunk in " + gltfPath; return false; }
         text.swap(json);
     }
+    g_malformed = false;
     JParser jp(text);
     JPtr root = jp.parse();
     if (!jp.ok || root->type != JVal::Obj) { error = "JSON parse error in " + gltfPath; return false; }
@@ -313,19 +328,24 @@ bool ImportScene(const std::string& gltfPath, SceneAsset& sc, std::string& error
             else if (!decode_data_uri(uri->str, d) && !read_file(base + "/" + uri->str, d)) { error = "cannot read glTF buffer " + uri->str; return false; }
             bufs.push_back(std::move(d));
         }
-    auto accessor = [&](int idx, std::vector<double>& out, int& ncomp) -> bool {
-        const JVal& a = (*g.get("accessors"))[(size_t)idx];
-        const JVal& bv = (*g.get("bufferViews"))[(size_t)a.number("bufferView", 0)];
+    auto accessor = [&](size_t idx, std::vector<double>& out, int& ncomp) -> bool {
+        const JVal& a = g.req("accessors")[idx];
+        const JVal& bv = g.req("bufferViews")[a.index("bufferView", 0)];
         int ct = (int)a.number("componentType", 5126);
-        const std::string& ty = a.get("type")->str;
-        ncomp = ty == "SCALAR" ? 1 : ty == "VEC2" ? 2 : ty == "VEC3" ? 3 : ty == "VEC4" ? 4 : 16;
-        size_t count = (size_t)a.number("count", 0);
-        size_t csz = ct == 5126 || ct == 5125 ? 4 : (ct == 5123 || ct == 5122 ? 2 : 1);
-        size_t off = (size_t)bv.number("byteOffset", 0) + (size_t)a.number("byteOffset", 0);
-        size_t stride = (size_t)bv.number("byteStride", 0);
+        const std::string& ty = a.req("type").str;
+        ncomp = ty == "SCALAR" ? 1 : ty == "VEC2" ? 2 : ty == "VEC3" ? 3 : ty == "VEC4" ? 4 : ty == "MAT4" ? 16 : 0;
+        const size_t bi = bv.index("buffer", 0);
+        if (g_malformed || ncomp == 0 || bi >= bufs.size()) return false;
+        const size_t count = a.index("count", 0);
+        const size_t csz = ct == 5126 || ct == 5125 ? 4 : (ct == 5123 || ct == 5122 ? 2 : 1);
+        const size_t off0 = bv.index("byteOffset", 0), off1 = a.index("byteOffset", 0);
+        size_t stride = bv.index("byteStride", 0);
         if (!stride) stride = csz * ncomp;
-        const std::string& buf = bufs[(size_t)bv.number("buffer", 0)];
-        if (off + (count ? (count - 1) * stride + csz * ncomp : 0) > buf.size()) return false;
+        const std::string& buf = bufs[bi];
+        // the last element must end inside the buffer; 128-bit arithmetic, so no crafted count / stride can wrap the check
+        const unsigned __int128 end = (unsigned __int128)off0 + off1 + (count ? (unsigned __int128)(count - 1) * stride + csz * ncomp : 0);
+        if (count == (size_t)-1 || off0 == (size_t)-1 || off1 == (size_t)-1 || stride == (size_t)-1 || end > buf.size()) return false;
+        const size_t off = off0 + off1;
         out.resize(count * ncomp);
         for (size_t k = 0; k < count; k++)
             for (int c = 0; c < ncomp; c++) {
@@ -349,8 +369,9 @@ bool ImportScene(const std::string& gltfPath, SceneAsset& sc, std::string& error
     std::map<std::string, uint32_t> texCache;
     auto textureIndex = [&](const JVal* ref, bool single, uint32_t& outIdx) -> bool {
         if (!ref) return true;
-        const JVal& tex = (*g.get("textures"))[(size_t)ref->number("index", 0)];
-        const JVal& img = (*g.get("images"))[(size_t)tex.number("source", 0)];
+        const JVal& tex = g.req("textures")[ref->index("index", 0)];
+        const JVal& img = g.req("images")[tex.index("source", 0)];
+        if (g_malformed) { error = "glTF texture / image index out of range"; return false; }
         // image source: external file, data: URI, or a bufferView (embedded PNG, the usual .glb form)
         const JVal* iuri = img.get("uri");
         std::string key = (iuri ? iuri->str : "bufferView:" + std::to_string((long long)img.number("bufferView", -1))) + (single ? "#r" : "");
@@ -363,8 +384,8 @@ bool ImportScene(const std::string& gltfPath, SceneAsset& sc, std::string& error
                 const long long bi = (long long)img.number("bufferView", -1);
                 if (!bvs || bi < 0 || (size_t)bi >= bvs->size()) { error = "glTF image without uri or bufferView"; return false; }
                 const JVal& bv = (*bvs)[(size_t)bi];
-                const size_t bidx = (size_t)bv.number("buffer", 0), off = (size_t)bv.number("byteOffset", 0), len = (size_t)bv.number("byteLength", 0);
-                if (bidx >= bufs.size() || off + len > bufs[bidx].size()) { error = "glTF image bufferView out of range"; return false; }
+                const size_t bidx = bv.index("buffer", 0), off = bv.index("byteOffset", 0), len = bv.index("byteLength", 0);
+                if (bidx >= bufs.size() || off > bufs[bidx].size() || len > bufs[bidx].size() - off) { error = "glTF image bufferView out of range"; return false; }
                 bytes = bufs[bidx].substr(off, len);
                 if (!DecodePNG(bytes, key, t, error)) return false;
             } else if (decode_data_uri(iuri->str, bytes)) {
@@ -415,15 +436,15 @@ bool ImportScene(const std::string& gltfPath, SceneAsset& sc, std::string& error
     std::map<std::pair<int, int>, std::pair<uint32_t, uint32_t>> primMesh;
     if (const JVal* meshes = g.get("meshes"))
         for (size_t mi = 0; mi < meshes->size(); mi++) {
-            const JVal& prims = *(*meshes)[mi].get("primitives");
+            const JVal& prims = (*meshes)[mi].req("primitives");
             for (size_t pi = 0; pi < prims.size(); pi++) {
                 const JVal& p = prims[pi];
-                const JVal& attr = *p.get("attributes");
+                const JVal& attr = p.req("attributes");
                 std::vector<double> pos, nrm, uv, idx; int nc;
-                if (!attr.has("POSITION") || !accessor((int)attr.number("POSITION", 0), pos, nc)) { error = "primitive without POSITION"; return false; }
+                if (!attr.has("POSITION") || !accessor(attr.index("POSITION", 0), pos, nc) || nc != 3) { error = "primitive without a readable POSITION accessor"; return false; }
                 size_t nv = pos.size() / 3;
-                if (attr.has("NORMAL")) accessor((int)attr.number("NORMAL", 0), nrm, nc);
-                if (attr.has("TEXCOORD_0")) accessor((int)attr.number("TEXCOORD_0", 0), uv, nc);
+                if (attr.has("NORMAL") && !accessor(attr.index("NORMAL", 0), nrm, nc)) { error = "unreadable NORMAL accessor"; return false; }
+                if (attr.has("TEXCOORD_0") && !accessor(attr.index("TEXCOORD_0", 0), uv, nc)) { error = "unreadable TEXCOORD_0 accessor"; return false; }
                 MeshAsset me; me.Vertices.resize(nv);
                 for (size_t v = 0; v < nv; v++) {
                     vpt_vertex& o = me.Vertices[v];
@@ -432,13 +453,14 @@ bool ImportScene(const std::string& gltfPath, SceneAsset& sc, std::string& error
                     else { o.normal[0] = o.normal[1] = o.normal[2] = 0; }
                     if (uv.size() == nv * 2) { o.texcoord[0] = (float)uv[v * 2]; o.texcoord[1] = (float)uv[v * 2 + 1]; } else { o.texcoord[0] = o.texcoord[1] = 0; }
                 }
-                if (p.has("indices")) { accessor((int)p.number("indices", 0), idx, nc); } else { idx.resize(nv); for (size_t k = 0; k < nv; k++) idx[k] = (double)k; }
+                if (p.has("indices")) { if (!accessor(p.index("indices", 0), idx, nc)) { error = "unreadable index accessor"; return false; } } else { idx.resize(nv); for (size_t k = 0; k < nv; k++) idx[k] = (double)k; }
                 me.Indices.resize(idx.size() / 3 * 3);
+                for (size_t t = 0; t < idx.size(); t++) if (!(idx[t] >= 0.0 && idx[t] < (double)nv)) { error = "vertex index out of range"; return false; }
                 for (size_t t = 0; t + 2 < idx.size(); t += 3) {  // mirror => swap the winding so geometric and vertex normals agree
                     me.Indices[t] = (uint32_t)idx[t]; me.Indices[t + 1] = (uint32_t)idx[t + 2]; me.Indices[t + 2] = (uint32_t)idx[t + 1];
                 }
                 sc.Meshes.push_back(std::move(me));
-                primMesh[{(int)mi, (int)pi}] = {(uint32_t)sc.Meshes.size() - 1, (uint32_t)p.number("material", 0)};
+                primMesh[{(int)mi, (int)pi}] = {(uint32_t)sc.Meshes.size() - 1, (uint32_t)std::min<size_t>(p.index("material", 0), 0xffffffffu)};
             }
         }
 
@@ -447,19 +469,24 @@ bool ImportScene(const std::string& gltfPath, SceneAsset& sc, std::string& error
     std::vector<Walk> stack;
     const JVal* nodes = g.get("nodes");
     const JVal* scenes = g.get("scenes");
+    std::vector<char> visited(nodes ? nodes->size() : 0, 0);   // a node has one parent in valid glTF: seeing one twice means a cycle or a DAG
     if (nodes && scenes && scenes->size()) {
-        const JVal& roots = *(*scenes)[(size_t)g.number("scene", 0)].get("nodes");
-        for (size_t i = roots.size(); i-- > 0;) { Walk w; w.node = (size_t)roots[i].num; for (int a = 0; a < 4; a++) for (int b = 0; b < 4; b++) w.M[a][b] = a == b; stack.push_back(w); }
+        const JVal& roots = (*scenes)[g.index("scene", 0)].req("nodes");
+        for (size_t i = roots.size(); i-- > 0;) { Walk w; w.node = roots[i].as_index(); for (int a = 0; a < 4; a++) for (int b = 0; b < 4; b++) w.M[a][b] = a == b; stack.push_back(w); }
     }
     while (!stack.empty()) {
         Walk w = stack.back(); stack.pop_back();
+        if (w.node >= visited.size() || visited[w.node]) { error = "glTF node index out of range or node reachable twice"; return false; }
+        visited[w.node] = 1;
         const JVal& n = (*nodes)[w.node];
         double L[4][4], M[4][4];
         node_matrix(n, L); matmul(w.M, L, M);
         double F[4][4]; std::memcpy(F, M, sizeof(F)); flip_y(F);
         if (n.has("mesh")) {
-            int mi = (int)n.number("mesh", 0);
-            const JVal& prims = *(*g.get("meshes"))[(size_t)mi].get("primitives");
+            const size_t mi_ = n.index("mesh", 0);
+            const JVal& prims = g.req("meshes")[mi_].req("primitives");
+            if (g_malformed) { error = "glTF node references a missing mesh"; return false; }
+            int mi = (int)mi_;
             for (size_t pi = 0; pi < prims.size(); pi++) {
                 auto pm = primMesh[{mi, (int)pi}];
                 MeshInstance inst; inst.MeshIndex = pm.first; inst.MaterialIndex = pm.second; inst.Transform = from_rows(F);
@@ -467,15 +494,16 @@ bool ImportScene(const std::string& gltfPath, SceneAsset& sc, std::string& error
             }
         }
         if (n.has("camera") && sc.Cameras.empty()) {
-            const JVal& c = (*g.get("cameras"))[(size_t)n.number("camera", 0)];
+            const JVal& c = g.req("cameras")[n.index("camera", 0)];
             CameraAsset cam;
             if (const JVal* p = c.get("perspective")) { cam.AspectRatio = (float)p->number("aspectRatio", 16.0 / 9.0); cam.FOV = degrees((float)p->number("yfov", 0.7853981633974483)); }
             cam.ViewMatrix = inverse(from_rows(F));
             sc.Cameras.push_back(cam);
         }
         if (const JVal* ch = n.get("children"))
-            for (size_t i = ch->size(); i-- > 0;) { Walk c; c.node = (size_t)(*ch)[i].num; std::memcpy(c.M, M, sizeof(M)); stack.push_back(c); }
+            for (size_t i = ch->size(); i-- > 0;) { Walk c; c.node = (*ch)[i].as_index(); std::memcpy(c.M, M, sizeof(M)); stack.push_back(c); }
     }
+    if (g_malformed) { error = "malformed glTF: an index or a required member is missing or out of range"; return false; }
     if (sc.Meshes.empty()) { error = "No meshes found in scene"; return false; }  // PathTracer.cpp:180
     return true;
 }
