@@ -1693,6 +1693,33 @@ void orc_fp32_eval(int fn, const float* x, const float* y, float* out, uint32_t 
     }
 }
 
+// Leaf primitives of the fp32 contract that the HIP kernels and this oracle SHARE (include/vpt_fp32.h), exposed one by one so
+// that tests/test_fp32_contract.py can hold them against independent float64 / numpy restatements — HIP-vs-oracle parity
+// cannot see a bug in code both sides compile.  fn: 0 ray_triangle (in: o3 d3 v0 3 e1 3 e2 3 tmin tmax; out: hit t u v),
+// 1 texel_coords (in: u size repeat; out: i0 i1 w), 2 lut_layer (in: layer layers; out: index), 3 refract (in: i3 n3 eta;
+// out: 3), 4 smoothstep (in: e0 e1 x), 5 reflect (in: i3 n3; out: 3), 6 normalize (in: 3; out: 3), 7 unorm8 (in: c),
+// 8 hit_is_local (in: o3 d3 v0 3 e1 3 e2 3 t; out: 0/1), 9 triangle_degenerate (in: e1 3 e2 3; out: 0/1).
+void orc_leaf_eval(int fn, const float* in, float* out, uint32_t n) {
+    for (uint32_t i = 0; i < n; i++) {
+        switch (fn) {
+            case 0: {
+                const float* a = in + (size_t)i * 17; float t = 0, u = 0, v = 0;
+                bool h = ray_triangle(v3(a[0], a[1], a[2]), v3(a[3], a[4], a[5]), v3(a[6], a[7], a[8]), v3(a[9], a[10], a[11]), v3(a[12], a[13], a[14]), a[15], a[16], &t, &u, &v);
+                out[i * 4] = h ? 1.0f : 0.0f; out[i * 4 + 1] = t; out[i * 4 + 2] = u; out[i * 4 + 3] = v; break;
+            }
+            case 1: { const float* a = in + (size_t)i * 3; int i0, i1; float w; texel_coords(a[0], (int)a[1], a[2] != 0.0f, &i0, &i1, &w); out[i * 3] = (float)i0; out[i * 3 + 1] = (float)i1; out[i * 3 + 2] = w; break; }
+            case 2: out[i] = (float)lut_layer(in[i * 2], (int)in[i * 2 + 1]); break;
+            case 3: { const float* a = in + (size_t)i * 7; V3 r = refract(v3(a[0], a[1], a[2]), v3(a[3], a[4], a[5]), a[6]); out[i * 3] = r.x; out[i * 3 + 1] = r.y; out[i * 3 + 2] = r.z; break; }
+            case 4: out[i] = smoothstep(in[i * 3], in[i * 3 + 1], in[i * 3 + 2]); break;
+            case 5: { const float* a = in + (size_t)i * 6; V3 r = reflect(v3(a[0], a[1], a[2]), v3(a[3], a[4], a[5])); out[i * 3] = r.x; out[i * 3 + 1] = r.y; out[i * 3 + 2] = r.z; break; }
+            case 6: { const float* a = in + (size_t)i * 3; V3 r = normalize(v3(a[0], a[1], a[2])); out[i * 3] = r.x; out[i * 3 + 1] = r.y; out[i * 3 + 2] = r.z; break; }
+            case 7: out[i] = (float)unorm8(in[i]); break;
+            case 8: { const float* a = in + (size_t)i * 16; out[i] = hit_is_local(v3(a[0], a[1], a[2]), v3(a[3], a[4], a[5]), v3(a[6], a[7], a[8]), v3(a[9], a[10], a[11]), v3(a[12], a[13], a[14]), a[15]) ? 1.0f : 0.0f; break; }
+            default: { const float* a = in + (size_t)i * 6; out[i] = triangle_degenerate(v3(a[0], a[1], a[2]), v3(a[3], a[4], a[5])) ? 1.0f : 0.0f; break; }
+        }
+    }
+}
+
 // LookupReflect.slang:25-85 for one table cell (x,y,z) of a (sx,sy,sz) table; nsamples MC samples.
 float orc_lut_reflect_cell(uint32_t x, uint32_t y, uint32_t z, uint32_t sx, uint32_t sy, uint32_t sz, uint32_t nsamples, uint32_t seed) {
     Rng r; r.s = y + x * x + seed;

@@ -62,6 +62,7 @@ def lib():
         L.orc_uniform_float.restype = C.c_float
         L.orc_uniform_float.argtypes = [C.c_uint32]
         L.orc_fp32_eval.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+        L.orc_leaf_eval.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_uint32]
         L.orc_lut_reflect_cell.restype = C.c_float
         L.orc_lut_reflect_cell.argtypes = [C.c_uint32] * 8
         L.orc_lut_refract_cell.restype = C.c_float
@@ -227,6 +228,19 @@ def postprocess(img, post_params, flags=None):
     bloom = np.zeros((h, w, 4), np.float32)
     L.orc_postprocess(img.ctypes.data, w, h, C.byref(post_params), _abi.FLAGS_DEFAULT if flags is None else flags, out.ctypes.data, bloom.ctypes.data)
     return out, bloom
+
+
+_LEAF = {"ray_triangle": (0, 17, 4), "texel_coords": (1, 3, 3), "lut_layer": (2, 2, 1), "refract": (3, 7, 3), "smoothstep": (4, 3, 1),
+         "reflect": (5, 6, 3), "normalize": (6, 3, 3), "unorm8": (7, 1, 1), "hit_is_local": (8, 16, 1), "triangle_degenerate": (9, 6, 1)}
+
+
+def leaf_eval(fn, x):
+    """A shared leaf primitive of include/vpt_fp32.h on rows of float32 inputs (orc_leaf_eval): -> [n, outputs]."""
+    code, nin, nout = _LEAF[fn]
+    x = np.ascontiguousarray(x, np.float32).reshape(-1, nin)
+    out = np.empty((len(x), nout), np.float32)
+    lib().orc_leaf_eval(code, x.ctypes.data, out.ctypes.data, len(x))
+    return out
 
 
 def fp32_eval(fn, x, y=None):
