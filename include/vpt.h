@@ -224,6 +224,8 @@ typedef struct vpt_stats {
     uint32_t emissive_triangle_count;
     uint32_t frames_in_flight;
     uint32_t shard_pixels;
+    uint32_t bvh8_nodes;       /* eight-wide nodes of the BVH8 experiment (0 until VPT_TRACE_VOTE8 was used) */
+    uint32_t reserved;
 } vpt_stats;
 
 typedef struct vpt_ctx vpt_ctx;
@@ -384,6 +386,7 @@ int vpt_trace_rays(vpt_ctx* ctx, const vpt_ray* rays_host, uint32_t n, vpt_hit* 
  * visited, from one extra counting launch. */
 #define VPT_TRACE_BASE 0u  /* one ray per lane, 64 rays per wave at a time (round 1's extend / shadow loop) */
 #define VPT_TRACE_VOTE 1u  /* persistent lanes, wave-level vote between node / triangle / fetch steps, ray replacement */
+#define VPT_TRACE_VOTE8 2u /* the same on an eight-wide tree with octant-ordered children (BVH8 experiment; built on first use) */
 int vpt_lab_set_rays(vpt_ctx* ctx, const vpt_ray* rays_host, uint32_t n);
 int vpt_lab_trace(vpt_ctx* ctx, uint32_t variant, uint32_t any_hit, const uint32_t* order_host, uint32_t param, uint32_t reps,
                   vpt_hit* hits_host, float* best_ms, uint64_t* visits);

@@ -76,12 +76,27 @@ def test_config3_atrium_1080p_pipelines_and_shards_agree(vpt, atrium):
         s.close()
 
 
-def test_config4_atrium_4k_runs_and_matches_between_pipelines(vpt, atrium):
-    """3840x2160 (config 4's per-frame size): 8.3 M paths per frame, two frames; staged == fused."""
+def test_config4_atrium_4k_matches_the_oracle_on_crops(vpt, oracle, atrium):
+    """3840x2160 (config 4's per-frame size): 8.3 M paths per frame, two frames.  Staged == fused over the whole image, and both
+    equal the ORACLE bit for bit on 4096 pixels: four 32x32 blocks (image corners' neighbourhood, centre) and 1024 random
+    pixels — the oracle renders single pixels of the 4K frame (orc_pixel_samples), so the check runs at the config's own size."""
     P = vpt.default_params(max_depth=8)
-    a = vpt.PathTracer(3840, 2160, pipeline=2, frames_in_flight=2); a.set_scene(atrium); a.set_params(P); a.render(2); ia = a.radiance(); a.close()
-    b = vpt.PathTracer(3840, 2160, pipeline=1, frames_in_flight=2); b.set_scene(atrium); b.set_params(P); b.render(2); ib = b.radiance(); b.close()
+    W, H = 3840, 2160
+    a = vpt.PathTracer(W, H, pipeline=2, frames_in_flight=2); a.set_scene(atrium); a.set_params(P); a.render(2); ia = a.radiance(); a.close()
+    b = vpt.PathTracer(W, H, pipeline=1, frames_in_flight=2); b.set_scene(atrium); b.set_params(P); b.render(2); ib = b.radiance(); b.close()
     assert np.array_equal(ia, ib) and np.isfinite(ia).all()
+    rng = np.random.default_rng(4)
+    xs, ys = [rng.integers(0, W, 1024)], [rng.integers(0, H, 1024)]
+    for bx, by in ((100, 80), (W - 140, 90), (W // 2 - 16, H // 2 - 16), (700, H - 120)):
+        yy, xx = np.mgrid[by:by + 32, bx:bx + 32]
+        xs.append(xx.ravel()); ys.append(yy.ravel())
+    xs, ys = np.concatenate(xs).astype(np.uint32), np.concatenate(ys).astype(np.uint32)
+    o = oracle.Oracle(atrium, W, H); o.set_params(P)
+    smp = o.pixel_samples(xs, ys, 0, 2); o.close()                       # [npix, 2 frames, 3]
+    # the running mean of two frames exactly as RayGen.slang:130-159 forms it: frame 0, then lerp(old, new, 1/2)
+    c = smp[:, 0, :].astype(np.float32)
+    ref = (c + (smp[:, 1, :] - c) * np.float32(1.0 / 2.0)).astype(np.float32)
+    assert np.array_equal(ia[ys, xs, :3], ref)
 
 
 def test_config3_known_grazing_samples_with_strict_hits(vpt, oracle):

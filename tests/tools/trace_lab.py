@@ -23,7 +23,7 @@ sys.path.insert(0, ROOT)
 vpt = importlib.import_module("vulkan-path-tracer_amd")
 
 W, H = 1920, 1080
-BASE, VOTE = 0, 1
+BASE, VOTE, VOTE8 = 0, 1, 2
 
 
 def world_triangles(sc):
@@ -156,14 +156,14 @@ def main():
         orders = {"stream": None} if quick else {"stream": None, "sorted": sort_order(rays)}
         ref = None
         for oname, order in orders.items():
-            for variant, param in ([(BASE, 0), (VOTE, 16), (VOTE, 256 + 16)] if quick else [(BASE, 0), (VOTE, 8), (VOTE, 16), (VOTE, 32), (VOTE, 48), (VOTE, 64), (VOTE, 256 + 16), (VOTE, 256 + 32)]):
-                first = ref is None or (variant == VOTE and param == 16)
+            for variant, param in ([(BASE, 0), (VOTE, 16), (VOTE, 256 + 16), (VOTE8, 16), (VOTE8, 256 + 16)] if quick else [(BASE, 0), (VOTE, 8), (VOTE, 16), (VOTE, 32), (VOTE, 48), (VOTE, 64), (VOTE, 256 + 16), (VOTE, 256 + 32)]):
+                first = ref is None or (variant in (VOTE, VOTE8) and param == 16)
                 ms, hits, vis = lab_trace(g, variant, any_hit, order, param, 5, True, first)
                 if ref is None:
                     ref = hits
                 same = bool(np.array_equal(hits["t"], ref["t"]) and np.array_equal(hits["u"], ref["u"]) and np.array_equal(hits["v"], ref["v"]) and
                             np.array_equal(hits["primitive"], ref["primitive"]) and np.array_equal(hits["instance"], ref["instance"]))
-                r = {"scene": which, "set": name, "rays": len(rays), "any_hit": any_hit, "order": oname, "variant": "base" if variant == BASE else "vote", "param": param,
+                r = {"scene": which, "set": name, "rays": len(rays), "any_hit": any_hit, "order": oname, "variant": ["base", "vote", "vote_bvh8"][variant], "param": param,
                      "ms": round(ms, 4), "grays_per_s": round(len(rays) / ms / 1e6, 3), "equal_to_reference": same,
                      "hit_fraction": round(float((ref["t"] > 0).mean()), 4)}
                 if vis:

@@ -107,7 +107,8 @@ struct Builder {
 inline int32_t leaf_code(int first, int count) { return ~(int32_t)(((uint32_t)first << 3) | (uint32_t)(count - 1)); }
 }  // namespace
 
-void build_bvh(const std::vector<BvhTri>& tris_in, std::vector<BvhNode>& nodes_out, std::vector<BvhNodeWide>& wide_out, std::vector<BvhTri>& tris_out, int* depth_out) {
+void build_bvh(const std::vector<BvhTri>& tris_in, std::vector<BvhNode>& nodes_out, std::vector<BvhNodeWide>& wide_out, std::vector<BvhTri>& tris_out, int* depth_out,
+               std::vector<BvhNode8>* nodes8_out) {
     nodes_out.clear(); wide_out.clear(); tris_out.clear();
     Builder b;
     b.refs.resize(tris_in.size());
@@ -221,6 +222,103 @@ void build_bvh(const std::vector<BvhTri>& tris_in, std::vector<BvhNode>& nodes_o
         }
     }
     if (depth_out) *depth_out = max_depth;
+    if (!nodes8_out) return;
+
+    // ---- the same binary tree collapsed EIGHT-wide (BVH8 experiment): a node adopts descendants, largest box first, until it
+    // has eight children; the children go into slots by octant (greedy assignment on the offset of the child's centre from the
+    // node's centre along the slot's diagonal, after Ylitie et al. 2017), so a traversal order follows from the ray's direction
+    // signs alone.
+    std::vector<BvhNode8>& out8 = *nodes8_out;
+    out8.clear();
+    auto empty8 = [&]() {
+        BvhNode8 n; std::memset(&n, 0, sizeof(n));
+        n.exps = 1u | 1u << 8 | 1u << 16;
+        for (int a = 0; a < 3; a++) { n.lo[a][0] = n.lo[a][1] = 0xffffffffu; n.hi[a][0] = n.hi[a][1] = 0u; }
+        for (int k = 0; k < 8; k++) n.child[k] = leaf_code(0, 1);
+        return n;
+    };
+    auto put_boxes8 = [&](BvhNode8& n, const Box* bx, const bool* used) {
+        n.exps = 0;
+        for (int a = 0; a < 3; a++) {
+            float lo = 3.0e38f, hi = -3.0e38f;
+            for (int k = 0; k < 8; k++) if (used[k]) { lo = std::min(lo, bx[k].lo[a] - pad); hi = std::max(hi, bx[k].hi[a] + pad); }
+            const double org = lo, ext = (double)hi - (double)lo;
+            int e = 1;
+            if (ext > 0.0) { int ex; std::frexp(ext / 255.0, &ex); e = std::min(std::max(ex + 127, 1), 254); }
+            while (e < 254 && org + 255.0 * std::ldexp(1.0, e - 127) < (double)hi) e++;
+            const double step = std::ldexp(1.0, e - 127);
+            n.origin[a] = lo;
+            n.exps |= (uint32_t)e << (8 * a);
+            for (int k = 0; k < 8; k++) {
+                int ql = 255, qh = 0;  // unused slot: inverted
+                if (used[k]) {
+                    const double cl = (double)(bx[k].lo[a] - pad), ch = (double)(bx[k].hi[a] + pad);
+                    ql = (int)std::floor((cl - org) / step); qh = (int)std::ceil((ch - org) / step);
+                    ql = std::min(std::max(ql, 0), 255); qh = std::min(std::max(qh, 0), 255);
+                    while (ql > 0 && org + ql * step > cl) ql--;
+                    while (qh < 255 && org + qh * step < ch) qh++;
+                }
+                uint32_t& wl = n.lo[a][k >> 2]; uint32_t& wh = n.hi[a][k >> 2];
+                const int sh = 8 * (k & 3);
+                wl = (wl & ~(0xffu << sh)) | (uint32_t)ql << sh;
+                wh = (wh & ~(0xffu << sh)) | (uint32_t)qh << sh;
+            }
+        }
+    };
+    out8.push_back(empty8());
+    if (b.nodes[0].left < 0) {
+        Box bx[8]; bool used[8] = {true, false, false, false, false, false, false, false};
+        bx[0] = b.nodes[0].b;
+        put_boxes8(out8[0], bx, used);
+        out8[0].child[0] = leaf_code(b.nodes[0].first, b.nodes[0].count);
+        return;
+    }
+    std::vector<std::pair<int, int>> work8;  // (binary node, output node)
+    work8.push_back({0, 0});
+    while (!work8.empty()) {
+        const std::pair<int, int> it = work8.back(); work8.pop_back();
+        int kids[8]; int nk = 0;
+        kids[nk++] = b.nodes[it.first].left; kids[nk++] = b.nodes[it.first].right;
+        while (nk < 8) {
+            int best = -1; float ba = -1.0f;
+            for (int k = 0; k < nk; k++)
+                if (b.nodes[kids[k]].left >= 0) { float a = b.nodes[kids[k]].b.half_area(); if (a > ba) { ba = a; best = k; } }
+            if (best < 0) break;
+            const int t = kids[best];
+            kids[best] = b.nodes[t].left; kids[nk++] = b.nodes[t].right;
+        }
+        // octant slots: repeatedly take the (child, free slot) pair with the largest projection of the child's offset on the slot's diagonal
+        const Box& nb = b.nodes[it.first].b;
+        float cx[3]; for (int a = 0; a < 3; a++) cx[a] = 0.5f * (nb.lo[a] + nb.hi[a]);
+        int slot_of[8]; bool taken[8] = {false, false, false, false, false, false, false, false}, placed[8] = {false, false, false, false, false, false, false, false};
+        for (int round = 0; round < nk; round++) {
+            int bk = -1, bs = -1; float bc = -3.0e38f;
+            for (int k = 0; k < nk; k++) {
+                if (placed[k]) continue;
+                const Box& cb = b.nodes[kids[k]].b;
+                for (int sidx = 0; sidx < 8; sidx++) {
+                    if (taken[sidx]) continue;
+                    float c = 0.0f;
+                    for (int a = 0; a < 3; a++) c += (0.5f * (cb.lo[a] + cb.hi[a]) - cx[a]) * (((sidx >> a) & 1) ? 1.0f : -1.0f);
+                    if (c > bc) { bc = c; bk = k; bs = sidx; }
+                }
+            }
+            slot_of[bk] = bs; placed[bk] = true; taken[bs] = true;
+        }
+        Box boxes[8]; bool used[8] = {false, false, false, false, false, false, false, false};
+        for (int k = 0; k < nk; k++) { boxes[slot_of[k]] = b.nodes[kids[k]].b; used[slot_of[k]] = true; }
+        put_boxes8(out8[it.second], boxes, used);
+        for (int k = 0; k < nk; k++) {
+            const TmpNode& c = b.nodes[kids[k]];
+            if (c.left < 0) out8[it.second].child[slot_of[k]] = leaf_code(c.first, c.count);
+            else {
+                const int idx = (int)out8.size();
+                out8.push_back(empty8());
+                out8[it.second].child[slot_of[k]] = idx;
+                work8.push_back({kids[k], idx});
+            }
+        }
+    }
 }
 
 }  // namespace vpt

@@ -7,5 +7,7 @@
 namespace vpt {
 // tris_in: world-space triangles in instance-major order (gid = index). Produces 128 B four-wide nodes
 // (root = node 0) and the triangles permuted into leaf order.
-void build_bvh(const std::vector<BvhTri>& tris_in, std::vector<BvhNode>& nodes_out, std::vector<BvhNodeWide>& wide_out, std::vector<BvhTri>& tris_out, int* depth_out);
+// nodes8_out (optional): the same binary tree collapsed eight-wide with octant-ordered slots, over the same tris_out.
+void build_bvh(const std::vector<BvhTri>& tris_in, std::vector<BvhNode>& nodes_out, std::vector<BvhNodeWide>& wide_out, std::vector<BvhTri>& tris_out, int* depth_out,
+               std::vector<BvhNode8>* nodes8_out = nullptr);
 }  // namespace vpt

@@ -27,6 +27,19 @@ struct BvhNode {
 };
 static_assert(sizeof(BvhNode) == 64, "node is 64 B");
 
+// Eight-wide variant of the quantised node (96 B, 6 x dwordx4) for the BVH8 experiment: same grid
+// quantisation, eight child boxes, children placed in slots by OCTANT — bit a of a slot index says on which side of the node's
+// centre the child lies along axis a — so that a ray can visit the hit children in the fixed order slot XOR (sign bits of its
+// direction) instead of sorting entry distances.  Unused slots hold the inverted box and a harmless leaf code.
+struct BvhNode8 {
+    float origin[3];
+    uint32_t exps;        // ex | ey << 8 | ez << 16
+    uint32_t lo[3][2];    // per axis: byte k of the 8 = lower plane of child k
+    uint32_t hi[3][2];
+    int32_t child[8];     // >= 0 inner node index; < 0 leaf, ~child = first << 3 | (count - 1)
+};
+static_assert(sizeof(BvhNode8) == 96, "BVH8 node is 96 B");
+
 // The same tree with fp32 child boxes in SoA form (128 B), used only when the whole BVH is staged into LDS
 // (scenes of a few dozen triangles): there the bytes are free and the plain slab test costs fewer VALU ops than
 // decoding the grid.  Unused slots hold an unreachable point box at 1e30.
@@ -103,6 +116,7 @@ struct DensityGrid {
 struct DeviceScene {
     const BvhNode* nodes;
     const BvhNodeWide* nodes_wide;  // non-null only for LDS-resident scenes
+    const BvhNode8* nodes8;         // eight-wide tree over the SAME leaf-ordered triangles (trace lab only; nullptr unless built)
     const BvhTri* tris;
     uint32_t node_count, tri_count;
     const vpt_vertex* vertices;

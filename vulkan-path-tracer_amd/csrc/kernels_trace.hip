@@ -83,7 +83,7 @@ __global__ __launch_bounds__(kTraverseBlock, 8) void k_trace_base(DeviceScene sc
 // Lane state: `cur` >= 0 inner node to visit; < 0 leaf code ~(first << 3 | count - 1) with `first` advancing as the
 // triangles are consumed; kLaneDone / kLaneIdle.  The wave owns a chunk [w_next, w_end) of the stream (one atomic per
 // chunk) and deals its entries to idle lanes in fetch steps.
-template <bool ANY, bool COUNT>
+template <bool ANY, bool COUNT, bool WIDE8>
 __global__ __launch_bounds__(kTraverseBlock, 8) void k_trace_vote(DeviceScene sc, TraceArgs a, Counters* ctr) {
     extern __shared__ __align__(16) unsigned char smem[];
     const LaneStack S = make_lane_stack(smem, sc.stack_overflow);
@@ -156,7 +156,8 @@ __global__ __launch_bounds__(kTraverseBlock, 8) void k_trace_vote(DeviceScene sc
         } else if (weighted ? nn > 2u * nl : nn >= nl) {
             if (at_node) {  // ---- inner-node step
                 if (COUNT) st_nodes++;
-                vote_node_step<ANY>(nodes, S, cur, sp, o, inv, a.tmin, best_t);
+                if (WIDE8) vote_node8_step(sc.nodes8, S, cur, sp, o, inv, a.tmin, best_t);
+                else vote_node_step<ANY>(nodes, S, cur, sp, o, inv, a.tmin, best_t);
             }
         } else {
             if (at_leaf) {  // ---- triangle step: ONE triangle of the lane's leaf
@@ -186,9 +187,12 @@ int trace_blocks_per_cu(uint32_t variant, bool any) {
     if (variant == VPT_TRACE_BASE) {
         if (any) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_base<true, false>, kTraverseBlock, lds);
         else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_base<false, false>, kTraverseBlock, lds);
+    } else if (variant == VPT_TRACE_VOTE8) {
+        if (any) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_vote<true, false, true>, kTraverseBlock, lds);
+        else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_vote<false, false, true>, kTraverseBlock, lds);
     } else {
-        if (any) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_vote<true, false>, kTraverseBlock, lds);
-        else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_vote<false, false>, kTraverseBlock, lds);
+        if (any) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_vote<true, false, false>, kTraverseBlock, lds);
+        else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_vote<false, false, false>, kTraverseBlock, lds);
     }
     return nb > 0 ? nb : 1;
 }
@@ -198,7 +202,10 @@ void launch_trace(hipStream_t s, uint32_t blocks, uint32_t variant, bool any, bo
     const dim3 g(blocks), b(kTraverseBlock);
 #define VPT_LT(K) do { if (any) { if (count) hipLaunchKernelGGL((K<true, true>), g, b, lds, s, sc, a, ctr); else hipLaunchKernelGGL((K<true, false>), g, b, lds, s, sc, a, ctr); } \
                        else { if (count) hipLaunchKernelGGL((K<false, true>), g, b, lds, s, sc, a, ctr); else hipLaunchKernelGGL((K<false, false>), g, b, lds, s, sc, a, ctr); } } while (0)
-    if (variant == VPT_TRACE_BASE) VPT_LT(k_trace_base); else VPT_LT(k_trace_vote);
+#define VPT_LV(W) do { if (any) { if (count) hipLaunchKernelGGL((k_trace_vote<true, true, W>), g, b, lds, s, sc, a, ctr); else hipLaunchKernelGGL((k_trace_vote<true, false, W>), g, b, lds, s, sc, a, ctr); } \
+                       else { if (count) hipLaunchKernelGGL((k_trace_vote<false, true, W>), g, b, lds, s, sc, a, ctr); else hipLaunchKernelGGL((k_trace_vote<false, false, W>), g, b, lds, s, sc, a, ctr); } } while (0)
+    if (variant == VPT_TRACE_BASE) VPT_LT(k_trace_base); else if (variant == VPT_TRACE_VOTE8) VPT_LV(true); else VPT_LV(false);
+#undef VPT_LV
 #undef VPT_LT
 }
 

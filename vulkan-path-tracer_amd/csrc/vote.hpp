@@ -65,6 +65,56 @@ __device__ __forceinline__ void vote_node_step(const BvhNode* nodes, const LaneS
         }
     }
 }
+// ---- BVH8 experiment: one visit of an eight-wide node (device_types.hpp BvhNode8).  Eight slab tests on the shared grid, then
+// the hit children in OCTANT order — slot XOR (sign bits of the ray direction), ascending — instead of a distance sort: the
+// children and the hit mask are permuted into that order with three conditional butterfly stages, the first hit child is
+// visited next, the others are pushed so that they pop in the same order.
+__device__ __forceinline__ void vote_node8_step(const BvhNode8* nodes, const LaneStack& S, int& cur, int& sp, V3 o, V3 inv, float tmin, float tlimit) {
+    const uint4* p = reinterpret_cast<const uint4*>(nodes + cur);
+    const uint4 w0 = p[0], w1 = p[1], w2 = p[2], w3 = p[3], w4 = p[4], w5 = p[5];
+    const bool negx = inv.x < 0.0f, negy = inv.y < 0.0f, negz = inv.z < 0.0f;
+    const float ax = __uint_as_float((w0.w & 0xffu) << 23) * inv.x;
+    const float ay = __uint_as_float(((w0.w >> 8) & 0xffu) << 23) * inv.y;
+    const float az = __uint_as_float(((w0.w >> 16) & 0xffu) << 23) * inv.z;
+    const float bx = (__uint_as_float(w0.x) - o.x) * inv.x, by = (__uint_as_float(w0.y) - o.y) * inv.y, bz = (__uint_as_float(w0.z) - o.z) * inv.z;
+    // lo: x = (w1.x, w1.y), y = (w1.z, w1.w), z = (w2.x, w2.y); hi: x = (w2.z, w2.w), y = (w3.x, w3.y), z = (w3.z, w3.w)
+    uint32_t hits = 0u;
+#define VPT_HALF(NX, FX, NY, FY, NZ, FZ, BASE)                                                                                        \
+    {                                                                                                                                 \
+        const uint32_t nx = negx ? FX : NX, fx = negx ? NX : FX, ny = negy ? FY : NY, fy = negy ? NY : FY, nz = negz ? FZ : NZ, fz = negz ? NZ : FZ; \
+        _Pragma("unroll") for (int k = 0; k < 4; k++) {                                                                               \
+            const float tn = fmax_(fmax_(__builtin_fmaf((float)((nx >> (8 * k)) & 0xffu), ax, bx), __builtin_fmaf((float)((ny >> (8 * k)) & 0xffu), ay, by)), \
+                                   fmax_(__builtin_fmaf((float)((nz >> (8 * k)) & 0xffu), az, bz), tmin));                             \
+            const float tf = fmin_(fmin_(__builtin_fmaf((float)((fx >> (8 * k)) & 0xffu), ax, bx), __builtin_fmaf((float)((fy >> (8 * k)) & 0xffu), ay, by)), \
+                                   fmin_(__builtin_fmaf((float)((fz >> (8 * k)) & 0xffu), az, bz), tlimit));                           \
+            hits |= (tn <= tf * 1.0000005f ? 1u : 0u) << (BASE + k);                                                                  \
+        }                                                                                                                             \
+    }
+    VPT_HALF(w1.x, w2.z, w1.z, w3.x, w2.x, w3.z, 0)
+    VPT_HALF(w1.y, w2.w, w1.w, w3.y, w2.y, w3.w, 4)
+#undef VPT_HALF
+    // children and hit bits into key order: key = slot ^ (negx | negy << 1 | negz << 2)
+    int c0 = (int)w4.x, c1 = (int)w4.y, c2 = (int)w4.z, c3 = (int)w4.w, c4 = (int)w5.x, c5 = (int)w5.y, c6 = (int)w5.z, c7 = (int)w5.w;
+#define VPT_SWAP(C, A, B) { const int t_ = (C) ? B : A; B = (C) ? A : B; A = t_; }
+    VPT_SWAP(negx, c0, c1) VPT_SWAP(negx, c2, c3) VPT_SWAP(negx, c4, c5) VPT_SWAP(negx, c6, c7)
+    VPT_SWAP(negy, c0, c2) VPT_SWAP(negy, c1, c3) VPT_SWAP(negy, c4, c6) VPT_SWAP(negy, c5, c7)
+    VPT_SWAP(negz, c0, c4) VPT_SWAP(negz, c1, c5) VPT_SWAP(negz, c2, c6) VPT_SWAP(negz, c3, c7)
+#undef VPT_SWAP
+    if (negx) hits = ((hits & 0x55u) << 1) | ((hits & 0xaau) >> 1);
+    if (negy) hits = ((hits & 0x33u) << 2) | ((hits & 0xccu) >> 2);
+    if (negz) hits = ((hits & 0x0fu) << 4) | ((hits & 0xf0u) >> 4);
+    if (hits == 0u) { S.pop_or_done(sp, cur); return; }
+    // every hit child except the first (lowest key) is pushed, highest key first
+    if ((hits & 0x80u) && (hits & 0x7fu)) S.push(sp, c7);
+    if ((hits & 0x40u) && (hits & 0x3fu)) S.push(sp, c6);
+    if ((hits & 0x20u) && (hits & 0x1fu)) S.push(sp, c5);
+    if ((hits & 0x10u) && (hits & 0x0fu)) S.push(sp, c4);
+    if ((hits & 0x08u) && (hits & 0x07u)) S.push(sp, c3);
+    if ((hits & 0x04u) && (hits & 0x03u)) S.push(sp, c2);
+    if ((hits & 0x02u) && (hits & 0x01u)) S.push(sp, c1);
+    cur = (hits & 1u) ? c0 : (hits & 2u) ? c1 : (hits & 4u) ? c2 : (hits & 8u) ? c3 : (hits & 16u) ? c4 : (hits & 32u) ? c5 : (hits & 64u) ? c6 : c7;
+}
+
 // One triangle of the lane's leaf, closest-hit search (ties in t -> smaller global id).
 __device__ __forceinline__ void vote_tri_step_closest(const BvhTri* tris, const LaneStack& S, int& cur, int& sp, V3 o, V3 d, float tmin, float tmax,
                                                       float& best_t, float& bu, float& bv, uint32_t& bslot, uint32_t& bgid) {

@@ -51,6 +51,7 @@ struct vpt_ctx {
     uint32_t* d_emissive_tri_offset = nullptr;
     float4* d_tri_ng = nullptr;
     unsigned char* d_inst_class = nullptr;   // shade class per instance (kernels_path.hip k_classify_instances)
+    std::vector<BvhTri> bvh_input;           // the triangles the BVH was built from (trace lab: the eight-wide tree is built from them on first use)
     bool lds_scene = false;
     int trav_blocks = 1024;
 
@@ -654,6 +655,7 @@ int vpt_set_scene(vpt_ctx* c, const vpt_scene_desc* sd) {
     }
     std::vector<BvhNode> nodes; std::vector<BvhNodeWide> wide; std::vector<BvhTri> leaf_tris; int depth = 0;
     build_bvh(tris, nodes, wide, leaf_tris, &depth);
+    c->bvh_input = tris; c->dsc.nodes8 = nullptr;
     c->bvh_depth = (uint32_t)depth;
     // ---- textures
     std::vector<TexDesc> tds; std::vector<uint8_t> texels;
@@ -1202,11 +1204,19 @@ int vpt_lab_set_rays(vpt_ctx* c, const vpt_ray* rays, uint32_t n) {
 }
 int vpt_lab_trace(vpt_ctx* c, uint32_t variant, uint32_t any_hit, const uint32_t* order, uint32_t param, uint32_t reps, vpt_hit* hits, float* best_ms,
                   uint64_t* visits) {
-    if (!c || variant > VPT_TRACE_VOTE || reps == 0) return VPT_ERR_INVALID_ARGUMENT;
+    if (!c || variant > VPT_TRACE_VOTE8 || reps == 0) return VPT_ERR_INVALID_ARGUMENT;
     if (!c->has_scene) return fail(c, VPT_ERR_NO_SCENE, "no scene");
     if (c->lds_scene) return fail(c, VPT_ERR_UNSUPPORTED, "the trace lab runs on scenes whose BVH lives in memory");
     if (c->lab_n == 0) return fail(c, VPT_ERR_INVALID_ARGUMENT, "vpt_lab_trace before vpt_lab_set_rays");
     HIPCHK(c, hipSetDevice(c->cfg.device));
+    if (variant == VPT_TRACE_VOTE8 && !c->dsc.nodes8) {   // BVH8 experiment: the same binary tree collapsed eight-wide, over the same leaf-ordered triangles
+        std::vector<BvhNode> n4; std::vector<BvhNodeWide> w4; std::vector<BvhTri> lt; std::vector<BvhNode8> n8; int d = 0;
+        build_bvh(c->bvh_input, n4, w4, lt, &d, &n8);
+        if (n8.empty()) return fail(c, VPT_ERR_UNSUPPORTED, "no eight-wide tree for an empty scene");
+        int rc8 = upload(c, n8, &c->dsc.nodes8);
+        if (rc8) return rc8;
+        c->stats.bvh8_nodes = (uint32_t)n8.size();
+    }
     const uint32_t n = c->lab_n;
     if (order) HIPCHK(c, hipMemcpy(c->lab_order, order, (size_t)n * 4, hipMemcpyHostToDevice));
     TraceArgs a{};
