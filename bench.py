@@ -233,12 +233,16 @@ def roofline_for(name, prof):
     traffic = pmc.get(dom, {}).get("hbm_bytes_per_launch")
     valu_busy = pmc.get(dom, {}).get("valu_busy")
     lds_scene = prof["bvh"]["node_bytes"] == 128
-    # the fused kernels of an LDS-resident scene are VALU-bound (profiles/*_pmc_sq.md); traversal of a memory-resident BVH is
-    # bounded by divergent VALU issue and dependent-fetch latency, shading by gathers: none of them is a streaming HBM kernel,
-    # so the HBM fraction below is what they leave of the memory roofline, not a claim that HBM is the limiter
-    bound = "valu" if lds_scene or dom in ("extend", "connect", "shadow", "shade") else "hbm"
+    # bound from the counters where profiles/traffic.json has them: whichever of VALU issue (rocprofv3 VALUBusy; a kernel that
+    # saturates issue reads 0.93-1.0, profiles/r02_valu_calibration.md) and HBM-side traffic / peak is higher.  None of the
+    # path kernels is a streaming HBM kernel, so "frac" below is what they leave of the memory roofline.
+    traffic_frac = traffic / (k["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS if traffic else None
+    if valu_busy is not None and traffic_frac is not None:
+        bound = "valu" if valu_busy >= traffic_frac else "hbm"
+    else:
+        bound = "valu" if lds_scene or dom in ("extend", "connect", "shadow", "shade") else "hbm"
     return {"bound": bound, "kernel": dom, "achieved": k["records_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(k["records_GBs"] / HBM_PEAK_GBS, 5),
-            "traffic": traffic, "valu_busy": valu_busy, "avg_launch_ms": k["avg_ms"],
+            "traffic": traffic, "traffic_frac_of_hbm_peak": round(traffic_frac, 4) if traffic_frac else None, "valu_busy": valu_busy, "avg_launch_ms": k["avg_ms"],
             "record_bytes_per_launch": round(k["record_bytes_per_unit"] * k["units_per_launch"], 0),
             "algorithmic_bytes_per_launch": round(k["algorithmic_bytes_per_unit"] * k["units_per_launch"], 0),
             "algorithmic_GBs": k["algorithmic_GBs"], "algorithmic_frac_of_hbm_peak": k["algorithmic_frac_of_hbm_peak"],

@@ -30,7 +30,7 @@ for f in glob.glob(os.path.join(G, "*", "**", "*counter_collection.csv"), recurs
             acc[s][r["Counter_Name"]] += float(r["Counter_Value"])
 rows = {}
 lines = ["# %s, pipeline %s — rocprofv3 summary (r02)" % (scene, pipe), "",
-         "`SCENE=%s PIPE=%s python tests/gpu_atrium_run.py` under profiles/collect_r02.sh: 1920x1080, 8 frames in flight, 2 measured batches (+1 warm-up, included in the sums)." % (scene, pipe), "",
+         "`SCENE=%s PIPE=%s python tests/gpu_atrium_run.py` under profiles/collect_r02.sh: 1920x1080, %s frames in flight, 2 measured batches (+1 warm-up, included in the sums)." % (scene, pipe, os.environ.get("FRAMES", "64")), "",
          "| stage | launches | total ms | wait | VALU busy | lane use | VALU wave-instr | L2 hit | fetched GB (2 x FETCH_SIZE) | written GB |", "|---|---|---|---|---|---|---|---|---|---|"]
 for s, (calls, tot) in sorted(dur.items(), key=lambda kv: -kv[1][1]):
     a = acc[s]

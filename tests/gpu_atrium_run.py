@@ -1,4 +1,4 @@
-"""Fixed workload for profiling (not a pytest): 1080p, depth 8 (atrium) / 32 (bust), 8 frames in flight, 1 warm-up batch + 2 measured.
+"""Fixed workload for profiling (not a pytest): 1080p, depth 8 (atrium) / 32 (bust), FRAMES (default 64, the library's default at 1080p) frames in flight, 1 warm-up batch + 2 measured.
     PIPE=2 (staged on streams, default) | 3 (round 1's stage kernels) | 1 (fused);  SCENE=atrium|bust"""
 import importlib, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -6,8 +6,9 @@ sys.path.insert(0, ROOT)
 vpt = importlib.import_module("vulkan-path-tracer_amd")
 pipe = int(os.environ.get("PIPE", "2"))
 which = os.environ.get("SCENE", "atrium")
+F = int(os.environ.get("FRAMES", "64"))
 sc = vpt.scenes.atrium() if which == "atrium" else vpt.scenes.glass_bust()
-g = vpt.PathTracer(1920, 1080, pipeline=pipe, frames_in_flight=8, profile=True); g.set_scene(sc)
+g = vpt.PathTracer(1920, 1080, pipeline=pipe, frames_in_flight=F, profile=True); g.set_scene(sc)
 g.set_params(vpt.default_params(max_depth=8 if which == "atrium" else 32, max_samples=1 << 30))
-g.render(8); g.reset_stats(); t = time.time(); g.render(16); dt = time.time() - t
+g.render(F); g.reset_stats(); t = time.time(); g.render(2 * F); dt = time.time() - t
 st = g.stats(); print("Msamples/s", round(st["samples"] / dt / 1e6, 1), {k: round(v, 2) for k, v in st["kernel_ms"].items() if v > 0})

@@ -1,4 +1,4 @@
-import importlib, sys, time, json
+import importlib, os, sys, time, json
 sys.path.insert(0,'.')
 vpt = importlib.import_module("vulkan-path-tracer_amd")
 import numpy as np
@@ -6,7 +6,7 @@ out = {}
 for name, sc, depth in (("atrium", vpt.scenes.atrium(), 8), ("bust", vpt.scenes.glass_bust(), 32)):
     imgs = {}
     for pipe in (3, 2, 4):
-        g = vpt.PathTracer(1920, 1080, pipeline=pipe, profile=True); g.set_scene(sc); g.set_params(vpt.default_params(max_depth=depth, max_samples=1<<30))
+        g = vpt.PathTracer(1920, 1080, pipeline=pipe, profile=True, frames_in_flight=int(os.environ.get("AB_FRAMES", "0"))); g.set_scene(sc); g.set_params(vpt.default_params(max_depth=depth, max_samples=1<<30))
         F = g.stats()["frames_in_flight"]
         g.render(F); g.reset_stats(); t=time.time(); g.render(F); g.render(F); dt=time.time()-t
         st = g.stats(); imgs[pipe] = g.radiance(); g.close()
