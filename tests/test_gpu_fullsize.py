@@ -6,16 +6,19 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def test_cornell_1080p_two_frames_exact(vpt, oracle, scenes):
+def test_cornell_1080p_eight_frames_exact(vpt, oracle, scenes):
+    """8 frames = 16.6 M paths in one batch: the bounce queues of the first bounces exceed 2^21 entries, so this is the test that
+    runs the long-queue code of the fused kernels (wave-private chunked appends, hit / miss regrouping through the LDS rings) as
+    well as the short-queue code of the late bounces."""
     sc = scenes("cornell_box")
     assert sc.default_size() == (1920, 1080)  # PathTracer.cpp:509-511
     p = vpt.default_params(max_depth=8)
-    o = oracle.Oracle(sc, 1920, 1080); o.set_params(p); o.render(2)
+    o = oracle.Oracle(sc, 1920, 1080); o.set_params(p); o.render(8)
     ref = o.radiance(); ctr = o.counters(); o.close()
-    g = vpt.PathTracer(1920, 1080); g.set_scene(sc); g.set_params(p); g.render(2)
+    g = vpt.PathTracer(1920, 1080, frames_in_flight=8); g.set_scene(sc); g.set_params(p); g.render(8)
     img = g.radiance(); st = g.stats(); g.close()
     assert np.array_equal(img, ref)
-    assert st["closest_rays"] == ctr["closest"] and st["samples"] == 2 * 1920 * 1080
+    assert st["closest_rays"] == ctr["closest"] and st["samples"] == 8 * 1920 * 1080
 
 
 def test_cornell_1080p_properties(vpt, scenes):

@@ -107,22 +107,72 @@ __global__ __launch_bounds__(256, 3) void k_shade_stream(DeviceScene sc, RenderP
     const uint32_t first_chunk = sctr->class_base[cls] / kAppendChunk + gw;   // this launch's static chunks follow the earlier launches'
     a_next.init(first_chunk, exact); a_pend.init(first_chunk, exact); a_sky.init(first_chunk, exact); a_light.init(first_chunk, exact);
     uint32_t w_paths = 0u, w_rays = 0u, w_pend = 0u, w_alive = 0u;  // wave totals (uniform)
-    uint32_t base = gw * 64u, span = 64u;          // the wave's static first 64 entries, then chunks through the cursor
+    // Regrouping (unsorted mode): the wave first looks at the hit records of its next 64 entries and parks their queue positions
+    // in two wave-private LDS rings, hits (with the hit record) and misses; the shaders then run on FULL chunks of 64 hits or 64
+    // misses, whichever ring has filled up, and the partial chunks are flushed when the input is exhausted.  Holes vanish on the
+    // way.  Nothing moves in memory and every path still gets exactly its own records, so the image cannot change; what changes is
+    // that misses and holes no longer idle through the closest-hit shader (glass bust: most paths leave the bust into the sky).
+    constexpr bool kRegroup = CLS == kShadeAny;
+    __shared__ uint32_t r_q[4][128], r_m[4][128];
+    __shared__ float4 r_h[4][128];
+    const uint32_t wave = threadIdx.x >> 6;
+    uint32_t hit_head = 0u, hit_count = 0u, miss_head = 0u, miss_count = 0u;   // wave-uniform
+    uint32_t pos = gw * 64u, end = pos + 64u;      // the wave's static first 64 entries, then chunks through the cursor
+    bool done = false;
     while (true) {
-        for (uint32_t k = 0u; k < span; k += 64u) {
-            const uint32_t i = base + k + lane_id();
-            if (base + k >= n) break;
-            // sorted mode: `order` holds positions in the ray queue (k_classify); unsorted: the queue is worked through in order
-            const uint32_t qi = i < n ? (order ? order[i] : i) : 0u;
-            const uint32_t slot = i < n ? queue[qi] : kHole;
-            const bool valid = slot != kHole;
+        {
+            uint32_t qi = 0u, slot = kHole;
+            bool valid = false;
+            float4 hrec = make_float4(-1.0f, 0.0f, 0.0f, 0.0f);
+            const bool pop_hits = kRegroup && (hit_count >= 64u || (done && hit_count > 0u));
+            const bool pop_miss = kRegroup && !pop_hits && (miss_count >= 64u || (done && miss_count > 0u));
+            if (pop_hits || pop_miss) {
+                const uint32_t cnt = pop_hits ? (hit_count < 64u ? hit_count : 64u) : (miss_count < 64u ? miss_count : 64u);
+                valid = lane_id() < cnt;
+                if (valid) {
+                    if (pop_hits) { const uint32_t q = (hit_head + lane_id()) & 127u; qi = r_q[wave][q]; hrec = r_h[wave][q]; }
+                    else qi = r_m[wave][(miss_head + lane_id()) & 127u];
+                    slot = queue[qi];
+                }
+                if (pop_hits) { hit_head += cnt; hit_count -= cnt; } else { miss_head += cnt; miss_count -= cnt; }
+            } else if (!done) {
+                if (pos >= end || pos >= n) {   // next chunk of the queue
+                    if (active * 64u >= n) { done = true; continue; }
+                    uint32_t nb = 0u;
+                    if (lane_id() == 0u) nb = atomicAdd(&sctr->class_head[cls].v, chunk);
+                    pos = active * 64u + __builtin_amdgcn_readfirstlane(nb);
+                    end = pos + chunk;
+                    if (pos >= n) done = true;
+                    continue;
+                }
+                const uint32_t i = pos + lane_id();
+                pos += 64u;
+                // sorted mode: `order` holds positions in the ray queue (k_classify); unsorted: the queue is worked through in order
+                qi = i < n ? (order ? order[i] : i) : 0u;
+                slot = i < n ? queue[qi] : kHole;
+                valid = slot != kHole;
+                if (valid) hrec = ss.SH[qi];
+                if (kRegroup) {   // each ring holds < 64 entries here, so 128 slots are enough
+                    const bool is_hit = valid && !(hrec.x < 0.0f);
+                    const unsigned long long mh = __ballot(is_hit), mm = __ballot(valid && !is_hit);
+                    if (is_hit) { const uint32_t q = (hit_head + hit_count + lanes_below(mh)) & 127u; r_q[wave][q] = qi; r_h[wave][q] = hrec; }
+                    if (valid && !is_hit) r_m[wave][(miss_head + miss_count + lanes_below(mm)) & 127u] = qi;
+                    hit_count += (uint32_t)__popcll(mh); miss_count += (uint32_t)__popcll(mm);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    continue;
+                }
+            } else {
+                break;
+            }
             bool alive = false, pending = false, want_sky = false, want_light = false;
             ShadeOut o;
             V3 thr_prev = v3s(0.0f);
             if (valid) {
                 const float4 a = ss.RA[parity][qi], b = ss.RB[parity][qi], t = ss.RT[parity][qi];
                 ShadeIn in_;
-                in_.h = ss.SH[qi];
+                in_.h = hrec;
                 in_.inst = in_.h.x < 0.0f ? 0u : ss.SHI[qi];
                 in_.rng = __float_as_uint(a.w);
                 in_.porg = xyz(a); in_.pdir = xyz(b);
@@ -166,12 +216,6 @@ __global__ __launch_bounds__(256, 3) void k_shade_stream(DeviceScene sc, RenderP
             w_rays += (uint32_t)__popcll(__ballot(want_sky)) + (uint32_t)__popcll(__ballot(want_light));
             w_pend += (uint32_t)__popcll(__ballot(pending));
         }
-        if (active * 64u >= n) break;
-        uint32_t nb = 0u;
-        if (lane_id() == 0u) nb = atomicAdd(&sctr->class_head[cls].v, chunk);
-        base = active * 64u + __builtin_amdgcn_readfirstlane(nb);
-        span = chunk;
-        if (base >= n) break;
     }
     // the unwritten tails of this wave's last chunks become holes
     for (uint32_t j = lane_id(); j < a_next.tail_count(); j += 64u) queue_next[a_next.tail_first() + j] = kHole;
