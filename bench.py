@@ -5,7 +5,7 @@ Headline workload (config.workload = "cornell_1080p_d8"): BASELINE.json configs[
 (diffuse walls + emissive quad, strength 50), black environment, 1920x1080, max depth 8, 1 sample per pixel per
 frame, base seed 1.  A *step* is one wavefront batch of the hot path: every rank renders
 `frames_per_step` consecutive frames of its own rows (all bounces until the ray queue is empty, then resolve).
-Rows are dealt round-robin over ranks, each rank keeps up to ~128M paths resident (64 frames of a whole 1080p image, 512 frames of a 1/8 shard), so per-GPU work per step is fixed
+Rows are dealt round-robin over ranks, each rank keeps up to ~256M paths resident (129 frames of a whole 1080p image, 1024 frames of a 1/8 shard), so per-GPU work per step is fixed
 (weak scaling) and
 
     value = (samples all ranks traced in the K timed steps) / (max over ranks of the wall time)
@@ -70,12 +70,12 @@ PRIMARY_ALIVE = 16 * 4 + 4          # a survivor writes records A, B, T, L and i
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=24)
-    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=8)   # 8 batches of 129 frames = 1032 samples per pixel: config 2's 1024-spp job
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="cornell_1080p_d8", choices=sorted(WORKLOADS), help="headline workload (the default is BASELINE's metric config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-workloads", action="store_true", help="skip the atrium / glass-bust blocks")
-    ap.add_argument("--frames-in-flight", type=int, default=0, help="frames per step per GPU (0 = backend default, ~128M resident paths)")
+    ap.add_argument("--frames-in-flight", type=int, default=0, help="frames per step per GPU (0 = backend default, ~256M resident paths)")
     ap.add_argument("--pipeline", type=int, default=0, help="vpt_config.pipeline (0 AUTO)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the oracle sample")
     return ap.parse_args()
@@ -325,7 +325,7 @@ def main():
                        "width": WIDTH, "height": HEIGHT, "max_depth": depth, "samples_per_frame": 1,
                        "frames_per_step_per_gpu": F, "paths_in_flight_per_gpu": shard_pixels * F,
                        "timed_samples_per_pixel": round(samples / (WIDTH * HEIGHT), 1),
-                       "note": "a rate metric: the timed region is steps x frames_per_step frames of the 1024-spp job, not all 1024 (full run: profiles/*_config2_full_parity.json)",
+                       "note": "a rate metric: the timed region renders steps x frames_per_step frames (timed_samples_per_pixel; config 2 asks for 1024 spp, which the default 8 steps cover); bit-exact full-size run: profiles/*_config2_full_parity.json",
                        "partition": "rows y % N == rank, one ncclGather at the end", "base_seed": BASE_SEED, "pipeline": prof["pipeline"]},
             "mrays_per_s": round((closest + shadow) / dt / 1e6, 2),
             "roofline": roofline_for(name, prof),

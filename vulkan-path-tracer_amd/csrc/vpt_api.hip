@@ -17,7 +17,8 @@
 
 using namespace vpt;
 
-constexpr uint32_t kMaxFramesInFlight = 1024;   // frames of one batch (a 1/8 shard of 1080p holds ~128M paths at 512 frames)
+constexpr uint64_t kBytesPerPath = 380;          // core slot records 68 + stream records ~290 (slack included) + queues 8 + image share
+constexpr uint32_t kMaxFramesInFlight = 1024;   // frames of one batch (a 1/8 shard of 1080p holds ~256M paths at 1024 frames)
 
 struct vpt_ctx {
     vpt_config cfg{};
@@ -61,7 +62,8 @@ struct vpt_ctx {
     RenderParams P{};
     uint32_t frames_in_flight = 1;
 
-    void* ps_block = nullptr;
+    void* ps_block = nullptr;    // slot-addressed records every pipeline uses (L, ACC, M + the dword arrays)
+    void* ps_legacy = nullptr;   // round 1's stage kernels only (A, B, T, H, C*, hinst): allocated on their first use
     PathState ps{};
     uint32_t* queue[2] = {nullptr, nullptr};
     uint32_t* cqueue = nullptr;  // connect queue (two-ended)
@@ -150,6 +152,8 @@ void free_lab(vpt_ctx* c) {
 void free_render_buffers(vpt_ctx* c) {
     if (c->ps_block) (void)hipFree(c->ps_block);
     c->ps_block = nullptr;
+    if (c->ps_legacy) (void)hipFree(c->ps_legacy);
+    c->ps_legacy = nullptr;
     for (int i = 0; i < 2; i++) { if (c->queue[i]) (void)hipFree(c->queue[i]); c->queue[i] = nullptr; }
     if (c->cqueue) (void)hipFree(c->cqueue);
     c->cqueue = nullptr;
@@ -179,10 +183,16 @@ int check_render_size(vpt_ctx* c, uint32_t width, uint32_t height, uint32_t* fra
     if (px == 0) return fail(c, VPT_ERR_INVALID_ARGUMENT, "empty shard");
     if (px >= (1ull << 31) || (uint64_t)width * height >= (1ull << 31)) return fail(c, VPT_ERR_INVALID_ARGUMENT, "image too large");
     uint64_t F = c->cfg.frames_in_flight;
-    // ~128M resident paths whatever the shard size (64 frames at 1080p; ~76 GB of records, queues and streams of the 288 GB):
-    // the last bounces of a batch are short launches that cannot fill 256 CUs, and a batch four times larger makes them four
-    // times longer for the same fixed cost — Cornell +8 %, atrium +16 %, glass bust (depth 32) +78 % over 32M paths
-    if (F == 0) F = (128ull << 20) / px;
+    // ~256M resident paths whatever the shard size (128 frames at 1080p; kBytesPerPath x 256M = ~95 GB of the 288 GB): the last
+    // bounces of a batch are short launches that cannot fill 256 CUs, and a larger batch makes them longer for the same fixed
+    // cost — from 32M to 128M paths: Cornell +8 %, atrium +16 %, glass bust (depth 32) +78 %; from 128M to 256M: +0 / +2 / +18 %.
+    // Never more than 60 % of the memory that is free right now.
+    if (F == 0) {
+        uint64_t paths = 256ull << 20;
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) paths = std::min<uint64_t>(paths, (uint64_t)(free_b * 0.6) / kBytesPerPath);
+        F = paths / px;
+    }
     F = std::max<uint64_t>(1, std::min<uint64_t>(F, kMaxFramesInFlight));
     if (px * F >= (1ull << 31)) return fail(c, VPT_ERR_INVALID_ARGUMENT, "too many paths in flight");
     *frames_out = (uint32_t)F;
@@ -212,27 +222,23 @@ int alloc_render_buffers_impl(vpt_ctx* c) {
     P.shard_pixels = P.shard_rows * P.width;
     c->frames_in_flight = F;
     uint32_t cap = P.shard_pixels * F;
-    // 15 float4 records + 4 dword arrays per slot (device_types.hpp PathState)
-    const size_t kRecords = 15, kWords = 5;
+    // slot-addressed records every pipeline uses: 3 float4 records + 4 dword arrays per slot (device_types.hpp PathState); the
+    // records of round 1's stage kernels come with ensure_legacy_buffers()
+    const size_t kRecords = 3, kWords = 4;
     size_t stride = ((size_t)cap + 63) & ~(size_t)63;
     HIPCHK(c, hipMalloc(&c->ps_block, stride * (16 * kRecords + 4 * kWords)));
     float4* rb = (float4*)c->ps_block;
-    size_t k = 0;
-    auto next4 = [&]() { return rb + stride * (k++); };
     PathState& s = c->ps;
+    s = PathState{};
     s.capacity = cap;
-    s.A = next4(); s.B = next4(); s.T[0] = next4(); s.T[1] = next4(); s.H = next4();
-    s.CE = next4(); s.CS = next4(); s.CSO = next4(); s.CSD = next4(); s.CL = next4(); s.CLO = next4(); s.CLD = next4();
-    s.L = next4(); s.ACC = next4(); s.M = next4();
-    if (k != kRecords) return fail(c, VPT_ERR_DEVICE, "internal: path state carve mismatch");
+    s.L = rb; s.ACC = rb + stride; s.M = rb + stride * 2;
     uint32_t* wb = (uint32_t*)(rb + stride * kRecords);
-    s.hinst = wb; s.maniso = (float*)(wb + stride); s.sidx = wb + stride * 2; s.vdepth = wb + stride * 3; s.cchan = (int32_t*)(wb + stride * 4);
+    s.maniso = (float*)wb; s.sidx = wb + stride; s.vdepth = wb + stride * 2; s.cchan = (int32_t*)(wb + stride * 3);
     // streams written by chunked appends hold up to one unwritten chunk tail per wave that appended to them: at most
     // 256 entries per 64 items processed, and never more than one per resident wave of the largest persistent grid
     c->stream_slack = (uint32_t)std::min<uint64_t>((uint64_t)cap * 4 + 256, (uint64_t)8192 * 4 * 256);
     const size_t scap = (size_t)cap + c->stream_slack;
     for (int i = 0; i < 2; i++) HIPCHK(c, hipMalloc((void**)&c->queue[i], scap * 4));
-    HIPCHK(c, hipMalloc((void**)&c->cqueue, (size_t)cap * 4));
     {
         const size_t sst = (scap + 63) & ~(size_t)63;
         HIPCHK(c, hipMalloc(&c->ss_block, sst * (16 * 17 + 4 + 2)));
@@ -244,8 +250,6 @@ int alloc_render_buffers_impl(vpt_ctx* c) {
         t.SH = q + 16 * sst; t.SHI = (uint32_t*)(q + 17 * sst);
         t.vis_sky = (unsigned char*)(t.SHI + sst); t.vis_light = t.vis_sky + sst;
         t.cap = (uint32_t)scap;
-        for (uint32_t k = 0; k < kShadeClasses; k++) HIPCHK(c, hipMalloc((void**)&c->class_queue[k], scap * 4));
-        HIPCHK(c, hipMalloc((void**)&c->cls_q, scap));
     }
     // padded to the largest shard's row count (vpt_shard_floats): the buffer is handed to ncclGather as it is
     const size_t image_bytes = (size_t)shard_rows_of(P.height, 0, P.shard_count) * P.width * 16;
@@ -256,6 +260,31 @@ int alloc_render_buffers_impl(vpt_ctx* c) {
         HIPCHK(c, hipMemset(c->full_image, 0, (size_t)P.width * P.height * 16));
     }
     c->full_valid = false;
+    return VPT_OK;
+}
+
+// Round 1's stage kernels (VPT_PIPELINE_STAGED_R1, VPT_FLAG_LOCAL_HITS, an LDS-sized scene forced into the staged pipeline)
+// keep a path's records by slot: 12 more float4 records, the hit instance and the two-ended connect queue, 200 bytes per path,
+// allocated when such a batch is first rendered and kept until the next resize.
+// The class queues of VPT_PIPELINE_STAGED_SORTED (21 bytes per path), likewise on first use.
+int ensure_sorted_buffers(vpt_ctx* c) {
+    if (c->cls_q) return VPT_OK;
+    const size_t scap = c->ss.cap;
+    for (uint32_t k = 0; k < kShadeClasses; k++) if (!c->class_queue[k]) HIPCHK(c, hipMalloc((void**)&c->class_queue[k], scap * 4));
+    HIPCHK(c, hipMalloc((void**)&c->cls_q, scap));
+    return VPT_OK;
+}
+
+int ensure_legacy_buffers(vpt_ctx* c) {
+    if (c->ps_legacy) return VPT_OK;
+    const size_t cap = c->ps.capacity, stride = (cap + 63) & ~(size_t)63;
+    HIPCHK(c, hipMalloc(&c->ps_legacy, stride * (16 * 12 + 4)));
+    float4* q = (float4*)c->ps_legacy;
+    PathState& s = c->ps;
+    s.A = q; s.B = q + stride; s.T[0] = q + stride * 2; s.T[1] = q + stride * 3; s.H = q + stride * 4;
+    s.CE = q + stride * 5; s.CS = q + stride * 6; s.CSO = q + stride * 7; s.CSD = q + stride * 8; s.CL = q + stride * 9; s.CLO = q + stride * 10; s.CLD = q + stride * 11;
+    s.hinst = (uint32_t*)(q + stride * 12);
+    if (!c->cqueue) HIPCHK(c, hipMalloc((void**)&c->cqueue, cap * 4));
     return VPT_OK;
 }
 
@@ -399,6 +428,8 @@ int render_batch(vpt_ctx* c, uint32_t frames, uint32_t dispatch_base) {
     const bool vol = !c->volumes.empty() || c->dsc.atm_on;
     const bool fused = vol || c->cfg.pipeline == VPT_PIPELINE_FUSED || (c->cfg.pipeline == VPT_PIPELINE_AUTO && (c->lds_scene || c->auto_fused));
     const bool stream = !fused && !c->lds_scene && !c->dsc.strict_hits && c->cfg.pipeline != VPT_PIPELINE_STAGED_R1;
+    if (!fused && !stream) { int rl = ensure_legacy_buffers(c); if (rl != VPT_OK) return rl; }
+    if (stream && c->cfg.pipeline == VPT_PIPELINE_STAGED_SORTED) { int rl = ensure_sorted_buffers(c); if (rl != VPT_OK) return rl; }
     HIPCHK(c, hipMemsetAsync(c->ctr, 0, offsetof(Counters, stat_closest), s));  // queue words only, stat_* keep running
     uint32_t parity;
     uint32_t k3 = 0;  // fused: bounce index % 3 (Counters::rc3)
