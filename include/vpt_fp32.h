@@ -315,8 +315,12 @@ VPT_HD void texel_coords(float u, int size, bool repeat, int* i0, int* i1, float
     int a = (int)fl;
     int b = a + 1;
     if (repeat) {
-        a %= size; if (a < 0) a += size;
-        b %= size; if (b < 0) b += size;
+        if ((size & (size - 1)) == 0) {  // power of two: the two's-complement mask IS the non-negative remainder (no integer division)
+            a &= size - 1; b &= size - 1;
+        } else {
+            a %= size; if (a < 0) a += size;
+            b %= size; if (b < 0) b += size;
+        }
     } else {
         a = a < 0 ? 0 : (a > size - 1 ? size - 1 : a);
         b = b < 0 ? 0 : (b > size - 1 ? size - 1 : b);
@@ -329,6 +333,14 @@ VPT_HD int lut_layer(float layer, int layers) {
     float l = rint_(clamp_(layer, 0.0f, (float)(layers - 1)));
     if (!(l >= 0.0f)) l = 0.0f;
     return (int)l;
+}
+// UNORM8 texel -> float: b / 255, correctly rounded, without a division sequence (16 of them per bilinear RGBA tap):
+// q = b * RN(1/255) is within an ulp, and one residual step q + (b - 255 q) * RN(1/255) lands on RN(b / 255) for every
+// b in 0..255 (checked exhaustively against the division, tests/test_fp32_contract.py).
+VPT_HD float unorm8_to_float(uint32_t b) {
+    const float x = (float)b, r = 0.0039215688593685627f;
+    const float q = x * r;
+    return fma(fma(-255.0f, q, x), r, q);
 }
 // float -> UNORM8 store: RNE(saturate(c)*255); NaN -> 0.
 VPT_HD uint8_t unorm8(float c) {

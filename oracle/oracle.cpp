@@ -1698,7 +1698,8 @@ void orc_fp32_eval(int fn, const float* x, const float* y, float* out, uint32_t 
 // cannot see a bug in code both sides compile.  fn: 0 ray_triangle (in: o3 d3 v0 3 e1 3 e2 3 tmin tmax; out: hit t u v),
 // 1 texel_coords (in: u size repeat; out: i0 i1 w), 2 lut_layer (in: layer layers; out: index), 3 refract (in: i3 n3 eta;
 // out: 3), 4 smoothstep (in: e0 e1 x), 5 reflect (in: i3 n3; out: 3), 6 normalize (in: 3; out: 3), 7 unorm8 (in: c),
-// 8 hit_is_local (in: o3 d3 v0 3 e1 3 e2 3 t; out: 0/1), 9 triangle_degenerate (in: e1 3 e2 3; out: 0/1).
+// 8 hit_is_local (in: o3 d3 v0 3 e1 3 e2 3 t; out: 0/1), 9 triangle_degenerate (in: e1 3 e2 3; out: 0/1),
+// 10 unorm8_to_float (in: byte as float; the HIP texel fetch uses it, this oracle divides by 255).
 void orc_leaf_eval(int fn, const float* in, float* out, uint32_t n) {
     for (uint32_t i = 0; i < n; i++) {
         switch (fn) {
@@ -1715,6 +1716,7 @@ void orc_leaf_eval(int fn, const float* in, float* out, uint32_t n) {
             case 6: { const float* a = in + (size_t)i * 3; V3 r = normalize(v3(a[0], a[1], a[2])); out[i * 3] = r.x; out[i * 3 + 1] = r.y; out[i * 3 + 2] = r.z; break; }
             case 7: out[i] = (float)unorm8(in[i]); break;
             case 8: { const float* a = in + (size_t)i * 16; out[i] = hit_is_local(v3(a[0], a[1], a[2]), v3(a[3], a[4], a[5]), v3(a[6], a[7], a[8]), v3(a[9], a[10], a[11]), v3(a[12], a[13], a[14]), a[15]) ? 1.0f : 0.0f; break; }
+            case 10: out[i] = unorm8_to_float((uint32_t)in[i]); break;
             default: { const float* a = in + (size_t)i * 6; out[i] = triangle_degenerate(v3(a[0], a[1], a[2]), v3(a[3], a[4], a[5])) ? 1.0f : 0.0f; break; }
         }
     }

@@ -231,7 +231,8 @@ def postprocess(img, post_params, flags=None):
 
 
 _LEAF = {"ray_triangle": (0, 17, 4), "texel_coords": (1, 3, 3), "lut_layer": (2, 2, 1), "refract": (3, 7, 3), "smoothstep": (4, 3, 1),
-         "reflect": (5, 6, 3), "normalize": (6, 3, 3), "unorm8": (7, 1, 1), "hit_is_local": (8, 16, 1), "triangle_degenerate": (9, 6, 1)}
+         "reflect": (5, 6, 3), "normalize": (6, 3, 3), "unorm8": (7, 1, 1), "hit_is_local": (8, 16, 1), "triangle_degenerate": (9, 6, 1),
+         "unorm8_to_float": (10, 1, 1)}
 
 
 def leaf_eval(fn, x):

@@ -154,6 +154,15 @@ def test_texel_coords_against_numpy(oracle):
             assert np.abs(got[:, 2] - w).max() < 1e-6 and (got[:, 2] >= 0).all() and (got[:, 2] < 1.0 + 1e-7).all()
 
 
+def test_unorm8_texel_decode_equals_the_division_for_every_byte(oracle):
+    """The HIP texel fetch decodes a byte as b * r + residual step instead of b / 255.0f (shading.hpp tex_fetch); the oracle divides.
+    All 256 inputs, against numpy's correctly rounded float32 division and against the float64 quotient rounded once."""
+    b = np.arange(256, dtype=np.float32)
+    got = oracle.leaf_eval("unorm8_to_float", b)[:, 0]
+    assert np.array_equal(got, b / np.float32(255.0))
+    assert np.array_equal(got, (b.astype(np.float64) / 255.0).astype(np.float32))
+
+
 def test_lut_layer_rounds_to_nearest_even(oracle):
     layers = 32
     x = np.concatenate([np.arange(-2, 34, 0.25), np.array([0.5, 1.5, 2.5, 30.5, 31.5, np.nan, 1e9, -1e9])]).astype(np.float32)

@@ -27,9 +27,9 @@ __device__ inline V4 lerp4(V4 a, V4 b, float t) { return v4(lerp(a.x, b.x, t), l
 __device__ inline V4 tex_fetch(const uint8_t* texels, const TexDesc& t, int x, int y) {
     if (t.c == 4) {
         uchar4 p = *reinterpret_cast<const uchar4*>(texels + t.offset + ((size_t)y * t.w + x) * 4);
-        return v4((float)p.x / 255.0f, (float)p.y / 255.0f, (float)p.z / 255.0f, (float)p.w / 255.0f);
+        return v4(unorm8_to_float(p.x), unorm8_to_float(p.y), unorm8_to_float(p.z), unorm8_to_float(p.w));   // == p / 255.0f, bit for bit
     }
-    float v = (float)texels[t.offset + (size_t)y * t.w + x] / 255.0f;
+    float v = unorm8_to_float(texels[t.offset + (size_t)y * t.w + x]);
     return v4(v, 0.0f, 0.0f, 1.0f);
 }
 // uTextureSampler: LINEAR / REPEAT (PathTracer.cpp:84-91)
@@ -362,7 +362,9 @@ __device__ inline void sample_env(const DeviceScene& sc, const RenderParams& P, 
     uint32_t ei;
     if (x1 < e.importance) { ei = idx; x1 /= e.importance; }
     else { ei = e.alias; x1 = (x1 - e.importance) / (1.0f - e.importance); }
-    uint32_t px = ei % w, py = ei / w;
+    uint32_t px, py;
+    if ((w & (w - 1u)) == 0u) { px = ei & (w - 1u); py = ei >> (31u - (uint32_t)__builtin_clz(w)); }   // power-of-two width: no integer division
+    else { px = ei % w; py = ei / w; }
     float u = ((float)px + x1) / (float)w;
     float sp, cp; sincos_(u * (2.0f * VPT_PI) - VPT_PI, &sp, &cp);
     float step = VPT_PI / (float)h;
