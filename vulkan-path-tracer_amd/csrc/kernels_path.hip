@@ -283,15 +283,18 @@ __global__ __launch_bounds__(kTraverseBlock, 3) void k_bounce(DeviceScene sc, Re
     a_next.init(gw, false, active * kAppendChunk);   // chunked mode: the counter rc3[kn] counts what is reserved beyond the static chunks
     TravStats st, sst; st.nodes = 0; st.tris = 0; sst.nodes = 0; sst.tris = 0;
     uint32_t w_paths = 0u, w_alive = 0u, w_rays = 0u, w_hits = 0u;  // wave totals (uniform)
-    // Regrouping (long queues of the plain later bounces): a wave does not shade the 64 paths it has just traced — hits and misses
-    // go into two wave-private rings in LDS, and the rest of the bounce runs on FULL chunks of 64 hits (closest-hit shader, shadow
-    // queries) or 64 misses (miss shader), whichever ring has filled up; the partial chunks are flushed at the end.  Queue holes
-    // vanish on the way.  Without it a wave drags its misses and holes through the whole closest-hit shader as idle lanes
-    // (Cornell bounces: 41 of 64 lanes active).  Results cannot change: every path still gets exactly its own records and hit.
+    // Regrouping (long queues of the plain later bounces): a wave does not run the closest-hit shader on the 64 paths it has just
+    // traced.  Its misses are finished at once (the miss shader is short), its hits are parked — hit record, ray and throughput
+    // records — in a wave-private ring in LDS, and the closest-hit shader and the shadow queries run on FULL chunks of 64 hits
+    // whenever the ring has that many (the partial last chunk is flushed at the end).  Queue holes vanish on the way.  Without it
+    // a wave drags its misses and holes through the whole closest-hit shader as idle lanes (Cornell bounces: 41 of 64 lanes
+    // active, 49 with it).  Every record is still read once, as a coalesced stream, except pathLight, which a parked hit fetches
+    // when its chunk runs.  Results cannot change: every path gets exactly its own records and hit.
     const bool regroup = !FIRST && !VOL && !exact;   // (bounce 0: its camera rays are coherent; regrouping them measured 12 % slower)
-    __shared__ uint32_t r_idx[kTraverseBlock / 64u][128], r_prim[kTraverseBlock / 64u][128], r_inst[kTraverseBlock / 64u][128], r_miss[kTraverseBlock / 64u][128];
+    __shared__ uint32_t r_idx[kTraverseBlock / 64u][128], r_prim[kTraverseBlock / 64u][128], r_inst[kTraverseBlock / 64u][128];
     __shared__ float r_t[kTraverseBlock / 64u][128], r_u[kTraverseBlock / 64u][128], r_v[kTraverseBlock / 64u][128];
-    uint32_t hit_head = 0u, hit_count = 0u, miss_head = 0u, miss_count = 0u;   // wave-uniform
+    __shared__ float4 r_ra[kTraverseBlock / 64u][128], r_rb[kTraverseBlock / 64u][128], r_rt[kTraverseBlock / 64u][128];
+    uint32_t hit_head = 0u, hit_count = 0u;   // wave-uniform
     uint32_t tile = blockIdx.x;
     for (;;) {
         {
@@ -305,39 +308,34 @@ __global__ __launch_bounds__(kTraverseBlock, 3) void k_bounce(DeviceScene sc, Re
             V3 light_prev = v3s(0.0f);
             bool aborted = false;
             const bool pop_hits = regroup && (hit_count >= 64u || (tiles_done && hit_count > 0u));
-            const bool pop_miss = regroup && !pop_hits && (miss_count >= 64u || (tiles_done && miss_count > 0u));
-            if (pop_hits || pop_miss) {   // a chunk of traced paths of ONE kind: fetch the records of each lane's path
-                const uint32_t cnt = pop_hits ? (hit_count < 64u ? hit_count : 64u) : (miss_count < 64u ? miss_count : 64u);
+            if (pop_hits) {   // a chunk of parked hits
+                const uint32_t cnt = hit_count < 64u ? hit_count : 64u;
                 valid = lane_id() < cnt;
-                HitRec hr; hr.t = -1.0f; hr.u = 0.0f; hr.v = 0.0f; hr.prim = 0u; hr.inst = 0u;
                 if (valid) {
-                    if (pop_hits) {
-                        const uint32_t q = (hit_head + lane_id()) & 127u;
-                        idx = r_idx[wave][q]; hr.t = r_t[wave][q]; hr.u = r_u[wave][q]; hr.v = r_v[wave][q]; hr.prim = r_prim[wave][q]; hr.inst = r_inst[wave][q];
-                    } else {
-                        idx = r_miss[wave][(miss_head + lane_id()) & 127u];
-                    }
+                    const uint32_t q = (hit_head + lane_id()) & 127u;
+                    idx = r_idx[wave][q];
+                    const float4 a = r_ra[wave][q], b = r_rb[wave][q], t = r_rt[wave][q];
                     slot = queue[idx];
-                    float4 a = ss.RA[parity][idx], b = ss.RB[parity][idx], t = ss.RT[parity][idx];
                     in_.rng = __float_as_uint(a.w);
                     in_.porg = xyz(a); in_.pdir = xyz(b);
-                    uint32_t dw = __float_as_uint(b.w);
+                    const uint32_t dw = __float_as_uint(b.w);
                     in_.depth = dw & 0x7fffffffu; in_.in_medium = (dw >> 31) != 0u;
                     in_.thr_prev = xyz(t); in_.prev_pdf = t.w;
                     light_prev = xyz(ss.RL[parity][idx]);
                     in_.vdepth = 0u; in_.cchan = -1;
                     in_.vol_index = -1; in_.vol_t = 0.0f; in_.atm_comp = -1;
-                    hit = pop_hits;
-                    in_.h = make_float4(hr.t, hr.u, hr.v, __uint_as_float(hr.prim));
-                    in_.inst = hr.inst;
+                    hit = true;
+                    in_.h = make_float4(r_t[wave][q], r_u[wave][q], r_v[wave][q], __uint_as_float(r_prim[wave][q]));
+                    in_.inst = r_inst[wave][q];
                 }
-                if (pop_hits) { hit_head += cnt; hit_count -= cnt; } else { miss_head += cnt; miss_count -= cnt; }
+                hit_head += cnt; hit_count -= cnt;
             } else if (!tiles_done) {
                 idx = tile * kTraverseBlock + threadIdx.x;
                 tile += gridDim.x;
                 slot = FIRST ? idx : (idx < n ? queue[idx] : kHole);
                 valid = idx < n && slot != kHole;
                 HitRec hr;
+                float4 rec_a = make_float4(0.0f, 0.0f, 0.0f, 0.0f), rec_b = rec_a, rec_t = rec_a;
                 if (valid) {
                     if (FIRST) {
                         uint32_t x, y, f;
@@ -349,18 +347,16 @@ __global__ __launch_bounds__(kTraverseBlock, 3) void k_bounce(DeviceScene sc, Re
                         in_.vdepth = 0u; in_.cchan = -1;
                         if (P.samples_per_frame > 1) ps.sidx[slot] = 0u;
                     } else {   // the path's records, in queue order
-                        float4 a = ss.RA[parity][idx], b = ss.RB[parity][idx];
+                        const float4 a = ss.RA[parity][idx], b = ss.RB[parity][idx], t = ss.RT[parity][idx];
+                        rec_a = a; rec_b = b; rec_t = t;
                         in_.rng = __float_as_uint(a.w);
                         in_.porg = xyz(a); in_.pdir = xyz(b);
                         uint32_t dw = __float_as_uint(b.w);
                         in_.depth = dw & 0x7fffffffu; in_.in_medium = (dw >> 31) != 0u;
                         in_.vdepth = VOL ? ps.vdepth[slot] : 0u;
                         in_.cchan = (VOL && sc.atm_on) ? ps.cchan[slot] : -1;
-                        if (!regroup) {
-                            float4 t = ss.RT[parity][idx];
-                            in_.thr_prev = xyz(t); in_.prev_pdf = t.w;
-                            light_prev = xyz(ss.RL[parity][idx]);
-                        }
+                        in_.thr_prev = xyz(t); in_.prev_pdf = t.w;
+                        light_prev = xyz(ss.RL[parity][idx]);
                     }
                     in_.vol_index = -1; in_.vol_t = 0.0f; in_.atm_comp = -1;
                     // RayGen.slang:76-84: a path whose origin is below the planet's surface leaves the loop at once
@@ -379,19 +375,19 @@ __global__ __launch_bounds__(kTraverseBlock, 3) void k_bounce(DeviceScene sc, Re
                     in_.h = make_float4(hit ? hr.t : -1.0f, hr.u, hr.v, __uint_as_float(hr.prim));
                     in_.inst = hr.inst;
                 }
-                if (regroup) {   // park the traced paths in the wave's rings (each ring holds < 64 entries here, so 128 is enough)
-                    const unsigned long long mh = __ballot(valid && hit), mm = __ballot(valid && !hit);
+                if (regroup) {   // park the hits (the ring holds < 64 entries here, so 128 slots are enough); the misses go on below
+                    const unsigned long long mh = __ballot(valid && hit);
                     if (valid && hit) {
                         const uint32_t q = (hit_head + hit_count + lanes_below(mh)) & 127u;
                         r_idx[wave][q] = idx; r_t[wave][q] = hr.t; r_u[wave][q] = hr.u; r_v[wave][q] = hr.v; r_prim[wave][q] = hr.prim; r_inst[wave][q] = hr.inst;
+                        r_ra[wave][q] = rec_a; r_rb[wave][q] = rec_b; r_rt[wave][q] = rec_t;
                     }
-                    if (valid && !hit) r_miss[wave][(miss_head + miss_count + lanes_below(mm)) & 127u] = idx;
-                    hit_count += (uint32_t)__popcll(mh); miss_count += (uint32_t)__popcll(mm);
-                    w_paths += (uint32_t)__popcll(mh | mm);
+                    hit_count += (uint32_t)__popcll(mh);
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    continue;
+                    valid = valid && !hit;
+                    if (__ballot(valid) == 0ull) continue;
                 }
             } else {
                 break;
@@ -493,7 +489,7 @@ __global__ __launch_bounds__(kTraverseBlock, 3) void k_bounce(DeviceScene sc, Re
                 ss.RT[parity ^ 1u][pn] = f4(o.thr, o.new_pdf);
                 ss.RL[parity ^ 1u][pn] = f4(light, 0.0f);
             }
-            if (!regroup) w_paths += (uint32_t)__popcll(__ballot(valid));
+            w_paths += (uint32_t)__popcll(__ballot(valid));
             w_alive += (uint32_t)__popcll(__ballot(alive));
             w_rays += (uint32_t)__popcll(__ballot(nrays >= 1u)) + (uint32_t)__popcll(__ballot(nrays >= 2u));
             w_hits += (uint32_t)__popcll(__ballot(hit));

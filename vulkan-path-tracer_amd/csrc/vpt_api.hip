@@ -713,8 +713,9 @@ int vpt_set_scene(vpt_ctx* c, const vpt_scene_desc* sd) {
     DeviceScene& D = c->dsc;
     int rc;
     if ((rc = upload(c, nodes, &D.nodes))) return rc;
-    // small scenes ride in LDS next to the traversal stacks, in the fp32 node form
-    c->lds_scene = (nodes.size() * sizeof(BvhNodeWide) + leaf_tris.size() * sizeof(BvhTri)) <= 16384;
+    // small scenes ride in LDS next to the traversal stacks, in the fp32 node form: up to 3 KB, so that three blocks of the fused
+    // kernel (14 KB of stacks + 36 KB of regrouping ring + the scene each) still fit the 160 KB of a CU
+    c->lds_scene = (nodes.size() * sizeof(BvhNodeWide) + leaf_tris.size() * sizeof(BvhTri)) <= 3072;
     D.nodes_wide = nullptr;
     if (c->lds_scene && (rc = upload(c, wide, &D.nodes_wide))) return rc;
     if ((rc = upload(c, leaf_tris, &D.tris))) return rc;
