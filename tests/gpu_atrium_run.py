@@ -8,7 +8,7 @@ pipe = int(os.environ.get("PIPE", "2"))
 which = os.environ.get("SCENE", "atrium")
 F = int(os.environ.get("FRAMES", "64"))
 sc = vpt.scenes.atrium() if which == "atrium" else vpt.scenes.glass_bust()
-g = vpt.PathTracer(1920, 1080, pipeline=pipe, frames_in_flight=F, profile=True); g.set_scene(sc)
+g = vpt.PathTracer(1920, 1080, pipeline=pipe, frames_in_flight=F, profile=os.environ.get("PROFILE", "1") == "1"); g.set_scene(sc)
 g.set_params(vpt.default_params(max_depth=8 if which == "atrium" else 32, max_samples=1 << 30))
 g.render(F); g.reset_stats(); t = time.time(); g.render(2 * F); dt = time.time() - t
 st = g.stats(); print("Msamples/s", round(st["samples"] / dt / 1e6, 1), {k: round(v, 2) for k, v in st["kernel_ms"].items() if v > 0})

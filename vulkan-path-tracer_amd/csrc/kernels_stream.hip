@@ -89,6 +89,7 @@ __global__ __launch_bounds__(256) void k_classify(const uint32_t* queue, const u
             if (!exact) reserved += active * kAppendChunk;
         }
         sc->queue_len[parity ^ 1u].v = reserved; sc->pend_len.v = reserved; sc->sky_len.v = reserved; sc->light_len.v = reserved;
+        sc->sky_head.v = 0u; sc->light_head.v = 0u;
         __threadfence();
     }
 }
@@ -389,12 +390,13 @@ __global__ void k_layout_single(StreamCounters* sc, uint32_t parity, uint32_t sh
     sc->class_len[0].v = n; sc->class_active[0] = active; sc->class_exact[0] = exact; sc->class_base[0] = 0u;
     const uint32_t reserved = exact ? 0u : active * kAppendChunk;
     sc->queue_len[parity ^ 1u].v = reserved; sc->pend_len.v = reserved; sc->sky_len.v = reserved; sc->light_len.v = reserved;
+    sc->sky_head.v = 0u; sc->light_head.v = 0u;
 }
 
 // Start of a bounce: cursors and class queue lengths to zero (the stream lengths are set by k_classify's last block).
 __global__ void k_prepare_stream(StreamCounters* sc, uint32_t parity) {
     sc->alive[parity ^ 1u].v = 0u;
-    sc->extend_head.v = 0u; sc->sky_head.v = 0u; sc->light_head.v = 0u;
+    sc->extend_head.v = 0u;   // (the shadow-ray cursors are reset where the streams are laid out: the previous bounce's shadow kernels may still run)
     for (uint32_t c = 0; c < kShadeClasses; c++) { sc->class_len[c].v = 0u; sc->class_head[c].v = 0u; }
     sc->classify_done = 0u;
 }

@@ -23,6 +23,8 @@ constexpr uint32_t kMaxFramesInFlight = 1024;   // frames of one batch (a 1/8 sh
 struct vpt_ctx {
     vpt_config cfg{};
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;             // staged pipeline: the shadow-ray kernels and the join of bounce k run here, beside the extend of bounce k + 1
+    hipEvent_t ev_shade = nullptr, ev_join = nullptr;
     std::string err;
     int cu_count = 256;
 
@@ -444,6 +446,12 @@ int render_batch(vpt_ctx* c, uint32_t frames, uint32_t dispatch_base) {
         TIMED(c, VPT_K_PRIMARY, launch_raygen(s, c->P, c->ps, c->queue[0], c->ctr, n_slots, dispatch_base));
         parity = 0;
     }
+    const bool sorted = c->cfg.pipeline == VPT_PIPELINE_STAGED_SORTED;
+    // Two streams: the shadow-ray kernels and the join of bounce k run beside the extend of bounce k + 1 (which needs only the ray
+    // queue shade k wrote), so the tail of one persistent traversal kernel is filled by the next one's first blocks.  Off while
+    // kernels are timed or visits counted (one kernel at a time then) and in the sorted pipeline.
+    const bool overlap = stream && !sorted && !c->cfg.profile && !count;
+    bool join_pending = false;
     const uint64_t min_bounces = (uint64_t)c->P.max_depth * c->P.samples_per_frame;
     const uint64_t iter_cap = min_bounces * 4ull + 1024ull;
     uint64_t iter = 0;
@@ -464,9 +472,11 @@ int render_batch(vpt_ctx* c, uint32_t frames, uint32_t dispatch_base) {
                 a.ro = c->ss.RA[parity]; a.rd = c->ss.RB[parity]; a.order = nullptr; a.valid = c->queue[parity]; a.hit = c->ss.SH; a.hinst = c->ss.SHI; a.cls = c->cls_q;
                 a.n = 0; a.n_dev = &c->sctr->queue_len[parity].v; a.head = &c->sctr->extend_head.v;
                 a.tmin = 0.01f; a.tmax = 100000.0f; a.normalize_dir = 1u; a.param = c->vote_param;
-                const bool sorted = c->cfg.pipeline == VPT_PIPELINE_STAGED_SORTED;
                 if (!sorted) a.cls = nullptr;
                 TIMED(c, VPT_K_EXTEND, launch_trace(s, (uint32_t)c->vote_blocks, VPT_TRACE_VOTE, false, count, c->dsc, a, c->ctr));
+                // the shade stage of this bounce overwrites the pending records and shadow-ray streams the join of the previous
+                // bounce reads (overlapped mode: that join runs on the second stream, beside the extend launched above)
+                if (overlap && join_pending) { HIPCHK(c, hipStreamWaitEvent(s, c->ev_join, 0)); join_pending = false; }
                 if (sorted) {   // the shade queue sorted by material class: one dense queue and one launch per class present in the scene
                     TIMED(c, VPT_K_SHADE, launch_classify(s, c->queue[parity], c->cls_q, c->class_queue, c->sctr, parity, n_slots + c->stream_slack, (uint32_t)c->shade_stream_blocks * 4u));
                     for (uint32_t k = 0; k < kShadeClasses; k++)
@@ -476,9 +486,16 @@ int render_batch(vpt_ctx* c, uint32_t frames, uint32_t dispatch_base) {
                     launch_layout_single(s, c->sctr, parity, (uint32_t)c->shade_stream_blocks * 4u);
                     TIMED(c, VPT_K_SHADE, launch_shade_stream(s, (uint32_t)c->shade_stream_blocks, 0u, false, c->dsc, c->P, c->ps, c->ss, c->queue[parity], nullptr, c->queue[parity ^ 1u], c->ctr, c->sctr, parity));
                 }
-                TIMED(c, VPT_K_SHADOW, launch_trace_shadow(s, (uint32_t)c->shadow_blocks, false, count, c->dsc, c->ss, c->ctr, c->sctr, c->vote_param));
-                TIMED(c, VPT_K_SHADOW, launch_trace_shadow(s, (uint32_t)c->shadow_blocks, true, count, c->dsc, c->ss, c->ctr, c->sctr, c->vote_param));
-                TIMED(c, VPT_K_JOIN, launch_join(s, (uint32_t)c->shade_blocks, c->P, c->ps, c->ss, c->sctr));
+                hipStream_t sb = s;
+                if (overlap) {   // shadow rays and join of this bounce on the second stream: the next bounce's extend does not depend on them
+                    HIPCHK(c, hipEventRecord(c->ev_shade, s));
+                    HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_shade, 0));
+                    sb = c->stream2;
+                }
+                TIMED(c, VPT_K_SHADOW, launch_trace_shadow(sb, (uint32_t)c->shadow_blocks, false, count, c->dsc, c->ss, c->ctr, c->sctr, c->vote_param));
+                TIMED(c, VPT_K_SHADOW, launch_trace_shadow(sb, (uint32_t)c->shadow_blocks, true, count, c->dsc, c->ss, c->ctr, c->sctr, c->vote_param));
+                TIMED(c, VPT_K_JOIN, launch_join(sb, (uint32_t)c->shade_blocks, c->P, c->ps, c->ss, c->sctr));
+                if (overlap) { HIPCHK(c, hipEventRecord(c->ev_join, c->stream2)); join_pending = true; }
                 parity ^= 1u;
                 continue;
             }
@@ -492,6 +509,7 @@ int render_batch(vpt_ctx* c, uint32_t frames, uint32_t dispatch_base) {
         if (!fused && !stream) launch_fold(s, c->ctr);
         // the resolve rides right behind the bounces that are expected to be the last ones; it does nothing if a path is
         // still alive (in-medium walks do not consume depth), in which case more bounces and another resolve follow
+        if (overlap && join_pending) { HIPCHK(c, hipStreamWaitEvent(s, c->ev_join, 0)); join_pending = false; }   // the resolve reads the frame sums the join writes
         const uint32_t* guard = fused ? &c->ctr->alive3[k3] : stream ? &c->sctr->alive[parity].v : &c->ctr->ray_count[parity];
         TIMED(c, VPT_K_RESOLVE, launch_resolve(s, c->P, c->ps, c->image, frames, dispatch_base, guard));
         Counters h{};
@@ -572,7 +590,9 @@ vpt_ctx* vpt_create(const vpt_config* cfg, int* err) {
     c->cfg = *cfg;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess) c->cu_count = prop.multiProcessorCount;
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipMalloc((void**)&c->ctr, sizeof(Counters)) != hipSuccess) {
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_shade, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
+        hipMalloc((void**)&c->ctr, sizeof(Counters)) != hipSuccess) {
         set(VPT_ERR_DEVICE); delete c; return nullptr;
     }
     (void)hipMemset(c->ctr, 0, sizeof(Counters));
@@ -604,6 +624,9 @@ void vpt_destroy(vpt_ctx* c) {
     for (DensityGrid& g : c->grids) { (void)hipFree((void*)g.values); (void)hipFree((void*)g.block_max); }
     if (c->d_grids) (void)hipFree(c->d_grids);
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
+    if (c->ev_shade) (void)hipEventDestroy(c->ev_shade);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
