@@ -137,6 +137,8 @@ struct DeviceScene {
     const float* lut_i;  // 128x128x32
     const MatResolved* mat_resolved;        // per material
     const float4* tri_ng;                   // per global triangle id: world-space geometric normal (Surface.slang:48-49)
+    const float4* tri_shade;                // per global triangle id: 8 float4 = the three vertices (position | normal | uv, as in vpt_vertex) + tri_ng,
+                                            // de-indexed into ONE 128-byte line, so a hit costs one line fetch instead of index triple + 3 vertices + normal
     const EmissiveTri* emissive_tri;        // per emissive triangle
     const uint32_t* emissive_tri_offset;    // per emissive mesh: first entry in emissive_tri
     const uint32_t* tri_slot_of_gid;        // per global triangle id: position in the leaf-ordered triangle array

@@ -22,6 +22,7 @@ void launch_trace_rays(hipStream_t s, uint32_t blocks, const DeviceScene& sc, co
 void launch_scatter_rows(hipStream_t s, const float* gathered, float* full, uint32_t w, uint32_t h, uint32_t shard_count, uint32_t stride_px);
 void launch_precompute_materials(hipStream_t s, const DeviceScene& sc, uint32_t flags, MatResolved* out, uint32_t n);
 void launch_precompute_tri_ng(hipStream_t s, const DeviceScene& sc, float4* out);
+void launch_precompute_tri_shade(hipStream_t s, const DeviceScene& sc, float4* out);
 void launch_precompute_emissive(hipStream_t s, const DeviceScene& sc, EmissiveTri* out, uint32_t total);
 size_t traverse_lds_bytes(const DeviceScene& sc, bool lds_scene);
 size_t stack_overflow_bytes(uint32_t blocks);  // per-thread spill region of the traversal stacks for a grid of `blocks`

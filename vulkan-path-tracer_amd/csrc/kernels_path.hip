@@ -704,6 +704,23 @@ __global__ __launch_bounds__(256) void k_precompute_tri_ng(DeviceScene sc, float
     V3 ng = triangle_ng(sc, sc.instances[t.inst], t.prim);
     out[t.gid] = make_float4(ng.x, ng.y, ng.z, 0.0f);
 }
+__global__ __launch_bounds__(256) void k_precompute_tri_shade(DeviceScene sc, float4* out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= sc.tri_count) return;
+    const BvhTri& t = sc.tris[i];
+    const InstanceDesc in = sc.instances[t.inst];
+    const MeshDesc me = sc.meshes[in.mesh];
+    const uint32_t* idx = sc.indices + me.index_offset + t.prim * 3;
+    const vpt_vertex* vb = sc.vertices + me.vertex_offset;
+    float4* q = out + (size_t)t.gid * 8;
+    for (int k = 0; k < 3; k++) {
+        const float4* v = reinterpret_cast<const float4*>(vb + idx[k]);
+        q[2 * k] = v[0]; q[2 * k + 1] = v[1];
+    }
+    V3 ng = triangle_ng(sc, in, t.prim);
+    q[6] = make_float4(ng.x, ng.y, ng.z, 0.0f);
+    q[7] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+}
 __global__ __launch_bounds__(256) void k_precompute_emissive(DeviceScene sc, EmissiveTri* out, uint32_t total) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
@@ -736,6 +753,9 @@ void launch_precompute_materials(hipStream_t s, const DeviceScene& sc, uint32_t 
 }
 void launch_precompute_tri_ng(hipStream_t s, const DeviceScene& sc, float4* out) {
     if (sc.tri_count) hipLaunchKernelGGL(k_precompute_tri_ng, dim3((sc.tri_count + 255) / 256), dim3(256), 0, s, sc, out);
+}
+void launch_precompute_tri_shade(hipStream_t s, const DeviceScene& sc, float4* out) {
+    if (sc.tri_count) hipLaunchKernelGGL(k_precompute_tri_shade, dim3((sc.tri_count + 255) / 256), dim3(256), 0, s, sc, out);
 }
 void launch_precompute_emissive(hipStream_t s, const DeviceScene& sc, EmissiveTri* out, uint32_t total) {
     if (total) hipLaunchKernelGGL(k_precompute_emissive, dim3((total + 255) / 256), dim3(256), 0, s, sc, out, total);

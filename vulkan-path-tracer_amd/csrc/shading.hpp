@@ -102,20 +102,16 @@ __device__ inline V3 triangle_ng(const DeviceScene& sc, const InstanceDesc& in, 
 
 __device__ inline void surface_init(const DeviceScene& sc, SurfaceFrame& s, const InstanceDesc& in, uint32_t prim, float hu,
                                     float hv, V3 raydir, uint32_t normal_tex, bool geo_only, const MatResolved& mr) {
-    const MeshDesc me = sc.meshes[in.mesh];
-    const uint32_t* idx = sc.indices + me.index_offset + prim * 3;
-    const vpt_vertex* vb = sc.vertices + me.vertex_offset;
-    const float4* q1 = reinterpret_cast<const float4*>(vb + idx[0]);
-    const float4* q2 = reinterpret_cast<const float4*>(vb + idx[1]);
-    const float4* q3 = reinterpret_cast<const float4*>(vb + idx[2]);
-    float4 a0 = q1[0], a1 = q1[1], b0 = q2[0], b1 = q2[1], c0 = q3[0], c1 = q3[1];
+    // the triangle's three vertices and its geometric normal from its de-indexed record (k_precompute_tri_shade): one 128-byte line
+    const float4* q = sc.tri_shade + (size_t)(in.tri_offset + prim) * 8;
+    const float4 a0 = q[0], a1 = q[1], b0 = q[2], b1 = q[3], c0 = q[4], c1 = q[5], g6 = q[6];
     s.p1 = v3(a0.x, a0.y, a0.z); s.p2 = v3(b0.x, b0.y, b0.z); s.p3 = v3(c0.x, c0.y, c0.z);
     V3 n1 = v3(a0.w, a1.x, a1.y), n2 = v3(b0.w, b1.x, b1.y), n3 = v3(c0.w, c1.x, c1.y);
     float bx = 1.0f - hu - hv, by = hu, bz = hv;  // ClosestHit.slang:45
     s.pos = mat_point(in.xform, (s.p1 * bx + s.p2 * by) + s.p3 * bz);
     s.uv.x = (a1.z * bx + b1.z * by) + c1.z * bz;
     s.uv.y = (a1.w * bx + b1.w * by) + c1.w * bz;
-    { float4 g = sc.tri_ng[in.tri_offset + prim]; s.Ng = v3(g.x, g.y, g.z); }
+    s.Ng = v3(g6.x, g6.y, g6.z);
     if (geo_only) {
         s.N = s.Ng;
     } else {

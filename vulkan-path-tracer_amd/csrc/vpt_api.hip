@@ -55,6 +55,7 @@ struct vpt_ctx {
     EmissiveTri* d_emissive_tri = nullptr;
     uint32_t* d_emissive_tri_offset = nullptr;
     float4* d_tri_ng = nullptr;
+    float4* d_tri_shade = nullptr;
     unsigned char* d_inst_class = nullptr;   // shade class per instance (kernels_path.hip k_classify_instances)
     std::vector<BvhTri> bvh_input;           // the triangles the BVH was built from (trace lab: the eight-wide tree is built from them on first use)
     bool lds_scene = false;
@@ -769,6 +770,9 @@ int vpt_set_scene(vpt_ctx* c, const vpt_scene_desc* sd) {
         HIPCHK(c, hipMalloc(&d2, sizeof(EmissiveTri) * std::max<size_t>(1, total_tris))); c->scene_allocs.push_back(d2);
         HIPCHK(c, hipMalloc(&d3, 4 * std::max<size_t>(1, c->instances.size()))); c->scene_allocs.push_back(d3);
         HIPCHK(c, hipMalloc(&d4, 16 * std::max<size_t>(1, total_tris))); c->scene_allocs.push_back(d4);
+        void* d6 = nullptr;
+        HIPCHK(c, hipMalloc(&d6, 128 * std::max<size_t>(1, total_tris))); c->scene_allocs.push_back(d6);
+        c->d_tri_shade = (float4*)d6; D.tri_shade = c->d_tri_shade;
         void* d5 = nullptr;
         HIPCHK(c, hipMalloc(&d5, std::max<size_t>(1, c->instances.size()))); c->scene_allocs.push_back(d5);
         c->d_inst_class = (unsigned char*)d5; D.inst_class = c->d_inst_class;
@@ -799,6 +803,7 @@ int vpt_set_scene(vpt_ctx* c, const vpt_scene_desc* sd) {
         D.stack_overflow = (uint32_t*)d;
     }
     launch_precompute_tri_ng(c->stream, D, c->d_tri_ng);
+    launch_precompute_tri_shade(c->stream, D, c->d_tri_shade);
     launch_precompute_materials(c->stream, D, c->params.flags, c->d_mat_resolved, (uint32_t)c->materials.size());
     launch_classify_instances(c->stream, D, c->d_inst_class, (uint32_t)c->instances.size());
     HIPCHK(c, hipStreamSynchronize(c->stream));
