@@ -258,6 +258,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # this image's driver shares device memory across processes through dmabuf only (RCCL needs it)
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
