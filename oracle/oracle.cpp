@@ -1928,9 +1928,45 @@ void orc_bsdf_eval(const vpt_material* mat, const float* V, const float* L, uint
         out[i * 4] = e.bxdf.x; out[i * 4 + 1] = e.bxdf.y; out[i * 4 + 2] = e.bxdf.z; out[i * 4 + 3] = e.pdf;
     }
 }
+// The same with energy compensation on and the three lookup tables given (reflection 64x64x32, refraction from outside / inside
+// 128x128x32), hit from outside (inside == 0) or inside: what tests/test_oracle_bsdf_fp64.py holds against a float64 restatement.
+void orc_bsdf_eval_ec(const vpt_material* mat, const float* V, const float* L, uint32_t n, const float* lut_r, const float* lut_o, const float* lut_i,
+                      int inside, float* out) {
+    static Oracle* holder = nullptr;   // only the tables are read through it
+    if (!holder) holder = new Oracle();
+    holder->lutR.assign(lut_r, lut_r + 64 * 64 * 32);
+    holder->lutO.assign(lut_o, lut_o + 128 * 128 * 32);
+    holder->lutI.assign(lut_i, lut_i + 128 * 128 * 32);
+    Mat m; hook_material(m, mat);
+    m.o = holder; m.ec = true;
+    if (inside) m.eta = m.p.ior;
+    V3 v = v3(V[0], V[1], V[2]);
+    for (uint32_t i = 0; i < n; i++) {
+        Eval e = m.eval_bsdf(v, v3(L[i * 3], L[i * 3 + 1], L[i * 3 + 2]));
+        out[i * 4] = e.bxdf.x; out[i * 4 + 1] = e.bxdf.y; out[i * 4 + 2] = e.bxdf.z; out[i * 4 + 3] = e.pdf;
+    }
+}
 // n draws of the VNDF + SampleBSDF (Sampler.slang:141-166, Material.slang:94-165) from one RNG stream: out[i*7..] = L.xyz, f.rgb, pdf
 void orc_bsdf_sample(const vpt_material* mat, const float* V, uint32_t seed, uint32_t n, float* out) {
     Mat m; hook_material(m, mat);
+    V3 v = v3(V[0], V[1], V[2]);
+    Rng r; r.s = seed;
+    for (uint32_t i = 0; i < n; i++) {
+        V3 H = ggx_sample(r, v, m.ax, m.ay);
+        BSample b = sample_bsdf(m, r, v, H);
+        float* q = out + (size_t)i * 7;
+        q[0] = b.L.x; q[1] = b.L.y; q[2] = b.L.z; q[3] = b.bxdf.x; q[4] = b.bxdf.y; q[5] = b.bxdf.z; q[6] = b.pdf;
+    }
+}
+// The same draws with energy compensation on and the three lookup tables given (orc_bsdf_eval_ec).
+void orc_bsdf_sample_ec(const vpt_material* mat, const float* V, uint32_t seed, uint32_t n, const float* lut_r, const float* lut_o, const float* lut_i, float* out) {
+    static Oracle* holder = nullptr;
+    if (!holder) holder = new Oracle();
+    holder->lutR.assign(lut_r, lut_r + 64 * 64 * 32);
+    holder->lutO.assign(lut_o, lut_o + 128 * 128 * 32);
+    holder->lutI.assign(lut_i, lut_i + 128 * 128 * 32);
+    Mat m; hook_material(m, mat);
+    m.o = holder; m.ec = true;
     V3 v = v3(V[0], V[1], V[2]);
     Rng r; r.s = seed;
     for (uint32_t i = 0; i < n; i++) {

@@ -39,6 +39,8 @@ def lib():
         L.orc_ggx_d.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
         L.orc_bsdf_eval.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
         L.orc_bsdf_sample.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.orc_bsdf_sample_ec.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_bsdf_eval_ec.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.orc_get_triangles.restype = C.c_uint32
         L.orc_get_triangles.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
         L.orc_pixel_rays.restype = C.c_uint32
@@ -92,10 +94,26 @@ def bsdf_eval(mat, V, L):
     return out[:, :3], out[:, 3]
 
 
+def bsdf_eval_ec(mat, V, L, luts, inside=False):
+    """EvaluateBSDF(V, L) with USE_ENERGY_COMPENSATION and the given (reflection, refraction-outside, refraction-inside) tables."""
+    V = np.ascontiguousarray(V, np.float32); L = np.ascontiguousarray(L, np.float32); out = np.zeros((len(L), 4), np.float32)
+    r, o, i = (np.ascontiguousarray(t, np.float32) for t in luts)
+    lib().orc_bsdf_eval_ec(C.byref(mat), V.ctypes.data, L.ctypes.data, len(L), r.ctypes.data, o.ctypes.data, i.ctypes.data, int(inside), out.ctypes.data)
+    return out[:, :3], out[:, 3]
+
+
 def bsdf_sample(mat, V, seed, n):
     """n draws of VNDF + SampleBSDF: (L [n, 3], f [n, 3], pdf [n])."""
     V = np.ascontiguousarray(V, np.float32); out = np.zeros((n, 7), np.float32)
     lib().orc_bsdf_sample(C.byref(mat), V.ctypes.data, seed, n, out.ctypes.data)
+    return out[:, :3], out[:, 3:6], out[:, 6]
+
+
+def bsdf_sample_ec(mat, V, seed, n, luts):
+    """n draws of VNDF + SampleBSDF with energy compensation: (L [n, 3], f [n, 3], pdf [n])."""
+    V = np.ascontiguousarray(V, np.float32); out = np.zeros((n, 7), np.float32)
+    r, o, i = (np.ascontiguousarray(t, np.float32) for t in luts)
+    lib().orc_bsdf_sample_ec(C.byref(mat), V.ctypes.data, seed, n, r.ctypes.data, o.ctypes.data, i.ctypes.data, out.ctypes.data)
     return out[:, :3], out[:, 3:6], out[:, 6]
 
 
