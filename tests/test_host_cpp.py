@@ -292,6 +292,36 @@ def test_glb_container_and_data_uris(cli, vpt, tmp_path, mode):
         assert p.returncode == 1 and b"glb" in p.stderr
 
 
+def test_material_extensions_import_identically(cli, vpt, tmp_path):
+    """Every material field the reference takes from its importer (PathTracer.cpp:338-348) has a glTF source: core PBR factors,
+    KHR_materials_emissive_strength / ior / transmission / specular / anisotropy (rotation: radians -> the reference's degrees).
+    C++ importer and Python loader produce the same 112-byte material records."""
+    import ctypes as C
+    doc, tri = _minimal()
+    doc["materials"] = [
+        {"name": "all", "pbrMetallicRoughness": {"baseColorFactor": [0.8, 0.5, 0.25, 1.0], "metallicFactor": 0.25, "roughnessFactor": 0.375},
+         "emissiveFactor": [1.0, 0.5, 0.25],
+         "extensions": {"KHR_materials_emissive_strength": {"emissiveStrength": 12.5}, "KHR_materials_ior": {"ior": 1.33},
+                        "KHR_materials_transmission": {"transmissionFactor": 0.75}, "KHR_materials_specular": {"specularColorFactor": [0.9, 0.8, 0.7]},
+                        "KHR_materials_anisotropy": {"anisotropyStrength": 0.6, "anisotropyRotation": 1.0}}},
+        {"name": "negative rotation", "extensions": {"KHR_materials_anisotropy": {"anisotropyStrength": 0.3, "anisotropyRotation": -7.5}}},
+        {"name": "plain"}]
+    doc["meshes"][0]["primitives"][0]["material"] = 0
+    doc["meshes"].append({"primitives": [{"attributes": {"POSITION": 0}, "indices": 1, "material": 1}]})
+    doc["meshes"].append({"primitives": [{"attributes": {"POSITION": 0}, "indices": 1, "material": 2}]})
+    doc["nodes"] = [{"mesh": 0}, {"mesh": 1}, {"mesh": 2}]; doc["scenes"] = [{"nodes": [0, 1, 2]}]
+    path = _gltf(tmp_path, "ext.gltf", doc, tri)
+    sc = vpt.scenes.load_gltf(path)
+    m = sc.materials[0]
+    assert abs(m["anisotropy"] - 0.6) < 1e-7 and abs(m["anisotropy_rotation"] - 57.29578) < 1e-4 and abs(m["ior"] - 1.33) < 1e-7
+    assert abs(m["emissive_color"][0] - 12.5) < 1e-6 and abs(m["transmission"] - 0.75) < 1e-7 and tuple(m["specular_color"]) == (0.9, 0.8, 0.7)
+    assert abs(sc.materials[1]["anisotropy_rotation"] - (360.0 - (7.5 * 180.0 / np.pi) % 360.0) % 360.0) < 1e-3 and 0 <= sc.materials[1]["anisotropy_rotation"] < 360
+    subprocess.check_output([cli, "--scene", path, "--dump-scene", str(tmp_path / "s.bin")])
+    _, mats, _, _, _ = read_dump(str(tmp_path / "s.bin"))
+    desc, keep = sc.to_desc()
+    assert mats == C.string_at(desc.materials, 112 * len(sc.materials))
+
+
 def _gltf(tmp_path, name, doc, bin_bytes=b"\x00" * 64):
     import json as _json
     (tmp_path / "b.bin").write_bytes(bin_bytes)

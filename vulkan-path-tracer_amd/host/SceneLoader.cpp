@@ -421,6 +421,13 @@ bool ImportScene(const std::string& gltfPath, SceneAsset& sc, std::string& error
             if (const JVal* e = extObj("KHR_materials_ior")) pm.ior = (float)e->number("ior", 1.5);
             if (const JVal* e = extObj("KHR_materials_transmission")) pm.transmission = (float)e->number("transmissionFactor", 0.0);
             if (const JVal* e = extObj("KHR_materials_specular")) if (const JVal* c = e->get("specularColorFactor")) for (int k = 0; k < 3; k++) pm.specular_color[k] = (float)(*c)[k].num;
+            if (const JVal* e = extObj("KHR_materials_anisotropy")) {   // rotation: radians (glTF) -> degrees in [0, 360) (Editor.cpp:325)
+                pm.anisotropy = (float)e->number("anisotropyStrength", 0.0);
+                double deg = std::fmod(e->number("anisotropyRotation", 0.0) * (180.0 / 3.14159265358979323846), 360.0);
+                if (deg < 0.0) deg += 360.0;
+                if (deg == 0.0) deg = 0.0;   // no negative zero
+                pm.anisotropy_rotation = (float)deg;
+            }
             if (!textureIndex(pbr ? pbr->get("baseColorTexture") : nullptr, false, pm.base_color_texture)) return false;
             if (!textureIndex(m.get("normalTexture"), false, pm.normal_texture)) return false;
             if (!textureIndex(pbr ? pbr->get("metallicRoughnessTexture") : nullptr, true, pm.roughness_texture)) return false;

@@ -7,7 +7,7 @@ from VulkanHelper::AssetImporter output (reference PathTracer.cpp:158-676).
 
 `load_gltf` is a minimal glTF 2.0 reader standing in for the absent VulkanHelper/assimp importer
 (parity unpinned): node TRS hierarchy, cameras, pbrMetallicRoughness,
-KHR_materials_{emissive_strength,transmission,ior,specular}.  The reference's world is Y-down
+KHR_materials_{emissive_strength,transmission,ior,specular,anisotropy}.  The reference's world is Y-down
 (Sampler.slang:336, RTCommon.slang:129-136, FlyCamera.cpp:52-56), glTF is Y-up, so every node matrix
 M becomes F·M·F with F = diag(1,-1,1,1), vertices/normals are mirrored and the winding is swapped so
 geometric and vertex normals stay on the same side.
@@ -16,6 +16,7 @@ import ctypes as C
 import json
 import os
 
+import math
 import numpy as np
 
 from . import _abi
@@ -331,7 +332,11 @@ def load_gltf(path, image_loader=None):
                       metallic=pbr.get("metallicFactor", 1.0), roughness=pbr.get("roughnessFactor", 1.0),
                       ior=ext.get("KHR_materials_ior", {}).get("ior", 1.5),
                       transmission=ext.get("KHR_materials_transmission", {}).get("transmissionFactor", 0.0),
-                      specular_color=tuple(ext.get("KHR_materials_specular", {}).get("specularColorFactor", [1, 1, 1])))
+                      specular_color=tuple(ext.get("KHR_materials_specular", {}).get("specularColorFactor", [1, 1, 1])),
+                      # KHR_materials_anisotropy: strength as is; rotation in radians counter-clockwise from the tangent, the
+                      # reference's AnisotropyRotation in degrees (Editor.cpp:325, 0..360)
+                      anisotropy=ext.get("KHR_materials_anisotropy", {}).get("anisotropyStrength", 0.0),
+                      anisotropy_rotation=float(np.float32(math.fmod(ext.get("KHR_materials_anisotropy", {}).get("anisotropyRotation", 0.0) * (180.0 / math.pi), 360.0) % 360.0)))
         for key, ref, single in (("base_color_texture", pbr.get("baseColorTexture"), False),
                                  ("normal_texture", m.get("normalTexture"), False),
                                  ("roughness_texture", pbr.get("metallicRoughnessTexture"), True),
