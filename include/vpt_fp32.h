@@ -254,6 +254,12 @@ VPT_HD V3 rotate(V3 v, V3 axis, float theta) {
     return (v * c) + (cross(a, v) * s) + (a * dot(a, v)) * (1.0f - c);
 }
 
+// The same rotation with sincos_(theta) supplied by the caller (an angle that is constant for a whole render is evaluated once).
+VPT_HD V3 rotate_sc(V3 v, V3 axis, float s, float c) {
+    V3 a = normalize(axis);
+    return (v * c) + (cross(a, v) * s) + (a * dot(a, v)) * (1.0f - c);
+}
+
 // ---------------------------------------------------------------- matrices
 // float[16] column-major exactly as glm stores a mat4: m[col*4+row].
 VPT_HD V3 mat_point(const float* m, V3 p) {  // mul(M, float4(p,1)).xyz

@@ -163,6 +163,9 @@ struct RenderParams {
     float max_luminance, focus_distance, dof_strength;
     float sky_azimuth, sky_altitude, sky_intensity, emissive_pdf_bias;
     uint32_t flags, base_seed;
+    // sincos_ of the four sky-rotation angles the shaders use, evaluated once per vpt_set_params with the shared fp32 contract
+    // (vpt_api.hip sync_params): {sin, cos} of azimuth, altitude (ImportanceSampleEnvMap) and of -altitude, -azimuth (Miss)
+    float sky_rot[8];
 };
 
 // ---- Wavefront path state: 16-byte records per slot (slot = frame_in_flight * shard_pixels +

@@ -186,8 +186,8 @@ __device__ __forceinline__ void shade_core(const DeviceScene& sc, const RenderPa
         if (((P.flags & VPT_FLAG_SHOW_ENV_DIRECTLY) || depth > 0) && sc.env_black) {
             cp = v4(0.0f, 0.0f, 0.0f, 0.0f);  // an all-zero env map returns exactly 0 (pdf included) for any direction
         } else if ((P.flags & VPT_FLAG_SHOW_ENV_DIRECTLY) || depth > 0) {
-            V3 d = rotate(pdir, v3(1.0f, 0.0f, 0.0f), -(P.sky_altitude / 180.0f * VPT_PI));
-            d = rotate(d, v3(0.0f, 1.0f, 0.0f), -(P.sky_azimuth / 180.0f * VPT_PI));
+            V3 d = rotate_sc(pdir, v3(1.0f, 0.0f, 0.0f), P.sky_rot[4], P.sky_rot[5]);   // rotate(.., -(sky_altitude / 180 * pi))
+            d = rotate_sc(d, v3(0.0f, 1.0f, 0.0f), P.sky_rot[6], P.sky_rot[7]);         // rotate(.., -(sky_azimuth / 180 * pi))
             V2 uv = direction_to_uv(d);
             cp = env_sample(sc, uv.x, uv.y);
         }

@@ -370,8 +370,8 @@ __device__ inline void sample_env(const DeviceScene& sc, const RenderParams& P, 
     float st = sin_(theta);
     float v = theta * VPT_1_OVER_PI;
     to_light = v3(sp * st, -ct, (-cp) * st);
-    to_light = rotate(to_light, v3(0.0f, 1.0f, 0.0f), P.sky_azimuth / 180.0f * VPT_PI);
-    to_light = rotate(to_light, v3(1.0f, 0.0f, 0.0f), P.sky_altitude / 180.0f * VPT_PI);
+    to_light = rotate_sc(to_light, v3(0.0f, 1.0f, 0.0f), P.sky_rot[0], P.sky_rot[1]);   // rotate(.., sky_azimuth / 180 * pi)
+    to_light = rotate_sc(to_light, v3(1.0f, 0.0f, 0.0f), P.sky_rot[2], P.sky_rot[3]);   // rotate(.., sky_altitude / 180 * pi)
     out = env_sample(sc, u, v);
     out.x *= P.sky_intensity; out.y *= P.sky_intensity; out.z *= P.sky_intensity;
 }

@@ -299,6 +299,12 @@ void sync_params(vpt_ctx* c) {
     P.sky_azimuth = p.sky_azimuth; P.sky_altitude = p.sky_altitude; P.sky_intensity = p.sky_intensity;
     P.emissive_pdf_bias = p.emissive_pdf_bias; P.flags = p.flags; P.base_seed = p.base_seed;
     P.split = p.screen_chunk_count; P.launch_off = c->d_launch_off;
+    // the angles exactly as the shaders form them (Sampler.slang:333-334, Miss.slang:28-29); same header, same bits as on the device
+    const float VPT_PI = 3.1415926535897F;   // shading.hpp's M_PI
+    vptfp::sincos_(P.sky_azimuth / 180.0f * VPT_PI, &P.sky_rot[0], &P.sky_rot[1]);
+    vptfp::sincos_(P.sky_altitude / 180.0f * VPT_PI, &P.sky_rot[2], &P.sky_rot[3]);
+    vptfp::sincos_(-(P.sky_altitude / 180.0f * VPT_PI), &P.sky_rot[4], &P.sky_rot[5]);
+    vptfp::sincos_(-(P.sky_azimuth / 180.0f * VPT_PI), &P.sky_rot[6], &P.sky_rot[7]);
 }
 
 void reset_accum(vpt_ctx* c) { c->frame_count = 0; c->dispatch_count = 0; c->samples_accum = 0; }  // PathTracer.h:183
