@@ -64,6 +64,7 @@ struct vpt_ctx {
     vpt_params params{};
     RenderParams P{};
     uint32_t frames_in_flight = 1;
+    uint32_t frames_cap = 0;     // alloc_render_buffers: upper bound of the next attempt after an out-of-memory failure
 
     void* ps_block = nullptr;    // slot-addressed records every pipeline uses (L, ACC, M + the dword arrays)
     void* ps_legacy = nullptr;   // round 1's stage kernels only (A, B, T, H, C*, hinst): allocated on their first use
@@ -197,6 +198,7 @@ int check_render_size(vpt_ctx* c, uint32_t width, uint32_t height, uint32_t* fra
         F = paths / px;
     }
     F = std::max<uint64_t>(1, std::min<uint64_t>(F, kMaxFramesInFlight));
+    if (c->frames_cap) F = std::min<uint64_t>(F, c->frames_cap);   // a retry after an allocation failure (alloc_render_buffers)
     if (px * F >= (1ull << 31)) return fail(c, VPT_ERR_INVALID_ARGUMENT, "too many paths in flight");
     *frames_out = (uint32_t)F;
     return VPT_OK;
@@ -207,8 +209,22 @@ int alloc_render_buffers_impl(vpt_ctx* c);
 // (buffers_ok == false): vpt_render / vpt_get_* / vpt_postprocess then return an error instead of touching freed memory.
 int alloc_render_buffers(vpt_ctx* c) {
     c->buffers_ok = false;
-    int rc = alloc_render_buffers_impl(c);
-    if (rc != VPT_OK) { std::string keep = c->err; free_render_buffers(c); c->err = keep; return rc; }
+    c->frames_cap = 0;
+    int rc = VPT_OK;
+    for (int attempt = 0; attempt < 8; attempt++) {
+        rc = alloc_render_buffers_impl(c);
+        if (rc == VPT_OK) break;
+        std::string keep = c->err;
+        const uint32_t tried = c->frames_in_flight;
+        free_render_buffers(c);
+        c->err = keep;
+        // a batch size the library chose itself (frames_in_flight == 0) is halved and tried again when the device runs out of
+        // memory after all (another process, fragmentation); an explicit request fails as it is
+        if (rc != VPT_ERR_DEVICE || c->cfg.frames_in_flight != 0 || tried <= 1) break;
+        (void)hipGetLastError();
+        c->frames_cap = tried / 2;
+    }
+    if (rc != VPT_OK) return rc;
     c->buffers_ok = true;
     return VPT_OK;
 }
@@ -279,15 +295,16 @@ int ensure_sorted_buffers(vpt_ctx* c) {
 }
 
 int ensure_legacy_buffers(vpt_ctx* c) {
-    if (c->ps_legacy) return VPT_OK;
     const size_t cap = c->ps.capacity, stride = (cap + 63) & ~(size_t)63;
-    HIPCHK(c, hipMalloc(&c->ps_legacy, stride * (16 * 12 + 4)));
-    float4* q = (float4*)c->ps_legacy;
-    PathState& s = c->ps;
-    s.A = q; s.B = q + stride; s.T[0] = q + stride * 2; s.T[1] = q + stride * 3; s.H = q + stride * 4;
-    s.CE = q + stride * 5; s.CS = q + stride * 6; s.CSO = q + stride * 7; s.CSD = q + stride * 8; s.CL = q + stride * 9; s.CLO = q + stride * 10; s.CLD = q + stride * 11;
-    s.hinst = (uint32_t*)(q + stride * 12);
-    if (!c->cqueue) HIPCHK(c, hipMalloc((void**)&c->cqueue, cap * 4));
+    if (!c->ps_legacy) {
+        HIPCHK(c, hipMalloc(&c->ps_legacy, stride * (16 * 12 + 4)));
+        float4* q = (float4*)c->ps_legacy;
+        PathState& s = c->ps;
+        s.A = q; s.B = q + stride; s.T[0] = q + stride * 2; s.T[1] = q + stride * 3; s.H = q + stride * 4;
+        s.CE = q + stride * 5; s.CS = q + stride * 6; s.CSO = q + stride * 7; s.CSD = q + stride * 8; s.CL = q + stride * 9; s.CLO = q + stride * 10; s.CLD = q + stride * 11;
+        s.hinst = (uint32_t*)(q + stride * 12);
+    }
+    if (!c->cqueue) HIPCHK(c, hipMalloc((void**)&c->cqueue, cap * 4));   // (a failed call leaves what it got; the next one completes it)
     return VPT_OK;
 }
 
