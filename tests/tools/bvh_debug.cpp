@@ -5,6 +5,7 @@
 // Test utility only (built on demand by tests); nothing in the product links it.
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <string>
@@ -43,8 +44,9 @@ int main(int argc, char** argv) {
         tris.swap(keep);
     }
     std::vector<BvhNode> nodes; std::vector<BvhNodeWide> wide; std::vector<BvhTri> leaf; int depth = 0;
-    build_bvh(tris, nodes, wide, leaf, &depth);
-    printf("tris %zu nodes %zu depth %d\n", tris.size(), nodes.size(), depth);
+    const bool sbvh = getenv("VPT_SBVH") && atoi(getenv("VPT_SBVH")) != 0;   // spatial splits (bvh_build.hpp)
+    build_bvh(tris, nodes, wide, leaf, &depth, nullptr, sbvh);
+    printf("tris %zu references %zu nodes %zu depth %d\n", tris.size(), leaf.size(), nodes.size(), depth);
     uint32_t max_gid = 0; for (const BvhTri& t : leaf) max_gid = std::max(max_gid, t.gid);
     std::vector<int> slot_of((size_t)max_gid + 1);
     for (size_t i = 0; i < leaf.size(); i++) slot_of[leaf[i].gid] = (int)i;

@@ -102,13 +102,182 @@ struct Builder {
         nodes[id].left = l; nodes[id].right = r; nodes[id].count = 0;
         return id;
     }
+
+    // ---- Spatial splits (Stich, Friedrich, Dietrich 2009): besides the object split of build(), a node may be cut by an axis-aligned
+    // plane; triangles crossing it are referenced from BOTH children, each with the bounds of its clipped part, so the children do not
+    // overlap.  References are lists per node here (they multiply); leaves append their triangle ids to leaf_tris in creation order.
+    const std::vector<BvhTri>* src = nullptr;
+    std::vector<uint32_t> leaf_tris;
+    float root_area = 0.0f;
+    size_t ref_budget = 0, ref_total = 0;
+
+    // bounds of (triangle t) ∩ (slab lo <= x[a] <= hi) ∩ box `within`; false if empty
+    bool clip_bounds(uint32_t t, int a, double lo, double hi, const Box& within, Box& out) const {
+        const BvhTri& tr = (*src)[t];
+        double poly[2][9][3]; int n = 3, cur = 0;
+        for (int k = 0; k < 3; k++) { poly[0][0][k] = tr.v0[k]; poly[0][1][k] = (double)tr.v0[k] + tr.e1[k]; poly[0][2][k] = (double)tr.v0[k] + tr.e2[k]; }
+        for (int side = 0; side < 2; side++) {   // keep x >= lo, then x <= hi
+            const double plane = side == 0 ? lo : hi, sgn = side == 0 ? 1.0 : -1.0;
+            int m = 0;
+            for (int i = 0; i < n; i++) {
+                const double* p = poly[cur][i]; const double* q = poly[cur][(i + 1) % n];
+                const double dp = sgn * (p[a] - plane), dq = sgn * (q[a] - plane);
+                if (dp >= 0.0) { for (int k = 0; k < 3; k++) poly[cur ^ 1][m][k] = p[k]; m++; }
+                if ((dp > 0.0 && dq < 0.0) || (dp < 0.0 && dq > 0.0)) {
+                    const double w = dp / (dp - dq);
+                    for (int k = 0; k < 3; k++) poly[cur ^ 1][m][k] = p[k] + (q[k] - p[k]) * w;
+                    poly[cur ^ 1][m][a] = plane;
+                    m++;
+                }
+            }
+            n = m; cur ^= 1;
+            if (n == 0) return false;
+        }
+        out.reset();
+        for (int i = 0; i < n; i++) {
+            for (int k = 0; k < 3; k++) {   // outward-rounded float bounds of the double vertices
+                float f = (float)poly[cur][i][k];
+                float fl = (double)f > poly[cur][i][k] ? std::nextafter(f, -3.0e38f) : f;
+                float fh = (double)f < poly[cur][i][k] ? std::nextafter(f, 3.0e38f) : f;
+                out.lo[k] = std::min(out.lo[k], fl); out.hi[k] = std::max(out.hi[k], fh);
+            }
+        }
+        for (int k = 0; k < 3; k++) { out.lo[k] = std::max(out.lo[k], within.lo[k]); out.hi[k] = std::min(out.hi[k], within.hi[k]); if (out.lo[k] > out.hi[k]) return false; }
+        return true;
+    }
+
+    int make_leaf(const std::vector<Ref>& r, const Box& nb) {
+        TmpNode n; n.b = nb; n.left = n.right = -1; n.first = (int)leaf_tris.size(); n.count = (int)r.size();
+        for (const Ref& x : r) leaf_tris.push_back(x.tri);
+        nodes.push_back(n);
+        return (int)nodes.size() - 1;
+    }
+
+    int build_spatial(std::vector<Ref>& r, int depth) {
+        const int count = (int)r.size();
+        Box nb; nb.reset(); Box cb; cb.reset();
+        for (const Ref& x : r) { nb.grow(x.b); cb.grow(x.c); }
+        if (count == 1) return make_leaf(r, nb);
+        const bool small = count <= kLeafSize;
+        int need = 0; { int c = (count + kLeafSize - 1) / kLeafSize; while ((1 << need) < c) need++; }
+        const bool force_median = depth + need + 1 >= kMaxDepth;
+        // object split (as build())
+        int o_axis = -1, o_bin = -1; float o_cost = 3.0e38f; float o_overlap = 0.0f;
+        if (!force_median) {
+            for (int a = 0; a < 3; a++) {
+                float ext = cb.hi[a] - cb.lo[a];
+                if (!(ext > 0.0f)) continue;
+                Box bb[kBins]; int bc[kBins];
+                for (int k = 0; k < kBins; k++) { bb[k].reset(); bc[k] = 0; }
+                float scale = (float)kBins / ext;
+                for (const Ref& x : r) {
+                    int k = (int)((x.c[a] - cb.lo[a]) * scale);
+                    k = k < 0 ? 0 : (k >= kBins ? kBins - 1 : k);
+                    bb[k].grow(x.b); bc[k]++;
+                }
+                Box lb[kBins]; int lc[kBins];
+                Box acc; acc.reset(); int cnt = 0;
+                for (int k = 0; k < kBins - 1; k++) { acc.grow(bb[k]); cnt += bc[k]; lb[k] = acc; lc[k] = cnt; }
+                acc.reset(); cnt = 0;
+                for (int k = kBins - 1; k > 0; k--) {
+                    acc.grow(bb[k]); cnt += bc[k];
+                    if (lc[k - 1] == 0 || cnt == 0) continue;
+                    float cost = lb[k - 1].half_area() * (float)lc[k - 1] + acc.half_area() * (float)cnt;
+                    if (cost < o_cost) {
+                        o_cost = cost; o_axis = a; o_bin = k;
+                        Box in; for (int q = 0; q < 3; q++) { in.lo[q] = std::max(lb[k - 1].lo[q], acc.lo[q]); in.hi[q] = std::min(lb[k - 1].hi[q], acc.hi[q]); }
+                        o_overlap = in.half_area();
+                    }
+                }
+            }
+        }
+        // spatial split: only where the object split leaves the children overlapping noticeably, and while references may still multiply
+        int s_axis = -1; float s_cost = 3.0e38f; double s_plane = 0.0;
+        if (!force_median && o_axis >= 0 && o_overlap > 1.0e-5f * root_area && ref_total + (size_t)count <= ref_budget) {
+            for (int a = 0; a < 3; a++) {
+                const double lo = nb.lo[a], ext = (double)nb.hi[a] - lo;
+                if (!(ext > 0.0)) continue;
+                Box bb[kBins]; int enter[kBins], leave[kBins];
+                for (int k = 0; k < kBins; k++) { bb[k].reset(); enter[k] = leave[k] = 0; }
+                const double scale = kBins / ext;
+                for (const Ref& x : r) {
+                    int k0 = (int)(((double)x.b.lo[a] - lo) * scale), k1 = (int)(((double)x.b.hi[a] - lo) * scale);
+                    k0 = k0 < 0 ? 0 : (k0 >= kBins ? kBins - 1 : k0); k1 = k1 < k0 ? k0 : (k1 >= kBins ? kBins - 1 : k1);
+                    enter[k0]++; leave[k1]++;
+                    if (k0 == k1) { bb[k0].grow(x.b); continue; }
+                    for (int k = k0; k <= k1; k++) {
+                        Box part;
+                        if (clip_bounds(x.tri, a, lo + k / scale, lo + (k + 1) / scale, x.b, part)) bb[k].grow(part);
+                    }
+                }
+                float la[kBins]; int lc[kBins];
+                Box acc; acc.reset(); int cnt = 0;
+                for (int k = 0; k < kBins - 1; k++) { acc.grow(bb[k]); cnt += enter[k]; la[k] = acc.half_area(); lc[k] = cnt; }
+                acc.reset(); cnt = 0;
+                for (int k = kBins - 1; k > 0; k--) {
+                    acc.grow(bb[k]); cnt += leave[k];
+                    if (lc[k - 1] == 0 || cnt == 0) continue;
+                    float cost = la[k - 1] * (float)lc[k - 1] + acc.half_area() * (float)cnt;
+                    if (cost < s_cost) { s_cost = cost; s_axis = a; s_plane = lo + k / scale; }
+                }
+            }
+        }
+        const bool use_spatial = s_axis >= 0 && s_cost < o_cost;
+        const float best_cost = use_spatial ? s_cost : o_cost;
+        if (small) {
+            float pa = nb.half_area();
+            if ((o_axis < 0 && !use_spatial) || !(pa > 0.0f) || kNodeCost + best_cost / pa >= (float)count) return make_leaf(r, nb);
+        }
+        std::vector<Ref> L, R;
+        if (use_spatial) {
+            const int a = s_axis;
+            for (const Ref& x : r) {
+                if ((double)x.b.hi[a] <= s_plane) L.push_back(x);
+                else if ((double)x.b.lo[a] >= s_plane) R.push_back(x);
+                else {
+                    Ref l = x, rr = x; bool hl = clip_bounds(x.tri, a, -1.0e300, s_plane, x.b, l.b), hr = clip_bounds(x.tri, a, s_plane, 1.0e300, x.b, rr.b);
+                    if (hl) { for (int k = 0; k < 3; k++) l.c[k] = 0.5f * (l.b.lo[k] + l.b.hi[k]); L.push_back(l); }
+                    if (hr) { for (int k = 0; k < 3; k++) rr.c[k] = 0.5f * (rr.b.lo[k] + rr.b.hi[k]); R.push_back(rr); }
+                    if (!hl && !hr) L.push_back(x);   // cannot happen for a triangle inside its own bounds; keep it somewhere
+                }
+            }
+            if (L.empty() || R.empty() || ((int)L.size() == count && (int)R.size() == count)) { L.clear(); R.clear(); }   // no progress: object split instead
+            else ref_total += L.size() + R.size() - (size_t)count;
+        }
+        if (L.empty() && R.empty()) {
+            if (o_axis >= 0) {
+                const int a = o_axis;
+                const float ext = cb.hi[a] - cb.lo[a], scale = (float)kBins / ext, lo = cb.lo[a];
+                for (const Ref& x : r) {
+                    int k = (int)((x.c[a] - lo) * scale);
+                    k = k < 0 ? 0 : (k >= kBins ? kBins - 1 : k);
+                    (k < o_bin ? L : R).push_back(x);
+                }
+            }
+            if (L.empty() || R.empty()) {   // object median on the widest centroid axis (also the depth-bounding fallback)
+                int a = 0; float e = -1.0f;
+                for (int k = 0; k < 3; k++) { float x = cb.hi[k] - cb.lo[k]; if (x > e) { e = x; a = k; } }
+                std::vector<Ref> all = r;
+                std::stable_sort(all.begin(), all.end(), [a](const Ref& x, const Ref& y) { return x.c[a] < y.c[a] || (x.c[a] == y.c[a] && x.tri < y.tri); });
+                L.assign(all.begin(), all.begin() + count / 2); R.assign(all.begin() + count / 2, all.end());
+            }
+        }
+        std::vector<Ref>().swap(r);   // the parent's list is not needed below
+        TmpNode n; n.b = nb; n.left = n.right = -1; n.first = 0; n.count = 0;
+        const int id = (int)nodes.size();
+        nodes.push_back(n);
+        const int l = build_spatial(L, depth + 1);
+        const int rr = build_spatial(R, depth + 1);
+        nodes[id].left = l; nodes[id].right = rr;
+        return id;
+    }
 };
 
 inline int32_t leaf_code(int first, int count) { return ~(int32_t)(((uint32_t)first << 3) | (uint32_t)(count - 1)); }
 }  // namespace
 
 void build_bvh(const std::vector<BvhTri>& tris_in, std::vector<BvhNode>& nodes_out, std::vector<BvhNodeWide>& wide_out, std::vector<BvhTri>& tris_out, int* depth_out,
-               std::vector<BvhNode8>* nodes8_out) {
+               std::vector<BvhNode8>* nodes8_out, bool spatial_splits) {
     nodes_out.clear(); wide_out.clear(); tris_out.clear();
     Builder b;
     b.refs.resize(tris_in.size());
@@ -144,9 +313,21 @@ void build_bvh(const std::vector<BvhTri>& tris_in, std::vector<BvhNode>& nodes_o
         if (depth_out) *depth_out = 0;
         return;
     }
-    b.build(0, (int)b.refs.size(), 0);
-    tris_out.resize(tris_in.size());
-    for (size_t i = 0; i < b.refs.size(); i++) tris_out[i] = tris_in[b.refs[i].tri];
+    if (spatial_splits) {
+        b.src = &tris_in;
+        Box rb; rb.reset();
+        for (const Ref& x : b.refs) rb.grow(x.b);
+        b.root_area = rb.half_area();
+        b.ref_total = b.refs.size(); b.ref_budget = b.refs.size() + b.refs.size() / 2;   // at most 1.5 references per triangle
+        std::vector<Ref> all; all.swap(b.refs);
+        b.build_spatial(all, 0);
+        tris_out.resize(b.leaf_tris.size());
+        for (size_t i = 0; i < b.leaf_tris.size(); i++) tris_out[i] = tris_in[b.leaf_tris[i]];
+    } else {
+        b.build(0, (int)b.refs.size(), 0);
+        tris_out.resize(tris_in.size());
+        for (size_t i = 0; i < b.refs.size(); i++) tris_out[i] = tris_in[b.refs[i].tri];
+    }
 
     // emit: collapse the binary tree into 4-wide nodes (a node adopts its grandchildren, largest box first),
     // depth-first order; a leaf root gets a wrapper node.

@@ -59,6 +59,7 @@ struct vpt_ctx {
     unsigned char* d_inst_class = nullptr;   // shade class per instance (kernels_path.hip k_classify_instances)
     std::vector<BvhTri> bvh_input;           // the triangles the BVH was built from (trace lab: the eight-wide tree is built from them on first use)
     bool lds_scene = false;
+    bool sbvh = false;
     int trav_blocks = 1024;
 
     vpt_params params{};
@@ -737,7 +738,8 @@ int vpt_set_scene(vpt_ctx* c, const vpt_scene_desc* sd) {
         }
     }
     std::vector<BvhNode> nodes; std::vector<BvhNodeWide> wide; std::vector<BvhTri> leaf_tris; int depth = 0;
-    build_bvh(tris, nodes, wide, leaf_tris, &depth);
+    c->sbvh = getenv("VPT_SBVH") != nullptr && atoi(getenv("VPT_SBVH")) != 0;   // experiment switch: spatial splits in the builder
+    build_bvh(tris, nodes, wide, leaf_tris, &depth, nullptr, c->sbvh);
     c->bvh_input = tris; c->dsc.nodes8 = nullptr;
     c->bvh_depth = (uint32_t)depth;
     // ---- textures
@@ -1299,7 +1301,7 @@ int vpt_lab_trace(vpt_ctx* c, uint32_t variant, uint32_t any_hit, const uint32_t
     HIPCHK(c, hipSetDevice(c->cfg.device));
     if (variant == VPT_TRACE_VOTE8 && !c->dsc.nodes8) {   // BVH8 experiment: the same binary tree collapsed eight-wide, over the same leaf-ordered triangles
         std::vector<BvhNode> n4; std::vector<BvhNodeWide> w4; std::vector<BvhTri> lt; std::vector<BvhNode8> n8; int d = 0;
-        build_bvh(c->bvh_input, n4, w4, lt, &d, &n8);
+        build_bvh(c->bvh_input, n4, w4, lt, &d, &n8, c->sbvh);
         if (n8.empty()) return fail(c, VPT_ERR_UNSUPPORTED, "no eight-wide tree for an empty scene");
         int rc8 = upload(c, n8, &c->dsc.nodes8);
         if (rc8) return rc8;
