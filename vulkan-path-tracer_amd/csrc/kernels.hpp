@@ -42,6 +42,7 @@ struct TraceArgs {
     uint32_t* head;         // work cursor for entries beyond the waves' static first 64 (zeroed before the launch)
     float tmin, tmax;
     uint32_t normalize_dir; // RayGen.slang:70 normalises the payload direction before tracing
+    uint32_t store_gid;     // 1: the hit record's fourth word is the GLOBAL triangle id (what the shade stage wants), 0: PrimitiveIndex (lab, vpt_hit)
     uint32_t param;         // variant parameter (vote: idle lanes that trigger a fetch step; 0 = default)
     unsigned char* cls;     // closest-hit only, optional: per queue entry, the shade class of what the ray hit (kShade*; 0xff for a hole)
 };

@@ -103,7 +103,7 @@ __global__ __launch_bounds__(kTraverseBlock, 8) void k_extend(DeviceScene sc, Pa
             V3 d = normalize(xyz(b));  // RayGen.slang:70
             HitRec h;
             bool found = trace_any<LDS_SCENE, COUNT>(sc, lds_nodes, lds_tris, xyz(a), d, 0.01f, 100000.0f, stack, h, st);
-            ps.H[slot] = make_float4(found ? h.t : -1.0f, h.u, h.v, __uint_as_float(h.prim));
+            ps.H[slot] = make_float4(found ? h.t : -1.0f, h.u, h.v, __uint_as_float(h.gid));   // the shade stage addresses the triangle's shading record by global id
             ps.hinst[slot] = h.inst;
         }
     }
@@ -372,14 +372,14 @@ __global__ __launch_bounds__(kTraverseBlock, 3) void k_bounce(DeviceScene sc, Re
                     }
                     if (!VOL || (!aborted && in_.vol_index == -1))
                         hit = trace_any<LDS_SCENE, COUNT>(sc, lds_nodes, lds_tris, in_.porg, normalize(in_.pdir), 0.01f, 100000.0f, stack, hr, st);
-                    in_.h = make_float4(hit ? hr.t : -1.0f, hr.u, hr.v, __uint_as_float(hr.prim));
+                    in_.h = make_float4(hit ? hr.t : -1.0f, hr.u, hr.v, __uint_as_float(hr.gid));
                     in_.inst = hr.inst;
                 }
                 if (regroup) {   // park the hits (the ring holds < 64 entries here, so 128 slots are enough); the misses go on below
                     const unsigned long long mh = __ballot(valid && hit);
                     if (valid && hit) {
                         const uint32_t q = (hit_head + hit_count + lanes_below(mh)) & 127u;
-                        r_idx[wave][q] = idx; r_t[wave][q] = hr.t; r_u[wave][q] = hr.u; r_v[wave][q] = hr.v; r_prim[wave][q] = hr.prim; r_inst[wave][q] = hr.inst;
+                        r_idx[wave][q] = idx; r_t[wave][q] = hr.t; r_u[wave][q] = hr.u; r_v[wave][q] = hr.v; r_prim[wave][q] = hr.gid; r_inst[wave][q] = hr.inst;
                         r_ra[wave][q] = rec_a; r_rb[wave][q] = rec_b; r_rt[wave][q] = rec_t;
                     }
                     hit_count += (uint32_t)__popcll(mh);

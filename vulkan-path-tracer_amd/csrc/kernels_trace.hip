@@ -35,7 +35,7 @@ __device__ inline void load_ray(const TraceArgs& a, uint32_t i, uint32_t& rid, V
 // hit record of a finished closest-hit search: prim / inst come from the winning triangle's record; returns the instance
 __device__ inline uint32_t store_closest(const TraceArgs& a, const BvhTri* tris, uint32_t rid, bool found, float t, float u, float v, uint32_t slot) {
     uint32_t prim = 0xffffffffu, inst = 0xffffffffu;
-    if (found) { prim = tris[slot].prim; inst = tris[slot].inst; }
+    if (found) { prim = a.store_gid ? tris[slot].gid : tris[slot].prim; inst = tris[slot].inst; }
     a.hit[rid] = make_float4(found ? t : -1.0f, found ? u : 0.0f, found ? v : 0.0f, __uint_as_float(prim));
     a.hinst[rid] = inst;
     return inst;
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(kTraverseBlock, 8) void k_trace_base(DeviceScene sc
             } else {
                 HitRec h;
                 bool found = trace_closest_pass<COUNT, false>(src, o, d, a.tmin, a.tmax, stack, h, st, 0xffffffffu, 0xffffffffu);
-                a.hit[rid] = make_float4(found ? h.t : -1.0f, found ? h.u : 0.0f, found ? h.v : 0.0f, __uint_as_float(h.prim));
+                a.hit[rid] = make_float4(found ? h.t : -1.0f, found ? h.u : 0.0f, found ? h.v : 0.0f, __uint_as_float(a.store_gid ? h.gid : h.prim));
                 a.hinst[rid] = h.inst;
             }
         }

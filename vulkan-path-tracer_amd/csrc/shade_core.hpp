@@ -283,7 +283,7 @@ __device__ __forceinline__ void shade_core(const DeviceScene& sc, const RenderPa
                     for (uint32_t k = 0; k < sc.emissive_count; k++)
                         if (sc.emissive[k].instance == inst_id) {
                             tc = sc.emissive[k].tri_count;
-                            area = sc.emissive_tri[sc.emissive_tri_offset[k] + __float_as_uint(h.w)].area;
+                            area = sc.emissive_tri[sc.emissive_tri_offset[k] + (__float_as_uint(h.w) - in.tri_offset)].area;   // h.w = global id; the table is per mesh triangle
                             break;
                         }
                     float lp = (1.0f / (float)sc.emissive_count) * (1.0f / (float)tc) * (1.0f / area) * (d2 / ct);

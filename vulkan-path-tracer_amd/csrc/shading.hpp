@@ -100,10 +100,11 @@ __device__ inline V3 triangle_ng(const DeviceScene& sc, const InstanceDesc& in, 
     return normalize(rowvec_mat3(ng, in.inv3));
 }
 
-__device__ inline void surface_init(const DeviceScene& sc, SurfaceFrame& s, const InstanceDesc& in, uint32_t prim, float hu,
+__device__ inline void surface_init(const DeviceScene& sc, SurfaceFrame& s, const InstanceDesc& in, uint32_t gid, float hu,
                                     float hv, V3 raydir, uint32_t normal_tex, bool geo_only, const MatResolved& mr) {
     // the triangle's three vertices and its geometric normal from its de-indexed record (k_precompute_tri_shade): one 128-byte line
-    const float4* q = sc.tri_shade + (size_t)(in.tri_offset + prim) * 8;
+    // (the hit record carries the GLOBAL triangle id, so this fetch does not wait for the instance record)
+    const float4* q = sc.tri_shade + (size_t)gid * 8;
     const float4 a0 = q[0], a1 = q[1], b0 = q[2], b1 = q[3], c0 = q[4], c1 = q[5], g6 = q[6];
     s.p1 = v3(a0.x, a0.y, a0.z); s.p2 = v3(b0.x, b0.y, b0.z); s.p3 = v3(c0.x, c0.y, c0.z);
     V3 n1 = v3(a0.w, a1.x, a1.y), n2 = v3(b0.w, b1.x, b1.y), n3 = v3(c0.w, c1.x, c1.y);

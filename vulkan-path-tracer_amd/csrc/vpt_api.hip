@@ -496,7 +496,7 @@ int render_batch(vpt_ctx* c, uint32_t frames, uint32_t dispatch_base) {
                 TraceArgs a{};
                 a.ro = c->ss.RA[parity]; a.rd = c->ss.RB[parity]; a.order = nullptr; a.valid = c->queue[parity]; a.hit = c->ss.SH; a.hinst = c->ss.SHI; a.cls = c->cls_q;
                 a.n = 0; a.n_dev = &c->sctr->queue_len[parity].v; a.head = &c->sctr->extend_head.v;
-                a.tmin = 0.01f; a.tmax = 100000.0f; a.normalize_dir = 1u; a.param = c->vote_param;
+                a.tmin = 0.01f; a.tmax = 100000.0f; a.normalize_dir = 1u; a.store_gid = 1u; a.param = c->vote_param;
                 if (!sorted) a.cls = nullptr;
                 TIMED(c, VPT_K_EXTEND, launch_trace(s, (uint32_t)c->vote_blocks, VPT_TRACE_VOTE, false, count, c->dsc, a, c->ctr));
                 // the shade stage of this bounce overwrites the pending records and shadow-ray streams the join of the previous
