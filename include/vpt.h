@@ -239,7 +239,9 @@ const char* vpt_last_error(const vpt_ctx* ctx);
 
 /* PathTracer::SetScene (PathTracer.cpp:158-676): uploads geometry/materials/textures, derives the
  * emissive-mesh list (449-469) and the env importance/alias tables (1137-1332), builds the BVH
- * (replaces BLASBuilder/TLAS, 488-505), resets accumulation. Arrays are borrowed for the call only. */
+ * (replaces BLASBuilder/TLAS, 488-505), resets accumulation. Arrays are borrowed for the call only.
+ * Experiment switch, read here: environment variable VPT_SBVH=1 builds the tree with spatial splits (bvh_build.hpp; identical
+ * images, pays on scenes of uneven triangle sizes only). */
 int vpt_set_scene(vpt_ctx* ctx, const vpt_scene_desc* scene);
 /* PathTracer::SetMaterial (PathTracer.cpp:712-810): patches one material, rebuilds the emissive list
  * if emission changed, resets accumulation. */
