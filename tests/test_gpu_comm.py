@@ -108,3 +108,24 @@ def test_bench_two_ranks_on_one_device():
     line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["value"] > 0 and line["scaling"] == "weak" and line["config"]["workload"] == "cornell_1080p_d8"
     assert line["roofline"]["frac"] <= 1.0 and line["roofline"]["bound"] in ("valu", "hbm")
+
+
+def test_bench_line_contract_single_gpu():
+    """`python bench.py` at N = 1 (short: 2 steps of 4 frames, CPU sample of ~1 s, no extra workloads): ONE JSON line with the driver's
+    fields, a roofline object whose fraction is a fraction, and the CPU baseline object."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--frames-in-flight", "4", "--no-extra-workloads", "--cpu-seconds", "1"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert line["n_gpus"] == 1 and line["steps"] == 2 and line["warmup"] == 1 and line["higher_is_better"] is True and line["vs_baseline"] is None
+    assert line["unit"] == "Msamples/s" and line["dtype"] == "f32" and line["data"] == "synthetic" and line["config"]["workload"] == "cornell_1080p_d8"
+    assert abs(line["value"] - 2 * 4 * 1920 * 1080 / (2 * line["ms_per_step"] * 1e-3) / 1e6) < 0.01 * line["value"]   # value = samples / timed seconds
+    r = line["roofline"]
+    assert r["bound"] in ("valu", "hbm") and r["unit"] == "GB/s" and r["peak"] == 8000.0 and 0 < r["frac"] <= 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
+    assert r["kernel"] in r["kernels"] and r["traversal"]["nodes_per_closest_ray"] > 0
+    c = line["cpu_baseline"]
+    assert c["kind"] == "port" and c["unit"] == "Msamples/s" and c["value"] > 0 and c["cores"] >= 1 and "frames" in c["sample"]
