@@ -19,7 +19,14 @@
 // against the only reference-produced numbers in the tree: Assets/LookupTables/*.bin (generated
 // by the reference's own Material/Sampler code; tests/test_oracle_kat.py reproduces table cells
 // by Monte Carlo through THIS file's BSDF functions), the PCG known answers derived from
-// Sampler.slang:4-9, and furnace-mode energy conservation.  BVH traversal, scene import and the
+// Sampler.slang:4-9, and furnace-mode energy conservation.  Beyond reference-produced numbers, the
+// algorithmic content is held against INDEPENDENT float64 restatements written from the Slang
+// sources, not from this file: the refraction tables' cells (tests/test_oracle_lut_fp64.py),
+// EvaluateBSDF and the VNDF / SampleBSDF draws (tests/test_oracle_bsdf_fp64.py), the bloom chain and
+// tonemap (tests/test_oracle_post.py), and the whole per-sample integrator — RayGen, ClosestHit, Miss,
+// Surface, emissive-triangle NEE, MIS, clamp, roulette (tests/ref_integrator64.py,
+// tests/test_oracle_integrator_fp64.py: per-sample values agree to 2e-4 on every sample compared).
+// Environment-map importance sampling and media are outside that second restatement.  BVH traversal, scene import and the
 // elementary fp32 functions live in the Vulkan driver / VulkanHelper / Slang: parity for those
 // is UNPINNED; they follow include/vpt_fp32.h on both sides.
 //

@@ -1,0 +1,226 @@
+"""A second, independent restatement of the reference's per-sample integrator — float64 Python, written from the Slang sources
+(RayGen.slang:9-160, ClosestHit.slang:20-378, Miss.slang:8-77, Surface.slang:26-147, Sampler.slang:286-422, RTCommon.slang:47-64,
+124-136, Material.slang via tests/test_oracle_bsdf_fp64.py) and NOT from oracle/oracle.cpp.  Scope: scenes whose textures are the
+default 1x1 ones, a black environment, no volumes, no atmosphere, ray-query shadow tests; brute-force intersection.  Used by
+tests/test_oracle_integrator_fp64.py to hold the oracle's per-sample values (orc_pixel_samples) against it.
+
+Test infrastructure only."""
+import numpy as np
+
+from test_oracle_bsdf_fp64 import Mat64, Rng64, _pcg, _norm, sample64
+
+MAX_DEPTH = 1000000   # Defines.slang:17
+
+
+def power_heuristics(a, b):   # RTCommon.slang:124-127
+    with np.errstate(all="ignore"):
+        return np.float64(a) ** 2 / (np.float64(a) ** 2 + np.float64(b) ** 2)
+
+
+class Scene64:
+    def __init__(self, sc, width, height):
+        self.W, self.H = width, height
+        self.view_inv = np.asarray(sc.view_inverse, np.float64)
+        self.proj_inv = np.asarray(sc.projection_inverse(width / height), np.float64)
+        self.materials = sc.materials
+        self.inst = []           # (mesh, material, M 4x4, inverse 3x3)
+        v0, e1, e2, ids = [], [], [], []
+        for ii, (mesh, mat, xf) in enumerate(sc.instances):
+            M = np.asarray(xf, np.float64)
+            self.inst.append((mesh, mat, M, np.linalg.inv(M[:3, :3])))
+            vert, idx = sc.meshes[mesh]
+            P = vert["position"].astype(np.float64) @ M[:3, :3].T + M[:3, 3]
+            t = idx.reshape(-1, 3)
+            for k, (a, b, c) in enumerate(t):
+                v0.append(P[a]); e1.append(P[b] - P[a]); e2.append(P[c] - P[a]); ids.append((ii, k))
+        self.meshes = sc.meshes
+        self.v0, self.e1, self.e2 = np.array(v0), np.array(e1), np.array(e2)
+        self.ids = ids
+        # emissive-mesh list: instances whose material emits, in instance order (PathTracer.cpp:449-469)
+        self.emissive = [i for i, (me, ma, _, _) in enumerate(self.inst) if any(c != 0 for c in sc.materials[ma]["emissive_color"])]
+        assert float(np.abs(np.asarray(sc.env)).max()) == 0.0, "black environment only"
+        for m in sc.materials:
+            assert (m["base_color_texture"], m["normal_texture"], m["roughness_texture"], m["metallic_texture"], m["emissive_texture"]) == (0, 1, 2, 3, 4), "default textures only"
+
+    def closest(self, o, d, tmin, tmax):
+        """Two-sided Moller-Trumbore over every triangle; ties in t -> smaller global id.  -> (t, u, v, gid) or None."""
+        p = np.cross(d, self.e2)
+        det = (self.e1 * p).sum(1)
+        with np.errstate(all="ignore"):
+            inv = 1.0 / det
+            s = o - self.v0
+            u = (s * p).sum(1) * inv
+            q = np.cross(s, self.e1)
+            v = (q * d).sum(1) * inv
+            t = (self.e2 * q).sum(1) * inv
+        ok = (det != 0) & (u >= 0) & (u <= 1) & (v >= 0) & (u + v <= 1) & (t > tmin) & (t < tmax)
+        if not ok.any():
+            return None
+        tt = np.where(ok, t, np.inf)
+        g = int(np.argmin(tt))   # argmin returns the first minimum = the smaller id on exact ties
+        return float(t[g]), float(u[g]), float(v[g]), g
+
+
+def sample_value(S, luts, x, y, frame, P):
+    """accumulatedLight of one sample (SampleCount == 1) of pixel (x, y) in dispatch `frame`."""
+    rng = Rng64((y + S.W * x + _pcg((P.base_seed + frame) & 0xffffffff)) & 0xffffffff)
+    j0 = rng.uf() * 1.0 - 0.5; j1 = rng.uf() * 1.0 - 0.5
+    d2 = np.array([(x + 0.5 + j0) / S.W, (y + 0.5 + j1) / S.H]) * 2.0 - 1.0
+    origin = (S.view_inv @ np.array([0.0, 0.0, 0.0, 1.0]))[:3]
+    target = (S.proj_inv @ np.array([d2[0], d2[1], 1.0, 1.0]))[:3]
+    direction = (S.view_inv @ np.append(_norm(target), 0.0))[:3]
+    focus = origin + direction * max(P.focus_distance, 0.001)
+    u1, u2 = rng.uf(), rng.uf()                       # RandomCircleVec: drawn whatever the strength is
+    off = np.array([np.sqrt(u2) * np.cos(2 * np.pi * u1), np.sqrt(u2) * np.sin(2 * np.pi * u1)]) * 0.5 * P.dof_strength
+    origin = origin + off[0] * S.view_inv[:3, 0] + off[1] * S.view_inv[:3, 1]
+    direction = _norm(focus - origin)
+    pay = dict(depth=0, origin=origin, direction=direction, bxdf=np.ones(3), pdf=1.0, emitted=np.zeros(3), in_medium=False,
+               med_density=0.0, med_aniso=0.0, med_color=np.zeros(3))
+    thr, light = np.ones(3), np.zeros(3)
+    while pay["depth"] < P.max_depth:
+        rd = _norm(pay["direction"])
+        pay["emitted"] = np.zeros(3)
+        hit = S.closest(pay["origin"], rd, 0.01, 100000.0)
+        if hit is None:
+            miss(pay, P)
+        else:
+            closest_hit(S, luts, pay, rd, hit, rng, P)
+        contrib = pay["emitted"] * thr
+        if pay["depth"] != 1:
+            lum = float(np.dot(contrib, [0.212671, 0.715160, 0.072169]))
+            contrib = contrib * (P.max_luminance / max(lum, P.max_luminance))
+        light = light + contrib
+        with np.errstate(all="ignore"):
+            thr = thr * (pay["bxdf"] / pay["pdf"])
+        p = min(max(thr[0], max(thr[1], thr[2])), 1.0) if not np.isnan(thr).any() else float("nan")
+        if p < rng.uf():
+            break
+        with np.errstate(all="ignore"):
+            thr = thr / p
+    return light if np.isfinite(light).all() else np.zeros(3)
+
+
+def miss(pay, P):   # Miss.slang, SHOW_ENV_MAP_DIRECTLY, black environment: every lookup returns (0, 0, 0, 0)
+    color_pdf = np.zeros(4)
+    pay["emitted"] = color_pdf[:3] * P.sky_intensity
+    if pay["depth"] > 0:   # ENABLE_SKY_MIS
+        pay["emitted"] = pay["emitted"] * power_heuristics(pay["pdf"], color_pdf[3])
+    pay["depth"] = MAX_DEPTH
+
+
+def closest_hit(S, luts, pay, rd, hit, rng, P):
+    t, hu, hv, gid = hit
+    inst_id, prim = S.ids[gid]
+    mesh, mat_id, M, Minv = S.inst[inst_id]
+    vert, idx = S.meshes[mesh]
+    i1, i2, i3 = (int(k) for k in idx.reshape(-1, 3)[prim])
+    P1, P2, P3 = (vert["position"][k].astype(np.float64) for k in (i1, i2, i3))
+    N1, N2, N3 = (vert["normal"][k].astype(np.float64) for k in (i1, i2, i3))
+    b = np.array([1.0 - hu - hv, hu, hv])
+    # ---- Surface.Initialize
+    pos = M[:3, :3] @ (P1 * b[0] + P2 * b[1] + P3 * b[2]) + M[:3, 3]
+    Ng = _norm(np.cross(P2 - P1, P3 - P1)); Ng = _norm(Ng @ Minv)      # mul(n, WorldToObject): row vector times the inverse
+    N = _norm(N1 * b[0] + N2 * b[1] + N3 * b[2]); N = _norm(N @ Minv)
+    view = -rd
+    inside = bool(np.dot(Ng, view) < 0.0)
+    if inside:
+        N, Ng = -N, -Ng
+    up = np.array([0.0, 0.0, 1.0]) if abs(N[2]) < 0.9999999 else np.array([1.0, 0.0, 0.0])
+    T = _norm(np.cross(up, N)); B = _norm(np.cross(N, T))
+    nm = np.array([128.0 / 255.0 * 2.0 - 1.0, 128.0 / 255.0 * 2.0 - 1.0, 255.0 / 255.0 * 2.0 - 1.0])   # the default normal map's texel
+    N = _norm(nm[0] * T + nm[1] * B + nm[2] * N)                          # TangentToWorld
+    if np.dot(N, view) < 0.0:
+        N = _norm(N - view * (np.dot(N, view) - 0.01))
+    refl = _norm(-view - 2.0 * np.dot(N, -view) * N)
+    if np.dot(refl, Ng) < 0.0:
+        N = _norm(N + Ng * (0.1 + np.dot(N, Ng)))
+    T = _norm(np.cross(N, up)); B = _norm(np.cross(N, T))
+    # ---- Material.Initialize (all textures 1x1 white) + RotateTangents
+    md = S.materials[mat_id]
+    m = Mat64(md, luts, inside=inside, ec=True)
+    emissive = np.array(md["emissive_color"], np.float64)
+    is_light = bool((emissive > 0).any())
+    rot = md["anisotropy_rotation"] * (np.pi / 180.0)
+    T = T * np.cos(rot) + np.cross(N, T) * np.sin(rot) + N * np.dot(N, T) * (1.0 - np.cos(rot))
+    B = np.cross(T, N)
+    w2t = lambda v: _norm(np.array([np.dot(v, T), np.dot(v, B), np.dot(v, N)]))
+    t2w = lambda v: _norm(v[0] * T + v[1] * B + v[2] * N)
+    # ---- medium walk (ClosestHit.slang:80-116)
+    if pay["in_medium"]:
+        dist = float(np.linalg.norm(pay["origin"] - pos))
+        if pay["med_aniso"] == 1.0:
+            pay["bxdf"] = np.exp(-(1.0 - np.array(md["medium_color"], np.float64)) * md["medium_density"] * dist)
+        else:
+            with np.errstate(all="ignore"):
+                sd = -np.log(rng.uf()) / pay["med_density"]
+            if sd < dist:
+                raise NotImplementedError("in-medium scattering event: outside this restatement's scope")
+    # ---- sky NEE: three draws; the black environment returns 0 with pdf 0, so nothing else of it matters
+    rng.uf(); rng.uf(); rng.uf()
+    # ---- light NEE (Sampler.slang:348-422)
+    can_light = False; light_rgb = np.zeros(3); light_pdf = 0.0; to_light_t = None
+    if not is_light and S.emissive:
+        ne = len(S.emissive)
+        mi = min(int(np.floor(rng.uf() * ne)), ne - 1)
+        e_inst = S.emissive[mi]
+        e_mesh, e_mat, eM, _ = S.inst[e_inst]
+        ev, eidx = S.meshes[e_mesh]
+        ntri = len(eidx) // 3
+        ti = min(int(np.floor(rng.uf() * ntri)), ntri - 1)
+        a0, a1, a2 = (eM[:3, :3] @ ev["position"][int(k)].astype(np.float64) + eM[:3, 3] for k in eidx.reshape(-1, 3)[ti])
+        x0, x1 = rng.uf(), rng.uf()
+        su1 = np.sqrt(x0); b0 = 1.0 - su1; b1 = x1 * su1; b2 = 1.0 - b0 - b1
+        tp = b0 * a0 + b1 * a1 + b2 * a2
+        to_light = _norm(tp - pos)
+        ln = _norm(np.cross(a2 - a0, a1 - a0))
+        area = float(np.linalg.norm(np.cross(a1 - a0, a2 - a0))) * 0.5
+        d2 = float(np.dot(tp - pos, tp - pos)); ct = abs(float(np.dot(ln, to_light)))
+        with np.errstate(all="ignore"):
+            light_pdf = d2 / (float(ne) * float(ntri) * area * ct)
+        light_rgb = np.array(S.materials[e_mat]["emissive_color"], np.float64)
+        if light_pdf > 0.0:
+            to_light_t = w2t(to_light)
+            h2 = S.closest(pos + to_light * 1e-2, to_light, 0.0001, 1000000.0)   # RTCommon.slang:54-60 (ray queries)
+            can_light = h2 is not None and S.ids[h2[3]] == (e_inst, ti)
+            if not can_light:
+                light_rgb = np.zeros(3); light_pdf = 0.0
+    # ---- BSDF sampling
+    V = w2t(_norm(-rd))
+    L = sample64(m, V, rng)
+    if L is None:
+        sL, s_f, s_pdf = np.zeros(3), np.zeros(3), 0.0
+    else:
+        f, p = m.evaluate(V, L[None, :]); sL, s_f, s_pdf = L, f[0], float(p[0])
+    refracted = bool(sL[2] < 0.0)
+    with np.errstate(all="ignore"):
+        scatter_w = t2w(sL)
+    if not refracted and np.dot(scatter_w, Ng) < 0.0:
+        s_pdf = 0.0; s_f = np.zeros(3)
+    if refracted and inside:
+        pay["in_medium"] = False
+    elif refracted and not inside:
+        pay["in_medium"] = True
+        pay["med_color"] = np.array(md["medium_color"], np.float64); pay["med_aniso"] = md["medium_anisotropy"]; pay["med_density"] = md["medium_density"]
+    l_f, l_pdf = np.zeros(3), 0.0
+    if can_light and not is_light:
+        f, p = m.evaluate(V, to_light_t[None, :]); l_f, l_pdf = f[0], float(p[0])
+    # ---- payload
+    if pay["depth"] == 0 and is_light:
+        pay["emitted"] = pay["emitted"] + emissive
+    elif is_light:
+        w1, w2_, w3 = (M[:3, :3] @ q + M[:3, 3] for q in (P1, P2, P3))
+        area = float(np.linalg.norm(np.cross(w2_ - w1, w3 - w1))) * 0.5
+        d2 = float(np.dot(pos - pay["origin"], pos - pay["origin"]))
+        ct = abs(float(np.dot(N, _norm(pay["origin"] - pos))))
+        ntri = len(idx) // 3
+        with np.errstate(all="ignore"):
+            lp = (1.0 / len(S.emissive)) * (1.0 / ntri) * (1.0 / area) * (d2 / ct)
+        lp = max(lp, P.emissive_pdf_bias)
+        pay["emitted"] = pay["emitted"] + emissive * power_heuristics(pay["pdf"], lp)
+    pay["origin"] = pos + N * (-1e-3 if refracted else 1e-3)
+    pay["direction"] = scatter_w
+    pay["bxdf"] = s_f; pay["pdf"] = s_pdf
+    if not is_light and can_light and light_pdf > 0.0 and l_pdf > 0.0:
+        pay["emitted"] = pay["emitted"] + (l_f * light_rgb / light_pdf) * power_heuristics(light_pdf, l_pdf)
+    invalid = s_pdf <= 0.0
+    pay["depth"] = MAX_DEPTH + pay["depth"] if invalid else pay["depth"] + 1
