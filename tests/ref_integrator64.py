@@ -1,7 +1,7 @@
 """A second, independent restatement of the reference's per-sample integrator — float64 Python, written from the Slang sources
 (RayGen.slang:9-160, ClosestHit.slang:20-378, Miss.slang:8-77, Surface.slang:26-147, Sampler.slang:286-422, RTCommon.slang:47-64,
-124-136, Material.slang via tests/test_oracle_bsdf_fp64.py) and NOT from oracle/oracle.cpp.  Scope: scenes whose textures are the
-default 1x1 ones, a black environment, no volumes, no atmosphere, ray-query shadow tests; brute-force intersection.  Used by
+124-136, Material.slang via tests/test_oracle_bsdf_fp64.py) and NOT from oracle/oracle.cpp.  PathTracer.cpp:1161-1296 for the environment tables).  Scope: scenes whose textures are the default 1x1 ones, any environment map, no
+volumes, no atmosphere, ray-query shadow tests; brute-force intersection.  Used by
 tests/test_oracle_integrator_fp64.py to hold the oracle's per-sample values (orc_pixel_samples) against it.
 
 Test infrastructure only."""
@@ -38,9 +38,66 @@ class Scene64:
         self.ids = ids
         # emissive-mesh list: instances whose material emits, in instance order (PathTracer.cpp:449-469)
         self.emissive = [i for i, (me, ma, _, _) in enumerate(self.inst) if any(c != 0 for c in sc.materials[ma]["emissive_color"])]
-        assert float(np.abs(np.asarray(sc.env)).max()) == 0.0, "black environment only"
+        self.build_env(np.asarray(sc.env, np.float32))
         for m in sc.materials:
             assert (m["base_color_texture"], m["normal_texture"], m["roughness_texture"], m["metallic_texture"], m["emissive_texture"]) == (0, 1, 2, 3, 4), "default textures only"
+
+    def build_env(self, env):
+        """LoadEnvironmentMap (PathTracer.cpp:1161-1296): importance = solid angle x max(r, g, b), the alias map with its partition
+        quirk (the low-energy list is filled from index 1), the pdf in alpha.  Sequential float32 arithmetic, as the C++ does it."""
+        f = np.float32
+        h, w = env.shape[:2]
+        px = env.reshape(-1, 4).copy()
+        size = w * h
+        imp = np.zeros(size, f)
+        cos0 = f(1.0)
+        step_phi = f(2.0) * f(np.pi) / f(w); step_theta = f(np.pi) / f(h)
+        mx = np.maximum(px[:, 0], np.maximum(px[:, 1], px[:, 2]))
+        for y in range(h):
+            cos1 = f(np.cos(f(y + 1) * step_theta))
+            area = f(f(cos0 - cos1) * step_phi)
+            cos0 = cos1
+            imp[y * w:(y + 1) * w] = area * mx[y * w:(y + 1) * w]
+        total = f(0.0)
+        for v in imp:
+            total = f(total + v)                       # std::accumulate, in order
+        avg = f(total / f(size))
+        importance = np.zeros(size, f) if avg == 0 else (imp / avg).astype(f)
+        alias = np.arange(size, dtype=np.int64)
+        part = np.zeros(size + 1, np.int64)
+        lo, hi = 0, size
+        for i in range(size):
+            if importance[i] < f(1.0):
+                lo += 1
+                if lo < size:
+                    part[lo] = i
+            else:
+                hi -= 1; part[hi] = i
+        lo = 0
+        while lo < hi and hi < size:
+            li, hh = part[lo], part[hi]
+            alias[li] = hh
+            importance[hh] = f(importance[hh] - f(f(1.0) - importance[li]))
+            if importance[hh] < f(1.0):
+                hi += 1
+            lo += 1
+        px[:, 3] = 0.0 if total == 0 else (mx / total).astype(f)
+        self.env_w, self.env_h = w, h
+        self.env_px = px.reshape(h, w, 4).astype(np.float64)
+        self.alias, self.importance = alias, importance.astype(np.float64)
+        self.env_black = bool(np.abs(px).max() == 0.0)
+
+    def env_lookup(self, u, v):
+        """uEnvMapTexture.SampleLevel: bilinear, REPEAT, texel centres at +0.5."""
+        def axis(c, n):
+            x = c * n - 0.5
+            fl = np.floor(x)
+            return int(fl) % n, (int(fl) + 1) % n, x - fl
+        x0, x1, fx = axis(u, self.env_w); y0, y1, fy = axis(v, self.env_h)
+        e = self.env_px
+        a = e[y0, x0] + (e[y0, x1] - e[y0, x0]) * fx
+        b = e[y1, x0] + (e[y1, x1] - e[y1, x0]) * fx
+        return a + (b - a) * fy
 
     def closest(self, o, d, tmin, tmax):
         """Two-sided Moller-Trumbore over every triangle; ties in t -> smaller global id.  -> (t, u, v, gid) or None."""
@@ -82,7 +139,7 @@ def sample_value(S, luts, x, y, frame, P):
         pay["emitted"] = np.zeros(3)
         hit = S.closest(pay["origin"], rd, 0.01, 100000.0)
         if hit is None:
-            miss(pay, P)
+            miss(S, pay, P)
         else:
             closest_hit(S, luts, pay, rd, hit, rng, P)
         contrib = pay["emitted"] * thr
@@ -100,8 +157,42 @@ def sample_value(S, luts, x, y, frame, P):
     return light if np.isfinite(light).all() else np.zeros(3)
 
 
-def miss(pay, P):   # Miss.slang, SHOW_ENV_MAP_DIRECTLY, black environment: every lookup returns (0, 0, 0, 0)
-    color_pdf = np.zeros(4)
+def rotate(v, axis, theta):   # RTCommon.slang:37-45
+    a = _norm(axis)
+    return v * np.cos(theta) + np.cross(a, v) * np.sin(theta) + a * np.dot(a, v) * (1.0 - np.cos(theta))
+
+
+def sample_env(S, rng, P):
+    """ImportanceSampleEnvMap (Sampler.slang:286-346): three draws -> (direction, rgb * intensity | pdf)."""
+    x0, x1, x2 = rng.uf(), rng.uf(), rng.uf()
+    w, h = S.env_w, S.env_h
+    size = w * h
+    idx = min(int(np.float32(x0) * np.float32(size)), size - 1)   # uint(xi.x * float(size)): a float32 product
+    if x1 < S.importance[idx]:
+        ei = idx; x1 = x1 / S.importance[idx]
+    else:
+        ei = int(S.alias[idx]); x1 = (x1 - S.importance[idx]) / (1.0 - S.importance[idx])
+    px_, py_ = ei % w, ei // w
+    u = (px_ + x1) / w
+    phi = u * (2.0 * np.pi) - np.pi
+    step = np.pi / h
+    th0 = py_ * step
+    ct = np.cos(th0) * (1.0 - x2) + np.cos(th0 + step) * x2
+    th = np.arccos(np.clip(ct, -1.0, 1.0))
+    st = np.sin(th)
+    v = th / np.pi
+    d = np.array([np.sin(phi) * st, -ct, -np.cos(phi) * st])
+    d = rotate(d, np.array([0.0, 1.0, 0.0]), P.sky_azimuth / 180.0 * np.pi)
+    d = rotate(d, np.array([1.0, 0.0, 0.0]), P.sky_altitude / 180.0 * np.pi)
+    val = S.env_lookup(u, v)
+    return d, np.append(val[:3] * P.sky_intensity, val[3])
+
+
+def miss(S, pay, P):   # Miss.slang with SHOW_ENV_MAP_DIRECTLY
+    d = rotate(pay["direction"], np.array([1.0, 0.0, 0.0]), -(P.sky_altitude / 180.0 * np.pi))
+    d = rotate(d, np.array([0.0, 1.0, 0.0]), -(P.sky_azimuth / 180.0 * np.pi))
+    gamma = np.arcsin(np.clip(d[1], -1.0, 1.0)); theta = np.arctan2(d[0], -d[2])      # DirectionToUV (RTCommon.slang:129-136)
+    color_pdf = S.env_lookup(theta / np.pi * 0.5 + 0.5, gamma / np.pi + 0.5)
     pay["emitted"] = color_pdf[:3] * P.sky_intensity
     if pay["depth"] > 0:   # ENABLE_SKY_MIS
         pay["emitted"] = pay["emitted"] * power_heuristics(pay["pdf"], color_pdf[3])
@@ -155,8 +246,13 @@ def closest_hit(S, luts, pay, rd, hit, rng, P):
                 sd = -np.log(rng.uf()) / pay["med_density"]
             if sd < dist:
                 raise NotImplementedError("in-medium scattering event: outside this restatement's scope")
-    # ---- sky NEE: three draws; the black environment returns 0 with pdf 0, so nothing else of it matters
-    rng.uf(); rng.uf(); rng.uf()
+    # ---- sky NEE (ClosestHit.slang:118-147): sample, then the visibility test from pos + N * 1e-5
+    to_sky, sky = sample_env(S, rng, P)
+    sky[:3] = sky[:3] * P.sky_intensity            # the intensity is applied a second time here (:131), as upstream does
+    to_sky_t = w2t(to_sky) if np.isfinite(to_sky).all() and np.abs(to_sky).max() > 0 else np.zeros(3)
+    can_sky = S.closest(pos + N * 1e-5, to_sky, 0.0001, 1000000.0) is None
+    if not can_sky:
+        sky = np.zeros(4)
     # ---- light NEE (Sampler.slang:348-422)
     can_light = False; light_rgb = np.zeros(3); light_pdf = 0.0; to_light_t = None
     if not is_light and S.emissive:
@@ -201,6 +297,9 @@ def closest_hit(S, luts, pay, rd, hit, rng, P):
     elif refracted and not inside:
         pay["in_medium"] = True
         pay["med_color"] = np.array(md["medium_color"], np.float64); pay["med_aniso"] = md["medium_anisotropy"]; pay["med_density"] = md["medium_density"]
+    k_f, k_pdf = np.zeros(3), 0.0
+    if can_sky:
+        f, p = m.evaluate(V, to_sky_t[None, :]); k_f, k_pdf = f[0], float(p[0])
     l_f, l_pdf = np.zeros(3), 0.0
     if can_light and not is_light:
         f, p = m.evaluate(V, to_light_t[None, :]); l_f, l_pdf = f[0], float(p[0])
@@ -220,6 +319,8 @@ def closest_hit(S, luts, pay, rd, hit, rng, P):
     pay["origin"] = pos + N * (-1e-3 if refracted else 1e-3)
     pay["direction"] = scatter_w
     pay["bxdf"] = s_f; pay["pdf"] = s_pdf
+    if can_sky and sky[3] > 0.0 and k_pdf > 0.0:
+        pay["emitted"] = pay["emitted"] + (k_f * sky[:3] / sky[3]) * power_heuristics(sky[3], k_pdf)
     if not is_light and can_light and light_pdf > 0.0 and l_pdf > 0.0:
         pay["emitted"] = pay["emitted"] + (l_f * light_rgb / light_pdf) * power_heuristics(light_pdf, l_pdf)
     invalid = s_pdf <= 0.0
