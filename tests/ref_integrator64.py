@@ -1,7 +1,7 @@
 """A second, independent restatement of the reference's per-sample integrator — float64 Python, written from the Slang sources
 (RayGen.slang:9-160, ClosestHit.slang:20-378, Miss.slang:8-77, Surface.slang:26-147, Sampler.slang:286-422, RTCommon.slang:47-64,
-124-136, Material.slang via tests/test_oracle_bsdf_fp64.py) and NOT from oracle/oracle.cpp.  PathTracer.cpp:1161-1296 for the environment tables).  Scope: scenes whose textures are the default 1x1 ones, any environment map, no
-volumes, no atmosphere, ray-query shadow tests; brute-force intersection.  Used by
+124-136, Material.slang via tests/test_oracle_bsdf_fp64.py) and NOT from oracle/oracle.cpp.  PathTracer.cpp:1161-1296 for the environment tables).  Scope: any textures (LINEAR / REPEAT, mip 0) and environment map, no volumes, no atmosphere, no
+in-medium scattering events, ray-query shadow tests; brute-force intersection.  Used by
 tests/test_oracle_integrator_fp64.py to hold the oracle's per-sample values (orc_pixel_samples) against it.
 
 Test infrastructure only."""
@@ -39,8 +39,23 @@ class Scene64:
         # emissive-mesh list: instances whose material emits, in instance order (PathTracer.cpp:449-469)
         self.emissive = [i for i, (me, ma, _, _) in enumerate(self.inst) if any(c != 0 for c in sc.materials[ma]["emissive_color"])]
         self.build_env(np.asarray(sc.env, np.float32))
-        for m in sc.materials:
-            assert (m["base_color_texture"], m["normal_texture"], m["roughness_texture"], m["metallic_texture"], m["emissive_texture"]) == (0, 1, 2, 3, 4), "default textures only"
+        self.textures = [np.asarray(t) for t in sc.textures]
+
+    def tex(self, ti, uv):
+        """uTextures[ti].SampleLevel(uTextureSampler, uv, 0): UNORM8, bilinear, REPEAT (PathTracer.cpp:84-91) -> rgba."""
+        t = self.textures[ti]
+        h, w, c = t.shape
+        def axis(x, n):
+            x = x * n - 0.5
+            fl = np.floor(x)
+            return int(fl) % n, (int(fl) + 1) % n, x - fl
+        x0, x1, fx = axis(uv[0], w); y0, y1, fy = axis(uv[1], h)
+        def texel(y, x):
+            p = t[y, x].astype(np.float64) / 255.0
+            return p if c == 4 else np.array([p[0], 0.0, 0.0, 1.0])
+        a = texel(y0, x0) + (texel(y0, x1) - texel(y0, x0)) * fx
+        b = texel(y1, x0) + (texel(y1, x1) - texel(y1, x0)) * fx
+        return a + (b - a) * fy
 
     def build_env(self, env):
         """LoadEnvironmentMap (PathTracer.cpp:1161-1296): importance = solid angle x max(r, g, b), the alias map with its partition
@@ -208,6 +223,7 @@ def closest_hit(S, luts, pay, rd, hit, rng, P):
     P1, P2, P3 = (vert["position"][k].astype(np.float64) for k in (i1, i2, i3))
     N1, N2, N3 = (vert["normal"][k].astype(np.float64) for k in (i1, i2, i3))
     b = np.array([1.0 - hu - hv, hu, hv])
+    uv = sum(vert["texcoord"][k].astype(np.float64) * w_ for k, w_ in zip((i1, i2, i3), b))
     # ---- Surface.Initialize
     pos = M[:3, :3] @ (P1 * b[0] + P2 * b[1] + P3 * b[2]) + M[:3, 3]
     Ng = _norm(np.cross(P2 - P1, P3 - P1)); Ng = _norm(Ng @ Minv)      # mul(n, WorldToObject): row vector times the inverse
@@ -218,7 +234,8 @@ def closest_hit(S, luts, pay, rd, hit, rng, P):
         N, Ng = -N, -Ng
     up = np.array([0.0, 0.0, 1.0]) if abs(N[2]) < 0.9999999 else np.array([1.0, 0.0, 0.0])
     T = _norm(np.cross(up, N)); B = _norm(np.cross(N, T))
-    nm = np.array([128.0 / 255.0 * 2.0 - 1.0, 128.0 / 255.0 * 2.0 - 1.0, 255.0 / 255.0 * 2.0 - 1.0])   # the default normal map's texel
+    md = S.materials[mat_id]
+    nm = S.tex(md["normal_texture"], uv)[:3] * 2.0 - 1.0                  # (the default normal map's texel is (128, 128, 255) / 255)
     N = _norm(nm[0] * T + nm[1] * B + nm[2] * N)                          # TangentToWorld
     if np.dot(N, view) < 0.0:
         N = _norm(N - view * (np.dot(N, view) - 0.01))
@@ -226,10 +243,13 @@ def closest_hit(S, luts, pay, rd, hit, rng, P):
     if np.dot(refl, Ng) < 0.0:
         N = _norm(N + Ng * (0.1 + np.dot(N, Ng)))
     T = _norm(np.cross(N, up)); B = _norm(np.cross(N, T))
-    # ---- Material.Initialize (all textures 1x1 white) + RotateTangents
-    md = S.materials[mat_id]
+    # ---- Material.Initialize (Material.slang:39-87) + RotateTangents
+    md = dict(md)
+    md["base_color"] = np.array(md["base_color"], np.float64) * S.tex(md["base_color_texture"], uv)[:3] ** 2.2
+    md["roughness"] = md["roughness"] * S.tex(md["roughness_texture"], uv)[0]
+    md["metallic"] = md["metallic"] * S.tex(md["metallic_texture"], uv)[0]
+    emissive = np.array(md["emissive_color"], np.float64) * S.tex(md["emissive_texture"], uv)[:3]
     m = Mat64(md, luts, inside=inside, ec=True)
-    emissive = np.array(md["emissive_color"], np.float64)
     is_light = bool((emissive > 0).any())
     rot = md["anisotropy_rotation"] * (np.pi / 180.0)
     T = T * np.cos(rot) + np.cross(N, T) * np.sin(rot) + N * np.dot(N, T) * (1.0 - np.cos(rot))
@@ -273,7 +293,8 @@ def closest_hit(S, luts, pay, rd, hit, rng, P):
         d2 = float(np.dot(tp - pos, tp - pos)); ct = abs(float(np.dot(ln, to_light)))
         with np.errstate(all="ignore"):
             light_pdf = d2 / (float(ne) * float(ntri) * area * ct)
-        light_rgb = np.array(S.materials[e_mat]["emissive_color"], np.float64)
+        t0, t1, t2 = (ev["texcoord"][int(k)].astype(np.float64) for k in eidx.reshape(-1, 3)[ti])
+        light_rgb = np.array(S.materials[e_mat]["emissive_color"], np.float64) * S.tex(S.materials[e_mat]["emissive_texture"], b0 * t0 + b1 * t1 + b2 * t2)[:3]
         if light_pdf > 0.0:
             to_light_t = w2t(to_light)
             h2 = S.closest(pos + to_light * 1e-2, to_light, 0.0001, 1000000.0)   # RTCommon.slang:54-60 (ray queries)

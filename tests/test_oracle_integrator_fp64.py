@@ -3,18 +3,19 @@ Surface / Sampler written from the Slang sources: per-sample values of single pi
 Everything the image is built from is in play: seeding and draw order, camera ray, surface frame with the default normal map,
 emissive-triangle NEE with the light-identity shadow test, environment importance sampling through the alias map (built as
 PathTracer.cpp:1161-1296 builds it) with its visibility test, the miss shader's environment lookup, VNDF + lobe sampling, EvaluateBSDF with energy compensation, MIS
-weights of both strategies, the luminance clamp, Russian roulette, refraction and the in-medium flag, the NaN guard.
+weights of both strategies, textures (LINEAR / REPEAT taps, gamma, metallic-roughness maps), the luminance clamp, Russian roulette, refraction and the in-medium flag, the NaN guard.
 
 Tolerance: float32 against float64 through up to 12 bounces: 2e-3 relative per sample (observed <= 2e-4; 1e-3 on one sample under
 the environment's 60:1 hot texel).  A decision that hangs on
 a float32-rounding-sized margin (a lobe pick, a roulette survival, a grazing hit) would change the whole remainder of that sample,
 so a sample may differ outright — at most 1 % of them (observed: none of 900)."""
 import copy
+import os
 import numpy as np
 import pytest
 
 
-def variants(scenes):
+def variants(scenes, vpt_scenes):
     base = scenes("cornell_box")
     metal = copy.deepcopy(base)
     for k, m in enumerate(metal.materials):
@@ -28,23 +29,28 @@ def variants(scenes):
     env[..., :3] = rng.gamma(0.8, 0.4, (8, 16, 3))
     env[2, 5, :3] = (60.0, 50.0, 40.0)
     sky.env = env
+    # textures: the Viking room (a 1024 x 1024 base-colour map) and the textured boxes (base colour + a metallic-roughness map) under the
+    # same environment
+    viking = copy.deepcopy(scenes("viking_room")); viking.env = env
+    boxes = copy.deepcopy(vpt_scenes.load_gltf(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "textured_boxes.gltf"))); boxes.env = env
     return {"cornell_d6": (base, 6, 90, 3), "cornell_d12": (base, 12, 60, 2), "metal_anisotropic": (metal, 6, 60, 2),
-            "glass_sphere": (scenes("cornell_box_glass"), 8, 60, 2), "environment": (sky, 6, 90, 3)}
+            "glass_sphere": (scenes("cornell_box_glass"), 8, 60, 2), "environment": (sky, 6, 90, 3),
+            "textured_viking_room": (viking, 5, 60, 2), "textured_boxes": (boxes, 5, 60, 2)}
 
 
-@pytest.mark.parametrize("which", ["cornell_d6", "cornell_d12", "metal_anisotropic", "glass_sphere", "environment"])
+@pytest.mark.parametrize("which", ["cornell_d6", "cornell_d12", "metal_anisotropic", "glass_sphere", "environment", "textured_viking_room", "textured_boxes"])
 def test_per_sample_values_match_the_float64_integrator(vpt, oracle, scenes, which):
     import ref_integrator64 as R
-    sc, depth, npix, frames = variants(scenes)[which]
+    sc, depth, npix, frames = variants(scenes, vpt.scenes)[which]
     W, H = 64, 36
     P = vpt.default_params(max_depth=depth)
-    if which == "environment":
+    if which in ("environment", "textured_viking_room", "textured_boxes"):
         P = vpt.default_params(max_depth=depth, sky_azimuth=35.0, sky_altitude=-20.0, sky_intensity=1.5)
     luts = vpt.scenes.load_luts()
     S = R.Scene64(sc, W, H)
     o = oracle.Oracle(sc, W, H); o.set_params(P)
     rng = np.random.default_rng(4)
-    lo_x, hi_x = (0, 64) if which == "environment" else (12, 52)                                        # with a sky, also the pixels beside the box
+    lo_x, hi_x = (12, 52) if which in ("cornell_d6", "cornell_d12", "metal_anisotropic", "glass_sphere") else (0, 64)                                        # with a sky, also the pixels beside the box
     xs = rng.integers(lo_x, hi_x, npix).astype(np.uint32); ys = rng.integers(4, 32, npix).astype(np.uint32)   # pixels that look into the box
     got = o.pixel_samples(xs, ys, 0, frames).astype(np.float64)
     o.close()
