@@ -1,7 +1,7 @@
 """A second, independent restatement of the reference's per-sample integrator — float64 Python, written from the Slang sources
 (RayGen.slang:9-160, ClosestHit.slang:20-378, Miss.slang:8-77, Surface.slang:26-147, Sampler.slang:286-422, RTCommon.slang:47-64,
-124-136, Material.slang via tests/test_oracle_bsdf_fp64.py) and NOT from oracle/oracle.cpp.  PathTracer.cpp:1161-1296 for the environment tables).  Scope: any textures (LINEAR / REPEAT, mip 0) and environment map, no volumes, no atmosphere, no
-in-medium scattering events, ray-query shadow tests; brute-force intersection.  Used by
+124-136, Material.slang via tests/test_oracle_bsdf_fp64.py) and NOT from oracle/oracle.cpp.  PathTracer.cpp:1161-1296 for the environment tables).  Scope: any textures (LINEAR / REPEAT, mip 0) and environment map, the medium inside a glass mesh (Beer's law, Henyey-Greenstein walk);
+no box volumes, no atmosphere; ray-query shadow tests; brute-force intersection.  Used by
 tests/test_oracle_integrator_fp64.py to hold the oracle's per-sample values (orc_pixel_samples) against it.
 
 Test infrastructure only."""
@@ -172,6 +172,21 @@ def sample_value(S, luts, x, y, frame, P):
     return light if np.isfinite(light).all() else np.zeros(3)
 
 
+def sample_hg(d, g, rng):   # Sampler.slang:168-192
+    r0, r1 = rng.uf(), rng.uf()
+    if abs(g) < 1e-5:
+        ct = 2.0 * r0 - 1.0
+    else:
+        sq = (1.0 - g * g) / (1.0 - g + 2.0 * g * r0)
+        ct = (1.0 + g * g - sq * sq) / (2.0 * g)
+    phi = 2.0 * np.pi * r1
+    st = np.sqrt(1.0 - ct * ct)
+    nd = np.array([st * np.cos(phi), st * np.sin(phi), ct])
+    up = np.array([0.0, 1.0, 0.0]) if abs(d[1]) < 0.9999999 else np.array([0.0, 0.0, 1.0])
+    t = _norm(np.cross(up, d)); b = np.cross(d, t)
+    return _norm(nd[0] * t + nd[1] * b + nd[2] * d)
+
+
 def rotate(v, axis, theta):   # RTCommon.slang:37-45
     a = _norm(axis)
     return v * np.cos(theta) + np.cross(a, v) * np.sin(theta) + a * np.dot(a, v) * (1.0 - np.cos(theta))
@@ -264,8 +279,11 @@ def closest_hit(S, luts, pay, rd, hit, rng, P):
         else:
             with np.errstate(all="ignore"):
                 sd = -np.log(rng.uf()) / pay["med_density"]
-            if sd < dist:
-                raise NotImplementedError("in-medium scattering event: outside this restatement's scope")
+            if sd < dist:   # still inside the medium: a scattering event, then back to the sample loop (depth, pdf and emission untouched)
+                pay["origin"] = pay["origin"] + sd * pay["direction"]
+                pay["direction"] = sample_hg(pay["direction"], pay["med_aniso"], rng)
+                pay["bxdf"] = np.array(pay["med_color"], np.float64)
+                return
     # ---- sky NEE (ClosestHit.slang:118-147): sample, then the visibility test from pos + N * 1e-5
     to_sky, sky = sample_env(S, rng, P)
     sky[:3] = sky[:3] * P.sky_intensity            # the intensity is applied a second time here (:131), as upstream does

@@ -29,16 +29,21 @@ def variants(scenes, vpt_scenes):
     env[..., :3] = rng.gamma(0.8, 0.4, (8, 16, 3))
     env[2, 5, :3] = (60.0, 50.0, 40.0)
     sky.env = env
+    # the glass sphere filled with a scattering medium (ClosestHit.slang:80-116): Henyey-Greenstein walk inside, stale pdf, no depth increment
+    murky = copy.deepcopy(scenes("cornell_box_glass"))
+    for m in murky.materials:
+        if m["transmission"] > 0:
+            m.update(roughness=0.2, medium_density=0.6, medium_anisotropy=0.4, medium_color=(0.9, 0.6, 0.3))
     # textures: the Viking room (a 1024 x 1024 base-colour map) and the textured boxes (base colour + a metallic-roughness map) under the
     # same environment
     viking = copy.deepcopy(scenes("viking_room")); viking.env = env
     boxes = copy.deepcopy(vpt_scenes.load_gltf(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "textured_boxes.gltf"))); boxes.env = env
     return {"cornell_d6": (base, 6, 90, 3), "cornell_d12": (base, 12, 60, 2), "metal_anisotropic": (metal, 6, 60, 2),
             "glass_sphere": (scenes("cornell_box_glass"), 8, 60, 2), "environment": (sky, 6, 90, 3),
-            "textured_viking_room": (viking, 5, 60, 2), "textured_boxes": (boxes, 5, 60, 2)}
+            "textured_viking_room": (viking, 5, 60, 2), "textured_boxes": (boxes, 5, 60, 2), "medium_in_glass": (murky, 10, 80, 2)}
 
 
-@pytest.mark.parametrize("which", ["cornell_d6", "cornell_d12", "metal_anisotropic", "glass_sphere", "environment", "textured_viking_room", "textured_boxes"])
+@pytest.mark.parametrize("which", ["cornell_d6", "cornell_d12", "metal_anisotropic", "glass_sphere", "environment", "textured_viking_room", "textured_boxes", "medium_in_glass"])
 def test_per_sample_values_match_the_float64_integrator(vpt, oracle, scenes, which):
     import ref_integrator64 as R
     sc, depth, npix, frames = variants(scenes, vpt.scenes)[which]
@@ -50,7 +55,7 @@ def test_per_sample_values_match_the_float64_integrator(vpt, oracle, scenes, whi
     S = R.Scene64(sc, W, H)
     o = oracle.Oracle(sc, W, H); o.set_params(P)
     rng = np.random.default_rng(4)
-    lo_x, hi_x = (12, 52) if which in ("cornell_d6", "cornell_d12", "metal_anisotropic", "glass_sphere") else (0, 64)                                        # with a sky, also the pixels beside the box
+    lo_x, hi_x = (12, 52) if which in ("cornell_d6", "cornell_d12", "metal_anisotropic", "glass_sphere", "medium_in_glass") else (0, 64)                                        # with a sky, also the pixels beside the box
     xs = rng.integers(lo_x, hi_x, npix).astype(np.uint32); ys = rng.integers(4, 32, npix).astype(np.uint32)   # pixels that look into the box
     got = o.pixel_samples(xs, ys, 0, frames).astype(np.float64)
     o.close()
