@@ -1,7 +1,8 @@
 """A second, independent restatement of the reference's per-sample integrator — float64 Python, written from the Slang sources
 (RayGen.slang:9-160, ClosestHit.slang:20-378, Miss.slang:8-77, Surface.slang:26-147, Sampler.slang:286-422, RTCommon.slang:47-64,
-124-136, Material.slang via tests/test_oracle_bsdf_fp64.py) and NOT from oracle/oracle.cpp.  PathTracer.cpp:1161-1296 for the environment tables).  Scope: any textures (LINEAR / REPEAT, mip 0) and environment map, the medium inside a glass mesh (Beer's law, Henyey-Greenstein walk);
-no box volumes, no atmosphere; ray-query shadow tests; brute-force intersection.  Used by
+124-136, Material.slang via tests/test_oracle_bsdf_fp64.py) and NOT from oracle/oracle.cpp.  PathTracer.cpp:1161-1296 for the environment tables).  Scope: any textures (LINEAR / REPEAT, mip 0) and environment map, the medium inside a glass mesh (Beer's law, Henyey-Greenstein walk),
+homogeneous box volumes with the Henyey-Greenstein phase function (RayGen.slang:162-372, Volume.slang:190-223, 256-286, 358-443);
+no density grids, no atmosphere; ray-query shadow tests; brute-force intersection.  Used by
 tests/test_oracle_integrator_fp64.py to hold the oracle's per-sample values (orc_pixel_samples) against it.
 
 Test infrastructure only."""
@@ -40,6 +41,13 @@ class Scene64:
         self.emissive = [i for i, (me, ma, _, _) in enumerate(self.inst) if any(c != 0 for c in sc.materials[ma]["emissive_color"])]
         self.build_env(np.asarray(sc.env, np.float32))
         self.textures = [np.asarray(t) for t in sc.textures]
+        self.volumes = []   # set_volumes(): dicts with corner_min, corner_max, color, emissive_color, density, anisotropy
+
+    def set_volumes(self, vols):
+        self.volumes = [dict(lo=np.array(v.corner_min[:], np.float64), hi=np.array(v.corner_max[:], np.float64), color=np.array(v.color[:], np.float64),
+                             emissive=np.array(v.emissive_color[:], np.float64), density=float(v.density), g=float(v.anisotropy)) for v in vols]
+        for v in vols:
+            assert v.density_data_index < 0 and not v.approximated_scattering, "homogeneous volumes only"
 
     def tex(self, ti, uv):
         """uTextures[ti].SampleLevel(uTextureSampler, uv, 0): UNORM8, bilinear, REPEAT (PathTracer.cpp:84-91) -> rgba."""
@@ -147,16 +155,19 @@ def sample_value(S, luts, x, y, frame, P):
     origin = origin + off[0] * S.view_inv[:3, 0] + off[1] * S.view_inv[:3, 1]
     direction = _norm(focus - origin)
     pay = dict(depth=0, origin=origin, direction=direction, bxdf=np.ones(3), pdf=1.0, emitted=np.zeros(3), in_medium=False,
-               med_density=0.0, med_aniso=0.0, med_color=np.zeros(3))
+               med_density=0.0, med_aniso=0.0, med_color=np.zeros(3), vdepth=0)
     thr, light = np.ones(3), np.zeros(3)
     while pay["depth"] < P.max_depth:
         rd = _norm(pay["direction"])
         pay["emitted"] = np.zeros(3)
-        hit = S.closest(pay["origin"], rd, 0.01, 100000.0)
-        if hit is None:
-            miss(S, pay, P)
+        if S.volumes and scattered_in_volume(S, pay, rng, P):
+            pass
         else:
-            closest_hit(S, luts, pay, rd, hit, rng, P)
+            hit = S.closest(pay["origin"], rd, 0.01, 100000.0)
+            if hit is None:
+                miss(S, pay, P)
+            else:
+                closest_hit(S, luts, pay, rd, hit, rng, P)
         contrib = pay["emitted"] * thr
         if pay["depth"] != 1:
             lum = float(np.dot(contrib, [0.212671, 0.715160, 0.072169]))
@@ -185,6 +196,119 @@ def sample_hg(d, g, rng):   # Sampler.slang:168-192
     up = np.array([0.0, 1.0, 0.0]) if abs(d[1]) < 0.9999999 else np.array([0.0, 0.0, 1.0])
     t = _norm(np.cross(up, d)); b = np.cross(d, t)
     return _norm(nd[0] * t + nd[1] * b + nd[2] * d)
+
+
+def box_hit(o, d, lo, hi):   # Volume.slang:190-213 (as written, quirks included: the x slab appears twice in each max / min)
+    with np.errstate(all="ignore"):
+        inv = 1.0 / d
+        t0, t1 = (lo - o) * inv, (hi - o) * inv
+    sm, bg = np.minimum(t0, t1), np.maximum(t0, t1)
+    tmin = max(max(sm[0], sm[1]), max(sm[0], sm[2])); tmax = min(min(bg[0], bg[1]), min(bg[0], bg[2]))
+    if tmax < 0.0 or tmin > tmax:
+        return -1.0, -1.0
+    return tmin, tmax
+
+
+def phase_hg(V, L, g):   # RTCommon.slang:213-220
+    if g == 0.0:
+        return 1.0 / (4.0 * np.pi)
+    return (1.0 / (4.0 * np.pi)) * ((1.0 - g * g) / (1.0 + g * g - 2.0 * g * float(np.dot(V, L))) ** 1.5)
+
+
+def volumes_transmittance(S, o, d):   # Volume.slang:419-446, homogeneous boxes
+    T = 1.0
+    for v in S.volumes:
+        near, far = box_hit(o, d, v["lo"], v["hi"])
+        near = max(near, 0.0)
+        if far - near > 0.0:
+            T *= np.exp(-v["density"] * (far - near))
+    return min(max(T, 0.0), 1.0)
+
+
+def scattered_in_volume(S, pay, rng, P):   # RayGen.slang:162-270 without an atmosphere
+    o, d = pay["origin"], pay["direction"]
+    n = len(S.volumes)
+    dist = [max(0.0, box_hit(o, d, v["lo"], v["hi"])[0]) for v in S.volumes]
+    idx = list(range(n))
+    for i in range(n):
+        for j in range(i + 1, n):
+            if dist[j] < dist[i]:
+                dist[i], dist[j] = dist[j], dist[i]; idx[i], idx[j] = idx[j], idx[i]
+    h = S.closest(o, d, 0.00001, 1000000.0)            # GetDistanceToGeometry (RTCommon.slang:86-101, ray queries): the direction as it is
+    dtg = h[0] if h is not None else -1.0
+    sd, sv = -1.0, -1
+    for i in range(n):
+        v = S.volumes[idx[i]]
+        near, far = box_hit(o, d, v["lo"], v["hi"])
+        t = -1.0
+        if not (far < 0.0) and not (sd >= 0.0 and near > sd):
+            inside = far - max(near, 0.0)
+            if inside > 0.0:
+                with np.errstate(all="ignore"):
+                    sampled = -np.log(rng.uf()) / v["density"]
+                if sampled < inside:
+                    t = max(near, 0.0) + sampled
+        if t >= 0.0 and (t < sd or sd < 0.0):
+            sd, sv = t, idx[i]
+    if not (sd >= 0.0 and (dtg < 0.0 or sd < dtg)):
+        return False
+    # ---- EvaluateVolumeScatteringEvent (RayGen.slang:272-380)
+    v = S.volumes[sv]
+    pay["origin"] = o + d * sd
+    pay["emitted"] = v["emissive"].copy()
+    po = pay["origin"]
+    to_sky, sky = sample_env(S, rng, P)
+    sky[:3] = sky[:3] * P.sky_intensity
+    if S.closest(po, to_sky, 0.0001, 1000000.0) is not None:
+        sky = np.zeros(4)
+    light = np.zeros(4); to_light = np.zeros(3)
+    if S.emissive:
+        to_light, light, e_inst, ti = sample_emissive(S, po, rng)
+        h2 = S.closest(po, to_light, 0.0001, 1000000.0)
+        hit_ids = S.ids[h2[3]] if h2 is not None else (0, 0)       # hitInstanceIndex / hitTriangleIdx default to 0 (RTCommon.slang:49-50)
+        if hit_ids != (e_inst, ti):
+            light = np.zeros(4)
+    vd = pay["vdepth"]
+    nd = sample_hg(d, v["g"], rng)
+    ph = phase_hg(d, nd, v["g"])
+    if sky[3] > 0.0:
+        pk = phase_hg(d, to_sky, v["g"])
+        T = volumes_transmittance(S, po, to_sky)
+        if pk > 0.0:
+            pay["emitted"] = pay["emitted"] + T * (v["color"] * pk) * (sky[:3] / sky[3]) * power_heuristics(sky[3], pk)
+    if light[3] > 0.0:
+        pl = phase_hg(d, to_light, v["g"])
+        T = volumes_transmittance(S, po, to_light)
+        if pl > 0.0:
+            pay["emitted"] = pay["emitted"] + T * (v["color"] * pl) * (light[:3] / light[3]) * power_heuristics(light[3], pl)
+    pay["direction"] = nd; pay["bxdf"] = v["color"] * ph; pay["pdf"] = ph
+    pay["depth"] += 1; pay["vdepth"] = vd + 1
+    return True
+
+
+def sample_emissive(S, position, rng):
+    """SampleEmissiveTriangle (Sampler.slang:348-422) -> (toLight, rgb | pdf, instance, triangle)."""
+    ne = len(S.emissive)
+    mi = min(int(np.floor(rng.uf() * ne)), ne - 1)
+    e_inst = S.emissive[mi]
+    e_mesh, e_mat, eM, _ = S.inst[e_inst]
+    ev, eidx = S.meshes[e_mesh]
+    ntri = len(eidx) // 3
+    ti = min(int(np.floor(rng.uf() * ntri)), ntri - 1)
+    tri = eidx.reshape(-1, 3)[ti]
+    a0, a1, a2 = (eM[:3, :3] @ ev["position"][int(k)].astype(np.float64) + eM[:3, 3] for k in tri)
+    x0, x1 = rng.uf(), rng.uf()
+    su1 = np.sqrt(x0); b0 = 1.0 - su1; b1 = x1 * su1; b2 = 1.0 - b0 - b1
+    tp = b0 * a0 + b1 * a1 + b2 * a2
+    to_light = _norm(tp - position)
+    ln = _norm(np.cross(a2 - a0, a1 - a0))
+    area = float(np.linalg.norm(np.cross(a1 - a0, a2 - a0))) * 0.5
+    d2 = float(np.dot(tp - position, tp - position)); ct = abs(float(np.dot(ln, to_light)))
+    with np.errstate(all="ignore"):
+        pdf = d2 / (float(ne) * float(ntri) * area * ct)
+    t0, t1, t2 = (ev["texcoord"][int(k)].astype(np.float64) for k in tri)
+    rgb = np.array(S.materials[e_mat]["emissive_color"], np.float64) * S.tex(S.materials[e_mat]["emissive_texture"], b0 * t0 + b1 * t1 + b2 * t2)[:3]
+    return to_light, np.append(rgb, pdf), e_inst, ti
 
 
 def rotate(v, axis, theta):   # RTCommon.slang:37-45
@@ -294,25 +418,8 @@ def closest_hit(S, luts, pay, rd, hit, rng, P):
     # ---- light NEE (Sampler.slang:348-422)
     can_light = False; light_rgb = np.zeros(3); light_pdf = 0.0; to_light_t = None
     if not is_light and S.emissive:
-        ne = len(S.emissive)
-        mi = min(int(np.floor(rng.uf() * ne)), ne - 1)
-        e_inst = S.emissive[mi]
-        e_mesh, e_mat, eM, _ = S.inst[e_inst]
-        ev, eidx = S.meshes[e_mesh]
-        ntri = len(eidx) // 3
-        ti = min(int(np.floor(rng.uf() * ntri)), ntri - 1)
-        a0, a1, a2 = (eM[:3, :3] @ ev["position"][int(k)].astype(np.float64) + eM[:3, 3] for k in eidx.reshape(-1, 3)[ti])
-        x0, x1 = rng.uf(), rng.uf()
-        su1 = np.sqrt(x0); b0 = 1.0 - su1; b1 = x1 * su1; b2 = 1.0 - b0 - b1
-        tp = b0 * a0 + b1 * a1 + b2 * a2
-        to_light = _norm(tp - pos)
-        ln = _norm(np.cross(a2 - a0, a1 - a0))
-        area = float(np.linalg.norm(np.cross(a1 - a0, a2 - a0))) * 0.5
-        d2 = float(np.dot(tp - pos, tp - pos)); ct = abs(float(np.dot(ln, to_light)))
-        with np.errstate(all="ignore"):
-            light_pdf = d2 / (float(ne) * float(ntri) * area * ct)
-        t0, t1, t2 = (ev["texcoord"][int(k)].astype(np.float64) for k in eidx.reshape(-1, 3)[ti])
-        light_rgb = np.array(S.materials[e_mat]["emissive_color"], np.float64) * S.tex(S.materials[e_mat]["emissive_texture"], b0 * t0 + b1 * t1 + b2 * t2)[:3]
+        to_light, lc, e_inst, ti = sample_emissive(S, pos, rng)
+        light_rgb, light_pdf = lc[:3], float(lc[3])
         if light_pdf > 0.0:
             to_light_t = w2t(to_light)
             h2 = S.closest(pos + to_light * 1e-2, to_light, 0.0001, 1000000.0)   # RTCommon.slang:54-60 (ray queries)
@@ -358,9 +465,9 @@ def closest_hit(S, luts, pay, rd, hit, rng, P):
     pay["origin"] = pos + N * (-1e-3 if refracted else 1e-3)
     pay["direction"] = scatter_w
     pay["bxdf"] = s_f; pay["pdf"] = s_pdf
-    if can_sky and sky[3] > 0.0 and k_pdf > 0.0:
-        pay["emitted"] = pay["emitted"] + (k_f * sky[:3] / sky[3]) * power_heuristics(sky[3], k_pdf)
+    if can_sky and sky[3] > 0.0 and k_pdf > 0.0:   # the transmittance is taken from the NEW origin (ClosestHit.slang:332-333)
+        pay["emitted"] = pay["emitted"] + (k_f * volumes_transmittance(S, pay["origin"], to_sky) * sky[:3] / sky[3]) * power_heuristics(sky[3], k_pdf)
     if not is_light and can_light and light_pdf > 0.0 and l_pdf > 0.0:
-        pay["emitted"] = pay["emitted"] + (l_f * light_rgb / light_pdf) * power_heuristics(light_pdf, l_pdf)
+        pay["emitted"] = pay["emitted"] + (l_f * volumes_transmittance(S, pay["origin"], to_light) * light_rgb / light_pdf) * power_heuristics(light_pdf, l_pdf)
     invalid = s_pdf <= 0.0
     pay["depth"] = MAX_DEPTH + pay["depth"] if invalid else pay["depth"] + 1

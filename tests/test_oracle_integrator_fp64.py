@@ -15,7 +15,7 @@ import numpy as np
 import pytest
 
 
-def variants(scenes, vpt_scenes):
+def variants(scenes, vpt_scenes, vpt_mod):
     base = scenes("cornell_box")
     metal = copy.deepcopy(base)
     for k, m in enumerate(metal.materials):
@@ -34,28 +34,37 @@ def variants(scenes, vpt_scenes):
     for m in murky.materials:
         if m["transmission"] > 0:
             m.update(roughness=0.2, medium_density=0.6, medium_anisotropy=0.4, medium_color=(0.9, 0.6, 0.3))
+    # homogeneous box volumes (RayGen.slang:162-372): fog filling the room; two overlapping boxes of different density under the environment
+    fog = [vpt_mod.volume(corner_min=(-5.0, -10.5, -5.0), corner_max=(5.0, -0.5, 5.0), color=(0.9, 0.9, 0.9), density=0.12, anisotropy=0.5)]
+    two = [vpt_mod.volume(corner_min=(-5.0, -10.5, -5.0), corner_max=(1.0, -4.0, 5.0), color=(0.8, 0.9, 1.0), density=0.15, anisotropy=-0.3),
+           vpt_mod.volume(corner_min=(-2.0, -7.0, -3.0), corner_max=(5.0, -0.5, 3.0), color=(1.0, 0.8, 0.7), density=0.3, anisotropy=0.0, emissive_color=(0.05, 0.02, 0.0))]
     # textures: the Viking room (a 1024 x 1024 base-colour map) and the textured boxes (base colour + a metallic-roughness map) under the
     # same environment
     viking = copy.deepcopy(scenes("viking_room")); viking.env = env
     boxes = copy.deepcopy(vpt_scenes.load_gltf(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "textured_boxes.gltf"))); boxes.env = env
     return {"cornell_d6": (base, 6, 90, 3), "cornell_d12": (base, 12, 60, 2), "metal_anisotropic": (metal, 6, 60, 2),
             "glass_sphere": (scenes("cornell_box_glass"), 8, 60, 2), "environment": (sky, 6, 90, 3),
-            "textured_viking_room": (viking, 5, 60, 2), "textured_boxes": (boxes, 5, 60, 2), "medium_in_glass": (murky, 10, 80, 2)}
+            "textured_viking_room": (viking, 5, 60, 2), "textured_boxes": (boxes, 5, 60, 2), "medium_in_glass": (murky, 10, 80, 2),
+            "fog": (base, 8, 80, 2, fog), "two_boxes_environment": (sky, 8, 80, 2, two)}
 
 
-@pytest.mark.parametrize("which", ["cornell_d6", "cornell_d12", "metal_anisotropic", "glass_sphere", "environment", "textured_viking_room", "textured_boxes", "medium_in_glass"])
+@pytest.mark.parametrize("which", ["cornell_d6", "cornell_d12", "metal_anisotropic", "glass_sphere", "environment", "textured_viking_room", "textured_boxes", "medium_in_glass", "fog", "two_boxes_environment"])
 def test_per_sample_values_match_the_float64_integrator(vpt, oracle, scenes, which):
     import ref_integrator64 as R
-    sc, depth, npix, frames = variants(scenes, vpt.scenes)[which]
+    v = variants(scenes, vpt.scenes, vpt)[which]
+    sc, depth, npix, frames = v[:4]
+    vols = v[4] if len(v) > 4 else []
     W, H = 64, 36
     P = vpt.default_params(max_depth=depth)
-    if which in ("environment", "textured_viking_room", "textured_boxes"):
+    if which in ("environment", "textured_viking_room", "textured_boxes", "two_boxes_environment"):
         P = vpt.default_params(max_depth=depth, sky_azimuth=35.0, sky_altitude=-20.0, sky_intensity=1.5)
     luts = vpt.scenes.load_luts()
-    S = R.Scene64(sc, W, H)
+    S = R.Scene64(sc, W, H); S.set_volumes(vols)
     o = oracle.Oracle(sc, W, H); o.set_params(P)
+    if vols:
+        o.set_volumes(vols)
     rng = np.random.default_rng(4)
-    lo_x, hi_x = (12, 52) if which in ("cornell_d6", "cornell_d12", "metal_anisotropic", "glass_sphere", "medium_in_glass") else (0, 64)                                        # with a sky, also the pixels beside the box
+    lo_x, hi_x = (12, 52) if which in ("cornell_d6", "cornell_d12", "metal_anisotropic", "glass_sphere", "medium_in_glass", "fog") else (0, 64)                                        # with a sky, also the pixels beside the box
     xs = rng.integers(lo_x, hi_x, npix).astype(np.uint32); ys = rng.integers(4, 32, npix).astype(np.uint32)   # pixels that look into the box
     got = o.pixel_samples(xs, ys, 0, frames).astype(np.float64)
     o.close()
