@@ -142,8 +142,16 @@ class Scene64:
 
 
 def sample_value(S, luts, x, y, frame, P):
-    """accumulatedLight of one sample (SampleCount == 1) of pixel (x, y) in dispatch `frame`."""
+    """accumulatedLight / SampleCount of pixel (x, y) in dispatch `frame` (RayGen.slang:27-130): one sampler per pixel and dispatch,
+    SampleCount samples drawn from it one after the other."""
     rng = Rng64((y + S.W * x + _pcg((P.base_seed + frame) & 0xffffffff)) & 0xffffffff)
+    acc = np.zeros(3)
+    for _ in range(P.samples_per_frame):
+        acc = acc + one_sample(S, luts, x, y, rng, P)
+    return acc / float(P.samples_per_frame)
+
+
+def one_sample(S, luts, x, y, rng, P):
     j0 = rng.uf() * 1.0 - 0.5; j1 = rng.uf() * 1.0 - 0.5
     d2 = np.array([(x + 0.5 + j0) / S.W, (y + 0.5 + j1) / S.H]) * 2.0 - 1.0
     origin = (S.view_inv @ np.array([0.0, 0.0, 0.0, 1.0]))[:3]

@@ -45,10 +45,10 @@ def variants(scenes, vpt_scenes, vpt_mod):
     return {"cornell_d6": (base, 6, 90, 3), "cornell_d12": (base, 12, 60, 2), "metal_anisotropic": (metal, 6, 60, 2),
             "glass_sphere": (scenes("cornell_box_glass"), 8, 60, 2), "environment": (sky, 6, 90, 3),
             "textured_viking_room": (viking, 5, 60, 2), "textured_boxes": (boxes, 5, 60, 2), "medium_in_glass": (murky, 10, 80, 2),
-            "fog": (base, 8, 80, 2, fog), "two_boxes_environment": (sky, 8, 80, 2, two)}
+            "fog": (base, 8, 80, 2, fog), "two_boxes_environment": (sky, 8, 80, 2, two), "depth_of_field_3spf": (base, 6, 80, 2)}
 
 
-@pytest.mark.parametrize("which", ["cornell_d6", "cornell_d12", "metal_anisotropic", "glass_sphere", "environment", "textured_viking_room", "textured_boxes", "medium_in_glass", "fog", "two_boxes_environment"])
+@pytest.mark.parametrize("which", ["cornell_d6", "cornell_d12", "metal_anisotropic", "glass_sphere", "environment", "textured_viking_room", "textured_boxes", "medium_in_glass", "fog", "two_boxes_environment", "depth_of_field_3spf"])
 def test_per_sample_values_match_the_float64_integrator(vpt, oracle, scenes, which):
     import ref_integrator64 as R
     v = variants(scenes, vpt.scenes, vpt)[which]
@@ -59,12 +59,14 @@ def test_per_sample_values_match_the_float64_integrator(vpt, oracle, scenes, whi
     if which in ("environment", "textured_viking_room", "textured_boxes", "two_boxes_environment"):
         P = vpt.default_params(max_depth=depth, sky_azimuth=35.0, sky_altitude=-20.0, sky_intensity=1.5)
     luts = vpt.scenes.load_luts()
+    if which == "depth_of_field_3spf":   # thin-lens offset on the camera plane, three samples per dispatch from one sampler
+        P = vpt.default_params(max_depth=depth, dof_strength=0.6, focus_distance=14.0, samples_per_frame=3)
     S = R.Scene64(sc, W, H); S.set_volumes(vols)
     o = oracle.Oracle(sc, W, H); o.set_params(P)
     if vols:
         o.set_volumes(vols)
     rng = np.random.default_rng(4)
-    lo_x, hi_x = (12, 52) if which in ("cornell_d6", "cornell_d12", "metal_anisotropic", "glass_sphere", "medium_in_glass", "fog") else (0, 64)                                        # with a sky, also the pixels beside the box
+    lo_x, hi_x = (12, 52) if which in ("cornell_d6", "cornell_d12", "metal_anisotropic", "glass_sphere", "medium_in_glass", "fog", "depth_of_field_3spf") else (0, 64)                                        # with a sky, also the pixels beside the box
     xs = rng.integers(lo_x, hi_x, npix).astype(np.uint32); ys = rng.integers(4, 32, npix).astype(np.uint32)   # pixels that look into the box
     got = o.pixel_samples(xs, ys, 0, frames).astype(np.float64)
     o.close()
