@@ -2,7 +2,9 @@
 (RayGen.slang:9-160, ClosestHit.slang:20-378, Miss.slang:8-77, Surface.slang:26-147, Sampler.slang:286-422, RTCommon.slang:47-64,
 124-136, Material.slang via tests/test_oracle_bsdf_fp64.py) and NOT from oracle/oracle.cpp.  PathTracer.cpp:1161-1296 for the environment tables).  Scope: any textures (LINEAR / REPEAT, mip 0) and environment map, the medium inside a glass mesh (Beer's law, Henyey-Greenstein walk),
 homogeneous box volumes with the Henyey-Greenstein phase function (RayGen.slang:162-372, Volume.slang:190-223, 256-286, 358-443);
-no density grids, no atmosphere; ray-query shadow tests; brute-force intersection.  Used by
+the atmosphere (Atmosphere.slang, RayGen.slang:214-250, 382-470, Sampler.slang:430-463; its sphere intersections and heights in
+float32, as the shader computes them: at a planet radius of 6.36e6 they are cancellation-limited and float64 would be a different
+function); no density grids; ray-query shadow tests; brute-force intersection.  Used by
 tests/test_oracle_integrator_fp64.py to hold the oracle's per-sample values (orc_pixel_samples) against it.
 
 Test infrastructure only."""
@@ -42,6 +44,10 @@ class Scene64:
         self.build_env(np.asarray(sc.env, np.float32))
         self.textures = [np.asarray(t) for t in sc.textures]
         self.volumes = []   # set_volumes(): dicts with corner_min, corner_max, color, emissive_color, density, anisotropy
+        self.atm = None     # set_atmosphere(): a vpt_atmosphere
+
+    def set_atmosphere(self, a):
+        self.atm = a
 
     def set_volumes(self, vols):
         self.volumes = [dict(lo=np.array(v.corner_min[:], np.float64), hi=np.array(v.corner_max[:], np.float64), color=np.array(v.color[:], np.float64),
@@ -163,12 +169,14 @@ def one_sample(S, luts, x, y, rng, P):
     origin = origin + off[0] * S.view_inv[:3, 0] + off[1] * S.view_inv[:3, 1]
     direction = _norm(focus - origin)
     pay = dict(depth=0, origin=origin, direction=direction, bxdf=np.ones(3), pdf=1.0, emitted=np.zeros(3), in_medium=False,
-               med_density=0.0, med_aniso=0.0, med_color=np.zeros(3), vdepth=0)
+               med_density=0.0, med_aniso=0.0, med_color=np.zeros(3), vdepth=0, cchan=-1)
     thr, light = np.ones(3), np.zeros(3)
     while pay["depth"] < P.max_depth:
         rd = _norm(pay["direction"])
         pay["emitted"] = np.zeros(3)
-        if S.volumes and scattered_in_volume(S, pay, rng, P):
+        if S.atm is not None and atm_height(S.atm, pay["origin"]) < 0.0:
+            break                                                         # below the planet's surface (RayGen.slang:76-84)
+        if (S.volumes or S.atm is not None) and scattered_in_volume(S, pay, rng, P):
             pass
         else:
             hit = S.closest(pay["origin"], rd, 0.01, 100000.0)
@@ -188,7 +196,12 @@ def one_sample(S, luts, x, y, rng, P):
             break
         with np.errstate(all="ignore"):
             thr = thr / p
-    return light if np.isfinite(light).all() else np.zeros(3)
+    if not np.isfinite(light).all():
+        return np.zeros(3)
+    if pay["cchan"] == -1:
+        return light
+    out = np.zeros(3); out[pay["cchan"]] = light[pay["cchan"]]           # a split path carries one colour channel (RayGen.slang:118-128)
+    return out
 
 
 def sample_hg(d, g, rng):   # Sampler.slang:168-192
@@ -258,14 +271,26 @@ def scattered_in_volume(S, pay, rng, P):   # RayGen.slang:162-270 without an atm
                     t = max(near, 0.0) + sampled
         if t >= 0.0 and (t < sd or sd < 0.0):
             sd, sv = t, idx[i]
+    cchan, comp = pay["cchan"], -1
+    if S.atm is not None:
+        if cchan == -1:
+            pick = rng.uf()
+            cchan = 0 if pick < 0.33333 else (1 if pick < 0.66666 else 2)
+        ta, comp = atm_scatter_distance(S.atm, rng, o, d, cchan)
+        if ta >= 0.0 and (ta < sd or sd < 0.0):
+            sd, sv = ta, -2
     if not (sd >= 0.0 and (dtg < 0.0 or sd < dtg)):
         return False
+    if sv == -2:
+        pay["cchan"] = cchan
+        atmosphere_event(S, pay, rng, P, sd, comp)
+        return True
     # ---- EvaluateVolumeScatteringEvent (RayGen.slang:272-380)
     v = S.volumes[sv]
     pay["origin"] = o + d * sd
     pay["emitted"] = v["emissive"].copy()
     po = pay["origin"]
-    to_sky, sky = sample_env(S, rng, P)
+    to_sky, sky = sample_sky(S, rng, P)
     sky[:3] = sky[:3] * P.sky_intensity
     if S.closest(po, to_sky, 0.0001, 1000000.0) is not None:
         sky = np.zeros(4)
@@ -282,6 +307,8 @@ def scattered_in_volume(S, pay, rng, P):   # RayGen.slang:162-270 without an atm
     if sky[3] > 0.0:
         pk = phase_hg(d, to_sky, v["g"])
         T = volumes_transmittance(S, po, to_sky)
+        if S.atm is not None:
+            T = T * nee_atmosphere_transmittance(S, rng, po, to_sky, pay["cchan"])
         if pk > 0.0:
             pay["emitted"] = pay["emitted"] + T * (v["color"] * pk) * (sky[:3] / sky[3]) * power_heuristics(sky[3], pk)
     if light[3] > 0.0:
@@ -319,6 +346,160 @@ def sample_emissive(S, position, rng):
     return to_light, np.append(rgb, pdf), e_inst, ti
 
 
+# ---------------------------------------------------------------- atmosphere
+C_RAYLEIGH = np.array([5.802, 13.558, 33.100]) * 1e-6
+C_MIE_S, C_MIE_A = 3.996e-6, 4.40e-6
+C_OZONE = np.array([0.650, 1.881, 0.085]) * 1e-6
+f32 = np.float32
+
+
+def intersect_sphere(o, d, centre, radius):   # RTCommon.slang:168-185, float32 term for term
+    ro = (o.astype(f32) - centre.astype(f32)).astype(f32)
+    dd = d.astype(f32)
+    dot = lambda a, b: f32(f32(f32(a[0] * b[0]) + f32(a[1] * b[1])) + f32(a[2] * b[2]))
+    a = dot(dd, dd); b = f32(f32(2.0) * dot(ro, dd)); c = f32(dot(ro, ro) - f32(f32(radius) * f32(radius)))
+    disc = f32(f32(b * b) - f32(f32(f32(4.0) * a) * c))
+    if disc < 0:
+        return -1.0, -1.0
+    sq = f32(np.sqrt(disc))
+    return float(f32(f32(-b - sq) / f32(f32(2.0) * a))), float(f32(f32(-b + sq) / f32(f32(2.0) * a)))
+
+
+def atm_height(A, p):   # length(position - planet) - radius, float32
+    q = (p.astype(f32) - np.array(A.planet_position[:], f32)).astype(f32)
+    l = f32(np.sqrt(f32(f32(f32(q[0] * q[0]) + f32(q[1] * q[1])) + f32(q[2] * q[2]))))
+    return float(f32(l - f32(A.planet_radius)))
+
+
+def atm_densities(A, h, ch):
+    r = np.exp(-h / A.rayleigh_density_falloff) * C_RAYLEIGH[ch] * A.rayleigh_multiplier[ch]
+    m = np.exp(-h / A.mie_density_falloff) * (C_MIE_S + C_MIE_A) * A.mie_multiplier[ch]
+    o = np.exp(-(abs(h - A.ozone_peak) / A.ozone_density_falloff)) * C_OZONE[ch] * A.ozone_multiplier[ch]
+    return r, m, o
+
+
+def atm_majorant(A, ch):
+    r, m, _ = atm_densities(A, 0.0, ch)
+    _, _, o = atm_densities(A, A.ozone_peak, ch)
+    return r + m + o
+
+
+def atm_transmittance(A, rng, o, d, ch):   # CalculateTransmittanceThroughAtmosphere: ratio tracking with roulette -> float3
+    centre = np.array(A.planet_position[:], np.float64)
+    if intersect_sphere(o, d, centre, A.planet_radius)[1] > 0.0:
+        return np.zeros(3)
+    t0, t1 = intersect_sphere(o, d, centre, A.planet_radius + A.atmosphere_height)
+    tmin, tmax = max(t0, 0.0), t1
+    if tmax < 0.0:
+        return np.ones(3)
+    maj = atm_majorant(A, ch)
+    if maj <= 0.0:
+        return np.ones(3)
+    t, T = 0.0, 1.0
+    for _ in range(1000):
+        t += -np.log(1.0 - rng.uf()) / maj
+        if t >= tmax - tmin:
+            break
+        h = atm_height(A, o + d * (t + tmin))
+        if h < 0.0:
+            break
+        r, m, oz = atm_densities(A, h, ch)
+        T *= 1.0 - (r + m + oz) / maj
+        if rng.uf() > T:
+            T = 0.0
+            break
+        T /= T
+    out = np.zeros(3); out[ch] = T
+    return out
+
+
+def atm_scatter_distance(A, rng, o, d, ch):   # SampleAtmosphereScatterDistance: delta tracking -> (t | -1, component)
+    centre = np.array(A.planet_position[:], np.float64)
+    a0, a1 = intersect_sphere(o, d, centre, A.planet_radius + A.atmosphere_height)
+    t_min_a, t_max_a = max(a0, 0.0), a1
+    p0, _ = intersect_sphere(o, d, centre, A.planet_radius)
+    if t_max_a < 0.0:
+        return -1.0, -1
+    maj = atm_majorant(A, ch)
+    if maj <= 0.0:
+        return -1.0, -1
+    t = t_min_a
+    for _ in range(1000):
+        t += -np.log(1.0 - rng.uf()) / maj
+        if t >= t_max_a:
+            break
+        if p0 > 0.0 and t >= p0:
+            break
+        r, m, oz = atm_densities(A, atm_height(A, o + d * t), ch)
+        dens = r + m + oz
+        if dens / maj < rng.uf():
+            continue
+        x = rng.uf()
+        return t, (0 if x <= r / dens else (1 if x <= r / dens + m / dens else 2))
+    return -1.0, -1
+
+
+def sample_sun(S, rng, P):   # SampleSunDisk(0.004675) (Sampler.slang:430-463) -> (direction, rgb | pdf)
+    A = S.atm
+    sun = rotate(np.array([0.0, 0.0, -1.0]), np.array([1.0, 0.0, 0.0]), P.sky_altitude / 180.0 * np.pi)
+    sun = rotate(sun, np.array([0.0, 1.0, 0.0]), P.sky_azimuth / 180.0 * np.pi)
+    ctm = np.cos(0.004675)
+    phi = 2.0 * np.pi * rng.uf()
+    ct = ctm + (1.0 - ctm) * rng.uf()
+    st = np.sqrt(1.0 - ct * ct)
+    w = _norm(sun)
+    up = np.array([0.0, 0.0, 1.0]) if abs(w[2]) < 0.999 else np.array([1.0, 0.0, 0.0])
+    u = _norm(np.cross(up, w)); v = np.cross(w, u)
+    d = u * (np.cos(phi) * st) + v * (np.sin(phi) * st) + w * ct
+    return d, np.append(2e5 * np.array(A.sun_color[:], np.float64) * P.sky_intensity, 1.0 / (2.0 * np.pi * (1.0 - ctm)))
+
+
+def sample_rayleigh(d, rng):   # Sampler.slang:194-214
+    r0, r1 = rng.uf(), rng.uf()
+    u = -np.cbrt(2.0 * (2.0 * r0 - 1.0) + np.sqrt(4.0 * (2.0 * r0 - 1.0) ** 2 + 1.0))
+    ct = u - 1.0 / u
+    phi = 2.0 * np.pi * r1
+    st = np.sqrt(1.0 - ct * ct)
+    nd = np.array([st * np.cos(phi), st * np.sin(phi), ct])
+    up = np.array([0.0, 1.0, 0.0]) if abs(d[1]) < 0.9999999 else np.array([0.0, 0.0, 1.0])
+    t = _norm(np.cross(up, d)); b = np.cross(d, t)
+    return _norm(nd[0] * t + nd[1] * b + nd[2] * d)
+
+
+def sample_sky(S, rng, P):   # ImportanceSampleSky (Sampler.slang:465-476)
+    return sample_sun(S, rng, P) if S.atm is not None else sample_env(S, rng, P)
+
+
+def nee_atmosphere_transmittance(S, rng, o, d, cchan):   # ClosestHit.slang:335-349 == RayGen.slang:328-343
+    A = S.atm
+    if cchan == -1:
+        return np.array([atm_transmittance(A, rng, o, d, 0)[0], atm_transmittance(A, rng, o, d, 1)[1], atm_transmittance(A, rng, o, d, 2)[2]])
+    return atm_transmittance(A, rng, o, d, cchan)
+
+
+def atmosphere_event(S, pay, rng, P, sd, comp):   # EvaluateAtmosphereScatteringEvent with ENABLE_SKY_MIS (RayGen.slang:382-443)
+    d = pay["direction"]
+    pay["origin"] = pay["origin"] + sd * d
+    nd = sample_rayleigh(d, rng) if comp == 0 else (sample_hg(d, 0.85, rng) if comp == 1 else d)
+    to_sun, cp = sample_sun(S, rng, P)
+    cp[:3] = cp[:3] * P.sky_intensity
+    if S.closest(pay["origin"], to_sun, 0.0001, 1000000.0) is None:
+        T = atm_transmittance(S.atm, rng, pay["origin"], to_sun, pay["cchan"]) * volumes_transmittance(S, pay["origin"], to_sun)
+    else:
+        T = np.zeros(3)
+    ray_phase = lambda a, b: (3.0 / (16.0 * np.pi)) * (1.0 + float(np.dot(a, b)) ** 2)
+    if comp == 0:
+        pay["emitted"] = pay["emitted"] + ray_phase(d, to_sun) * T * (cp[:3] / cp[3])
+        pay["bxdf"] = np.full(3, ray_phase(d, nd)); pay["pdf"] = ray_phase(d, nd)
+    elif comp == 1:
+        pay["emitted"] = pay["emitted"] + phase_hg(d, to_sun, 0.85) * T * (cp[:3] / cp[3])
+        pay["bxdf"] = np.full(3, phase_hg(d, nd, 0.85) * (1.0 - C_MIE_A / (C_MIE_S + C_MIE_A))); pay["pdf"] = phase_hg(d, nd, 0.85)
+    else:
+        pay["bxdf"] = np.zeros(3); pay["pdf"] = 1.0
+    pay["direction"] = nd
+    pay["depth"] += 1
+
+
 def rotate(v, axis, theta):   # RTCommon.slang:37-45
     a = _norm(axis)
     return v * np.cos(theta) + np.cross(a, v) * np.sin(theta) + a * np.dot(a, v) * (1.0 - np.cos(theta))
@@ -351,6 +532,9 @@ def sample_env(S, rng, P):
 
 
 def miss(S, pay, P):   # Miss.slang with SHOW_ENV_MAP_DIRECTLY
+    if S.atm is not None:   # :11-14: the sky is in-scattered sunlight only
+        pay["depth"] = MAX_DEPTH
+        return
     d = rotate(pay["direction"], np.array([1.0, 0.0, 0.0]), -(P.sky_altitude / 180.0 * np.pi))
     d = rotate(d, np.array([0.0, 1.0, 0.0]), -(P.sky_azimuth / 180.0 * np.pi))
     gamma = np.arcsin(np.clip(d[1], -1.0, 1.0)); theta = np.arctan2(d[0], -d[2])      # DirectionToUV (RTCommon.slang:129-136)
@@ -417,7 +601,7 @@ def closest_hit(S, luts, pay, rd, hit, rng, P):
                 pay["bxdf"] = np.array(pay["med_color"], np.float64)
                 return
     # ---- sky NEE (ClosestHit.slang:118-147): sample, then the visibility test from pos + N * 1e-5
-    to_sky, sky = sample_env(S, rng, P)
+    to_sky, sky = sample_sky(S, rng, P)
     sky[:3] = sky[:3] * P.sky_intensity            # the intensity is applied a second time here (:131), as upstream does
     to_sky_t = w2t(to_sky) if np.isfinite(to_sky).all() and np.abs(to_sky).max() > 0 else np.zeros(3)
     can_sky = S.closest(pos + N * 1e-5, to_sky, 0.0001, 1000000.0) is None
@@ -473,8 +657,12 @@ def closest_hit(S, luts, pay, rd, hit, rng, P):
     pay["origin"] = pos + N * (-1e-3 if refracted else 1e-3)
     pay["direction"] = scatter_w
     pay["bxdf"] = s_f; pay["pdf"] = s_pdf
-    if can_sky and sky[3] > 0.0 and k_pdf > 0.0:   # the transmittance is taken from the NEW origin (ClosestHit.slang:332-333)
-        pay["emitted"] = pay["emitted"] + (k_f * volumes_transmittance(S, pay["origin"], to_sky) * sky[:3] / sky[3]) * power_heuristics(sky[3], k_pdf)
+    if can_sky:   # the transmittance is taken from the NEW origin (ClosestHit.slang:332-349); its draws happen whether or not it is used
+        T_sky = volumes_transmittance(S, pay["origin"], to_sky)
+        if S.atm is not None:
+            T_sky = T_sky * nee_atmosphere_transmittance(S, rng, pay["origin"], to_sky, pay["cchan"])
+        if sky[3] > 0.0 and k_pdf > 0.0:
+            pay["emitted"] = pay["emitted"] + (k_f * T_sky * sky[:3] / sky[3]) * power_heuristics(sky[3], k_pdf)
     if not is_light and can_light and light_pdf > 0.0 and l_pdf > 0.0:
         pay["emitted"] = pay["emitted"] + (l_f * volumes_transmittance(S, pay["origin"], to_light) * light_rgb / light_pdf) * power_heuristics(light_pdf, l_pdf)
     invalid = s_pdf <= 0.0
