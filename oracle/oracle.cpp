@@ -27,7 +27,7 @@
 // Surface, emissive-triangle NEE, MIS, clamp, roulette (tests/ref_integrator64.py,
 // tests/test_oracle_integrator_fp64.py: per-sample values agree to 2e-4 .. 1e-3 on every sample compared).
 // The second restatement covers textures, environment importance sampling (alias map included), the medium inside a glass
-// mesh, homogeneous box volumes (Henyey-Greenstein) and the atmosphere; density grids and Draine phase functions are outside it.  BVH traversal, scene import and the
+// mesh, homogeneous box volumes with all three phase functions and the atmosphere; density grids are outside it.  BVH traversal, scene import and the
 // elementary fp32 functions live in the Vulkan driver / VulkanHelper / Slang: parity for those
 // is UNPINNED; they follow include/vpt_fp32.h on both sides.
 //

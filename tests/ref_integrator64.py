@@ -45,13 +45,15 @@ class Scene64:
         self.textures = [np.asarray(t) for t in sc.textures]
         self.volumes = []   # set_volumes(): dicts with corner_min, corner_max, color, emissive_color, density, anisotropy
         self.atm = None     # set_atmosphere(): a vpt_atmosphere
+        self.phase = 0      # 0 Henyey-Greenstein, 1 Draine, 2 Henyey-Greenstein + Draine (the reference's PHASE_FUNCTION_* defines)
 
     def set_atmosphere(self, a):
         self.atm = a
 
     def set_volumes(self, vols):
         self.volumes = [dict(lo=np.array(v.corner_min[:], np.float64), hi=np.array(v.corner_max[:], np.float64), color=np.array(v.color[:], np.float64),
-                             emissive=np.array(v.emissive_color[:], np.float64), density=float(v.density), g=float(v.anisotropy)) for v in vols]
+                             emissive=np.array(v.emissive_color[:], np.float64), density=float(v.density), g=float(v.anisotropy), alpha=float(v.alpha),
+                             droplet=float(v.droplet_size)) for v in vols]
         for v in vols:
             assert v.density_data_index < 0 and not v.approximated_scattering, "homogeneous volumes only"
 
@@ -236,6 +238,74 @@ def phase_hg(V, L, g):   # RTCommon.slang:213-220
     return (1.0 / (4.0 * np.pi)) * ((1.0 - g * g) / (1.0 + g * g - 2.0 * g * float(np.dot(V, L))) ** 1.5)
 
 
+def phase_draine(V, L, g, a):   # RTCommon.slang:222-227
+    c = float(np.dot(V, L))
+    return ((1 - g * g) * (1 + a * c * c)) / (4.0 * (1 + (a * (1 + 2 * g * g)) / 3.0) * np.pi * (1 + g * g - 2 * g * c) ** 1.5)
+
+
+def hgd_params(d):   # Volume.slang:396-407 == Sampler.slang:268-272
+    return (np.exp(-(0.0990567 / (d - 1.67154))), np.exp(-(2.20679 / (d + 3.91029)) - 0.428934), np.exp(3.62489 - (8.29288 / (d + 5.52825))),
+            np.exp(-(0.599085 / (d - 0.641583)) - 0.665888))
+
+
+def eval_phase(S, v, V, L):   # Volume.slang:377-407 (no approximated scattering: the anisotropy does not change with depth)
+    if S.phase == 0:
+        return phase_hg(V, L, v["g"])
+    if S.phase == 1:
+        return phase_draine(V, L, v["g"], v["alpha"])
+    ghg, gd, ad, wd = hgd_params(v["droplet"])
+    hg, dr = phase_hg(V, L, ghg), phase_draine(V, L, gd, ad)
+    return hg + (dr - hg) * wd
+
+
+def to_world(d, nd):
+    up = np.array([0.0, 1.0, 0.0]) if abs(d[1]) < 0.9999999 else np.array([0.0, 0.0, 1.0])
+    t = _norm(np.cross(up, d)); b = np.cross(d, t)
+    return _norm(nd[0] * t + nd[1] * b + nd[2] * d)
+
+
+def sample_draine(d, g, a, rng):   # Sampler.slang:216-264; the closed-form root in float32, term for term (it cancels catastrophically)
+    r0, r1 = rng.uf(), rng.uf()
+    if abs(g) < 1e-5:
+        ct = 2.0 * r0 - 1.0
+    elif abs(a) < 1e-5:
+        sq = (1.0 - g * g) / (1.0 - g + 2.0 * g * r0)
+        ct = (1.0 + g * g - sq * sq) / (2.0 * g)
+    else:
+        f = np.float32
+        g, a, x = f(g), f(a), f(r0)
+        g2 = g * g; g3 = g * g2; g4 = g2 * g2; g6 = g2 * g4
+        p2 = (1 + g2) * (1 + g2)
+        T1a = -a + a * g4
+        T1a3 = T1a * T1a * T1a
+        T2 = -1296 * (-1 + g2) * (a - a * g2) * (T1a) * (4 * g2 + a * p2)
+        T3 = 3 * g2 * (1 + g * (-1 + 2 * x)) + a * (2 + g2 + g3 * (1 + 2 * g2) * (-1 + 2 * x))
+        T4a = 432 * T1a3 + T2 + 432 * (a - a * g2) * T3 * T3
+        T4b = -144 * a * g2 + 288 * a * g4 - 144 * a * g6
+        T4b3 = T4b * T4b * T4b
+        with np.errstate(all="ignore"):
+            T4 = T4a + np.sqrt(-4 * T4b3 + T4a * T4a)
+            T4p3 = f(np.power(T4, f(1.0 / 3.0)))
+            c2 = f(np.power(f(2.0), f(1.0 / 3.0)))
+            T6 = (2 * T1a + (48 * c2 * (-(a * g2) + 2 * a * g4 - a * g6)) / T4p3 + T4p3 / (f(3.0) * c2)) / (a - a * g2)
+            T5 = 6 * (1 + g2) + T6
+            inner = f(-0.5) * np.sqrt(T5) + np.sqrt(6 * (1 + g2) - (8 * T3) / (a * (-1 + g2) * np.sqrt(T5)) - T6) / f(2.0)
+            ct = float((1 + g2 - inner * inner) / (f(2.0) * g))
+    phi = 2.0 * np.pi * r1
+    st = np.sqrt(1.0 - ct * ct)
+    return to_world(d, np.array([st * np.cos(phi), st * np.sin(phi), ct]))
+
+
+def sample_phase(S, v, d, vdepth, rng):   # Volume.slang:358-375
+    if S.phase == 0:
+        return sample_hg(d, v["g"], rng)
+    if S.phase == 1:
+        return sample_draine(d, v["g"], v["alpha"], rng)
+    ghg, gd, ad, wd = hgd_params(v["droplet"])
+    ghg = max(ghg, 0.0) ** (1.0 + vdepth); gd = max(gd, 0.0) ** (1.0 + vdepth)     # sampling narrows with depth, evaluation does not (upstream)
+    return sample_hg(d, ghg, rng) if rng.uf() < wd else sample_draine(d, gd, ad, rng)
+
+
 def volumes_transmittance(S, o, d):   # Volume.slang:419-446, homogeneous boxes
     T = 1.0
     for v in S.volumes:
@@ -302,17 +372,17 @@ def scattered_in_volume(S, pay, rng, P):   # RayGen.slang:162-270 without an atm
         if hit_ids != (e_inst, ti):
             light = np.zeros(4)
     vd = pay["vdepth"]
-    nd = sample_hg(d, v["g"], rng)
-    ph = phase_hg(d, nd, v["g"])
+    nd = sample_phase(S, v, d, vd, rng)
+    ph = eval_phase(S, v, d, nd)
     if sky[3] > 0.0:
-        pk = phase_hg(d, to_sky, v["g"])
+        pk = eval_phase(S, v, d, to_sky)
         T = volumes_transmittance(S, po, to_sky)
         if S.atm is not None:
             T = T * nee_atmosphere_transmittance(S, rng, po, to_sky, pay["cchan"])
         if pk > 0.0:
             pay["emitted"] = pay["emitted"] + T * (v["color"] * pk) * (sky[:3] / sky[3]) * power_heuristics(sky[3], pk)
     if light[3] > 0.0:
-        pl = phase_hg(d, to_light, v["g"])
+        pl = eval_phase(S, v, d, to_light)
         T = volumes_transmittance(S, po, to_light)
         if pl > 0.0:
             pay["emitted"] = pay["emitted"] + T * (v["color"] * pl) * (light[:3] / light[3]) * power_heuristics(light[3], pl)

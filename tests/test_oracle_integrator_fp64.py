@@ -46,10 +46,11 @@ def variants(scenes, vpt_scenes, vpt_mod):
             "glass_sphere": (scenes("cornell_box_glass"), 8, 60, 2), "environment": (sky, 6, 90, 3),
             "textured_viking_room": (viking, 5, 60, 2), "textured_boxes": (boxes, 5, 60, 2), "medium_in_glass": (murky, 10, 80, 2),
             "fog": (base, 8, 80, 2, fog), "two_boxes_environment": (sky, 8, 80, 2, two), "depth_of_field_3spf": (base, 6, 80, 2),
-            "atmosphere": (base, 10, 120, 2), "atmosphere_with_fog": (base, 10, 120, 2, fog)}
+            "atmosphere": (base, 10, 120, 2), "atmosphere_with_fog": (base, 10, 120, 2, fog),
+            "fog_draine": (base, 8, 80, 2, fog), "fog_hg_plus_draine": (sky, 8, 80, 2, fog)}
 
 
-@pytest.mark.parametrize("which", ["cornell_d6", "cornell_d12", "metal_anisotropic", "glass_sphere", "environment", "textured_viking_room", "textured_boxes", "medium_in_glass", "fog", "two_boxes_environment", "depth_of_field_3spf", "atmosphere", "atmosphere_with_fog"])
+@pytest.mark.parametrize("which", ["cornell_d6", "cornell_d12", "metal_anisotropic", "glass_sphere", "environment", "textured_viking_room", "textured_boxes", "medium_in_glass", "fog", "two_boxes_environment", "depth_of_field_3spf", "atmosphere", "atmosphere_with_fog", "fog_draine", "fog_hg_plus_draine"])
 def test_per_sample_values_match_the_float64_integrator(vpt, oracle, scenes, which):
     import ref_integrator64 as R
     v = variants(scenes, vpt.scenes, vpt)[which]
@@ -57,7 +58,7 @@ def test_per_sample_values_match_the_float64_integrator(vpt, oracle, scenes, whi
     vols = v[4] if len(v) > 4 else []
     W, H = 64, 36
     P = vpt.default_params(max_depth=depth)
-    if which in ("environment", "textured_viking_room", "textured_boxes", "two_boxes_environment"):
+    if which in ("environment", "textured_viking_room", "textured_boxes", "two_boxes_environment", "fog_hg_plus_draine"):
         P = vpt.default_params(max_depth=depth, sky_azimuth=35.0, sky_altitude=-20.0, sky_intensity=1.5)
     luts = vpt.scenes.load_luts()
     if which == "depth_of_field_3spf":   # thin-lens offset on the camera plane, three samples per dispatch from one sampler
@@ -67,11 +68,14 @@ def test_per_sample_values_match_the_float64_integrator(vpt, oracle, scenes, whi
         P = vpt.default_params(max_depth=depth, sky_altitude=-55.0, sky_azimuth=160.0)
         atm = vpt.atmosphere()
     S = R.Scene64(sc, W, H); S.set_volumes(vols); S.set_atmosphere(atm)
+    S.phase = {"fog_draine": 1, "fog_hg_plus_draine": 2}.get(which, 0)
     o = oracle.Oracle(sc, W, H); o.set_params(P)
     if vols:
         o.set_volumes(vols)
     if atm is not None:
         o.set_atmosphere(atm)
+    if S.phase:
+        o.set_phase_function(S.phase)
     rng = np.random.default_rng(4)
     lo_x, hi_x = (12, 52) if which in ("cornell_d6", "cornell_d12", "metal_anisotropic", "glass_sphere", "medium_in_glass", "fog", "depth_of_field_3spf") else (0, 64)                                        # with a sky, also the pixels beside the box
     xs = rng.integers(lo_x, hi_x, npix).astype(np.uint32); ys = rng.integers(4, 32, npix).astype(np.uint32)   # pixels that look into the box
