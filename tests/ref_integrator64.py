@@ -13,6 +13,7 @@ import numpy as np
 from test_oracle_bsdf_fp64 import Mat64, Rng64, _pcg, _norm, sample64
 
 MAX_DEPTH = 1000000   # Defines.slang:17
+FLAG_SKY_MIS, FLAG_MESH_MIS, FLAG_SHOW_ENV_DIRECTLY, FLAG_GEOMETRY_NORMALS, FLAG_ENERGY_COMPENSATION, FLAG_FURNACE = 1, 2, 4, 8, 16, 32   # the reference's #defines as vpt_params.flags bits
 
 
 def power_heuristics(a, b):   # RTCommon.slang:124-127
@@ -608,9 +609,14 @@ def miss(S, pay, P):   # Miss.slang with SHOW_ENV_MAP_DIRECTLY
     d = rotate(pay["direction"], np.array([1.0, 0.0, 0.0]), -(P.sky_altitude / 180.0 * np.pi))
     d = rotate(d, np.array([0.0, 1.0, 0.0]), -(P.sky_azimuth / 180.0 * np.pi))
     gamma = np.arcsin(np.clip(d[1], -1.0, 1.0)); theta = np.arctan2(d[0], -d[2])      # DirectionToUV (RTCommon.slang:129-136)
-    color_pdf = S.env_lookup(theta / np.pi * 0.5 + 0.5, gamma / np.pi + 0.5)
+    if (P.flags & FLAG_SHOW_ENV_DIRECTLY) or pay["depth"] > 0:
+        color_pdf = S.env_lookup(theta / np.pi * 0.5 + 0.5, gamma / np.pi + 0.5)
+    else:
+        color_pdf = np.array([0.0, 0.0, 0.0, 1.0])
     pay["emitted"] = color_pdf[:3] * P.sky_intensity
-    if pay["depth"] > 0:   # ENABLE_SKY_MIS
+    if P.flags & FLAG_FURNACE:
+        pay["emitted"] = np.ones(3)
+    if (P.flags & FLAG_SKY_MIS) and pay["depth"] > 0:
         pay["emitted"] = pay["emitted"] * power_heuristics(pay["pdf"], color_pdf[3])
     pay["depth"] = MAX_DEPTH
 
@@ -628,7 +634,8 @@ def closest_hit(S, luts, pay, rd, hit, rng, P):
     # ---- Surface.Initialize
     pos = M[:3, :3] @ (P1 * b[0] + P2 * b[1] + P3 * b[2]) + M[:3, 3]
     Ng = _norm(np.cross(P2 - P1, P3 - P1)); Ng = _norm(Ng @ Minv)      # mul(n, WorldToObject): row vector times the inverse
-    N = _norm(N1 * b[0] + N2 * b[1] + N3 * b[2]); N = _norm(N @ Minv)
+    geo = bool(P.flags & FLAG_GEOMETRY_NORMALS)
+    N = Ng.copy() if geo else _norm(_norm(N1 * b[0] + N2 * b[1] + N3 * b[2]) @ Minv)
     view = -rd
     inside = bool(np.dot(Ng, view) < 0.0)
     if inside:
@@ -636,8 +643,9 @@ def closest_hit(S, luts, pay, rd, hit, rng, P):
     up = np.array([0.0, 0.0, 1.0]) if abs(N[2]) < 0.9999999 else np.array([1.0, 0.0, 0.0])
     T = _norm(np.cross(up, N)); B = _norm(np.cross(N, T))
     md = S.materials[mat_id]
-    nm = S.tex(md["normal_texture"], uv)[:3] * 2.0 - 1.0                  # (the default normal map's texel is (128, 128, 255) / 255)
-    N = _norm(nm[0] * T + nm[1] * B + nm[2] * N)                          # TangentToWorld
+    if not geo:
+        nm = S.tex(md["normal_texture"], uv)[:3] * 2.0 - 1.0              # (the default normal map's texel is (128, 128, 255) / 255)
+        N = _norm(nm[0] * T + nm[1] * B + nm[2] * N)                      # TangentToWorld
     if np.dot(N, view) < 0.0:
         N = _norm(N - view * (np.dot(N, view) - 0.01))
     refl = _norm(-view - 2.0 * np.dot(N, -view) * N)
@@ -650,7 +658,9 @@ def closest_hit(S, luts, pay, rd, hit, rng, P):
     md["roughness"] = md["roughness"] * S.tex(md["roughness_texture"], uv)[0]
     md["metallic"] = md["metallic"] * S.tex(md["metallic_texture"], uv)[0]
     emissive = np.array(md["emissive_color"], np.float64) * S.tex(md["emissive_texture"], uv)[:3]
-    m = Mat64(md, luts, inside=inside, ec=True)
+    if P.flags & FLAG_FURNACE:   # Material.slang:78-86
+        md["base_color"] = np.ones(3); emissive = np.zeros(3); md["specular_color"] = (1.0, 1.0, 1.0); md["medium_color"] = (1.0, 1.0, 1.0)
+    m = Mat64(md, luts, inside=inside, ec=bool(P.flags & FLAG_ENERGY_COMPENSATION))
     is_light = bool((emissive > 0).any())
     rot = md["anisotropy_rotation"] * (np.pi / 180.0)
     T = T * np.cos(rot) + np.cross(N, T) * np.sin(rot) + N * np.dot(N, T) * (1.0 - np.cos(rot))
@@ -671,15 +681,17 @@ def closest_hit(S, luts, pay, rd, hit, rng, P):
                 pay["bxdf"] = np.array(pay["med_color"], np.float64)
                 return
     # ---- sky NEE (ClosestHit.slang:118-147): sample, then the visibility test from pos + N * 1e-5
-    to_sky, sky = sample_sky(S, rng, P)
-    sky[:3] = sky[:3] * P.sky_intensity            # the intensity is applied a second time here (:131), as upstream does
-    to_sky_t = w2t(to_sky) if np.isfinite(to_sky).all() and np.abs(to_sky).max() > 0 else np.zeros(3)
-    can_sky = S.closest(pos + N * 1e-5, to_sky, 0.0001, 1000000.0) is None
-    if not can_sky:
-        sky = np.zeros(4)
+    can_sky = False; sky = np.zeros(4); to_sky = np.zeros(3); to_sky_t = np.zeros(3)
+    if P.flags & FLAG_SKY_MIS:
+        to_sky, sky = sample_sky(S, rng, P)
+        sky[:3] = sky[:3] * P.sky_intensity            # the intensity is applied a second time here (:131), as upstream does
+        to_sky_t = w2t(to_sky) if np.isfinite(to_sky).all() and np.abs(to_sky).max() > 0 else np.zeros(3)
+        can_sky = S.closest(pos + N * 1e-5, to_sky, 0.0001, 1000000.0) is None
+        if not can_sky:
+            sky = np.zeros(4)
     # ---- light NEE (Sampler.slang:348-422)
     can_light = False; light_rgb = np.zeros(3); light_pdf = 0.0; to_light_t = None
-    if not is_light and S.emissive:
+    if (P.flags & FLAG_MESH_MIS) and not is_light and S.emissive:
         to_light, lc, e_inst, ti = sample_emissive(S, pos, rng)
         light_rgb, light_pdf = lc[:3], float(lc[3])
         if light_pdf > 0.0:
@@ -712,7 +724,9 @@ def closest_hit(S, luts, pay, rd, hit, rng, P):
     if can_light and not is_light:
         f, p = m.evaluate(V, to_light_t[None, :]); l_f, l_pdf = f[0], float(p[0])
     # ---- payload
-    if pay["depth"] == 0 and is_light:
+    if not (P.flags & FLAG_MESH_MIS):
+        pay["emitted"] = pay["emitted"] + emissive
+    elif pay["depth"] == 0 and is_light:
         pay["emitted"] = pay["emitted"] + emissive
     elif is_light:
         w1, w2_, w3 = (M[:3, :3] @ q + M[:3, 3] for q in (P1, P2, P3))

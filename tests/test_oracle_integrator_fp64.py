@@ -47,10 +47,11 @@ def variants(scenes, vpt_scenes, vpt_mod):
             "textured_viking_room": (viking, 5, 60, 2), "textured_boxes": (boxes, 5, 60, 2), "medium_in_glass": (murky, 10, 80, 2),
             "fog": (base, 8, 80, 2, fog), "two_boxes_environment": (sky, 8, 80, 2, two), "depth_of_field_3spf": (base, 6, 80, 2),
             "atmosphere": (base, 10, 120, 2), "atmosphere_with_fog": (base, 10, 120, 2, fog),
-            "fog_draine": (base, 8, 80, 2, fog), "fog_hg_plus_draine": (sky, 8, 80, 2, fog)}
+            "fog_draine": (base, 8, 80, 2, fog), "fog_hg_plus_draine": (sky, 8, 80, 2, fog),
+            "flags_no_mis_no_compensation": (sky, 6, 80, 2), "flags_geometry_normals_hidden_env": (sky, 6, 80, 2), "flags_furnace": (sky, 6, 80, 2)}
 
 
-@pytest.mark.parametrize("which", ["cornell_d6", "cornell_d12", "metal_anisotropic", "glass_sphere", "environment", "textured_viking_room", "textured_boxes", "medium_in_glass", "fog", "two_boxes_environment", "depth_of_field_3spf", "atmosphere", "atmosphere_with_fog", "fog_draine", "fog_hg_plus_draine"])
+@pytest.mark.parametrize("which", ["cornell_d6", "cornell_d12", "metal_anisotropic", "glass_sphere", "environment", "textured_viking_room", "textured_boxes", "medium_in_glass", "fog", "two_boxes_environment", "depth_of_field_3spf", "atmosphere", "atmosphere_with_fog", "fog_draine", "fog_hg_plus_draine", "flags_no_mis_no_compensation", "flags_geometry_normals_hidden_env", "flags_furnace"])
 def test_per_sample_values_match_the_float64_integrator(vpt, oracle, scenes, which):
     import ref_integrator64 as R
     v = variants(scenes, vpt.scenes, vpt)[which]
@@ -63,6 +64,12 @@ def test_per_sample_values_match_the_float64_integrator(vpt, oracle, scenes, whi
     luts = vpt.scenes.load_luts()
     if which == "depth_of_field_3spf":   # thin-lens offset on the camera plane, three samples per dispatch from one sampler
         P = vpt.default_params(max_depth=depth, dof_strength=0.6, focus_distance=14.0, samples_per_frame=3)
+    if which.startswith("flags_"):   # the reference's feature #defines (vpt_params.flags)
+        a = vpt._abi
+        fl = {"flags_no_mis_no_compensation": a.FLAGS_DEFAULT & ~(a.FLAG_SKY_MIS | a.FLAG_MESH_MIS | a.FLAG_ENERGY_COMPENSATION),
+              "flags_geometry_normals_hidden_env": (a.FLAGS_DEFAULT | a.FLAG_GEOMETRY_NORMALS) & ~a.FLAG_SHOW_ENV_DIRECTLY,
+              "flags_furnace": a.FLAGS_DEFAULT | a.FLAG_FURNACE}[which]
+        P = vpt.default_params(max_depth=depth, sky_azimuth=35.0, sky_altitude=-20.0, sky_intensity=1.5, flags=fl)
     atm = None
     if which.startswith("atmosphere"):   # Rayleigh / Mie / ozone delta tracking, one colour channel per path after the first collision, sun-disk NEE
         P = vpt.default_params(max_depth=depth, sky_altitude=-55.0, sky_azimuth=160.0)
