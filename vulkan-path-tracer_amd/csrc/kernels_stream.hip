@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256, 3) void k_shade_stream(DeviceScene sc, RenderP
             ShadeOut o;
             V3 thr_prev = v3s(0.0f);
             if (valid) {
-                const float4 a = ss.RA[parity][qi], b = ss.RB[parity][qi], t = ss.RT[parity][qi];
+                const float4 a = ld_stream(&ss.RA[parity][qi]), b = ld_stream(&ss.RB[parity][qi]), t = ld_stream(&ss.RT[parity][qi]);
                 ShadeIn in_;
                 in_.h = hrec;
                 in_.inst = in_.h.x < 0.0f ? 0u : ss.SHI[qi];
@@ -191,26 +191,26 @@ __global__ __launch_bounds__(256, 3) void k_shade_stream(DeviceScene sc, RenderP
             const uint32_t p_next = a_next.append(alive, &sctr->queue_len[parity ^ 1u].v);
             if (alive) {   // the survivor's records move to where its queue entry goes
                 queue_next[p_next] = slot;
-                ss.RA[parity ^ 1u][p_next] = f4u(o.new_o, o.rng);
-                ss.RB[parity ^ 1u][p_next] = f4u(o.new_d, o.new_depth | (o.in_medium ? 0x80000000u : 0u));
-                ss.RT[parity ^ 1u][p_next] = f4(o.thr, o.new_pdf);
+                st_stream(&ss.RA[parity ^ 1u][p_next], f4u(o.new_o, o.rng));
+                st_stream(&ss.RB[parity ^ 1u][p_next], f4u(o.new_d, o.new_depth | (o.in_medium ? 0x80000000u : 0u)));
+                st_stream(&ss.RT[parity ^ 1u][p_next], f4(o.thr, o.new_pdf));
             }
             const uint32_t p_sky = a_sky.append(want_sky, &sctr->sky_len.v);
             if (want_sky) {
-                ss.SKO[p_sky] = f4(o.sky_o, o.sky_d.x);
-                ss.SKD[p_sky] = make_float4(o.sky_d.y, o.sky_d.z, __uint_as_float(0xffffffffu), 0.0f);
+                st_stream(&ss.SKO[p_sky], f4(o.sky_o, o.sky_d.x));
+                st_stream(&ss.SKD[p_sky], make_float4(o.sky_d.y, o.sky_d.z, __uint_as_float(0xffffffffu), 0.0f));
             }
             const uint32_t p_light = a_light.append(want_light, &sctr->light_len.v);
             if (want_light) {
-                ss.LTO[p_light] = f4(o.light_o, o.light_d.x);
-                ss.LTD[p_light] = make_float4(o.light_d.y, o.light_d.z, __uint_as_float(o.light_gid), 0.0f);
+                st_stream(&ss.LTO[p_light], f4(o.light_o, o.light_d.x));
+                st_stream(&ss.LTD[p_light], make_float4(o.light_d.y, o.light_d.z, __uint_as_float(o.light_gid), 0.0f));
             }
             const uint32_t p_pend = a_pend.append(pending, &sctr->pend_len.v);
             if (pending) {
-                ss.PE[p_pend] = f4u(o.emitted, o.cflags);
-                ss.PS[p_pend] = f4u(o.csky, p_sky);
-                ss.PL[p_pend] = f4u(o.clight, p_light);
-                ss.PT[p_pend] = f4u(thr_prev, slot);
+                st_stream(&ss.PE[p_pend], f4u(o.emitted, o.cflags));
+                st_stream(&ss.PS[p_pend], f4u(o.csky, p_sky));
+                st_stream(&ss.PL[p_pend], f4u(o.clight, p_light));
+                st_stream(&ss.PT[p_pend], f4u(thr_prev, slot));
             }
             w_paths += (uint32_t)__popcll(__ballot(valid));
             w_alive += (uint32_t)__popcll(__ballot(alive));
@@ -278,10 +278,10 @@ __global__ __launch_bounds__(kTraverseBlock, 8) void k_trace_shadow(DeviceScene 
                 const unsigned long long m_idle = __ballot(cur == kLaneIdle);
                 const uint32_t i = w_next + lanes_below(m_idle);
                 if (cur == kLaneIdle && i < w_end) {
-                    const float4 rd = RD[i];
+                    const float4 rd = ld_stream(&RD[i]);
                     expect = __float_as_uint(rd.z);
                     if (expect != kRayHole) {
-                        const float4 ro = RO[i];
+                        const float4 ro = ld_stream(&RO[i]);
                         rid = i;
                         o = vptfp::v3(ro.x, ro.y, ro.z); d = vptfp::v3(ro.w, rd.x, rd.y); inv = safe_inverse(d);
                         tlim = tmax; visible = true;  // until an occluder / a closer triangle is found

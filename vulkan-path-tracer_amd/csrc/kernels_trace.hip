@@ -36,7 +36,7 @@ __device__ inline void load_ray(const TraceArgs& a, uint32_t i, uint32_t& rid, V
 __device__ inline uint32_t store_closest(const TraceArgs& a, const BvhTri* tris, uint32_t rid, bool found, float t, float u, float v, uint32_t slot) {
     uint32_t prim = 0xffffffffu, inst = 0xffffffffu;
     if (found) { prim = a.store_gid ? tris[slot].gid : tris[slot].prim; inst = tris[slot].inst; }
-    a.hit[rid] = make_float4(found ? t : -1.0f, found ? u : 0.0f, found ? v : 0.0f, __uint_as_float(prim));
+    st_stream(&a.hit[rid], make_float4(found ? t : -1.0f, found ? u : 0.0f, found ? v : 0.0f, __uint_as_float(prim)));
     a.hinst[rid] = inst;
     return inst;
 }
@@ -140,8 +140,8 @@ __global__ __launch_bounds__(kTraverseBlock, 8) void k_trace_vote(DeviceScene sc
                     qi = i;
                     if (rid == kHole) { if (a.cls) a.cls[i] = 0xffu; }   // a hole has no class: the classify step drops it
                     if (rid != kHole) {  // a hole: the tail of some wave's last chunk of the queue (vote.hpp WaveAppender)
-                        o = xyz4(a.ro[rid]);
-                        d = xyz4(a.rd[rid]);
+                        o = xyz4(ld_stream(&a.ro[rid]));
+                        d = xyz4(ld_stream(&a.rd[rid]));
                         if (a.normalize_dir) d = vptfp::normalize(d);  // RayGen.slang:70
                         inv = safe_inverse(d);
                         best_t = a.tmax; bslot = 0xffffffffu; bgid = 0xffffffffu;

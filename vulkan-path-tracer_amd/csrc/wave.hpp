@@ -31,4 +31,13 @@ __device__ inline uint32_t fetch_chunk(uint32_t n) {
     return c < 64u ? 64u : (c > 1024u ? 1024u : c);
 }
 
+// Stream records are written once and read once, a bounce later: stores and loads that bypass cache retention leave L2 to the
+// scene data (BVH nodes, triangles, textures) the kernels gather.
+__device__ __forceinline__ void st_stream(float4* p, float4 v) {
+    __builtin_nontemporal_store(v.x, &p->x); __builtin_nontemporal_store(v.y, &p->y); __builtin_nontemporal_store(v.z, &p->z); __builtin_nontemporal_store(v.w, &p->w);
+}
+__device__ __forceinline__ float4 ld_stream(const float4* p) {
+    return make_float4(__builtin_nontemporal_load(&p->x), __builtin_nontemporal_load(&p->y), __builtin_nontemporal_load(&p->z), __builtin_nontemporal_load(&p->w));
+}
+
 }  // namespace vpt
