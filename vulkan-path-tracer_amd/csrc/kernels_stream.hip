@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256, 3) void k_shade_stream(DeviceScene sc, RenderP
                 qi = i < n ? (order ? order[i] : i) : 0u;
                 slot = i < n ? queue[qi] : kHole;
                 valid = slot != kHole;
-                if (valid) hrec = ss.SH[qi];
+                if (valid) hrec = ld_stream(&ss.SH[qi]);
                 if (kRegroup) {   // each ring holds < 64 entries here, so 128 slots are enough
                     const bool is_hit = valid && !(hrec.x < 0.0f);
                     const unsigned long long mh = __ballot(is_hit), mm = __ballot(valid && !is_hit);
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256, 3) void k_shade_stream(DeviceScene sc, RenderP
                 const float4 a = ld_stream(&ss.RA[parity][qi]), b = ld_stream(&ss.RB[parity][qi]), t = ld_stream(&ss.RT[parity][qi]);
                 ShadeIn in_;
                 in_.h = hrec;
-                in_.inst = in_.h.x < 0.0f ? 0u : ss.SHI[qi];
+                in_.inst = in_.h.x < 0.0f ? 0u : __builtin_nontemporal_load(&ss.SHI[qi]);
                 in_.rng = __float_as_uint(a.w);
                 in_.porg = xyz(a); in_.pdir = xyz(b);
                 const uint32_t dw = __float_as_uint(b.w);
