@@ -351,7 +351,7 @@ __global__ __launch_bounds__(256) void k_join(RenderParams P, PathState ps, Stre
             }
             light = v3s(0.0f);  // a regenerated sample starts from pathLight = 0
         }
-        ps.L[sl] = f4(light, 0.0f);
+        st_stream(&ps.L[sl], f4(light, 0.0f));
     }
 }
 
