@@ -79,17 +79,11 @@ struct vpt_ctx {
     uint32_t class_present = 0x1fu;   // shade classes some instance of the scene belongs to (bit kShadeMiss always set): the others get no launch
     uint32_t stream_slack = 0;   // entries a stream may hold beyond its true count: unwritten chunk tails (vote.hpp WaveAppender)
     int shade_stream_blocks = 768, shadow_blocks = 2048;
-    // AUTO pipeline on a scene whose BVH does not fit LDS: the first four full batches are timed, staged and fused
-    // alternating (both produce identical bits; the first of each also pays its kernels' one-time load), and the
-    // pipeline with the smaller minimum is kept until the scene, size or params change.
     std::vector<vpt_volume> volumes;       // homogeneous box volumes (vpt_set_volumes)
     vpt_volume* d_volumes = nullptr;
     std::vector<DensityGrid> grids;        // device pointers inside (vpt_add_density_grid)
     DensityGrid* d_grids = nullptr;
     uint32_t phase = VPT_PHASE_HENYEY_GREENSTEIN;
-    int tune_state = 0;  // batches timed so far (even: staged next, odd: fused next); kTuneBatches = decided
-    bool auto_fused = false;
-    double tune_ms[2] = {1e30, 1e30};
     uint32_t* d_launch_off = nullptr;  // split-screen: launch-grid prefix sums of the dispatches of a batch
     int shade_blocks = 1024, primary_blocks = 768, max_blocks = 1536;
     int vote_blocks = 2048;   // persistent grid of the vote-scheduled traversal kernels
@@ -453,7 +447,9 @@ int render_batch(vpt_ctx* c, uint32_t frames, uint32_t dispatch_base) {
     // fused (one kernel per bounce, bounce 0 included) when the BVH rides in LDS; staged otherwise
     // volumes are integrated in the fused per-bounce kernel only
     const bool vol = !c->volumes.empty() || c->dsc.atm_on;
-    const bool fused = vol || c->cfg.pipeline == VPT_PIPELINE_FUSED || (c->cfg.pipeline == VPT_PIPELINE_AUTO && (c->lds_scene || c->auto_fused));
+    // AUTO: fused for LDS-resident scenes, the stream pipeline otherwise (atrium 1150 vs 575, glass bust 2410 vs 1290, Cornell box with
+    // the 960-triangle glass sphere 2880 vs 2600 Msamples/s: no scene measured prefers the fused kernel once its BVH lives in memory)
+    const bool fused = vol || c->cfg.pipeline == VPT_PIPELINE_FUSED || (c->cfg.pipeline == VPT_PIPELINE_AUTO && c->lds_scene);
     const bool stream = !fused && !c->lds_scene && !c->dsc.strict_hits && c->cfg.pipeline != VPT_PIPELINE_STAGED_R1;
     if (!fused && !stream) { int rl = ensure_legacy_buffers(c); if (rl != VPT_OK) return rl; }
     if (stream && c->cfg.pipeline == VPT_PIPELINE_STAGED_SORTED) { int rl = ensure_sorted_buffers(c); if (rl != VPT_OK) return rl; }
@@ -813,7 +809,6 @@ int vpt_set_scene(vpt_ctx* c, const vpt_scene_desc* sd) {
     if ((rc = upload(c, lr, &D.lut_r))) return rc;
     if ((rc = upload(c, lo, &D.lut_o))) return rc;
     if ((rc = upload(c, li, &D.lut_i))) return rc;
-    c->tune_state = 0; c->auto_fused = false; c->tune_ms[0] = c->tune_ms[1] = 1e30;
     c->trav_blocks = traverse_blocks_per_cu(c->lds_scene, D) * c->cu_count;
     c->shade_blocks = shade_blocks_per_cu() * c->cu_count;
     c->primary_blocks = bounce_blocks_per_cu(c->lds_scene, D) * c->cu_count;
@@ -886,7 +881,6 @@ int vpt_set_params(vpt_ctx* c, const vpt_params* p) {
     }
     const bool flags_changed = c->params.flags != p->flags;
     c->dsc.strict_hits = (p->flags & VPT_FLAG_LOCAL_HITS) ? 1u : 0u;
-    if (flags_changed || c->params.max_depth != p->max_depth) { c->tune_state = 0; c->auto_fused = false; c->tune_ms[0] = c->tune_ms[1] = 1e30; }
     c->params = *p;
     sync_params(c);
     reset_accum(c);
@@ -1022,17 +1016,8 @@ int vpt_render(vpt_ctx* c, uint32_t dispatches, int* done) {
         uint64_t frames_needed = ((uint64_t)c->params.max_samples + c->params.samples_per_frame - 1) / c->params.samples_per_frame;
         uint64_t disp_left = frames_needed * S2 - c->dispatch_count;
         uint32_t nf = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(left, c->frames_in_flight), disp_left);
-        constexpr int kTuneBatches = 4;
-        const bool tune = c->cfg.pipeline == VPT_PIPELINE_AUTO && !c->lds_scene && c->tune_state < kTuneBatches && nf == c->frames_in_flight;
-        if (tune) c->auto_fused = (c->tune_state & 1) != 0;
-        const auto t0 = std::chrono::steady_clock::now();
         int rc = render_batch(c, nf, (uint32_t)c->dispatch_count);  // returns with the stream drained
         if (rc) return rc;
-        if (tune) {
-            double& best = c->tune_ms[c->tune_state & 1];
-            best = std::min(best, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
-            c->auto_fused = ++c->tune_state == kTuneBatches && c->tune_ms[1] < c->tune_ms[0];
-        }
         c->dispatch_count += nf;
         c->frame_count = (uint32_t)(c->dispatch_count / S2);
         c->samples_accum = c->frame_count * c->params.samples_per_frame;
