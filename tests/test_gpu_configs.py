@@ -118,3 +118,14 @@ def test_config3_known_grazing_samples_with_strict_hits(vpt, oracle):
             g.set_params(Pk); g.render(1)
             assert np.array_equal(g.radiance()[y, x, :3], o.pixel_samples([x], [y], k, 1)[0, 0]), (x, y, k, brute)
     g.close(); o.close()
+
+
+def test_two_stream_schedule_equals_the_serial_one(vpt, atrium):
+    """The staged pipeline runs the shadow kernels and the join of bounce k beside the extend of bounce k + 1 (two HIP streams); with
+    vpt_config.profile every kernel runs alone.  Same image, bit for bit, and the overlapped schedule repeats itself."""
+    P = vpt.default_params(max_depth=8, max_samples=1 << 30)
+    imgs = []
+    for prof in (False, False, True):
+        g = vpt.PathTracer(640, 360, frames_in_flight=16, profile=prof, pipeline=2); g.set_scene(atrium); g.set_params(P)
+        g.render(48); imgs.append(g.radiance()); g.close()
+    assert np.array_equal(imgs[0], imgs[1]) and np.array_equal(imgs[0], imgs[2])
