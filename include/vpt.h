@@ -173,7 +173,12 @@ typedef struct vpt_config {
     uint32_t profile;    /* 1 = bracket every kernel launch with hipEvents (vpt_get_stats kernel times) */
     uint32_t count_traversal; /* 1 = count BVH node/triangle visits (slower; for the roofline's algorithmic bytes) */
     uint32_t pipeline;   /* VPT_PIPELINE_* */
+    uint32_t build_flags; /* VPT_BUILD_*: how vpt_set_scene builds the BVH of this context (reported back in vpt_stats.build_flags) */
 } vpt_config;
+
+/* Spatial splits in the BVH builder (bvh_build.hpp): identical images, pays on scenes of uneven triangle sizes only.
+ * Per context, never read from the environment: two contexts of one process cannot silently build different trees. */
+#define VPT_BUILD_SBVH 1u
 
 /* AUTO = FUSED when the BVH fits in LDS next to the traversal stacks, else STAGED. Results are identical. */
 #define VPT_PIPELINE_AUTO 0u
@@ -225,7 +230,7 @@ typedef struct vpt_stats {
     uint32_t frames_in_flight;
     uint32_t shard_pixels;
     uint32_t bvh8_nodes;       /* eight-wide nodes of the BVH8 experiment (0 until VPT_TRACE_VOTE8 was used) */
-    uint32_t reserved;
+    uint32_t build_flags;      /* VPT_BUILD_* the scene's BVH was built with */
 } vpt_stats;
 
 typedef struct vpt_ctx vpt_ctx;
@@ -239,9 +244,8 @@ const char* vpt_last_error(const vpt_ctx* ctx);
 
 /* PathTracer::SetScene (PathTracer.cpp:158-676): uploads geometry/materials/textures, derives the
  * emissive-mesh list (449-469) and the env importance/alias tables (1137-1332), builds the BVH
- * (replaces BLASBuilder/TLAS, 488-505), resets accumulation. Arrays are borrowed for the call only.
- * Experiment switch, read here: environment variable VPT_SBVH=1 builds the tree with spatial splits (bvh_build.hpp; identical
- * images, pays on scenes of uneven triangle sizes only). */
+ * (replaces BLASBuilder/TLAS, 488-505; builder options: vpt_config.build_flags), resets accumulation. Arrays are borrowed
+ * for the call only. */
 int vpt_set_scene(vpt_ctx* ctx, const vpt_scene_desc* scene);
 /* PathTracer::SetMaterial (PathTracer.cpp:712-810): patches one material, rebuilds the emissive list
  * if emission changed, resets accumulation. */

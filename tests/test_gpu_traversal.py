@@ -67,16 +67,15 @@ def test_empty_ray_list(vpt, scenes):
     g.close()
 
 
-def test_spatial_split_tree_renders_the_same_image(vpt, oracle, scenes, monkeypatch):
-    """VPT_SBVH=1 (read when the scene is set): the tree built with spatial splits references some triangles from several leaves;
+def test_spatial_split_tree_renders_the_same_image(vpt, oracle, scenes):
+    """vpt_config.build_flags = VPT_BUILD_SBVH: the tree built with spatial splits references some triangles from several leaves;
     closest hits, light-identity queries and therefore the image stay bit-identical to the oracle's (ties in t -> smaller global id)."""
     sc = scenes("viking_room")
     P = vpt.default_params(max_depth=6)
     o = oracle.Oracle(sc, 160, 90); o.set_params(P); o.render(3); ref = o.radiance(); o.close()
-    monkeypatch.setenv("VPT_SBVH", "1")
-    g = vpt.PathTracer(160, 90); g.set_scene(sc); g.set_params(P); g.render(3)
+    g = vpt.PathTracer(160, 90, build_flags=1); g.set_scene(sc); g.set_params(P); g.render(3)   # VPT_BUILD_SBVH
     img = g.radiance(); st = g.stats(); g.close()
-    monkeypatch.delenv("VPT_SBVH")
     h = vpt.PathTracer(160, 90); h.set_scene(sc); h.set_params(P); h.render(3); st0 = h.stats(); h.close()
+    assert st["build_flags"] == 1 and st0["build_flags"] == 0
     assert np.array_equal(img, ref)
     assert st["bvh_triangles"] > st0["bvh_triangles"] == sc.triangle_count()   # references multiplied, triangles did not

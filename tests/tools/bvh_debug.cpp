@@ -19,7 +19,7 @@ struct Slab { V3 o, inv; bool nx, ny, nz; };
 static float sinv(float d) { return (std::fabs(d) > 1e-30f) ? 1.0f / d : (std::signbit(d) ? -1e30f : 1e30f); }
 static const float kMiss = 3.0e38f;
 static void entries(const BvhNode& n, const Slab& r, float tmin, float tlimit, float t[4], float tn_[4], float tf_[4]) {
-    const float ax = u2f((n.exps & 0xffu) << 23) * r.inv.x, ay = u2f(((n.exps >> 8) & 0xffu) << 23) * r.inv.y, az = u2f(((n.exps >> 16) & 0xffu) << 23) * r.inv.z;
+    const float ax = n.step_x * r.inv.x, ay = n.step_y * r.inv.y, az = n.step_z * r.inv.z;
     const float bx = (n.origin[0] - r.o.x) * r.inv.x, by = (n.origin[1] - r.o.y) * r.inv.y, bz = (n.origin[2] - r.o.z) * r.inv.z;
     const uint32_t nxw = r.nx ? n.hi[0] : n.lo[0], fxw = r.nx ? n.lo[0] : n.hi[0];
     const uint32_t nyw = r.ny ? n.hi[1] : n.lo[1], fyw = r.ny ? n.lo[1] : n.hi[1];
@@ -112,8 +112,8 @@ int main(int argc, char** argv) {
                         if (has) {
                             float t[4], a[4], b[4]; entries(nodes[node], s, tmin, tmax, t, a, b);
                             const BvhNode& n = nodes[node];
-                            printf("  lvl %d node %d child %d: tn %.9g tf %.9g %s | exps %u %u %u origin %.9g %.9g %.9g lo %u %u %u hi %u %u %u\n", lvl, node, k, a[k], b[k], t[k] < kMiss ? "enter" : "CULLED",
-                                   n.exps & 255, (n.exps >> 8) & 255, (n.exps >> 16) & 255, n.origin[0], n.origin[1], n.origin[2], (n.lo[0] >> (8 * k)) & 255, (n.lo[1] >> (8 * k)) & 255, (n.lo[2] >> (8 * k)) & 255,
+                            printf("  lvl %d node %d child %d: tn %.9g tf %.9g %s | steps %.9g %.9g %.9g origin %.9g %.9g %.9g lo %u %u %u hi %u %u %u\n", lvl, node, k, a[k], b[k], t[k] < kMiss ? "enter" : "CULLED",
+                                   n.step_x, n.step_y, n.step_z, n.origin[0], n.origin[1], n.origin[2], (n.lo[0] >> (8 * k)) & 255, (n.lo[1] >> (8 * k)) & 255, (n.lo[2] >> (8 * k)) & 255,
                                    (n.hi[0] >> (8 * k)) & 255, (n.hi[1] >> (8 * k)) & 255, (n.hi[2] >> (8 * k)) & 255);
                             return true;
                         }

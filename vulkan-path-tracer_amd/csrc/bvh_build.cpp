@@ -295,8 +295,7 @@ void build_bvh(const std::vector<BvhTri>& tris_in, std::vector<BvhNode>& nodes_o
     const float pad = 2.0e-5f * maxabs + 1.0e-6f;
     auto empty_node = [&]() {
         BvhNode n; std::memset(&n, 0, sizeof(n));
-        n.exps = 1u | 1u << 8 | 1u << 16;
-        for (int a = 0; a < 3; a++) { n.lo[a] = 0xffffffffu; n.hi[a] = 0u; }  // inverted: never entered
+        for (int a = 0; a < 3; a++) { n.set_step(a, 1u); n.lo[a] = 0xffffffffu; n.hi[a] = 0u; }  // inverted: never entered
         for (int k = 0; k < 4; k++) n.child[k] = leaf_code(0, 1);
         return n;
     };
@@ -349,7 +348,7 @@ void build_bvh(const std::vector<BvhTri>& tris_in, std::vector<BvhNode>& nodes_o
             while (e < 254 && org + 255.0 * std::ldexp(1.0, e - 127) < (double)hi) e++;
             const double step = std::ldexp(1.0, e - 127);
             n.origin[a] = lo;
-            n.exps |= (uint32_t)e << (8 * a);
+            n.set_step(a, (uint32_t)e);
             uint32_t wl = 0xffffffffu, wh = 0u;
             for (int k = 0; k < nk; k++) {
                 const double cl = (double)(bx[k].lo[a] - pad), ch = (double)(bx[k].hi[a] + pad);
@@ -367,7 +366,6 @@ void build_bvh(const std::vector<BvhTri>& tris_in, std::vector<BvhNode>& nodes_o
     std::vector<Item> work;
     nodes_out.push_back(empty_node()); wide_out.push_back(empty_wide());
     if (b.nodes[0].left < 0) {
-        nodes_out[0].exps = 0;
         put_boxes(nodes_out[0], wide_out[0], &b.nodes[0].b, 1);
         nodes_out[0].child[0] = wide_out[0].child[0] = leaf_code(b.nodes[0].first, b.nodes[0].count);
     } else {
@@ -388,7 +386,6 @@ void build_bvh(const std::vector<BvhTri>& tris_in, std::vector<BvhNode>& nodes_o
         }
         Box boxes[4];
         for (int k = 0; k < nk; k++) boxes[k] = b.nodes[kids[k]].b;
-        nodes_out[it.out].exps = 0;
         put_boxes(nodes_out[it.out], wide_out[it.out], boxes, nk);
         for (int k = 0; k < nk; k++) {
             const TmpNode& c = b.nodes[kids[k]];

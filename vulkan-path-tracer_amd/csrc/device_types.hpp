@@ -13,17 +13,23 @@ using vptfp::V3;
 using vptfp::V4;
 
 // ---- BVH4, 64-byte nodes (two per cache line, 4 x dwordx4): the four child boxes are 8-bit offsets on a
-// per-node grid, plane = origin + q * 2^(e-127) per axis, rounded OUTWARD at build time so a decoded box always
-// contains the (already padded) fp32 child box.  One fetch decides four children.
+// per-node grid, plane = origin + q * step per axis with step a power of two, rounded OUTWARD at build time so a decoded box
+// always contains the (already padded) fp32 child box.  One fetch decides four children.  The steps are stored as the floats
+// themselves (2^(e-127), e in [1, 254]; round 2 packed the three exponents into one word and left 8 bytes of the node unused:
+// same values, six integer instructions more per visit).
 //   child >= 0: inner node index; child < 0: leaf, ~child = first<<3 | (count-1).
 // Unused slots hold the inverted box lo = 255, hi = 0 (empty interval on every axis) and a harmless leaf code.
 struct BvhNode {
     float origin[3];
-    uint32_t exps;     // biased exponents of the grid steps: ex | ey << 8 | ez << 16
+    float step_x;      // grid step along x
     uint32_t lo[3];    // per axis: byte k = lower plane of child k
     uint32_t hi[3];    // per axis: byte k = upper plane of child k
-    uint32_t pad[2];
+    float step_y, step_z;
     int32_t child[4];
+    __host__ __device__ void set_step(int axis, uint32_t biased_exponent) {
+        uint32_t bits = biased_exponent << 23; float f; __builtin_memcpy(&f, &bits, 4);
+        (axis == 0 ? step_x : axis == 1 ? step_y : step_z) = f;
+    }
 };
 static_assert(sizeof(BvhNode) == 64, "node is 64 B");
 

@@ -1,23 +1,22 @@
-// kernels_stream.hip — the staged pipeline's shade / shadow / join stages on compact streams.
+// kernels_stream.hip — the staged pipeline's shade / join stages on compact streams (the shadow stage's kernel, k_trace_shadow,
+// lives with the other traversal kernels in kernels_trace.hip).
 //
 //   shade   ClosestHit.slang + Miss.slang + the visibility-independent tail of the bounce loop (shade_core.hpp), one path
 //           per lane, persistent.  What a path leaves behind goes into streams by wave-private chunked appends (vote.hpp):
 //           its slot into the next ray queue if it lives on, a pending record (emission | flags, the two NEE contributions,
 //           the pre-update throughput) if anything has to be joined, and its <= 2 shadow rays into the sky-ray and
 //           light-ray streams — so a wave of the shadow stage sees rays of ONE kind, read as coalesced 32-byte records.
-//   shadow  RTCommon.slang:47-64 as exact any-hit searches (traverse.hpp) on the vote scheduler (vote.hpp), one ray per
-//           lane job; the answer is one byte per ray.
 //   join    RayGen.slang:92-128: visible NEE contributions joined with the emission BEFORE the luminance clamp, pathLight,
 //           NaN guard and frame sum at the end of a sample.
 //
-// Path records A, B, T, L, H stay addressed by slot (a path never moves), so nothing here can change a bit of the image.
+// The ray records (origin | rng, direction | depth, throughput | pdf) MOVE with a path's queue entry; its frame sum, pathLight and
+// medium stay addressed by slot, and every value is computed per path, so nothing here can change a bit of the image.
 #include "kernels.hpp"
 #include "shade_core.hpp"
 #include "vote.hpp"
 
 namespace vpt {
 
-constexpr uint32_t kRayHole = 0xfffffffeu;  // SKD.z / LTD.z of an entry nobody wrote
 
 // ------------------------------------------------------------------ classify: the shade queue, sorted by shade class
 // The extend stage leaves one class byte per queue entry (kShade*: miss | plain | textured | glass | emissive; 0xff for a
@@ -231,99 +230,6 @@ __global__ __launch_bounds__(256, 3) void k_shade_stream(DeviceScene sc, RenderP
     }
 }
 
-// ------------------------------------------------------------------ shadow rays
-// LIGHT = false: visible <=> nothing is hit (ClosestHit.slang:139, 344-353).  LIGHT = true: visible <=> the closest hit is
-// the sampled triangle (ClosestHit.slang:171-176, 358-370): that triangle is tested first by its own record, then the search
-// looks for anything that beats it (traverse.hpp closest_is).
-template <bool LIGHT, bool COUNT>
-__global__ __launch_bounds__(kTraverseBlock, 8) void k_trace_shadow(DeviceScene sc, const float4* RO, const float4* RD, unsigned char* vis, const uint32_t* n_dev,
-                                                                  uint32_t* head, Counters* ctr, uint32_t param) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    const LaneStack S = make_lane_stack(smem, sc.stack_overflow);
-    const BvhNode* const nodes = sc.nodes;
-    const BvhTri* const tris = sc.tris;
-    const uint32_t n = *n_dev;
-    const uint32_t chunk = fetch_chunk(n);
-    const uint32_t fetch_at = (param & 0xffu) ? (param & 0xffu) : 16u;
-    const bool weighted = ((param >> 8) & 1u) != 0u;
-    const float tmin = 0.0001f, tmax = 1000000.0f;  // RTCommon.slang:47-64
-    const uint32_t n_static = gridDim.x * (kTraverseBlock / 64u) * 64u;  // every wave starts on its own 64 entries, no atomic
-    uint32_t w_next = (blockIdx.x * (kTraverseBlock / 64u) + (threadIdx.x >> 6)) * 64u, w_end = w_next + 64u < n ? w_next + 64u : n;
-    if (w_next >= n) { w_next = 0u; w_end = 0u; }
-    bool exhausted = false;
-    int cur = kLaneIdle, sp = 0;
-    uint32_t rid = 0u, expect = 0xffffffffu;
-    bool visible = false;
-    V3 o = vptfp::v3(0.0f, 0.0f, 0.0f), d = o, inv = o;
-    float tlim = tmax;
-    uint32_t st_nodes = 0u, st_tris = 0u;
-    while (true) {   // one kind of step per iteration (kernels_trace.hip k_trace_vote)
-        const bool busy = cur < kLaneDone;
-        const bool at_node = busy && cur >= 0;
-        const bool at_leaf = busy && cur < 0;
-        const uint32_t nn = (uint32_t)__popcll(__ballot(at_node)), nl = (uint32_t)__popcll(__ballot(at_leaf));
-        if (!exhausted && (64u - nn - nl >= fetch_at || nn + nl == 0u)) {
-            if (cur == kLaneDone) { vis[rid] = visible ? 1 : 0; cur = kLaneIdle; }
-            if (w_next >= w_end) {
-                if (n_static >= n) exhausted = true;
-                else {
-                    uint32_t base = 0u;
-                    if (lane_id() == 0u) base = atomicAdd(head, chunk);
-                    base = n_static + __builtin_amdgcn_readfirstlane(base);
-                    if (base >= n) exhausted = true;
-                    else { w_next = base; w_end = base + chunk < n ? base + chunk : n; }
-                }
-            }
-            if (!exhausted) {
-                const unsigned long long m_idle = __ballot(cur == kLaneIdle);
-                const uint32_t i = w_next + lanes_below(m_idle);
-                if (cur == kLaneIdle && i < w_end) {
-                    const float4 rd = ld_stream(&RD[i]);
-                    expect = __float_as_uint(rd.z);
-                    if (expect != kRayHole) {
-                        const float4 ro = ld_stream(&RO[i]);
-                        rid = i;
-                        o = vptfp::v3(ro.x, ro.y, ro.z); d = vptfp::v3(ro.w, rd.x, rd.y); inv = safe_inverse(d);
-                        tlim = tmax; visible = true;  // until an occluder / a closer triangle is found
-                        sp = 0; cur = 0;
-                        if (LIGHT) {
-                            const uint32_t slot = sc.tri_slot_of_gid[expect];
-                            bool hit_it = false;
-                            if (slot != 0xffffffffu) {  // 0xffffffff: the sampled light triangle is a sliver, nothing can hit it
-                                const float4* q = reinterpret_cast<const float4*>(tris + slot);
-                                const float4 ta = q[0], tb = q[1], tc = q[2];
-                                if (COUNT) st_tris++;
-                                float u, v;
-                                hit_it = vptfp::ray_triangle(o, d, vptfp::v3(ta.x, ta.y, ta.z), vptfp::v3(ta.w, tb.x, tb.y), vptfp::v3(tb.z, tb.w, tc.x), tmin, tmax, &tlim, &u, &v);
-                            }
-                            if (!hit_it) { visible = false; cur = kLaneDone; }
-                        }
-                    }
-                }
-                const uint32_t want = (uint32_t)__popcll(m_idle), left = w_end - w_next;
-                w_next += want < left ? want : left;
-            }
-        } else if (nn + nl == 0u) {
-            break;
-        } else if (weighted ? nn > 2u * nl : nn >= nl) {
-            if (at_node) {
-                if (COUNT) st_nodes++;
-                vote_node_step<true>(nodes, S, cur, sp, o, inv, tmin, tlim);
-            }
-        } else {
-            if (at_leaf) {
-                if (COUNT) st_tris++;
-                if (vote_tri_step_any(tris, S, cur, sp, o, d, tmin, tmax, tlim, expect)) visible = false;
-            }
-        }
-    }
-    if (cur == kLaneDone) vis[rid] = visible ? 1 : 0;
-    if (COUNT) {
-        atomicAdd(&ctr->stat_shadow_nodes, (unsigned long long)st_nodes);
-        atomicAdd(&ctr->stat_shadow_tris, (unsigned long long)st_tris);
-    }
-}
-
 // ------------------------------------------------------------------ join
 __global__ __launch_bounds__(256) void k_join(RenderParams P, PathState ps, StreamState ss, const StreamCounters* sctr) {
     const uint32_t n = sctr->pend_len.v;
@@ -423,18 +329,6 @@ void launch_shade_stream(hipStream_t s, uint32_t blocks, uint32_t cls, bool sort
     else if (cls == kShadePlain) hipLaunchKernelGGL((k_shade_stream<(int)kShadePlain>), g, b, 0, s, sc, P, ps, ss, queue, order, queue_next, ctr, sctr, parity, cls);
     else hipLaunchKernelGGL((k_shade_stream<(int)kShadeTextured>), g, b, 0, s, sc, P, ps, ss, queue, order, queue_next, ctr, sctr, parity, cls);  // textured, glass, emissive: the general hit code
 }
-void launch_trace_shadow(hipStream_t s, uint32_t blocks, bool light, bool count, const DeviceScene& sc, const StreamState& ss, Counters* ctr,
-                         StreamCounters* sctr, uint32_t param) {
-    const size_t lds = kVoteStackBytes;
-    const dim3 g(blocks), b(kTraverseBlock);
-    if (light) {
-        if (count) hipLaunchKernelGGL((k_trace_shadow<true, true>), g, b, lds, s, sc, ss.LTO, ss.LTD, ss.vis_light, &sctr->light_len.v, &sctr->light_head.v, ctr, param);
-        else hipLaunchKernelGGL((k_trace_shadow<true, false>), g, b, lds, s, sc, ss.LTO, ss.LTD, ss.vis_light, &sctr->light_len.v, &sctr->light_head.v, ctr, param);
-    } else {
-        if (count) hipLaunchKernelGGL((k_trace_shadow<false, true>), g, b, lds, s, sc, ss.SKO, ss.SKD, ss.vis_sky, &sctr->sky_len.v, &sctr->sky_head.v, ctr, param);
-        else hipLaunchKernelGGL((k_trace_shadow<false, false>), g, b, lds, s, sc, ss.SKO, ss.SKD, ss.vis_sky, &sctr->sky_len.v, &sctr->sky_head.v, ctr, param);
-    }
-}
 void launch_join(hipStream_t s, uint32_t blocks, const RenderParams& P, const PathState& ps, const StreamState& ss, const StreamCounters* sctr) {
     hipLaunchKernelGGL(k_join, dim3(blocks), dim3(256), 0, s, P, ps, ss, sctr);
 }
@@ -443,13 +337,4 @@ int shade_stream_blocks_per_cu() {
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_shade_stream<kShadeAny>, 256, 0);
     return nb > 0 ? nb : 1;
 }
-int trace_shadow_blocks_per_cu() {
-    int a = 0, b = 0;
-    const size_t lds = kVoteStackBytes;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_trace_shadow<true, false>, kTraverseBlock, lds);
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_trace_shadow<false, false>, kTraverseBlock, lds);
-    int nb = a < b ? a : b;
-    return nb > 0 ? nb : 1;
-}
-
 }  // namespace vpt

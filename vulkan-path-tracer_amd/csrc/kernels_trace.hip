@@ -83,7 +83,9 @@ __global__ __launch_bounds__(kTraverseBlock, 8) void k_trace_base(DeviceScene sc
 // Lane state: `cur` >= 0 inner node to visit; < 0 leaf code ~(first << 3 | count - 1) with `first` advancing as the
 // triangles are consumed; kLaneDone / kLaneIdle.  The wave owns a chunk [w_next, w_end) of the stream (one atomic per
 // chunk) and deals its entries to idle lanes in fetch steps.
-template <bool ANY, bool COUNT, bool WIDE8>
+// TUNED: the vote parameters are the compile-time defaults (fetch step at 16 idle lanes, weighted vote: kVoteParamDefault), which
+// the pipeline always uses; the lab's other settings go through the instantiation that reads them from a.param.
+template <bool ANY, bool COUNT, bool WIDE8, bool TUNED>
 __global__ __launch_bounds__(kTraverseBlock, 8) void k_trace_vote(DeviceScene sc, TraceArgs a, Counters* ctr) {
     extern __shared__ __align__(16) unsigned char smem[];
     const LaneStack S = make_lane_stack(smem, sc.stack_overflow);
@@ -91,12 +93,15 @@ __global__ __launch_bounds__(kTraverseBlock, 8) void k_trace_vote(DeviceScene sc
     const BvhTri* const tris = sc.tris;
     const uint32_t n = a.n_dev ? *a.n_dev : a.n;
     const uint32_t chunk = fetch_chunk(n);
-    const uint32_t fetch_at = (a.param & 0xffu) ? (a.param & 0xffu) : 16u;  // idle lanes that trigger a fetch step (64: only when all are idle)
-    const bool weighted = ((a.param >> 8) & 1u) != 0u;  // vote by lanes served per instruction issued: a triangle step costs about half a node step
+    const uint32_t fetch_at = TUNED ? 16u : (a.param & 0xffu) ? (a.param & 0xffu) : 16u;  // idle lanes that trigger a fetch step (64: only when all are idle)
+    const bool weighted = TUNED || ((a.param >> 8) & 1u) != 0u;  // vote by lanes served per instruction issued: a triangle step costs about half a node step
     // every wave starts on its own 64 entries without an atomic (8192 waves fetching at once would queue ~90 us on the cursor);
     // entries beyond the grid's static part are fetched chunk-wise through the cursor
     const uint32_t n_static = gridDim.x * (kTraverseBlock / 64u) * 64u;
-    uint32_t w_next = (blockIdx.x * (kTraverseBlock / 64u) + (threadIdx.x >> 6)) * 64u, w_end = w_next + 64u < n ? w_next + 64u : n;
+    // wave-uniform on purpose (readfirstlane): with the wave index taken from threadIdx the compiler must treat the chunk bounds, and
+    // through them `exhausted` and every branch of the vote loop, as divergent, which turns the loop into exec-masked regions with
+    // ~48 register copies per iteration at their joins (profiles/r03_trace_isa_budget.md)
+    uint32_t w_next = __builtin_amdgcn_readfirstlane((blockIdx.x * (kTraverseBlock / 64u) + (threadIdx.x >> 6)) * 64u), w_end = w_next + 64u < n ? w_next + 64u : n;
     if (w_next >= n) { w_next = 0u; w_end = 0u; }
     bool exhausted = false;
     int cur = kLaneIdle, sp = 0;
@@ -107,66 +112,77 @@ __global__ __launch_bounds__(kTraverseBlock, 8) void k_trace_vote(DeviceScene sc
     uint32_t qi = 0u;  // the ray's position in the queue: where its shade class goes (a.cls)
     // Vote loop: one kind of step per iteration.  (Giving each kind its own inner loop, which lets the lane state stay in fixed
     // registers across the back edge, was measured 5-7 % slower on closest-hit rays: the vote then sticks to a kind for too long.)
+    // The fetch step sits in an OUTER loop and the node / triangle steps in an inner one that re-votes every iteration: the ray
+    // (o, d, inv, rid, qi) is then loop-invariant where the steps run, and the compiler no longer copies the whole lane state
+    // between two register sets on every iteration (29 v_mov per step before, profiles/r03_trace_isa_budget.md).
     while (true) {
-        const bool busy = cur < kLaneDone;
-        const bool at_node = busy && cur >= 0;
-        const bool at_leaf = busy && cur < 0;
-        const uint32_t nn = (uint32_t)__popcll(__ballot(at_node)), nl = (uint32_t)__popcll(__ballot(at_leaf));
-        if (!exhausted && (64u - nn - nl >= fetch_at || nn + nl == 0u)) {
-            // ---- fetch step: retire finished rays, deal new ones to the idle lanes
-            if (cur == kLaneDone) {
-                if (ANY) a.hit[rid] = make_float4(bslot != 0xffffffffu ? 1.0f : -1.0f, 0.0f, 0.0f, 0.0f);
-                else {
-                    const uint32_t inst = store_closest(a, tris, rid, bslot != 0xffffffffu, best_t, bu, bv, bslot);
-                    if (a.cls) a.cls[qi] = bslot != 0xffffffffu ? sc.inst_class[inst] : (unsigned char)kShadeMiss;  // the shade-queue sort key
-                }
-                cur = kLaneIdle;
-            }
-            if (w_next >= w_end) {
-                if (n_static >= n) exhausted = true;
-                else {
-                    uint32_t base = 0;
-                    if (lane_id() == 0) base = atomicAdd(a.head, chunk);
-                    base = n_static + __builtin_amdgcn_readfirstlane(base);
-                    if (base >= n) exhausted = true;
-                    else { w_next = base; w_end = base + chunk < n ? base + chunk : n; }
-                }
-            }
-            if (!exhausted) {
-                const unsigned long long m_idle = __ballot(cur == kLaneIdle);
-                const uint32_t i = w_next + lanes_below(m_idle);
-                if (cur == kLaneIdle && i < w_end) {
-                    rid = a.order ? a.order[i] : (a.valid && a.valid[i] == kHole) ? kHole : i;
-                    qi = i;
-                    if (rid == kHole) { if (a.cls) a.cls[i] = 0xffu; }   // a hole has no class: the classify step drops it
-                    if (rid != kHole) {  // a hole: the tail of some wave's last chunk of the queue (vote.hpp WaveAppender)
-                        o = xyz4(ld_stream(&a.ro[rid]));
-                        d = xyz4(ld_stream(&a.rd[rid]));
-                        if (a.normalize_dir) d = vptfp::normalize(d);  // RayGen.slang:70
-                        inv = safe_inverse(d);
-                        best_t = a.tmax; bslot = 0xffffffffu; bgid = 0xffffffffu;
-                        sp = 0; cur = 0;  // root
-                    }
-                }
-                const uint32_t want = (uint32_t)__popcll(m_idle), left = w_end - w_next;
-                w_next += want < left ? want : left;
-            }
-        } else if (nn + nl == 0u) {
-            break;
-        } else if (weighted ? nn > 2u * nl : nn >= nl) {
-            if (at_node) {  // ---- inner-node step
+        uint32_t nn, nl;
+        while (true) {
+            VPT_MARK("vote");
+            const bool busy = cur < kLaneDone;
+            const bool at_node = busy && cur >= 0;
+            const bool at_leaf = busy && cur < 0;
+            nn = (uint32_t)__popcll(__ballot(at_node)); nl = (uint32_t)__popcll(__ballot(at_leaf));
+            if ((!exhausted && 64u - nn - nl >= fetch_at) || nn + nl == 0u) break;
+            const bool node_wins = weighted ? nn > 2u * nl : nn >= nl;
+            // two predicated regions in sequence rather than if / else on the (uniform) vote: the if / else form is compiled into a
+            // flag-linked pair of regions that hands the lane state from one register set to another and back (14 v_mov per step)
+            VPT_MARK("node");
+            if (node_wins & at_node) {  // ---- inner-node step
                 if (COUNT) st_nodes++;
                 if (WIDE8) vote_node8_step(sc.nodes8, S, cur, sp, o, inv, a.tmin, best_t);
                 else vote_node_step<ANY>(nodes, S, cur, sp, o, inv, a.tmin, best_t);
             }
-        } else {
-            if (at_leaf) {  // ---- triangle step: ONE triangle of the lane's leaf
+            VPT_MARK("tri");
+            if (!node_wins & at_leaf) {  // ---- triangle step: ONE triangle of the lane's leaf
                 if (COUNT) st_tris++;
                 if (ANY) { if (vote_tri_step_any(tris, S, cur, sp, o, d, a.tmin, a.tmax, a.tmax, 0xffffffffu)) bslot = 0u; }
                 else vote_tri_step_closest(tris, S, cur, sp, o, d, a.tmin, a.tmax, best_t, bu, bv, bslot, bgid);
             }
         }
+        VPT_MARK("exit");
+        if (exhausted) break;   // nothing left to fetch and (inner loop's exit) no lane busy
+        VPT_MARK("fetch");
+        // ---- fetch step: retire finished rays, deal new ones to the idle lanes
+        if (cur == kLaneDone) {
+            if (ANY) a.hit[rid] = make_float4(bslot != 0xffffffffu ? 1.0f : -1.0f, 0.0f, 0.0f, 0.0f);
+            else {
+                const uint32_t inst = store_closest(a, tris, rid, bslot != 0xffffffffu, best_t, bu, bv, bslot);
+                if (a.cls) a.cls[qi] = bslot != 0xffffffffu ? sc.inst_class[inst] : (unsigned char)kShadeMiss;  // the shade-queue sort key
+            }
+            cur = kLaneIdle;
+        }
+        if (w_next >= w_end) {
+            if (n_static >= n) exhausted = true;
+            else {
+                uint32_t base = 0;
+                if (lane_id() == 0) base = atomicAdd(a.head, chunk);
+                base = n_static + __builtin_amdgcn_readfirstlane(base);
+                if (base >= n) exhausted = true;
+                else { w_next = base; w_end = base + chunk < n ? base + chunk : n; }
+            }
+        }
+        if (!exhausted) {
+            const unsigned long long m_idle = __ballot(cur == kLaneIdle);
+            const uint32_t i = w_next + lanes_below(m_idle);
+            if (cur == kLaneIdle && i < w_end) {
+                rid = a.order ? a.order[i] : (a.valid && a.valid[i] == kHole) ? kHole : i;
+                qi = i;
+                if (rid == kHole) { if (a.cls) a.cls[i] = 0xffu; }   // a hole has no class: the classify step drops it
+                if (rid != kHole) {  // a hole: the tail of some wave's last chunk of the queue (vote.hpp WaveAppender)
+                    o = xyz4(ld_stream(&a.ro[rid]));
+                    d = xyz4(ld_stream(&a.rd[rid]));
+                    if (a.normalize_dir) d = vptfp::normalize(d);  // RayGen.slang:70
+                    inv = safe_inverse(d);
+                    best_t = a.tmax; bslot = 0xffffffffu; bgid = 0xffffffffu;
+                    sp = 0; cur = 0;  // root
+                }
+            }
+            const uint32_t want = (uint32_t)__popcll(m_idle), left = w_end - w_next;
+            w_next += want < left ? want : left;
+        }
     }
+    VPT_MARK("done");
     if (cur == kLaneDone) {  // rays that finished after the stream ran dry
         if (ANY) a.hit[rid] = make_float4(bslot != 0xffffffffu ? 1.0f : -1.0f, 0.0f, 0.0f, 0.0f);
         else {
@@ -180,6 +196,105 @@ __global__ __launch_bounds__(kTraverseBlock, 8) void k_trace_vote(DeviceScene sc
     }
 }
 
+// ------------------------------------------------------------------ shadow rays
+// LIGHT = false: visible <=> nothing is hit (ClosestHit.slang:139, 344-353).  LIGHT = true: visible <=> the closest hit is
+// the sampled triangle (ClosestHit.slang:171-176, 358-370): that triangle is tested first by its own record, then the search
+// looks for anything that beats it (traverse.hpp closest_is).
+template <bool LIGHT, bool COUNT, bool TUNED>
+__global__ __launch_bounds__(kTraverseBlock, 8) void k_trace_shadow(DeviceScene sc, const float4* RO, const float4* RD, unsigned char* vis, const uint32_t* n_dev,
+                                                                  uint32_t* head, Counters* ctr, uint32_t param) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const LaneStack S = make_lane_stack(smem, sc.stack_overflow);
+    const BvhNode* const nodes = sc.nodes;
+    const BvhTri* const tris = sc.tris;
+    const uint32_t n = *n_dev;
+    const uint32_t chunk = fetch_chunk(n);
+    const uint32_t fetch_at = TUNED ? 16u : (param & 0xffu) ? (param & 0xffu) : 16u;
+    const bool weighted = TUNED || ((param >> 8) & 1u) != 0u;
+    const float tmin = 0.0001f, tmax = 1000000.0f;  // RTCommon.slang:47-64
+    const uint32_t n_static = gridDim.x * (kTraverseBlock / 64u) * 64u;  // every wave starts on its own 64 entries, no atomic
+    // wave-uniform by construction (see k_trace_vote)
+    uint32_t w_next = __builtin_amdgcn_readfirstlane((blockIdx.x * (kTraverseBlock / 64u) + (threadIdx.x >> 6)) * 64u), w_end = w_next + 64u < n ? w_next + 64u : n;
+    if (w_next >= n) { w_next = 0u; w_end = 0u; }
+    bool exhausted = false;
+    int cur = kLaneIdle, sp = 0;
+    uint32_t rid = 0u, expect = 0xffffffffu;
+    bool visible = false;
+    V3 o = vptfp::v3(0.0f, 0.0f, 0.0f), d = o, inv = o;
+    float tlim = tmax;
+    uint32_t st_nodes = 0u, st_tris = 0u;
+    while (true) {   // fetch steps outside, node / triangle steps in the inner loop, one kind per iteration (kernels_trace.hip k_trace_vote)
+        while (true) {
+            VPT_MARK("vote");
+            const bool busy = cur < kLaneDone;
+            const bool at_node = busy && cur >= 0;
+            const bool at_leaf = busy && cur < 0;
+            const uint32_t nn = (uint32_t)__popcll(__ballot(at_node)), nl = (uint32_t)__popcll(__ballot(at_leaf));
+            if ((!exhausted && 64u - nn - nl >= fetch_at) || nn + nl == 0u) break;
+            const bool node_wins = weighted ? nn > 2u * nl : nn >= nl;
+            VPT_MARK("node");   // two predicated regions in sequence, not if / else (see k_trace_vote)
+            if (node_wins & at_node) {
+                if (COUNT) st_nodes++;
+                vote_node_step<true>(nodes, S, cur, sp, o, inv, tmin, tlim);
+            }
+            VPT_MARK("tri");
+            if (!node_wins & at_leaf) {
+                if (COUNT) st_tris++;
+                if (vote_tri_step_any(tris, S, cur, sp, o, d, tmin, tmax, tlim, expect)) visible = false;
+            }
+        }
+        VPT_MARK("exit");
+        if (exhausted) break;
+        VPT_MARK("fetch");
+        if (cur == kLaneDone) { vis[rid] = visible ? 1 : 0; cur = kLaneIdle; }
+        if (w_next >= w_end) {
+            if (n_static >= n) exhausted = true;
+            else {
+                uint32_t base = 0u;
+                if (lane_id() == 0u) base = atomicAdd(head, chunk);
+                base = n_static + __builtin_amdgcn_readfirstlane(base);
+                if (base >= n) exhausted = true;
+                else { w_next = base; w_end = base + chunk < n ? base + chunk : n; }
+            }
+        }
+        if (!exhausted) {
+            const unsigned long long m_idle = __ballot(cur == kLaneIdle);
+            const uint32_t i = w_next + lanes_below(m_idle);
+            if (cur == kLaneIdle && i < w_end) {
+                const float4 rd = ld_stream(&RD[i]);
+                expect = __float_as_uint(rd.z);
+                if (expect != kRayHole) {
+                    const float4 ro = ld_stream(&RO[i]);
+                    rid = i;
+                    o = vptfp::v3(ro.x, ro.y, ro.z); d = vptfp::v3(ro.w, rd.x, rd.y); inv = safe_inverse(d);
+                    tlim = tmax; visible = true;  // until an occluder / a closer triangle is found
+                    sp = 0; cur = 0;
+                    if (LIGHT) {
+                        const uint32_t slot = sc.tri_slot_of_gid[expect];
+                        bool hit_it = false;
+                        if (slot != 0xffffffffu) {  // 0xffffffff: the sampled light triangle is a sliver, nothing can hit it
+                            const float4* q = reinterpret_cast<const float4*>(tris + slot);
+                            const float4 ta = q[0], tb = q[1], tc = q[2];
+                            if (COUNT) st_tris++;
+                            float u, v;
+                            hit_it = vptfp::ray_triangle(o, d, vptfp::v3(ta.x, ta.y, ta.z), vptfp::v3(ta.w, tb.x, tb.y), vptfp::v3(tb.z, tb.w, tc.x), tmin, tmax, &tlim, &u, &v);
+                        }
+                        if (!hit_it) { visible = false; cur = kLaneDone; }
+                    }
+                }
+            }
+            const uint32_t want = (uint32_t)__popcll(m_idle), left = w_end - w_next;
+            w_next += want < left ? want : left;
+        }
+    }
+    VPT_MARK("done");
+    if (cur == kLaneDone) vis[rid] = visible ? 1 : 0;
+    if (COUNT) {
+        atomicAdd(&ctr->stat_shadow_nodes, (unsigned long long)st_nodes);
+        atomicAdd(&ctr->stat_shadow_tris, (unsigned long long)st_tris);
+    }
+}
+
 // ------------------------------------------------------------------ launch
 int trace_blocks_per_cu(uint32_t variant, bool any) {
     int nb = 0;
@@ -188,11 +303,11 @@ int trace_blocks_per_cu(uint32_t variant, bool any) {
         if (any) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_base<true, false>, kTraverseBlock, lds);
         else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_base<false, false>, kTraverseBlock, lds);
     } else if (variant == VPT_TRACE_VOTE8) {
-        if (any) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_vote<true, false, true>, kTraverseBlock, lds);
-        else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_vote<false, false, true>, kTraverseBlock, lds);
+        if (any) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_vote<true, false, true, false>, kTraverseBlock, lds);
+        else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_vote<false, false, true, false>, kTraverseBlock, lds);
     } else {
-        if (any) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_vote<true, false, false>, kTraverseBlock, lds);
-        else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_vote<false, false, false>, kTraverseBlock, lds);
+        if (any) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_vote<true, false, false, true>, kTraverseBlock, lds);
+        else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_vote<false, false, false, true>, kTraverseBlock, lds);
     }
     return nb > 0 ? nb : 1;
 }
@@ -202,11 +317,38 @@ void launch_trace(hipStream_t s, uint32_t blocks, uint32_t variant, bool any, bo
     const dim3 g(blocks), b(kTraverseBlock);
 #define VPT_LT(K) do { if (any) { if (count) hipLaunchKernelGGL((K<true, true>), g, b, lds, s, sc, a, ctr); else hipLaunchKernelGGL((K<true, false>), g, b, lds, s, sc, a, ctr); } \
                        else { if (count) hipLaunchKernelGGL((K<false, true>), g, b, lds, s, sc, a, ctr); else hipLaunchKernelGGL((K<false, false>), g, b, lds, s, sc, a, ctr); } } while (0)
-#define VPT_LV(W) do { if (any) { if (count) hipLaunchKernelGGL((k_trace_vote<true, true, W>), g, b, lds, s, sc, a, ctr); else hipLaunchKernelGGL((k_trace_vote<true, false, W>), g, b, lds, s, sc, a, ctr); } \
-                       else { if (count) hipLaunchKernelGGL((k_trace_vote<false, true, W>), g, b, lds, s, sc, a, ctr); else hipLaunchKernelGGL((k_trace_vote<false, false, W>), g, b, lds, s, sc, a, ctr); } } while (0)
-    if (variant == VPT_TRACE_BASE) VPT_LT(k_trace_base); else if (variant == VPT_TRACE_VOTE8) VPT_LV(true); else VPT_LV(false);
+#define VPT_LV(W, T) do { if (any) { if (count) hipLaunchKernelGGL((k_trace_vote<true, true, W, T>), g, b, lds, s, sc, a, ctr); else hipLaunchKernelGGL((k_trace_vote<true, false, W, T>), g, b, lds, s, sc, a, ctr); } \
+                          else { if (count) hipLaunchKernelGGL((k_trace_vote<false, true, W, T>), g, b, lds, s, sc, a, ctr); else hipLaunchKernelGGL((k_trace_vote<false, false, W, T>), g, b, lds, s, sc, a, ctr); } } while (0)
+    if (variant == VPT_TRACE_BASE) VPT_LT(k_trace_base); else if (variant == VPT_TRACE_VOTE8) VPT_LV(true, false);
+    else if (a.param == kVoteParamDefault) VPT_LV(false, true); else VPT_LV(false, false);
 #undef VPT_LV
 #undef VPT_LT
+}
+
+void launch_trace_shadow(hipStream_t s, uint32_t blocks, bool light, bool count, const DeviceScene& sc, const StreamState& ss, Counters* ctr,
+                         StreamCounters* sctr, uint32_t param) {
+    const size_t lds = kVoteStackBytes;
+    const dim3 g(blocks), b(kTraverseBlock);
+#define VPT_LS(L, C, T, RO, RD, VIS, LEN, HEAD) hipLaunchKernelGGL((k_trace_shadow<L, C, T>), g, b, lds, s, sc, RO, RD, VIS, LEN, HEAD, ctr, param)
+    const bool tuned = param == kVoteParamDefault && !count;
+    if (light) {
+        if (tuned) VPT_LS(true, false, true, ss.LTO, ss.LTD, ss.vis_light, &sctr->light_len.v, &sctr->light_head.v);
+        else if (count) VPT_LS(true, true, false, ss.LTO, ss.LTD, ss.vis_light, &sctr->light_len.v, &sctr->light_head.v);
+        else VPT_LS(true, false, false, ss.LTO, ss.LTD, ss.vis_light, &sctr->light_len.v, &sctr->light_head.v);
+    } else {
+        if (tuned) VPT_LS(false, false, true, ss.SKO, ss.SKD, ss.vis_sky, &sctr->sky_len.v, &sctr->sky_head.v);
+        else if (count) VPT_LS(false, true, false, ss.SKO, ss.SKD, ss.vis_sky, &sctr->sky_len.v, &sctr->sky_head.v);
+        else VPT_LS(false, false, false, ss.SKO, ss.SKD, ss.vis_sky, &sctr->sky_len.v, &sctr->sky_head.v);
+    }
+#undef VPT_LS
+}
+int trace_shadow_blocks_per_cu() {
+    int a = 0, b = 0;
+    const size_t lds = kVoteStackBytes;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_trace_shadow<true, false, true>, kTraverseBlock, lds);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_trace_shadow<false, false, true>, kTraverseBlock, lds);
+    int nb = a < b ? a : b;
+    return nb > 0 ? nb : 1;
 }
 
 }  // namespace vpt

@@ -55,13 +55,13 @@ __device__ inline TravStack make_stack(unsigned char* smem, uint32_t* overflow) 
 
 struct NodeData {
     float ox, oy, oz;
-    uint32_t exps;
+    float sx, sy, sz;   // grid steps (powers of two)
     uint32_t lox, loy, loz, hix, hiy, hiz;
     int c0, c1, c2, c3;
 };
 __device__ inline void unpack_node(const uint4& w0, const uint4& w1, const uint4& w2, const uint4& w3, NodeData& n) {
-    n.ox = __uint_as_float(w0.x); n.oy = __uint_as_float(w0.y); n.oz = __uint_as_float(w0.z); n.exps = w0.w;
-    n.lox = w1.x; n.loy = w1.y; n.loz = w1.z; n.hix = w1.w; n.hiy = w2.x; n.hiz = w2.y;
+    n.ox = __uint_as_float(w0.x); n.oy = __uint_as_float(w0.y); n.oz = __uint_as_float(w0.z); n.sx = __uint_as_float(w0.w);
+    n.lox = w1.x; n.loy = w1.y; n.loz = w1.z; n.hix = w1.w; n.hiy = w2.x; n.hiz = w2.y; n.sy = __uint_as_float(w2.z); n.sz = __uint_as_float(w2.w);
     n.c0 = (int)w3.x; n.c1 = (int)w3.y; n.c2 = (int)w3.z; n.c3 = (int)w3.w;
 }
 
@@ -134,9 +134,7 @@ template <int K> __device__ inline float byte_f(uint32_t w) { return (float)((w 
 // ray-to-node distance, which the build-time padding of every box covers.  The near/far byte is picked by the
 // sign of the direction, so an inverted (unused) slot gives near > far on every axis and is never entered.
 __device__ inline void node_entries(const NodeData& n, const RaySlab& r, float tmin, float tlimit, float& t0, float& t1, float& t2, float& t3) {
-    const float ax = __uint_as_float((n.exps & 0xffu) << 23) * r.inv.x;
-    const float ay = __uint_as_float(((n.exps >> 8) & 0xffu) << 23) * r.inv.y;
-    const float az = __uint_as_float(((n.exps >> 16) & 0xffu) << 23) * r.inv.z;
+    const float ax = n.sx * r.inv.x, ay = n.sy * r.inv.y, az = n.sz * r.inv.z;
     const float bx = (n.ox - r.o.x) * r.inv.x, by = (n.oy - r.o.y) * r.inv.y, bz = (n.oz - r.o.z) * r.inv.z;
     const uint32_t nx = r.negx ? n.hix : n.lox, fx = r.negx ? n.lox : n.hix;
     const uint32_t ny = r.negy ? n.hiy : n.loy, fy = r.negy ? n.loy : n.hiy;

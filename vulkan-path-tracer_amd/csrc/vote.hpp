@@ -9,6 +9,8 @@ namespace vpt {
 
 constexpr int kLaneIdle = 0x7fffffff;  // the lane holds no ray
 constexpr int kLaneDone = 0x7ffffffe;  // the lane's ray is finished, its result not yet written
+constexpr uint32_t kVoteParamDefault = 256u + 16u;  // weighted vote, fetch step at 16 idle lanes (profiles/r02_trace_lab_*.json)
+constexpr uint32_t kRayHole = 0xfffffffeu;  // SKD.z / LTD.z of a shadow-ray stream entry nobody wrote
 constexpr uint32_t kHole = 0xffffffffu;  // a stream entry nobody wrote (tail of a wave's last chunk, see WaveAppender)
 
 constexpr int kVoteStackRows = kStackDepth;   // LDS rows of the vote kernels' stacks
@@ -20,9 +22,18 @@ struct LaneStack {
         else if (sp < kStackDepth + kStackOverflow) ovf[sp - kStackDepth] = (uint32_t)v;
         sp++;
     }
+    // The LDS read is unconditional (row clamped) and the spill read sits behind its own rare branch: written as one
+    // `sp < kStackDepth ? stk[..] : ovf[..]` the two loads are merged into a flat_load of a selected address, which is
+    // slower than ds_read_b32 and waits on both memory counters.
     __device__ __forceinline__ void pop_or_done(int& sp, int& cur) const {
         if (sp == 0) cur = kLaneDone;
-        else { sp--; cur = (int)(sp < kStackDepth ? stk[sp * kTraverseBlock] : ovf[sp - kStackDepth]); }
+        else {
+            sp--;
+            int v = (int)stk[(sp < kStackDepth ? sp : kStackDepth - 1) * kTraverseBlock];
+            asm volatile("" : "+v"(v));   // keeps the two loads apart (the optimiser would otherwise select between the addresses again)
+            if (sp >= kStackDepth) v = (int)ovf[sp - kStackDepth];
+            cur = v;
+        }
     }
 };
 __device__ __forceinline__ LaneStack make_lane_stack(unsigned char* smem, uint32_t* overflow) {
@@ -115,6 +126,24 @@ __device__ __forceinline__ void vote_node8_step(const BvhNode8* nodes, const Lan
     cur = (hits & 1u) ? c0 : (hits & 2u) ? c1 : (hits & 4u) ? c2 : (hits & 8u) ? c3 : (hits & 16u) ? c4 : (hits & 32u) ? c5 : (hits & 64u) ? c6 : c7;
 }
 
+// vptfp::ray_triangle() without its early returns: the same operations in the same order (the build has no contraction and no
+// fast-math, so u, v, t are the contract's values bit for bit wherever the contract accepts the hit), and ONE predicate at the
+// end.  With det == 0 the reciprocal is an infinity, u, v, t are infinities or NaNs and the explicit det test rejects the hit as
+// the contract does.  Why: in a vote step a wave runs the whole test anyway as soon as one lane passes each early-out, and the
+// nested exits made the compiler carry the best-hit registers through five nested exec regions (50 register copies per triangle
+// step, profiles/r03_trace_isa_budget.md); straight-line code has none.
+__device__ __forceinline__ bool ray_triangle_flat(V3 o, V3 d, V3 v0, V3 e1, V3 e2, float tmin, float tmax, float& t, float& u, float& v) {
+    const V3 p = vptfp::cross(d, e2);
+    const float det = vptfp::dot(e1, p);
+    const float inv = 1.0f / det;
+    const V3 s = o - v0;
+    u = vptfp::dot(s, p) * inv;
+    const V3 q = vptfp::cross(s, e1);
+    v = vptfp::dot(d, q) * inv;
+    t = vptfp::dot(e2, q) * inv;
+    return (det != 0.0f) & (u >= 0.0f) & (u <= 1.0f) & (v >= 0.0f) & (u + v <= 1.0f) & (t > tmin) & (t < tmax);
+}
+
 // One triangle of the lane's leaf, closest-hit search (ties in t -> smaller global id).
 __device__ __forceinline__ void vote_tri_step_closest(const BvhTri* tris, const LaneStack& S, int& cur, int& sp, V3 o, V3 d, float tmin, float tmax,
                                                       float& best_t, float& bu, float& bv, uint32_t& bslot, uint32_t& bgid) {
@@ -124,10 +153,10 @@ __device__ __forceinline__ void vote_tri_step_closest(const BvhTri* tris, const 
     const float4* q = reinterpret_cast<const float4*>(tris + first);
     const float4 ta = q[0], tb = q[1], tc = q[2];
     float t, u, v;
-    if (vptfp::ray_triangle(o, d, vptfp::v3(ta.x, ta.y, ta.z), vptfp::v3(ta.w, tb.x, tb.y), vptfp::v3(tb.z, tb.w, tc.x), tmin, tmax, &t, &u, &v)) {
-        const uint32_t gid = __float_as_uint(tc.w);
-        if (bslot == 0xffffffffu || t < best_t || (t == best_t && gid < bgid)) { best_t = t; bu = u; bv = v; bslot = (uint32_t)first; bgid = gid; }
-    }
+    const bool hit = ray_triangle_flat(o, d, vptfp::v3(ta.x, ta.y, ta.z), vptfp::v3(ta.w, tb.x, tb.y), vptfp::v3(tb.z, tb.w, tc.x), tmin, tmax, t, u, v);
+    const uint32_t gid = __float_as_uint(tc.w);
+    const bool better = hit & ((bslot == 0xffffffffu) | (t < best_t) | ((t == best_t) & (gid < bgid)));
+    best_t = better ? t : best_t; bu = better ? u : bu; bv = better ? v : bv; bslot = better ? (uint32_t)first : bslot; bgid = better ? gid : bgid;
     if (more) cur = ~(int)((((uint32_t)first + 1u) << 3) | (more - 1u));
     else S.pop_or_done(sp, cur);
 }
@@ -142,10 +171,10 @@ __device__ __forceinline__ bool vote_tri_step_any(const BvhTri* tris, const Lane
     const float4* q = reinterpret_cast<const float4*>(tris + first);
     const float4 ta = q[0], tb = q[1], tc = q[2];
     float t, u, v;
-    if (vptfp::ray_triangle(o, d, vptfp::v3(ta.x, ta.y, ta.z), vptfp::v3(ta.w, tb.x, tb.y), vptfp::v3(tb.z, tb.w, tc.x), tmin, tmax, &t, &u, &v)) {
-        const uint32_t gid = __float_as_uint(tc.w);
-        if (t < tlim || (t == tlim && gid < expect)) { cur = kLaneDone; return true; }
-    }
+    const bool hit = ray_triangle_flat(o, d, vptfp::v3(ta.x, ta.y, ta.z), vptfp::v3(ta.w, tb.x, tb.y), vptfp::v3(tb.z, tb.w, tc.x), tmin, tmax, t, u, v);
+    const uint32_t gid = __float_as_uint(tc.w);
+    const bool stop = hit & ((t < tlim) | ((t == tlim) & (gid < expect)));
+    if (stop) { cur = kLaneDone; return true; }
     if (more) cur = ~(int)((((uint32_t)first + 1u) << 3) | (more - 1u));
     else S.pop_or_done(sp, cur);
     return false;

@@ -60,6 +60,7 @@ struct vpt_ctx {
     std::vector<BvhTri> bvh_input;           // the triangles the BVH was built from (trace lab: the eight-wide tree is built from them on first use)
     bool lds_scene = false;
     bool sbvh = false;
+    uint32_t* stack_overflow2 = nullptr;   // spill region of the traversal kernels launched on stream2
     int trav_blocks = 1024;
 
     vpt_params params{};
@@ -508,13 +509,15 @@ int render_batch(vpt_ctx* c, uint32_t frames, uint32_t dispatch_base) {
                     TIMED(c, VPT_K_SHADE, launch_shade_stream(s, (uint32_t)c->shade_stream_blocks, 0u, false, c->dsc, c->P, c->ps, c->ss, c->queue[parity], nullptr, c->queue[parity ^ 1u], c->ctr, c->sctr, parity));
                 }
                 hipStream_t sb = s;
+                DeviceScene dsc_shadow = c->dsc;
                 if (overlap) {   // shadow rays and join of this bounce on the second stream: the next bounce's extend does not depend on them
                     HIPCHK(c, hipEventRecord(c->ev_shade, s));
                     HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_shade, 0));
                     sb = c->stream2;
+                    dsc_shadow.stack_overflow = c->stack_overflow2;   // its own stack spill region: it runs beside the next extend
                 }
-                TIMED(c, VPT_K_SHADOW, launch_trace_shadow(sb, (uint32_t)c->shadow_blocks, false, count, c->dsc, c->ss, c->ctr, c->sctr, c->vote_param));
-                TIMED(c, VPT_K_SHADOW, launch_trace_shadow(sb, (uint32_t)c->shadow_blocks, true, count, c->dsc, c->ss, c->ctr, c->sctr, c->vote_param));
+                TIMED(c, VPT_K_SHADOW, launch_trace_shadow(sb, (uint32_t)c->shadow_blocks, false, count, dsc_shadow, c->ss, c->ctr, c->sctr, c->vote_param));
+                TIMED(c, VPT_K_SHADOW, launch_trace_shadow(sb, (uint32_t)c->shadow_blocks, true, count, dsc_shadow, c->ss, c->ctr, c->sctr, c->vote_param));
                 TIMED(c, VPT_K_JOIN, launch_join(sb, (uint32_t)c->shade_blocks, c->P, c->ps, c->ss, c->sctr));
                 if (overlap) { HIPCHK(c, hipEventRecord(c->ev_join, c->stream2)); join_pending = true; }
                 parity ^= 1u;
@@ -734,7 +737,7 @@ int vpt_set_scene(vpt_ctx* c, const vpt_scene_desc* sd) {
         }
     }
     std::vector<BvhNode> nodes; std::vector<BvhNodeWide> wide; std::vector<BvhTri> leaf_tris; int depth = 0;
-    c->sbvh = getenv("VPT_SBVH") != nullptr && atoi(getenv("VPT_SBVH")) != 0;   // experiment switch: spatial splits in the builder
+    c->sbvh = (c->cfg.build_flags & VPT_BUILD_SBVH) != 0u;   // spatial splits in the builder: a per-context option
     build_bvh(tris, nodes, wide, leaf_tris, &depth, nullptr, c->sbvh);
     c->bvh_input = tris; c->dsc.nodes8 = nullptr;
     c->bvh_depth = (uint32_t)depth;
@@ -818,9 +821,13 @@ int vpt_set_scene(vpt_ctx* c, const vpt_scene_desc* sd) {
     {   // per-thread overflow region of the traversal stacks, for the largest persistent grid launched
         c->max_blocks = std::max(std::max(std::max(std::max(c->trav_blocks, c->shade_blocks), c->primary_blocks), c->vote_blocks), std::max(c->shade_stream_blocks, c->shadow_blocks));
         void* d = nullptr;
-        HIPCHK(c, hipMalloc(&d, stack_overflow_bytes((uint32_t)c->max_blocks)));
+        // two regions: the shadow kernels of bounce k run on the second stream beside the extend kernel of bounce k + 1, and a
+        // spill slot is addressed by (block, thread) alone, so concurrent grids must not share one region (round 2 did)
+        const size_t region = stack_overflow_bytes((uint32_t)c->max_blocks);
+        HIPCHK(c, hipMalloc(&d, 2 * region));
         c->scene_allocs.push_back(d);
         D.stack_overflow = (uint32_t*)d;
+        c->stack_overflow2 = (uint32_t*)((char*)d + region);
     }
     launch_precompute_tri_ng(c->stream, D, c->d_tri_ng);
     launch_precompute_tri_shade(c->stream, D, c->d_tri_shade);
@@ -1130,6 +1137,7 @@ int vpt_get_stats(vpt_ctx* c, vpt_stats* out) {
     s.bvh_node_bytes = c->lds_scene ? sizeof(BvhNodeWide) : sizeof(BvhNode); s.bvh_tri_bytes = sizeof(BvhTri);
     s.emissive_mesh_count = (uint32_t)c->emissive.size(); s.emissive_triangle_count = c->emissive_tris;
     s.frames_in_flight = c->frames_in_flight; s.shard_pixels = c->P.shard_pixels;
+    s.build_flags = c->sbvh ? VPT_BUILD_SBVH : 0u;
     *out = s;
     return VPT_OK;
 }

@@ -4,6 +4,11 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Region markers for the ISA budget (tests/tools/isa_budget.py attributes every instruction between two markers to a step of the
+// vote loop).  A marker is a comment in the assembly — no instruction — and it is part of the product build on purpose: a build
+// with markers only for measuring gets a different register allocation than the one that ships.
+#define VPT_MARK(name) asm volatile("; VPT_MARK " name)
+
 namespace vpt {
 
 __device__ inline uint32_t lane_id() { return threadIdx.x & 63u; }
