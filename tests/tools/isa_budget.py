@@ -133,6 +133,34 @@ def region_instructions(blocks):
                 for s2 in blocks[bi]["succ"]:
                     work.append((s2, 0))
         regions[region] = got
+    # "vote>X": the part of the vote region that lies on a way to marker X (forward-reachable from the vote marker and
+    # backward-reachable from X without crossing a marker) = what one iteration issues BEFORE it enters step X
+    pred = collections.defaultdict(list)
+    for bi, b in enumerate(blocks):
+        for s2 in b["succ"]:
+            pred[s2].append(bi)
+    vote = regions.get("vote", set())
+    for target, entry_points in starts.items():
+        if target in ("vote", "prologue"):
+            continue
+        back, seen, work = set(), set(), [(bi, k - 2) for bi, k in entry_points]   # item before the marker
+        while work:
+            bi, k = work.pop()
+            if (bi, k) in seen:
+                continue
+            seen.add((bi, k))
+            items = blocks[bi]["items"]
+            stopped = False
+            while k >= 0:
+                if items[k][0] == "mark":
+                    stopped = True
+                    break
+                back.add((bi, k))
+                k -= 1
+            if not stopped:
+                for p2 in pred[bi]:
+                    work.append((p2, len(blocks[p2]["items"]) - 1))
+        regions["vote>" + target] = vote & back
     return regions
 
 
@@ -182,9 +210,14 @@ def main():
     with tempfile.TemporaryDirectory() as tmp:
         asm = {}
         for label, (fname, pattern) in KERNELS.items():
-            if fname not in asm:
-                asm[fname] = compile_asm(src, fname, tmp)
-            lines = kernel_text(asm[fname], pattern)
+            lines = []
+            for cand in (fname, "kernels_stream.hip"):   # round 2 kept k_trace_shadow in kernels_stream.hip
+                if cand not in asm:
+                    asm[cand] = compile_asm(src, cand, tmp)
+                lines = kernel_text(asm[cand], pattern)
+                if lines:
+                    fname = cand
+                    break
             if not lines:
                 print("%s: kernel not found" % label, file=sys.stderr)
                 continue
@@ -204,7 +237,7 @@ def main():
             print("## %s   %s" % (label, meta))
             print("| region | VALU | SALU | VMEM | LDS | SMEM | branch | wait/nop | VALU by kind |")
             print("|---|---|---|---|---|---|---|---|---|")
-            for region in ("vote", "node", "tri", "exit", "fetch", "done", "prologue"):
+            for region in ("vote>node", "node", "vote>tri", "tri", "vote>exit", "vote>fetch", "fetch", "exit", "done", "prologue", "vote"):
                 c = table.get(region)
                 if not c:
                     continue

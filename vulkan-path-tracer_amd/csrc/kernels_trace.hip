@@ -95,6 +95,7 @@ __global__ __launch_bounds__(kTraverseBlock, 8) void k_trace_vote(DeviceScene sc
     const uint32_t chunk = fetch_chunk(n);
     const uint32_t fetch_at = TUNED ? 16u : (a.param & 0xffu) ? (a.param & 0xffu) : 16u;  // idle lanes that trigger a fetch step (64: only when all are idle)
     const bool weighted = TUNED || ((a.param >> 8) & 1u) != 0u;  // vote by lanes served per instruction issued: a triangle step costs about half a node step
+    const uint32_t w4 = TUNED ? kVoteWeight4 : ((a.param >> 12) & 15u) ? ((a.param >> 12) & 15u) : kVoteWeight4;   // the weight in quarters (lab: bits 12-15)
     // every wave starts on its own 64 entries without an atomic (8192 waves fetching at once would queue ~90 us on the cursor);
     // entries beyond the grid's static part are fetched chunk-wise through the cursor
     const uint32_t n_static = gridDim.x * (kTraverseBlock / 64u) * 64u;
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(kTraverseBlock, 8) void k_trace_vote(DeviceScene sc
             const bool at_leaf = busy && cur < 0;
             nn = (uint32_t)__popcll(__ballot(at_node)); nl = (uint32_t)__popcll(__ballot(at_leaf));
             if ((!exhausted && 64u - nn - nl >= fetch_at) || nn + nl == 0u) break;
-            const bool node_wins = weighted ? nn > 2u * nl : nn >= nl;
+            const bool node_wins = weighted ? 4u * nn > w4 * nl : nn >= nl;
             // two predicated regions in sequence rather than if / else on the (uniform) vote: the if / else form is compiled into a
             // flag-linked pair of regions that hands the lane state from one register set to another and back (14 v_mov per step)
             VPT_MARK("node");
@@ -211,6 +212,7 @@ __global__ __launch_bounds__(kTraverseBlock, 8) void k_trace_shadow(DeviceScene 
     const uint32_t chunk = fetch_chunk(n);
     const uint32_t fetch_at = TUNED ? 16u : (param & 0xffu) ? (param & 0xffu) : 16u;
     const bool weighted = TUNED || ((param >> 8) & 1u) != 0u;
+    const uint32_t w4 = TUNED ? kVoteWeight4 : ((param >> 12) & 15u) ? ((param >> 12) & 15u) : kVoteWeight4;
     const float tmin = 0.0001f, tmax = 1000000.0f;  // RTCommon.slang:47-64
     const uint32_t n_static = gridDim.x * (kTraverseBlock / 64u) * 64u;  // every wave starts on its own 64 entries, no atomic
     // wave-uniform by construction (see k_trace_vote)
@@ -231,7 +233,7 @@ __global__ __launch_bounds__(kTraverseBlock, 8) void k_trace_shadow(DeviceScene 
             const bool at_leaf = busy && cur < 0;
             const uint32_t nn = (uint32_t)__popcll(__ballot(at_node)), nl = (uint32_t)__popcll(__ballot(at_leaf));
             if ((!exhausted && 64u - nn - nl >= fetch_at) || nn + nl == 0u) break;
-            const bool node_wins = weighted ? nn > 2u * nl : nn >= nl;
+            const bool node_wins = weighted ? 4u * nn > w4 * nl : nn >= nl;
             VPT_MARK("node");   // two predicated regions in sequence, not if / else (see k_trace_vote)
             if (node_wins & at_node) {
                 if (COUNT) st_nodes++;
