@@ -46,7 +46,7 @@ def read_dump(path):
     return meshes, mats, inst, texs, cams
 
 
-@pytest.mark.parametrize("name", ["cornell_box", "textured_boxes"])
+@pytest.mark.parametrize("name", ["cornell_box", "textured_boxes", "textured_boxes_jpg"])
 def test_cpp_importer_equals_python_loader(cli, vpt, tmp_path, name):
     import ctypes as C
     gltf = os.path.join(GOLDEN, name + ".gltf")
@@ -97,7 +97,7 @@ def test_multi_gpu_cli_is_bit_identical_to_one_device(cli, tmp_path, gpus):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,extra", [("cornell_box", []), ("textured_boxes", []), ("cornell_box", ["--split", "2"])])
+@pytest.mark.parametrize("name,extra", [("cornell_box", []), ("textured_boxes", []), ("textured_boxes_jpg", []), ("cornell_box", ["--split", "2"])])
 def test_render_through_the_cpp_facade_matches_the_oracle(cli, vpt, oracle, tmp_path, name, extra):
     gltf = os.path.join(GOLDEN, name + ".gltf")
     rad, cam, ppm = str(tmp_path / "r.f32"), str(tmp_path / "c.f32"), str(tmp_path / "o.ppm")

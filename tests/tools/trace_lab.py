@@ -157,12 +157,12 @@ def main():
         ref = None
         for oname, order in orders.items():
             # param: bits 0-7 idle lanes that trigger a fetch step, bit 8 weighted vote, bits 12-15 the weight in quarters (0 = 8, i.e. 2.0)
-            W = lambda w4, fetch: (w4 << 12) | 256 | fetch
+            PW = lambda w4, fetch: (w4 << 12) | 256 | fetch
             sweep = os.environ.get("LAB_SWEEP") == "1"
             plan = ([(BASE, 0), (VOTE, 16), (VOTE, 256 + 16), (VOTE8, 16), (VOTE8, 256 + 16)] if quick else
                     [(BASE, 0), (VOTE, 8), (VOTE, 16), (VOTE, 32), (VOTE, 48), (VOTE, 64), (VOTE, 256 + 16), (VOTE, 256 + 32)])
             if sweep:   # vote weight x fetch threshold around the default (2.0, 16)
-                plan = [(VOTE, 16), (VOTE, 256 + 16)] + [(VOTE, W(w4, f)) for w4 in (4, 5, 6, 7, 10, 12) for f in (16,)] + [(VOTE, W(w4, f)) for w4 in (6, 8) for f in (8, 12, 24)]
+                plan = [(VOTE, 16), (VOTE, 256 + 16)] + [(VOTE, PW(w4, f)) for w4 in (4, 5, 6, 7, 10, 12) for f in (16,)] + [(VOTE, PW(w4, f)) for w4 in (6, 8) for f in (8, 12, 24)]
             for variant, param in plan:
                 first = ref is None or (variant in (VOTE, VOTE8) and param == 16)
                 ms, hits, vis = lab_trace(g, variant, any_hit, order, param, 5, True, first)

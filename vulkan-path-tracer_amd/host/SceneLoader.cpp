@@ -135,15 +135,17 @@ void default_material(vpt_material& m) {  // PathTracer.h:14-33
     m.base_color_texture = 0; m.normal_texture = 1; m.roughness_texture = 2; m.metallic_texture = 3; m.emissive_texture = 4;
 }
 
-uint8_t paeth(int a, int b, int c) { int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c); return (uint8_t)(pa <= pb && pa <= pc ? a : (pb <= pc ? b : c)); }
-
 }  // namespace
 
-bool DecodePNG(const std::string& f, const std::string& path, TextureAsset& out, std::string& error);
 bool LoadPNG(const std::string& path, TextureAsset& out, std::string& error) {
     std::string f;
     if (!read_file(path, f)) { error = "cannot open " + path; return false; }
     return DecodePNG(f, path, out, error);
+}
+bool LoadImage(const std::string& path, TextureAsset& out, std::string& error) {   // PNG or JPEG, by content
+    std::string f;
+    if (!read_file(path, f)) { error = "cannot open " + path; return false; }
+    return DecodeImage(f, path, out, error);
 }
 // base64 payload of a "data:<mime>;base64,<payload>" URI (glTF 2.0 section 2.6); false if `uri` is not one
 static bool decode_data_uri(const std::string& uri, std::string& out) {
@@ -161,52 +163,6 @@ static bool decode_data_uri(const std::string& uri, std::string& out) {
     }
     return true;
 }
-bool DecodePNG(const std::string& f, const std::string& path, TextureAsset& out, std::string& error) {
-    static const unsigned char sig[8] = {137, 80, 78, 71, 13, 10, 26, 10};
-    if (f.size() < 33 || std::memcmp(f.data(), sig, 8) != 0) { error = "not a PNG: " + path; return false; }
-    auto be32 = [&](size_t o) { return ((uint32_t)(uint8_t)f[o] << 24) | ((uint32_t)(uint8_t)f[o + 1] << 16) | ((uint32_t)(uint8_t)f[o + 2] << 8) | (uint8_t)f[o + 3]; };
-    uint32_t w = 0, h = 0; int depth = 0, ctype = 0, interlace = 0;
-    std::string idat;
-    for (size_t p = 8; p + 12 <= f.size();) {
-        uint32_t len = be32(p); std::string type = f.substr(p + 4, 4);
-        if (p + 12 + len > f.size()) break;
-        if (type == "IHDR") {
-            if (len < 13) { error = "bad PNG header: " + path; return false; }
-            w = be32(p + 8); h = be32(p + 12); depth = (uint8_t)f[p + 16]; ctype = (uint8_t)f[p + 17]; interlace = (uint8_t)f[p + 20];
-        }
-        else if (type == "IDAT") idat.append(f, p + 8, len);
-        else if (type == "IEND") break;
-        p += 12 + len;
-    }
-    int ch = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
-    if (depth != 8 || ch == 0 || interlace != 0 || w == 0 || h == 0) { error = "unsupported PNG format (need 8-bit gray/RGB/RGBA, non-interlaced): " + path; return false; }
-    if (w > 32768u || h > 32768u) { error = "PNG larger than 32768 x 32768: " + path; return false; }   // bounds every size computed below (< 2^32 bytes)
-    const size_t stride = (size_t)w * ch;
-    std::vector<uint8_t> raw((stride + 1) * h);
-    uLongf dl = (uLongf)raw.size();
-    if (uncompress(raw.data(), &dl, (const Bytef*)idat.data(), (uLong)idat.size()) != Z_OK || dl != raw.size()) { error = "PNG inflate failed: " + path; return false; }
-    std::vector<uint8_t> img(stride * h);
-    for (uint32_t y = 0; y < h; y++) {
-        const uint8_t* src = &raw[(stride + 1) * y]; uint8_t ft = src[0]; src++;
-        uint8_t* dst = &img[stride * y]; const uint8_t* up = y ? &img[stride * (y - 1)] : nullptr;
-        for (size_t x = 0; x < stride; x++) {
-            int a = x >= (size_t)ch ? dst[x - ch] : 0, b = up ? up[x] : 0, c = (up && x >= (size_t)ch) ? up[x - ch] : 0;
-            int v = src[x];
-            switch (ft) { case 1: v += a; break; case 2: v += b; break; case 3: v += (a + b) / 2; break; case 4: v += paeth(a, b, c); break; default: break; }
-            dst[x] = (uint8_t)v;
-        }
-    }
-    out.Width = w; out.Height = h; out.Channels = 4; out.Data.resize((size_t)w * h * 4);
-    for (size_t i = 0; i < (size_t)w * h; i++) {
-        const uint8_t* s = &img[i * ch]; uint8_t* d = &out.Data[i * 4];
-        if (ch == 1) { d[0] = d[1] = d[2] = s[0]; d[3] = 255; }
-        else if (ch == 2) { d[0] = d[1] = d[2] = s[0]; d[3] = s[1]; }
-        else if (ch == 3) { d[0] = s[0]; d[1] = s[1]; d[2] = s[2]; d[3] = 255; }
-        else { d[0] = s[0]; d[1] = s[1]; d[2] = s[2]; d[3] = s[3]; }
-    }
-    return true;
-}
-
 bool LoadHDR(const std::string& path, std::vector<float>& rgba, uint32_t& width, uint32_t& height, std::string& error) {
     std::string f;
     if (!read_file(path, f)) { error = "cannot open " + path; return false; }
@@ -372,7 +328,7 @@ bool ImportScene(const std::string& gltfPath, SceneAsset& sc, std::string& error
         const JVal& tex = g.req("textures")[ref->index("index", 0)];
         const JVal& img = g.req("images")[tex.index("source", 0)];
         if (g_malformed) { error = "glTF texture / image index out of range"; return false; }
-        // image source: external file, data: URI, or a bufferView (embedded PNG, the usual .glb form)
+        // image source: external file, data: URI, or a bufferView (the usual .glb form); PNG or JPEG, glTF's two core formats
         const JVal* iuri = img.get("uri");
         std::string key = (iuri ? iuri->str : "bufferView:" + std::to_string((long long)img.number("bufferView", -1))) + (single ? "#r" : "");
         auto it = texCache.find(key);
@@ -387,10 +343,10 @@ bool ImportScene(const std::string& gltfPath, SceneAsset& sc, std::string& error
                 const size_t bidx = bv.index("buffer", 0), off = bv.index("byteOffset", 0), len = bv.index("byteLength", 0);
                 if (bidx >= bufs.size() || off > bufs[bidx].size() || len > bufs[bidx].size() - off) { error = "glTF image bufferView out of range"; return false; }
                 bytes = bufs[bidx].substr(off, len);
-                if (!DecodePNG(bytes, key, t, error)) return false;
+                if (!DecodeImage(bytes, key, t, error)) return false;
             } else if (decode_data_uri(iuri->str, bytes)) {
-                if (!DecodePNG(bytes, "data URI", t, error)) return false;
-            } else if (!LoadPNG(base + "/" + iuri->str, t, error)) return false;
+                if (!DecodeImage(bytes, "data URI", t, error)) return false;
+            } else if (!LoadImage(base + "/" + iuri->str, t, error)) return false;
             if (single) {  // LoadTexture(..., onlySingleChannel=true) keeps R (PathTracer.cpp:826-836)
                 std::vector<uint8_t> r((size_t)t.Width * t.Height);
                 for (size_t i = 0; i < r.size(); i++) r[i] = t.Data[i * 4];

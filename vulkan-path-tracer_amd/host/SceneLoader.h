@@ -39,7 +39,14 @@ struct SceneAsset {
 
 // Returns false and fills `error` on failure (the reference aborts via VH_ASSERT, PathTracer.cpp:168).
 bool ImportScene(const std::string& gltfPath, SceneAsset& out, std::string& error);
-bool LoadPNG(const std::string& path, TextureAsset& out, std::string& error);  // 8-bit gray/RGB/RGBA, non-interlaced
+// LDR textures as stbi_load(path, 4) delivers them to LoadTexture (PathTracer.cpp:812-836): RGBA8, rows top to bottom (ImageCodec.cpp).
+// PNG: every colour type and bit depth of the format, palette, tRNS, Adam7.  JPEG: baseline and progressive Huffman, 8 bit,
+// 1 or 3 components, any sampling factors, restart intervals; stb_image's IDCT / chroma upsampling / YCbCr arithmetic.
+bool LoadPNG(const std::string& path, TextureAsset& out, std::string& error);
+bool LoadImage(const std::string& path, TextureAsset& out, std::string& error);   // PNG or JPEG, decided by content
+bool DecodePNG(const std::string& bytes, const std::string& name, TextureAsset& out, std::string& error);
+bool DecodeJPEG(const std::string& bytes, const std::string& name, TextureAsset& out, std::string& error);
+bool DecodeImage(const std::string& bytes, const std::string& name, TextureAsset& out, std::string& error);
 // Radiance .hdr (RGBE; flat or new-style RLE scanlines; "-Y h +X w" orientation) -> RGBA32F rows top to bottom, A = 1:
 // what ImportTexture hands LoadEnvironmentMap for the default env map (PathTracer.cpp:1137-1164, PathTracer.h:208).
 // value = mantissa * 2^(e - 136), 0 when e == 0 (the stb_image convention the reference's importer follows).

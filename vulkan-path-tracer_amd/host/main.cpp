@@ -33,7 +33,7 @@ static void write_file(const std::string& path, const void* data, size_t bytes) 
 }
 
 int main(int argc, char** argv) {
-    std::string scene, luts, radiance, camera, ppm, png, envHdr, dumpEnv, pngTest, dump, makeLut, lutOut;
+    std::string scene, luts, radiance, camera, ppm, png, envHdr, dumpEnv, pngTest, decodeImage, dumpImage, dump, makeLut, lutOut;
     std::vector<PathTracer::Volume> volumes; int phase = 0; bool atmosphere = false; float sunAlt = 0.0f, sunAz = 0.0f;
     uint32_t lutSamples = 10000000u, lutTime = 0; UVec3 lutSize{0, 0, 0};
     uint32_t w = 0, h = 0, spp = 16, depth = 8, seed = 1, split = 1, gpus = 1; std::vector<int> devices;
@@ -57,6 +57,8 @@ int main(int argc, char** argv) {
         else if (a == "--png") png = next();                 // Editor::SaveToFile
         else if (a == "--env-hdr") envHdr = next();          // SetEnvMapFilepath
         else if (a == "--dump-env") dumpEnv = next();        // with --env-hdr: decoded RGBA32F (no device needed)
+        else if (a == "--decode-image") decodeImage = next(); // with --dump-image: a PNG / JPEG texture as the importer decodes it, raw RGBA8 (no device needed)
+        else if (a == "--dump-image") dumpImage = next();
         else if (a == "--png-roundtrip") pngTest = next();   // with --dump-env unused: writes a test pattern PNG and reads it back (no device needed)
         else if (a == "--info") info = true;
         else if (a == "--selftest") selftest = true;
@@ -99,9 +101,15 @@ int main(int argc, char** argv) {
                cam.GetPosition().y - (-2.0f), moveOk ? "true" : "false");
         return (ev < 1e-4 && ep < 1e-5 && ei < 1e-5 && moveOk) ? 0 : 1;
     }
-    if (!dumpEnv.empty() || !pngTest.empty()) {  // host-side file formats only
+    if (!dumpEnv.empty() || !pngTest.empty() || !decodeImage.empty()) {  // host-side file formats only
         try {
             std::string err;
+            if (!decodeImage.empty()) {
+                TextureAsset t;
+                if (!LoadImage(decodeImage, t, err)) throw std::runtime_error(err);
+                if (!dumpImage.empty()) write_file(dumpImage, t.Data.data(), t.Data.size());
+                printf("{\"width\": %u, \"height\": %u, \"channels\": %u}\n", t.Width, t.Height, t.Channels);
+            }
             if (!dumpEnv.empty()) {
                 std::vector<float> rgba; uint32_t ew = 0, eh = 0;
                 if (!LoadHDR(envHdr, rgba, ew, eh, err)) throw std::runtime_error(err);

@@ -1,11 +1,13 @@
 """Image files of the reference's asset path, without third-party decoders: Radiance .hdr environment maps
-(PathTracer.cpp:1137-1164 via the absent VulkanHelper::AssetImporter) and 8-bit PNG (glTF textures in,
-Editor::SaveToFile out, Editor.cpp:815-843).  host/SceneLoader.cpp holds the same readers/writers in C++; the tests
-compare the two byte for byte."""
+(PathTracer.cpp:1137-1164 via the absent VulkanHelper::AssetImporter), PNG / JPEG textures (imagecodec.py; glTF's two core
+image formats) and the PNG export (Editor::SaveToFile, Editor.cpp:815-843).  host/SceneLoader.cpp + host/ImageCodec.cpp hold
+the same readers/writers in C++; the tests compare the two byte for byte."""
 import struct
 import zlib
 
 import numpy as np
+
+from .imagecodec import decode_image, decode_jpeg, decode_png, load_image  # noqa: F401  (the LDR texture decoders)
 
 _PNG_SIG = b"\x89PNG\r\n\x1a\n"
 
@@ -104,62 +106,8 @@ def save_hdr(path, rgb, rle=True):
 
 
 def load_png(path):
-    """8-bit gray / gray+alpha / RGB / RGBA, non-interlaced -> uint8 [h, w, 4]."""
+    """Any PNG (imagecodec.decode_png) -> uint8 [h, w, 4]."""
     return decode_png(open(path, "rb").read(), path)
-
-
-def decode_png(b, path="<memory>"):
-    if b[:8] != _PNG_SIG:
-        raise ValueError("not a PNG: %s" % path)
-    p, idat, hdr = 8, b"", None
-    while p + 12 <= len(b):
-        n, typ = struct.unpack(">I4s", b[p:p + 8])
-        if typ == b"IHDR":
-            hdr = struct.unpack(">IIBBBBB", b[p + 8:p + 21])
-        elif typ == b"IDAT":
-            idat += b[p + 8:p + 8 + n]
-        elif typ == b"IEND":
-            break
-        p += 12 + n
-    w, h, depth, ctype, _, _, interlace = hdr
-    ch = {0: 1, 2: 3, 4: 2, 6: 4}.get(ctype, 0)
-    if depth != 8 or ch == 0 or interlace:
-        raise ValueError("unsupported PNG format (need 8-bit gray/RGB/RGBA, non-interlaced): %s" % path)
-    raw = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(h, w * ch + 1)
-    img = np.zeros((h, w * ch), np.uint8)
-    for y in range(h):
-        ft, src = int(raw[y, 0]), raw[y, 1:].astype(np.int32)
-        up = img[y - 1].astype(np.int32) if y else np.zeros(w * ch, np.int32)
-        if ft == 0:
-            img[y] = src
-        elif ft == 2:
-            img[y] = (src + up) & 255
-        else:  # filters 1, 3, 4 depend on the pixel to the left: sequential
-            row = np.zeros(w * ch, np.int32)
-            for x in range(w * ch):
-                a = row[x - ch] if x >= ch else 0
-                c = up[x - ch] if x >= ch else 0
-                bb = up[x]
-                if ft == 1:
-                    pr = a
-                elif ft == 3:
-                    pr = (a + bb) // 2
-                else:
-                    pa, pb, pc = abs(bb - c), abs(a - c), abs(a + bb - 2 * c)
-                    pr = a if (pa <= pb and pa <= pc) else (bb if pb <= pc else c)
-                row[x] = (src[x] + pr) & 255
-            img[y] = row
-    img = img.reshape(h, w, ch)
-    out = np.full((h, w, 4), 255, np.uint8)
-    if ch == 1:
-        out[..., :3] = img
-    elif ch == 2:
-        out[..., :3] = img[..., :1]; out[..., 3] = img[..., 1]
-    elif ch == 3:
-        out[..., :3] = img
-    else:
-        out[:] = img
-    return out
 
 
 def save_png(path, rgba):

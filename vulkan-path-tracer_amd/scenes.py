@@ -307,14 +307,14 @@ def load_gltf(path, image_loader=None):
         key = (img.get("uri", "bufferView:%d" % img.get("bufferView", -1)), single_channel)
         if key not in tex_cache:
             from . import imagefiles
-            if "uri" not in img:      # embedded PNG (the usual .glb form)
+            if "uri" not in img:      # embedded image (the usual .glb form); PNG or JPEG, glTF's two core formats
                 bv = g["bufferViews"][img["bufferView"]]
                 off = bv.get("byteOffset", 0)
-                arr = imagefiles.decode_png(bufs[bv["buffer"]][off:off + bv["byteLength"]])
+                arr = imagefiles.decode_image(bufs[bv["buffer"]][off:off + bv["byteLength"]])
             elif data_uri(img["uri"]) is not None:
-                arr = imagefiles.decode_png(data_uri(img["uri"]))
+                arr = imagefiles.decode_image(data_uri(img["uri"]))
             elif image_loader is None:
-                arr = imagefiles.load_png(os.path.join(base, img["uri"]))
+                arr = imagefiles.load_image(os.path.join(base, img["uri"]))
             else:
                 arr = image_loader(os.path.join(base, img["uri"]))
             if single_channel:  # LoadTexture(..., onlySingleChannel=true) keeps R (PathTracer.cpp:826-836)
