@@ -146,12 +146,12 @@ def default_params(**kw):
 
 class PostParams(C.Structure):
     _fields_ = [("exposure", C.c_float), ("gamma", C.c_float), ("bloom_threshold", C.c_float),
-                ("bloom_strength", C.c_float), ("mip_count", C.c_uint32), ("falloff_range", C.c_float)]
+                ("bloom_strength", C.c_float), ("mip_count", C.c_uint32), ("falloff_range", C.c_float), ("schedule", C.c_uint32)]
 
 
 def default_post_params(**kw):
     """PostProcessor.h:8-21 defaults."""
-    p = PostParams(1.0, 2.2, 2.0, 1.0, 10, 5.0)
+    p = PostParams(1.0, 2.2, 2.0, 1.0, 10, 5.0, 0)
     for k, v in kw.items():
         if not hasattr(p, k):
             raise AttributeError(k)

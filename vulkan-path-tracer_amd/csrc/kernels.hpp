@@ -72,6 +72,12 @@ void launch_lut(hipStream_t s, int kind, float* table, uint32_t sx, uint32_t sy,
 void launch_bloom_threshold(hipStream_t s, const float* in, float* out, uint32_t w, uint32_t h, float threshold, float falloff);
 void launch_bloom_down(hipStream_t s, const float* in, uint32_t iw, uint32_t ih, float* out, uint32_t ow, uint32_t oh, float strength);
 void launch_bloom_up(hipStream_t s, const float* in, uint32_t iw, uint32_t ih, float* out, uint32_t ow, uint32_t oh, float strength);
+// fused schedule: threshold inside the first down-sample, the small mips down and up in one launch, last up-sample + tonemap in one
+void launch_bloom_down_first(hipStream_t s, const float* hdr, uint32_t iw, uint32_t ih, float* out, uint32_t ow, uint32_t oh, float strength, float threshold, float falloff);
+void launch_bloom_tail(hipStream_t s, float* base, uint32_t bw, uint32_t bh, const uint32_t* w, const uint32_t* h, uint32_t levels, float strength);
+void launch_post_final(hipStream_t s, const float* hdr, const float* mip1, uint32_t mw, uint32_t mh, float* bloom0_out, uint8_t* out, uint32_t w, uint32_t h,
+                       float threshold, float falloff, float strength, float exposure, float gamma, bool linear_tap);
+constexpr uint32_t kBloomTailMaxTexels = 2048, kBloomTailMaxLevels = 8;   // largest mip the one-launch tail keeps in LDS; levels it can hold
 void launch_tonemap(hipStream_t s, const float* hdr, const float* bloom0, uint8_t* out, uint32_t w, uint32_t h, float exposure,
                     float gamma, bool linear_tap);
 

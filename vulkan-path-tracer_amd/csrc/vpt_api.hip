@@ -601,6 +601,7 @@ void vpt_default_params(vpt_params* p) {  // PathTracer.h:197-233
     p->screen_chunk_count = 1; p->emissive_pdf_bias = 0.0f; p->flags = VPT_FLAGS_DEFAULT; p->base_seed = 1;
 }
 void vpt_default_post_params(vpt_post_params* p) {  // PostProcessor.h:8-21
+    p->schedule = VPT_POST_FUSED;
     p->exposure = 1.0f; p->gamma = 2.2f; p->bloom_threshold = 2.0f; p->bloom_strength = 1.0f; p->mip_count = 10; p->falloff_range = 5.0f;
 }
 
@@ -1111,15 +1112,36 @@ int vpt_postprocess(vpt_ctx* c, const vpt_post_params* pp, uint8_t* out8, float*
     const float* hdr = whole_image(c);
     const uint32_t W = c->P.width, H = c->P.height;
     uint32_t mip_count = std::max(1u, std::min(pp->mip_count, (uint32_t)c->mips.size()));
-    TIMED(c, VPT_K_BLOOM, launch_bloom_threshold(s, hdr, c->mips[0], W, H, pp->bloom_threshold, pp->falloff_range));
-    for (uint32_t i = 1; i < mip_count; i++)
-        TIMED(c, VPT_K_BLOOM, launch_bloom_down(s, c->mips[i - 1], c->mip_sizes[i - 1].first, c->mip_sizes[i - 1].second, c->mips[i],
-                                                c->mip_sizes[i].first, c->mip_sizes[i].second, pp->bloom_strength));
-    for (uint32_t i = mip_count - 1; i > 0; i--)
-        TIMED(c, VPT_K_BLOOM, launch_bloom_up(s, c->mips[i], c->mip_sizes[i].first, c->mip_sizes[i].second, c->mips[i - 1],
-                                              c->mip_sizes[i - 1].first, c->mip_sizes[i - 1].second, pp->bloom_strength));
-    TIMED(c, VPT_K_TONEMAP, launch_tonemap(s, hdr, c->mips[0], c->post_out, W, H, pp->exposure, pp->gamma,
-                                           (c->params.flags & VPT_FLAG_TONEMAP_LINEAR_BLOOM_TAP) != 0));
+    const bool linear_tap = (c->params.flags & VPT_FLAG_TONEMAP_LINEAR_BLOOM_TAP) != 0;
+    auto MW = [&](uint32_t i) { return c->mip_sizes[i].first; };
+    auto MH = [&](uint32_t i) { return c->mip_sizes[i].second; };
+    if (pp->schedule == VPT_POST_REFERENCE_PASSES) {   // PostProcessor.cpp:193-246 pass by pass: threshold, down x (n-1), up x (n-1), tonemap
+        TIMED(c, VPT_K_BLOOM, launch_bloom_threshold(s, hdr, c->mips[0], W, H, pp->bloom_threshold, pp->falloff_range));
+        for (uint32_t i = 1; i < mip_count; i++)
+            TIMED(c, VPT_K_BLOOM, launch_bloom_down(s, c->mips[i - 1], MW(i - 1), MH(i - 1), c->mips[i], MW(i), MH(i), pp->bloom_strength));
+        for (uint32_t i = mip_count - 1; i > 0; i--)
+            TIMED(c, VPT_K_BLOOM, launch_bloom_up(s, c->mips[i], MW(i), MH(i), c->mips[i - 1], MW(i - 1), MH(i - 1), pp->bloom_strength));
+        TIMED(c, VPT_K_TONEMAP, launch_tonemap(s, hdr, c->mips[0], c->post_out, W, H, pp->exposure, pp->gamma, linear_tap));
+    } else {
+        // Fused schedule, same values (kernels_post.hip): mip 0 is never materialised unless the caller asks for it.
+        //   T = first mip the one-launch tail keeps in LDS (<= kBloomTailMaxTexels texels, and >= 2: its base mip must exist in memory)
+        uint32_t T = mip_count;
+        for (uint32_t i = 2; i < mip_count; i++) if ((uint64_t)MW(i) * MH(i) <= kBloomTailMaxTexels) { T = i; break; }
+        if (mip_count - T > kBloomTailMaxLevels) T = mip_count;   // cannot happen with <= 10 mips; the per-pass kernels cover it
+        if (mip_count >= 2) TIMED(c, VPT_K_BLOOM, launch_bloom_down_first(s, hdr, W, H, c->mips[1], MW(1), MH(1), pp->bloom_strength, pp->bloom_threshold, pp->falloff_range));
+        for (uint32_t i = 2; i < std::min(T, mip_count); i++)
+            TIMED(c, VPT_K_BLOOM, launch_bloom_down(s, c->mips[i - 1], MW(i - 1), MH(i - 1), c->mips[i], MW(i), MH(i), pp->bloom_strength));
+        if (T < mip_count) {
+            uint32_t tw[kBloomTailMaxLevels], th[kBloomTailMaxLevels];
+            for (uint32_t i = T; i < mip_count; i++) { tw[i - T] = MW(i); th[i - T] = MH(i); }
+            TIMED(c, VPT_K_BLOOM, launch_bloom_tail(s, c->mips[T - 1], MW(T - 1), MH(T - 1), tw, th, mip_count - T, pp->bloom_strength));
+        }
+        for (uint32_t i = std::min(T, mip_count) - 1; i > 1; i--)
+            TIMED(c, VPT_K_BLOOM, launch_bloom_up(s, c->mips[i], MW(i), MH(i), c->mips[i - 1], MW(i - 1), MH(i - 1), pp->bloom_strength));
+        TIMED(c, VPT_K_TONEMAP, launch_post_final(s, hdr, mip_count >= 2 ? c->mips[1] : nullptr, mip_count >= 2 ? MW(1) : 0u, mip_count >= 2 ? MH(1) : 0u,
+                                                  bloom0 ? c->mips[0] : nullptr, c->post_out, W, H, pp->bloom_threshold, pp->falloff_range, pp->bloom_strength,
+                                                  pp->exposure, pp->gamma, linear_tap));
+    }
     HIPCHK(c, hipStreamSynchronize(s));
     collect_timing(c);
     HIPCHK(c, hipGetLastError());
