@@ -43,6 +43,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 GB/s measured copy
+VALU_LANE_OPS_PEAK = 256 * 4 * 16 * 2.4e9   # lane-operations per second: CUs x SIMDs x lanes per cycle x clock
+FRAMES_AT_N1 = 129      # the library's default frames in flight for a whole 1080p image (~256M resident paths): the step of the strong-scaling job
 WIDTH, HEIGHT, BASE_SEED = 1920, 1080, 1
 WORKLOADS = {   # name -> (max depth, scene description)
     "cornell_1080p_d8": (8, "CornellBox (12 triangles, emissive quad 50), black env"),
@@ -78,6 +80,10 @@ def parse():
     ap.add_argument("--frames-in-flight", type=int, default=0, help="frames per step per GPU (0 = backend default, ~256M resident paths)")
     ap.add_argument("--pipeline", type=int, default=0, help="vpt_config.pipeline (0 AUTO)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the oracle sample")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak (default): every rank renders `steps` batches of its own default size (~256M resident paths), so work grows with N; "
+                         "strong: the FIXED job steps x 129 frames of the whole 1080p image (8 steps = config 2's 1024-spp job) is split over the ranks")
+    ap.add_argument("--no-latency", action="store_true", help="skip the per-frame latency block (vpt_render(1) + vpt_postprocess, the reference's call pattern)")
     return ap.parse_args()
 
 
@@ -224,14 +230,39 @@ def kernel_profile(vpt, name, scene, device, rank, world, pipeline, frames_in_fl
             "traversal": {k: round(v, 3) for k, v in tc.items() if k.endswith("_ray")}, "kernels": kernels}
 
 
+def frame_latency(vpt, scene, params, device, frames=30):
+    """The reference's per-frame call pattern (Editor::Draw: PathTrace once, PostProcess every frame — Editor.cpp:116,129): one
+    vpt_render(ctx, 1) followed by one vpt_postprocess per frame on a context that keeps a single frame in flight, wall clock per
+    frame incl. both blocking syncs and the RGBA8 read-back."""
+    g = vpt.PathTracer(WIDTH, HEIGHT, device=device, frames_in_flight=1)
+    g.set_scene(scene); g.set_params(params)
+    for _ in range(5):
+        g.render(1); g.postprocess()
+    tr = tp = 0.0
+    for _ in range(frames):
+        t0 = time.perf_counter(); g.render(1); t1 = time.perf_counter(); g.postprocess(); t2 = time.perf_counter()
+        tr += t1 - t0; tp += t2 - t1
+    g.close()
+    return {"frame_ms": round((tr + tp) / frames * 1e3, 4), "render_1spp_ms": round(tr / frames * 1e3, 4), "postprocess_ms": round(tp / frames * 1e3, 4),
+            "frames": frames, "what": "vpt_render(ctx, 1) + vpt_postprocess per frame at 1920x1080, 1 frame in flight, host wall clock incl. syncs and the 8 MB RGBA8 read-back"}
+
+
 def roofline_for(name, prof):
     """The roofline object of the bench line, for the kernel with the largest share of GPU time."""
     kernels = prof["kernels"]
     dom = max(kernels, key=lambda k: kernels[k]["share"])
     k = kernels[dom]
     pmc = load_json(os.path.join(ROOT, "profiles", "traffic.json")).get(name, {})   # written from rocprofv3 --pmc passes (profiles/README.md)
-    traffic = pmc.get(dom, {}).get("hbm_bytes_per_launch")
-    valu_busy = pmc.get(dom, {}).get("valu_busy")
+    entry = pmc.get(dom, {})
+    # the counters belong to the build they were collected on: an entry whose recorded mean launch time is not within 5 % of
+    # this run's is a different kernel (or another clock) and is NOT copied into the line
+    pmc_ms = entry.get("mean_duration_us", 0.0) / 1e3
+    stale = bool(entry) and not (0.95 <= pmc_ms / max(k["avg_ms"], 1e-9) <= 1.05)
+    if stale:
+        entry = {}
+    traffic = entry.get("hbm_bytes_per_launch")
+    valu_busy = entry.get("valu_busy")
+    lanes = entry.get("lanes_per_valu_instr")
     lds_scene = prof["bvh"]["node_bytes"] == 128
     # bound from the counters where profiles/traffic.json has them: whichever of VALU issue (rocprofv3 VALUBusy; a kernel that
     # saturates issue reads 0.93-1.0, profiles/r02_valu_calibration.md) and HBM-side traffic / peak is higher.  None of the
@@ -243,6 +274,16 @@ def roofline_for(name, prof):
         bound = "valu" if lds_scene or dom in ("extend", "connect", "shadow", "shade") else "hbm"
     return {"bound": bound, "kernel": dom, "achieved": k["records_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(k["records_GBs"] / HBM_PEAK_GBS, 5),
             "traffic": traffic, "traffic_frac_of_hbm_peak": round(traffic_frac, 4) if traffic_frac else None, "valu_busy": valu_busy, "avg_launch_ms": k["avg_ms"],
+            "pmc": {"source": "profiles/traffic.json", "recorded_avg_launch_ms": round(pmc_ms, 5) if pmc_ms else None, "stale": stale,
+                    "rule": "copied only when the recorded mean launch time is within 5 % of this run's"},
+            # the roof that actually binds these kernels (SURVEY 8d's secondary figure): VALU lane throughput.  frac = share of issue
+            # cycles with a VALU instruction (VALUBusy) x share of its 64 lanes that are active; the peak is 256 CUs x 4 SIMDs x 16
+            # lanes x 2.4 GHz lane-operations per second, of which the 157 TFLOP/s fp32 figure counts 4 flops each (packed FMA)
+            "valu": None if valu_busy is None or lanes is None else {
+                "busy": valu_busy, "active_lanes_of_64": lanes, "frac": round(min(valu_busy, 1.0) * lanes / 64.0, 4),
+                "lane_ops_per_s": round(min(valu_busy, 1.0) * lanes / 64.0 * VALU_LANE_OPS_PEAK, 1), "peak_lane_ops_per_s": VALU_LANE_OPS_PEAK,
+                "fp32_tflops_if_every_op_were_an_fma": round(min(valu_busy, 1.0) * lanes / 64.0 * VALU_LANE_OPS_PEAK * 2 / 1e12, 2), "fp32_peak_tflops": 157.3,
+                "note": "the traversal kernels' instruction mix is ~40 % fp32 arithmetic (profiles/r03_trace_isa_budget.md), none of it packed"},
             "record_bytes_per_launch": round(k["record_bytes_per_unit"] * k["units_per_launch"], 0),
             "algorithmic_bytes_per_launch": round(k["algorithmic_bytes_per_unit"] * k["units_per_launch"], 0),
             "algorithmic_GBs": k["algorithmic_GBs"], "algorithmic_frac_of_hbm_peak": k["algorithmic_frac_of_hbm_peak"],
@@ -291,15 +332,22 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # strong scaling: the job is fixed (steps x 129 whole frames) and each rank renders all of its frames for its rows, in batches of
+    # its own frames-in-flight; weak (default): steps batches of the rank's own default size
+    batches = [F] * args.steps
+    if args.scaling == "strong":
+        left, batches = args.steps * FRAMES_AT_N1, []
+        while left > 0:
+            batches.append(min(F, left)); left -= batches[-1]
     for _ in range(args.warmup):
-        pt.render(F)
+        pt.render(batches[0])
     if comm:
         comm.gather_and_assemble()   # warm the communicator outside the timed region
     pt.reset_stats()
     sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        pt.render(F)
+    for nb in batches:
+        pt.render(nb)
     if comm:
         comm.gather_and_assemble()   # one ncclGather of the row shards to rank 0 + row re-interleave there
     sync()
@@ -314,6 +362,7 @@ def main():
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
     samples, closest, shadow = (float(x) for x in tot.tolist())
     shard_pixels = st["shard_pixels"]
+    comm_info = comm.info() if comm and not one_device else None
     pt.close()
 
     if rank == 0:
@@ -321,16 +370,21 @@ def main():
         line = {
             "metric": "Msamples/s at 1920x1080", "value": round(samples / dt / 1e6, 3), "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": name, "scene": WORKLOADS[name][1],
                        "width": WIDTH, "height": HEIGHT, "max_depth": depth, "samples_per_frame": 1,
                        "frames_per_step_per_gpu": F, "paths_in_flight_per_gpu": shard_pixels * F,
                        "timed_samples_per_pixel": round(samples / (WIDTH * HEIGHT), 1),
                        "note": "a rate metric: the timed region renders steps x frames_per_step frames (timed_samples_per_pixel; config 2 asks for 1024 spp, which the default 8 steps cover); bit-exact full-size run: profiles/*_config2_full_parity.json",
+                       "batches_per_gpu": batches if len(set(batches)) > 1 else "%d x %d frames" % (len(batches), batches[0]),
                        "partition": "rows y % N == rank, one ncclGather at the end", "base_seed": BASE_SEED, "pipeline": prof["pipeline"]},
             "mrays_per_s": round((closest + shadow) / dt / 1e6, 2),
             "roofline": roofline_for(name, prof),
         }
+        if comm_info:   # what RCCL itself says about the communicator the gather ran on (vpt_comm_get_info)
+            line["rccl"] = comm_info
+        if world == 1 and not args.no_latency:
+            line["latency"] = frame_latency(vpt, scene, params, local_rank)
         if world == 1 and not args.no_extra_workloads:
             extra = {}
             for other in ("atrium_1080p_d8", "glass_bust_1080p_d32"):

@@ -370,6 +370,23 @@ int vpt_comm_unique_id(void* id_out);
 int vpt_comm_init(vpt_ctx* ctx, const void* id, int rank, int world);
 int vpt_comm_gather_shards(vpt_ctx* ctx, int root);
 int vpt_comm_destroy(vpt_ctx* ctx);
+/* What the communicator actually is: the RCCL the process has MAPPED (a host that loaded another librccl first — PyTorch ships its
+ * own — gets that one behind this library's calls, whatever it was linked against), the one this library was compiled against,
+ * and what RCCL itself reports for the communicator.  vpt_comm_init refuses (VPT_ERR_DEVICE) a mapped RCCL whose major version
+ * differs from the compiled one.  Valid after vpt_comm_init; without a communicator nranks = 0 and only the versions / path are filled. */
+typedef struct vpt_comm_info {
+    int32_t rccl_version_runtime;   /* ncclGetVersion() of the mapped library, e.g. 22606 */
+    int32_t rccl_version_compiled;  /* NCCL_VERSION_CODE of the headers this library was built with */
+    int32_t nranks;                 /* ncclCommCount */
+    int32_t rank;                   /* ncclCommUserRank */
+    int32_t device;                 /* ncclCommCuDevice */
+    int32_t reserved;
+    char library_path[232];         /* file the ncclGather symbol in use comes from (dladdr) */
+} vpt_comm_info;
+int vpt_comm_get_info(vpt_ctx* ctx, vpt_comm_info* out);
+/* "<PCI bus id>" of the context's device (e.g. 0000:05:00.0): lets the host's control plane refuse two ranks on one device before
+ * ncclCommInitRank is entered (RCCL rejects that configuration itself, but only after its bootstrap has run). out: >= 32 bytes. */
+int vpt_device_identity(vpt_ctx* ctx, char* out, uint32_t out_bytes);
 int vpt_multi_gather_shards(vpt_ctx* const* ctxs, uint32_t count, uint32_t root);
 
 /* PostProcessor::SetTonemappingData/SetBloomData + PostProcess (PostProcessor.cpp:193-246) on the

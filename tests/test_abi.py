@@ -34,7 +34,7 @@ def test_struct_layouts_match_reference_contract(vpt):
     assert C.sizeof(a.Instance) == 72
     assert C.sizeof(a.Ray) == 32 and C.sizeof(a.Hit) == 20  # ray in 32 B, hit out 20 B
     assert C.sizeof(a.Params) == 13 * 4
-    assert C.sizeof(a.PostParams) == 24
+    assert C.sizeof(a.PostParams) == 28          # the six fields of PostProcessor.h:8-21 + the schedule selector
 
 
 def test_defaults_match_reference(vpt):
@@ -79,7 +79,7 @@ def test_ctypes_mirror_matches_the_compiled_header(vpt, tmp_path):
     a = vpt._abi
     pairs = [("vpt_material", a.Material), ("vpt_volume", a.Volume), ("vpt_atmosphere", a.Atmosphere), ("vpt_mesh", a.Mesh), ("vpt_instance", a.Instance),
              ("vpt_texture", a.Texture), ("vpt_scene_desc", a.SceneDesc), ("vpt_params", a.Params), ("vpt_post_params", a.PostParams),
-             ("vpt_config", a.Config), ("vpt_stats", a.Stats), ("vpt_ray", a.Ray), ("vpt_hit", a.Hit)]
+             ("vpt_config", a.Config), ("vpt_stats", a.Stats), ("vpt_ray", a.Ray), ("vpt_hit", a.Hit), ("vpt_comm_info", a.CommInfo)]
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "vpt.h"', 'int main(void) {']
     for cname, cls in pairs:
         lines.append('printf("%s %%zu", sizeof(%s));' % (cname, cname))

@@ -41,6 +41,49 @@ def test_rccl_communicator_world1(vpt, scenes):
     g.close()
 
 
+@pytest.mark.parametrize("world,root,h", [(2, 0, 54), (3, 2, 55)])
+def test_library_gather_at_world_n_through_a_stub_rccl(vpt, scenes, tmp_path, world, root, h):
+    """The C++ gather path itself — vpt_comm_init, vpt_comm_gather_shards (padding, root-only receive buffer, offset r * count per
+    rank), the row re-interleave on the root, post-processing of the assembled image — at world > 1: `world` PROCESSES on this box's
+    one GPU, each calling the library's real entry points, with tests/tools/rccl_stub.cpp in front of librccl (LD_PRELOAD; RCCL
+    itself refuses two ranks on one device).  The stub moves the bytes (through files); everything else is the product's code,
+    which until this test had only ever executed with world = 1.  Bit-identical to the unsharded render; RCCL-side facts
+    (nranks, rank) come back through vpt_comm_get_info from what the communicator reports."""
+    stub = str(tmp_path / "librccl_stub.so")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-shared", "-fPIC", "-O2", "-o", stub, os.path.join(ROOT, "tests", "tools", "rccl_stub.cpp")])
+    sc = scenes("cornell_box_glass")
+    P = vpt.default_params(max_depth=5)
+    w, frames = 80, 2
+    ref = render_whole(vpt, sc, w, h, P, frames)
+    g = vpt.PathTracer(w, h); g.set_scene(sc); g.set_params(P); g.render(frames); ref8 = g.postprocess(); g.close()
+    env = dict(os.environ, LD_PRELOAD=stub, VPT_RCCL_STUB_DIR=str(tmp_path))
+    out = str(tmp_path / "img.npy")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "tools", "comm_worker.py"), str(r), str(world), str(root), str(w), str(h), str(frames),
+                               str(tmp_path / "id.bin"), out], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+    logs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+    assert np.array_equal(np.load(out), ref) and np.array_equal(np.load(out + ".post.npy"), ref8)
+    for r in range(world):
+        info = json.load(open(out + ".rank%d.json" % r))
+        assert info["nranks"] == world and info["rank"] == r and info["library_path"].endswith("librccl_stub.so")
+
+
+def test_comm_info_names_the_mapped_rccl(vpt, scenes):
+    """vpt_comm_get_info: which librccl the process mapped (PyTorch's own wins over /opt/rocm's when torch was imported first), its
+    version next to the one this library was compiled against, and the communicator as RCCL sees it."""
+    g = vpt.PathTracer(32, 18); g.set_scene(scenes("cornell_box"))
+    ci = vpt._abi.CommInfo()
+    assert g.lib.vpt_comm_get_info(g.ctx, C.byref(ci)) == 0
+    assert ci.nranks == 0 and ci.rccl_version_runtime // 10000 == ci.rccl_version_compiled // 10000 and b"rccl" in ci.library_path
+    ident = (C.c_ubyte * 128)()
+    assert g.lib.vpt_comm_unique_id(ident) == 0 and g.lib.vpt_comm_init(g.ctx, bytes(ident), 0, 1) == 0
+    assert g.lib.vpt_comm_get_info(g.ctx, C.byref(ci)) == 0 and (ci.nranks, ci.rank) == (1, 0)
+    bus = C.create_string_buffer(64)
+    assert g.lib.vpt_device_identity(g.ctx, bus, 64) == 0 and bus.value.count(b":") >= 2
+    assert g.lib.vpt_device_identity(g.ctx, bus, 8) == -1
+    g.lib.vpt_comm_destroy(g.ctx); g.close()
+
+
 @pytest.mark.parametrize("n,h", [(2, 54), (3, 55), (8, 61)])
 def test_multi_gather_shards_equals_one_context(vpt, scenes, n, h):
     sc = scenes("cornell_box_glass")

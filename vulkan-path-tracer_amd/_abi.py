@@ -178,6 +178,11 @@ class Stats(C.Structure):
     ]
 
 
+class CommInfo(C.Structure):
+    _fields_ = [("rccl_version_runtime", C.c_int32), ("rccl_version_compiled", C.c_int32), ("nranks", C.c_int32), ("rank", C.c_int32),
+                ("device", C.c_int32), ("reserved", C.c_int32), ("library_path", C.c_char * 232)]
+
+
 class Ray(C.Structure):
     _fields_ = [("origin", C.c_float * 3), ("tmin", C.c_float), ("direction", C.c_float * 3), ("tmax", C.c_float)]
 
@@ -217,6 +222,8 @@ PROTOTYPES = {
     "vpt_comm_unique_id": (C.c_int, [C.c_void_p]),
     "vpt_comm_init": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "vpt_comm_gather_shards": (C.c_int, [C.c_void_p, C.c_int]),
+    "vpt_comm_get_info": (C.c_int, [C.c_void_p, C.POINTER(CommInfo)]),
+    "vpt_device_identity": (C.c_int, [C.c_void_p, C.c_char_p, C.c_uint32]),
     "vpt_comm_destroy": (C.c_int, [C.c_void_p]),
     "vpt_multi_gather_shards": (C.c_int, [C.POINTER(C.c_void_p), C.c_uint32, C.c_uint32]),
     "vpt_postprocess": (C.c_int, [C.c_void_p, C.POINTER(PostParams), C.c_void_p, C.c_void_p]),

@@ -185,14 +185,21 @@ __global__ __launch_bounds__(kTailThreads) void k_bloom_tail(BloomTail t) {
     for (int k = t.levels - 1; k >= 0; k--) {   // up: level k is added into level k - 1 (into the base for k == 0)
         float4* dst = k == 0 ? t.base : m + t.off[k - 1];
         const int ow = k == 0 ? t.bw : t.w[k - 1], oh = k == 0 ? t.bh : t.h[k - 1];
-        for (int i = threadIdx.x; i < ow * oh; i += kTailThreads) {
-            const int y = i / ow, x = i - y * ow;
-            V3 c = up_taps(m + t.off[k], t.w[k], t.h[k], x, y);
+        // the 16 taps of an output texel depend on (x / 2, y / 2) only: one evaluation serves the 2 x 2 texels that share them
+        const int qw = (ow + 1) / 2, qh = (oh + 1) / 2;
+        for (int i = threadIdx.x; i < qw * qh; i += kTailThreads) {
+            const int qy = i / qw, qx = i - qy * qw;
+            V3 c = up_taps(m + t.off[k], t.w[k], t.h[k], 2 * qx, 2 * qy);
             c = c / 25.0f;
             c = c * t.strength;
-            const float4 cur = dst[i];
-            c = c + v3(cur.x, cur.y, cur.z);
-            dst[i] = make_float4(c.x, c.y, c.z, 1.0f);
+            for (int dy = 0; dy < 2; dy++)
+                for (int dx = 0; dx < 2; dx++) {
+                    const int x = 2 * qx + dx, y = 2 * qy + dy;
+                    if (x >= ow || y >= oh) continue;
+                    const float4 cur = dst[(size_t)y * ow + x];
+                    const V3 r = c + v3(cur.x, cur.y, cur.z);
+                    dst[(size_t)y * ow + x] = make_float4(r.x, r.y, r.z, 1.0f);
+                }
         }
         __syncthreads();
     }
@@ -224,23 +231,37 @@ __global__ __launch_bounds__(256) void k_post_final(const float4* hdr, const flo
         }
     }
     __syncthreads();
+    // the blurred mip-1 value a mip-0 texel receives depends on (gx / 2, gy / 2) only: evaluate it once per such position —
+    // 33 x 3 of them under this tile ((x0 - 1) / 2 ... (x0 + 63) / 2) — instead of once per texel
+    constexpr int UW = kTileW / 2 + 1, UH = kTileH / 2 + 1;
+    __shared__ float4 s_up[UP ? UH : 1][UP ? UW : 1];
+    const int ux0 = x0 / 2 - 1, uy0 = y0 / 2 - 1;             // first position (may be -1 at the image's edge: never used there)
+    if (UP) {
+        for (int i = threadIdx.x; i < UW * UH; i += 256) {
+            const int ty = i / UW, tx = i - ty * UW;
+            const int px = ux0 + tx, py = uy0 + ty;           // = gx / 2, gy / 2 of the texels it serves
+            V3 u = v3s(0.0f);
+            for (int a = -2; a < 2; a++)
+                for (int b = -2; b < 2; b++) {
+                    // the tile entry at the UNclamped position holds the clamped texel (the loader clamped while fetching): the
+                    // reference's clamp(xy / 2 + (a, b) + 1)
+                    const float4 p = s_m1[py + b + 1 - my0][px + a + 1 - mx0];
+                    u = u + v3(p.x, p.y, p.z);
+                }
+            u = u / 25.0f;
+            u = u * strength;
+            s_up[ty][tx] = make_float4(u.x, u.y, u.z, 0.0f);
+        }
+        __syncthreads();
+    }
     for (int i = threadIdx.x; i < BW * BH; i += 256) {
         const int ty = i / BW, tx = i - ty * BW;
         const int gx = iclamp(x0 - 1 + tx, 0, w - 1), gy = iclamp(y0 - 1 + ty, 0, h - 1);   // the mip-0 texel this entry stands for
         const float4 th = soft_threshold(s_hdr[ty][tx], threshold, falloff);
         V3 c = v3(th.x, th.y, th.z);
         if (UP) {
-            V3 u = v3s(0.0f);
-            for (int a = -2; a < 2; a++)
-                for (int b = -2; b < 2; b++) {
-                    // the tile entry at the UNclamped position holds the clamped texel (the loader clamped while fetching): the
-                    // reference's clamp(xy / 2 + (a, b) + 1)
-                    const float4 p = s_m1[gy / 2 + b + 1 - my0][gx / 2 + a + 1 - mx0];
-                    u = u + v3(p.x, p.y, p.z);
-                }
-            u = u / 25.0f;
-            u = u * strength;
-            c = u + c;   // k_bloom_up: blurred + what mip 0 held
+            const float4 u = s_up[gy / 2 - uy0][gx / 2 - ux0];
+            c = v3(u.x, u.y, u.z) + c;   // k_bloom_up: blurred + what mip 0 held
         }
         s_bloom[ty][tx] = make_float4(c.x, c.y, c.z, 1.0f);
     }

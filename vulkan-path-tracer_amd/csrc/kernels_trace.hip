@@ -85,7 +85,9 @@ __global__ __launch_bounds__(kTraverseBlock, 8) void k_trace_base(DeviceScene sc
 // chunk) and deals its entries to idle lanes in fetch steps.
 // TUNED: the vote parameters are the compile-time defaults (fetch step at 16 idle lanes, weighted vote: kVoteParamDefault), which
 // the pipeline always uses; the lab's other settings go through the instantiation that reads them from a.param.
-template <bool ANY, bool COUNT, bool WIDE8, bool TUNED>
+// STRICT (VPT_FLAG_LOCAL_HITS, traverse.hpp trace_closest_strict / trace_occluded_strict): a closest-hit winner is validated when its
+// ray retires and the ray is traced again without that triangle if the hit was not local to it; an any-hit stop is validated on the spot.
+template <bool ANY, bool COUNT, bool WIDE8, bool TUNED, bool STRICT = false>
 __global__ __launch_bounds__(kTraverseBlock, 8) void k_trace_vote(DeviceScene sc, TraceArgs a, Counters* ctr) {
     extern __shared__ __align__(16) unsigned char smem[];
     const LaneStack S = make_lane_stack(smem, sc.stack_overflow);
@@ -111,6 +113,8 @@ __global__ __launch_bounds__(kTraverseBlock, 8) void k_trace_vote(DeviceScene sc
     float best_t = 0.0f, bu = 0.0f, bv = 0.0f;
     uint32_t st_nodes = 0, st_tris = 0;
     uint32_t qi = 0u;  // the ray's position in the queue: where its shade class goes (a.cls)
+    uint32_t ex0 = 0xffffffffu, ex1 = 0xffffffffu;   // STRICT: triangles excluded from this ray's search
+    bool validated = false;                           // STRICT: the lane's finished ray holds a validated winner (or none)
     // Vote loop: one kind of step per iteration.  (Giving each kind its own inner loop, which lets the lane state stay in fixed
     // registers across the back edge, was measured 5-7 % slower on closest-hit rays: the vote then sticks to a kind for too long.)
     // The fetch step sits in an OUTER loop and the node / triangle steps in an inner one that re-votes every iteration: the ray
@@ -137,11 +141,27 @@ __global__ __launch_bounds__(kTraverseBlock, 8) void k_trace_vote(DeviceScene sc
             VPT_MARK("tri");
             if (!node_wins & at_leaf) {  // ---- triangle step: ONE triangle of the lane's leaf
                 if (COUNT) st_tris++;
-                if (ANY) { if (vote_tri_step_any(tris, S, cur, sp, o, d, a.tmin, a.tmax, a.tmax, 0xffffffffu)) bslot = 0u; }
-                else vote_tri_step_closest(tris, S, cur, sp, o, d, a.tmin, a.tmax, best_t, bu, bv, bslot, bgid);
+                if (ANY) { if (vote_tri_step_any<STRICT>(tris, S, cur, sp, o, d, a.tmin, a.tmax, a.tmax, 0xffffffffu)) bslot = 0u; }
+                else vote_tri_step_closest<STRICT>(tris, S, cur, sp, o, d, a.tmin, a.tmax, best_t, bu, bv, bslot, bgid, ex0, ex1);
             }
         }
         VPT_MARK("exit");
+        if (STRICT && !ANY) {   // finished rays: is the winner's hit local to the winner?  If not: once more without that triangle
+            bool again = false;
+            if (cur == kLaneDone && !validated) {
+                validated = true;
+                if (bslot != 0xffffffffu) {
+                    const float4* q = reinterpret_cast<const float4*>(tris + bslot);
+                    const float4 ta = q[0], tb = q[1], tc = q[2];
+                    if (!vptfp::hit_is_local(o, d, vptfp::v3(ta.x, ta.y, ta.z), vptfp::v3(ta.w, tb.x, tb.y), vptfp::v3(tb.z, tb.w, tc.x), best_t)) {
+                        ex1 = ex0; ex0 = bgid;
+                        best_t = a.tmax; bslot = 0xffffffffu; bgid = 0xffffffffu; sp = 0; cur = 0; validated = false;
+                        again = true;
+                    }
+                }
+            }
+            if (exhausted && __ballot(again) != 0ull) continue;   // nothing left to fetch, but a lane is busy again
+        }
         if (exhausted) break;   // nothing left to fetch and (inner loop's exit) no lane busy
         VPT_MARK("fetch");
         // ---- fetch step: retire finished rays, deal new ones to the idle lanes
@@ -176,6 +196,7 @@ __global__ __launch_bounds__(kTraverseBlock, 8) void k_trace_vote(DeviceScene sc
                     if (a.normalize_dir) d = vptfp::normalize(d);  // RayGen.slang:70
                     inv = safe_inverse(d);
                     best_t = a.tmax; bslot = 0xffffffffu; bgid = 0xffffffffu;
+                    ex0 = 0xffffffffu; ex1 = 0xffffffffu; validated = false;
                     sp = 0; cur = 0;  // root
                 }
             }
@@ -201,7 +222,7 @@ __global__ __launch_bounds__(kTraverseBlock, 8) void k_trace_vote(DeviceScene sc
 // LIGHT = false: visible <=> nothing is hit (ClosestHit.slang:139, 344-353).  LIGHT = true: visible <=> the closest hit is
 // the sampled triangle (ClosestHit.slang:171-176, 358-370): that triangle is tested first by its own record, then the search
 // looks for anything that beats it (traverse.hpp closest_is).
-template <bool LIGHT, bool COUNT, bool TUNED>
+template <bool LIGHT, bool COUNT, bool TUNED, bool STRICT = false>
 __global__ __launch_bounds__(kTraverseBlock, 8) void k_trace_shadow(DeviceScene sc, const float4* RO, const float4* RD, unsigned char* vis, const uint32_t* n_dev,
                                                                   uint32_t* head, Counters* ctr, uint32_t param) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -242,7 +263,7 @@ __global__ __launch_bounds__(kTraverseBlock, 8) void k_trace_shadow(DeviceScene 
             VPT_MARK("tri");
             if (!node_wins & at_leaf) {
                 if (COUNT) st_tris++;
-                if (vote_tri_step_any(tris, S, cur, sp, o, d, tmin, tmax, tlim, expect)) visible = false;
+                if (vote_tri_step_any<STRICT>(tris, S, cur, sp, o, d, tmin, tmax, tlim, expect)) visible = false;
             }
         }
         VPT_MARK("exit");
@@ -280,6 +301,7 @@ __global__ __launch_bounds__(kTraverseBlock, 8) void k_trace_shadow(DeviceScene 
                             if (COUNT) st_tris++;
                             float u, v;
                             hit_it = vptfp::ray_triangle(o, d, vptfp::v3(ta.x, ta.y, ta.z), vptfp::v3(ta.w, tb.x, tb.y), vptfp::v3(tb.z, tb.w, tc.x), tmin, tmax, &tlim, &u, &v);
+                            if (STRICT) { if (hit_it) hit_it = vptfp::hit_is_local(o, d, vptfp::v3(ta.x, ta.y, ta.z), vptfp::v3(ta.w, tb.x, tb.y), vptfp::v3(tb.z, tb.w, tc.x), tlim); }   // traverse.hpp closest_is
                         }
                         if (!hit_it) { visible = false; cur = kLaneDone; }
                     }
@@ -322,6 +344,10 @@ void launch_trace(hipStream_t s, uint32_t blocks, uint32_t variant, bool any, bo
 #define VPT_LV(W, T) do { if (any) { if (count) hipLaunchKernelGGL((k_trace_vote<true, true, W, T>), g, b, lds, s, sc, a, ctr); else hipLaunchKernelGGL((k_trace_vote<true, false, W, T>), g, b, lds, s, sc, a, ctr); } \
                           else { if (count) hipLaunchKernelGGL((k_trace_vote<false, true, W, T>), g, b, lds, s, sc, a, ctr); else hipLaunchKernelGGL((k_trace_vote<false, false, W, T>), g, b, lds, s, sc, a, ctr); } } while (0)
     if (variant == VPT_TRACE_BASE) VPT_LT(k_trace_base); else if (variant == VPT_TRACE_VOTE8) VPT_LV(true, false);
+    else if (sc.strict_hits) {   // VPT_FLAG_LOCAL_HITS: the validating instantiations (default vote parameters)
+        if (any) hipLaunchKernelGGL((k_trace_vote<true, false, false, true, true>), g, b, lds, s, sc, a, ctr);
+        else hipLaunchKernelGGL((k_trace_vote<false, false, false, true, true>), g, b, lds, s, sc, a, ctr);
+    }
     else if (a.param == kVoteParamDefault) VPT_LV(false, true); else VPT_LV(false, false);
 #undef VPT_LV
 #undef VPT_LT
@@ -333,7 +359,10 @@ void launch_trace_shadow(hipStream_t s, uint32_t blocks, bool light, bool count,
     const dim3 g(blocks), b(kTraverseBlock);
 #define VPT_LS(L, C, T, RO, RD, VIS, LEN, HEAD) hipLaunchKernelGGL((k_trace_shadow<L, C, T>), g, b, lds, s, sc, RO, RD, VIS, LEN, HEAD, ctr, param)
     const bool tuned = param == kVoteParamDefault && !count;
-    if (light) {
+    if (sc.strict_hits) {   // VPT_FLAG_LOCAL_HITS
+        if (light) hipLaunchKernelGGL((k_trace_shadow<true, false, true, true>), g, b, lds, s, sc, ss.LTO, ss.LTD, ss.vis_light, &sctr->light_len.v, &sctr->light_head.v, ctr, param);
+        else hipLaunchKernelGGL((k_trace_shadow<false, false, true, true>), g, b, lds, s, sc, ss.SKO, ss.SKD, ss.vis_sky, &sctr->sky_len.v, &sctr->sky_head.v, ctr, param);
+    } else if (light) {
         if (tuned) VPT_LS(true, false, true, ss.LTO, ss.LTD, ss.vis_light, &sctr->light_len.v, &sctr->light_head.v);
         else if (count) VPT_LS(true, true, false, ss.LTO, ss.LTD, ss.vis_light, &sctr->light_len.v, &sctr->light_head.v);
         else VPT_LS(true, false, false, ss.LTO, ss.LTD, ss.vis_light, &sctr->light_len.v, &sctr->light_head.v);

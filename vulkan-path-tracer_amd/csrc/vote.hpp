@@ -145,9 +145,13 @@ __device__ __forceinline__ bool ray_triangle_flat(V3 o, V3 d, V3 v0, V3 e1, V3 e
     return (det != 0.0f) & (u >= 0.0f) & (u <= 1.0f) & (v >= 0.0f) & (u + v <= 1.0f) & (t > tmin) & (t < tmax);
 }
 
-// One triangle of the lane's leaf, closest-hit search (ties in t -> smaller global id).
+// One triangle of the lane's leaf, closest-hit search (ties in t -> smaller global id).  STRICT (VPT_FLAG_LOCAL_HITS): triangles
+// ex0 / ex1 — winners of earlier passes over this ray whose hit was not local to them — are not candidates (traverse.hpp
+// trace_closest_strict).
+template <bool STRICT = false>
 __device__ __forceinline__ void vote_tri_step_closest(const BvhTri* tris, const LaneStack& S, int& cur, int& sp, V3 o, V3 d, float tmin, float tmax,
-                                                      float& best_t, float& bu, float& bv, uint32_t& bslot, uint32_t& bgid) {
+                                                      float& best_t, float& bu, float& bv, uint32_t& bslot, uint32_t& bgid, uint32_t ex0 = 0xffffffffu,
+                                                      uint32_t ex1 = 0xffffffffu) {
     const uint32_t enc = (uint32_t)(~cur);
     const int first = (int)(enc >> 3);
     const uint32_t more = enc & 7u;  // triangles left after this one
@@ -156,14 +160,16 @@ __device__ __forceinline__ void vote_tri_step_closest(const BvhTri* tris, const 
     float t, u, v;
     const bool hit = ray_triangle_flat(o, d, vptfp::v3(ta.x, ta.y, ta.z), vptfp::v3(ta.w, tb.x, tb.y), vptfp::v3(tb.z, tb.w, tc.x), tmin, tmax, t, u, v);
     const uint32_t gid = __float_as_uint(tc.w);
-    const bool better = hit & ((bslot == 0xffffffffu) | (t < best_t) | ((t == best_t) & (gid < bgid)));
+    const bool better = hit & (!STRICT | ((gid != ex0) & (gid != ex1))) & ((bslot == 0xffffffffu) | (t < best_t) | ((t == best_t) & (gid < bgid)));
     best_t = better ? t : best_t; bu = better ? u : bu; bv = better ? v : bv; bslot = better ? (uint32_t)first : bslot; bgid = better ? gid : bgid;
     if (more) cur = ~(int)((((uint32_t)first + 1u) << 3) | (more - 1u));
     else S.pop_or_done(sp, cur);
 }
 // One triangle of the lane's leaf, any-hit search: stops at the first triangle hit with t < tlim, or t == tlim and a
 // smaller global id than `expect` (traverse.hpp: with tlim = tmax this is plain occlusion; with tlim = t_e of the sampled
-// light triangle it decides "is the closest hit that triangle").  Returns true when the search is over.
+// light triangle it decides "is the closest hit that triangle").  Returns true when the search is over.  STRICT: a triangle stops
+// the search only if its hit is local to it (vpt_fp32.h hit_is_local; validated on the spot, stops are rare).
+template <bool STRICT = false>
 __device__ __forceinline__ bool vote_tri_step_any(const BvhTri* tris, const LaneStack& S, int& cur, int& sp, V3 o, V3 d, float tmin, float tmax,
                                                   float tlim, uint32_t expect) {
     const uint32_t enc = (uint32_t)(~cur);
@@ -174,7 +180,8 @@ __device__ __forceinline__ bool vote_tri_step_any(const BvhTri* tris, const Lane
     float t, u, v;
     const bool hit = ray_triangle_flat(o, d, vptfp::v3(ta.x, ta.y, ta.z), vptfp::v3(ta.w, tb.x, tb.y), vptfp::v3(tb.z, tb.w, tc.x), tmin, tmax, t, u, v);
     const uint32_t gid = __float_as_uint(tc.w);
-    const bool stop = hit & ((t < tlim) | ((t == tlim) & (gid < expect)));
+    bool stop = hit & ((t < tlim) | ((t == tlim) & (gid < expect)));
+    if (STRICT) { if (stop) stop = vptfp::hit_is_local(o, d, vptfp::v3(ta.x, ta.y, ta.z), vptfp::v3(ta.w, tb.x, tb.y), vptfp::v3(tb.z, tb.w, tc.x), t); }
     if (stop) { cur = kLaneDone; return true; }
     if (more) cur = ~(int)((((uint32_t)first + 1u) << 3) | (more - 1u));
     else S.pop_or_done(sp, cur);

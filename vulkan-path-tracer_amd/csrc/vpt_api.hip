@@ -10,6 +10,7 @@
 #include <string>
 #include <vector>
 
+#include <dlfcn.h>
 #include <rccl/rccl.h>
 
 #include "bvh_build.hpp"
@@ -451,7 +452,7 @@ int render_batch(vpt_ctx* c, uint32_t frames, uint32_t dispatch_base) {
     // AUTO: fused for LDS-resident scenes, the stream pipeline otherwise (atrium 1150 vs 575, glass bust 2410 vs 1290, Cornell box with
     // the 960-triangle glass sphere 2880 vs 2600 Msamples/s: no scene measured prefers the fused kernel once its BVH lives in memory)
     const bool fused = vol || c->cfg.pipeline == VPT_PIPELINE_FUSED || (c->cfg.pipeline == VPT_PIPELINE_AUTO && c->lds_scene);
-    const bool stream = !fused && !c->lds_scene && !c->dsc.strict_hits && c->cfg.pipeline != VPT_PIPELINE_STAGED_R1;
+    const bool stream = !fused && !c->lds_scene && c->cfg.pipeline != VPT_PIPELINE_STAGED_R1;   // VPT_FLAG_LOCAL_HITS included: the stream kernels have validating instantiations
     if (!fused && !stream) { int rl = ensure_legacy_buffers(c); if (rl != VPT_OK) return rl; }
     if (stream && c->cfg.pipeline == VPT_PIPELINE_STAGED_SORTED) { int rl = ensure_sorted_buffers(c); if (rl != VPT_OK) return rl; }
     HIPCHK(c, hipMemsetAsync(c->ctr, 0, offsetof(Counters, stat_closest), s));  // queue words only, stat_* keep running
@@ -1228,6 +1229,14 @@ int vpt_comm_init(vpt_ctx* c, const void* id, int rank, int world) {
         return fail(c, VPT_ERR_INVALID_ARGUMENT, "vpt_comm_init: rank / world must equal the context's shard_rank / shard_count");
     if (c->comm) return fail(c, VPT_ERR_INVALID_ARGUMENT, "vpt_comm_init: the context already has a communicator");
     HIPCHK(c, hipSetDevice(c->cfg.device));
+    {   // the RCCL behind these calls is whichever librccl the process mapped first, not necessarily the one linked against
+        int v = 0;
+        if (ncclGetVersion(&v) != ncclSuccess) return fail(c, VPT_ERR_DEVICE, "ncclGetVersion failed");
+        if (v / 10000 != NCCL_VERSION_CODE / 10000) {
+            char msg[160]; snprintf(msg, sizeof(msg), "vpt_comm_init: the mapped RCCL is version %d, this library was built against %d (different major version)", v, (int)NCCL_VERSION_CODE);
+            return fail(c, VPT_ERR_DEVICE, msg);
+        }
+    }
     ncclUniqueId uid; memcpy(&uid, id, sizeof(uid));
     ncclResult_t r = ncclCommInitRank(&c->comm, world, uid, rank);
     if (r != ncclSuccess) { c->comm = nullptr; return nccl_fail(c, "ncclCommInitRank", r); }
@@ -1248,6 +1257,28 @@ int vpt_comm_gather_shards(vpt_ctx* c, int root) {
     if (r != ncclSuccess) return nccl_fail(c, "ncclGather", r);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return is_root ? assemble_from_gather_buf(c) : VPT_OK;
+}
+int vpt_comm_get_info(vpt_ctx* c, vpt_comm_info* out) {
+    if (!c || !out) return VPT_ERR_INVALID_ARGUMENT;
+    memset(out, 0, sizeof(*out));
+    int v = 0;
+    if (ncclGetVersion(&v) == ncclSuccess) out->rccl_version_runtime = v;
+    out->rccl_version_compiled = (int32_t)NCCL_VERSION_CODE;
+    Dl_info di{};
+    if (dladdr((const void*)&ncclGather, &di) && di.dli_fname) snprintf(out->library_path, sizeof(out->library_path), "%s", di.dli_fname);
+    out->rank = -1; out->device = -1;
+    if (c->comm) {
+        int n = 0, r = -1, d = -1;
+        if (ncclCommCount(c->comm, &n) != ncclSuccess || ncclCommUserRank(c->comm, &r) != ncclSuccess || ncclCommCuDevice(c->comm, &d) != ncclSuccess)
+            return fail(c, VPT_ERR_DEVICE, "ncclCommCount / ncclCommUserRank / ncclCommCuDevice failed");
+        out->nranks = n; out->rank = r; out->device = d;
+    }
+    return VPT_OK;
+}
+int vpt_device_identity(vpt_ctx* c, char* out, uint32_t out_bytes) {
+    if (!c || !out || out_bytes < 32) return VPT_ERR_INVALID_ARGUMENT;
+    HIPCHK(c, hipDeviceGetPCIBusId(out, (int)out_bytes, c->cfg.device));
+    return VPT_OK;
 }
 int vpt_comm_destroy(vpt_ctx* c) {
     if (!c) return VPT_ERR_INVALID_ARGUMENT;

@@ -25,6 +25,13 @@ class ShardComm:
         self.pt, self.rank, self.world, self.root, self.host_staged, self.group = pt, rank, world, root, host_staged, group
         self.ready = False
         if world > 1 and not host_staged:
+            # two ranks on one device: refuse here, with a message, before RCCL's bootstrap is entered (it rejects the configuration
+            # itself — "Duplicate GPU detected" — but only after every rank has joined)
+            me = self.device_identity()
+            names = [None] * world
+            dist.all_gather_object(names, me, group=group)
+            if len(set(names)) != world:
+                raise RuntimeError("ShardComm: ranks share a device %r — one process per GPU is required (VPT_ERR_DEVICE)" % (names,))
             ident = torch.zeros(_abi.COMM_ID_BYTES, dtype=torch.uint8)
             if rank == root:
                 buf = (C.c_ubyte * _abi.COMM_ID_BYTES)()
@@ -38,6 +45,25 @@ class ShardComm:
             if rc != 0:
                 raise RuntimeError("vpt_comm_init failed: %s" % pt.lib.vpt_last_error(pt.ctx).decode())
             self.ready = True
+
+    def device_identity(self):
+        """(host name, PCI bus id) of this rank's device (vpt_device_identity)."""
+        import socket
+        buf = C.create_string_buffer(64)
+        rc = self.pt.lib.vpt_device_identity(self.pt.ctx, buf, 64)
+        if rc != 0:
+            raise RuntimeError("vpt_device_identity failed: %s" % self.pt.lib.vpt_last_error(self.pt.ctx).decode())
+        return (socket.gethostname(), buf.value.decode())
+
+    def info(self):
+        """vpt_comm_get_info as a dict: the mapped RCCL's version and file, the compiled-against version, nranks / rank / device as
+        RCCL reports them for this communicator."""
+        ci = _abi.CommInfo()
+        rc = self.pt.lib.vpt_comm_get_info(self.pt.ctx, C.byref(ci))
+        if rc != 0:
+            raise RuntimeError("vpt_comm_get_info failed: %s" % self.pt.lib.vpt_last_error(self.pt.ctx).decode())
+        return {"rccl_version_runtime": ci.rccl_version_runtime, "rccl_version_compiled": ci.rccl_version_compiled, "nranks": ci.nranks, "rank": ci.rank,
+                "device": ci.device, "library_path": ci.library_path.decode()}
 
     def gather_and_assemble(self):
         """After this call the root context holds the whole image (radiance() / postprocess() work there)."""
