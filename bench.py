@@ -393,7 +393,7 @@ def main():
                 sc2 = load_scene(vpt, other)
                 w = profile_workload(vpt, other, sc2, local_rank, 0, 1, 0, 0, steps=6, warmup=5)
                 r = roofline_for(other, w)
-                w["roofline"] = {k: r[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_frac_of_hbm_peak", "valu_busy", "avg_launch_ms", "algorithmic_GBs", "algorithmic_frac_of_hbm_peak")}
+                w["roofline"] = {k: r[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_frac_of_hbm_peak", "valu_busy", "avg_launch_ms", "algorithmic_GBs", "algorithmic_frac_of_hbm_peak", "pmc", "valu")}
                 extra[other] = w
             line["workloads"] = extra
         if world == 1 and not args.no_cpu_baseline:

@@ -212,14 +212,14 @@ struct StreamState {
     float4* RA[2];  // payload.Origin.xyz | RNG state
     float4* RB[2];  // payload.Direction.xyz | payload.Depth, bit31 = InMedium
     float4* RT[2];  // pathThroughput.xyz | payload.PDF
-    float4* RL[2];  // pathLight.xyz (fused pipeline only: the staged one keeps pathLight by slot, where the join stage adds to it)
+    float4* RL[2];  // pathLight.xyz: moves with the queue entry like the other records; the join stage adds to it where the path now is
     float4* SH;     // hit record t,u,v | PrimitiveIndex of queue entry i (extend W, shade R)
     uint32_t* SHI;  // hit record InstanceIndex
     // pending paths of this bounce (anything to join: emission, NEE candidates, end of sample)
     float4* PE;   // emission / miss radiance .xyz | connect flags
     float4* PS;   // sky NEE contribution .xyz | index of its ray in the sky-ray stream
     float4* PL;   // light NEE contribution .xyz | index of its ray in the light-ray stream
-    float4* PT;   // pathThroughput before this bounce .xyz | slot (kHole: nobody wrote this entry)
+    float4* PT;   // pathThroughput before this bounce .xyz | the path's queue entry: in the next queue if kCF_Alive, else in this one (kHole: nobody wrote this entry)
     // shadow rays
     float4* SKO;  // sky rays: origin.xyz | dir.x
     float4* SKD;  //           dir.y, dir.z, 0xffffffff (0xfffffffe: hole), -
@@ -261,6 +261,7 @@ struct StreamCounters {
 
 // connect flags (CE.w)
 constexpr uint32_t kCF_Sky = 1u, kCF_Light = 2u, kCF_Finalize = 4u, kCF_Clamp = 8u;
+constexpr uint32_t kCF_Alive = 16u;   // streams pipeline: the path lives on, PT.w is its entry in the NEXT queue (else: in this one)
 
 struct Counters {
     uint32_t ray_count[2];    // active-path queue sizes (ping-pong by bounce parity)

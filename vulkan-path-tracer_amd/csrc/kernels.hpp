@@ -60,7 +60,8 @@ void launch_shade_stream(hipStream_t s, uint32_t blocks, uint32_t cls, bool sort
 void launch_classify_instances(hipStream_t s, const DeviceScene& sc, unsigned char* out, uint32_t n);
 void launch_trace_shadow(hipStream_t s, uint32_t blocks, bool light, bool count, const DeviceScene& sc, const StreamState& ss, Counters* ctr,
                          StreamCounters* sctr, uint32_t param);
-void launch_join(hipStream_t s, uint32_t blocks, const RenderParams& P, const PathState& ps, const StreamState& ss, const StreamCounters* sctr);
+void launch_join(hipStream_t s, uint32_t blocks, const RenderParams& P, const PathState& ps, const StreamState& ss, const StreamCounters* sctr, const uint32_t* queue,
+                 const uint32_t* queue_next, uint32_t parity);
 int shade_stream_blocks_per_cu();
 int trace_shadow_blocks_per_cu();
 

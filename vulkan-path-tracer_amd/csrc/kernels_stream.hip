@@ -188,11 +188,13 @@ __global__ __launch_bounds__(256, 3) void k_shade_stream(DeviceScene sc, RenderP
                 pending = want_sky || want_light || o.terminated || o.emitted.x != 0.0f || o.emitted.y != 0.0f || o.emitted.z != 0.0f || !thr_finite;
             }
             const uint32_t p_next = a_next.append(alive, &sctr->queue_len[parity ^ 1u].v);
-            if (alive) {   // the survivor's records move to where its queue entry goes
+            if (alive) {   // the survivor's records move to where its queue entry goes — pathLight included: the join stage then
+                           // updates it in stream order (two coalesced streams) instead of a scattered read-modify-write by slot
                 queue_next[p_next] = slot;
                 st_stream(&ss.RA[parity ^ 1u][p_next], f4u(o.new_o, o.rng));
                 st_stream(&ss.RB[parity ^ 1u][p_next], f4u(o.new_d, o.new_depth | (o.in_medium ? 0x80000000u : 0u)));
                 st_stream(&ss.RT[parity ^ 1u][p_next], f4(o.thr, o.new_pdf));
+                st_stream(&ss.RL[parity ^ 1u][p_next], ld_stream(&ss.RL[parity][qi]));
             }
             const uint32_t p_sky = a_sky.append(want_sky, &sctr->sky_len.v);
             if (want_sky) {
@@ -205,11 +207,12 @@ __global__ __launch_bounds__(256, 3) void k_shade_stream(DeviceScene sc, RenderP
                 st_stream(&ss.LTD[p_light], make_float4(o.light_d.y, o.light_d.z, __uint_as_float(o.light_gid), 0.0f));
             }
             const uint32_t p_pend = a_pend.append(pending, &sctr->pend_len.v);
-            if (pending) {
-                st_stream(&ss.PE[p_pend], f4u(o.emitted, o.cflags));
+            if (pending) {   // where the join finds the path's pathLight (and its slot, in the queue): its entry in the NEXT queue if it
+                             // lives on (a regenerated sample included), else its entry in this one
+                st_stream(&ss.PE[p_pend], f4u(o.emitted, o.cflags | (alive ? kCF_Alive : 0u)));
                 st_stream(&ss.PS[p_pend], f4u(o.csky, p_sky));
                 st_stream(&ss.PL[p_pend], f4u(o.clight, p_light));
-                st_stream(&ss.PT[p_pend], f4u(thr_prev, slot));
+                st_stream(&ss.PT[p_pend], f4u(thr_prev, alive ? p_next : qi));
             }
             w_paths += (uint32_t)__popcll(__ballot(valid));
             w_alive += (uint32_t)__popcll(__ballot(alive));
@@ -231,12 +234,13 @@ __global__ __launch_bounds__(256, 3) void k_shade_stream(DeviceScene sc, RenderP
 }
 
 // ------------------------------------------------------------------ join
-__global__ __launch_bounds__(256) void k_join(RenderParams P, PathState ps, StreamState ss, const StreamCounters* sctr) {
+__global__ __launch_bounds__(256) void k_join(RenderParams P, PathState ps, StreamState ss, const StreamCounters* sctr, const uint32_t* queue, const uint32_t* queue_next,
+                                              uint32_t parity) {
     const uint32_t n = sctr->pend_len.v;
     for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
         const float4 pt = ss.PT[j];
-        const uint32_t sl = __float_as_uint(pt.w);
-        if (sl == kHole) continue;
+        const uint32_t pos = __float_as_uint(pt.w);   // the path's entry in the next queue (it lives on) or in this one (it ended)
+        if (pos == kHole) continue;
         const float4 pe = ss.PE[j];
         const uint32_t fl = __float_as_uint(pe.w);
         V3 E = xyz(pe);
@@ -247,8 +251,12 @@ __global__ __launch_bounds__(256) void k_join(RenderParams P, PathState ps, Stre
             float lum = dot(contrib, v3(0.212671f, 0.715160f, 0.072169f));
             contrib = contrib * (P.max_luminance / max_(lum, P.max_luminance));
         }
-        V3 light = xyz(ps.L[sl]) + contrib;
+        // pathLight travels with the path's queue entry (k_shade_stream): pending entries and queue entries were appended by the
+        // same waves in the same order, so these accesses are streams too
+        float4* Lp = (fl & kCF_Alive) ? &ss.RL[parity ^ 1u][pos] : &ss.RL[parity][pos];
+        V3 light = xyz(*Lp) + contrib;
         if (fl & kCF_Finalize) {  // end of a sample: NaN/Inf guard, frame sum (RayGen.slang:116-128)
+            const uint32_t sl = (fl & kCF_Alive) ? queue_next[pos] : queue[pos];
             bool ok = !isinf_(light.x) && !isinf_(light.y) && !isinf_(light.z) && !isnan_(light.x) && !isnan_(light.y) && !isnan_(light.z);
             if (P.samples_per_frame == 1) {  // the only finalisation of this slot: 0 + pathLight
                 ps.ACC[sl] = ok ? f4(v3s(0.0f) + light, 0.0f) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -257,7 +265,7 @@ __global__ __launch_bounds__(256) void k_join(RenderParams P, PathState ps, Stre
             }
             light = v3s(0.0f);  // a regenerated sample starts from pathLight = 0
         }
-        st_stream(&ps.L[sl], f4(light, 0.0f));
+        if (fl & kCF_Alive) *Lp = f4(light, 0.0f);   // a path that ended has no use for it any more
     }
 }
 
@@ -275,7 +283,7 @@ __global__ __launch_bounds__(256) void k_raygen_stream(RenderParams P, PathState
     ss.RA[0][li] = f4u(o, r.s);
     ss.RB[0][li] = f4u(d, 0u);
     ss.RT[0][li] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);  // pathThroughput = 1, payload.PDF = 1
-    ps.L[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    ss.RL[0][li] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);   // pathLight = 0
     if (P.samples_per_frame > 1) { ps.ACC[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); ps.sidx[slot] = 0u; }
     queue[li] = slot;
 }
@@ -329,8 +337,9 @@ void launch_shade_stream(hipStream_t s, uint32_t blocks, uint32_t cls, bool sort
     else if (cls == kShadePlain) hipLaunchKernelGGL((k_shade_stream<(int)kShadePlain>), g, b, 0, s, sc, P, ps, ss, queue, order, queue_next, ctr, sctr, parity, cls);
     else hipLaunchKernelGGL((k_shade_stream<(int)kShadeTextured>), g, b, 0, s, sc, P, ps, ss, queue, order, queue_next, ctr, sctr, parity, cls);  // textured, glass, emissive: the general hit code
 }
-void launch_join(hipStream_t s, uint32_t blocks, const RenderParams& P, const PathState& ps, const StreamState& ss, const StreamCounters* sctr) {
-    hipLaunchKernelGGL(k_join, dim3(blocks), dim3(256), 0, s, P, ps, ss, sctr);
+void launch_join(hipStream_t s, uint32_t blocks, const RenderParams& P, const PathState& ps, const StreamState& ss, const StreamCounters* sctr, const uint32_t* queue,
+                 const uint32_t* queue_next, uint32_t parity) {
+    hipLaunchKernelGGL(k_join, dim3(blocks), dim3(256), 0, s, P, ps, ss, sctr, queue, queue_next, parity);
 }
 int shade_stream_blocks_per_cu() {
     int nb = 0;

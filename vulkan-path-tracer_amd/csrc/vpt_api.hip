@@ -519,7 +519,7 @@ int render_batch(vpt_ctx* c, uint32_t frames, uint32_t dispatch_base) {
                 }
                 TIMED(c, VPT_K_SHADOW, launch_trace_shadow(sb, (uint32_t)c->shadow_blocks, false, count, dsc_shadow, c->ss, c->ctr, c->sctr, c->vote_param));
                 TIMED(c, VPT_K_SHADOW, launch_trace_shadow(sb, (uint32_t)c->shadow_blocks, true, count, dsc_shadow, c->ss, c->ctr, c->sctr, c->vote_param));
-                TIMED(c, VPT_K_JOIN, launch_join(sb, (uint32_t)c->shade_blocks, c->P, c->ps, c->ss, c->sctr));
+                TIMED(c, VPT_K_JOIN, launch_join(sb, (uint32_t)c->shade_blocks, c->P, c->ps, c->ss, c->sctr, c->queue[parity], c->queue[parity ^ 1u], parity));
                 if (overlap) { HIPCHK(c, hipEventRecord(c->ev_join, c->stream2)); join_pending = true; }
                 parity ^= 1u;
                 continue;
