@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libvpt_hip.so")
-SOURCES = ["kernels_path.hip", "kernels_trace.hip", "kernels_stream.hip", "kernels_post.hip", "kernels_lut.hip", "vpt_api.hip", "bvh_build.cpp"]
+SOURCES = ["kernels_path.hip", "kernels_trace.hip", "kernels_stream.hip", "kernels_media.hip", "kernels_post.hip", "kernels_lut.hip", "vpt_api.hip", "bvh_build.cpp"]
 HEADERS = ["device_types.hpp", "kernels.hpp", "shading.hpp", "traverse.hpp", "bvh_build.hpp", "volume.hpp", "atmosphere.hpp", "wave.hpp", "shade_core.hpp", "vote.hpp",
            os.path.join("..", "..", "include", "vpt.h"), os.path.join("..", "..", "include", "vpt_fp32.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",

@@ -230,6 +230,14 @@ struct StreamState {
     uint32_t cap;              // entries allocated per stream
 };
 
+// Streams of the media variant of the staged pipeline (kernels_media.hip), indexed by QUEUE ENTRY like the path records: allocated
+// when a batch with volumes / atmosphere first runs on the streams pipeline (11 float4 per path).
+struct MediaState {
+    float4* MS;       // scatter decision: vol_index (int) | distance | atmosphere component + 1, bit 4 aborted, (colour channel + 1) << 8 | RNG state after the draws
+    float4* MP[10];   // what shade_core<VOL> leaves for the tail stage (emission | rng, new origin | depth, new direction | pdf, BxDF | flags, the two
+                      // NEE samples' ingredients, transmittance depths | VolumeDepth | ColorChannel, indices of the two shadow rays)
+};
+
 // Counters of the stream pipeline.  Every word several hundred waves hit with atomics sits in its OWN 256-byte block:
 // atomics on one line serialise at ~11 ns each whichever word they address (MI355X_MICROARCH.md 'dequeue'), and the first
 // version, with four stream lengths in one line, paid ~0.15 ms per launch for it.

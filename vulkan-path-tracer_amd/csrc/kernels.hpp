@@ -51,7 +51,7 @@ int trace_blocks_per_cu(uint32_t variant, bool any);
 
 // staged pipeline on compact streams (kernels_stream.hip)
 void launch_stream_begin(hipStream_t s, StreamCounters* sc, uint32_t n_slots);
-void launch_raygen_stream(hipStream_t s, const RenderParams& P, const PathState& ps, const StreamState& ss, uint32_t* queue, uint32_t n_slots, uint32_t dispatch_base);
+void launch_raygen_stream(hipStream_t s, const RenderParams& P, const PathState& ps, const StreamState& ss, uint32_t* queue, uint32_t n_slots, uint32_t dispatch_base, bool media);
 void launch_prepare_stream(hipStream_t s, StreamCounters* sc, uint32_t parity);
 void launch_classify(hipStream_t s, const uint32_t* queue, const unsigned char* cls, uint32_t* const* class_queue, StreamCounters* sc, uint32_t parity, uint32_t max_entries, uint32_t shade_waves);
 void launch_layout_single(hipStream_t s, StreamCounters* sc, uint32_t parity, uint32_t shade_waves);
@@ -63,6 +63,16 @@ void launch_trace_shadow(hipStream_t s, uint32_t blocks, bool light, bool count,
 void launch_join(hipStream_t s, uint32_t blocks, const RenderParams& P, const PathState& ps, const StreamState& ss, const StreamCounters* sctr, const uint32_t* queue,
                  const uint32_t* queue_next, uint32_t parity);
 int shade_stream_blocks_per_cu();
+// participating media on the streams (kernels_media.hip)
+void launch_media_scatter(hipStream_t s, uint32_t blocks, const DeviceScene& sc, const PathState& ps, const StreamState& ss, const MediaState& ms, const uint32_t* queue,
+                          const StreamCounters* sctr, uint32_t parity);
+void launch_layout_media(hipStream_t s, StreamCounters* sctr, uint32_t parity, uint32_t shade_waves, uint32_t tail_waves);
+void launch_shade_media(hipStream_t s, uint32_t blocks, const DeviceScene& sc, const RenderParams& P, const PathState& ps, const StreamState& ss, const MediaState& ms,
+                        const uint32_t* queue, Counters* ctr, StreamCounters* sctr, uint32_t parity);
+void launch_media_tail(hipStream_t s, uint32_t blocks, const DeviceScene& sc, const RenderParams& P, const PathState& ps, const StreamState& ss, const MediaState& ms,
+                       const uint32_t* queue, uint32_t* queue_next, Counters* ctr, StreamCounters* sctr, uint32_t parity);
+int shade_media_blocks_per_cu();
+int media_tail_blocks_per_cu();
 int trace_shadow_blocks_per_cu();
 
 // lookup-table generator (kernels_lut.hip)

@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256) void k_join(RenderParams P, PathState ps, Stre
 
 // Camera rays of a batch as the first ray queue and its records (RayGen.slang:12-64; the staged pipeline runs bounce 0 through
 // the same stages as every other bounce).
-__global__ __launch_bounds__(256) void k_raygen_stream(RenderParams P, PathState ps, StreamState ss, uint32_t* queue, uint32_t n_slots, uint32_t dispatch_base) {
+__global__ __launch_bounds__(256) void k_raygen_stream(RenderParams P, PathState ps, StreamState ss, uint32_t* queue, uint32_t n_slots, uint32_t dispatch_base, uint32_t media) {
     const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
     if (li >= n_slots) return;
     uint32_t slot, x, y, f;
@@ -285,10 +285,11 @@ __global__ __launch_bounds__(256) void k_raygen_stream(RenderParams P, PathState
     ss.RT[0][li] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);  // pathThroughput = 1, payload.PDF = 1
     ss.RL[0][li] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);   // pathLight = 0
     if (P.samples_per_frame > 1) { ps.ACC[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); ps.sidx[slot] = 0u; }
+    if (media) { ps.vdepth[slot] = 0u; ps.cchan[slot] = -1; }   // payload.VolumeDepth, payload.ColorChannel (RayGen.slang:54-62)
     queue[li] = slot;
 }
-void launch_raygen_stream(hipStream_t s, const RenderParams& P, const PathState& ps, const StreamState& ss, uint32_t* queue, uint32_t n_slots, uint32_t dispatch_base) {
-    hipLaunchKernelGGL(k_raygen_stream, dim3((n_slots + 255u) / 256u), dim3(256), 0, s, P, ps, ss, queue, n_slots, dispatch_base);
+void launch_raygen_stream(hipStream_t s, const RenderParams& P, const PathState& ps, const StreamState& ss, uint32_t* queue, uint32_t n_slots, uint32_t dispatch_base, bool media) {
+    hipLaunchKernelGGL(k_raygen_stream, dim3((n_slots + 255u) / 256u), dim3(256), 0, s, P, ps, ss, queue, n_slots, dispatch_base, media ? 1u : 0u);
 }
 
 // Start of a batch: the ray queue raygen filled.
@@ -310,7 +311,7 @@ __global__ void k_layout_single(StreamCounters* sc, uint32_t parity, uint32_t sh
 // Start of a bounce: cursors and class queue lengths to zero (the stream lengths are set by k_classify's last block).
 __global__ void k_prepare_stream(StreamCounters* sc, uint32_t parity) {
     sc->alive[parity ^ 1u].v = 0u;
-    sc->extend_head.v = 0u;   // (the shadow-ray cursors are reset where the streams are laid out: the previous bounce's shadow kernels may still run)
+    sc->extend_head.v = 0u; sc->shade_head.v = 0u;   // (shade_head: the distance stage's cursor in media batches; the shadow-ray cursors are reset where the streams are laid out: the previous bounce's shadow kernels may still run)
     for (uint32_t c = 0; c < kShadeClasses; c++) { sc->class_len[c].v = 0u; sc->class_head[c].v = 0u; }
     sc->classify_done = 0u;
 }

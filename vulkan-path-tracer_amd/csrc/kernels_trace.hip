@@ -303,7 +303,12 @@ __global__ __launch_bounds__(kTraverseBlock, 8) void k_trace_shadow(DeviceScene 
                             hit_it = vptfp::ray_triangle(o, d, vptfp::v3(ta.x, ta.y, ta.z), vptfp::v3(ta.w, tb.x, tb.y), vptfp::v3(tb.z, tb.w, tc.x), tmin, tmax, &tlim, &u, &v);
                             if (STRICT) { if (hit_it) hit_it = vptfp::hit_is_local(o, d, vptfp::v3(ta.x, ta.y, ta.z), vptfp::v3(ta.w, tb.x, tb.y), vptfp::v3(tb.z, tb.w, tc.x), tlim); }   // traverse.hpp closest_is
                         }
-                        if (!hit_it) { visible = false; cur = kLaneDone; }
+                        if (!hit_it) {
+                            // media NEE (RayGen.slang:296-299 compares a miss as "hit (0, 0)"): a ray flagged in RD.w is also visible when
+                            // it hits nothing at all — then this becomes a plain occlusion query; otherwise the sample is not visible
+                            if (rd.w != 0.0f) { tlim = tmax; expect = 0xffffffffu; }
+                            else { visible = false; cur = kLaneDone; }
+                        }
                     }
                 }
             }

@@ -78,6 +78,9 @@ struct vpt_ctx {
     uint32_t* class_queue[kShadeClasses] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // the shade queue sorted by class
     unsigned char* cls_q = nullptr;          // shade class per ray-queue entry, written by the extend stage
     StreamState ss{};
+    void* media_block = nullptr; // streams of the media variant of the staged pipeline (kernels_media.hip): allocated on first use
+    MediaState ms{};
+    int shade_media_blocks = 768, media_tail_blocks = 768;
     uint32_t class_present = 0x1fu;   // shade classes some instance of the scene belongs to (bit kShadeMiss always set): the others get no launch
     uint32_t stream_slack = 0;   // entries a stream may hold beyond its true count: unwritten chunk tails (vote.hpp WaveAppender)
     int shade_stream_blocks = 768, shadow_blocks = 2048;
@@ -160,6 +163,8 @@ void free_render_buffers(vpt_ctx* c) {
     c->cqueue = nullptr;
     if (c->ss_block) (void)hipFree(c->ss_block);
     c->ss_block = nullptr;
+    if (c->media_block) (void)hipFree(c->media_block);
+    c->media_block = nullptr; c->ms = MediaState{};
     for (uint32_t k = 0; k < kShadeClasses; k++) { if (c->class_queue[k]) (void)hipFree(c->class_queue[k]); c->class_queue[k] = nullptr; }
     if (c->cls_q) (void)hipFree(c->cls_q);
     c->cls_q = nullptr;
@@ -283,6 +288,22 @@ int alloc_render_buffers_impl(vpt_ctx* c) {
 // keep a path's records by slot: 12 more float4 records, the hit instance and the two-ended connect queue, 200 bytes per path,
 // allocated when such a batch is first rendered and kept until the next resize.
 // The class queues of VPT_PIPELINE_STAGED_SORTED (21 bytes per path), likewise on first use.
+// Media on the streams pipeline: 11 more float4 streams per queue entry (176 bytes per path), allocated when such a batch is first
+// rendered and kept until the next resize.  With the library's own batch size (~256M paths) that is 48 GB on top of ~95 GB.
+int ensure_media_buffers(vpt_ctx* c) {
+    if (c->media_block) return VPT_OK;
+    const size_t sst = ((size_t)c->ss.cap + 63) & ~(size_t)63;
+    if (hipMalloc(&c->media_block, sst * 16 * 11) != hipSuccess) {
+        (void)hipGetLastError();
+        c->media_block = nullptr;
+        return fail(c, VPT_ERR_DEVICE, "out of device memory for the media streams (176 bytes per resident path): lower vpt_config.frames_in_flight");
+    }
+    float4* q = (float4*)c->media_block;
+    c->ms.MS = q;
+    for (int k = 0; k < 10; k++) c->ms.MP[k] = q + (size_t)(k + 1) * sst;
+    return VPT_OK;
+}
+
 int ensure_sorted_buffers(vpt_ctx* c) {
     if (c->cls_q) return VPT_OK;
     const size_t scap = c->ss.cap;
@@ -451,8 +472,14 @@ int render_batch(vpt_ctx* c, uint32_t frames, uint32_t dispatch_base) {
     const bool vol = !c->volumes.empty() || c->dsc.atm_on;
     // AUTO: fused for LDS-resident scenes, the stream pipeline otherwise (atrium 1150 vs 575, glass bust 2410 vs 1290, Cornell box with
     // the 960-triangle glass sphere 2880 vs 2600 Msamples/s: no scene measured prefers the fused kernel once its BVH lives in memory)
-    const bool fused = vol || c->cfg.pipeline == VPT_PIPELINE_FUSED || (c->cfg.pipeline == VPT_PIPELINE_AUTO && c->lds_scene);
+    // Media (volumes / atmosphere): on the streams when the BVH lives in memory (kernels_media.hip: the traversal then runs on the
+    // vote-scheduled kernels), in the fused per-bounce kernel when it rides in LDS or when the fused pipeline is asked for.
+    const bool media_stream = vol && !c->lds_scene && (c->cfg.pipeline == VPT_PIPELINE_AUTO || c->cfg.pipeline == VPT_PIPELINE_STAGED);
+    const bool fused = (vol && !media_stream) || c->cfg.pipeline == VPT_PIPELINE_FUSED || (c->cfg.pipeline == VPT_PIPELINE_AUTO && c->lds_scene);
     const bool stream = !fused && !c->lds_scene && c->cfg.pipeline != VPT_PIPELINE_STAGED_R1;   // VPT_FLAG_LOCAL_HITS included: the stream kernels have validating instantiations
+    if (vol && c->cfg.pipeline == VPT_PIPELINE_STAGED && c->lds_scene)
+        return fail(c, VPT_ERR_UNSUPPORTED, "media with VPT_PIPELINE_STAGED need a scene whose BVH lives in memory (this one rides in LDS: use VPT_PIPELINE_AUTO or _FUSED)");
+    if (media_stream) { int rl = ensure_media_buffers(c); if (rl != VPT_OK) return rl; }
     if (!fused && !stream) { int rl = ensure_legacy_buffers(c); if (rl != VPT_OK) return rl; }
     if (stream && c->cfg.pipeline == VPT_PIPELINE_STAGED_SORTED) { int rl = ensure_sorted_buffers(c); if (rl != VPT_OK) return rl; }
     HIPCHK(c, hipMemsetAsync(c->ctr, 0, offsetof(Counters, stat_closest), s));  // queue words only, stat_* keep running
@@ -462,7 +489,7 @@ int render_batch(vpt_ctx* c, uint32_t frames, uint32_t dispatch_base) {
         TIMED(c, VPT_K_PRIMARY, launch_bounce(s, (uint32_t)c->primary_blocks, c->lds_scene, count, true, c->dsc, c->P, c->ps, c->ss, nullptr, c->queue[1], c->ctr, 0u, n_slots, dispatch_base, 0u));
         parity = 1; k3 = 1;
     } else if (stream) {
-        TIMED(c, VPT_K_PRIMARY, launch_raygen_stream(s, c->P, c->ps, c->ss, c->queue[0], n_slots, dispatch_base));
+        TIMED(c, VPT_K_PRIMARY, launch_raygen_stream(s, c->P, c->ps, c->ss, c->queue[0], n_slots, dispatch_base, media_stream));
         launch_stream_begin(s, c->sctr, n_slots);
         parity = 0;
     } else {
@@ -473,7 +500,7 @@ int render_batch(vpt_ctx* c, uint32_t frames, uint32_t dispatch_base) {
     // Two streams: the shadow-ray kernels and the join of bounce k run beside the extend of bounce k + 1 (which needs only the ray
     // queue shade k wrote), so the tail of one persistent traversal kernel is filled by the next one's first blocks.  Off while
     // kernels are timed or visits counted (one kernel at a time then) and in the sorted pipeline.
-    const bool overlap = stream && !sorted && !c->cfg.profile && !count;
+    const bool overlap = stream && !sorted && !c->cfg.profile && !count && !media_stream;
     bool join_pending = false;
     const uint64_t min_bounces = (uint64_t)c->P.max_depth * c->P.samples_per_frame;
     const uint64_t iter_cap = min_bounces * 4ull + 1024ull;
@@ -489,6 +516,25 @@ int render_batch(vpt_ctx* c, uint32_t frames, uint32_t dispatch_base) {
             // a memory-resident BVH runs the staged pipeline on the vote-scheduled traversal kernels and compact streams
             // (kernels_trace.hip, kernels_stream.hip); round 1's stage kernels serve LDS-resident scenes forced into the staged
             // pipeline, VPT_FLAG_LOCAL_HITS and VPT_PIPELINE_STAGED_R1
+            if (media_stream) {   // distance -> scatter -> extend -> shade -> sky rays, light rays -> tail (kernels_media.hip), one stream
+                launch_prepare_stream(s, c->sctr, parity);
+                TraceArgs a{};
+                a.ro = c->ss.RA[parity]; a.rd = c->ss.RB[parity]; a.order = nullptr; a.valid = c->queue[parity]; a.hit = c->ss.SH; a.hinst = c->ss.SHI; a.cls = nullptr;
+                a.n = 0; a.n_dev = &c->sctr->queue_len[parity].v; a.store_gid = 1u; a.param = c->vote_param;
+                // GetDistanceToGeometry (RTCommon.slang:86-101): the payload direction as it is, TMin 1e-5, TMax 1e6
+                a.head = &c->sctr->shade_head.v; a.tmin = 0.00001f; a.tmax = 1000000.0f; a.normalize_dir = 0u;
+                TIMED(c, VPT_K_EXTEND, launch_trace(s, (uint32_t)c->vote_blocks, VPT_TRACE_VOTE, false, count, c->dsc, a, c->ctr));
+                TIMED(c, VPT_K_SHADE, launch_media_scatter(s, (uint32_t)c->shade_blocks, c->dsc, c->ps, c->ss, c->ms, c->queue[parity], c->sctr, parity));
+                a.head = &c->sctr->extend_head.v; a.tmin = 0.01f; a.tmax = 100000.0f; a.normalize_dir = 1u;
+                TIMED(c, VPT_K_EXTEND, launch_trace(s, (uint32_t)c->vote_blocks, VPT_TRACE_VOTE, false, count, c->dsc, a, c->ctr));
+                launch_layout_media(s, c->sctr, parity, (uint32_t)c->shade_media_blocks * 4u, (uint32_t)c->media_tail_blocks * 4u);
+                TIMED(c, VPT_K_SHADE, launch_shade_media(s, (uint32_t)c->shade_media_blocks, c->dsc, c->P, c->ps, c->ss, c->ms, c->queue[parity], c->ctr, c->sctr, parity));
+                TIMED(c, VPT_K_SHADOW, launch_trace_shadow(s, (uint32_t)c->shadow_blocks, false, count, c->dsc, c->ss, c->ctr, c->sctr, c->vote_param));
+                TIMED(c, VPT_K_SHADOW, launch_trace_shadow(s, (uint32_t)c->shadow_blocks, true, count, c->dsc, c->ss, c->ctr, c->sctr, c->vote_param));
+                TIMED(c, VPT_K_JOIN, launch_media_tail(s, (uint32_t)c->media_tail_blocks, c->dsc, c->P, c->ps, c->ss, c->ms, c->queue[parity], c->queue[parity ^ 1u], c->ctr, c->sctr, parity));
+                parity ^= 1u;
+                continue;
+            }
             if (stream) {   // stream pipeline: extend -> classify -> shade per class (streams out) -> sky rays, light rays -> join
                 launch_prepare_stream(s, c->sctr, parity);
                 TraceArgs a{};
@@ -818,6 +864,8 @@ int vpt_set_scene(vpt_ctx* c, const vpt_scene_desc* sd) {
     c->shade_blocks = shade_blocks_per_cu() * c->cu_count;
     c->primary_blocks = bounce_blocks_per_cu(c->lds_scene, D) * c->cu_count;
     c->shade_stream_blocks = shade_stream_blocks_per_cu() * c->cu_count;
+    c->shade_media_blocks = shade_media_blocks_per_cu() * c->cu_count;
+    c->media_tail_blocks = media_tail_blocks_per_cu() * c->cu_count;
     c->shadow_blocks = trace_shadow_blocks_per_cu() * c->cu_count;
     c->vote_blocks = std::min(trace_blocks_per_cu(VPT_TRACE_VOTE, false), trace_blocks_per_cu(VPT_TRACE_VOTE, true)) * c->cu_count;
     {   // per-thread overflow region of the traversal stacks, for the largest persistent grid launched
@@ -906,7 +954,8 @@ int vpt_set_params(vpt_ctx* c, const vpt_params* p) {
 int vpt_set_volumes(vpt_ctx* c, const vpt_volume* v, uint32_t count) {
     if (!c || (count && !v)) return VPT_ERR_INVALID_ARGUMENT;
     if (count > VPT_MAX_VOLUMES) return fail(c, VPT_ERR_LIMIT, "more than VPT_MAX_VOLUMES volumes");
-    if (count && c->cfg.pipeline >= VPT_PIPELINE_STAGED) return fail(c, VPT_ERR_UNSUPPORTED, "volumes run on the fused pipeline (use VPT_PIPELINE_AUTO or _FUSED)");
+    if (count && (c->cfg.pipeline > VPT_PIPELINE_STAGED || (c->cfg.pipeline == VPT_PIPELINE_STAGED && c->has_scene && c->lds_scene)))
+        return fail(c, VPT_ERR_UNSUPPORTED, "volumes run on the fused pipeline or, for a scene whose BVH lives in memory, on the streams (VPT_PIPELINE_AUTO, _FUSED, _STAGED)");
     for (uint32_t i = 0; i < count; i++) {
         if (v[i].density_data_index < -1 || v[i].density_data_index >= (int)c->grids.size())
             return fail(c, VPT_ERR_INVALID_ARGUMENT, "density_data_index must be -1 or an index returned by vpt_add_density_grid");
@@ -981,7 +1030,8 @@ void vpt_default_atmosphere(vpt_atmosphere* a) {  // PathTracer.h:222-232
 }
 int vpt_set_atmosphere(vpt_ctx* c, const vpt_atmosphere* a) {
     if (!c) return VPT_ERR_INVALID_ARGUMENT;
-    if (a && c->cfg.pipeline >= VPT_PIPELINE_STAGED) return fail(c, VPT_ERR_UNSUPPORTED, "the atmosphere runs on the fused pipeline (use VPT_PIPELINE_AUTO or _FUSED)");
+    if (a && (c->cfg.pipeline > VPT_PIPELINE_STAGED || (c->cfg.pipeline == VPT_PIPELINE_STAGED && c->has_scene && c->lds_scene)))
+        return fail(c, VPT_ERR_UNSUPPORTED, "the atmosphere runs on the fused pipeline or, for a scene whose BVH lives in memory, on the streams (VPT_PIPELINE_AUTO, _FUSED, _STAGED)");
     if (a && (!(a->planet_radius > 0.0f) || !(a->atmosphere_height > 0.0f) || !(a->rayleigh_density_falloff > 0.0f) || !(a->mie_density_falloff > 0.0f) ||
               !(a->ozone_density_falloff > 0.0f)))
         return fail(c, VPT_ERR_INVALID_ARGUMENT, "planet radius, atmosphere height and the density falloffs must be > 0");
