@@ -37,6 +37,22 @@ def test_config3_atrium_exact_at_320x180(vpt, oracle, atrium, pipeline):
     assert 0.99 * atrium.triangle_count() <= st["bvh_triangles"] < atrium.triangle_count()   # the generator emits a few exact slivers; they are dropped
 
 
+@pytest.mark.parametrize("pipeline", [0, 1, 2])   # AUTO (= the media stages on the streams for this scene), the fused media kernel, the streams forced
+def test_fog_in_the_atrium_exact_at_320x180(vpt, oracle, atrium, pipeline):
+    """Media on a scene whose BVH lives in memory (kernels_media.hip): a homogeneous fog box over the whole hall, under the
+    sun-and-sky environment — every NEE sample crosses the box — against the oracle, on the fused media kernel and on the streams."""
+    lo = np.min([np.asarray(xf, np.float64)[:3, 3] for _, _, xf in atrium.instances], 0) - 6.0
+    hi = np.max([np.asarray(xf, np.float64)[:3, 3] for _, _, xf in atrium.instances], 0) + 6.0
+    fog = vpt.volume(corner_min=tuple(lo), corner_max=tuple(hi), color=(0.9, 0.9, 0.92), density=0.03, anisotropy=0.4)
+    P = vpt.default_params(max_depth=8)
+    o = oracle.Oracle(atrium, 320, 180); o.set_params(P); o.set_volumes([fog]); o.render(2)
+    ref = o.radiance(); o.close()
+    g = vpt.PathTracer(320, 180, pipeline=pipeline); g.set_scene(atrium); g.set_params(P); g.set_volumes([fog]); g.render(2)
+    img = g.radiance(); st = g.stats(); g.close()
+    assert np.array_equal(img, ref)
+    assert (st["kernel_launches"]["bounce"] > 0) == (pipeline == 1) and (st["kernel_launches"]["join"] > 0) == (pipeline != 1)
+
+
 @pytest.mark.parametrize("pipeline", [1, 2, 3, 4])
 def test_config5_glass_bust_exact_at_320x180_depth32(vpt, oracle, bust, pipeline):
     P = vpt.default_params(max_depth=32)
