@@ -602,11 +602,11 @@ int render_batch(vpt_ctx* c, uint32_t frames, uint32_t dispatch_base) {
             uint32_t len = 0;
             HIPCHK(c, hipMemcpy(&n, &c->sctr->alive[parity].v, 4, hipMemcpyDeviceToHost));
             HIPCHK(c, hipMemcpy(&len, &c->sctr->queue_len[parity].v, 4, hipMemcpyDeviceToHost));
-            if ((uint64_t)len > (uint64_t)c->ps.capacity + c->stream_slack) return fail(c, VPT_ERR_DEVICE, "internal: stream overflow");
+            if ((uint64_t)len > (uint64_t)c->ps.capacity + c->stream_slack) { (void)hipStreamSynchronize(c->stream2); return fail(c, VPT_ERR_DEVICE, "internal: stream overflow"); }
         }
-        if (n > n_slots) return fail(c, VPT_ERR_DEVICE, "internal: queue overflow");
+        if (n > n_slots) { (void)hipStreamSynchronize(c->stream2); return fail(c, VPT_ERR_DEVICE, "internal: queue overflow"); }
         if (n == 0) break;
-        if (iter > iter_cap) return fail(c, VPT_ERR_DEVICE, "internal: bounce loop did not terminate");
+        if (iter > iter_cap) { (void)hipStreamSynchronize(c->stream2); return fail(c, VPT_ERR_DEVICE, "internal: bounce loop did not terminate"); }
         chunk = 4;
     }
     HIPCHK(c, hipGetLastError());
@@ -868,6 +868,13 @@ int vpt_set_scene(vpt_ctx* c, const vpt_scene_desc* sd) {
     c->media_tail_blocks = media_tail_blocks_per_cu() * c->cu_count;
     c->shadow_blocks = trace_shadow_blocks_per_cu() * c->cu_count;
     c->vote_blocks = std::min(trace_blocks_per_cu(VPT_TRACE_VOTE, false), trace_blocks_per_cu(VPT_TRACE_VOTE, true)) * c->cu_count;
+    {   // every wave of a launch that appends to a stream may leave one unwritten chunk tail in it (vote.hpp WaveAppender): the streams were
+        // allocated with room for stream_slack such entries — refuse here, not after a kernel has written past a stream, if a device
+        // with more CUs / other occupancy than the allocation assumed ever needs more
+        const uint64_t appending_waves = 4ull * (uint64_t)std::max(std::max(c->shade_stream_blocks, c->primary_blocks), std::max(c->shade_media_blocks, c->media_tail_blocks));
+        if (c->buffers_ok && appending_waves * kAppendChunk > (uint64_t)c->stream_slack && (uint64_t)c->ps.capacity * 4 + 256 > (uint64_t)c->stream_slack)
+            return fail(c, VPT_ERR_DEVICE, "internal: the stream slack allocated for chunk tails is smaller than one chunk per appending wave of this device");
+    }
     {   // per-thread overflow region of the traversal stacks, for the largest persistent grid launched
         c->max_blocks = std::max(std::max(std::max(std::max(c->trav_blocks, c->shade_blocks), c->primary_blocks), c->vote_blocks), std::max(c->shade_stream_blocks, c->shadow_blocks));
         void* d = nullptr;
@@ -887,7 +894,8 @@ int vpt_set_scene(vpt_ctx* c, const vpt_scene_desc* sd) {
     if ((rc = update_class_present(c))) return rc;
     HIPCHK(c, hipGetLastError());
     c->has_scene = true;
-    HIPCHK(c, hipMemset(c->image, 0, (size_t)c->P.shard_pixels * 16));
+    // (after a failed vpt_resize there is no image to clear: the scene is installed all the same, rendering needs a successful resize first)
+    if (c->buffers_ok) HIPCHK(c, hipMemset(c->image, 0, (size_t)c->P.shard_pixels * 16));
     return VPT_OK;
 }
 
