@@ -872,7 +872,7 @@ int vpt_set_scene(vpt_ctx* c, const vpt_scene_desc* sd) {
         // allocated with room for stream_slack such entries — refuse here, not after a kernel has written past a stream, if a device
         // with more CUs / other occupancy than the allocation assumed ever needs more
         const uint64_t appending_waves = 4ull * (uint64_t)std::max(std::max(c->shade_stream_blocks, c->primary_blocks), std::max(c->shade_media_blocks, c->media_tail_blocks));
-        if (c->buffers_ok && appending_waves * kAppendChunk > (uint64_t)c->stream_slack && (uint64_t)c->ps.capacity * 4 + 256 > (uint64_t)c->stream_slack)
+        if (c->buffers_ok && appending_waves * 256u /* vote.hpp kAppendChunk */ > (uint64_t)c->stream_slack && (uint64_t)c->ps.capacity * 4 + 256 > (uint64_t)c->stream_slack)
             return fail(c, VPT_ERR_DEVICE, "internal: the stream slack allocated for chunk tails is smaller than one chunk per appending wave of this device");
     }
     {   // per-thread overflow region of the traversal stacks, for the largest persistent grid launched
