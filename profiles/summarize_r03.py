@@ -23,11 +23,15 @@ for r in csv.DictReader(open(ks)):
     if s:
         d = dur.setdefault(s, [0, 0.0]); d[0] += int(r["Calls"]); d[1] += float(r["TotalDurationNs"])
 acc = collections.defaultdict(lambda: collections.defaultdict(float))
+passes = collections.defaultdict(set)   # a counter collected in several passes (GRBM_GUI_ACTIVE, SQ_INSTS_VALU, ...) is averaged over them
 for f in glob.glob(os.path.join(G, "*", "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
         s = stage(r["Kernel_Name"])
         if s:
-            acc[s][r["Counter_Name"]] += float(r["Counter_Value"])
+            acc[s][r["Counter_Name"]] += float(r["Counter_Value"]); passes[r["Counter_Name"]].add(f)
+for s in acc:
+    for k in acc[s]:
+        acc[s][k] /= max(len(passes[k]), 1)
 rows = {}
 lines = ["# %s, pipeline %s — rocprofv3 summary (%s)" % (scene, pipe, os.environ.get("TAG", "r03")), "",
          "`SCENE=%s PIPE=%s python tests/gpu_atrium_run.py` under profiles/collect_r03.sh: 1920x1080, %s frames in flight, 2 measured batches (+1 warm-up, included in the sums)." % (scene, pipe, os.environ.get("FRAMES", "64")), "",
@@ -54,7 +58,7 @@ if any("TA_TA_BUSY_sum" in acc[s] for s in acc):
         fp = a["SQ_INSTS_VALU_ADD_F32"] + a["SQ_INSTS_VALU_MUL_F32"] + a["SQ_INSTS_VALU_FMA_F32"] + a["SQ_INSTS_VALU_TRANS_F32"]
         flop = (a["SQ_INSTS_VALU_ADD_F32"] + a["SQ_INSTS_VALU_MUL_F32"] + a["SQ_INSTS_VALU_TRANS_F32"] + 2 * a["SQ_INSTS_VALU_FMA_F32"]) * 64 * rows[s]["lane_use"]
         tfl = div(flop, tot / 1e9) / 1e12
-        rows[s].update({"ta_busy": div(a["TA_TA_BUSY_sum"], 256 * a["GRBM_GUI_ACTIVE"] / 3 if False else 256 * a["GRBM_GUI_ACTIVE"]), "fp32_tflops": tfl,
+        rows[s].update({"ta_busy": div(a["TA_TA_BUSY_sum"], 256 * a["GRBM_GUI_ACTIVE"]), "fp32_tflops": tfl,
                         "l1_accesses_per_vmem_rd": div(a["TCP_TOTAL_CACHE_ACCESSES_sum"], a["SQ_INSTS_VMEM_RD"]), "icache_hit": div(a["SQC_ICACHE_HITS"], a["SQC_ICACHE_REQ"])})
         lines.append("| %s | %.0f %% | %.1f | %.0f %% | %.0f %% | %.2f | %.3f | %.1f %% | %.2f |" % (
             s, 100 * rows[s]["ta_busy"], rows[s]["l1_accesses_per_vmem_rd"], 100 * div(a["TCP_PENDING_STALL_CYCLES_sum"], a["TCP_GATE_EN1_sum"]),
