@@ -217,7 +217,7 @@ def kernel_profile(vpt, name, scene, device, rank, world, pipeline, frames_in_fl
     pp = vpt.PathTracer(WIDTH, HEIGHT, device=device, shard_rank=rank, shard_count=world, pipeline=pipeline, frames_in_flight=frames_in_flight, profile=True)
     pp.set_scene(scene); pp.set_params(params)
     F = pp.stats()["frames_in_flight"]
-    for _ in range(4):        # AUTO times both pipelines over the first four full batches
+    for _ in range(2):        # warm-up batches (buffers of the chosen pipeline are allocated on first use)
         pp.render(F)
     pp.reset_stats()
     for _ in range(steps):

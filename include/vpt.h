@@ -424,7 +424,11 @@ int vpt_lab_trace(vpt_ctx* ctx, uint32_t variant, uint32_t any_hit, const uint32
  * order and divided by the pass count.  The reference puts wall-clock milliseconds into time_ms (one reading
  * per pass); here it is one caller-chosen value, so a table is reproducible.  Application.cpp:41,54,67 use
  * sizes 64x64x32 (reflect) and 128x128x32 (refract) with 10'000'000 samples.
- * out_host receives size_x*size_y*size_z floats, x fastest.  Needs no context (runs on `device`). */
+ * out_host receives size_x*size_y*size_z floats, x fastest.  Needs no context (runs on `device`).
+ * Known disagreement with the shipped tables (tests/test_oracle_lut_fp64.py): in the grazing near-mirror corner of
+ * the two refraction tables (rows y <= 4 with x <= 31, and layer z = 0) this generator — like a float64 evaluation of the same
+ * algorithm — gives 0.896 where Assets/LookupTables/RefractionLookup*.bin hold 0.819.  Everywhere else the generated tables match the
+ * shipped ones within Monte-Carlo error.  Rendering is unaffected: the integrator consumes whichever tables vpt_set_scene is given. */
 #define VPT_LUT_REFLECT 0
 #define VPT_LUT_REFRACT_ABOVE 1
 #define VPT_LUT_REFRACT_BELOW 2

@@ -5,8 +5,9 @@
 //   * GetOutputImage() hands back the RGBA32F accumulation image as host floats;
 //   * the seed is explicit (SetSeed): the reference draws it from the wall clock (PathTracer.cpp:127-140);
 //   * errors throw std::runtime_error where the reference VH_ASSERT-aborts.
-// Homogeneous box volumes are in (AddVolume / SetVolume / RemoveVolume / SetPhaseFunction); NanoVDB density grids
-// (AddDensityDataToVolume) and the atmosphere members are absent.
+// Box volumes (AddVolume / SetVolume / RemoveVolume / SetPhaseFunction) and the atmosphere members (SetEnableAtmosphere, SetPlanetRadius,
+// ...) are in; heterogeneous volumes take their density as a dense grid of decoded voxels (the C-ABI's vpt_add_density_grid): reading
+// .vdb / NanoVDB files (AddDensityDataToVolume, PathTracer.cpp:1347-1516) is the one member that is absent.
 #pragma once
 #include <cstdint>
 #include <string>
