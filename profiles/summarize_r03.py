@@ -48,20 +48,22 @@ for s, (calls, tot) in sorted(dur.items(), key=lambda kv: -kv[1][1]):
     lines.append("| %s | %d | %.2f | %.0f %% | %.0f %% | %.0f %% | %.3g | %.0f %% | %.2f | %.2f |" % (s, calls, tot / 1e6, 100 * wait, 100 * busy, 100 * lane, a["SQ_INSTS_VALU"], 100 * l2, rows[s]["fetched_GB"], rows[s]["written_GB"]))
 # ---- round 3 additions: vector-memory pipeline, fp32 mix, instruction cache (only when those passes were collected)
 if any("TA_TA_BUSY_sum" in acc[s] for s in acc):
-    lines += ["", "Vector-memory pipeline, fp32 operation mix and instruction fetch (separate passes: `ta`, `flops`, `icache`).  TA busy = TA_TA_BUSY_sum / (256 TAs x GRBM_GUI_ACTIVE);",
+    lines += ["", "Vector-memory pipeline, fp32 operation mix and instruction fetch (separate passes: `ta`, `flops`, `icache`).  TA busy = TA_TA_BUSY_sum / (32 x GRBM_GUI_ACTIVE): GRBM_GUI_ACTIVE sums the 8 XCDs, each with 32 CUs / TAs (TCP_GATE_EN1_sum / GRBM_GUI_ACTIVE reads 31.7 on a kernel that keeps every CU's L1 clocked);",
               "L1 accesses per VMEM-read wave-instruction = TCP_TOTAL_CACHE_ACCESSES_sum / SQ_INSTS_VMEM_RD (64 = every lane its own 64-byte request, 16 = four lanes per request);",
               "fp32 FLOP = (ADD + MUL + TRANS + 2 x FMA) wave-instructions x 64 lanes x lane use; peak 157.3 TFLOP/s (which assumes packed FMA on every lane).", "",
-              "| stage | TA busy | L1 accesses / VMEM-rd instr | TCP pending-stall share | fp32 share of VALU instr | fp32 TFLOP/s | of 157.3 | I-cache hit | SALU / VALU instr |", "|---|---|---|---|---|---|---|---|---|"]
+              "L1 accesses per clock per CU = TCP_TOTAL_CACHE_ACCESSES_sum / (256 CUs x kernel time x 2.4 GHz): a CU's L1 takes about one access per clock (tests/tools/gather_calib.hip).", "",
+              "| stage | TA busy | L1 accesses / clk / CU | L1 accesses / VMEM-rd instr | TCP pending-stall share | fp32 share of VALU instr | fp32 TFLOP/s | of 157.3 | I-cache hit | SALU / VALU instr |", "|---|---|---|---|---|---|---|---|---|---|"]
     for s, (calls, tot) in sorted(dur.items(), key=lambda kv: -kv[1][1]):
         a = acc[s]
         div = lambda x, y: x / y if y else float("nan")
         fp = a["SQ_INSTS_VALU_ADD_F32"] + a["SQ_INSTS_VALU_MUL_F32"] + a["SQ_INSTS_VALU_FMA_F32"] + a["SQ_INSTS_VALU_TRANS_F32"]
         flop = (a["SQ_INSTS_VALU_ADD_F32"] + a["SQ_INSTS_VALU_MUL_F32"] + a["SQ_INSTS_VALU_TRANS_F32"] + 2 * a["SQ_INSTS_VALU_FMA_F32"]) * 64 * rows[s]["lane_use"]
         tfl = div(flop, tot / 1e9) / 1e12
-        rows[s].update({"ta_busy": div(a["TA_TA_BUSY_sum"], 256 * a["GRBM_GUI_ACTIVE"]), "fp32_tflops": tfl,
+        rows[s].update({"ta_busy": div(a["TA_TA_BUSY_sum"], 32 * a["GRBM_GUI_ACTIVE"]), "fp32_tflops": tfl,
                         "l1_accesses_per_vmem_rd": div(a["TCP_TOTAL_CACHE_ACCESSES_sum"], a["SQ_INSTS_VMEM_RD"]), "icache_hit": div(a["SQC_ICACHE_HITS"], a["SQC_ICACHE_REQ"])})
-        lines.append("| %s | %.0f %% | %.1f | %.0f %% | %.0f %% | %.2f | %.3f | %.1f %% | %.2f |" % (
-            s, 100 * rows[s]["ta_busy"], rows[s]["l1_accesses_per_vmem_rd"], 100 * div(a["TCP_PENDING_STALL_CYCLES_sum"], a["TCP_GATE_EN1_sum"]),
+        rows[s]["l1_accesses_per_clk_per_cu"] = div(a["TCP_TOTAL_CACHE_ACCESSES_sum"], 256 * (tot / 1e9) * 2.4e9)
+        lines.append("| %s | %.0f %% | %.2f | %.1f | %.0f %% | %.0f %% | %.2f | %.3f | %.1f %% | %.2f |" % (
+            s, 100 * rows[s]["ta_busy"], rows[s]["l1_accesses_per_clk_per_cu"], rows[s]["l1_accesses_per_vmem_rd"], 100 * div(a["TCP_PENDING_STALL_CYCLES_sum"], a["TCP_GATE_EN1_sum"]),
             100 * div(fp, a["SQ_INSTS_VALU"]), tfl, tfl / 157.3, 100 * rows[s]["icache_hit"], div(a["SQ_INSTS_SALU"], a["SQ_INSTS_VALU"])))
 open(os.path.join(ROOT, "profiles", tag + "_summary.md"), "w").write("\n".join(lines) + "\n")
 json.dump(rows, open(os.path.join(ROOT, "profiles", tag + "_counters.json"), "w"), indent=1)

@@ -163,6 +163,8 @@ def main():
                     [(BASE, 0), (VOTE, 8), (VOTE, 16), (VOTE, 32), (VOTE, 48), (VOTE, 64), (VOTE, 256 + 16), (VOTE, 256 + 32)])
             if sweep:   # vote weight x fetch threshold around the default (2.0, 16)
                 plan = [(VOTE, 16), (VOTE, 256 + 16)] + [(VOTE, PW(w4, f)) for w4 in (4, 5, 6, 7, 10, 12) for f in (16,)] + [(VOTE, PW(w4, f)) for w4 in (6, 8) for f in (8, 12, 24)]
+            if os.environ.get("LAB_TOP") == "1":   # LDS-resident tree top on / off (bit 16) in the run-time-parameter instantiation, next to the product one
+                plan = [(VOTE, 16), (VOTE, 256 + 16), (VOTE, PW(8, 16)), (VOTE, PW(8, 16) | (1 << 16))]
             for variant, param in plan:
                 first = ref is None or (variant in (VOTE, VOTE8) and param == 16)
                 ms, hits, vis = lab_trace(g, variant, any_hit, order, param, 5, True, first)

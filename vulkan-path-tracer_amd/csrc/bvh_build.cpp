@@ -400,6 +400,28 @@ void build_bvh(const std::vector<BvhTri>& tris_in, std::vector<BvhNode>& nodes_o
         }
     }
     if (depth_out) *depth_out = max_depth;
+    {   // The top of the tree first, in breadth-first order: nodes 0 .. kBvhTopNodes-1 are the ones the traversal kernels keep in LDS
+        // (vote.hpp LaneStack / kernels_trace.hip: every ray visits them, and a node fetched from LDS costs the vector L1 nothing);
+        // the rest keep their depth-first order (subtrees contiguous).  A pure renumbering: boxes, children and leaves are unchanged.
+        const size_t n = nodes_out.size();
+        std::vector<int> order; order.reserve(n);
+        std::vector<char> taken(n, 0);
+        order.push_back(0); taken[0] = 1;
+        for (size_t head = 0; head < order.size() && order.size() < (size_t)kBvhTopNodes; head++)
+            for (int k = 0; k < 4 && order.size() < (size_t)kBvhTopNodes; k++) {
+                const int c = nodes_out[order[head]].child[k];
+                if (c >= 0 && !taken[c]) { taken[c] = 1; order.push_back(c); }
+            }
+        for (size_t i = 0; i < n; i++) if (!taken[i]) order.push_back((int)i);
+        std::vector<int> new_index(n);
+        for (size_t i = 0; i < n; i++) new_index[order[i]] = (int)i;
+        std::vector<BvhNode> nn(n); std::vector<BvhNodeWide> nw(n);
+        for (size_t i = 0; i < n; i++) {
+            nn[i] = nodes_out[order[i]]; nw[i] = wide_out[order[i]];
+            for (int k = 0; k < 4; k++) if (nn[i].child[k] >= 0) { nn[i].child[k] = new_index[nn[i].child[k]]; nw[i].child[k] = nn[i].child[k]; }
+        }
+        nodes_out.swap(nn); wide_out.swap(nw);
+    }
     if (!nodes8_out) return;
 
     // ---- the same binary tree collapsed EIGHT-wide (BVH8 experiment): a node adopts descendants, largest box first, until it

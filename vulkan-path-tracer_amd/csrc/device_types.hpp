@@ -32,6 +32,9 @@ struct BvhNode {
     }
 };
 static_assert(sizeof(BvhNode) == 64, "node is 64 B");
+// The builder numbers the top of the tree breadth-first: nodes 0 .. kBvhTopNodes-1 (root, its children, ...) are the ones the ray-stream
+// traversal kernels copy into LDS (4 KB per block next to the 14 KB of stacks: 8 blocks per CU still fit the 160 KB).
+constexpr int kBvhTopNodes = 64;
 
 // Eight-wide variant of the quantised node (96 B, 6 x dwordx4) for the BVH8 experiment: same grid
 // quantisation, eight child boxes, children placed in slots by OCTANT — bit a of a slot index says on which side of the node's

@@ -93,6 +93,7 @@ __global__ __launch_bounds__(kTraverseBlock, 8) void k_trace_vote(DeviceScene sc
     const LaneStack S = make_lane_stack(smem, sc.stack_overflow);
     const BvhNode* const nodes = sc.nodes;
     const BvhTri* const tris = sc.tris;
+    const TreeTop top = stage_tree_top(smem, nodes, sc.node_count, !WIDE8 && (TUNED || ((a.param >> 16) & 1u) == 0u));   // lab: bit 16 switches the LDS tree top off
     const uint32_t n = a.n_dev ? *a.n_dev : a.n;
     const uint32_t chunk = fetch_chunk(n);
     const uint32_t fetch_at = TUNED ? 16u : (a.param & 0xffu) ? (a.param & 0xffu) : 16u;  // idle lanes that trigger a fetch step (64: only when all are idle)
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(kTraverseBlock, 8) void k_trace_vote(DeviceScene sc
             if (node_wins & at_node) {  // ---- inner-node step
                 if (COUNT) st_nodes++;
                 if (WIDE8) vote_node8_step(sc.nodes8, S, cur, sp, o, inv, a.tmin, best_t);
-                else vote_node_step<ANY>(nodes, S, cur, sp, o, inv, a.tmin, best_t);
+                else vote_node_step<ANY>(nodes, top, S, cur, sp, o, inv, a.tmin, best_t);
             }
             VPT_MARK("tri");
             if (!node_wins & at_leaf) {  // ---- triangle step: ONE triangle of the lane's leaf
@@ -229,6 +230,7 @@ __global__ __launch_bounds__(kTraverseBlock, 8) void k_trace_shadow(DeviceScene 
     const LaneStack S = make_lane_stack(smem, sc.stack_overflow);
     const BvhNode* const nodes = sc.nodes;
     const BvhTri* const tris = sc.tris;
+    const TreeTop top = stage_tree_top(smem, nodes, sc.node_count, TUNED || ((param >> 16) & 1u) == 0u);
     const uint32_t n = *n_dev;
     const uint32_t chunk = fetch_chunk(n);
     const uint32_t fetch_at = TUNED ? 16u : (param & 0xffu) ? (param & 0xffu) : 16u;
@@ -258,7 +260,7 @@ __global__ __launch_bounds__(kTraverseBlock, 8) void k_trace_shadow(DeviceScene 
             VPT_MARK("node");   // two predicated regions in sequence, not if / else (see k_trace_vote)
             if (node_wins & at_node) {
                 if (COUNT) st_nodes++;
-                vote_node_step<true>(nodes, S, cur, sp, o, inv, tmin, tlim);
+                vote_node_step<true>(nodes, top, S, cur, sp, o, inv, tmin, tlim);
             }
             VPT_MARK("tri");
             if (!node_wins & at_leaf) {
@@ -327,7 +329,7 @@ __global__ __launch_bounds__(kTraverseBlock, 8) void k_trace_shadow(DeviceScene 
 // ------------------------------------------------------------------ launch
 int trace_blocks_per_cu(uint32_t variant, bool any) {
     int nb = 0;
-    const size_t lds = kVoteStackBytes;
+    const size_t lds = variant == VPT_TRACE_BASE ? kVoteStackBytes : kVoteLdsBytes;
     if (variant == VPT_TRACE_BASE) {
         if (any) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_base<true, false>, kTraverseBlock, lds);
         else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_base<false, false>, kTraverseBlock, lds);
@@ -342,7 +344,7 @@ int trace_blocks_per_cu(uint32_t variant, bool any) {
 }
 
 void launch_trace(hipStream_t s, uint32_t blocks, uint32_t variant, bool any, bool count, const DeviceScene& sc, const TraceArgs& a, Counters* ctr) {
-    const size_t lds = kVoteStackBytes;
+    const size_t lds = variant == VPT_TRACE_BASE ? kVoteStackBytes : kVoteLdsBytes;
     const dim3 g(blocks), b(kTraverseBlock);
 #define VPT_LT(K) do { if (any) { if (count) hipLaunchKernelGGL((K<true, true>), g, b, lds, s, sc, a, ctr); else hipLaunchKernelGGL((K<true, false>), g, b, lds, s, sc, a, ctr); } \
                        else { if (count) hipLaunchKernelGGL((K<false, true>), g, b, lds, s, sc, a, ctr); else hipLaunchKernelGGL((K<false, false>), g, b, lds, s, sc, a, ctr); } } while (0)
@@ -360,7 +362,7 @@ void launch_trace(hipStream_t s, uint32_t blocks, uint32_t variant, bool any, bo
 
 void launch_trace_shadow(hipStream_t s, uint32_t blocks, bool light, bool count, const DeviceScene& sc, const StreamState& ss, Counters* ctr,
                          StreamCounters* sctr, uint32_t param) {
-    const size_t lds = kVoteStackBytes;
+    const size_t lds = kVoteLdsBytes;
     const dim3 g(blocks), b(kTraverseBlock);
 #define VPT_LS(L, C, T, RO, RD, VIS, LEN, HEAD) hipLaunchKernelGGL((k_trace_shadow<L, C, T>), g, b, lds, s, sc, RO, RD, VIS, LEN, HEAD, ctr, param)
     const bool tuned = param == kVoteParamDefault && !count;
@@ -380,7 +382,7 @@ void launch_trace_shadow(hipStream_t s, uint32_t blocks, bool light, bool count,
 }
 int trace_shadow_blocks_per_cu() {
     int a = 0, b = 0;
-    const size_t lds = kVoteStackBytes;
+    const size_t lds = kVoteLdsBytes;
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_trace_shadow<true, false, true>, kTraverseBlock, lds);
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_trace_shadow<false, false, true>, kTraverseBlock, lds);
     int nb = a < b ? a : b;

@@ -44,13 +44,34 @@ __device__ __forceinline__ LaneStack make_lane_stack(unsigned char* smem, uint32
     return S;
 }
 constexpr size_t kVoteStackBytes = (size_t)kVoteStackRows * kTraverseBlock * 4;
+// The block's LDS copy of the tree top (device_types.hpp kBvhTopNodes) sits behind the stacks.  A node index below `top` is fetched
+// from it through a GENERIC pointer — one flat_load per 16-byte piece, the lane's address decides between LDS and the vector L1 —
+// so the lanes at the top of the tree, which every ray passes, cost the L1 nothing.  Why: the traversal kernels sit at ~0.9 L1
+// accesses per clock per CU with the texture-address unit 90-96 % busy (profiles/r03_atrium_p2_summary.md): the L1 takes one
+// per-lane access per clock, four per node visit (profiles/r03_trace_isa_budget.md, tests/tools/gather_calib.hip mode E).
+constexpr size_t kVoteTopBytes = (size_t)kBvhTopNodes * sizeof(BvhNode);
+constexpr size_t kVoteLdsBytes = kVoteStackBytes + kVoteTopBytes;
+struct TreeTop {
+    const uint4* lds;   // generic pointer into LDS
+    int count;          // nodes held there (0: none — the lab's other variants)
+};
+__device__ __forceinline__ TreeTop stage_tree_top(unsigned char* smem, const BvhNode* nodes, uint32_t node_count, bool enable) {
+    TreeTop t;
+    uint4* dst = reinterpret_cast<uint4*>(smem + kVoteStackBytes);
+    t.lds = dst;
+    t.count = enable ? (int)(node_count < (uint32_t)kBvhTopNodes ? node_count : (uint32_t)kBvhTopNodes) : 0;
+    const uint4* src = reinterpret_cast<const uint4*>(nodes);
+    for (int i = (int)threadIdx.x; i < t.count * 4; i += (int)blockDim.x) dst[i] = src[i];
+    __syncthreads();
+    return t;
+}
 
 // One inner-node visit: 64 B fetch, four slab tests against [tmin, tlimit], then either the nearest hit child with the
 // others pushed far -> near (closest-hit search) or the hit children in slot order (any-hit search).  (Measured and not kept: branch-free pushes through
 // a trash row — closest-hit -8 %, any-hit +2 %; farthest-child-first for the light-identity queries — shadow stage -25 %.)
 template <bool ANY>
-__device__ __forceinline__ void vote_node_step(const BvhNode* nodes, const LaneStack& S, int& cur, int& sp, V3 o, V3 inv, float tmin, float tlimit) {
-    const uint4* p = reinterpret_cast<const uint4*>(nodes + cur);
+__device__ __forceinline__ void vote_node_step(const BvhNode* nodes, const TreeTop& top, const LaneStack& S, int& cur, int& sp, V3 o, V3 inv, float tmin, float tlimit) {
+    const uint4* p = cur < top.count ? top.lds + cur * 4 : reinterpret_cast<const uint4*>(nodes + cur);
     NodeData n;
     unpack_node(p[0], p[1], p[2], p[3], n);
     RaySlab slab; slab.o = o; slab.inv = inv;
