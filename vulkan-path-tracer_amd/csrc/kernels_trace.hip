@@ -93,7 +93,7 @@ __global__ __launch_bounds__(kTraverseBlock, 8) void k_trace_vote(DeviceScene sc
     const LaneStack S = make_lane_stack(smem, sc.stack_overflow);
     const BvhNode* const nodes = sc.nodes;
     const BvhTri* const tris = sc.tris;
-    const TreeTop top = stage_tree_top(smem, nodes, sc.node_count, !WIDE8 && (TUNED || ((a.param >> 16) & 1u) == 0u));   // lab: bit 16 switches the LDS tree top off
+    const TreeTop top = stage_tree_top(smem, nodes, sc.node_count, ANY && !WIDE8 && (TUNED || ((a.param >> 16) & 1u) == 0u));   // any-hit only (vote.hpp vote_node_step); lab: bit 16 switches it off
     const uint32_t n = a.n_dev ? *a.n_dev : a.n;
     const uint32_t chunk = fetch_chunk(n);
     const uint32_t fetch_at = TUNED ? 16u : (a.param & 0xffu) ? (a.param & 0xffu) : 16u;  // idle lanes that trigger a fetch step (64: only when all are idle)
