@@ -172,7 +172,7 @@ typedef struct vpt_config {
     uint32_t height;
     uint32_t shard_rank; /* this context renders rows y with y % shard_count == shard_rank */
     uint32_t shard_count;/* 1 = whole image */
-    uint32_t frames_in_flight; /* 0 = choose so that ~256M paths are resident (128 frames at 1080p, ~95 GB), never more than 60 % of the free device memory; at most 1024 frames */
+    uint32_t frames_in_flight; /* 0 = choose so that ~448M paths are resident (226 frames at 1080p, ~170 GB), never more than 60 % of the free device memory; at most 2048 frames */
     uint32_t profile;    /* 1 = bracket every kernel launch with hipEvents (vpt_get_stats kernel times) */
     uint32_t count_traversal; /* 1 = count BVH node/triangle visits (slower; for the roofline's algorithmic bytes) */
     uint32_t pipeline;   /* VPT_PIPELINE_* */

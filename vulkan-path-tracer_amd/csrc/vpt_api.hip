@@ -19,7 +19,8 @@
 using namespace vpt;
 
 constexpr uint64_t kBytesPerPath = 380;          // core slot records 68 + stream records ~290 (slack included) + queues 8 + image share
-constexpr uint32_t kMaxFramesInFlight = 1024;   // frames of one batch (a 1/8 shard of 1080p holds ~256M paths at 1024 frames)
+constexpr uint32_t kMaxFramesInFlight = 2048;   // frames of one batch (a 1/8 shard of 1080p holds ~448M paths at 1728 frames)
+constexpr uint64_t kResidentPaths = 448ull << 20;   // what a context keeps in flight by default (see check_render_size)
 
 struct vpt_ctx {
     vpt_config cfg{};
@@ -81,6 +82,7 @@ struct vpt_ctx {
     void* media_block = nullptr; // streams of the media variant of the staged pipeline (kernels_media.hip): allocated on first use
     MediaState ms{};
     int shade_media_blocks = 768, media_tail_blocks = 768;
+    uint32_t media_frames = 0;   // frames a media batch on the streams can hold (ensure_media_buffers)
     uint32_t class_present = 0x1fu;   // shade classes some instance of the scene belongs to (bit kShadeMiss always set): the others get no launch
     uint32_t stream_slack = 0;   // entries a stream may hold beyond its true count: unwritten chunk tails (vote.hpp WaveAppender)
     int shade_stream_blocks = 768, shadow_blocks = 2048;
@@ -164,7 +166,7 @@ void free_render_buffers(vpt_ctx* c) {
     if (c->ss_block) (void)hipFree(c->ss_block);
     c->ss_block = nullptr;
     if (c->media_block) (void)hipFree(c->media_block);
-    c->media_block = nullptr; c->ms = MediaState{};
+    c->media_block = nullptr; c->ms = MediaState{}; c->media_frames = 0;
     for (uint32_t k = 0; k < kShadeClasses; k++) { if (c->class_queue[k]) (void)hipFree(c->class_queue[k]); c->class_queue[k] = nullptr; }
     if (c->cls_q) (void)hipFree(c->cls_q);
     c->cls_q = nullptr;
@@ -189,12 +191,12 @@ int check_render_size(vpt_ctx* c, uint32_t width, uint32_t height, uint32_t* fra
     if (px == 0) return fail(c, VPT_ERR_INVALID_ARGUMENT, "empty shard");
     if (px >= (1ull << 31) || (uint64_t)width * height >= (1ull << 31)) return fail(c, VPT_ERR_INVALID_ARGUMENT, "image too large");
     uint64_t F = c->cfg.frames_in_flight;
-    // ~256M resident paths whatever the shard size (128 frames at 1080p; kBytesPerPath x 256M = ~95 GB of the 288 GB): the last
-    // bounces of a batch are short launches that cannot fill 256 CUs, and a larger batch makes them longer for the same fixed
-    // cost — from 32M to 128M paths: Cornell +8 %, atrium +16 %, glass bust (depth 32) +78 %; from 128M to 256M: +0 / +2 / +18 %.
-    // Never more than 60 % of the memory that is free right now.
+    // ~448M resident paths whatever the shard size (226 frames at 1080p; kBytesPerPath x 448M = ~170 GB of the 288 GB, and never more
+    // than 60 % of the memory that is free right now): the last bounces of a batch are short launches that cannot fill 256 CUs, and
+    // a larger batch makes them longer for the same fixed cost.  Msamples/s from 32M to 128M paths: Cornell +8 %, atrium +16 %, glass
+    // bust (depth 32) +78 %; 128M to 256M: +0 / +2 / +18 %; 256M to 512M: +0 / +2.4 / +9.1 % (profiles/r03_frames_sweep.json).
     if (F == 0) {
-        uint64_t paths = 256ull << 20;
+        uint64_t paths = kResidentPaths;
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) paths = std::min<uint64_t>(paths, (uint64_t)(free_b * 0.6) / kBytesPerPath);
         F = paths / px;
@@ -289,15 +291,27 @@ int alloc_render_buffers_impl(vpt_ctx* c) {
 // allocated when such a batch is first rendered and kept until the next resize.
 // The class queues of VPT_PIPELINE_STAGED_SORTED (21 bytes per path), likewise on first use.
 // Media on the streams pipeline: 11 more float4 streams per queue entry (176 bytes per path), allocated when such a batch is first
-// rendered and kept until the next resize.  With the library's own batch size (~256M paths) that is 48 GB on top of ~95 GB.
+// rendered and kept until the next resize.  They are sized to what is free then (at most 85 % of it): a media batch holds
+// media_frames frames, which may be fewer than frames_in_flight (vpt_render then renders in more, smaller batches; the image is
+// the same for any batch size).
 int ensure_media_buffers(vpt_ctx* c) {
     if (c->media_block) return VPT_OK;
-    const size_t sst = ((size_t)c->ss.cap + 63) & ~(size_t)63;
+    const uint64_t px = c->P.shard_pixels;
+    uint64_t frames = c->frames_in_flight;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+        const uint64_t fit = (uint64_t)(free_b * 0.85) / (16ull * 11ull);
+        const uint64_t fit_frames = fit > c->stream_slack ? (fit - c->stream_slack) / px : 0;
+        frames = std::min<uint64_t>(frames, fit_frames);
+    }
+    if (frames == 0) return fail(c, VPT_ERR_DEVICE, "out of device memory for the media streams (176 bytes per resident path)");
+    const size_t sst = (((size_t)frames * px + c->stream_slack) + 63) & ~(size_t)63;
     if (hipMalloc(&c->media_block, sst * 16 * 11) != hipSuccess) {
         (void)hipGetLastError();
         c->media_block = nullptr;
         return fail(c, VPT_ERR_DEVICE, "out of device memory for the media streams (176 bytes per resident path): lower vpt_config.frames_in_flight");
     }
+    c->media_frames = (uint32_t)frames;
     float4* q = (float4*)c->media_block;
     c->ms.MS = q;
     for (int k = 0; k < 10; k++) c->ms.MP[k] = q + (size_t)(k + 1) * sst;
@@ -1082,7 +1096,13 @@ int vpt_render(vpt_ctx* c, uint32_t dispatches, int* done) {
         const uint64_t S2 = (uint64_t)c->params.screen_chunk_count * c->params.screen_chunk_count;
         uint64_t frames_needed = ((uint64_t)c->params.max_samples + c->params.samples_per_frame - 1) / c->params.samples_per_frame;
         uint64_t disp_left = frames_needed * S2 - c->dispatch_count;
-        uint32_t nf = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(left, c->frames_in_flight), disp_left);
+        uint32_t batch_cap = c->frames_in_flight;
+        if ((!c->volumes.empty() || c->dsc.atm_on) && !c->lds_scene && (c->cfg.pipeline == VPT_PIPELINE_AUTO || c->cfg.pipeline == VPT_PIPELINE_STAGED)) {
+            int rm = ensure_media_buffers(c);   // media on the streams: the batch is what the media streams hold
+            if (rm) return rm;
+            batch_cap = std::min(batch_cap, c->media_frames);
+        }
+        uint32_t nf = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(left, batch_cap), disp_left);
         int rc = render_batch(c, nf, (uint32_t)c->dispatch_count);  // returns with the stream drained
         if (rc) return rc;
         c->dispatch_count += nf;
