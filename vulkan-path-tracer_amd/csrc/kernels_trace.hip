@@ -96,7 +96,7 @@ __global__ __launch_bounds__(kTraverseBlock, 8) void k_trace_vote(DeviceScene sc
     const TreeTop top = stage_tree_top(smem, nodes, sc.node_count, ANY && !WIDE8 && (TUNED || ((a.param >> 16) & 1u) == 0u));   // any-hit only (vote.hpp vote_node_step); lab: bit 16 switches it off
     const uint32_t n = a.n_dev ? *a.n_dev : a.n;
     const uint32_t chunk = fetch_chunk(n);
-    const uint32_t fetch_at = TUNED ? 16u : (a.param & 0xffu) ? (a.param & 0xffu) : 16u;  // idle lanes that trigger a fetch step (64: only when all are idle)
+    const uint32_t fetch_at = TUNED ? kVoteFetchAt : (a.param & 0xffu) ? (a.param & 0xffu) : 16u;  // idle lanes that trigger a fetch step (64: only when all are idle)
     const bool weighted = TUNED || ((a.param >> 8) & 1u) != 0u;  // vote by lanes served per instruction issued: a triangle step costs about half a node step
     const uint32_t w4 = TUNED ? kVoteWeight4 : ((a.param >> 12) & 15u) ? ((a.param >> 12) & 15u) : kVoteWeight4;   // the weight in quarters (lab: bits 12-15)
     // every wave starts on its own 64 entries without an atomic (8192 waves fetching at once would queue ~90 us on the cursor);
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(kTraverseBlock, 8) void k_trace_shadow(DeviceScene 
     const TreeTop top = stage_tree_top(smem, nodes, sc.node_count, TUNED || ((param >> 16) & 1u) == 0u);
     const uint32_t n = *n_dev;
     const uint32_t chunk = fetch_chunk(n);
-    const uint32_t fetch_at = TUNED ? 16u : (param & 0xffu) ? (param & 0xffu) : 16u;
+    const uint32_t fetch_at = TUNED ? kVoteFetchAt : (param & 0xffu) ? (param & 0xffu) : 16u;
     const bool weighted = TUNED || ((param >> 8) & 1u) != 0u;
     const uint32_t w4 = TUNED ? kVoteWeight4 : ((param >> 12) & 15u) ? ((param >> 12) & 15u) : kVoteWeight4;
     const float tmin = 0.0001f, tmax = 1000000.0f;  // RTCommon.slang:47-64

@@ -10,6 +10,7 @@ namespace vpt {
 constexpr int kLaneIdle = 0x7fffffff;  // the lane holds no ray
 constexpr int kLaneDone = 0x7ffffffe;  // the lane's ray is finished, its result not yet written
 constexpr uint32_t kVoteParamDefault = 256u + 16u;  // weighted vote, fetch step at 16 idle lanes (profiles/r02_trace_lab_*.json)
+constexpr uint32_t kVoteFetchAt = 24u;  // idle lanes that trigger a fetch step in the product instantiation (Msamples/s at 16 / 24 / 32: atrium 1331 / 1351 / 1343, glass bust 2907 / 2938 / 2938)
 constexpr uint32_t kVoteWeight4 = 8u;   // a node step wins the vote when 4 x (lanes at nodes) > kVoteWeight4 x (lanes in leaves)
 constexpr uint32_t kRayHole = 0xfffffffeu;  // SKD.z / LTD.z of a shadow-ray stream entry nobody wrote
 constexpr uint32_t kHole = 0xffffffffu;  // a stream entry nobody wrote (tail of a wave's last chunk, see WaveAppender)
