@@ -153,6 +153,27 @@ def test_bench_two_ranks_on_one_device():
     assert line["roofline"]["frac"] <= 1.0 and line["roofline"]["bound"] in ("valu", "hbm")
 
 
+def test_bench_strong_scaling_splits_a_fixed_job():
+    """bench.py --scaling strong: the job is steps x 129 whole frames whatever N; two ranks (on this box's one device, host-staged
+    gather) trace together exactly the samples one rank does alone, and the line says so."""
+    totals = []
+    for n in (1, 2):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+        args = [os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "1", "--frames-in-flight", "70", "--scaling", "strong",
+                "--no-cpu-baseline", "--no-extra-workloads", "--no-latency"]
+        if n == 1:
+            cmd = [sys.executable] + args
+        else:
+            env["VPT_BENCH_DEVICE"] = "0"
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port())] + args
+        p = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+        assert p.returncode == 0, p.stderr[-3000:]
+        line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+        assert line["scaling"] == "strong" and line["n_gpus"] == n and line["config"]["batches_per_gpu"] == [70, 59]   # 129 frames in batches of <= 70
+        totals.append(round(line["value"] * line["ms_per_step"] * 1e-3 * line["steps"] * 1e6))
+    assert abs(totals[0] - 129 * 1920 * 1080) < 1e-3 * totals[0] and abs(totals[1] - totals[0]) < 1e-3 * totals[0]
+
+
 def test_bench_line_contract_single_gpu():
     """`python bench.py` at N = 1 (short: 2 steps of 4 frames, CPU sample of ~1 s, no extra workloads): ONE JSON line with the driver's
     fields, a roofline object whose fraction is a fraction, and the CPU baseline object."""
@@ -170,5 +191,8 @@ def test_bench_line_contract_single_gpu():
     r = line["roofline"]
     assert r["bound"] in ("valu", "hbm") and r["unit"] == "GB/s" and r["peak"] == 8000.0 and 0 < r["frac"] <= 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
     assert r["kernel"] in r["kernels"] and r["traversal"]["nodes_per_closest_ray"] > 0
+    lat = line["latency"]   # the reference's per-frame call pattern: vpt_render(ctx, 1) + vpt_postprocess
+    assert lat["frame_ms"] > 0 and abs(lat["frame_ms"] - lat["render_1spp_ms"] - lat["postprocess_ms"]) < 1e-3
+    assert r["pmc"]["rule"] and (r["pmc"]["stale"] or r["valu"] is None or 0 < r["valu"]["frac"] <= 1.0)
     c = line["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "Msamples/s" and c["value"] > 0 and c["cores"] >= 1 and "frames" in c["sample"]
