@@ -48,7 +48,7 @@ constexpr size_t kVoteStackBytes = (size_t)kVoteStackRows * kTraverseBlock * 4;
 // The block's LDS copy of the tree top (device_types.hpp kBvhTopNodes) sits behind the stacks.  A node index below `top` is fetched
 // from it through a GENERIC pointer — one flat_load per 16-byte piece, the lane's address decides between LDS and the vector L1 —
 // so the lanes at the top of the tree, which every ray passes, cost the L1 nothing.  Why: the traversal kernels sit at ~0.9 L1
-// accesses per clock per CU with the texture-address unit 90-96 % busy (profiles/r03_atrium_p2_summary.md): the L1 takes one
+// accesses per clock per CU with the texture-address unit 90-96 % busy (profiles/r03_atrium_p2_f129_summary.md): the L1 takes one
 // per-lane access per clock, four per node visit (profiles/r03_trace_isa_budget.md, tests/tools/gather_calib.hip mode E).
 constexpr size_t kVoteTopBytes = (size_t)kBvhTopNodes * sizeof(BvhNode);
 constexpr size_t kVoteLdsBytes = kVoteStackBytes + kVoteTopBytes;
