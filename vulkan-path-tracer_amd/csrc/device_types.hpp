@@ -90,16 +90,37 @@ struct EmissiveDesc {  // == EmissiveMeshEntry (PathTracer.h:321-328), 80 B
 };
 // Derived tables, filled on the device by the same expressions the shade stage would otherwise evaluate
 // per hit (kernels_path.hip k_precompute_*), so using them cannot change a bit of the result.
-struct MatResolved {  // Material.Initialize (Material.slang:39-87) for a material whose value textures are all 1x1
+struct MatResolved {  // Material.Initialize (Material.slang:39-87), per material: every field whose texture is 1x1 (k_precompute_materials)
     float base[3], roughness;
     float emissive[3], metallic;
     float ax, ay, ior, inv_ior;
     float pm, pd, pg;
-    uint32_t flags;   // bit0: base/roughness/metallic/emissive textures are 1x1 -> fields valid; bit1: normal map 1x1 -> nmap valid
-    float nmap[3], pad;
+    uint32_t flags;   // kMat*: which fields are valid (the others are fetched per hit, shading.hpp material_issue / material_finish)
+    float nmap[3], aspect;  // aspect = sqrt(1 - sqrt(Anisotropy) * 0.9), Material.slang:62
     float rot_sin, rot_cos, pad1, pad2;  // sincos(AnisotropyRotation in radians), Surface.slang:129-136
+    // copies of textures[normal | base colour | roughness | metallic | emissive]: a hit's texel fetches are issued as soon as its
+    // uv is known, all of them together, without waiting for a descriptor first
+    TexDesc tex[5];
 };
-static_assert(sizeof(MatResolved) == 96, "MatResolved is 96 B");
+static_assert(sizeof(MatResolved) == 176, "MatResolved is 176 B");
+enum : uint32_t {
+    kMatAllValues = 1u,   // base / roughness / metallic / emissive textures are ALL 1x1: no value texture is sampled per hit
+    kMatNormal = 2u,      // normal map 1x1 -> nmap valid
+    kMatBase = 4u,        // base colour texture 1x1 -> base valid
+    kMatRoughness = 8u,   // roughness texture 1x1 -> roughness, ax, ay valid
+    kMatMetallic = 16u,   // metallic texture 1x1 -> metallic, pm, pd, pg valid
+    kMatEmissive = 32u,   // emissive texture 1x1 -> emissive valid
+};
+// What SampleEmissiveTriangle (Sampler.slang:348-422) needs about the emissive mesh it has picked, gathered from EmissiveDesc,
+// InstanceDesc, vpt_material and TexDesc into one record (k_precompute_lights): the sample costs two dependent fetches (this record,
+// the light triangle) instead of six.
+struct LightSampler {
+    uint32_t tri_count, gid_base, tri_base, uniform;  // first global triangle id; first entry in emissive_tri; 1: the emissive texture is 1x1
+    float emissive_color[3], pad0;
+    float radiance[3], pad1;                          // uniform: EmissiveColor * the one texel
+    TexDesc tex;                                      // otherwise: the emissive texture
+};
+static_assert(sizeof(LightSampler) == 64, "LightSampler is 64 B");
 struct EmissiveTri {  // world-space light triangle as SampleEmissiveTriangle (Sampler.slang:375-404) derives it per sample
     float p0[3], area;
     float p1[3], u0;
@@ -150,6 +171,7 @@ struct DeviceScene {
                                             // de-indexed into ONE 128-byte line, so a hit costs one line fetch instead of index triple + 3 vertices + normal
     const EmissiveTri* emissive_tri;        // per emissive triangle
     const uint32_t* emissive_tri_offset;    // per emissive mesh: first entry in emissive_tri
+    const LightSampler* lights;             // per emissive mesh
     const uint32_t* tri_slot_of_gid;        // per global triangle id: position in the leaf-ordered triangle array
     const unsigned char* inst_class;        // per instance: shade class of its material (kShade*), the sort key of the shade queues
     uint32_t* stack_overflow;               // traversal stack entries beyond the LDS part, kStackOverflow per resident thread

@@ -686,16 +686,36 @@ __global__ __launch_bounds__(256) void k_precompute_materials(DeviceScene sc, ui
     const vpt_material& m = sc.materials[i];
     MatResolved r;
     V2 uv; uv.x = 0.0f; uv.y = 0.0f;
-    material_resolve(sc, m, uv, flags, r);
+    material_resolve(sc, m, uv, flags, r);   // a field whose texture is not 1x1 holds a value nobody reads (its flag stays clear)
     auto one = [&](uint32_t t) { return sc.textures[t].w == 1 && sc.textures[t].h == 1; };
-    r.flags = (one(m.base_color_texture) && one(m.roughness_texture) && one(m.metallic_texture) && one(m.emissive_texture)) ? 1u : 0u;
+    r.flags = (one(m.base_color_texture) ? kMatBase : 0u) | (one(m.roughness_texture) ? kMatRoughness : 0u) |
+              (one(m.metallic_texture) ? kMatMetallic : 0u) | (one(m.emissive_texture) ? kMatEmissive : 0u);
+    if ((r.flags & (kMatBase | kMatRoughness | kMatMetallic | kMatEmissive)) == (kMatBase | kMatRoughness | kMatMetallic | kMatEmissive)) r.flags |= kMatAllValues;
     if (one(m.normal_texture)) {
         V4 nm = tex_sample(sc, m.normal_texture, 0.0f, 0.0f);
         r.nmap[0] = nm.x * 2.0f - 1.0f; r.nmap[1] = nm.y * 2.0f - 1.0f; r.nmap[2] = nm.z * 2.0f - 1.0f;
-        r.flags |= 2u;
+        r.flags |= kMatNormal;
     } else { r.nmap[0] = r.nmap[1] = r.nmap[2] = 0.0f; }
-    r.pad = 0.0f;
+    r.pad1 = r.pad2 = 0.0f;
+    r.tex[0] = sc.textures[m.normal_texture]; r.tex[1] = sc.textures[m.base_color_texture]; r.tex[2] = sc.textures[m.roughness_texture];
+    r.tex[3] = sc.textures[m.metallic_texture]; r.tex[4] = sc.textures[m.emissive_texture];
     out[i] = r;
+}
+// One LightSampler per emissive mesh (device_types.hpp): the fields SampleEmissiveTriangle reads through four tables, side by side.
+__global__ __launch_bounds__(64) void k_precompute_lights(DeviceScene sc, LightSampler* out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= sc.emissive_count) return;
+    const EmissiveDesc& em = sc.emissive[i];
+    const vpt_material& m = sc.materials[em.material];
+    LightSampler ls;
+    ls.tri_count = em.tri_count; ls.gid_base = sc.instances[em.instance].tri_offset; ls.tri_base = sc.emissive_tri_offset[i];
+    ls.tex = sc.textures[m.emissive_texture];
+    ls.uniform = (ls.tex.w == 1 && ls.tex.h == 1) ? 1u : 0u;
+    ls.emissive_color[0] = m.emissive_color[0]; ls.emissive_color[1] = m.emissive_color[1]; ls.emissive_color[2] = m.emissive_color[2];
+    V4 te = tex_sample(sc, m.emissive_texture, 0.0f, 0.0f);
+    ls.radiance[0] = m.emissive_color[0] * te.x; ls.radiance[1] = m.emissive_color[1] * te.y; ls.radiance[2] = m.emissive_color[2] * te.z;
+    ls.pad0 = ls.pad1 = 0.0f;
+    out[i] = ls;
 }
 __global__ __launch_bounds__(256) void k_precompute_tri_ng(DeviceScene sc, float4* out) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -737,19 +757,21 @@ __global__ __launch_bounds__(256) void k_classify_instances(DeviceScene sc, unsi
     const uint32_t mi = sc.instances[i].material;
     const vpt_material& m = sc.materials[mi];
     const MatResolved& r = sc.mat_resolved[mi];
-    const bool emissive = (r.flags & 1u) ? (r.emissive[0] > 0.0f || r.emissive[1] > 0.0f || r.emissive[2] > 0.0f)
+    const bool emissive = (r.flags & kMatEmissive) ? (r.emissive[0] > 0.0f || r.emissive[1] > 0.0f || r.emissive[2] > 0.0f)
                                          : (m.emissive_color[0] != 0.0f || m.emissive_color[1] != 0.0f || m.emissive_color[2] != 0.0f);
     uint32_t c = kShadeTextured;
     if (emissive) c = kShadeEmissive;
     else if (m.transmission > 0.0f) c = kShadeGlass;
-    else if ((r.flags & 3u) == 3u) c = kShadePlain;   // the promise k_shade_stream<kShadePlain> relies on: no texture of this material is ever sampled
+    else if ((r.flags & (kMatAllValues | kMatNormal)) == (kMatAllValues | kMatNormal)) c = kShadePlain;   // the promise k_shade_stream<kShadePlain> relies on: no texture of this material is ever sampled
     out[i] = (unsigned char)c;
 }
 void launch_classify_instances(hipStream_t s, const DeviceScene& sc, unsigned char* out, uint32_t n) {
     if (n) hipLaunchKernelGGL(k_classify_instances, dim3((n + 255) / 256), dim3(256), 0, s, sc, out, n);
 }
+// (the light table reads materials and textures too: every caller that refreshes one refreshes the other)
 void launch_precompute_materials(hipStream_t s, const DeviceScene& sc, uint32_t flags, MatResolved* out, uint32_t n) {
     if (n) hipLaunchKernelGGL(k_precompute_materials, dim3((n + 255) / 256), dim3(256), 0, s, sc, flags, out, n);
+    if (sc.emissive_count) hipLaunchKernelGGL(k_precompute_lights, dim3((sc.emissive_count + 63) / 64), dim3(64), 0, s, sc, const_cast<LightSampler*>(sc.lights));
 }
 void launch_precompute_tri_ng(hipStream_t s, const DeviceScene& sc, float4* out) {
     if (sc.tri_count) hipLaunchKernelGGL(k_precompute_tri_ng, dim3((sc.tri_count + 255) / 256), dim3(256), 0, s, sc, out);

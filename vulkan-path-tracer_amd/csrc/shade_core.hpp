@@ -202,11 +202,15 @@ __device__ __forceinline__ void shade_core(const DeviceScene& sc, const RenderPa
         const InstanceDesc& in = sc.instances[inst_id];
         const vpt_material& mat = sc.materials[in.material];
         MatResolved mr = sc.mat_resolved[in.material];
-        if (CLS == (int)kShadePlain) mr.flags = 3u;  // what the class promises, as a compile-time fact: no texel fetch is compiled in
+        if (CLS == (int)kShadePlain) mr.flags = 63u;                // what the class promises, as a compile-time fact: no texel fetch is compiled in
+        const bool geo_only = (P.flags & VPT_FLAG_GEOMETRY_NORMALS) != 0;
         SurfaceFrame s;
-        surface_init(sc, s, in, __float_as_uint(h.w), h.y, h.z, rd, mat.normal_texture, (P.flags & VPT_FLAG_GEOMETRY_NORMALS) != 0, mr);
+        surface_geom(sc, s, in, __float_as_uint(h.w), h.y, h.z, rd, geo_only);
+        MatTaps taps;
+        material_issue(sc.texels, mr, s.uv, geo_only, taps);   // every texel this hit needs, in flight together
+        surface_frame(s, rd, geo_only, mr, taps.normal);
         Bsdf bs; V3 mcol; float mdens, maniso, arot;
-        bsdf_init(sc, bs, mat, mr, s.uv, s.inside, P.flags, mcol, mdens, maniso, arot);
+        bsdf_init(bs, sc, mat, mr, taps, s.inside, P.flags, mcol, mdens, maniso, arot);
         bool is_light = bs.emissive.x > 0.0f || bs.emissive.y > 0.0f || bs.emissive.z > 0.0f;
         rotate_tangents(s, mr.rot_sin, mr.rot_cos);  // AnisotropyRotation has no texture: the table entry is always valid
         bool scattered = false;

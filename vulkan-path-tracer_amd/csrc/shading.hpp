@@ -43,6 +43,33 @@ __device__ inline V4 tex_sample(const DeviceScene& sc, uint32_t ti, float u, flo
     V4 b = lerp4(tex_fetch(sc.texels, t, x0, y1), tex_fetch(sc.texels, t, x1, y1), fx);
     return lerp4(a, b, fy);
 }
+// The same lookup in two halves, so that a hit can have the taps of all its textures in flight at once: tex_issue computes the four
+// tap addresses and starts the loads, tex_finish decodes and filters (the operations of tex_sample in its order; a 1x1 texture has all
+// four taps on its one texel and both weights 0, which filters to that texel bit for bit).
+struct TexTaps { uint32_t r00, r10, r01, r11, c; float fx, fy; };
+__device__ inline void tex_issue(const uint8_t* texels, const TexDesc& t, float u, float v, TexTaps& k) {
+    int x0, x1, y0, y1;
+    texel_coords(u, (int)t.w, true, &x0, &x1, &k.fx);
+    texel_coords(v, (int)t.h, true, &y0, &y1, &k.fy);
+    const uint32_t row0 = (uint32_t)y0 * t.w, row1 = (uint32_t)y1 * t.w;
+    k.c = t.c;
+    if (t.c == 4) {
+        const uint32_t* p = reinterpret_cast<const uint32_t*>(texels + t.offset);
+        k.r00 = p[row0 + (uint32_t)x0]; k.r10 = p[row0 + (uint32_t)x1]; k.r01 = p[row1 + (uint32_t)x0]; k.r11 = p[row1 + (uint32_t)x1];
+    } else {
+        const uint8_t* p = texels + t.offset;
+        k.r00 = p[row0 + (uint32_t)x0]; k.r10 = p[row0 + (uint32_t)x1]; k.r01 = p[row1 + (uint32_t)x0]; k.r11 = p[row1 + (uint32_t)x1];
+    }
+}
+__device__ inline V4 tex_decode(uint32_t r, uint32_t c) {
+    if (c == 4) return v4(unorm8_to_float(r & 255u), unorm8_to_float((r >> 8) & 255u), unorm8_to_float((r >> 16) & 255u), unorm8_to_float(r >> 24));
+    return v4(unorm8_to_float(r), 0.0f, 0.0f, 1.0f);
+}
+__device__ inline V4 tex_finish(const TexTaps& k) {
+    V4 a = lerp4(tex_decode(k.r00, k.c), tex_decode(k.r10, k.c), k.fx);
+    V4 b = lerp4(tex_decode(k.r01, k.c), tex_decode(k.r11, k.c), k.fx);
+    return lerp4(a, b, k.fy);
+}
 __device__ inline V4 env_sample(const DeviceScene& sc, float u, float v) {
     int w = (int)sc.env_w, h = (int)sc.env_h;
     const float4* e = reinterpret_cast<const float4*>(sc.env);
@@ -100,8 +127,9 @@ __device__ inline V3 triangle_ng(const DeviceScene& sc, const InstanceDesc& in, 
     return normalize(rowvec_mat3(ng, in.inv3));
 }
 
-__device__ inline void surface_init(const DeviceScene& sc, SurfaceFrame& s, const InstanceDesc& in, uint32_t gid, float hu,
-                                    float hv, V3 raydir, uint32_t normal_tex, bool geo_only, const MatResolved& mr) {
+// SurfaceFrame in two halves around the texel fetches: surface_geom reads the triangle and interpolates (the uv is known after it),
+// surface_frame applies the normal map and the reference's two normal corrections.
+__device__ inline void surface_geom(const DeviceScene& sc, SurfaceFrame& s, const InstanceDesc& in, uint32_t gid, float hu, float hv, V3 raydir, bool geo_only) {
     // the triangle's three vertices and its geometric normal from its de-indexed record (k_precompute_tri_shade): one 128-byte line
     // (the hit record carries the GLOBAL triangle id, so this fetch does not wait for the instance record)
     const float4* q = sc.tri_shade + (size_t)gid * 8;
@@ -121,13 +149,16 @@ __device__ inline void surface_init(const DeviceScene& sc, SurfaceFrame& s, cons
     }
     V3 view = -raydir;
     if (dot(s.Ng, view) < 0.0f) { s.N = -s.N; s.Ng = -s.Ng; s.inside = true; } else { s.inside = false; }
+}
+__device__ inline void surface_frame(SurfaceFrame& s, V3 raydir, bool geo_only, const MatResolved& mr, const TexTaps& normal_taps) {
+    V3 view = -raydir;
     V3 up = fabs_(s.N.z) < 0.9999999f ? v3(0.0f, 0.0f, 1.0f) : v3(1.0f, 0.0f, 0.0f);
     s.T = normalize(cross(up, s.N));
     s.B = normalize(cross(s.N, s.T));
     if (!geo_only) {
         V3 nv;
-        if (mr.flags & 2u) nv = v3(mr.nmap[0], mr.nmap[1], mr.nmap[2]);
-        else { V4 nm = tex_sample(sc, normal_tex, s.uv.x, s.uv.y); nv = v3(nm.x * 2.0f - 1.0f, nm.y * 2.0f - 1.0f, nm.z * 2.0f - 1.0f); }
+        if (mr.flags & kMatNormal) nv = v3(mr.nmap[0], mr.nmap[1], mr.nmap[2]);
+        else { V4 nm = tex_finish(normal_taps); nv = v3(nm.x * 2.0f - 1.0f, nm.y * 2.0f - 1.0f, nm.z * 2.0f - 1.0f); }
         s.N = s.tangent_to_world(nv);
     }
     float nv = dot(s.N, view);
@@ -268,6 +299,7 @@ __device__ inline void material_resolve(const DeviceScene& sc, const vpt_materia
     V4 te = tex_sample(sc, m.emissive_texture, uv.x, uv.y);
     r.emissive[0] = m.emissive_color[0] * te.x; r.emissive[1] = m.emissive_color[1] * te.y; r.emissive[2] = m.emissive_color[2] * te.z;
     float aspect = sqrt_(1.0f - sqrt_(m.anisotropy) * 0.9f);
+    r.aspect = aspect;
     r.ax = max_(0.00001f, r.roughness / aspect);
     r.ay = max_(0.00001f, r.roughness * aspect);
     if (flags & VPT_FLAG_FURNACE) { r.base[0] = r.base[1] = r.base[2] = 1.0f; r.emissive[0] = r.emissive[1] = r.emissive[2] = 0.0f; }
@@ -278,10 +310,47 @@ __device__ inline void material_resolve(const DeviceScene& sc, const vpt_materia
     r.pm /= sum; r.pd /= sum; r.pg /= sum;
     sincos_(m.anisotropy_rotation * (VPT_PI / 180.0f), &r.rot_sin, &r.rot_cos);
 }
-__device__ inline void bsdf_init(const DeviceScene& sc, Bsdf& b, const vpt_material& m, const MatResolved& pre, V2 uv, bool inside,
+// The same per hit, for the fields whose texture is not 1x1 (MatResolved.flags says which are already valid): material_issue starts
+// the texel loads of those textures (and of the normal map) together, material_finish evaluates material_resolve's expressions on them.
+struct MatTaps { TexTaps normal, base, rough, metal, emis; };
+__device__ inline void material_issue(const uint8_t* texels, const MatResolved& pre, V2 uv, bool geo_only, MatTaps& k) {
+    if (!geo_only && !(pre.flags & kMatNormal)) tex_issue(texels, pre.tex[0], uv.x, uv.y, k.normal);
+    if (pre.flags & kMatAllValues) return;
+    if (!(pre.flags & kMatBase)) tex_issue(texels, pre.tex[1], uv.x, uv.y, k.base);
+    if (!(pre.flags & kMatRoughness)) tex_issue(texels, pre.tex[2], uv.x, uv.y, k.rough);
+    if (!(pre.flags & kMatMetallic)) tex_issue(texels, pre.tex[3], uv.x, uv.y, k.metal);
+    if (!(pre.flags & kMatEmissive)) tex_issue(texels, pre.tex[4], uv.x, uv.y, k.emis);
+}
+__device__ inline void material_finish(const vpt_material& m, const MatTaps& k, uint32_t flags, MatResolved& r) {
+    if (r.flags & kMatAllValues) return;
+    if (!(r.flags & kMatBase)) {
+        V4 tb = tex_finish(k.base);
+        r.base[0] = m.base_color[0] * pow_(tb.x, 2.2f); r.base[1] = m.base_color[1] * pow_(tb.y, 2.2f); r.base[2] = m.base_color[2] * pow_(tb.z, 2.2f);
+        if (flags & VPT_FLAG_FURNACE) r.base[0] = r.base[1] = r.base[2] = 1.0f;
+    }
+    if (!(r.flags & kMatRoughness)) {
+        r.roughness = m.roughness * tex_finish(k.rough).x;
+        r.ax = max_(0.00001f, r.roughness / r.aspect);
+        r.ay = max_(0.00001f, r.roughness * r.aspect);
+    }
+    if (!(r.flags & kMatMetallic)) {
+        r.metallic = m.metallic * tex_finish(k.metal).x;
+        r.pm = r.metallic;
+        r.pd = (1.0f - r.metallic) * (1.0f - m.transmission);
+        r.pg = (1.0f - r.metallic) * m.transmission;
+        float sum = r.pm + r.pd + r.pg;
+        r.pm /= sum; r.pd /= sum; r.pg /= sum;
+    }
+    if (!(r.flags & kMatEmissive)) {
+        V4 te = tex_finish(k.emis);
+        r.emissive[0] = m.emissive_color[0] * te.x; r.emissive[1] = m.emissive_color[1] * te.y; r.emissive[2] = m.emissive_color[2] * te.z;
+        if (flags & VPT_FLAG_FURNACE) r.emissive[0] = r.emissive[1] = r.emissive[2] = 0.0f;
+    }
+}
+__device__ inline void bsdf_init(Bsdf& b, const DeviceScene& sc, const vpt_material& m, const MatResolved& pre, const MatTaps& taps, bool inside,
                                  uint32_t flags, V3& medium_color, float& medium_density, float& medium_aniso, float& aniso_rotation) {
     MatResolved r = pre;
-    if (!(pre.flags & 1u)) material_resolve(sc, m, uv, flags, r);
+    material_finish(m, taps, flags, r);
     b.ior = r.ior;
     b.base = v3(r.base[0], r.base[1], r.base[2]);
     b.roughness = r.roughness; b.metallic = r.metallic;
@@ -398,12 +467,12 @@ __device__ inline void sample_emissive(const DeviceScene& sc, Rng& r, V3 pos, V3
     if (n == 0) { to_light = v3s(0.0f); cpdf = v4(0.0f, 0.0f, 0.0f, 0.0f); return; }
     uint32_t mi = (uint32_t)floor_(r.uf() * (float)n);
     mi = mi < n - 1 ? mi : n - 1;
-    const EmissiveDesc& em = sc.emissive[mi];
-    uint32_t tc = em.tri_count;
+    const LightSampler ls = sc.lights[mi];
+    uint32_t tc = ls.tri_count;
     uint32_t ti = (uint32_t)floor_(r.uf() * (float)tc);
     ti = ti < tc - 1 ? ti : tc - 1;
-    gid = sc.instances[em.instance].tri_offset + ti;
-    const float4* tq = reinterpret_cast<const float4*>(sc.emissive_tri + sc.emissive_tri_offset[mi] + ti);
+    gid = ls.gid_base + ti;
+    const float4* tq = reinterpret_cast<const float4*>(sc.emissive_tri + ls.tri_base + ti);
     float4 q0 = tq[0], q1 = tq[1], q2 = tq[2], q3 = tq[3], q4 = tq[4];
     V3 p0 = v3(q0.x, q0.y, q0.z), p1 = v3(q1.x, q1.y, q1.z), p2 = v3(q2.x, q2.y, q2.z), nrm = v3(q3.x, q3.y, q3.z);
     float area = q0.w;
@@ -417,9 +486,14 @@ __device__ inline void sample_emissive(const DeviceScene& sc, Rng& r, V3 pos, V3
     float d2 = dot(tp - pos, tp - pos);
     float ct = fabs_(dot(nrm, to_light));
     cpdf.w = d2 / ((float)n * (float)tc * area * ct);
-    const vpt_material& m = sc.materials[em.material];
-    V4 te = tex_sample(sc, m.emissive_texture, uu, vv);
-    cpdf.x = m.emissive_color[0] * te.x; cpdf.y = m.emissive_color[1] * te.y; cpdf.z = m.emissive_color[2] * te.z;
+    if (ls.uniform) {
+        cpdf.x = ls.radiance[0]; cpdf.y = ls.radiance[1]; cpdf.z = ls.radiance[2];
+    } else {
+        TexTaps k;
+        tex_issue(sc.texels, ls.tex, uu, vv, k);
+        V4 te = tex_finish(k);
+        cpdf.x = ls.emissive_color[0] * te.x; cpdf.y = ls.emissive_color[1] * te.y; cpdf.z = ls.emissive_color[2] * te.z;
+    }
 }
 
 // Camera ray + AA jitter + DOF, RayGen.slang:35-50 (4 draws, the DOF pair always drawn).

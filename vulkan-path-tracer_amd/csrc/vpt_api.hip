@@ -812,6 +812,8 @@ int vpt_set_scene(vpt_ctx* c, const vpt_scene_desc* sd) {
         texels.insert(texels.end(), tx.data, tx.data + (size_t)tx.width * tx.height * tx.channels);
         tds.push_back(d);
     }
+    // TexDesc.offset and the shade stage's texel addresses are 32-bit byte offsets into the pool
+    if (texels.size() > 0xffffffffull) return fail(c, VPT_ERR_LIMIT, "the scene's textures exceed the 4 GiB texel pool");
     // ---- environment + tables
     std::vector<float> env; std::vector<AliasEntry> alias;
     build_env_tables(sd->env_rgba, sd->env_width, sd->env_height, env, alias);
@@ -859,6 +861,9 @@ int vpt_set_scene(vpt_ctx* c, const vpt_scene_desc* sd) {
         void* d6 = nullptr;
         HIPCHK(c, hipMalloc(&d6, 128 * std::max<size_t>(1, total_tris))); c->scene_allocs.push_back(d6);
         c->d_tri_shade = (float4*)d6; D.tri_shade = c->d_tri_shade;
+        void* d7 = nullptr;   // one LightSampler per emissive mesh (at most one per instance)
+        HIPCHK(c, hipMalloc(&d7, sizeof(LightSampler) * std::max<size_t>(1, c->instances.size()))); c->scene_allocs.push_back(d7);
+        D.lights = (const LightSampler*)d7;
         void* d5 = nullptr;
         HIPCHK(c, hipMalloc(&d5, std::max<size_t>(1, c->instances.size()))); c->scene_allocs.push_back(d5);
         c->d_inst_class = (unsigned char*)d5; D.inst_class = c->d_inst_class;
