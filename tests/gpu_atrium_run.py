@@ -1,5 +1,5 @@
 """Fixed workload for profiling (not a pytest): 1080p, depth 8 (atrium) / 32 (bust), FRAMES (default 64, the library's default at 1080p) frames in flight, 1 warm-up batch + 2 measured.
-    PIPE=2 (staged on streams, default) | 3 (round 1's stage kernels) | 1 (fused);  SCENE=atrium|bust"""
+    PIPE=2 (staged on streams, default) | 3 (round 1's stage kernels) | 1 (fused) | 0 (the library chooses);  SCENE=atrium|bust|cornell"""
 import importlib, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -7,8 +7,11 @@ vpt = importlib.import_module("vulkan-path-tracer_amd")
 pipe = int(os.environ.get("PIPE", "2"))
 which = os.environ.get("SCENE", "atrium")
 F = int(os.environ.get("FRAMES", "64"))
-sc = vpt.scenes.atrium() if which == "atrium" else vpt.scenes.glass_bust()
+if which == "cornell":   # the headline scene (LDS-resident: the library picks the fused pipeline whatever PIPE says unless PIPE forces a staged one)
+    sc = vpt.scenes.Scene.load(os.path.join(ROOT, "tests", "golden", "cornell_box.npz"))
+else:
+    sc = vpt.scenes.atrium() if which == "atrium" else vpt.scenes.glass_bust()
 g = vpt.PathTracer(1920, 1080, pipeline=pipe, frames_in_flight=F, profile=os.environ.get("PROFILE", "1") == "1"); g.set_scene(sc)
-g.set_params(vpt.default_params(max_depth=8 if which == "atrium" else 32, max_samples=1 << 30))
+g.set_params(vpt.default_params(max_depth=32 if which == "bust" else 8, max_samples=1 << 30))
 g.render(F); g.reset_stats(); t = time.time(); g.render(2 * F); dt = time.time() - t
 st = g.stats(); print("Msamples/s", round(st["samples"] / dt / 1e6, 1), {k: round(v, 2) for k, v in st["kernel_ms"].items() if v > 0})

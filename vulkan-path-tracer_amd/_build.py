@@ -19,7 +19,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 # vectoriser turns 28 of them into 14 packed ones at the price of 20-30 register moves to pair the operands up
 # (profiles/r03_trace_isa_budget.md), a net loss in issued instructions, so it is off for that file.  Values are unaffected:
 # packed and scalar fp32 operations round identically and no contraction is allowed either way.
-EXTRA_FLAGS = {"kernels_trace.hip": ["-fno-slp-vectorize"]}
+EXTRA_FLAGS = {"kernels_trace.hip": ["-fno-slp-vectorize"], "kernels_stream.hip": ["-fno-slp-vectorize"], "kernels_path.hip": ["-fno-slp-vectorize"], "kernels_media.hip": ["-fno-slp-vectorize"]}
 
 
 def hipcc():
@@ -33,7 +33,8 @@ def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+    # (this file holds the compiler flags: a change here rebuilds too)
+    return os.path.getmtime(__file__) > t or any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
 
 
 def build(force=False, verbose=False):
@@ -42,7 +43,7 @@ def build(force=False, verbose=False):
     objs = []
     procs = []
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
-    newest_header = max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS)
+    newest_header = max([os.path.getmtime(__file__)] + [os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS])
     for src in SOURCES:
         obj = os.path.join(HERE, "build", src + ".o")
         objs.append(obj)
