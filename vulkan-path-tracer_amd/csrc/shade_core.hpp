@@ -266,6 +266,7 @@ __device__ __forceinline__ void shade_core(const DeviceScene& sc, const RenderPa
             Eval se; se.f = v3s(0.0f); se.pdf = 0.0f;
             V3 Ls = v3s(0.0f);
             const float gv = bs.smith(V);  // G1(V): shared by every evaluation of this hit
+            bs.set_view(V, ec_r, ec_g);
     if (valid_dir) { se = bs.eval(V, L, ec_r, ec_g, gv); Ls = L; }
             bool was_refracted = Ls.z < 0.0f;
             V3 scatter_world = s.tangent_to_world(Ls);

@@ -183,6 +183,14 @@ struct Bsdf {
     float pm, pd, pg;  // normalised lobe probabilities (Material.slang:97-106 == 170-179)
     const float *lut_r, *lut_o, *lut_i;
     bool ec;
+    // What every evaluation of one hit shares (set_view): the expressions below are the ones eval() used to evaluate per call, with
+    // the same operands — each is now evaluated once per hit instead of once per evaluated direction (up to three).
+    float inv_4vz;       // 1 / (4 V.z): the divisor of EvaluateReflection's f, applied as in V3 operator/ (multiply by the reciprocal)
+    float ec_c, inv_ec_r, inv_ec_g;  // (1 - ec_r) / ec_r, 1 / ec_r, 1 / ec_g
+    __device__ inline void set_view(V3 V, float ec_r, float ec_g) {
+        inv_4vz = 1.0f / (4.0f * V.z);
+        ec_c = (1.0f - ec_r) / ec_r; inv_ec_r = 1.0f / ec_r; inv_ec_g = 1.0f / ec_g;
+    }
 
     __device__ inline float fresnel(float c) const {  // :434-449
         float st2 = eta * eta * (1.0f - c * c);
@@ -217,7 +225,7 @@ struct Bsdf {
     }
     __device__ inline V3 reflection_f(const ReflCommon& c, V3 V, V3 F, float gv) const {
         if (!c.valid) return v3s(0.0f);
-        return ((F * c.D) * gv) * c.GL / (4.0f * V.z);
+        return (((F * c.D) * gv) * c.GL) * inv_4vz;   // == ... / (4.0f * V.z)
     }
     __device__ inline Eval refraction(V3 V, V3 L, V3 F, float gv) const {  // :359-387
         Eval e; e.f = v3s(0.0f); e.pdf = 0.0f;
@@ -257,7 +265,7 @@ struct Bsdf {
                 float m = clamp_(1.0f - dot(V, H), 0.0f, 1.0f);
                 float m2 = m * m;
                 V3 ef = reflection_f(rc, V, lerp(base, spec, m2 * m2 * m), gv);
-                if (ec) { float c = (1.0f - ec_r) / ec_r; ef = (v3s(1.0f) + base * c) * ef; }
+                if (ec) ef = (v3s(1.0f) + base * ec_c) * ef;
                 r.f = r.f + ef * pm; r.pdf += rc.pdf * pm;
             }
             // diffuse (:256-264)
@@ -270,16 +278,16 @@ struct Bsdf {
             {
                 V3 ef = reflection_f(rc, V, spec, gv);
                 V3 sf = ef;
-                if (ec) sf = sf / ec_r;
+                if (ec) sf = sf * inv_ec_r;   // == sf / ec_r
                 r.f = r.f + sf * pd * F; r.pdf += rc.pdf * pd * F;
                 V3 gf = ef;
-                if (ec && ec_g > 0.01f) gf = gf / ec_g;
+                if (ec && ec_g > 0.01f) gf = gf * inv_ec_g;   // == gf / ec_g
                 r.f = r.f + gf * pg * F; r.pdf += rc.pdf * pg * F;
             }
         }
         if (refracted && valid_refr) {  // :240-252
             Eval e = refraction(V, L, base, gv);
-            if (ec && ec_g > 0.01f) e.f = e.f / ec_g;
+            if (ec && ec_g > 0.01f) e.f = e.f * inv_ec_g;   // == e.f / ec_g
             r.f = r.f + e.f * pg * (1.0f - F); r.pdf += e.pdf * pg * (1.0f - F);
         }
         return r;
