@@ -12,6 +12,9 @@ if which == "cornell":   # the headline scene (LDS-resident: the library picks t
 else:
     sc = vpt.scenes.atrium() if which == "atrium" else vpt.scenes.glass_bust()
 g = vpt.PathTracer(1920, 1080, pipeline=pipe, frames_in_flight=F, profile=os.environ.get("PROFILE", "1") == "1"); g.set_scene(sc)
-g.set_params(vpt.default_params(max_depth=32 if which == "bust" else 8, max_samples=1 << 30))
+P = vpt.default_params(max_depth=32 if which == "bust" else 8, max_samples=1 << 30)
+P.flags &= ~int(os.environ.get("CLEAR_FLAGS", "0"))   # section costs: 1 sky NEE, 2 light NEE, 16 energy-compensation taps, 8 -> geometry normals
+P.flags |= int(os.environ.get("SET_FLAGS", "0"))
+g.set_params(P)
 g.render(F); g.reset_stats(); t = time.time(); g.render(2 * F); dt = time.time() - t
 st = g.stats(); print("Msamples/s", round(st["samples"] / dt / 1e6, 1), {k: round(v, 2) for k, v in st["kernel_ms"].items() if v > 0})
