@@ -56,6 +56,7 @@ __global__ __launch_bounds__(64) void k_lut(float* table, uint32_t sx, uint32_t 
             const V3 V = normalize(v3(mag * c, mag * s, vc));
             const V3 H = ggx_sample(r, V, m.ax, m.ay);
             const float gv = m.smith(V);
+            m.set_view(V, 1.0f, 1.0f);   // reflection_f's 1 / (4 V.z)
             if (KIND == 0) {
                 const V3 L = normalize(reflect(-V, H));
                 if (L.z <= 0.0f) continue;
