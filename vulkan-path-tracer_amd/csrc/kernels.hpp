@@ -63,6 +63,7 @@ void launch_trace_shadow(hipStream_t s, uint32_t blocks, bool light, bool count,
 void launch_join(hipStream_t s, uint32_t blocks, const RenderParams& P, const PathState& ps, const StreamState& ss, const StreamCounters* sctr, const uint32_t* queue,
                  const uint32_t* queue_next, uint32_t parity);
 int shade_stream_blocks_per_cu();
+int join_blocks_per_cu();
 // participating media on the streams (kernels_media.hip)
 void launch_media_scatter(hipStream_t s, uint32_t blocks, const DeviceScene& sc, const PathState& ps, const StreamState& ss, const MediaState& ms, const uint32_t* queue,
                           const StreamCounters* sctr, uint32_t parity);

@@ -234,38 +234,74 @@ __global__ __launch_bounds__(256, 3) void k_shade_stream(DeviceScene sc, RenderP
 }
 
 // ------------------------------------------------------------------ join
+constexpr int kJoinUnroll = 4;
 __global__ __launch_bounds__(256) void k_join(RenderParams P, PathState ps, StreamState ss, const StreamCounters* sctr, const uint32_t* queue, const uint32_t* queue_next,
                                               uint32_t parity) {
     const uint32_t n = sctr->pend_len.v;
-    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
-        const float4 pt = ss.PT[j];
-        const uint32_t pos = __float_as_uint(pt.w);   // the path's entry in the next queue (it lives on) or in this one (it ended)
-        if (pos == kHole) continue;
-        const float4 pe = ss.PE[j];
-        const uint32_t fl = __float_as_uint(pe.w);
-        V3 E = xyz(pe);
-        if (fl & kCF_Sky) { const float4 s4 = ss.PS[j]; if (ss.vis_sky[__float_as_uint(s4.w)]) E = E + xyz(s4); }
-        if (fl & kCF_Light) { const float4 l4 = ss.PL[j]; if (ss.vis_light[__float_as_uint(l4.w)]) E = E + xyz(l4); }
-        V3 contrib = E * xyz(pt);  // RayGen.slang:92
-        if (fl & kCF_Clamp) {
-            float lum = dot(contrib, v3(0.212671f, 0.715160f, 0.072169f));
-            contrib = contrib * (P.max_luminance / max_(lum, P.max_luminance));
+    // Six dependent fetches per entry (pending record -> its flags -> the two NEE records -> their visibility bytes -> pathLight): a
+    // thread walks kJoinUnroll entries in step, phase by phase, so that four of each are in flight per lane (memory-level
+    // parallelism is what bounds this kernel: it does no arithmetic to speak of).  Entries are independent: a path has one pending
+    // entry per bounce, and the scattered frame sums are touched once per slot per bounce.
+    constexpr int K = kJoinUnroll;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t j0 = blockIdx.x * blockDim.x + threadIdx.x; j0 < n; j0 += stride * K) {
+        float4 pt[K], pe[K], s4[K], l4[K], lp[K];
+        uint32_t pos[K], fl[K], sl[K];
+        bool on[K], vs[K], vl[K];
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const uint32_t j = j0 + (uint32_t)k * stride;
+            on[k] = j < n;
+            pt[k] = on[k] ? ss.PT[j] : make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(kHole));
         }
-        // pathLight travels with the path's queue entry (k_shade_stream): pending entries and queue entries were appended by the
-        // same waves in the same order, so these accesses are streams too
-        float4* Lp = (fl & kCF_Alive) ? &ss.RL[parity ^ 1u][pos] : &ss.RL[parity][pos];
-        V3 light = xyz(*Lp) + contrib;
-        if (fl & kCF_Finalize) {  // end of a sample: NaN/Inf guard, frame sum (RayGen.slang:116-128)
-            const uint32_t sl = (fl & kCF_Alive) ? queue_next[pos] : queue[pos];
-            bool ok = !isinf_(light.x) && !isinf_(light.y) && !isinf_(light.z) && !isnan_(light.x) && !isnan_(light.y) && !isnan_(light.z);
-            if (P.samples_per_frame == 1) {  // the only finalisation of this slot: 0 + pathLight
-                ps.ACC[sl] = ok ? f4(v3s(0.0f) + light, 0.0f) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            } else if (ok) {
-                float4 acc = ps.ACC[sl]; ps.ACC[sl] = f4(xyz(acc) + light, 0.0f);
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            pos[k] = __float_as_uint(pt[k].w);   // the path's entry in the next queue (it lives on) or in this one (it ended)
+            on[k] = on[k] && pos[k] != kHole;
+            pe[k] = on[k] ? ss.PE[j0 + (uint32_t)k * stride] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const uint32_t j = j0 + (uint32_t)k * stride;
+            fl[k] = __float_as_uint(pe[k].w);
+            vs[k] = on[k] && (fl[k] & kCF_Sky); vl[k] = on[k] && (fl[k] & kCF_Light);
+            if (vs[k]) s4[k] = ss.PS[j];
+            if (vl[k]) l4[k] = ss.PL[j];
+            // pathLight travels with the path's queue entry (k_shade_stream): pending entries and queue entries were appended by the
+            // same waves in the same order, so these accesses are streams too
+            if (on[k]) {
+                lp[k] = (fl[k] & kCF_Alive) ? ss.RL[parity ^ 1u][pos[k]] : ss.RL[parity][pos[k]];
+                if (fl[k] & kCF_Finalize) sl[k] = (fl[k] & kCF_Alive) ? queue_next[pos[k]] : queue[pos[k]];
             }
-            light = v3s(0.0f);  // a regenerated sample starts from pathLight = 0
         }
-        if (fl & kCF_Alive) *Lp = f4(light, 0.0f);   // a path that ended has no use for it any more
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            if (vs[k]) vs[k] = ss.vis_sky[__float_as_uint(s4[k].w)] != 0;
+            if (vl[k]) vl[k] = ss.vis_light[__float_as_uint(l4[k].w)] != 0;
+        }
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            if (!on[k]) continue;
+            V3 E = xyz(pe[k]);
+            if (vs[k]) E = E + xyz(s4[k]);
+            if (vl[k]) E = E + xyz(l4[k]);
+            V3 contrib = E * xyz(pt[k]);  // RayGen.slang:92
+            if (fl[k] & kCF_Clamp) {
+                float lum = dot(contrib, v3(0.212671f, 0.715160f, 0.072169f));
+                contrib = contrib * (P.max_luminance / max_(lum, P.max_luminance));
+            }
+            V3 light = xyz(lp[k]) + contrib;
+            if (fl[k] & kCF_Finalize) {  // end of a sample: NaN/Inf guard, frame sum (RayGen.slang:116-128)
+                bool ok = !isinf_(light.x) && !isinf_(light.y) && !isinf_(light.z) && !isnan_(light.x) && !isnan_(light.y) && !isnan_(light.z);
+                if (P.samples_per_frame == 1) {  // the only finalisation of this slot: 0 + pathLight
+                    ps.ACC[sl[k]] = ok ? f4(v3s(0.0f) + light, 0.0f) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                } else if (ok) {
+                    float4 acc = ps.ACC[sl[k]]; ps.ACC[sl[k]] = f4(xyz(acc) + light, 0.0f);
+                }
+                light = v3s(0.0f);  // a regenerated sample starts from pathLight = 0
+            }
+            if (fl[k] & kCF_Alive) ss.RL[parity ^ 1u][pos[k]] = f4(light, 0.0f);   // a path that ended has no use for it any more
+        }
     }
 }
 
@@ -341,6 +377,11 @@ void launch_shade_stream(hipStream_t s, uint32_t blocks, uint32_t cls, bool sort
 void launch_join(hipStream_t s, uint32_t blocks, const RenderParams& P, const PathState& ps, const StreamState& ss, const StreamCounters* sctr, const uint32_t* queue,
                  const uint32_t* queue_next, uint32_t parity) {
     hipLaunchKernelGGL(k_join, dim3(blocks), dim3(256), 0, s, P, ps, ss, sctr, queue, queue_next, parity);
+}
+int join_blocks_per_cu() {   // a streaming kernel: as many waves as fit (its grid-stride loop takes any grid)
+    int nb = 0;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_join, 256, 0);
+    return nb > 0 ? nb : 1;
 }
 int shade_stream_blocks_per_cu() {
     int nb = 0;

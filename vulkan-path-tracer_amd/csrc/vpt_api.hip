@@ -92,7 +92,7 @@ struct vpt_ctx {
     DensityGrid* d_grids = nullptr;
     uint32_t phase = VPT_PHASE_HENYEY_GREENSTEIN;
     uint32_t* d_launch_off = nullptr;  // split-screen: launch-grid prefix sums of the dispatches of a batch
-    int shade_blocks = 1024, primary_blocks = 768, max_blocks = 1536;
+    int shade_blocks = 1024, primary_blocks = 768, max_blocks = 1536, join_blocks = 2048;
     int vote_blocks = 2048;   // persistent grid of the vote-scheduled traversal kernels
     uint32_t vote_param = 256u + 16u;  // weighted vote, fetch step at 16 idle lanes (profiles/r02_trace_lab_*.json)
     Counters* ctr = nullptr;
@@ -579,7 +579,7 @@ int render_batch(vpt_ctx* c, uint32_t frames, uint32_t dispatch_base) {
                 }
                 TIMED(c, VPT_K_SHADOW, launch_trace_shadow(sb, (uint32_t)c->shadow_blocks, false, count, dsc_shadow, c->ss, c->ctr, c->sctr, c->vote_param));
                 TIMED(c, VPT_K_SHADOW, launch_trace_shadow(sb, (uint32_t)c->shadow_blocks, true, count, dsc_shadow, c->ss, c->ctr, c->sctr, c->vote_param));
-                TIMED(c, VPT_K_JOIN, launch_join(sb, (uint32_t)c->shade_blocks, c->P, c->ps, c->ss, c->sctr, c->queue[parity], c->queue[parity ^ 1u], parity));
+                TIMED(c, VPT_K_JOIN, launch_join(sb, (uint32_t)c->join_blocks, c->P, c->ps, c->ss, c->sctr, c->queue[parity], c->queue[parity ^ 1u], parity));
                 if (overlap) { HIPCHK(c, hipEventRecord(c->ev_join, c->stream2)); join_pending = true; }
                 parity ^= 1u;
                 continue;
@@ -881,6 +881,7 @@ int vpt_set_scene(vpt_ctx* c, const vpt_scene_desc* sd) {
     if ((rc = upload(c, li, &D.lut_i))) return rc;
     c->trav_blocks = traverse_blocks_per_cu(c->lds_scene, D) * c->cu_count;
     c->shade_blocks = shade_blocks_per_cu() * c->cu_count;
+    c->join_blocks = join_blocks_per_cu() * c->cu_count;
     c->primary_blocks = bounce_blocks_per_cu(c->lds_scene, D) * c->cu_count;
     c->shade_stream_blocks = shade_stream_blocks_per_cu() * c->cu_count;
     c->shade_media_blocks = shade_media_blocks_per_cu() * c->cu_count;
