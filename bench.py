@@ -5,7 +5,7 @@ Headline workload (config.workload = "cornell_1080p_d8"): BASELINE.json configs[
 (diffuse walls + emissive quad, strength 50), black environment, 1920x1080, max depth 8, 1 sample per pixel per
 frame, base seed 1.  A *step* is one wavefront batch of the hot path: every rank renders
 `frames_per_step` consecutive frames of its own rows (all bounces until the ray queue is empty, then resolve).
-Rows are dealt round-robin over ranks, each rank keeps up to ~256M paths resident (129 frames of a whole 1080p image, 1024 frames of a 1/8 shard), so per-GPU work per step is fixed
+Rows are dealt round-robin over ranks, each rank keeps ~448M paths resident (226 frames of a whole 1080p image, 1808 frames of a 1/8 shard), so per-GPU work per step is fixed
 (weak scaling) and
 
     value = (samples all ranks traced in the K timed steps) / (max over ranks of the wall time)
@@ -19,7 +19,7 @@ After the timed region the same workload runs a few more steps with profiling ON
 around every launch on its own stream) and with traversal counters, which feed
 
   roofline     — for the kernel with the largest share of GPU time: `bound` says what limits it ("valu" for the fused
-                 Cornell kernels: 74-82 % VALU-busy in profiles/, their BVH rides in LDS; "hbm" only where the
+                 Cornell kernels: 94-97 % VALU-busy in profiles/, their BVH rides in LDS; "hbm" only where the
                  bytes really cross HBM).  `achieved` = bytes that MUST cross HBM per launch (path records, queue
                  words, frame sums) / mean launch duration, so frac <= 1 by construction; `traffic` = the PMC
                  measurement (profiles/traffic.json); `algorithmic_GBs` is SURVEY §8d's figure (records + scene
@@ -44,7 +44,8 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 GB/s measured copy
 VALU_LANE_OPS_PEAK = 256 * 4 * 16 * 2.4e9   # lane-operations per second: CUs x SIMDs x lanes per cycle x clock
-FRAMES_AT_N1 = 129      # the library's default frames in flight for a whole 1080p image (~256M resident paths): the step of the strong-scaling job
+FRAMES_AT_N1 = 129      # the step of the strong-scaling job: 8 steps x 129 whole 1080p frames = 1032 spp, config 2's 1024-spp job (the weak-scaling
+                        # step is the library's default batch, 226 frames at N=1)
 WIDTH, HEIGHT, BASE_SEED = 1920, 1080, 1
 WORKLOADS = {   # name -> (max depth, scene description)
     "cornell_1080p_d8": (8, "CornellBox (12 triangles, emissive quad 50), black env"),
@@ -72,7 +73,7 @@ PRIMARY_ALIVE = 16 * 4 + 4          # a survivor writes records A, B, T, L and i
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)   # 8 batches of 129 frames = 1032 samples per pixel: config 2's 1024-spp job
+    ap.add_argument("--steps", type=int, default=8)   # weak: 8 batches of 226 frames = 1808 samples per pixel (covers config 2's 1024 spp); strong: 8 x 129 frames = its 1032-spp job
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="cornell_1080p_d8", choices=sorted(WORKLOADS), help="headline workload (the default is BASELINE's metric config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
