@@ -72,8 +72,9 @@ def test_full_hd_post_properties(vpt, oracle):
     ref8, refb = oracle.postprocess(img, vpt.default_post_params())
     assert np.array_equal(out8, ref8) and np.array_equal(bloom, refb)
     assert (out8[..., 3] == 255).all() and np.isfinite(bloom).all() and (bloom[..., :3] >= 0).all()
-    # fused: down x 4 (the first one thresholds), tail (mips 5-9 down and up), up x 3, then last up-sample + tonemap in one
-    assert st["kernel_launches"]["bloom"] == 4 + 1 + 3 and st["kernel_launches"]["tonemap"] == 1
+    # fused: first down-sample (thresholds), down-samples 2 -> 3 -> 4 in one launch, tail (mips 5-9 down and up), the three up-samples
+    # 4 -> 3 -> 2 -> 1 in one launch, then last up-sample + tonemap in one
+    assert st["kernel_launches"]["bloom"] == 1 + 1 + 1 + 1 and st["kernel_launches"]["tonemap"] == 1
     g = vpt.PathTracer(1920, 1080)
     g.set_radiance(img, 1)
     p8 = g.postprocess(vpt.default_post_params(schedule=1))

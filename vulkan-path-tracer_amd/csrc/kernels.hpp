@@ -84,6 +84,13 @@ void launch_lut(hipStream_t s, int kind, float* table, uint32_t sx, uint32_t sy,
 void launch_bloom_threshold(hipStream_t s, const float* in, float* out, uint32_t w, uint32_t h, float threshold, float falloff);
 void launch_bloom_down(hipStream_t s, const float* in, uint32_t iw, uint32_t ih, float* out, uint32_t ow, uint32_t oh, float strength);
 void launch_bloom_up(hipStream_t s, const float* in, uint32_t iw, uint32_t ih, float* out, uint32_t ow, uint32_t oh, float strength);
+// levels mips[0 .. n - 1] receive their up-samples in one launch (only mips[0] is written); mips[n] is read as it stands; n <= kBloomChainMax
+constexpr uint32_t kBloomChainMax = 4;
+// outs[0 .. n - 1] = successive down-samples of `in`, all written, one launch; n = 2 or 3 (kBloomDownChainMax)
+constexpr uint32_t kBloomDownChainMax = 3;
+constexpr uint32_t kBloomDownChainTexels = 160000;   // 480 x 270 and below: smaller than what fills the chip for the length of a launch
+void launch_bloom_down_chain(hipStream_t s, const float* in, uint32_t iw, uint32_t ih, float* const* outs, const uint32_t* w, const uint32_t* h, uint32_t n, float strength);
+void launch_bloom_up_chain(hipStream_t s, float* const* mips, const uint32_t* w, const uint32_t* h, uint32_t n, float strength);
 // fused schedule: threshold inside the first down-sample, the small mips down and up in one launch, last up-sample + tonemap in one
 void launch_bloom_down_first(hipStream_t s, const float* hdr, uint32_t iw, uint32_t ih, float* out, uint32_t ow, uint32_t oh, float strength, float threshold, float falloff);
 void launch_bloom_tail(hipStream_t s, float* base, uint32_t bw, uint32_t bh, const uint32_t* w, const uint32_t* h, uint32_t levels, float strength);

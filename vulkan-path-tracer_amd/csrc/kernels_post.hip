@@ -45,13 +45,16 @@ __device__ __forceinline__ float4 soft_threshold(float4 p, float threshold, floa
 // tile is staged — each texel once per tile — so the thresholded full-resolution mip is never written or read back.
 template <bool FIRST>
 __global__ __launch_bounds__(256) void k_bloom_down(const float4* in, int iw, int ih, float4* out, int ow, int oh, float strength, float threshold, float falloff) {
-    __shared__ float4 tile[kDownH][kDownW];
+    // rgb only (alpha is not read): 15.6 KB per block instead of 20.8, so that the 2025 blocks of the 1080p first pass are resident together
+    // (10 per CU) rather than in one full round and a 13 % tail
+    __shared__ float tile[kDownH][kDownW][3];
     const int x0 = blockIdx.x * kTileW, y0 = blockIdx.y * kTileH;
     const int sx0 = 2 * x0 - 2, sy0 = 2 * y0 - 2;
     for (int i = threadIdx.x; i < kDownW * kDownH; i += 256) {
         int ty = i / kDownW, tx = i - ty * kDownW;
-        const float4 p = in[(size_t)iclamp(sy0 + ty, 0, ih - 1) * iw + iclamp(sx0 + tx, 0, iw - 1)];
-        tile[ty][tx] = FIRST ? soft_threshold(p, threshold, falloff) : p;
+        float4 p = in[(size_t)iclamp(sy0 + ty, 0, ih - 1) * iw + iclamp(sx0 + tx, 0, iw - 1)];
+        if (FIRST) p = soft_threshold(p, threshold, falloff);
+        tile[ty][tx][0] = p.x; tile[ty][tx][1] = p.y; tile[ty][tx][2] = p.z;
     }
     __syncthreads();
     const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
@@ -60,8 +63,8 @@ __global__ __launch_bounds__(256) void k_bloom_down(const float4* in, int iw, in
     V3 c = v3s(0.0f);
     for (int a = -2; a < 2; a++)
         for (int b = -2; b < 2; b++) {
-            float4 p = tile[2 * ly + b + 2][2 * lx + a + 2];
-            c = c + v3(p.x, p.y, p.z);
+            const float* p = tile[2 * ly + b + 2][2 * lx + a + 2];
+            c = c + v3(p[0], p[1], p[2]);
         }
     c = c / 25.0f;
     c = c * strength;
@@ -168,8 +171,90 @@ __device__ __forceinline__ V3 up_taps(const float4* src, int iw, int ih, int x, 
         }
     return c;
 }
+// One block walks ~14 dependent phases (six levels down, six up, the base in and out); what a phase costs is the latency of its slowest
+// instruction chain, so the staged variant keeps every operand a phase needs where it is cheapest to reach: the level loop is unrolled
+// (sizes and offsets of a level are scalars, not indexed loads from the argument block) and every source is an LDS array by type
+// (a pointer that may be global or LDS compiles to flat loads, which wait for both memory pipelines).
+// STAGED: the base mip (<= kTailMaxBase texels) is copied into LDS once, as rgb — its 16-tap reads by the first down-sample (32 k
+// 16-byte loads through one CU's L1) and its read-modify-write by the last up-sample become one coalesced read and one coalesced write.
+constexpr int kTailMaxBase = 8448;
+template <bool STAGED>
 __global__ __launch_bounds__(kTailThreads) void k_bloom_tail(BloomTail t) {
     __shared__ float4 m[kTailMaxTexels];
+    __shared__ float base3[STAGED ? kTailMaxBase * 3 : 3];
+    if (STAGED) {   // all of a thread's loads in flight together (one block: nothing else hides a round trip)
+        constexpr int R = (kTailMaxBase + kTailThreads - 1) / kTailThreads;
+        float4 v[R];
+        const int n = t.bw * t.bh;
+#pragma unroll
+        for (int r = 0; r < R; r++) { const int i = (int)threadIdx.x + r * kTailThreads; if (i < n) v[r] = t.base[i]; }
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int i = (int)threadIdx.x + r * kTailThreads;
+            if (i < n) { base3[3 * i] = v[r].x; base3[3 * i + 1] = v[r].y; base3[3 * i + 2] = v[r].z; }
+        }
+        __syncthreads();
+    }
+    if (STAGED) {
+#pragma unroll
+        for (int k = 0; k < kTailMaxLevels; k++) {   // down: base -> level 0 -> level 1 ...
+            if (k >= t.levels) break;
+            const int iw = k == 0 ? t.bw : t.w[k > 0 ? k - 1 : 0], ih = k == 0 ? t.bh : t.h[k > 0 ? k - 1 : 0];
+            const int ow = t.w[k], n = ow * t.h[k];
+            const float4* src = m + t.off[k > 0 ? k - 1 : 0];
+            for (int i = threadIdx.x; i < n; i += kTailThreads) {
+                const int y = i / ow, x = i - y * ow;
+                V3 c = v3s(0.0f);
+                for (int a = -2; a < 2; a++)
+                    for (int b = -2; b < 2; b++) {
+                        const int si = iclamp(2 * y + b, 0, ih - 1) * iw + iclamp(2 * x + a, 0, iw - 1);
+                        if (k == 0) { const float* p = base3 + 3 * si; c = c + v3(p[0], p[1], p[2]); }
+                        else { const float4 p = src[si]; c = c + v3(p.x, p.y, p.z); }
+                    }
+                c = c / 25.0f;
+                c = c * t.strength;
+                m[t.off[k] + i] = make_float4(c.x, c.y, c.z, 1.0f);
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int k = kTailMaxLevels - 1; k >= 0; k--) {   // up: level k is added into level k - 1 (into the base for k == 0)
+            if (k >= t.levels) continue;
+            const int ow = k == 0 ? t.bw : t.w[k > 0 ? k - 1 : 0], oh = k == 0 ? t.bh : t.h[k > 0 ? k - 1 : 0];
+            const int iw = t.w[k], ih = t.h[k];
+            const float4* src = m + t.off[k];
+            float4* dstl = m + t.off[k > 0 ? k - 1 : 0];
+            // the 16 taps of an output texel depend on (x / 2, y / 2) only: one evaluation serves the 2 x 2 texels that share them
+            const int qw = (ow + 1) / 2, qh = (oh + 1) / 2;
+            for (int i = threadIdx.x; i < qw * qh; i += kTailThreads) {
+                const int qy = i / qw, qx = i - qy * qw;
+                V3 c = v3s(0.0f);
+                for (int a = -2; a < 2; a++)
+                    for (int b = -2; b < 2; b++) {
+                        const float4 p = src[iclamp(qy + b + 1, 0, ih - 1) * iw + iclamp(qx + a + 1, 0, iw - 1)];
+                        c = c + v3(p.x, p.y, p.z);
+                    }
+                c = c / 25.0f;
+                c = c * t.strength;
+                for (int dy = 0; dy < 2; dy++)
+                    for (int dx = 0; dx < 2; dx++) {
+                        const int x = 2 * qx + dx, y = 2 * qy + dy;
+                        if (x >= ow || y >= oh) continue;
+                        if (k == 0) {
+                            const float* p = base3 + 3 * (y * ow + x);
+                            const V3 r = c + v3(p[0], p[1], p[2]);
+                            t.base[(size_t)y * ow + x] = make_float4(r.x, r.y, r.z, 1.0f);
+                        } else {
+                            const float4 q = dstl[y * ow + x];
+                            const V3 r = c + v3(q.x, q.y, q.z);
+                            dstl[y * ow + x] = make_float4(r.x, r.y, r.z, 1.0f);
+                        }
+                    }
+            }
+            __syncthreads();
+        }
+        return;
+    }
     for (int k = 0; k < t.levels; k++) {   // down: base -> level 0 -> level 1 ...
         const float4* src = k == 0 ? t.base : m + t.off[k - 1];
         const int iw = k == 0 ? t.bw : t.w[k - 1], ih = k == 0 ? t.bh : t.h[k - 1];
@@ -200,6 +285,161 @@ __global__ __launch_bounds__(kTailThreads) void k_bloom_tail(BloomTail t) {
                     const V3 r = c + v3(cur.x, cur.y, cur.z);
                     dst[(size_t)y * ow + x] = make_float4(r.x, r.y, r.z, 1.0f);
                 }
+        }
+        __syncthreads();
+    }
+}
+
+// Several down-samples in one launch (the small middle levels, where a launch costs more than its work): out[0] = down(in), out[1] =
+// down(out[0]), out[2] = down(out[1]), every level written.  A block owns an 8 x 4 tile of the last level and the texels of the levels
+// below that fold into it (a level with an odd size has one more row / column than twice the next one: the last tile owns it), and it
+// evaluates, level by level in LDS, the texels of each level that the next one taps — its own and a halo that neighbouring blocks
+// evaluate too (1.4-1.6 x redundant on levels of a few thousand texels).  Every texel by k_bloom_down's expression in its tap order; a
+// tile entry at an out-of-range position holds the clamped texel's value, so the next level indexes the tile with unclamped taps.
+constexpr int kDcMax = 3, kDcTW = 8, kDcTH = 4;
+constexpr int kDcW1 = 2 * kDcTW + 3, kDcH1 = 2 * kDcTH + 3, kDcW0 = 2 * kDcW1 + 3, kDcH0 = 2 * kDcH1 + 3;   // 19 x 11, 41 x 25
+struct DownChain {
+    int n;                       // levels produced (2 or 3)
+    const float4* in; int iw, ih;
+    float4* out[kDcMax]; int w[kDcMax], h[kDcMax];
+    float strength;
+};
+__global__ __launch_bounds__(256) void k_bloom_down_chain(DownChain c) {
+    __shared__ float4 tile0[kDcW0 * kDcH0];
+    __shared__ float4 tile1[kDcW1 * kDcH1];
+    const int top = c.n - 1;
+    int olx[kDcMax], ohx[kDcMax], oly[kDcMax], ohy[kDcMax];   // owned texels of each level
+    int nlx[kDcMax], nhx[kDcMax], nly[kDcMax], nhy[kDcMax];   // evaluated texels (unclamped positions)
+#pragma unroll
+    for (int j = kDcMax - 1; j >= 0; j--) {
+        if (j > top) { olx[j] = ohx[j] = oly[j] = ohy[j] = nlx[j] = nhx[j] = nly[j] = nhy[j] = 0; continue; }
+        if (j == top) {
+            olx[j] = blockIdx.x * kDcTW; ohx[j] = min(olx[j] + kDcTW - 1, c.w[j] - 1);
+            oly[j] = blockIdx.y * kDcTH; ohy[j] = min(oly[j] + kDcTH - 1, c.h[j] - 1);
+            nlx[j] = olx[j]; nhx[j] = ohx[j]; nly[j] = oly[j]; nhy[j] = ohy[j];
+        } else {
+            const int u = j + 1 < kDcMax ? j + 1 : j;
+            olx[j] = 2 * olx[u]; ohx[j] = ohx[u] == c.w[u] - 1 ? c.w[j] - 1 : 2 * ohx[u] + 1;
+            oly[j] = 2 * oly[u]; ohy[j] = ohy[u] == c.h[u] - 1 ? c.h[j] - 1 : 2 * ohy[u] + 1;
+            nlx[j] = min(olx[j], 2 * iclamp(nlx[u], 0, c.w[u] - 1) - 2); nhx[j] = max(ohx[j], 2 * iclamp(nhx[u], 0, c.w[u] - 1) + 1);
+            nly[j] = min(oly[j], 2 * iclamp(nly[u], 0, c.h[u] - 1) - 2); nhy[j] = max(ohy[j], 2 * iclamp(nhy[u], 0, c.h[u] - 1) + 1);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < kDcMax; j++) {
+        if (j > top) break;
+        const int tw = nhx[j] - nlx[j] + 1, th = nhy[j] - nly[j] + 1;
+        const int pw = j > 0 ? nhx[j - 1] - nlx[j - 1] + 1 : 0;
+        const float4* prev = j == 1 ? tile0 : tile1;
+        float4* mine = j == 0 ? tile0 : tile1;
+        for (int i = threadIdx.x; i < tw * th; i += 256) {
+            const int ty = i / tw, tx = i - ty * tw;
+            const int px = nlx[j] + tx, py = nly[j] + ty;
+            const int x = iclamp(px, 0, c.w[j] - 1), y = iclamp(py, 0, c.h[j] - 1);
+            V3 v = v3s(0.0f);
+#pragma unroll
+            for (int a = -2; a < 2; a++)
+#pragma unroll
+                for (int b = -2; b < 2; b++) {
+                    float4 p;
+                    if (j == 0) p = c.in[(size_t)iclamp(2 * y + b, 0, c.ih - 1) * c.iw + iclamp(2 * x + a, 0, c.iw - 1)];
+                    else p = prev[(2 * y + b - nly[j > 0 ? j - 1 : 0]) * pw + (2 * x + a - nlx[j > 0 ? j - 1 : 0])];
+                    v = v + v3(p.x, p.y, p.z);
+                }
+            v = v / 25.0f;
+            v = v * c.strength;
+            const float4 r = make_float4(v.x, v.y, v.z, 1.0f);
+            if (j < top) mine[i] = r;
+            if (px == x && py == y && x >= olx[j] && x <= ohx[j] && y >= oly[j] && y <= ohy[j]) c.out[j][(size_t)y * c.w[j] + x] = r;
+        }
+        __syncthreads();
+    }
+}
+
+// Several up-samples in one launch: out[j] = blur(out[j + 1]) / 25 * strength + mip[j] for j = n - 1 .. 0, where out[n] is the level above
+// as it stands in memory (the tail's result).  Only out[0] is written: the levels between are consumed by the next level down alone,
+// so a block evaluates the part of each that its 64 x 8 tile of level 0 depends on — 35 x 7, 21 x 7, 14 x 7 texels — in LDS, top level
+// first, every texel by k_bloom_up's expression in its tap order.  A tile entry at an out-of-range position holds the clamped texel's
+// value (the reference clamps tap coordinates), so the next level indexes the tile with unclamped taps.
+constexpr int kChainMax = 4, kChainTileH = 8, kChainW1 = kTileW / 2 + 3, kChainRows = kChainTileH / 2 + 3;   // level 1 of the chain: 35 x 7
+struct UpChain {
+    int n;                          // levels computed (1 .. kChainMax)
+    float4* mip[kChainMax + 1];     // mip[0]: updated in place; mip[1 .. n - 1]: the down-sampled levels (read only); mip[n]: final, read only
+    int w[kChainMax + 1], h[kChainMax + 1];
+    float strength;
+};
+__global__ __launch_bounds__(256) void k_bloom_up_chain(UpChain c) {
+    __shared__ float4 tile[kChainMax - 1][kChainRows * (kChainW1 + 1)];
+    int lox[kChainMax], hix[kChainMax], loy[kChainMax], hiy[kChainMax];
+    lox[0] = blockIdx.x * kTileW; hix[0] = lox[0] + kTileW - 1; loy[0] = blockIdx.y * kChainTileH; hiy[0] = loy[0] + kChainTileH - 1;
+#pragma unroll
+    for (int j = 1; j < kChainMax; j++) {   // the positions of level j the tile of level j - 1 taps: x / 2 - 1 .. x / 2 + 2 of its (clamped) texels
+        lox[j] = iclamp(lox[j - 1], 0, c.w[j - 1] - 1) / 2 - 1; hix[j] = iclamp(hix[j - 1], 0, c.w[j - 1] - 1) / 2 + 2;
+        loy[j] = iclamp(loy[j - 1], 0, c.h[j - 1] - 1) / 2 - 1; hiy[j] = iclamp(hiy[j - 1], 0, c.h[j - 1] - 1) / 2 + 2;
+    }
+    // Everything a thread reads from memory is requested before the first level is evaluated (the levels follow each other through LDS and
+    // barriers; a fetch inside each would put a memory round trip into every one of them): the texel of each level it will add its blur
+    // to, and, for the top level of the chain, the 16 taps of the level above.
+    // Levels 1 .. n - 1: one tile entry per thread (<= 252 entries).  Level 0: a thread owns two neighbouring texels of one row; their
+    // taps depend on (x / 2, y / 2) only, which they share.
+    float4 cur[kChainMax];          // levels >= 1
+    int ex[kChainMax], ey[kChainMax]; bool eon[kChainMax];
+#pragma unroll
+    for (int j = 1; j < kChainMax; j++) {
+        const int tw = hix[j] - lox[j] + 1, th = hiy[j] - loy[j] + 1;
+        eon[j] = j < c.n && (int)threadIdx.x < tw * th;
+        const int ty = (int)threadIdx.x / tw, tx = (int)threadIdx.x - ty * tw;
+        ex[j] = iclamp(lox[j] + tx, 0, c.w[j] - 1); ey[j] = iclamp(loy[j] + ty, 0, c.h[j] - 1);
+        if (eon[j]) cur[j] = c.mip[j][(size_t)ey[j] * c.w[j] + ex[j]];
+    }
+    const int qx = (int)(threadIdx.x & 31u), qy = (int)(threadIdx.x >> 6), dy = (int)((threadIdx.x >> 5) & 1u);
+    const int x0 = lox[0] + 2 * qx, y0 = loy[0] + 2 * qy + dy;         // this thread's texels of level 0: (x0, y0), (x0 + 1, y0)
+    const bool on0 = x0 < c.w[0] && y0 < c.h[0], on1 = on0 && x0 + 1 < c.w[0];
+    float4 c0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), c1 = c0;
+    if (on0) c0 = c.mip[0][(size_t)y0 * c.w[0] + x0];
+    if (on1) c1 = c.mip[0][(size_t)y0 * c.w[0] + x0 + 1];
+    float4 tap[16];
+    const int jt = c.n - 1;                                           // the chain's top level: its taps come from memory
+#pragma unroll
+    for (int j = 0; j < kChainMax; j++) {
+        if (j != jt) continue;
+        const int x = j == 0 ? x0 : ex[j], y = j == 0 ? y0 : ey[j];
+        if (j == 0 ? on0 : eon[j])
+#pragma unroll
+            for (int a = -2; a < 2; a++)
+#pragma unroll
+                for (int b = -2; b < 2; b++)
+                    tap[(a + 2) * 4 + (b + 2)] = c.mip[j + 1][(size_t)iclamp(y / 2 + b + 1, 0, c.h[j + 1] - 1) * c.w[j + 1] + iclamp(x / 2 + a + 1, 0, c.w[j + 1] - 1)];
+    }
+#pragma unroll
+    for (int j = kChainMax - 1; j >= 0; j--) {
+        if (j >= c.n) continue;
+        const bool act = j == 0 ? on0 : eon[j];
+        if (act) {
+            const int x = j == 0 ? x0 : ex[j], y = j == 0 ? y0 : ey[j];
+            V3 u = v3s(0.0f);
+            if (j == jt) {
+#pragma unroll
+                for (int k = 0; k < 16; k++) u = u + v3(tap[k].x, tap[k].y, tap[k].z);   // (a outer, b inner): the order they were fetched in
+            } else {
+                const int sj = j + 1 < kChainMax ? j + 1 : 0;         // (never read with j == kChainMax - 1: that level is always the top)
+                const int sw = hix[sj] - lox[sj] + 1;
+                for (int a = -2; a < 2; a++)
+                    for (int b = -2; b < 2; b++) {
+                        const float4 p = tile[sj - 1 >= 0 ? sj - 1 : 0][(y / 2 + b + 1 - loy[sj]) * sw + (x / 2 + a + 1 - lox[sj])];
+                        u = u + v3(p.x, p.y, p.z);
+                    }
+            }
+            u = u / 25.0f;
+            u = u * c.strength;
+            if (j == 0) {
+                const V3 r0 = u + v3(c0.x, c0.y, c0.z);
+                c.mip[0][(size_t)y0 * c.w[0] + x0] = make_float4(r0.x, r0.y, r0.z, 1.0f);
+                if (on1) { const V3 r1 = u + v3(c1.x, c1.y, c1.z); c.mip[0][(size_t)y0 * c.w[0] + x0 + 1] = make_float4(r1.x, r1.y, r1.z, 1.0f); }
+            } else {
+                const V3 r = u + v3(cur[j].x, cur[j].y, cur[j].z);
+                tile[j - 1][threadIdx.x] = make_float4(r.x, r.y, r.z, 1.0f);   // entry index = ty * tw + tx = threadIdx.x
+            }
         }
         __syncthreads();
     }
@@ -312,7 +552,8 @@ void launch_bloom_tail(hipStream_t s, float* base, uint32_t bw, uint32_t bh, con
     t.base = reinterpret_cast<float4*>(base); t.bw = (int)bw; t.bh = (int)bh; t.levels = (int)levels; t.strength = strength;
     int off = 0;
     for (uint32_t k = 0; k < levels; k++) { t.w[k] = (int)w[k]; t.h[k] = (int)h[k]; t.off[k] = off; off += (int)(w[k] * h[k]); }
-    hipLaunchKernelGGL(k_bloom_tail, dim3(1), dim3(kTailThreads), 0, s, t);
+    if (bw * bh <= (uint32_t)kTailMaxBase) hipLaunchKernelGGL(k_bloom_tail<true>, dim3(1), dim3(kTailThreads), 0, s, t);
+    else hipLaunchKernelGGL(k_bloom_tail<false>, dim3(1), dim3(kTailThreads), 0, s, t);
 }
 void launch_post_final(hipStream_t s, const float* hdr, const float* mip1, uint32_t mw, uint32_t mh, float* bloom0_out, uint8_t* out, uint32_t w, uint32_t h,
                        float threshold, float falloff, float strength, float exposure, float gamma, bool linear_tap) {
@@ -326,6 +567,21 @@ void launch_post_final(hipStream_t s, const float* hdr, const float* mip1, uint3
 void launch_bloom_up(hipStream_t s, const float* in, uint32_t iw, uint32_t ih, float* out, uint32_t ow, uint32_t oh, float strength) {
     hipLaunchKernelGGL(k_bloom_up, dim3(cdiv_(ow, 64), cdiv_(oh, 4)), dim3(256), 0, s, reinterpret_cast<const float4*>(in), (int)iw, (int)ih,
                        reinterpret_cast<float4*>(out), (int)ow, (int)oh, strength);
+}
+void launch_bloom_down_chain(hipStream_t s, const float* in, uint32_t iw, uint32_t ih, float* const* outs, const uint32_t* w, const uint32_t* h, uint32_t n, float strength) {
+    DownChain c{};
+    c.n = (int)n; c.in = reinterpret_cast<const float4*>(in); c.iw = (int)iw; c.ih = (int)ih; c.strength = strength;
+    for (uint32_t j = 0; j < kDcMax; j++) { const uint32_t k = j < n ? j : n - 1; c.out[j] = reinterpret_cast<float4*>(outs[k]); c.w[j] = (int)w[k]; c.h[j] = (int)h[k]; }
+    hipLaunchKernelGGL(k_bloom_down_chain, dim3(cdiv_(w[n - 1], kDcTW), cdiv_(h[n - 1], kDcTH)), dim3(256), 0, s, c);
+}
+void launch_bloom_up_chain(hipStream_t s, float* const* mips, const uint32_t* w, const uint32_t* h, uint32_t n, float strength) {
+    UpChain c{};
+    c.n = (int)n; c.strength = strength;
+    for (uint32_t j = 0; j <= kChainMax; j++) {   // unused levels repeat the last one: the range arithmetic stays defined
+        const uint32_t k = j <= n ? j : n;
+        c.mip[j] = reinterpret_cast<float4*>(mips[k]); c.w[j] = (int)w[k]; c.h[j] = (int)h[k];
+    }
+    hipLaunchKernelGGL(k_bloom_up_chain, dim3(cdiv_(w[0], kTileW), cdiv_(h[0], kChainTileH)), dim3(256), 0, s, c);
 }
 void launch_tonemap(hipStream_t s, const float* hdr, const float* bloom0, uint8_t* out, uint32_t w, uint32_t h, float exposure, float gamma,
                     bool linear_tap) {

@@ -1214,15 +1214,41 @@ int vpt_postprocess(vpt_ctx* c, const vpt_post_params* pp, uint8_t* out8, float*
         for (uint32_t i = 2; i < mip_count; i++) if ((uint64_t)MW(i) * MH(i) <= kBloomTailMaxTexels) { T = i; break; }
         if (mip_count - T > kBloomTailMaxLevels) T = mip_count;   // cannot happen with <= 10 mips; the per-pass kernels cover it
         if (mip_count >= 2) TIMED(c, VPT_K_BLOOM, launch_bloom_down_first(s, hdr, W, H, c->mips[1], MW(1), MH(1), pp->bloom_strength, pp->bloom_threshold, pp->falloff_range));
-        for (uint32_t i = 2; i < std::min(T, mip_count); i++)
-            TIMED(c, VPT_K_BLOOM, launch_bloom_down(s, c->mips[i - 1], MW(i - 1), MH(i - 1), c->mips[i], MW(i), MH(i), pp->bloom_strength));
+        {   // down-samples between mip 1 and the tail's base: one launch each while the levels are large, the last (up to three, at most
+            // kBloomDownChainTexels texels in the first of them) in one launch
+            const uint32_t last = std::min(T, mip_count) - 1;   // last level produced here
+            uint32_t i = 2;
+            while (i <= last) {
+                const uint32_t left = last - i + 1;
+                if (left >= 2 && left <= kBloomDownChainMax && (uint64_t)MW(i) * MH(i) <= kBloomDownChainTexels) {
+                    float* lv[kBloomDownChainMax]; uint32_t lw[kBloomDownChainMax], lh[kBloomDownChainMax];
+                    for (uint32_t k = 0; k < left; k++) { lv[k] = c->mips[i + k]; lw[k] = MW(i + k); lh[k] = MH(i + k); }
+                    TIMED(c, VPT_K_BLOOM, launch_bloom_down_chain(s, c->mips[i - 1], MW(i - 1), MH(i - 1), lv, lw, lh, left, pp->bloom_strength));
+                    i += left;
+                } else {
+                    TIMED(c, VPT_K_BLOOM, launch_bloom_down(s, c->mips[i - 1], MW(i - 1), MH(i - 1), c->mips[i], MW(i), MH(i), pp->bloom_strength));
+                    i++;
+                }
+            }
+        }
         if (T < mip_count) {
             uint32_t tw[kBloomTailMaxLevels], th[kBloomTailMaxLevels];
             for (uint32_t i = T; i < mip_count; i++) { tw[i - T] = MW(i); th[i - T] = MH(i); }
             TIMED(c, VPT_K_BLOOM, launch_bloom_tail(s, c->mips[T - 1], MW(T - 1), MH(T - 1), tw, th, mip_count - T, pp->bloom_strength));
         }
-        for (uint32_t i = std::min(T, mip_count) - 1; i > 1; i--)
-            TIMED(c, VPT_K_BLOOM, launch_bloom_up(s, c->mips[i], MW(i), MH(i), c->mips[i - 1], MW(i - 1), MH(i - 1), pp->bloom_strength));
+        // up-samples of the levels between the tail and mip 1: up to kBloomChainMax of them per launch, only the lowest level written
+        // (the levels between are read by nothing else)
+        for (uint32_t top = std::min(T, mip_count) - 1; top > 1;) {
+            const uint32_t n = std::min(top - 1u, kBloomChainMax), base = top - n;
+            if (n == 1) {
+                TIMED(c, VPT_K_BLOOM, launch_bloom_up(s, c->mips[top], MW(top), MH(top), c->mips[base], MW(base), MH(base), pp->bloom_strength));
+            } else {
+                float* lv[kBloomChainMax + 1]; uint32_t lw[kBloomChainMax + 1], lh[kBloomChainMax + 1];
+                for (uint32_t k = 0; k <= n; k++) { lv[k] = c->mips[base + k]; lw[k] = MW(base + k); lh[k] = MH(base + k); }
+                TIMED(c, VPT_K_BLOOM, launch_bloom_up_chain(s, lv, lw, lh, n, pp->bloom_strength));
+            }
+            top = base;
+        }
         TIMED(c, VPT_K_TONEMAP, launch_post_final(s, hdr, mip_count >= 2 ? c->mips[1] : nullptr, mip_count >= 2 ? MW(1) : 0u, mip_count >= 2 ? MH(1) : 0u,
                                                   bloom0 ? c->mips[0] : nullptr, c->post_out, W, H, pp->bloom_threshold, pp->falloff_range, pp->bloom_strength,
                                                   pp->exposure, pp->gamma, linear_tap));
