@@ -93,7 +93,10 @@ void launch_bloom_down_chain(hipStream_t s, const float* in, uint32_t iw, uint32
 void launch_bloom_up_chain(hipStream_t s, float* const* mips, const uint32_t* w, const uint32_t* h, uint32_t n, float strength);
 // fused schedule: threshold inside the first down-sample, the small mips down and up in one launch, last up-sample + tonemap in one
 void launch_bloom_down_first(hipStream_t s, const float* hdr, uint32_t iw, uint32_t ih, float* out, uint32_t ow, uint32_t oh, float strength, float threshold, float falloff);
-void launch_bloom_tail(hipStream_t s, float* base, uint32_t bw, uint32_t bh, const uint32_t* w, const uint32_t* h, uint32_t levels, float strength);
+// staged (base mip <= 8448 texels, bloom_tail_is_staged): levels w[0..] go down and up in LDS and level 0, finished, is written to top_out — the
+// up-sample into the base is the caller's (the up chain's); otherwise (huge base) the base itself is updated and top_out is not used
+bool bloom_tail_is_staged(uint32_t bw, uint32_t bh);
+void launch_bloom_tail(hipStream_t s, float* base, float* top_out, uint32_t bw, uint32_t bh, const uint32_t* w, const uint32_t* h, uint32_t levels, float strength);
 void launch_post_final(hipStream_t s, const float* hdr, const float* mip1, uint32_t mw, uint32_t mh, float* bloom0_out, uint8_t* out, uint32_t w, uint32_t h,
                        float threshold, float falloff, float strength, float exposure, float gamma, bool linear_tap);
 constexpr uint32_t kBloomTailMaxTexels = 2048, kBloomTailMaxLevels = 8;   // largest mip the one-launch tail keeps in LDS; levels it can hold

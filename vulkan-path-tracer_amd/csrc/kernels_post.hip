@@ -147,7 +147,9 @@ __global__ __launch_bounds__(256) void k_tonemap(const float4* hdr, const float4
 
 constexpr int kTailThreads = 1024, kTailMaxLevels = 8, kTailMaxTexels = 2048 + 512 + 128 + 32 + 8 + 2 + 1 + 1;
 struct BloomTail {
-    float4* base;              // the mip above the tail (global memory): read by the first down-sample, updated by the last up-sample
+    float4* base;              // the mip above the tail (global memory): read by the first down-sample; updated by the last up-sample unless top_out
+    float4* top_out;           // staged variant: the tail's first level, finished, goes here instead (the up-sample INTO the base — four times
+                               // as many texels, on this one CU — is left to the up chain, which runs on all of them)
     int bw, bh;
     int levels;                // mips held in LDS
     int w[kTailMaxLevels], h[kTailMaxLevels], off[kTailMaxLevels];   // size and first texel of each in the LDS array
@@ -219,11 +221,11 @@ __global__ __launch_bounds__(kTailThreads) void k_bloom_tail(BloomTail t) {
         }
 #pragma unroll
         for (int k = kTailMaxLevels - 1; k >= 0; k--) {   // up: level k is added into level k - 1 (into the base for k == 0)
-            if (k >= t.levels) continue;
-            const int ow = k == 0 ? t.bw : t.w[k > 0 ? k - 1 : 0], oh = k == 0 ? t.bh : t.h[k > 0 ? k - 1 : 0];
+            if (k >= t.levels || k == 0) continue;
+            const int ow = t.w[k - 1], oh = t.h[k - 1];
             const int iw = t.w[k], ih = t.h[k];
             const float4* src = m + t.off[k];
-            float4* dstl = m + t.off[k > 0 ? k - 1 : 0];
+            float4* dstl = m + t.off[k - 1];
             // the 16 taps of an output texel depend on (x / 2, y / 2) only: one evaluation serves the 2 x 2 texels that share them
             const int qw = (ow + 1) / 2, qh = (oh + 1) / 2;
             for (int i = threadIdx.x; i < qw * qh; i += kTailThreads) {
@@ -240,19 +242,14 @@ __global__ __launch_bounds__(kTailThreads) void k_bloom_tail(BloomTail t) {
                     for (int dx = 0; dx < 2; dx++) {
                         const int x = 2 * qx + dx, y = 2 * qy + dy;
                         if (x >= ow || y >= oh) continue;
-                        if (k == 0) {
-                            const float* p = base3 + 3 * (y * ow + x);
-                            const V3 r = c + v3(p[0], p[1], p[2]);
-                            t.base[(size_t)y * ow + x] = make_float4(r.x, r.y, r.z, 1.0f);
-                        } else {
-                            const float4 q = dstl[y * ow + x];
-                            const V3 r = c + v3(q.x, q.y, q.z);
-                            dstl[y * ow + x] = make_float4(r.x, r.y, r.z, 1.0f);
-                        }
+                        const float4 q = dstl[y * ow + x];
+                        const V3 r = c + v3(q.x, q.y, q.z);
+                        dstl[y * ow + x] = make_float4(r.x, r.y, r.z, 1.0f);
                     }
             }
             __syncthreads();
         }
+        for (int i = threadIdx.x; i < t.w[0] * t.h[0]; i += kTailThreads) t.top_out[i] = m[t.off[0] + i];
         return;
     }
     for (int k = 0; k < t.levels; k++) {   // down: base -> level 0 -> level 1 ...
@@ -547,12 +544,13 @@ void launch_bloom_down_first(hipStream_t s, const float* hdr, uint32_t iw, uint3
     hipLaunchKernelGGL(k_bloom_down<true>, dim3(cdiv_(ow, 64), cdiv_(oh, 4)), dim3(256), 0, s, reinterpret_cast<const float4*>(hdr), (int)iw, (int)ih,
                        reinterpret_cast<float4*>(out), (int)ow, (int)oh, strength, threshold, falloff);
 }
-void launch_bloom_tail(hipStream_t s, float* base, uint32_t bw, uint32_t bh, const uint32_t* w, const uint32_t* h, uint32_t levels, float strength) {
+bool bloom_tail_is_staged(uint32_t bw, uint32_t bh) { return (uint64_t)bw * bh <= (uint64_t)kTailMaxBase; }
+void launch_bloom_tail(hipStream_t s, float* base, float* top_out, uint32_t bw, uint32_t bh, const uint32_t* w, const uint32_t* h, uint32_t levels, float strength) {
     BloomTail t{};
-    t.base = reinterpret_cast<float4*>(base); t.bw = (int)bw; t.bh = (int)bh; t.levels = (int)levels; t.strength = strength;
+    t.base = reinterpret_cast<float4*>(base); t.top_out = reinterpret_cast<float4*>(top_out); t.bw = (int)bw; t.bh = (int)bh; t.levels = (int)levels; t.strength = strength;
     int off = 0;
     for (uint32_t k = 0; k < levels; k++) { t.w[k] = (int)w[k]; t.h[k] = (int)h[k]; t.off[k] = off; off += (int)(w[k] * h[k]); }
-    if (bw * bh <= (uint32_t)kTailMaxBase) hipLaunchKernelGGL(k_bloom_tail<true>, dim3(1), dim3(kTailThreads), 0, s, t);
+    if (bloom_tail_is_staged(bw, bh)) hipLaunchKernelGGL(k_bloom_tail<true>, dim3(1), dim3(kTailThreads), 0, s, t);
     else hipLaunchKernelGGL(k_bloom_tail<false>, dim3(1), dim3(kTailThreads), 0, s, t);
 }
 void launch_post_final(hipStream_t s, const float* hdr, const float* mip1, uint32_t mw, uint32_t mh, float* bloom0_out, uint8_t* out, uint32_t w, uint32_t h,

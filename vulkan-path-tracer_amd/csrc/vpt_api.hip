@@ -1231,14 +1231,17 @@ int vpt_postprocess(vpt_ctx* c, const vpt_post_params* pp, uint8_t* out8, float*
                 }
             }
         }
+        uint32_t up_from = std::min(T, mip_count) - 1;   // the highest level that is final once the tail has run
         if (T < mip_count) {
             uint32_t tw[kBloomTailMaxLevels], th[kBloomTailMaxLevels];
             for (uint32_t i = T; i < mip_count; i++) { tw[i - T] = MW(i); th[i - T] = MH(i); }
-            TIMED(c, VPT_K_BLOOM, launch_bloom_tail(s, c->mips[T - 1], MW(T - 1), MH(T - 1), tw, th, mip_count - T, pp->bloom_strength));
+            const bool staged = bloom_tail_is_staged(MW(T - 1), MH(T - 1));
+            TIMED(c, VPT_K_BLOOM, launch_bloom_tail(s, c->mips[T - 1], c->mips[T], MW(T - 1), MH(T - 1), tw, th, mip_count - T, pp->bloom_strength));
+            if (staged) up_from = T;   // the staged tail leaves mip T finished in memory and mip T - 1 as the down-samples left it
         }
         // up-samples of the levels between the tail and mip 1: up to kBloomChainMax of them per launch, only the lowest level written
         // (the levels between are read by nothing else)
-        for (uint32_t top = std::min(T, mip_count) - 1; top > 1;) {
+        for (uint32_t top = up_from; top > 1;) {
             const uint32_t n = std::min(top - 1u, kBloomChainMax), base = top - n;
             if (n == 1) {
                 TIMED(c, VPT_K_BLOOM, launch_bloom_up(s, c->mips[top], MW(top), MH(top), c->mips[base], MW(base), MH(base), pp->bloom_strength));
