@@ -46,6 +46,26 @@ def test_elementary_accuracy(oracle, fn, lo, hi, ref, tol):
     assert err.max() <= tol, (fn, err.max())
 
 
+def test_acos_is_its_three_branch_definition_bit_for_bit(oracle):
+    """acos_ evaluates asin once on a selected argument (vpt_fp32.h); its definition is three branches with an asin_ each.  Same bits on
+    4 M random inputs, every branch boundary and the neighbours of +-0.5 and +-1 (an exhaustive run over all 2^32 inputs was done once:
+    0 differences)."""
+    rng = np.random.RandomState(11)
+    x = np.concatenate([(rng.rand(1 << 22) * 2.0 - 1.0).astype(np.float32),
+                        np.array([0.0, -0.0, 0.5, -0.5, 1.0, -1.0], np.float32)])
+    for v in (0.5, -0.5, 1.0, -1.0):
+        c = np.float32(v)
+        x = np.concatenate([x, np.array([np.nextafter(c, np.float32(2)), np.nextafter(c, np.float32(-2))], np.float32)])
+    x = x[np.abs(x) <= 1.0]
+    f32 = np.float32
+    a_lo = oracle.fp32_eval("asin", np.sqrt(f32(0.5) * (f32(1.0) + x)))      # float32 numpy arithmetic = the IEEE operations of the C side
+    a_hi = oracle.fp32_eval("asin", np.sqrt(f32(0.5) * (f32(1.0) - x)))
+    a_mid = oracle.fp32_eval("asin", x)
+    ref = np.where(x < f32(-0.5), f32(3.14159265358979323846) - f32(2.0) * a_lo, np.where(x > f32(0.5), f32(2.0) * a_hi, f32(1.57079632679489661923) - a_mid)).astype(np.float32)
+    got = oracle.fp32_eval("acos", x)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
 def test_atan2_and_pow(oracle):
     rng = np.random.RandomState(4)
     y = (rng.rand(100000) * 4 - 2).astype(np.float32)
