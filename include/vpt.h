@@ -163,7 +163,7 @@ typedef struct vpt_post_params {
     float falloff_range;   /* 5.0 */
     uint32_t schedule;     /* VPT_POST_FUSED (default) | VPT_POST_REFERENCE_PASSES; the output is identical, byte for byte */
 } vpt_post_params;
-#define VPT_POST_FUSED 0u            /* threshold inside the first down-sample, the small mips down and up in one launch, last up-sample + tonemap in one */
+#define VPT_POST_FUSED 0u            /* threshold inside the first down-sample; middle mips down in one launch, up in one; the smallest down and up in one; last up-sample + tonemap in one */
 #define VPT_POST_REFERENCE_PASSES 1u /* one kernel per pass as PostProcessor.cpp:193-246 records them (the A/B baseline) */
 
 typedef struct vpt_config {
