@@ -61,9 +61,10 @@ __device__ inline void tex_issue(const uint8_t* texels, const TexDesc& t, float 
         k.r00 = p[row0 + (uint32_t)x0]; k.r10 = p[row0 + (uint32_t)x1]; k.r01 = p[row1 + (uint32_t)x0]; k.r11 = p[row1 + (uint32_t)x1];
     }
 }
+// (a one-channel tap was loaded as a zero-extended byte: its bytes 1-3 are 0, which decode to the 0.0f the one-channel texel has there;
+// only alpha differs — so one decode serves both kinds, and a wave that holds both issues it once)
 __device__ inline V4 tex_decode(uint32_t r, uint32_t c) {
-    if (c == 4) return v4(unorm8_to_float(r & 255u), unorm8_to_float((r >> 8) & 255u), unorm8_to_float((r >> 16) & 255u), unorm8_to_float(r >> 24));
-    return v4(unorm8_to_float(r), 0.0f, 0.0f, 1.0f);
+    return v4(unorm8_to_float(r & 255u), unorm8_to_float((r >> 8) & 255u), unorm8_to_float((r >> 16) & 255u), c == 4 ? unorm8_to_float(r >> 24) : 1.0f);
 }
 __device__ inline V4 tex_finish(const TexTaps& k) {
     V4 a = lerp4(tex_decode(k.r00, k.c), tex_decode(k.r10, k.c), k.fx);
