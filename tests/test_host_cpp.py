@@ -349,6 +349,7 @@ def test_cpp_importer_rejects_malformed_files_without_crashing(cli, tmp_path):
     bad = {}
     d = copy.deepcopy(doc); d["accessors"][0]["count"] = 2 ** 62; bad["huge_count"] = d
     d = copy.deepcopy(doc); d["accessors"][0]["count"] = 2 ** 40; d["bufferViews"][0]["byteStride"] = 2 ** 40; bad["stride_overflow"] = d
+    d = copy.deepcopy(doc); d["bufferViews"][0]["byteStride"] = 1; bad["stride_below_element_size"] = d   # would let `count` outgrow the buffer it reads
     d = copy.deepcopy(doc); d["accessors"][0]["bufferView"] = 7; bad["bufferview_index"] = d
     d = copy.deepcopy(doc); d["bufferViews"][0]["buffer"] = 3; bad["buffer_index"] = d
     d = copy.deepcopy(doc); del d["accessors"]; bad["no_accessors"] = d

@@ -297,6 +297,7 @@ bool ImportScene(const std::string& gltfPath, SceneAsset& sc, std::string& error
         const size_t off0 = bv.index("byteOffset", 0), off1 = a.index("byteOffset", 0);
         size_t stride = bv.index("byteStride", 0);
         if (!stride) stride = csz * ncomp;
+        if (stride < csz * ncomp) return false;   // (glTF: byteStride >= the element size) — with it, count * element size <= buffer size bounds the allocation below
         const std::string& buf = bufs[bi];
         // the last element must end inside the buffer; 128-bit arithmetic, so no crafted count / stride can wrap the check
         const unsigned __int128 end = (unsigned __int128)off0 + off1 + (count ? (unsigned __int128)(count - 1) * stride + csz * ncomp : 0);

@@ -289,6 +289,10 @@ def load_gltf(path, image_loader=None):
         stride = bv.get("byteStride", 0)
         isz = np.dtype(dt).itemsize * nc
         raw = bufs[bv["buffer"]]
+        if stride and stride < isz:   # (glTF: byteStride >= the element size; as host/SceneLoader.cpp)
+            raise ValueError("glTF accessor %d: byteStride smaller than an element" % i)
+        if a["count"] and off + (a["count"] - 1) * (stride or isz) + isz > len(raw):
+            raise ValueError("glTF accessor %d reaches past its buffer" % i)
         if stride and stride != isz:
             out = np.zeros((a["count"], nc), dt)
             for k in range(a["count"]):
