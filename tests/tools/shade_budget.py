@@ -5,13 +5,14 @@
 2. Compiles one tiny kernel per contract / shading function and counts its instructions: what one call costs.
 
     python tests/tools/shade_budget.py [--json out.json]
+    python tests/tools/shade_budget.py --fused        # the same breakdown for the fused kernels of the headline workload (kernels_path.hip)
 """
 import collections, importlib, json, os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 _build = importlib.import_module("vulkan-path-tracer_amd._build")
 CSRC = os.path.join(ROOT, "vulkan-path-tracer_amd", "csrc")
-FLAGS = [f for f in _build.FLAGS if f not in ("-fPIC",)] + _build.EXTRA_FLAGS.get("kernels_stream.hip", [])
+FLAGS = [f for f in _build.FLAGS if f not in ("-fPIC",)] + _build.EXTRA_FLAGS.get("kernels_stream.hip", [])   # (kernels_path.hip has the same per-file flags)
 
 def asm(src, extra=()):
     out = tempfile.mktemp(suffix=".s")
@@ -36,13 +37,13 @@ def function_ranges(path):
                 rows.append(tuple(cur)); cur = None
     return rows
 
-def shade_kernel_by_function():
-    lines = asm(os.path.join(CSRC, "kernels_stream.hip"), ["-gline-tables-only"])
+def shade_kernel_by_function(src="kernels_stream.hip", symbol="_ZN3vpt14k_shade_streamILin1EEE"):
+    lines = asm(os.path.join(CSRC, src), ["-gline-tables-only"])
     files = {}
     for l in lines:
         m = re.match(r'\s*\.file\s+(\d+)\s+"([^"]*)"(?:\s+"([^"]*)")?', l)
         if m: files[int(m.group(1))] = os.path.basename(m.group(3) or m.group(2))
-    start = next(i for i, l in enumerate(lines) if l.startswith("_ZN3vpt14k_shade_streamILin1EEE") and "@" in l)
+    start = next(i for i, l in enumerate(lines) if l.startswith(symbol) and "@" in l)
     end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))
     by_line, cur, total = collections.Counter(), None, collections.Counter()
     for l in lines[start + 1:end]:
@@ -55,7 +56,7 @@ def shade_kernel_by_function():
         total[kind] += 1
         if kind == "valu": by_line[cur] += 1
     ranges = {}
-    for f in ("vpt_fp32.h", "shading.hpp", "shade_core.hpp", "kernels_stream.hip", "vote.hpp", "wave.hpp", "volume.hpp", "atmosphere.hpp"):
+    for f in ("vpt_fp32.h", "shading.hpp", "shade_core.hpp", "kernels_stream.hip", "kernels_path.hip", "traverse.hpp", "vote.hpp", "wave.hpp", "volume.hpp", "atmosphere.hpp"):
         p = os.path.join(ROOT, "include", f) if f == "vpt_fp32.h" else os.path.join(CSRC, f)
         ranges[f] = function_ranges(p)
     by_fn = collections.Counter()
@@ -103,6 +104,15 @@ def micro_costs():
     return out
 
 if __name__ == "__main__":
+    if "--fused" in sys.argv:   # the headline's two kernels: k_bounce<LDS scene> for bounces >= 1 and its FIRST variant (camera ray + bounce 0)
+        for label, sym in (("k_bounce<LDS, bounce >= 1>", "_ZN3vpt8k_bounceILb1ELb0ELb0ELb0ELb0EEE"), ("k_bounce<LDS, FIRST>", "_ZN3vpt8k_bounceILb1ELb0ELb1ELb0ELb0EEE")):
+            total, by_fn = shade_kernel_by_function("kernels_path.hip", sym)
+            print("%s: %d VALU, %d SALU, %d memory instructions (static)\n" % (label, total["valu"], total["salu"], total["mem"]))
+            print("| source function (innermost inlined) | VALU instructions | share |\n|---|---|---|")
+            for (f, n), c in by_fn.most_common(16):
+                print("| `%s` (%s) | %d | %.1f %% |" % (n, f, c, 100.0 * c / total["valu"]))
+            print()
+        sys.exit(0)
     total, by_fn = shade_kernel_by_function()
     micro = micro_costs()
     print("k_shade_stream<kShadeAny>: %d VALU, %d SALU, %d memory instructions (static)\n" % (total["valu"], total["salu"], total["mem"]))
