@@ -78,7 +78,7 @@ def parse():
     ap.add_argument("--workload", default="cornell_1080p_d8", choices=sorted(WORKLOADS), help="headline workload (the default is BASELINE's metric config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-workloads", action="store_true", help="skip the atrium / glass-bust blocks")
-    ap.add_argument("--frames-in-flight", type=int, default=0, help="frames per step per GPU (0 = backend default, ~256M resident paths)")
+    ap.add_argument("--frames-in-flight", type=int, default=0, help="frames per step per GPU (0 = backend default, ~448M resident paths)")
     ap.add_argument("--pipeline", type=int, default=0, help="vpt_config.pipeline (0 AUTO)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the oracle sample")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
