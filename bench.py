@@ -15,6 +15,11 @@ per-launch event profiling OFF.  The timed region ends with the single collectiv
 finished row shards issued by the library itself (vpt_comm_gather_shards, include/vpt.h) and the row re-interleave on
 rank 0.  torch.distributed is only the launcher / control plane (rendezvous, barrier, max-over-ranks).
 
+Launching: `python bench.py --gpus N` is enough.  Without a launcher environment (no WORLD_SIZE) and N > 1 the script starts
+its own `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1` and relays rank 0's JSON line;
+under torchrun / the driver's launcher it is one rank.  Fewer visible devices than ranks is an error (exit 2) — unless
+VPT_BENCH_DEVICE pins every rank to one device, the 1-GPU-box test hook (the gather then goes through host memory).
+
 After the timed region the same workload runs a few more steps with profiling ON (HIP events the library records
 around every launch on its own stream) and with traversal counters, which feed
 
@@ -25,10 +30,11 @@ around every launch on its own stream) and with traversal counters, which feed
                  measurement (profiles/traffic.json); `algorithmic_GBs` is SURVEY §8d's figure (records + scene
                  gathers + measured BVH visits), which on an LDS/L2-resident scene exceeds what HBM moves and is
                  therefore reported beside the fraction, not as it.
-  workloads    — (N=1 only) the two scenes whose traversal touches memory, BASELINE configs 3 and 5 at their own
-                 resolution and depth ("atrium_1080p_d8", "glass_bust_1080p_d32"): Msamples/s and per-kernel
-                 algorithmic bytes from MEASURED node / triangle visits, with the traversal kernels' fraction of
-                 the 8 TB/s roofline.
+  workloads    — the scenes whose traversal touches memory, BASELINE configs 3, 4 and 5 at their own resolution and
+                 depth ("atrium_1080p_d8", "atrium_4k_d8" = 3840x2160, "glass_bust_1080p_d32" with bloom + tonemap
+                 on the root INSIDE its timed region): Msamples/s and, from rank 0, per-kernel algorithmic bytes from
+                 MEASURED node / triangle visits with the traversal kernels' fraction of the 8 TB/s roofline.  At N > 1
+                 every workload runs sharded over all ranks, once weak (per-rank batch fixed) and once strong (job fixed).
   cpu_baseline — the CPU oracle (oracle/, a port of the reference shaders; the reference has no CPU path) on this
                  box's host cores, on a bounded sample of the headline workload.
 """
@@ -44,14 +50,20 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 GB/s measured copy
 VALU_LANE_OPS_PEAK = 256 * 4 * 16 * 2.4e9   # lane-operations per second: CUs x SIMDs x lanes per cycle x clock
-FRAMES_AT_N1 = 129      # the step of the strong-scaling job: 8 steps x 129 whole 1080p frames = 1032 spp, config 2's 1024-spp job (the weak-scaling
-                        # step is the library's default batch, 226 frames at N=1)
-WIDTH, HEIGHT, BASE_SEED = 1920, 1080, 1
-WORKLOADS = {   # name -> (max depth, scene description)
-    "cornell_1080p_d8": (8, "CornellBox (12 triangles, emissive quad 50), black env"),
-    "atrium_1080p_d8": (8, "procedural Sponza-class atrium, 253,002 triangles, 25 PBR materials, 12 textures, sun-and-sky env 2048x1024"),
-    "glass_bust_1080p_d32": (32, "glass bust 510,992 triangles (transmission 1, roughness 0.05, IOR 1.5) on a plinth, sun-and-sky env 4096x2048"),
+BASE_SEED = 1
+RESIDENT_PATHS = 448 << 20   # what a context keeps in flight by default (vpt_api.hip kResidentPaths): the N = 1 batch is RESIDENT_PATHS / pixels frames
+# name -> width, height, max depth, frames per step of the STRONG-scaling job (the fixed job is steps x this many whole frames), post, scene
+WORKLOADS = {
+    "cornell_1080p_d8": {"w": 1920, "h": 1080, "depth": 8, "strong_frames": 129, "post": False,      # 8 steps x 129 = 1032 spp: config 2's 1024-spp job
+                         "scene": "CornellBox (12 triangles, emissive quad 50), black env"},
+    "atrium_1080p_d8": {"w": 1920, "h": 1080, "depth": 8, "strong_frames": 32, "post": False,        # 8 steps x 32 = 256 spp: config 3's job
+                        "scene": "procedural Sponza-class atrium, 253,002 triangles, 25 PBR materials, 12 textures, sun-and-sky env 2048x1024"},
+    "atrium_4k_d8": {"w": 3840, "h": 2160, "depth": 8, "strong_frames": 32, "post": False,           # config 4's scene and resolution (its 1024 spp = 32 such steps)
+                     "scene": "the same atrium at 3840x2160 (BASELINE config 4: pixel rows sharded over the GPUs, one RCCL gather)"},
+    "glass_bust_1080p_d32": {"w": 1920, "h": 1080, "depth": 32, "strong_frames": 129, "post": True,  # config 5: bloom + tonemap on the root inside the timed region
+                             "scene": "glass bust 510,992 triangles (transmission 1, roughness 0.05, IOR 1.5) on a plinth, sun-and-sky env 4096x2048; bloom + tonemap on the gathered image"},
 }
+EXTRA_WORKLOADS = ("atrium_1080p_d8", "atrium_4k_d8", "glass_bust_1080p_d32")
 
 # Algorithmic bytes per unit for each stage: state words actually read/written per path or
 # ray by the algorithm with this build's struct sizes; BVH node/triangle visits are measured, not assumed.
@@ -77,30 +89,56 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="cornell_1080p_d8", choices=sorted(WORKLOADS), help="headline workload (the default is BASELINE's metric config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra-workloads", action="store_true", help="skip the atrium / glass-bust blocks")
+    ap.add_argument("--no-extra-workloads", action="store_true", help="skip the atrium / atrium 4K / glass-bust blocks")
+    ap.add_argument("--extra-steps", type=int, default=6, help="timed steps of each extra workload")
     ap.add_argument("--frames-in-flight", type=int, default=0, help="frames per step per GPU (0 = backend default, ~448M resident paths)")
     ap.add_argument("--pipeline", type=int, default=0, help="vpt_config.pipeline (0 AUTO)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the oracle sample")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
-                    help="weak (default): every rank renders `steps` batches of its own default size (~256M resident paths), so work grows with N; "
-                         "strong: the FIXED job steps x 129 frames of the whole 1080p image (8 steps = config 2's 1024-spp job) is split over the ranks")
-    ap.add_argument("--no-latency", action="store_true", help="skip the per-frame latency block (vpt_render(1) + vpt_postprocess, the reference's call pattern)")
+                    help="weak (default): every rank renders `steps` batches of its own default size (~448M resident paths), so work grows with N; "
+                         "strong: the FIXED job steps x strong_frames whole frames (Cornell: 8 x 129 = config 2's 1024-spp job) is split over the ranks")
+    ap.add_argument("--no-latency", action="store_true", help="skip the per-frame latency block (the reference's per-frame call pattern)")
     return ap.parse_args()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with no launcher environment: become the launcher.  One rank per GPU under torch.distributed.run on
+    127.0.0.1, the same command line; rank 0's JSON line comes back on this process's stdout.  Refuses (exit 2) when the box shows
+    fewer devices than ranks — a run that silently timed one GPU would be a void measurement."""
+    import socket
+    import subprocess
+    one_device = "VPT_BENCH_DEVICE" in os.environ
+    if not one_device:
+        import torch
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus:
+            sys.stderr.write("bench.py: --gpus %d but %d HIP device(s) visible (VPT_BENCH_DEVICE=<ordinal> is the one-device test hook)\n" % (args.gpus, have))
+            raise SystemExit(2)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))   # torchrun would pin it to 1: the atrium's host-side BVH build and the oracle use threads
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def load_scene(vpt, name):
     if name == "cornell_1080p_d8":
         return vpt.scenes.Scene.load(os.path.join(ROOT, "tests", "golden", "cornell_box.npz"))
-    if name == "atrium_1080p_d8":
+    if name.startswith("atrium"):
         return vpt.scenes.atrium()
     return vpt.scenes.glass_bust()
 
 
-def cpu_baseline(vpt, scene, depth, seconds):
-    """Oracle on the host cores: bounded sample of the same workload (whole 1080p frames)."""
+def cpu_baseline(vpt, name, scene, seconds):
+    """Oracle on the host cores: bounded sample of the same workload (whole frames at the workload's resolution)."""
     from oracle import oracle_py
+    W, H, depth = WORKLOADS[name]["w"], WORKLOADS[name]["h"], WORKLOADS[name]["depth"]
     cores = os.cpu_count() or 1
-    o = oracle_py.Oracle(scene, WIDTH, HEIGHT, threads=cores)
+    o = oracle_py.Oracle(scene, W, H, threads=cores)
     o.set_params(vpt.default_params(max_depth=depth, base_seed=BASE_SEED))
     t0 = time.perf_counter()
     o.render(1)
@@ -111,14 +149,14 @@ def cpu_baseline(vpt, scene, depth, seconds):
     dt = time.perf_counter() - t0
     c = o.counters()
     o.close()
-    return {"value": round(WIDTH * HEIGHT * frames / dt / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
-            "sample": "%d full 1920x1080 frames (1 spp each, depth %d) of the same workload, OpenMP over rows" % (frames, depth),
+    return {"value": round(W * H * frames / dt / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "sample": "%d full %dx%d frames (1 spp each, depth %d) of the same workload, OpenMP over rows" % (frames, W, H, depth),
             "mrays_per_s": round((c["closest"] + c["shadow"]) * frames / (frames + 1) / dt / 1e6, 3)}
 
 
-def traversal_counts(vpt, scene, params, device, rank, world, pipeline, frames):
+def traversal_counts(vpt, name, scene, params, device, rank, world, pipeline, frames):
     """Mean BVH nodes / triangles visited per closest-hit and per shadow ray, from the counting kernel variants."""
-    cnt = vpt.PathTracer(WIDTH, HEIGHT, device=device, shard_rank=rank, shard_count=world, count_traversal=True, pipeline=pipeline,
+    cnt = vpt.PathTracer(WORKLOADS[name]["w"], WORKLOADS[name]["h"], device=device, shard_rank=rank, shard_count=world, count_traversal=True, pipeline=pipeline,
                          frames_in_flight=frames)
     cnt.set_scene(scene); cnt.set_params(params); cnt.render(frames)
     cs = cnt.stats(); cnt.close()
@@ -190,32 +228,92 @@ def load_json(path):
         return {}
 
 
-def profile_workload(vpt, name, scene, device, rank, world, pipeline, frames_in_flight, steps, warmup):
-    """Un-profiled throughput, then profiled per-kernel times, then traversal counts, for one workload on this rank."""
-    depth = WORKLOADS[name][0]
-    params = vpt.default_params(max_depth=depth, base_seed=BASE_SEED, max_samples=0x7fffffff)
-    pt = vpt.PathTracer(WIDTH, HEIGHT, device=device, shard_rank=rank, shard_count=world, pipeline=pipeline, frames_in_flight=frames_in_flight)
+class Ranks:
+    """The launcher's view of this process: rank, world, device and the control-plane helpers every timed region uses."""
+
+    def __init__(self, rank, world, device, one_device, torch, dist):
+        self.rank, self.world, self.device, self.one_device, self.torch, self.dist = rank, world, device, one_device, torch, dist
+
+    def sync(self):   # barrier + device synchronisation: both sides of every timed region
+        if self.world > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def max(self, v):
+        t = self.torch.tensor([v], dtype=self.torch.float64)
+        if self.world > 1:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def sums(self, vals):
+        t = self.torch.tensor([float(v) for v in vals], dtype=self.torch.float64)
+        if self.world > 1:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return [float(x) for x in t.tolist()]
+
+
+def timed_run(vpt, sharding, R, name, scene, pipeline, frames_in_flight, steps, warmup, scaling):
+    """One workload on all ranks: W warm-up steps, then the timed region — barrier + sync, `steps` batches per rank (weak) or the fixed job
+    split over the ranks (strong), the library's one gather of the row shards (N > 1), bloom + tonemap on the root for the workloads
+    that have post, barrier + sync — and the max over ranks of its wall time.  Rows y % N == rank (RayGen.slang:16-25 along one axis)."""
+    wl = WORKLOADS[name]
+    params = vpt.default_params(max_depth=wl["depth"], base_seed=BASE_SEED, max_samples=0x7fffffff)
+    pt = vpt.PathTracer(wl["w"], wl["h"], device=R.device, shard_rank=R.rank, shard_count=R.world, pipeline=pipeline, frames_in_flight=frames_in_flight)
+    t_scene = time.perf_counter()
     pt.set_scene(scene); pt.set_params(params)
+    t_scene = time.perf_counter() - t_scene
     F = pt.stats()["frames_in_flight"]
+    comm = sharding.ShardComm(pt, R.rank, R.world, host_staged=R.one_device) if R.world > 1 else None   # ncclCommInitRank inside libvpt_hip.so; the id travels over gloo
+    batches = [F] * steps
+    if scaling == "strong":   # the job is fixed: each rank renders all of its frames for its rows, in batches of its own frames-in-flight
+        left, batches = steps * wl["strong_frames"], []
+        while left > 0:
+            batches.append(min(F, left)); left -= batches[-1]
     for _ in range(warmup):
-        pt.render(F)
+        pt.render(batches[0])
+    if comm:
+        comm.gather_and_assemble()   # warm the communicator outside the timed region
+    if wl["post"] and R.rank == 0:
+        pt.postprocess()             # post buffers are allocated on first use
     pt.reset_stats()
+    R.sync()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        pt.render(F)          # vpt_render returns with the stream drained
-    dt = time.perf_counter() - t0
-    st = pt.stats(); pt.close()
-    out = {"value": round(st["samples"] / dt / 1e6, 2), "unit": "Msamples/s", "steps": steps, "frames_per_step": F, "ms_per_step": round(dt / steps * 1e3, 3),
-           "mrays_per_s": round((st["closest_rays"] + st["shadow_rays"]) / dt / 1e6, 1), "scene": WORKLOADS[name][1], "max_depth": depth,
-           "rays_per_sample": round((st["closest_rays"] + st["shadow_rays"]) / max(st["samples"], 1), 3)}
-    out.update(kernel_profile(vpt, name, scene, device, rank, world, pipeline, frames_in_flight, max(2, min(steps, 4))))
+    for nb in batches:
+        pt.render(nb)
+    if comm:
+        comm.gather_and_assemble()   # one ncclGather of the row shards to rank 0 + row re-interleave there
+    post_ms = None
+    if wl["post"] and R.rank == 0:   # config 5: PostProcessor::PostProcess on the whole image, on the root
+        tp = time.perf_counter(); pt.postprocess(); post_ms = round((time.perf_counter() - tp) * 1e3, 3)
+    R.sync()
+    dt = R.max(time.perf_counter() - t0)
+    st = pt.stats()
+    samples, closest, shadow = R.sums([st["samples"], st["closest_rays"], st["shadow_rays"]])
+    rccl = None
+    if comm:   # what RCCL itself says about the communicator the gather ran on (vpt_comm_get_info); host-staged: versions only
+        rccl = comm.info()
+        if R.one_device:
+            rccl.update({"nranks": R.world, "rank": R.rank, "transport": "host-staged through the torch process group (VPT_BENCH_DEVICE test hook: RCCL refuses two ranks on one device)"})
+        comm.close()
+    out = {"value": round(samples / dt / 1e6, 3), "unit": "Msamples/s", "scaling": scaling, "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 4),
+           "frames_per_step_per_gpu": F, "paths_in_flight_per_gpu": st["shard_pixels"] * F, "timed_samples_per_pixel": round(samples / (wl["w"] * wl["h"]), 1),
+           "batches_per_gpu": batches if len(set(batches)) > 1 else "%d x %d frames" % (len(batches), batches[0]),
+           "mrays_per_s": round((closest + shadow) / dt / 1e6, 2), "rays_per_sample": round((closest + shadow) / max(samples, 1), 3),
+           "set_scene_s": round(t_scene, 3), "bvh_build_ms": round(st.get("bvh_build_ms", 0.0), 1), "set_scene_ms": round(st.get("set_scene_ms", 0.0), 1),
+           "width": wl["w"], "height": wl["h"], "max_depth": wl["depth"], "scene": wl["scene"]}
+    if post_ms is not None:
+        out["post_ms_in_timed_region"] = post_ms
+    if rccl:
+        out["rccl"] = rccl
+    pt.close()
     return out
 
 
 def kernel_profile(vpt, name, scene, device, rank, world, pipeline, frames_in_flight, steps):
-    depth = WORKLOADS[name][0]
-    params = vpt.default_params(max_depth=depth, base_seed=BASE_SEED, max_samples=0x7fffffff)
-    pp = vpt.PathTracer(WIDTH, HEIGHT, device=device, shard_rank=rank, shard_count=world, pipeline=pipeline, frames_in_flight=frames_in_flight, profile=True)
+    """Profiled pass (HIP events the library records around every launch, on the stream it launches on) + traversal counts, this rank only."""
+    wl = WORKLOADS[name]
+    params = vpt.default_params(max_depth=wl["depth"], base_seed=BASE_SEED, max_samples=0x7fffffff)
+    pp = vpt.PathTracer(wl["w"], wl["h"], device=device, shard_rank=rank, shard_count=world, pipeline=pipeline, frames_in_flight=frames_in_flight, profile=True)
     pp.set_scene(scene); pp.set_params(params)
     F = pp.stats()["frames_in_flight"]
     for _ in range(2):        # warm-up batches (buffers of the chosen pipeline are allocated on first use)
@@ -225,17 +323,21 @@ def kernel_profile(vpt, name, scene, device, rank, world, pipeline, frames_in_fl
         pp.render(F)
     st = pp.stats(); pp.close()
     used = 1 if st["kernel_launches"]["bounce"] > 0 else 2    # the pipeline AUTO settled on: count with the same one
-    tc = traversal_counts(vpt, scene, params, device, rank, world, used if pipeline == 0 else pipeline, min(F, 4))
+    tc = traversal_counts(vpt, name, scene, params, device, rank, world, used if pipeline == 0 else pipeline, min(F, 4))
     kernels = kernel_table(st, tc)
     return {"pipeline": "fused" if used == 1 else ("staged (streams)" if st["kernel_launches"]["join"] > 0 else "staged (round-1 kernels)"), "bvh": {"nodes": st["bvh_nodes"], "triangles": st["bvh_triangles"], "node_bytes": st["bvh_node_bytes"], "tri_bytes": st["bvh_tri_bytes"]},
             "traversal": {k: round(v, 3) for k, v in tc.items() if k.endswith("_ray")}, "kernels": kernels}
 
 
-def frame_latency(vpt, scene, params, device, frames=30):
-    """The reference's per-frame call pattern (Editor::Draw: PathTrace once, PostProcess every frame — Editor.cpp:116,129): one
-    vpt_render(ctx, 1) followed by one vpt_postprocess per frame on a context that keeps a single frame in flight, wall clock per
-    frame incl. both blocking syncs and the RGBA8 read-back."""
-    g = vpt.PathTracer(WIDTH, HEIGHT, device=device, frames_in_flight=1)
+def frame_latency(vpt, name, scene, params, device, frames=30):
+    """The reference's per-frame call pattern (Editor::Draw: PathTrace once, PostProcess every frame — Editor.cpp:116,129) on a context
+    that keeps a single frame in flight.  Two forms: `blocking` = vpt_render(ctx, 1) + vpt_postprocess, host wall clock per frame incl.
+    both blocking syncs and the 8 MB RGBA8 read-back (what round 3 reported as frame_ms); `async` = what the reference actually does —
+    PathTrace(cmd) and PostProcess(cmd) record and return, the output stays on the device (PathTracer.h:94-95) — through
+    vpt_render_async + vpt_postprocess_device with one vpt_wait per frame on the frame BEFORE (two frames in flight on the host side,
+    like a swapchain): steady-state wall clock per frame."""
+    W, H = WORKLOADS[name]["w"], WORKLOADS[name]["h"]
+    g = vpt.PathTracer(W, H, device=device, frames_in_flight=1)
     g.set_scene(scene); g.set_params(params)
     for _ in range(5):
         g.render(1); g.postprocess()
@@ -243,9 +345,29 @@ def frame_latency(vpt, scene, params, device, frames=30):
     for _ in range(frames):
         t0 = time.perf_counter(); g.render(1); t1 = time.perf_counter(); g.postprocess(); t2 = time.perf_counter()
         tr += t1 - t0; tp += t2 - t1
+    out = {"blocking_frame_ms": round((tr + tp) / frames * 1e3, 4), "render_1spp_ms": round(tr / frames * 1e3, 4), "postprocess_ms": round(tp / frames * 1e3, 4),
+           "frames": frames, "what": "per 1-spp frame at %dx%d, 1 frame in flight; blocking: vpt_render(ctx, 1) + vpt_postprocess incl. syncs and the RGBA8 read-back; "
+                                     "frame_ms: vpt_render_async + vpt_postprocess_device (RGBA8 stays on the device), one vpt_wait per frame on the previous frame" % (W, H)}
+    if hasattr(g, "render_async"):
+        n = frames * 4
+        for _ in range(8):
+            g.render_async(1); g.postprocess_device()
+        g.wait()
+        t0 = time.perf_counter()
+        prev = 0
+        for _ in range(n):
+            g.render_async(1)
+            cur = g.postprocess_device()
+            if prev:
+                g.wait(prev)   # returns once the PREVIOUS frame's post has finished: the host runs one frame ahead, like a swapchain
+            prev = cur
+        g.wait()
+        out["frame_ms"] = round((time.perf_counter() - t0) / n * 1e3, 4)
+        out["graph"] = bool(g.stats().get("graph_launches", 0))
+    else:
+        out["frame_ms"] = out["blocking_frame_ms"]
     g.close()
-    return {"frame_ms": round((tr + tp) / frames * 1e3, 4), "render_1spp_ms": round(tr / frames * 1e3, 4), "postprocess_ms": round(tp / frames * 1e3, 4),
-            "frames": frames, "what": "vpt_render(ctx, 1) + vpt_postprocess per frame at 1920x1080, 1 frame in flight, host wall clock incl. syncs and the 8 MB RGBA8 read-back"}
+    return out
 
 
 def roofline_for(name, prof):
@@ -295,11 +417,16 @@ def roofline_for(name, prof):
 
 def main():
     args = parse()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args)   # does not return
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks\n" % (args.gpus, world))
+        raise SystemExit(2)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # this image's driver shares device memory across processes through dmabuf only (RCCL needs it)
     import torch
     import torch.distributed as dist
@@ -310,100 +437,72 @@ def main():
     one_device = "VPT_BENCH_DEVICE" in os.environ
     if one_device:
         local_rank = int(os.environ["VPT_BENCH_DEVICE"])
+    elif torch.cuda.device_count() < world:
+        sys.stderr.write("bench.py: %d ranks but %d HIP device(s) visible\n" % (world, torch.cuda.device_count()))
+        raise SystemExit(2)
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)   # control plane only: the data-path gather is the library's RCCL call
     vpt = importlib.import_module("vulkan-path-tracer_amd")
     sharding = importlib.import_module("vulkan-path-tracer_amd.sharding")
+    R = Ranks(rank, world, local_rank, one_device, torch, dist)
     name = args.workload
-    depth = WORKLOADS[name][0]
+    wl = WORKLOADS[name]
     scene = load_scene(vpt, name)
-    params = vpt.default_params(max_depth=depth, base_seed=BASE_SEED, max_samples=0x7fffffff)
+    params = vpt.default_params(max_depth=wl["depth"], base_seed=BASE_SEED, max_samples=0x7fffffff)
 
-    pt = vpt.PathTracer(WIDTH, HEIGHT, device=local_rank, shard_rank=rank, shard_count=world, pipeline=args.pipeline, frames_in_flight=args.frames_in_flight)
-    pt.set_scene(scene); pt.set_params(params)
-    F = pt.stats()["frames_in_flight"]
-    comm = None
-    if world > 1:
-        comm = sharding.ShardComm(pt, rank, world, host_staged=one_device)   # ncclCommInitRank inside libvpt_hip.so; the id travels over gloo
+    head = timed_run(vpt, sharding, R, name, scene, args.pipeline, args.frames_in_flight, args.steps, args.warmup, args.scaling)
 
-    def sync():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    # strong scaling: the job is fixed (steps x 129 whole frames) and each rank renders all of its frames for its rows, in batches of
-    # its own frames-in-flight; weak (default): steps batches of the rank's own default size
-    batches = [F] * args.steps
-    if args.scaling == "strong":
-        left, batches = args.steps * FRAMES_AT_N1, []
-        while left > 0:
-            batches.append(min(F, left)); left -= batches[-1]
-    for _ in range(args.warmup):
-        pt.render(batches[0])
-    if comm:
-        comm.gather_and_assemble()   # warm the communicator outside the timed region
-    pt.reset_stats()
-    sync()
-    t0 = time.perf_counter()
-    for nb in batches:
-        pt.render(nb)
-    if comm:
-        comm.gather_and_assemble()   # one ncclGather of the row shards to rank 0 + row re-interleave there
-    sync()
-    dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
-    st = pt.stats()
-    tot = torch.tensor([float(st["samples"]), float(st["closest_rays"]), float(st["shadow_rays"])], dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-    samples, closest, shadow = (float(x) for x in tot.tolist())
-    shard_pixels = st["shard_pixels"]
-    comm_info = comm.info() if comm and not one_device else None
-    pt.close()
-
+    line = None
     if rank == 0:
         prof = kernel_profile(vpt, name, scene, local_rank, rank, world, args.pipeline, args.frames_in_flight, 4)
         line = {
-            "metric": "Msamples/s at 1920x1080", "value": round(samples / dt / 1e6, 3), "unit": "Msamples/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "metric": "Msamples/s at %dx%d" % (wl["w"], wl["h"]), "value": head["value"], "unit": "Msamples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": name, "scene": WORKLOADS[name][1],
-                       "width": WIDTH, "height": HEIGHT, "max_depth": depth, "samples_per_frame": 1,
-                       "frames_per_step_per_gpu": F, "paths_in_flight_per_gpu": shard_pixels * F,
-                       "timed_samples_per_pixel": round(samples / (WIDTH * HEIGHT), 1),
-                       "note": "a rate metric: the timed region renders steps x frames_per_step frames (timed_samples_per_pixel; config 2 asks for 1024 spp, which the default 8 steps cover); bit-exact full-size run: profiles/*_config2_full_parity.json",
-                       "batches_per_gpu": batches if len(set(batches)) > 1 else "%d x %d frames" % (len(batches), batches[0]),
+            "config": {"workload": name, "scene": wl["scene"],
+                       "width": wl["w"], "height": wl["h"], "max_depth": wl["depth"], "samples_per_frame": 1,
+                       "frames_per_step_per_gpu": head["frames_per_step_per_gpu"], "paths_in_flight_per_gpu": head["paths_in_flight_per_gpu"],
+                       "timed_samples_per_pixel": head["timed_samples_per_pixel"],
+                       "note": "a rate metric: the timed region renders steps x frames_per_step frames (timed_samples_per_pixel; config 2 asks for 1024 spp, which the default 8 steps cover); bit-exact full-size runs: profiles/*_config*_full_parity.json",
+                       "batches_per_gpu": head["batches_per_gpu"], "post_in_timed_region": wl["post"],
                        "partition": "rows y % N == rank, one ncclGather at the end", "base_seed": BASE_SEED, "pipeline": prof["pipeline"]},
-            "mrays_per_s": round((closest + shadow) / dt / 1e6, 2),
+            "mrays_per_s": head["mrays_per_s"],
+            "set_scene": {"wall_s": head["set_scene_s"], "bvh_build_ms": head["bvh_build_ms"], "set_scene_ms": head["set_scene_ms"]},
             "roofline": roofline_for(name, prof),
         }
-        if comm_info:   # what RCCL itself says about the communicator the gather ran on (vpt_comm_get_info)
-            line["rccl"] = comm_info
-        if world == 1 and not args.no_latency:
-            line["latency"] = frame_latency(vpt, scene, params, local_rank)
-        if world == 1 and not args.no_extra_workloads:
-            extra = {}
-            for other in ("atrium_1080p_d8", "glass_bust_1080p_d32"):
-                if other == name:
-                    continue
-                sc2 = load_scene(vpt, other)
-                w = profile_workload(vpt, other, sc2, local_rank, 0, 1, 0, 0, steps=6, warmup=5)
+        if "post_ms_in_timed_region" in head:
+            line["post_ms_in_timed_region"] = head["post_ms_in_timed_region"]
+        if "rccl" in head:
+            line["rccl"] = head["rccl"]
+        if world == 1 and not args.no_latency and name == "cornell_1080p_d8":
+            line["latency"] = frame_latency(vpt, name, scene, params, local_rank)
+    if not args.no_extra_workloads:   # every rank takes part: the extra workloads run sharded like the headline one
+        extra = {}
+        for other in EXTRA_WORKLOADS:
+            if other == name:
+                continue
+            sc2 = load_scene(vpt, other)
+            modes = ("weak",) if world == 1 else ("weak", "strong")
+            runs = {m: timed_run(vpt, sharding, R, other, sc2, 0, 0, args.extra_steps, 3, m) for m in modes}
+            if rank == 0:
+                w = dict(runs["weak"])
+                if world > 1:
+                    w["strong"] = {k: runs["strong"][k] for k in ("value", "unit", "ms_per_step", "batches_per_gpu", "timed_samples_per_pixel", "mrays_per_s")}
+                w.update(kernel_profile(vpt, other, sc2, local_rank, rank, world, 0, 0, 3))
                 r = roofline_for(other, w)
                 w["roofline"] = {k: r[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_frac_of_hbm_peak", "valu_busy", "avg_launch_ms", "algorithmic_GBs", "algorithmic_frac_of_hbm_peak", "pmc", "valu")}
                 extra[other] = w
+            del sc2
+        if rank == 0:
             line["workloads"] = extra
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(vpt, scene, depth, args.cpu_seconds)
+            line["cpu_baseline"] = cpu_baseline(vpt, name, scene, args.cpu_seconds)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
-        if comm:
-            comm.close()
         dist.destroy_process_group()
 
 

@@ -172,7 +172,11 @@ typedef struct vpt_config {
     uint32_t height;
     uint32_t shard_rank; /* this context renders rows y with y % shard_count == shard_rank */
     uint32_t shard_count;/* 1 = whole image */
-    uint32_t frames_in_flight; /* 0 = choose so that ~448M paths are resident (226 frames at 1080p, ~170 GB), never more than 60 % of the free device memory; at most 2048 frames */
+    uint32_t frames_in_flight; /* largest batch (frames per wavefront batch) the context will hold; 0 = ~448M paths (226 frames at 1080p), never more than 60 % of
+                                * the free device memory, at most 2048 frames.  This is a CAP, not an allocation: vpt_create allocates the path records of ONE
+                                * frame (~0.8 GB at 1080p) and the buffers grow to the largest batch a vpt_render / vpt_render_async call actually asks for
+                                * (min(dispatches, cap) frames, 380 B per path; vpt_stats.frames_allocated) — an interactive host that renders a frame per
+                                * call never holds more than that one frame */
     uint32_t profile;    /* 1 = bracket every kernel launch with hipEvents (vpt_get_stats kernel times) */
     uint32_t count_traversal; /* 1 = count BVH node/triangle visits (slower; for the roofline's algorithmic bytes) */
     uint32_t pipeline;   /* VPT_PIPELINE_* */
@@ -234,6 +238,15 @@ typedef struct vpt_stats {
     uint32_t shard_pixels;
     uint32_t bvh8_nodes;       /* eight-wide nodes of the BVH8 experiment (0 until VPT_TRACE_VOTE8 was used) */
     uint32_t build_flags;      /* VPT_BUILD_* the scene's BVH was built with */
+    uint32_t frames_allocated; /* frames the path-record buffers currently hold (grows with the largest batch requested, <= frames_in_flight) */
+    uint32_t graph_launches;   /* batches replayed from a captured hipGraph by vpt_render_async since vpt_reset_stats */
+    /* Words of the traversal stacks' global SPILL regions written since vpt_set_scene (a lane's stack is 14 LDS entries, deeper entries
+     * spill to a per-thread region; vpt_api.hip keeps one region per concurrently running traversal grid): [0] the context's main
+     * stream, [1] the second stream the shadow kernels of bounce k run on beside the extend of bounce k + 1.  Counted from the regions
+     * themselves (they are preset to a pattern no stack entry can be), so the figure belongs to the product kernels, not to counting variants. */
+    uint64_t stack_spills[2];
+    double set_scene_ms;       /* wall time of the last vpt_set_scene (validation, BVH build, uploads, derived tables) */
+    double bvh_build_ms;       /* of which: the host-side BVH build (bvh_build.cpp; the reference builds BLAS / TLAS on the device, PathTracer.cpp:484-505) */
 } vpt_stats;
 
 typedef struct vpt_ctx vpt_ctx;
@@ -338,6 +351,29 @@ int vpt_reset(vpt_ctx* ctx);
 /* PathTracer::PathTrace x dispatches (PathTracer.cpp:122-156); blocking. *done (if non-NULL) is
  * PathTrace's return value: 1 once samples accumulated >= max_samples (then nothing is launched). */
 int vpt_render(vpt_ctx* ctx, uint32_t dispatches, int* done);
+
+/* ---- the reference's asynchronous per-frame shape --------------------------------------------------------------------
+ * PathTracer::PathTrace(cmd) RECORDS the dispatch and returns (PathTracer.cpp:122-156); Editor::Draw calls it once and then
+ * PostProcessor::PostProcess(cmd) every frame (Editor.cpp:116,129); both outputs stay on the device (PathTracer.h:94-95
+ * GetOutputImage, PostProcessor GetOutputImageView) and the host waits on a fence of an EARLIER frame.  Same here:
+ *   vpt_render_async      enqueues `dispatches` dispatches on the context's stream and returns; bookkeeping (frame count, *done) advances
+ *                         at enqueue time as PathTrace's does.  *ticket (optional) identifies the work enqueued so far.
+ *   vpt_postprocess_device the post chain behind it on the same stream, no synchronisation, RGBA8 left in the context's output image
+ *                         (vpt_output_device) and, if rgba8_device != NULL, copied there device-to-device (an interop / swapchain image).
+ *   vpt_wait(ticket)      blocks until that ticket's work has finished (0: everything enqueued so far).
+ * When every path of a batch provably ends within max_depth * samples_per_frame bounces (no material scatters inside a medium, no
+ * volumes / atmosphere) and that number is <= VPT_ASYNC_MAX_BOUNCES, a batch is a fixed schedule: nothing in it waits for the host, any
+ * number of frames can be in flight, and a 1-frame batch of the fused pipeline is captured once as a hipGraph and replayed
+ * (vpt_stats.graph_launches).  Otherwise the enqueued part is the first VPT_ASYNC_MAX_BOUNCES bounces and the NEXT call on the context
+ * (or vpt_wait) finishes the batch first, exactly as vpt_render would have.  Images are bit-identical to vpt_render's either way.
+ * Every other entry point that reads or changes device state drains outstanding work first. */
+#define VPT_ASYNC_MAX_BOUNCES 16u
+int vpt_render_async(vpt_ctx* ctx, uint32_t dispatches, int* done, uint64_t* ticket);
+int vpt_postprocess_device(vpt_ctx* ctx, const vpt_post_params* params, void* rgba8_device, uint64_t* ticket);
+int vpt_wait(vpt_ctx* ctx, uint64_t ticket);
+/* GetOutputImageView(): device pointer to the RGBA8 UNORM image of the last vpt_postprocess / vpt_postprocess_device (width*height*4 bytes,
+ * owned by the context, valid until vpt_resize / vpt_destroy); NULL before the first post-process. */
+const void* vpt_output_device(vpt_ctx* ctx);
 
 /* GetOutputImage(): the RGBA32F accumulation image (alpha 1). Whole image (shard_count==1, or after
  * vpt_assemble_shards) to a caller-owned host / device buffer of width*height*4 floats. */

@@ -1,0 +1,155 @@
+"""The reference's asynchronous per-frame contract behind the C-ABI (include/vpt.h vpt_render_async / vpt_postprocess_device /
+vpt_wait: PathTracer::PathTrace(cmd) records and returns, PathTracer.cpp:122-156; Editor.cpp:116,129) and the lazily grown path
+buffers: every image must equal the blocking path's — and the oracle's — bit for bit."""
+import copy
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_image(oracle, sc, w, h, params, frames):
+    o = oracle.Oracle(sc, w, h)
+    o.set_params(params)
+    o.render(frames)
+    ref = o.radiance()
+    o.close()
+    return ref
+
+
+def test_async_frames_equal_blocking_frames_and_replay_from_a_graph(vpt, oracle, scenes):
+    """Cornell box, depth 8: a fixed schedule (no medium scatters, 8 <= VPT_ASYNC_MAX_BOUNCES) — frames are enqueued back to back, the
+    third identical call onwards replays a captured hipGraph, and the accumulated image equals vpt_render's and the oracle's."""
+    sc, w, h, frames = scenes("cornell_box"), 160, 90, 12
+    p = vpt.default_params(max_depth=8)
+    ref = oracle_image(oracle, sc, w, h, p, frames)
+    blocking = vpt.PathTracer(w, h, frames_in_flight=1)
+    blocking.set_scene(sc); blocking.set_params(p)
+    for _ in range(frames):
+        blocking.render(1)
+    img_b = blocking.radiance(); out_b = blocking.postprocess(); blocking.close()
+    g = vpt.PathTracer(w, h, frames_in_flight=1)
+    g.set_scene(sc); g.set_params(p)
+    prev = 0
+    for _ in range(frames):
+        done, _t = g.render_async(1)
+        assert not done
+        cur = g.postprocess_device()
+        if prev:
+            g.wait(prev)
+        prev = cur
+    g.wait()
+    st = g.stats()
+    img_a = g.radiance()
+    out_dev = g.output_to_host()
+    assert np.array_equal(img_a, img_b) and np.array_equal(img_a, ref)
+    assert np.array_equal(out_dev, out_b), "vpt_postprocess_device differs from vpt_postprocess"
+    assert st["frames"] == frames and st["samples"] == w * h * frames
+    assert st["graph_launches"] >= frames - 3, "the fused 1-frame batch was not replayed from a graph: %r" % (st["graph_launches"],)
+    assert st["kernel_launches"]["primary"] == frames and st["kernel_launches"]["bounce"] == frames * 7 and st["kernel_launches"]["resolve"] == frames
+    g.close()
+
+
+def test_async_renders_interleaved_with_material_edits(vpt, oracle, scenes):
+    """SetMaterial between asynchronous frames (it drains, patches the tables, resets the accumulation): same images as the blocking path."""
+    sc, w, h = copy.deepcopy(scenes("cornell_box")), 128, 72
+    p = vpt.default_params(max_depth=6)
+
+    def run(use_async):
+        g = vpt.PathTracer(w, h, frames_in_flight=1)
+        g.set_scene(sc); g.set_params(p)
+        imgs = []
+        for edit in range(3):
+            for _ in range(4):
+                if use_async:
+                    g.render_async(1); g.postprocess_device()
+                else:
+                    g.render(1)
+            m = g.get_material(1)
+            m.base_color[:] = (0.2 + 0.3 * edit, 0.9 - 0.2 * edit, 0.3)
+            m.roughness = 0.3 + 0.2 * edit
+            imgs.append(g.radiance())          # drains
+            g.set_material(1, m)               # resets the accumulation
+        for _ in range(3):
+            if use_async:
+                g.render_async(1)
+            else:
+                g.render(1)
+        imgs.append(g.radiance())
+        st = g.stats(); g.close()
+        return imgs, st
+
+    a, sa = run(True)
+    b, sb = run(False)
+    assert len(a) == len(b) == 4
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    assert sa["samples"] == sb["samples"]
+    # the last image against the oracle with the final material
+    sc2 = copy.deepcopy(sc)
+    sc2.materials[1].update(base_color=(0.2 + 0.3 * 2, 0.9 - 0.2 * 2, 0.3), roughness=0.3 + 0.2 * 2)
+    assert np.array_equal(a[-1], oracle_image(oracle, sc2, w, h, p, 3))
+
+
+@pytest.mark.parametrize("name,depth,pipeline", [("cornell_box", 200, 0), ("cornell_box_glass", 12, 0), ("cornell_box_glass", 40, 0), ("cornell_box", 6, 2)])
+def test_async_batches_that_may_outlive_their_enqueued_bounces(vpt, oracle, scenes, name, depth, pipeline):
+    """Deeper than VPT_ASYNC_MAX_BOUNCES, the streams pipeline, round 1's stage kernels: the enqueued part is the first bounces and the
+    next call finishes the batch as vpt_render would have; multi-frame batches included."""
+    sc, w, h = scenes(name), 96, 54
+    p = vpt.default_params(max_depth=depth)
+    g = vpt.PathTracer(w, h, pipeline=pipeline, frames_in_flight=3)
+    g.set_scene(sc); g.set_params(p)
+    g.render_async(3)
+    g.render_async(2)      # finishes the first batch, then enqueues
+    g.postprocess_device() # finishes the second
+    g.render_async(1)
+    img = g.radiance()     # drains
+    st = g.stats(); g.close()
+    assert st["frames"] == 6
+    assert np.array_equal(img, oracle_image(oracle, sc, w, h, p, 6))
+
+
+def test_async_with_a_scattering_medium_inside_glass(vpt, oracle, scenes):
+    """A transmissive material with a dense medium: scattering events inside it do not raise the depth, so the batch is not a fixed
+    schedule whatever max_depth says."""
+    sc = copy.deepcopy(scenes("cornell_box_glass"))
+    for m in sc.materials:
+        if m["transmission"] > 0:
+            m.update(medium_density=6.0, medium_anisotropy=0.3, medium_color=(0.9, 0.6, 0.4))
+    w, h, p = 96, 54, vpt.default_params(max_depth=5)
+    g = vpt.PathTracer(w, h, frames_in_flight=2)
+    g.set_scene(sc); g.set_params(p)
+    for _ in range(3):
+        g.render_async(2)
+    img = g.radiance(); g.close()
+    assert np.array_equal(img, oracle_image(oracle, sc, w, h, p, 6))
+
+
+def test_path_buffers_grow_with_the_batches_asked_for(vpt, scenes):
+    """vpt_create holds the records of ONE frame (the verdict's interactive host: < 2 GB at 1080p with AUTO); the buffers grow to the
+    largest batch requested, never beyond frames_in_flight, and the image does not depend on how they grew."""
+    import torch
+    sc = scenes("cornell_box")
+    free0, _ = torch.cuda.mem_get_info()
+    g = vpt.PathTracer(1920, 1080)            # AUTO: the cap is ~448M paths (226 frames)
+    g.set_scene(sc); g.set_params(vpt.default_params(max_depth=4))
+    st = g.stats()
+    free1, _ = torch.cuda.mem_get_info()
+    assert st["frames_allocated"] == 1 and st["frames_in_flight"] >= 64
+    assert free0 - free1 < 2 * 1024 ** 3, "vpt_create + vpt_set_scene took %.2f GB" % ((free0 - free1) / 2 ** 30)
+    g.render(1)
+    assert g.stats()["frames_allocated"] == 1
+    g.render(5)
+    assert g.stats()["frames_allocated"] == 5
+    g.render(2)
+    assert g.stats()["frames_allocated"] == 5
+    img = g.radiance(); g.close()
+    ref = vpt.PathTracer(1920, 1080, frames_in_flight=8)
+    ref.set_scene(sc); ref.set_params(vpt.default_params(max_depth=4))
+    ref.render(8)
+    assert ref.stats()["frames_allocated"] == 8
+    assert np.array_equal(img, ref.radiance())
+    ref.close()
+    free2, _ = torch.cuda.mem_get_info()
+    assert free0 - free2 < 1024 ** 3, "device memory not returned by vpt_destroy"

@@ -145,6 +145,39 @@ class PathTracer:
         _check(self.lib, self.ctx, self.lib.vpt_render(self.ctx, dispatches, C.byref(done)), "vpt_render")
         return bool(done.value)
 
+    # ---- the asynchronous per-frame form (PathTrace(cmd) / PostProcess(cmd) record and return; include/vpt.h)
+    def render_async(self, dispatches):
+        """vpt_render_async: enqueues and returns (done, ticket)."""
+        done, ticket = C.c_int(0), C.c_uint64(0)
+        _check(self.lib, self.ctx, self.lib.vpt_render_async(self.ctx, dispatches, C.byref(done), C.byref(ticket)), "vpt_render_async")
+        return bool(done.value), int(ticket.value)
+
+    def postprocess_device(self, post_params=None, rgba8_device=None):
+        """vpt_postprocess_device: the post chain behind the render, RGBA8 left on the device (output_device()); returns the ticket."""
+        pp = post_params or default_post_params()
+        ticket = C.c_uint64(0)
+        _check(self.lib, self.ctx, self.lib.vpt_postprocess_device(self.ctx, C.byref(pp), rgba8_device, C.byref(ticket)), "vpt_postprocess_device")
+        return int(ticket.value)
+
+    def wait(self, ticket=0):
+        """vpt_wait.  ticket 0: everything enqueued so far; otherwise the work up to that ticket (a host that runs one frame ahead of the
+        device waits for the PREVIOUS frame's post-process ticket)."""
+        _check(self.lib, self.ctx, self.lib.vpt_wait(self.ctx, ticket), "vpt_wait")
+
+    def output_device(self):
+        """GetOutputImageView(): device pointer of the RGBA8 image (None before the first post-process)."""
+        return self.lib.vpt_output_device(self.ctx)
+
+    def output_to_host(self):
+        """The RGBA8 image the last post-process left on the device, copied out (test helper; needs torch for the copy)."""
+        import torch
+        self.wait()
+        ptr = self.output_device()
+        out = torch.empty((self.height, self.width, 4), dtype=torch.uint8, device="cuda")
+        rc = torch.cuda.cudart().cudaMemcpy(out.data_ptr(), ptr, out.numel(), 3)
+        assert int(rc) == 0
+        return out.cpu().numpy()
+
     def radiance(self):
         out = np.empty((self.height, self.width, 4), np.float32)
         _check(self.lib, self.ctx, self.lib.vpt_get_radiance(self.ctx, out.ctypes.data), "vpt_get_radiance")
@@ -178,7 +211,8 @@ class PathTracer:
     def stats(self):
         s = _abi.Stats()
         _check(self.lib, self.ctx, self.lib.vpt_get_stats(self.ctx, C.byref(s)), "vpt_get_stats")
-        d = {k: getattr(s, k) for k, _ in _abi.Stats._fields_ if k not in ("kernel_launches", "kernel_ms")}
+        d = {k: getattr(s, k) for k, _ in _abi.Stats._fields_ if k not in ("kernel_launches", "kernel_ms", "stack_spills")}
+        d["stack_spills"] = [int(s.stack_spills[0]), int(s.stack_spills[1])]
         d["kernel_launches"] = {n: int(s.kernel_launches[i]) for i, n in enumerate(_abi.KERNEL_NAMES)}
         d["kernel_ms"] = {n: float(s.kernel_ms[i]) for i, n in enumerate(_abi.KERNEL_NAMES)}
         return d

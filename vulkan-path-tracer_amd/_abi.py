@@ -22,6 +22,7 @@ FLAGS_DEFAULT = (FLAG_SKY_MIS | FLAG_MESH_MIS | FLAG_SHOW_ENV_DIRECTLY | FLAG_EN
 KERNEL_NAMES = ["primary", "extend", "shade", "connect", "bounce", "resolve", "bloom", "tonemap", "shadow", "join"]
 KERNEL_COUNT = 10
 PIPELINE_AUTO, PIPELINE_FUSED, PIPELINE_STAGED = 0, 1, 2
+ASYNC_MAX_BOUNCES = 16
 
 
 class Material(C.Structure):
@@ -175,6 +176,8 @@ class Stats(C.Structure):
         ("bvh_nodes", C.c_uint32), ("bvh_triangles", C.c_uint32), ("bvh_node_bytes", C.c_uint32),
         ("bvh_tri_bytes", C.c_uint32), ("emissive_mesh_count", C.c_uint32), ("emissive_triangle_count", C.c_uint32),
         ("frames_in_flight", C.c_uint32), ("shard_pixels", C.c_uint32), ("bvh8_nodes", C.c_uint32), ("build_flags", C.c_uint32),
+        ("frames_allocated", C.c_uint32), ("graph_launches", C.c_uint32), ("stack_spills", C.c_uint64 * 2),
+        ("set_scene_ms", C.c_double), ("bvh_build_ms", C.c_double),
     ]
 
 
@@ -213,6 +216,10 @@ PROTOTYPES = {
     "vpt_resize": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),
     "vpt_reset": (C.c_int, [C.c_void_p]),
     "vpt_render": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_int)]),
+    "vpt_render_async": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_int), C.POINTER(C.c_uint64)]),
+    "vpt_postprocess_device": (C.c_int, [C.c_void_p, C.POINTER(PostParams), C.c_void_p, C.POINTER(C.c_uint64)]),
+    "vpt_wait": (C.c_int, [C.c_void_p, C.c_uint64]),
+    "vpt_output_device": (C.c_void_p, [C.c_void_p]),
     "vpt_get_radiance": (C.c_int, [C.c_void_p, C.c_void_p]),
     "vpt_get_radiance_device": (C.c_int, [C.c_void_p, C.c_void_p]),
     "vpt_set_radiance": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32]),

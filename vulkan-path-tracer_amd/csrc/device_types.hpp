@@ -161,7 +161,9 @@ struct DeviceScene {
     const float* env;  // RGBA32F, alpha = pdf
     const AliasEntry* alias;
     uint32_t env_w, env_h;
-    uint32_t env_black, env_pad;  // 1: every env texel (and so its pdf) is exactly 0 -> lookups return 0 without fetching
+    uint32_t env_black;  // 1: every env texel (and so its pdf) is exactly 0 -> lookups return 0 without fetching
+    uint32_t all_plain;  // always 0 from the host; the fused kernel's PLAIN instantiation sets it (a compile-time fact there): every material's textures
+                         // are 1x1 (MatResolved.flags == 63, every LightSampler uniform), so no texel is ever fetched and the texture code drops out
     const float* lut_r;  // 64x64x32
     const float* lut_o;  // 128x128x32
     const float* lut_i;  // 128x128x32
@@ -194,6 +196,9 @@ struct RenderParams {
     float max_luminance, focus_distance, dof_strength;
     float sky_azimuth, sky_altitude, sky_intensity, emissive_pdf_bias;
     uint32_t flags, base_seed;
+    // Graph replays (vpt_render_async): when non-null, the batch's first dispatch index is read from here instead of the kernels'
+    // dispatch_base / frame_base arguments, so that one captured batch serves every frame
+    const uint32_t* dispatch_base_dev;
     // sincos_ of the four sky-rotation angles the shaders use, evaluated once per vpt_set_params with the shared fp32 contract
     // (vpt_api.hip sync_params): {sin, cos} of azimuth, altitude (ImportanceSampleEnvMap) and of -altitude, -azimuth (Miss)
     float sky_rot[8];
@@ -291,6 +296,11 @@ struct StreamCounters {
     uint32_t class_base[kShadeClasses];     // first entry of the launch's static chunks in every stream it appends to
     uint32_t classify_done;                 // blocks of the classify launch that have finished (the last one lays the streams out)
 };
+
+// Stream appends (vote.hpp WaveAppender): chunk size of the wave-private chunked appends, and the queue length below which a launch
+// appends exactly instead (no holes).  The host sizes the streams' slack for unwritten chunk tails by these (vpt_api.hip alloc_path_buffers).
+constexpr uint32_t kAppendChunk = 256;
+constexpr uint32_t kAppendExactBelow = 1u << 21;
 
 // connect flags (CE.w)
 constexpr uint32_t kCF_Sky = 1u, kCF_Light = 2u, kCF_Finalize = 4u, kCF_Clamp = 8u;

@@ -6,8 +6,8 @@ namespace vpt {
 
 void launch_bounce(hipStream_t s, uint32_t blocks, bool lds_scene, bool count, bool first, const DeviceScene& sc, const RenderParams& P,
                    const PathState& ps, const StreamState& ss, const uint32_t* queue, uint32_t* queue_next, Counters* ctr, uint32_t parity, uint32_t n_slots,
-                   uint32_t dispatch_base, uint32_t k3);
-int bounce_blocks_per_cu(bool lds_scene, const DeviceScene& sc);
+                   uint32_t dispatch_base, uint32_t k3, bool plain = false);
+int bounce_blocks_per_cu(bool lds_scene, const DeviceScene& sc, bool plain = false);
 void launch_raygen(hipStream_t s, const RenderParams& P, const PathState& ps, uint32_t* queue, Counters* ctr, uint32_t n_slots, uint32_t dispatch_base);
 void launch_prepare(hipStream_t s, Counters* ctr, uint32_t parity);
 void launch_fold(hipStream_t s, Counters* ctr);

@@ -249,11 +249,16 @@ __global__ __launch_bounds__(256, 3) void k_shade(DeviceScene sc, RenderParams P
 // The same kernel with FIRST = false runs every later bounce of scenes whose BVH rides in LDS (traversal is
 // then a handful of LDS reads, so a separate extend/connect stage would only move records through HBM):
 // it reads a queued path's records A, B, T, L, does the whole bounce, and writes them back for survivors.
-template <bool LDS_SCENE, bool COUNT, bool FIRST, bool VOL, bool STRICT>
+// PLAIN: the scene class set this instantiation serves — every material's textures are 1x1 and the environment is black (the Cornell
+// box; chosen by vpt_set_scene / vpt_set_material, vpt_api.hip scene_is_plain).  The general kernel skips the texture taps and the
+// environment sampler through uniform branches; here they are not compiled in at all (a quarter of the general kernel's instructions).
+template <bool LDS_SCENE, bool COUNT, bool FIRST, bool VOL, bool STRICT, bool PLAIN = false>
 __global__ __launch_bounds__(kTraverseBlock, 3) void k_bounce(DeviceScene sc, RenderParams P, PathState ps, StreamState ss, const uint32_t* queue,
                                                              uint32_t* queue_next, Counters* ctr, uint32_t parity, uint32_t n_slots,
                                                              uint32_t dispatch_base, uint32_t k3) {
     sc.strict_hits = STRICT ? 1u : 0u;  // compile-time constant from here on (VPT_FLAG_LOCAL_HITS picks the instantiation)
+    if (PLAIN) { sc.all_plain = 1u; sc.env_black = 1u; } else sc.all_plain = 0u;   // likewise
+    if (FIRST && P.dispatch_base_dev) dispatch_base = *P.dispatch_base_dev;   // a replayed graph: the batch's first dispatch index lives in device memory
     extern __shared__ __align__(16) unsigned char smem[];
     const TravStack stack = make_stack(smem, sc.stack_overflow);
     float4* lds_nodes = reinterpret_cast<float4*>(smem + kStackDepth * kTraverseBlock * 4);
@@ -625,6 +630,7 @@ __global__ __launch_bounds__(kTraverseBlock, 8) void k_connect(DeviceScene sc, R
 // launch does nothing and is repeated after more bounces.
 __global__ __launch_bounds__(256) void k_resolve(RenderParams P, PathState ps, float4* image, uint32_t frames, uint32_t frame_base, const uint32_t* guard) {
     if (guard && *guard != 0u) return;
+    if (P.dispatch_base_dev) frame_base = *P.dispatch_base_dev;   // a replayed graph (see k_bounce)
     uint32_t sp = blockIdx.x * blockDim.x + threadIdx.x;
     if (sp >= P.shard_pixels) return;
     float4 px = image[sp];
@@ -789,9 +795,14 @@ static inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 // first == true: bounce 0 of n_slots fresh slots (queue unused); otherwise one fused bounce of queue[parity].
 void launch_bounce(hipStream_t s, uint32_t blocks, bool lds_scene, bool count, bool first, const DeviceScene& sc, const RenderParams& P,
                    const PathState& ps, const StreamState& ss, const uint32_t* queue, uint32_t* queue_next, Counters* ctr, uint32_t parity, uint32_t n_slots,
-                   uint32_t dispatch_base, uint32_t k3) {
+                   uint32_t dispatch_base, uint32_t k3, bool plain) {
     size_t lds = traverse_lds_bytes(sc, lds_scene);
     dim3 g(blocks), b(kTraverseBlock);
+    if (plain && lds_scene && !count && !sc.strict_hits && sc.volume_count == 0u && !sc.atm_on && sc.env_black) {   // the scene-class instantiation
+        if (first) hipLaunchKernelGGL((k_bounce<true, false, true, false, false, true>), g, b, lds, s, sc, P, ps, ss, queue, queue_next, ctr, parity, n_slots, dispatch_base, k3);
+        else hipLaunchKernelGGL((k_bounce<true, false, false, false, false, true>), g, b, lds, s, sc, P, ps, ss, queue, queue_next, ctr, parity, n_slots, dispatch_base, k3);
+        return;
+    }
 #define VPT_LAUNCH_BOUNCE_V(L, C, F, V) do { if (sc.strict_hits) hipLaunchKernelGGL((k_bounce<L, C, F, V, true>), g, b, lds, s, sc, P, ps, ss, queue, queue_next, ctr, parity, n_slots, dispatch_base, k3); \
         else hipLaunchKernelGGL((k_bounce<L, C, F, V, false>), g, b, lds, s, sc, P, ps, ss, queue, queue_next, ctr, parity, n_slots, dispatch_base, k3); } while (0)
 #define VPT_LAUNCH_BOUNCE(L, C, F) VPT_LAUNCH_BOUNCE_V(L, C, F, false)
@@ -808,9 +819,16 @@ void launch_bounce(hipStream_t s, uint32_t blocks, bool lds_scene, bool count, b
 #undef VPT_LAUNCH_BOUNCE
 #undef VPT_LAUNCH_BOUNCE_V
 }
-int bounce_blocks_per_cu(bool lds_scene, const DeviceScene& sc) {
+int bounce_blocks_per_cu(bool lds_scene, const DeviceScene& sc, bool plain) {
     int nb = 0;
     size_t lds = traverse_lds_bytes(sc, lds_scene);
+    if (lds_scene && plain) {   // the smaller of the two instantiations a batch launches
+        int a = 0, b = 0;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_bounce<true, false, true, false, false, true>, kTraverseBlock, lds);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_bounce<true, false, false, false, false, true>, kTraverseBlock, lds);
+        nb = a < b ? a : b;
+        return nb > 0 ? nb : 1;
+    }
     if (lds_scene) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_bounce<true, false, false, false, false>, kTraverseBlock, lds);
     else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_bounce<false, false, false, false, false>, kTraverseBlock, lds);
     return nb > 0 ? nb : 1;

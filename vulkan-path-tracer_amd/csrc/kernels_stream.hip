@@ -310,6 +310,7 @@ __global__ __launch_bounds__(256) void k_join(RenderParams P, PathState ps, Stre
 __global__ __launch_bounds__(256) void k_raygen_stream(RenderParams P, PathState ps, StreamState ss, uint32_t* queue, uint32_t n_slots, uint32_t dispatch_base, uint32_t media) {
     const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
     if (li >= n_slots) return;
+    if (P.dispatch_base_dev) dispatch_base = *P.dispatch_base_dev;   // a replayed graph (kernels_path.hip k_bounce)
     uint32_t slot, x, y, f;
     launch_pixel(P, li, dispatch_base, slot, x, y, f);
     const uint32_t seed = pcg_hash(P.base_seed + dispatch_base + f);  // PathTracer.cpp:139 with an explicit seed

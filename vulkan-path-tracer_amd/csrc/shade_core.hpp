@@ -202,7 +202,7 @@ __device__ __forceinline__ void shade_core(const DeviceScene& sc, const RenderPa
         const InstanceDesc& in = sc.instances[inst_id];
         const vpt_material& mat = sc.materials[in.material];
         MatResolved mr = sc.mat_resolved[in.material];
-        if (CLS == (int)kShadePlain) mr.flags = 63u;                // what the class promises, as a compile-time fact: no texel fetch is compiled in
+        if (CLS == (int)kShadePlain || sc.all_plain) mr.flags = 63u;   // what the class (or the scene: k_bounce<PLAIN>) promises, as a compile-time fact: no texel fetch is compiled in
         const bool geo_only = (P.flags & VPT_FLAG_GEOMETRY_NORMALS) != 0;
         SurfaceFrame s;
         surface_geom(sc, s, in, __float_as_uint(h.w), h.y, h.z, rd, geo_only);

@@ -495,7 +495,7 @@ __device__ inline void sample_emissive(const DeviceScene& sc, Rng& r, V3 pos, V3
     float d2 = dot(tp - pos, tp - pos);
     float ct = fabs_(dot(nrm, to_light));
     cpdf.w = d2 / ((float)n * (float)tc * area * ct);
-    if (ls.uniform) {
+    if (sc.all_plain || ls.uniform) {
         cpdf.x = ls.radiance[0]; cpdf.y = ls.radiance[1]; cpdf.z = ls.radiance[2];
     } else {
         TexTaps k;

@@ -220,11 +220,10 @@ __device__ __forceinline__ bool vote_tri_step_any(const BvhTri* tris, const Lane
 // The only unwritten entries of a stream are therefore the tail of each participating wave's LAST chunk, which the wave marks
 // as holes when it is done (consumers skip them).  The stream counter, preset to waves x kAppendChunk, holds the stream's
 // LENGTH (holes included); every write lands in a 256-entry run owned by one wave.
-constexpr uint32_t kAppendChunk = 256;
+// (kAppendChunk = 256 and kAppendExactBelow = 1 << 21 live in device_types.hpp: the host sizes the streams' slack by them)
 // Short streams are appended to EXACTLY instead (one atomic per wave per append, no holes at all): with fewer than
 // kAppendExactBelow entries to process a launch issues at most ~30 k such atomics per stream, while chunk tails of several
 // thousand waves would outnumber the entries themselves.
-constexpr uint32_t kAppendExactBelow = 1u << 21;
 struct WaveAppender {
     uint32_t base, used;  // wave-uniform
     uint32_t dyn_base;    // where the counter's reservations start in the stream (0 when the counter was preset to the static part)

@@ -22,6 +22,22 @@ constexpr uint64_t kBytesPerPath = 380;          // core slot records 68 + strea
 constexpr uint32_t kMaxFramesInFlight = 2048;   // frames of one batch (a 1/8 shard of 1080p holds ~448M paths at 1728 frames)
 constexpr uint64_t kResidentPaths = 448ull << 20;   // what a context keeps in flight by default (see check_render_size)
 
+// One wavefront batch in progress: what render_batch's stages hand to each other (and what an asynchronous batch leaves behind for
+// the call that finishes it).
+struct BatchState {
+    uint32_t frames = 0, dispatch_base = 0, n_slots = 0;
+    bool fused = false, stream = false, media_stream = false, sorted = false, overlap = false, count = false;
+    uint32_t parity = 0, k3 = 0;
+    bool join_pending = false;
+    uint64_t iter = 0, iter_cap = 0, min_bounces = 0;
+};
+// Counter words a finished batch copies to pinned host memory (asynchronously, behind its resolve).
+struct HostCounters {
+    Counters ctr;
+    uint32_t alive[2], queue_len[2];
+};
+constexpr int kTickets = 16;
+
 struct vpt_ctx {
     vpt_config cfg{};
     hipStream_t stream = nullptr;
@@ -61,14 +77,36 @@ struct vpt_ctx {
     unsigned char* d_inst_class = nullptr;   // shade class per instance (kernels_path.hip k_classify_instances)
     std::vector<BvhTri> bvh_input;           // the triangles the BVH was built from (trace lab: the eight-wide tree is built from them on first use)
     bool lds_scene = false;
+    bool scene_plain = false;    // every material's five textures are 1x1 and the environment is black: the fused kernel's PLAIN instantiation serves it
+    std::vector<unsigned char> tex_1x1;   // per texture of the scene
     bool sbvh = false;
     uint32_t* stack_overflow2 = nullptr;   // spill region of the traversal kernels launched on stream2
     int trav_blocks = 1024;
 
     vpt_params params{};
     RenderParams P{};
-    uint32_t frames_in_flight = 1;
-    uint32_t frames_cap = 0;     // alloc_render_buffers: upper bound of the next attempt after an out-of-memory failure
+    uint32_t frames_in_flight = 1;   // largest batch the context will render at once (the cap; vpt_config.frames_in_flight)
+    uint32_t frames_cap = 0;     // upper bound of frames_in_flight after an out-of-memory failure of a size the library chose itself
+    uint32_t frames_alloc = 0;   // frames the path-record buffers hold now: they grow to the largest batch actually requested (ensure_path_buffers)
+    bool depth_bounded = true;   // every path ends within max_depth * samples_per_frame bounces (no material scatters inside a medium): see vpt_render_async
+    // asynchronous batches (vpt_render_async / vpt_postprocess_device / vpt_wait)
+    hipEvent_t tick_ev[kTickets] = {};
+    uint64_t tick_issued = 0;
+    HostCounters* h_ctr = nullptr;   // pinned
+    bool async_dirty = false;        // work has been enqueued without a host synchronisation behind it
+    bool out_active = false;         // an enqueued batch whose paths may outlive the bounces enqueued so far: the next call finishes it
+    BatchState out_batch;
+    uint64_t out_ticket = 0;
+    uint32_t* d_dispatch_base = nullptr;   // graph replays read the batch's first dispatch index from here (RenderParams::dispatch_base_dev)
+    hipGraphExec_t graph = nullptr;
+    uint64_t graph_gen = 0, state_gen = 1;   // state_gen: bumped by everything a captured batch bakes in (scene tables' addresses, params, camera, buffers)
+    uint32_t graph_frames = 0, graph_bounces = 0, graph_streak = 0;
+    uint64_t graph_streak_gen = 0;
+    uint64_t graph_kernel_launches[VPT_KERNEL_COUNT] = {};
+    bool graph_broken = false;       // a capture failed once on this context: stay on plain launches
+    uint32_t stack_overflow_words = 0;   // words per spill region
+    unsigned long long* d_spill_count = nullptr;
+    double set_scene_ms = 0.0, bvh_build_ms = 0.0;
 
     void* ps_block = nullptr;    // slot-addressed records every pipeline uses (L, ACC, M + the dword arrays)
     void* ps_legacy = nullptr;   // round 1's stage kernels only (A, B, T, H, C*, hinst): allocated on their first use
@@ -93,6 +131,7 @@ struct vpt_ctx {
     uint32_t phase = VPT_PHASE_HENYEY_GREENSTEIN;
     uint32_t* d_launch_off = nullptr;  // split-screen: launch-grid prefix sums of the dispatches of a batch
     int shade_blocks = 1024, primary_blocks = 768, max_blocks = 1536, join_blocks = 2048;
+    int primary_blocks_general = 768, primary_blocks_plain = 768;   // grids of the fused kernel's two instantiations (primary_blocks = the one scene_plain picks)
     int vote_blocks = 2048;   // persistent grid of the vote-scheduled traversal kernels
     uint32_t vote_param = 256u + 16u;  // weighted vote, fetch step at 16 idle lanes (profiles/r02_trace_lab_*.json)
     Counters* ctr = nullptr;
@@ -155,7 +194,8 @@ void free_lab(vpt_ctx* c) {
     for (void* p : {(void*)c->lab_ro, (void*)c->lab_rd, (void*)c->lab_hit, (void*)c->lab_hinst, (void*)c->lab_order}) if (p) (void)hipFree(p);
     c->lab_ro = c->lab_rd = c->lab_hit = nullptr; c->lab_hinst = c->lab_order = nullptr; c->lab_n = 0;
 }
-void free_render_buffers(vpt_ctx* c) {
+// Everything sized by (frames held) x (shard pixels): path records, queues, streams.
+void free_path_buffers(vpt_ctx* c) {
     if (c->ps_block) (void)hipFree(c->ps_block);
     c->ps_block = nullptr;
     if (c->ps_legacy) (void)hipFree(c->ps_legacy);
@@ -170,6 +210,12 @@ void free_render_buffers(vpt_ctx* c) {
     for (uint32_t k = 0; k < kShadeClasses; k++) { if (c->class_queue[k]) (void)hipFree(c->class_queue[k]); c->class_queue[k] = nullptr; }
     if (c->cls_q) (void)hipFree(c->cls_q);
     c->cls_q = nullptr;
+    c->ps = PathState{}; c->ss = StreamState{};
+    c->frames_alloc = 0;
+    c->state_gen++;   // a captured batch holds these addresses
+}
+void free_render_buffers(vpt_ctx* c) {
+    free_path_buffers(c);
     if (c->image) (void)hipFree(c->image);
     c->image = nullptr;
     if (c->full_image) (void)hipFree(c->full_image);
@@ -184,7 +230,7 @@ void free_render_buffers(vpt_ctx* c) {
 
 uint32_t shard_rows_of(uint32_t height, uint32_t rank, uint32_t count) { return rank < height ? (height - rank + count - 1) / count : 0; }
 
-// Size checks of a (width, height) before anything is freed or changed.
+// Size checks of a (width, height) before anything is freed or changed; *frames_out = the largest batch this context will render.
 int check_render_size(vpt_ctx* c, uint32_t width, uint32_t height, uint32_t* frames_out) {
     const uint64_t rows = shard_rows_of(height, c->cfg.shard_rank, c->cfg.shard_count);
     const uint64_t px = rows * width;
@@ -195,6 +241,7 @@ int check_render_size(vpt_ctx* c, uint32_t width, uint32_t height, uint32_t* fra
     // than 60 % of the memory that is free right now): the last bounces of a batch are short launches that cannot fill 256 CUs, and
     // a larger batch makes them longer for the same fixed cost.  Msamples/s from 32M to 128M paths: Cornell +8 %, atrium +16 %, glass
     // bust (depth 32) +78 %; 128M to 256M: +0 / +2 / +18 %; 256M to 512M: +0 / +2.4 / +9.1 % (profiles/r03_frames_sweep.json).
+    // This is the CAP of a batch; the buffers hold what has actually been asked for (ensure_path_buffers).
     if (F == 0) {
         uint64_t paths = kResidentPaths;
         size_t free_b = 0, total_b = 0;
@@ -202,49 +249,17 @@ int check_render_size(vpt_ctx* c, uint32_t width, uint32_t height, uint32_t* fra
         F = paths / px;
     }
     F = std::max<uint64_t>(1, std::min<uint64_t>(F, kMaxFramesInFlight));
-    if (c->frames_cap) F = std::min<uint64_t>(F, c->frames_cap);   // a retry after an allocation failure (alloc_render_buffers)
     if (px * F >= (1ull << 31)) return fail(c, VPT_ERR_INVALID_ARGUMENT, "too many paths in flight");
     *frames_out = (uint32_t)F;
     return VPT_OK;
 }
 
-int alloc_render_buffers_impl(vpt_ctx* c);
-// (Re)allocates everything that depends on the image size.  On failure the context keeps NO render buffers and says so
-// (buffers_ok == false): vpt_render / vpt_get_* / vpt_postprocess then return an error instead of touching freed memory.
-int alloc_render_buffers(vpt_ctx* c) {
-    c->buffers_ok = false;
-    c->frames_cap = 0;
-    int rc = VPT_OK;
-    for (int attempt = 0; attempt < 8; attempt++) {
-        rc = alloc_render_buffers_impl(c);
-        if (rc == VPT_OK) break;
-        std::string keep = c->err;
-        const uint32_t tried = c->frames_in_flight;
-        free_render_buffers(c);
-        c->err = keep;
-        // a batch size the library chose itself (frames_in_flight == 0) is halved and tried again when the device runs out of
-        // memory after all (another process, fragmentation); an explicit request fails as it is
-        if (rc != VPT_ERR_DEVICE || c->cfg.frames_in_flight != 0 || tried <= 1) break;
-        (void)hipGetLastError();
-        c->frames_cap = tried / 2;
-    }
-    if (rc != VPT_OK) return rc;
-    c->buffers_ok = true;
-    return VPT_OK;
-}
-
-int alloc_render_buffers_impl(vpt_ctx* c) {
-    uint32_t F = 1;
-    int rcs = check_render_size(c, c->cfg.width, c->cfg.height, &F);
-    if (rcs != VPT_OK) return rcs;
-    free_render_buffers(c);
-    RenderParams& P = c->P;
-    P.width = c->cfg.width; P.height = c->cfg.height;
-    P.shard_rank = c->cfg.shard_rank; P.shard_count = c->cfg.shard_count;
-    P.shard_rows = shard_rows_of(P.height, P.shard_rank, P.shard_count);
-    P.shard_pixels = P.shard_rows * P.width;
-    c->frames_in_flight = F;
-    uint32_t cap = P.shard_pixels * F;
+// Path records, queues and streams for `frames` frames of this shard (the caller has drained the streams).
+int alloc_path_buffers(vpt_ctx* c, uint32_t frames) {
+    free_path_buffers(c);
+    const RenderParams& P = c->P;
+    if ((uint64_t)P.shard_pixels * frames >= (1ull << 31)) return fail(c, VPT_ERR_INVALID_ARGUMENT, "too many paths in flight");
+    uint32_t cap = P.shard_pixels * frames;
     // slot-addressed records every pipeline uses: 3 float4 records + 4 dword arrays per slot (device_types.hpp PathState); the
     // records of round 1's stage kernels come with ensure_legacy_buffers()
     const size_t kRecords = 3, kWords = 4;
@@ -258,8 +273,10 @@ int alloc_render_buffers_impl(vpt_ctx* c) {
     uint32_t* wb = (uint32_t*)(rb + stride * kRecords);
     s.maniso = (float*)wb; s.sidx = wb + stride; s.vdepth = wb + stride * 2; s.cchan = (int32_t*)(wb + stride * 3);
     // streams written by chunked appends hold up to one unwritten chunk tail per wave that appended to them: at most
-    // 256 entries per 64 items processed, and never more than one per resident wave of the largest persistent grid
-    c->stream_slack = (uint32_t)std::min<uint64_t>((uint64_t)cap * 4 + 256, (uint64_t)8192 * 4 * 256);
+    // 256 entries per 64 items processed, and never more than one per resident wave of the largest persistent grid.  A launch
+    // appends in chunks only when its queue holds >= kAppendExactBelow entries (holes included); below that every append is exact
+    // and no stream ever holds a hole, so buffers that cannot reach that length need no slack (one frame at 1080p: 2,073,600 paths).
+    c->stream_slack = cap < kAppendExactBelow ? 256u : (uint32_t)std::min<uint64_t>((uint64_t)cap * 4 + 256, (uint64_t)8192 * 4 * 256);
     const size_t scap = (size_t)cap + c->stream_slack;
     for (int i = 0; i < 2; i++) HIPCHK(c, hipMalloc((void**)&c->queue[i], scap * 4));
     {
@@ -274,16 +291,87 @@ int alloc_render_buffers_impl(vpt_ctx* c) {
         t.vis_sky = (unsigned char*)(t.SHI + sst); t.vis_light = t.vis_sky + sst;
         t.cap = (uint32_t)scap;
     }
-    // padded to the largest shard's row count (vpt_shard_floats): the buffer is handed to ncclGather as it is
-    const size_t image_bytes = (size_t)shard_rows_of(P.height, 0, P.shard_count) * P.width * 16;
-    HIPCHK(c, hipMalloc((void**)&c->image, image_bytes));
-    HIPCHK(c, hipMemset(c->image, 0, image_bytes));
-    if (P.shard_count > 1) {
-        HIPCHK(c, hipMalloc((void**)&c->full_image, (size_t)P.width * P.height * 16));
-        HIPCHK(c, hipMemset(c->full_image, 0, (size_t)P.width * P.height * 16));
+    c->frames_alloc = frames;
+    return VPT_OK;
+}
+
+// Every wave of a launch that appends to a stream may leave one unwritten chunk tail in it (vote.hpp WaveAppender): the streams are
+// allocated with room for stream_slack such entries.  Refuse — not after a kernel has written past a stream — if a device with more
+// CUs / other occupancy than the allocation assumed ever needs more.  Called wherever the grids (vpt_set_scene) or the buffers change.
+int check_stream_slack(vpt_ctx* c) {
+    if (!c->has_scene || c->frames_alloc == 0 || c->ps.capacity < kAppendExactBelow) return VPT_OK;   // short streams are appended to exactly: no tails
+    const uint64_t appending_waves = 4ull * (uint64_t)std::max(std::max(c->shade_stream_blocks, c->primary_blocks), std::max(c->shade_media_blocks, c->media_tail_blocks));
+    if (appending_waves * kAppendChunk > (uint64_t)c->stream_slack && (uint64_t)c->ps.capacity * 4 + 256 > (uint64_t)c->stream_slack)
+        return fail(c, VPT_ERR_DEVICE, "internal: the stream slack allocated for chunk tails is smaller than one chunk per appending wave of this device");
+    return VPT_OK;
+}
+
+// (Re)allocates everything that depends on the image size: the accumulation image(s) and the path buffers of ONE frame.  On failure
+// the context keeps NO render buffers and says so (buffers_ok == false): vpt_render / vpt_get_* / vpt_postprocess then return an error
+// instead of touching freed memory.
+int alloc_render_buffers(vpt_ctx* c) {
+    c->buffers_ok = false;
+    c->frames_cap = 0;
+    uint32_t F = 1;
+    int rc = check_render_size(c, c->cfg.width, c->cfg.height, &F);
+    if (rc != VPT_OK) return rc;
+    free_render_buffers(c);
+    RenderParams& P = c->P;
+    P.width = c->cfg.width; P.height = c->cfg.height;
+    P.shard_rank = c->cfg.shard_rank; P.shard_count = c->cfg.shard_count;
+    P.shard_rows = shard_rows_of(P.height, P.shard_rank, P.shard_count);
+    P.shard_pixels = P.shard_rows * P.width;
+    c->frames_in_flight = F;
+    auto images = [&]() -> int {
+        // padded to the largest shard's row count (vpt_shard_floats): the buffer is handed to ncclGather as it is
+        const size_t image_bytes = (size_t)shard_rows_of(P.height, 0, P.shard_count) * P.width * 16;
+        HIPCHK(c, hipMalloc((void**)&c->image, image_bytes));
+        HIPCHK(c, hipMemset(c->image, 0, image_bytes));
+        if (P.shard_count > 1) {
+            HIPCHK(c, hipMalloc((void**)&c->full_image, (size_t)P.width * P.height * 16));
+            HIPCHK(c, hipMemset(c->full_image, 0, (size_t)P.width * P.height * 16));
+        }
+        return VPT_OK;
+    };
+    rc = images();
+    if (rc == VPT_OK) rc = alloc_path_buffers(c, 1);
+    if (rc != VPT_OK) {
+        std::string keep = c->err;
+        free_render_buffers(c);
+        (void)hipGetLastError();
+        c->err = keep;
+        return rc;
     }
     c->full_valid = false;
-    return VPT_OK;
+    c->buffers_ok = true;
+    return check_stream_slack(c);
+}
+
+// Grows the path buffers so that a batch of `want` frames (<= frames_in_flight) fits; the caller has drained the streams.  A size the
+// library chose itself (vpt_config.frames_in_flight == 0) is halved and tried again when the device runs out of memory after all
+// (another process, fragmentation) — frames_in_flight then drops to what was obtained and the caller renders in smaller batches;
+// an explicit size fails as it is and the context keeps the buffers it had.
+int ensure_path_buffers(vpt_ctx* c, uint32_t want) {
+    if (want <= c->frames_alloc) return VPT_OK;
+    const uint32_t old = std::max(c->frames_alloc, 1u);
+    uint32_t tryf = want;
+    while (true) {
+        int rc = alloc_path_buffers(c, tryf);
+        if (rc == VPT_OK) break;
+        std::string keep = c->err;
+        free_path_buffers(c);
+        (void)hipGetLastError();
+        const bool oom = rc == VPT_ERR_OUT_OF_MEMORY || rc == VPT_ERR_DEVICE;
+        if (!oom || c->cfg.frames_in_flight != 0 || tryf <= old) {
+            if (alloc_path_buffers(c, old) != VPT_OK) { free_path_buffers(c); (void)hipGetLastError(); c->buffers_ok = false; }
+            c->err = keep;
+            return rc;
+        }
+        tryf = std::max(tryf / 2, old);
+        c->frames_cap = tryf;
+        c->frames_in_flight = std::min(c->frames_in_flight, tryf);
+    }
+    return check_stream_slack(c);
 }
 
 // Round 1's stage kernels (VPT_PIPELINE_STAGED_R1, VPT_FLAG_LOCAL_HITS, an LDS-sized scene forced into the staged pipeline)
@@ -297,7 +385,7 @@ int alloc_render_buffers_impl(vpt_ctx* c) {
 int ensure_media_buffers(vpt_ctx* c) {
     if (c->media_block) return VPT_OK;
     const uint64_t px = c->P.shard_pixels;
-    uint64_t frames = c->frames_in_flight;
+    uint64_t frames = c->frames_alloc;   // what the path buffers hold now (free_path_buffers drops this block with them)
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
         const uint64_t fit = (uint64_t)(free_b * 0.85) / (16ull * 11ull);
@@ -428,6 +516,34 @@ void build_env_tables(const float* rgba, uint32_t w, uint32_t h, std::vector<flo
     }
 }
 
+// Does every path end within max_depth * samples_per_frame bounces?  A bounce either raises payload.Depth or ends the path — except a
+// scattering event INSIDE a medium (ClosestHit.slang:80-116: depth unchanged), which needs a transmissive material whose medium has a
+// density and an anisotropy other than 1 (shade_core.hpp); media (volumes / atmosphere) raise the depth per event but their batches
+// run stages with host-visible fallbacks, so they count as unbounded too.
+void update_depth_bounded(vpt_ctx* c) {
+    bool bounded = true;
+    for (const vpt_material& m : c->materials)
+        if (m.transmission > 0.0f && m.medium_density != 0.0f && m.medium_anisotropy != 1.0f) bounded = false;
+    c->depth_bounded = bounded;
+    // the scene class the fused kernel is specialised for (kernels_path.hip k_bounce<PLAIN>): what k_precompute_materials turns into
+    // MatResolved.flags == 63 for every material, and k_precompute_lights into uniform light samplers
+    bool plain = c->dsc.env_black != 0u;
+    auto one = [&](uint32_t t) { return t < c->tex_1x1.size() && c->tex_1x1[t] != 0; };
+    for (const vpt_material& m : c->materials)
+        if (!(one(m.base_color_texture) && one(m.normal_texture) && one(m.roughness_texture) && one(m.metallic_texture) && one(m.emissive_texture))) plain = false;
+    c->scene_plain = plain;
+    c->primary_blocks = (plain && c->lds_scene) ? c->primary_blocks_plain : c->primary_blocks_general;
+}
+
+constexpr int kSpillPatternByte = 0x7f;
+constexpr uint32_t kSpillPattern = 0x7f7f7f7fu;
+__global__ __launch_bounds__(256) void k_count_spilled(const uint32_t* p, uint32_t n, unsigned long long* out) {
+    unsigned long long cnt = 0ull;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) cnt += p[i] != kSpillPattern ? 1ull : 0ull;
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o);
+    if ((threadIdx.x & 63u) == 0u && cnt) atomicAdd(out, cnt);
+}
+
 // Which shade classes occur in the scene: the staged pipeline launches the shade stage once per class that does.
 int update_class_present(vpt_ctx* c) {
     std::vector<unsigned char> cls(c->instances.size());
@@ -461,11 +577,20 @@ void collect_timing(vpt_ctx* c) {  // call after a stream sync
         end_timing(ctx, eb_);                   \
     } while (0)
 
-// One batch of `frames` consecutive dispatches starting at dispatch index `dispatch_base`.  The bounce loop runs
-// without host round-trips: every stage reads its queue size from device memory, so the host only
-// checks the queue every few bounces (and right after max_depth bounces, when a surface-only batch is done).
-int render_batch(vpt_ctx* c, uint32_t frames, uint32_t dispatch_base) {
+// ---- One batch of `frames` consecutive dispatches starting at dispatch index `dispatch_base`, in stages: batch_begin (camera rays /
+// bounce 0), batch_bounces (k more bounces), batch_resolve (the guarded resolve + the counters on their way to pinned host memory),
+// batch_check (host synchronisation: how many paths are still alive).  The bounce loop runs without host round-trips: every stage
+// reads its queue size from device memory, so the host only looks at the counters every few bounces (render_batch) or not at all
+// until somebody waits (vpt_render_async).
+bool media_on_streams(const vpt_ctx* c) {
+    const bool vol = !c->volumes.empty() || c->dsc.atm_on;
+    return vol && !c->lds_scene && (c->cfg.pipeline == VPT_PIPELINE_AUTO || c->cfg.pipeline == VPT_PIPELINE_STAGED);
+}
+int batch_begin(vpt_ctx* c, uint32_t frames, uint32_t dispatch_base, BatchState& b) {
     hipStream_t s = c->stream;
+    b = BatchState{};
+    b.frames = frames; b.dispatch_base = dispatch_base;
+    if (frames == 0 || frames > c->frames_alloc) return fail(c, VPT_ERR_DEVICE, "internal: batch larger than the path buffers");
     uint32_t n_slots = frames * c->P.shard_pixels;  // launch-grid size of the batch
     const uint32_t S = c->P.split;
     if (S > 1) {  // RayTrace(ceil(W/S), ceil(H/S)) per dispatch, in-bounds part only (PathTracer.cpp:145-150, RayGen.slang:24)
@@ -479,152 +604,281 @@ int render_batch(vpt_ctx* c, uint32_t frames, uint32_t dispatch_base) {
         HIPCHK(c, hipMemcpyAsync(c->d_launch_off, off.data(), off.size() * 4, hipMemcpyHostToDevice, s));
         HIPCHK(c, hipStreamSynchronize(s));  // `off` is a stack-lifetime staging buffer
     }
-    if (n_slots == 0) return VPT_OK;
-    const bool count = c->cfg.count_traversal != 0;
+    b.n_slots = n_slots;
+    b.count = c->cfg.count_traversal != 0;
     // fused (one kernel per bounce, bounce 0 included) when the BVH rides in LDS; staged otherwise
-    // volumes are integrated in the fused per-bounce kernel only
     const bool vol = !c->volumes.empty() || c->dsc.atm_on;
     // AUTO: fused for LDS-resident scenes, the stream pipeline otherwise (atrium 1150 vs 575, glass bust 2410 vs 1290, Cornell box with
     // the 960-triangle glass sphere 2880 vs 2600 Msamples/s: no scene measured prefers the fused kernel once its BVH lives in memory)
     // Media (volumes / atmosphere): on the streams when the BVH lives in memory (kernels_media.hip: the traversal then runs on the
     // vote-scheduled kernels), in the fused per-bounce kernel when it rides in LDS or when the fused pipeline is asked for.
-    const bool media_stream = vol && !c->lds_scene && (c->cfg.pipeline == VPT_PIPELINE_AUTO || c->cfg.pipeline == VPT_PIPELINE_STAGED);
-    const bool fused = (vol && !media_stream) || c->cfg.pipeline == VPT_PIPELINE_FUSED || (c->cfg.pipeline == VPT_PIPELINE_AUTO && c->lds_scene);
-    const bool stream = !fused && !c->lds_scene && c->cfg.pipeline != VPT_PIPELINE_STAGED_R1;   // VPT_FLAG_LOCAL_HITS included: the stream kernels have validating instantiations
+    b.media_stream = media_on_streams(c);
+    b.fused = (vol && !b.media_stream) || c->cfg.pipeline == VPT_PIPELINE_FUSED || (c->cfg.pipeline == VPT_PIPELINE_AUTO && c->lds_scene);
+    b.stream = !b.fused && !c->lds_scene && c->cfg.pipeline != VPT_PIPELINE_STAGED_R1;   // VPT_FLAG_LOCAL_HITS included: the stream kernels have validating instantiations
     if (vol && c->cfg.pipeline == VPT_PIPELINE_STAGED && c->lds_scene)
         return fail(c, VPT_ERR_UNSUPPORTED, "media with VPT_PIPELINE_STAGED need a scene whose BVH lives in memory (this one rides in LDS: use VPT_PIPELINE_AUTO or _FUSED)");
-    if (media_stream) { int rl = ensure_media_buffers(c); if (rl != VPT_OK) return rl; }
-    if (!fused && !stream) { int rl = ensure_legacy_buffers(c); if (rl != VPT_OK) return rl; }
-    if (stream && c->cfg.pipeline == VPT_PIPELINE_STAGED_SORTED) { int rl = ensure_sorted_buffers(c); if (rl != VPT_OK) return rl; }
-    HIPCHK(c, hipMemsetAsync(c->ctr, 0, offsetof(Counters, stat_closest), s));  // queue words only, stat_* keep running
-    uint32_t parity;
-    uint32_t k3 = 0;  // fused: bounce index % 3 (Counters::rc3)
-    if (fused) {  // bounce 0 of every slot needs no input records; survivors land in queue[1]
-        TIMED(c, VPT_K_PRIMARY, launch_bounce(s, (uint32_t)c->primary_blocks, c->lds_scene, count, true, c->dsc, c->P, c->ps, c->ss, nullptr, c->queue[1], c->ctr, 0u, n_slots, dispatch_base, 0u));
-        parity = 1; k3 = 1;
-    } else if (stream) {
-        TIMED(c, VPT_K_PRIMARY, launch_raygen_stream(s, c->P, c->ps, c->ss, c->queue[0], n_slots, dispatch_base, media_stream));
-        launch_stream_begin(s, c->sctr, n_slots);
-        parity = 0;
-    } else {
-        TIMED(c, VPT_K_PRIMARY, launch_raygen(s, c->P, c->ps, c->queue[0], c->ctr, n_slots, dispatch_base));
-        parity = 0;
+    if (b.media_stream) {
+        int rl = ensure_media_buffers(c); if (rl != VPT_OK) return rl;
+        if (frames > c->media_frames) return fail(c, VPT_ERR_DEVICE, "internal: media batch larger than the media streams");
     }
-    const bool sorted = c->cfg.pipeline == VPT_PIPELINE_STAGED_SORTED;
+    if (!b.fused && !b.stream) { int rl = ensure_legacy_buffers(c); if (rl != VPT_OK) return rl; }
+    if (b.stream && c->cfg.pipeline == VPT_PIPELINE_STAGED_SORTED) { int rl = ensure_sorted_buffers(c); if (rl != VPT_OK) return rl; }
+    b.min_bounces = (uint64_t)c->P.max_depth * c->P.samples_per_frame;
+    b.iter_cap = b.min_bounces * 4ull + 1024ull;
+    b.sorted = c->cfg.pipeline == VPT_PIPELINE_STAGED_SORTED;
     // Two streams: the shadow-ray kernels and the join of bounce k run beside the extend of bounce k + 1 (which needs only the ray
     // queue shade k wrote), so the tail of one persistent traversal kernel is filled by the next one's first blocks.  Off while
     // kernels are timed or visits counted (one kernel at a time then) and in the sorted pipeline.
-    const bool overlap = stream && !sorted && !c->cfg.profile && !count && !media_stream;
-    bool join_pending = false;
-    const uint64_t min_bounces = (uint64_t)c->P.max_depth * c->P.samples_per_frame;
-    const uint64_t iter_cap = min_bounces * 4ull + 1024ull;
-    uint64_t iter = 0;
-    uint32_t chunk = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(min_bounces - (fused ? 1 : 0), 1), 8);
-    while (true) {
-        for (uint32_t j = 0; j < chunk; j++) {
-            if (fused) {  // no reset kernel in between: the bounce kernels rotate three queue-size words
-                TIMED(c, VPT_K_BOUNCE, launch_bounce(s, (uint32_t)c->primary_blocks, c->lds_scene, count, false, c->dsc, c->P, c->ps, c->ss, c->queue[parity], c->queue[parity ^ 1u], c->ctr, parity, 0u, 0u, k3));
-                parity ^= 1u; k3 = (k3 + 1u) % 3u;
-                continue;
-            }
-            // a memory-resident BVH runs the staged pipeline on the vote-scheduled traversal kernels and compact streams
-            // (kernels_trace.hip, kernels_stream.hip); round 1's stage kernels serve LDS-resident scenes forced into the staged
-            // pipeline, VPT_FLAG_LOCAL_HITS and VPT_PIPELINE_STAGED_R1
-            if (media_stream) {   // distance -> scatter -> extend -> shade -> sky rays, light rays -> tail (kernels_media.hip), one stream
-                launch_prepare_stream(s, c->sctr, parity);
-                TraceArgs a{};
-                a.ro = c->ss.RA[parity]; a.rd = c->ss.RB[parity]; a.order = nullptr; a.valid = c->queue[parity]; a.hit = c->ss.SH; a.hinst = c->ss.SHI; a.cls = nullptr;
-                a.n = 0; a.n_dev = &c->sctr->queue_len[parity].v; a.store_gid = 1u; a.param = c->vote_param;
-                // GetDistanceToGeometry (RTCommon.slang:86-101): the payload direction as it is, TMin 1e-5, TMax 1e6
-                a.head = &c->sctr->shade_head.v; a.tmin = 0.00001f; a.tmax = 1000000.0f; a.normalize_dir = 0u;
-                TIMED(c, VPT_K_EXTEND, launch_trace(s, (uint32_t)c->vote_blocks, VPT_TRACE_VOTE, false, count, c->dsc, a, c->ctr));
-                TIMED(c, VPT_K_SHADE, launch_media_scatter(s, (uint32_t)c->shade_blocks, c->dsc, c->ps, c->ss, c->ms, c->queue[parity], c->sctr, parity));
-                a.head = &c->sctr->extend_head.v; a.tmin = 0.01f; a.tmax = 100000.0f; a.normalize_dir = 1u;
-                TIMED(c, VPT_K_EXTEND, launch_trace(s, (uint32_t)c->vote_blocks, VPT_TRACE_VOTE, false, count, c->dsc, a, c->ctr));
-                launch_layout_media(s, c->sctr, parity, (uint32_t)c->shade_media_blocks * 4u, (uint32_t)c->media_tail_blocks * 4u);
-                TIMED(c, VPT_K_SHADE, launch_shade_media(s, (uint32_t)c->shade_media_blocks, c->dsc, c->P, c->ps, c->ss, c->ms, c->queue[parity], c->ctr, c->sctr, parity));
-                TIMED(c, VPT_K_SHADOW, launch_trace_shadow(s, (uint32_t)c->shadow_blocks, false, count, c->dsc, c->ss, c->ctr, c->sctr, c->vote_param));
-                TIMED(c, VPT_K_SHADOW, launch_trace_shadow(s, (uint32_t)c->shadow_blocks, true, count, c->dsc, c->ss, c->ctr, c->sctr, c->vote_param));
-                TIMED(c, VPT_K_JOIN, launch_media_tail(s, (uint32_t)c->media_tail_blocks, c->dsc, c->P, c->ps, c->ss, c->ms, c->queue[parity], c->queue[parity ^ 1u], c->ctr, c->sctr, parity));
-                parity ^= 1u;
-                continue;
-            }
-            if (stream) {   // stream pipeline: extend -> classify -> shade per class (streams out) -> sky rays, light rays -> join
-                launch_prepare_stream(s, c->sctr, parity);
-                TraceArgs a{};
-                a.ro = c->ss.RA[parity]; a.rd = c->ss.RB[parity]; a.order = nullptr; a.valid = c->queue[parity]; a.hit = c->ss.SH; a.hinst = c->ss.SHI; a.cls = c->cls_q;
-                a.n = 0; a.n_dev = &c->sctr->queue_len[parity].v; a.head = &c->sctr->extend_head.v;
-                a.tmin = 0.01f; a.tmax = 100000.0f; a.normalize_dir = 1u; a.store_gid = 1u; a.param = c->vote_param;
-                if (!sorted) a.cls = nullptr;
-                TIMED(c, VPT_K_EXTEND, launch_trace(s, (uint32_t)c->vote_blocks, VPT_TRACE_VOTE, false, count, c->dsc, a, c->ctr));
-                // the shade stage of this bounce overwrites the pending records and shadow-ray streams the join of the previous
-                // bounce reads (overlapped mode: that join runs on the second stream, beside the extend launched above)
-                if (overlap && join_pending) { HIPCHK(c, hipStreamWaitEvent(s, c->ev_join, 0)); join_pending = false; }
-                if (sorted) {   // the shade queue sorted by material class: one dense queue and one launch per class present in the scene
-                    TIMED(c, VPT_K_SHADE, launch_classify(s, c->queue[parity], c->cls_q, c->class_queue, c->sctr, parity, n_slots + c->stream_slack, (uint32_t)c->shade_stream_blocks * 4u));
-                    for (uint32_t k = 0; k < kShadeClasses; k++)
-                        if (c->class_present & (1u << k))
-                            TIMED(c, VPT_K_SHADE, launch_shade_stream(s, (uint32_t)c->shade_stream_blocks, k, true, c->dsc, c->P, c->ps, c->ss, c->queue[parity], c->class_queue[k], c->queue[parity ^ 1u], c->ctr, c->sctr, parity));
-                } else {
-                    launch_layout_single(s, c->sctr, parity, (uint32_t)c->shade_stream_blocks * 4u);
-                    TIMED(c, VPT_K_SHADE, launch_shade_stream(s, (uint32_t)c->shade_stream_blocks, 0u, false, c->dsc, c->P, c->ps, c->ss, c->queue[parity], nullptr, c->queue[parity ^ 1u], c->ctr, c->sctr, parity));
-                }
-                hipStream_t sb = s;
-                DeviceScene dsc_shadow = c->dsc;
-                if (overlap) {   // shadow rays and join of this bounce on the second stream: the next bounce's extend does not depend on them
-                    HIPCHK(c, hipEventRecord(c->ev_shade, s));
-                    HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_shade, 0));
-                    sb = c->stream2;
-                    dsc_shadow.stack_overflow = c->stack_overflow2;   // its own stack spill region: it runs beside the next extend
-                }
-                TIMED(c, VPT_K_SHADOW, launch_trace_shadow(sb, (uint32_t)c->shadow_blocks, false, count, dsc_shadow, c->ss, c->ctr, c->sctr, c->vote_param));
-                TIMED(c, VPT_K_SHADOW, launch_trace_shadow(sb, (uint32_t)c->shadow_blocks, true, count, dsc_shadow, c->ss, c->ctr, c->sctr, c->vote_param));
-                TIMED(c, VPT_K_JOIN, launch_join(sb, (uint32_t)c->join_blocks, c->P, c->ps, c->ss, c->sctr, c->queue[parity], c->queue[parity ^ 1u], parity));
-                if (overlap) { HIPCHK(c, hipEventRecord(c->ev_join, c->stream2)); join_pending = true; }
-                parity ^= 1u;
-                continue;
-            }
-            launch_prepare(s, c->ctr, parity);
-            TIMED(c, VPT_K_EXTEND, launch_extend(s, (uint32_t)c->trav_blocks, c->lds_scene, count, c->dsc, c->ps, c->queue[parity], c->ctr, parity));
-            TIMED(c, VPT_K_SHADE, launch_shade(s, (uint32_t)c->shade_blocks, c->dsc, c->P, c->ps, c->queue[parity], c->queue[parity ^ 1u], c->cqueue, c->ctr, parity));
-            TIMED(c, VPT_K_CONNECT, launch_connect(s, (uint32_t)c->trav_blocks, c->lds_scene, count, c->dsc, c->P, c->ps, c->cqueue, c->ctr, parity));
+    b.overlap = b.stream && !b.sorted && !c->cfg.profile && !b.count && !b.media_stream;
+    if (n_slots == 0) return VPT_OK;
+    HIPCHK(c, hipMemsetAsync(c->ctr, 0, offsetof(Counters, stat_closest), s));  // queue words only, stat_* keep running
+    if (b.fused) {  // bounce 0 of every slot needs no input records; survivors land in queue[1]
+        TIMED(c, VPT_K_PRIMARY, launch_bounce(s, (uint32_t)c->primary_blocks, c->lds_scene, b.count, true, c->dsc, c->P, c->ps, c->ss, nullptr, c->queue[1], c->ctr, 0u, n_slots, dispatch_base, 0u, c->scene_plain));
+        b.parity = 1; b.k3 = 1; b.iter = 1;
+    } else if (b.stream) {
+        TIMED(c, VPT_K_PRIMARY, launch_raygen_stream(s, c->P, c->ps, c->ss, c->queue[0], n_slots, dispatch_base, b.media_stream));
+        launch_stream_begin(s, c->sctr, n_slots);
+        b.parity = 0;
+    } else {
+        TIMED(c, VPT_K_PRIMARY, launch_raygen(s, c->P, c->ps, c->queue[0], c->ctr, n_slots, dispatch_base));
+        b.parity = 0;
+    }
+    return VPT_OK;
+}
+
+int batch_bounces(vpt_ctx* c, BatchState& b, uint32_t bounces) {
+    hipStream_t s = c->stream;
+    const bool count = b.count, sorted = b.sorted, overlap = b.overlap;
+    uint32_t& parity = b.parity;
+    const uint32_t n_slots = b.n_slots;
+    if (n_slots == 0) return VPT_OK;
+    for (uint32_t j = 0; j < bounces; j++) {
+        b.iter++;
+        if (b.fused) {  // no reset kernel in between: the bounce kernels rotate three queue-size words
+            TIMED(c, VPT_K_BOUNCE, launch_bounce(s, (uint32_t)c->primary_blocks, c->lds_scene, count, false, c->dsc, c->P, c->ps, c->ss, c->queue[parity], c->queue[parity ^ 1u], c->ctr, parity, 0u, 0u, b.k3, c->scene_plain));
+            parity ^= 1u; b.k3 = (b.k3 + 1u) % 3u;
+            continue;
+        }
+        // a memory-resident BVH runs the staged pipeline on the vote-scheduled traversal kernels and compact streams
+        // (kernels_trace.hip, kernels_stream.hip); round 1's stage kernels serve LDS-resident scenes forced into the staged
+        // pipeline and VPT_PIPELINE_STAGED_R1
+        if (b.media_stream) {   // distance -> scatter -> extend -> shade -> sky rays, light rays -> tail (kernels_media.hip), one stream
+            launch_prepare_stream(s, c->sctr, parity);
+            TraceArgs a{};
+            a.ro = c->ss.RA[parity]; a.rd = c->ss.RB[parity]; a.order = nullptr; a.valid = c->queue[parity]; a.hit = c->ss.SH; a.hinst = c->ss.SHI; a.cls = nullptr;
+            a.n = 0; a.n_dev = &c->sctr->queue_len[parity].v; a.store_gid = 1u; a.param = c->vote_param;
+            // GetDistanceToGeometry (RTCommon.slang:86-101): the payload direction as it is, TMin 1e-5, TMax 1e6
+            a.head = &c->sctr->shade_head.v; a.tmin = 0.00001f; a.tmax = 1000000.0f; a.normalize_dir = 0u;
+            TIMED(c, VPT_K_EXTEND, launch_trace(s, (uint32_t)c->vote_blocks, VPT_TRACE_VOTE, false, count, c->dsc, a, c->ctr));
+            TIMED(c, VPT_K_SHADE, launch_media_scatter(s, (uint32_t)c->shade_blocks, c->dsc, c->ps, c->ss, c->ms, c->queue[parity], c->sctr, parity));
+            a.head = &c->sctr->extend_head.v; a.tmin = 0.01f; a.tmax = 100000.0f; a.normalize_dir = 1u;
+            TIMED(c, VPT_K_EXTEND, launch_trace(s, (uint32_t)c->vote_blocks, VPT_TRACE_VOTE, false, count, c->dsc, a, c->ctr));
+            launch_layout_media(s, c->sctr, parity, (uint32_t)c->shade_media_blocks * 4u, (uint32_t)c->media_tail_blocks * 4u);
+            TIMED(c, VPT_K_SHADE, launch_shade_media(s, (uint32_t)c->shade_media_blocks, c->dsc, c->P, c->ps, c->ss, c->ms, c->queue[parity], c->ctr, c->sctr, parity));
+            TIMED(c, VPT_K_SHADOW, launch_trace_shadow(s, (uint32_t)c->shadow_blocks, false, count, c->dsc, c->ss, c->ctr, c->sctr, c->vote_param));
+            TIMED(c, VPT_K_SHADOW, launch_trace_shadow(s, (uint32_t)c->shadow_blocks, true, count, c->dsc, c->ss, c->ctr, c->sctr, c->vote_param));
+            TIMED(c, VPT_K_JOIN, launch_media_tail(s, (uint32_t)c->media_tail_blocks, c->dsc, c->P, c->ps, c->ss, c->ms, c->queue[parity], c->queue[parity ^ 1u], c->ctr, c->sctr, parity));
             parity ^= 1u;
+            continue;
         }
-        iter += chunk;
-        if (!fused && !stream) launch_fold(s, c->ctr);
-        // the resolve rides right behind the bounces that are expected to be the last ones; it does nothing if a path is
-        // still alive (in-medium walks do not consume depth), in which case more bounces and another resolve follow
-        if (overlap && join_pending) { HIPCHK(c, hipStreamWaitEvent(s, c->ev_join, 0)); join_pending = false; }   // the resolve reads the frame sums the join writes
-        const uint32_t* guard = fused ? &c->ctr->alive3[k3] : stream ? &c->sctr->alive[parity].v : &c->ctr->ray_count[parity];
-        TIMED(c, VPT_K_RESOLVE, launch_resolve(s, c->P, c->ps, c->image, frames, dispatch_base, guard));
-        Counters h{};
-        HIPCHK(c, hipMemcpyAsync(&h, c->ctr, sizeof(Counters), hipMemcpyDeviceToHost, s));
-        HIPCHK(c, hipStreamSynchronize(s));
-        collect_timing(c);
-        c->stats.closest_rays = h.stat_closest;
-        c->stats.shadow_rays = h.stat_shadow;
-        c->stats.connect_paths = h.stat_connect;
-        c->stats.primary_hits = h.stat_primary_hits;
-        c->stats.primary_survivors = h.stat_primary_alive;
-        c->stats.primary_shadow_rays = h.stat_primary_rays;
-        c->stats.nodes_visited = h.stat_nodes;
-        c->stats.tris_tested = h.stat_tris;
-        c->stats.shadow_nodes_visited = h.stat_shadow_nodes;
-        c->stats.shadow_tris_tested = h.stat_shadow_tris;
-        uint32_t n = fused ? h.alive3[k3] : h.ray_count[parity];
-        if (stream) {  // the exact number of live paths; the queue length (holes included) must fit the queue allocation
-            uint32_t len = 0;
-            HIPCHK(c, hipMemcpy(&n, &c->sctr->alive[parity].v, 4, hipMemcpyDeviceToHost));
-            HIPCHK(c, hipMemcpy(&len, &c->sctr->queue_len[parity].v, 4, hipMemcpyDeviceToHost));
-            if ((uint64_t)len > (uint64_t)c->ps.capacity + c->stream_slack) { (void)hipStreamSynchronize(c->stream2); return fail(c, VPT_ERR_DEVICE, "internal: stream overflow"); }
+        if (b.stream) {   // stream pipeline: extend -> classify -> shade per class (streams out) -> sky rays, light rays -> join
+            launch_prepare_stream(s, c->sctr, parity);
+            TraceArgs a{};
+            a.ro = c->ss.RA[parity]; a.rd = c->ss.RB[parity]; a.order = nullptr; a.valid = c->queue[parity]; a.hit = c->ss.SH; a.hinst = c->ss.SHI; a.cls = c->cls_q;
+            a.n = 0; a.n_dev = &c->sctr->queue_len[parity].v; a.head = &c->sctr->extend_head.v;
+            a.tmin = 0.01f; a.tmax = 100000.0f; a.normalize_dir = 1u; a.store_gid = 1u; a.param = c->vote_param;
+            if (!sorted) a.cls = nullptr;
+            TIMED(c, VPT_K_EXTEND, launch_trace(s, (uint32_t)c->vote_blocks, VPT_TRACE_VOTE, false, count, c->dsc, a, c->ctr));
+            // the shade stage of this bounce overwrites the pending records and shadow-ray streams the join of the previous
+            // bounce reads (overlapped mode: that join runs on the second stream, beside the extend launched above)
+            if (overlap && b.join_pending) { HIPCHK(c, hipStreamWaitEvent(s, c->ev_join, 0)); b.join_pending = false; }
+            if (sorted) {   // the shade queue sorted by material class: one dense queue and one launch per class present in the scene
+                TIMED(c, VPT_K_SHADE, launch_classify(s, c->queue[parity], c->cls_q, c->class_queue, c->sctr, parity, n_slots + c->stream_slack, (uint32_t)c->shade_stream_blocks * 4u));
+                for (uint32_t k = 0; k < kShadeClasses; k++)
+                    if (c->class_present & (1u << k))
+                        TIMED(c, VPT_K_SHADE, launch_shade_stream(s, (uint32_t)c->shade_stream_blocks, k, true, c->dsc, c->P, c->ps, c->ss, c->queue[parity], c->class_queue[k], c->queue[parity ^ 1u], c->ctr, c->sctr, parity));
+            } else {
+                launch_layout_single(s, c->sctr, parity, (uint32_t)c->shade_stream_blocks * 4u);
+                TIMED(c, VPT_K_SHADE, launch_shade_stream(s, (uint32_t)c->shade_stream_blocks, 0u, false, c->dsc, c->P, c->ps, c->ss, c->queue[parity], nullptr, c->queue[parity ^ 1u], c->ctr, c->sctr, parity));
+            }
+            hipStream_t sb = s;
+            DeviceScene dsc_shadow = c->dsc;
+            if (overlap) {   // shadow rays and join of this bounce on the second stream: the next bounce's extend does not depend on them
+                HIPCHK(c, hipEventRecord(c->ev_shade, s));
+                HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_shade, 0));
+                sb = c->stream2;
+                dsc_shadow.stack_overflow = c->stack_overflow2;   // its own stack spill region: it runs beside the next extend
+            }
+            TIMED(c, VPT_K_SHADOW, launch_trace_shadow(sb, (uint32_t)c->shadow_blocks, false, count, dsc_shadow, c->ss, c->ctr, c->sctr, c->vote_param));
+            TIMED(c, VPT_K_SHADOW, launch_trace_shadow(sb, (uint32_t)c->shadow_blocks, true, count, dsc_shadow, c->ss, c->ctr, c->sctr, c->vote_param));
+            TIMED(c, VPT_K_JOIN, launch_join(sb, (uint32_t)c->join_blocks, c->P, c->ps, c->ss, c->sctr, c->queue[parity], c->queue[parity ^ 1u], parity));
+            if (overlap) { HIPCHK(c, hipEventRecord(c->ev_join, c->stream2)); b.join_pending = true; }
+            parity ^= 1u;
+            continue;
         }
-        if (n > n_slots) { (void)hipStreamSynchronize(c->stream2); return fail(c, VPT_ERR_DEVICE, "internal: queue overflow"); }
+        launch_prepare(s, c->ctr, parity);
+        TIMED(c, VPT_K_EXTEND, launch_extend(s, (uint32_t)c->trav_blocks, c->lds_scene, count, c->dsc, c->ps, c->queue[parity], c->ctr, parity));
+        TIMED(c, VPT_K_SHADE, launch_shade(s, (uint32_t)c->shade_blocks, c->dsc, c->P, c->ps, c->queue[parity], c->queue[parity ^ 1u], c->cqueue, c->ctr, parity));
+        TIMED(c, VPT_K_CONNECT, launch_connect(s, (uint32_t)c->trav_blocks, c->lds_scene, count, c->dsc, c->P, c->ps, c->cqueue, c->ctr, parity));
+        parity ^= 1u;
+    }
+    return VPT_OK;
+}
+
+// The resolve rides right behind the bounces that are expected to be the last ones; it does nothing if a path is still alive
+// (in-medium walks do not consume depth), in which case more bounces and another resolve follow.  Behind it the counters travel to
+// pinned host memory, for whoever synchronises next.
+int batch_resolve(vpt_ctx* c, BatchState& b) {
+    hipStream_t s = c->stream;
+    if (b.n_slots == 0) return VPT_OK;
+    if (!b.fused && !b.stream) launch_fold(s, c->ctr);
+    if (b.overlap && b.join_pending) { HIPCHK(c, hipStreamWaitEvent(s, c->ev_join, 0)); b.join_pending = false; }   // the resolve reads the frame sums the join writes
+    const uint32_t* guard = b.fused ? &c->ctr->alive3[b.k3] : b.stream ? &c->sctr->alive[b.parity].v : &c->ctr->ray_count[b.parity];
+    TIMED(c, VPT_K_RESOLVE, launch_resolve(s, c->P, c->ps, c->image, b.frames, b.dispatch_base, guard));
+    HIPCHK(c, hipMemcpyAsync(&c->h_ctr->ctr, c->ctr, sizeof(Counters), hipMemcpyDeviceToHost, s));
+    if (b.stream) {  // the exact number of live paths, and the queue length (holes included), which must fit the queue allocation
+        HIPCHK(c, hipMemcpyAsync(&c->h_ctr->alive[0], &c->sctr->alive[b.parity].v, 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipMemcpyAsync(&c->h_ctr->queue_len[0], &c->sctr->queue_len[b.parity].v, 4, hipMemcpyDeviceToHost, s));
+    }
+    return VPT_OK;
+}
+
+// Host synchronisation: statistics, overflow checks, *alive = paths of the batch still in flight.
+int batch_check(vpt_ctx* c, BatchState& b, uint32_t* alive) {
+    *alive = 0;
+    if (b.n_slots == 0) return VPT_OK;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    collect_timing(c);
+    const Counters& h = c->h_ctr->ctr;
+    c->stats.closest_rays = h.stat_closest;
+    c->stats.shadow_rays = h.stat_shadow;
+    c->stats.connect_paths = h.stat_connect;
+    c->stats.primary_hits = h.stat_primary_hits;
+    c->stats.primary_survivors = h.stat_primary_alive;
+    c->stats.primary_shadow_rays = h.stat_primary_rays;
+    c->stats.nodes_visited = h.stat_nodes;
+    c->stats.tris_tested = h.stat_tris;
+    c->stats.shadow_nodes_visited = h.stat_shadow_nodes;
+    c->stats.shadow_tris_tested = h.stat_shadow_tris;
+    uint32_t n = b.fused ? h.alive3[b.k3] : h.ray_count[b.parity];
+    if (b.stream) {
+        n = c->h_ctr->alive[0];
+        const uint64_t len = c->h_ctr->queue_len[0];
+        const uint64_t room = b.media_stream ? (uint64_t)c->media_frames * c->P.shard_pixels + c->stream_slack : (uint64_t)c->ps.capacity + c->stream_slack;
+        if (len > room || len > (uint64_t)c->ps.capacity + c->stream_slack) { (void)hipStreamSynchronize(c->stream2); return fail(c, VPT_ERR_DEVICE, "internal: stream overflow"); }
+    }
+    if (n > b.n_slots) { (void)hipStreamSynchronize(c->stream2); return fail(c, VPT_ERR_DEVICE, "internal: queue overflow"); }
+    if (n != 0 && b.iter > b.iter_cap) { (void)hipStreamSynchronize(c->stream2); return fail(c, VPT_ERR_DEVICE, "internal: bounce loop did not terminate"); }
+    *alive = n;
+    return VPT_OK;
+}
+
+// Runs a begun batch to its end: resolve + check, and while paths are alive four more bounces at a time.
+int batch_finish(vpt_ctx* c, BatchState& b, bool resolve_enqueued) {
+    while (true) {
+        if (!resolve_enqueued) { int rc = batch_resolve(c, b); if (rc) return rc; }
+        resolve_enqueued = false;
+        uint32_t n = 0;
+        int rc = batch_check(c, b, &n);
+        if (rc) return rc;
         if (n == 0) break;
-        if (iter > iter_cap) { (void)hipStreamSynchronize(c->stream2); return fail(c, VPT_ERR_DEVICE, "internal: bounce loop did not terminate"); }
-        chunk = 4;
+        rc = batch_bounces(c, b, 4);
+        if (rc) return rc;
     }
     HIPCHK(c, hipGetLastError());
-    c->stats.samples += (uint64_t)n_slots * c->P.samples_per_frame;
+    return VPT_OK;
+}
+
+int render_batch(vpt_ctx* c, uint32_t frames, uint32_t dispatch_base) {
+    BatchState b;
+    int rc = batch_begin(c, frames, dispatch_base, b);
+    if (rc) return rc;
+    if (b.n_slots == 0) return VPT_OK;
+    // the host looks at the queue after max_depth bounces (when a surface-only batch is done) or after eight, whichever comes first
+    const uint32_t first = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(b.min_bounces - (b.fused ? 1 : 0), 1), 8);
+    rc = batch_bounces(c, b, first);
+    if (rc) return rc;
+    rc = batch_finish(c, b, false);
+    if (rc) return rc;
+    c->stats.samples += (uint64_t)b.n_slots * c->P.samples_per_frame;
+    return VPT_OK;
+}
+
+// ---- asynchronous batches -------------------------------------------------------------------------------------------------
+uint64_t issue_ticket(vpt_ctx* c) {
+    c->tick_issued++;
+    (void)hipEventRecord(c->tick_ev[c->tick_issued % kTickets], c->stream);
+    c->async_dirty = true;
+    return c->tick_issued;
+}
+// An enqueued batch whose paths may outlive the bounces enqueued with it: finish it exactly as render_batch would have.
+int finish_outstanding(vpt_ctx* c) {
+    if (!c->out_active) return VPT_OK;
+    c->out_active = false;
+    return batch_finish(c, c->out_batch, true);
+}
+// Everything enqueued so far has finished when this returns (and an unfinished batch has been finished).
+int drain(vpt_ctx* c) {
+    int rc = finish_outstanding(c);
+    if (rc) return rc;
+    if (!c->async_dirty) return VPT_OK;
+    c->async_dirty = false;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream2));
+    collect_timing(c);
+    // fixed-schedule batches copy their counters to pinned memory too: a path alive after max_depth * spp bounces would be a bug
+    const Counters& h = c->h_ctr->ctr;
+    c->stats.closest_rays = h.stat_closest; c->stats.shadow_rays = h.stat_shadow; c->stats.connect_paths = h.stat_connect;
+    c->stats.primary_hits = h.stat_primary_hits; c->stats.primary_survivors = h.stat_primary_alive; c->stats.primary_shadow_rays = h.stat_primary_rays;
+    HIPCHK(c, hipGetLastError());
+    return VPT_OK;
+}
+void destroy_graph(vpt_ctx* c) {
+    if (c->graph) (void)hipGraphExecDestroy(c->graph);
+    c->graph = nullptr; c->graph_gen = 0;
+}
+// A whole batch as a fixed schedule of `bounces` bounces after bounce 0 (or the camera rays) + the guarded resolve.
+int enqueue_fixed(vpt_ctx* c, uint32_t frames, uint32_t dispatch_base, uint32_t bounces_total, BatchState& b) {
+    int rc = batch_begin(c, frames, dispatch_base, b);
+    if (rc) return rc;
+    if (b.n_slots == 0) return VPT_OK;
+    rc = batch_bounces(c, b, b.fused ? bounces_total - 1u : bounces_total);
+    if (rc) return rc;
+    return batch_resolve(c, b);
+}
+// The same through a captured hipGraph: the fused pipeline's batch (memset, bounce 0, bounces, resolve, counter copy) with the first
+// dispatch index read from device memory, captured once per (state, frames, bounces) and replayed.
+int enqueue_graph(vpt_ctx* c, uint32_t frames, uint32_t dispatch_base, uint32_t bounces_total, bool* used) {
+    *used = false;
+    if (c->graph_broken) return VPT_OK;
+    if (!c->graph || c->graph_gen != c->state_gen || c->graph_frames != frames || c->graph_bounces != bounces_total) {
+        destroy_graph(c);
+        uint64_t before[VPT_KERNEL_COUNT];
+        memcpy(before, c->stats.kernel_launches, sizeof(before));
+        c->P.dispatch_base_dev = c->d_dispatch_base;
+        hipGraph_t g = nullptr;
+        BatchState b;
+        bool ok = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+        int rc = ok ? enqueue_fixed(c, frames, 0u, bounces_total, b) : VPT_ERR_DEVICE;
+        if (ok && hipStreamEndCapture(c->stream, &g) != hipSuccess) { ok = false; g = nullptr; }
+        c->P.dispatch_base_dev = nullptr;
+        for (int k = 0; k < VPT_KERNEL_COUNT; k++) { c->graph_kernel_launches[k] = c->stats.kernel_launches[k] - before[k]; c->stats.kernel_launches[k] = before[k]; }
+        if (ok && rc == VPT_OK && g && hipGraphInstantiate(&c->graph, g, nullptr, nullptr, 0) != hipSuccess) { ok = false; c->graph = nullptr; }
+        if (g) (void)hipGraphDestroy(g);
+        if (!ok || rc != VPT_OK || !c->graph) {   // capture is an optimisation: without it the batch goes out as plain launches
+            (void)hipGetLastError();
+            destroy_graph(c);
+            c->graph_broken = true;
+            c->err.clear();
+            return VPT_OK;
+        }
+        c->graph_gen = c->state_gen; c->graph_frames = frames; c->graph_bounces = bounces_total;
+    }
+    HIPCHK(c, hipMemsetD32Async((hipDeviceptr_t)c->d_dispatch_base, (int)dispatch_base, 1, c->stream));
+    HIPCHK(c, hipGraphLaunch(c->graph, c->stream));
+    for (int k = 0; k < VPT_KERNEL_COUNT; k++) c->stats.kernel_launches[k] += c->graph_kernel_launches[k];
+    c->stats.graph_launches++;
+    *used = true;
     return VPT_OK;
 }
 
@@ -685,6 +939,11 @@ vpt_ctx* vpt_create(const vpt_config* cfg, int* err) {
     if (hipMalloc((void**)&c->sctr, sizeof(StreamCounters)) != hipSuccess) { set(VPT_ERR_DEVICE); vpt_destroy(c); return nullptr; }
     (void)hipMemset(c->sctr, 0, sizeof(StreamCounters));
     if (hipMalloc((void**)&c->d_launch_off, (kMaxFramesInFlight + 1) * 4) != hipSuccess) { set(VPT_ERR_DEVICE); vpt_destroy(c); return nullptr; }
+    for (int k = 0; k < kTickets; k++)
+        if (hipEventCreateWithFlags(&c->tick_ev[k], hipEventDisableTiming) != hipSuccess) { c->tick_ev[k] = nullptr; set(VPT_ERR_DEVICE); vpt_destroy(c); return nullptr; }
+    if (hipHostMalloc((void**)&c->h_ctr, sizeof(HostCounters), hipHostMallocDefault) != hipSuccess) { c->h_ctr = nullptr; set(VPT_ERR_DEVICE); vpt_destroy(c); return nullptr; }
+    memset(c->h_ctr, 0, sizeof(HostCounters));
+    if (hipMalloc((void**)&c->d_dispatch_base, 256) != hipSuccess || hipMalloc((void**)&c->d_spill_count, 256) != hipSuccess) { set(VPT_ERR_DEVICE); vpt_destroy(c); return nullptr; }
     vpt_default_params(&c->params);
     const float id[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
     memcpy(c->P.view_inv, id, 64); memcpy(c->P.proj_inv, id, 64);
@@ -699,7 +958,13 @@ void vpt_destroy(vpt_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->stream2) (void)hipStreamSynchronize(c->stream2);
+    destroy_graph(c);
     if (c->comm) { (void)ncclCommDestroy(c->comm); c->comm = nullptr; }
+    for (int k = 0; k < kTickets; k++) if (c->tick_ev[k]) (void)hipEventDestroy(c->tick_ev[k]);
+    if (c->h_ctr) (void)hipHostFree(c->h_ctr);
+    if (c->d_dispatch_base) (void)hipFree(c->d_dispatch_base);
+    if (c->d_spill_count) (void)hipFree(c->d_spill_count);
     free_lab(c);
     free_scene(c);
     free_render_buffers(c);
@@ -728,6 +993,8 @@ int vpt_set_scene(vpt_ctx* c, const vpt_scene_desc* sd) {
         sd->env_width == 0 || sd->env_height == 0 || !sd->lut_reflection || !sd->lut_refraction_outside || !sd->lut_refraction_inside)
         return fail(c, VPT_ERR_INVALID_ARGUMENT, "incomplete scene description");
     HIPCHK(c, hipSetDevice(c->cfg.device));
+    { int rd = drain(c); if (rd) return rd; }
+    const auto t_scene0 = std::chrono::steady_clock::now();
     // ---- validate the whole description first: a rejected scene leaves the current one untouched
     {
         uint64_t nv = 0, ni = 0, texel_bytes = 0;
@@ -757,6 +1024,7 @@ int vpt_set_scene(vpt_ctx* c, const vpt_scene_desc* sd) {
     }
     free_scene(c);
     reset_accum(c);
+    c->state_gen++;
     // ---- geometry pools
     std::vector<vpt_vertex> verts; std::vector<uint32_t> idx;
     c->meshes.clear(); c->total_vertices = 0; c->total_indices = 0;
@@ -800,15 +1068,19 @@ int vpt_set_scene(vpt_ctx* c, const vpt_scene_desc* sd) {
     }
     std::vector<BvhNode> nodes; std::vector<BvhNodeWide> wide; std::vector<BvhTri> leaf_tris; int depth = 0;
     c->sbvh = (c->cfg.build_flags & VPT_BUILD_SBVH) != 0u;   // spatial splits in the builder: a per-context option
+    const auto t_bvh0 = std::chrono::steady_clock::now();
     build_bvh(tris, nodes, wide, leaf_tris, &depth, nullptr, c->sbvh);
+    c->bvh_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_bvh0).count();
     c->bvh_input = tris; c->dsc.nodes8 = nullptr;
     c->bvh_depth = (uint32_t)depth;
     // ---- textures
+    c->tex_1x1.clear();
     std::vector<TexDesc> tds; std::vector<uint8_t> texels;
     for (uint32_t t = 0; t < sd->texture_count; t++) {
         const vpt_texture& tx = sd->textures[t];
         while (texels.size() % 4) texels.push_back(0);
         TexDesc d; d.offset = (uint32_t)texels.size(); d.w = tx.width; d.h = tx.height; d.c = tx.channels;
+        c->tex_1x1.push_back(tx.width == 1 && tx.height == 1 ? 1 : 0);
         texels.insert(texels.end(), tx.data, tx.data + (size_t)tx.width * tx.height * tx.channels);
         tds.push_back(d);
     }
@@ -882,19 +1154,14 @@ int vpt_set_scene(vpt_ctx* c, const vpt_scene_desc* sd) {
     c->trav_blocks = traverse_blocks_per_cu(c->lds_scene, D) * c->cu_count;
     c->shade_blocks = shade_blocks_per_cu() * c->cu_count;
     c->join_blocks = join_blocks_per_cu() * c->cu_count;
-    c->primary_blocks = bounce_blocks_per_cu(c->lds_scene, D) * c->cu_count;
+    c->primary_blocks_general = bounce_blocks_per_cu(c->lds_scene, D, false) * c->cu_count;
+    c->primary_blocks_plain = bounce_blocks_per_cu(c->lds_scene, D, true) * c->cu_count;
+    c->primary_blocks = std::max(c->primary_blocks_general, c->primary_blocks_plain);   // (sizes the spill regions below; update_depth_bounded picks the grid)
     c->shade_stream_blocks = shade_stream_blocks_per_cu() * c->cu_count;
     c->shade_media_blocks = shade_media_blocks_per_cu() * c->cu_count;
     c->media_tail_blocks = media_tail_blocks_per_cu() * c->cu_count;
     c->shadow_blocks = trace_shadow_blocks_per_cu() * c->cu_count;
     c->vote_blocks = std::min(trace_blocks_per_cu(VPT_TRACE_VOTE, false), trace_blocks_per_cu(VPT_TRACE_VOTE, true)) * c->cu_count;
-    {   // every wave of a launch that appends to a stream may leave one unwritten chunk tail in it (vote.hpp WaveAppender): the streams were
-        // allocated with room for stream_slack such entries — refuse here, not after a kernel has written past a stream, if a device
-        // with more CUs / other occupancy than the allocation assumed ever needs more
-        const uint64_t appending_waves = 4ull * (uint64_t)std::max(std::max(c->shade_stream_blocks, c->primary_blocks), std::max(c->shade_media_blocks, c->media_tail_blocks));
-        if (c->buffers_ok && appending_waves * 256u /* vote.hpp kAppendChunk */ > (uint64_t)c->stream_slack && (uint64_t)c->ps.capacity * 4 + 256 > (uint64_t)c->stream_slack)
-            return fail(c, VPT_ERR_DEVICE, "internal: the stream slack allocated for chunk tails is smaller than one chunk per appending wave of this device");
-    }
     {   // per-thread overflow region of the traversal stacks, for the largest persistent grid launched
         c->max_blocks = std::max(std::max(std::max(std::max(c->trav_blocks, c->shade_blocks), c->primary_blocks), c->vote_blocks), std::max(c->shade_stream_blocks, c->shadow_blocks));
         void* d = nullptr;
@@ -905,6 +1172,9 @@ int vpt_set_scene(vpt_ctx* c, const vpt_scene_desc* sd) {
         c->scene_allocs.push_back(d);
         D.stack_overflow = (uint32_t*)d;
         c->stack_overflow2 = (uint32_t*)((char*)d + region);
+        // preset to a word no stack entry can be (a node index of 2.1e9; leaf codes are negative): vpt_get_stats counts what was spilled
+        HIPCHK(c, hipMemset(d, kSpillPatternByte, 2 * region));
+        c->stack_overflow_words = (uint32_t)(region / 4);
     }
     launch_precompute_tri_ng(c->stream, D, c->d_tri_ng);
     launch_precompute_tri_shade(c->stream, D, c->d_tri_shade);
@@ -914,9 +1184,11 @@ int vpt_set_scene(vpt_ctx* c, const vpt_scene_desc* sd) {
     if ((rc = update_class_present(c))) return rc;
     HIPCHK(c, hipGetLastError());
     c->has_scene = true;
+    update_depth_bounded(c);
     // (after a failed vpt_resize there is no image to clear: the scene is installed all the same, rendering needs a successful resize first)
     if (c->buffers_ok) HIPCHK(c, hipMemset(c->image, 0, (size_t)c->P.shard_pixels * 16));
-    return VPT_OK;
+    c->set_scene_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_scene0).count();
+    return check_stream_slack(c);
 }
 
 int vpt_set_material(vpt_ctx* c, uint32_t index, const vpt_material* m) {
@@ -927,6 +1199,8 @@ int vpt_set_material(vpt_ctx* c, uint32_t index, const vpt_material* m) {
         m->metallic_texture >= c->texture_count || m->emissive_texture >= c->texture_count)
         return fail(c, VPT_ERR_INVALID_ARGUMENT, "material texture index out of range");   // the shade stage indexes textures[] unchecked
     HIPCHK(c, hipSetDevice(c->cfg.device));
+    { int rd = drain(c); if (rd) return rd; }   // batches in flight read the tables patched below
+    c->state_gen++;
     const vpt_material& old = c->materials[index];
     bool emissive_changed = old.emissive_color[0] != m->emissive_color[0] || old.emissive_color[1] != m->emissive_color[1] || old.emissive_color[2] != m->emissive_color[2];
     c->materials[index] = *m;
@@ -936,6 +1210,7 @@ int vpt_set_material(vpt_ctx* c, uint32_t index, const vpt_material* m) {
     launch_classify_instances(c->stream, c->dsc, c->d_inst_class, (uint32_t)c->instances.size());
     HIPCHK(c, hipStreamSynchronize(c->stream));
     { int rc2 = update_class_present(c); if (rc2) return rc2; }
+    update_depth_bounded(c);
     reset_accum(c);
     return VPT_OK;
 }
@@ -947,7 +1222,8 @@ int vpt_get_material(const vpt_ctx* c, uint32_t index, vpt_material* out) {
 
 int vpt_set_camera(vpt_ctx* c, const float* vi, const float* pi) {
     if (!c || !vi || !pi) return VPT_ERR_INVALID_ARGUMENT;
-    memcpy(c->P.view_inv, vi, 64); memcpy(c->P.proj_inv, pi, 64);
+    memcpy(c->P.view_inv, vi, 64); memcpy(c->P.proj_inv, pi, 64);   // host state only: batches already enqueued carry their own copy
+    c->state_gen++;
     reset_accum(c);
     return VPT_OK;
 }
@@ -964,6 +1240,8 @@ int vpt_set_params(vpt_ctx* c, const vpt_params* p) {
         vpt_params same = *p; same.max_samples = c->params.max_samples;
         if (p->max_samples != c->params.max_samples && memcmp(&same, &c->params, sizeof(vpt_params)) == 0) { c->params.max_samples = p->max_samples; return VPT_OK; }
     }
+    { int rd = drain(c); if (rd) return rd; }
+    c->state_gen++;
     const bool flags_changed = c->params.flags != p->flags;
     c->dsc.strict_hits = (p->flags & VPT_FLAG_LOCAL_HITS) ? 1u : 0u;
     c->params = *p;
@@ -991,7 +1269,9 @@ int vpt_set_volumes(vpt_ctx* c, const vpt_volume* v, uint32_t count) {
         if (!(v[i].density > 0.0f)) return fail(c, VPT_ERR_INVALID_ARGUMENT, "volume density must be > 0");  // -log(u)/0 (Sampler.slang:427)
     }
     HIPCHK(c, hipSetDevice(c->cfg.device));
+    { int rd = drain(c); if (rd) return rd; }
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->state_gen++;
     if (c->d_volumes) { (void)hipFree(c->d_volumes); c->d_volumes = nullptr; }
     c->volumes.assign(v, v + count);
     if (count) {
@@ -1022,7 +1302,9 @@ int vpt_add_density_grid(vpt_ctx* c, uint32_t dx, uint32_t dy, uint32_t dz, cons
                 if (block_max[bi] < dens) block_max[bi] = dens;
             }
     HIPCHK(c, hipSetDevice(c->cfg.device));
+    { int rd = drain(c); if (rd) return rd; }
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->state_gen++;
     DensityGrid g{};
     float *dv = nullptr, *db = nullptr;
     HIPCHK(c, hipMalloc((void**)&dv, n * 4));
@@ -1041,7 +1323,9 @@ int vpt_clear_density_grids(vpt_ctx* c) {
     if (!c) return VPT_ERR_INVALID_ARGUMENT;
     for (const vpt_volume& v : c->volumes) if (v.density_data_index >= 0) return fail(c, VPT_ERR_INVALID_ARGUMENT, "a volume still references a density grid");
     HIPCHK(c, hipSetDevice(c->cfg.device));
+    { int rd = drain(c); if (rd) return rd; }
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->state_gen++;
     for (DensityGrid& g : c->grids) { (void)hipFree((void*)g.values); (void)hipFree((void*)g.block_max); }
     c->grids.clear();
     if (c->d_grids) { (void)hipFree(c->d_grids); c->d_grids = nullptr; }
@@ -1063,6 +1347,8 @@ int vpt_set_atmosphere(vpt_ctx* c, const vpt_atmosphere* a) {
     if (a && (!(a->planet_radius > 0.0f) || !(a->atmosphere_height > 0.0f) || !(a->rayleigh_density_falloff > 0.0f) || !(a->mie_density_falloff > 0.0f) ||
               !(a->ozone_density_falloff > 0.0f)))
         return fail(c, VPT_ERR_INVALID_ARGUMENT, "planet radius, atmosphere height and the density falloffs must be > 0");
+    { int rd = drain(c); if (rd) return rd; }
+    c->state_gen++;
     c->dsc.atm_on = a ? 1u : 0u;
     if (a) c->dsc.atm = *a;
     reset_accum(c);
@@ -1071,6 +1357,8 @@ int vpt_set_atmosphere(vpt_ctx* c, const vpt_atmosphere* a) {
 int vpt_set_phase_function(vpt_ctx* c, uint32_t phase) {
     if (!c) return VPT_ERR_INVALID_ARGUMENT;
     if (phase > VPT_PHASE_HENYEY_GREENSTEIN_PLUS_DRAINE) return fail(c, VPT_ERR_INVALID_ARGUMENT, "unknown phase function");
+    { int rd = drain(c); if (rd) return rd; }
+    c->state_gen++;
     c->phase = phase; c->dsc.phase = phase;
     reset_accum(c);
     return VPT_OK;
@@ -1082,6 +1370,8 @@ int vpt_resize(vpt_ctx* c, uint32_t w, uint32_t h) {
     uint32_t F = 1;
     int rc = check_render_size(c, w, h, &F);   // nothing is freed or changed for a size this context cannot hold
     if (rc != VPT_OK) return rc;
+    if ((rc = drain(c))) return rc;
+    c->state_gen++;
     c->cfg.width = w; c->cfg.height = h;
     reset_accum(c);
     return alloc_render_buffers(c);
@@ -1089,35 +1379,108 @@ int vpt_resize(vpt_ctx* c, uint32_t w, uint32_t h) {
 
 int vpt_reset(vpt_ctx* c) { if (!c) return VPT_ERR_INVALID_ARGUMENT; reset_accum(c); return VPT_OK; }
 
+// The next batch of a render call: how many dispatches it takes (PathTrace's accounting), with the path buffers grown to hold them.
+// *nf == 0: max_samples reached (PathTrace returns true and launches nothing).
+int next_batch(vpt_ctx* c, uint32_t left, uint32_t* nf) {
+    *nf = 0;
+    if (c->samples_accum >= c->params.max_samples) return VPT_OK;   // PathTracer.cpp:124-125
+    // dispatches until PathTrace would return true: samples = floor(dispatches / S^2) * spp (PathTracer.cpp:151-153)
+    const uint64_t S2 = (uint64_t)c->params.screen_chunk_count * c->params.screen_chunk_count;
+    const uint64_t frames_needed = ((uint64_t)c->params.max_samples + c->params.samples_per_frame - 1) / c->params.samples_per_frame;
+    const uint64_t disp_left = frames_needed * S2 - c->dispatch_count;
+    uint32_t n = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(left, c->frames_in_flight), disp_left);
+    if (n > c->frames_alloc) {   // the buffers grow to the largest batch asked for; nothing may be in flight while they are replaced
+        int rc = drain(c);
+        if (rc) return rc;
+        if ((rc = ensure_path_buffers(c, n))) return rc;
+        n = std::min(n, c->frames_alloc);   // (a size the library chose itself may have been halved)
+    }
+    if (media_on_streams(c)) {   // media on the streams: the batch is what the media streams hold
+        int rm = ensure_media_buffers(c);
+        if (rm) return rm;
+        n = std::min(n, c->media_frames);
+    }
+    *nf = n;
+    return VPT_OK;
+}
+void advance_counts(vpt_ctx* c, uint32_t nf) {
+    const uint64_t S2 = (uint64_t)c->params.screen_chunk_count * c->params.screen_chunk_count;
+    c->dispatch_count += nf;
+    c->frame_count = (uint32_t)(c->dispatch_count / S2);
+    c->samples_accum = c->frame_count * c->params.samples_per_frame;
+    c->full_valid = false;
+}
+
 int vpt_render(vpt_ctx* c, uint32_t dispatches, int* done) {
     if (!c) return VPT_ERR_INVALID_ARGUMENT;
     if (!c->has_scene) return fail(c, VPT_ERR_NO_SCENE, "vpt_render before vpt_set_scene");
     if (!c->buffers_ok) return fail(c, VPT_ERR_DEVICE, "no render buffers: the last vpt_resize failed");
     HIPCHK(c, hipSetDevice(c->cfg.device));
+    { int rd = drain(c); if (rd) return rd; }
     if (done) *done = 0;
     uint32_t left = dispatches;
     while (left > 0) {
-        if (c->samples_accum >= c->params.max_samples) { if (done) *done = 1; break; }  // PathTracer.cpp:124-125
-        // dispatches until PathTrace would return true: samples = floor(dispatches / S^2) * spp (PathTracer.cpp:151-153)
-        const uint64_t S2 = (uint64_t)c->params.screen_chunk_count * c->params.screen_chunk_count;
-        uint64_t frames_needed = ((uint64_t)c->params.max_samples + c->params.samples_per_frame - 1) / c->params.samples_per_frame;
-        uint64_t disp_left = frames_needed * S2 - c->dispatch_count;
-        uint32_t batch_cap = c->frames_in_flight;
-        if ((!c->volumes.empty() || c->dsc.atm_on) && !c->lds_scene && (c->cfg.pipeline == VPT_PIPELINE_AUTO || c->cfg.pipeline == VPT_PIPELINE_STAGED)) {
-            int rm = ensure_media_buffers(c);   // media on the streams: the batch is what the media streams hold
-            if (rm) return rm;
-            batch_cap = std::min(batch_cap, c->media_frames);
-        }
-        uint32_t nf = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(left, batch_cap), disp_left);
-        int rc = render_batch(c, nf, (uint32_t)c->dispatch_count);  // returns with the stream drained
+        uint32_t nf = 0;
+        int rc = next_batch(c, left, &nf);
         if (rc) return rc;
-        c->dispatch_count += nf;
-        c->frame_count = (uint32_t)(c->dispatch_count / S2);
-        c->samples_accum = c->frame_count * c->params.samples_per_frame;
+        if (nf == 0) { if (done) *done = 1; break; }
+        rc = render_batch(c, nf, (uint32_t)c->dispatch_count);  // returns with the stream drained
+        if (rc) return rc;
+        advance_counts(c, nf);
         left -= nf;
-        c->full_valid = false;
     }
-    if (done && c->samples_accum >= c->params.max_samples && left == 0) *done = c->samples_accum >= c->params.max_samples ? *done : 0;
+    return VPT_OK;
+}
+
+// PathTrace(cmd) as the reference has it: recorded, not waited for (include/vpt.h).
+int vpt_render_async(vpt_ctx* c, uint32_t dispatches, int* done, uint64_t* ticket) {
+    if (!c) return VPT_ERR_INVALID_ARGUMENT;
+    if (!c->has_scene) return fail(c, VPT_ERR_NO_SCENE, "vpt_render_async before vpt_set_scene");
+    if (!c->buffers_ok) return fail(c, VPT_ERR_DEVICE, "no render buffers: the last vpt_resize failed");
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    if (done) *done = 0;
+    uint32_t left = dispatches;
+    while (left > 0) {
+        int rc = finish_outstanding(c);   // the path buffers are single: an unfinished batch goes first
+        if (rc) return rc;
+        uint32_t nf = 0;
+        if ((rc = next_batch(c, left, &nf))) return rc;
+        if (nf == 0) { if (done) *done = 1; break; }
+        const uint64_t bounds = (uint64_t)c->P.max_depth * c->P.samples_per_frame;
+        const bool vol = !c->volumes.empty() || c->dsc.atm_on;
+        // a fixed schedule: every path has ended after `bounds` bounces, whatever the random numbers say
+        const bool fixed = c->depth_bounded && !vol && bounds <= VPT_ASYNC_MAX_BOUNCES;
+        const uint32_t enq = (uint32_t)std::min<uint64_t>(bounds, VPT_ASYNC_MAX_BOUNCES);
+        const uint32_t base = (uint32_t)c->dispatch_count;
+        BatchState b;
+        bool graphed = false;
+        // the fused pipeline's fixed batch, asked for again with nothing changed since the last two calls: replay it from a graph
+        const bool fused_auto = (c->cfg.pipeline == VPT_PIPELINE_FUSED || (c->cfg.pipeline == VPT_PIPELINE_AUTO && c->lds_scene)) && !vol;
+        if (c->graph_streak_gen == c->state_gen) c->graph_streak++; else { c->graph_streak = 0; c->graph_streak_gen = c->state_gen; }
+        if (fixed && fused_auto && !c->cfg.profile && !c->cfg.count_traversal && c->P.split == 1u && c->graph_streak >= 2u) {
+            if ((rc = enqueue_graph(c, nf, base, enq, &graphed))) return rc;
+            if (graphed) { b.n_slots = nf * c->P.shard_pixels; }
+        }
+        if (!graphed) {
+            if ((rc = enqueue_fixed(c, nf, base, enq, b))) return rc;
+        }
+        c->stats.samples += (uint64_t)b.n_slots * c->P.samples_per_frame;
+        advance_counts(c, nf);
+        left -= nf;
+        const uint64_t t = issue_ticket(c);
+        if (!fixed && b.n_slots) { c->out_active = true; c->out_batch = b; c->out_ticket = t; }
+    }
+    if (ticket) *ticket = c->tick_issued;
+    return VPT_OK;
+}
+
+int vpt_wait(vpt_ctx* c, uint64_t ticket) {
+    if (!c) return VPT_ERR_INVALID_ARGUMENT;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    if (ticket == 0 || ticket >= c->tick_issued) return drain(c);
+    if (c->out_active && c->out_ticket <= ticket) { int rc = finish_outstanding(c); if (rc) return rc; }
+    // the events are reused round-robin and recorded in stream order: the latest record of ticket's event belongs to a ticket >= it
+    HIPCHK(c, hipEventSynchronize(c->tick_ev[ticket % kTickets]));
     return VPT_OK;
 }
 
@@ -1126,6 +1489,7 @@ int vpt_get_radiance_device(vpt_ctx* c, void* dst) {
     if (!c->buffers_ok) return fail(c, VPT_ERR_DEVICE, "no render buffers: the last vpt_resize failed");
     if (c->P.shard_count > 1 && !c->full_valid) return fail(c, VPT_ERR_INVALID_ARGUMENT, "sharded context: call vpt_assemble_shards first");
     HIPCHK(c, hipSetDevice(c->cfg.device));
+    { int rd = drain(c); if (rd) return rd; }
     HIPCHK(c, hipMemcpyAsync(dst, whole_image(c), (size_t)c->P.width * c->P.height * 16, hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return VPT_OK;
@@ -1135,6 +1499,7 @@ int vpt_get_radiance(vpt_ctx* c, float* dst) {
     if (!c->buffers_ok) return fail(c, VPT_ERR_DEVICE, "no render buffers: the last vpt_resize failed");
     if (c->P.shard_count > 1 && !c->full_valid) return fail(c, VPT_ERR_INVALID_ARGUMENT, "sharded context: call vpt_assemble_shards first");
     HIPCHK(c, hipSetDevice(c->cfg.device));
+    { int rd = drain(c); if (rd) return rd; }
     HIPCHK(c, hipMemcpy(dst, whole_image(c), (size_t)c->P.width * c->P.height * 16, hipMemcpyDeviceToHost));
     return VPT_OK;
 }
@@ -1142,6 +1507,7 @@ int vpt_set_radiance(vpt_ctx* c, const float* src, uint32_t frame_count) {
     if (!c || !src) return VPT_ERR_INVALID_ARGUMENT;
     if (!c->buffers_ok) return fail(c, VPT_ERR_DEVICE, "no render buffers: the last vpt_resize failed");
     HIPCHK(c, hipSetDevice(c->cfg.device));
+    { int rd = drain(c); if (rd) return rd; }
     const uint32_t W = c->P.width;
     if (c->P.shard_count == 1) {
         HIPCHK(c, hipMemcpy(c->image, src, (size_t)W * c->P.height * 16, hipMemcpyHostToDevice));
@@ -1166,6 +1532,7 @@ int vpt_get_shard_device(vpt_ctx* c, void* dst) {
     if (!c || !dst) return VPT_ERR_INVALID_ARGUMENT;
     if (!c->buffers_ok) return fail(c, VPT_ERR_DEVICE, "no render buffers: the last vpt_resize failed");
     HIPCHK(c, hipSetDevice(c->cfg.device));
+    { int rd = drain(c); if (rd) return rd; }
     size_t bytes = (size_t)c->P.shard_pixels * 16, padded = vpt_shard_floats(c) * 4;
     HIPCHK(c, hipMemcpyAsync(dst, c->image, bytes, hipMemcpyDeviceToDevice, c->stream));
     if (padded > bytes) HIPCHK(c, hipMemsetAsync((char*)dst + bytes, 0, padded - bytes, c->stream));
@@ -1177,6 +1544,7 @@ int vpt_assemble_shards(vpt_ctx* c, const void* gathered, uint32_t shard_count) 
     if (shard_count != c->P.shard_count) return fail(c, VPT_ERR_INVALID_ARGUMENT, "shard_count mismatch");
     if (!c->buffers_ok) return fail(c, VPT_ERR_DEVICE, "no render buffers: the last vpt_resize failed");
     HIPCHK(c, hipSetDevice(c->cfg.device));
+    { int rd = drain(c); if (rd) return rd; }
     float* dst = c->P.shard_count > 1 ? c->full_image : c->image;
     launch_scatter_rows(c->stream, (const float*)gathered, dst, c->P.width, c->P.height, shard_count, (uint32_t)(vpt_shard_floats(c) / 4));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1185,12 +1553,9 @@ int vpt_assemble_shards(vpt_ctx* c, const void* gathered, uint32_t shard_count) 
     return VPT_OK;
 }
 
-// PostProcessor::PostProcess, PostProcessor.cpp:193-246.
-int vpt_postprocess(vpt_ctx* c, const vpt_post_params* pp, uint8_t* out8, float* bloom0) {
-    if (!c || !pp || !out8) return VPT_ERR_INVALID_ARGUMENT;
-    if (!c->buffers_ok) return fail(c, VPT_ERR_DEVICE, "no render buffers: the last vpt_resize failed");
-    if (c->P.shard_count > 1 && !c->full_valid) return fail(c, VPT_ERR_INVALID_ARGUMENT, "sharded context: call vpt_assemble_shards first");
-    HIPCHK(c, hipSetDevice(c->cfg.device));
+// PostProcessor::PostProcess, PostProcessor.cpp:193-246: the launches, on the context's stream, nothing waited for.
+namespace {
+int enqueue_post(vpt_ctx* c, const vpt_post_params* pp, bool bloom0) {
     int rc = ensure_post_buffers(c);
     if (rc) return rc;
     hipStream_t s = c->stream;
@@ -1256,7 +1621,24 @@ int vpt_postprocess(vpt_ctx* c, const vpt_post_params* pp, uint8_t* out8, float*
                                                   bloom0 ? c->mips[0] : nullptr, c->post_out, W, H, pp->bloom_threshold, pp->falloff_range, pp->bloom_strength,
                                                   pp->exposure, pp->gamma, linear_tap));
     }
-    HIPCHK(c, hipStreamSynchronize(s));
+    return VPT_OK;
+}
+int post_preconditions(vpt_ctx* c) {
+    if (!c->buffers_ok) return fail(c, VPT_ERR_DEVICE, "no render buffers: the last vpt_resize failed");
+    if (c->P.shard_count > 1 && !c->full_valid) return fail(c, VPT_ERR_INVALID_ARGUMENT, "sharded context: call vpt_assemble_shards first");
+    return VPT_OK;
+}
+}  // namespace
+
+int vpt_postprocess(vpt_ctx* c, const vpt_post_params* pp, uint8_t* out8, float* bloom0) {
+    if (!c || !pp || !out8) return VPT_ERR_INVALID_ARGUMENT;
+    int rc = post_preconditions(c);
+    if (rc) return rc;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    if ((rc = drain(c))) return rc;
+    if ((rc = enqueue_post(c, pp, bloom0 != nullptr))) return rc;
+    const uint32_t W = c->P.width, H = c->P.height;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     collect_timing(c);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpy(out8, c->post_out, (size_t)W * H * 4, hipMemcpyDeviceToHost));
@@ -1264,8 +1646,27 @@ int vpt_postprocess(vpt_ctx* c, const vpt_post_params* pp, uint8_t* out8, float*
     return VPT_OK;
 }
 
+// PostProcess(cmd) as the reference has it: recorded behind the render on the same stream, the RGBA8 image stays on the device.
+int vpt_postprocess_device(vpt_ctx* c, const vpt_post_params* pp, void* rgba8_device, uint64_t* ticket) {
+    if (!c || !pp) return VPT_ERR_INVALID_ARGUMENT;
+    int rc = post_preconditions(c);
+    if (rc) return rc;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    if ((rc = finish_outstanding(c))) return rc;   // the image must be complete: an unfinished batch is finished first
+    if ((rc = enqueue_post(c, pp, false))) return rc;
+    if (rgba8_device) HIPCHK(c, hipMemcpyAsync(rgba8_device, c->post_out, (size_t)c->P.width * c->P.height * 4, hipMemcpyDeviceToDevice, c->stream));
+    const uint64_t t = issue_ticket(c);
+    if (ticket) *ticket = t;
+    return VPT_OK;
+}
+const void* vpt_output_device(vpt_ctx* c) { return c ? c->post_out : nullptr; }
+
 int vpt_get_stats(vpt_ctx* c, vpt_stats* out) {
     if (!c || !out) return VPT_ERR_INVALID_ARGUMENT;
+    if (c->async_dirty || c->out_active) {
+        HIPCHK(c, hipSetDevice(c->cfg.device));
+        int rd = drain(c); if (rd) return rd;
+    }
     vpt_stats s = c->stats;
     s.frames = c->frame_count; s.dispatches = c->dispatch_count;
     s.total_vertex_count = c->total_vertices; s.total_index_count = c->total_indices;
@@ -1274,14 +1675,29 @@ int vpt_get_stats(vpt_ctx* c, vpt_stats* out) {
     s.emissive_mesh_count = (uint32_t)c->emissive.size(); s.emissive_triangle_count = c->emissive_tris;
     s.frames_in_flight = c->frames_in_flight; s.shard_pixels = c->P.shard_pixels;
     s.build_flags = c->sbvh ? VPT_BUILD_SBVH : 0u;
+    s.frames_allocated = c->frames_alloc;
+    s.set_scene_ms = c->set_scene_ms; s.bvh_build_ms = c->bvh_build_ms;
+    s.stack_spills[0] = s.stack_spills[1] = 0;
+    if (c->has_scene && c->stack_overflow_words && c->dsc.stack_overflow) {   // what the traversal kernels have written into their spill regions
+        HIPCHK(c, hipSetDevice(c->cfg.device));
+        unsigned long long h[2] = {0ull, 0ull};
+        HIPCHK(c, hipMemsetAsync(c->d_spill_count, 0, 16, c->stream));
+        hipLaunchKernelGGL(k_count_spilled, dim3(1024), dim3(256), 0, c->stream, c->dsc.stack_overflow, c->stack_overflow_words, c->d_spill_count);
+        hipLaunchKernelGGL(k_count_spilled, dim3(1024), dim3(256), 0, c->stream, c->stack_overflow2, c->stack_overflow_words, c->d_spill_count + 1);
+        HIPCHK(c, hipMemcpyAsync(h, c->d_spill_count, 16, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        s.stack_spills[0] = h[0]; s.stack_spills[1] = h[1];
+    }
     *out = s;
     return VPT_OK;
 }
 int vpt_reset_stats(vpt_ctx* c) {
     if (!c) return VPT_ERR_INVALID_ARGUMENT;
-    c->stats = vpt_stats{};
     HIPCHK(c, hipSetDevice(c->cfg.device));
+    { int rd = drain(c); if (rd) return rd; }
+    c->stats = vpt_stats{};
     HIPCHK(c, hipMemset(c->ctr, 0, sizeof(Counters)));
+    memset(c->h_ctr, 0, sizeof(HostCounters));
     return VPT_OK;
 }
 
@@ -1290,6 +1706,7 @@ int vpt_trace_rays(vpt_ctx* c, const vpt_ray* rays, uint32_t n, vpt_hit* hits) {
     if (!c->has_scene) return fail(c, VPT_ERR_NO_SCENE, "no scene");
     if (n == 0) return VPT_OK;
     HIPCHK(c, hipSetDevice(c->cfg.device));
+    { int rd = drain(c); if (rd) return rd; }
     vpt_ray* dr = nullptr; vpt_hit* dh = nullptr;
     HIPCHK(c, hipMalloc((void**)&dr, (size_t)n * sizeof(vpt_ray)));
     if (hipMalloc((void**)&dh, (size_t)n * sizeof(vpt_hit)) != hipSuccess) { (void)hipFree(dr); return fail(c, VPT_ERR_OUT_OF_MEMORY, "hipMalloc hits"); }
@@ -1362,6 +1779,7 @@ int vpt_comm_gather_shards(vpt_ctx* c, int root) {
     if (root < 0 || root >= c->comm_world) return fail(c, VPT_ERR_INVALID_ARGUMENT, "root out of range");
     if (!c->buffers_ok) return fail(c, VPT_ERR_DEVICE, "no render buffers: the last vpt_resize failed");
     HIPCHK(c, hipSetDevice(c->cfg.device));
+    { int rd = drain(c); if (rd) return rd; }
     const bool is_root = c->comm_rank == root;
     if (is_root) { int rc = ensure_gather_buf(c); if (rc) return rc; }
     // every rank contributes its rows padded to the largest shard (the image buffer is allocated at that size);
@@ -1412,6 +1830,7 @@ int vpt_multi_gather_shards(vpt_ctx* const* ctxs, uint32_t count, uint32_t root)
         if (!c || c->P.shard_rank != k || c->P.shard_count != count || c->P.width != R->P.width || c->P.height != R->P.height || !c->buffers_ok)
             return fail(R, VPT_ERR_INVALID_ARGUMENT, "vpt_multi_gather_shards: context k must be shard k of the same image");
     }
+    for (uint32_t k = 0; k < count; k++) { HIPCHK(R, hipSetDevice(ctxs[k]->cfg.device)); int rd = drain(ctxs[k]); if (rd) return rd; }
     HIPCHK(R, hipSetDevice(R->cfg.device));
     int rc = ensure_gather_buf(R);
     if (rc) return rc;
@@ -1458,6 +1877,7 @@ int vpt_lab_trace(vpt_ctx* c, uint32_t variant, uint32_t any_hit, const uint32_t
     if (c->lds_scene) return fail(c, VPT_ERR_UNSUPPORTED, "the trace lab runs on scenes whose BVH lives in memory");
     if (c->lab_n == 0) return fail(c, VPT_ERR_INVALID_ARGUMENT, "vpt_lab_trace before vpt_lab_set_rays");
     HIPCHK(c, hipSetDevice(c->cfg.device));
+    { int rd = drain(c); if (rd) return rd; }
     if (variant == VPT_TRACE_VOTE8 && !c->dsc.nodes8) {   // BVH8 experiment: the same binary tree collapsed eight-wide, over the same leaf-ordered triangles
         std::vector<BvhNode> n4; std::vector<BvhNodeWide> w4; std::vector<BvhTri> lt; std::vector<BvhNode8> n8; int d = 0;
         build_bvh(c->bvh_input, n4, w4, lt, &d, &n8, c->sbvh);
