@@ -186,6 +186,9 @@ typedef struct vpt_config {
 /* Spatial splits in the BVH builder (bvh_build.hpp): identical images, pays on scenes of uneven triangle sizes only.
  * Per context, never read from the environment: two contexts of one process cannot silently build different trees. */
 #define VPT_BUILD_SBVH 1u
+/* Keep the general instantiation of the fused per-bounce kernel even when the scene qualifies for the class-specialised one (every
+ * texture 1x1 and a black environment: k_bounce<PLAIN>, kernels_path.hip).  Images are identical; this is the A/B switch of that choice. */
+#define VPT_BUILD_GENERAL_KERNELS 2u
 
 /* AUTO = FUSED when the BVH fits in LDS next to the traversal stacks, else STAGED. Results are identical. */
 #define VPT_PIPELINE_AUTO 0u
@@ -374,6 +377,8 @@ int vpt_wait(vpt_ctx* ctx, uint64_t ticket);
 /* GetOutputImageView(): device pointer to the RGBA8 UNORM image of the last vpt_postprocess / vpt_postprocess_device (width*height*4 bytes,
  * owned by the context, valid until vpt_resize / vpt_destroy); NULL before the first post-process. */
 const void* vpt_output_device(vpt_ctx* ctx);
+/* The same image read back (waits for outstanding work): width*height*4 bytes to host memory.  VPT_ERR_INVALID_ARGUMENT before the first post-process. */
+int vpt_get_output(vpt_ctx* ctx, uint8_t* rgba8_host);
 
 /* GetOutputImage(): the RGBA32F accumulation image (alpha 1). Whole image (shard_count==1, or after
  * vpt_assemble_shards) to a caller-owned host / device buffer of width*height*4 floats. */

@@ -80,3 +80,21 @@ def test_spatial_splits_keep_the_hits_and_cut_the_visits(vpt, oracle, tmp_path):
         refs = int([l for l in p.stdout.split("\n") if l.startswith("tris ")][0].split("references")[1].split()[0])
         assert refs == len(tris) if sb == "0" else len(tris) < refs <= 1.5 * len(tris)
     assert visits["1"][0] < 0.97 * visits["0"][0] and visits["1"][1] < 0.95 * visits["0"][1], visits
+
+
+def test_threaded_builder_equals_the_single_threaded_one(vpt, oracle, tmp_path):
+    """bvh_build.cpp builds large subtrees on threads of their own (the host build was 0.3 s of vpt_set_scene on the 511 k-triangle bust;
+    the reference builds on the device, PathTracer.cpp:484-505): same nodes, same leaf order, bit for bit."""
+    exe = str(tmp_path / "bvh_time")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-march=x86-64-v3", "-pthread", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                           "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "tools", "bvh_time.cpp"),
+                           os.path.join(ROOT, "vulkan-path-tracer_amd", "csrc", "bvh_build.cpp"), "-o", exe])
+    sc = vpt.scenes.glass_bust()
+    o = oracle.Oracle(sc, 8, 8); tris = o.triangles(); o.close()
+    assert len(tris) > 400000
+    tris.tofile(str(tmp_path / "tris.bin"))
+    out = subprocess.run([exe, str(tmp_path / "tris.bin")], capture_output=True, text=True, check=True).stdout.splitlines()
+    par, ser = out[0].split(), out[1].split()
+    assert par[0] == "parallel" and ser[0] == "serial"
+    assert par[3:] == ser[3:], (out[0], out[1])                       # nodes, triangles, depth, hash
+    print(out[0]); print(out[1])   # (the wall times depend on the cores the box really gives the process: reported by bench.py's set_scene block, not asserted here)

@@ -145,3 +145,25 @@ def test_two_stream_schedule_equals_the_serial_one(vpt, atrium):
         g = vpt.PathTracer(640, 360, frames_in_flight=16, profile=prof, pipeline=2); g.set_scene(atrium); g.set_params(P)
         g.render(48); imgs.append(g.radiance()); g.close()
     assert np.array_equal(imgs[0], imgs[1]) and np.array_equal(imgs[0], imgs[2])
+
+
+def test_traversal_counters_with_strict_hits(vpt, scenes):
+    """vpt_config.count_traversal together with VPT_FLAG_LOCAL_HITS on the streams pipeline (the strict instantiations did
+    not count, so the roofline's visit statistics read zero): a ray visits what it visits whatever validates its winner afterwards,
+    so the counters of the two modes agree up to the re-traced rays (none in this scene)."""
+    from importlib import import_module
+    abi = import_module("vulkan-path-tracer_amd._abi")
+    sc = scenes("cornell_box_glass")
+    stats = []
+    for strict in (False, True):
+        P = vpt.default_params(max_depth=6)
+        if strict:
+            P.flags |= abi.FLAG_LOCAL_HITS
+        g = vpt.PathTracer(160, 90, count_traversal=True, frames_in_flight=2); g.set_scene(sc); g.set_params(P); g.render(4)
+        stats.append(g.stats()); g.close()
+    a, b = stats
+    assert a["kernel_launches"]["join"] > 0 and b["kernel_launches"]["join"] > 0
+    for k in ("nodes_visited", "tris_tested", "shadow_nodes_visited", "shadow_tris_tested"):
+        assert a[k] > 0 and b[k] > 0, (k, a[k], b[k])
+        assert abs(a[k] - b[k]) <= 0.001 * a[k], (k, a[k], b[k])
+    assert a["closest_rays"] == b["closest_rays"] and a["shadow_rays"] == b["shadow_rays"]

@@ -111,6 +111,61 @@ def test_rejects_what_it_cannot_decode(tmp_path, cli):
     assert p.returncode != 0 and "2^28" in p.stderr
 
 
+def test_png_inflate_is_bounded_by_the_header(tmp_path, cli):
+    """(a) a small image whose IDAT inflates to far more than its header declares must not be inflated in full (the numpy
+    twin used zlib.decompress without a bound); (b) a header that declares a 1 GiB image over a few bytes of IDAT is refused before
+    the buffers for it are allocated, in both twins — deflate cannot expand 1032 : 1 past what is there."""
+    import time
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xffffffff)
+
+    def png(w, h, depth, ctype, idat):
+        return b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, 0)) + chunk(b"IDAT", idat) + chunk(b"IEND", b"")
+    bomb = png(4, 4, 8, 6, zlib.compress(b"\0" * (512 << 20), 9))    # 512 MiB of zeros in ~0.5 MB of IDAT behind a 4x4 header
+    t = time.perf_counter()
+    with pytest.raises(ValueError):
+        codec.decode_png(bomb)
+    assert time.perf_counter() - t < 0.5, "the numpy twin inflated the whole stream"
+    (tmp_path / "bomb.png").write_bytes(bomb)
+    p = subprocess.run([cli, "--decode-image", str(tmp_path / "bomb.png")], capture_output=True, text=True)
+    assert p.returncode != 0 and "inflate" in p.stderr
+    lie = png(16384, 16384, 16, 6, zlib.compress(b"\0" * 4096))      # 2^28 texels of RGBA16 = 2 GiB declared, 4 KB delivered
+    t = time.perf_counter()
+    with pytest.raises(ValueError):
+        codec.decode_png(lie)
+    assert time.perf_counter() - t < 0.5
+    (tmp_path / "lie.png").write_bytes(lie)
+    t = time.perf_counter()
+    p = subprocess.run([cli, "--decode-image", str(tmp_path / "lie.png")], capture_output=True, text=True)
+    assert p.returncode != 0 and "inflate" in p.stderr
+    assert time.perf_counter() - t < 1.0, "the C++ twin allocated (and zero-filled) the declared 2 GiB before looking at the stream"
+    # the bound does not reject what is legitimate: a highly compressible full-size image still decodes
+    flat = png(512, 512, 8, 6, zlib.compress(b"\0" * ((512 * 4 + 1) * 512), 9))
+    assert codec.decode_png(flat).shape == (512, 512, 4)
+
+
+def test_jpeg_scan_count_is_capped(tmp_path, cli):
+    """every SOS walks every MCU of the declared image, so a file repeating a tiny scan thousands of times costs
+    O(scans x pixels); both twins refuse more than 64 scans (a real progressive file has about ten)."""
+    data = open(os.path.join(IMAGES, "j444_prog.jpg"), "rb").read()
+    i = data.index(b"\xff\xda")
+    n = struct.unpack(">H", data[i + 2:i + 4])[0]
+    j = i + 2 + n
+    while not (data[j] == 0xff and data[j + 1] not in (0x00, 0xff) and not 0xd0 <= data[j + 1] <= 0xd7):
+        j += 1
+    scan = data[i:j]                        # the first scan: its SOS header and entropy data
+    assert codec.decode_jpeg(data).shape[2] == 4
+    many = data[:i] + scan * 80 + data[i:]
+    with pytest.raises(ValueError, match="too many scans"):
+        codec.decode_jpeg(many)
+    (tmp_path / "many.jpg").write_bytes(many)
+    p = subprocess.run([cli, "--decode-image", str(tmp_path / "many.jpg")], capture_output=True, text=True)
+    assert p.returncode != 0 and "too many scans" in p.stderr
+    (tmp_path / "some.jpg").write_bytes(data[:i] + scan * 20 + data[i:])   # below the cap: decodes, and identically in both twins
+    assert np.array_equal(cpp_decode(cli, str(tmp_path / "some.jpg"), tmp_path), codec.load_image(str(tmp_path / "some.jpg")))
+
+
 def make_fixtures():
     """How tests/golden/images was written (PIL 10; run once, results committed): python tests/test_image_codecs.py"""
     from PIL import Image

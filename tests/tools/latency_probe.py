@@ -1,0 +1,66 @@
+"""Probe (not a pytest): where a 1-frame batch spends its time.  Cornell box 1920x1080 depth 8 on the fused pipeline: per-kernel means
+(HIP events, profile mode) at 1 / 2 / 4 / 16 frames per batch, then the un-profiled per-frame wall clock of the blocking pair
+(vpt_render(1) + vpt_postprocess) and of the asynchronous pair with a one-frame lag, with and without the post chain.
+    python tests/tools/latency_probe.py [outdir]"""
+import importlib, json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+vpt = importlib.import_module("vulkan-path-tracer_amd")
+out_dir = os.path.join(ROOT, "gpurun_out", sys.argv[1] if len(sys.argv) > 1 else "r04")
+os.makedirs(out_dir, exist_ok=True)
+sc = vpt.scenes.Scene.load(os.path.join(ROOT, "tests", "golden", "cornell_box.npz"))
+P = vpt.default_params(max_depth=8, max_samples=0x7fffffff)
+res = {"profiled": [], "wall": {}}
+for F in (1, 2, 4, 16):
+    g = vpt.PathTracer(1920, 1080, frames_in_flight=F, profile=True)
+    g.set_scene(sc); g.set_params(P)
+    for _ in range(3):
+        g.render(F); g.postprocess()
+    g.reset_stats()
+    n = 20
+    for _ in range(n):
+        g.render(F); g.postprocess()
+    st = g.stats(); g.close()
+    row = {"frames_per_batch": F}
+    for k in ("primary", "bounce", "resolve", "bloom", "tonemap"):
+        L = st["kernel_launches"][k]
+        row[k] = {"launches_per_batch": L / n, "mean_us": round(st["kernel_ms"][k] / max(L, 1) * 1e3, 2), "sum_us_per_batch": round(st["kernel_ms"][k] / n * 1e3, 1)}
+    row["kernel_us_per_frame"] = round(sum(st["kernel_ms"].values()) / n / F * 1e3, 1)
+    res["profiled"].append(row); print(json.dumps(row), flush=True)
+g = vpt.PathTracer(1920, 1080, frames_in_flight=1)
+g.set_scene(sc); g.set_params(P)
+for _ in range(10):
+    g.render(1); g.postprocess()
+N = 200
+t = time.perf_counter()
+for _ in range(N):
+    g.render(1)
+res["wall"]["blocking_render_ms"] = (time.perf_counter() - t) / N * 1e3
+t = time.perf_counter()
+for _ in range(N):
+    g.render(1); g.postprocess()
+res["wall"]["blocking_render_post_ms"] = (time.perf_counter() - t) / N * 1e3
+for with_post in (False, True):
+    for _ in range(8):
+        g.render_async(1)
+    g.wait()
+    t = time.perf_counter(); prev = 0
+    for _ in range(N):
+        _, cur = g.render_async(1)
+        if with_post:
+            cur = g.postprocess_device()
+        if prev:
+            g.wait(prev)
+        prev = cur
+    g.wait()
+    res["wall"]["async_render%s_ms" % ("_post" if with_post else "")] = (time.perf_counter() - t) / N * 1e3
+# issue cost alone: how long the host needs to enqueue a frame (no waiting until the end)
+t = time.perf_counter()
+for _ in range(N):
+    g.render_async(1); g.postprocess_device()
+res["wall"]["host_issue_ms_per_frame"] = (time.perf_counter() - t) / N * 1e3
+g.wait()
+res["wall"]["graph_launches"] = g.stats()["graph_launches"]
+g.close()
+print(json.dumps(res["wall"]))
+json.dump(res, open(os.path.join(out_dir, "latency_probe.json"), "w"), indent=1)

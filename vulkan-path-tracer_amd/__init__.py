@@ -169,14 +169,10 @@ class PathTracer:
         return self.lib.vpt_output_device(self.ctx)
 
     def output_to_host(self):
-        """The RGBA8 image the last post-process left on the device, copied out (test helper; needs torch for the copy)."""
-        import torch
-        self.wait()
-        ptr = self.output_device()
-        out = torch.empty((self.height, self.width, 4), dtype=torch.uint8, device="cuda")
-        rc = torch.cuda.cudart().cudaMemcpy(out.data_ptr(), ptr, out.numel(), 3)
-        assert int(rc) == 0
-        return out.cpu().numpy()
+        """vpt_get_output: the RGBA8 image the last post-process left on the device, read back (drains)."""
+        out = np.empty((self.height, self.width, 4), np.uint8)
+        _check(self.lib, self.ctx, self.lib.vpt_get_output(self.ctx, out.ctypes.data), "vpt_get_output")
+        return out
 
     def radiance(self):
         out = np.empty((self.height, self.width, 4), np.float32)

@@ -220,6 +220,7 @@ PROTOTYPES = {
     "vpt_postprocess_device": (C.c_int, [C.c_void_p, C.POINTER(PostParams), C.c_void_p, C.POINTER(C.c_uint64)]),
     "vpt_wait": (C.c_int, [C.c_void_p, C.c_uint64]),
     "vpt_output_device": (C.c_void_p, [C.c_void_p]),
+    "vpt_get_output": (C.c_int, [C.c_void_p, C.c_void_p]),
     "vpt_get_radiance": (C.c_int, [C.c_void_p, C.c_void_p]),
     "vpt_get_radiance_device": (C.c_int, [C.c_void_p, C.c_void_p]),
     "vpt_set_radiance": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32]),

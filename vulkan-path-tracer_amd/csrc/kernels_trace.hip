@@ -351,9 +351,9 @@ void launch_trace(hipStream_t s, uint32_t blocks, uint32_t variant, bool any, bo
 #define VPT_LV(W, T) do { if (any) { if (count) hipLaunchKernelGGL((k_trace_vote<true, true, W, T>), g, b, lds, s, sc, a, ctr); else hipLaunchKernelGGL((k_trace_vote<true, false, W, T>), g, b, lds, s, sc, a, ctr); } \
                           else { if (count) hipLaunchKernelGGL((k_trace_vote<false, true, W, T>), g, b, lds, s, sc, a, ctr); else hipLaunchKernelGGL((k_trace_vote<false, false, W, T>), g, b, lds, s, sc, a, ctr); } } while (0)
     if (variant == VPT_TRACE_BASE) VPT_LT(k_trace_base); else if (variant == VPT_TRACE_VOTE8) VPT_LV(true, false);
-    else if (sc.strict_hits) {   // VPT_FLAG_LOCAL_HITS: the validating instantiations (default vote parameters)
-        if (any) hipLaunchKernelGGL((k_trace_vote<true, false, false, true, true>), g, b, lds, s, sc, a, ctr);
-        else hipLaunchKernelGGL((k_trace_vote<false, false, false, true, true>), g, b, lds, s, sc, a, ctr);
+    else if (sc.strict_hits) {   // VPT_FLAG_LOCAL_HITS: the validating instantiations (default vote parameters; the counting ones read them from a.param)
+        if (any) { if (count) hipLaunchKernelGGL((k_trace_vote<true, true, false, false, true>), g, b, lds, s, sc, a, ctr); else hipLaunchKernelGGL((k_trace_vote<true, false, false, true, true>), g, b, lds, s, sc, a, ctr); }
+        else { if (count) hipLaunchKernelGGL((k_trace_vote<false, true, false, false, true>), g, b, lds, s, sc, a, ctr); else hipLaunchKernelGGL((k_trace_vote<false, false, false, true, true>), g, b, lds, s, sc, a, ctr); }
     }
     else if (a.param == kVoteParamDefault) VPT_LV(false, true); else VPT_LV(false, false);
 #undef VPT_LV
@@ -366,9 +366,11 @@ void launch_trace_shadow(hipStream_t s, uint32_t blocks, bool light, bool count,
     const dim3 g(blocks), b(kTraverseBlock);
 #define VPT_LS(L, C, T, RO, RD, VIS, LEN, HEAD) hipLaunchKernelGGL((k_trace_shadow<L, C, T>), g, b, lds, s, sc, RO, RD, VIS, LEN, HEAD, ctr, param)
     const bool tuned = param == kVoteParamDefault && !count;
-    if (sc.strict_hits) {   // VPT_FLAG_LOCAL_HITS
-        if (light) hipLaunchKernelGGL((k_trace_shadow<true, false, true, true>), g, b, lds, s, sc, ss.LTO, ss.LTD, ss.vis_light, &sctr->light_len.v, &sctr->light_head.v, ctr, param);
-        else hipLaunchKernelGGL((k_trace_shadow<false, false, true, true>), g, b, lds, s, sc, ss.SKO, ss.SKD, ss.vis_sky, &sctr->sky_len.v, &sctr->sky_head.v, ctr, param);
+    if (sc.strict_hits) {   // VPT_FLAG_LOCAL_HITS (with vpt_config.count_traversal: the counting instantiations, so the visit statistics are not silently zero)
+        if (light) { if (count) hipLaunchKernelGGL((k_trace_shadow<true, true, false, true>), g, b, lds, s, sc, ss.LTO, ss.LTD, ss.vis_light, &sctr->light_len.v, &sctr->light_head.v, ctr, param);
+                     else hipLaunchKernelGGL((k_trace_shadow<true, false, true, true>), g, b, lds, s, sc, ss.LTO, ss.LTD, ss.vis_light, &sctr->light_len.v, &sctr->light_head.v, ctr, param); }
+        else { if (count) hipLaunchKernelGGL((k_trace_shadow<false, true, false, true>), g, b, lds, s, sc, ss.SKO, ss.SKD, ss.vis_sky, &sctr->sky_len.v, &sctr->sky_head.v, ctr, param);
+               else hipLaunchKernelGGL((k_trace_shadow<false, false, true, true>), g, b, lds, s, sc, ss.SKO, ss.SKD, ss.vis_sky, &sctr->sky_len.v, &sctr->sky_head.v, ctr, param); }
     } else if (light) {
         if (tuned) VPT_LS(true, false, true, ss.LTO, ss.LTD, ss.vis_light, &sctr->light_len.v, &sctr->light_head.v);
         else if (count) VPT_LS(true, true, false, ss.LTO, ss.LTD, ss.vis_light, &sctr->light_len.v, &sctr->light_head.v);

@@ -527,7 +527,7 @@ void update_depth_bounded(vpt_ctx* c) {
     c->depth_bounded = bounded;
     // the scene class the fused kernel is specialised for (kernels_path.hip k_bounce<PLAIN>): what k_precompute_materials turns into
     // MatResolved.flags == 63 for every material, and k_precompute_lights into uniform light samplers
-    bool plain = c->dsc.env_black != 0u;
+    bool plain = c->dsc.env_black != 0u && !(c->cfg.build_flags & VPT_BUILD_GENERAL_KERNELS);
     auto one = [&](uint32_t t) { return t < c->tex_1x1.size() && c->tex_1x1[t] != 0; };
     for (const vpt_material& m : c->materials)
         if (!(one(m.base_color_texture) && one(m.normal_texture) && one(m.roughness_texture) && one(m.metallic_texture) && one(m.emissive_texture))) plain = false;
@@ -1660,6 +1660,15 @@ int vpt_postprocess_device(vpt_ctx* c, const vpt_post_params* pp, void* rgba8_de
     return VPT_OK;
 }
 const void* vpt_output_device(vpt_ctx* c) { return c ? c->post_out : nullptr; }
+int vpt_get_output(vpt_ctx* c, uint8_t* out8) {
+    if (!c || !out8) return VPT_ERR_INVALID_ARGUMENT;
+    if (!c->post_out) return fail(c, VPT_ERR_INVALID_ARGUMENT, "vpt_get_output before the first post-process");
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    { int rd = drain(c); if (rd) return rd; }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(out8, c->post_out, (size_t)c->post_w * c->post_h * 4, hipMemcpyDeviceToHost));
+    return VPT_OK;
+}
 
 int vpt_get_stats(vpt_ctx* c, vpt_stats* out) {
     if (!c || !out) return VPT_ERR_INVALID_ARGUMENT;
@@ -1674,7 +1683,7 @@ int vpt_get_stats(vpt_ctx* c, vpt_stats* out) {
     s.bvh_node_bytes = c->lds_scene ? sizeof(BvhNodeWide) : sizeof(BvhNode); s.bvh_tri_bytes = sizeof(BvhTri);
     s.emissive_mesh_count = (uint32_t)c->emissive.size(); s.emissive_triangle_count = c->emissive_tris;
     s.frames_in_flight = c->frames_in_flight; s.shard_pixels = c->P.shard_pixels;
-    s.build_flags = c->sbvh ? VPT_BUILD_SBVH : 0u;
+    s.build_flags = (c->sbvh ? VPT_BUILD_SBVH : 0u) | (c->cfg.build_flags & VPT_BUILD_GENERAL_KERNELS);
     s.frames_allocated = c->frames_alloc;
     s.set_scene_ms = c->set_scene_ms; s.bvh_build_ms = c->bvh_build_ms;
     s.stack_spills[0] = s.stack_spills[1] = 0;

@@ -26,6 +26,7 @@ namespace {
 // No image this importer accepts has more texels than this (the texel pool vpt_set_scene accepts is < 4 GiB; ADVICE r2: a
 // crafted header must not force a multi-GiB allocation before any pixel data has been validated).
 constexpr uint64_t kMaxTexels = 1ull << 28;   // 16384 x 16384
+constexpr int kMaxJpegScans = 64;             // a progressive file of real encoders has about ten
 
 // ------------------------------------------------------------------------------------------------ PNG
 inline int paeth(int a, int b, int c) {
@@ -116,6 +117,9 @@ bool DecodePNG(const std::string& f, const std::string& path, TextureAsset& out,
         const uint32_t pw = (I.w - xo[k] + xs[k] - 1) / xs[k], ph = (I.h - yo[k] + ys[k] - 1) / ys[k];
         if (I.w > (uint32_t)xo[k] && I.h > (uint32_t)yo[k] && pw && ph) total += (((size_t)pw * bits + 7) / 8 + 1) * ph;
     }
+    // deflate expands at most ~1032 : 1: a stream too short for the size the header declares is rejected BEFORE the (up to 2 GiB) buffers
+    // below are allocated and zero-filled — a crafted header with a few KB of IDAT costs nothing
+    if ((uint64_t)idat.size() * 1032ull + 1024ull < (uint64_t)total) { error = "PNG inflate failed: " + path; return false; }
     std::vector<uint8_t> raw(total);
     uLongf dl = (uLongf)raw.size();
     if (uncompress(raw.data(), &dl, (const Bytef*)idat.data(), (uLong)idat.size()) != Z_OK || dl != raw.size()) { error = "PNG inflate failed: " + path; return false; }
@@ -509,6 +513,7 @@ struct Jpeg {
     bool decode_file() {
         if (get8() != 0xff || get8() != 0xd8) return fail("not a JPEG");
         bool have_sof = false, have_scan = false;
+        int scans = 0;
         while (true) {
             int m = next_marker();
             while (m < 0 && p < end) m = next_marker();   // garbage between segments
@@ -516,6 +521,7 @@ struct Jpeg {
             if (m == 0xd9) break;
             if (m == 0xda) {
                 if (!have_sof) return fail("SOS before SOF");
+                if (++scans > kMaxJpegScans) return fail("too many scans");   // every scan walks every MCU of the image: bounded work for a crafted file
                 const int len = get16();
                 if (!read_sos(len)) return false;
                 if (!decode_scan()) return false;

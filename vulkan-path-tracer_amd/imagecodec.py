@@ -17,6 +17,8 @@ _PNG_SIG = b"\x89PNG\r\n\x1a\n"
 MAX_TEXELS = 1 << 28
 
 
+MAX_JPEG_SCANS = 64   # a progressive file of real encoders has about ten
+
 # ---------------------------------------------------------------------------------------------------- PNG
 def _png_unfilter(raw, off, w, h, channels, depth, path):
     """One (sub)image: filtered scanlines at raw[off:] -> samples uint16 [h, w, channels], bytes consumed."""
@@ -111,16 +113,30 @@ def decode_png(b, path="<memory>"):
         if len(trns) < channels * 2:
             raise ValueError("bad PNG tRNS: %s" % path)
         key = np.array(struct.unpack(">%dH" % channels, trns[:channels * 2]), np.uint16)
+    # the inflated size is known from the header: inflate at most that much (a few KB of IDAT must not expand into gigabytes), and a
+    # stream too short to hold it (deflate expands at most ~1032 : 1) is rejected before anything is allocated — as the C++ twin does
+    passes = ((0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2))
+    bits = channels * depth
+    if not interlace:
+        total = ((w * bits + 7) // 8 + 1) * h
+    else:
+        total = sum((((w - xo + xs - 1) // xs * bits + 7) // 8 + 1) * ((h - yo + ys - 1) // ys) for xo, yo, xs, ys in passes if w > xo and h > yo)
+    data = b"".join(idat)
+    if len(data) * 1032 + 1024 < total:
+        raise ValueError("PNG inflate failed: %s" % path)
     try:
-        raw = zlib.decompress(b"".join(idat))
+        z = zlib.decompressobj()
+        raw = z.decompress(data, total + 1)
     except zlib.error:
+        raise ValueError("PNG inflate failed: %s" % path)
+    if len(raw) != total or not z.eof:
         raise ValueError("PNG inflate failed: %s" % path)
     if not interlace:
         img, used = _png_unfilter(raw, 0, w, h, channels, depth, path)
     else:
         img = np.zeros((h, w, channels), np.uint16)
         off = 0
-        for xo, yo, xs, ys in ((0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2)):
+        for xo, yo, xs, ys in passes:
             if w <= xo or h <= yo:
                 continue
             pw, ph = (w - xo + xs - 1) // xs, (h - yo + ys - 1) // ys
@@ -527,6 +543,7 @@ class _Jpeg:
         if self.get8() != 0xff or self.get8() != 0xd8:
             self.fail("not a JPEG")
         have_sof = have_scan = False
+        scans = 0
         while True:
             m = self.next_marker()
             while m < 0 and self.p < len(self.d):
@@ -536,6 +553,9 @@ class _Jpeg:
             if m == 0xda:
                 if not have_sof:
                     self.fail("SOS before SOF")
+                scans += 1
+                if scans > MAX_JPEG_SCANS:   # every scan walks every MCU of the image: bounded work for a crafted file (the C++ twin has the same cap)
+                    self.fail("too many scans")
                 self.read_sos(self.get16())
                 self.decode_scan()
                 have_scan = True
