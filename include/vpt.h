@@ -181,6 +181,14 @@ typedef struct vpt_config {
     uint32_t count_traversal; /* 1 = count BVH node/triangle visits (slower; for the roofline's algorithmic bytes) */
     uint32_t pipeline;   /* VPT_PIPELINE_* */
     uint32_t build_flags; /* VPT_BUILD_*: how vpt_set_scene builds the BVH of this context (reported back in vpt_stats.build_flags) */
+    /* Path regeneration: frames of PATHS a batch keeps in flight at a time.  A batch of F frames has F x pixels samples; with K < F resident
+     * frames a lane whose sample has ended starts the same pixel's sample K frames later in the same launch (a fresh camera ray; seeds
+     * depend on pixel and frame only, the running mean is applied in frame order when the batch has finished), so every launch works on
+     * ~K x pixels paths until the samples run out — no shrinking launches after the first bounces, ~290 B per resident path + 48 B per
+     * sample instead of 380 B per sample.  0 = ~32M paths (16 frames at 1080p); a value >= the batch size keeps every sample resident
+     * (round 3's schedule).  Media batches, split-screen dispatch and VPT_PIPELINE_STAGED_R1 always keep every sample resident.
+     * Images do not depend on it, bit for bit.  Reference loop being unrolled: RayGen.slang:28-33,116-159. */
+    uint32_t resident_frames;
 } vpt_config;
 
 /* Spatial splits in the BVH builder (bvh_build.hpp): identical images, pays on scenes of uneven triangle sizes only.
@@ -241,7 +249,9 @@ typedef struct vpt_stats {
     uint32_t shard_pixels;
     uint32_t bvh8_nodes;       /* eight-wide nodes of the BVH8 experiment (0 until VPT_TRACE_VOTE8 was used) */
     uint32_t build_flags;      /* VPT_BUILD_* the scene's BVH was built with */
-    uint32_t frames_allocated; /* frames the path-record buffers currently hold (grows with the largest batch requested, <= frames_in_flight) */
+    uint32_t frames_allocated; /* frames of samples the buffers currently hold (grows with the largest batch requested, <= frames_in_flight) */
+    uint32_t resident_frames;  /* frames of paths the queues / stream records hold (vpt_config.resident_frames; < frames_allocated when paths are regenerated) */
+    uint32_t reserved0;
     uint32_t graph_launches;   /* batches replayed from a captured hipGraph by vpt_render_async since vpt_reset_stats */
     /* Words of the traversal stacks' global SPILL regions written since vpt_set_scene (a lane's stack is 14 LDS entries, deeper entries
      * spill to a per-thread region; vpt_api.hip keeps one region per concurrently running traversal grid): [0] the context's main

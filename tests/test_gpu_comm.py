@@ -191,8 +191,10 @@ def test_bench_line_contract_single_gpu():
     r = line["roofline"]
     assert r["bound"] in ("valu", "hbm") and r["unit"] == "GB/s" and r["peak"] == 8000.0 and 0 < r["frac"] <= 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
     assert r["kernel"] in r["kernels"] and r["traversal"]["nodes_per_closest_ray"] > 0
-    lat = line["latency"]   # the reference's per-frame call pattern: vpt_render(ctx, 1) + vpt_postprocess
-    assert lat["frame_ms"] > 0 and abs(lat["frame_ms"] - lat["render_1spp_ms"] - lat["postprocess_ms"]) < 1e-3
+    lat = line["latency"]   # the reference's per-frame call pattern, blocking (vpt_render(ctx, 1) + vpt_postprocess) and asynchronous
+    assert lat["blocking_frame_ms"] > 0 and abs(lat["blocking_frame_ms"] - lat["render_1spp_ms"] - lat["postprocess_ms"]) < 1e-3
+    assert 0 < lat["frame_ms"] <= lat["blocking_frame_ms"] * 1.05 and lat["graph"] is True
+    assert line["set_scene"]["set_scene_ms"] > 0
     assert r["pmc"]["rule"] and (r["pmc"]["stale"] or r["valu"] is None or 0 < r["valu"]["frac"] <= 1.0)
     c = line["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "Msamples/s" and c["value"] > 0 and c["cores"] >= 1 and "frames" in c["sample"]

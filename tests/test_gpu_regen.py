@@ -1,0 +1,100 @@
+"""Path regeneration (vpt_config.resident_frames; RenderParams::regen_stride): a batch of F frames with only K < F frames of paths in
+flight — a lane whose sample has ended starts the same pixel's sample K frames later in the same launch.  Seeds depend on (pixel, frame)
+only and the running mean is applied in frame order after the batch, so the image must equal the all-resident schedule's and the
+oracle's bit for bit, for every K, on every pipeline that regenerates (fused, streams, class-sorted streams), with several samples
+per frame, across batches, and on row shards."""
+import copy
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_image(oracle, sc, w, h, params, frames):
+    o = oracle.Oracle(sc, w, h)
+    o.set_params(params)
+    o.render(frames)
+    ref = o.radiance()
+    o.close()
+    return ref
+
+
+@pytest.mark.parametrize("name,pipeline,depth", [("cornell_box", 0, 8), ("cornell_box", 1, 8), ("cornell_box_glass", 0, 12), ("cornell_box_glass", 4, 12), ("cornell_box_glass", 1, 12),
+                                                 ("viking_room", 0, 6)])
+def test_regenerated_batches_equal_the_oracle(vpt, oracle, scenes, name, pipeline, depth):
+    sc, w, h, frames = scenes(name), 96, 54, 13
+    p = vpt.default_params(max_depth=depth)
+    ref = oracle_image(oracle, sc, w, h, p, frames)
+    for K in (1, 3, 5, 13):
+        g = vpt.PathTracer(w, h, pipeline=pipeline, frames_in_flight=frames, resident_frames=K)
+        g.set_scene(sc); g.set_params(p)
+        g.render(frames)
+        st = g.stats()
+        assert st["resident_frames"] == K and st["frames_allocated"] == frames and st["samples"] == w * h * frames
+        assert np.array_equal(g.radiance(), ref), (name, pipeline, K)
+        g.close()
+
+
+def test_regeneration_with_samples_per_frame_and_several_batches(vpt, oracle, scenes):
+    """samples_per_frame = 3 regenerates inside a slot first (RayGen.slang:33: the RNG stream continues), then across frames; the second
+    batch starts where the first ended (dispatch base) and a short last batch fits the resident window entirely."""
+    sc, w, h = scenes("cornell_box_glass"), 80, 45
+    p = vpt.default_params(max_depth=6, samples_per_frame=3)
+    ref = oracle_image(oracle, sc, w, h, p, 11)
+    for pipeline in (0, 1):
+        g = vpt.PathTracer(w, h, pipeline=pipeline, frames_in_flight=5, resident_frames=2)
+        g.set_scene(sc); g.set_params(p)
+        g.render(11)          # batches of 5, 5 and 1 frames
+        assert np.array_equal(g.radiance(), ref), pipeline
+        g.close()
+
+
+def test_regeneration_on_row_shards_and_after_a_material_edit(vpt, oracle, scenes):
+    sc, w, h, frames = copy.deepcopy(scenes("cornell_box")), 64, 37, 9      # 37 rows over 3 shards: ragged
+    p = vpt.default_params(max_depth=5)
+    whole = vpt.PathTracer(w, h, frames_in_flight=frames, resident_frames=2)
+    whole.set_scene(sc); whole.set_params(p); whole.render(frames)
+    img = whole.radiance()
+    assert np.array_equal(img, oracle_image(oracle, sc, w, h, p, frames))
+    for r in range(3):
+        g = vpt.PathTracer(w, h, shard_rank=r, shard_count=3, frames_in_flight=frames, resident_frames=2)
+        g.set_scene(sc); g.set_params(p); g.render(frames)
+        import torch
+        buf = torch.empty(g.shard_floats(), dtype=torch.float32, device="cuda")
+        g.shard_to_device(buf.data_ptr())
+        rows = len(range(r, h, 3))
+        assert np.array_equal(buf.cpu().numpy()[: rows * w * 4].reshape(rows, w, 4), img[r::3])
+        g.close()
+    m = whole.get_material(2); m.base_color[:] = (0.9, 0.2, 0.1)
+    whole.set_material(2, m); whole.render(frames)
+    sc.materials[2].update(base_color=(0.9, 0.2, 0.1))
+    assert np.array_equal(whole.radiance(), oracle_image(oracle, sc, w, h, p, frames))
+    whole.close()
+
+
+def test_configurations_that_keep_every_sample_resident(vpt, oracle, scenes):
+    """Media batches, split-screen dispatch and round 1's stage kernels do not regenerate: resident_frames is ignored there (and the
+    buffers grow accordingly), images as before."""
+    sc, w, h, frames = scenes("cornell_box_glass"), 64, 36, 6
+    p = vpt.default_params(max_depth=5)
+    ref = oracle_image(oracle, sc, w, h, p, frames)
+    g = vpt.PathTracer(w, h, pipeline=3, frames_in_flight=frames, resident_frames=2)     # VPT_PIPELINE_STAGED_R1
+    g.set_scene(sc); g.set_params(p); g.render(frames)
+    assert g.stats()["resident_frames"] == frames and np.array_equal(g.radiance(), ref)
+    g.close()
+    ps = vpt.default_params(max_depth=5, screen_chunk_count=2)
+    o = oracle.Oracle(sc, w, h); o.set_params(ps); o.render(8); ref2 = o.radiance(); o.close()
+    g = vpt.PathTracer(w, h, frames_in_flight=8, resident_frames=2)
+    g.set_scene(sc); g.set_params(ps); g.render(8)
+    assert g.stats()["resident_frames"] == 8 and np.array_equal(g.radiance(), ref2)
+    # the same context back on whole-frame dispatches (the larger buffers stay, so this batch is all-resident again)
+    g.set_params(p); g.render(frames)
+    assert np.array_equal(g.radiance(), ref)
+    g.close()
+    vol = vpt.volume(corner_min=(-0.6, -1.2, -0.6), corner_max=(0.6, 0.0, 0.6), color=(0.8, 0.8, 0.9), density=1.5)
+    o = oracle.Oracle(sc, w, h); o.set_params(p); o.set_volumes([vol]); o.render(frames); ref3 = o.radiance(); o.close()
+    g = vpt.PathTracer(w, h, frames_in_flight=frames, resident_frames=2)
+    g.set_scene(sc); g.set_params(p); g.set_volumes([vol]); g.render(frames)
+    assert g.stats()["resident_frames"] == frames and np.array_equal(g.radiance(), ref3)
+    g.close()

@@ -1,17 +1,42 @@
-"""Probe (not a pytest): throughput vs frames in flight (resident paths) for the three BASELINE scenes."""
+"""Probe (not a pytest): throughput vs RESIDENT frames for the three BASELINE scenes at 1920x1080, batches of 226 frames (the default
+batch), vpt_config.resident_frames = K: K = 226 keeps every sample resident (round 3's schedule: 448M paths, shrinking launches), smaller
+K regenerates paths (a lane whose sample has ended starts the pixel's sample K frames later).  Also the device memory each
+configuration holds.  Images are compared (first round, 24-frame batches) against K = batch.  Writes gpurun_out/<dir>/frames_sweep.json.
+    python tests/tools/frames_sweep.py [outdir] [scenes]"""
 import importlib, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
+import numpy as np
+import torch
 vpt = importlib.import_module("vulkan-path-tracer_amd")
-scenes = {"cornell": (vpt.scenes.Scene.load(os.path.join(ROOT, "tests", "golden", "cornell_box.npz")), 8), "atrium": (vpt.scenes.atrium(), 8), "bust": (vpt.scenes.glass_bust(), 32)}
-out = {}
-for name, (sc, depth) in scenes.items():
-    for F in (64, 128):
-        g = vpt.PathTracer(1920, 1080, frames_in_flight=F); g.set_scene(sc); g.set_params(vpt.default_params(max_depth=depth, max_samples=1 << 30))
-        for _ in range(5): g.render(F)
-        g.reset_stats(); t = time.time(); n = max(2, 128 // F)
+out_dir = os.path.join(ROOT, "gpurun_out", sys.argv[1] if len(sys.argv) > 1 else "r04")
+os.makedirs(out_dir, exist_ok=True)
+which = sys.argv[2].split(",") if len(sys.argv) > 2 else ["cornell", "atrium", "bust"]
+make = {"cornell": lambda: (vpt.scenes.Scene.load(os.path.join(ROOT, "tests", "golden", "cornell_box.npz")), 8), "atrium": lambda: (vpt.scenes.atrium(), 8), "bust": lambda: (vpt.scenes.glass_bust(), 32)}
+F = 226
+rows = []
+for name in which:
+    sc, depth = make[name]()
+    P = vpt.default_params(max_depth=depth, max_samples=1 << 30)
+    ref = None
+    for K in (226, 128, 64, 32, 16, 8, 4):
+        free0, _ = torch.cuda.mem_get_info()
+        g = vpt.PathTracer(1920, 1080, frames_in_flight=F, resident_frames=K); g.set_scene(sc); g.set_params(P)
+        g.render(24)
+        img = g.radiance()
+        if ref is None:
+            ref = img
+        same = bool(np.array_equal(img, ref))
+        g.reset()
+        for _ in range(2): g.render(F)
+        free1, _ = torch.cuda.mem_get_info()
+        g.reset_stats(); t = time.perf_counter(); n = 4
         for _ in range(n): g.render(F)
-        dt = time.time() - t; st = g.stats(); g.close()
-        out["%s_F%d" % (name, F)] = round(st["samples"] / dt / 1e6, 1)
-        print(name, F, out["%s_F%d" % (name, F)], flush=True)
-json.dump(out, open(os.path.join(ROOT, "gpurun_out", "frames_sweep.json"), "w"), indent=1)
+        dt = time.perf_counter() - t; st = g.stats(); g.close()
+        launches = sum(st["kernel_launches"][k] for k in ("primary", "bounce", "extend"))
+        row = {"scene": name, "batch_frames": F, "resident_frames": st["resident_frames"], "resident_paths_M": round(st["resident_frames"] * 1920 * 1080 / 1e6, 1),
+               "msamples_per_s": round(st["samples"] / dt / 1e6, 1), "device_GB": round((free0 - free1) / 2 ** 30, 2), "bounce_launches_per_batch": launches / n,
+               "image_identical_to_all_resident": same}
+        rows.append(row); print(json.dumps(row), flush=True)
+        assert same
+json.dump(rows, open(os.path.join(out_dir, "frames_sweep.json"), "w"), indent=1)

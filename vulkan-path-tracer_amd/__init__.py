@@ -67,9 +67,9 @@ class PathTracer:
     """Mirror of the reference's PathTracer + PostProcessor call surface over the C-ABI."""
 
     def __init__(self, width, height, device=0, shard_rank=0, shard_count=1, frames_in_flight=0, profile=False,
-                 count_traversal=False, pipeline=0, build_flags=0):
+                 count_traversal=False, pipeline=0, build_flags=0, resident_frames=0):
         self.lib = load_library()
-        cfg = _abi.Config(device, width, height, shard_rank, shard_count, frames_in_flight, int(profile), int(count_traversal), int(pipeline), int(build_flags))
+        cfg = _abi.Config(device, width, height, shard_rank, shard_count, frames_in_flight, int(profile), int(count_traversal), int(pipeline), int(build_flags), int(resident_frames))
         err = C.c_int(0)
         self.ctx = self.lib.vpt_create(C.byref(cfg), C.byref(err))
         if not self.ctx:

@@ -163,7 +163,7 @@ def default_post_params(**kw):
 class Config(C.Structure):
     _fields_ = [("device", C.c_int), ("width", C.c_uint32), ("height", C.c_uint32), ("shard_rank", C.c_uint32),
                 ("shard_count", C.c_uint32), ("frames_in_flight", C.c_uint32), ("profile", C.c_uint32),
-                ("count_traversal", C.c_uint32), ("pipeline", C.c_uint32), ("build_flags", C.c_uint32)]
+                ("count_traversal", C.c_uint32), ("pipeline", C.c_uint32), ("build_flags", C.c_uint32), ("resident_frames", C.c_uint32)]
 
 
 class Stats(C.Structure):
@@ -176,7 +176,7 @@ class Stats(C.Structure):
         ("bvh_nodes", C.c_uint32), ("bvh_triangles", C.c_uint32), ("bvh_node_bytes", C.c_uint32),
         ("bvh_tri_bytes", C.c_uint32), ("emissive_mesh_count", C.c_uint32), ("emissive_triangle_count", C.c_uint32),
         ("frames_in_flight", C.c_uint32), ("shard_pixels", C.c_uint32), ("bvh8_nodes", C.c_uint32), ("build_flags", C.c_uint32),
-        ("frames_allocated", C.c_uint32), ("graph_launches", C.c_uint32), ("stack_spills", C.c_uint64 * 2),
+        ("frames_allocated", C.c_uint32), ("resident_frames", C.c_uint32), ("reserved0", C.c_uint32), ("graph_launches", C.c_uint32), ("stack_spills", C.c_uint64 * 2),
         ("set_scene_ms", C.c_double), ("bvh_build_ms", C.c_double),
     ]
 

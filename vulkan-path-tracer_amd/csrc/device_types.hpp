@@ -196,6 +196,12 @@ struct RenderParams {
     float max_luminance, focus_distance, dof_strength;
     float sky_azimuth, sky_altitude, sky_intensity, emissive_pdf_bias;
     uint32_t flags, base_seed;
+    // Path regeneration (vpt_api.hip batch_begin): a batch of F frames keeps only K < F frames of paths resident.  A slot is a SAMPLE id
+    // (frame-in-batch * shard_pixels + shard pixel); when the sample in slot s has ended, its lane starts the sample s + regen_stride
+    // (same pixel, K frames later) while that is < regen_total — a fresh camera ray seeded as k_raygen_stream / k_bounce<FIRST> seed it
+    // (seeds depend on pixel and frame only) — instead of leaving the queue.  regen_stride == 0: off (every sample of the batch is
+    // resident).  batch_base = index of the batch's first dispatch (what the camera-ray kernels get as an argument).
+    uint32_t regen_stride, regen_total, batch_base;
     // Graph replays (vpt_render_async): when non-null, the batch's first dispatch index is read from here instead of the kernels'
     // dispatch_base / frame_base arguments, so that one captured batch serves every frame
     const uint32_t* dispatch_base_dev;
@@ -224,7 +230,7 @@ struct PathState {
     float4* CL;      // pending: light NEE contribution .xyz | global id of the sampled triangle
     float4* CLO;     //          light ray origin.xyz | dir.x
     float4* CLD;     //          light ray dir.yz
-    float4* L;       // pathLight.xyz                                          connect RW
+    float4* L;       // pathLight.xyz                                          connect RW   (round 1's stage kernels only: allocated with their records)
     float4* ACC;     // accumulatedLight of the frame (sum over samples_per_frame)  connect RW at path end
     float4* M;       // medium colour.rgb | density (only glass)               shade RW when refracting
     float* maniso;   // medium anisotropy
@@ -305,6 +311,8 @@ constexpr uint32_t kAppendExactBelow = 1u << 21;
 // connect flags (CE.w)
 constexpr uint32_t kCF_Sky = 1u, kCF_Light = 2u, kCF_Finalize = 4u, kCF_Clamp = 8u;
 constexpr uint32_t kCF_Alive = 16u;   // streams pipeline: the path lives on, PT.w is its entry in the NEXT queue (else: in this one)
+constexpr uint32_t kCF_NewFrame = 32u;   // with kCF_Finalize | kCF_Alive: the lane goes on with the sample regen_stride slots further (RenderParams), so the
+                                         // sample being finalised is (slot of the next-queue entry) - regen_stride
 
 struct Counters {
     uint32_t ray_count[2];    // active-path queue sizes (ping-pong by bounce parity)

@@ -401,7 +401,7 @@ __global__ __launch_bounds__(kTraverseBlock, 3) void k_bounce(DeviceScene sc, Re
                 if (VOL && aborted) {
                     o.want_sky = false; o.want_light = false; o.emitted = v3s(0.0f); o.csky = v3s(0.0f); o.clight = v3s(0.0f);
                     o.rng = in_.rng; o.new_depth = in_.depth; o.new_o = in_.porg; o.new_d = in_.pdir; o.new_pdf = in_.prev_pdf; o.bxdf = v3s(1.0f);
-                    o.in_medium = in_.in_medium; o.vdepth = in_.vdepth; o.cchan = in_.cchan; o.light_gid = 0xffffffffu; o.light_miss_ok = false;
+                    o.in_medium = in_.in_medium; o.vdepth = in_.vdepth; o.cchan = in_.cchan; o.light_gid = 0xffffffffu; o.light_miss_ok = false; o.next_slot = slot;
                 } else {
                     shade_core<VOL>(sc, P, ps, slot, in_, o);
                 }
@@ -488,7 +488,7 @@ __global__ __launch_bounds__(kTraverseBlock, 3) void k_bounce(DeviceScene sc, Re
                 pn = s_base[wave] + lanes_below(ma);
             }
             if (alive) {
-                queue_next[pn] = slot;
+                queue_next[pn] = o.next_slot;   // its own slot, or the pixel's next resident sample (path regeneration, shade_core.hpp)
                 ss.RA[parity ^ 1u][pn] = f4u(o.new_o, o.rng);
                 ss.RB[parity ^ 1u][pn] = f4u(o.new_d, o.new_depth | (o.in_medium ? 0x80000000u : 0u));
                 ss.RT[parity ^ 1u][pn] = f4(o.thr, o.new_pdf);

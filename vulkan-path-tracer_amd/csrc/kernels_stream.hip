@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256, 3) void k_shade_stream(DeviceScene sc, RenderP
             const uint32_t p_next = a_next.append(alive, &sctr->queue_len[parity ^ 1u].v);
             if (alive) {   // the survivor's records move to where its queue entry goes — pathLight included: the join stage then
                            // updates it in stream order (two coalesced streams) instead of a scattered read-modify-write by slot
-                queue_next[p_next] = slot;
+                queue_next[p_next] = o.next_slot;   // its own slot, or the pixel's next resident sample (path regeneration, shade_core.hpp)
                 st_stream(&ss.RA[parity ^ 1u][p_next], f4u(o.new_o, o.rng));
                 st_stream(&ss.RB[parity ^ 1u][p_next], f4u(o.new_d, o.new_depth | (o.in_medium ? 0x80000000u : 0u)));
                 st_stream(&ss.RT[parity ^ 1u][p_next], f4(o.thr, o.new_pdf));
@@ -271,7 +271,10 @@ __global__ __launch_bounds__(256) void k_join(RenderParams P, PathState ps, Stre
             // same waves in the same order, so these accesses are streams too
             if (on[k]) {
                 lp[k] = (fl[k] & kCF_Alive) ? ss.RL[parity ^ 1u][pos[k]] : ss.RL[parity][pos[k]];
-                if (fl[k] & kCF_Finalize) sl[k] = (fl[k] & kCF_Alive) ? queue_next[pos[k]] : queue[pos[k]];
+                if (fl[k] & kCF_Finalize) {
+                    sl[k] = (fl[k] & kCF_Alive) ? queue_next[pos[k]] : queue[pos[k]];
+                    if (fl[k] & kCF_NewFrame) sl[k] -= P.regen_stride;   // the next-queue entry already names the regenerated sample
+                }
             }
         }
 #pragma unroll

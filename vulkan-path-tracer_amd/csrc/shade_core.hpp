@@ -72,6 +72,7 @@ struct ShadeOut {
     int sky_kind;       // 0 surface, 1 box scatter event, 2 atmosphere scatter event (the three expressions differ in association)
     bool sky_add;       // false: trace and track (the draws count) but add nothing (ozone collision)
     int cchan;          // payload.ColorChannel after this bounce
+    uint32_t next_slot; // the slot a live path goes on in: its own, or (path regeneration, kCF_NewFrame) the one of the pixel's next resident sample
 };
 
 // The miss / closest-hit shader and the visibility-independent tail of the bounce loop for ONE path, on
@@ -338,6 +339,7 @@ __device__ __forceinline__ void shade_core(const DeviceScene& sc, const RenderPa
         out.new_o = new_o; out.new_d = new_d; out.new_pdf = new_pdf; out.bxdf = bxdf; out.cchan = in_.cchan;
         out.emitted = emitted; out.csky = csky; out.clight = clight;
         out.sky_o = sky_o; out.sky_d = sky_d; out.light_o = light_o; out.light_d = light_d;
+        out.next_slot = slot;
         return;
     }
     // ---- RayGen.slang:104-113: throughput, Russian roulette (drawn on every iteration), loop condition
@@ -348,6 +350,7 @@ __device__ __forceinline__ void shade_core(const DeviceScene& sc, const RenderPa
     if (!terminated) thr = thr / p;
     if (!(new_depth < P.max_depth)) terminated = true;
     uint32_t cflags = (want_sky ? kCF_Sky : 0u) | (want_light ? kCF_Light : 0u) | (new_depth != 1u ? kCF_Clamp : 0u);
+    uint32_t next_slot = slot;
     if (terminated) {
         cflags |= kCF_Finalize;
         if (P.samples_per_frame > 1) {
@@ -361,9 +364,27 @@ __device__ __forceinline__ void shade_core(const DeviceScene& sc, const RenderPa
                 alive = true;
             }
         }
+        // path regeneration: the frame's last sample of this slot has ended, the lane starts the pixel's next resident frame.  The new
+        // sample is seeded from (pixel, frame) alone, exactly as the camera-ray kernels seed it (RayGen.slang:28, PathTracer.cpp:139).
+        if (!alive && P.regen_stride != 0u) {
+            const uint32_t ns = slot + P.regen_stride;
+            if (ns < P.regen_total) {
+                uint32_t x, y, f;
+                pixel_of_slot(P, ns, x, y, f);
+                const uint32_t seed = pcg_hash(P.base_seed + P.batch_base + f);
+                rng.s = y + P.width * x + seed;
+                camera_ray(P, rng, x, y, new_o, new_d);
+                thr = v3s(1.0f); new_pdf = 1.0f; new_depth = 0u; in_medium = false; vdepth = 0u;
+                if (P.samples_per_frame > 1) { ps.sidx[ns] = 0u; ps.ACC[ns] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); }   // later finalisations add to it
+                next_slot = ns;
+                cflags |= kCF_NewFrame;
+                alive = true;
+            }
+        }
     } else {
         alive = true;
     }
+    out.next_slot = next_slot;
     out.alive = alive; out.terminated = terminated; out.want_sky = want_sky; out.want_light = want_light; out.in_medium = in_medium;
     out.rng = rng.s; out.new_depth = new_depth; out.cflags = cflags; out.light_gid = light_gid;
     out.light_miss_ok = light_miss_ok; out.vdepth = vdepth;

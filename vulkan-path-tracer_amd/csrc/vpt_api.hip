@@ -20,12 +20,14 @@ using namespace vpt;
 
 constexpr uint64_t kBytesPerPath = 380;          // core slot records 68 + stream records ~290 (slack included) + queues 8 + image share
 constexpr uint32_t kMaxFramesInFlight = 2048;   // frames of one batch (a 1/8 shard of 1080p holds ~448M paths at 1728 frames)
-constexpr uint64_t kResidentPaths = 448ull << 20;   // what a context keeps in flight by default (see check_render_size)
+constexpr uint64_t kResidentPaths = 448ull << 20;   // samples of a batch by default (see check_render_size)
+constexpr uint64_t kRegenResidentPaths = 32ull << 20;   // of which resident at a time when paths are regenerated (vpt_config.resident_frames == 0)
 
 // One wavefront batch in progress: what render_batch's stages hand to each other (and what an asynchronous batch leaves behind for
 // the call that finishes it).
 struct BatchState {
     uint32_t frames = 0, dispatch_base = 0, n_slots = 0;
+    uint32_t n_first = 0;   // slots the camera-ray launch starts (n_slots, or the resident part of it when paths are regenerated)
     bool fused = false, stream = false, media_stream = false, sorted = false, overlap = false, count = false;
     uint32_t parity = 0, k3 = 0;
     bool join_pending = false;
@@ -87,7 +89,8 @@ struct vpt_ctx {
     RenderParams P{};
     uint32_t frames_in_flight = 1;   // largest batch the context will render at once (the cap; vpt_config.frames_in_flight)
     uint32_t frames_cap = 0;     // upper bound of frames_in_flight after an out-of-memory failure of a size the library chose itself
-    uint32_t frames_alloc = 0;   // frames the path-record buffers hold now: they grow to the largest batch actually requested (ensure_path_buffers)
+    uint32_t frames_alloc = 0;   // frames of SAMPLES the slot-addressed buffers hold now: they grow to the largest batch actually requested (ensure_path_buffers)
+    uint32_t resident_alloc = 0; // frames of PATHS the queues and stream records hold (<= frames_alloc; less when paths are regenerated)
     bool depth_bounded = true;   // every path ends within max_depth * samples_per_frame bounces (no material scatters inside a medium): see vpt_render_async
     // asynchronous batches (vpt_render_async / vpt_postprocess_device / vpt_wait)
     hipEvent_t tick_ev[kTickets] = {};
@@ -211,7 +214,7 @@ void free_path_buffers(vpt_ctx* c) {
     if (c->cls_q) (void)hipFree(c->cls_q);
     c->cls_q = nullptr;
     c->ps = PathState{}; c->ss = StreamState{};
-    c->frames_alloc = 0;
+    c->frames_alloc = 0; c->resident_alloc = 0;
     c->state_gen++;   // a captured batch holds these addresses
 }
 void free_render_buffers(vpt_ctx* c) {
@@ -254,22 +257,26 @@ int check_render_size(vpt_ctx* c, uint32_t width, uint32_t height, uint32_t* fra
     return VPT_OK;
 }
 
-// Path records, queues and streams for `frames` frames of this shard (the caller has drained the streams).
-int alloc_path_buffers(vpt_ctx* c, uint32_t frames) {
+// Buffers for batches of up to `frames` frames of this shard of which `resident` frames of paths are in flight at a time (the caller
+// has drained the streams): slot-addressed records (frame sum, medium, per-sample words: 48 B per SAMPLE of the batch) and the queues
+// and stream records (~290 B per RESIDENT path).
+int alloc_path_buffers(vpt_ctx* c, uint32_t frames, uint32_t resident) {
     free_path_buffers(c);
     const RenderParams& P = c->P;
+    resident = std::min(resident, frames);
     if ((uint64_t)P.shard_pixels * frames >= (1ull << 31)) return fail(c, VPT_ERR_INVALID_ARGUMENT, "too many paths in flight");
-    uint32_t cap = P.shard_pixels * frames;
-    // slot-addressed records every pipeline uses: 3 float4 records + 4 dword arrays per slot (device_types.hpp PathState); the
+    const uint32_t samples = P.shard_pixels * frames;
+    uint32_t cap = P.shard_pixels * resident;
+    // slot-addressed records every pipeline uses: 2 float4 records + 4 dword arrays per slot (device_types.hpp PathState); the
     // records of round 1's stage kernels come with ensure_legacy_buffers()
-    const size_t kRecords = 3, kWords = 4;
-    size_t stride = ((size_t)cap + 63) & ~(size_t)63;
+    const size_t kRecords = 2, kWords = 4;
+    size_t stride = ((size_t)samples + 63) & ~(size_t)63;
     HIPCHK(c, hipMalloc(&c->ps_block, stride * (16 * kRecords + 4 * kWords)));
     float4* rb = (float4*)c->ps_block;
     PathState& s = c->ps;
     s = PathState{};
     s.capacity = cap;
-    s.L = rb; s.ACC = rb + stride; s.M = rb + stride * 2;
+    s.ACC = rb; s.M = rb + stride;
     uint32_t* wb = (uint32_t*)(rb + stride * kRecords);
     s.maniso = (float*)wb; s.sidx = wb + stride; s.vdepth = wb + stride * 2; s.cchan = (int32_t*)(wb + stride * 3);
     // streams written by chunked appends hold up to one unwritten chunk tail per wave that appended to them: at most
@@ -291,7 +298,7 @@ int alloc_path_buffers(vpt_ctx* c, uint32_t frames) {
         t.vis_sky = (unsigned char*)(t.SHI + sst); t.vis_light = t.vis_sky + sst;
         t.cap = (uint32_t)scap;
     }
-    c->frames_alloc = frames;
+    c->frames_alloc = frames; c->resident_alloc = resident;
     return VPT_OK;
 }
 
@@ -334,7 +341,7 @@ int alloc_render_buffers(vpt_ctx* c) {
         return VPT_OK;
     };
     rc = images();
-    if (rc == VPT_OK) rc = alloc_path_buffers(c, 1);
+    if (rc == VPT_OK) rc = alloc_path_buffers(c, 1, 1);
     if (rc != VPT_OK) {
         std::string keep = c->err;
         free_render_buffers(c);
@@ -347,23 +354,41 @@ int alloc_render_buffers(vpt_ctx* c) {
     return check_stream_slack(c);
 }
 
-// Grows the path buffers so that a batch of `want` frames (<= frames_in_flight) fits; the caller has drained the streams.  A size the
+// Frames of paths a batch of `frames` frames keeps resident.  Paths are regenerated (device_types.hpp RenderParams::regen_stride) on the
+// fused and the stream pipelines; round 1's stage kernels address a path's records by slot, media batches carry per-entry media streams
+// and split-screen dispatches map launch indices to pixels per dispatch: those keep every sample of the batch resident.
+bool regen_allowed(const vpt_ctx* c) {
+    if (!c->has_scene) return false;
+    const bool vol = !c->volumes.empty() || c->dsc.atm_on;
+    if (vol || c->P.split != 1u) return false;
+    if (c->cfg.pipeline == VPT_PIPELINE_STAGED_R1) return false;
+    if (c->lds_scene && c->cfg.pipeline != VPT_PIPELINE_AUTO && c->cfg.pipeline != VPT_PIPELINE_FUSED) return false;   // an LDS-sized scene forced into the staged pipeline runs round 1's kernels
+    return true;
+}
+uint32_t resident_frames_for(const vpt_ctx* c, uint32_t frames) {
+    if (!regen_allowed(c)) return frames;
+    uint64_t k = c->cfg.resident_frames;
+    if (k == 0) k = std::max<uint64_t>(1, kRegenResidentPaths / std::max<uint64_t>(1, c->P.shard_pixels));
+    return (uint32_t)std::min<uint64_t>(frames, k);
+}
+
+// Grows the buffers so that a batch of `want` frames (<= frames_in_flight) fits; the caller has drained the streams.  A size the
 // library chose itself (vpt_config.frames_in_flight == 0) is halved and tried again when the device runs out of memory after all
 // (another process, fragmentation) — frames_in_flight then drops to what was obtained and the caller renders in smaller batches;
 // an explicit size fails as it is and the context keeps the buffers it had.
 int ensure_path_buffers(vpt_ctx* c, uint32_t want) {
-    if (want <= c->frames_alloc) return VPT_OK;
-    const uint32_t old = std::max(c->frames_alloc, 1u);
-    uint32_t tryf = want;
+    if (want <= c->frames_alloc && resident_frames_for(c, want) <= c->resident_alloc) return VPT_OK;
+    const uint32_t old = std::max(c->frames_alloc, 1u), old_res = std::max(c->resident_alloc, 1u);
+    uint32_t tryf = std::max(want, old);
     while (true) {
-        int rc = alloc_path_buffers(c, tryf);
+        int rc = alloc_path_buffers(c, tryf, std::max(resident_frames_for(c, tryf), std::min(old_res, tryf)));
         if (rc == VPT_OK) break;
         std::string keep = c->err;
         free_path_buffers(c);
         (void)hipGetLastError();
         const bool oom = rc == VPT_ERR_OUT_OF_MEMORY || rc == VPT_ERR_DEVICE;
         if (!oom || c->cfg.frames_in_flight != 0 || tryf <= old) {
-            if (alloc_path_buffers(c, old) != VPT_OK) { free_path_buffers(c); (void)hipGetLastError(); c->buffers_ok = false; }
+            if (alloc_path_buffers(c, old, old_res) != VPT_OK) { free_path_buffers(c); (void)hipGetLastError(); c->buffers_ok = false; }
             c->err = keep;
             return rc;
         }
@@ -375,7 +400,7 @@ int ensure_path_buffers(vpt_ctx* c, uint32_t want) {
 }
 
 // Round 1's stage kernels (VPT_PIPELINE_STAGED_R1, VPT_FLAG_LOCAL_HITS, an LDS-sized scene forced into the staged pipeline)
-// keep a path's records by slot: 12 more float4 records, the hit instance and the two-ended connect queue, 200 bytes per path,
+// keep a path's records by slot: 13 more float4 records (pathLight among them), the hit instance and the two-ended connect queue, 216 bytes per path,
 // allocated when such a batch is first rendered and kept until the next resize.
 // The class queues of VPT_PIPELINE_STAGED_SORTED (21 bytes per path), likewise on first use.
 // Media on the streams pipeline: 11 more float4 streams per queue entry (176 bytes per path), allocated when such a batch is first
@@ -385,7 +410,7 @@ int ensure_path_buffers(vpt_ctx* c, uint32_t want) {
 int ensure_media_buffers(vpt_ctx* c) {
     if (c->media_block) return VPT_OK;
     const uint64_t px = c->P.shard_pixels;
-    uint64_t frames = c->frames_alloc;   // what the path buffers hold now (free_path_buffers drops this block with them)
+    uint64_t frames = c->resident_alloc;   // what the queues and streams hold now (free_path_buffers drops this block with them)
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
         const uint64_t fit = (uint64_t)(free_b * 0.85) / (16ull * 11ull);
@@ -417,12 +442,13 @@ int ensure_sorted_buffers(vpt_ctx* c) {
 int ensure_legacy_buffers(vpt_ctx* c) {
     const size_t cap = c->ps.capacity, stride = (cap + 63) & ~(size_t)63;
     if (!c->ps_legacy) {
-        HIPCHK(c, hipMalloc(&c->ps_legacy, stride * (16 * 12 + 4)));
+        HIPCHK(c, hipMalloc(&c->ps_legacy, stride * (16 * 13 + 4)));
         float4* q = (float4*)c->ps_legacy;
         PathState& s = c->ps;
+        s.L = q + stride * 12;
         s.A = q; s.B = q + stride; s.T[0] = q + stride * 2; s.T[1] = q + stride * 3; s.H = q + stride * 4;
         s.CE = q + stride * 5; s.CS = q + stride * 6; s.CSO = q + stride * 7; s.CSD = q + stride * 8; s.CL = q + stride * 9; s.CLO = q + stride * 10; s.CLD = q + stride * 11;
-        s.hinst = (uint32_t*)(q + stride * 12);
+        s.hinst = (uint32_t*)(q + stride * 13);
     }
     if (!c->cqueue) HIPCHK(c, hipMalloc((void**)&c->cqueue, cap * 4));   // (a failed call leaves what it got; the next one completes it)
     return VPT_OK;
@@ -591,7 +617,15 @@ int batch_begin(vpt_ctx* c, uint32_t frames, uint32_t dispatch_base, BatchState&
     b = BatchState{};
     b.frames = frames; b.dispatch_base = dispatch_base;
     if (frames == 0 || frames > c->frames_alloc) return fail(c, VPT_ERR_DEVICE, "internal: batch larger than the path buffers");
-    uint32_t n_slots = frames * c->P.shard_pixels;  // launch-grid size of the batch
+    // path regeneration: only `resident` frames of the batch's samples are in flight; a lane whose sample has ended starts the same
+    // pixel's sample `resident` frames later (shade_core.hpp), until the batch's samples are used up
+    const uint32_t resident = std::min(frames, c->resident_alloc);
+    const bool regen = resident < frames;
+    if (regen && !regen_allowed(c)) return fail(c, VPT_ERR_DEVICE, "internal: this batch needs all of its samples resident");
+    c->P.regen_stride = regen ? resident * c->P.shard_pixels : 0u;
+    c->P.regen_total = frames * c->P.shard_pixels;
+    c->P.batch_base = dispatch_base;
+    uint32_t n_slots = frames * c->P.shard_pixels;  // samples of the batch
     const uint32_t S = c->P.split;
     if (S > 1) {  // RayTrace(ceil(W/S), ceil(H/S)) per dispatch, in-bounds part only (PathTracer.cpp:145-150, RayGen.slang:24)
         std::vector<uint32_t> off(frames + 1, 0u);
@@ -605,6 +639,7 @@ int batch_begin(vpt_ctx* c, uint32_t frames, uint32_t dispatch_base, BatchState&
         HIPCHK(c, hipStreamSynchronize(s));  // `off` is a stack-lifetime staging buffer
     }
     b.n_slots = n_slots;
+    b.n_first = regen ? c->P.regen_stride : n_slots;   // launch-grid size of the camera-ray kernel
     b.count = c->cfg.count_traversal != 0;
     // fused (one kernel per bounce, bounce 0 included) when the BVH rides in LDS; staged otherwise
     const bool vol = !c->volumes.empty() || c->dsc.atm_on;
@@ -624,7 +659,7 @@ int batch_begin(vpt_ctx* c, uint32_t frames, uint32_t dispatch_base, BatchState&
     if (!b.fused && !b.stream) { int rl = ensure_legacy_buffers(c); if (rl != VPT_OK) return rl; }
     if (b.stream && c->cfg.pipeline == VPT_PIPELINE_STAGED_SORTED) { int rl = ensure_sorted_buffers(c); if (rl != VPT_OK) return rl; }
     b.min_bounces = (uint64_t)c->P.max_depth * c->P.samples_per_frame;
-    b.iter_cap = b.min_bounces * 4ull + 1024ull;
+    b.iter_cap = (b.min_bounces * 4ull + 1024ull) * ((frames + resident - 1) / resident);
     b.sorted = c->cfg.pipeline == VPT_PIPELINE_STAGED_SORTED;
     // Two streams: the shadow-ray kernels and the join of bounce k run beside the extend of bounce k + 1 (which needs only the ray
     // queue shade k wrote), so the tail of one persistent traversal kernel is filled by the next one's first blocks.  Off while
@@ -633,11 +668,11 @@ int batch_begin(vpt_ctx* c, uint32_t frames, uint32_t dispatch_base, BatchState&
     if (n_slots == 0) return VPT_OK;
     HIPCHK(c, hipMemsetAsync(c->ctr, 0, offsetof(Counters, stat_closest), s));  // queue words only, stat_* keep running
     if (b.fused) {  // bounce 0 of every slot needs no input records; survivors land in queue[1]
-        TIMED(c, VPT_K_PRIMARY, launch_bounce(s, (uint32_t)c->primary_blocks, c->lds_scene, b.count, true, c->dsc, c->P, c->ps, c->ss, nullptr, c->queue[1], c->ctr, 0u, n_slots, dispatch_base, 0u, c->scene_plain));
+        TIMED(c, VPT_K_PRIMARY, launch_bounce(s, (uint32_t)c->primary_blocks, c->lds_scene, b.count, true, c->dsc, c->P, c->ps, c->ss, nullptr, c->queue[1], c->ctr, 0u, b.n_first, dispatch_base, 0u, c->scene_plain));
         b.parity = 1; b.k3 = 1; b.iter = 1;
     } else if (b.stream) {
-        TIMED(c, VPT_K_PRIMARY, launch_raygen_stream(s, c->P, c->ps, c->ss, c->queue[0], n_slots, dispatch_base, b.media_stream));
-        launch_stream_begin(s, c->sctr, n_slots);
+        TIMED(c, VPT_K_PRIMARY, launch_raygen_stream(s, c->P, c->ps, c->ss, c->queue[0], b.n_first, dispatch_base, b.media_stream));
+        launch_stream_begin(s, c->sctr, b.n_first);
         b.parity = 0;
     } else {
         TIMED(c, VPT_K_PRIMARY, launch_raygen(s, c->P, c->ps, c->queue[0], c->ctr, n_slots, dispatch_base));
@@ -650,7 +685,7 @@ int batch_bounces(vpt_ctx* c, BatchState& b, uint32_t bounces) {
     hipStream_t s = c->stream;
     const bool count = b.count, sorted = b.sorted, overlap = b.overlap;
     uint32_t& parity = b.parity;
-    const uint32_t n_slots = b.n_slots;
+    const uint32_t n_slots = b.n_first;   // (upper bound of a queue's live entries)
     if (n_slots == 0) return VPT_OK;
     for (uint32_t j = 0; j < bounces; j++) {
         b.iter++;
@@ -767,7 +802,7 @@ int batch_check(vpt_ctx* c, BatchState& b, uint32_t* alive) {
         const uint64_t room = b.media_stream ? (uint64_t)c->media_frames * c->P.shard_pixels + c->stream_slack : (uint64_t)c->ps.capacity + c->stream_slack;
         if (len > room || len > (uint64_t)c->ps.capacity + c->stream_slack) { (void)hipStreamSynchronize(c->stream2); return fail(c, VPT_ERR_DEVICE, "internal: stream overflow"); }
     }
-    if (n > b.n_slots) { (void)hipStreamSynchronize(c->stream2); return fail(c, VPT_ERR_DEVICE, "internal: queue overflow"); }
+    if (n > b.n_first) { (void)hipStreamSynchronize(c->stream2); return fail(c, VPT_ERR_DEVICE, "internal: queue overflow"); }
     if (n != 0 && b.iter > b.iter_cap) { (void)hipStreamSynchronize(c->stream2); return fail(c, VPT_ERR_DEVICE, "internal: bounce loop did not terminate"); }
     *alive = n;
     return VPT_OK;
@@ -782,7 +817,7 @@ int batch_finish(vpt_ctx* c, BatchState& b, bool resolve_enqueued) {
         int rc = batch_check(c, b, &n);
         if (rc) return rc;
         if (n == 0) break;
-        rc = batch_bounces(c, b, 4);
+        rc = batch_bounces(c, b, b.n_first < b.n_slots ? 8u : 4u);   // (a regenerating batch runs many more launches than max_depth: fewer host round trips)
         if (rc) return rc;
     }
     HIPCHK(c, hipGetLastError());
@@ -1389,12 +1424,13 @@ int next_batch(vpt_ctx* c, uint32_t left, uint32_t* nf) {
     const uint64_t frames_needed = ((uint64_t)c->params.max_samples + c->params.samples_per_frame - 1) / c->params.samples_per_frame;
     const uint64_t disp_left = frames_needed * S2 - c->dispatch_count;
     uint32_t n = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(left, c->frames_in_flight), disp_left);
-    if (n > c->frames_alloc) {   // the buffers grow to the largest batch asked for; nothing may be in flight while they are replaced
+    if (n > c->frames_alloc || resident_frames_for(c, n) > c->resident_alloc) {   // the buffers grow to the largest batch asked for; nothing may be in flight while they are replaced
         int rc = drain(c);
         if (rc) return rc;
         if ((rc = ensure_path_buffers(c, n))) return rc;
         n = std::min(n, c->frames_alloc);   // (a size the library chose itself may have been halved)
     }
+    if (!regen_allowed(c)) n = std::min(n, c->resident_alloc);
     if (media_on_streams(c)) {   // media on the streams: the batch is what the media streams hold
         int rm = ensure_media_buffers(c);
         if (rm) return rm;
@@ -1449,7 +1485,7 @@ int vpt_render_async(vpt_ctx* c, uint32_t dispatches, int* done, uint64_t* ticke
         const uint64_t bounds = (uint64_t)c->P.max_depth * c->P.samples_per_frame;
         const bool vol = !c->volumes.empty() || c->dsc.atm_on;
         // a fixed schedule: every path has ended after `bounds` bounces, whatever the random numbers say
-        const bool fixed = c->depth_bounded && !vol && bounds <= VPT_ASYNC_MAX_BOUNCES;
+        const bool fixed = c->depth_bounded && !vol && bounds <= VPT_ASYNC_MAX_BOUNCES && nf <= c->resident_alloc;   // (a regenerating batch has no fixed length)
         const uint32_t enq = (uint32_t)std::min<uint64_t>(bounds, VPT_ASYNC_MAX_BOUNCES);
         const uint32_t base = (uint32_t)c->dispatch_count;
         BatchState b;
@@ -1684,7 +1720,7 @@ int vpt_get_stats(vpt_ctx* c, vpt_stats* out) {
     s.emissive_mesh_count = (uint32_t)c->emissive.size(); s.emissive_triangle_count = c->emissive_tris;
     s.frames_in_flight = c->frames_in_flight; s.shard_pixels = c->P.shard_pixels;
     s.build_flags = (c->sbvh ? VPT_BUILD_SBVH : 0u) | (c->cfg.build_flags & VPT_BUILD_GENERAL_KERNELS);
-    s.frames_allocated = c->frames_alloc;
+    s.frames_allocated = c->frames_alloc; s.resident_frames = c->resident_alloc;
     s.set_scene_ms = c->set_scene_ms; s.bvh_build_ms = c->bvh_build_ms;
     s.stack_spills[0] = s.stack_spills[1] = 0;
     if (c->has_scene && c->stack_overflow_words && c->dsc.stack_overflow) {   // what the traversal kernels have written into their spill regions
