@@ -182,11 +182,12 @@ typedef struct vpt_config {
     uint32_t pipeline;   /* VPT_PIPELINE_* */
     uint32_t build_flags; /* VPT_BUILD_*: how vpt_set_scene builds the BVH of this context (reported back in vpt_stats.build_flags) */
     /* Path regeneration: frames of PATHS a batch keeps in flight at a time.  A batch of F frames has F x pixels samples; with K < F resident
-     * frames a lane whose sample has ended starts the same pixel's sample K frames later in the same launch (a fresh camera ray; seeds
-     * depend on pixel and frame only, the running mean is applied in frame order when the batch has finished), so every launch works on
-     * ~K x pixels paths until the samples run out — no shrinking launches after the first bounces, ~290 B per resident path + 48 B per
-     * sample instead of 380 B per sample.  0 = ~32M paths (16 frames at 1080p); a value >= the batch size keeps every sample resident
-     * (round 3's schedule).  Media batches, split-screen dispatch and VPT_PIPELINE_STAGED_R1 always keep every sample resident.
+     * frames a lane whose sample has ended takes the next unstarted sample of the batch in the same launch (a fresh camera ray; seeds
+     * depend on pixel and frame only, a sample's result lands in its own slot of the frame sums and the running mean is applied in frame
+     * order when the batch has finished), so every launch works on ~K x pixels paths until the samples run out — one shrinking tail per
+     * batch instead of one per frame, ~290 B per resident path + 48 B per sample instead of 380 B per sample.  0 = the library's choice
+     * (what was measured fastest per pipeline); a value >= the batch size keeps every sample resident (round 3's
+     * schedule).  Media batches, split-screen dispatch and VPT_PIPELINE_STAGED_R1 always keep every sample resident.
      * Images do not depend on it, bit for bit.  Reference loop being unrolled: RayGen.slang:28-33,116-159. */
     uint32_t resident_frames;
 } vpt_config;

@@ -57,14 +57,23 @@ def test_regeneration_on_row_shards_and_after_a_material_edit(vpt, oracle, scene
     whole.set_scene(sc); whole.set_params(p); whole.render(frames)
     img = whole.radiance()
     assert np.array_equal(img, oracle_image(oracle, sc, w, h, p, frames))
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    parts = []
     for r in range(3):
         g = vpt.PathTracer(w, h, shard_rank=r, shard_count=3, frames_in_flight=frames, resident_frames=2)
         g.set_scene(sc); g.set_params(p); g.render(frames)
-        import torch
-        buf = torch.empty(g.shard_floats(), dtype=torch.float32, device="cuda")
-        g.shard_to_device(buf.data_ptr())
-        rows = len(range(r, h, 3))
-        assert np.array_equal(buf.cpu().numpy()[: rows * w * 4].reshape(rows, w, 4), img[r::3])
+        assert g.stats()["resident_frames"] == 2
+        parts.append(g)
+    n = parts[0].shard_floats()
+    buf = C.c_void_p()
+    assert hip.hipMalloc(C.byref(buf), n * 4 * 3) == 0
+    for r, g in enumerate(parts):
+        g.shard_to_device(C.c_void_p(buf.value + r * n * 4))
+    parts[0].assemble_shards(buf, 3)
+    assert np.array_equal(parts[0].radiance(), img)
+    hip.hipFree(buf)
+    for g in parts:
         g.close()
     m = whole.get_material(2); m.base_color[:] = (0.9, 0.2, 0.1)
     whole.set_material(2, m); whole.render(frames)

@@ -7,7 +7,14 @@ import importlib, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
-import torch
+import ctypes as C
+hip = C.CDLL("libamdhip64.so")
+
+
+def free_bytes():
+    f, t = C.c_size_t(0), C.c_size_t(0)
+    hip.hipMemGetInfo(C.byref(f), C.byref(t))
+    return f.value
 vpt = importlib.import_module("vulkan-path-tracer_amd")
 out_dir = os.path.join(ROOT, "gpurun_out", sys.argv[1] if len(sys.argv) > 1 else "r04")
 os.makedirs(out_dir, exist_ok=True)
@@ -20,7 +27,7 @@ for name in which:
     P = vpt.default_params(max_depth=depth, max_samples=1 << 30)
     ref = None
     for K in (226, 128, 64, 32, 16, 8, 4):
-        free0, _ = torch.cuda.mem_get_info()
+        free0 = free_bytes()
         g = vpt.PathTracer(1920, 1080, frames_in_flight=F, resident_frames=K); g.set_scene(sc); g.set_params(P)
         g.render(24)
         img = g.radiance()
@@ -29,7 +36,7 @@ for name in which:
         same = bool(np.array_equal(img, ref))
         g.reset()
         for _ in range(2): g.render(F)
-        free1, _ = torch.cuda.mem_get_info()
+        free1 = free_bytes()
         g.reset_stats(); t = time.perf_counter(); n = 4
         for _ in range(n): g.render(F)
         dt = time.perf_counter() - t; st = g.stats(); g.close()

@@ -186,6 +186,7 @@ struct DeviceScene {
     vpt_atmosphere atm;
 };
 
+constexpr uint32_t kRegenShards = 64;
 struct RenderParams {
     float view_inv[16], proj_inv[16];
     uint32_t width, height;
@@ -197,11 +198,15 @@ struct RenderParams {
     float sky_azimuth, sky_altitude, sky_intensity, emissive_pdf_bias;
     uint32_t flags, base_seed;
     // Path regeneration (vpt_api.hip batch_begin): a batch of F frames keeps only K < F frames of paths resident.  A slot is a SAMPLE id
-    // (frame-in-batch * shard_pixels + shard pixel); when the sample in slot s has ended, its lane starts the sample s + regen_stride
-    // (same pixel, K frames later) while that is < regen_total — a fresh camera ray seeded as k_raygen_stream / k_bounce<FIRST> seed it
-    // (seeds depend on pixel and frame only) — instead of leaving the queue.  regen_stride == 0: off (every sample of the batch is
-    // resident).  batch_base = index of the batch's first dispatch (what the camera-ray kernels get as an argument).
-    uint32_t regen_stride, regen_total, batch_base;
+    // (frame-in-batch * shard_pixels + shard pixel).  The camera-ray launch starts samples [0, regen_first); a lane whose sample has
+    // ended takes the next unstarted sample of the batch — dealt out by kRegenShards counters, one cache line each, shard r owning the
+    // contiguous ids [regen_first + r * regen_shard, ...) (shade_core.hpp regen_take) — and starts it with a fresh camera ray, seeded as
+    // k_raygen_stream / k_bounce<FIRST> seed it (seeds depend on pixel and frame only).  Which lane runs which sample depends on
+    // timing; nothing else does: a sample's result lands in the frame sum of its own slot and the running mean is applied in frame
+    // order when the batch has finished.  regen_next == nullptr: off (every sample of the batch is resident).
+    // batch_base = index of the batch's first dispatch (what the camera-ray kernels get as an argument).
+    struct HotWord* regen_next;
+    uint32_t regen_first, regen_total, regen_shard, batch_base;
     // Graph replays (vpt_render_async): when non-null, the batch's first dispatch index is read from here instead of the kernels'
     // dispatch_base / frame_base arguments, so that one captured batch serves every frame
     const uint32_t* dispatch_base_dev;
@@ -311,8 +316,6 @@ constexpr uint32_t kAppendExactBelow = 1u << 21;
 // connect flags (CE.w)
 constexpr uint32_t kCF_Sky = 1u, kCF_Light = 2u, kCF_Finalize = 4u, kCF_Clamp = 8u;
 constexpr uint32_t kCF_Alive = 16u;   // streams pipeline: the path lives on, PT.w is its entry in the NEXT queue (else: in this one)
-constexpr uint32_t kCF_NewFrame = 32u;   // with kCF_Finalize | kCF_Alive: the lane goes on with the sample regen_stride slots further (RenderParams), so the
-                                         // sample being finalised is (slot of the next-queue entry) - regen_stride
 
 struct Counters {
     uint32_t ray_count[2];    // active-path queue sizes (ping-pong by bounce parity)

@@ -194,7 +194,8 @@ __global__ __launch_bounds__(256, 3) void k_shade_stream(DeviceScene sc, RenderP
                 st_stream(&ss.RA[parity ^ 1u][p_next], f4u(o.new_o, o.rng));
                 st_stream(&ss.RB[parity ^ 1u][p_next], f4u(o.new_d, o.new_depth | (o.in_medium ? 0x80000000u : 0u)));
                 st_stream(&ss.RT[parity ^ 1u][p_next], f4(o.thr, o.new_pdf));
-                st_stream(&ss.RL[parity ^ 1u][p_next], ld_stream(&ss.RL[parity][qi]));
+                // (path regeneration: a lane that goes on with ANOTHER sample starts it with pathLight = 0; the sample that ended keeps its own entry, below)
+                st_stream(&ss.RL[parity ^ 1u][p_next], o.new_frame ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : ld_stream(&ss.RL[parity][qi]));
             }
             const uint32_t p_sky = a_sky.append(want_sky, &sctr->sky_len.v);
             if (want_sky) {
@@ -209,10 +210,11 @@ __global__ __launch_bounds__(256, 3) void k_shade_stream(DeviceScene sc, RenderP
             const uint32_t p_pend = a_pend.append(pending, &sctr->pend_len.v);
             if (pending) {   // where the join finds the path's pathLight (and its slot, in the queue): its entry in the NEXT queue if it
                              // lives on (a regenerated sample included), else its entry in this one
-                st_stream(&ss.PE[p_pend], f4u(o.emitted, o.cflags | (alive ? kCF_Alive : 0u)));
+                const bool lives_on = alive && !o.new_frame;   // THIS sample's path (a regenerated lane carries another sample on)
+                st_stream(&ss.PE[p_pend], f4u(o.emitted, o.cflags | (lives_on ? kCF_Alive : 0u)));
                 st_stream(&ss.PS[p_pend], f4u(o.csky, p_sky));
                 st_stream(&ss.PL[p_pend], f4u(o.clight, p_light));
-                st_stream(&ss.PT[p_pend], f4u(thr_prev, alive ? p_next : qi));
+                st_stream(&ss.PT[p_pend], f4u(thr_prev, lives_on ? p_next : qi));
             }
             w_paths += (uint32_t)__popcll(__ballot(valid));
             w_alive += (uint32_t)__popcll(__ballot(alive));
@@ -271,10 +273,7 @@ __global__ __launch_bounds__(256) void k_join(RenderParams P, PathState ps, Stre
             // same waves in the same order, so these accesses are streams too
             if (on[k]) {
                 lp[k] = (fl[k] & kCF_Alive) ? ss.RL[parity ^ 1u][pos[k]] : ss.RL[parity][pos[k]];
-                if (fl[k] & kCF_Finalize) {
-                    sl[k] = (fl[k] & kCF_Alive) ? queue_next[pos[k]] : queue[pos[k]];
-                    if (fl[k] & kCF_NewFrame) sl[k] -= P.regen_stride;   // the next-queue entry already names the regenerated sample
-                }
+                if (fl[k] & kCF_Finalize) sl[k] = (fl[k] & kCF_Alive) ? queue_next[pos[k]] : queue[pos[k]];
             }
         }
 #pragma unroll

@@ -6,6 +6,7 @@
 #include "shading.hpp"
 #include "volume.hpp"
 #include "atmosphere.hpp"
+#include "wave.hpp"
 
 namespace vpt {
 
@@ -36,6 +37,36 @@ __device__ inline void launch_pixel(const RenderParams& P, uint32_t li, uint32_t
     uint32_t ly = r / lw, lx = r - ly * lw;
     x = lx * P.split + cx; y = ly * P.split + cy; f = k;
     slot = k * P.shard_pixels + y * P.width + x;
+}
+
+// Path regeneration: the lanes of the wave with `want` each take an unstarted sample id of the batch (RenderParams::regen_next).  The
+// wave asks its home shard first — one aggregated atomic for all its lanes — and moves on to the next shard that still has samples
+// when that one runs out (its counter is read before it is added to, so an exhausted shard's counter stops growing).  Every lane of
+// the wave that is active at the call site must call; returns true and the id where the lane got one.
+__device__ __forceinline__ bool regen_take(const RenderParams& P, bool want, uint32_t& id) {
+    bool got = false;
+    uint32_t shard = ((blockIdx.x * (blockDim.x >> 6)) + (threadIdx.x >> 6)) % kRegenShards;
+    const uint32_t span = P.regen_total - P.regen_first;
+    for (uint32_t tries = 0; tries < kRegenShards; tries++) {
+        const unsigned long long m = __ballot(want && !got);
+        if (m == 0ull) break;
+        const uint32_t lo = shard * P.regen_shard, hi = lo + P.regen_shard < span ? lo + P.regen_shard : span;   // ids of this shard, relative
+        const uint32_t size = lo < hi ? hi - lo : 0u;
+        uint32_t base = size;
+        if (want && !got) {
+            const uint32_t leader = (uint32_t)__ffsll((long long)m) - 1u;
+            if (lane_id() == leader) {
+                base = size;
+                if (size != 0u && __hip_atomic_load(&P.regen_next[shard].v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < size)
+                    base = atomicAdd(&P.regen_next[shard].v, (uint32_t)__popcll(m));
+            }
+            base = __shfl(base, (int)leader);
+            const uint32_t k = base + lanes_below(m);
+            if (k < size) { id = P.regen_first + lo + k; got = true; }
+        }
+        shard = (shard + 1u) % kRegenShards;
+    }
+    return got;
 }
 
 struct ShadeIn {
@@ -72,7 +103,8 @@ struct ShadeOut {
     int sky_kind;       // 0 surface, 1 box scatter event, 2 atmosphere scatter event (the three expressions differ in association)
     bool sky_add;       // false: trace and track (the draws count) but add nothing (ozone collision)
     int cchan;          // payload.ColorChannel after this bounce
-    uint32_t next_slot; // the slot a live path goes on in: its own, or (path regeneration, kCF_NewFrame) the one of the pixel's next resident sample
+    uint32_t next_slot; // the slot a live path goes on in: its own, or (path regeneration) the one of the sample the lane has just started
+    bool new_frame;     // alive && the lane goes on with ANOTHER sample: this slot's sample has ended (the records the callers leave for it say so)
 };
 
 // The miss / closest-hit shader and the visibility-independent tail of the bounce loop for ONE path, on
@@ -339,7 +371,7 @@ __device__ __forceinline__ void shade_core(const DeviceScene& sc, const RenderPa
         out.new_o = new_o; out.new_d = new_d; out.new_pdf = new_pdf; out.bxdf = bxdf; out.cchan = in_.cchan;
         out.emitted = emitted; out.csky = csky; out.clight = clight;
         out.sky_o = sky_o; out.sky_d = sky_d; out.light_o = light_o; out.light_d = light_d;
-        out.next_slot = slot;
+        out.next_slot = slot; out.new_frame = false;
         return;
     }
     // ---- RayGen.slang:104-113: throughput, Russian roulette (drawn on every iteration), loop condition
@@ -364,27 +396,29 @@ __device__ __forceinline__ void shade_core(const DeviceScene& sc, const RenderPa
                 alive = true;
             }
         }
-        // path regeneration: the frame's last sample of this slot has ended, the lane starts the pixel's next resident frame.  The new
-        // sample is seeded from (pixel, frame) alone, exactly as the camera-ray kernels seed it (RayGen.slang:28, PathTracer.cpp:139).
-        if (!alive && P.regen_stride != 0u) {
-            const uint32_t ns = slot + P.regen_stride;
-            if (ns < P.regen_total) {
-                uint32_t x, y, f;
-                pixel_of_slot(P, ns, x, y, f);
-                const uint32_t seed = pcg_hash(P.base_seed + P.batch_base + f);
-                rng.s = y + P.width * x + seed;
-                camera_ray(P, rng, x, y, new_o, new_d);
-                thr = v3s(1.0f); new_pdf = 1.0f; new_depth = 0u; in_medium = false; vdepth = 0u;
-                if (P.samples_per_frame > 1) { ps.sidx[ns] = 0u; ps.ACC[ns] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); }   // later finalisations add to it
-                next_slot = ns;
-                cflags |= kCF_NewFrame;
-                alive = true;
-            }
-        }
     } else {
         alive = true;
     }
-    out.next_slot = next_slot;
+    // path regeneration: the (frame's last) sample of this slot has ended and the lane takes an unstarted sample of the batch.  The new
+    // sample is seeded from (pixel, frame) alone, exactly as the camera-ray kernels seed it (RayGen.slang:28, PathTracer.cpp:139); the
+    // ended sample is finalised as any other (the callers' records say "ended"), the new one enters the next queue with pathLight = 0.
+    bool new_frame = false;
+    if (P.regen_next != nullptr) {
+        uint32_t ns = 0u;
+        if (regen_take(P, terminated && !alive, ns)) {
+            uint32_t x, y, f;
+            pixel_of_slot(P, ns, x, y, f);
+            const uint32_t seed = pcg_hash(P.base_seed + P.batch_base + f);
+            rng.s = y + P.width * x + seed;
+            camera_ray(P, rng, x, y, new_o, new_d);
+            thr = v3s(1.0f); new_pdf = 1.0f; new_depth = 0u; in_medium = false; vdepth = 0u;
+            if (P.samples_per_frame > 1) { ps.sidx[ns] = 0u; ps.ACC[ns] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); }   // later finalisations add to it
+            next_slot = ns;
+            new_frame = true;
+            alive = true;
+        }
+    }
+    out.next_slot = next_slot; out.new_frame = new_frame;
     out.alive = alive; out.terminated = terminated; out.want_sky = want_sky; out.want_light = want_light; out.in_medium = in_medium;
     out.rng = rng.s; out.new_depth = new_depth; out.cflags = cflags; out.light_gid = light_gid;
     out.light_miss_ok = light_miss_ok; out.vdepth = vdepth;

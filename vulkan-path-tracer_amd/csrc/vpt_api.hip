@@ -101,12 +101,30 @@ struct vpt_ctx {
     BatchState out_batch;
     uint64_t out_ticket = 0;
     uint32_t* d_dispatch_base = nullptr;   // graph replays read the batch's first dispatch index from here (RenderParams::dispatch_base_dev)
+    HotWord* d_regen = nullptr;            // path regeneration: kRegenShards sample counters, one cache line each (RenderParams::regen_next)
     hipGraphExec_t graph = nullptr;
     uint64_t graph_gen = 0, state_gen = 1;   // state_gen: bumped by everything a captured batch bakes in (scene tables' addresses, params, camera, buffers)
     uint32_t graph_frames = 0, graph_bounces = 0, graph_streak = 0;
     uint64_t graph_streak_gen = 0;
     uint64_t graph_kernel_launches[VPT_KERNEL_COUNT] = {};
     bool graph_broken = false;       // a capture failed once on this context: stay on plain launches
+    // Pipelined 1-frame batches (vpt_render_async): a frame of the fused fixed schedule is a chain of ~9 dependent launches, each bounded
+    // below by the latency of one bounce (~60-90 us on nearly empty queues), so one frame at a time leaves most of the chip idle
+    // (profiles/r04_latency_probe.json: 0.95 ms of kernels per 1080p frame against 0.33 ms per frame in 16-frame batches).  Consecutive
+    // frames are independent until their resolve, so they go round-robin over kLanes lanes — the context itself and kLanes - 1 lane
+    // contexts with a stream, counters, 1-frame path buffers and a spill region of their own, sharing the scene tables and the
+    // accumulation image — and only the resolves are ordered (frame k's waits for frame k - 1's: the running mean is applied in frame order).
+    vpt_ctx* lanes[2] = {nullptr, nullptr};
+    vpt_ctx* owner = nullptr;        // set in a lane: the context whose scene and image it borrows
+    void* lane_spill = nullptr;      // a lane's own traversal spill region
+    hipEvent_t ev_resolved = nullptr;    // recorded behind this lane's latest resolve
+    vpt_ctx* order_lane = nullptr;   // owner only: the lane the latest resolve was enqueued on (nullptr: nothing pipelined since the last drain)
+    hipEvent_t ev_post = nullptr;    // owner only: recorded behind the latest vpt_postprocess_device — the next frame's resolve must not touch the image before
+    bool post_pending = false;
+    uint32_t lane_rr = 0;
+    BatchState graph_batch;          // the captured batch as it stands before its resolve
+    BatchState last_fixed;           // the latest fixed-schedule batch enqueued on this lane (drain checks that nothing outlived it)
+    bool last_fixed_valid = false;
     uint32_t stack_overflow_words = 0;   // words per spill region
     unsigned long long* d_spill_count = nullptr;
     double set_scene_ms = 0.0, bvh_build_ms = 0.0;
@@ -354,7 +372,7 @@ int alloc_render_buffers(vpt_ctx* c) {
     return check_stream_slack(c);
 }
 
-// Frames of paths a batch of `frames` frames keeps resident.  Paths are regenerated (device_types.hpp RenderParams::regen_stride) on the
+// Frames of paths a batch of `frames` frames keeps resident.  Paths are regenerated (device_types.hpp RenderParams::regen_next) on the
 // fused and the stream pipelines; round 1's stage kernels address a path's records by slot, media batches carry per-entry media streams
 // and split-screen dispatches map launch indices to pixels per dispatch: those keep every sample of the batch resident.
 bool regen_allowed(const vpt_ctx* c) {
@@ -368,7 +386,12 @@ bool regen_allowed(const vpt_ctx* c) {
 uint32_t resident_frames_for(const vpt_ctx* c, uint32_t frames) {
     if (!regen_allowed(c)) return frames;
     uint64_t k = c->cfg.resident_frames;
-    if (k == 0) k = std::max<uint64_t>(1, kRegenResidentPaths / std::max<uint64_t>(1, c->P.shard_pixels));
+    if (k == 0) {
+        // the library's choice: the fused pipeline (LDS-sized scenes) keeps every sample resident — its bounce 0 is a kernel of its own
+        // that reads nothing, which a regenerated sample forgoes (profiles/r04_frames_sweep.json) —, the streams keep ~32M paths
+        const bool fused = c->cfg.pipeline == VPT_PIPELINE_FUSED || (c->cfg.pipeline == VPT_PIPELINE_AUTO && c->lds_scene);
+        k = fused ? frames : std::max<uint64_t>(1, kRegenResidentPaths / std::max<uint64_t>(1, c->P.shard_pixels));
+    }
     return (uint32_t)std::min<uint64_t>(frames, k);
 }
 
@@ -622,9 +645,12 @@ int batch_begin(vpt_ctx* c, uint32_t frames, uint32_t dispatch_base, BatchState&
     const uint32_t resident = std::min(frames, c->resident_alloc);
     const bool regen = resident < frames;
     if (regen && !regen_allowed(c)) return fail(c, VPT_ERR_DEVICE, "internal: this batch needs all of its samples resident");
-    c->P.regen_stride = regen ? resident * c->P.shard_pixels : 0u;
+    c->P.regen_next = regen ? c->d_regen : nullptr;
+    c->P.regen_first = resident * c->P.shard_pixels;
     c->P.regen_total = frames * c->P.shard_pixels;
+    c->P.regen_shard = (c->P.regen_total - c->P.regen_first + kRegenShards - 1u) / kRegenShards;
     c->P.batch_base = dispatch_base;
+    if (regen) HIPCHK(c, hipMemsetAsync(c->d_regen, 0, sizeof(HotWord) * kRegenShards, s));
     uint32_t n_slots = frames * c->P.shard_pixels;  // samples of the batch
     const uint32_t S = c->P.split;
     if (S > 1) {  // RayTrace(ceil(W/S), ceil(H/S)) per dispatch, in-bounds part only (PathTracer.cpp:145-150, RayGen.slang:24)
@@ -639,7 +665,7 @@ int batch_begin(vpt_ctx* c, uint32_t frames, uint32_t dispatch_base, BatchState&
         HIPCHK(c, hipStreamSynchronize(s));  // `off` is a stack-lifetime staging buffer
     }
     b.n_slots = n_slots;
-    b.n_first = regen ? c->P.regen_stride : n_slots;   // launch-grid size of the camera-ray kernel
+    b.n_first = regen ? c->P.regen_first : n_slots;   // launch-grid size of the camera-ray kernel
     b.count = c->cfg.count_traversal != 0;
     // fused (one kernel per bounce, bounce 0 included) when the BVH rides in LDS; staged otherwise
     const bool vol = !c->volumes.empty() || c->dsc.atm_on;
@@ -778,6 +804,20 @@ int batch_resolve(vpt_ctx* c, BatchState& b) {
     return VPT_OK;
 }
 
+// The device-side ray statistics are running totals per lane (Counters::stat_*), copied to pinned memory behind every resolve.
+void update_ray_stats(vpt_ctx* c) {
+    vpt_ctx* root = c->owner ? c->owner : c;
+    unsigned long long v[6] = {0, 0, 0, 0, 0, 0};
+    auto add = [&](const vpt_ctx* x) {
+        const Counters& h = x->h_ctr->ctr;
+        v[0] += h.stat_closest; v[1] += h.stat_shadow; v[2] += h.stat_connect; v[3] += h.stat_primary_hits; v[4] += h.stat_primary_alive; v[5] += h.stat_primary_rays;
+    };
+    add(root);
+    for (vpt_ctx* L : root->lanes) if (L) add(L);
+    root->stats.closest_rays = v[0]; root->stats.shadow_rays = v[1]; root->stats.connect_paths = v[2];
+    root->stats.primary_hits = v[3]; root->stats.primary_survivors = v[4]; root->stats.primary_shadow_rays = v[5];
+}
+
 // Host synchronisation: statistics, overflow checks, *alive = paths of the batch still in flight.
 int batch_check(vpt_ctx* c, BatchState& b, uint32_t* alive) {
     *alive = 0;
@@ -785,12 +825,7 @@ int batch_check(vpt_ctx* c, BatchState& b, uint32_t* alive) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     collect_timing(c);
     const Counters& h = c->h_ctr->ctr;
-    c->stats.closest_rays = h.stat_closest;
-    c->stats.shadow_rays = h.stat_shadow;
-    c->stats.connect_paths = h.stat_connect;
-    c->stats.primary_hits = h.stat_primary_hits;
-    c->stats.primary_survivors = h.stat_primary_alive;
-    c->stats.primary_shadow_rays = h.stat_primary_rays;
+    update_ray_stats(c);
     c->stats.nodes_visited = h.stat_nodes;
     c->stats.tris_tested = h.stat_tris;
     c->stats.shadow_nodes_visited = h.stat_shadow_nodes;
@@ -840,9 +875,9 @@ int render_batch(vpt_ctx* c, uint32_t frames, uint32_t dispatch_base) {
 }
 
 // ---- asynchronous batches -------------------------------------------------------------------------------------------------
-uint64_t issue_ticket(vpt_ctx* c) {
+uint64_t issue_ticket(vpt_ctx* c, hipStream_t on) {
     c->tick_issued++;
-    (void)hipEventRecord(c->tick_ev[c->tick_issued % kTickets], c->stream);
+    (void)hipEventRecord(c->tick_ev[c->tick_issued % kTickets], on);
     c->async_dirty = true;
     return c->tick_issued;
 }
@@ -852,19 +887,25 @@ int finish_outstanding(vpt_ctx* c) {
     c->out_active = false;
     return batch_finish(c, c->out_batch, true);
 }
-// Everything enqueued so far has finished when this returns (and an unfinished batch has been finished).
+// Everything enqueued so far — on every lane — has finished when this returns (and an unfinished batch has been finished).
 int drain(vpt_ctx* c) {
     int rc = finish_outstanding(c);
     if (rc) return rc;
     if (!c->async_dirty) return VPT_OK;
     c->async_dirty = false;
+    for (vpt_ctx* L : c->lanes)
+        if (L) {
+            HIPCHK(c, hipStreamSynchronize(L->stream));
+            if (L->last_fixed_valid && L->h_ctr->ctr.alive3[L->last_fixed.k3] != 0u) return fail(c, VPT_ERR_DEVICE, "internal: a path outlived a fixed-schedule batch");
+            L->last_fixed_valid = false;
+            for (int k = 0; k < VPT_KERNEL_COUNT; k++) { c->stats.kernel_launches[k] += L->stats.kernel_launches[k]; L->stats.kernel_launches[k] = 0; }
+            c->stats.graph_launches += L->stats.graph_launches; L->stats.graph_launches = 0;
+        }
+    c->order_lane = nullptr; c->post_pending = false;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream2));
     collect_timing(c);
-    // fixed-schedule batches copy their counters to pinned memory too: a path alive after max_depth * spp bounces would be a bug
-    const Counters& h = c->h_ctr->ctr;
-    c->stats.closest_rays = h.stat_closest; c->stats.shadow_rays = h.stat_shadow; c->stats.connect_paths = h.stat_connect;
-    c->stats.primary_hits = h.stat_primary_hits; c->stats.primary_survivors = h.stat_primary_alive; c->stats.primary_shadow_rays = h.stat_primary_rays;
+    update_ray_stats(c);   // fixed-schedule batches copy their counters to pinned memory too
     HIPCHK(c, hipGetLastError());
     return VPT_OK;
 }
@@ -872,18 +913,16 @@ void destroy_graph(vpt_ctx* c) {
     if (c->graph) (void)hipGraphExecDestroy(c->graph);
     c->graph = nullptr; c->graph_gen = 0;
 }
-// A whole batch as a fixed schedule of `bounces` bounces after bounce 0 (or the camera rays) + the guarded resolve.
+// A whole batch as a fixed schedule: bounce 0 (or the camera rays) and `bounces_total` bounces in all; the guarded resolve is the caller's.
 int enqueue_fixed(vpt_ctx* c, uint32_t frames, uint32_t dispatch_base, uint32_t bounces_total, BatchState& b) {
     int rc = batch_begin(c, frames, dispatch_base, b);
     if (rc) return rc;
     if (b.n_slots == 0) return VPT_OK;
-    rc = batch_bounces(c, b, b.fused ? bounces_total - 1u : bounces_total);
-    if (rc) return rc;
-    return batch_resolve(c, b);
+    return batch_bounces(c, b, b.fused ? bounces_total - 1u : bounces_total);
 }
-// The same through a captured hipGraph: the fused pipeline's batch (memset, bounce 0, bounces, resolve, counter copy) with the first
-// dispatch index read from device memory, captured once per (state, frames, bounces) and replayed.
-int enqueue_graph(vpt_ctx* c, uint32_t frames, uint32_t dispatch_base, uint32_t bounces_total, bool* used) {
+// The same through a captured hipGraph: the fused pipeline's batch (memset, bounce 0, bounces) with the first dispatch index read from
+// device memory, captured once per (state, frames, bounces) and replayed.  b: the batch as it stands before its resolve.
+int enqueue_graph(vpt_ctx* c, uint32_t frames, uint32_t dispatch_base, uint32_t bounces_total, bool* used, BatchState& b) {
     *used = false;
     if (c->graph_broken) return VPT_OK;
     if (!c->graph || c->graph_gen != c->state_gen || c->graph_frames != frames || c->graph_bounces != bounces_total) {
@@ -892,9 +931,8 @@ int enqueue_graph(vpt_ctx* c, uint32_t frames, uint32_t dispatch_base, uint32_t 
         memcpy(before, c->stats.kernel_launches, sizeof(before));
         c->P.dispatch_base_dev = c->d_dispatch_base;
         hipGraph_t g = nullptr;
-        BatchState b;
         bool ok = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
-        int rc = ok ? enqueue_fixed(c, frames, 0u, bounces_total, b) : VPT_ERR_DEVICE;
+        int rc = ok ? enqueue_fixed(c, frames, 0u, bounces_total, c->graph_batch) : VPT_ERR_DEVICE;
         if (ok && hipStreamEndCapture(c->stream, &g) != hipSuccess) { ok = false; g = nullptr; }
         c->P.dispatch_base_dev = nullptr;
         for (int k = 0; k < VPT_KERNEL_COUNT; k++) { c->graph_kernel_launches[k] = c->stats.kernel_launches[k] - before[k]; c->stats.kernel_launches[k] = before[k]; }
@@ -913,8 +951,84 @@ int enqueue_graph(vpt_ctx* c, uint32_t frames, uint32_t dispatch_base, uint32_t 
     HIPCHK(c, hipGraphLaunch(c->graph, c->stream));
     for (int k = 0; k < VPT_KERNEL_COUNT; k++) c->stats.kernel_launches[k] += c->graph_kernel_launches[k];
     c->stats.graph_launches++;
+    b = c->graph_batch;
+    b.dispatch_base = dispatch_base;
     *used = true;
     return VPT_OK;
+}
+
+// ---- lanes (see vpt_ctx::lanes)
+int init_ctx_resources(vpt_ctx* c) {
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_shade, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_resolved, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_post, hipEventDisableTiming) != hipSuccess ||
+        hipMalloc((void**)&c->ctr, sizeof(Counters)) != hipSuccess) return VPT_ERR_DEVICE;
+    (void)hipMemset(c->ctr, 0, sizeof(Counters));
+    if (hipMalloc((void**)&c->sctr, sizeof(StreamCounters)) != hipSuccess) return VPT_ERR_DEVICE;
+    (void)hipMemset(c->sctr, 0, sizeof(StreamCounters));
+    if (hipMalloc((void**)&c->d_launch_off, (kMaxFramesInFlight + 1) * 4) != hipSuccess) return VPT_ERR_DEVICE;
+    for (int k = 0; k < kTickets; k++)
+        if (hipEventCreateWithFlags(&c->tick_ev[k], hipEventDisableTiming) != hipSuccess) { c->tick_ev[k] = nullptr; return VPT_ERR_DEVICE; }
+    if (hipHostMalloc((void**)&c->h_ctr, sizeof(HostCounters), hipHostMallocDefault) != hipSuccess) { c->h_ctr = nullptr; return VPT_ERR_DEVICE; }
+    memset(c->h_ctr, 0, sizeof(HostCounters));
+    if (hipMalloc((void**)&c->d_dispatch_base, 256) != hipSuccess || hipMalloc((void**)&c->d_spill_count, 256) != hipSuccess ||
+        hipMalloc((void**)&c->d_regen, sizeof(HotWord) * kRegenShards) != hipSuccess) return VPT_ERR_DEVICE;
+    return VPT_OK;
+}
+void destroy_lane(vpt_ctx* L);
+// Lane k of the owner: created on first use, holds one frame of path buffers for the owner's image size.
+vpt_ctx* get_lane(vpt_ctx* c, int k) {
+    if (c->lanes[k]) return c->lanes[k];
+    vpt_ctx* L = new vpt_ctx();
+    L->owner = c; L->cfg = c->cfg; L->cfg.frames_in_flight = 1; L->cfg.resident_frames = 1; L->cfg.profile = 0; L->cfg.count_traversal = 0;
+    L->cu_count = c->cu_count;
+    L->P = c->P;
+    bool ok = init_ctx_resources(L) == VPT_OK && alloc_path_buffers(L, 1, 1) == VPT_OK;
+    if (ok) {
+        const size_t bytes = stack_overflow_bytes((uint32_t)std::max(c->primary_blocks_general, c->primary_blocks_plain));
+        ok = hipMalloc(&L->lane_spill, bytes) == hipSuccess;
+    }
+    if (!ok) { (void)hipGetLastError(); destroy_lane(L); return nullptr; }
+    L->frames_in_flight = 1; L->buffers_ok = true;
+    c->lanes[k] = L;
+    return L;
+}
+// What a lane borrows from its owner, refreshed before every use: scene tables, parameters, camera, the accumulation image.
+void sync_lane(vpt_ctx* c, vpt_ctx* L) {
+    L->P = c->P; L->P.dispatch_base_dev = nullptr;
+    L->dsc = c->dsc; L->dsc.stack_overflow = (uint32_t*)L->lane_spill;
+    L->params = c->params;
+    L->lds_scene = c->lds_scene; L->scene_plain = c->scene_plain; L->depth_bounded = c->depth_bounded; L->has_scene = true;
+    L->primary_blocks = c->primary_blocks;
+    L->image = c->image;
+    L->state_gen = c->state_gen;   // the owner's generation invalidates the lane's captured batch too
+}
+void destroy_lane(vpt_ctx* L) {
+    if (!L) return;
+    if (L->stream) (void)hipStreamSynchronize(L->stream);
+    destroy_graph(L);
+    L->image = nullptr; L->full_image = nullptr;   // borrowed
+    free_render_buffers(L);
+    if (L->lane_spill) (void)hipFree(L->lane_spill);
+    for (int k = 0; k < kTickets; k++) if (L->tick_ev[k]) (void)hipEventDestroy(L->tick_ev[k]);
+    if (L->h_ctr) (void)hipHostFree(L->h_ctr);
+    if (L->d_dispatch_base) (void)hipFree(L->d_dispatch_base);
+    if (L->d_spill_count) (void)hipFree(L->d_spill_count);
+    if (L->d_regen) (void)hipFree(L->d_regen);
+    if (L->ctr) (void)hipFree(L->ctr);
+    if (L->sctr) (void)hipFree(L->sctr);
+    if (L->d_launch_off) (void)hipFree(L->d_launch_off);
+    if (L->ev_shade) (void)hipEventDestroy(L->ev_shade);
+    if (L->ev_join) (void)hipEventDestroy(L->ev_join);
+    if (L->ev_resolved) (void)hipEventDestroy(L->ev_resolved);
+    if (L->ev_post) (void)hipEventDestroy(L->ev_post);
+    if (L->stream2) (void)hipStreamDestroy(L->stream2);
+    if (L->stream) (void)hipStreamDestroy(L->stream);
+    delete L;
+}
+void destroy_lanes(vpt_ctx* c) {
+    for (vpt_ctx*& L : c->lanes) { destroy_lane(L); L = nullptr; }
+    c->order_lane = nullptr;
 }
 
 int ensure_post_buffers(vpt_ctx* c) {
@@ -965,20 +1079,7 @@ vpt_ctx* vpt_create(const vpt_config* cfg, int* err) {
     c->cfg = *cfg;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess) c->cu_count = prop.multiProcessorCount;
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_shade, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
-        hipMalloc((void**)&c->ctr, sizeof(Counters)) != hipSuccess) {
-        set(VPT_ERR_DEVICE); delete c; return nullptr;
-    }
-    (void)hipMemset(c->ctr, 0, sizeof(Counters));
-    if (hipMalloc((void**)&c->sctr, sizeof(StreamCounters)) != hipSuccess) { set(VPT_ERR_DEVICE); vpt_destroy(c); return nullptr; }
-    (void)hipMemset(c->sctr, 0, sizeof(StreamCounters));
-    if (hipMalloc((void**)&c->d_launch_off, (kMaxFramesInFlight + 1) * 4) != hipSuccess) { set(VPT_ERR_DEVICE); vpt_destroy(c); return nullptr; }
-    for (int k = 0; k < kTickets; k++)
-        if (hipEventCreateWithFlags(&c->tick_ev[k], hipEventDisableTiming) != hipSuccess) { c->tick_ev[k] = nullptr; set(VPT_ERR_DEVICE); vpt_destroy(c); return nullptr; }
-    if (hipHostMalloc((void**)&c->h_ctr, sizeof(HostCounters), hipHostMallocDefault) != hipSuccess) { c->h_ctr = nullptr; set(VPT_ERR_DEVICE); vpt_destroy(c); return nullptr; }
-    memset(c->h_ctr, 0, sizeof(HostCounters));
-    if (hipMalloc((void**)&c->d_dispatch_base, 256) != hipSuccess || hipMalloc((void**)&c->d_spill_count, 256) != hipSuccess) { set(VPT_ERR_DEVICE); vpt_destroy(c); return nullptr; }
+    if (init_ctx_resources(c) != VPT_OK) { (void)hipGetLastError(); set(VPT_ERR_DEVICE); vpt_destroy(c); return nullptr; }
     vpt_default_params(&c->params);
     const float id[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
     memcpy(c->P.view_inv, id, 64); memcpy(c->P.proj_inv, id, 64);
@@ -994,12 +1095,16 @@ void vpt_destroy(vpt_ctx* c) {
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->stream2) (void)hipStreamSynchronize(c->stream2);
+    destroy_lanes(c);
     destroy_graph(c);
     if (c->comm) { (void)ncclCommDestroy(c->comm); c->comm = nullptr; }
+    if (c->ev_resolved) (void)hipEventDestroy(c->ev_resolved);
+    if (c->ev_post) (void)hipEventDestroy(c->ev_post);
     for (int k = 0; k < kTickets; k++) if (c->tick_ev[k]) (void)hipEventDestroy(c->tick_ev[k]);
     if (c->h_ctr) (void)hipHostFree(c->h_ctr);
     if (c->d_dispatch_base) (void)hipFree(c->d_dispatch_base);
     if (c->d_spill_count) (void)hipFree(c->d_spill_count);
+    if (c->d_regen) (void)hipFree(c->d_regen);
     free_lab(c);
     free_scene(c);
     free_render_buffers(c);
@@ -1059,6 +1164,7 @@ int vpt_set_scene(vpt_ctx* c, const vpt_scene_desc* sd) {
     }
     free_scene(c);
     reset_accum(c);
+    destroy_lanes(c);   // (their spill regions are sized by this scene's grids)
     c->state_gen++;
     // ---- geometry pools
     std::vector<vpt_vertex> verts; std::vector<uint32_t> idx;
@@ -1406,6 +1512,7 @@ int vpt_resize(vpt_ctx* c, uint32_t w, uint32_t h) {
     int rc = check_render_size(c, w, h, &F);   // nothing is freed or changed for a size this context cannot hold
     if (rc != VPT_OK) return rc;
     if ((rc = drain(c))) return rc;
+    destroy_lanes(c);   // (they hold path buffers of the old size)
     c->state_gen++;
     c->cfg.width = w; c->cfg.height = h;
     reset_accum(c);
@@ -1488,22 +1595,40 @@ int vpt_render_async(vpt_ctx* c, uint32_t dispatches, int* done, uint64_t* ticke
         const bool fixed = c->depth_bounded && !vol && bounds <= VPT_ASYNC_MAX_BOUNCES && nf <= c->resident_alloc;   // (a regenerating batch has no fixed length)
         const uint32_t enq = (uint32_t)std::min<uint64_t>(bounds, VPT_ASYNC_MAX_BOUNCES);
         const uint32_t base = (uint32_t)c->dispatch_count;
+        const bool fused_auto = (c->cfg.pipeline == VPT_PIPELINE_FUSED || (c->cfg.pipeline == VPT_PIPELINE_AUTO && c->lds_scene)) && !vol;
+        const bool plain_launches = c->cfg.profile || c->cfg.count_traversal || c->P.split != 1u;
+        if (c->graph_streak_gen == c->state_gen) c->graph_streak++; else { c->graph_streak = 0; c->graph_streak_gen = c->state_gen; }
+        // the fused pipeline's fixed 1-frame batch goes to the next lane (vpt_ctx::lanes); asked for again with nothing changed since the
+        // last two calls it is replayed from the lane's captured graph
+        vpt_ctx* X = c;
+        if (fixed && fused_auto && !plain_launches && nf == 1u && c->P.shard_count >= 1u) {
+            const uint32_t k = c->lane_rr++ % 3u;
+            if (k != 0u) { vpt_ctx* L = get_lane(c, (int)k - 1); if (L) { sync_lane(c, L); X = L; } }
+        }
+        // a batch on the main lane behind pipelined frames: their resolves come first (frame order), and the records it overwrites are the main lane's own
+        if (X == c && c->order_lane && c->order_lane != c) HIPCHK(c, hipStreamWaitEvent(c->stream, c->order_lane->ev_resolved, 0));
         BatchState b;
         bool graphed = false;
-        // the fused pipeline's fixed batch, asked for again with nothing changed since the last two calls: replay it from a graph
-        const bool fused_auto = (c->cfg.pipeline == VPT_PIPELINE_FUSED || (c->cfg.pipeline == VPT_PIPELINE_AUTO && c->lds_scene)) && !vol;
-        if (c->graph_streak_gen == c->state_gen) c->graph_streak++; else { c->graph_streak = 0; c->graph_streak_gen = c->state_gen; }
-        if (fixed && fused_auto && !c->cfg.profile && !c->cfg.count_traversal && c->P.split == 1u && c->graph_streak >= 2u) {
-            if ((rc = enqueue_graph(c, nf, base, enq, &graphed))) return rc;
-            if (graphed) { b.n_slots = nf * c->P.shard_pixels; }
+        if (fixed && fused_auto && !plain_launches && c->graph_streak >= 2u) {
+            if ((rc = enqueue_graph(X, nf, base, enq, &graphed, b))) { if (X != c) c->err = X->err; return rc; }
         }
         if (!graphed) {
-            if ((rc = enqueue_fixed(c, nf, base, enq, b))) return rc;
+            if ((rc = enqueue_fixed(X, nf, base, enq, b))) { if (X != c) c->err = X->err; return rc; }
+        }
+        if (fixed && b.n_slots) {   // frames resolve in order: this one's resolve waits for the previous frame's, whichever lane that ran on
+            if (c->order_lane && c->order_lane != X) HIPCHK(c, hipStreamWaitEvent(X->stream, c->order_lane->ev_resolved, 0));
+            if (c->post_pending && X != c) HIPCHK(c, hipStreamWaitEvent(X->stream, c->ev_post, 0));   // ... and for the post-process that is still reading the image
+        }
+        if ((rc = batch_resolve(X, b))) { if (X != c) c->err = X->err; return rc; }
+        if (fixed && b.n_slots) {
+            HIPCHK(c, hipEventRecord(X->ev_resolved, X->stream));
+            c->order_lane = X;
+            X->last_fixed = b; X->last_fixed_valid = true;
         }
         c->stats.samples += (uint64_t)b.n_slots * c->P.samples_per_frame;
         advance_counts(c, nf);
         left -= nf;
-        const uint64_t t = issue_ticket(c);
+        const uint64_t t = issue_ticket(c, X->stream);
         if (!fixed && b.n_slots) { c->out_active = true; c->out_batch = b; c->out_ticket = t; }
     }
     if (ticket) *ticket = c->tick_issued;
@@ -1689,9 +1814,12 @@ int vpt_postprocess_device(vpt_ctx* c, const vpt_post_params* pp, void* rgba8_de
     if (rc) return rc;
     HIPCHK(c, hipSetDevice(c->cfg.device));
     if ((rc = finish_outstanding(c))) return rc;   // the image must be complete: an unfinished batch is finished first
+    if (c->order_lane && c->order_lane != c) HIPCHK(c, hipStreamWaitEvent(c->stream, c->order_lane->ev_resolved, 0));   // the latest frame was resolved on another lane
     if ((rc = enqueue_post(c, pp, false))) return rc;
     if (rgba8_device) HIPCHK(c, hipMemcpyAsync(rgba8_device, c->post_out, (size_t)c->P.width * c->P.height * 4, hipMemcpyDeviceToDevice, c->stream));
-    const uint64_t t = issue_ticket(c);
+    HIPCHK(c, hipEventRecord(c->ev_post, c->stream));
+    c->post_pending = true;
+    const uint64_t t = issue_ticket(c, c->stream);
     if (ticket) *ticket = t;
     return VPT_OK;
 }
@@ -1743,6 +1871,7 @@ int vpt_reset_stats(vpt_ctx* c) {
     c->stats = vpt_stats{};
     HIPCHK(c, hipMemset(c->ctr, 0, sizeof(Counters)));
     memset(c->h_ctr, 0, sizeof(HostCounters));
+    for (vpt_ctx* L : c->lanes) if (L) { HIPCHK(c, hipMemset(L->ctr, 0, sizeof(Counters))); memset(L->h_ctr, 0, sizeof(HostCounters)); L->stats = vpt_stats{}; }
     return VPT_OK;
 }
 

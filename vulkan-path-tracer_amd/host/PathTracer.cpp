@@ -1,6 +1,8 @@
 // PathTracer.cpp — forwards the reference's PathTracer members to the C-ABI (see PathTracer.h).
 #include "PathTracer.h"
 
+#include <algorithm>
+
 #include <cstring>
 #include <stdexcept>
 #include <utility>
@@ -177,6 +179,23 @@ bool PathTracer::PathTrace(uint32_t dispatches) {
     m_DispatchCount = st.dispatches;
     m_SamplesAccumulated = (uint32_t)st.frames * m_Params.samples_per_frame;  // PathTracer.cpp:151-153
     return done != 0;
+}
+
+bool PathTracer::PathTraceAsync(uint32_t dispatches, uint64_t* ticket) {
+    if (!m_Ctx) throw std::runtime_error("PathTrace before SetScene");
+    int done = 0;
+    Check(vpt_render_async(m_Ctx, dispatches, &done, ticket), "vpt_render_async");
+    // the counters advance at record time, as PathTrace's do (PathTracer.cpp:141-153); vpt_get_stats would wait for the device
+    if (!done) {
+        const uint64_t s2 = (uint64_t)m_Params.screen_chunk_count * m_Params.screen_chunk_count;
+        const uint64_t frames_needed = ((uint64_t)m_Params.max_samples + m_Params.samples_per_frame - 1) / m_Params.samples_per_frame;
+        m_DispatchCount = std::min<uint64_t>(m_DispatchCount + dispatches, frames_needed * s2);
+        m_SamplesAccumulated = (uint32_t)(m_DispatchCount / s2) * m_Params.samples_per_frame;
+    }
+    return done != 0;
+}
+void PathTracer::Wait(uint64_t ticket) {
+    if (m_Ctx) Check(vpt_wait(m_Ctx, ticket), "vpt_wait");
 }
 
 void PathTracer::ResizeImage(uint32_t width, uint32_t height) {

@@ -59,6 +59,11 @@ public:
     // True when all samples were accumulated (PathTracer.cpp:122-156). `dispatches` > 1 lets the backend keep
     // several frames in flight; PathTrace() == one reference call.
     bool PathTrace(uint32_t dispatches = 1);
+    // The same as the reference has it — the dispatch is RECORDED and the call returns (PathTracer.cpp:122-156 records into the frame's
+    // command buffer): vpt_render_async.  The returned ticket is the fence value of that work; Wait(ticket) blocks until it has finished
+    // (0: everything enqueued so far).  Every member that reads or changes device state drains outstanding work first.
+    bool PathTraceAsync(uint32_t dispatches = 1, uint64_t* ticket = nullptr);
+    void Wait(uint64_t ticket = 0);
     void ResizeImage(uint32_t width, uint32_t height);
 
     [[nodiscard]] const std::vector<float>& GetOutputImage();  // RGBA32F, width*height*4

@@ -16,6 +16,11 @@ public:
     static PostProcessor New() { return PostProcessor(); }
     void SetInputImage(PathTracer& source) { m_Source = &source; }
     void PostProcess();
+    // PostProcess(cmd) as the reference records it (PostProcessor.cpp:193-246): enqueued behind the source's renders, nothing waited for;
+    // the RGBA8 image stays on the device — GetOutputImageView() is its pointer (PostProcessor.h GetOutputImageView upstream), or pass
+    // an interop / swapchain image as `rgba8Device`.  Returns the ticket to hand to PathTracer::Wait.
+    uint64_t PostProcessAsync(void* rgba8Device = nullptr);
+    [[nodiscard]] const void* GetOutputImageView() const;
     void SetTonemappingData(const TonemappingData& data) { m_Tonemap = data; }
     void SetBloomData(const BloomData& data) { m_Bloom = data; }
     [[nodiscard]] const std::vector<uint8_t>& GetOutputImage() const { return m_Output; }  // RGBA8 UNORM
