@@ -198,6 +198,9 @@ typedef struct vpt_config {
 /* Keep the general instantiation of the fused per-bounce kernel even when the scene qualifies for the class-specialised one (every
  * texture 1x1 and a black environment: k_bounce<PLAIN>, kernels_path.hip).  Images are identical; this is the A/B switch of that choice. */
 #define VPT_BUILD_GENERAL_KERNELS 2u
+/* Closest-hit traversal of the streams pipeline: a stack entry whose child was entered beyond the best hit found since the push is
+ * dropped at the pop instead of costing a node step (vote.hpp pop_or_done_cull).  Hits are unchanged; the A/B switch of that choice. */
+#define VPT_BUILD_CULL_STALE 4u
 
 /* AUTO = FUSED when the BVH fits in LDS next to the traversal stacks, else STAGED. Results are identical. */
 #define VPT_PIPELINE_AUTO 0u

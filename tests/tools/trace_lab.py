@@ -165,8 +165,13 @@ def main():
                 plan = [(VOTE, 16), (VOTE, 256 + 16)] + [(VOTE, PW(w4, f)) for w4 in (4, 5, 6, 7, 10, 12) for f in (16,)] + [(VOTE, PW(w4, f)) for w4 in (6, 8) for f in (8, 12, 24)]
             if os.environ.get("LAB_TOP") == "1":   # LDS-resident tree top on / off (bit 16) in the run-time-parameter instantiation, next to the product one
                 plan = [(VOTE, 16), (VOTE, 256 + 16), (VOTE, PW(8, 16)), (VOTE, PW(8, 16) | (1 << 16))]
+            cull_mode = os.environ.get("LAB_CULL") == "1"
+            if cull_mode:   # stale-entry culling (bit 17, closest-hit sets) against the product instantiation, node / triangle visits of both
+                if any_hit:
+                    continue
+                plan = [(VOTE, 256 + 16), (VOTE, (256 + 16) | (1 << 17)), (VOTE, 256 + 16), (VOTE, (256 + 16) | (1 << 17))]
             for variant, param in plan:
-                first = ref is None or (variant in (VOTE, VOTE8) and param == 16)
+                first = ref is None or (variant in (VOTE, VOTE8) and param == 16) or cull_mode
                 ms, hits, vis = lab_trace(g, variant, any_hit, order, param, 5, True, first)
                 if ref is None:
                     ref = hits

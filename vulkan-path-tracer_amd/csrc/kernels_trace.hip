@@ -87,7 +87,8 @@ __global__ __launch_bounds__(kTraverseBlock, 8) void k_trace_base(DeviceScene sc
 // the pipeline always uses; the lab's other settings go through the instantiation that reads them from a.param.
 // STRICT (VPT_FLAG_LOCAL_HITS, traverse.hpp trace_closest_strict / trace_occluded_strict): a closest-hit winner is validated when its
 // ray retires and the ray is traced again without that triangle if the hit was not local to it; an any-hit stop is validated on the spot.
-template <bool ANY, bool COUNT, bool WIDE8, bool TUNED, bool STRICT = false>
+// CULL (closest-hit, four-wide tree): stale stack entries are dropped at the pop (vote.hpp LaneStack::pop_or_done_cull).
+template <bool ANY, bool COUNT, bool WIDE8, bool TUNED, bool STRICT = false, bool CULL = false>
 __global__ __launch_bounds__(kTraverseBlock, 8) void k_trace_vote(DeviceScene sc, TraceArgs a, Counters* ctr) {
     extern __shared__ __align__(16) unsigned char smem[];
     const LaneStack S = make_lane_stack(smem, sc.stack_overflow);
@@ -137,13 +138,13 @@ __global__ __launch_bounds__(kTraverseBlock, 8) void k_trace_vote(DeviceScene sc
             if (node_wins & at_node) {  // ---- inner-node step
                 if (COUNT) st_nodes++;
                 if (WIDE8) vote_node8_step(sc.nodes8, S, cur, sp, o, inv, a.tmin, best_t);
-                else vote_node_step<ANY>(nodes, top, S, cur, sp, o, inv, a.tmin, best_t);
+                else vote_node_step<ANY, ANY, CULL>(nodes, top, S, cur, sp, o, inv, a.tmin, best_t);
             }
             VPT_MARK("tri");
             if (!node_wins & at_leaf) {  // ---- triangle step: ONE triangle of the lane's leaf
                 if (COUNT) st_tris++;
                 if (ANY) { if (vote_tri_step_any<STRICT>(tris, S, cur, sp, o, d, a.tmin, a.tmax, a.tmax, 0xffffffffu)) bslot = 0u; }
-                else vote_tri_step_closest<STRICT>(tris, S, cur, sp, o, d, a.tmin, a.tmax, best_t, bu, bv, bslot, bgid, ex0, ex1);
+                else vote_tri_step_closest<STRICT, CULL>(tris, S, cur, sp, o, d, a.tmin, a.tmax, best_t, bu, bv, bslot, bgid, ex0, ex1);
             }
         }
         VPT_MARK("exit");
@@ -354,6 +355,11 @@ void launch_trace(hipStream_t s, uint32_t blocks, uint32_t variant, bool any, bo
     else if (sc.strict_hits) {   // VPT_FLAG_LOCAL_HITS: the validating instantiations (default vote parameters; the counting ones read them from a.param)
         if (any) { if (count) hipLaunchKernelGGL((k_trace_vote<true, true, false, false, true>), g, b, lds, s, sc, a, ctr); else hipLaunchKernelGGL((k_trace_vote<true, false, false, true, true>), g, b, lds, s, sc, a, ctr); }
         else { if (count) hipLaunchKernelGGL((k_trace_vote<false, true, false, false, true>), g, b, lds, s, sc, a, ctr); else hipLaunchKernelGGL((k_trace_vote<false, false, false, true, true>), g, b, lds, s, sc, a, ctr); }
+    }
+    else if (a.cull && !any) {   // stale-entry culling (closest-hit only)
+        if (count) hipLaunchKernelGGL((k_trace_vote<false, true, false, false, false, true>), g, b, lds, s, sc, a, ctr);
+        else if (a.param == kVoteParamDefault) hipLaunchKernelGGL((k_trace_vote<false, false, false, true, false, true>), g, b, lds, s, sc, a, ctr);
+        else hipLaunchKernelGGL((k_trace_vote<false, false, false, false, false, true>), g, b, lds, s, sc, a, ctr);
     }
     else if (a.param == kVoteParamDefault) VPT_LV(false, true); else VPT_LV(false, false);
 #undef VPT_LV

@@ -45,27 +45,33 @@ __device__ inline void launch_pixel(const RenderParams& P, uint32_t li, uint32_t
 // the wave that is active at the call site must call; returns true and the id where the lane got one.
 __device__ __forceinline__ bool regen_take(const RenderParams& P, bool want, uint32_t& id) {
     bool got = false;
+    if (__ballot(want) == 0ull) return false;
+    // word kRegenShards of the array: set once a wave has found every shard empty — from then on (the batch's last max_depth launches)
+    // a finished lane costs one load instead of a walk over all the counters
+    if (__hip_atomic_load(&P.regen_next[kRegenShards].v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
     uint32_t shard = ((blockIdx.x * (blockDim.x >> 6)) + (threadIdx.x >> 6)) % kRegenShards;
     const uint32_t span = P.regen_total - P.regen_first;
+    bool all_empty = true;   // of the shards this lane has seen (lanes that still want after the walk have seen all of them)
     for (uint32_t tries = 0; tries < kRegenShards; tries++) {
         const unsigned long long m = __ballot(want && !got);
         if (m == 0ull) break;
         const uint32_t lo = shard * P.regen_shard, hi = lo + P.regen_shard < span ? lo + P.regen_shard : span;   // ids of this shard, relative
         const uint32_t size = lo < hi ? hi - lo : 0u;
-        uint32_t base = size;
         if (want && !got) {
+            uint32_t base = size;
             const uint32_t leader = (uint32_t)__ffsll((long long)m) - 1u;
             if (lane_id() == leader) {
-                base = size;
                 if (size != 0u && __hip_atomic_load(&P.regen_next[shard].v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < size)
                     base = atomicAdd(&P.regen_next[shard].v, (uint32_t)__popcll(m));
             }
             base = __shfl(base, (int)leader);
             const uint32_t k = base + lanes_below(m);
             if (k < size) { id = P.regen_first + lo + k; got = true; }
+            if (base < size) all_empty = false;   // (somebody got one here: the shard was not empty when this wave came by)
         }
         shard = (shard + 1u) % kRegenShards;
     }
+    if (want && !got && all_empty) P.regen_next[kRegenShards].v = 1u;
     return got;
 }
 

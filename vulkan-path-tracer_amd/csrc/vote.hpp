@@ -16,9 +16,41 @@ constexpr uint32_t kRayHole = 0xfffffffeu;  // SKD.z / LTD.z of a shadow-ray str
 constexpr uint32_t kHole = 0xffffffffu;  // a stream entry nobody wrote (tail of a wave's last chunk, see WaveAppender)
 
 constexpr int kVoteStackRows = kStackDepth;   // LDS rows of the vote kernels' stacks
+constexpr size_t kVoteStackBytes = (size_t)kVoteStackRows * kTraverseBlock * 4;
+// Stale-entry culling (closest-hit search, CULL instantiations): next to every LDS stack entry sits one byte, the entry distance of
+// the pushed child quantised DOWN (sign-free float bits >> 20: 3 mantissa bits, 12.5 % steps; clamped into a byte).  When the ray has
+// found a closer hit since the push, a pop sees `byte > quantised best_t` — which implies entry distance > best_t, strictly — and drops
+// the entry instead of spending a whole node step (four slab tests) on finding out that nothing in it can win.  A pruned node holds no
+// candidate with t <= best_t, so hits (ties included) cannot change.  Spilled entries carry no byte and are never culled.
+constexpr uint32_t kCullBias = 900u;   // float bits >> 20 of 2^-8 .. 2^23 map to 902 .. 1150; the byte clamps below and above (conservatively)
+__device__ __forceinline__ uint32_t cull_quant(float t) {
+    const uint32_t b = __float_as_uint(t) >> 20;
+    const uint32_t q = b > kCullBias ? b - kCullBias : 0u;
+    return q < 255u ? q : 255u;
+}
 struct LaneStack {
     uint32_t* stk;  // LDS: entry k of this lane at stk[k * kTraverseBlock]
     uint32_t* ovf;  // global: entries beyond kStackDepth
+    unsigned char* tq;  // LDS (CULL kernels only): byte k of this lane at tq[k * kTraverseBlock]
+    __device__ __forceinline__ void push_t(int& sp, int v, float t) const {
+        if (sp < kStackDepth) { stk[sp * kTraverseBlock] = (uint32_t)v; tq[sp * kTraverseBlock] = (unsigned char)cull_quant(t); }
+        else if (sp < kStackDepth + kStackOverflow) ovf[sp - kStackDepth] = (uint32_t)v;
+        sp++;
+    }
+    __device__ __forceinline__ void pop_or_done_cull(int& sp, int& cur, float best_t) const {
+        const uint32_t qb = cull_quant(best_t);
+        while (true) {
+            if (sp == 0) { cur = kLaneDone; return; }
+            sp--;
+            if (sp < kStackDepth) {
+                if ((uint32_t)tq[sp * kTraverseBlock] > qb) continue;   // entered beyond the best hit found since: nothing in it can win
+                cur = (int)stk[sp * kTraverseBlock];
+                return;
+            }
+            cur = (int)ovf[sp - kStackDepth];
+            return;
+        }
+    }
     __device__ __forceinline__ void push(int& sp, int v) const {
         if (sp < kStackDepth) stk[sp * kTraverseBlock] = (uint32_t)v;
         else if (sp < kStackDepth + kStackOverflow) ovf[sp - kStackDepth] = (uint32_t)v;
@@ -42,9 +74,9 @@ __device__ __forceinline__ LaneStack make_lane_stack(unsigned char* smem, uint32
     LaneStack S;
     S.stk = reinterpret_cast<uint32_t*>(smem) + threadIdx.x;
     S.ovf = overflow + (size_t)(blockIdx.x * blockDim.x + threadIdx.x) * kStackOverflow;
+    S.tq = smem + kVoteStackBytes + threadIdx.x;   // the bytes live where the any-hit kernels keep their tree top (kVoteTopBytes >= kStackDepth * kTraverseBlock)
     return S;
 }
-constexpr size_t kVoteStackBytes = (size_t)kVoteStackRows * kTraverseBlock * 4;
 // The block's LDS copy of the tree top (device_types.hpp kBvhTopNodes) sits behind the stacks.  A node index below `top` is fetched
 // from it through a GENERIC pointer — one flat_load per 16-byte piece, the lane's address decides between LDS and the vector L1 —
 // so the lanes at the top of the tree, which every ray passes, cost the L1 nothing.  Why: the traversal kernels sit at ~0.9 L1
@@ -52,6 +84,7 @@ constexpr size_t kVoteStackBytes = (size_t)kVoteStackRows * kTraverseBlock * 4;
 // per-lane access per clock, four per node visit (profiles/r03_trace_isa_budget.md, tests/tools/gather_calib.hip mode E).
 constexpr size_t kVoteTopBytes = (size_t)kBvhTopNodes * sizeof(BvhNode);
 constexpr size_t kVoteLdsBytes = kVoteStackBytes + kVoteTopBytes;
+static_assert(kVoteTopBytes >= (size_t)kStackDepth * kTraverseBlock, "the culling bytes of the closest-hit kernels share the tree-top region");
 struct TreeTop {
     const uint4* lds;   // generic pointer into LDS
     int count;          // nodes held there (0: none — the lab's other variants)
@@ -73,7 +106,7 @@ __device__ __forceinline__ TreeTop stage_tree_top(unsigned char* smem, const Bvh
 // USE_TOP: only the any-hit kernels use the LDS tree top.  Measured (atrium / glass bust, bench kernel means): shadow stage 4.46 -> 3.94 ms
 // and 0.318 -> 0.311 ms with it — those kernels are L1-bound with VALU issue to spare (VALUBusy 82-85 %); the closest-hit extend kernel,
 // VALU-saturated, pays for the six instructions of the address select: 6.37 -> 6.71 ms and 1.12 -> 1.19 ms, so it keeps the plain load.
-template <bool ANY, bool USE_TOP = ANY>
+template <bool ANY, bool USE_TOP = ANY, bool CULL = false>
 __device__ __forceinline__ void vote_node_step(const BvhNode* nodes, const TreeTop& top, const LaneStack& S, int& cur, int& sp, V3 o, V3 inv, float tmin, float tlimit) {
     const uint4* p = (USE_TOP && cur < top.count) ? top.lds + cur * 4 : reinterpret_cast<const uint4*>(nodes + cur);
     NodeData n;
@@ -93,12 +126,18 @@ __device__ __forceinline__ void vote_node_step(const BvhNode* nodes, const TreeT
     } else {
         cswap(t0, c0, t1, c1); cswap(t2, c2, t3, c3); cswap(t0, c0, t2, c2); cswap(t1, c1, t3, c3); cswap(t1, c1, t2, c2);
         if (t0 < kMissT) {  // nearest child next, the others pushed far -> near
-            if (t3 < kMissT) S.push(sp, c3);
-            if (t2 < kMissT) S.push(sp, c2);
-            if (t1 < kMissT) S.push(sp, c1);
+            if (CULL) {
+                if (t3 < kMissT) S.push_t(sp, c3, t3);
+                if (t2 < kMissT) S.push_t(sp, c2, t2);
+                if (t1 < kMissT) S.push_t(sp, c1, t1);
+            } else {
+                if (t3 < kMissT) S.push(sp, c3);
+                if (t2 < kMissT) S.push(sp, c2);
+                if (t1 < kMissT) S.push(sp, c1);
+            }
             cur = c0;
         } else {
-            S.pop_or_done(sp, cur);
+            if (CULL) S.pop_or_done_cull(sp, cur, tlimit); else S.pop_or_done(sp, cur);
         }
     }
 }
@@ -173,7 +212,7 @@ __device__ __forceinline__ bool ray_triangle_flat(V3 o, V3 d, V3 v0, V3 e1, V3 e
 // One triangle of the lane's leaf, closest-hit search (ties in t -> smaller global id).  STRICT (VPT_FLAG_LOCAL_HITS): triangles
 // ex0 / ex1 — winners of earlier passes over this ray whose hit was not local to them — are not candidates (traverse.hpp
 // trace_closest_strict).
-template <bool STRICT = false>
+template <bool STRICT = false, bool CULL = false>
 __device__ __forceinline__ void vote_tri_step_closest(const BvhTri* tris, const LaneStack& S, int& cur, int& sp, V3 o, V3 d, float tmin, float tmax,
                                                       float& best_t, float& bu, float& bv, uint32_t& bslot, uint32_t& bgid, uint32_t ex0 = 0xffffffffu,
                                                       uint32_t ex1 = 0xffffffffu) {
@@ -188,6 +227,7 @@ __device__ __forceinline__ void vote_tri_step_closest(const BvhTri* tris, const 
     const bool better = hit & (!STRICT | ((gid != ex0) & (gid != ex1))) & ((bslot == 0xffffffffu) | (t < best_t) | ((t == best_t) & (gid < bgid)));
     best_t = better ? t : best_t; bu = better ? u : bu; bv = better ? v : bv; bslot = better ? (uint32_t)first : bslot; bgid = better ? gid : bgid;
     if (more) cur = ~(int)((((uint32_t)first + 1u) << 3) | (more - 1u));
+    else if (CULL) S.pop_or_done_cull(sp, cur, best_t);
     else S.pop_or_done(sp, cur);
 }
 // One triangle of the lane's leaf, any-hit search: stops at the first triangle hit with t < tlim, or t == tlim and a

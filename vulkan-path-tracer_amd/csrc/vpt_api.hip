@@ -155,6 +155,7 @@ struct vpt_ctx {
     int primary_blocks_general = 768, primary_blocks_plain = 768;   // grids of the fused kernel's two instantiations (primary_blocks = the one scene_plain picks)
     int vote_blocks = 2048;   // persistent grid of the vote-scheduled traversal kernels
     uint32_t vote_param = 256u + 16u;  // weighted vote, fetch step at 16 idle lanes (profiles/r02_trace_lab_*.json)
+    bool trace_cull = false;           // extend stage: stale stack entries dropped at the pop (vote.hpp; vpt_config.build_flags & VPT_BUILD_CULL_STALE)
     Counters* ctr = nullptr;
     StreamCounters* sctr = nullptr;   // stream pipeline: lengths, exact live counts and work cursors, one cache line each
     float* image = nullptr;       // this shard's rows, RGBA32F
@@ -650,7 +651,7 @@ int batch_begin(vpt_ctx* c, uint32_t frames, uint32_t dispatch_base, BatchState&
     c->P.regen_total = frames * c->P.shard_pixels;
     c->P.regen_shard = (c->P.regen_total - c->P.regen_first + kRegenShards - 1u) / kRegenShards;
     c->P.batch_base = dispatch_base;
-    if (regen) HIPCHK(c, hipMemsetAsync(c->d_regen, 0, sizeof(HotWord) * kRegenShards, s));
+    if (regen) HIPCHK(c, hipMemsetAsync(c->d_regen, 0, sizeof(HotWord) * (kRegenShards + 1), s));
     uint32_t n_slots = frames * c->P.shard_pixels;  // samples of the batch
     const uint32_t S = c->P.split;
     if (S > 1) {  // RayTrace(ceil(W/S), ceil(H/S)) per dispatch, in-bounds part only (PathTracer.cpp:145-150, RayGen.slang:24)
@@ -748,6 +749,7 @@ int batch_bounces(vpt_ctx* c, BatchState& b, uint32_t bounces) {
             a.ro = c->ss.RA[parity]; a.rd = c->ss.RB[parity]; a.order = nullptr; a.valid = c->queue[parity]; a.hit = c->ss.SH; a.hinst = c->ss.SHI; a.cls = c->cls_q;
             a.n = 0; a.n_dev = &c->sctr->queue_len[parity].v; a.head = &c->sctr->extend_head.v;
             a.tmin = 0.01f; a.tmax = 100000.0f; a.normalize_dir = 1u; a.store_gid = 1u; a.param = c->vote_param;
+            a.cull = c->trace_cull ? 1u : 0u;
             if (!sorted) a.cls = nullptr;
             TIMED(c, VPT_K_EXTEND, launch_trace(s, (uint32_t)c->vote_blocks, VPT_TRACE_VOTE, false, count, c->dsc, a, c->ctr));
             // the shade stage of this bounce overwrites the pending records and shadow-ray streams the join of the previous
@@ -972,7 +974,7 @@ int init_ctx_resources(vpt_ctx* c) {
     if (hipHostMalloc((void**)&c->h_ctr, sizeof(HostCounters), hipHostMallocDefault) != hipSuccess) { c->h_ctr = nullptr; return VPT_ERR_DEVICE; }
     memset(c->h_ctr, 0, sizeof(HostCounters));
     if (hipMalloc((void**)&c->d_dispatch_base, 256) != hipSuccess || hipMalloc((void**)&c->d_spill_count, 256) != hipSuccess ||
-        hipMalloc((void**)&c->d_regen, sizeof(HotWord) * kRegenShards) != hipSuccess) return VPT_ERR_DEVICE;
+        hipMalloc((void**)&c->d_regen, sizeof(HotWord) * (kRegenShards + 1)) != hipSuccess) return VPT_ERR_DEVICE;
     return VPT_OK;
 }
 void destroy_lane(vpt_ctx* L);
@@ -1209,6 +1211,7 @@ int vpt_set_scene(vpt_ctx* c, const vpt_scene_desc* sd) {
     }
     std::vector<BvhNode> nodes; std::vector<BvhNodeWide> wide; std::vector<BvhTri> leaf_tris; int depth = 0;
     c->sbvh = (c->cfg.build_flags & VPT_BUILD_SBVH) != 0u;   // spatial splits in the builder: a per-context option
+    c->trace_cull = (c->cfg.build_flags & VPT_BUILD_CULL_STALE) != 0u;
     const auto t_bvh0 = std::chrono::steady_clock::now();
     build_bvh(tris, nodes, wide, leaf_tris, &depth, nullptr, c->sbvh);
     c->bvh_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_bvh0).count();
@@ -1609,12 +1612,22 @@ int vpt_render_async(vpt_ctx* c, uint32_t dispatches, int* done, uint64_t* ticke
         if (X == c && c->order_lane && c->order_lane != c) HIPCHK(c, hipStreamWaitEvent(c->stream, c->order_lane->ev_resolved, 0));
         BatchState b;
         bool graphed = false;
+        const bool pipelined = fixed && fused_auto && !plain_launches && nf == 1u && c->graph_streak >= 2u;
+        // Frames in steady accumulation share the chip: each lane's kernels take a third of the persistent grid (one block per CU of the
+        // three the fused kernel's LDS allows), so that the three lanes' chains are co-resident and the tail of one frame — launches that are
+        // bounded by one bounce's latency, not by throughput — runs beside the first bounces of the next two.  (A full-size grid fills every
+        // CU's LDS and keeps the other lanes' blocks out until it retires.)
+        const int full_grid = X->primary_blocks;
+        if (pipelined) X->primary_blocks = std::max(c->cu_count, (c->primary_blocks / 3 / std::max(c->cu_count, 1)) * c->cu_count);
         if (fixed && fused_auto && !plain_launches && c->graph_streak >= 2u) {
-            if ((rc = enqueue_graph(X, nf, base, enq, &graphed, b))) { if (X != c) c->err = X->err; return rc; }
+            rc = enqueue_graph(X, nf, base, enq, &graphed, b);
+            if (rc) { X->primary_blocks = full_grid; if (X != c) c->err = X->err; return rc; }
         }
         if (!graphed) {
-            if ((rc = enqueue_fixed(X, nf, base, enq, b))) { if (X != c) c->err = X->err; return rc; }
+            rc = enqueue_fixed(X, nf, base, enq, b);
+            if (rc) { X->primary_blocks = full_grid; if (X != c) c->err = X->err; return rc; }
         }
+        X->primary_blocks = full_grid;
         if (fixed && b.n_slots) {   // frames resolve in order: this one's resolve waits for the previous frame's, whichever lane that ran on
             if (c->order_lane && c->order_lane != X) HIPCHK(c, hipStreamWaitEvent(X->stream, c->order_lane->ev_resolved, 0));
             if (c->post_pending && X != c) HIPCHK(c, hipStreamWaitEvent(X->stream, c->ev_post, 0));   // ... and for the post-process that is still reading the image
@@ -2064,7 +2077,8 @@ int vpt_lab_trace(vpt_ctx* c, uint32_t variant, uint32_t any_hit, const uint32_t
     if (order) HIPCHK(c, hipMemcpy(c->lab_order, order, (size_t)n * 4, hipMemcpyHostToDevice));
     TraceArgs a{};
     a.ro = c->lab_ro; a.rd = c->lab_rd; a.order = order ? c->lab_order : nullptr; a.hit = c->lab_hit; a.hinst = c->lab_hinst;
-    a.n = n; a.head = &c->ctr->extend_head; a.tmin = c->lab_tmin; a.tmax = c->lab_tmax; a.normalize_dir = 0u; a.param = param;
+    a.n = n; a.head = &c->ctr->extend_head; a.tmin = c->lab_tmin; a.tmax = c->lab_tmax; a.normalize_dir = 0u; a.param = param & 0xfffdffffu;
+    a.cull = (param >> 17) & 1u;   // lab: bit 17 = stale-entry culling (closest-hit, VPT_TRACE_VOTE)
     const uint32_t blocks = (uint32_t)std::min(trace_blocks_per_cu(variant, any_hit != 0) * c->cu_count, c->max_blocks);
     hipEvent_t e0, e1;
     HIPCHK(c, hipEventCreate(&e0)); HIPCHK(c, hipEventCreate(&e1));
