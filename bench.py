@@ -406,6 +406,9 @@ def roofline_for(name, prof):
                 "busy": valu_busy, "active_lanes_of_64": lanes, "frac": round(min(valu_busy, 1.0) * lanes / 64.0, 4),
                 "lane_ops_per_s": round(min(valu_busy, 1.0) * lanes / 64.0 * VALU_LANE_OPS_PEAK, 1), "peak_lane_ops_per_s": VALU_LANE_OPS_PEAK,
                 "fp32_tflops_if_every_op_were_an_fma": round(min(valu_busy, 1.0) * lanes / 64.0 * VALU_LANE_OPS_PEAK * 2 / 1e12, 2), "fp32_peak_tflops": 157.3,
+                # measured, not derived (profiles/collect_bench_r04.sh `flops` pass: SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F32 x 64 lanes x lane use / launch time)
+                "fp32_tflops_measured": entry.get("fp32_tflops"), "fp32_frac_of_peak": None if entry.get("fp32_tflops") is None else round(entry["fp32_tflops"] / 157.3, 4),
+                "fp32_share_of_valu_instr": entry.get("fp32_share_of_valu_instr"),
                 "note": "the traversal kernels' instruction mix is ~40 % fp32 arithmetic (profiles/r03_trace_isa_budget.md), none of it packed"},
             "record_bytes_per_launch": round(k["record_bytes_per_unit"] * k["units_per_launch"], 0),
             "algorithmic_bytes_per_launch": round(k["algorithmic_bytes_per_unit"] * k["units_per_launch"], 0),

@@ -53,7 +53,8 @@ extern "C" {
  * where the ray is inside the triangle's own bounding box (vpt_fp32.h hit_is_local).  Without it, a ray grazing a small
  * triangle at < 1e-3 rad can be given a hit up to ~1e-2 scene units off the triangle by fp32 rounding, which a box
  * hierarchy sees or not depending on its shape — about one ray in 1e9, 1e-11 relative L2 on a 531 M-sample image.
- * With it the image equals brute-force intersection bit for bit at any size, for ~11 % of the throughput. */
+ * With it the image equals brute-force intersection bit for bit at any size.  Cost in throughput, measured at 1080p on the default
+ * pipelines (profiles/r04_strict_rate.json): Cornell box (fused kernel) 11.5 %, atrium (streams) 6.8 %, glass bust (streams, depth 32) 0.5 %. */
 #define VPT_FLAG_LOCAL_HITS (1u << 8)
 #define VPT_FLAGS_DEFAULT                                                                                   \
     (VPT_FLAG_SKY_MIS | VPT_FLAG_MESH_MIS | VPT_FLAG_SHOW_ENV_DIRECTLY | VPT_FLAG_ENERGY_COMPENSATION |    \
@@ -185,9 +186,12 @@ typedef struct vpt_config {
      * frames a lane whose sample has ended takes the next unstarted sample of the batch in the same launch (a fresh camera ray; seeds
      * depend on pixel and frame only, a sample's result lands in its own slot of the frame sums and the running mean is applied in frame
      * order when the batch has finished), so every launch works on ~K x pixels paths until the samples run out — one shrinking tail per
-     * batch instead of one per frame, ~290 B per resident path + 48 B per sample instead of 380 B per sample.  0 = the library's choice
-     * (what was measured fastest per pipeline); a value >= the batch size keeps every sample resident (round 3's
-     * schedule).  Media batches, split-screen dispatch and VPT_PIPELINE_STAGED_R1 always keep every sample resident.
+     * batch instead of one per frame, ~290 B per resident path + 48 B per sample instead of 380 B per sample.  It trades throughput for
+     * memory (1080p, batches of 226 frames, profiles/r04_frames_sweep.json): all 469M samples resident 149 GB; 265M paths 94 GB at -4 % (atrium)
+     * / -6 % (glass bust) / -9 % (Cornell box, whose bounce 0 otherwise runs in a kernel that reads nothing); 33M paths 33 GB at -13 / -19 /
+     * -31 %: every bounce is five dependent launches whose ramp and tail weigh more on smaller queues.  0 (default) or a value >= the batch
+     * size: every sample resident (round 3's schedule — the fastest, and with buffers that grow only to the batches actually asked
+     * for an interactive host never pays for it).  Media batches, split-screen dispatch and VPT_PIPELINE_STAGED_R1 always keep every sample resident.
      * Images do not depend on it, bit for bit.  Reference loop being unrolled: RayGen.slang:28-33,116-159. */
     uint32_t resident_frames;
 } vpt_config;
@@ -198,9 +202,6 @@ typedef struct vpt_config {
 /* Keep the general instantiation of the fused per-bounce kernel even when the scene qualifies for the class-specialised one (every
  * texture 1x1 and a black environment: k_bounce<PLAIN>, kernels_path.hip).  Images are identical; this is the A/B switch of that choice. */
 #define VPT_BUILD_GENERAL_KERNELS 2u
-/* Closest-hit traversal of the streams pipeline: a stack entry whose child was entered beyond the best hit found since the push is
- * dropped at the pop instead of costing a node step (vote.hpp pop_or_done_cull).  Hits are unchanged; the A/B switch of that choice. */
-#define VPT_BUILD_CULL_STALE 4u
 
 /* AUTO = FUSED when the BVH fits in LDS next to the traversal stacks, else STAGED. Results are identical. */
 #define VPT_PIPELINE_AUTO 0u

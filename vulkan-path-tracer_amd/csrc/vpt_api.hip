@@ -21,7 +21,6 @@ using namespace vpt;
 constexpr uint64_t kBytesPerPath = 380;          // core slot records 68 + stream records ~290 (slack included) + queues 8 + image share
 constexpr uint32_t kMaxFramesInFlight = 2048;   // frames of one batch (a 1/8 shard of 1080p holds ~448M paths at 1728 frames)
 constexpr uint64_t kResidentPaths = 448ull << 20;   // samples of a batch by default (see check_render_size)
-constexpr uint64_t kRegenResidentPaths = 32ull << 20;   // of which resident at a time when paths are regenerated (vpt_config.resident_frames == 0)
 
 // One wavefront batch in progress: what render_batch's stages hand to each other (and what an asynchronous batch leaves behind for
 // the call that finishes it).
@@ -155,7 +154,6 @@ struct vpt_ctx {
     int primary_blocks_general = 768, primary_blocks_plain = 768;   // grids of the fused kernel's two instantiations (primary_blocks = the one scene_plain picks)
     int vote_blocks = 2048;   // persistent grid of the vote-scheduled traversal kernels
     uint32_t vote_param = 256u + 16u;  // weighted vote, fetch step at 16 idle lanes (profiles/r02_trace_lab_*.json)
-    bool trace_cull = false;           // extend stage: stale stack entries dropped at the pop (vote.hpp; vpt_config.build_flags & VPT_BUILD_CULL_STALE)
     Counters* ctr = nullptr;
     StreamCounters* sctr = nullptr;   // stream pipeline: lengths, exact live counts and work cursors, one cache line each
     float* image = nullptr;       // this shard's rows, RGBA32F
@@ -387,12 +385,9 @@ bool regen_allowed(const vpt_ctx* c) {
 uint32_t resident_frames_for(const vpt_ctx* c, uint32_t frames) {
     if (!regen_allowed(c)) return frames;
     uint64_t k = c->cfg.resident_frames;
-    if (k == 0) {
-        // the library's choice: the fused pipeline (LDS-sized scenes) keeps every sample resident — its bounce 0 is a kernel of its own
-        // that reads nothing, which a regenerated sample forgoes (profiles/r04_frames_sweep.json) —, the streams keep ~32M paths
-        const bool fused = c->cfg.pipeline == VPT_PIPELINE_FUSED || (c->cfg.pipeline == VPT_PIPELINE_AUTO && c->lds_scene);
-        k = fused ? frames : std::max<uint64_t>(1, kRegenResidentPaths / std::max<uint64_t>(1, c->P.shard_pixels));
-    }
+    // 0: every sample resident — the fastest schedule on every scene measured (profiles/r04_frames_sweep.json: regeneration costs 4-9 % at
+    // 265M resident paths, 13-31 % at 33M); regeneration is the caller's trade of throughput for memory
+    if (k == 0) k = frames;
     return (uint32_t)std::min<uint64_t>(frames, k);
 }
 
@@ -749,7 +744,6 @@ int batch_bounces(vpt_ctx* c, BatchState& b, uint32_t bounces) {
             a.ro = c->ss.RA[parity]; a.rd = c->ss.RB[parity]; a.order = nullptr; a.valid = c->queue[parity]; a.hit = c->ss.SH; a.hinst = c->ss.SHI; a.cls = c->cls_q;
             a.n = 0; a.n_dev = &c->sctr->queue_len[parity].v; a.head = &c->sctr->extend_head.v;
             a.tmin = 0.01f; a.tmax = 100000.0f; a.normalize_dir = 1u; a.store_gid = 1u; a.param = c->vote_param;
-            a.cull = c->trace_cull ? 1u : 0u;
             if (!sorted) a.cls = nullptr;
             TIMED(c, VPT_K_EXTEND, launch_trace(s, (uint32_t)c->vote_blocks, VPT_TRACE_VOTE, false, count, c->dsc, a, c->ctr));
             // the shade stage of this bounce overwrites the pending records and shadow-ray streams the join of the previous
@@ -1211,7 +1205,6 @@ int vpt_set_scene(vpt_ctx* c, const vpt_scene_desc* sd) {
     }
     std::vector<BvhNode> nodes; std::vector<BvhNodeWide> wide; std::vector<BvhTri> leaf_tris; int depth = 0;
     c->sbvh = (c->cfg.build_flags & VPT_BUILD_SBVH) != 0u;   // spatial splits in the builder: a per-context option
-    c->trace_cull = (c->cfg.build_flags & VPT_BUILD_CULL_STALE) != 0u;
     const auto t_bvh0 = std::chrono::steady_clock::now();
     build_bvh(tris, nodes, wide, leaf_tris, &depth, nullptr, c->sbvh);
     c->bvh_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_bvh0).count();
