@@ -334,8 +334,8 @@ def frame_latency(vpt, name, scene, params, device, frames=30):
     that keeps a single frame in flight.  Two forms: `blocking` = vpt_render(ctx, 1) + vpt_postprocess, host wall clock per frame incl.
     both blocking syncs and the 8 MB RGBA8 read-back (what round 3 reported as frame_ms); `async` = what the reference actually does —
     PathTrace(cmd) and PostProcess(cmd) record and return, the output stays on the device (PathTracer.h:94-95) — through
-    vpt_render_async + vpt_postprocess_device with one vpt_wait per frame on the frame BEFORE (two frames in flight on the host side,
-    like a swapchain): steady-state wall clock per frame."""
+    vpt_render_async + vpt_postprocess_device with one vpt_wait per frame on an EARLIER frame's ticket (two or three frames in flight,
+    like a double- / triple-buffered swapchain): steady-state wall clock per frame."""
     W, H = WORKLOADS[name]["w"], WORKLOADS[name]["h"]
     g = vpt.PathTracer(W, H, device=device, frames_in_flight=1)
     g.set_scene(scene); g.set_params(params)
@@ -347,25 +347,22 @@ def frame_latency(vpt, name, scene, params, device, frames=30):
         tr += t1 - t0; tp += t2 - t1
     out = {"blocking_frame_ms": round((tr + tp) / frames * 1e3, 4), "render_1spp_ms": round(tr / frames * 1e3, 4), "postprocess_ms": round(tp / frames * 1e3, 4),
            "frames": frames, "what": "per 1-spp frame at %dx%d, 1 frame in flight; blocking: vpt_render(ctx, 1) + vpt_postprocess incl. syncs and the RGBA8 read-back; "
-                                     "frame_ms: vpt_render_async + vpt_postprocess_device (RGBA8 stays on the device), one vpt_wait per frame on the previous frame" % (W, H)}
-    if hasattr(g, "render_async"):
-        n = frames * 4
+                                     "frame_ms: vpt_render_async + vpt_postprocess_device (RGBA8 stays on the device), steady state with two frames in flight (after issuing frame k the host waits for frame k - 1), frame_ms_3_in_flight: with three" % (W, H)}
+    def async_loop(in_flight, n):
         for _ in range(8):
             g.render_async(1); g.postprocess_device()
         g.wait()
-        t0 = time.perf_counter()
-        prev = 0
+        t0 = time.perf_counter(); tickets = []
         for _ in range(n):
             g.render_async(1)
-            cur = g.postprocess_device()
-            if prev:
-                g.wait(prev)   # returns once the PREVIOUS frame's post has finished: the host runs one frame ahead, like a swapchain
-            prev = cur
+            tickets.append(g.postprocess_device())
+            if len(tickets) >= in_flight:
+                g.wait(tickets[-in_flight])   # the frame-in-flight fence: the host records frame k while frames k - in_flight + 1 .. k may still be on the device
         g.wait()
-        out["frame_ms"] = round((time.perf_counter() - t0) / n * 1e3, 4)
-        out["graph"] = bool(g.stats().get("graph_launches", 0))
-    else:
-        out["frame_ms"] = out["blocking_frame_ms"]
+        return round((time.perf_counter() - t0) / n * 1e3, 4)
+    out["frame_ms"] = async_loop(2, frames * 4)                 # two frames in flight (a double-buffered swapchain)
+    out["frame_ms_3_in_flight"] = async_loop(3, frames * 4)     # three (triple buffering): all three lanes busy
+    out["graph"] = bool(g.stats().get("graph_launches", 0))
     g.close()
     return out
 

@@ -470,6 +470,14 @@ int vpt_trace_rays(vpt_ctx* ctx, const vpt_ray* rays_host, uint32_t n, vpt_hit* 
 #define VPT_TRACE_VOTE 1u  /* persistent lanes, wave-level vote between node / triangle / fetch steps, ray replacement */
 #define VPT_TRACE_VOTE8 2u /* the same on an eight-wide tree with octant-ordered children (BVH8 experiment; built on first use) */
 int vpt_lab_set_rays(vpt_ctx* ctx, const vpt_ray* rays_host, uint32_t n);
+/* Measurement hook on the scheduling of pipelined 1-frame batches (vpt_render_async; tests/tools/latency_probe.py): images never depend on it.
+ *   VPT_LAB_LANES       lanes consecutive frames are dealt to (1-3; default 3: a frame takes the first lane whose previous frame is resolved)
+ *   VPT_LAB_LANE_GRID   divisor of the fused kernel's persistent grid while frames are pipelined (1-3; default 1)
+ *   VPT_LAB_TAIL_GRID   divisor of the grid of a 1-frame batch's bounces >= 2, whose queues hold a fraction of the frame's paths (1-3; default 3) */
+#define VPT_LAB_LANES 1u
+#define VPT_LAB_LANE_GRID 2u
+#define VPT_LAB_TAIL_GRID 3u
+int vpt_lab_set(vpt_ctx* ctx, uint32_t key, uint32_t value);
 int vpt_lab_trace(vpt_ctx* ctx, uint32_t variant, uint32_t any_hit, const uint32_t* order_host, uint32_t param, uint32_t reps,
                   vpt_hit* hits_host, float* best_ms, uint64_t* visits);
 

@@ -40,20 +40,32 @@ t = time.perf_counter()
 for _ in range(N):
     g.render(1); g.postprocess()
 res["wall"]["blocking_render_post_ms"] = (time.perf_counter() - t) / N * 1e3
-for with_post in (False, True):
+def async_loop(in_flight, with_post=True, n=N):
+    """Steady-state wall clock per frame with `in_flight` frames outstanding at most (the host waits for frame k - in_flight + 1 after issuing frame k)."""
     for _ in range(8):
         g.render_async(1)
     g.wait()
-    t = time.perf_counter(); prev = 0
-    for _ in range(N):
+    t = time.perf_counter(); tickets = []
+    for _ in range(n):
         _, cur = g.render_async(1)
         if with_post:
             cur = g.postprocess_device()
-        if prev:
-            g.wait(prev)
-        prev = cur
+        tickets.append(cur)
+        if len(tickets) >= in_flight:
+            g.wait(tickets[-in_flight])
     g.wait()
-    res["wall"]["async_render%s_ms" % ("_post" if with_post else "")] = (time.perf_counter() - t) / N * 1e3
+    return (time.perf_counter() - t) / n * 1e3
+
+
+res["wall"]["async_render_ms"] = async_loop(2, with_post=False)
+res["wall"]["async_render_post_ms"] = async_loop(2)
+res["policies"] = []
+for lanes, lane_grid, tail_grid in ((3, 1, 3), (1, 1, 1), (2, 1, 1), (2, 2, 1), (2, 1, 3), (3, 1, 1), (3, 3, 1), (3, 2, 3), (3, 3, 3), (3, 1, 2), (3, 1, 3)):
+    assert g.lib.vpt_lab_set(g.ctx, 1, lanes) == 0 and g.lib.vpt_lab_set(g.ctx, 2, lane_grid) == 0 and g.lib.vpt_lab_set(g.ctx, 3, tail_grid) == 0
+    row = {"lanes": lanes, "lane_grid_div": lane_grid, "tail_grid_div": tail_grid}
+    for infl in (2, 3, 4):
+        row["frame_ms_%d_in_flight" % infl] = round(async_loop(infl), 4)
+    res["policies"].append(row); print(json.dumps(row), flush=True)
 # issue cost alone: how long the host needs to enqueue a frame (no waiting until the end)
 t = time.perf_counter()
 for _ in range(N):

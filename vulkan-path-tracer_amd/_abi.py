@@ -238,6 +238,7 @@ PROTOTYPES = {
     "vpt_get_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
     "vpt_reset_stats": (C.c_int, [C.c_void_p]),
     "vpt_trace_rays": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
+    "vpt_lab_set": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),
     "vpt_lab_set_rays": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32]),
     "vpt_lab_trace": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_uint64)]),
     "vpt_lut_calculate": (C.c_int, [C.c_int] + [C.c_uint32] * 6 + [C.c_void_p]),

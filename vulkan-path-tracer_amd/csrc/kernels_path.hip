@@ -271,12 +271,12 @@ __global__ __launch_bounds__(kTraverseBlock, 3) void k_bounce(DeviceScene sc, Re
     const uint32_t n = FIRST ? n_slots : ctr->rc3_static[k3] + ctr->rc3[k3];
     const uint32_t waves = gridDim.x * (kTraverseBlock / 64u);
     const uint32_t need = (n + 63u) / 64u, active = need < waves ? need : waves;
-    const bool exact = n < kAppendExactBelow;
+    const bool exact = n < kFusedExactBelow;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         ctr->rc3_static[kn] = exact ? 0u : active * kAppendChunk;
         ctr->rc3[kz] = 0u; ctr->alive3[kz] = 0u;
     }
-    // Long queues: wave-private chunked appends (vote.hpp).  Short ones (< kAppendExactBelow entries): the block's four waves
+    // Long queues: wave-private chunked appends (vote.hpp).  Short ones (< kFusedExactBelow entries): the block's four waves
     // add up their survivors in LDS and reserve them with ONE atomic per 256 paths, exactly — no holes, and few enough atomics
     // for a kernel whose whole launch takes ~0.1 ms at that size (one per wave would saturate the counter, ~88 / us).
     __shared__ uint32_t s_cnt[kTraverseBlock / 64u];

@@ -121,6 +121,12 @@ struct vpt_ctx {
     hipEvent_t ev_post = nullptr;    // owner only: recorded behind the latest vpt_postprocess_device — the next frame's resolve must not touch the image before
     bool post_pending = false;
     uint32_t lane_rr = 0;
+    // vpt_lab_set; defaults = what tests/tools/latency_probe.py measured best (profiles/r04_latency_probe.json): a frame goes to the first
+    // lane whose previous frame has been resolved (so a host with two frames in flight alternates between two lanes, one with three
+    // uses all three), every lane launches the full persistent grid, and the bounces >= 2 of a 1-frame batch — queues of a quarter of
+    // the frame's paths and less — a third of it, which leaves room for the other lanes' blocks
+    uint32_t lab_lanes = 3, lab_lane_grid = 1, lab_tail_grid = 3;
+    int tail_blocks = 0;             // > 0: grid of the bounces >= 2 of the batch being enqueued (pipelined 1-frame batches)
     BatchState graph_batch;          // the captured batch as it stands before its resolve
     BatchState last_fixed;           // the latest fixed-schedule batch enqueued on this lane (drain checks that nothing outlived it)
     bool last_fixed_valid = false;
@@ -298,9 +304,13 @@ int alloc_path_buffers(vpt_ctx* c, uint32_t frames, uint32_t resident) {
     s.maniso = (float*)wb; s.sidx = wb + stride; s.vdepth = wb + stride * 2; s.cchan = (int32_t*)(wb + stride * 3);
     // streams written by chunked appends hold up to one unwritten chunk tail per wave that appended to them: at most
     // 256 entries per 64 items processed, and never more than one per resident wave of the largest persistent grid.  A launch
-    // appends in chunks only when its queue holds >= kAppendExactBelow entries (holes included); below that every append is exact
-    // and no stream ever holds a hole, so buffers that cannot reach that length need no slack (one frame at 1080p: 2,073,600 paths).
-    c->stream_slack = cap < kAppendExactBelow ? 256u : (uint32_t)std::min<uint64_t>((uint64_t)cap * 4 + 256, (uint64_t)8192 * 4 * 256);
+    // appends in chunks only when its queue holds >= kFusedExactBelow (fused kernel) / kAppendExactBelow (streams) entries, holes
+    // included; below that every append is exact and no stream ever holds a hole, so buffers that cannot reach that length need no slack.
+    // (the appending kernels' persistent grids: blocks per CU from the occupancy query, the fused kernel's at most 3 by its LDS; checked
+    // against the real grids by check_stream_slack once the scene is known.  Round 3 reserved for 8192 blocks: 2 GB of a large batch's streams)
+    const int per_cu = std::max(4, std::max(shade_stream_blocks_per_cu(), std::max(shade_media_blocks_per_cu(), media_tail_blocks_per_cu())));
+    const uint64_t max_tails = (uint64_t)c->cu_count * (uint64_t)per_cu * 4u * kAppendChunk;
+    c->stream_slack = cap < kFusedExactBelow ? 256u : (uint32_t)std::min<uint64_t>((uint64_t)cap * 4 + 256, max_tails);
     const size_t scap = (size_t)cap + c->stream_slack;
     for (int i = 0; i < 2; i++) HIPCHK(c, hipMalloc((void**)&c->queue[i], scap * 4));
     {
@@ -323,7 +333,7 @@ int alloc_path_buffers(vpt_ctx* c, uint32_t frames, uint32_t resident) {
 // allocated with room for stream_slack such entries.  Refuse — not after a kernel has written past a stream — if a device with more
 // CUs / other occupancy than the allocation assumed ever needs more.  Called wherever the grids (vpt_set_scene) or the buffers change.
 int check_stream_slack(vpt_ctx* c) {
-    if (!c->has_scene || c->frames_alloc == 0 || c->ps.capacity < kAppendExactBelow) return VPT_OK;   // short streams are appended to exactly: no tails
+    if (!c->has_scene || c->frames_alloc == 0 || c->ps.capacity < kFusedExactBelow) return VPT_OK;   // short streams are appended to exactly: no tails
     const uint64_t appending_waves = 4ull * (uint64_t)std::max(std::max(c->shade_stream_blocks, c->primary_blocks), std::max(c->shade_media_blocks, c->media_tail_blocks));
     if (appending_waves * kAppendChunk > (uint64_t)c->stream_slack && (uint64_t)c->ps.capacity * 4 + 256 > (uint64_t)c->stream_slack)
         return fail(c, VPT_ERR_DEVICE, "internal: the stream slack allocated for chunk tails is smaller than one chunk per appending wave of this device");
@@ -712,7 +722,8 @@ int batch_bounces(vpt_ctx* c, BatchState& b, uint32_t bounces) {
     for (uint32_t j = 0; j < bounces; j++) {
         b.iter++;
         if (b.fused) {  // no reset kernel in between: the bounce kernels rotate three queue-size words
-            TIMED(c, VPT_K_BOUNCE, launch_bounce(s, (uint32_t)c->primary_blocks, c->lds_scene, count, false, c->dsc, c->P, c->ps, c->ss, c->queue[parity], c->queue[parity ^ 1u], c->ctr, parity, 0u, 0u, b.k3, c->scene_plain));
+            const int grid = (c->tail_blocks > 0 && b.iter >= 3) ? c->tail_blocks : c->primary_blocks;   // (b.iter counts bounce 0)
+            TIMED(c, VPT_K_BOUNCE, launch_bounce(s, (uint32_t)grid, c->lds_scene, count, false, c->dsc, c->P, c->ps, c->ss, c->queue[parity], c->queue[parity ^ 1u], c->ctr, parity, 0u, 0u, b.k3, c->scene_plain));
             parity ^= 1u; b.k3 = (b.k3 + 1u) % 3u;
             continue;
         }
@@ -1597,9 +1608,24 @@ int vpt_render_async(vpt_ctx* c, uint32_t dispatches, int* done, uint64_t* ticke
         // the fused pipeline's fixed 1-frame batch goes to the next lane (vpt_ctx::lanes); asked for again with nothing changed since the
         // last two calls it is replayed from the lane's captured graph
         vpt_ctx* X = c;
-        if (fixed && fused_auto && !plain_launches && nf == 1u && c->P.shard_count >= 1u) {
-            const uint32_t k = c->lane_rr++ % 3u;
-            if (k != 0u) { vpt_ctx* L = get_lane(c, (int)k - 1); if (L) { sync_lane(c, L); X = L; } }
+        if (fixed && fused_auto && !plain_launches && nf == 1u) {
+            const uint32_t max_lanes = std::max(1u, std::min(c->lab_lanes, 3u));
+            vpt_ctx* idle = nullptr;
+            uint32_t have = 1;
+            if (hipEventQuery(c->ev_resolved) == hipSuccess) idle = c;
+            for (uint32_t k = 0; k + 1 < max_lanes; k++) {
+                vpt_ctx* L = c->lanes[k];
+                if (!L) { if (!idle) { L = get_lane(c, (int)k); if (L) idle = L; } break; }   // every existing lane is busy: one more
+                have++;
+                if (!idle && hipEventQuery(L->ev_resolved) == hipSuccess) idle = L;
+            }
+            (void)hipGetLastError();   // (hipErrorNotReady is not an error)
+            if (!idle) {   // all lanes busy: round robin
+                const uint32_t k = c->lane_rr++ % have;
+                idle = k == 0u ? c : c->lanes[k - 1];
+            }
+            X = idle;
+            if (X != c) sync_lane(c, X);
         }
         // a batch on the main lane behind pipelined frames: their resolves come first (frame order), and the records it overwrites are the main lane's own
         if (X == c && c->order_lane && c->order_lane != c) HIPCHK(c, hipStreamWaitEvent(c->stream, c->order_lane->ev_resolved, 0));
@@ -1611,16 +1637,20 @@ int vpt_render_async(vpt_ctx* c, uint32_t dispatches, int* done, uint64_t* ticke
         // bounded by one bounce's latency, not by throughput — runs beside the first bounces of the next two.  (A full-size grid fills every
         // CU's LDS and keeps the other lanes' blocks out until it retires.)
         const int full_grid = X->primary_blocks;
-        if (pipelined) X->primary_blocks = std::max(c->cu_count, (c->primary_blocks / 3 / std::max(c->cu_count, 1)) * c->cu_count);
+        auto part = [&](uint32_t div) { return std::max(c->cu_count, (c->primary_blocks / (int)std::max(1u, div) / std::max(c->cu_count, 1)) * c->cu_count); };
+        if (pipelined) {
+            X->primary_blocks = part(std::max(1u, c->lab_lane_grid));
+            X->tail_blocks = c->lab_tail_grid > 1u ? std::min(X->primary_blocks, part(c->lab_tail_grid)) : 0;
+        }
         if (fixed && fused_auto && !plain_launches && c->graph_streak >= 2u) {
             rc = enqueue_graph(X, nf, base, enq, &graphed, b);
-            if (rc) { X->primary_blocks = full_grid; if (X != c) c->err = X->err; return rc; }
+            if (rc) { X->primary_blocks = full_grid; X->tail_blocks = 0; if (X != c) c->err = X->err; return rc; }
         }
         if (!graphed) {
             rc = enqueue_fixed(X, nf, base, enq, b);
-            if (rc) { X->primary_blocks = full_grid; if (X != c) c->err = X->err; return rc; }
+            if (rc) { X->primary_blocks = full_grid; X->tail_blocks = 0; if (X != c) c->err = X->err; return rc; }
         }
-        X->primary_blocks = full_grid;
+        X->primary_blocks = full_grid; X->tail_blocks = 0;
         if (fixed && b.n_slots) {   // frames resolve in order: this one's resolve waits for the previous frame's, whichever lane that ran on
             if (c->order_lane && c->order_lane != X) HIPCHK(c, hipStreamWaitEvent(X->stream, c->order_lane->ev_resolved, 0));
             if (c->post_pending && X != c) HIPCHK(c, hipStreamWaitEvent(X->stream, c->ev_post, 0));   // ... and for the post-process that is still reading the image
@@ -2033,6 +2063,17 @@ int vpt_multi_gather_shards(vpt_ctx* const* ctxs, uint32_t count, uint32_t root)
     return assemble_from_gather_buf(R);
 }
 
+int vpt_lab_set(vpt_ctx* c, uint32_t key, uint32_t value) {
+    if (!c || value > 3u) return VPT_ERR_INVALID_ARGUMENT;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    { int rd = drain(c); if (rd) return rd; }
+    if (key == VPT_LAB_LANES && value >= 1u) c->lab_lanes = value;
+    else if (key == VPT_LAB_LANE_GRID && value >= 1u) c->lab_lane_grid = value;
+    else if (key == VPT_LAB_TAIL_GRID && value >= 1u) c->lab_tail_grid = value;
+    else return VPT_ERR_INVALID_ARGUMENT;
+    c->state_gen++;   // captured batches hold the old grids
+    return VPT_OK;
+}
 int vpt_lab_set_rays(vpt_ctx* c, const vpt_ray* rays, uint32_t n) {
     if (!c || !rays || n == 0) return VPT_ERR_INVALID_ARGUMENT;
     HIPCHK(c, hipSetDevice(c->cfg.device));
