@@ -159,3 +159,49 @@ def test_path_buffers_grow_with_the_batches_asked_for(vpt, scenes):
     ref.close()
     free2 = free_bytes()
     assert free0 - free2 < 1024 ** 3, "device memory not returned by vpt_destroy"
+
+
+def test_async_edge_cases(vpt, oracle, scenes):
+    """Camera moves between asynchronous frames (every move invalidates the captured batches: frames fall back to plain launches), max_samples
+    reached (PathTrace's `true`: nothing more is launched), a resize with frames in flight, output getters before / after a post-process,
+    and tickets of work long finished."""
+    sc, w, h = scenes("cornell_box"), 96, 54
+    p = vpt.default_params(max_depth=5, max_samples=7)
+    g = vpt.PathTracer(w, h, frames_in_flight=1)
+    g.set_scene(sc); g.set_params(p)
+    assert g.output_device() is None
+    with pytest.raises(vpt.VptError):
+        g.output_to_host()
+    tickets = []
+    for k in range(10):
+        done, t = g.render_async(1)
+        tickets.append(t)
+        assert done == (k >= 7)
+    g.wait(tickets[0]); g.wait(tickets[3]); g.wait(10 ** 9)     # long finished; in the ring; beyond what was issued (= everything)
+    st = g.stats()
+    assert st["frames"] == 7 and st["samples"] == 7 * w * h
+    ref = oracle_image(oracle, sc, w, h, p, 7)
+    assert np.array_equal(g.radiance(), ref)
+    # a moving camera: accumulation restarts with every move, each image is a 1-frame render of that view
+    views = []
+    for k in range(4):
+        vi = np.array(sc.view_inverse, np.float32).copy(); vi[0, 3] += 0.05 * k
+        g.set_camera(vi, sc.projection_inverse(w / h))
+        g.render_async(1); g.postprocess_device()
+        views.append((vi, g.radiance(), g.output_to_host()))
+    for vi, img, out8 in views[1:]:
+        o = oracle.Oracle(sc, w, h); o.set_camera(vi, sc.projection_inverse(w / h)); o.set_params(p); o.render(1)
+        r = o.radiance(); o.close()
+        assert np.array_equal(img, r)
+        ref8, _ = oracle.postprocess(r, vpt.default_post_params())
+        assert np.array_equal(out8, ref8)
+    # resize with frames in flight: drains, the lanes' buffers of the old size go, rendering goes on at the new size
+    g.set_camera(sc.view_inverse, sc.projection_inverse(w / h))
+    for _ in range(3):
+        g.render_async(1)
+    g.resize(64, 36)
+    g.set_camera(sc.view_inverse, sc.projection_inverse(64 / 36))
+    for _ in range(5):
+        g.render_async(1)
+    assert np.array_equal(g.radiance(), oracle_image(oracle, sc, 64, 36, p, 5))
+    g.close()

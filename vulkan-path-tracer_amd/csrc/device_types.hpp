@@ -312,10 +312,10 @@ struct StreamCounters {
 // appends exactly instead (no holes).  The host sizes the streams' slack for unwritten chunk tails by these (vpt_api.hip alloc_path_buffers).
 constexpr uint32_t kAppendChunk = 256;
 constexpr uint32_t kAppendExactBelow = 1u << 21;
-// The fused per-bounce kernel switches earlier: its exact mode costs two block-wide barriers and one atomic per 256 paths, which on the
-// 2M-path launches of a 1-frame batch at 1080p was 85 us of a 234 us bounce 0 and ~180 us over the seven later bounces
-// (profiles/r04_latency_probe.json: 1 frame per batch against 2); holes in its queues cost a skipped tile each.
-constexpr uint32_t kFusedExactBelow = 1u << 18;
+// The fused per-bounce kernel's threshold.  Measured at 2^18 (round 4, profiles/r04_latency_probe_exact18.json: the 2M-path launches of a
+// 1-frame batch at 1080p then append in chunks): bounce 0 234 -> 206 us, but the seven later bounces 605 -> 733 us (holes in queues
+// that are short anyway, tiles of mixed holes without the regrouping ring) — slower overall, so it stays where the streams' is.
+constexpr uint32_t kFusedExactBelow = kAppendExactBelow;
 
 // connect flags (CE.w)
 constexpr uint32_t kCF_Sky = 1u, kCF_Light = 2u, kCF_Finalize = 4u, kCF_Clamp = 8u;
