@@ -61,6 +61,8 @@ for s, (calls, tot) in sorted(dur.items(), key=lambda kv: -kv[1][1]):
     lines.append("| %s | %d | %.1f | %.3e | %.3e | %.3e | %.0f %% | %.1f | %.0f %% | %.0f %% |" % (s, calls, tot / calls / 1e3, 2 * fetch + write, 2 * fetch, write, 100 * busy, lanes, 100 * wait, 100 * l2))
 for scene, wl in (("atrium", "atrium_1080p_d8"), ("bust", "glass_bust_1080p_d32")):
     p = os.path.join(ROOT, "profiles", "r04_%s_p2_counters.json" % scene)
+    if not os.path.exists(p):   # not re-collected this round: round 3's passes (bench.py copies an entry only while its launch time is within 5 % of the run's own)
+        p = os.path.join(ROOT, "profiles", "r03_%s_p2_counters.json" % scene)
     if os.path.exists(p):
         d = json.load(open(p)); o = out.setdefault(wl, {})
         names = {"trace_vote": "extend", "shade_stream": "shade", "join": "join", "shadow_sky": "shadow_sky", "shadow_light": "shadow_light"}

@@ -4,7 +4,7 @@
 homogeneous box volumes with the Henyey-Greenstein phase function (RayGen.slang:162-372, Volume.slang:190-223, 256-286, 358-443);
 the atmosphere (Atmosphere.slang, RayGen.slang:214-250, 382-470, Sampler.slang:430-463; its sphere intersections and heights in
 float32, as the shader computes them: at a planet radius of 6.36e6 they are cancellation-limited and float64 would be a different
-function); no density grids; ray-query shadow tests; brute-force intersection.  Used by
+function); density grids as the backend takes them (dense, include/vpt.h), their block walk in float32 (see hetero_walk); ray-query shadow tests; brute-force intersection.  Used by
 tests/test_oracle_integrator_fp64.py to hold the oracle's per-sample values (orc_pixel_samples) against it.
 
 Test infrastructure only."""
@@ -51,12 +51,24 @@ class Scene64:
     def set_atmosphere(self, a):
         self.atm = a
 
-    def set_volumes(self, vols):
+    def set_volumes(self, vols, grids=()):
+        """grids: the dense density grids (float32 [z, y, x] raw densities, as handed to vpt_add_density_grid) a volume's density_data_index
+        refers to.  What AddDensityDataToVolume derives from a grid (PathTracer.cpp:1390-1442) is derived here the same way: the maximum, and
+        the 32 x 32 x 32 table of per-block maxima of density / max with y flipped ("Y has to be flipped for vulkan", :1435)."""
         self.volumes = [dict(lo=np.array(v.corner_min[:], np.float64), hi=np.array(v.corner_max[:], np.float64), color=np.array(v.color[:], np.float64),
                              emissive=np.array(v.emissive_color[:], np.float64), density=float(v.density), g=float(v.anisotropy), alpha=float(v.alpha),
-                             droplet=float(v.droplet_size)) for v in vols]
-        for v in vols:
-            assert v.density_data_index < 0 and not v.approximated_scattering, "homogeneous volumes only"
+                             droplet=float(v.droplet_size), grid=None, sharpness=float(v.grid_sharpness)) for v in vols]
+        for v, d in zip(vols, self.volumes):
+            assert not v.approximated_scattering and not v.has_temperature_data, "no approximated scattering, no temperature grids"
+            if v.density_data_index >= 0:
+                g = np.asarray(grids[v.density_data_index], np.float32)
+                dz, dy, dx = g.shape
+                mx = float(g.max())
+                norm = np.clip(g.astype(np.float64) / mx, 0.0, 1.0)[:, ::-1, :]          # y flipped
+                bx = (np.arange(dx) * 32) // dx; by = (np.arange(dy) * 32) // dy; bz = (np.arange(dz) * 32) // dz
+                bm = np.zeros((32, 32, 32))                                               # [bz, by, bx]
+                np.maximum.at(bm, (bz[:, None, None], by[None, :, None], bx[None, None, :]), norm)
+                d["grid"] = dict(values=g, max=mx, block_max=bm, dim=(dx, dy, dz))
 
     def tex(self, ti, uv):
         """uTextures[ti].SampleLevel(uTextureSampler, uv, 0): UNORM8, bilinear, REPEAT (PathTracer.cpp:84-91) -> rgba."""
@@ -307,12 +319,104 @@ def sample_phase(S, v, d, vdepth, rng):   # Volume.slang:358-375
     return sample_hg(d, ghg, rng) if rng.uf() < wd else sample_draine(d, gd, ad, rng)
 
 
-def volumes_transmittance(S, o, d):   # Volume.slang:419-446, homogeneous boxes
+def sample_grid(v, rng, x):
+    """SampleNanoVDBBuffer (Volume.slang:69-117) on the dense grid the backend takes in place of the NanoVDB tree (include/vpt.h
+    vpt_add_density_grid): position normalised in the box, y flipped, scaled to the grid, floor to a voxel, +-1 voxel of jitter per axis
+    (three raw PCG draws, `% 3 - 1`), clamp to the grid; value / max * GridSharpness clamped to [0, 1]."""
+    g = v["grid"]
+    n = (x - v["lo"]) / (v["hi"] - v["lo"])
+    n[1] = 1.0 - n[1]
+    dx, dy, dz = g["dim"]
+    c = [int(np.floor(n[0] * dx)), int(np.floor(n[1] * dy)), int(np.floor(n[2] * dz))]
+    for a in range(3):
+        c[a] += int(rng.raw() % 3) - 1
+    cx, cy, cz = min(max(c[0], 0), dx - 1), min(max(c[1], 0), dy - 1), min(max(c[2], 0), dz - 1)
+    return min(max(float(g["values"][cz, cy, cx]) / g["max"] * v["sharpness"], 0.0), 1.0)
+
+
+_f = np.float32
+
+
+def box_hit32(o, d, lo, hi):   # ComputeRayAABBIntersection (Volume.slang:190-213) in float32, term for term
+    with np.errstate(all="ignore"):
+        inv = _f(1.0) / d
+        t0, t1 = (lo - o) * inv, (hi - o) * inv
+    sm, bg = np.minimum(t0, t1), np.maximum(t0, t1)
+    tmin = max(max(sm[0], sm[1]), max(sm[0], sm[2])); tmax = min(min(bg[0], bg[1]), min(bg[0], bg[2]))
+    if tmax < 0.0 or tmin > tmax:
+        return _f(-1.0), _f(-1.0)
+    return tmin, tmax
+
+
+def hetero_walk(S, v, o, d, rng, near, far, transmittance):
+    """ProcessHeterogeneousVolumeScattering (Volume.slang:299-348: delta tracking, returns the scatter distance or -1) and
+    ProcessHeterogeneousVolumeTransmittance (:448-520: ratio tracking with roulette, returns the transmittance): one loop, block by
+    block through the 32^3 table of majorants; the two differ in what a real collision does and in the step limit.
+    In FLOAT32, term for term: every block crossing re-enters the volume `epsilon` (1e-4 of the box) beyond the exit point, positions
+    are formed as origin + direction * (tEnter + t + epsilon) at distances of 10-20 units, so about one crossing in a few thousand
+    lands on the other side of a block face than float64 would put it — one more or one less iteration, i.e. one more or one less
+    random draw, which changes the whole remainder of the sample (measured with this function in float64: 4 % of the samples of a
+    depth-1 render differ, 19 % at depth 8).  Float64 is a different function here, as with the atmosphere's sphere intersections."""
+    o, d, lo, hi = o.astype(_f), d.astype(_f), v["lo"].astype(_f), v["hi"].astype(_f)
+    eps = _f(0.0001) * _f((hi - lo).max())
+    t_enter, t_exit = _f(max(near, 0.0)), _f(far)
+    bs = (hi - lo) / _f(32.0)
+
+    def block_info(pos):   # CalculateBlockInfo, Volume.slang:129-147
+        rel = (pos - lo) / (hi - lo)
+        idx = np.clip(np.trunc(rel * _f(32.0)).astype(np.int64), 0, 31)                   # int3(...) truncates
+        blo = lo + bs * idx.astype(_f)
+        return _f(v["grid"]["block_max"][idx[2], idx[1], idx[0]]), blo, blo + bs
+    bmax, blo, bhi = block_info(o + d * (t_enter + eps))
+    t, T = _f(0.0), _f(1.0)
+    for _ in range(1000 if transmittance else 10000):
+        cur = o + d * (t_enter + t + eps)
+        bn, bf = box_hit32(cur, d, blo, bhi)
+        maxd = bmax * _f(v["density"])
+        with np.errstate(all="ignore"):
+            sampled = _f(-np.log(_f(rng.uf()))) / maxd   # SampleScatteringDistance: -log(u) / density (a zero majorant gives +inf: on to the next block)
+        if bf <= 0.0:                                   # "ray doesn't intersect block properly": advance by epsilon
+            t = t + eps
+            if t_enter + t > t_exit:
+                break
+            bmax, blo, bhi = block_info(o + d * (t_enter + t + eps))
+            continue
+        to_exit = bf - max(bn, _f(0.0))
+        if sampled > to_exit:
+            t = t + (to_exit + eps)
+            if t_enter + t > t_exit:
+                break
+            bmax, blo, bhi = block_info(o + d * (t_enter + t + eps))
+            continue
+        t = t + sampled
+        if t_enter + t > t_exit:
+            break
+        dens = _f(sample_grid(v, rng, (o + d * (t_enter + t)).astype(np.float64))) * _f(v["density"])
+        if transmittance:
+            with np.errstate(all="ignore"):
+                T = T * (_f(1.0) - dens / maxd)
+            pr = T
+            if _f(rng.uf()) > pr:
+                return 0.0
+            T = T / pr
+        else:
+            with np.errstate(all="ignore"):
+                if dens / maxd < _f(rng.uf()):
+                    continue                            # null collision
+            return float(t_enter + t)
+    return float(T) if transmittance else -1.0
+
+
+def volumes_transmittance(S, o, d, rng=None):   # CalculateVolumesTransmittance, Volume.slang:419-446
     T = 1.0
     for v in S.volumes:
         near, far = box_hit(o, d, v["lo"], v["hi"])
         near = max(near, 0.0)
-        if far - near > 0.0:
+        if v["grid"] is not None and far >= 0.0:      # heterogeneous: tracked (draws random numbers)
+            T *= hetero_walk(S, v, o, d, rng, near, far, True)
+            if T <= 0.0:
+                return 0.0
+        elif far - near > 0.0:
             T *= np.exp(-v["density"] * (far - near))
     return min(max(T, 0.0), 1.0)
 
@@ -335,7 +439,9 @@ def scattered_in_volume(S, pay, rng, P):   # RayGen.slang:162-270 without an atm
         t = -1.0
         if not (far < 0.0) and not (sd >= 0.0 and near > sd):
             inside = far - max(near, 0.0)
-            if inside > 0.0:
+            if inside > 0.0 and v["grid"] is not None:
+                t = hetero_walk(S, v, o, d, rng, near, far, False)
+            elif inside > 0.0:
                 with np.errstate(all="ignore"):
                     sampled = -np.log(rng.uf()) / v["density"]
                 if sampled < inside:
@@ -377,14 +483,14 @@ def scattered_in_volume(S, pay, rng, P):   # RayGen.slang:162-270 without an atm
     ph = eval_phase(S, v, d, nd)
     if sky[3] > 0.0:
         pk = eval_phase(S, v, d, to_sky)
-        T = volumes_transmittance(S, po, to_sky)
+        T = volumes_transmittance(S, po, to_sky, rng)
         if S.atm is not None:
             T = T * nee_atmosphere_transmittance(S, rng, po, to_sky, pay["cchan"])
         if pk > 0.0:
             pay["emitted"] = pay["emitted"] + T * (v["color"] * pk) * (sky[:3] / sky[3]) * power_heuristics(sky[3], pk)
     if light[3] > 0.0:
         pl = eval_phase(S, v, d, to_light)
-        T = volumes_transmittance(S, po, to_light)
+        T = volumes_transmittance(S, po, to_light, rng)
         if pl > 0.0:
             pay["emitted"] = pay["emitted"] + T * (v["color"] * pl) * (light[:3] / light[3]) * power_heuristics(light[3], pl)
     pay["direction"] = nd; pay["bxdf"] = v["color"] * ph; pay["pdf"] = ph
@@ -555,7 +661,7 @@ def atmosphere_event(S, pay, rng, P, sd, comp):   # EvaluateAtmosphereScattering
     to_sun, cp = sample_sun(S, rng, P)
     cp[:3] = cp[:3] * P.sky_intensity
     if S.closest(pay["origin"], to_sun, 0.0001, 1000000.0) is None:
-        T = atm_transmittance(S.atm, rng, pay["origin"], to_sun, pay["cchan"]) * volumes_transmittance(S, pay["origin"], to_sun)
+        T = atm_transmittance(S.atm, rng, pay["origin"], to_sun, pay["cchan"]) * volumes_transmittance(S, pay["origin"], to_sun, rng)
     else:
         T = np.zeros(3)
     ray_phase = lambda a, b: (3.0 / (16.0 * np.pi)) * (1.0 + float(np.dot(a, b)) ** 2)
@@ -742,12 +848,12 @@ def closest_hit(S, luts, pay, rd, hit, rng, P):
     pay["direction"] = scatter_w
     pay["bxdf"] = s_f; pay["pdf"] = s_pdf
     if can_sky:   # the transmittance is taken from the NEW origin (ClosestHit.slang:332-349); its draws happen whether or not it is used
-        T_sky = volumes_transmittance(S, pay["origin"], to_sky)
+        T_sky = volumes_transmittance(S, pay["origin"], to_sky, rng)
         if S.atm is not None:
             T_sky = T_sky * nee_atmosphere_transmittance(S, rng, pay["origin"], to_sky, pay["cchan"])
         if sky[3] > 0.0 and k_pdf > 0.0:
             pay["emitted"] = pay["emitted"] + (k_f * T_sky * sky[:3] / sky[3]) * power_heuristics(sky[3], k_pdf)
     if not is_light and can_light and light_pdf > 0.0 and l_pdf > 0.0:
-        pay["emitted"] = pay["emitted"] + (l_f * volumes_transmittance(S, pay["origin"], to_light) * light_rgb / light_pdf) * power_heuristics(light_pdf, l_pdf)
+        pay["emitted"] = pay["emitted"] + (l_f * volumes_transmittance(S, pay["origin"], to_light, rng) * light_rgb / light_pdf) * power_heuristics(light_pdf, l_pdf)
     invalid = s_pdf <= 0.0
     pay["depth"] = MAX_DEPTH + pay["depth"] if invalid else pay["depth"] + 1

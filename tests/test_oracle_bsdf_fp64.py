@@ -181,6 +181,9 @@ def _pcg(s):
 
 class Rng64:
     def __init__(self, seed): self.s = int(seed) & 0xffffffff
+    def raw(self):   # Sampler.PCG(): the next hash itself (what the jittered density-grid lookups take modulo 3)
+        self.s = _pcg(self.s)
+        return self.s
     def uf(self):   # Sampler.slang:38-43: float(hash) / float(UINT_MAX); float(UINT_MAX) is 2^32 in fp32
         self.s = _pcg(self.s)
         return float(np.float32(self.s)) / 4294967296.0
