@@ -3,6 +3,7 @@
     config3         atrium (253,002 triangles), 1920x1080, depth 8        (default 256 spp)
     config3_strict  the same with VPT_FLAG_LOCAL_HITS on both sides: the structure-independent hit rule, expected 0 differing pixels
     config4         atrium, 3840x2160, depth 8: one rank's worth of BASELINE config 4, whole frames   (default 1 spp)
+    config4_strict  the same with VPT_FLAG_LOCAL_HITS
     config5         glass bust, 1920x1080, depth 32, + bloom / tonemap post, RGBA8 compared too     (default 8 spp)
 Writes gpurun_out/<config>_full_parity.json.
     python tests/full_config_parity.py <config> [spp]"""
@@ -15,9 +16,9 @@ abi = importlib.import_module("vulkan-path-tracer_amd._abi")
 from oracle import oracle_py as O
 
 cfg = sys.argv[1] if len(sys.argv) > 1 else "config2"
-DEFAULT_SPP = {"config2": 1024, "config3": 256, "config3_strict": 256, "config4": 1, "config5": 8}
+DEFAULT_SPP = {"config2": 1024, "config3": 256, "config3_strict": 256, "config4": 1, "config4_strict": 1, "config5": 8}
 spp = int(sys.argv[2]) if len(sys.argv) > 2 else DEFAULT_SPP[cfg]
-W, H = (3840, 2160) if cfg == "config4" else (1920, 1080)
+W, H = (3840, 2160) if cfg.startswith("config4") else (1920, 1080)
 depth = 32 if cfg == "config5" else 8
 if cfg == "config2":
     sc, what = vpt.scenes.Scene.load(os.path.join(ROOT, "tests", "golden", "cornell_box.npz")), "cornell"
@@ -26,7 +27,7 @@ elif cfg == "config5":
 else:
     sc = vpt.scenes.atrium(); what = "atrium (%d triangles)" % sc.triangle_count()
 P = vpt.default_params(max_depth=depth, max_samples=spp)
-if cfg == "config3_strict":
+if cfg.endswith("_strict"):
     P.flags |= abi.FLAG_LOCAL_HITS
 t = time.time()
 g = vpt.PathTracer(W, H); g.set_scene(sc); g.set_params(P); g.render(spp)
@@ -40,7 +41,7 @@ ref = o.radiance(); ctr = o.counters(); o.close()
 to = time.time() - t
 diff = int((np.abs(img - ref).max(axis=2) > 0).sum())
 rel = float(np.sqrt(((img[..., :3].astype(np.float64) - ref[..., :3]) ** 2).sum()) / np.sqrt((ref[..., :3].astype(np.float64) ** 2).sum()))
-res = {"config": "%s %dx%d, %d spp, depth %d, base seed 1%s" % (what, W, H, spp, depth, ", VPT_FLAG_LOCAL_HITS" if cfg == "config3_strict" else ""),
+res = {"config": "%s %dx%d, %d spp, depth %d, base seed 1%s" % (what, W, H, spp, depth, ", VPT_FLAG_LOCAL_HITS" if cfg.endswith("_strict") else ""),
        "samples": int(st["samples"]), "bit_exact": bool(np.array_equal(img, ref)),
        "differing_pixels": diff, "rel_l2": rel, "tolerance_rel_l2": 1e-4, "closest_rays_gpu": int(st["closest_rays"]), "closest_rays_oracle": int(ctr["closest"]),
        "pipeline_kernels": {k: int(v) for k, v in st["kernel_launches"].items() if v},
