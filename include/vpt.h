@@ -210,6 +210,11 @@ typedef struct vpt_config {
 #define VPT_PIPELINE_STAGED_SORTED 4u /* STAGED with the shade queue sorted by material class (miss | plain | textured | glass | emissive),
                                        * one shade launch per class, the miss and plain ones specialised.  Bit-identical; measured
                                        * 10-14 % SLOWER than STAGED on the BASELINE scenes, so AUTO never picks it */
+#define VPT_PIPELINE_WHOLE 5u  /* ONE launch per batch: persistent waves run every path from its camera ray to its end, a lane whose path has ended takes
+                               * the batch's next sample (kernels_path.hip k_whole; the reference's own shape: one RayGen thread = one whole path).
+                               * For scenes whose BVH rides in LDS, no media, samples_per_frame == 1, every sample resident — VPT_ERR_UNSUPPORTED
+                               * otherwise.  Bit-identical.  AUTO takes it for 1-frame batches of such scenes (the interactive case: the
+                               * per-bounce launches of one frame do not fill the chip) and FUSED for longer ones */
 #define VPT_PIPELINE_STAGED_R1 3u /* the same stages with round 1's traversal loops (64 rays per wave at a time): kept as the measured baseline */
 
 #define VPT_KERNEL_COUNT 10
@@ -473,10 +478,12 @@ int vpt_lab_set_rays(vpt_ctx* ctx, const vpt_ray* rays_host, uint32_t n);
 /* Measurement hook on the scheduling of pipelined 1-frame batches (vpt_render_async; tests/tools/latency_probe.py): images never depend on it.
  *   VPT_LAB_LANES       lanes consecutive frames are dealt to (1-3; default 3: a frame takes the first lane whose previous frame is resolved)
  *   VPT_LAB_LANE_GRID   divisor of the fused kernel's persistent grid while frames are pipelined (1-3; default 1)
- *   VPT_LAB_TAIL_GRID   divisor of the grid of a 1-frame batch's bounces >= 2, whose queues hold a fraction of the frame's paths (1-3; default 3) */
+ *   VPT_LAB_TAIL_GRID   divisor of the grid of a 1-frame batch's bounces >= 2, whose queues hold a fraction of the frame's paths (1-3; default 3)
+ *   VPT_LAB_WHOLE_FRAMES  VPT_PIPELINE_AUTO runs batches of at most this many frames as one whole-path launch where VPT_PIPELINE_WHOLE applies (default 1; 0: never) */
 #define VPT_LAB_LANES 1u
 #define VPT_LAB_LANE_GRID 2u
 #define VPT_LAB_TAIL_GRID 3u
+#define VPT_LAB_WHOLE_FRAMES 4u
 int vpt_lab_set(vpt_ctx* ctx, uint32_t key, uint32_t value);
 int vpt_lab_trace(vpt_ctx* ctx, uint32_t variant, uint32_t any_hit, const uint32_t* order_host, uint32_t param, uint32_t reps,
                   vpt_hit* hits_host, float* best_ms, uint64_t* visits);

@@ -19,17 +19,18 @@ def oracle_image(oracle, sc, w, h, params, frames):
 
 
 def test_async_frames_equal_blocking_frames_and_replay_from_a_graph(vpt, oracle, scenes):
-    """Cornell box, depth 8: a fixed schedule (no medium scatters, 8 <= VPT_ASYNC_MAX_BOUNCES) — frames are enqueued back to back, the
+    """Cornell box, depth 8, the per-bounce pipeline (VPT_PIPELINE_FUSED; AUTO would run a 1-frame batch as one whole-path launch,
+    tests/test_gpu_whole.py): a fixed schedule (no medium scatters, 8 <= VPT_ASYNC_MAX_BOUNCES) — frames are enqueued back to back, the
     third identical call onwards replays a captured hipGraph, and the accumulated image equals vpt_render's and the oracle's."""
     sc, w, h, frames = scenes("cornell_box"), 160, 90, 12
     p = vpt.default_params(max_depth=8)
     ref = oracle_image(oracle, sc, w, h, p, frames)
-    blocking = vpt.PathTracer(w, h, frames_in_flight=1)
+    blocking = vpt.PathTracer(w, h, frames_in_flight=1, pipeline=vpt._abi.PIPELINE_FUSED)
     blocking.set_scene(sc); blocking.set_params(p)
     for _ in range(frames):
         blocking.render(1)
     img_b = blocking.radiance(); out_b = blocking.postprocess(); blocking.close()
-    g = vpt.PathTracer(w, h, frames_in_flight=1)
+    g = vpt.PathTracer(w, h, frames_in_flight=1, pipeline=vpt._abi.PIPELINE_FUSED)
     g.set_scene(sc); g.set_params(p)
     prev = 0
     for _ in range(frames):

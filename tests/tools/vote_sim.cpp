@@ -1,0 +1,181 @@
+// vote_sim — host model of ONE wave of the vote-scheduled traversal kernels (csrc/kernels_trace.hip k_trace_vote / k_trace_shadow,
+// csrc/vote.hpp) running a ray stream over the product BVH: which kind of step the wave votes for, how many of its 64 lanes take part,
+// and what the schedule costs in VALU wave-instructions per ray (step costs from profiles/r03_trace_isa_budget.md).  It exists to
+// cost scheduling policies before a kernel family is spent on them; every policy must return the same hits as the first.
+//   vote_sim tris.bin rays.bin kind      rays: m x 10 floats {o, tmin, d, tmax, tlim, expect-gid as float bits}; kind: closest | any
+// Policies: 0 = the product's (weighted vote, fetch at 24 idle lanes); 1.. = postponed leaves (see Policy).  Test utility only.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../vulkan-path-tracer_amd/csrc/bvh_build.hpp"
+using namespace vpt;
+using vptfp::V3;
+
+static const float kMiss = 3.0e38f;
+static const int kIdle = 0x7fffffff, kDone = 0x7ffffffe, kEmpty = 0x7ffffffd;
+struct Slab { V3 o, inv; bool nx, ny, nz; };
+static float sinv(float d) { return (std::fabs(d) > 1e-30f) ? 1.0f / d : (std::signbit(d) ? -1e30f : 1e30f); }
+static void entries(const BvhNode& n, const Slab& r, float tmin, float tlimit, float t[4]) {
+    const float ax = n.step_x * r.inv.x, ay = n.step_y * r.inv.y, az = n.step_z * r.inv.z;
+    const float bx = (n.origin[0] - r.o.x) * r.inv.x, by = (n.origin[1] - r.o.y) * r.inv.y, bz = (n.origin[2] - r.o.z) * r.inv.z;
+    const uint32_t nxw = r.nx ? n.hi[0] : n.lo[0], fxw = r.nx ? n.lo[0] : n.hi[0];
+    const uint32_t nyw = r.ny ? n.hi[1] : n.lo[1], fyw = r.ny ? n.lo[1] : n.hi[1];
+    const uint32_t nzw = r.nz ? n.hi[2] : n.lo[2], fzw = r.nz ? n.lo[2] : n.hi[2];
+    for (int k = 0; k < 4; k++) {
+        auto B = [&](uint32_t w) { return (float)((w >> (8 * k)) & 0xffu); };
+        float tn = std::fmax(std::fmax(std::fmaf(B(nxw), ax, bx), std::fmaf(B(nyw), ay, by)), std::fmax(std::fmaf(B(nzw), az, bz), tmin));
+        float tf = std::fmin(std::fmin(std::fmaf(B(fxw), ax, bx), std::fmaf(B(fyw), ay, by)), std::fmin(std::fmaf(B(fzw), az, bz), tlimit));
+        t[k] = (tn <= tf * 1.0000005f) ? tn : kMiss;
+    }
+}
+
+struct Policy {
+    const char* name;
+    int stash;          // leaves a lane may set aside while it goes on with inner nodes (0: the product)
+    int w4;             // a node step wins when 4 x (lanes able to take one) > w4 x (lanes able to take a triangle step)
+    int fetch_at;       // idle lanes that trigger a fetch step
+    int node_extra, tri_extra;   // VALU a step costs more than the product's (stash bookkeeping)
+    bool drain_first;   // a triangle step wins outright while some lane can do nothing else and holds a full stash
+    int tri_per_step;   // triangles of ONE leaf a triangle step tests (1: the product)
+};
+
+struct Lane {
+    int cur = kIdle, sp = 0;
+    int stash[4] = {kEmpty, kEmpty, kEmpty, kEmpty}; int ns = 0;
+    std::vector<int> st;
+    Slab s; V3 o, d; float tmin, tmax, tlim, best; int bgid; uint32_t expect; bool found; size_t rid;
+};
+
+int main(int argc, char** argv) {
+    if (argc < 4) return 2;
+    std::vector<BvhTri> tris; std::vector<float> rays;
+    { FILE* f = fopen(argv[1], "rb"); if (!f) return 3; fseek(f, 0, SEEK_END); long n = ftell(f); fseek(f, 0, SEEK_SET); tris.resize(n / 48); if (fread(tris.data(), 48, tris.size(), f) != tris.size()) return 3; fclose(f); }
+    { FILE* f = fopen(argv[2], "rb"); if (!f) return 3; fseek(f, 0, SEEK_END); long n = ftell(f); fseek(f, 0, SEEK_SET); rays.resize(n / 4); if (fread(rays.data(), 4, rays.size(), f) != rays.size()) return 3; fclose(f); }
+    const bool any = std::string(argv[3]) == "any";
+    {
+        std::vector<BvhTri> keep;
+        for (const BvhTri& t : tris) if (!vptfp::triangle_degenerate(vptfp::v3(t.e1[0], t.e1[1], t.e1[2]), vptfp::v3(t.e2[0], t.e2[1], t.e2[2]))) keep.push_back(t);
+        tris.swap(keep);
+    }
+    std::vector<BvhNode> nodes; std::vector<BvhNodeWide> wide; std::vector<BvhTri> leaf; int depth = 0;
+    build_bvh(tris, nodes, wide, leaf, &depth, nullptr, false);
+    const size_t nrays = rays.size() / 10;
+    printf("%s: %zu rays, %zu triangles, %zu nodes, depth %d\n", argv[3], nrays, leaf.size(), nodes.size(), depth);
+    const int node_cost = any ? 133 : 155, tri_cost = any ? 91 : 97, fetch_cost = 148;
+    const Policy policies[] = {
+        {"product (vote 2.0, fetch at 24)", 0, 8, 24, 0, 0, false, 1},
+        {"product, fetch at 8", 0, 8, 8, 0, 0, false, 1},
+        {"product, vote 1.0", 0, 4, 24, 0, 0, false, 1},
+        {"stash 1, vote 2.0", 1, 8, 24, 14, 8, false, 1},
+        {"stash 1, vote 1.0", 1, 4, 24, 14, 8, false, 1},
+        {"stash 1, vote 4.0", 1, 16, 24, 14, 8, false, 1},
+        {"stash 1, vote 2.0, drain first", 1, 8, 24, 14, 8, true, 1},
+        {"stash 2, vote 2.0", 2, 8, 24, 20, 12, false, 1},
+        {"stash 2, vote 4.0", 2, 16, 24, 20, 12, false, 1},
+        {"stash 4, vote 4.0", 4, 16, 24, 28, 16, false, 1},
+        {"stash 1, vote 2.0, fetch at 8", 1, 8, 8, 14, 8, false, 1},
+        {"product, 2 triangles per step", 0, 8, 24, 0, 70, false, 2},
+    };
+    std::vector<float> ref_t(nrays); std::vector<int> ref_g(nrays);
+    for (size_t pi = 0; pi < sizeof(policies) / sizeof(policies[0]); pi++) {
+        const Policy& P = policies[pi];
+        Lane L[64];
+        size_t next = 0; bool exhausted = false;
+        double n_node_steps = 0, n_tri_steps = 0, n_fetch_steps = 0, part_node = 0, part_tri = 0, visits = 0, tests = 0, idle_lane_steps = 0;
+        size_t mismatches = 0;
+        auto pop_or_done = [&](Lane& l) {
+            if (!l.st.empty()) { l.cur = l.st.back(); l.st.pop_back(); }
+            else if (l.ns > 0) { l.cur = l.stash[--l.ns]; l.stash[l.ns] = kEmpty; }
+            else l.cur = kDone;
+        };
+        auto set_aside = [&](Lane& l) {   // a lane that arrived at a leaf sets it aside and goes on with an inner node, if it has room and something to go on with
+            while (l.cur < 0 && l.ns < P.stash && !l.st.empty()) { l.stash[l.ns++] = l.cur; l.cur = l.st.back(); l.st.pop_back(); }
+        };
+        while (true) {
+            int nn = 0, nl = 0, stuck = 0;
+            for (Lane& l : L) {
+                const bool busy = l.cur < kDone;
+                const bool can_node = busy && l.cur >= 0, can_tri = busy && (l.cur < 0 || l.ns > 0);
+                nn += can_node; nl += can_tri; stuck += busy && !can_node;
+            }
+            int busy_lanes = 0; for (Lane& l : L) busy_lanes += l.cur < kDone;
+            const bool want_fetch = (!exhausted && 64 - busy_lanes >= P.fetch_at) || busy_lanes == 0;
+            if (want_fetch) {
+                if (exhausted) break;
+                n_fetch_steps++;
+                for (Lane& l : L) {
+                    if (l.cur == kDone) {
+                        if (pi == 0) { ref_t[l.rid] = l.found ? l.best : -1.0f; ref_g[l.rid] = l.bgid; }
+                        else if ((l.found ? l.best : -1.0f) != ref_t[l.rid] || (!any && l.bgid != ref_g[l.rid])) mismatches++;
+                        l.cur = kIdle;
+                    }
+                    if (l.cur == kIdle && next < nrays) {
+                        const float* q = &rays[next * 10];
+                        l.rid = next++;
+                        l.o = vptfp::v3(q[0], q[1], q[2]); l.d = vptfp::v3(q[4], q[5], q[6]); l.tmin = q[3]; l.tmax = q[7]; l.tlim = q[8];
+                        memcpy(&l.expect, &q[9], 4);
+                        l.s.o = l.o; l.s.inv = vptfp::v3(sinv(l.d.x), sinv(l.d.y), sinv(l.d.z)); l.s.nx = l.s.inv.x < 0; l.s.ny = l.s.inv.y < 0; l.s.nz = l.s.inv.z < 0;
+                        l.best = any ? l.tlim : l.tmax; l.bgid = -1; l.found = false; l.st.clear(); l.ns = 0; l.cur = 0;
+                    }
+                }
+                if (next >= nrays) exhausted = true;
+                continue;
+            }
+            bool node_wins = 4 * nn > P.w4 * nl;
+            if (P.drain_first && stuck > 0 && nl > 0) { bool full = false; for (Lane& l : L) full |= (l.cur < 0 && l.ns == P.stash); if (full && nn < 48) node_wins = false; }
+            if (nl == 0) node_wins = true;
+            if (nn == 0) node_wins = false;
+            idle_lane_steps += 64 - busy_lanes;
+            if (node_wins) {
+                n_node_steps++; part_node += nn;
+                for (Lane& l : L) {
+                    if (!(l.cur < kDone && l.cur >= 0)) continue;
+                    visits++;
+                    float t[4]; entries(nodes[l.cur], l.s, l.tmin, l.best, t);
+                    int c[4] = {nodes[l.cur].child[0], nodes[l.cur].child[1], nodes[l.cur].child[2], nodes[l.cur].child[3]};
+                    if (any) {
+                        int nxt = kIdle;
+                        for (int k = 3; k >= 0; k--) if (t[k] < kMiss) { if (nxt != kIdle) l.st.push_back(nxt); nxt = c[k]; }
+                        if (nxt != kIdle) l.cur = nxt; else pop_or_done(l);
+                    } else {
+                        for (int i = 0; i < 4; i++) for (int j = i + 1; j < 4; j++) if (t[j] < t[i]) { std::swap(t[i], t[j]); std::swap(c[i], c[j]); }
+                        if (t[0] < kMiss) { if (t[3] < kMiss) l.st.push_back(c[3]); if (t[2] < kMiss) l.st.push_back(c[2]); if (t[1] < kMiss) l.st.push_back(c[1]); l.cur = c[0]; }
+                        else pop_or_done(l);
+                    }
+                    set_aside(l);
+                }
+            } else {
+                n_tri_steps++; part_tri += nl;
+                for (Lane& l : L) {
+                    if (!(l.cur < kDone && (l.cur < 0 || l.ns > 0))) continue;
+                    const bool own = l.cur < 0;
+                    int code = own ? l.cur : l.stash[l.ns - 1];
+                    bool stop = false;
+                    for (int rep = 0; rep < P.tri_per_step && code != kEmpty && !stop; rep++) {
+                        const uint32_t enc = (uint32_t)(~code); const int first = (int)(enc >> 3); const uint32_t more = enc & 7u;
+                        const BvhTri& tr = leaf[first]; tests++;
+                        float tt, u, v;
+                        const bool hit = vptfp::ray_triangle(l.o, l.d, vptfp::v3(tr.v0[0], tr.v0[1], tr.v0[2]), vptfp::v3(tr.e1[0], tr.e1[1], tr.e1[2]), vptfp::v3(tr.e2[0], tr.e2[1], tr.e2[2]), l.tmin, l.tmax, &tt, &u, &v);
+                        if (any) { if (hit && (tt < l.tlim || (tt == l.tlim && tr.gid < l.expect))) stop = true; }
+                        else if (hit && (!l.found || tt < l.best || (tt == l.best && (int)tr.gid < l.bgid))) { l.best = tt; l.bgid = (int)tr.gid; l.found = true; }
+                        code = more ? ~(int)((((uint32_t)first + 1u) << 3) | (more - 1u)) : kEmpty;
+                    }
+                    if (stop) { l.found = true; l.best = 1.0f; l.cur = kDone; l.ns = 0; l.st.clear(); continue; }
+                    if (own) { if (code != kEmpty) l.cur = code; else { pop_or_done(l); set_aside(l); } }
+                    else { if (code != kEmpty) l.stash[l.ns - 1] = code; else l.stash[--l.ns] = kEmpty; }
+                }
+            }
+        }
+        for (Lane& l : L) if (l.cur == kDone) { if (pi == 0) { ref_t[l.rid] = l.found ? l.best : -1.0f; ref_g[l.rid] = l.bgid; } else if ((l.found ? l.best : -1.0f) != ref_t[l.rid] || (!any && l.bgid != ref_g[l.rid])) mismatches++; }
+        const double cost = n_node_steps * (node_cost + P.node_extra) + n_tri_steps * (tri_cost + P.tri_extra) + n_fetch_steps * fetch_cost;
+        const double lane_instr = part_node * (node_cost + P.node_extra) + part_tri * (tri_cost + P.tri_extra) + n_fetch_steps * fetch_cost * 24.0;
+        printf("%-36s VALU/ray %7.1f | node steps/ray %6.3f (%4.1f lanes) tri %6.3f (%4.1f lanes) fetch %5.3f | visits/ray %6.2f tests %5.2f | lane use %4.1f %% | idle lanes %4.1f | mismatches %zu\n", P.name,
+               cost / nrays, n_node_steps / nrays, part_node / std::max(1.0, n_node_steps), n_tri_steps / nrays, part_tri / std::max(1.0, n_tri_steps), n_fetch_steps / nrays,
+               visits / nrays, tests / nrays, 100.0 * lane_instr / (64.0 * cost), idle_lane_steps / std::max(1.0, n_node_steps + n_tri_steps), mismatches);
+    }
+    return 0;
+}

@@ -164,6 +164,10 @@ class PathTracer:
         device waits for the PREVIOUS frame's post-process ticket)."""
         _check(self.lib, self.ctx, self.lib.vpt_wait(self.ctx, ticket), "vpt_wait")
 
+    def lab_set(self, key, value):
+        """Measurement hooks of include/vpt.h (VPT_LAB_*): scheduling only, images never depend on them."""
+        _check(self.lib, self.ctx, self.lib.vpt_lab_set(self.ctx, key, value), "vpt_lab_set")
+
     def output_device(self):
         """GetOutputImageView(): device pointer of the RGBA8 image (None before the first post-process)."""
         return self.lib.vpt_output_device(self.ctx)

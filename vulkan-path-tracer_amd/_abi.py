@@ -22,6 +22,8 @@ FLAGS_DEFAULT = (FLAG_SKY_MIS | FLAG_MESH_MIS | FLAG_SHOW_ENV_DIRECTLY | FLAG_EN
 KERNEL_NAMES = ["primary", "extend", "shade", "connect", "bounce", "resolve", "bloom", "tonemap", "shadow", "join"]
 KERNEL_COUNT = 10
 PIPELINE_AUTO, PIPELINE_FUSED, PIPELINE_STAGED = 0, 1, 2
+PIPELINE_STAGED_R1, PIPELINE_STAGED_SORTED, PIPELINE_WHOLE = 3, 4, 5
+LAB_LANES, LAB_LANE_GRID, LAB_TAIL_GRID, LAB_WHOLE_FRAMES = 1, 2, 3, 4
 ASYNC_MAX_BOUNCES = 16
 
 

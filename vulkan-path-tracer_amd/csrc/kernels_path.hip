@@ -519,6 +519,193 @@ __global__ __launch_bounds__(kTraverseBlock, 3) void k_bounce(DeviceScene sc, Re
     }
 }
 
+// ------------------------------------------------------------------ whole paths in one launch
+// The reference's RayGen invocation IS a whole path: one thread runs the bounce loop of its pixel's sample to the end
+// (RayGen.slang:66-114).  k_whole is that loop on persistent waves, for scenes whose BVH rides in LDS and which have no media:
+// a lane keeps its path in registers from bounce to bounce, and a lane whose path has ended takes the next unstarted sample of the
+// batch, so a launch runs until the batch's samples are used up and no path record, queue or counter crosses HBM in between —
+// only the per-sample frame sums (ACC) do.  One launch per batch instead of max_depth: what a 1-frame batch at 1080p needs (its
+// later bounces are launches of 10^5 paths that do not fill the chip, vpt_render_async).
+// A wave alternates two steps, each on full lanes:
+//   trace   every lane holds a ray — a survivor of the shade step or a fresh camera ray — and finds its closest hit; misses run the
+//           miss shader and end there, hits are parked in a wave-private ring in LDS (hit record + the path's registers);
+//   shade   once the ring holds 64 hits: closest-hit shader, the <= 2 shadow queries, contribution, Russian roulette for those 64;
+//           survivors keep their lanes for the next trace step.
+// Per path this is k_bounce's arithmetic in k_bounce's order (same shade_core, same connect code), and which lane or wave runs a
+// sample cannot matter: seeds come from (pixel, frame), results go to ACC[slot].  pathLight of a parked hit waits in ACC[slot].
+__device__ __forceinline__ V3 whole_finish(const RenderParams& P, const PathState& ps, uint32_t slot, V3 E, V3 thr_prev, V3 light_prev, const ShadeOut& o) {
+    V3 contrib = E * thr_prev;
+    if (o.cflags & kCF_Clamp) {
+        float lum = dot(contrib, v3(0.212671f, 0.715160f, 0.072169f));
+        contrib = contrib * (P.max_luminance / max_(lum, P.max_luminance));
+    }
+    V3 light = light_prev + contrib;
+    if (o.terminated) {  // end of the sample: NaN/Inf guard, frame sum (RayGen.slang:116-128)
+        bool ok = !isinf_(light.x) && !isinf_(light.y) && !isinf_(light.z) && !isnan_(light.x) && !isnan_(light.y) && !isnan_(light.z);
+        ps.ACC[slot] = ok ? f4(v3s(0.0f) + light, 0.0f) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    return light;
+}
+constexpr uint32_t kWholeChunk = 256u;   // samples a wave reserves per atomic beyond its static first 64
+template <bool COUNT, bool STRICT, bool PLAIN>
+__global__ __launch_bounds__(kTraverseBlock, 3) void k_whole(DeviceScene sc, RenderParams P, PathState ps, Counters* ctr, uint32_t n_slots, uint32_t dispatch_base) {
+    sc.strict_hits = STRICT ? 1u : 0u;
+    if (PLAIN) { sc.all_plain = 1u; sc.env_black = 1u; } else sc.all_plain = 0u;
+    if (P.dispatch_base_dev) dispatch_base = *P.dispatch_base_dev;   // a replayed graph: the batch's first dispatch index lives in device memory
+    extern __shared__ __align__(16) unsigned char smem[];
+    const TravStack stack = make_stack(smem, sc.stack_overflow);
+    float4* lds_nodes = reinterpret_cast<float4*>(smem + kStackDepth * kTraverseBlock * 4);
+    float4* lds_tris = lds_nodes + sc.node_count * 8;
+    stage_scene<true>(sc, lds_nodes, lds_tris);
+    __shared__ uint32_t r_slot[kTraverseBlock / 64u][128], r_prim[kTraverseBlock / 64u][128], r_inst[kTraverseBlock / 64u][128];
+    __shared__ float r_t[kTraverseBlock / 64u][128], r_u[kTraverseBlock / 64u][128], r_v[kTraverseBlock / 64u][128];
+    __shared__ float4 r_ra[kTraverseBlock / 64u][128], r_rb[kTraverseBlock / 64u][128], r_rt[kTraverseBlock / 64u][128];
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t n = n_slots;
+    // sample cursor, wave-uniform by construction (kernels_trace.hip k_trace_vote): a static first 64 per wave, then chunks through ctr->extend_head
+    const uint32_t n_static = gridDim.x * (kTraverseBlock / 64u) * 64u;
+    uint32_t w_next = __builtin_amdgcn_readfirstlane((blockIdx.x * (kTraverseBlock / 64u) + wave) * 64u), w_end = w_next + 64u < n ? w_next + 64u : n;
+    if (w_next >= n) { w_next = 0u; w_end = 0u; }
+    bool exhausted = false;
+    uint32_t hit_head = 0u, hit_count = 0u;   // wave-uniform
+    TravStats st, sst; st.nodes = 0; st.tris = 0; sst.nodes = 0; sst.tris = 0;
+    uint32_t w_paths = 0u, w_rays = 0u, w_hits0 = 0u, w_alive0 = 0u, w_rays0 = 0u;   // wave totals (uniform); *0: bounce 0 only
+    // the lane's path between two steps
+    bool has_ray = false;
+    uint32_t slot = 0u, rng_s = 0u, depth = 0u;
+    bool in_medium = false;
+    V3 porg = v3s(0.0f), pdir = v3s(0.0f), thr = v3s(1.0f), lightp = v3s(0.0f);
+    float pdf = 1.0f;
+    for (;;) {
+        // ---- shade: a chunk of parked hits (a partial one only when nothing can be added to it any more: no lane holds a ray here)
+        if (hit_count >= 64u || (exhausted && hit_count > 0u)) {
+            const uint32_t cnt = hit_count < 64u ? hit_count : 64u;
+            const bool valid = lane_id() < cnt;
+            uint32_t nrays = 0u;
+            bool first = false, alive = false;
+            if (valid) {
+                const uint32_t q = (hit_head + lane_id()) & 127u;
+                ShadeIn in_;
+                const float4 a = r_ra[wave][q], b = r_rb[wave][q], t = r_rt[wave][q];
+                slot = r_slot[wave][q];
+                in_.rng = __float_as_uint(a.w);
+                in_.porg = xyz(a); in_.pdir = xyz(b);
+                const uint32_t dw = __float_as_uint(b.w);
+                in_.depth = dw & 0x7fffffffu; in_.in_medium = (dw >> 31) != 0u;
+                in_.thr_prev = xyz(t); in_.prev_pdf = t.w;
+                in_.vdepth = 0u; in_.cchan = -1; in_.vol_index = -1; in_.vol_t = 0.0f; in_.atm_comp = -1;
+                in_.h = make_float4(r_t[wave][q], r_u[wave][q], r_v[wave][q], __uint_as_float(r_prim[wave][q]));
+                in_.inst = r_inst[wave][q];
+                first = in_.depth == 0u;   // (only a camera ray has depth 0: the in-medium walk that leaves the depth alone starts behind a refraction)
+                const V3 light_prev = first ? v3s(0.0f) : xyz(ps.ACC[slot]);
+                ShadeOut o;
+                shade_core<false, (int)kShadeTextured>(sc, P, ps, slot, in_, o);   // "all of these hit something"
+                // connect, inline (RayGen.slang:92-102)
+                V3 E = o.emitted;
+                if (o.want_sky) {
+                    if (sky_visible<true, COUNT>(sc, lds_nodes, lds_tris, o.sky_o, o.sky_d, stack, sst)) E = E + o.csky;
+                    nrays++;
+                }
+                if (o.want_light) {
+                    if (light_visible<true, COUNT>(sc, lds_nodes, lds_tris, o.light_o, o.light_d, o.light_gid, stack, sst)) E = E + o.clight;
+                    nrays++;
+                }
+                const V3 light = whole_finish(P, ps, slot, E, in_.thr_prev, light_prev, o);
+                alive = o.alive;
+                if (alive) {
+                    has_ray = true;
+                    rng_s = o.rng; porg = o.new_o; pdir = o.new_d; depth = o.new_depth; in_medium = o.in_medium; thr = o.thr; pdf = o.new_pdf; lightp = light;
+                }
+            }
+            hit_head += cnt; hit_count -= cnt;
+            w_rays += (uint32_t)__popcll(__ballot(nrays >= 1u)) + (uint32_t)__popcll(__ballot(nrays >= 2u));
+            w_rays0 += (uint32_t)__popcll(__ballot(first && nrays >= 1u)) + (uint32_t)__popcll(__ballot(first && nrays >= 2u));
+            w_alive0 += (uint32_t)__popcll(__ballot(first && alive));
+        }
+        // ---- refill: free lanes take the next unstarted samples (a second pass when the wave's chunk ran out half-way)
+        if (!exhausted) {
+#pragma unroll 1
+            for (int pass = 0; pass < 2; pass++) {
+                const unsigned long long m_free = __ballot(!has_ray);
+                if (m_free == 0ull) break;
+                if (w_next >= w_end) {
+                    if (n_static >= n) exhausted = true;
+                    else {
+                        uint32_t base = 0u;
+                        if (lane_id() == 0u) base = atomicAdd(&ctr->extend_head, kWholeChunk);
+                        base = n_static + __builtin_amdgcn_readfirstlane(base);
+                        if (base >= n) exhausted = true;
+                        else { w_next = base; w_end = base + kWholeChunk < n ? base + kWholeChunk : n; }
+                    }
+                }
+                if (exhausted) break;
+                const uint32_t li = w_next + lanes_below(m_free);
+                if (!has_ray && li < w_end) {
+                    uint32_t x, y, f;
+                    launch_pixel(P, li, dispatch_base, slot, x, y, f);
+                    const uint32_t seed = pcg_hash(P.base_seed + dispatch_base + f);  // PathTracer.cpp:139 with an explicit seed
+                    Rng r; r.s = y + P.width * x + seed;                              // RayGen.slang:28
+                    camera_ray(P, r, x, y, porg, pdir);
+                    rng_s = r.s; depth = 0u; in_medium = false; thr = v3s(1.0f); pdf = 1.0f; lightp = v3s(0.0f);
+                    has_ray = true;
+                }
+                const uint32_t want = (uint32_t)__popcll(m_free), left = w_end - w_next;
+                w_next += want < left ? want : left;
+            }
+        }
+        if (__ballot(has_ray) == 0ull) {
+            if (exhausted && hit_count == 0u) break;
+            continue;
+        }
+        // ---- trace: closest hits; park the hits, finish the misses
+        {
+            HitRec hr;
+            bool hit = false;
+            if (has_ray) hit = trace_any<true, COUNT>(sc, lds_nodes, lds_tris, porg, normalize(pdir), 0.01f, 100000.0f, stack, hr, st);
+            const unsigned long long mh = __ballot(has_ray && hit);
+            if (has_ray && hit) {
+                const uint32_t q = (hit_head + hit_count + lanes_below(mh)) & 127u;
+                r_slot[wave][q] = slot; r_t[wave][q] = hr.t; r_u[wave][q] = hr.u; r_v[wave][q] = hr.v; r_prim[wave][q] = hr.gid; r_inst[wave][q] = hr.inst;
+                r_ra[wave][q] = f4u(porg, rng_s);
+                r_rb[wave][q] = f4u(pdir, depth | (in_medium ? 0x80000000u : 0u));
+                r_rt[wave][q] = f4(thr, pdf);
+                if (depth != 0u) ps.ACC[slot] = f4(lightp, 0.0f);   // pathLight so far (a camera ray's is 0)
+            }
+            hit_count += (uint32_t)__popcll(mh);
+            w_paths += (uint32_t)__popcll(__ballot(has_ray));
+            w_hits0 += (uint32_t)__popcll(__ballot(has_ray && hit && depth == 0u));
+            if (has_ray && !hit) {   // Miss.slang; the path ends here
+                ShadeIn in_;
+                in_.rng = rng_s; in_.porg = porg; in_.pdir = pdir; in_.depth = depth; in_.in_medium = in_medium; in_.thr_prev = thr; in_.prev_pdf = pdf;
+                in_.vdepth = 0u; in_.cchan = -1; in_.vol_index = -1; in_.vol_t = 0.0f; in_.atm_comp = -1;
+                in_.h = make_float4(-1.0f, 0.0f, 0.0f, 0.0f); in_.inst = 0u;
+                ShadeOut o;
+                shade_core<false, (int)kShadeMiss>(sc, P, ps, slot, in_, o);
+                (void)whole_finish(P, ps, slot, o.emitted, thr, lightp, o);
+            }
+            has_ray = false;
+            // nothing of the lane's path is live across the shade step (hits wait in the ring): say so, or its 17 registers stay allocated through shade_core
+            porg = v3s(0.0f); pdir = v3s(0.0f); thr = v3s(1.0f); lightp = v3s(0.0f); pdf = 1.0f; rng_s = 0u; depth = 0u; in_medium = false;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    }
+    if (lane_id() == 0) {
+        if (w_paths) atomicAdd(&ctr->stat_closest, (unsigned long long)w_paths);
+        if (w_rays) atomicAdd(&ctr->stat_shadow, (unsigned long long)w_rays);
+        if (w_hits0) atomicAdd(&ctr->stat_primary_hits, (unsigned long long)w_hits0);
+        if (w_alive0) atomicAdd(&ctr->stat_primary_alive, (unsigned long long)w_alive0);
+        if (w_rays0) atomicAdd(&ctr->stat_primary_rays, (unsigned long long)w_rays0);
+    }
+    if (COUNT) {
+        atomicAdd(&ctr->stat_nodes, (unsigned long long)st.nodes);
+        atomicAdd(&ctr->stat_tris, (unsigned long long)st.tris);
+        atomicAdd(&ctr->stat_shadow_nodes, (unsigned long long)sst.nodes);
+        atomicAdd(&ctr->stat_shadow_tris, (unsigned long long)sst.tris);
+    }
+}
+
 // ------------------------------------------------------------------ connect
 // Per pending path: trace its (<= 2) shadow rays (RTCommon.slang:47-64: closest committed hit), join the
 // visible NEE contributions with the emission BEFORE the luminance clamp (RayGen.slang:92-102), add to
@@ -818,6 +1005,24 @@ void launch_bounce(hipStream_t s, uint32_t blocks, bool lds_scene, bool count, b
     }
 #undef VPT_LAUNCH_BOUNCE
 #undef VPT_LAUNCH_BOUNCE_V
+}
+// Whole paths in one launch (k_whole): LDS-resident scenes without media, one sample per pixel and frame.
+void launch_whole(hipStream_t s, uint32_t blocks, bool count, const DeviceScene& sc, const RenderParams& P, const PathState& ps, Counters* ctr, uint32_t n_slots,
+                  uint32_t dispatch_base, bool plain) {
+    const size_t lds = traverse_lds_bytes(sc, true);
+    const dim3 g(blocks), b(kTraverseBlock);
+    if (plain && !count && !sc.strict_hits && sc.env_black) hipLaunchKernelGGL((k_whole<false, false, true>), g, b, lds, s, sc, P, ps, ctr, n_slots, dispatch_base);
+    else if (sc.strict_hits) { if (count) hipLaunchKernelGGL((k_whole<true, true, false>), g, b, lds, s, sc, P, ps, ctr, n_slots, dispatch_base);
+                               else hipLaunchKernelGGL((k_whole<false, true, false>), g, b, lds, s, sc, P, ps, ctr, n_slots, dispatch_base); }
+    else if (count) hipLaunchKernelGGL((k_whole<true, false, false>), g, b, lds, s, sc, P, ps, ctr, n_slots, dispatch_base);
+    else hipLaunchKernelGGL((k_whole<false, false, false>), g, b, lds, s, sc, P, ps, ctr, n_slots, dispatch_base);
+}
+int whole_blocks_per_cu(const DeviceScene& sc, bool plain) {
+    int nb = 0;
+    const size_t lds = traverse_lds_bytes(sc, true);
+    if (plain) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_whole<false, false, true>, kTraverseBlock, lds);
+    else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_whole<false, false, false>, kTraverseBlock, lds);
+    return nb > 0 ? nb : 1;
 }
 int bounce_blocks_per_cu(bool lds_scene, const DeviceScene& sc, bool plain) {
     int nb = 0;

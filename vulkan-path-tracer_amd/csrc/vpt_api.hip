@@ -28,6 +28,7 @@ struct BatchState {
     uint32_t frames = 0, dispatch_base = 0, n_slots = 0;
     uint32_t n_first = 0;   // slots the camera-ray launch starts (n_slots, or the resident part of it when paths are regenerated)
     bool fused = false, stream = false, media_stream = false, sorted = false, overlap = false, count = false;
+    bool whole = false;     // the whole batch is ONE launch of k_whole (kernels_path.hip): no bounces follow
     uint32_t parity = 0, k3 = 0;
     bool join_pending = false;
     uint64_t iter = 0, iter_cap = 0, min_bounces = 0;
@@ -90,6 +91,8 @@ struct vpt_ctx {
     uint32_t frames_cap = 0;     // upper bound of frames_in_flight after an out-of-memory failure of a size the library chose itself
     uint32_t frames_alloc = 0;   // frames of SAMPLES the slot-addressed buffers hold now: they grow to the largest batch actually requested (ensure_path_buffers)
     uint32_t resident_alloc = 0; // frames of PATHS the queues and stream records hold (<= frames_alloc; less when paths are regenerated)
+    int whole_blocks = 0;        // persistent grid of the whole-path kernel (kernels_path.hip k_whole), 0: the scene does not ride in LDS
+    uint32_t lab_whole_frames = 1u;   // VPT_PIPELINE_AUTO runs batches of at most this many frames as ONE whole-path launch (VPT_LAB_WHOLE_FRAMES)
     bool depth_bounded = true;   // every path ends within max_depth * samples_per_frame bounces (no material scatters inside a medium): see vpt_render_async
     // asynchronous batches (vpt_render_async / vpt_postprocess_device / vpt_wait)
     hipEvent_t tick_ev[kTickets] = {};
@@ -637,6 +640,16 @@ void collect_timing(vpt_ctx* c) {  // call after a stream sync
 // batch_check (host synchronisation: how many paths are still alive).  The bounce loop runs without host round-trips: every stage
 // reads its queue size from device memory, so the host only looks at the counters every few bounces (render_batch) or not at all
 // until somebody waits (vpt_render_async).
+// One launch per batch (kernels_path.hip k_whole): the scene rides in LDS, no media, one sample per pixel and frame, every sample resident.
+// VPT_PIPELINE_WHOLE asks for it; AUTO takes it for short batches (lab_whole_frames), where the per-bounce launches do not fill the chip.
+bool whole_possible(const vpt_ctx* c) {
+    const bool vol = !c->volumes.empty() || c->dsc.atm_on;
+    return c->has_scene && c->lds_scene && c->whole_blocks > 0 && !vol && c->P.samples_per_frame == 1u;
+}
+bool whole_applies(const vpt_ctx* c, uint32_t frames) {
+    if (!whole_possible(c) || frames > c->resident_alloc) return false;
+    return c->cfg.pipeline == VPT_PIPELINE_WHOLE || (c->cfg.pipeline == VPT_PIPELINE_AUTO && frames <= c->lab_whole_frames);
+}
 bool media_on_streams(const vpt_ctx* c) {
     const bool vol = !c->volumes.empty() || c->dsc.atm_on;
     return vol && !c->lds_scene && (c->cfg.pipeline == VPT_PIPELINE_AUTO || c->cfg.pipeline == VPT_PIPELINE_STAGED);
@@ -680,7 +693,10 @@ int batch_begin(vpt_ctx* c, uint32_t frames, uint32_t dispatch_base, BatchState&
     // Media (volumes / atmosphere): on the streams when the BVH lives in memory (kernels_media.hip: the traversal then runs on the
     // vote-scheduled kernels), in the fused per-bounce kernel when it rides in LDS or when the fused pipeline is asked for.
     b.media_stream = media_on_streams(c);
-    b.fused = (vol && !b.media_stream) || c->cfg.pipeline == VPT_PIPELINE_FUSED || (c->cfg.pipeline == VPT_PIPELINE_AUTO && c->lds_scene);
+    b.fused = (vol && !b.media_stream) || c->cfg.pipeline == VPT_PIPELINE_FUSED || (c->cfg.pipeline == VPT_PIPELINE_AUTO && c->lds_scene) || c->cfg.pipeline == VPT_PIPELINE_WHOLE;
+    b.whole = !regen && whole_applies(c, frames);
+    if (c->cfg.pipeline == VPT_PIPELINE_WHOLE && !b.whole)
+        return fail(c, VPT_ERR_UNSUPPORTED, "VPT_PIPELINE_WHOLE needs a scene whose BVH rides in LDS, no media, samples_per_frame == 1 and every sample of a batch resident");
     b.stream = !b.fused && !c->lds_scene && c->cfg.pipeline != VPT_PIPELINE_STAGED_R1;   // VPT_FLAG_LOCAL_HITS included: the stream kernels have validating instantiations
     if (vol && c->cfg.pipeline == VPT_PIPELINE_STAGED && c->lds_scene)
         return fail(c, VPT_ERR_UNSUPPORTED, "media with VPT_PIPELINE_STAGED need a scene whose BVH lives in memory (this one rides in LDS: use VPT_PIPELINE_AUTO or _FUSED)");
@@ -699,7 +715,11 @@ int batch_begin(vpt_ctx* c, uint32_t frames, uint32_t dispatch_base, BatchState&
     b.overlap = b.stream && !b.sorted && !c->cfg.profile && !b.count && !b.media_stream;
     if (n_slots == 0) return VPT_OK;
     HIPCHK(c, hipMemsetAsync(c->ctr, 0, offsetof(Counters, stat_closest), s));  // queue words only, stat_* keep running
-    if (b.fused) {  // bounce 0 of every slot needs no input records; survivors land in queue[1]
+    if (b.whole) {  // the batch's paths from camera ray to their end in one launch; no queue is written, alive3[] stays 0 for the resolve's guard
+        const uint32_t grid = std::min<uint32_t>((uint32_t)std::min(c->whole_blocks, c->primary_blocks), (n_slots + 255u) / 256u);   // (blocks of 256 lanes)
+        TIMED(c, VPT_K_PRIMARY, launch_whole(s, std::max(grid, 1u), b.count, c->dsc, c->P, c->ps, c->ctr, n_slots, dispatch_base, c->scene_plain));
+        b.parity = 1; b.k3 = 1; b.iter = 1;
+    } else if (b.fused) {  // bounce 0 of every slot needs no input records; survivors land in queue[1]
         TIMED(c, VPT_K_PRIMARY, launch_bounce(s, (uint32_t)c->primary_blocks, c->lds_scene, b.count, true, c->dsc, c->P, c->ps, c->ss, nullptr, c->queue[1], c->ctr, 0u, b.n_first, dispatch_base, 0u, c->scene_plain));
         b.parity = 1; b.k3 = 1; b.iter = 1;
     } else if (b.stream) {
@@ -718,7 +738,7 @@ int batch_bounces(vpt_ctx* c, BatchState& b, uint32_t bounces) {
     const bool count = b.count, sorted = b.sorted, overlap = b.overlap;
     uint32_t& parity = b.parity;
     const uint32_t n_slots = b.n_first;   // (upper bound of a queue's live entries)
-    if (n_slots == 0) return VPT_OK;
+    if (n_slots == 0 || b.whole) return VPT_OK;   // (a whole-path batch has no bounces left to launch)
     for (uint32_t j = 0; j < bounces; j++) {
         b.iter++;
         if (b.fused) {  // no reset kernel in between: the bounce kernels rotate three queue-size words
@@ -992,7 +1012,7 @@ vpt_ctx* get_lane(vpt_ctx* c, int k) {
     L->P = c->P;
     bool ok = init_ctx_resources(L) == VPT_OK && alloc_path_buffers(L, 1, 1) == VPT_OK;
     if (ok) {
-        const size_t bytes = stack_overflow_bytes((uint32_t)std::max(c->primary_blocks_general, c->primary_blocks_plain));
+        const size_t bytes = stack_overflow_bytes((uint32_t)std::max(std::max(c->primary_blocks_general, c->primary_blocks_plain), c->whole_blocks));
         ok = hipMalloc(&L->lane_spill, bytes) == hipSuccess;
     }
     if (!ok) { (void)hipGetLastError(); destroy_lane(L); return nullptr; }
@@ -1006,7 +1026,7 @@ void sync_lane(vpt_ctx* c, vpt_ctx* L) {
     L->dsc = c->dsc; L->dsc.stack_overflow = (uint32_t*)L->lane_spill;
     L->params = c->params;
     L->lds_scene = c->lds_scene; L->scene_plain = c->scene_plain; L->depth_bounded = c->depth_bounded; L->has_scene = true;
-    L->primary_blocks = c->primary_blocks;
+    L->primary_blocks = c->primary_blocks; L->whole_blocks = c->whole_blocks; L->lab_whole_frames = c->lab_whole_frames;
     L->image = c->image;
     L->state_gen = c->state_gen;   // the owner's generation invalidates the lane's captured batch too
 }
@@ -1078,7 +1098,7 @@ void vpt_default_post_params(vpt_post_params* p) {  // PostProcessor.h:8-21
 
 vpt_ctx* vpt_create(const vpt_config* cfg, int* err) {
     auto set = [&](int e) { if (err) *err = e; };
-    if (!cfg || cfg->width == 0 || cfg->height == 0 || cfg->shard_count == 0 || cfg->shard_rank >= cfg->shard_count || cfg->pipeline > VPT_PIPELINE_STAGED_SORTED) { set(VPT_ERR_INVALID_ARGUMENT); return nullptr; }
+    if (!cfg || cfg->width == 0 || cfg->height == 0 || cfg->shard_count == 0 || cfg->shard_rank >= cfg->shard_count || cfg->pipeline > VPT_PIPELINE_WHOLE) { set(VPT_ERR_INVALID_ARGUMENT); return nullptr; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev) { set(VPT_ERR_NO_DEVICE); return nullptr; }
     if (hipSetDevice(cfg->device) != hipSuccess) { set(VPT_ERR_NO_DEVICE); return nullptr; }
@@ -1305,13 +1325,14 @@ int vpt_set_scene(vpt_ctx* c, const vpt_scene_desc* sd) {
     c->primary_blocks_general = bounce_blocks_per_cu(c->lds_scene, D, false) * c->cu_count;
     c->primary_blocks_plain = bounce_blocks_per_cu(c->lds_scene, D, true) * c->cu_count;
     c->primary_blocks = std::max(c->primary_blocks_general, c->primary_blocks_plain);   // (sizes the spill regions below; update_depth_bounded picks the grid)
+    c->whole_blocks = c->lds_scene ? std::max(whole_blocks_per_cu(D, false), whole_blocks_per_cu(D, true)) * c->cu_count : 0;
     c->shade_stream_blocks = shade_stream_blocks_per_cu() * c->cu_count;
     c->shade_media_blocks = shade_media_blocks_per_cu() * c->cu_count;
     c->media_tail_blocks = media_tail_blocks_per_cu() * c->cu_count;
     c->shadow_blocks = trace_shadow_blocks_per_cu() * c->cu_count;
     c->vote_blocks = std::min(trace_blocks_per_cu(VPT_TRACE_VOTE, false), trace_blocks_per_cu(VPT_TRACE_VOTE, true)) * c->cu_count;
     {   // per-thread overflow region of the traversal stacks, for the largest persistent grid launched
-        c->max_blocks = std::max(std::max(std::max(std::max(c->trav_blocks, c->shade_blocks), c->primary_blocks), c->vote_blocks), std::max(c->shade_stream_blocks, c->shadow_blocks));
+        c->max_blocks = std::max(std::max(std::max(std::max(c->trav_blocks, c->shade_blocks), std::max(c->primary_blocks, c->whole_blocks)), c->vote_blocks), std::max(c->shade_stream_blocks, c->shadow_blocks));
         void* d = nullptr;
         // two regions: the shadow kernels of bounce k run on the second stream beside the extend kernel of bounce k + 1, and a
         // spill slot is addressed by (block, thread) alone, so concurrent grids must not share one region (round 2 did)
@@ -1599,10 +1620,12 @@ int vpt_render_async(vpt_ctx* c, uint32_t dispatches, int* done, uint64_t* ticke
         const uint64_t bounds = (uint64_t)c->P.max_depth * c->P.samples_per_frame;
         const bool vol = !c->volumes.empty() || c->dsc.atm_on;
         // a fixed schedule: every path has ended after `bounds` bounces, whatever the random numbers say
-        const bool fixed = c->depth_bounded && !vol && bounds <= VPT_ASYNC_MAX_BOUNCES && nf <= c->resident_alloc;   // (a regenerating batch has no fixed length)
+        // ... or the batch is ONE launch that runs every path to its end (k_whole), whatever max_depth is
+        const bool whole = whole_applies(c, nf);
+        const bool fixed = whole || (c->depth_bounded && !vol && bounds <= VPT_ASYNC_MAX_BOUNCES && nf <= c->resident_alloc);   // (a regenerating batch has no fixed length)
         const uint32_t enq = (uint32_t)std::min<uint64_t>(bounds, VPT_ASYNC_MAX_BOUNCES);
         const uint32_t base = (uint32_t)c->dispatch_count;
-        const bool fused_auto = (c->cfg.pipeline == VPT_PIPELINE_FUSED || (c->cfg.pipeline == VPT_PIPELINE_AUTO && c->lds_scene)) && !vol;
+        const bool fused_auto = (whole || c->cfg.pipeline == VPT_PIPELINE_FUSED || (c->cfg.pipeline == VPT_PIPELINE_AUTO && c->lds_scene)) && !vol;
         const bool plain_launches = c->cfg.profile || c->cfg.count_traversal || c->P.split != 1u;
         if (c->graph_streak_gen == c->state_gen) c->graph_streak++; else { c->graph_streak = 0; c->graph_streak_gen = c->state_gen; }
         // the fused pipeline's fixed 1-frame batch goes to the next lane (vpt_ctx::lanes); asked for again with nothing changed since the
@@ -2064,12 +2087,13 @@ int vpt_multi_gather_shards(vpt_ctx* const* ctxs, uint32_t count, uint32_t root)
 }
 
 int vpt_lab_set(vpt_ctx* c, uint32_t key, uint32_t value) {
-    if (!c || value > 3u) return VPT_ERR_INVALID_ARGUMENT;
+    if (!c || (value > 3u && key != VPT_LAB_WHOLE_FRAMES)) return VPT_ERR_INVALID_ARGUMENT;
     HIPCHK(c, hipSetDevice(c->cfg.device));
     { int rd = drain(c); if (rd) return rd; }
     if (key == VPT_LAB_LANES && value >= 1u) c->lab_lanes = value;
     else if (key == VPT_LAB_LANE_GRID && value >= 1u) c->lab_lane_grid = value;
     else if (key == VPT_LAB_TAIL_GRID && value >= 1u) c->lab_tail_grid = value;
+    else if (key == VPT_LAB_WHOLE_FRAMES) c->lab_whole_frames = value;
     else return VPT_ERR_INVALID_ARGUMENT;
     c->state_gen++;   // captured batches hold the old grids
     return VPT_OK;
