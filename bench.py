@@ -79,6 +79,8 @@ CONNECT_RAY = 48                    # per shadow ray: the three records shade qu
 CONNECT_FINAL = 16                  # frame-sum write at the end of a sample (samples_per_frame == 1)
 PRIMARY_DONE = 16                   # a path that ends at bounce 0 writes only its frame sum
 PRIMARY_ALIVE = 16 * 4 + 4          # a survivor writes records A, B, T, L and its queue id
+WHOLE_FINAL = 16                    # whole-path launch: a sample's frame sum, written once
+WHOLE_PARKED = 32                   # ... and per hit of a bounce >= 1: pathLight out to the frame-sum slot and back (16 + 16)
 # resolve: 16 B frame sum per (pixel, frame) in, plus one 32 B image read+write per pixel per batch
 
 
@@ -177,6 +179,7 @@ def kernel_table(st, tc):
     """Per stage: launches, mean ms, units, algorithmic bytes per unit (records + scene gathers + measured BVH visits) and
     the part of them that is unique per path (records / queue words / frame sums) and therefore has to cross HBM."""
     n0 = st["samples"]
+    whole = st["kernel_launches"]["bounce"] == 0 and st["kernel_launches"]["extend"] == 0 and st["kernel_launches"]["primary"] > 0   # one whole-path launch per batch (k_whole)
     fused0 = st["kernel_launches"]["bounce"] > 0 or st["kernel_launches"]["extend"] == 0   # bounce 0 ran in the fused primary kernel
     streams = st["kernel_launches"]["join"] > 0                                            # staged pipeline on compact streams
     n_later = st["closest_rays"] - (n0 if fused0 else 0)
@@ -196,6 +199,10 @@ def kernel_table(st, tc):
         "extend": (n_later, EXTEND_FIXED + trav, EXTEND_FIXED),
         "resolve": (st["samples"], 16 + 32.0 / max(st["frames_in_flight"], 1), 16 + 32.0 / max(st["frames_in_flight"], 1)),
     }
+    if whole:   # kernels_path.hip k_whole: the unit is a SAMPLE (camera ray to the path's end).  What must cross HBM per sample: its 16 B frame sum, and for
+        # every hit of a bounce >= 1 (vpt_stats.connect_paths) pathLight's round trip through the frame-sum slot while the hit is parked: 16 B out + 16 B back
+        rec = WHOLE_FINAL + WHOLE_PARKED * pend / max(n0, 1)
+        units["primary"] = (n0, rec + (SHADE_SCENE * (hits0 + pend) + trav * st["closest_rays"] + strav * st["shadow_rays"]) / max(n0, 1), rec)
     if streams:
         rec = SHADE_STREAM_IN + (SHADE_STREAM_ALIVE * alive_later + SHADE_STREAM_PENDING * pend + 32 * later_rays) / max(n_later, 1)
         units["shade"] = (n_later, rec + SHADE_SCENE, rec)
@@ -322,10 +329,11 @@ def kernel_profile(vpt, name, scene, device, rank, world, pipeline, frames_in_fl
     for _ in range(steps):
         pp.render(F)
     st = pp.stats(); pp.close()
-    used = 1 if st["kernel_launches"]["bounce"] > 0 else 2    # the pipeline AUTO settled on: count with the same one
+    whole = st["kernel_launches"]["bounce"] == 0 and st["kernel_launches"]["extend"] == 0
+    used = 5 if whole else 1 if st["kernel_launches"]["bounce"] > 0 else 2    # the pipeline AUTO settled on: count with the same one
     tc = traversal_counts(vpt, name, scene, params, device, rank, world, used if pipeline == 0 else pipeline, min(F, 4))
     kernels = kernel_table(st, tc)
-    return {"pipeline": "fused" if used == 1 else ("staged (streams)" if st["kernel_launches"]["join"] > 0 else "staged (round-1 kernels)"), "bvh": {"nodes": st["bvh_nodes"], "triangles": st["bvh_triangles"], "node_bytes": st["bvh_node_bytes"], "tri_bytes": st["bvh_tri_bytes"]},
+    return {"pipeline": "whole paths (one launch per batch)" if whole else "fused" if used == 1 else ("staged (streams)" if st["kernel_launches"]["join"] > 0 else "staged (round-1 kernels)"), "bvh": {"nodes": st["bvh_nodes"], "triangles": st["bvh_triangles"], "node_bytes": st["bvh_node_bytes"], "tri_bytes": st["bvh_tri_bytes"]},
             "traversal": {k: round(v, 3) for k, v in tc.items() if k.endswith("_ray")}, "kernels": kernels}
 
 

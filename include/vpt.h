@@ -203,7 +203,8 @@ typedef struct vpt_config {
  * texture 1x1 and a black environment: k_bounce<PLAIN>, kernels_path.hip).  Images are identical; this is the A/B switch of that choice. */
 #define VPT_BUILD_GENERAL_KERNELS 2u
 
-/* AUTO = FUSED when the BVH fits in LDS next to the traversal stacks, else STAGED. Results are identical. */
+/* AUTO = WHOLE where it applies (BVH in LDS, no media, one sample per pixel and frame), FUSED for the other scenes whose BVH fits in LDS next to
+ * the traversal stacks, else STAGED.  Results are identical. */
 #define VPT_PIPELINE_AUTO 0u
 #define VPT_PIPELINE_FUSED 1u   /* one kernel per bounce */
 #define VPT_PIPELINE_STAGED 2u  /* extend -> shade -> connect with compacted queues; traversal on the vote-scheduled persistent kernels */
@@ -213,8 +214,8 @@ typedef struct vpt_config {
 #define VPT_PIPELINE_WHOLE 5u  /* ONE launch per batch: persistent waves run every path from its camera ray to its end, a lane whose path has ended takes
                                * the batch's next sample (kernels_path.hip k_whole; the reference's own shape: one RayGen thread = one whole path).
                                * For scenes whose BVH rides in LDS, no media, samples_per_frame == 1, every sample resident — VPT_ERR_UNSUPPORTED
-                               * otherwise.  Bit-identical.  AUTO takes it for 1-frame batches of such scenes (the interactive case: the
-                               * per-bounce launches of one frame do not fill the chip) and FUSED for longer ones */
+                               * otherwise.  Bit-identical.  AUTO takes it wherever it applies: measured faster than FUSED at every batch size
+                               * (Cornell box 1080p: 8.3 vs 7.4 Gsamples/s at 226 frames per batch, 3.8 vs 2.4 at one; profiles/r04_whole_ab.json) */
 #define VPT_PIPELINE_STAGED_R1 3u /* the same stages with round 1's traversal loops (64 rays per wave at a time): kept as the measured baseline */
 
 #define VPT_KERNEL_COUNT 10
@@ -237,7 +238,8 @@ typedef struct vpt_stats {
     uint64_t dispatches;       /* m_DispatchCount */
     uint64_t closest_rays;     /* rays traced by the extend kernel */
     uint64_t shadow_rays;      /* rays traced by the connect kernel */
-    uint64_t connect_paths;    /* path-bounces that went through the connect kernel */
+    uint64_t connect_paths;    /* path-bounces that went through the connect kernel (staged pipelines); whole-path launches: hits of bounces >= 1, whose
+                                * pathLight waits in the frame-sum slot while the hit is parked (16 B written + 16 B read each) */
     uint64_t primary_hits;     /* camera rays that hit geometry */
     uint64_t primary_survivors;   /* paths that continue after bounce 0 */
     uint64_t primary_shadow_rays; /* shadow rays traced inside the primary kernel */
@@ -479,11 +481,15 @@ int vpt_lab_set_rays(vpt_ctx* ctx, const vpt_ray* rays_host, uint32_t n);
  *   VPT_LAB_LANES       lanes consecutive frames are dealt to (1-3; default 3: a frame takes the first lane whose previous frame is resolved)
  *   VPT_LAB_LANE_GRID   divisor of the fused kernel's persistent grid while frames are pipelined (1-3; default 1)
  *   VPT_LAB_TAIL_GRID   divisor of the grid of a 1-frame batch's bounces >= 2, whose queues hold a fraction of the frame's paths (1-3; default 3)
- *   VPT_LAB_WHOLE_FRAMES  VPT_PIPELINE_AUTO runs batches of at most this many frames as one whole-path launch where VPT_PIPELINE_WHOLE applies (default 1; 0: never) */
+ *   VPT_LAB_WHOLE_FRAMES  VPT_PIPELINE_AUTO runs batches of at most this many frames as one whole-path launch where VPT_PIPELINE_WHOLE applies
+ *                         (0: never — the per-bounce kernels; 0xffff: no bound, the default)
+ *   VPT_LAB_WHOLE_SCHED   how a whole-path launch deals its tiles of 64 samples: low 4 bits = tiles per atomic (1-15), bits 4-5 = rounds dealt without
+ *                         an atomic (0: the first, 1: all but the last, 2: half).  Default 4 (first round static, then four tiles per atomic) */
 #define VPT_LAB_LANES 1u
 #define VPT_LAB_LANE_GRID 2u
 #define VPT_LAB_TAIL_GRID 3u
 #define VPT_LAB_WHOLE_FRAMES 4u
+#define VPT_LAB_WHOLE_SCHED 5u
 int vpt_lab_set(vpt_ctx* ctx, uint32_t key, uint32_t value);
 int vpt_lab_trace(vpt_ctx* ctx, uint32_t variant, uint32_t any_hit, const uint32_t* order_host, uint32_t param, uint32_t reps,
                   vpt_hit* hits_host, float* best_ms, uint64_t* visits);

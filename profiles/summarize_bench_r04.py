@@ -12,6 +12,8 @@ G = os.path.join(ROOT, "gpurun_out", "prof_bench")
 def stage(name):
     m = re.search(r"<([^>]*)>", name)
     a = [x.strip() for x in m.group(1).split(",")] if m else []
+    if "k_whole" in name:   # the whole-path launch (round 4): bench.py times it under "primary"; <COUNT, STRICT, PLAIN>
+        return None if a and a[0] == "true" else "primary"
     if "k_bounce" in name:
         if len(a) >= 2 and a[1] == "true":
             return None   # traversal-counting variants (bench.py's counting pass)
@@ -33,7 +35,7 @@ for f in glob.glob(os.path.join(G, "*", "**", "*counter_collection.csv"), recurs
         if s:
             acc[s][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[s][r["Counter_Name"]] += 1
 out = {"cornell_1080p_d8": {}}
-lines = ["# Cornell 1080p depth 8 (bench.py headline workload, fused pipeline) — rocprofv3 summary (r04)", "",
+lines = ["# Cornell 1080p depth 8 (bench.py headline workload; `primary` is the whole-path launch k_whole where AUTO takes it, else k_bounce<FIRST>) — rocprofv3 summary (r04)", "",
          "`python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-extra-workloads` under profiles/collect_bench_r04.sh (kernel trace + separate PMC passes).", "",
          "| stage | calls | mean us | HBM bytes / launch (2 x FETCH + WRITE) | fetched | written | VALU busy | lanes / VALU instr | wait | L2 hit |", "|---|---|---|---|---|---|---|---|---|---|"]
 flops_rows = []

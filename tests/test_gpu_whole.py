@@ -29,15 +29,28 @@ def gpu_image(vpt, sc, w, h, params, batches, **kw):
     return img, st
 
 
+def scene_of(vpt, scenes, name):
+    """cornell_box as shipped (every texture 1x1, black environment: the PLAIN instantiation), or the same 12 triangles — the golden
+    Cornell box with the glass sphere keeps its BVH in memory, where the whole-path launch does not apply — with a glass wall, a rough
+    glass floor holding a scattering medium and a sky (the general instantiation)."""
+    if name == "cornell_box":
+        return scenes(name)
+    sc = copy.deepcopy(scenes("cornell_box"))
+    sc.materials[0].update(transmission=1.0, roughness=0.05, ior=1.5, base_color=(1, 1, 1))
+    sc.materials[2].update(transmission=1.0, roughness=0.3, ior=1.33, medium_density=0.6, medium_anisotropy=0.3, medium_color=(0.9, 0.5, 0.4))
+    sc.env = vpt.scenes.sun_sky_env(64, 32, seed=9, sun_peak=100.0)
+    return sc
+
+
 RAY_STATS = ("closest_rays", "shadow_rays", "primary_hits", "primary_survivors", "primary_shadow_rays", "samples", "frames")
 
 
 @pytest.mark.parametrize("name,depth,w,h", [("cornell_box", 8, 160, 90), ("cornell_box", 1, 97, 53), ("cornell_box", 200, 96, 54),
-                                            ("cornell_box_glass", 12, 128, 72), ("cornell_box_glass", 40, 96, 54), ("cornell_box", 8, 8, 8)])
+                                            ("cornell_glass", 12, 128, 72), ("cornell_glass", 40, 96, 54), ("cornell_box", 8, 8, 8)])
 def test_whole_path_launches_equal_the_oracle_and_the_per_bounce_pipeline(vpt, oracle, scenes, name, depth, w, h):
-    """The Cornell box runs the scene-class instantiation (PLAIN), the glass sphere the general one (refraction, the medium state of
-    a slot); 8 x 8 is less than one wave's first 64 samples, 97 x 53 leaves ragged tails everywhere."""
-    sc = scenes(name)
+    """The Cornell box runs the scene-class instantiation (PLAIN), the glass variant the general one (refraction, the medium state of
+    a slot, environment lookups); 8 x 8 is less than one wave's first 64 samples, 97 x 53 leaves ragged tails everywhere."""
+    sc = scene_of(vpt, scenes, name)
     p = vpt.default_params(max_depth=depth)
     ref, ctr = oracle_image(oracle, sc, w, h, p, 7)
     img, st = gpu_image(vpt, sc, w, h, p, [3, 3, 1], pipeline=vpt._abi.PIPELINE_WHOLE, frames_in_flight=3)
@@ -69,8 +82,7 @@ def test_whole_path_general_kernel_with_textures_environment_and_every_material_
 @pytest.mark.parametrize("kw", [dict(dof_strength=0.8, focus_distance=20.0), dict(max_luminance=2.0), dict(emissive_pdf_bias=0.5), dict(screen_chunk_count=2),
                                 dict(flags="local_hits"), dict(flags="no_mis"), dict(flags="furnace")])
 def test_whole_path_parameter_and_flag_variants(vpt, oracle, scenes, kw):
-    sc = copy.deepcopy(scenes("cornell_box_glass"))
-    sc.env = vpt.scenes.sun_sky_env(64, 32, seed=9, sun_peak=100.0)
+    sc = scene_of(vpt, scenes, "cornell_glass")
     p = vpt.default_params(max_depth=6)
     for k, v in kw.items():
         if k == "flags":
@@ -87,7 +99,7 @@ def test_whole_path_parameter_and_flag_variants(vpt, oracle, scenes, kw):
 
 def test_whole_path_counting_instantiations_count_what_the_per_bounce_kernels_count(vpt, scenes):
     """vpt_config.count_traversal: node and triangle visits are per ray, so the totals cannot depend on the schedule."""
-    sc, p = scenes("cornell_box_glass"), vpt.default_params(max_depth=10)
+    sc, p = scene_of(vpt, scenes, "cornell_glass"), vpt.default_params(max_depth=10)
     for flags in (vpt._abi.FLAGS_DEFAULT, vpt._abi.FLAGS_DEFAULT | vpt._abi.FLAG_LOCAL_HITS):
         p.flags = flags
         a, sa = gpu_image(vpt, sc, 96, 54, p, [4], pipeline=vpt._abi.PIPELINE_WHOLE, count_traversal=True)
@@ -97,34 +109,44 @@ def test_whole_path_counting_instantiations_count_what_the_per_bounce_kernels_co
             assert sa[k] == sb[k] and sa[k] > 0, (k, sa[k], sb[k])
 
 
-def test_auto_takes_the_whole_path_launch_for_one_frame_batches_only(vpt, oracle, scenes):
-    """AUTO: a 1-frame batch of an LDS-resident scene is one launch (the interactive case); longer batches keep the per-bounce kernels;
-    VPT_LAB_WHOLE_FRAMES moves the boundary.  Same image whichever way the frames were grouped."""
+def test_auto_takes_the_whole_path_launch_wherever_it_applies(vpt, oracle, scenes):
+    """AUTO: every batch of an LDS-resident scene without media is one launch (measured faster at every batch size,
+    profiles/r04_whole_ab.json); VPT_LAB_WHOLE_FRAMES bounds the batch size it is taken for (0: the per-bounce kernels — the A/B switch).
+    Same image whichever way the frames were grouped and run."""
     sc, w, h = scenes("cornell_box"), 128, 72
     p = vpt.default_params(max_depth=8)
-    ref, _ = oracle_image(oracle, sc, w, h, p, 6)
+    ref, _ = oracle_image(oracle, sc, w, h, p, 7)
     g = vpt.PathTracer(w, h, frames_in_flight=4)
     g.set_scene(sc); g.set_params(p)
-    g.render(1); g.render(1)
+    g.render(1); g.render(3)
     st = g.stats()
     assert st["kernel_launches"]["primary"] == 2 and st["kernel_launches"]["bounce"] == 0
+    g.lab_set(vpt._abi.LAB_WHOLE_FRAMES, 1)
     g.render(2)
     st = g.stats()
     assert st["kernel_launches"]["primary"] == 3 and st["kernel_launches"]["bounce"] == 7
     g.lab_set(vpt._abi.LAB_WHOLE_FRAMES, 0)
     g.render(1)
     assert g.stats()["kernel_launches"]["bounce"] == 14
-    g.lab_set(vpt._abi.LAB_WHOLE_FRAMES, 4)
-    g.render(1)
+    g.lab_set(vpt._abi.LAB_WHOLE_FRAMES, 0xffff)
+    g.render(4)
     st = g.stats()
-    assert st["kernel_launches"]["bounce"] == 14 and st["kernel_launches"]["primary"] == 5
+    assert st["kernel_launches"]["bounce"] == 14 and st["kernel_launches"]["primary"] == 5 and st["frames"] == 11
+    g.close()
+    g = vpt.PathTracer(w, h, frames_in_flight=4)
+    g.set_scene(sc); g.set_params(p)
+    g.render(1); g.render(3)
+    g.lab_set(vpt._abi.LAB_WHOLE_FRAMES, 1)
+    g.render(2)
+    g.lab_set(vpt._abi.LAB_WHOLE_FRAMES, 0)
+    g.render(1)
     assert np.array_equal(g.radiance(), ref)
     g.close()
 
 
 def test_whole_path_where_it_does_not_apply(vpt, scenes):
     """Asked for explicitly it fails loudly (no silent other pipeline); AUTO simply does not take it."""
-    sc = copy.deepcopy(scenes("viking_room"))          # BVH in memory
+    sc = scenes("cornell_box_glass")                   # the 960-triangle glass sphere: BVH in memory
     g = vpt.PathTracer(64, 36, pipeline=vpt._abi.PIPELINE_WHOLE)
     g.set_scene(sc); g.set_params(vpt.default_params(max_depth=4))
     with pytest.raises(vpt.VptError, match="VPT_PIPELINE_WHOLE"):
@@ -144,11 +166,11 @@ def test_whole_path_where_it_does_not_apply(vpt, scenes):
     g.close()
 
 
-@pytest.mark.parametrize("name,depth", [("cornell_box", 8), ("cornell_box", 200), ("cornell_box_glass", 40)])
+@pytest.mark.parametrize("name,depth", [("cornell_box", 8), ("cornell_box", 200), ("cornell_glass", 40)])
 def test_async_frames_are_whole_path_launches(vpt, oracle, scenes, name, depth):
     """vpt_render_async, one frame per call: with the whole-path launch every such batch is a fixed schedule — max_depth = 200 included,
     which the per-bounce pipeline could only enqueue partially — dealt to the lanes and replayed from captured graphs."""
-    sc, w, h, frames = scenes(name), 128, 72, 10
+    sc, w, h, frames = scene_of(vpt, scenes, name), 128, 72, 10
     p = vpt.default_params(max_depth=depth)
     ref, _ = oracle_image(oracle, sc, w, h, p, frames)
     g = vpt.PathTracer(w, h, frames_in_flight=1)

@@ -13,11 +13,15 @@ out_dir = os.path.join(ROOT, "gpurun_out", sys.argv[1] if len(sys.argv) > 1 else
 os.makedirs(out_dir, exist_ok=True)
 res = {"throughput": [], "latency": [], "kernel": []}
 W, H = 1920, 1080
-SCENES = (("cornell_box", 8), ("cornell_box_glass", 12))
+SCENES = (("cornell_box", 8), ("cornell_glass", 12))   # the second: the same 12 triangles with glass walls and a sky (general instantiation)
 PIPES = (("fused", A.PIPELINE_FUSED), ("whole", A.PIPELINE_WHOLE))
 imgs = {}
 for name, depth in SCENES:
-    sc = vpt.scenes.Scene.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
+    sc = vpt.scenes.Scene.load(os.path.join(ROOT, "tests", "golden", "cornell_box.npz"))
+    if name == "cornell_glass":
+        sc.materials[0].update(transmission=1.0, roughness=0.05, ior=1.5, base_color=(1, 1, 1))
+        sc.materials[2].update(transmission=1.0, roughness=0.3, ior=1.33, medium_density=0.6, medium_anisotropy=0.3, medium_color=(0.9, 0.5, 0.4))
+        sc.env = vpt.scenes.sun_sky_env(64, 32, seed=9, sun_peak=100.0)
     P = vpt.default_params(max_depth=depth, max_samples=0x7fffffff)
     for F in ((1, 4, 16, 64, 0) if name == "cornell_box" else (1, 0)):
         for pname, pipe in PIPES:

@@ -9,7 +9,7 @@ void launch_bounce(hipStream_t s, uint32_t blocks, bool lds_scene, bool count, b
                    uint32_t dispatch_base, uint32_t k3, bool plain = false);
 int bounce_blocks_per_cu(bool lds_scene, const DeviceScene& sc, bool plain = false);
 void launch_whole(hipStream_t s, uint32_t blocks, bool count, const DeviceScene& sc, const RenderParams& P, const PathState& ps, Counters* ctr, uint32_t n_slots,
-                  uint32_t dispatch_base, bool plain);
+                  uint32_t dispatch_base, bool plain, uint32_t static_rounds, uint32_t chunk_tiles);
 int whole_blocks_per_cu(const DeviceScene& sc, bool plain);
 void launch_raygen(hipStream_t s, const RenderParams& P, const PathState& ps, uint32_t* queue, Counters* ctr, uint32_t n_slots, uint32_t dispatch_base);
 void launch_prepare(hipStream_t s, Counters* ctr, uint32_t parity);

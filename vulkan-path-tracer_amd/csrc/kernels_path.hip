@@ -546,9 +546,13 @@ __device__ __forceinline__ V3 whole_finish(const RenderParams& P, const PathStat
     }
     return light;
 }
-constexpr uint32_t kWholeChunk = 256u;   // samples a wave reserves per atomic beyond its static first 64
+// Samples are dealt in tiles of 64 (consecutive pixels of a row).  Wave w of W takes tiles w, w + W, ... for the first `static_rounds` rounds
+// without an atomic, and the tiles behind them `chunk_tiles` at a time through ctr->extend_head (the host picks both: vpt_api.hip whole_schedule).
+// (Measured and not kept: one-wave blocks, which leave the CU as soon as THEIR paths have ended and so let the next frame's launch in earlier —
+// a 1-frame launch at 1080p 542 us against 509 us, and slower with two or three frames in flight too: profiles/r04_whole_lanes.json.)
 template <bool COUNT, bool STRICT, bool PLAIN>
-__global__ __launch_bounds__(kTraverseBlock, 3) void k_whole(DeviceScene sc, RenderParams P, PathState ps, Counters* ctr, uint32_t n_slots, uint32_t dispatch_base) {
+__global__ __launch_bounds__(kTraverseBlock, 3) void k_whole(DeviceScene sc, RenderParams P, PathState ps, Counters* ctr, uint32_t n_slots, uint32_t dispatch_base,
+                                                            uint32_t static_rounds, uint32_t chunk_tiles) {
     sc.strict_hits = STRICT ? 1u : 0u;
     if (PLAIN) { sc.all_plain = 1u; sc.env_black = 1u; } else sc.all_plain = 0u;
     if (P.dispatch_base_dev) dispatch_base = *P.dispatch_base_dev;   // a replayed graph: the batch's first dispatch index lives in device memory
@@ -557,19 +561,22 @@ __global__ __launch_bounds__(kTraverseBlock, 3) void k_whole(DeviceScene sc, Ren
     float4* lds_nodes = reinterpret_cast<float4*>(smem + kStackDepth * kTraverseBlock * 4);
     float4* lds_tris = lds_nodes + sc.node_count * 8;
     stage_scene<true>(sc, lds_nodes, lds_tris);
-    __shared__ uint32_t r_slot[kTraverseBlock / 64u][128], r_prim[kTraverseBlock / 64u][128], r_inst[kTraverseBlock / 64u][128];
-    __shared__ float r_t[kTraverseBlock / 64u][128], r_u[kTraverseBlock / 64u][128], r_v[kTraverseBlock / 64u][128];
-    __shared__ float4 r_ra[kTraverseBlock / 64u][128], r_rb[kTraverseBlock / 64u][128], r_rt[kTraverseBlock / 64u][128];
+    constexpr uint32_t kWaves = kTraverseBlock / 64u;
+    __shared__ uint32_t r_slot[kWaves][128], r_prim[kWaves][128], r_inst[kWaves][128];
+    __shared__ float r_t[kWaves][128], r_u[kWaves][128], r_v[kWaves][128];
+    __shared__ float4 r_ra[kWaves][128], r_rb[kWaves][128], r_rt[kWaves][128];
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t n = n_slots;
-    // sample cursor, wave-uniform by construction (kernels_trace.hip k_trace_vote): a static first 64 per wave, then chunks through ctr->extend_head
-    const uint32_t n_static = gridDim.x * (kTraverseBlock / 64u) * 64u;
-    uint32_t w_next = __builtin_amdgcn_readfirstlane((blockIdx.x * (kTraverseBlock / 64u) + wave) * 64u), w_end = w_next + 64u < n ? w_next + 64u : n;
-    if (w_next >= n) { w_next = 0u; w_end = 0u; }
+    // tile cursor, wave-uniform by construction (kernels_trace.hip k_trace_vote)
+    const uint32_t n_waves = gridDim.x * kWaves, n_tiles = (n + 63u) / 64u;
+    const uint32_t dyn_first = static_rounds * n_waves;   // tiles from here on are taken through the counter
+    uint32_t static_left = static_rounds;
+    uint32_t next_static = __builtin_amdgcn_readfirstlane(blockIdx.x * kWaves + wave);
+    uint32_t w_next = 0u, w_end = 0u;
     bool exhausted = false;
     uint32_t hit_head = 0u, hit_count = 0u;   // wave-uniform
     TravStats st, sst; st.nodes = 0; st.tris = 0; sst.nodes = 0; sst.tris = 0;
-    uint32_t w_paths = 0u, w_rays = 0u, w_hits0 = 0u, w_alive0 = 0u, w_rays0 = 0u;   // wave totals (uniform); *0: bounce 0 only
+    uint32_t w_paths = 0u, w_rays = 0u, w_hits0 = 0u, w_alive0 = 0u, w_rays0 = 0u, w_parked = 0u;   // wave totals (uniform); *0: bounce 0 only; parked: hits of later bounces (their pathLight waits in ACC)
     // the lane's path between two steps
     bool has_ray = false;
     uint32_t slot = 0u, rng_s = 0u, depth = 0u;
@@ -628,15 +635,16 @@ __global__ __launch_bounds__(kTraverseBlock, 3) void k_whole(DeviceScene sc, Ren
             for (int pass = 0; pass < 2; pass++) {
                 const unsigned long long m_free = __ballot(!has_ray);
                 if (m_free == 0ull) break;
-                if (w_next >= w_end) {
-                    if (n_static >= n) exhausted = true;
+                if (w_next >= w_end) {   // the next tile(s)
+                    uint32_t tile, span = 1u;
+                    if (static_left != 0u) { tile = next_static; next_static += n_waves; static_left--; }
                     else {
-                        uint32_t base = 0u;
-                        if (lane_id() == 0u) base = atomicAdd(&ctr->extend_head, kWholeChunk);
-                        base = n_static + __builtin_amdgcn_readfirstlane(base);
-                        if (base >= n) exhausted = true;
-                        else { w_next = base; w_end = base + kWholeChunk < n ? base + kWholeChunk : n; }
+                        uint32_t k = 0u;
+                        if (lane_id() == 0u) k = atomicAdd(&ctr->extend_head, chunk_tiles);
+                        tile = dyn_first + __builtin_amdgcn_readfirstlane(k); span = chunk_tiles;
                     }
+                    if (tile >= n_tiles) exhausted = true;
+                    else { w_next = tile * 64u; w_end = (tile + span) * 64u < n ? (tile + span) * 64u : n; }
                 }
                 if (exhausted) break;
                 const uint32_t li = w_next + lanes_below(m_free);
@@ -674,6 +682,7 @@ __global__ __launch_bounds__(kTraverseBlock, 3) void k_whole(DeviceScene sc, Ren
             hit_count += (uint32_t)__popcll(mh);
             w_paths += (uint32_t)__popcll(__ballot(has_ray));
             w_hits0 += (uint32_t)__popcll(__ballot(has_ray && hit && depth == 0u));
+            w_parked += (uint32_t)__popcll(__ballot(has_ray && hit && depth != 0u));
             if (has_ray && !hit) {   // Miss.slang; the path ends here
                 ShadeIn in_;
                 in_.rng = rng_s; in_.porg = porg; in_.pdir = pdir; in_.depth = depth; in_.in_medium = in_medium; in_.thr_prev = thr; in_.prev_pdf = pdf;
@@ -697,6 +706,7 @@ __global__ __launch_bounds__(kTraverseBlock, 3) void k_whole(DeviceScene sc, Ren
         if (w_hits0) atomicAdd(&ctr->stat_primary_hits, (unsigned long long)w_hits0);
         if (w_alive0) atomicAdd(&ctr->stat_primary_alive, (unsigned long long)w_alive0);
         if (w_rays0) atomicAdd(&ctr->stat_primary_rays, (unsigned long long)w_rays0);
+        if (w_parked) atomicAdd(&ctr->stat_connect, (unsigned long long)w_parked);   // vpt_stats.connect_paths: here, the hits whose pathLight made the round trip through ACC
     }
     if (COUNT) {
         atomicAdd(&ctr->stat_nodes, (unsigned long long)st.nodes);
@@ -1008,14 +1018,15 @@ void launch_bounce(hipStream_t s, uint32_t blocks, bool lds_scene, bool count, b
 }
 // Whole paths in one launch (k_whole): LDS-resident scenes without media, one sample per pixel and frame.
 void launch_whole(hipStream_t s, uint32_t blocks, bool count, const DeviceScene& sc, const RenderParams& P, const PathState& ps, Counters* ctr, uint32_t n_slots,
-                  uint32_t dispatch_base, bool plain) {
+                  uint32_t dispatch_base, bool plain, uint32_t static_rounds, uint32_t chunk_tiles) {
     const size_t lds = traverse_lds_bytes(sc, true);
     const dim3 g(blocks), b(kTraverseBlock);
-    if (plain && !count && !sc.strict_hits && sc.env_black) hipLaunchKernelGGL((k_whole<false, false, true>), g, b, lds, s, sc, P, ps, ctr, n_slots, dispatch_base);
-    else if (sc.strict_hits) { if (count) hipLaunchKernelGGL((k_whole<true, true, false>), g, b, lds, s, sc, P, ps, ctr, n_slots, dispatch_base);
-                               else hipLaunchKernelGGL((k_whole<false, true, false>), g, b, lds, s, sc, P, ps, ctr, n_slots, dispatch_base); }
-    else if (count) hipLaunchKernelGGL((k_whole<true, false, false>), g, b, lds, s, sc, P, ps, ctr, n_slots, dispatch_base);
-    else hipLaunchKernelGGL((k_whole<false, false, false>), g, b, lds, s, sc, P, ps, ctr, n_slots, dispatch_base);
+#define VPT_LW(C, S, PL) hipLaunchKernelGGL((k_whole<C, S, PL>), g, b, lds, s, sc, P, ps, ctr, n_slots, dispatch_base, static_rounds, chunk_tiles)
+    if (plain && !count && !sc.strict_hits && sc.env_black) VPT_LW(false, false, true);
+    else if (sc.strict_hits) { if (count) VPT_LW(true, true, false); else VPT_LW(false, true, false); }
+    else if (count) VPT_LW(true, false, false);
+    else VPT_LW(false, false, false);
+#undef VPT_LW
 }
 int whole_blocks_per_cu(const DeviceScene& sc, bool plain) {
     int nb = 0;

@@ -92,7 +92,10 @@ struct vpt_ctx {
     uint32_t frames_alloc = 0;   // frames of SAMPLES the slot-addressed buffers hold now: they grow to the largest batch actually requested (ensure_path_buffers)
     uint32_t resident_alloc = 0; // frames of PATHS the queues and stream records hold (<= frames_alloc; less when paths are regenerated)
     int whole_blocks = 0;        // persistent grid of the whole-path kernel (kernels_path.hip k_whole), 0: the scene does not ride in LDS
-    uint32_t lab_whole_frames = 1u;   // VPT_PIPELINE_AUTO runs batches of at most this many frames as ONE whole-path launch (VPT_LAB_WHOLE_FRAMES)
+    uint32_t lab_whole_sched = 4u;   // how k_whole's waves get their tiles (VPT_LAB_WHOLE_SCHED): tiles per atomic | static-rounds mode << 4
+    uint32_t lab_whole_frames = 0xffffffffu;   // VPT_PIPELINE_AUTO runs batches of at most this many frames as ONE whole-path launch (VPT_LAB_WHOLE_FRAMES); default: every batch
+                                               // (Cornell box 1080p, Msamples/s whole vs per-bounce at 1 / 4 / 16 / 64 / 226 frames per batch: 3821 / 6413 / 7737 / 8183 / 8315 vs
+                                               // 2401 / 4753 / 6493 / 7244 / 7359; general instantiation 8840 vs 7713: profiles/r04_whole_ab.json)
     bool depth_bounded = true;   // every path ends within max_depth * samples_per_frame bounces (no material scatters inside a medium): see vpt_render_async
     // asynchronous batches (vpt_render_async / vpt_postprocess_device / vpt_wait)
     hipEvent_t tick_ev[kTickets] = {};
@@ -641,7 +644,7 @@ void collect_timing(vpt_ctx* c) {  // call after a stream sync
 // reads its queue size from device memory, so the host only looks at the counters every few bounces (render_batch) or not at all
 // until somebody waits (vpt_render_async).
 // One launch per batch (kernels_path.hip k_whole): the scene rides in LDS, no media, one sample per pixel and frame, every sample resident.
-// VPT_PIPELINE_WHOLE asks for it; AUTO takes it for short batches (lab_whole_frames), where the per-bounce launches do not fill the chip.
+// VPT_PIPELINE_WHOLE asks for it; AUTO takes it wherever it applies (lab_whole_frames bounds the batch size, for the A/B).
 bool whole_possible(const vpt_ctx* c) {
     const bool vol = !c->volumes.empty() || c->dsc.atm_on;
     return c->has_scene && c->lds_scene && c->whole_blocks > 0 && !vol && c->P.samples_per_frame == 1u;
@@ -716,8 +719,11 @@ int batch_begin(vpt_ctx* c, uint32_t frames, uint32_t dispatch_base, BatchState&
     if (n_slots == 0) return VPT_OK;
     HIPCHK(c, hipMemsetAsync(c->ctr, 0, offsetof(Counters, stat_closest), s));  // queue words only, stat_* keep running
     if (b.whole) {  // the batch's paths from camera ray to their end in one launch; no queue is written, alive3[] stays 0 for the resolve's guard
-        const uint32_t grid = std::min<uint32_t>((uint32_t)std::min(c->whole_blocks, c->primary_blocks), (n_slots + 255u) / 256u);   // (blocks of 256 lanes)
-        TIMED(c, VPT_K_PRIMARY, launch_whole(s, std::max(grid, 1u), b.count, c->dsc, c->P, c->ps, c->ctr, n_slots, dispatch_base, c->scene_plain));
+        const uint32_t grid = std::max(1u, std::min<uint32_t>((uint32_t)std::min(c->whole_blocks, c->primary_blocks), (n_slots + 255u) / 256u));   // (blocks of 256 lanes)
+        // tiles of 64 samples: `rounds` per wave; mode 0: the first round static, mode 1: all but the last, mode 2: half of them; the rest through the counter
+        const uint32_t n_waves = grid * 4u, rounds = ((n_slots + 63u) / 64u) / n_waves, mode = c->lab_whole_sched >> 4;
+        const uint32_t static_rounds = mode == 0u ? std::min(rounds, 1u) : mode == 1u ? (rounds >= 2u ? rounds - 1u : 0u) : rounds / 2u;
+        TIMED(c, VPT_K_PRIMARY, launch_whole(s, grid, b.count, c->dsc, c->P, c->ps, c->ctr, n_slots, dispatch_base, c->scene_plain, static_rounds, std::max(1u, c->lab_whole_sched & 15u)));
         b.parity = 1; b.k3 = 1; b.iter = 1;
     } else if (b.fused) {  // bounce 0 of every slot needs no input records; survivors land in queue[1]
         TIMED(c, VPT_K_PRIMARY, launch_bounce(s, (uint32_t)c->primary_blocks, c->lds_scene, b.count, true, c->dsc, c->P, c->ps, c->ss, nullptr, c->queue[1], c->ctr, 0u, b.n_first, dispatch_base, 0u, c->scene_plain));
@@ -1026,7 +1032,7 @@ void sync_lane(vpt_ctx* c, vpt_ctx* L) {
     L->dsc = c->dsc; L->dsc.stack_overflow = (uint32_t*)L->lane_spill;
     L->params = c->params;
     L->lds_scene = c->lds_scene; L->scene_plain = c->scene_plain; L->depth_bounded = c->depth_bounded; L->has_scene = true;
-    L->primary_blocks = c->primary_blocks; L->whole_blocks = c->whole_blocks; L->lab_whole_frames = c->lab_whole_frames;
+    L->primary_blocks = c->primary_blocks; L->whole_blocks = c->whole_blocks; L->lab_whole_frames = c->lab_whole_frames; L->lab_whole_sched = c->lab_whole_sched;
     L->image = c->image;
     L->state_gen = c->state_gen;   // the owner's generation invalidates the lane's captured batch too
 }
@@ -2087,13 +2093,14 @@ int vpt_multi_gather_shards(vpt_ctx* const* ctxs, uint32_t count, uint32_t root)
 }
 
 int vpt_lab_set(vpt_ctx* c, uint32_t key, uint32_t value) {
-    if (!c || (value > 3u && key != VPT_LAB_WHOLE_FRAMES)) return VPT_ERR_INVALID_ARGUMENT;
+    if (!c || (value > 3u && key != VPT_LAB_WHOLE_FRAMES && key != VPT_LAB_WHOLE_SCHED)) return VPT_ERR_INVALID_ARGUMENT;
     HIPCHK(c, hipSetDevice(c->cfg.device));
     { int rd = drain(c); if (rd) return rd; }
     if (key == VPT_LAB_LANES && value >= 1u) c->lab_lanes = value;
     else if (key == VPT_LAB_LANE_GRID && value >= 1u) c->lab_lane_grid = value;
     else if (key == VPT_LAB_TAIL_GRID && value >= 1u) c->lab_tail_grid = value;
-    else if (key == VPT_LAB_WHOLE_FRAMES) c->lab_whole_frames = value;
+    else if (key == VPT_LAB_WHOLE_SCHED && (value & 15u) >= 1u && (value >> 4) <= 2u) c->lab_whole_sched = value;
+    else if (key == VPT_LAB_WHOLE_FRAMES) c->lab_whole_frames = value == 0xffffu ? 0xffffffffu : value;   // (0xffff: no bound, the default)
     else return VPT_ERR_INVALID_ARGUMENT;
     c->state_gen++;   // captured batches hold the old grids
     return VPT_OK;
