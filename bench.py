@@ -23,9 +23,9 @@ VPT_BENCH_DEVICE pins every rank to one device, the 1-GPU-box test hook (the gat
 After the timed region the same workload runs a few more steps with profiling ON (HIP events the library records
 around every launch on its own stream) and with traversal counters, which feed
 
-  roofline     — for the kernel with the largest share of GPU time: `bound` says what limits it ("valu" for the fused
-                 Cornell kernels: 94-97 % VALU-busy in profiles/, their BVH rides in LDS; "hbm" only where the
-                 bytes really cross HBM).  `achieved` = bytes that MUST cross HBM per launch (path records, queue
+  roofline     — for the kernel with the largest share of GPU time (the headline's is the whole-path launch k_whole,
+                 timed under "primary"): `bound` says what limits it ("valu" for the Cornell kernels: VALU issue
+                 saturated in profiles/, their BVH rides in LDS; "hbm" only where the bytes really cross HBM).  `achieved` = bytes that MUST cross HBM per launch (path records, queue
                  words, frame sums) / mean launch duration, so frac <= 1 by construction; `traffic` = the PMC
                  measurement (profiles/traffic.json); `algorithmic_GBs` is SURVEY §8d's figure (records + scene
                  gathers + measured BVH visits), which on an LDS/L2-resident scene exceeds what HBM moves and is

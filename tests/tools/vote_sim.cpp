@@ -41,6 +41,8 @@ struct Policy {
     int node_extra, tri_extra;   // VALU a step costs more than the product's (stash bookkeeping)
     bool drain_first;   // a triangle step wins outright while some lane can do nothing else and holds a full stash
     int tri_per_step;   // triangles of ONE leaf a triangle step tests (1: the product)
+    int pool;           // ray slots per wave (64: a ray lives in a lane's registers, the product).  More: rays live in LDS slots and a step runs on
+                        // up to 64 of the slots that want it (lanes are workers, not owners)
 };
 
 struct Lane {
@@ -67,23 +69,31 @@ int main(int argc, char** argv) {
     printf("%s: %zu rays, %zu triangles, %zu nodes, depth %d\n", argv[3], nrays, leaf.size(), nodes.size(), depth);
     const int node_cost = any ? 133 : 155, tri_cost = any ? 91 : 97, fetch_cost = 148;
     const Policy policies[] = {
-        {"product (vote 2.0, fetch at 24)", 0, 8, 24, 0, 0, false, 1},
-        {"product, fetch at 8", 0, 8, 8, 0, 0, false, 1},
-        {"product, vote 1.0", 0, 4, 24, 0, 0, false, 1},
-        {"stash 1, vote 2.0", 1, 8, 24, 14, 8, false, 1},
-        {"stash 1, vote 1.0", 1, 4, 24, 14, 8, false, 1},
-        {"stash 1, vote 4.0", 1, 16, 24, 14, 8, false, 1},
-        {"stash 1, vote 2.0, drain first", 1, 8, 24, 14, 8, true, 1},
-        {"stash 2, vote 2.0", 2, 8, 24, 20, 12, false, 1},
-        {"stash 2, vote 4.0", 2, 16, 24, 20, 12, false, 1},
-        {"stash 4, vote 4.0", 4, 16, 24, 28, 16, false, 1},
-        {"stash 1, vote 2.0, fetch at 8", 1, 8, 8, 14, 8, false, 1},
-        {"product, 2 triangles per step", 0, 8, 24, 0, 70, false, 2},
+        {"product (vote 2.0, fetch at 24)", 0, 8, 24, 0, 0, false, 1, 64},
+        {"product, fetch at 8", 0, 8, 8, 0, 0, false, 1, 64},
+        {"product, vote 1.0", 0, 4, 24, 0, 0, false, 1, 64},
+        {"stash 1, vote 2.0", 1, 8, 24, 14, 8, false, 1, 64},
+        {"stash 1, vote 1.0", 1, 4, 24, 14, 8, false, 1, 64},
+        {"stash 1, vote 4.0", 1, 16, 24, 14, 8, false, 1, 64},
+        {"stash 1, vote 2.0, drain first", 1, 8, 24, 14, 8, true, 1, 64},
+        {"stash 2, vote 2.0", 2, 8, 24, 20, 12, false, 1, 64},
+        {"stash 2, vote 4.0", 2, 16, 24, 20, 12, false, 1, 64},
+        {"stash 4, vote 4.0", 4, 16, 24, 28, 16, false, 1, 64},
+        {"stash 1, vote 2.0, fetch at 8", 1, 8, 8, 14, 8, false, 1, 64},
+        {"product, 2 triangles per step", 0, 8, 24, 0, 70, false, 2, 64},
+        {"pool 80, fetch at 16", 0, 8, 16, 20, 20, false, 1, 80},
+        {"pool 96, fetch at 24", 0, 8, 24, 20, 20, false, 1, 96},
+        {"pool 96, fetch at 32", 0, 8, 32, 20, 20, false, 1, 96},
+        {"pool 128, fetch at 32", 0, 8, 32, 20, 20, false, 1, 128},
+        {"pool 128, fetch at 48", 0, 8, 48, 20, 20, false, 1, 128},
+        {"pool 128, vote 4.0, fetch at 48", 0, 16, 48, 20, 20, false, 1, 128},
+        {"pool 192, fetch at 64", 0, 8, 64, 20, 20, false, 1, 192},
     };
     std::vector<float> ref_t(nrays); std::vector<int> ref_g(nrays);
     for (size_t pi = 0; pi < sizeof(policies) / sizeof(policies[0]); pi++) {
         const Policy& P = policies[pi];
-        Lane L[64];
+        std::vector<Lane> L((size_t)P.pool);
+        const int pool = P.pool;
         size_t next = 0; bool exhausted = false;
         double n_node_steps = 0, n_tri_steps = 0, n_fetch_steps = 0, part_node = 0, part_tri = 0, visits = 0, tests = 0, idle_lane_steps = 0;
         size_t mismatches = 0;
@@ -103,7 +113,7 @@ int main(int argc, char** argv) {
                 nn += can_node; nl += can_tri; stuck += busy && !can_node;
             }
             int busy_lanes = 0; for (Lane& l : L) busy_lanes += l.cur < kDone;
-            const bool want_fetch = (!exhausted && 64 - busy_lanes >= P.fetch_at) || busy_lanes == 0;
+            const bool want_fetch = (!exhausted && pool - busy_lanes >= P.fetch_at) || busy_lanes == 0;
             if (want_fetch) {
                 if (exhausted) break;
                 n_fetch_steps++;
@@ -125,15 +135,18 @@ int main(int argc, char** argv) {
                 if (next >= nrays) exhausted = true;
                 continue;
             }
-            bool node_wins = 4 * nn > P.w4 * nl;
+            bool node_wins = 4 * std::min(nn, 64) > P.w4 * std::min(nl, 64);   // (a step serves 64 slots at most)
+            if (pool > 64) node_wins = (nn >= 64 && nl < 64) ? true : (nl >= 64 && nn < 64) ? false : 4 * nn > P.w4 * nl;
             if (P.drain_first && stuck > 0 && nl > 0) { bool full = false; for (Lane& l : L) full |= (l.cur < 0 && l.ns == P.stash); if (full && nn < 48) node_wins = false; }
             if (nl == 0) node_wins = true;
             if (nn == 0) node_wins = false;
-            idle_lane_steps += 64 - busy_lanes;
+            idle_lane_steps += pool - busy_lanes;
             if (node_wins) {
-                n_node_steps++; part_node += nn;
+                n_node_steps++; part_node += std::min(nn, 64);
+                int served = 0;
                 for (Lane& l : L) {
                     if (!(l.cur < kDone && l.cur >= 0)) continue;
+                    if (++served > 64) break;
                     visits++;
                     float t[4]; entries(nodes[l.cur], l.s, l.tmin, l.best, t);
                     int c[4] = {nodes[l.cur].child[0], nodes[l.cur].child[1], nodes[l.cur].child[2], nodes[l.cur].child[3]};
@@ -149,9 +162,11 @@ int main(int argc, char** argv) {
                     set_aside(l);
                 }
             } else {
-                n_tri_steps++; part_tri += nl;
+                n_tri_steps++; part_tri += std::min(nl, 64);
+                int served = 0;
                 for (Lane& l : L) {
                     if (!(l.cur < kDone && (l.cur < 0 || l.ns > 0))) continue;
+                    if (++served > 64) break;
                     const bool own = l.cur < 0;
                     int code = own ? l.cur : l.stash[l.ns - 1];
                     bool stop = false;
@@ -172,7 +187,7 @@ int main(int argc, char** argv) {
         }
         for (Lane& l : L) if (l.cur == kDone) { if (pi == 0) { ref_t[l.rid] = l.found ? l.best : -1.0f; ref_g[l.rid] = l.bgid; } else if ((l.found ? l.best : -1.0f) != ref_t[l.rid] || (!any && l.bgid != ref_g[l.rid])) mismatches++; }
         const double cost = n_node_steps * (node_cost + P.node_extra) + n_tri_steps * (tri_cost + P.tri_extra) + n_fetch_steps * fetch_cost;
-        const double lane_instr = part_node * (node_cost + P.node_extra) + part_tri * (tri_cost + P.tri_extra) + n_fetch_steps * fetch_cost * 24.0;
+        const double lane_instr = part_node * (node_cost + P.node_extra) + part_tri * (tri_cost + P.tri_extra) + n_fetch_steps * fetch_cost * (double)P.fetch_at;
         printf("%-36s VALU/ray %7.1f | node steps/ray %6.3f (%4.1f lanes) tri %6.3f (%4.1f lanes) fetch %5.3f | visits/ray %6.2f tests %5.2f | lane use %4.1f %% | idle lanes %4.1f | mismatches %zu\n", P.name,
                cost / nrays, n_node_steps / nrays, part_node / std::max(1.0, n_node_steps), n_tri_steps / nrays, part_tri / std::max(1.0, n_tri_steps), n_fetch_steps / nrays,
                visits / nrays, tests / nrays, 100.0 * lane_instr / (64.0 * cost), idle_lane_steps / std::max(1.0, n_node_steps + n_tri_steps), mismatches);
