@@ -419,7 +419,10 @@ def roofline_for(name, prof):
             "algorithmic_bytes_per_launch": round(k["algorithmic_bytes_per_unit"] * k["units_per_launch"], 0),
             "algorithmic_GBs": k["algorithmic_GBs"], "algorithmic_frac_of_hbm_peak": k["algorithmic_frac_of_hbm_peak"],
             "note": "achieved = path records / queue words / frame sums (must cross HBM) per launch / mean launch time; algorithmic_* adds scene gathers and measured "
-                    "BVH visits by SURVEY 8d's formula, which LDS / L1 / L2 serve on a resident scene; traffic and valu_busy are rocprofv3 PMC passes (profiles/)",
+                    "BVH visits by SURVEY 8d's formula, which LDS / L1 / L2 serve on a resident scene; traffic and valu_busy are rocprofv3 PMC passes (profiles/)"
+                    + ("; this kernel (k_whole: a batch as ONE launch of persistent waves) keeps a path in registers from bounce to bounce, so the bytes that must cross HBM are the "
+                       "16 B frame sum per sample plus 32 B per parked later hit — 109 -> ~32 B per sample against round 3's per-bounce kernels: `frac` FELL because the kernel "
+                       "moves less, while Msamples/s rose 13-17 %; the roof that binds it is VALU issue (`valu`)" if prof.get("pipeline", "").startswith("whole") else ""),
             "traversal": prof["traversal"], "kernels": kernels}
 
 

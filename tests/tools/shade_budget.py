@@ -5,7 +5,8 @@
 2. Compiles one tiny kernel per contract / shading function and counts its instructions: what one call costs.
 
     python tests/tools/shade_budget.py [--json out.json]
-    python tests/tools/shade_budget.py --fused        # the same breakdown for the fused kernels of the headline workload (kernels_path.hip)
+    python tests/tools/shade_budget.py --fused        # the same breakdown for the fused per-bounce kernels (kernels_path.hip)
+    python tests/tools/shade_budget.py --whole        # ... and for the whole-path launch k_whole
 """
 import collections, importlib, json, os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -110,6 +111,15 @@ if __name__ == "__main__":
             print("%s: %d VALU, %d SALU, %d memory instructions (static)\n" % (label, total["valu"], total["salu"], total["mem"]))
             print("| source function (innermost inlined) | VALU instructions | share |\n|---|---|---|")
             for (f, n), c in by_fn.most_common(16):
+                print("| `%s` (%s) | %d | %.1f %% |" % (n, f, c, 100.0 * c / total["valu"]))
+            print()
+        sys.exit(0)
+    if "--whole" in sys.argv:   # the whole-path launch (round 4): scene-class and general instantiation
+        for label, sym in (("k_whole<PLAIN>", "_ZN3vpt7k_wholeILb0ELb0ELb1EEE"), ("k_whole<general>", "_ZN3vpt7k_wholeILb0ELb0ELb0EEE")):
+            total, by_fn = shade_kernel_by_function("kernels_path.hip", sym)
+            print("%s: %d VALU, %d SALU, %d memory instructions (static)\n" % (label, total["valu"], total["salu"], total["mem"]))
+            print("| source function (innermost inlined) | VALU instructions | share |\n|---|---|---|")
+            for (f, n), c in by_fn.most_common(24):
                 print("| `%s` (%s) | %d | %.1f %% |" % (n, f, c, 100.0 * c / total["valu"]))
             print()
         sys.exit(0)

@@ -604,9 +604,10 @@ __global__ __launch_bounds__(kTraverseBlock, 3) void k_whole(DeviceScene sc, Ren
                 in_.h = make_float4(r_t[wave][q], r_u[wave][q], r_v[wave][q], __uint_as_float(r_prim[wave][q]));
                 in_.inst = r_inst[wave][q];
                 first = in_.depth == 0u;   // (only a camera ray has depth 0: the in-medium walk that leaves the depth alone starts behind a refraction)
-                const V3 light_prev = first ? v3s(0.0f) : xyz(ps.ACC[slot]);
                 ShadeOut o;
                 shade_core<false, (int)kShadeTextured>(sc, P, ps, slot, in_, o);   // "all of these hit something"
+                // pathLight so far: fetched behind the shader (three registers less across its peak), in flight during the shadow queries
+                const V3 light_prev = first ? v3s(0.0f) : xyz(ps.ACC[slot]);
                 // connect, inline (RayGen.slang:92-102)
                 V3 E = o.emitted;
                 if (o.want_sky) {
