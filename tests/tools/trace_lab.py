@@ -23,7 +23,7 @@ sys.path.insert(0, ROOT)
 vpt = importlib.import_module("vulkan-path-tracer_amd")
 
 W, H = 1920, 1080
-BASE, VOTE, VOTE8 = 0, 1, 2
+BASE, VOTE, VOTE8, POOL = 0, 1, 2, 3
 
 
 def world_triangles(sc):
@@ -170,6 +170,11 @@ def main():
                 if any_hit:
                     continue
                 plan = [(VOTE, 256 + 16), (VOTE, (256 + 16) | (1 << 17)), (VOTE, 256 + 16), (VOTE, (256 + 16) | (1 << 17))]
+            if os.environ.get("LAB_POOL") == "1":   # ray slots in LDS (k_trace_pool, closest hit) against the product instantiation: param = idle slots that trigger a fetch | 256 for 96 slots per wave
+                if any_hit:
+                    continue
+                plan = [(VOTE, 256 + 16), (POOL, 40), (POOL, 24), (POOL, 56), (POOL, 256 | 30), (POOL, 256 | 18), (VOTE, 256 + 16), (POOL, 40)]
+                cull_mode = True   # (visit counts for every row)
             for variant, param in plan:
                 first = ref is None or (variant in (VOTE, VOTE8) and param == 16) or cull_mode
                 ms, hits, vis = lab_trace(g, variant, any_hit, order, param, 5, True, first)
@@ -177,7 +182,7 @@ def main():
                     ref = hits
                 same = bool(np.array_equal(hits["t"], ref["t"]) and np.array_equal(hits["u"], ref["u"]) and np.array_equal(hits["v"], ref["v"]) and
                             np.array_equal(hits["primitive"], ref["primitive"]) and np.array_equal(hits["instance"], ref["instance"]))
-                r = {"scene": which, "set": name, "rays": len(rays), "any_hit": any_hit, "order": oname, "variant": ["base", "vote", "vote_bvh8"][variant], "param": param,
+                r = {"scene": which, "set": name, "rays": len(rays), "any_hit": any_hit, "order": oname, "variant": ["base", "vote", "vote_bvh8", "pool"][variant], "param": param,
                      "ms": round(ms, 4), "grays_per_s": round(len(rays) / ms / 1e6, 3), "equal_to_reference": same,
                      "hit_fraction": round(float((ref["t"] > 0).mean()), 4)}
                 if vis:

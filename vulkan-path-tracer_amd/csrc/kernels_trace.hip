@@ -220,6 +220,173 @@ __global__ __launch_bounds__(kTraverseBlock, 8) void k_trace_vote(DeviceScene sc
     }
 }
 
+// ------------------------------------------------------------------ ray slots in LDS (trace lab variant VPT_TRACE_POOL, closest hit)
+// In k_trace_vote a ray lives in a lane's registers, so a step of one kind runs on the lanes whose OWN ray wants it: 42 of 64 lanes in
+// a node step, 21 in a triangle step (profiles/r04_vote_sim_*.txt; the counters say the same).  Here a wave owns kPoolSlots ray slots in LDS —
+// ray, best hit, traversal state and stack of every ray — and a step runs on up to 64 of the slots that want it, whichever they are:
+// lanes are workers, not owners.  The host model puts that at -31 % VALU wave-instructions per ray at 128 slots (+ 20 per step for the
+// selection and the state traffic).  What it costs on the device: 13 KB of LDS per wave, i.e. 3 waves per SIMD instead of 8 behind
+// every 64-byte node fetch, and the same number of L1 accesses per ray as before.  Results are per ray: bit-identical hits by the lab's check.
+constexpr int kPoolStack = 10;    // stack entries per slot in LDS (the rest in the slot's global spill region)
+constexpr int kPoolRows = 16;     // state dwords per slot: o 0-2, d 3-5, 1/d 6-8, best_t 9, u 10, v 11, best slot 12, cur 13, sp 14, ray id 15
+// SLOTS per wave: 128 (13.3 KB of LDS per wave: 3 waves per SIMD) or 96 (10 KB: 4 waves per SIMD)
+constexpr size_t pool_wave_bytes(int slots) { return (size_t)(kPoolRows + kPoolStack) * slots * 4 + 64 * 4; }   // + the step's slot list
+constexpr size_t pool_lds_bytes(int slots) { return pool_wave_bytes(slots) * (kTraverseBlock / 64); }
+template <int kPoolSlots>
+struct PoolStack {
+    uint32_t* stk;  // LDS: entry k of this slot at stk[k * kPoolSlots]
+    uint32_t* ovf;  // global: entries beyond kPoolStack
+    __device__ __forceinline__ void push(int& sp, int v) const {
+        if (sp < kPoolStack) stk[sp * kPoolSlots] = (uint32_t)v;
+        else if (sp < kPoolStack + kStackOverflow) ovf[sp - kPoolStack] = (uint32_t)v;
+        sp++;
+    }
+    __device__ __forceinline__ void pop_or_done(int& sp, int& cur) const {
+        if (sp == 0) cur = kLaneDone;
+        else {
+            sp--;
+            int v = (int)stk[(sp < kPoolStack ? sp : kPoolStack - 1) * kPoolSlots];
+            asm volatile("" : "+v"(v));   // (vote.hpp LaneStack::pop_or_done)
+            if (sp >= kPoolStack) v = (int)ovf[sp - kPoolStack];
+            cur = v;
+        }
+    }
+    // (vote_node_step names these in its CULL branches, which this stack is never instantiated with)
+    __device__ __forceinline__ void push_t(int& sp, int v, float) const { push(sp, v); }
+    __device__ __forceinline__ void pop_or_done_cull(int& sp, int& cur, float) const { pop_or_done(sp, cur); }
+};
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+template <bool COUNT, int kPoolSlots>
+__global__ __launch_bounds__(kTraverseBlock, 3) void k_trace_pool(DeviceScene sc, TraceArgs a, Counters* ctr) {
+    constexpr size_t kPoolWaveBytes = pool_wave_bytes(kPoolSlots);
+    constexpr uint32_t kHalf2 = (uint32_t)kPoolSlots - 64u;   // slots of the second half (lanes below this own two slots)
+    extern __shared__ __align__(16) unsigned char smem[];
+    const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
+    uint32_t* const W = reinterpret_cast<uint32_t*>(smem + wave * kPoolWaveBytes);
+    float* const F = reinterpret_cast<float*>(W);
+    uint32_t* const stack0 = W + kPoolRows * kPoolSlots;
+    uint32_t* const list = stack0 + kPoolStack * kPoolSlots;
+    const uint32_t gw = __builtin_amdgcn_readfirstlane(blockIdx.x * (kTraverseBlock / 64u) + wave);
+    uint32_t* const spill = sc.stack_overflow + (size_t)gw * kPoolSlots * kStackOverflow;
+#define ST(row, slot) W[(row) * kPoolSlots + (slot)]
+#define SF(row, slot) F[(row) * kPoolSlots + (slot)]
+    const BvhNode* const nodes = sc.nodes;
+    const BvhTri* const tris = sc.tris;
+    TreeTop top; top.lds = nullptr; top.count = 0;
+    const uint32_t n = a.n_dev ? *a.n_dev : a.n;
+    const uint32_t chunk = fetch_chunk(n);
+    const uint32_t fetch_at = (a.param & 0xffu) ? (a.param & 0xffu) : 40u;            // idle SLOTS that trigger a fetch step
+    const uint32_t w4 = ((a.param >> 12) & 15u) ? ((a.param >> 12) & 15u) : kVoteWeight4;
+    const uint32_t n_static = gridDim.x * (kTraverseBlock / 64u) * (uint32_t)kPoolSlots;   // every wave starts on its own kPoolSlots entries, no atomic
+    uint32_t w_next = gw * (uint32_t)kPoolSlots, w_end = w_next + (uint32_t)kPoolSlots < n ? w_next + (uint32_t)kPoolSlots : n;
+    if (w_next >= n) { w_next = 0u; w_end = 0u; }
+    bool exhausted = false;
+    uint32_t st_nodes = 0u, st_tris = 0u;
+    const bool two = lane < kHalf2;   // this lane looks after slot lane + 64 as well
+    ST(13, lane) = (uint32_t)kLaneIdle; if (two) ST(13, lane + 64u) = (uint32_t)kLaneIdle;
+    wave_lds_sync();
+    while (true) {
+        // ---- vote over the pool: every lane looks at two slots
+        const int c0 = (int)ST(13, lane), c1 = two ? (int)ST(13, lane + 64u) : kLaneIdle;
+        const bool n0 = c0 >= 0 && c0 < kLaneDone, n1 = c1 >= 0 && c1 < kLaneDone, l0 = c0 < 0, l1 = c1 < 0;
+        const unsigned long long bn0 = __ballot(n0), bn1 = __ballot(n1), bl0 = __ballot(l0), bl1 = __ballot(l1);
+        const uint32_t nn = (uint32_t)(__popcll(bn0) + __popcll(bn1)), nl = (uint32_t)(__popcll(bl0) + __popcll(bl1));
+        if ((!exhausted && (uint32_t)kPoolSlots - nn - nl >= fetch_at) || nn + nl == 0u) {
+            // ---- fetch step: retire finished slots, deal new rays to the idle ones (two passes of 64 slots)
+#pragma unroll 1
+            for (uint32_t h = 0u; h < 2u; h++) {
+                const uint32_t s = lane + 64u * h;
+                const bool mine = h == 0u || two;
+                int c = mine ? (int)ST(13, s) : kLaneDone - 1;   // (a slot that does not exist is neither done nor idle)
+                if (c == kLaneDone) {
+                    const uint32_t bslot = ST(12, s);
+                    (void)store_closest(a, tris, ST(15, s), bslot != 0xffffffffu, SF(9, s), SF(10, s), SF(11, s), bslot);
+                    c = kLaneIdle; ST(13, s) = (uint32_t)kLaneIdle;
+                }
+                if (exhausted) continue;
+                if (w_next >= w_end) {
+                    if (n_static >= n) exhausted = true;
+                    else {
+                        uint32_t base = 0u;
+                        if (lane == 0u) base = atomicAdd(a.head, chunk);
+                        base = n_static + __builtin_amdgcn_readfirstlane(base);
+                        if (base >= n) exhausted = true;
+                        else { w_next = base; w_end = base + chunk < n ? base + chunk : n; }
+                    }
+                }
+                if (exhausted) continue;
+                const unsigned long long m_idle = __ballot(c == kLaneIdle);
+                const uint32_t i = w_next + lanes_below(m_idle);
+                if (c == kLaneIdle && i < w_end) {
+                    const uint32_t rid = a.order ? a.order[i] : i;
+                    V3 o = xyz4(ld_stream(&a.ro[rid])), d = xyz4(ld_stream(&a.rd[rid]));
+                    if (a.normalize_dir) d = vptfp::normalize(d);
+                    const V3 inv = safe_inverse(d);
+                    SF(0, s) = o.x; SF(1, s) = o.y; SF(2, s) = o.z; SF(3, s) = d.x; SF(4, s) = d.y; SF(5, s) = d.z; SF(6, s) = inv.x; SF(7, s) = inv.y; SF(8, s) = inv.z;
+                    SF(9, s) = a.tmax; ST(12, s) = 0xffffffffu; ST(13, s) = 0u; ST(14, s) = 0u; ST(15, s) = rid;
+                }
+                const uint32_t want = (uint32_t)__popcll(m_idle), left = w_end - w_next;
+                w_next += want < left ? want : left;
+            }
+            wave_lds_sync();
+            if (exhausted) {   // nothing came in: done when no slot is busy
+                const int d0 = (int)ST(13, lane), d1 = two ? (int)ST(13, lane + 64u) : kLaneIdle;
+                if (__ballot(d0 < kLaneDone) == 0ull && __ballot(d1 < kLaneDone) == 0ull) break;
+            }
+            continue;
+        }
+        // ---- which kind of step, and the (up to) 64 slots that take it
+        const bool node_wins = (nn >= 64u && nl < 64u) ? true : (nl >= 64u && nn < 64u) ? false : 4u * nn > w4 * nl;
+        const unsigned long long m0 = node_wins ? bn0 : bl0, m1 = node_wins ? bn1 : bl1;
+        const bool w0 = node_wins ? n0 : l0, w1 = node_wins ? n1 : l1;
+        const uint32_t r0 = lanes_below(m0), r1 = (uint32_t)__popcll(m0) + lanes_below(m1);
+        if (w0 && r0 < 64u) list[r0] = lane;
+        if (w1 && r1 < 64u) list[r1] = lane + 64u;
+        wave_lds_sync();
+        const uint32_t total = (uint32_t)(__popcll(m0) + __popcll(m1)), cnt = total < 64u ? total : 64u;
+        if (lane < cnt) {
+            const uint32_t s = list[lane];
+            int cur = (int)ST(13, s), sp = (int)ST(14, s);
+            PoolStack<kPoolSlots> S; S.stk = stack0 + s; S.ovf = spill + (size_t)s * kStackOverflow;
+            const V3 o = vptfp::v3(SF(0, s), SF(1, s), SF(2, s));
+            float best_t = SF(9, s);
+            if (node_wins) {
+                if (COUNT) st_nodes++;
+                const V3 inv = vptfp::v3(SF(6, s), SF(7, s), SF(8, s));
+                vote_node_step<false, false, false, PoolStack<kPoolSlots>>(nodes, top, S, cur, sp, o, inv, a.tmin, best_t);
+            } else {   // ONE triangle of the slot's leaf (vote.hpp vote_tri_step_closest; the best triangle's global id is read only on a tie in t)
+                if (COUNT) st_tris++;
+                const V3 d = vptfp::v3(SF(3, s), SF(4, s), SF(5, s));
+                const uint32_t enc = (uint32_t)(~cur);
+                const int first = (int)(enc >> 3);
+                const uint32_t more = enc & 7u;
+                const float4* q = reinterpret_cast<const float4*>(tris + first);
+                const float4 ta = q[0], tb = q[1], tc = q[2];
+                float t, u, v;
+                const bool hit = ray_triangle_flat(o, d, vptfp::v3(ta.x, ta.y, ta.z), vptfp::v3(ta.w, tb.x, tb.y), vptfp::v3(tb.z, tb.w, tc.x), a.tmin, a.tmax, t, u, v);
+                const uint32_t bslot = ST(12, s);
+                bool better = hit & ((bslot == 0xffffffffu) | (t < best_t));
+                if (hit & (bslot != 0xffffffffu) & (t == best_t)) better = __float_as_uint(tc.w) < tris[bslot].gid;   // ties in t go to the smaller global id
+                if (better) { SF(9, s) = t; SF(10, s) = u; SF(11, s) = v; ST(12, s) = (uint32_t)first; }
+                if (more) cur = ~(int)((((uint32_t)first + 1u) << 3) | (more - 1u));
+                else S.pop_or_done(sp, cur);
+            }
+            ST(13, s) = (uint32_t)cur; ST(14, s) = (uint32_t)sp;
+        }
+        wave_lds_sync();
+    }
+#undef ST
+#undef SF
+    if (COUNT) {
+        atomicAdd(&ctr->stat_nodes, (unsigned long long)st_nodes);
+        atomicAdd(&ctr->stat_tris, (unsigned long long)st_tris);
+    }
+}
+
 // ------------------------------------------------------------------ shadow rays
 // LIGHT = false: visible <=> nothing is hit (ClosestHit.slang:139, 344-353).  LIGHT = true: visible <=> the closest hit is
 // the sampled triangle (ClosestHit.slang:171-176, 358-370): that triangle is tested first by its own record, then the search
@@ -330,6 +497,10 @@ __global__ __launch_bounds__(kTraverseBlock, 8) void k_trace_shadow(DeviceScene 
 // ------------------------------------------------------------------ launch
 int trace_blocks_per_cu(uint32_t variant, bool any) {
     int nb = 0;
+    if (variant == VPT_TRACE_POOL) {   // (the 128-slot form; the launch asks again for the 96-slot one)
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_pool<false, 128>, kTraverseBlock, pool_lds_bytes(128));
+        return nb > 0 ? nb : 1;
+    }
     const size_t lds = variant == VPT_TRACE_BASE ? kVoteStackBytes : kVoteLdsBytes;
     if (variant == VPT_TRACE_BASE) {
         if (any) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_base<true, false>, kTraverseBlock, lds);
@@ -345,6 +516,17 @@ int trace_blocks_per_cu(uint32_t variant, bool any) {
 }
 
 void launch_trace(hipStream_t s, uint32_t blocks, uint32_t variant, bool any, bool count, const DeviceScene& sc, const TraceArgs& a, Counters* ctr) {
+    if (variant == VPT_TRACE_POOL) {   // closest hit only (the lab refuses the any-hit form); param bit 8: 96 slots per wave instead of 128, on a third more blocks
+        if ((a.param >> 8) & 1u) {
+            const uint32_t b96 = blocks + blocks / 3u;
+            if (count) hipLaunchKernelGGL((k_trace_pool<true, 96>), dim3(b96), dim3(kTraverseBlock), pool_lds_bytes(96), s, sc, a, ctr);
+            else hipLaunchKernelGGL((k_trace_pool<false, 96>), dim3(b96), dim3(kTraverseBlock), pool_lds_bytes(96), s, sc, a, ctr);
+        } else {
+            if (count) hipLaunchKernelGGL((k_trace_pool<true, 128>), dim3(blocks), dim3(kTraverseBlock), pool_lds_bytes(128), s, sc, a, ctr);
+            else hipLaunchKernelGGL((k_trace_pool<false, 128>), dim3(blocks), dim3(kTraverseBlock), pool_lds_bytes(128), s, sc, a, ctr);
+        }
+        return;
+    }
     const size_t lds = variant == VPT_TRACE_BASE ? kVoteStackBytes : kVoteLdsBytes;
     const dim3 g(blocks), b(kTraverseBlock);
 #define VPT_LT(K) do { if (any) { if (count) hipLaunchKernelGGL((K<true, true>), g, b, lds, s, sc, a, ctr); else hipLaunchKernelGGL((K<true, false>), g, b, lds, s, sc, a, ctr); } \

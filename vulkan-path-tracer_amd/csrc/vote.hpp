@@ -106,8 +106,8 @@ __device__ __forceinline__ TreeTop stage_tree_top(unsigned char* smem, const Bvh
 // USE_TOP: only the any-hit kernels use the LDS tree top.  Measured (atrium / glass bust, bench kernel means): shadow stage 4.46 -> 3.94 ms
 // and 0.318 -> 0.311 ms with it — those kernels are L1-bound with VALU issue to spare (VALUBusy 82-85 %); the closest-hit extend kernel,
 // VALU-saturated, pays for the six instructions of the address select: 6.37 -> 6.71 ms and 1.12 -> 1.19 ms, so it keeps the plain load.
-template <bool ANY, bool USE_TOP = ANY, bool CULL = false>
-__device__ __forceinline__ void vote_node_step(const BvhNode* nodes, const TreeTop& top, const LaneStack& S, int& cur, int& sp, V3 o, V3 inv, float tmin, float tlimit) {
+template <bool ANY, bool USE_TOP = ANY, bool CULL = false, class STK = LaneStack>
+__device__ __forceinline__ void vote_node_step(const BvhNode* nodes, const TreeTop& top, const STK& S, int& cur, int& sp, V3 o, V3 inv, float tmin, float tlimit) {
     const uint4* p = (USE_TOP && cur < top.count) ? top.lds + cur * 4 : reinterpret_cast<const uint4*>(nodes + cur);
     NodeData n;
     unpack_node(p[0], p[1], p[2], p[3], n);
