@@ -476,8 +476,10 @@ int vpt_trace_rays(vpt_ctx* ctx, const vpt_ray* rays_host, uint32_t n, vpt_hit* 
 #define VPT_TRACE_BASE 0u  /* one ray per lane, 64 rays per wave at a time (round 1's extend / shadow loop) */
 #define VPT_TRACE_VOTE 1u  /* persistent lanes, wave-level vote between node / triangle / fetch steps, ray replacement */
 #define VPT_TRACE_VOTE8 2u /* the same on an eight-wide tree with octant-ordered children (BVH8 experiment; built on first use) */
-#define VPT_TRACE_POOL 3u  /* closest hit only: a wave owns 128 ray slots in LDS and every step runs on up to 64 of the slots that want it (lanes are
-                            * workers, not owners of a ray; kernels_trace.hip k_trace_pool).  param: low byte = idle slots that trigger a fetch (0: 40) */
+#define VPT_TRACE_POOL 3u  /* closest hit only: a wave owns 64-128 ray slots in LDS and every step runs on up to 64 of the slots that want it (lanes are
+                            * workers, not owners of a ray; kernels_trace.hip k_trace_pool).  param: low byte = idle slots that trigger a fetch (0: 5/16 of the pool); bits 8-9 = slots per wave /
+                            * LDS stack entries 128/10, 96/10, 80/8, 64/8 (3-6 blocks per CU); bit 10 = a node step and a triangle step per iteration, loads
+                            * of both in flight together; bits 16-21 = slots at leaves that make such an iteration carry the triangle step (0: 32) */
 int vpt_lab_set_rays(vpt_ctx* ctx, const vpt_ray* rays_host, uint32_t n);
 /* Measurement hook on the scheduling of pipelined 1-frame batches (vpt_render_async; tests/tools/latency_probe.py): images never depend on it.
  *   VPT_LAB_LANES       lanes consecutive frames are dealt to (1-3; default 3: a frame takes the first lane whose previous frame is resolved)

@@ -170,10 +170,11 @@ def main():
                 if any_hit:
                     continue
                 plan = [(VOTE, 256 + 16), (VOTE, (256 + 16) | (1 << 17)), (VOTE, 256 + 16), (VOTE, (256 + 16) | (1 << 17))]
-            if os.environ.get("LAB_POOL") == "1":   # ray slots in LDS (k_trace_pool, closest hit) against the product instantiation: param = idle slots that trigger a fetch | 256 for 96 slots per wave
+            if os.environ.get("LAB_POOL") == "1":   # ray slots in LDS (k_trace_pool, closest hit) against the product instantiation: param bits as in include/vpt.h VPT_TRACE_POOL
                 if any_hit:
                     continue
-                plan = [(VOTE, 256 + 16), (POOL, 40), (POOL, 24), (POOL, 56), (POOL, 256 | 30), (POOL, 256 | 18), (VOTE, 256 + 16), (POOL, 40)]
+                PP = lambda cfg, dual=0, fetch=0, tri_at=0: (cfg << 8) | (dual << 10) | fetch | (tri_at << 16)   # cfg 0..3 = 128/10, 96/10, 80/8, 64/8 slots / LDS stack entries
+                plan = [(VOTE, 256 + 16)] + [(POOL, PP(cfg, dual)) for cfg in (0, 1, 2, 3) for dual in (0, 1)] + [(POOL, PP(1, 1, 0, 16)), (POOL, PP(1, 1, 0, 48)), (POOL, PP(2, 1, 0, 16)), (POOL, PP(2, 1, 16)), (POOL, PP(2, 1, 36)), (VOTE, 256 + 16)]
                 cull_mode = True   # (visit counts for every row)
             for variant, param in plan:
                 first = ref is None or (variant in (VOTE, VOTE8) and param == 16) or cull_mode

@@ -222,67 +222,83 @@ __global__ __launch_bounds__(kTraverseBlock, 8) void k_trace_vote(DeviceScene sc
 
 // ------------------------------------------------------------------ ray slots in LDS (trace lab variant VPT_TRACE_POOL, closest hit)
 // In k_trace_vote a ray lives in a lane's registers, so a step of one kind runs on the lanes whose OWN ray wants it: 42 of 64 lanes in
-// a node step, 21 in a triangle step (profiles/r04_vote_sim_*.txt; the counters say the same).  Here a wave owns kPoolSlots ray slots in LDS —
+// a node step, 21 in a triangle step (profiles/r04_vote_sim_*.txt; the counters say the same).  Here a wave owns SLOTS ray slots in LDS —
 // ray, best hit, traversal state and stack of every ray — and a step runs on up to 64 of the slots that want it, whichever they are:
-// lanes are workers, not owners.  The host model puts that at -31 % VALU wave-instructions per ray at 128 slots (+ 20 per step for the
-// selection and the state traffic).  What it costs on the device: 13 KB of LDS per wave, i.e. 3 waves per SIMD instead of 8 behind
-// every 64-byte node fetch, and the same number of L1 accesses per ray as before.  Results are per ray: bit-identical hits by the lab's check.
-constexpr int kPoolStack = 10;    // stack entries per slot in LDS (the rest in the slot's global spill region)
+// lanes are workers, not owners.  The host model puts that at -21 / -31 % VALU wave-instructions per ray at 96 / 128 slots (+ 20 per step
+// for the selection and the state traffic).  What it costs on the device: 10-13 KB of LDS per wave, i.e. 4 or 3 waves per SIMD instead of
+// 8 behind every 64-byte node fetch, and the same number of L1 accesses per ray as before.  DUAL: an iteration runs a node step AND (when
+// enough slots wait at leaves) a triangle step on disjoint slots, with the loads of both in flight together.
+// Results are per ray: bit-identical hits by the lab's check.
 constexpr int kPoolRows = 16;     // state dwords per slot: o 0-2, d 3-5, 1/d 6-8, best_t 9, u 10, v 11, best slot 12, cur 13, sp 14, ray id 15
-// SLOTS per wave: 128 (13.3 KB of LDS per wave: 3 waves per SIMD) or 96 (10 KB: 4 waves per SIMD)
-constexpr size_t pool_wave_bytes(int slots) { return (size_t)(kPoolRows + kPoolStack) * slots * 4 + 64 * 4; }   // + the step's slot list
-constexpr size_t pool_lds_bytes(int slots) { return pool_wave_bytes(slots) * (kTraverseBlock / 64); }
-template <int kPoolSlots>
+constexpr size_t pool_wave_bytes(int slots, int stack) { return (size_t)(kPoolRows + stack) * slots * 4 + 128; }   // + the step's two slot lists (one byte per entry)
+constexpr size_t pool_lds_bytes(int slots, int stack) { return pool_wave_bytes(slots, stack) * (kTraverseBlock / 64); }
+template <int SLOTS, int STACK>
 struct PoolStack {
-    uint32_t* stk;  // LDS: entry k of this slot at stk[k * kPoolSlots]
-    uint32_t* ovf;  // global: entries beyond kPoolStack
+    uint32_t* stk;  // LDS: entry k of this slot at stk[k * SLOTS]
+    uint32_t* ovf;  // global: entries beyond STACK
     __device__ __forceinline__ void push(int& sp, int v) const {
-        if (sp < kPoolStack) stk[sp * kPoolSlots] = (uint32_t)v;
-        else if (sp < kPoolStack + kStackOverflow) ovf[sp - kPoolStack] = (uint32_t)v;
+        if (sp < STACK) stk[sp * SLOTS] = (uint32_t)v;
+        else if (sp < STACK + kStackOverflow) ovf[sp - STACK] = (uint32_t)v;
         sp++;
     }
     __device__ __forceinline__ void pop_or_done(int& sp, int& cur) const {
         if (sp == 0) cur = kLaneDone;
         else {
             sp--;
-            int v = (int)stk[(sp < kPoolStack ? sp : kPoolStack - 1) * kPoolSlots];
+            int v = (int)stk[(sp < STACK ? sp : STACK - 1) * SLOTS];
             asm volatile("" : "+v"(v));   // (vote.hpp LaneStack::pop_or_done)
-            if (sp >= kPoolStack) v = (int)ovf[sp - kPoolStack];
+            if (sp >= STACK) v = (int)ovf[sp - STACK];
             cur = v;
         }
     }
-    // (vote_node_step names these in its CULL branches, which this stack is never instantiated with)
-    __device__ __forceinline__ void push_t(int& sp, int v, float) const { push(sp, v); }
-    __device__ __forceinline__ void pop_or_done_cull(int& sp, int& cur, float) const { pop_or_done(sp, cur); }
 };
 __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-template <bool COUNT, int kPoolSlots>
+// vote.hpp vote_node_step<closest hit> on node words that are already in registers
+template <class STK>
+__device__ __forceinline__ void pool_node_step(const uint4& w0, const uint4& w1, const uint4& w2, const uint4& w3, const STK& S, int& cur, int& sp, V3 o, V3 inv, float tmin, float tlimit) {
+    NodeData n;
+    unpack_node(w0, w1, w2, w3, n);
+    RaySlab slab; slab.o = o; slab.inv = inv;
+    slab.negx = inv.x < 0.0f; slab.negy = inv.y < 0.0f; slab.negz = inv.z < 0.0f;
+    float t0, t1, t2, t3;
+    node_entries(n, slab, tmin, tlimit, t0, t1, t2, t3);
+    int c0 = n.c0, c1 = n.c1, c2 = n.c2, c3 = n.c3;
+    cswap(t0, c0, t1, c1); cswap(t2, c2, t3, c3); cswap(t0, c0, t2, c2); cswap(t1, c1, t3, c3); cswap(t1, c1, t2, c2);
+    if (t0 < kMissT) {  // nearest child next, the others pushed far -> near
+        if (t3 < kMissT) S.push(sp, c3);
+        if (t2 < kMissT) S.push(sp, c2);
+        if (t1 < kMissT) S.push(sp, c1);
+        cur = c0;
+    } else S.pop_or_done(sp, cur);
+}
+template <bool COUNT, int SLOTS, int STACK, bool DUAL>
 __global__ __launch_bounds__(kTraverseBlock, 3) void k_trace_pool(DeviceScene sc, TraceArgs a, Counters* ctr) {
-    constexpr size_t kPoolWaveBytes = pool_wave_bytes(kPoolSlots);
-    constexpr uint32_t kHalf2 = (uint32_t)kPoolSlots - 64u;   // slots of the second half (lanes below this own two slots)
+    constexpr size_t kWaveBytes = pool_wave_bytes(SLOTS, STACK);
+    constexpr uint32_t kHalf2 = (uint32_t)SLOTS - 64u;   // slots of the second half (lanes below this look after two slots)
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
-    uint32_t* const W = reinterpret_cast<uint32_t*>(smem + wave * kPoolWaveBytes);
+    uint32_t* const W = reinterpret_cast<uint32_t*>(smem + wave * kWaveBytes);
     float* const F = reinterpret_cast<float*>(W);
-    uint32_t* const stack0 = W + kPoolRows * kPoolSlots;
-    uint32_t* const list = stack0 + kPoolStack * kPoolSlots;
+    uint32_t* const stack0 = W + kPoolRows * SLOTS;
+    unsigned char* const list_n = reinterpret_cast<unsigned char*>(stack0 + STACK * SLOTS);
+    unsigned char* const list_l = list_n + 64;
     const uint32_t gw = __builtin_amdgcn_readfirstlane(blockIdx.x * (kTraverseBlock / 64u) + wave);
-    uint32_t* const spill = sc.stack_overflow + (size_t)gw * kPoolSlots * kStackOverflow;
-#define ST(row, slot) W[(row) * kPoolSlots + (slot)]
-#define SF(row, slot) F[(row) * kPoolSlots + (slot)]
+    uint32_t* const spill = sc.stack_overflow + (size_t)gw * SLOTS * kStackOverflow;
+#define ST(row, slot) W[(row) * SLOTS + (slot)]
+#define SF(row, slot) F[(row) * SLOTS + (slot)]
     const BvhNode* const nodes = sc.nodes;
     const BvhTri* const tris = sc.tris;
-    TreeTop top; top.lds = nullptr; top.count = 0;
     const uint32_t n = a.n_dev ? *a.n_dev : a.n;
     const uint32_t chunk = fetch_chunk(n);
-    const uint32_t fetch_at = (a.param & 0xffu) ? (a.param & 0xffu) : 40u;            // idle SLOTS that trigger a fetch step
+    const uint32_t fetch_at = (a.param & 0xffu) ? (a.param & 0xffu) : (uint32_t)SLOTS * 5u / 16u;   // idle SLOTS that trigger a fetch step
     const uint32_t w4 = ((a.param >> 12) & 15u) ? ((a.param >> 12) & 15u) : kVoteWeight4;
-    const uint32_t n_static = gridDim.x * (kTraverseBlock / 64u) * (uint32_t)kPoolSlots;   // every wave starts on its own kPoolSlots entries, no atomic
-    uint32_t w_next = gw * (uint32_t)kPoolSlots, w_end = w_next + (uint32_t)kPoolSlots < n ? w_next + (uint32_t)kPoolSlots : n;
+    const uint32_t tri_at = ((a.param >> 16) & 63u) ? ((a.param >> 16) & 63u) : 32u;                  // DUAL: slots at leaves that make an iteration carry a triangle step
+    const uint32_t n_static = gridDim.x * (kTraverseBlock / 64u) * (uint32_t)SLOTS;   // every wave starts on its own SLOTS entries, no atomic
+    uint32_t w_next = gw * (uint32_t)SLOTS, w_end = w_next + (uint32_t)SLOTS < n ? w_next + (uint32_t)SLOTS : n;
     if (w_next >= n) { w_next = 0u; w_end = 0u; }
     bool exhausted = false;
     uint32_t st_nodes = 0u, st_tris = 0u;
@@ -290,15 +306,15 @@ __global__ __launch_bounds__(kTraverseBlock, 3) void k_trace_pool(DeviceScene sc
     ST(13, lane) = (uint32_t)kLaneIdle; if (two) ST(13, lane + 64u) = (uint32_t)kLaneIdle;
     wave_lds_sync();
     while (true) {
-        // ---- vote over the pool: every lane looks at two slots
+        // ---- vote over the pool: every lane looks at (up to) two slots
         const int c0 = (int)ST(13, lane), c1 = two ? (int)ST(13, lane + 64u) : kLaneIdle;
         const bool n0 = c0 >= 0 && c0 < kLaneDone, n1 = c1 >= 0 && c1 < kLaneDone, l0 = c0 < 0, l1 = c1 < 0;
         const unsigned long long bn0 = __ballot(n0), bn1 = __ballot(n1), bl0 = __ballot(l0), bl1 = __ballot(l1);
         const uint32_t nn = (uint32_t)(__popcll(bn0) + __popcll(bn1)), nl = (uint32_t)(__popcll(bl0) + __popcll(bl1));
-        if ((!exhausted && (uint32_t)kPoolSlots - nn - nl >= fetch_at) || nn + nl == 0u) {
+        if ((!exhausted && (uint32_t)SLOTS - nn - nl >= fetch_at) || nn + nl == 0u) {
             // ---- fetch step: retire finished slots, deal new rays to the idle ones (two passes of 64 slots)
 #pragma unroll 1
-            for (uint32_t h = 0u; h < 2u; h++) {
+            for (uint32_t h = 0u; h < (SLOTS > 64 ? 2u : 1u); h++) {
                 const uint32_t s = lane + 64u * h;
                 const bool mine = h == 0u || two;
                 int c = mine ? (int)ST(13, s) : kLaneDone - 1;   // (a slot that does not exist is neither done nor idle)
@@ -339,43 +355,61 @@ __global__ __launch_bounds__(kTraverseBlock, 3) void k_trace_pool(DeviceScene sc
             }
             continue;
         }
-        // ---- which kind of step, and the (up to) 64 slots that take it
+        // ---- which kind(s) of step, and the (up to) 64 slots that take each
         const bool node_wins = (nn >= 64u && nl < 64u) ? true : (nl >= 64u && nn < 64u) ? false : 4u * nn > w4 * nl;
-        const unsigned long long m0 = node_wins ? bn0 : bl0, m1 = node_wins ? bn1 : bl1;
-        const bool w0 = node_wins ? n0 : l0, w1 = node_wins ? n1 : l1;
-        const uint32_t r0 = lanes_below(m0), r1 = (uint32_t)__popcll(m0) + lanes_below(m1);
-        if (w0 && r0 < 64u) list[r0] = lane;
-        if (w1 && r1 < 64u) list[r1] = lane + 64u;
+        const bool do_node = DUAL ? nn > 0u : node_wins, do_tri = DUAL ? (nl >= tri_at || nn == 0u) : !node_wins;
+        if (do_node) {
+            const uint32_t r0 = lanes_below(bn0), r1 = (uint32_t)__popcll(bn0) + lanes_below(bn1);
+            if (n0 && r0 < 64u) list_n[r0] = (unsigned char)lane;
+            if (n1 && r1 < 64u) list_n[r1] = (unsigned char)(lane + 64u);
+        }
+        if (do_tri) {
+            const uint32_t r0 = lanes_below(bl0), r1 = (uint32_t)__popcll(bl0) + lanes_below(bl1);
+            if (l0 && r0 < 64u) list_l[r0] = (unsigned char)lane;
+            if (l1 && r1 < 64u) list_l[r1] = (unsigned char)(lane + 64u);
+        }
         wave_lds_sync();
-        const uint32_t total = (uint32_t)(__popcll(m0) + __popcll(m1)), cnt = total < 64u ? total : 64u;
-        if (lane < cnt) {
-            const uint32_t s = list[lane];
-            int cur = (int)ST(13, s), sp = (int)ST(14, s);
-            PoolStack<kPoolSlots> S; S.stk = stack0 + s; S.ovf = spill + (size_t)s * kStackOverflow;
-            const V3 o = vptfp::v3(SF(0, s), SF(1, s), SF(2, s));
-            float best_t = SF(9, s);
-            if (node_wins) {
-                if (COUNT) st_nodes++;
-                const V3 inv = vptfp::v3(SF(6, s), SF(7, s), SF(8, s));
-                vote_node_step<false, false, false, PoolStack<kPoolSlots>>(nodes, top, S, cur, sp, o, inv, a.tmin, best_t);
-            } else {   // ONE triangle of the slot's leaf (vote.hpp vote_tri_step_closest; the best triangle's global id is read only on a tie in t)
-                if (COUNT) st_tris++;
-                const V3 d = vptfp::v3(SF(3, s), SF(4, s), SF(5, s));
-                const uint32_t enc = (uint32_t)(~cur);
-                const int first = (int)(enc >> 3);
-                const uint32_t more = enc & 7u;
-                const float4* q = reinterpret_cast<const float4*>(tris + first);
-                const float4 ta = q[0], tb = q[1], tc = q[2];
-                float t, u, v;
-                const bool hit = ray_triangle_flat(o, d, vptfp::v3(ta.x, ta.y, ta.z), vptfp::v3(ta.w, tb.x, tb.y), vptfp::v3(tb.z, tb.w, tc.x), a.tmin, a.tmax, t, u, v);
-                const uint32_t bslot = ST(12, s);
-                bool better = hit & ((bslot == 0xffffffffu) | (t < best_t));
-                if (hit & (bslot != 0xffffffffu) & (t == best_t)) better = __float_as_uint(tc.w) < tris[bslot].gid;   // ties in t go to the smaller global id
-                if (better) { SF(9, s) = t; SF(10, s) = u; SF(11, s) = v; ST(12, s) = (uint32_t)first; }
-                if (more) cur = ~(int)((((uint32_t)first + 1u) << 3) | (more - 1u));
-                else S.pop_or_done(sp, cur);
-            }
-            ST(13, s) = (uint32_t)cur; ST(14, s) = (uint32_t)sp;
+        const bool an = do_node && lane < (nn < 64u ? nn : 64u), al = do_tri && lane < (nl < 64u ? nl : 64u);
+        // the loads of both steps first
+        uint32_t sn = 0u, sl = 0u;
+        int cur_n = 0, cur_l = 0;
+        uint4 w0 = make_uint4(0u, 0u, 0u, 0u), w1 = w0, w2 = w0, w3 = w0;
+        float4 ta = make_float4(0.0f, 0.0f, 0.0f, 0.0f), tb = ta, tc = ta;
+        if (an) {
+            sn = list_n[lane]; cur_n = (int)ST(13, sn);
+            const uint4* p = reinterpret_cast<const uint4*>(nodes + cur_n);
+            w0 = p[0]; w1 = p[1]; w2 = p[2]; w3 = p[3];
+        }
+        if (al) {
+            sl = list_l[lane]; cur_l = (int)ST(13, sl);
+            const float4* q = reinterpret_cast<const float4*>(tris + (int)(((uint32_t)(~cur_l)) >> 3));
+            ta = q[0]; tb = q[1]; tc = q[2];
+        }
+        if (an) {   // ---- inner-node step
+            if (COUNT) st_nodes++;
+            int sp = (int)ST(14, sn);
+            PoolStack<SLOTS, STACK> S; S.stk = stack0 + sn; S.ovf = spill + (size_t)sn * kStackOverflow;
+            pool_node_step(w0, w1, w2, w3, S, cur_n, sp, vptfp::v3(SF(0, sn), SF(1, sn), SF(2, sn)), vptfp::v3(SF(6, sn), SF(7, sn), SF(8, sn)), a.tmin, SF(9, sn));
+            ST(13, sn) = (uint32_t)cur_n; ST(14, sn) = (uint32_t)sp;
+        }
+        if (al) {   // ---- ONE triangle of the slot's leaf (vote.hpp vote_tri_step_closest; the best triangle's global id is read only on a tie in t)
+            if (COUNT) st_tris++;
+            int sp = (int)ST(14, sl);
+            PoolStack<SLOTS, STACK> S; S.stk = stack0 + sl; S.ovf = spill + (size_t)sl * kStackOverflow;
+            const uint32_t enc = (uint32_t)(~cur_l);
+            const int first = (int)(enc >> 3);
+            const uint32_t more = enc & 7u;
+            float t, u, v;
+            const bool hit = ray_triangle_flat(vptfp::v3(SF(0, sl), SF(1, sl), SF(2, sl)), vptfp::v3(SF(3, sl), SF(4, sl), SF(5, sl)), vptfp::v3(ta.x, ta.y, ta.z), vptfp::v3(ta.w, tb.x, tb.y),
+                                               vptfp::v3(tb.z, tb.w, tc.x), a.tmin, a.tmax, t, u, v);
+            const uint32_t bslot = ST(12, sl);
+            const float best_t = SF(9, sl);
+            bool better = hit & ((bslot == 0xffffffffu) | (t < best_t));
+            if (hit & (bslot != 0xffffffffu) & (t == best_t)) better = __float_as_uint(tc.w) < tris[bslot].gid;   // ties in t go to the smaller global id
+            if (better) { SF(9, sl) = t; SF(10, sl) = u; SF(11, sl) = v; ST(12, sl) = (uint32_t)first; }
+            if (more) cur_l = ~(int)((((uint32_t)first + 1u) << 3) | (more - 1u));
+            else S.pop_or_done(sp, cur_l);
+            ST(13, sl) = (uint32_t)cur_l; ST(14, sl) = (uint32_t)sp;
         }
         wave_lds_sync();
     }
@@ -497,8 +531,8 @@ __global__ __launch_bounds__(kTraverseBlock, 8) void k_trace_shadow(DeviceScene 
 // ------------------------------------------------------------------ launch
 int trace_blocks_per_cu(uint32_t variant, bool any) {
     int nb = 0;
-    if (variant == VPT_TRACE_POOL) {   // (the 128-slot form; the launch asks again for the 96-slot one)
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_pool<false, 128>, kTraverseBlock, pool_lds_bytes(128));
+    if (variant == VPT_TRACE_POOL) {   // (the 128-slot form: 3 blocks per CU; the launch scales the grid for the smaller pools)
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_pool<false, 128, 10, false>, kTraverseBlock, pool_lds_bytes(128, 10));
         return nb > 0 ? nb : 1;
     }
     const size_t lds = variant == VPT_TRACE_BASE ? kVoteStackBytes : kVoteLdsBytes;
@@ -516,15 +550,21 @@ int trace_blocks_per_cu(uint32_t variant, bool any) {
 }
 
 void launch_trace(hipStream_t s, uint32_t blocks, uint32_t variant, bool any, bool count, const DeviceScene& sc, const TraceArgs& a, Counters* ctr) {
-    if (variant == VPT_TRACE_POOL) {   // closest hit only (the lab refuses the any-hit form); param bit 8: 96 slots per wave instead of 128, on a third more blocks
-        if ((a.param >> 8) & 1u) {
-            const uint32_t b96 = blocks + blocks / 3u;
-            if (count) hipLaunchKernelGGL((k_trace_pool<true, 96>), dim3(b96), dim3(kTraverseBlock), pool_lds_bytes(96), s, sc, a, ctr);
-            else hipLaunchKernelGGL((k_trace_pool<false, 96>), dim3(b96), dim3(kTraverseBlock), pool_lds_bytes(96), s, sc, a, ctr);
-        } else {
-            if (count) hipLaunchKernelGGL((k_trace_pool<true, 128>), dim3(blocks), dim3(kTraverseBlock), pool_lds_bytes(128), s, sc, a, ctr);
-            else hipLaunchKernelGGL((k_trace_pool<false, 128>), dim3(blocks), dim3(kTraverseBlock), pool_lds_bytes(128), s, sc, a, ctr);
-        }
+    if (variant == VPT_TRACE_POOL) {   // closest hit only (the lab refuses the any-hit form).  param bits 8-9: slots per wave / LDS stack entries 128/10, 96/10, 80/8, 64/8
+        // (3, 4, 5, 6 blocks per CU: the grid — and with it the slot-indexed spill region — keeps blocks x slots constant); bit 10: DUAL
+        const uint32_t cfg = (a.param >> 8) & 3u;
+        const bool dual = ((a.param >> 10) & 1u) != 0u;
+        const dim3 b(kTraverseBlock);
+#define VPT_LP(SL, STK, G) do { const dim3 g(G); const size_t lds = pool_lds_bytes(SL, STK);                                                   \
+            if (dual) { if (count) hipLaunchKernelGGL((k_trace_pool<true, SL, STK, true>), g, b, lds, s, sc, a, ctr);                               \
+                        else hipLaunchKernelGGL((k_trace_pool<false, SL, STK, true>), g, b, lds, s, sc, a, ctr); }                                 \
+            else { if (count) hipLaunchKernelGGL((k_trace_pool<true, SL, STK, false>), g, b, lds, s, sc, a, ctr);                                  \
+                   else hipLaunchKernelGGL((k_trace_pool<false, SL, STK, false>), g, b, lds, s, sc, a, ctr); } } while (0)
+        if (cfg == 0u) VPT_LP(128, 10, blocks);
+        else if (cfg == 1u) VPT_LP(96, 10, blocks + blocks / 3u);
+        else if (cfg == 2u) VPT_LP(80, 8, blocks + (blocks * 2u) / 3u);
+        else VPT_LP(64, 8, blocks * 2u);
+#undef VPT_LP
         return;
     }
     const size_t lds = variant == VPT_TRACE_BASE ? kVoteStackBytes : kVoteLdsBytes;
