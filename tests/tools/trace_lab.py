@@ -170,6 +170,9 @@ def main():
                 if any_hit:
                     continue
                 plan = [(VOTE, 256 + 16), (VOTE, (256 + 16) | (1 << 17)), (VOTE, 256 + 16), (VOTE, (256 + 16) | (1 << 17))]
+            if os.environ.get("LAB_PK") == "1":   # packed plane arithmetic in the node step (bit 18) against the product instantiation, alternating
+                plan = [(VOTE, 256 + 16), (VOTE, (256 + 16) | (1 << 18))] * 3
+                cull_mode = True
             if os.environ.get("LAB_POOL") == "1":   # ray slots in LDS (k_trace_pool, closest hit) against the product instantiation: param bits as in include/vpt.h VPT_TRACE_POOL
                 if any_hit:
                     continue

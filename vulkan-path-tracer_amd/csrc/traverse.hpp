@@ -150,6 +150,30 @@ __device__ inline void node_entries(const NodeData& n, const RaySlab& r, float t
     VPT_CHILD(0, t0) VPT_CHILD(1, t1) VPT_CHILD(2, t2) VPT_CHILD(3, t3)
 #undef VPT_CHILD
 }
+// The same with the 24 plane fmas and the four slack multiplies issued as 12 + 2 packed instructions (v_pk_fma_f32 / v_pk_mul_f32: two
+// IEEE fp32 operations per issue slot, each rounded exactly as its scalar form, so every entry distance is the one node_entries() returns).
+typedef float vpt_f2 __attribute__((ext_vector_type(2)));
+__device__ inline void node_entries_pk(const NodeData& n, const RaySlab& r, float tmin, float tlimit, float& t0, float& t1, float& t2, float& t3) {
+    const float ax = n.sx * r.inv.x, ay = n.sy * r.inv.y, az = n.sz * r.inv.z;
+    const float bx = (n.ox - r.o.x) * r.inv.x, by = (n.oy - r.o.y) * r.inv.y, bz = (n.oz - r.o.z) * r.inv.z;
+    const uint32_t nx = r.negx ? n.hix : n.lox, fx = r.negx ? n.lox : n.hix;
+    const uint32_t ny = r.negy ? n.hiy : n.loy, fy = r.negy ? n.loy : n.hiy;
+    const uint32_t nz = r.negz ? n.hiz : n.loz, fz = r.negz ? n.loz : n.hiz;
+    const vpt_f2 ax2 = {ax, ax}, ay2 = {ay, ay}, az2 = {az, az}, bx2 = {bx, bx}, by2 = {by, by}, bz2 = {bz, bz};
+#define VPT_PAIR(W, A, B, K0, K1) __builtin_elementwise_fma((vpt_f2){byte_f<K0>(W), byte_f<K1>(W)}, A, B)
+    const vpt_f2 nx01 = VPT_PAIR(nx, ax2, bx2, 0, 1), nx23 = VPT_PAIR(nx, ax2, bx2, 2, 3), ny01 = VPT_PAIR(ny, ay2, by2, 0, 1), ny23 = VPT_PAIR(ny, ay2, by2, 2, 3);
+    const vpt_f2 nz01 = VPT_PAIR(nz, az2, bz2, 0, 1), nz23 = VPT_PAIR(nz, az2, bz2, 2, 3);
+    const vpt_f2 fx01 = VPT_PAIR(fx, ax2, bx2, 0, 1), fx23 = VPT_PAIR(fx, ax2, bx2, 2, 3), fy01 = VPT_PAIR(fy, ay2, by2, 0, 1), fy23 = VPT_PAIR(fy, ay2, by2, 2, 3);
+    const vpt_f2 fz01 = VPT_PAIR(fz, az2, bz2, 0, 1), fz23 = VPT_PAIR(fz, az2, bz2, 2, 3);
+#undef VPT_PAIR
+    const float tn0 = fmax_(fmax_(nx01.x, ny01.x), fmax_(nz01.x, tmin)), tn1 = fmax_(fmax_(nx01.y, ny01.y), fmax_(nz01.y, tmin));
+    const float tn2 = fmax_(fmax_(nx23.x, ny23.x), fmax_(nz23.x, tmin)), tn3 = fmax_(fmax_(nx23.y, ny23.y), fmax_(nz23.y, tmin));
+    const vpt_f2 tf01 = {fmin_(fmin_(fx01.x, fy01.x), fmin_(fz01.x, tlimit)), fmin_(fmin_(fx01.y, fy01.y), fmin_(fz01.y, tlimit))};
+    const vpt_f2 tf23 = {fmin_(fmin_(fx23.x, fy23.x), fmin_(fz23.x, tlimit)), fmin_(fmin_(fx23.y, fy23.y), fmin_(fz23.y, tlimit))};
+    const vpt_f2 slack = {1.0000005f, 1.0000005f};
+    const vpt_f2 s01 = tf01 * slack, s23 = tf23 * slack;
+    t0 = (tn0 <= s01.x) ? tn0 : kMissT; t1 = (tn1 <= s01.y) ? tn1 : kMissT; t2 = (tn2 <= s23.x) ? tn2 : kMissT; t3 = (tn3 <= s23.y) ? tn3 : kMissT;
+}
 // fp32 nodes: the plain slab test.
 __device__ inline float box_entry(float bx0, float by0, float bz0, float bx1, float by1, float bz1, V3 o, V3 inv, float tmin, float tlimit) {
     float t0x = (bx0 - o.x) * inv.x, t1x = (bx1 - o.x) * inv.x;

@@ -106,7 +106,7 @@ __device__ __forceinline__ TreeTop stage_tree_top(unsigned char* smem, const Bvh
 // USE_TOP: only the any-hit kernels use the LDS tree top.  Measured (atrium / glass bust, bench kernel means): shadow stage 4.46 -> 3.94 ms
 // and 0.318 -> 0.311 ms with it — those kernels are L1-bound with VALU issue to spare (VALUBusy 82-85 %); the closest-hit extend kernel,
 // VALU-saturated, pays for the six instructions of the address select: 6.37 -> 6.71 ms and 1.12 -> 1.19 ms, so it keeps the plain load.
-template <bool ANY, bool USE_TOP = ANY, bool CULL = false, class STK = LaneStack>
+template <bool ANY, bool USE_TOP = ANY, bool CULL = false, class STK = LaneStack, bool PK = false>
 __device__ __forceinline__ void vote_node_step(const BvhNode* nodes, const TreeTop& top, const STK& S, int& cur, int& sp, V3 o, V3 inv, float tmin, float tlimit) {
     const uint4* p = (USE_TOP && cur < top.count) ? top.lds + cur * 4 : reinterpret_cast<const uint4*>(nodes + cur);
     NodeData n;
@@ -114,7 +114,8 @@ __device__ __forceinline__ void vote_node_step(const BvhNode* nodes, const TreeT
     RaySlab slab; slab.o = o; slab.inv = inv;
     slab.negx = inv.x < 0.0f; slab.negy = inv.y < 0.0f; slab.negz = inv.z < 0.0f;
     float t0, t1, t2, t3;
-    node_entries(n, slab, tmin, tlimit, t0, t1, t2, t3);
+    if (PK) node_entries_pk(n, slab, tmin, tlimit, t0, t1, t2, t3);   // (trace lab, bit 18: the plane arithmetic in packed instructions)
+    else node_entries(n, slab, tmin, tlimit, t0, t1, t2, t3);
     int c0 = n.c0, c1 = n.c1, c2 = n.c2, c3 = n.c3;
     if (ANY) {   // order is irrelevant for an any-hit search: hit children in slot order
         int next = kLaneIdle;
