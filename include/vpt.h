@@ -54,7 +54,7 @@ extern "C" {
  * triangle at < 1e-3 rad can be given a hit up to ~1e-2 scene units off the triangle by fp32 rounding, which a box
  * hierarchy sees or not depending on its shape — about one ray in 1e9, 1e-11 relative L2 on a 531 M-sample image.
  * With it the image equals brute-force intersection bit for bit at any size.  Cost in throughput, measured at 1080p on the default
- * pipelines (profiles/r04_strict_rate.json): Cornell box (fused kernel) 11.5 %, atrium (streams) 6.8 %, glass bust (streams, depth 32) 0.5 %. */
+ * pipelines (profiles/r04_strict_rate.json): Cornell box (fused per-bounce kernels) 11.5 %, atrium (streams) 6.8 %, glass bust (streams, depth 32) 0.5 %. */
 #define VPT_FLAG_LOCAL_HITS (1u << 8)
 #define VPT_FLAGS_DEFAULT                                                                                   \
     (VPT_FLAG_SKY_MIS | VPT_FLAG_MESH_MIS | VPT_FLAG_SHOW_ENV_DIRECTLY | VPT_FLAG_ENERGY_COMPENSATION |    \
@@ -199,8 +199,8 @@ typedef struct vpt_config {
 /* Spatial splits in the BVH builder (bvh_build.hpp): identical images, pays on scenes of uneven triangle sizes only.
  * Per context, never read from the environment: two contexts of one process cannot silently build different trees. */
 #define VPT_BUILD_SBVH 1u
-/* Keep the general instantiation of the fused per-bounce kernel even when the scene qualifies for the class-specialised one (every
- * texture 1x1 and a black environment: k_bounce<PLAIN>, kernels_path.hip).  Images are identical; this is the A/B switch of that choice. */
+/* Keep the general instantiation of the whole-path / fused per-bounce kernels even when the scene qualifies for the class-specialised one
+ * (every texture 1x1 and a black environment: k_whole<PLAIN>, k_bounce<PLAIN>, kernels_path.hip).  Images are identical; this is the A/B switch of that choice. */
 #define VPT_BUILD_GENERAL_KERNELS 2u
 
 /* AUTO = WHOLE where it applies (BVH in LDS, no media, one sample per pixel and frame), FUSED for the other scenes whose BVH fits in LDS next to
@@ -220,7 +220,8 @@ typedef struct vpt_config {
 
 #define VPT_KERNEL_COUNT 10
 enum vpt_kernel_id {
-    VPT_K_PRIMARY = 0,  /* fused pipeline: bounce 0 (camera ray + extend + shade + connect); staged pipeline: raygen */
+    VPT_K_PRIMARY = 0,  /* whole-path pipeline: the batch's one launch (k_whole); fused pipeline: bounce 0 (camera ray + extend + shade + connect);
+                         * staged pipeline: raygen */
     VPT_K_EXTEND = 1,
     VPT_K_SHADE = 2,
     VPT_K_CONNECT = 3,  /* shadow rays + light accumulation + end-of-sample in one kernel (VPT_PIPELINE_STAGED_R1) */
@@ -387,9 +388,10 @@ int vpt_render(vpt_ctx* ctx, uint32_t dispatches, int* done);
  *                         (vpt_output_device) and, if rgba8_device != NULL, copied there device-to-device (an interop / swapchain image).
  *   vpt_wait(ticket)      blocks until that ticket's work has finished (0: everything enqueued so far).
  * When every path of a batch provably ends within max_depth * samples_per_frame bounces (no material scatters inside a medium, no
- * volumes / atmosphere) and that number is <= VPT_ASYNC_MAX_BOUNCES, a batch is a fixed schedule: nothing in it waits for the host, any
- * number of frames can be in flight, and a 1-frame batch of the fused pipeline is captured once as a hipGraph and replayed
- * (vpt_stats.graph_launches).  Otherwise the enqueued part is the first VPT_ASYNC_MAX_BOUNCES bounces and the NEXT call on the context
+ * volumes / atmosphere) and that number is <= VPT_ASYNC_MAX_BOUNCES — or when the batch is ONE whole-path launch (VPT_PIPELINE_WHOLE, which
+ * AUTO takes for LDS-resident scenes: every path runs to its end inside it, whatever max_depth is) — a batch is a fixed schedule: nothing in
+ * it waits for the host, any number of frames can be in flight, and a 1-frame batch of the whole-path / fused pipelines is captured once as a
+ * hipGraph and replayed (vpt_stats.graph_launches).  Otherwise the enqueued part is the first VPT_ASYNC_MAX_BOUNCES bounces and the NEXT call on the context
  * (or vpt_wait) finishes the batch first, exactly as vpt_render would have.  Images are bit-identical to vpt_render's either way.
  * Every other entry point that reads or changes device state drains outstanding work first. */
 #define VPT_ASYNC_MAX_BOUNCES 16u
