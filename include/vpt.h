@@ -490,7 +490,8 @@ int vpt_lab_set_rays(vpt_ctx* ctx, const vpt_ray* rays_host, uint32_t n);
  *   VPT_LAB_WHOLE_FRAMES  VPT_PIPELINE_AUTO runs batches of at most this many frames as one whole-path launch where VPT_PIPELINE_WHOLE applies
  *                         (0: never — the per-bounce kernels; 0xffff: no bound, the default)
  *   VPT_LAB_WHOLE_SCHED   how a whole-path launch deals its tiles of 64 samples: low 4 bits = tiles per atomic (1-15), bits 4-5 = rounds dealt without
- *                         an atomic (0: the first, 1: all but the last, 2: half).  Default 4 (first round static, then four tiles per atomic) */
+ *                         an atomic (0: the first, 1: all but the last, 2: half, 3: the first, and the chunks shrink towards the end of the batch).  Default 4 (first
+ *                         round static, then four tiles per atomic) */
 #define VPT_LAB_LANES 1u
 #define VPT_LAB_LANE_GRID 2u
 #define VPT_LAB_TAIL_GRID 3u

@@ -12,8 +12,8 @@ os.makedirs(out_dir, exist_ok=True)
 sc = vpt.scenes.Scene.load(os.path.join(ROOT, "tests", "golden", "cornell_box.npz"))
 P = vpt.default_params(max_depth=8, max_samples=0x7fffffff)
 res = {"launch": [], "policies": []}
-SCHEDS = (0x04, 0x01, 0x02, 0x08, 0x11, 0x14, 0x21, 0x24)   # VPT_LAB_WHOLE_SCHED: tiles per atomic | static-rounds mode << 4
-for F in (1, 2, 4, 32):
+SCHEDS = (0x04, 0x34, 0x38, 0x14, 0x04, 0x34)   # VPT_LAB_WHOLE_SCHED: tiles per atomic | static-rounds mode << 4
+for F in (1, 2, 4, 32, 226):
     g = vpt.PathTracer(1920, 1080, frames_in_flight=F, profile=True)
     g.set_scene(sc); g.set_params(P)
     for sched in SCHEDS:
@@ -21,7 +21,7 @@ for F in (1, 2, 4, 32):
         for _ in range(3):
             g.render(F)
         g.reset_stats()
-        n = 30 if F <= 4 else 6
+        n = 30 if F <= 4 else 6 if F <= 32 else 2
         for _ in range(n):
             g.render(F)
         st = g.stats()
@@ -48,7 +48,7 @@ def async_loop(in_flight, n=N):
     return (time.perf_counter() - t) / n * 1e3
 
 
-for sched in (0x04, 0x11, 0x21, 0x01):
+for sched in (0x04, 0x34, 0x38, 0x04, 0x34):
     g.lab_set(A.LAB_WHOLE_SCHED, sched)
     for lanes in (1, 2, 3):
         g.lab_set(A.LAB_LANES, lanes)

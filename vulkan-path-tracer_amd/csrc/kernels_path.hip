@@ -573,6 +573,7 @@ __global__ __launch_bounds__(kTraverseBlock, 3) void k_whole(DeviceScene sc, Ren
     uint32_t static_left = static_rounds;
     uint32_t next_static = __builtin_amdgcn_readfirstlane(blockIdx.x * kWaves + wave);
     uint32_t w_next = 0u, w_end = 0u;
+    uint32_t last_seen = dyn_first;   // how far the tile counter had got when this wave last took from it
     bool exhausted = false;
     uint32_t hit_head = 0u, hit_count = 0u;   // wave-uniform
     TravStats st, sst; st.nodes = 0; st.tris = 0; sst.nodes = 0; sst.tris = 0;
@@ -640,9 +641,16 @@ __global__ __launch_bounds__(kTraverseBlock, 3) void k_whole(DeviceScene sc, Ren
                     uint32_t tile, span = 1u;
                     if (static_left != 0u) { tile = next_static; next_static += n_waves; static_left--; }
                     else {
+                        // guided (chunk_tiles bit 8): the chunk shrinks with what is left — by this wave's last look at the counter — so that the waves run dry within a tile of each other
+                        uint32_t take = chunk_tiles & 0xffu;
+                        if (chunk_tiles & 0x100u) {
+                            const uint32_t left_tiles = n_tiles > last_seen ? n_tiles - last_seen : 0u, fair = left_tiles / (2u * n_waves);
+                            take = fair < 1u ? 1u : (fair < take ? fair : take);
+                        }
                         uint32_t k = 0u;
-                        if (lane_id() == 0u) k = atomicAdd(&ctr->extend_head, chunk_tiles);
-                        tile = dyn_first + __builtin_amdgcn_readfirstlane(k); span = chunk_tiles;
+                        if (lane_id() == 0u) k = atomicAdd(&ctr->extend_head, take);
+                        tile = dyn_first + __builtin_amdgcn_readfirstlane(k); span = take;
+                        last_seen = tile + take;
                     }
                     if (tile >= n_tiles) exhausted = true;
                     else { w_next = tile * 64u; w_end = (tile + span) * 64u < n ? (tile + span) * 64u : n; }

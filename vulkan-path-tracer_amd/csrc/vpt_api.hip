@@ -722,8 +722,9 @@ int batch_begin(vpt_ctx* c, uint32_t frames, uint32_t dispatch_base, BatchState&
         const uint32_t grid = std::max(1u, std::min<uint32_t>((uint32_t)std::min(c->whole_blocks, c->primary_blocks), (n_slots + 255u) / 256u));   // (blocks of 256 lanes)
         // tiles of 64 samples: `rounds` per wave; mode 0: the first round static, mode 1: all but the last, mode 2: half of them; the rest through the counter
         const uint32_t n_waves = grid * 4u, rounds = ((n_slots + 63u) / 64u) / n_waves, mode = c->lab_whole_sched >> 4;
-        const uint32_t static_rounds = mode == 0u ? std::min(rounds, 1u) : mode == 1u ? (rounds >= 2u ? rounds - 1u : 0u) : rounds / 2u;
-        TIMED(c, VPT_K_PRIMARY, launch_whole(s, grid, b.count, c->dsc, c->P, c->ps, c->ctr, n_slots, dispatch_base, c->scene_plain, static_rounds, std::max(1u, c->lab_whole_sched & 15u)));
+        const uint32_t static_rounds = (mode == 0u || mode == 3u) ? std::min(rounds, 1u) : mode == 1u ? (rounds >= 2u ? rounds - 1u : 0u) : rounds / 2u;
+        // (mode 3: mode 0 with guided chunks — at most the given tiles per atomic, fewer towards the end of the batch)
+        TIMED(c, VPT_K_PRIMARY, launch_whole(s, grid, b.count, c->dsc, c->P, c->ps, c->ctr, n_slots, dispatch_base, c->scene_plain, static_rounds, std::max(1u, c->lab_whole_sched & 15u) | (mode == 3u ? 0x100u : 0u)));
         b.parity = 1; b.k3 = 1; b.iter = 1;
     } else if (b.fused) {  // bounce 0 of every slot needs no input records; survivors land in queue[1]
         TIMED(c, VPT_K_PRIMARY, launch_bounce(s, (uint32_t)c->primary_blocks, c->lds_scene, b.count, true, c->dsc, c->P, c->ps, c->ss, nullptr, c->queue[1], c->ctr, 0u, b.n_first, dispatch_base, 0u, c->scene_plain));
@@ -2099,7 +2100,7 @@ int vpt_lab_set(vpt_ctx* c, uint32_t key, uint32_t value) {
     if (key == VPT_LAB_LANES && value >= 1u) c->lab_lanes = value;
     else if (key == VPT_LAB_LANE_GRID && value >= 1u) c->lab_lane_grid = value;
     else if (key == VPT_LAB_TAIL_GRID && value >= 1u) c->lab_tail_grid = value;
-    else if (key == VPT_LAB_WHOLE_SCHED && (value & 15u) >= 1u && (value >> 4) <= 2u) c->lab_whole_sched = value;
+    else if (key == VPT_LAB_WHOLE_SCHED && (value & 15u) >= 1u && (value >> 4) <= 3u) c->lab_whole_sched = value;
     else if (key == VPT_LAB_WHOLE_FRAMES) c->lab_whole_frames = value == 0xffffu ? 0xffffffffu : value;   // (0xffff: no bound, the default)
     else return VPT_ERR_INVALID_ARGUMENT;
     c->state_gen++;   // captured batches hold the old grids
