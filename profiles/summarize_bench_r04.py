@@ -77,6 +77,22 @@ for scene, wl in (("atrium", "atrium_1080p_d8"), ("bust", "glass_bust_1080p_d32"
             o["shadow"] = {"mean_duration_us": (a["mean_duration_us"] + b["mean_duration_us"]) / 2, "hbm_bytes_per_launch": (a["hbm_bytes_per_launch"] + b["hbm_bytes_per_launch"]) / 2,
                            "valu_busy": round((a["valu_busy"] * a["mean_duration_us"] + b["valu_busy"] * b["mean_duration_us"]) / (a["mean_duration_us"] + b["mean_duration_us"]), 3),
                            "lanes_per_valu_instr": round((a["lanes_per_valu_instr"] * a["mean_duration_us"] + b["lanes_per_valu_instr"] * b["mean_duration_us"]) / (a["mean_duration_us"] + b["mean_duration_us"]), 1)}
+lds_rows = []
+for s_, (calls, tot) in sorted(dur.items(), key=lambda kv: -kv[1][1]):
+    a, c = acc[s_], cnt[s_]
+    if not c["SQ_INSTS_LDS"]:
+        continue
+    per = lambda k: a[k] / c[k] if c[k] else float("nan")
+    # SQ_ACTIVE_INST_LDS / SQ_LDS_* count quad-cycles summed over the SIMDs' wave slots (as SQ_ACTIVE_INST_VALU does): x 4 / (1024 SIMDs x GRBM_GUI_ACTIVE / 8) = share of time
+    gui = per("GRBM_GUI_ACTIVE")
+    share = lambda k: per(k) * 4 / (1024 * gui / 8) if gui else float("nan")
+    lds_rows.append("| %s | %.3g | %.0f %% | %.0f %% | %.0f %% | %.1f %% |" % (s_, per("SQ_INSTS_LDS"), 100 * share("SQ_ACTIVE_INST_LDS"), 100 * share("SQ_LDS_IDX_ACTIVE"), 100 * share("SQ_WAIT_INST_LDS"),
+                                                                      100 * per("SQ_LDS_BANK_CONFLICT") / max(per("SQ_LDS_IDX_ACTIVE"), 1.0)))
+    out["cornell_1080p_d8"][s_].update({"lds_instr_per_launch": per("SQ_INSTS_LDS"), "lds_active_share": round(share("SQ_ACTIVE_INST_LDS"), 3), "lds_idx_active_share": round(share("SQ_LDS_IDX_ACTIVE"), 3),
+                                        "lds_wait_share": round(share("SQ_WAIT_INST_LDS"), 3), "lds_bank_conflict_of_active": round(per("SQ_LDS_BANK_CONFLICT") / max(per("SQ_LDS_IDX_ACTIVE"), 1.0), 4)})
+if lds_rows:
+    lines += ["", "LDS side (`lds` pass; shares are of the launch's time, normalised as VALU busy is; bank conflicts as a share of the cycles the LDS index unit is active):", "",
+              "| stage | LDS wave-instructions / launch | LDS instruction active | LDS index unit active | waiting on an LDS instruction | bank-conflict cycles of active |", "|---|---|---|---|---|---|"] + lds_rows
 lines += ["", "fp32 operation mix (`flops` pass: SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F32; FLOP = (ADD + MUL + TRANS + 2 x FMA) wave-instructions x 64 lanes x lane use; peak 157.3 TFLOP/s assumes a packed FMA on every lane every cycle):", "",
           "| stage | fp32 share of VALU instructions | fp32 TFLOP/s | of 157.3 |", "|---|---|---|---|"] + flops_rows
 open(os.path.join(ROOT, "profiles", "r04_cornell_summary.md"), "w").write("\n".join(lines) + "\n")
