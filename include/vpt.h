@@ -177,7 +177,9 @@ typedef struct vpt_config {
                                 * the free device memory, at most 2048 frames.  This is a CAP, not an allocation: vpt_create allocates the path records of ONE
                                 * frame (~0.8 GB at 1080p) and the buffers grow to the largest batch a vpt_render / vpt_render_async call actually asks for
                                 * (min(dispatches, cap) frames, 380 B per path; vpt_stats.frames_allocated) — an interactive host that renders a frame per
-                                * call never holds more than that one frame */
+                                * call never holds more than that one frame.  Contexts whose batches run as whole-path launches (VPT_PIPELINE_WHOLE, or AUTO
+                                * where it applies) keep their paths in registers and allocate 48 B per sample + the records of one frame
+                                * (vpt_stats.resident_frames == 1): 22.6 GB instead of 149 GB for 226 frames at 1080p */
     uint32_t profile;    /* 1 = bracket every kernel launch with hipEvents (vpt_get_stats kernel times) */
     uint32_t count_traversal; /* 1 = count BVH node/triangle visits (slower; for the roofline's algorithmic bytes) */
     uint32_t pipeline;   /* VPT_PIPELINE_* */

@@ -191,3 +191,44 @@ def test_async_frames_are_whole_path_launches(vpt, oracle, scenes, name, depth):
     out8, _ = oracle.postprocess(ref, vpt.default_post_params())
     assert np.array_equal(g.output_to_host(), out8)
     g.close()
+
+
+def test_whole_path_contexts_hold_per_sample_buffers_only(vpt, oracle, scenes):
+    """A whole-path batch keeps its paths in registers: the context allocates 48 B per sample (frame sum, medium state) and the records of ONE
+    frame instead of ~290 B per resident path — a 32-frame batch at 1080p in < 5 GB (the per-bounce pipelines: 25 GB).  When the parameters
+    stop qualifying (two samples per frame) the buffers are replaced before the next batch, and the images stay the oracle's."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+
+    def free_bytes():
+        f, t = C.c_size_t(0), C.c_size_t(0)
+        assert hip.hipMemGetInfo(C.byref(f), C.byref(t)) == 0
+        return f.value
+    sc = scenes("cornell_box")
+    free0 = free_bytes()
+    g = vpt.PathTracer(1920, 1080, frames_in_flight=32)
+    g.set_scene(sc); g.set_params(vpt.default_params(max_depth=4))
+    g.render(32)
+    st = g.stats()
+    used = free0 - free_bytes()
+    assert st["frames_allocated"] == 32 and st["resident_frames"] == 1 and st["kernel_launches"]["bounce"] == 0
+    assert used < 5 * 1024 ** 3, "a 32-frame whole-path batch holds %.1f GB" % (used / 2 ** 30)
+    g.close()
+    # the same context type at a size the oracle does in seconds: whole-path batches, then two samples per frame (per-bounce kernels, records for every resident path)
+    w, h = 96, 54
+    g = vpt.PathTracer(w, h, frames_in_flight=6)
+    g.set_scene(sc)
+    p = vpt.default_params(max_depth=5)
+    g.set_params(p)
+    g.render(6)
+    assert g.stats()["resident_frames"] == 1
+    o = oracle.Oracle(sc, w, h); o.set_params(p); o.render(6); ref = o.radiance(); o.close()
+    assert np.array_equal(g.radiance(), ref)
+    p2 = vpt.default_params(max_depth=5, samples_per_frame=2)
+    g.set_params(p2); g.reset()
+    g.render(6)
+    st = g.stats()
+    assert st["resident_frames"] == 6 and st["kernel_launches"]["bounce"] > 0
+    o = oracle.Oracle(sc, w, h); o.set_params(p2); o.render(6); ref2 = o.radiance(); o.close()
+    assert np.array_equal(g.radiance(), ref2)
+    g.close()

@@ -387,6 +387,26 @@ int alloc_render_buffers(vpt_ctx* c) {
     return check_stream_slack(c);
 }
 
+// One launch per batch (kernels_path.hip k_whole): the scene rides in LDS, no media, one sample per pixel and frame.
+// VPT_PIPELINE_WHOLE asks for it; AUTO takes it wherever it applies (lab_whole_frames bounds the batch size, for the A/B).
+bool whole_possible(const vpt_ctx* c) {
+    const bool vol = !c->volumes.empty() || c->dsc.atm_on;
+    return c->has_scene && c->lds_scene && c->whole_blocks > 0 && !vol && c->P.samples_per_frame == 1u;
+}
+// ... as far as scene, parameters and configuration go (the buffers are the callers' business)
+bool whole_policy(const vpt_ctx* c, uint32_t frames) {
+    if (!whole_possible(c)) return false;
+    return c->cfg.pipeline == VPT_PIPELINE_WHOLE || (c->cfg.pipeline == VPT_PIPELINE_AUTO && frames <= c->lab_whole_frames);
+}
+// Does a batch of `frames` frames need only its per-sample buffers (48 B per sample: frame sum, medium state), not the ~290 B of records per
+// resident path?  A whole-path launch keeps its paths in registers.  vpt_config.resident_frames != 0 is the caller asking for the
+// per-bounce pipelines' regeneration: then the records are sized as asked and a batch beyond them is not a whole-path one.
+bool whole_without_records(const vpt_ctx* c, uint32_t frames) { return c->cfg.resident_frames == 0u && whole_policy(c, frames); }
+bool whole_applies(const vpt_ctx* c, uint32_t frames) {
+    if (!whole_policy(c, frames) || frames > c->frames_alloc) return false;
+    return c->cfg.resident_frames == 0u || frames <= c->resident_alloc;
+}
+
 // Frames of paths a batch of `frames` frames keeps resident.  Paths are regenerated (device_types.hpp RenderParams::regen_next) on the
 // fused and the stream pipelines; round 1's stage kernels address a path's records by slot, media batches carry per-entry media streams
 // and split-screen dispatches map launch indices to pixels per dispatch: those keep every sample of the batch resident.
@@ -399,6 +419,7 @@ bool regen_allowed(const vpt_ctx* c) {
     return true;
 }
 uint32_t resident_frames_for(const vpt_ctx* c, uint32_t frames) {
+    if (whole_without_records(c, frames)) return 1u;   // (one frame of records stays: what the context would need for a per-bounce batch of one frame)
     if (!regen_allowed(c)) return frames;
     uint64_t k = c->cfg.resident_frames;
     // 0: every sample resident — the fastest schedule on every scene measured (profiles/r04_frames_sweep.json: regeneration costs 4-9 % at
@@ -643,16 +664,6 @@ void collect_timing(vpt_ctx* c) {  // call after a stream sync
 // batch_check (host synchronisation: how many paths are still alive).  The bounce loop runs without host round-trips: every stage
 // reads its queue size from device memory, so the host only looks at the counters every few bounces (render_batch) or not at all
 // until somebody waits (vpt_render_async).
-// One launch per batch (kernels_path.hip k_whole): the scene rides in LDS, no media, one sample per pixel and frame, every sample resident.
-// VPT_PIPELINE_WHOLE asks for it; AUTO takes it wherever it applies (lab_whole_frames bounds the batch size, for the A/B).
-bool whole_possible(const vpt_ctx* c) {
-    const bool vol = !c->volumes.empty() || c->dsc.atm_on;
-    return c->has_scene && c->lds_scene && c->whole_blocks > 0 && !vol && c->P.samples_per_frame == 1u;
-}
-bool whole_applies(const vpt_ctx* c, uint32_t frames) {
-    if (!whole_possible(c) || frames > c->resident_alloc) return false;
-    return c->cfg.pipeline == VPT_PIPELINE_WHOLE || (c->cfg.pipeline == VPT_PIPELINE_AUTO && frames <= c->lab_whole_frames);
-}
 bool media_on_streams(const vpt_ctx* c) {
     const bool vol = !c->volumes.empty() || c->dsc.atm_on;
     return vol && !c->lds_scene && (c->cfg.pipeline == VPT_PIPELINE_AUTO || c->cfg.pipeline == VPT_PIPELINE_STAGED);
@@ -664,7 +675,8 @@ int batch_begin(vpt_ctx* c, uint32_t frames, uint32_t dispatch_base, BatchState&
     if (frames == 0 || frames > c->frames_alloc) return fail(c, VPT_ERR_DEVICE, "internal: batch larger than the path buffers");
     // path regeneration: only `resident` frames of the batch's samples are in flight; a lane whose sample has ended starts the same
     // pixel's sample `resident` frames later (shade_core.hpp), until the batch's samples are used up
-    const uint32_t resident = std::min(frames, c->resident_alloc);
+    const bool whole = whole_applies(c, frames);   // (keeps its paths in registers: no records, nothing to regenerate)
+    const uint32_t resident = whole ? frames : std::min(frames, c->resident_alloc);
     const bool regen = resident < frames;
     if (regen && !regen_allowed(c)) return fail(c, VPT_ERR_DEVICE, "internal: this batch needs all of its samples resident");
     c->P.regen_next = regen ? c->d_regen : nullptr;
@@ -697,7 +709,7 @@ int batch_begin(vpt_ctx* c, uint32_t frames, uint32_t dispatch_base, BatchState&
     // vote-scheduled kernels), in the fused per-bounce kernel when it rides in LDS or when the fused pipeline is asked for.
     b.media_stream = media_on_streams(c);
     b.fused = (vol && !b.media_stream) || c->cfg.pipeline == VPT_PIPELINE_FUSED || (c->cfg.pipeline == VPT_PIPELINE_AUTO && c->lds_scene) || c->cfg.pipeline == VPT_PIPELINE_WHOLE;
-    b.whole = !regen && whole_applies(c, frames);
+    b.whole = whole;
     if (c->cfg.pipeline == VPT_PIPELINE_WHOLE && !b.whole)
         return fail(c, VPT_ERR_UNSUPPORTED, "VPT_PIPELINE_WHOLE needs a scene whose BVH rides in LDS, no media, samples_per_frame == 1 and every sample of a batch resident");
     b.stream = !b.fused && !c->lds_scene && c->cfg.pipeline != VPT_PIPELINE_STAGED_R1;   // VPT_FLAG_LOCAL_HITS included: the stream kernels have validating instantiations
@@ -1572,7 +1584,7 @@ int next_batch(vpt_ctx* c, uint32_t left, uint32_t* nf) {
         if ((rc = ensure_path_buffers(c, n))) return rc;
         n = std::min(n, c->frames_alloc);   // (a size the library chose itself may have been halved)
     }
-    if (!regen_allowed(c)) n = std::min(n, c->resident_alloc);
+    if (!regen_allowed(c) && !whole_without_records(c, n)) n = std::min(n, c->resident_alloc);
     if (media_on_streams(c)) {   // media on the streams: the batch is what the media streams hold
         int rm = ensure_media_buffers(c);
         if (rm) return rm;
