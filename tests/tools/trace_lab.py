@@ -170,6 +170,9 @@ def main():
                 if any_hit:
                     continue
                 plan = [(VOTE, 256 + 16), (VOTE, (256 + 16) | (1 << 17)), (VOTE, 256 + 16), (VOTE, (256 + 16) | (1 << 17))]
+            if os.environ.get("LAB_TRI2") == "1":   # two triangles per triangle step (bit 19) against the product instantiation, alternating
+                plan = [(VOTE, 256 + 16), (VOTE, (256 + 16) | (1 << 19))] * 3
+                cull_mode = True
             if os.environ.get("LAB_PK") == "1":   # packed plane arithmetic in the node step (bit 18) against the product instantiation, alternating
                 plan = [(VOTE, 256 + 16), (VOTE, (256 + 16) | (1 << 18))] * 3
                 cull_mode = True

@@ -88,7 +88,7 @@ __global__ __launch_bounds__(kTraverseBlock, 8) void k_trace_base(DeviceScene sc
 // STRICT (VPT_FLAG_LOCAL_HITS, traverse.hpp trace_closest_strict / trace_occluded_strict): a closest-hit winner is validated when its
 // ray retires and the ray is traced again without that triangle if the hit was not local to it; an any-hit stop is validated on the spot.
 // CULL (closest-hit, four-wide tree): stale stack entries are dropped at the pop (vote.hpp LaneStack::pop_or_done_cull).
-template <bool ANY, bool COUNT, bool WIDE8, bool TUNED, bool STRICT = false, bool CULL = false, bool PK = false>
+template <bool ANY, bool COUNT, bool WIDE8, bool TUNED, bool STRICT = false, bool CULL = false, bool PK = false, bool TRI2 = false>
 __global__ __launch_bounds__(kTraverseBlock, 8) void k_trace_vote(DeviceScene sc, TraceArgs a, Counters* ctr) {
     extern __shared__ __align__(16) unsigned char smem[];
     const LaneStack S = make_lane_stack(smem, sc.stack_overflow);
@@ -142,8 +142,12 @@ __global__ __launch_bounds__(kTraverseBlock, 8) void k_trace_vote(DeviceScene sc
             }
             VPT_MARK("tri");
             if (!node_wins & at_leaf) {  // ---- triangle step: ONE triangle of the lane's leaf
-                if (COUNT) st_tris++;
-                if (ANY) { if (vote_tri_step_any<STRICT>(tris, S, cur, sp, o, d, a.tmin, a.tmax, a.tmax, 0xffffffffu)) bslot = 0u; }
+                if (COUNT) st_tris += TRI2 ? (((uint32_t)(~cur)) & 7u ? 2u : 1u) : 1u;
+                if (TRI2) {   // trace lab, bit 19: two triangles of the leaf per step
+                    if (ANY) { if (vote_tri2_step_any(tris, S, cur, sp, o, d, a.tmin, a.tmax, a.tmax, 0xffffffffu)) bslot = 0u; }
+                    else vote_tri2_step_closest(tris, S, cur, sp, o, d, a.tmin, a.tmax, best_t, bu, bv, bslot, bgid);
+                }
+                else if (ANY) { if (vote_tri_step_any<STRICT>(tris, S, cur, sp, o, d, a.tmin, a.tmax, a.tmax, 0xffffffffu)) bslot = 0u; }
                 else vote_tri_step_closest<STRICT, CULL>(tris, S, cur, sp, o, d, a.tmin, a.tmax, best_t, bu, bv, bslot, bgid, ex0, ex1);
             }
         }
@@ -577,6 +581,10 @@ void launch_trace(hipStream_t s, uint32_t blocks, uint32_t variant, bool any, bo
     else if (sc.strict_hits) {   // VPT_FLAG_LOCAL_HITS: the validating instantiations (default vote parameters; the counting ones read them from a.param)
         if (any) { if (count) hipLaunchKernelGGL((k_trace_vote<true, true, false, false, true>), g, b, lds, s, sc, a, ctr); else hipLaunchKernelGGL((k_trace_vote<true, false, false, true, true>), g, b, lds, s, sc, a, ctr); }
         else { if (count) hipLaunchKernelGGL((k_trace_vote<false, true, false, false, true>), g, b, lds, s, sc, a, ctr); else hipLaunchKernelGGL((k_trace_vote<false, false, false, true, true>), g, b, lds, s, sc, a, ctr); }
+    }
+    else if (a.tri2) {   // trace lab bit 19: two triangles per triangle step, product vote parameters
+        if (any) { if (count) hipLaunchKernelGGL((k_trace_vote<true, true, false, true, false, false, false, true>), g, b, lds, s, sc, a, ctr); else hipLaunchKernelGGL((k_trace_vote<true, false, false, true, false, false, false, true>), g, b, lds, s, sc, a, ctr); }
+        else { if (count) hipLaunchKernelGGL((k_trace_vote<false, true, false, true, false, false, false, true>), g, b, lds, s, sc, a, ctr); else hipLaunchKernelGGL((k_trace_vote<false, false, false, true, false, false, false, true>), g, b, lds, s, sc, a, ctr); }
     }
     else if (a.packed) {   // trace lab bit 18: packed plane arithmetic in the node step, product vote parameters
         if (any) { if (count) hipLaunchKernelGGL((k_trace_vote<true, true, false, true, false, false, true>), g, b, lds, s, sc, a, ctr); else hipLaunchKernelGGL((k_trace_vote<true, false, false, true, false, false, true>), g, b, lds, s, sc, a, ctr); }

@@ -231,6 +231,53 @@ __device__ __forceinline__ void vote_tri_step_closest(const BvhTri* tris, const 
     else if (CULL) S.pop_or_done_cull(sp, cur, best_t);
     else S.pop_or_done(sp, cur);
 }
+// (trace lab, bit 19) UP TO TWO triangles of the lane's leaf in one step: the second one's record is fetched with the first (a leaf's triangles are
+// consecutive) and tested behind it with the best hit the first left, i.e. exactly what two single steps would have done.
+__device__ __forceinline__ void vote_tri2_step_closest(const BvhTri* tris, const LaneStack& S, int& cur, int& sp, V3 o, V3 d, float tmin, float tmax,
+                                                       float& best_t, float& bu, float& bv, uint32_t& bslot, uint32_t& bgid) {
+    const uint32_t enc = (uint32_t)(~cur);
+    const int first = (int)(enc >> 3);
+    const uint32_t more = enc & 7u;  // triangles left after the first
+    const float4* q = reinterpret_cast<const float4*>(tris + first);
+    const float4* q2 = reinterpret_cast<const float4*>(tris + first + (more ? 1 : 0));
+    const float4 ta = q[0], tb = q[1], tc = q[2], ua = q2[0], ub = q2[1], uc = q2[2];
+    {
+        float t, u, v;
+        const bool hit = ray_triangle_flat(o, d, vptfp::v3(ta.x, ta.y, ta.z), vptfp::v3(ta.w, tb.x, tb.y), vptfp::v3(tb.z, tb.w, tc.x), tmin, tmax, t, u, v);
+        const uint32_t gid = __float_as_uint(tc.w);
+        const bool better = hit & ((bslot == 0xffffffffu) | (t < best_t) | ((t == best_t) & (gid < bgid)));
+        best_t = better ? t : best_t; bu = better ? u : bu; bv = better ? v : bv; bslot = better ? (uint32_t)first : bslot; bgid = better ? gid : bgid;
+    }
+    if (more) {
+        float t, u, v;
+        const bool hit = ray_triangle_flat(o, d, vptfp::v3(ua.x, ua.y, ua.z), vptfp::v3(ua.w, ub.x, ub.y), vptfp::v3(ub.z, ub.w, uc.x), tmin, tmax, t, u, v);
+        const uint32_t gid = __float_as_uint(uc.w);
+        const bool better = hit & ((bslot == 0xffffffffu) | (t < best_t) | ((t == best_t) & (gid < bgid)));
+        best_t = better ? t : best_t; bu = better ? u : bu; bv = better ? v : bv; bslot = better ? (uint32_t)first + 1u : bslot; bgid = better ? gid : bgid;
+    }
+    if (more >= 2u) cur = ~(int)((((uint32_t)first + 2u) << 3) | (more - 2u));
+    else S.pop_or_done(sp, cur);
+}
+__device__ __forceinline__ bool vote_tri2_step_any(const BvhTri* tris, const LaneStack& S, int& cur, int& sp, V3 o, V3 d, float tmin, float tmax, float tlim, uint32_t expect) {
+    const uint32_t enc = (uint32_t)(~cur);
+    const int first = (int)(enc >> 3);
+    const uint32_t more = enc & 7u;
+    const float4* q = reinterpret_cast<const float4*>(tris + first);
+    const float4* q2 = reinterpret_cast<const float4*>(tris + first + (more ? 1 : 0));
+    const float4 ta = q[0], tb = q[1], tc = q[2], ua = q2[0], ub = q2[1], uc = q2[2];
+    float t, u, v;
+    bool hit = ray_triangle_flat(o, d, vptfp::v3(ta.x, ta.y, ta.z), vptfp::v3(ta.w, tb.x, tb.y), vptfp::v3(tb.z, tb.w, tc.x), tmin, tmax, t, u, v);
+    bool stop = hit & ((t < tlim) | ((t == tlim) & (__float_as_uint(tc.w) < expect)));
+    if (more) {
+        hit = ray_triangle_flat(o, d, vptfp::v3(ua.x, ua.y, ua.z), vptfp::v3(ua.w, ub.x, ub.y), vptfp::v3(ub.z, ub.w, uc.x), tmin, tmax, t, u, v);
+        stop = stop | (hit & ((t < tlim) | ((t == tlim) & (__float_as_uint(uc.w) < expect))));
+    }
+    if (stop) { cur = kLaneDone; return true; }
+    if (more >= 2u) cur = ~(int)((((uint32_t)first + 2u) << 3) | (more - 2u));
+    else S.pop_or_done(sp, cur);
+    return false;
+}
+
 // One triangle of the lane's leaf, any-hit search: stops at the first triangle hit with t < tlim, or t == tlim and a
 // smaller global id than `expect` (traverse.hpp: with tlim = tmax this is plain occlusion; with tlim = t_e of the sampled
 // light triangle it decides "is the closest hit that triangle").  Returns true when the search is over.  STRICT: a triangle stops
