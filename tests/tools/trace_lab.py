@@ -170,7 +170,7 @@ def main():
                 if any_hit:
                     continue
                 plan = [(VOTE, 256 + 16), (VOTE, (256 + 16) | (1 << 17)), (VOTE, 256 + 16), (VOTE, (256 + 16) | (1 << 17))]
-            if os.environ.get("LAB_TRI2") == "1":   # two triangles per triangle step (bit 19) against the product instantiation, alternating
+            if os.environ.get("LAB_TRI2") == "1":   # the product (two triangles per triangle step) against the one-triangle step (bit 19), alternating (profiles/r04_trace_lab_tri2_*.json were taken with the bit's meaning reversed: 0x80110 = two)
                 plan = [(VOTE, 256 + 16), (VOTE, (256 + 16) | (1 << 19))] * 3
                 cull_mode = True
             if os.environ.get("LAB_PK") == "1":   # packed plane arithmetic in the node step (bit 18) against the product instantiation, alternating

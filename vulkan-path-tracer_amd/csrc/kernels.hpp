@@ -49,7 +49,7 @@ struct TraceArgs {
     uint32_t param;         // variant parameter (vote: idle lanes that trigger a fetch step; 0 = default)
     unsigned char* cls;     // closest-hit only, optional: per queue entry, the shade class of what the ray hit (kShade*; 0xff for a hole)
     uint32_t cull;          // closest-hit only: 1 = drop stale stack entries at the pop (vote.hpp pop_or_done_cull); hits are unchanged
-    uint32_t tri2;          // trace lab: 1 = up to two triangles of a leaf per triangle step (vote.hpp vote_tri2_step_*); hits are unchanged
+    uint32_t tri2;          // trace lab: 1 = ONE triangle per triangle step (round 3's step) instead of the product's up to two (vote.hpp vote_tri2_step_*); hits are unchanged
     uint32_t packed;        // trace lab: 1 = the node step's plane arithmetic in packed fp32 instructions (traverse.hpp node_entries_pk); hits are unchanged
 };
 void launch_trace(hipStream_t s, uint32_t blocks, uint32_t variant, bool any, bool count, const DeviceScene& sc, const TraceArgs& a, Counters* ctr);

@@ -143,7 +143,7 @@ __global__ __launch_bounds__(kTraverseBlock, 8) void k_trace_vote(DeviceScene sc
             VPT_MARK("tri");
             if (!node_wins & at_leaf) {  // ---- triangle step: ONE triangle of the lane's leaf
                 if (COUNT) st_tris += TRI2 ? (((uint32_t)(~cur)) & 7u ? 2u : 1u) : 1u;
-                if (TRI2) {   // trace lab, bit 19: two triangles of the leaf per step
+                if (TRI2) {   // the product instantiation: up to two triangles of the leaf per step (-3 ... -6 %, profiles/r04_trace_lab_tri2_*.json)
                     if (ANY) { if (vote_tri2_step_any(tris, S, cur, sp, o, d, a.tmin, a.tmax, a.tmax, 0xffffffffu)) bslot = 0u; }
                     else vote_tri2_step_closest(tris, S, cur, sp, o, d, a.tmin, a.tmax, best_t, bu, bv, bslot, bgid);
                 }
@@ -429,7 +429,9 @@ __global__ __launch_bounds__(kTraverseBlock, 3) void k_trace_pool(DeviceScene sc
 // LIGHT = false: visible <=> nothing is hit (ClosestHit.slang:139, 344-353).  LIGHT = true: visible <=> the closest hit is
 // the sampled triangle (ClosestHit.slang:171-176, 358-370): that triangle is tested first by its own record, then the search
 // looks for anything that beats it (traverse.hpp closest_is).
-template <bool LIGHT, bool COUNT, bool TUNED, bool STRICT = false>
+// TRI2: up to two triangles of a leaf per triangle step (vote.hpp vote_tri2_step_any: -3 ... -6 % on atrium and bust shadow rays, profiles/r04_trace_lab_tri2_*.json); the
+// product instantiation only — the counting and the validating ones keep the one-triangle step, so the visit statistics stay what a ray needs.
+template <bool LIGHT, bool COUNT, bool TUNED, bool STRICT = false, bool TRI2 = false>
 __global__ __launch_bounds__(kTraverseBlock, 8) void k_trace_shadow(DeviceScene sc, const float4* RO, const float4* RD, unsigned char* vis, const uint32_t* n_dev,
                                                                   uint32_t* head, Counters* ctr, uint32_t param) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -471,7 +473,8 @@ __global__ __launch_bounds__(kTraverseBlock, 8) void k_trace_shadow(DeviceScene 
             VPT_MARK("tri");
             if (!node_wins & at_leaf) {
                 if (COUNT) st_tris++;
-                if (vote_tri_step_any<STRICT>(tris, S, cur, sp, o, d, tmin, tmax, tlim, expect)) visible = false;
+                if (TRI2) { if (vote_tri2_step_any(tris, S, cur, sp, o, d, tmin, tmax, tlim, expect)) visible = false; }
+                else if (vote_tri_step_any<STRICT>(tris, S, cur, sp, o, d, tmin, tmax, tlim, expect)) visible = false;
             }
         }
         VPT_MARK("exit");
@@ -547,8 +550,8 @@ int trace_blocks_per_cu(uint32_t variant, bool any) {
         if (any) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_vote<true, false, true, false>, kTraverseBlock, lds);
         else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_vote<false, false, true, false>, kTraverseBlock, lds);
     } else {
-        if (any) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_vote<true, false, false, true>, kTraverseBlock, lds);
-        else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_vote<false, false, false, true>, kTraverseBlock, lds);
+        if (any) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_vote<true, false, false, true, false, false, false, true>, kTraverseBlock, lds);
+        else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_vote<false, false, false, true, false, false, false, true>, kTraverseBlock, lds);
     }
     return nb > 0 ? nb : 1;
 }
@@ -582,9 +585,9 @@ void launch_trace(hipStream_t s, uint32_t blocks, uint32_t variant, bool any, bo
         if (any) { if (count) hipLaunchKernelGGL((k_trace_vote<true, true, false, false, true>), g, b, lds, s, sc, a, ctr); else hipLaunchKernelGGL((k_trace_vote<true, false, false, true, true>), g, b, lds, s, sc, a, ctr); }
         else { if (count) hipLaunchKernelGGL((k_trace_vote<false, true, false, false, true>), g, b, lds, s, sc, a, ctr); else hipLaunchKernelGGL((k_trace_vote<false, false, false, true, true>), g, b, lds, s, sc, a, ctr); }
     }
-    else if (a.tri2) {   // trace lab bit 19: two triangles per triangle step, product vote parameters
-        if (any) { if (count) hipLaunchKernelGGL((k_trace_vote<true, true, false, true, false, false, false, true>), g, b, lds, s, sc, a, ctr); else hipLaunchKernelGGL((k_trace_vote<true, false, false, true, false, false, false, true>), g, b, lds, s, sc, a, ctr); }
-        else { if (count) hipLaunchKernelGGL((k_trace_vote<false, true, false, true, false, false, false, true>), g, b, lds, s, sc, a, ctr); else hipLaunchKernelGGL((k_trace_vote<false, false, false, true, false, false, false, true>), g, b, lds, s, sc, a, ctr); }
+    else if (a.tri2 && !count) {   // trace lab bit 19: ONE triangle per triangle step (round 3's step) with the product vote parameters, for the A/B against the product's two
+        if (any) hipLaunchKernelGGL((k_trace_vote<true, false, false, true, false, false, false, false>), g, b, lds, s, sc, a, ctr);
+        else hipLaunchKernelGGL((k_trace_vote<false, false, false, true, false, false, false, false>), g, b, lds, s, sc, a, ctr);
     }
     else if (a.packed) {   // trace lab bit 18: packed plane arithmetic in the node step, product vote parameters
         if (any) { if (count) hipLaunchKernelGGL((k_trace_vote<true, true, false, true, false, false, true>), g, b, lds, s, sc, a, ctr); else hipLaunchKernelGGL((k_trace_vote<true, false, false, true, false, false, true>), g, b, lds, s, sc, a, ctr); }
@@ -594,6 +597,10 @@ void launch_trace(hipStream_t s, uint32_t blocks, uint32_t variant, bool any, bo
         if (count) hipLaunchKernelGGL((k_trace_vote<false, true, false, false, false, true>), g, b, lds, s, sc, a, ctr);
         else if (a.param == kVoteParamDefault) hipLaunchKernelGGL((k_trace_vote<false, false, false, true, false, true>), g, b, lds, s, sc, a, ctr);
         else hipLaunchKernelGGL((k_trace_vote<false, false, false, false, false, true>), g, b, lds, s, sc, a, ctr);
+    }
+    else if (a.param == kVoteParamDefault && !count) {   // the product instantiation: compile-time vote parameters, two triangles per triangle step
+        if (any) hipLaunchKernelGGL((k_trace_vote<true, false, false, true, false, false, false, true>), g, b, lds, s, sc, a, ctr);
+        else hipLaunchKernelGGL((k_trace_vote<false, false, false, true, false, false, false, true>), g, b, lds, s, sc, a, ctr);
     }
     else if (a.param == kVoteParamDefault) VPT_LV(false, true); else VPT_LV(false, false);
 #undef VPT_LV
@@ -612,11 +619,11 @@ void launch_trace_shadow(hipStream_t s, uint32_t blocks, bool light, bool count,
         else { if (count) hipLaunchKernelGGL((k_trace_shadow<false, true, false, true>), g, b, lds, s, sc, ss.SKO, ss.SKD, ss.vis_sky, &sctr->sky_len.v, &sctr->sky_head.v, ctr, param);
                else hipLaunchKernelGGL((k_trace_shadow<false, false, true, true>), g, b, lds, s, sc, ss.SKO, ss.SKD, ss.vis_sky, &sctr->sky_len.v, &sctr->sky_head.v, ctr, param); }
     } else if (light) {
-        if (tuned) VPT_LS(true, false, true, ss.LTO, ss.LTD, ss.vis_light, &sctr->light_len.v, &sctr->light_head.v);
+        if (tuned) hipLaunchKernelGGL((k_trace_shadow<true, false, true, false, true>), g, b, lds, s, sc, ss.LTO, ss.LTD, ss.vis_light, &sctr->light_len.v, &sctr->light_head.v, ctr, param);
         else if (count) VPT_LS(true, true, false, ss.LTO, ss.LTD, ss.vis_light, &sctr->light_len.v, &sctr->light_head.v);
         else VPT_LS(true, false, false, ss.LTO, ss.LTD, ss.vis_light, &sctr->light_len.v, &sctr->light_head.v);
     } else {
-        if (tuned) VPT_LS(false, false, true, ss.SKO, ss.SKD, ss.vis_sky, &sctr->sky_len.v, &sctr->sky_head.v);
+        if (tuned) hipLaunchKernelGGL((k_trace_shadow<false, false, true, false, true>), g, b, lds, s, sc, ss.SKO, ss.SKD, ss.vis_sky, &sctr->sky_len.v, &sctr->sky_head.v, ctr, param);
         else if (count) VPT_LS(false, true, false, ss.SKO, ss.SKD, ss.vis_sky, &sctr->sky_len.v, &sctr->sky_head.v);
         else VPT_LS(false, false, false, ss.SKO, ss.SKD, ss.vis_sky, &sctr->sky_len.v, &sctr->sky_head.v);
     }
@@ -625,8 +632,8 @@ void launch_trace_shadow(hipStream_t s, uint32_t blocks, bool light, bool count,
 int trace_shadow_blocks_per_cu() {
     int a = 0, b = 0;
     const size_t lds = kVoteLdsBytes;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_trace_shadow<true, false, true>, kTraverseBlock, lds);
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_trace_shadow<false, false, true>, kTraverseBlock, lds);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_trace_shadow<true, false, true, false, true>, kTraverseBlock, lds);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_trace_shadow<false, false, true, false, true>, kTraverseBlock, lds);
     int nb = a < b ? a : b;
     return nb > 0 ? nb : 1;
 }

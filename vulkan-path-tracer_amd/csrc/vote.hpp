@@ -231,7 +231,7 @@ __device__ __forceinline__ void vote_tri_step_closest(const BvhTri* tris, const 
     else if (CULL) S.pop_or_done_cull(sp, cur, best_t);
     else S.pop_or_done(sp, cur);
 }
-// (trace lab, bit 19) UP TO TWO triangles of the lane's leaf in one step: the second one's record is fetched with the first (a leaf's triangles are
+// UP TO TWO triangles of the lane's leaf in one step (the product instantiations of the closest-hit and the shadow kernels; trace-lab bit 19 selects the one-triangle step for the A/B): the second one's record is fetched with the first (a leaf's triangles are
 // consecutive) and tested behind it with the best hit the first left, i.e. exactly what two single steps would have done.
 __device__ __forceinline__ void vote_tri2_step_closest(const BvhTri* tris, const LaneStack& S, int& cur, int& sp, V3 o, V3 d, float tmin, float tmax,
                                                        float& best_t, float& bu, float& bv, uint32_t& bslot, uint32_t& bgid) {

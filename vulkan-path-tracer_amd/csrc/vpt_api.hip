@@ -2158,7 +2158,7 @@ int vpt_lab_trace(vpt_ctx* c, uint32_t variant, uint32_t any_hit, const uint32_t
     a.ro = c->lab_ro; a.rd = c->lab_rd; a.order = order ? c->lab_order : nullptr; a.hit = c->lab_hit; a.hinst = c->lab_hinst;
     a.n = n; a.head = &c->ctr->extend_head; a.tmin = c->lab_tmin; a.tmax = c->lab_tmax; a.normalize_dir = 0u; a.param = variant == VPT_TRACE_POOL ? param : param & 0xfff1ffffu;
     a.cull = variant == VPT_TRACE_VOTE ? (param >> 17) & 1u : 0u;     // lab: bit 17 = stale-entry culling (closest-hit, VPT_TRACE_VOTE)
-    a.tri2 = variant == VPT_TRACE_VOTE ? (param >> 19) & 1u : 0u;     // lab: bit 19 = two triangles per triangle step (VPT_TRACE_VOTE, product vote parameters)
+    a.tri2 = variant == VPT_TRACE_VOTE ? (param >> 19) & 1u : 0u;     // lab: bit 19 = one triangle per triangle step, as before round 4 (VPT_TRACE_VOTE, product vote parameters)
     a.packed = variant == VPT_TRACE_VOTE ? (param >> 18) & 1u : 0u;   // lab: bit 18 = packed plane arithmetic in the node step (VPT_TRACE_VOTE, product vote parameters)
     // (the pool variant's spill region is indexed by slot: 512 slots per block against 256 threads)
     const uint32_t blocks = (uint32_t)std::min(trace_blocks_per_cu(variant, any_hit != 0) * c->cu_count, variant == VPT_TRACE_POOL ? c->max_blocks / 2 : c->max_blocks);
