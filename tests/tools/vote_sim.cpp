@@ -81,6 +81,10 @@ int main(int argc, char** argv) {
         {"stash 4, vote 4.0", 4, 16, 24, 28, 16, false, 1, 64},
         {"stash 1, vote 2.0, fetch at 8", 1, 8, 8, 14, 8, false, 1, 64},
         {"product, 2 triangles per step", 0, 8, 24, 0, 70, false, 2, 64},
+        {"2 triangles per step, vote 1.5", 0, 6, 24, 0, 70, false, 2, 64},
+        {"2 triangles per step, vote 1.0", 0, 4, 24, 0, 70, false, 2, 64},
+        {"2 triangles per step, vote 3.0", 0, 12, 24, 0, 70, false, 2, 64},
+        {"4 triangles per step, vote 1.0", 0, 4, 24, 0, 210, false, 4, 64},
         {"pool 80, fetch at 16", 0, 8, 16, 20, 20, false, 1, 80},
         {"pool 96, fetch at 24", 0, 8, 24, 20, 20, false, 1, 96},
         {"pool 96, fetch at 32", 0, 8, 32, 20, 20, false, 1, 96},
