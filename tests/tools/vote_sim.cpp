@@ -41,6 +41,7 @@ struct Policy {
     int node_extra, tri_extra;   // VALU a step costs more than the product's (stash bookkeeping)
     bool drain_first;   // a triangle step wins outright while some lane can do nothing else and holds a full stash
     int tri_per_step;   // triangles of ONE leaf a triangle step tests (1: the product)
+    int pair;           // 1 (with pool 128): lane i owns slots i and i + 64 — two rays in its registers — and serves at most one of them per step
     int pool;           // ray slots per wave (64: a ray lives in a lane's registers, the product).  More: rays live in LDS slots and a step runs on
                         // up to 64 of the slots that want it (lanes are workers, not owners)
 };
@@ -69,29 +70,31 @@ int main(int argc, char** argv) {
     printf("%s: %zu rays, %zu triangles, %zu nodes, depth %d\n", argv[3], nrays, leaf.size(), nodes.size(), depth);
     const int node_cost = any ? 133 : 155, tri_cost = any ? 91 : 97, fetch_cost = 148;
     const Policy policies[] = {
-        {"product (vote 2.0, fetch at 24)", 0, 8, 24, 0, 0, false, 1, 64},
-        {"product, fetch at 8", 0, 8, 8, 0, 0, false, 1, 64},
-        {"product, vote 1.0", 0, 4, 24, 0, 0, false, 1, 64},
-        {"stash 1, vote 2.0", 1, 8, 24, 14, 8, false, 1, 64},
-        {"stash 1, vote 1.0", 1, 4, 24, 14, 8, false, 1, 64},
-        {"stash 1, vote 4.0", 1, 16, 24, 14, 8, false, 1, 64},
-        {"stash 1, vote 2.0, drain first", 1, 8, 24, 14, 8, true, 1, 64},
-        {"stash 2, vote 2.0", 2, 8, 24, 20, 12, false, 1, 64},
-        {"stash 2, vote 4.0", 2, 16, 24, 20, 12, false, 1, 64},
-        {"stash 4, vote 4.0", 4, 16, 24, 28, 16, false, 1, 64},
-        {"stash 1, vote 2.0, fetch at 8", 1, 8, 8, 14, 8, false, 1, 64},
-        {"product, 2 triangles per step", 0, 8, 24, 0, 70, false, 2, 64},
-        {"2 triangles per step, vote 1.5", 0, 6, 24, 0, 70, false, 2, 64},
-        {"2 triangles per step, vote 1.0", 0, 4, 24, 0, 70, false, 2, 64},
-        {"2 triangles per step, vote 3.0", 0, 12, 24, 0, 70, false, 2, 64},
-        {"4 triangles per step, vote 1.0", 0, 4, 24, 0, 210, false, 4, 64},
-        {"pool 80, fetch at 16", 0, 8, 16, 20, 20, false, 1, 80},
-        {"pool 96, fetch at 24", 0, 8, 24, 20, 20, false, 1, 96},
-        {"pool 96, fetch at 32", 0, 8, 32, 20, 20, false, 1, 96},
-        {"pool 128, fetch at 32", 0, 8, 32, 20, 20, false, 1, 128},
-        {"pool 128, fetch at 48", 0, 8, 48, 20, 20, false, 1, 128},
-        {"pool 128, vote 4.0, fetch at 48", 0, 16, 48, 20, 20, false, 1, 128},
-        {"pool 192, fetch at 64", 0, 8, 64, 20, 20, false, 1, 192},
+        {"product (vote 2.0, fetch at 24)", 0, 8, 24, 0, 0, false, 1, 0, 64},
+        {"product, fetch at 8", 0, 8, 8, 0, 0, false, 1, 0, 64},
+        {"product, vote 1.0", 0, 4, 24, 0, 0, false, 1, 0, 64},
+        {"stash 1, vote 2.0", 1, 8, 24, 14, 8, false, 1, 0, 64},
+        {"stash 1, vote 1.0", 1, 4, 24, 14, 8, false, 1, 0, 64},
+        {"stash 1, vote 4.0", 1, 16, 24, 14, 8, false, 1, 0, 64},
+        {"stash 1, vote 2.0, drain first", 1, 8, 24, 14, 8, true, 1, 0, 64},
+        {"stash 2, vote 2.0", 2, 8, 24, 20, 12, false, 1, 0, 64},
+        {"stash 2, vote 4.0", 2, 16, 24, 20, 12, false, 1, 0, 64},
+        {"stash 4, vote 4.0", 4, 16, 24, 28, 16, false, 1, 0, 64},
+        {"stash 1, vote 2.0, fetch at 8", 1, 8, 8, 14, 8, false, 1, 0, 64},
+        {"product, 2 triangles per step", 0, 8, 24, 0, 70, false, 2, 0, 64},
+        {"2 triangles per step, vote 1.5", 0, 6, 24, 0, 70, false, 2, 0, 64},
+        {"2 triangles per step, vote 1.0", 0, 4, 24, 0, 70, false, 2, 0, 64},
+        {"2 triangles per step, vote 3.0", 0, 12, 24, 0, 70, false, 2, 0, 64},
+        {"4 triangles per step, vote 1.0", 0, 4, 24, 0, 210, false, 4, 0, 64},
+        {"pool 80, fetch at 16", 0, 8, 16, 20, 20, false, 1, 0, 80},
+        {"pool 96, fetch at 24", 0, 8, 24, 20, 20, false, 1, 0, 96},
+        {"pool 96, fetch at 32", 0, 8, 32, 20, 20, false, 1, 0, 96},
+        {"pool 128, fetch at 32", 0, 8, 32, 20, 20, false, 1, 0, 128},
+        {"pool 128, fetch at 48", 0, 8, 48, 20, 20, false, 1, 0, 128},
+        {"pool 128, vote 4.0, fetch at 48", 0, 16, 48, 20, 20, false, 1, 0, 128},
+        {"pool 192, fetch at 64", 0, 8, 64, 20, 20, false, 1, 0, 192},
+        {"two rays per lane (registers), fetch at 48", 0, 8, 48, 28, 28, false, 1, 1, 128},
+        {"two rays per lane, 2 triangles per step", 0, 8, 48, 28, 98, false, 2, 1, 128},
     };
     std::vector<float> ref_t(nrays); std::vector<int> ref_g(nrays);
     for (size_t pi = 0; pi < sizeof(policies) / sizeof(policies[0]); pi++) {
@@ -139,17 +142,35 @@ int main(int argc, char** argv) {
                 if (next >= nrays) exhausted = true;
                 continue;
             }
+            if (P.pair) {   // the vote counts LANES that could take each kind of step
+                nn = 0; nl = 0;
+                for (int i = 0; i < 64; i++) {
+                    nn += (L[i].cur < kDone && L[i].cur >= 0) || (L[i + 64].cur < kDone && L[i + 64].cur >= 0);
+                    nl += L[i].cur < 0 || L[i + 64].cur < 0;
+                }
+            }
             bool node_wins = 4 * std::min(nn, 64) > P.w4 * std::min(nl, 64);   // (a step serves 64 slots at most)
-            if (pool > 64) node_wins = (nn >= 64 && nl < 64) ? true : (nl >= 64 && nn < 64) ? false : 4 * nn > P.w4 * nl;
+            if (pool > 64 && !P.pair) node_wins = (nn >= 64 && nl < 64) ? true : (nl >= 64 && nn < 64) ? false : 4 * nn > P.w4 * nl;
             if (P.drain_first && stuck > 0 && nl > 0) { bool full = false; for (Lane& l : L) full |= (l.cur < 0 && l.ns == P.stash); if (full && nn < 48) node_wins = false; }
             if (nl == 0) node_wins = true;
             if (nn == 0) node_wins = false;
             idle_lane_steps += pool - busy_lanes;
             if (node_wins) {
-                n_node_steps++; part_node += std::min(nn, 64);
+                n_node_steps++;
+                std::vector<char> take(L.size(), 1);
+                if (P.pair) {   // a lane serves one of its two slots
+                    int lanes_busy = 0;
+                    for (int i = 0; i < 64; i++) {
+                        const bool a0 = L[i].cur < kDone && L[i].cur >= 0, a1 = L[i + 64].cur < kDone && L[i + 64].cur >= 0;
+                        take[i] = a0; take[i + 64] = !a0 && a1; lanes_busy += a0 || a1;
+                    }
+                    part_node += lanes_busy;
+                } else part_node += std::min(nn, 64);
                 int served = 0;
-                for (Lane& l : L) {
+                for (size_t li = 0; li < L.size(); li++) {
+                    Lane& l = L[li];
                     if (!(l.cur < kDone && l.cur >= 0)) continue;
+                    if (!take[li]) continue;
                     if (++served > 64) break;
                     visits++;
                     float t[4]; entries(nodes[l.cur], l.s, l.tmin, l.best, t);
@@ -166,10 +187,21 @@ int main(int argc, char** argv) {
                     set_aside(l);
                 }
             } else {
-                n_tri_steps++; part_tri += std::min(nl, 64);
+                n_tri_steps++;
+                std::vector<char> take(L.size(), 1);
+                if (P.pair) {
+                    int lanes_busy = 0;
+                    for (int i = 0; i < 64; i++) {
+                        const bool a0 = L[i].cur < 0, a1 = L[i + 64].cur < 0;
+                        take[i] = a0; take[i + 64] = !a0 && a1; lanes_busy += a0 || a1;
+                    }
+                    part_tri += lanes_busy;
+                } else part_tri += std::min(nl, 64);
                 int served = 0;
-                for (Lane& l : L) {
+                for (size_t li = 0; li < L.size(); li++) {
+                    Lane& l = L[li];
                     if (!(l.cur < kDone && (l.cur < 0 || l.ns > 0))) continue;
+                    if (!take[li]) continue;
                     if (++served > 64) break;
                     const bool own = l.cur < 0;
                     int code = own ? l.cur : l.stash[l.ns - 1];
