@@ -484,6 +484,8 @@ int vpt_trace_rays(vpt_ctx* ctx, const vpt_ray* rays_host, uint32_t n, vpt_hit* 
                             * workers, not owners of a ray; kernels_trace.hip k_trace_pool).  param: low byte = idle slots that trigger a fetch (0: 5/16 of the pool); bits 8-9 = slots per wave /
                             * LDS stack entries 128/10, 96/10, 80/8, 64/8 (3-6 blocks per CU); bit 10 = a node step and a triangle step per iteration, loads
                             * of both in flight together; bits 16-21 = slots at leaves that make such an iteration carry the triangle step (0: 32) */
+#define VPT_TRACE_PAIR 4u  /* closest hit only: every lane keeps TWO rays in its registers and serves, in a step of the voted kind, whichever of them wants it
+                            * (kernels_trace.hip k_trace_pair).  param: low byte = idle rays (of 128 per wave) that trigger a fetch (0: 48) */
 int vpt_lab_set_rays(vpt_ctx* ctx, const vpt_ray* rays_host, uint32_t n);
 /* Measurement hook on the scheduling of pipelined 1-frame batches (vpt_render_async; tests/tools/latency_probe.py): images never depend on it.
  *   VPT_LAB_LANES       lanes consecutive frames are dealt to (1-3; default 3: a frame takes the first lane whose previous frame is resolved)

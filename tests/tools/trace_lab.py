@@ -23,7 +23,7 @@ sys.path.insert(0, ROOT)
 vpt = importlib.import_module("vulkan-path-tracer_amd")
 
 W, H = 1920, 1080
-BASE, VOTE, VOTE8, POOL = 0, 1, 2, 3
+BASE, VOTE, VOTE8, POOL, PAIR = 0, 1, 2, 3, 4
 
 
 def world_triangles(sc):
@@ -170,6 +170,11 @@ def main():
                 if any_hit:
                     continue
                 plan = [(VOTE, 256 + 16), (VOTE, (256 + 16) | (1 << 17)), (VOTE, 256 + 16), (VOTE, (256 + 16) | (1 << 17))]
+            if os.environ.get("LAB_PAIR") == "1":   # two rays per lane in registers (k_trace_pair, closest hit; param = idle rays of 128 that trigger a fetch) against the product kernel
+                if any_hit:
+                    continue
+                plan = [(VOTE, 256 + 16), (PAIR, 0), (PAIR, 32), (PAIR, 64), (VOTE, 256 + 16), (PAIR, 0)]
+                cull_mode = True
             if os.environ.get("LAB_TRI2") == "1":   # the product (two triangles per triangle step) against the one-triangle step (bit 19), alternating (profiles/r04_trace_lab_tri2_*.json were taken with the bit's meaning reversed: 0x80110 = two)
                 plan = [(VOTE, 256 + 16), (VOTE, (256 + 16) | (1 << 19))] * 3
                 cull_mode = True
@@ -189,7 +194,7 @@ def main():
                     ref = hits
                 same = bool(np.array_equal(hits["t"], ref["t"]) and np.array_equal(hits["u"], ref["u"]) and np.array_equal(hits["v"], ref["v"]) and
                             np.array_equal(hits["primitive"], ref["primitive"]) and np.array_equal(hits["instance"], ref["instance"]))
-                r = {"scene": which, "set": name, "rays": len(rays), "any_hit": any_hit, "order": oname, "variant": ["base", "vote", "vote_bvh8", "pool"][variant], "param": param,
+                r = {"scene": which, "set": name, "rays": len(rays), "any_hit": any_hit, "order": oname, "variant": ["base", "vote", "vote_bvh8", "pool", "pair"][variant], "param": param,
                      "ms": round(ms, 4), "grays_per_s": round(len(rays) / ms / 1e6, 3), "equal_to_reference": same,
                      "hit_fraction": round(float((ref["t"] > 0).mean()), 4)}
                 if vis:

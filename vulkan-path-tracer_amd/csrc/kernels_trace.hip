@@ -425,6 +425,106 @@ __global__ __launch_bounds__(kTraverseBlock, 3) void k_trace_pool(DeviceScene sc
     }
 }
 
+// ------------------------------------------------------------------ two rays per lane (trace lab variant VPT_TRACE_PAIR, closest hit)
+// The pool's idea without its LDS traffic: a lane keeps TWO rays in its registers and, in a step of the voted kind, serves whichever of them wants it
+// (the first if both do).  A lane then takes part in a node step when either ray stands at a node (0.66 -> 0.88 of the lanes by the model,
+// tests/tools/vote_sim "two rays per lane": -8 ... -12 % VALU per ray on top of the two-triangle step).  The price: the select of ~14 state registers into
+// the step and the write-back behind it, 17 more live registers, a second stack per lane in LDS.  Results are per ray: bit-identical hits by the lab's check.
+constexpr size_t kPairLdsBytes = 2 * kVoteStackBytes;
+struct RayRegs {
+    int cur, sp;
+    uint32_t rid, bslot, bgid;
+    V3 o, d, inv;
+    float best_t, bu, bv;
+};
+template <bool COUNT>
+__global__ __launch_bounds__(kTraverseBlock, 5) void k_trace_pair(DeviceScene sc, TraceArgs a, Counters* ctr) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint32_t* const stk0 = reinterpret_cast<uint32_t*>(smem) + threadIdx.x;
+    uint32_t* const stk1 = stk0 + kVoteStackRows * kTraverseBlock;
+    uint32_t* const ovf0 = sc.stack_overflow + (size_t)(blockIdx.x * blockDim.x + threadIdx.x) * 2u * kStackOverflow;
+    const BvhNode* const nodes = sc.nodes;
+    const BvhTri* const tris = sc.tris;
+    TreeTop top; top.lds = nullptr; top.count = 0;
+    const uint32_t n = a.n_dev ? *a.n_dev : a.n;
+    const uint32_t chunk = fetch_chunk(n);
+    const uint32_t fetch_at = (a.param & 0xffu) ? (a.param & 0xffu) : 48u;   // idle RAYS (of 128) that trigger a fetch step
+    const uint32_t n_static = gridDim.x * (kTraverseBlock / 64u) * 128u;     // every wave starts on its own 128 entries, no atomic
+    uint32_t w_next = __builtin_amdgcn_readfirstlane((blockIdx.x * (kTraverseBlock / 64u) + (threadIdx.x >> 6)) * 128u), w_end = w_next + 128u < n ? w_next + 128u : n;
+    if (w_next >= n) { w_next = 0u; w_end = 0u; }
+    bool exhausted = false;
+    RayRegs r0, r1;
+    r0.cur = kLaneIdle; r0.sp = 0; r0.rid = 0u; r0.bslot = 0xffffffffu; r0.bgid = 0xffffffffu; r0.o = vptfp::v3(0.0f, 0.0f, 0.0f); r0.d = r0.o; r0.inv = r0.o; r0.best_t = 0.0f; r0.bu = 0.0f; r0.bv = 0.0f;
+    r1 = r0;
+    uint32_t st_nodes = 0u, st_tris = 0u;
+    auto retire_and_refill = [&](RayRegs& r) {   // every lane of the wave calls
+        if (r.cur == kLaneDone) { (void)store_closest(a, tris, r.rid, r.bslot != 0xffffffffu, r.best_t, r.bu, r.bv, r.bslot); r.cur = kLaneIdle; }
+        if (exhausted) return;
+        if (w_next >= w_end) {
+            if (n_static >= n) exhausted = true;
+            else {
+                uint32_t base = 0u;
+                if (lane_id() == 0u) base = atomicAdd(a.head, chunk);
+                base = n_static + __builtin_amdgcn_readfirstlane(base);
+                if (base >= n) exhausted = true;
+                else { w_next = base; w_end = base + chunk < n ? base + chunk : n; }
+            }
+        }
+        if (exhausted) return;
+        const unsigned long long m_idle = __ballot(r.cur == kLaneIdle);
+        const uint32_t i = w_next + lanes_below(m_idle);
+        if (r.cur == kLaneIdle && i < w_end) {
+            r.rid = a.order ? a.order[i] : i;
+            r.o = xyz4(ld_stream(&a.ro[r.rid]));
+            r.d = xyz4(ld_stream(&a.rd[r.rid]));
+            if (a.normalize_dir) r.d = vptfp::normalize(r.d);
+            r.inv = safe_inverse(r.d);
+            r.best_t = a.tmax; r.bslot = 0xffffffffu; r.bgid = 0xffffffffu; r.sp = 0; r.cur = 0;
+        }
+        const uint32_t want = (uint32_t)__popcll(m_idle), left = w_end - w_next;
+        w_next += want < left ? want : left;
+    };
+    while (true) {
+        const bool n0 = r0.cur >= 0 && r0.cur < kLaneDone, n1 = r1.cur >= 0 && r1.cur < kLaneDone, l0 = r0.cur < 0, l1 = r1.cur < 0;
+        const uint32_t nn = (uint32_t)__popcll(__ballot(n0 | n1)), nl = (uint32_t)__popcll(__ballot(l0 | l1));
+        const uint32_t busy = (uint32_t)(__popcll(__ballot(n0 | l0)) + __popcll(__ballot(n1 | l1)));
+        if ((!exhausted && 128u - busy >= fetch_at) || busy == 0u) {
+            retire_and_refill(r0);
+            retire_and_refill(r1);
+            if (exhausted && __ballot(r0.cur < kLaneDone) == 0ull && __ballot(r1.cur < kLaneDone) == 0ull) break;
+            continue;
+        }
+        const bool node_wins = 4u * nn > kVoteWeight4 * nl;
+        const bool take0 = node_wins ? n0 : l0, take1 = !take0 && (node_wins ? n1 : l1);
+        if (take0 | take1) {
+            // the served ray into the step's registers
+            int cur = take0 ? r0.cur : r1.cur, sp = take0 ? r0.sp : r1.sp;
+            const V3 o = vptfp::v3(take0 ? r0.o.x : r1.o.x, take0 ? r0.o.y : r1.o.y, take0 ? r0.o.z : r1.o.z);
+            float best_t = take0 ? r0.best_t : r1.best_t;
+            LaneStack S; S.stk = take0 ? stk0 : stk1; S.ovf = ovf0 + (take0 ? 0 : kStackOverflow); S.tq = nullptr;
+            if (node_wins) {
+                if (COUNT) st_nodes++;
+                const V3 inv = vptfp::v3(take0 ? r0.inv.x : r1.inv.x, take0 ? r0.inv.y : r1.inv.y, take0 ? r0.inv.z : r1.inv.z);
+                vote_node_step<false, false, false>(nodes, top, S, cur, sp, o, inv, a.tmin, best_t);
+            } else {
+                if (COUNT) st_tris += (((uint32_t)(~cur)) & 7u) ? 2u : 1u;
+                const V3 d = vptfp::v3(take0 ? r0.d.x : r1.d.x, take0 ? r0.d.y : r1.d.y, take0 ? r0.d.z : r1.d.z);
+                float bu = take0 ? r0.bu : r1.bu, bv = take0 ? r0.bv : r1.bv;
+                uint32_t bslot = take0 ? r0.bslot : r1.bslot, bgid = take0 ? r0.bgid : r1.bgid;
+                vote_tri2_step_closest(tris, S, cur, sp, o, d, a.tmin, a.tmax, best_t, bu, bv, bslot, bgid);
+                if (take0) { r0.best_t = best_t; r0.bu = bu; r0.bv = bv; r0.bslot = bslot; r0.bgid = bgid; }
+                else { r1.best_t = best_t; r1.bu = bu; r1.bv = bv; r1.bslot = bslot; r1.bgid = bgid; }
+            }
+            if (take0) { r0.cur = cur; r0.sp = sp; } else { r1.cur = cur; r1.sp = sp; }
+        }
+    }
+    // (the loop leaves with every ray retired: the fetch step that found nothing busy stored the last results)
+    if (COUNT) {
+        atomicAdd(&ctr->stat_nodes, (unsigned long long)st_nodes);
+        atomicAdd(&ctr->stat_tris, (unsigned long long)st_tris);
+    }
+}
+
 // ------------------------------------------------------------------ shadow rays
 // LIGHT = false: visible <=> nothing is hit (ClosestHit.slang:139, 344-353).  LIGHT = true: visible <=> the closest hit is
 // the sampled triangle (ClosestHit.slang:171-176, 358-370): that triangle is tested first by its own record, then the search
@@ -538,6 +638,10 @@ __global__ __launch_bounds__(kTraverseBlock, 8) void k_trace_shadow(DeviceScene 
 // ------------------------------------------------------------------ launch
 int trace_blocks_per_cu(uint32_t variant, bool any) {
     int nb = 0;
+    if (variant == VPT_TRACE_PAIR) {
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_pair<false>, kTraverseBlock, kPairLdsBytes);
+        return nb > 0 ? nb : 1;
+    }
     if (variant == VPT_TRACE_POOL) {   // (the 128-slot form: 3 blocks per CU; the launch scales the grid for the smaller pools)
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_pool<false, 128, 10, false>, kTraverseBlock, pool_lds_bytes(128, 10));
         return nb > 0 ? nb : 1;
@@ -557,6 +661,11 @@ int trace_blocks_per_cu(uint32_t variant, bool any) {
 }
 
 void launch_trace(hipStream_t s, uint32_t blocks, uint32_t variant, bool any, bool count, const DeviceScene& sc, const TraceArgs& a, Counters* ctr) {
+    if (variant == VPT_TRACE_PAIR) {   // closest hit only
+        if (count) hipLaunchKernelGGL((k_trace_pair<true>), dim3(blocks), dim3(kTraverseBlock), kPairLdsBytes, s, sc, a, ctr);
+        else hipLaunchKernelGGL((k_trace_pair<false>), dim3(blocks), dim3(kTraverseBlock), kPairLdsBytes, s, sc, a, ctr);
+        return;
+    }
     if (variant == VPT_TRACE_POOL) {   // closest hit only (the lab refuses the any-hit form).  param bits 8-9: slots per wave / LDS stack entries 128/10, 96/10, 80/8, 64/8
         // (3, 4, 5, 6 blocks per CU: the grid — and with it the slot-indexed spill region — keeps blocks x slots constant); bit 10: DUAL
         const uint32_t cfg = (a.param >> 8) & 3u;

@@ -2137,8 +2137,8 @@ int vpt_lab_set_rays(vpt_ctx* c, const vpt_ray* rays, uint32_t n) {
 }
 int vpt_lab_trace(vpt_ctx* c, uint32_t variant, uint32_t any_hit, const uint32_t* order, uint32_t param, uint32_t reps, vpt_hit* hits, float* best_ms,
                   uint64_t* visits) {
-    if (!c || variant > VPT_TRACE_POOL || reps == 0) return VPT_ERR_INVALID_ARGUMENT;
-    if (variant == VPT_TRACE_POOL && any_hit) return fail(c, VPT_ERR_UNSUPPORTED, "VPT_TRACE_POOL is a closest-hit variant");
+    if (!c || variant > VPT_TRACE_PAIR || reps == 0) return VPT_ERR_INVALID_ARGUMENT;
+    if ((variant == VPT_TRACE_POOL || variant == VPT_TRACE_PAIR) && any_hit) return fail(c, VPT_ERR_UNSUPPORTED, "VPT_TRACE_POOL / _PAIR are closest-hit variants");
     if (!c->has_scene) return fail(c, VPT_ERR_NO_SCENE, "no scene");
     if (c->lds_scene) return fail(c, VPT_ERR_UNSUPPORTED, "the trace lab runs on scenes whose BVH lives in memory");
     if (c->lab_n == 0) return fail(c, VPT_ERR_INVALID_ARGUMENT, "vpt_lab_trace before vpt_lab_set_rays");
@@ -2156,12 +2156,12 @@ int vpt_lab_trace(vpt_ctx* c, uint32_t variant, uint32_t any_hit, const uint32_t
     if (order) HIPCHK(c, hipMemcpy(c->lab_order, order, (size_t)n * 4, hipMemcpyHostToDevice));
     TraceArgs a{};
     a.ro = c->lab_ro; a.rd = c->lab_rd; a.order = order ? c->lab_order : nullptr; a.hit = c->lab_hit; a.hinst = c->lab_hinst;
-    a.n = n; a.head = &c->ctr->extend_head; a.tmin = c->lab_tmin; a.tmax = c->lab_tmax; a.normalize_dir = 0u; a.param = variant == VPT_TRACE_POOL ? param : param & 0xfff1ffffu;
+    a.n = n; a.head = &c->ctr->extend_head; a.tmin = c->lab_tmin; a.tmax = c->lab_tmax; a.normalize_dir = 0u; a.param = (variant == VPT_TRACE_POOL || variant == VPT_TRACE_PAIR) ? param : param & 0xfff1ffffu;
     a.cull = variant == VPT_TRACE_VOTE ? (param >> 17) & 1u : 0u;     // lab: bit 17 = stale-entry culling (closest-hit, VPT_TRACE_VOTE)
     a.tri2 = variant == VPT_TRACE_VOTE ? (param >> 19) & 1u : 0u;     // lab: bit 19 = one triangle per triangle step, as before round 4 (VPT_TRACE_VOTE, product vote parameters)
     a.packed = variant == VPT_TRACE_VOTE ? (param >> 18) & 1u : 0u;   // lab: bit 18 = packed plane arithmetic in the node step (VPT_TRACE_VOTE, product vote parameters)
     // (the pool variant's spill region is indexed by slot: 512 slots per block against 256 threads)
-    const uint32_t blocks = (uint32_t)std::min(trace_blocks_per_cu(variant, any_hit != 0) * c->cu_count, variant == VPT_TRACE_POOL ? c->max_blocks / 2 : c->max_blocks);
+    const uint32_t blocks = (uint32_t)std::min(trace_blocks_per_cu(variant, any_hit != 0) * c->cu_count, (variant == VPT_TRACE_POOL || variant == VPT_TRACE_PAIR) ? c->max_blocks / 2 : c->max_blocks);
     hipEvent_t e0, e1;
     HIPCHK(c, hipEventCreate(&e0)); HIPCHK(c, hipEventCreate(&e1));
     float best = 1e30f;
