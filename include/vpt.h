@@ -185,16 +185,15 @@ typedef struct vpt_config {
     uint32_t pipeline;   /* VPT_PIPELINE_* */
     uint32_t build_flags; /* VPT_BUILD_*: how vpt_set_scene builds the BVH of this context (reported back in vpt_stats.build_flags) */
     /* Path regeneration: frames of PATHS a batch keeps in flight at a time.  A batch of F frames has F x pixels samples; with K < F resident
-     * frames a lane whose sample has ended takes the next unstarted sample of the batch in the same launch (a fresh camera ray; seeds
-     * depend on pixel and frame only, a sample's result lands in its own slot of the frame sums and the running mean is applied in frame
-     * order when the batch has finished), so every launch works on ~K x pixels paths until the samples run out — one shrinking tail per
-     * batch instead of one per frame, ~290 B per resident path + 48 B per sample instead of 380 B per sample.  It trades throughput for
-     * memory (1080p, batches of 226 frames, profiles/r04_frames_sweep.json): all 469M samples resident 149 GB; 265M paths 94 GB at -4 % (atrium)
-     * / -6 % (glass bust) / -9 % (Cornell box, whose bounce 0 otherwise runs in a kernel that reads nothing); 33M paths 33 GB at -13 / -19 /
-     * -31 %: every bounce is five dependent launches whose ramp and tail weigh more on smaller queues.  0 (default) or a value >= the batch
-     * size: every sample resident (round 3's schedule — the fastest, and with buffers that grow only to the batches actually asked
-     * for an interactive host never pays for it).  Media batches, split-screen dispatch and VPT_PIPELINE_STAGED_R1 always keep every sample resident.
-     * Images do not depend on it, bit for bit.  Reference loop being unrolled: RayGen.slang:28-33,116-159. */
+     * frames the camera-ray launch starts the first K x pixels samples, and behind every shade stage the room that ended paths left in the
+     * next ray queue is REFILLED with the batch's next unstarted samples — a contiguous run of sample ids, i.e. a block of coherent camera
+     * rays appended behind the survivors (seeds depend on pixel and frame only, a sample's result lands in its own slot of the frame sums
+     * and the running mean is applied in frame order when the batch has finished) — so every launch works on ~K x pixels paths until the
+     * samples run out: ~290 B per resident path + 48 B per sample instead of 380 B per sample.  Applies to the streams pipeline (scenes whose
+     * BVH lives in memory; VPT_PIPELINE_AUTO / _STAGED / _STAGED_SORTED).  Whole-path launches (scenes that ride in LDS) hold no path records
+     * at all, whatever this says; the fused per-bounce kernels, media batches, split-screen dispatch and VPT_PIPELINE_STAGED_R1 keep every
+     * sample resident.  0 (default) or a value >= the batch size: every sample resident.  Measured trade: profiles/r05_frames_sweep.json
+     * (DESIGN.md section 4 "Path regeneration").  Images do not depend on it, bit for bit.  Reference loop being unrolled: RayGen.slang:28-33,116-159. */
     uint32_t resident_frames;
 } vpt_config;
 
@@ -218,7 +217,8 @@ typedef struct vpt_config {
                                * For scenes whose BVH rides in LDS, no media, samples_per_frame == 1, every sample resident — VPT_ERR_UNSUPPORTED
                                * otherwise.  Bit-identical.  AUTO takes it wherever it applies: measured faster than FUSED at every batch size
                                * (Cornell box 1080p: 8.3 vs 7.4 Gsamples/s at 226 frames per batch, 3.8 vs 2.4 at one; profiles/r04_whole_ab.json) */
-#define VPT_PIPELINE_STAGED_R1 3u /* the same stages with round 1's traversal loops (64 rays per wave at a time): kept as the measured baseline */
+#define VPT_PIPELINE_STAGED_R1 3u /* LABORATORY build only (include/vpt_lab.h, libvpt_hip_lab.so): the same stages with round 1's kernels (slot-addressed records, 64 rays per
+                                   * wave at a time), kept as the measured baseline.  vpt_create of the product library answers VPT_ERR_UNSUPPORTED */
 
 #define VPT_KERNEL_COUNT 10
 enum vpt_kernel_id {
@@ -226,7 +226,7 @@ enum vpt_kernel_id {
                          * staged pipeline: raygen */
     VPT_K_EXTEND = 1,
     VPT_K_SHADE = 2,
-    VPT_K_CONNECT = 3,  /* shadow rays + light accumulation + end-of-sample in one kernel (VPT_PIPELINE_STAGED_R1) */
+    VPT_K_CONNECT = 3,  /* shadow rays + light accumulation + end-of-sample in one kernel (VPT_PIPELINE_STAGED_R1, laboratory build) */
     VPT_K_BOUNCE = 4,   /* bounce >= 1 fused (LDS-resident scenes): extend + shade + connect in one kernel */
     VPT_K_RESOLVE = 5,
     VPT_K_BLOOM = 6,
@@ -262,7 +262,7 @@ typedef struct vpt_stats {
     uint32_t emissive_triangle_count;
     uint32_t frames_in_flight;
     uint32_t shard_pixels;
-    uint32_t bvh8_nodes;       /* eight-wide nodes of the BVH8 experiment (0 until VPT_TRACE_VOTE8 was used) */
+    uint32_t bvh8_nodes;       /* laboratory build: eight-wide nodes of the BVH8 experiment (0 in the product library) */
     uint32_t build_flags;      /* VPT_BUILD_* the scene's BVH was built with */
     uint32_t frames_allocated; /* frames of samples the buffers currently hold (grows with the largest batch requested, <= frames_in_flight) */
     uint32_t resident_frames;  /* frames of paths the queues / stream records hold (vpt_config.resident_frames; < frames_allocated when paths are regenerated) */
@@ -470,40 +470,6 @@ int vpt_reset_stats(vpt_ctx* ctx);
 typedef struct vpt_ray { float origin[3]; float tmin; float direction[3]; float tmax; } vpt_ray;
 typedef struct vpt_hit { float t; float u; float v; uint32_t primitive; uint32_t instance; } vpt_hit;
 int vpt_trace_rays(vpt_ctx* ctx, const vpt_ray* rays_host, uint32_t n, vpt_hit* hits_host);
-
-/* Measurement hook on the ray-stream traversal kernels alone (the "trace lab"): keep a ray set resident on the device,
- * then time kernel variants on exactly those rays, optionally visiting them in a caller-given order (a permutation of
- * 0..n-1: e.g. sorted by origin cell and direction octant).  All rays of a set share ray 0's tmin / tmax.  Results are
- * per ray whatever the variant or order: hits_host (optional, n entries; any-hit: t = 1 occluded / -1 clear).
- * best_ms = fastest of `reps` launches (HIP events on the context's stream); visits (optional) = {nodes, triangles}
- * visited, from one extra counting launch. */
-#define VPT_TRACE_BASE 0u  /* one ray per lane, 64 rays per wave at a time (round 1's extend / shadow loop) */
-#define VPT_TRACE_VOTE 1u  /* persistent lanes, wave-level vote between node / triangle / fetch steps, ray replacement */
-#define VPT_TRACE_VOTE8 2u /* the same on an eight-wide tree with octant-ordered children (BVH8 experiment; built on first use) */
-#define VPT_TRACE_POOL 3u  /* closest hit only: a wave owns 64-128 ray slots in LDS and every step runs on up to 64 of the slots that want it (lanes are
-                            * workers, not owners of a ray; kernels_trace.hip k_trace_pool).  param: low byte = idle slots that trigger a fetch (0: 5/16 of the pool); bits 8-9 = slots per wave /
-                            * LDS stack entries 128/10, 96/10, 80/8, 64/8 (3-6 blocks per CU); bit 10 = a node step and a triangle step per iteration, loads
-                            * of both in flight together; bits 16-21 = slots at leaves that make such an iteration carry the triangle step (0: 32) */
-#define VPT_TRACE_PAIR 4u  /* closest hit only: every lane keeps TWO rays in its registers and serves, in a step of the voted kind, whichever of them wants it
-                            * (kernels_trace.hip k_trace_pair).  param: low byte = idle rays (of 128 per wave) that trigger a fetch (0: 48) */
-int vpt_lab_set_rays(vpt_ctx* ctx, const vpt_ray* rays_host, uint32_t n);
-/* Measurement hook on the scheduling of pipelined 1-frame batches (vpt_render_async; tests/tools/latency_probe.py): images never depend on it.
- *   VPT_LAB_LANES       lanes consecutive frames are dealt to (1-3; default 3: a frame takes the first lane whose previous frame is resolved)
- *   VPT_LAB_LANE_GRID   divisor of the fused kernel's persistent grid while frames are pipelined (1-3; default 1)
- *   VPT_LAB_TAIL_GRID   divisor of the grid of a 1-frame batch's bounces >= 2, whose queues hold a fraction of the frame's paths (1-3; default 3)
- *   VPT_LAB_WHOLE_FRAMES  VPT_PIPELINE_AUTO runs batches of at most this many frames as one whole-path launch where VPT_PIPELINE_WHOLE applies
- *                         (0: never — the per-bounce kernels; 0xffff: no bound, the default)
- *   VPT_LAB_WHOLE_SCHED   how a whole-path launch deals its tiles of 64 samples: low 4 bits = tiles per atomic (1-15), bits 4-5 = rounds dealt without
- *                         an atomic (0: the first, 1: all but the last, 2: half, 3: the first, and the chunks shrink towards the end of the batch).  Default 4 (first
- *                         round static, then four tiles per atomic) */
-#define VPT_LAB_LANES 1u
-#define VPT_LAB_LANE_GRID 2u
-#define VPT_LAB_TAIL_GRID 3u
-#define VPT_LAB_WHOLE_FRAMES 4u
-#define VPT_LAB_WHOLE_SCHED 5u
-int vpt_lab_set(vpt_ctx* ctx, uint32_t key, uint32_t value);
-int vpt_lab_trace(vpt_ctx* ctx, uint32_t variant, uint32_t any_hit, const uint32_t* order_host, uint32_t param, uint32_t reps,
-                  vpt_hit* hits_host, float* best_ms, uint64_t* visits);
 
 /* ---- energy-compensation lookup tables -------------------------------------------
  * Replaces LookupTableCalculator::CalculateTable(tableSize, sampleCount) (LookupTableCalculator.cpp:44-157)

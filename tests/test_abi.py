@@ -1,4 +1,5 @@
-"""The C-ABI library loads and exports every symbol include/vpt.h declares (no compute without a GPU)."""
+"""The C-ABI library loads and exports every symbol include/vpt.h declares — and NONE of the laboratory's (include/vpt_lab.h), which exist in
+libvpt_hip_lab.so only (no compute without a GPU)."""
 import ctypes as C
 import os
 import re
@@ -8,8 +9,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def header_functions():
-    src = open(os.path.join(ROOT, "include", "vpt.h")).read()
+def header_functions(name="vpt.h"):
+    src = open(os.path.join(ROOT, "include", name)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(vpt_[a-z_0-9]+)\s*\(", src)))
 
@@ -23,8 +24,28 @@ def test_library_exports_every_declared_symbol(vpt):
     lib = vpt.load_library()
     for name in header_functions():
         assert hasattr(lib, name), name
-    # and the ctypes mirror covers the whole header
-    assert sorted(vpt._abi.PROTOTYPES) == header_functions()
+    lab = header_functions("vpt_lab.h")
+    assert lab == sorted(vpt._abi.LAB_ENTRY_POINTS)
+    # and the ctypes mirror covers both headers
+    assert sorted(vpt._abi.PROTOTYPES) == sorted(header_functions() + lab)
+
+
+def test_product_library_has_no_laboratory(vpt):
+    """libvpt_hip.so: no vpt_lab_* symbol, no laboratory kernel, under 3 MB; VPT_PIPELINE_STAGED_R1 is refused at vpt_create (checked before any device is touched)."""
+    import subprocess
+    path = vpt.library_path(lab=False)
+    vpt.build(lab=False)
+    names = subprocess.check_output(["nm", "-D", path], text=True)
+    assert "vpt_lab_" not in names and "vpt_create" in names
+    blob = open(path, "rb").read()
+    for kernel in (b"k_trace_pool", b"k_trace_pair", b"k_trace_base", b"k_extend", b"k_connect", b"k_raygenE"):
+        assert kernel not in blob, kernel
+    assert len(blob) < 3 * 1024 * 1024, len(blob)
+    lib = C.CDLL(path)
+    lib.vpt_create.restype = C.c_void_p
+    err = C.c_int(0)
+    cfg = vpt._abi.Config(0, 16, 16, 0, 1, 0, 0, 0, vpt._abi.PIPELINE_STAGED_R1, 0, 0)
+    assert not lib.vpt_create(C.byref(cfg), C.byref(err)) and err.value == -6   # VPT_ERR_UNSUPPORTED
 
 
 def test_struct_layouts_match_reference_contract(vpt):

@@ -95,7 +95,7 @@ def test_async_renders_interleaved_with_material_edits(vpt, oracle, scenes):
 
 @pytest.mark.parametrize("name,depth,pipeline", [("cornell_box", 200, 0), ("cornell_box_glass", 12, 0), ("cornell_box_glass", 40, 0), ("cornell_box", 6, 2)])
 def test_async_batches_that_may_outlive_their_enqueued_bounces(vpt, oracle, scenes, name, depth, pipeline):
-    """Deeper than VPT_ASYNC_MAX_BOUNCES, the streams pipeline, round 1's stage kernels: the enqueued part is the first bounces and the
+    """Deeper than VPT_ASYNC_MAX_BOUNCES, the streams pipeline (also forced on a scene that rides in LDS): the enqueued part is the first bounces and the
     next call finishes the batch as vpt_render would have; multi-frame batches included."""
     sc, w, h = scenes(name), 96, 54
     p = vpt.default_params(max_depth=depth)

@@ -62,7 +62,7 @@ def test_spilling_stacks_with_the_two_stream_schedule(vpt, oracle):
     assert np.array_equal(img_overlap, img_serial)
     assert np.array_equal(img_overlap, ref)
     # the other pipelines share the spill path (TravStack in traverse.hpp): fused per-bounce kernel, round 1's stage kernels
-    for pipeline in (1, 3):
+    for pipeline in (1, 3) if vpt.has_lab() else (1,):
         img, st = run(pipeline=pipeline)
         assert st["stack_spills"][0] > 0
         assert np.array_equal(img, ref)

@@ -121,6 +121,11 @@ def test_auto_takes_the_whole_path_launch_wherever_it_applies(vpt, oracle, scene
     g.render(1); g.render(3)
     st = g.stats()
     assert st["kernel_launches"]["primary"] == 2 and st["kernel_launches"]["bounce"] == 0
+    if not vpt.has_lab():   # the A/B switch below is a laboratory entry point (include/vpt_lab.h)
+        g.render(3)
+        assert g.stats()["kernel_launches"]["bounce"] == 0 and np.array_equal(g.radiance(), ref)
+        g.close()
+        return
     g.lab_set(vpt._abi.LAB_WHOLE_FRAMES, 1)
     g.render(2)
     st = g.stats()

@@ -98,7 +98,9 @@ def test_multi_gpu_cli_is_bit_identical_to_one_device(cli, tmp_path, gpus):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,extra", [("cornell_box", []), ("textured_boxes", []), ("textured_boxes_jpg", []), ("cornell_box", ["--split", "2"]),
-                                        ("cornell_box", ["--split", "1", "--async"]), ("textured_boxes", ["--split", "1", "--async"])])
+                                        ("cornell_box", ["--split", "1", "--async"]), ("textured_boxes", ["--split", "1", "--async"]),
+                                        # 4 dispatches per call against a budget of 5: the second call runs one AND reports done (GetSamplesAccumulated must say 5)
+                                        ("cornell_box", ["--split", "1", "--async", "--async-step", "4"])])
 def test_render_through_the_cpp_facade_matches_the_oracle(cli, vpt, oracle, tmp_path, name, extra):
     """(--async: PathTraceAsync + PostProcessAsync per frame with a one-frame fence lag, the reference's Editor loop — Editor.cpp:116,129;
     the fused pipeline's frames go over the lanes and captured graphs, the streams pipeline's are finished by the next call.)"""

@@ -1,5 +1,6 @@
 import importlib, os, sys, time, json
 sys.path.insert(0,'.')
+os.environ.setdefault("VPT_LAB", "1")   # a laboratory tool: loads libvpt_hip_lab.so (include/vpt_lab.h)
 vpt = importlib.import_module("vulkan-path-tracer_amd")
 import numpy as np
 out = {}

@@ -5,6 +5,7 @@
 import importlib, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("VPT_LAB", "1")   # a laboratory tool: loads libvpt_hip_lab.so (include/vpt_lab.h)
 vpt = importlib.import_module("vulkan-path-tracer_amd")
 A = vpt._abi
 out_dir = os.path.join(ROOT, "gpurun_out", sys.argv[1] if len(sys.argv) > 1 else "r04")

@@ -21,17 +21,24 @@ class VptError(RuntimeError):
     pass
 
 
-def library_path():
-    return os.path.join(_HERE, "libvpt_hip.so")
+def _want_lab():
+    """VPT_LAB=1 in the environment selects the LABORATORY build (libvpt_hip_lab.so: include/vpt_lab.h, the measured-and-rejected kernel
+    variants, round 1's stage kernels).  It chooses which LIBRARY is loaded — a measuring tool's choice — never a behaviour of the product library."""
+    return os.environ.get("VPT_LAB", "0") not in ("", "0")
 
 
-def build(force=False, verbose=False):
+def library_path(lab=None):
+    lab = _want_lab() if lab is None else lab
+    return os.path.join(_HERE, "libvpt_hip_lab.so" if lab else "libvpt_hip.so")
+
+
+def build(force=False, verbose=False, lab=None):
     from . import _build as _b
-    return _b.build(force=force, verbose=verbose)
+    return _b.build(force=force, verbose=verbose, lab=_want_lab() if lab is None else lab)
 
 
 def load_library():
-    """Loads libvpt_hip.so (building it first when hipcc is available and sources are newer)."""
+    """Loads libvpt_hip.so — or libvpt_hip_lab.so with VPT_LAB=1 — building it first when hipcc is available and sources are newer."""
     global _LIB
     if _LIB is None:
         path = library_path()
@@ -39,9 +46,14 @@ def load_library():
             path = build()
         except Exception as e:  # no hipcc on this box: the prebuilt in-tree .so must exist
             if not os.path.exists(path):
-                raise VptError("libvpt_hip.so is missing and cannot be built: %s" % e)
+                raise VptError("%s is missing and cannot be built: %s" % (os.path.basename(path), e))
         _LIB = _abi.bind(C.CDLL(path))
     return _LIB
+
+
+def has_lab():
+    """True when the loaded library is the laboratory build (exports vpt_lab_*, accepts VPT_PIPELINE_STAGED_R1)."""
+    return bool(load_library().has_lab)
 
 
 def _check(lib, ctx, rc, what):
@@ -165,7 +177,9 @@ class PathTracer:
         _check(self.lib, self.ctx, self.lib.vpt_wait(self.ctx, ticket), "vpt_wait")
 
     def lab_set(self, key, value):
-        """Measurement hooks of include/vpt.h (VPT_LAB_*): scheduling only, images never depend on them."""
+        """Measurement hooks of include/vpt_lab.h (VPT_LAB_*; laboratory build only): scheduling only, images never depend on them."""
+        if not self.lib.has_lab:
+            raise VptError("vpt_lab_set: the product library has no laboratory entry points (run with VPT_LAB=1)")
         _check(self.lib, self.ctx, self.lib.vpt_lab_set(self.ctx, key, value), "vpt_lab_set")
 
     def output_device(self):

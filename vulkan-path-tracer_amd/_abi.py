@@ -250,8 +250,17 @@ PROTOTYPES = {
 COMM_ID_BYTES = 128
 
 
+LAB_ENTRY_POINTS = ("vpt_lab_set", "vpt_lab_set_rays", "vpt_lab_trace")   # include/vpt_lab.h: exported by the laboratory build only
+
+
 def bind(lib):
+    """Sets the prototypes of every entry point of include/vpt.h (all must be present) and of include/vpt_lab.h (present in
+    libvpt_hip_lab.so only); lib.has_lab says which library this is."""
+    lib.has_lab = True
     for name, (res, args) in PROTOTYPES.items():
+        if name in LAB_ENTRY_POINTS and not hasattr(lib, name):
+            lib.has_lab = False
+            continue
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args

@@ -10,9 +10,12 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libvpt_hip.so")
+# The LABORATORY build: the same sources with -DVPT_LAB=1 — every kernel variant that was measured against the product kernels and found
+# slower, round 1's stage kernels (VPT_PIPELINE_STAGED_R1) and the vpt_lab_* entry points of include/vpt_lab.h.  The product library has none of it.
+LIB_LAB = os.path.join(HERE, "libvpt_hip_lab.so")
 SOURCES = ["kernels_path.hip", "kernels_trace.hip", "kernels_stream.hip", "kernels_media.hip", "kernels_post.hip", "kernels_lut.hip", "vpt_api.hip", "bvh_build.cpp"]
 HEADERS = ["device_types.hpp", "kernels.hpp", "shading.hpp", "traverse.hpp", "bvh_build.hpp", "volume.hpp", "atmosphere.hpp", "wave.hpp", "shade_core.hpp", "vote.hpp",
-           os.path.join("..", "..", "include", "vpt.h"), os.path.join("..", "..", "include", "vpt_fp32.h")]
+           os.path.join("..", "..", "include", "vpt.h"), os.path.join("..", "..", "include", "vpt_lab.h"), os.path.join("..", "..", "include", "vpt_fp32.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wno-unused-result", "-Wno-pass-failed"]
 # Per-file additions.  The traversal kernels are VALU-issue-bound and their triangle test is 51 scalar fp32 operations: the SLP
@@ -29,27 +32,30 @@ def hipcc():
     raise RuntimeError("hipcc not found")
 
 
-def needs_build():
-    if not os.path.exists(LIB):
+def needs_build(lab=False):
+    lib = LIB_LAB if lab else LIB
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB)
+    t = os.path.getmtime(lib)
     # (this file holds the compiler flags: a change here rebuilds too)
     return os.path.getmtime(__file__) > t or any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
 
 
-def build(force=False, verbose=False):
-    if not force and not needs_build():
-        return LIB
+def build(force=False, verbose=False, lab=False):
+    lib = LIB_LAB if lab else LIB
+    if not force and not needs_build(lab):
+        return lib
     objs = []
     procs = []
-    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    objdir = os.path.join(HERE, "build", "lab" if lab else "product")
+    os.makedirs(objdir, exist_ok=True)
     newest_header = max([os.path.getmtime(__file__)] + [os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS])
     for src in SOURCES:
-        obj = os.path.join(HERE, "build", src + ".o")
+        obj = os.path.join(objdir, src + ".o")
         objs.append(obj)
         if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(newest_header, os.path.getmtime(os.path.join(CSRC, src))):
             continue   # this object is newer than its source and every header
-        cmd = [hipcc()] + FLAGS + EXTRA_FLAGS.get(src, []) + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc()] + FLAGS + ["-DVPT_LAB=%d" % (1 if lab else 0)] + EXTRA_FLAGS.get(src, []) + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
@@ -59,10 +65,10 @@ def build(force=False, verbose=False):
             raise RuntimeError("hipcc failed on %s:\n%s" % (src, out))
         if verbose and out.strip():
             print(out)
-    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs + ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib", "-Wl,--strip-all"]
     subprocess.check_call(cmd)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, lab="--lab" in sys.argv))

@@ -186,7 +186,6 @@ struct DeviceScene {
     vpt_atmosphere atm;
 };
 
-constexpr uint32_t kRegenShards = 64;
 struct RenderParams {
     float view_inv[16], proj_inv[16];
     uint32_t width, height;
@@ -197,16 +196,6 @@ struct RenderParams {
     float max_luminance, focus_distance, dof_strength;
     float sky_azimuth, sky_altitude, sky_intensity, emissive_pdf_bias;
     uint32_t flags, base_seed;
-    // Path regeneration (vpt_api.hip batch_begin): a batch of F frames keeps only K < F frames of paths resident.  A slot is a SAMPLE id
-    // (frame-in-batch * shard_pixels + shard pixel).  The camera-ray launch starts samples [0, regen_first); a lane whose sample has
-    // ended takes the next unstarted sample of the batch — dealt out by kRegenShards counters, one cache line each, shard r owning the
-    // contiguous ids [regen_first + r * regen_shard, ...) (shade_core.hpp regen_take) — and starts it with a fresh camera ray, seeded as
-    // k_raygen_stream / k_bounce<FIRST> seed it (seeds depend on pixel and frame only).  Which lane runs which sample depends on
-    // timing; nothing else does: a sample's result lands in the frame sum of its own slot and the running mean is applied in frame
-    // order when the batch has finished.  regen_next == nullptr: off (every sample of the batch is resident).
-    // batch_base = index of the batch's first dispatch (what the camera-ray kernels get as an argument).
-    struct HotWord* regen_next;
-    uint32_t regen_first, regen_total, regen_shard, batch_base;
     // Graph replays (vpt_render_async): when non-null, the batch's first dispatch index is read from here instead of the kernels'
     // dispatch_base / frame_base arguments, so that one captured batch serves every frame
     const uint32_t* dispatch_base_dev;
@@ -306,6 +295,11 @@ struct StreamCounters {
     uint32_t class_exact[kShadeClasses];    // 1: the launch appends exactly (short queue), 0: chunked with static first chunks
     uint32_t class_base[kShadeClasses];     // first entry of the launch's static chunks in every stream it appends to
     uint32_t classify_done;                 // blocks of the classify launch that have finished (the last one lays the streams out)
+    // Path regeneration by refill (vpt_config.resident_frames, kernels_stream.hip k_refill_plan): a batch of F frames keeps at most
+    // `cap` paths resident; behind every shade stage the free room of the next ray queue is filled with the batch's next unstarted
+    // samples — a CONTIGUOUS run of sample ids, i.e. coherent camera rays appended as one block — until the samples are used up.
+    uint32_t refill_next, refill_total;     // next unstarted sample id of the batch | samples of the batch (== : nothing left to start)
+    uint32_t refill_entry, refill_first, refill_count;   // the plan of the current refill: first queue entry, first sample id, how many
 };
 
 // Stream appends (vote.hpp WaveAppender): chunk size of the wave-private chunked appends, and the queue length below which a launch

@@ -1,6 +1,10 @@
 // kernels.hpp — host-callable launch wrappers of the HIP stages (definitions in kernels_*.hip).
 #pragma once
 #include "device_types.hpp"
+#include "../../include/vpt_lab.h"   // VPT_TRACE_* / VPT_LAB_* constants (the functions exist in the laboratory build only)
+#ifndef VPT_LAB
+#define VPT_LAB 0
+#endif
 
 namespace vpt {
 
@@ -49,14 +53,17 @@ struct TraceArgs {
     uint32_t param;         // variant parameter (vote: idle lanes that trigger a fetch step; 0 = default)
     unsigned char* cls;     // closest-hit only, optional: per queue entry, the shade class of what the ray hit (kShade*; 0xff for a hole)
     uint32_t cull;          // closest-hit only: 1 = drop stale stack entries at the pop (vote.hpp pop_or_done_cull); hits are unchanged
-    uint32_t tri2;          // trace lab: 1 = ONE triangle per triangle step (round 3's step) instead of the product's up to two (vote.hpp vote_tri2_step_*); hits are unchanged
+    uint32_t one_tri;       // trace lab: 1 = ONE triangle per triangle step (round 3's step) instead of the product's up to two (vote.hpp vote_tri2_step_*); hits are unchanged
     uint32_t packed;        // trace lab: 1 = the node step's plane arithmetic in packed fp32 instructions (traverse.hpp node_entries_pk); hits are unchanged
 };
 void launch_trace(hipStream_t s, uint32_t blocks, uint32_t variant, bool any, bool count, const DeviceScene& sc, const TraceArgs& a, Counters* ctr);
 int trace_blocks_per_cu(uint32_t variant, bool any);
 
 // staged pipeline on compact streams (kernels_stream.hip)
-void launch_stream_begin(hipStream_t s, StreamCounters* sc, uint32_t n_slots);
+void launch_stream_begin(hipStream_t s, StreamCounters* sc, uint32_t n_first, uint32_t n_total);
+// path regeneration by refill: the room the ended paths left in the next ray queue is filled with the batch's next unstarted samples
+void launch_refill(hipStream_t s, uint32_t blocks, const RenderParams& P, const PathState& ps, const StreamState& ss, uint32_t* queue_next, StreamCounters* sc, uint32_t parity_next,
+                   uint32_t cap, uint32_t dispatch_base);
 void launch_raygen_stream(hipStream_t s, const RenderParams& P, const PathState& ps, const StreamState& ss, uint32_t* queue, uint32_t n_slots, uint32_t dispatch_base, bool media);
 void launch_prepare_stream(hipStream_t s, StreamCounters* sc, uint32_t parity);
 void launch_classify(hipStream_t s, const uint32_t* queue, const unsigned char* cls, uint32_t* const* class_queue, StreamCounters* sc, uint32_t parity, uint32_t max_entries, uint32_t shade_waves);

@@ -21,7 +21,8 @@
 
 namespace vpt {
 
-// ------------------------------------------------------------------ raygen (staged pipeline only)
+#if VPT_LAB   // round 1's stage kernels (VPT_PIPELINE_STAGED_R1): laboratory build only
+// ------------------------------------------------------------------ raygen (round 1's staged pipeline only)
 // Scenes whose BVH does not fit in LDS run bounce 0 through the same extend / shade / connect stages as every
 // other bounce, so the camera rays are written out as ordinary path records.
 __global__ __launch_bounds__(256) void k_raygen(RenderParams P, PathState ps, uint32_t* queue, Counters* ctr, uint32_t n_slots, uint32_t dispatch_base) {
@@ -41,6 +42,8 @@ __global__ __launch_bounds__(256) void k_raygen(RenderParams P, PathState ps, ui
     if (P.samples_per_frame > 1) { ps.ACC[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); ps.sidx[slot] = 0u; }
     queue[li] = slot;
 }
+
+#endif  // VPT_LAB
 
 // ------------------------------------------------------------------ persistent work fetch
 template <bool LDS_SCENE>
@@ -77,7 +80,8 @@ __device__ inline bool light_visible(const DeviceScene& sc, const float4* lds_no
     return closest_is<COUNT>(src, o, d, 0.0001f, 1000000.0f, gid, slot, stack, st);
 }
 
-// ------------------------------------------------------------------ extend: closest hit of every queued path
+#if VPT_LAB
+// ------------------------------------------------------------------ extend: closest hit of every queued path (round 1's stage kernels)
 template <bool LDS_SCENE, bool COUNT, bool STRICT>
 __global__ __launch_bounds__(kTraverseBlock, 8) void k_extend(DeviceScene sc, PathState ps, const uint32_t* queue,
                                                           Counters* ctr, uint32_t parity) {
@@ -113,7 +117,9 @@ __global__ __launch_bounds__(kTraverseBlock, 8) void k_extend(DeviceScene sc, Pa
     }
 }
 
-// Test hook: the extend traversal on caller-supplied rays.
+#endif  // VPT_LAB
+
+// Test hook: the closest-hit traversal on caller-supplied rays.
 __global__ __launch_bounds__(kTraverseBlock) void k_trace_rays(DeviceScene sc, const vpt_ray* rays, uint32_t n, vpt_hit* hits) {
     extern __shared__ __align__(16) unsigned char smem[];
     const TravStack stack = make_stack(smem, sc.stack_overflow);
@@ -128,7 +134,8 @@ __global__ __launch_bounds__(kTraverseBlock) void k_trace_rays(DeviceScene sc, c
     }
 }
 
-// ------------------------------------------------------------------ shade
+#if VPT_LAB
+// ------------------------------------------------------------------ shade (round 1's stage kernels)
 // One path per lane: miss shader or closest-hit shader, then the tail of the reference's bounce loop that
 // does not depend on visibility (throughput update, Russian roulette, termination, next-sample
 // regeneration).  Survivors are ballot-compacted into the next ray queue; paths with anything pending
@@ -239,6 +246,8 @@ __global__ __launch_bounds__(256, 3) void k_shade(DeviceScene sc, RenderParams P
     }
 }
 
+#endif  // VPT_LAB
+
 // ------------------------------------------------------------------ primary: bounce 0, fully fused
 // Bounce 0 is ~60 % of all path-bounces of a frame (every pixel has one; later bounces only see the
 // survivors), its rays are coherent, and nothing about it has to be read from memory: the slot id gives
@@ -256,7 +265,10 @@ template <bool LDS_SCENE, bool COUNT, bool FIRST, bool VOL, bool STRICT, bool PL
 __global__ __launch_bounds__(kTraverseBlock, 3) void k_bounce(DeviceScene sc, RenderParams P, PathState ps, StreamState ss, const uint32_t* queue,
                                                              uint32_t* queue_next, Counters* ctr, uint32_t parity, uint32_t n_slots,
                                                              uint32_t dispatch_base, uint32_t k3) {
-    sc.strict_hits = STRICT ? 1u : 0u;  // compile-time constant from here on (VPT_FLAG_LOCAL_HITS picks the instantiation)
+    // compile-time constant from here on (VPT_FLAG_LOCAL_HITS picks the instantiation) — except in the media kernels (180 KB of code each, 688-720 B of
+    // scratch per lane) and in the fused kernel on a tree in memory (VPT_PIPELINE_FUSED forced on a scene AUTO gives to the streams: half their rate),
+    // which read the flag at run time: neither is near the speed of light, so one instantiation serves both hit rules
+    if (!VOL && LDS_SCENE) sc.strict_hits = STRICT ? 1u : 0u;
     if (PLAIN) { sc.all_plain = 1u; sc.env_black = 1u; } else sc.all_plain = 0u;   // likewise
     if (FIRST && P.dispatch_base_dev) dispatch_base = *P.dispatch_base_dev;   // a replayed graph: the batch's first dispatch index lives in device memory
     extern __shared__ __align__(16) unsigned char smem[];
@@ -401,7 +413,7 @@ __global__ __launch_bounds__(kTraverseBlock, 3) void k_bounce(DeviceScene sc, Re
                 if (VOL && aborted) {
                     o.want_sky = false; o.want_light = false; o.emitted = v3s(0.0f); o.csky = v3s(0.0f); o.clight = v3s(0.0f);
                     o.rng = in_.rng; o.new_depth = in_.depth; o.new_o = in_.porg; o.new_d = in_.pdir; o.new_pdf = in_.prev_pdf; o.bxdf = v3s(1.0f);
-                    o.in_medium = in_.in_medium; o.vdepth = in_.vdepth; o.cchan = in_.cchan; o.light_gid = 0xffffffffu; o.light_miss_ok = false; o.next_slot = slot;
+                    o.in_medium = in_.in_medium; o.vdepth = in_.vdepth; o.cchan = in_.cchan; o.light_gid = 0xffffffffu; o.light_miss_ok = false;
                 } else {
                     shade_core<VOL>(sc, P, ps, slot, in_, o);
                 }
@@ -488,7 +500,7 @@ __global__ __launch_bounds__(kTraverseBlock, 3) void k_bounce(DeviceScene sc, Re
                 pn = s_base[wave] + lanes_below(ma);
             }
             if (alive) {
-                queue_next[pn] = o.next_slot;   // its own slot, or the pixel's next resident sample (path regeneration, shade_core.hpp)
+                queue_next[pn] = slot;
                 ss.RA[parity ^ 1u][pn] = f4u(o.new_o, o.rng);
                 ss.RB[parity ^ 1u][pn] = f4u(o.new_d, o.new_depth | (o.in_medium ? 0x80000000u : 0u));
                 ss.RT[parity ^ 1u][pn] = f4(o.thr, o.new_pdf);
@@ -725,7 +737,8 @@ __global__ __launch_bounds__(kTraverseBlock, 3) void k_whole(DeviceScene sc, Ren
     }
 }
 
-// ------------------------------------------------------------------ connect
+#if VPT_LAB
+// ------------------------------------------------------------------ connect (round 1's stage kernels)
 // Per pending path: trace its (<= 2) shadow rays (RTCommon.slang:47-64: closest committed hit), join the
 // visible NEE contributions with the emission BEFORE the luminance clamp (RayGen.slang:92-102), add to
 // pathLight, and at the end of a sample apply the NaN/Inf guard and add to the frame sum (:116-128).
@@ -817,7 +830,7 @@ __global__ __launch_bounds__(kTraverseBlock, 8) void k_connect(DeviceScene sc, R
                     } else if (ok) {
                         float4 acc = ps.ACC[sl]; ps.ACC[sl] = f4(xyz(acc) + light, 0.0f);
                     }
-                    light = v3s(0.0f);  // a regenerated sample starts from pathLight = 0
+                    light = v3s(0.0f);  // the pixel's next sample of the frame starts from pathLight = 0
                 }
                 ps.L[sl] = f4(light, 0.0f);
             }
@@ -828,6 +841,8 @@ __global__ __launch_bounds__(kTraverseBlock, 8) void k_connect(DeviceScene sc, R
         atomicAdd(&ctr->stat_shadow_tris, (unsigned long long)st.tris);
     }
 }
+
+#endif  // VPT_LAB
 
 // ------------------------------------------------------------------ resolve: running mean, frames applied in order
 // frame_base = index of the first dispatch of the batch (== FrameCount when ScreenSplitCount is 1).
@@ -867,7 +882,8 @@ __global__ __launch_bounds__(256) void k_resolve(RenderParams P, PathState ps, f
     image[sp] = make_float4(color.x, color.y, color.z, 1.0f);
 }
 
-// Start of a bounce: fold the statistics of the previous one, reset cursors and the output queue sizes.
+#if VPT_LAB
+// Start of a bounce (round 1's stage kernels): fold the statistics of the previous one, reset cursors and the output queue sizes.
 __global__ void k_prepare(Counters* ctr, uint32_t parity) {
     ctr->stat_closest += ctr->ray_count[parity];
     ctr->stat_shadow += ctr->shadow_rays;
@@ -880,6 +896,8 @@ __global__ void k_fold(Counters* ctr) {
     ctr->stat_shadow += ctr->shadow_rays; ctr->shadow_rays = 0u;
     ctr->stat_connect += ctr->connect_front + ctr->connect_back; ctr->connect_front = 0u; ctr->connect_back = 0u;
 }
+
+#endif  // VPT_LAB
 
 // shard rows <-> full image
 __global__ __launch_bounds__(256) void k_scatter_rows(const float4* gathered, float4* full, uint32_t width, uint32_t height,
@@ -1012,16 +1030,20 @@ void launch_bounce(hipStream_t s, uint32_t blocks, bool lds_scene, bool count, b
 #define VPT_LAUNCH_BOUNCE_V(L, C, F, V) do { if (sc.strict_hits) hipLaunchKernelGGL((k_bounce<L, C, F, V, true>), g, b, lds, s, sc, P, ps, ss, queue, queue_next, ctr, parity, n_slots, dispatch_base, k3); \
         else hipLaunchKernelGGL((k_bounce<L, C, F, V, false>), g, b, lds, s, sc, P, ps, ss, queue, queue_next, ctr, parity, n_slots, dispatch_base, k3); } while (0)
 #define VPT_LAUNCH_BOUNCE(L, C, F) VPT_LAUNCH_BOUNCE_V(L, C, F, false)
-    if (sc.volume_count > 0u || sc.atm_on) {  // the media variants carry no traversal counters
-        if (lds_scene) { if (first) VPT_LAUNCH_BOUNCE_V(true, false, true, true); else VPT_LAUNCH_BOUNCE_V(true, false, false, true); }
-        else { if (first) VPT_LAUNCH_BOUNCE_V(false, false, true, true); else VPT_LAUNCH_BOUNCE_V(false, false, false, true); }
+#define VPT_LAUNCH_MEDIA(L, F) hipLaunchKernelGGL((k_bounce<L, false, F, true, false>), g, b, lds, s, sc, P, ps, ss, queue, queue_next, ctr, parity, n_slots, dispatch_base, k3)
+    if (sc.volume_count > 0u || sc.atm_on) {  // the media variants carry no traversal counters and read VPT_FLAG_LOCAL_HITS at run time
+        if (lds_scene) { if (first) VPT_LAUNCH_MEDIA(true, true); else VPT_LAUNCH_MEDIA(true, false); }
+        else { if (first) VPT_LAUNCH_MEDIA(false, true); else VPT_LAUNCH_MEDIA(false, false); }
     } else if (lds_scene) {
         if (count) { if (first) VPT_LAUNCH_BOUNCE(true, true, true); else VPT_LAUNCH_BOUNCE(true, true, false); }
         else { if (first) VPT_LAUNCH_BOUNCE(true, false, true); else VPT_LAUNCH_BOUNCE(true, false, false); }
-    } else {
-        if (count) { if (first) VPT_LAUNCH_BOUNCE(false, true, true); else VPT_LAUNCH_BOUNCE(false, true, false); }
-        else { if (first) VPT_LAUNCH_BOUNCE(false, false, true); else VPT_LAUNCH_BOUNCE(false, false, false); }
+    } else {   // a tree in memory: the hit rule is read at run time (above)
+#define VPT_LAUNCH_MEM(C, F) hipLaunchKernelGGL((k_bounce<false, C, F, false, false>), g, b, lds, s, sc, P, ps, ss, queue, queue_next, ctr, parity, n_slots, dispatch_base, k3)
+        if (count) { if (first) VPT_LAUNCH_MEM(true, true); else VPT_LAUNCH_MEM(true, false); }
+        else { if (first) VPT_LAUNCH_MEM(false, true); else VPT_LAUNCH_MEM(false, false); }
+#undef VPT_LAUNCH_MEM
     }
+#undef VPT_LAUNCH_MEDIA
 #undef VPT_LAUNCH_BOUNCE
 #undef VPT_LAUNCH_BOUNCE_V
 }
@@ -1058,17 +1080,20 @@ int bounce_blocks_per_cu(bool lds_scene, const DeviceScene& sc, bool plain) {
     else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_bounce<false, false, false, false, false>, kTraverseBlock, lds);
     return nb > 0 ? nb : 1;
 }
+#if VPT_LAB
 void launch_raygen(hipStream_t s, const RenderParams& P, const PathState& ps, uint32_t* queue, Counters* ctr, uint32_t n_slots, uint32_t dispatch_base) {
     hipLaunchKernelGGL(k_raygen, dim3(cdiv(n_slots, 256)), dim3(256), 0, s, P, ps, queue, ctr, n_slots, dispatch_base);
 }
 void launch_prepare(hipStream_t s, Counters* ctr, uint32_t parity) { hipLaunchKernelGGL(k_prepare, dim3(1), dim3(1), 0, s, ctr, parity); }
 void launch_fold(hipStream_t s, Counters* ctr) { hipLaunchKernelGGL(k_fold, dim3(1), dim3(1), 0, s, ctr); }
+#endif
 
 size_t traverse_lds_bytes(const DeviceScene& sc, bool lds_scene) {
     size_t b = (size_t)kStackDepth * kTraverseBlock * 4;
     if (lds_scene) b += (size_t)sc.node_count * sizeof(BvhNodeWide) + (size_t)sc.tri_count * sizeof(BvhTri);
     return b;
 }
+#if VPT_LAB
 void launch_extend(hipStream_t s, uint32_t blocks, bool lds_scene, bool count, const DeviceScene& sc, const PathState& ps,
                    const uint32_t* queue, Counters* ctr, uint32_t parity) {
     size_t lds = traverse_lds_bytes(sc, lds_scene);
@@ -1095,6 +1120,7 @@ void launch_shade(hipStream_t s, uint32_t blocks, const DeviceScene& sc, const R
                   const uint32_t* queue, uint32_t* queue_next, uint32_t* cqueue, Counters* ctr, uint32_t parity) {
     hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(256), 0, s, sc, P, ps, queue, queue_next, cqueue, ctr, parity);
 }
+#endif  // VPT_LAB
 void launch_resolve(hipStream_t s, const RenderParams& P, const PathState& ps, float* image, uint32_t frames, uint32_t frame_base, const uint32_t* guard) {
     hipLaunchKernelGGL(k_resolve, dim3(cdiv(P.shard_pixels, 256)), dim3(256), 0, s, P, ps, reinterpret_cast<float4*>(image), frames, frame_base, guard);
 }
@@ -1107,6 +1133,7 @@ void launch_scatter_rows(hipStream_t s, const float* gathered, float* full, uint
                        reinterpret_cast<float4*>(full), w, h, shard_count, stride_px);
 }
 size_t stack_overflow_bytes(uint32_t blocks) { return (size_t)blocks * kTraverseBlock * kStackOverflow * 4; }
+#if VPT_LAB
 int traverse_blocks_per_cu(bool lds_scene, const DeviceScene& sc) {
     int nb = 0;
     size_t lds = traverse_lds_bytes(sc, lds_scene) + kConnectScratch;
@@ -1119,5 +1146,6 @@ int shade_blocks_per_cu() {
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_shade, 256, 0);
     return nb > 0 ? nb : 1;
 }
+#endif
 
 }  // namespace vpt

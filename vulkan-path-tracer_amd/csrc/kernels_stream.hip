@@ -190,12 +190,11 @@ __global__ __launch_bounds__(256, 3) void k_shade_stream(DeviceScene sc, RenderP
             const uint32_t p_next = a_next.append(alive, &sctr->queue_len[parity ^ 1u].v);
             if (alive) {   // the survivor's records move to where its queue entry goes — pathLight included: the join stage then
                            // updates it in stream order (two coalesced streams) instead of a scattered read-modify-write by slot
-                queue_next[p_next] = o.next_slot;   // its own slot, or the pixel's next resident sample (path regeneration, shade_core.hpp)
+                queue_next[p_next] = slot;
                 st_stream(&ss.RA[parity ^ 1u][p_next], f4u(o.new_o, o.rng));
                 st_stream(&ss.RB[parity ^ 1u][p_next], f4u(o.new_d, o.new_depth | (o.in_medium ? 0x80000000u : 0u)));
                 st_stream(&ss.RT[parity ^ 1u][p_next], f4(o.thr, o.new_pdf));
-                // (path regeneration: a lane that goes on with ANOTHER sample starts it with pathLight = 0; the sample that ended keeps its own entry, below)
-                st_stream(&ss.RL[parity ^ 1u][p_next], o.new_frame ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : ld_stream(&ss.RL[parity][qi]));
+                st_stream(&ss.RL[parity ^ 1u][p_next], ld_stream(&ss.RL[parity][qi]));
             }
             const uint32_t p_sky = a_sky.append(want_sky, &sctr->sky_len.v);
             if (want_sky) {
@@ -209,8 +208,8 @@ __global__ __launch_bounds__(256, 3) void k_shade_stream(DeviceScene sc, RenderP
             }
             const uint32_t p_pend = a_pend.append(pending, &sctr->pend_len.v);
             if (pending) {   // where the join finds the path's pathLight (and its slot, in the queue): its entry in the NEXT queue if it
-                             // lives on (a regenerated sample included), else its entry in this one
-                const bool lives_on = alive && !o.new_frame;   // THIS sample's path (a regenerated lane carries another sample on)
+                             // lives on (the pixel's next sample of this frame included: samples_per_frame > 1), else its entry in this one
+                const bool lives_on = alive;
                 st_stream(&ss.PE[p_pend], f4u(o.emitted, o.cflags | (lives_on ? kCF_Alive : 0u)));
                 st_stream(&ss.PS[p_pend], f4u(o.csky, p_sky));
                 st_stream(&ss.PL[p_pend], f4u(o.clight, p_light));
@@ -300,7 +299,7 @@ __global__ __launch_bounds__(256) void k_join(RenderParams P, PathState ps, Stre
                 } else if (ok) {
                     float4 acc = ps.ACC[sl[k]]; ps.ACC[sl[k]] = f4(xyz(acc) + light, 0.0f);
                 }
-                light = v3s(0.0f);  // a regenerated sample starts from pathLight = 0
+                light = v3s(0.0f);  // the pixel's next sample of the frame (samples_per_frame > 1) starts from pathLight = 0
             }
             if (fl[k] & kCF_Alive) ss.RL[parity ^ 1u][pos[k]] = f4(light, 0.0f);   // a path that ended has no use for it any more
         }
@@ -331,10 +330,52 @@ void launch_raygen_stream(hipStream_t s, const RenderParams& P, const PathState&
     hipLaunchKernelGGL(k_raygen_stream, dim3((n_slots + 255u) / 256u), dim3(256), 0, s, P, ps, ss, queue, n_slots, dispatch_base, media ? 1u : 0u);
 }
 
-// Start of a batch: the ray queue raygen filled.
-__global__ void k_stream_begin(StreamCounters* sc, uint32_t n_slots) {
-    sc->queue_len[0].v = n_slots; sc->alive[0].v = n_slots;
+// Start of a batch: the ray queue raygen filled (samples [0, n_first) of the batch's n_total; the rest are started by refills).
+__global__ void k_stream_begin(StreamCounters* sc, uint32_t n_first, uint32_t n_total) {
+    sc->queue_len[0].v = n_first; sc->alive[0].v = n_first;
     sc->queue_len[1].v = 0u; sc->alive[1].v = 0u;
+    sc->refill_next = n_first; sc->refill_total = n_total; sc->refill_count = 0u;
+}
+
+// ---- Path regeneration by refill (vpt_config.resident_frames = K: at most cap = K frames of paths are resident in a batch of F > K).
+// The reference's RayGen thread starts its pixel's next sample when a path has ended (RayGen.slang:28-33).  Here that happens at the
+// QUEUE level: once the shade stage of a bounce has written the next ray queue, the room the ended paths left (cap - live paths) is
+// filled with the next unstarted samples of the batch — a contiguous run of sample ids, so a block of coherent camera rays appended
+// behind the survivors, written by the camera-ray code of k_raygen_stream.  The shade kernels know nothing of it.  (Round 4 regenerated
+// per LANE inside the shade stage: the fresh camera rays were scattered through the queue in runs of a few entries — incoherent for the
+// extend stage — and every shade instantiation carried the hook: -4 ... -19 % on the streams, profiles/r04_frames_sweep.json.)
+// A sample's seed depends on (pixel, frame) and its result lands in ACC[its slot]: which launch starts it cannot matter.
+__global__ void k_refill_plan(StreamCounters* sc, uint32_t parity_next, uint32_t cap) {
+    const uint32_t alive = sc->alive[parity_next].v, len = sc->queue_len[parity_next].v;
+    const uint32_t left = sc->refill_total - sc->refill_next;
+    uint32_t add = alive < cap ? cap - alive : 0u;
+    if (add > left) add = left;
+    sc->refill_entry = len; sc->refill_first = sc->refill_next; sc->refill_count = add;
+    sc->refill_next += add;
+    sc->queue_len[parity_next].v = len + add; sc->alive[parity_next].v = alive + add;
+}
+__global__ __launch_bounds__(256) void k_refill_stream(RenderParams P, PathState ps, StreamState ss, uint32_t* queue, const StreamCounters* sc, uint32_t parity_next, uint32_t dispatch_base) {
+    const uint32_t count = sc->refill_count, e0 = sc->refill_entry, s0 = sc->refill_first;
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < count; j += gridDim.x * blockDim.x) {
+        const uint32_t slot = s0 + j, e = e0 + j;
+        uint32_t x, y, f;
+        pixel_of_slot(P, slot, x, y, f);
+        const uint32_t seed = pcg_hash(P.base_seed + dispatch_base + f);  // PathTracer.cpp:139 with an explicit seed
+        Rng r; r.s = y + P.width * x + seed;                              // RayGen.slang:28
+        V3 o, d;
+        camera_ray(P, r, x, y, o, d);
+        st_stream(&ss.RA[parity_next][e], f4u(o, r.s));
+        st_stream(&ss.RB[parity_next][e], f4u(d, 0u));
+        st_stream(&ss.RT[parity_next][e], make_float4(1.0f, 1.0f, 1.0f, 1.0f));
+        st_stream(&ss.RL[parity_next][e], make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+        if (P.samples_per_frame > 1) { ps.ACC[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); ps.sidx[slot] = 0u; }
+        queue[e] = slot;
+    }
+}
+void launch_refill(hipStream_t s, uint32_t blocks, const RenderParams& P, const PathState& ps, const StreamState& ss, uint32_t* queue_next, StreamCounters* sc, uint32_t parity_next,
+                   uint32_t cap, uint32_t dispatch_base) {
+    hipLaunchKernelGGL(k_refill_plan, dim3(1), dim3(1), 0, s, sc, parity_next, cap);
+    hipLaunchKernelGGL(k_refill_stream, dim3(blocks), dim3(256), 0, s, P, ps, ss, queue_next, sc, parity_next, dispatch_base);
 }
 // Unsorted mode: the whole ray queue is "class 0" of one shade launch running the general code (k_shade_stream<kShadeAny>).
 __global__ void k_layout_single(StreamCounters* sc, uint32_t parity, uint32_t shade_waves) {
@@ -356,7 +397,7 @@ __global__ void k_prepare_stream(StreamCounters* sc, uint32_t parity) {
 }
 
 // ------------------------------------------------------------------ launch
-void launch_stream_begin(hipStream_t s, StreamCounters* sc, uint32_t n_slots) { hipLaunchKernelGGL(k_stream_begin, dim3(1), dim3(1), 0, s, sc, n_slots); }
+void launch_stream_begin(hipStream_t s, StreamCounters* sc, uint32_t n_first, uint32_t n_total) { hipLaunchKernelGGL(k_stream_begin, dim3(1), dim3(1), 0, s, sc, n_first, n_total); }
 void launch_prepare_stream(hipStream_t s, StreamCounters* sc, uint32_t parity) { hipLaunchKernelGGL(k_prepare_stream, dim3(1), dim3(1), 0, s, sc, parity); }
 void launch_classify(hipStream_t s, const uint32_t* queue, const unsigned char* cls, uint32_t* const* class_queue, StreamCounters* sc, uint32_t parity,
                      uint32_t max_entries, uint32_t shade_waves) {

@@ -42,7 +42,8 @@ __device__ inline uint32_t store_closest(const TraceArgs& a, const BvhTri* tris,
 }
 }  // namespace
 
-// ------------------------------------------------------------------ baseline: 64 rays per wave at a time
+#if VPT_LAB
+// ------------------------------------------------------------------ baseline: 64 rays per wave at a time (laboratory build only)
 template <bool ANY, bool COUNT>
 __global__ __launch_bounds__(kTraverseBlock, 8) void k_trace_base(DeviceScene sc, TraceArgs a, Counters* ctr) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -79,6 +80,8 @@ __global__ __launch_bounds__(kTraverseBlock, 8) void k_trace_base(DeviceScene sc
     }
 }
 
+#endif  // VPT_LAB
+
 // ------------------------------------------------------------------ vote-scheduled persistent lanes
 // Lane state: `cur` >= 0 inner node to visit; < 0 leaf code ~(first << 3 | count - 1) with `first` advancing as the
 // triangles are consumed; kLaneDone / kLaneIdle.  The wave owns a chunk [w_next, w_end) of the stream (one atomic per
@@ -90,6 +93,7 @@ __global__ __launch_bounds__(kTraverseBlock, 8) void k_trace_base(DeviceScene sc
 // CULL (closest-hit, four-wide tree): stale stack entries are dropped at the pop (vote.hpp LaneStack::pop_or_done_cull).
 template <bool ANY, bool COUNT, bool WIDE8, bool TUNED, bool STRICT = false, bool CULL = false, bool PK = false, bool TRI2 = false>
 __global__ __launch_bounds__(kTraverseBlock, 8) void k_trace_vote(DeviceScene sc, TraceArgs a, Counters* ctr) {
+    static_assert(!(TRI2 && STRICT), "the two-triangle steps have no validating form: VPT_FLAG_LOCAL_HITS keeps the one-triangle step");
     extern __shared__ __align__(16) unsigned char smem[];
     const LaneStack S = make_lane_stack(smem, sc.stack_overflow);
     const BvhNode* const nodes = sc.nodes;
@@ -224,7 +228,8 @@ __global__ __launch_bounds__(kTraverseBlock, 8) void k_trace_vote(DeviceScene sc
     }
 }
 
-// ------------------------------------------------------------------ ray slots in LDS (trace lab variant VPT_TRACE_POOL, closest hit)
+#if VPT_LAB
+// ------------------------------------------------------------------ ray slots in LDS (trace lab variant VPT_TRACE_POOL, closest hit; laboratory build only)
 // In k_trace_vote a ray lives in a lane's registers, so a step of one kind runs on the lanes whose OWN ray wants it: 42 of 64 lanes in
 // a node step, 21 in a triangle step (profiles/r04_vote_sim_*.txt; the counters say the same).  Here a wave owns SLOTS ray slots in LDS —
 // ray, best hit, traversal state and stack of every ray — and a step runs on up to 64 of the slots that want it, whichever they are:
@@ -525,6 +530,8 @@ __global__ __launch_bounds__(kTraverseBlock, 5) void k_trace_pair(DeviceScene sc
     }
 }
 
+#endif  // VPT_LAB
+
 // ------------------------------------------------------------------ shadow rays
 // LIGHT = false: visible <=> nothing is hit (ClosestHit.slang:139, 344-353).  LIGHT = true: visible <=> the closest hit is
 // the sampled triangle (ClosestHit.slang:171-176, 358-370): that triangle is tested first by its own record, then the search
@@ -534,6 +541,7 @@ __global__ __launch_bounds__(kTraverseBlock, 5) void k_trace_pair(DeviceScene sc
 template <bool LIGHT, bool COUNT, bool TUNED, bool STRICT = false, bool TRI2 = false>
 __global__ __launch_bounds__(kTraverseBlock, 8) void k_trace_shadow(DeviceScene sc, const float4* RO, const float4* RD, unsigned char* vis, const uint32_t* n_dev,
                                                                   uint32_t* head, Counters* ctr, uint32_t param) {
+    static_assert(!(TRI2 && STRICT), "the two-triangle steps have no validating form: VPT_FLAG_LOCAL_HITS keeps the one-triangle step");
     extern __shared__ __align__(16) unsigned char smem[];
     const LaneStack S = make_lane_stack(smem, sc.stack_overflow);
     const BvhNode* const nodes = sc.nodes;
@@ -636,8 +644,13 @@ __global__ __launch_bounds__(kTraverseBlock, 8) void k_trace_shadow(DeviceScene 
 }
 
 // ------------------------------------------------------------------ launch
+// The PRODUCT library holds four instantiations of k_trace_vote (closest hit: default, counting, validating, validating + counting — the
+// pipeline always runs the compile-time vote parameters) and eight of k_trace_shadow.  Everything else — the baseline loop, the eight-wide
+// tree, culling, packed arithmetic, ray pools, ray pairs, the one-triangle step for the A/B, run-time vote parameters, any-hit k_trace_vote —
+// was measured slower and lives in the LABORATORY build only (-DVPT_LAB=1: libvpt_hip_lab.so, include/vpt_lab.h, tests/tools/trace_lab.py).
 int trace_blocks_per_cu(uint32_t variant, bool any) {
     int nb = 0;
+#if VPT_LAB
     if (variant == VPT_TRACE_PAIR) {
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_pair<false>, kTraverseBlock, kPairLdsBytes);
         return nb > 0 ? nb : 1;
@@ -646,21 +659,29 @@ int trace_blocks_per_cu(uint32_t variant, bool any) {
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_pool<false, 128, 10, false>, kTraverseBlock, pool_lds_bytes(128, 10));
         return nb > 0 ? nb : 1;
     }
-    const size_t lds = variant == VPT_TRACE_BASE ? kVoteStackBytes : kVoteLdsBytes;
+    const size_t lds_lab = variant == VPT_TRACE_BASE ? kVoteStackBytes : kVoteLdsBytes;
     if (variant == VPT_TRACE_BASE) {
-        if (any) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_base<true, false>, kTraverseBlock, lds);
-        else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_base<false, false>, kTraverseBlock, lds);
-    } else if (variant == VPT_TRACE_VOTE8) {
-        if (any) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_vote<true, false, true, false>, kTraverseBlock, lds);
-        else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_vote<false, false, true, false>, kTraverseBlock, lds);
-    } else {
-        if (any) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_vote<true, false, false, true, false, false, false, true>, kTraverseBlock, lds);
-        else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_vote<false, false, false, true, false, false, false, true>, kTraverseBlock, lds);
+        if (any) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_base<true, false>, kTraverseBlock, lds_lab);
+        else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_base<false, false>, kTraverseBlock, lds_lab);
+        return nb > 0 ? nb : 1;
     }
+    if (variant == VPT_TRACE_VOTE8) {
+        if (any) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_vote<true, false, true, false>, kTraverseBlock, lds_lab);
+        else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_vote<false, false, true, false>, kTraverseBlock, lds_lab);
+        return nb > 0 ? nb : 1;
+    }
+    if (any) {
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_vote<true, false, false, true, false, false, false, true>, kTraverseBlock, lds_lab);
+        return nb > 0 ? nb : 1;
+    }
+#endif
+    (void)variant; (void)any;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_vote<false, false, false, true, false, false, false, true>, kTraverseBlock, kVoteLdsBytes);
     return nb > 0 ? nb : 1;
 }
 
 void launch_trace(hipStream_t s, uint32_t blocks, uint32_t variant, bool any, bool count, const DeviceScene& sc, const TraceArgs& a, Counters* ctr) {
+#if VPT_LAB
     if (variant == VPT_TRACE_PAIR) {   // closest hit only
         if (count) hipLaunchKernelGGL((k_trace_pair<true>), dim3(blocks), dim3(kTraverseBlock), kPairLdsBytes, s, sc, a, ctr);
         else hipLaunchKernelGGL((k_trace_pair<false>), dim3(blocks), dim3(kTraverseBlock), kPairLdsBytes, s, sc, a, ctr);
@@ -683,58 +704,81 @@ void launch_trace(hipStream_t s, uint32_t blocks, uint32_t variant, bool any, bo
 #undef VPT_LP
         return;
     }
-    const size_t lds = variant == VPT_TRACE_BASE ? kVoteStackBytes : kVoteLdsBytes;
-    const dim3 g(blocks), b(kTraverseBlock);
+    {
+        const size_t lds = variant == VPT_TRACE_BASE ? kVoteStackBytes : kVoteLdsBytes;
+        const dim3 g(blocks), b(kTraverseBlock);
 #define VPT_LT(K) do { if (any) { if (count) hipLaunchKernelGGL((K<true, true>), g, b, lds, s, sc, a, ctr); else hipLaunchKernelGGL((K<true, false>), g, b, lds, s, sc, a, ctr); } \
                        else { if (count) hipLaunchKernelGGL((K<false, true>), g, b, lds, s, sc, a, ctr); else hipLaunchKernelGGL((K<false, false>), g, b, lds, s, sc, a, ctr); } } while (0)
 #define VPT_LV(W, T) do { if (any) { if (count) hipLaunchKernelGGL((k_trace_vote<true, true, W, T>), g, b, lds, s, sc, a, ctr); else hipLaunchKernelGGL((k_trace_vote<true, false, W, T>), g, b, lds, s, sc, a, ctr); } \
                           else { if (count) hipLaunchKernelGGL((k_trace_vote<false, true, W, T>), g, b, lds, s, sc, a, ctr); else hipLaunchKernelGGL((k_trace_vote<false, false, W, T>), g, b, lds, s, sc, a, ctr); } } while (0)
-    if (variant == VPT_TRACE_BASE) VPT_LT(k_trace_base); else if (variant == VPT_TRACE_VOTE8) VPT_LV(true, false);
-    else if (sc.strict_hits) {   // VPT_FLAG_LOCAL_HITS: the validating instantiations (default vote parameters; the counting ones read them from a.param)
-        if (any) { if (count) hipLaunchKernelGGL((k_trace_vote<true, true, false, false, true>), g, b, lds, s, sc, a, ctr); else hipLaunchKernelGGL((k_trace_vote<true, false, false, true, true>), g, b, lds, s, sc, a, ctr); }
-        else { if (count) hipLaunchKernelGGL((k_trace_vote<false, true, false, false, true>), g, b, lds, s, sc, a, ctr); else hipLaunchKernelGGL((k_trace_vote<false, false, false, true, true>), g, b, lds, s, sc, a, ctr); }
-    }
-    else if (a.tri2 && !count) {   // trace lab bit 19: ONE triangle per triangle step (round 3's step) with the product vote parameters, for the A/B against the product's two
-        if (any) hipLaunchKernelGGL((k_trace_vote<true, false, false, true, false, false, false, false>), g, b, lds, s, sc, a, ctr);
-        else hipLaunchKernelGGL((k_trace_vote<false, false, false, true, false, false, false, false>), g, b, lds, s, sc, a, ctr);
-    }
-    else if (a.packed) {   // trace lab bit 18: packed plane arithmetic in the node step, product vote parameters
-        if (any) { if (count) hipLaunchKernelGGL((k_trace_vote<true, true, false, true, false, false, true>), g, b, lds, s, sc, a, ctr); else hipLaunchKernelGGL((k_trace_vote<true, false, false, true, false, false, true>), g, b, lds, s, sc, a, ctr); }
-        else { if (count) hipLaunchKernelGGL((k_trace_vote<false, true, false, true, false, false, true>), g, b, lds, s, sc, a, ctr); else hipLaunchKernelGGL((k_trace_vote<false, false, false, true, false, false, true>), g, b, lds, s, sc, a, ctr); }
-    }
-    else if (a.cull && !any) {   // stale-entry culling (closest-hit only)
-        if (count) hipLaunchKernelGGL((k_trace_vote<false, true, false, false, false, true>), g, b, lds, s, sc, a, ctr);
-        else if (a.param == kVoteParamDefault) hipLaunchKernelGGL((k_trace_vote<false, false, false, true, false, true>), g, b, lds, s, sc, a, ctr);
-        else hipLaunchKernelGGL((k_trace_vote<false, false, false, false, false, true>), g, b, lds, s, sc, a, ctr);
-    }
-    else if (a.param == kVoteParamDefault && !count) {   // the product instantiation: compile-time vote parameters, two triangles per triangle step
-        if (any) hipLaunchKernelGGL((k_trace_vote<true, false, false, true, false, false, false, true>), g, b, lds, s, sc, a, ctr);
-        else hipLaunchKernelGGL((k_trace_vote<false, false, false, true, false, false, false, true>), g, b, lds, s, sc, a, ctr);
-    }
-    else if (a.param == kVoteParamDefault) VPT_LV(false, true); else VPT_LV(false, false);
+        if (variant == VPT_TRACE_BASE) { VPT_LT(k_trace_base); return; }
+        if (variant == VPT_TRACE_VOTE8) { VPT_LV(true, false); return; }
+        if (!sc.strict_hits) {
+            if (a.one_tri && !count) {   // trace lab bit 19: ONE triangle per triangle step (round 3's step) with the product vote parameters, for the A/B against the product's two
+                if (any) hipLaunchKernelGGL((k_trace_vote<true, false, false, true, false, false, false, false>), g, b, lds, s, sc, a, ctr);
+                else hipLaunchKernelGGL((k_trace_vote<false, false, false, true, false, false, false, false>), g, b, lds, s, sc, a, ctr);
+                return;
+            }
+            if (a.packed) {   // trace lab bit 18: packed plane arithmetic in the node step, product vote parameters
+                if (any) { if (count) hipLaunchKernelGGL((k_trace_vote<true, true, false, true, false, false, true>), g, b, lds, s, sc, a, ctr); else hipLaunchKernelGGL((k_trace_vote<true, false, false, true, false, false, true>), g, b, lds, s, sc, a, ctr); }
+                else { if (count) hipLaunchKernelGGL((k_trace_vote<false, true, false, true, false, false, true>), g, b, lds, s, sc, a, ctr); else hipLaunchKernelGGL((k_trace_vote<false, false, false, true, false, false, true>), g, b, lds, s, sc, a, ctr); }
+                return;
+            }
+            if (a.cull && !any) {   // stale-entry culling (closest-hit only)
+                if (count) hipLaunchKernelGGL((k_trace_vote<false, true, false, false, false, true>), g, b, lds, s, sc, a, ctr);
+                else if (a.param == kVoteParamDefault) hipLaunchKernelGGL((k_trace_vote<false, false, false, true, false, true>), g, b, lds, s, sc, a, ctr);
+                else hipLaunchKernelGGL((k_trace_vote<false, false, false, false, false, true>), g, b, lds, s, sc, a, ctr);
+                return;
+            }
+            if (a.param != kVoteParamDefault) { VPT_LV(false, false); return; }   // run-time vote parameters
+            if (any) {   // (the pipeline's shadow rays go through k_trace_shadow: the any-hit form of k_trace_vote exists for the lab's ray sets)
+                if (count) hipLaunchKernelGGL((k_trace_vote<true, true, false, true>), g, b, lds, s, sc, a, ctr);
+                else hipLaunchKernelGGL((k_trace_vote<true, false, false, true, false, false, false, true>), g, b, lds, s, sc, a, ctr);
+                return;
+            }
+        } else if (any) {
+            if (count) hipLaunchKernelGGL((k_trace_vote<true, true, false, true, true>), g, b, lds, s, sc, a, ctr);
+            else hipLaunchKernelGGL((k_trace_vote<true, false, false, true, true>), g, b, lds, s, sc, a, ctr);
+            return;
+        }
 #undef VPT_LV
 #undef VPT_LT
+    }
+#endif
+    // ---- the product's closest-hit search: compile-time vote parameters; two triangles per triangle step unless visits are counted or hits validated
+    (void)variant; (void)any;
+    const dim3 g(blocks), b(kTraverseBlock);
+    if (sc.strict_hits) {   // VPT_FLAG_LOCAL_HITS: the validating instantiations
+        if (count) hipLaunchKernelGGL((k_trace_vote<false, true, false, true, true>), g, b, kVoteLdsBytes, s, sc, a, ctr);
+        else hipLaunchKernelGGL((k_trace_vote<false, false, false, true, true>), g, b, kVoteLdsBytes, s, sc, a, ctr);
+    } else if (count) hipLaunchKernelGGL((k_trace_vote<false, true, false, true>), g, b, kVoteLdsBytes, s, sc, a, ctr);
+    else hipLaunchKernelGGL((k_trace_vote<false, false, false, true, false, false, false, true>), g, b, kVoteLdsBytes, s, sc, a, ctr);
 }
 
 void launch_trace_shadow(hipStream_t s, uint32_t blocks, bool light, bool count, const DeviceScene& sc, const StreamState& ss, Counters* ctr,
                          StreamCounters* sctr, uint32_t param) {
     const size_t lds = kVoteLdsBytes;
     const dim3 g(blocks), b(kTraverseBlock);
-#define VPT_LS(L, C, T, RO, RD, VIS, LEN, HEAD) hipLaunchKernelGGL((k_trace_shadow<L, C, T>), g, b, lds, s, sc, RO, RD, VIS, LEN, HEAD, ctr, param)
-    const bool tuned = param == kVoteParamDefault && !count;
-    if (sc.strict_hits) {   // VPT_FLAG_LOCAL_HITS (with vpt_config.count_traversal: the counting instantiations, so the visit statistics are not silently zero)
-        if (light) { if (count) hipLaunchKernelGGL((k_trace_shadow<true, true, false, true>), g, b, lds, s, sc, ss.LTO, ss.LTD, ss.vis_light, &sctr->light_len.v, &sctr->light_head.v, ctr, param);
-                     else hipLaunchKernelGGL((k_trace_shadow<true, false, true, true>), g, b, lds, s, sc, ss.LTO, ss.LTD, ss.vis_light, &sctr->light_len.v, &sctr->light_head.v, ctr, param); }
-        else { if (count) hipLaunchKernelGGL((k_trace_shadow<false, true, false, true>), g, b, lds, s, sc, ss.SKO, ss.SKD, ss.vis_sky, &sctr->sky_len.v, &sctr->sky_head.v, ctr, param);
-               else hipLaunchKernelGGL((k_trace_shadow<false, false, true, true>), g, b, lds, s, sc, ss.SKO, ss.SKD, ss.vis_sky, &sctr->sky_len.v, &sctr->sky_head.v, ctr, param); }
-    } else if (light) {
-        if (tuned) hipLaunchKernelGGL((k_trace_shadow<true, false, true, false, true>), g, b, lds, s, sc, ss.LTO, ss.LTD, ss.vis_light, &sctr->light_len.v, &sctr->light_head.v, ctr, param);
-        else if (count) VPT_LS(true, true, false, ss.LTO, ss.LTD, ss.vis_light, &sctr->light_len.v, &sctr->light_head.v);
-        else VPT_LS(true, false, false, ss.LTO, ss.LTD, ss.vis_light, &sctr->light_len.v, &sctr->light_head.v);
+    const float4 *RO = light ? ss.LTO : ss.SKO, *RD = light ? ss.LTD : ss.SKD;
+    unsigned char* vis = light ? ss.vis_light : ss.vis_sky;
+    uint32_t *len = light ? &sctr->light_len.v : &sctr->sky_len.v, *head = light ? &sctr->light_head.v : &sctr->sky_head.v;
+#define VPT_LS(L, C, T, ST, T2) hipLaunchKernelGGL((k_trace_shadow<L, C, T, ST, T2>), g, b, lds, s, sc, RO, RD, vis, len, head, ctr, param)
+#if VPT_LAB
+    if (param != kVoteParamDefault && !sc.strict_hits) {   // run-time vote parameters (trace-lab sweeps through the pipeline)
+        if (light) { if (count) VPT_LS(true, true, false, false, false); else VPT_LS(true, false, false, false, false); }
+        else { if (count) VPT_LS(false, true, false, false, false); else VPT_LS(false, false, false, false, false); }
+        return;
+    }
+#endif
+    // the product instantiations: compile-time vote parameters; two triangles per triangle step unless visits are counted or hits validated
+    // (VPT_FLAG_LOCAL_HITS with vpt_config.count_traversal runs the counting + validating one, so the visit statistics are not silently zero)
+    if (sc.strict_hits) {
+        if (light) { if (count) VPT_LS(true, true, true, true, false); else VPT_LS(true, false, true, true, false); }
+        else { if (count) VPT_LS(false, true, true, true, false); else VPT_LS(false, false, true, true, false); }
+    } else if (count) {
+        if (light) VPT_LS(true, true, true, false, false); else VPT_LS(false, true, true, false, false);
     } else {
-        if (tuned) hipLaunchKernelGGL((k_trace_shadow<false, false, true, false, true>), g, b, lds, s, sc, ss.SKO, ss.SKD, ss.vis_sky, &sctr->sky_len.v, &sctr->sky_head.v, ctr, param);
-        else if (count) VPT_LS(false, true, false, ss.SKO, ss.SKD, ss.vis_sky, &sctr->sky_len.v, &sctr->sky_head.v);
-        else VPT_LS(false, false, false, ss.SKO, ss.SKD, ss.vis_sky, &sctr->sky_len.v, &sctr->sky_head.v);
+        if (light) VPT_LS(true, false, true, false, true); else VPT_LS(false, false, true, false, true);
     }
 #undef VPT_LS
 }

@@ -39,42 +39,6 @@ __device__ inline void launch_pixel(const RenderParams& P, uint32_t li, uint32_t
     slot = k * P.shard_pixels + y * P.width + x;
 }
 
-// Path regeneration: the lanes of the wave with `want` each take an unstarted sample id of the batch (RenderParams::regen_next).  The
-// wave asks its home shard first — one aggregated atomic for all its lanes — and moves on to the next shard that still has samples
-// when that one runs out (its counter is read before it is added to, so an exhausted shard's counter stops growing).  Every lane of
-// the wave that is active at the call site must call; returns true and the id where the lane got one.
-__device__ __forceinline__ bool regen_take(const RenderParams& P, bool want, uint32_t& id) {
-    bool got = false;
-    if (__ballot(want) == 0ull) return false;
-    // word kRegenShards of the array: set once a wave has found every shard empty — from then on (the batch's last max_depth launches)
-    // a finished lane costs one load instead of a walk over all the counters
-    if (__hip_atomic_load(&P.regen_next[kRegenShards].v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
-    uint32_t shard = ((blockIdx.x * (blockDim.x >> 6)) + (threadIdx.x >> 6)) % kRegenShards;
-    const uint32_t span = P.regen_total - P.regen_first;
-    bool all_empty = true;   // of the shards this lane has seen (lanes that still want after the walk have seen all of them)
-    for (uint32_t tries = 0; tries < kRegenShards; tries++) {
-        const unsigned long long m = __ballot(want && !got);
-        if (m == 0ull) break;
-        const uint32_t lo = shard * P.regen_shard, hi = lo + P.regen_shard < span ? lo + P.regen_shard : span;   // ids of this shard, relative
-        const uint32_t size = lo < hi ? hi - lo : 0u;
-        if (want && !got) {
-            uint32_t base = size;
-            const uint32_t leader = (uint32_t)__ffsll((long long)m) - 1u;
-            if (lane_id() == leader) {
-                if (size != 0u && __hip_atomic_load(&P.regen_next[shard].v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < size)
-                    base = atomicAdd(&P.regen_next[shard].v, (uint32_t)__popcll(m));
-            }
-            base = __shfl(base, (int)leader);
-            const uint32_t k = base + lanes_below(m);
-            if (k < size) { id = P.regen_first + lo + k; got = true; }
-            if (base < size) all_empty = false;   // (somebody got one here: the shard was not empty when this wave came by)
-        }
-        shard = (shard + 1u) % kRegenShards;
-    }
-    if (want && !got && all_empty) P.regen_next[kRegenShards].v = 1u;
-    return got;
-}
-
 struct ShadeIn {
     uint32_t rng;
     V3 porg, pdir;      // payload.Origin / payload.Direction
@@ -109,8 +73,6 @@ struct ShadeOut {
     int sky_kind;       // 0 surface, 1 box scatter event, 2 atmosphere scatter event (the three expressions differ in association)
     bool sky_add;       // false: trace and track (the draws count) but add nothing (ozone collision)
     int cchan;          // payload.ColorChannel after this bounce
-    uint32_t next_slot; // the slot a live path goes on in: its own, or (path regeneration) the one of the sample the lane has just started
-    bool new_frame;     // alive && the lane goes on with ANOTHER sample: this slot's sample has ended (the records the callers leave for it say so)
 };
 
 // The miss / closest-hit shader and the visibility-independent tail of the bounce loop for ONE path, on
@@ -377,7 +339,6 @@ __device__ __forceinline__ void shade_core(const DeviceScene& sc, const RenderPa
         out.new_o = new_o; out.new_d = new_d; out.new_pdf = new_pdf; out.bxdf = bxdf; out.cchan = in_.cchan;
         out.emitted = emitted; out.csky = csky; out.clight = clight;
         out.sky_o = sky_o; out.sky_d = sky_d; out.light_o = light_o; out.light_d = light_d;
-        out.next_slot = slot; out.new_frame = false;
         return;
     }
     // ---- RayGen.slang:104-113: throughput, Russian roulette (drawn on every iteration), loop condition
@@ -388,7 +349,6 @@ __device__ __forceinline__ void shade_core(const DeviceScene& sc, const RenderPa
     if (!terminated) thr = thr / p;
     if (!(new_depth < P.max_depth)) terminated = true;
     uint32_t cflags = (want_sky ? kCF_Sky : 0u) | (want_light ? kCF_Light : 0u) | (new_depth != 1u ? kCF_Clamp : 0u);
-    uint32_t next_slot = slot;
     if (terminated) {
         cflags |= kCF_Finalize;
         if (P.samples_per_frame > 1) {
@@ -405,26 +365,6 @@ __device__ __forceinline__ void shade_core(const DeviceScene& sc, const RenderPa
     } else {
         alive = true;
     }
-    // path regeneration: the (frame's last) sample of this slot has ended and the lane takes an unstarted sample of the batch.  The new
-    // sample is seeded from (pixel, frame) alone, exactly as the camera-ray kernels seed it (RayGen.slang:28, PathTracer.cpp:139); the
-    // ended sample is finalised as any other (the callers' records say "ended"), the new one enters the next queue with pathLight = 0.
-    bool new_frame = false;
-    if (P.regen_next != nullptr) {
-        uint32_t ns = 0u;
-        if (regen_take(P, terminated && !alive, ns)) {
-            uint32_t x, y, f;
-            pixel_of_slot(P, ns, x, y, f);
-            const uint32_t seed = pcg_hash(P.base_seed + P.batch_base + f);
-            rng.s = y + P.width * x + seed;
-            camera_ray(P, rng, x, y, new_o, new_d);
-            thr = v3s(1.0f); new_pdf = 1.0f; new_depth = 0u; in_medium = false; vdepth = 0u;
-            if (P.samples_per_frame > 1) { ps.sidx[ns] = 0u; ps.ACC[ns] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); }   // later finalisations add to it
-            next_slot = ns;
-            new_frame = true;
-            alive = true;
-        }
-    }
-    out.next_slot = next_slot; out.new_frame = new_frame;
     out.alive = alive; out.terminated = terminated; out.want_sky = want_sky; out.want_light = want_light; out.in_medium = in_medium;
     out.rng = rng.s; out.new_depth = new_depth; out.cflags = cflags; out.light_gid = light_gid;
     out.light_miss_ok = light_miss_ok; out.vdepth = vdepth;

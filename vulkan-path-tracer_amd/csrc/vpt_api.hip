@@ -29,6 +29,7 @@ struct BatchState {
     uint32_t n_first = 0;   // slots the camera-ray launch starts (n_slots, or the resident part of it when paths are regenerated)
     bool fused = false, stream = false, media_stream = false, sorted = false, overlap = false, count = false;
     bool whole = false;     // the whole batch is ONE launch of k_whole (kernels_path.hip): no bounces follow
+    bool regen = false;     // only n_first of the batch's n_slots samples start with the camera-ray launch; refills start the rest (kernels_stream.hip k_refill_plan)
     uint32_t parity = 0, k3 = 0;
     bool join_pending = false;
     uint64_t iter = 0, iter_cap = 0, min_bounces = 0;
@@ -106,7 +107,6 @@ struct vpt_ctx {
     BatchState out_batch;
     uint64_t out_ticket = 0;
     uint32_t* d_dispatch_base = nullptr;   // graph replays read the batch's first dispatch index from here (RenderParams::dispatch_base_dev)
-    HotWord* d_regen = nullptr;            // path regeneration: kRegenShards sample counters, one cache line each (RenderParams::regen_next)
     hipGraphExec_t graph = nullptr;
     uint64_t graph_gen = 0, state_gen = 1;   // state_gen: bumped by everything a captured batch bakes in (scene tables' addresses, params, camera, buffers)
     uint32_t graph_frames = 0, graph_bounces = 0, graph_streak = 0;
@@ -138,6 +138,8 @@ struct vpt_ctx {
     bool last_fixed_valid = false;
     uint32_t stack_overflow_words = 0;   // words per spill region
     unsigned long long* d_spill_count = nullptr;
+    bool spill_dirty = true;         // traversal kernels have run since the spill regions were last counted (vpt_get_stats counts lazily)
+    uint64_t spill_cached[2] = {0, 0};
     double set_scene_ms = 0.0, bvh_build_ms = 0.0;
 
     void* ps_block = nullptr;    // slot-addressed records every pipeline uses (L, ACC, M + the dword arrays)
@@ -314,7 +316,8 @@ int alloc_path_buffers(vpt_ctx* c, uint32_t frames, uint32_t resident) {
     // included; below that every append is exact and no stream ever holds a hole, so buffers that cannot reach that length need no slack.
     // (the appending kernels' persistent grids: blocks per CU from the occupancy query, the fused kernel's at most 3 by its LDS; checked
     // against the real grids by check_stream_slack once the scene is known.  Round 3 reserved for 8192 blocks: 2 GB of a large batch's streams)
-    const int per_cu = std::max(4, std::max(shade_stream_blocks_per_cu(), std::max(shade_media_blocks_per_cu(), media_tail_blocks_per_cu())));
+    const int fused_per_cu = (std::max(c->primary_blocks_general, c->primary_blocks_plain) + std::max(c->cu_count, 1) - 1) / std::max(c->cu_count, 1);   // (the scene's, once one is set)
+    const int per_cu = std::max(std::max(4, fused_per_cu), std::max(shade_stream_blocks_per_cu(), std::max(shade_media_blocks_per_cu(), media_tail_blocks_per_cu())));
     const uint64_t max_tails = (uint64_t)c->cu_count * (uint64_t)per_cu * 4u * kAppendChunk;
     c->stream_slack = cap < kFusedExactBelow ? 256u : (uint32_t)std::min<uint64_t>((uint64_t)cap * 4 + 256, max_tails);
     const size_t scap = (size_t)cap + c->stream_slack;
@@ -399,32 +402,28 @@ bool whole_policy(const vpt_ctx* c, uint32_t frames) {
     return c->cfg.pipeline == VPT_PIPELINE_WHOLE || (c->cfg.pipeline == VPT_PIPELINE_AUTO && frames <= c->lab_whole_frames);
 }
 // Does a batch of `frames` frames need only its per-sample buffers (48 B per sample: frame sum, medium state), not the ~290 B of records per
-// resident path?  A whole-path launch keeps its paths in registers.  vpt_config.resident_frames != 0 is the caller asking for the
-// per-bounce pipelines' regeneration: then the records are sized as asked and a batch beyond them is not a whole-path one.
-bool whole_without_records(const vpt_ctx* c, uint32_t frames) { return c->cfg.resident_frames == 0u && whole_policy(c, frames); }
-bool whole_applies(const vpt_ctx* c, uint32_t frames) {
-    if (!whole_policy(c, frames) || frames > c->frames_alloc) return false;
-    return c->cfg.resident_frames == 0u || frames <= c->resident_alloc;
-}
+// resident path?  A whole-path launch keeps its paths in registers (vpt_config.resident_frames means nothing to it: no path of it is resident in memory).
+bool whole_without_records(const vpt_ctx* c, uint32_t frames) { return whole_policy(c, frames); }
+bool whole_applies(const vpt_ctx* c, uint32_t frames) { return whole_policy(c, frames) && frames <= c->frames_alloc; }
 
-// Frames of paths a batch of `frames` frames keeps resident.  Paths are regenerated (device_types.hpp RenderParams::regen_next) on the
-// fused and the stream pipelines; round 1's stage kernels address a path's records by slot, media batches carry per-entry media streams
-// and split-screen dispatches map launch indices to pixels per dispatch: those keep every sample of the batch resident.
+// Frames of paths a batch of `frames` frames keeps resident.  Paths are regenerated — the next ray queue refilled with fresh camera rays
+// behind every shade stage, kernels_stream.hip k_refill_plan — on the STREAMS pipeline (scenes whose BVH lives in memory, no media, whole-frame
+// dispatches).  Everything else keeps every sample of a batch resident: the fused per-bounce kernels (scenes that ride in LDS run whole-path
+// launches, which hold no records at all; what is left for k_bounce — media, several samples per frame — is not worth a second mechanism),
+// round 1's stage kernels (records by slot), media batches (per-entry media streams), split-screen dispatches (launch indices map to
+// pixels per dispatch).
 bool regen_allowed(const vpt_ctx* c) {
     if (!c->has_scene) return false;
     const bool vol = !c->volumes.empty() || c->dsc.atm_on;
     if (vol || c->P.split != 1u) return false;
-    if (c->cfg.pipeline == VPT_PIPELINE_STAGED_R1) return false;
-    if (c->lds_scene && c->cfg.pipeline != VPT_PIPELINE_AUTO && c->cfg.pipeline != VPT_PIPELINE_FUSED) return false;   // an LDS-sized scene forced into the staged pipeline runs round 1's kernels
-    return true;
+    if (c->cfg.pipeline == VPT_PIPELINE_STAGED || c->cfg.pipeline == VPT_PIPELINE_STAGED_SORTED) return true;   // the stream kernels, whatever the scene's size
+    return c->cfg.pipeline == VPT_PIPELINE_AUTO && !c->lds_scene;
 }
 uint32_t resident_frames_for(const vpt_ctx* c, uint32_t frames) {
     if (whole_without_records(c, frames)) return 1u;   // (one frame of records stays: what the context would need for a per-bounce batch of one frame)
     if (!regen_allowed(c)) return frames;
     uint64_t k = c->cfg.resident_frames;
-    // 0: every sample resident — the fastest schedule on every scene measured (profiles/r04_frames_sweep.json: regeneration costs 4-9 % at
-    // 265M resident paths, 13-31 % at 33M); regeneration is the caller's trade of throughput for memory
-    if (k == 0) k = frames;
+    if (k == 0) k = frames;   // 0: every sample resident (the fastest schedule; regeneration is the caller's trade of a little throughput for memory: profiles/r05_frames_sweep.json)
     return (uint32_t)std::min<uint64_t>(frames, k);
 }
 
@@ -672,19 +671,14 @@ int batch_begin(vpt_ctx* c, uint32_t frames, uint32_t dispatch_base, BatchState&
     hipStream_t s = c->stream;
     b = BatchState{};
     b.frames = frames; b.dispatch_base = dispatch_base;
+    (c->owner ? c->owner : c)->spill_dirty = true;
     if (frames == 0 || frames > c->frames_alloc) return fail(c, VPT_ERR_DEVICE, "internal: batch larger than the path buffers");
-    // path regeneration: only `resident` frames of the batch's samples are in flight; a lane whose sample has ended starts the same
-    // pixel's sample `resident` frames later (shade_core.hpp), until the batch's samples are used up
+    // path regeneration: only `resident` frames of the batch's samples are in flight; the room ended paths leave in the next ray queue is
+    // refilled with the batch's next unstarted samples behind every shade stage (kernels_stream.hip k_refill_plan), until they are used up
     const bool whole = whole_applies(c, frames);   // (keeps its paths in registers: no records, nothing to regenerate)
     const uint32_t resident = whole ? frames : std::min(frames, c->resident_alloc);
     const bool regen = resident < frames;
     if (regen && !regen_allowed(c)) return fail(c, VPT_ERR_DEVICE, "internal: this batch needs all of its samples resident");
-    c->P.regen_next = regen ? c->d_regen : nullptr;
-    c->P.regen_first = resident * c->P.shard_pixels;
-    c->P.regen_total = frames * c->P.shard_pixels;
-    c->P.regen_shard = (c->P.regen_total - c->P.regen_first + kRegenShards - 1u) / kRegenShards;
-    c->P.batch_base = dispatch_base;
-    if (regen) HIPCHK(c, hipMemsetAsync(c->d_regen, 0, sizeof(HotWord) * (kRegenShards + 1), s));
     uint32_t n_slots = frames * c->P.shard_pixels;  // samples of the batch
     const uint32_t S = c->P.split;
     if (S > 1) {  // RayTrace(ceil(W/S), ceil(H/S)) per dispatch, in-bounds part only (PathTracer.cpp:145-150, RayGen.slang:24)
@@ -699,7 +693,8 @@ int batch_begin(vpt_ctx* c, uint32_t frames, uint32_t dispatch_base, BatchState&
         HIPCHK(c, hipStreamSynchronize(s));  // `off` is a stack-lifetime staging buffer
     }
     b.n_slots = n_slots;
-    b.n_first = regen ? c->P.regen_first : n_slots;   // launch-grid size of the camera-ray kernel
+    b.regen = regen;
+    b.n_first = regen ? resident * c->P.shard_pixels : n_slots;   // launch-grid size of the camera-ray kernel = the most paths ever resident
     b.count = c->cfg.count_traversal != 0;
     // fused (one kernel per bounce, bounce 0 included) when the BVH rides in LDS; staged otherwise
     const bool vol = !c->volumes.empty() || c->dsc.atm_on;
@@ -712,14 +707,18 @@ int batch_begin(vpt_ctx* c, uint32_t frames, uint32_t dispatch_base, BatchState&
     b.whole = whole;
     if (c->cfg.pipeline == VPT_PIPELINE_WHOLE && !b.whole)
         return fail(c, VPT_ERR_UNSUPPORTED, "VPT_PIPELINE_WHOLE needs a scene whose BVH rides in LDS, no media, samples_per_frame == 1 and every sample of a batch resident");
-    b.stream = !b.fused && !c->lds_scene && c->cfg.pipeline != VPT_PIPELINE_STAGED_R1;   // VPT_FLAG_LOCAL_HITS included: the stream kernels have validating instantiations
+    b.stream = !b.fused && c->cfg.pipeline != VPT_PIPELINE_STAGED_R1;   // (a scene that rides in LDS and is forced into the staged pipeline runs the stream kernels on its tree in memory; round 1's stage kernels: laboratory build, VPT_PIPELINE_STAGED_R1)
     if (vol && c->cfg.pipeline == VPT_PIPELINE_STAGED && c->lds_scene)
         return fail(c, VPT_ERR_UNSUPPORTED, "media with VPT_PIPELINE_STAGED need a scene whose BVH lives in memory (this one rides in LDS: use VPT_PIPELINE_AUTO or _FUSED)");
     if (b.media_stream) {
         int rl = ensure_media_buffers(c); if (rl != VPT_OK) return rl;
         if (frames > c->media_frames) return fail(c, VPT_ERR_DEVICE, "internal: media batch larger than the media streams");
     }
+#if VPT_LAB
     if (!b.fused && !b.stream) { int rl = ensure_legacy_buffers(c); if (rl != VPT_OK) return rl; }
+#else
+    if (!b.fused && !b.stream) return fail(c, VPT_ERR_UNSUPPORTED, "VPT_PIPELINE_STAGED_R1 needs the laboratory build");
+#endif
     if (b.stream && c->cfg.pipeline == VPT_PIPELINE_STAGED_SORTED) { int rl = ensure_sorted_buffers(c); if (rl != VPT_OK) return rl; }
     b.min_bounces = (uint64_t)c->P.max_depth * c->P.samples_per_frame;
     b.iter_cap = (b.min_bounces * 4ull + 1024ull) * ((frames + resident - 1) / resident);
@@ -743,10 +742,12 @@ int batch_begin(vpt_ctx* c, uint32_t frames, uint32_t dispatch_base, BatchState&
         b.parity = 1; b.k3 = 1; b.iter = 1;
     } else if (b.stream) {
         TIMED(c, VPT_K_PRIMARY, launch_raygen_stream(s, c->P, c->ps, c->ss, c->queue[0], b.n_first, dispatch_base, b.media_stream));
-        launch_stream_begin(s, c->sctr, b.n_first);
+        launch_stream_begin(s, c->sctr, b.n_first, n_slots);
         b.parity = 0;
     } else {
+#if VPT_LAB
         TIMED(c, VPT_K_PRIMARY, launch_raygen(s, c->P, c->ps, c->queue[0], c->ctr, n_slots, dispatch_base));
+#endif
         b.parity = 0;
     }
     return VPT_OK;
@@ -816,6 +817,9 @@ int batch_bounces(vpt_ctx* c, BatchState& b, uint32_t bounces) {
                 sb = c->stream2;
                 dsc_shadow.stack_overflow = c->stack_overflow2;   // its own stack spill region: it runs beside the next extend
             }
+            // regeneration: fresh camera rays into the room the ended paths left in the next queue (entries behind the ones the join of this
+            // bounce addresses, so it may run beside the shadow kernels and the join)
+            if (b.regen) TIMED(c, VPT_K_PRIMARY, launch_refill(s, 2048u, c->P, c->ps, c->ss, c->queue[parity ^ 1u], c->sctr, parity ^ 1u, b.n_first, b.dispatch_base));
             TIMED(c, VPT_K_SHADOW, launch_trace_shadow(sb, (uint32_t)c->shadow_blocks, false, count, dsc_shadow, c->ss, c->ctr, c->sctr, c->vote_param));
             TIMED(c, VPT_K_SHADOW, launch_trace_shadow(sb, (uint32_t)c->shadow_blocks, true, count, dsc_shadow, c->ss, c->ctr, c->sctr, c->vote_param));
             TIMED(c, VPT_K_JOIN, launch_join(sb, (uint32_t)c->join_blocks, c->P, c->ps, c->ss, c->sctr, c->queue[parity], c->queue[parity ^ 1u], parity));
@@ -823,10 +827,12 @@ int batch_bounces(vpt_ctx* c, BatchState& b, uint32_t bounces) {
             parity ^= 1u;
             continue;
         }
+#if VPT_LAB
         launch_prepare(s, c->ctr, parity);
         TIMED(c, VPT_K_EXTEND, launch_extend(s, (uint32_t)c->trav_blocks, c->lds_scene, count, c->dsc, c->ps, c->queue[parity], c->ctr, parity));
         TIMED(c, VPT_K_SHADE, launch_shade(s, (uint32_t)c->shade_blocks, c->dsc, c->P, c->ps, c->queue[parity], c->queue[parity ^ 1u], c->cqueue, c->ctr, parity));
         TIMED(c, VPT_K_CONNECT, launch_connect(s, (uint32_t)c->trav_blocks, c->lds_scene, count, c->dsc, c->P, c->ps, c->cqueue, c->ctr, parity));
+#endif
         parity ^= 1u;
     }
     return VPT_OK;
@@ -838,7 +844,9 @@ int batch_bounces(vpt_ctx* c, BatchState& b, uint32_t bounces) {
 int batch_resolve(vpt_ctx* c, BatchState& b) {
     hipStream_t s = c->stream;
     if (b.n_slots == 0) return VPT_OK;
+#if VPT_LAB
     if (!b.fused && !b.stream) launch_fold(s, c->ctr);
+#endif
     if (b.overlap && b.join_pending) { HIPCHK(c, hipStreamWaitEvent(s, c->ev_join, 0)); b.join_pending = false; }   // the resolve reads the frame sums the join writes
     const uint32_t* guard = b.fused ? &c->ctr->alive3[b.k3] : b.stream ? &c->sctr->alive[b.parity].v : &c->ctr->ray_count[b.parity];
     TIMED(c, VPT_K_RESOLVE, launch_resolve(s, c->P, c->ps, c->image, b.frames, b.dispatch_base, guard));
@@ -898,7 +906,7 @@ int batch_finish(vpt_ctx* c, BatchState& b, bool resolve_enqueued) {
         int rc = batch_check(c, b, &n);
         if (rc) return rc;
         if (n == 0) break;
-        rc = batch_bounces(c, b, b.n_first < b.n_slots ? 8u : 4u);   // (a regenerating batch runs many more launches than max_depth: fewer host round trips)
+        rc = batch_bounces(c, b, b.regen ? 8u : 4u);   // (a regenerating batch runs many more launches than max_depth: fewer host round trips)
         if (rc) return rc;
     }
     HIPCHK(c, hipGetLastError());
@@ -950,6 +958,14 @@ int drain(vpt_ctx* c) {
     c->order_lane = nullptr; c->post_pending = false;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream2));
+    if (c->last_fixed_valid) {   // a fixed-schedule batch on the main lane: nothing may have outlived it either (its guarded resolve would have been a no-op)
+        c->last_fixed_valid = false;
+        const BatchState& f = c->last_fixed;
+        if (f.stream) {
+            if (c->h_ctr->alive[0] != 0u) return fail(c, VPT_ERR_DEVICE, "internal: a path outlived a fixed-schedule batch");
+            if ((uint64_t)c->h_ctr->queue_len[0] > (uint64_t)c->ps.capacity + c->stream_slack) return fail(c, VPT_ERR_DEVICE, "internal: stream overflow");
+        } else if (f.fused && c->h_ctr->ctr.alive3[f.k3] != 0u) return fail(c, VPT_ERR_DEVICE, "internal: a path outlived a fixed-schedule batch");
+    }
     collect_timing(c);
     update_ray_stats(c);   // fixed-schedule batches copy their counters to pinned memory too
     HIPCHK(c, hipGetLastError());
@@ -1017,8 +1033,7 @@ int init_ctx_resources(vpt_ctx* c) {
         if (hipEventCreateWithFlags(&c->tick_ev[k], hipEventDisableTiming) != hipSuccess) { c->tick_ev[k] = nullptr; return VPT_ERR_DEVICE; }
     if (hipHostMalloc((void**)&c->h_ctr, sizeof(HostCounters), hipHostMallocDefault) != hipSuccess) { c->h_ctr = nullptr; return VPT_ERR_DEVICE; }
     memset(c->h_ctr, 0, sizeof(HostCounters));
-    if (hipMalloc((void**)&c->d_dispatch_base, 256) != hipSuccess || hipMalloc((void**)&c->d_spill_count, 256) != hipSuccess ||
-        hipMalloc((void**)&c->d_regen, sizeof(HotWord) * (kRegenShards + 1)) != hipSuccess) return VPT_ERR_DEVICE;
+    if (hipMalloc((void**)&c->d_dispatch_base, 256) != hipSuccess || hipMalloc((void**)&c->d_spill_count, 256) != hipSuccess) return VPT_ERR_DEVICE;
     return VPT_OK;
 }
 void destroy_lane(vpt_ctx* L);
@@ -1032,7 +1047,8 @@ vpt_ctx* get_lane(vpt_ctx* c, int k) {
     bool ok = init_ctx_resources(L) == VPT_OK && alloc_path_buffers(L, 1, 1) == VPT_OK;
     if (ok) {
         const size_t bytes = stack_overflow_bytes((uint32_t)std::max(std::max(c->primary_blocks_general, c->primary_blocks_plain), c->whole_blocks));
-        ok = hipMalloc(&L->lane_spill, bytes) == hipSuccess;
+        ok = hipMalloc(&L->lane_spill, bytes) == hipSuccess && hipMemset(L->lane_spill, 0x7f, bytes) == hipSuccess;   // (kSpillPatternByte: vpt_get_stats counts what was spilled)
+        L->stack_overflow_words = (uint32_t)(bytes / 4);
     }
     if (!ok) { (void)hipGetLastError(); destroy_lane(L); return nullptr; }
     L->frames_in_flight = 1; L->buffers_ok = true;
@@ -1060,7 +1076,6 @@ void destroy_lane(vpt_ctx* L) {
     if (L->h_ctr) (void)hipHostFree(L->h_ctr);
     if (L->d_dispatch_base) (void)hipFree(L->d_dispatch_base);
     if (L->d_spill_count) (void)hipFree(L->d_spill_count);
-    if (L->d_regen) (void)hipFree(L->d_regen);
     if (L->ctr) (void)hipFree(L->ctr);
     if (L->sctr) (void)hipFree(L->sctr);
     if (L->d_launch_off) (void)hipFree(L->d_launch_off);
@@ -1118,6 +1133,9 @@ void vpt_default_post_params(vpt_post_params* p) {  // PostProcessor.h:8-21
 vpt_ctx* vpt_create(const vpt_config* cfg, int* err) {
     auto set = [&](int e) { if (err) *err = e; };
     if (!cfg || cfg->width == 0 || cfg->height == 0 || cfg->shard_count == 0 || cfg->shard_rank >= cfg->shard_count || cfg->pipeline > VPT_PIPELINE_WHOLE) { set(VPT_ERR_INVALID_ARGUMENT); return nullptr; }
+#if !VPT_LAB
+    if (cfg->pipeline == VPT_PIPELINE_STAGED_R1) { set(VPT_ERR_UNSUPPORTED); return nullptr; }   // round 1's stage kernels live in the laboratory build (libvpt_hip_lab.so)
+#endif
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev) { set(VPT_ERR_NO_DEVICE); return nullptr; }
     if (hipSetDevice(cfg->device) != hipSuccess) { set(VPT_ERR_NO_DEVICE); return nullptr; }
@@ -1150,7 +1168,6 @@ void vpt_destroy(vpt_ctx* c) {
     if (c->h_ctr) (void)hipHostFree(c->h_ctr);
     if (c->d_dispatch_base) (void)hipFree(c->d_dispatch_base);
     if (c->d_spill_count) (void)hipFree(c->d_spill_count);
-    if (c->d_regen) (void)hipFree(c->d_regen);
     free_lab(c);
     free_scene(c);
     free_render_buffers(c);
@@ -1338,8 +1355,13 @@ int vpt_set_scene(vpt_ctx* c, const vpt_scene_desc* sd) {
     if ((rc = upload(c, lr, &D.lut_r))) return rc;
     if ((rc = upload(c, lo, &D.lut_o))) return rc;
     if ((rc = upload(c, li, &D.lut_i))) return rc;
+#if VPT_LAB
     c->trav_blocks = traverse_blocks_per_cu(c->lds_scene, D) * c->cu_count;
     c->shade_blocks = shade_blocks_per_cu() * c->cu_count;
+#else
+    c->trav_blocks = 0;
+    c->shade_blocks = 4 * c->cu_count;   // (the media scatter stage's grid-stride launch)
+#endif
     c->join_blocks = join_blocks_per_cu() * c->cu_count;
     c->primary_blocks_general = bounce_blocks_per_cu(c->lds_scene, D, false) * c->cu_count;
     c->primary_blocks_plain = bounce_blocks_per_cu(c->lds_scene, D, true) * c->cu_count;
@@ -1363,6 +1385,7 @@ int vpt_set_scene(vpt_ctx* c, const vpt_scene_desc* sd) {
         // preset to a word no stack entry can be (a node index of 2.1e9; leaf codes are negative): vpt_get_stats counts what was spilled
         HIPCHK(c, hipMemset(d, kSpillPatternByte, 2 * region));
         c->stack_overflow_words = (uint32_t)(region / 4);
+        c->spill_dirty = true;
     }
     launch_precompute_tri_ng(c->stream, D, c->d_tri_ng);
     launch_precompute_tri_shade(c->stream, D, c->d_tri_shade);
@@ -1928,17 +1951,23 @@ int vpt_get_stats(vpt_ctx* c, vpt_stats* out) {
     s.build_flags = (c->sbvh ? VPT_BUILD_SBVH : 0u) | (c->cfg.build_flags & VPT_BUILD_GENERAL_KERNELS);
     s.frames_allocated = c->frames_alloc; s.resident_frames = c->resident_alloc;
     s.set_scene_ms = c->set_scene_ms; s.bvh_build_ms = c->bvh_build_ms;
-    s.stack_spills[0] = s.stack_spills[1] = 0;
-    if (c->has_scene && c->stack_overflow_words && c->dsc.stack_overflow) {   // what the traversal kernels have written into their spill regions
+    // what the traversal kernels have written into their spill regions: counted when something has run since the last count (the scan reads
+    // ~0.4 GB: a host that asks for the statistics after every frame would otherwise pay 0.1-0.2 ms per call for a number that does not change)
+    if (c->has_scene && c->stack_overflow_words && c->dsc.stack_overflow && c->spill_dirty) {
         HIPCHK(c, hipSetDevice(c->cfg.device));
         unsigned long long h[2] = {0ull, 0ull};
         HIPCHK(c, hipMemsetAsync(c->d_spill_count, 0, 16, c->stream));
         hipLaunchKernelGGL(k_count_spilled, dim3(1024), dim3(256), 0, c->stream, c->dsc.stack_overflow, c->stack_overflow_words, c->d_spill_count);
         hipLaunchKernelGGL(k_count_spilled, dim3(1024), dim3(256), 0, c->stream, c->stack_overflow2, c->stack_overflow_words, c->d_spill_count + 1);
+        for (vpt_ctx* L : c->lanes)   // the lanes' own regions (pipelined asynchronous frames) count towards the first figure
+            if (L && L->lane_spill && L->stack_overflow_words)
+                hipLaunchKernelGGL(k_count_spilled, dim3(1024), dim3(256), 0, c->stream, (const uint32_t*)L->lane_spill, L->stack_overflow_words, c->d_spill_count);
         HIPCHK(c, hipMemcpyAsync(h, c->d_spill_count, 16, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        s.stack_spills[0] = h[0]; s.stack_spills[1] = h[1];
+        c->spill_cached[0] = h[0]; c->spill_cached[1] = h[1];
+        c->spill_dirty = false;
     }
+    s.stack_spills[0] = c->has_scene ? c->spill_cached[0] : 0; s.stack_spills[1] = c->has_scene ? c->spill_cached[1] : 0;
     *out = s;
     return VPT_OK;
 }
@@ -2105,6 +2134,7 @@ int vpt_multi_gather_shards(vpt_ctx* const* ctxs, uint32_t count, uint32_t root)
     return assemble_from_gather_buf(R);
 }
 
+#if VPT_LAB   // ---- the laboratory's entry points (include/vpt_lab.h): absent from the product library
 int vpt_lab_set(vpt_ctx* c, uint32_t key, uint32_t value) {
     if (!c || (value > 3u && key != VPT_LAB_WHOLE_FRAMES && key != VPT_LAB_WHOLE_SCHED)) return VPT_ERR_INVALID_ARGUMENT;
     HIPCHK(c, hipSetDevice(c->cfg.device));
@@ -2158,7 +2188,7 @@ int vpt_lab_trace(vpt_ctx* c, uint32_t variant, uint32_t any_hit, const uint32_t
     a.ro = c->lab_ro; a.rd = c->lab_rd; a.order = order ? c->lab_order : nullptr; a.hit = c->lab_hit; a.hinst = c->lab_hinst;
     a.n = n; a.head = &c->ctr->extend_head; a.tmin = c->lab_tmin; a.tmax = c->lab_tmax; a.normalize_dir = 0u; a.param = (variant == VPT_TRACE_POOL || variant == VPT_TRACE_PAIR) ? param : param & 0xfff1ffffu;
     a.cull = variant == VPT_TRACE_VOTE ? (param >> 17) & 1u : 0u;     // lab: bit 17 = stale-entry culling (closest-hit, VPT_TRACE_VOTE)
-    a.tri2 = variant == VPT_TRACE_VOTE ? (param >> 19) & 1u : 0u;     // lab: bit 19 = one triangle per triangle step, as before round 4 (VPT_TRACE_VOTE, product vote parameters)
+    a.one_tri = variant == VPT_TRACE_VOTE ? (param >> 19) & 1u : 0u;     // lab: bit 19 = one triangle per triangle step, as before round 4 (VPT_TRACE_VOTE, product vote parameters)
     a.packed = variant == VPT_TRACE_VOTE ? (param >> 18) & 1u : 0u;   // lab: bit 18 = packed plane arithmetic in the node step (VPT_TRACE_VOTE, product vote parameters)
     // (the pool variant's spill region is indexed by slot: 512 slots per block against 256 threads)
     const uint32_t blocks = (uint32_t)std::min(trace_blocks_per_cu(variant, any_hit != 0) * c->cu_count, (variant == VPT_TRACE_POOL || variant == VPT_TRACE_PAIR) ? c->max_blocks / 2 : c->max_blocks);
@@ -2197,6 +2227,8 @@ int vpt_lab_trace(vpt_ctx* c, uint32_t variant, uint32_t any_hit, const uint32_t
     }
     return VPT_OK;
 }
+
+#endif  // VPT_LAB
 
 int vpt_lut_calculate(int device, uint32_t kind, uint32_t sx, uint32_t sy, uint32_t sz, uint32_t sample_count, uint32_t time_ms, float* out) {
     // sampleCount / 20 passes (LookupTableCalculator.cpp:97); fewer than one pass would divide the table by zero

@@ -185,8 +185,10 @@ bool PathTracer::PathTraceAsync(uint32_t dispatches, uint64_t* ticket) {
     if (!m_Ctx) throw std::runtime_error("PathTrace before SetScene");
     int done = 0;
     Check(vpt_render_async(m_Ctx, dispatches, &done, ticket), "vpt_render_async");
-    // the counters advance at record time, as PathTrace's do (PathTracer.cpp:141-153); vpt_get_stats would wait for the device
-    if (!done) {
+    // the counters advance at record time, as PathTrace's do (PathTracer.cpp:141-153); vpt_get_stats would wait for the device.  Unconditionally:
+    // a call can make progress AND report done (2 dispatches left, 4 asked for: 2 run, then max_samples is reached), and the clamp makes the
+    // update a no-op when nothing ran
+    {
         const uint64_t s2 = (uint64_t)m_Params.screen_chunk_count * m_Params.screen_chunk_count;
         const uint64_t frames_needed = ((uint64_t)m_Params.max_samples + m_Params.samples_per_frame - 1) / m_Params.samples_per_frame;
         m_DispatchCount = std::min<uint64_t>(m_DispatchCount + dispatches, frames_needed * s2);
