@@ -502,6 +502,10 @@ def main():
                 if world > 1:
                     w["strong"] = {k: runs["strong"][k] for k in ("value", "unit", "ms_per_step", "batches_per_gpu", "timed_samples_per_pixel", "mrays_per_s")}
                 w.update(kernel_profile(vpt, other, sc2, local_rank, rank, world, 0, 0, 3))
+                if world == 1 and not args.no_latency:   # one frame per call on the real scenes too (Editor.cpp:116,129): the streams pipeline's ~7 launches per bounce
+                    wl2 = WORKLOADS[other]
+                    w["latency"] = frame_latency(vpt, other, sc2, vpt.default_params(max_depth=wl2["depth"], base_seed=BASE_SEED, max_samples=0x7fffffff), local_rank, frames=10)
+                    w["latency"]["batch_ms_per_frame"] = round(wl2["w"] * wl2["h"] / (w["value"] * 1e3), 4)   # what a frame costs inside a full batch: the floor
                 r = roofline_for(other, w)
                 w["roofline"] = {k: r[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_frac_of_hbm_peak", "valu_busy", "avg_launch_ms", "algorithmic_GBs", "algorithmic_frac_of_hbm_peak", "pmc", "valu")}
                 extra[other] = w

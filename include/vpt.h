@@ -45,7 +45,13 @@ extern "C" {
 #define VPT_FLAG_GEOMETRY_NORMALS (1u << 3)    /* USE_ONLY_GEOMETRY_NORMALS SetUseOnlyGeometryNormals */
 #define VPT_FLAG_ENERGY_COMPENSATION (1u << 4) /* USE_ENERGY_COMPENSATION   SetUseEnergyCompensation */
 #define VPT_FLAG_FURNACE (1u << 5)             /* FURNACE_TEST_MODE         SetFurnaceTestMode   */
-#define VPT_FLAG_RAY_QUERIES (1u << 6)         /* USE_RAY_QUERIES (only mode implemented)        */
+#define VPT_FLAG_RAY_QUERIES (1u << 6)         /* USE_RAY_QUERIES: shadow / distance queries as ray queries (RTCommon.slang:52-63, 88-101: direction as it is,
+                                                * TMin 1e-4 / 1e-5, TMax 1e6, closest committed hit).  CLEAR = the TraceRay forms (RTCommon.slang:64-84, 103-117,
+                                                * MissShadow.slang:4-9): normalised direction, TMin 1e-5, TMax 1000, accept-first-hit.  Upstream, the light-identity
+                                                * compare of an emissive-mesh NEE sample then reads payload.TriangleIdx / InstanceIdx, which nothing on that path
+                                                * writes (closest-hit shader skipped, MissShadow leaves them alone): an UNDEFINED word.  Pinned here (oracle and
+                                                * kernels alike) as "never equal": in this mode an emissive-mesh NEE sample is drawn and never visible, so meshes
+                                                * light the scene through BSDF-sampled hits only; sky visibility and GetDistanceToGeometry are well defined and exact */
 /* Tonemap.slang:170 samples the bloom image with a sampler whose filter is VulkanHelper's
  * default (PostProcessor.cpp:67, unpinned): set = LINEAR (default), clear = NEAREST. */
 #define VPT_FLAG_TONEMAP_LINEAR_BLOOM_TAP (1u << 7)
@@ -392,11 +398,11 @@ int vpt_render(vpt_ctx* ctx, uint32_t dispatches, int* done);
  * When every path of a batch provably ends within max_depth * samples_per_frame bounces (no material scatters inside a medium, no
  * volumes / atmosphere) and that number is <= VPT_ASYNC_MAX_BOUNCES — or when the batch is ONE whole-path launch (VPT_PIPELINE_WHOLE, which
  * AUTO takes for LDS-resident scenes: every path runs to its end inside it, whatever max_depth is) — a batch is a fixed schedule: nothing in
- * it waits for the host, any number of frames can be in flight, and a 1-frame batch of the whole-path / fused pipelines is captured once as a
- * hipGraph and replayed (vpt_stats.graph_launches).  Otherwise the enqueued part is the first VPT_ASYNC_MAX_BOUNCES bounces and the NEXT call on the context
+ * it waits for the host, any number of frames can be in flight, and such a batch — the whole-path / fused pipelines', and the streams pipeline's ~7 launches
+ * per bounce on one stream — is captured once as a hipGraph and replayed while nothing changes (vpt_stats.graph_launches).  Otherwise the enqueued part is the first VPT_ASYNC_MAX_BOUNCES bounces and the NEXT call on the context
  * (or vpt_wait) finishes the batch first, exactly as vpt_render would have.  Images are bit-identical to vpt_render's either way.
  * Every other entry point that reads or changes device state drains outstanding work first. */
-#define VPT_ASYNC_MAX_BOUNCES 16u
+#define VPT_ASYNC_MAX_BOUNCES 32u
 int vpt_render_async(vpt_ctx* ctx, uint32_t dispatches, int* done, uint64_t* ticket);
 int vpt_postprocess_device(vpt_ctx* ctx, const vpt_post_params* params, void* rgba8_device, uint64_t* ticket);
 int vpt_wait(vpt_ctx* ctx, uint64_t ticket);

@@ -279,10 +279,19 @@ bool closest_hit_impl(const Oracle& o, V3 org, V3 dir, float tmin, float tmax, H
 }
 
 // RTCommon.slang:47-64 (USE_RAY_QUERIES path): TMin 1e-4, TMax 1e6, closest committed hit.
+// Without USE_RAY_QUERIES (RTCommon.slang:64-84, MissShadow.slang:4-9): TraceRay with ACCEPT_FIRST_HIT_AND_END_SEARCH | SKIP_CLOSEST_HIT_SHADER and
+// the shadow miss shader, on the NORMALISED direction with TMin 1e-5, TMax 1000; "intersects" = payload.Depth stayed 0 = some triangle was hit.
+// Nothing on that path writes payload.TriangleIdx / InstanceIdx (the closest-hit shader is skipped, MissShadow leaves them alone), so the
+// callers' light-identity compare reads an UNDEFINED word upstream.  Pinned here as "never equal to a sampled light": an emissive-mesh NEE
+// sample is never visible in this mode (its random draws still happen).  DESIGN.md section 5.
 bool does_ray_intersect(const Oracle& o, V3 org, V3 dir, uint32_t& tri, uint32_t& inst, Counters* c) {
     tri = 0; inst = 0;
     Hit h;
     if (c) c->shadow++;
+    if (!(o.P.flags & VPT_FLAG_RAY_QUERIES)) {
+        tri = 0xffffffffu; inst = 0xffffffffu;
+        return closest_hit(o, org, normalize(dir), 0.00001f, 1000.0f, h, c);
+    }
     if (closest_hit(o, org, dir, 0.0001f, 1000000.0f, h, c)) { tri = h.prim; inst = h.inst; return true; }
     return false;
 }
@@ -1111,9 +1120,10 @@ bool scattered_in_volume(const Oracle& o, Payload& p, Counters* c) {
     for (int i = 0; i < n; i++)
         for (int j = i + 1; j < n; j++)
             if (dist[j] < dist[i]) { std::swap(dist[i], dist[j]); std::swap(idx[i], idx[j]); }
-    float dgeo = -1.0f;  // GetDistanceToGeometry, RTCommon.slang:86-101: the payload direction as is
+    float dgeo = -1.0f;  // GetDistanceToGeometry, RTCommon.slang:86-101: the payload direction as is; without USE_RAY_QUERIES (:103-117) normalised, TMax 1000
     Hit h;
-    if (closest_hit(o, p.origin, p.direction, 0.00001f, 1000000.0f, h, c)) dgeo = h.t;
+    if (o.P.flags & VPT_FLAG_RAY_QUERIES) { if (closest_hit(o, p.origin, p.direction, 0.00001f, 1000000.0f, h, c)) dgeo = h.t; }
+    else if (closest_hit(o, p.origin, normalize(p.direction), 0.00001f, 1000.0f, h, c)) dgeo = h.t;
     float sd = -1.0f; int sv = -1;
     for (int i = 0; i < n; i++) {
         float t = does_ray_scatter(o, o.volumes[idx[i]], p.origin, p.direction, p.rng, (float)p.depth, sd);

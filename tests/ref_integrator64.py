@@ -14,6 +14,17 @@ from test_oracle_bsdf_fp64 import Mat64, Rng64, _pcg, _norm, sample64
 
 MAX_DEPTH = 1000000   # Defines.slang:17
 FLAG_SKY_MIS, FLAG_MESH_MIS, FLAG_SHOW_ENV_DIRECTLY, FLAG_GEOMETRY_NORMALS, FLAG_ENERGY_COMPENSATION, FLAG_FURNACE = 1, 2, 4, 8, 16, 32   # the reference's #defines as vpt_params.flags bits
+FLAG_RAY_QUERIES = 64
+
+
+def shadow_hit(S, P, o, d):
+    """DoesRayIntersectWithAS (RTCommon.slang:47-84) -> (closest hit or None, are payload.TriangleIdx / InstanceIdx defined).
+    USE_RAY_QUERIES: the direction as it is, [1e-4, 1e6], the committed hit's identity.  Otherwise the TraceRay form (:64-84, MissShadow.slang:4-9):
+    normalised direction, [1e-5, 1000], accept-first-hit with the closest-hit shader skipped — nothing writes the identity words, and a compare
+    against them is pinned as 'never equal' (include/vpt.h VPT_FLAG_RAY_QUERIES)."""
+    if P.flags & FLAG_RAY_QUERIES:
+        return S.closest(o, d, 0.0001, 1000000.0), True
+    return S.closest(o, _norm(d), 0.00001, 1000.0), False
 
 
 def power_heuristics(a, b):   # RTCommon.slang:124-127
@@ -430,7 +441,8 @@ def scattered_in_volume(S, pay, rng, P):   # RayGen.slang:162-270 without an atm
         for j in range(i + 1, n):
             if dist[j] < dist[i]:
                 dist[i], dist[j] = dist[j], dist[i]; idx[i], idx[j] = idx[j], idx[i]
-    h = S.closest(o, d, 0.00001, 1000000.0)            # GetDistanceToGeometry (RTCommon.slang:86-101, ray queries): the direction as it is
+    # GetDistanceToGeometry (RTCommon.slang:86-101, ray queries): the direction as it is; the TraceRay form (:103-117): normalised, TMax 1000
+    h = S.closest(o, d, 0.00001, 1000000.0) if (P.flags & FLAG_RAY_QUERIES) else S.closest(o, _norm(d), 0.00001, 1000.0)
     dtg = h[0] if h is not None else -1.0
     sd, sv = -1.0, -1
     for i in range(n):
@@ -469,14 +481,14 @@ def scattered_in_volume(S, pay, rng, P):   # RayGen.slang:162-270 without an atm
     po = pay["origin"]
     to_sky, sky = sample_sky(S, rng, P)
     sky[:3] = sky[:3] * P.sky_intensity
-    if S.closest(po, to_sky, 0.0001, 1000000.0) is not None:
+    if shadow_hit(S, P, po, to_sky)[0] is not None:
         sky = np.zeros(4)
     light = np.zeros(4); to_light = np.zeros(3)
     if S.emissive:
         to_light, light, e_inst, ti = sample_emissive(S, po, rng)
-        h2 = S.closest(po, to_light, 0.0001, 1000000.0)
+        h2, ids_defined = shadow_hit(S, P, po, to_light)
         hit_ids = S.ids[h2[3]] if h2 is not None else (0, 0)       # hitInstanceIndex / hitTriangleIdx default to 0 (RTCommon.slang:49-50)
-        if hit_ids != (e_inst, ti):
+        if hit_ids != (e_inst, ti) or not ids_defined:
             light = np.zeros(4)
     vd = pay["vdepth"]
     nd = sample_phase(S, v, d, vd, rng)
@@ -660,7 +672,7 @@ def atmosphere_event(S, pay, rng, P, sd, comp):   # EvaluateAtmosphereScattering
     nd = sample_rayleigh(d, rng) if comp == 0 else (sample_hg(d, 0.85, rng) if comp == 1 else d)
     to_sun, cp = sample_sun(S, rng, P)
     cp[:3] = cp[:3] * P.sky_intensity
-    if S.closest(pay["origin"], to_sun, 0.0001, 1000000.0) is None:
+    if shadow_hit(S, P, pay["origin"], to_sun)[0] is None:
         T = atm_transmittance(S.atm, rng, pay["origin"], to_sun, pay["cchan"]) * volumes_transmittance(S, pay["origin"], to_sun, rng)
     else:
         T = np.zeros(3)
@@ -792,7 +804,7 @@ def closest_hit(S, luts, pay, rd, hit, rng, P):
         to_sky, sky = sample_sky(S, rng, P)
         sky[:3] = sky[:3] * P.sky_intensity            # the intensity is applied a second time here (:131), as upstream does
         to_sky_t = w2t(to_sky) if np.isfinite(to_sky).all() and np.abs(to_sky).max() > 0 else np.zeros(3)
-        can_sky = S.closest(pos + N * 1e-5, to_sky, 0.0001, 1000000.0) is None
+        can_sky = shadow_hit(S, P, pos + N * 1e-5, to_sky)[0] is None
         if not can_sky:
             sky = np.zeros(4)
     # ---- light NEE (Sampler.slang:348-422)
@@ -802,8 +814,8 @@ def closest_hit(S, luts, pay, rd, hit, rng, P):
         light_rgb, light_pdf = lc[:3], float(lc[3])
         if light_pdf > 0.0:
             to_light_t = w2t(to_light)
-            h2 = S.closest(pos + to_light * 1e-2, to_light, 0.0001, 1000000.0)   # RTCommon.slang:54-60 (ray queries)
-            can_light = h2 is not None and S.ids[h2[3]] == (e_inst, ti)
+            h2, ids_defined = shadow_hit(S, P, pos + to_light * 1e-2, to_light)   # RTCommon.slang:54-60 (ray queries) / :64-84
+            can_light = h2 is not None and ids_defined and S.ids[h2[3]] == (e_inst, ti)
             if not can_light:
                 light_rgb = np.zeros(3); light_pdf = 0.0
     # ---- BSDF sampling

@@ -206,3 +206,24 @@ def test_async_edge_cases(vpt, oracle, scenes):
         g.render_async(1)
     assert np.array_equal(g.radiance(), oracle_image(oracle, sc, 64, 36, p, 5))
     g.close()
+
+
+def test_fixed_stream_batches_are_replayed_from_a_graph(vpt, oracle, scenes):
+    """A frame per call on a scene whose BVH lives in memory: the streams pipeline's fixed batch (depth 8 <= VPT_ASYNC_MAX_BOUNCES, no medium) is
+    captured once — on one stream — and replayed; a parameter change in between re-captures.  Same image as the oracle's."""
+    sc, w, h = scenes("cornell_box_glass"), 96, 54
+    p = vpt.default_params(max_depth=8)
+    g = vpt.PathTracer(w, h, frames_in_flight=1)
+    g.set_scene(sc); g.set_params(p)
+    for _ in range(7):
+        g.render_async(1); g.postprocess_device()
+    img = g.radiance()
+    st = g.stats()
+    assert st["frames"] == 7 and st["graph_launches"] >= 4 and st["kernel_launches"]["join"] == 7 * 8
+    assert np.array_equal(img, oracle_image(oracle, sc, w, h, p, 7))
+    p2 = vpt.default_params(max_depth=5)
+    g.set_params(p2)
+    for _ in range(5):
+        g.render_async(1)
+    assert np.array_equal(g.radiance(), oracle_image(oracle, sc, w, h, p2, 5))
+    g.close()

@@ -14,4 +14,4 @@ def test_smoke_entry_point(capsys):
     entry = importlib.import_module("__graft_entry__")
     entry.smoke()
     out = capsys.readouterr().out
-    assert out.count("smoke ok") == 3
+    assert out.count("smoke ok") == 5

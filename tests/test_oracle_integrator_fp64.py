@@ -49,6 +49,9 @@ def variants(scenes, vpt_scenes, vpt_mod):
             "atmosphere": (base, 10, 120, 2), "atmosphere_with_fog": (base, 10, 120, 2, fog),
             "fog_draine": (base, 8, 80, 2, fog), "fog_hg_plus_draine": (sky, 8, 80, 2, fog),
             "flags_no_mis_no_compensation": (sky, 6, 80, 2), "flags_geometry_normals_hidden_env": (sky, 6, 80, 2), "flags_furnace": (sky, 6, 80, 2),
+            # SetUseRayQueries(false): the TraceRay forms of the shadow / distance queries (RTCommon.slang:64-84, 103-117) — under the environment
+            # with the lamp on (its NEE sample is drawn and never visible), and with fog (the distance query)
+            "flags_no_ray_queries": (sky, 6, 90, 3), "flags_no_ray_queries_fog": (sky, 8, 80, 2, fog),
             # heterogeneous boxes (Volume.slang:69-147, 299-348, 448-520): density from a grid — delta-tracked scattering block by block through
             # the 32^3 majorant table, ratio-tracked transmittance with roulette (it draws, so NEE order matters), jittered lookups; a smoke
             # column in the room, and the same column inside homogeneous fog under the environment
@@ -66,7 +69,7 @@ def smoke_grid():
     return (d * 3.7 / d.max()).astype(np.float32)
 
 
-@pytest.mark.parametrize("which", ["cornell_d6", "cornell_d12", "metal_anisotropic", "glass_sphere", "environment", "textured_viking_room", "textured_boxes", "medium_in_glass", "fog", "two_boxes_environment", "depth_of_field_3spf", "atmosphere", "atmosphere_with_fog", "fog_draine", "fog_hg_plus_draine", "flags_no_mis_no_compensation", "flags_geometry_normals_hidden_env", "flags_furnace", "smoke_grid", "smoke_grid_in_fog_environment"])
+@pytest.mark.parametrize("which", ["cornell_d6", "cornell_d12", "metal_anisotropic", "glass_sphere", "environment", "textured_viking_room", "textured_boxes", "medium_in_glass", "fog", "two_boxes_environment", "depth_of_field_3spf", "atmosphere", "atmosphere_with_fog", "fog_draine", "fog_hg_plus_draine", "flags_no_mis_no_compensation", "flags_geometry_normals_hidden_env", "flags_furnace", "flags_no_ray_queries", "flags_no_ray_queries_fog", "smoke_grid", "smoke_grid_in_fog_environment"])
 def test_per_sample_values_match_the_float64_integrator(vpt, oracle, scenes, which):
     import ref_integrator64 as R
     v = variants(scenes, vpt.scenes, vpt)[which]
@@ -84,7 +87,8 @@ def test_per_sample_values_match_the_float64_integrator(vpt, oracle, scenes, whi
         a = vpt._abi
         fl = {"flags_no_mis_no_compensation": a.FLAGS_DEFAULT & ~(a.FLAG_SKY_MIS | a.FLAG_MESH_MIS | a.FLAG_ENERGY_COMPENSATION),
               "flags_geometry_normals_hidden_env": (a.FLAGS_DEFAULT | a.FLAG_GEOMETRY_NORMALS) & ~a.FLAG_SHOW_ENV_DIRECTLY,
-              "flags_furnace": a.FLAGS_DEFAULT | a.FLAG_FURNACE}[which]
+              "flags_furnace": a.FLAGS_DEFAULT | a.FLAG_FURNACE,
+              "flags_no_ray_queries": a.FLAGS_DEFAULT & ~a.FLAG_RAY_QUERIES, "flags_no_ray_queries_fog": a.FLAGS_DEFAULT & ~a.FLAG_RAY_QUERIES}[which]
         P = vpt.default_params(max_depth=depth, sky_azimuth=35.0, sky_altitude=-20.0, sky_intensity=1.5, flags=fl)
     atm = None
     if which.startswith("atmosphere"):   # Rayleigh / Mie / ozone delta tracking, one colour channel per path after the first collision, sun-disk NEE

@@ -24,7 +24,7 @@ KERNEL_COUNT = 10
 PIPELINE_AUTO, PIPELINE_FUSED, PIPELINE_STAGED = 0, 1, 2
 PIPELINE_STAGED_R1, PIPELINE_STAGED_SORTED, PIPELINE_WHOLE = 3, 4, 5
 LAB_LANES, LAB_LANE_GRID, LAB_TAIL_GRID, LAB_WHOLE_FRAMES, LAB_WHOLE_SCHED = 1, 2, 3, 4, 5
-ASYNC_MAX_BOUNCES = 16
+ASYNC_MAX_BOUNCES = 32
 
 
 class Material(C.Structure):

@@ -72,7 +72,7 @@ void launch_shade_stream(hipStream_t s, uint32_t blocks, uint32_t cls, bool sort
                          const uint32_t* queue, const uint32_t* order, uint32_t* queue_next, Counters* ctr, StreamCounters* sctr, uint32_t parity);
 void launch_classify_instances(hipStream_t s, const DeviceScene& sc, unsigned char* out, uint32_t n);
 void launch_trace_shadow(hipStream_t s, uint32_t blocks, bool light, bool count, const DeviceScene& sc, const StreamState& ss, Counters* ctr,
-                         StreamCounters* sctr, uint32_t param);
+                         StreamCounters* sctr, uint32_t param, uint32_t ray_queries = 1u);   // ray_queries: USE_RAY_QUERIES (RTCommon.slang:52 / :64)
 void launch_join(hipStream_t s, uint32_t blocks, const RenderParams& P, const PathState& ps, const StreamState& ss, const StreamCounters* sctr, const uint32_t* queue,
                  const uint32_t* queue_next, uint32_t parity);
 int shade_stream_blocks_per_cu();

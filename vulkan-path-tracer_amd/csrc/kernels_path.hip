@@ -65,11 +65,14 @@ __device__ inline bool trace_any(const DeviceScene& sc, const float4* lds_nodes,
 }
 
 // Sky visibility / light identity as exact any-hit queries (traverse.hpp).
+// rq: USE_RAY_QUERIES (RTCommon.slang:52-63: the direction as it is, TMin 1e-4, TMax 1e6); otherwise RTCommon.slang:64-84: normalised, TMin 1e-5, TMax 1000.
 template <bool LDS_SCENE, bool COUNT>
-__device__ inline bool sky_visible(const DeviceScene& sc, const float4* lds_nodes, const float4* lds_tris, V3 o, V3 d, const TravStack& stack, TravStats& st) {
-    if (LDS_SCENE) { LdsSceneSrc src{lds_nodes, lds_tris, sc.strict_hits != 0u}; return !trace_occluded<COUNT, false>(src, o, d, 0.0001f, 1000000.0f, 0.0f, 0u, stack, st); }
+__device__ inline bool sky_visible(const DeviceScene& sc, const float4* lds_nodes, const float4* lds_tris, V3 o, V3 d, const TravStack& stack, TravStats& st, bool rq) {
+    const float tmin = rq ? 0.0001f : 0.00001f, tmax = rq ? 1000000.0f : 1000.0f;
+    if (!rq) d = normalize(d);
+    if (LDS_SCENE) { LdsSceneSrc src{lds_nodes, lds_tris, sc.strict_hits != 0u}; return !trace_occluded<COUNT, false>(src, o, d, tmin, tmax, 0.0f, 0u, stack, st); }
     GlobalSceneSrc src{sc.nodes, sc.tris, sc.strict_hits != 0u};
-    return !trace_occluded<COUNT, false>(src, o, d, 0.0001f, 1000000.0f, 0.0f, 0u, stack, st);
+    return !trace_occluded<COUNT, false>(src, o, d, tmin, tmax, 0.0f, 0u, stack, st);
 }
 template <bool LDS_SCENE, bool COUNT>
 __device__ inline bool light_visible(const DeviceScene& sc, const float4* lds_nodes, const float4* lds_tris, V3 o, V3 d, uint32_t gid, const TravStack& stack, TravStats& st) {
@@ -271,6 +274,7 @@ __global__ __launch_bounds__(kTraverseBlock, 3) void k_bounce(DeviceScene sc, Re
     if (!VOL && LDS_SCENE) sc.strict_hits = STRICT ? 1u : 0u;
     if (PLAIN) { sc.all_plain = 1u; sc.env_black = 1u; } else sc.all_plain = 0u;   // likewise
     if (FIRST && P.dispatch_base_dev) dispatch_base = *P.dispatch_base_dev;   // a replayed graph: the batch's first dispatch index lives in device memory
+    const bool rq = (P.flags & VPT_FLAG_RAY_QUERIES) != 0u;   // USE_RAY_QUERIES (RTCommon.slang:52 / :64): which interval and direction the shadow and distance queries use
     extern __shared__ __align__(16) unsigned char smem[];
     const TravStack stack = make_stack(smem, sc.stack_overflow);
     float4* lds_nodes = reinterpret_cast<float4*>(smem + kStackDepth * kTraverseBlock * 4);
@@ -380,7 +384,8 @@ __global__ __launch_bounds__(kTraverseBlock, 3) void k_bounce(DeviceScene sc, Re
                     aborted = VOL && sc.atm_on && atmosphere_height(sc, in_.porg) < 0.0f;
                     if (VOL && !aborted) {  // ScatteredInVolume (RayGen.slang:86): GetDistanceToGeometry uses the payload direction as is,
                                             // TMin 1e-5, TMax 1e6 (RTCommon.slang:86-101)
-                        bool g = trace_any<LDS_SCENE, COUNT>(sc, lds_nodes, lds_tris, in_.porg, in_.pdir, 0.00001f, 1000000.0f, stack, hr, st);
+                        // (without USE_RAY_QUERIES: RTCommon.slang:103-117 — normalised direction, TMax 1000)
+                        bool g = trace_any<LDS_SCENE, COUNT>(sc, lds_nodes, lds_tris, in_.porg, rq ? in_.pdir : normalize(in_.pdir), 0.00001f, rq ? 1000000.0f : 1000.0f, stack, hr, st);
                         Rng vr; vr.s = in_.rng;
                         int cc;
                         in_.vol_index = scattered_in_media(sc, in_.porg, in_.pdir, vr, g ? hr.t : -1.0f, (float)in_.depth, in_.cchan, in_.vol_t, in_.atm_comp, cc);
@@ -420,12 +425,12 @@ __global__ __launch_bounds__(kTraverseBlock, 3) void k_bounce(DeviceScene sc, Re
             // connect, inline (RayGen.slang:92-102; FIRST: pathThroughput == 1, pathLight == 0)
                 V3 E = o.emitted;
                 if (!VOL && o.want_sky) {
-                    if (sky_visible<LDS_SCENE, COUNT>(sc, lds_nodes, lds_tris, o.sky_o, o.sky_d, stack, sst)) E = E + o.csky;
+                    if (sky_visible<LDS_SCENE, COUNT>(sc, lds_nodes, lds_tris, o.sky_o, o.sky_d, stack, sst, rq)) E = E + o.csky;
                     nrays++;
                 }
                 if (VOL && o.want_sky) {  // the sky term is assembled now: its transmittance draws come after the visibility test
                     nrays++;
-                    if (sky_visible<LDS_SCENE, COUNT>(sc, lds_nodes, lds_tris, o.sky_o, o.sky_d, stack, sst)) {
+                    if (sky_visible<LDS_SCENE, COUNT>(sc, lds_nodes, lds_tris, o.sky_o, o.sky_d, stack, sst, rq)) {
                         Rng tr_rng; tr_rng.s = o.rng;
                         V3 csky;
                         if (o.sky_kind == 2) {        // RayGen.slang:405-424: (phase * T_atm * T_boxes) * (sun / pdf)
@@ -444,7 +449,7 @@ __global__ __launch_bounds__(kTraverseBlock, 3) void k_bounce(DeviceScene sc, Re
                 }
                 if (o.want_light) {
                     bool vis = light_visible<LDS_SCENE, COUNT>(sc, lds_nodes, lds_tris, o.light_o, o.light_d, o.light_gid, stack, sst);
-                    if (VOL && !vis && o.light_miss_ok) vis = sky_visible<LDS_SCENE, COUNT>(sc, lds_nodes, lds_tris, o.light_o, o.light_d, stack, sst);
+                    if (VOL && !vis && o.light_miss_ok) vis = sky_visible<LDS_SCENE, COUNT>(sc, lds_nodes, lds_tris, o.light_o, o.light_d, stack, sst, true);   // (light rays exist with USE_RAY_QUERIES only)
                     if (VOL) {
                         if (vis) {  // ClosestHit.slang:361-370, RayGen.slang:348-361: the light term with the box transmittance
                             Rng tr_rng; tr_rng.s = o.rng;
@@ -568,6 +573,7 @@ __global__ __launch_bounds__(kTraverseBlock, 3) void k_whole(DeviceScene sc, Ren
     sc.strict_hits = STRICT ? 1u : 0u;
     if (PLAIN) { sc.all_plain = 1u; sc.env_black = 1u; } else sc.all_plain = 0u;
     if (P.dispatch_base_dev) dispatch_base = *P.dispatch_base_dev;   // a replayed graph: the batch's first dispatch index lives in device memory
+    const bool rq = (P.flags & VPT_FLAG_RAY_QUERIES) != 0u;
     extern __shared__ __align__(16) unsigned char smem[];
     const TravStack stack = make_stack(smem, sc.stack_overflow);
     float4* lds_nodes = reinterpret_cast<float4*>(smem + kStackDepth * kTraverseBlock * 4);
@@ -624,7 +630,7 @@ __global__ __launch_bounds__(kTraverseBlock, 3) void k_whole(DeviceScene sc, Ren
                 // connect, inline (RayGen.slang:92-102)
                 V3 E = o.emitted;
                 if (o.want_sky) {
-                    if (sky_visible<true, COUNT>(sc, lds_nodes, lds_tris, o.sky_o, o.sky_d, stack, sst)) E = E + o.csky;
+                    if (sky_visible<true, COUNT>(sc, lds_nodes, lds_tris, o.sky_o, o.sky_d, stack, sst, rq)) E = E + o.csky;
                     nrays++;
                 }
                 if (o.want_light) {
@@ -801,7 +807,7 @@ __global__ __launch_bounds__(kTraverseBlock, 8) void k_connect(DeviceScene sc, R
             if (r < ns) {  // ClosestHit.slang:139, 344-353
                 const uint32_t j = t_list[r], sl = t_slot[j];
                 float4 so = ps.CSO[sl], sd = ps.CSD[sl];
-                t_vis[2u * j] = sky_visible<LDS_SCENE, COUNT>(sc, lds_nodes, lds_tris, xyz(so), v3(so.w, sd.x, sd.y), stack, st) ? 1 : 0;
+                t_vis[2u * j] = sky_visible<LDS_SCENE, COUNT>(sc, lds_nodes, lds_tris, xyz(so), v3(so.w, sd.x, sd.y), stack, st, (P.flags & VPT_FLAG_RAY_QUERIES) != 0u) ? 1 : 0;
             } else {       // ClosestHit.slang:171-176, 358-370
                 const uint32_t j = t_list[2u * kConnectTile - 1u - (r - ns)], sl = t_slot[j];
                 float4 lo = ps.CLO[sl], ld = ps.CLD[sl];

@@ -540,7 +540,7 @@ __global__ __launch_bounds__(kTraverseBlock, 5) void k_trace_pair(DeviceScene sc
 // product instantiation only — the counting and the validating ones keep the one-triangle step, so the visit statistics stay what a ray needs.
 template <bool LIGHT, bool COUNT, bool TUNED, bool STRICT = false, bool TRI2 = false>
 __global__ __launch_bounds__(kTraverseBlock, 8) void k_trace_shadow(DeviceScene sc, const float4* RO, const float4* RD, unsigned char* vis, const uint32_t* n_dev,
-                                                                  uint32_t* head, Counters* ctr, uint32_t param) {
+                                                                  uint32_t* head, Counters* ctr, uint32_t param, uint32_t ray_queries) {
     static_assert(!(TRI2 && STRICT), "the two-triangle steps have no validating form: VPT_FLAG_LOCAL_HITS keeps the one-triangle step");
     extern __shared__ __align__(16) unsigned char smem[];
     const LaneStack S = make_lane_stack(smem, sc.stack_overflow);
@@ -552,7 +552,8 @@ __global__ __launch_bounds__(kTraverseBlock, 8) void k_trace_shadow(DeviceScene 
     const uint32_t fetch_at = TUNED ? kVoteFetchAt : (param & 0xffu) ? (param & 0xffu) : 16u;
     const bool weighted = TUNED || ((param >> 8) & 1u) != 0u;
     const uint32_t w4 = TUNED ? kVoteWeight4 : ((param >> 12) & 15u) ? ((param >> 12) & 15u) : kVoteWeight4;
-    const float tmin = 0.0001f, tmax = 1000000.0f;  // RTCommon.slang:47-64
+    // RTCommon.slang:52-63 (USE_RAY_QUERIES: the direction as it is, [1e-4, 1e6]) or :64-84 (normalised direction, [1e-5, 1000]; sky rays only — light rays are not queued then, shade_core.hpp)
+    const float tmin = ray_queries ? 0.0001f : 0.00001f, tmax = ray_queries ? 1000000.0f : 1000.0f;
     const uint32_t n_static = gridDim.x * (kTraverseBlock / 64u) * 64u;  // every wave starts on its own 64 entries, no atomic
     // wave-uniform by construction (see k_trace_vote)
     uint32_t w_next = __builtin_amdgcn_readfirstlane((blockIdx.x * (kTraverseBlock / 64u) + (threadIdx.x >> 6)) * 64u), w_end = w_next + 64u < n ? w_next + 64u : n;
@@ -608,7 +609,9 @@ __global__ __launch_bounds__(kTraverseBlock, 8) void k_trace_shadow(DeviceScene 
                 if (expect != kRayHole) {
                     const float4 ro = ld_stream(&RO[i]);
                     rid = i;
-                    o = vptfp::v3(ro.x, ro.y, ro.z); d = vptfp::v3(ro.w, rd.x, rd.y); inv = safe_inverse(d);
+                    o = vptfp::v3(ro.x, ro.y, ro.z); d = vptfp::v3(ro.w, rd.x, rd.y);
+                    if (!ray_queries) d = vptfp::normalize(d);
+                    inv = safe_inverse(d);
                     tlim = tmax; visible = true;  // until an occluder / a closer triangle is found
                     sp = 0; cur = 0;
                     if (LIGHT) {
@@ -756,13 +759,13 @@ void launch_trace(hipStream_t s, uint32_t blocks, uint32_t variant, bool any, bo
 }
 
 void launch_trace_shadow(hipStream_t s, uint32_t blocks, bool light, bool count, const DeviceScene& sc, const StreamState& ss, Counters* ctr,
-                         StreamCounters* sctr, uint32_t param) {
+                         StreamCounters* sctr, uint32_t param, uint32_t ray_queries) {
     const size_t lds = kVoteLdsBytes;
     const dim3 g(blocks), b(kTraverseBlock);
     const float4 *RO = light ? ss.LTO : ss.SKO, *RD = light ? ss.LTD : ss.SKD;
     unsigned char* vis = light ? ss.vis_light : ss.vis_sky;
     uint32_t *len = light ? &sctr->light_len.v : &sctr->sky_len.v, *head = light ? &sctr->light_head.v : &sctr->sky_head.v;
-#define VPT_LS(L, C, T, ST, T2) hipLaunchKernelGGL((k_trace_shadow<L, C, T, ST, T2>), g, b, lds, s, sc, RO, RD, vis, len, head, ctr, param)
+#define VPT_LS(L, C, T, ST, T2) hipLaunchKernelGGL((k_trace_shadow<L, C, T, ST, T2>), g, b, lds, s, sc, RO, RD, vis, len, head, ctr, param, ray_queries)
 #if VPT_LAB
     if (param != kVoteParamDefault && !sc.strict_hits) {   // run-time vote parameters (trace-lab sweeps through the pipeline)
         if (light) { if (count) VPT_LS(true, true, false, false, false); else VPT_LS(true, false, false, false, false); }

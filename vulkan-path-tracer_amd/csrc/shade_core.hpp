@@ -84,6 +84,10 @@ template <bool VOL, int CLS = kShadeAny>
 __device__ __forceinline__ void shade_core(const DeviceScene& sc, const RenderParams& P, const PathState& ps, uint32_t slot,
                                            const ShadeIn& in_, ShadeOut& out) {
     bool alive = false, want_sky = false, want_light = false, light_miss_ok = false;
+    // Without USE_RAY_QUERIES (RTCommon.slang:64-84) the light-identity compare of an emissive-mesh NEE sample reads a payload word nothing has
+    // written: pinned as "never equal" (oracle.cpp does_ray_intersect), i.e. the sample is drawn (its random numbers count) and never visible.
+    // Its shadow ray is therefore not even queued: no result of it could matter.
+    const bool light_rays = (P.flags & VPT_FLAG_RAY_QUERIES) != 0u;
     if (VOL) {
         out.sky_add = true; out.sky_kind = 0; out.sky_tdepth = 0.0f; out.sky_w = 1.0f; out.sky_mis = 1.0f; out.sky_f = v3s(0.0f); out.sky_rgb = v3s(0.0f);
         out.light_add = true; out.light_kind = 0; out.light_tdepth = 0.0f; out.light_w = 1.0f; out.light_mis = 1.0f; out.light_f = v3s(0.0f); out.light_rgb = v3s(0.0f);
@@ -128,7 +132,7 @@ __device__ __forceinline__ void shade_core(const DeviceScene& sc, const RenderPa
                 want_sky = true; sky_o = new_o; sky_d = to_sky;
             }
         }
-        if ((P.flags & VPT_FLAG_MESH_MIS) && lc.w > 0.0f) {
+        if ((P.flags & VPT_FLAG_MESH_MIS) && lc.w > 0.0f && light_rays) {
             float pl = volume_phase(sc.phase, v, pdir, to_light, vdepth);
             if (pl > 0.0f || tracked) {
                 out.light_f = ld3(v.color) * pl; out.light_tdepth = (float)(vdepth + 1u);  // :353 passes VolumeDepth + 1
@@ -316,7 +320,7 @@ __device__ __forceinline__ void shade_core(const DeviceScene& sc, const RenderPa
                     want_sky = true; sky_o = s.pos + s.N * 1e-5f; sky_d = to_sky;
                 }
             }
-            if ((P.flags & VPT_FLAG_MESH_MIS) && !is_light && lc.w > 0.0f) {
+            if ((P.flags & VPT_FLAG_MESH_MIS) && !is_light && lc.w > 0.0f && light_rays) {
                 Eval e = bs.eval(V, s.world_to_tangent(to_light), ec_r, ec_g, gv);
                 if (e.pdf > 0.0f) {
                     if (VOL) {

@@ -113,6 +113,7 @@ struct vpt_ctx {
     uint64_t graph_streak_gen = 0;
     uint64_t graph_kernel_launches[VPT_KERNEL_COUNT] = {};
     bool graph_broken = false;       // a capture failed once on this context: stay on plain launches
+    bool capturing = false;          // a batch is being captured into a hipGraph: one stream only (no shadow / join overlap on stream2)
     // Pipelined 1-frame batches (vpt_render_async): a frame of the fused fixed schedule is a chain of ~9 dependent launches, each bounded
     // below by the latency of one bounce (~60-90 us on nearly empty queues), so one frame at a time leaves most of the chip idle
     // (profiles/r04_latency_probe.json: 0.95 ms of kernels per 1080p frame against 0.33 ms per frame in 16-frame batches).  Consecutive
@@ -726,7 +727,7 @@ int batch_begin(vpt_ctx* c, uint32_t frames, uint32_t dispatch_base, BatchState&
     // Two streams: the shadow-ray kernels and the join of bounce k run beside the extend of bounce k + 1 (which needs only the ray
     // queue shade k wrote), so the tail of one persistent traversal kernel is filled by the next one's first blocks.  Off while
     // kernels are timed or visits counted (one kernel at a time then) and in the sorted pipeline.
-    b.overlap = b.stream && !b.sorted && !c->cfg.profile && !b.count && !b.media_stream;
+    b.overlap = b.stream && !b.sorted && !c->cfg.profile && !b.count && !b.media_stream && !c->capturing;
     if (n_slots == 0) return VPT_OK;
     HIPCHK(c, hipMemsetAsync(c->ctr, 0, offsetof(Counters, stat_closest), s));  // queue words only, stat_* keep running
     if (b.whole) {  // the batch's paths from camera ray to their end in one launch; no queue is written, alive3[] stays 0 for the resolve's guard
@@ -777,14 +778,15 @@ int batch_bounces(vpt_ctx* c, BatchState& b, uint32_t bounces) {
             a.n = 0; a.n_dev = &c->sctr->queue_len[parity].v; a.store_gid = 1u; a.param = c->vote_param;
             // GetDistanceToGeometry (RTCommon.slang:86-101): the payload direction as it is, TMin 1e-5, TMax 1e6
             a.head = &c->sctr->shade_head.v; a.tmin = 0.00001f; a.tmax = 1000000.0f; a.normalize_dir = 0u;
+            if (!(c->P.flags & VPT_FLAG_RAY_QUERIES)) { a.tmax = 1000.0f; a.normalize_dir = 1u; }   // RTCommon.slang:103-117
             TIMED(c, VPT_K_EXTEND, launch_trace(s, (uint32_t)c->vote_blocks, VPT_TRACE_VOTE, false, count, c->dsc, a, c->ctr));
             TIMED(c, VPT_K_SHADE, launch_media_scatter(s, (uint32_t)c->shade_blocks, c->dsc, c->ps, c->ss, c->ms, c->queue[parity], c->sctr, parity));
             a.head = &c->sctr->extend_head.v; a.tmin = 0.01f; a.tmax = 100000.0f; a.normalize_dir = 1u;
             TIMED(c, VPT_K_EXTEND, launch_trace(s, (uint32_t)c->vote_blocks, VPT_TRACE_VOTE, false, count, c->dsc, a, c->ctr));
             launch_layout_media(s, c->sctr, parity, (uint32_t)c->shade_media_blocks * 4u, (uint32_t)c->media_tail_blocks * 4u);
             TIMED(c, VPT_K_SHADE, launch_shade_media(s, (uint32_t)c->shade_media_blocks, c->dsc, c->P, c->ps, c->ss, c->ms, c->queue[parity], c->ctr, c->sctr, parity));
-            TIMED(c, VPT_K_SHADOW, launch_trace_shadow(s, (uint32_t)c->shadow_blocks, false, count, c->dsc, c->ss, c->ctr, c->sctr, c->vote_param));
-            TIMED(c, VPT_K_SHADOW, launch_trace_shadow(s, (uint32_t)c->shadow_blocks, true, count, c->dsc, c->ss, c->ctr, c->sctr, c->vote_param));
+            TIMED(c, VPT_K_SHADOW, launch_trace_shadow(s, (uint32_t)c->shadow_blocks, false, count, c->dsc, c->ss, c->ctr, c->sctr, c->vote_param, (c->P.flags & VPT_FLAG_RAY_QUERIES) ? 1u : 0u));
+            TIMED(c, VPT_K_SHADOW, launch_trace_shadow(s, (uint32_t)c->shadow_blocks, true, count, c->dsc, c->ss, c->ctr, c->sctr, c->vote_param, (c->P.flags & VPT_FLAG_RAY_QUERIES) ? 1u : 0u));
             TIMED(c, VPT_K_JOIN, launch_media_tail(s, (uint32_t)c->media_tail_blocks, c->dsc, c->P, c->ps, c->ss, c->ms, c->queue[parity], c->queue[parity ^ 1u], c->ctr, c->sctr, parity));
             parity ^= 1u;
             continue;
@@ -820,8 +822,8 @@ int batch_bounces(vpt_ctx* c, BatchState& b, uint32_t bounces) {
             // regeneration: fresh camera rays into the room the ended paths left in the next queue (entries behind the ones the join of this
             // bounce addresses, so it may run beside the shadow kernels and the join)
             if (b.regen) TIMED(c, VPT_K_PRIMARY, launch_refill(s, 2048u, c->P, c->ps, c->ss, c->queue[parity ^ 1u], c->sctr, parity ^ 1u, b.n_first, b.dispatch_base));
-            TIMED(c, VPT_K_SHADOW, launch_trace_shadow(sb, (uint32_t)c->shadow_blocks, false, count, dsc_shadow, c->ss, c->ctr, c->sctr, c->vote_param));
-            TIMED(c, VPT_K_SHADOW, launch_trace_shadow(sb, (uint32_t)c->shadow_blocks, true, count, dsc_shadow, c->ss, c->ctr, c->sctr, c->vote_param));
+            TIMED(c, VPT_K_SHADOW, launch_trace_shadow(sb, (uint32_t)c->shadow_blocks, false, count, dsc_shadow, c->ss, c->ctr, c->sctr, c->vote_param, (c->P.flags & VPT_FLAG_RAY_QUERIES) ? 1u : 0u));
+            TIMED(c, VPT_K_SHADOW, launch_trace_shadow(sb, (uint32_t)c->shadow_blocks, true, count, dsc_shadow, c->ss, c->ctr, c->sctr, c->vote_param, (c->P.flags & VPT_FLAG_RAY_QUERIES) ? 1u : 0u));
             TIMED(c, VPT_K_JOIN, launch_join(sb, (uint32_t)c->join_blocks, c->P, c->ps, c->ss, c->sctr, c->queue[parity], c->queue[parity ^ 1u], parity));
             if (overlap) { HIPCHK(c, hipEventRecord(c->ev_join, c->stream2)); b.join_pending = true; }
             parity ^= 1u;
@@ -994,7 +996,9 @@ int enqueue_graph(vpt_ctx* c, uint32_t frames, uint32_t dispatch_base, uint32_t 
         c->P.dispatch_base_dev = c->d_dispatch_base;
         hipGraph_t g = nullptr;
         bool ok = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+        c->capturing = true;
         int rc = ok ? enqueue_fixed(c, frames, 0u, bounces_total, c->graph_batch) : VPT_ERR_DEVICE;
+        c->capturing = false;
         if (ok && hipStreamEndCapture(c->stream, &g) != hipSuccess) { ok = false; g = nullptr; }
         c->P.dispatch_base_dev = nullptr;
         for (int k = 0; k < VPT_KERNEL_COUNT; k++) { c->graph_kernel_launches[k] = c->stats.kernel_launches[k] - before[k]; c->stats.kernel_launches[k] = before[k]; }
@@ -1446,7 +1450,6 @@ int vpt_set_params(vpt_ctx* c, const vpt_params* p) {
     if (p->max_depth == 0 || p->max_depth > 1000000u) return fail(c, VPT_ERR_INVALID_ARGUMENT, "max_depth must be in [1, 1000000]");
     if (p->screen_chunk_count == 0 || p->screen_chunk_count > 64) return fail(c, VPT_ERR_INVALID_ARGUMENT, "screen_chunk_count must be in [1, 64]");
     if (p->screen_chunk_count != 1 && c->P.shard_count != 1) return fail(c, VPT_ERR_UNSUPPORTED, "split-screen dispatch needs the whole image in one context (shard_count == 1): its first dispatch copies pixels across rows");
-    if (!(p->flags & VPT_FLAG_RAY_QUERIES)) return fail(c, VPT_ERR_UNSUPPORTED, "only the USE_RAY_QUERIES semantics are implemented");
     {   // SetMaxSamplesAccumulated alone keeps the accumulated image (PathTracer.cpp:1003-1006 does not reset)
         vpt_params same = *p; same.max_samples = c->params.max_samples;
         if (p->max_samples != c->params.max_samples && memcmp(&same, &c->params, sizeof(vpt_params)) == 0) { c->params.max_samples = p->max_samples; return VPT_OK; }
@@ -1669,6 +1672,9 @@ int vpt_render_async(vpt_ctx* c, uint32_t dispatches, int* done, uint64_t* ticke
         const uint32_t base = (uint32_t)c->dispatch_count;
         const bool fused_auto = (whole || c->cfg.pipeline == VPT_PIPELINE_FUSED || (c->cfg.pipeline == VPT_PIPELINE_AUTO && c->lds_scene)) && !vol;
         const bool plain_launches = c->cfg.profile || c->cfg.count_traversal || c->P.split != 1u;
+        // the streams pipeline's fixed batch (a frame per call on a scene whose BVH lives in memory: ~7 launches per bounce, every one of them short)
+        // is replayed from a captured graph too — on one stream, without lanes
+        const bool stream_fixed = fixed && !fused_auto && !vol && (c->cfg.pipeline == VPT_PIPELINE_AUTO || c->cfg.pipeline == VPT_PIPELINE_STAGED);
         if (c->graph_streak_gen == c->state_gen) c->graph_streak++; else { c->graph_streak = 0; c->graph_streak_gen = c->state_gen; }
         // the fused pipeline's fixed 1-frame batch goes to the next lane (vpt_ctx::lanes); asked for again with nothing changed since the
         // last two calls it is replayed from the lane's captured graph
@@ -1707,7 +1713,7 @@ int vpt_render_async(vpt_ctx* c, uint32_t dispatches, int* done, uint64_t* ticke
             X->primary_blocks = part(std::max(1u, c->lab_lane_grid));
             X->tail_blocks = c->lab_tail_grid > 1u ? std::min(X->primary_blocks, part(c->lab_tail_grid)) : 0;
         }
-        if (fixed && fused_auto && !plain_launches && c->graph_streak >= 2u) {
+        if (fixed && (fused_auto || stream_fixed) && !plain_launches && c->graph_streak >= 2u) {
             rc = enqueue_graph(X, nf, base, enq, &graphed, b);
             if (rc) { X->primary_blocks = full_grid; X->tail_blocks = 0; if (X != c) c->err = X->err; return rc; }
         }

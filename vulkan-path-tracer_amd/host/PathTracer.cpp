@@ -219,7 +219,7 @@ void PathTracer::SetMaterial(uint32_t index, const Material& material) {  // Pat
     ResetPathTracing();
 }
 
-void PathTracer::SetUseRayQueries(bool value) { if (!value) throw std::runtime_error("only the USE_RAY_QUERIES semantics are implemented"); }
+void PathTracer::SetUseRayQueries(bool value) { SetFlag(VPT_FLAG_RAY_QUERIES, value); }   // PathTracer.cpp:1086-1096 (false: RTCommon.slang:64-84, include/vpt.h VPT_FLAG_RAY_QUERIES)
 void PathTracer::SetCameraViewInverse(const Mat4& view) { m_CameraViewInverse = view; if (m_Ctx) Check(vpt_set_camera(m_Ctx, m_CameraViewInverse.m, m_CameraProjectionInverse.m), "vpt_set_camera"); ResetPathTracing(); }
 void PathTracer::SetCameraProjectionInverse(const Mat4& p) { m_CameraProjectionInverse = p; if (m_Ctx) Check(vpt_set_camera(m_Ctx, m_CameraViewInverse.m, m_CameraProjectionInverse.m), "vpt_set_camera"); ResetPathTracing(); }
 void PathTracer::SetFlag(uint32_t bit, bool value) { m_Params.flags = value ? (m_Params.flags | bit) : (m_Params.flags & ~bit); Push(true); }

@@ -157,7 +157,7 @@ public:
     [[nodiscard]] bool UseOnlyGeometryNormals() const { return m_Params.flags & VPT_FLAG_GEOMETRY_NORMALS; }
     [[nodiscard]] bool UseEnergyCompensation() const { return m_Params.flags & VPT_FLAG_ENERGY_COMPENSATION; }
     [[nodiscard]] bool IsInFurnaceTestMode() const { return m_Params.flags & VPT_FLAG_FURNACE; }
-    [[nodiscard]] bool UseRayQueries() const { return true; }
+    [[nodiscard]] bool UseRayQueries() const { return (m_Params.flags & VPT_FLAG_RAY_QUERIES) != 0; }
     [[nodiscard]] uint32_t GetSplitScreenCount() const { return m_Params.screen_chunk_count; }
     [[nodiscard]] float GetEmissiveMeshSamplingPDFBias() const { return m_Params.emissive_pdf_bias; }
     [[nodiscard]] const Mat4& GetCameraViewInverse() const { return m_CameraViewInverse; }

@@ -6,6 +6,7 @@
 //              [--volume minx,miny,minz,maxx,maxy,maxz,density,g,r,g,b]... [--phase hg|draine|hg+draine]
 //              [--async]   one PathTraceAsync + PostProcessAsync per frame with a one-frame fence lag (the reference's Editor loop) instead of blocking batches
 //              [--async-step N]   dispatches per PathTraceAsync call (default 1)
+//              [--no-ray-queries]   SetUseRayQueries(false): the TraceRay forms of the shadow / distance queries (RTCommon.slang:64-84)
 //              [--gpus N [--devices d0,d1,...]]   rows y % N == k rendered on device k (one host thread each), one gather of
 //                                                 the shards into device 0 over xGMI, post-process there; the image is
 //                                                 bit-identical for every N (a device may be listed more than once)
@@ -39,7 +40,7 @@ int main(int argc, char** argv) {
     std::vector<PathTracer::Volume> volumes; int phase = 0; bool atmosphere = false; float sunAlt = 0.0f, sunAz = 0.0f;
     uint32_t lutSamples = 10000000u, lutTime = 0; UVec3 lutSize{0, 0, 0};
     uint32_t w = 0, h = 0, spp = 16, depth = 8, seed = 1, split = 1, gpus = 1; std::vector<int> devices;
-    bool async = false; uint32_t asyncStep = 1;
+    bool async = false, rayQueries = true; uint32_t asyncStep = 1;
     bool info = false, selftest = false; float env[3] = {0, 0, 0}; bool haveEnv = false;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
@@ -49,6 +50,7 @@ int main(int argc, char** argv) {
         else if (a == "--size") { std::string s = next(); if (sscanf(s.c_str(), "%ux%u", &w, &h) != 2) { fprintf(stderr, "--size WxH\n"); return 2; } }
         else if (a == "--spp") spp = (uint32_t)atoi(next().c_str());
         else if (a == "--async") async = true;
+        else if (a == "--no-ray-queries") rayQueries = false;
         else if (a == "--async-step") { int v = atoi(next().c_str()); asyncStep = v > 1 ? (uint32_t)v : 1u; }
         else if (a == "--depth") depth = (uint32_t)atoi(next().c_str());
         else if (a == "--seed") seed = (uint32_t)strtoul(next().c_str(), nullptr, 10);
@@ -195,6 +197,7 @@ int main(int argc, char** argv) {
                 pt.SetCameraProjectionInverse(inverse(cam.GetProjectionMatrix()));
             }
             pt.SetMaxDepth(depth); pt.SetSeed(seed); pt.SetSplitScreenCount(split); pt.SetMaxSamplesAccumulated(spp);
+            if (!rayQueries) pt.SetUseRayQueries(false);
             if (phase != 0) pt.SetPhaseFunction((PathTracer::PhaseFunction)phase);
             for (const auto& v : volumes) pt.AddVolume(v);
             if (sunAlt != 0.0f || sunAz != 0.0f) { pt.SetSkyAltitude(sunAlt); pt.SetSkyAzimuth(sunAz); }
