@@ -92,6 +92,7 @@ struct vpt_ctx {
     uint32_t frames_cap = 0;     // upper bound of frames_in_flight after an out-of-memory failure of a size the library chose itself
     uint32_t frames_alloc = 0;   // frames of SAMPLES the slot-addressed buffers hold now: they grow to the largest batch actually requested (ensure_path_buffers)
     uint32_t resident_alloc = 0; // frames of PATHS the queues and stream records hold (<= frames_alloc; less when paths are regenerated)
+    bool ps_has_sidx = false, ps_has_media = false;   // the per-sample words only some batches touch are allocated only for them: sample index (samples_per_frame > 1), VolumeDepth / ColorChannel (media)
     int whole_blocks = 0;        // persistent grid of the whole-path kernel (kernels_path.hip k_whole), 0: the scene does not ride in LDS
     uint32_t lab_whole_sched = 4u;   // how k_whole's waves get their tiles (VPT_LAB_WHOLE_SCHED): tiles per atomic | static-rounds mode << 4
     uint32_t lab_whole_frames = 0xffffffffu;   // VPT_PIPELINE_AUTO runs batches of at most this many frames as ONE whole-path launch (VPT_LAB_WHOLE_FRAMES); default: every batch
@@ -299,9 +300,12 @@ int alloc_path_buffers(vpt_ctx* c, uint32_t frames, uint32_t resident) {
     if ((uint64_t)P.shard_pixels * frames >= (1ull << 31)) return fail(c, VPT_ERR_INVALID_ARGUMENT, "too many paths in flight");
     const uint32_t samples = P.shard_pixels * frames;
     uint32_t cap = P.shard_pixels * resident;
-    // slot-addressed records every pipeline uses: 2 float4 records + 4 dword arrays per slot (device_types.hpp PathState); the
-    // records of round 1's stage kernels come with ensure_legacy_buffers()
-    const size_t kRecords = 2, kWords = 4;
+    // slot-addressed records every pipeline uses: 2 float4 records + up to 4 dword arrays per slot (device_types.hpp PathState): the medium
+    // anisotropy always; the sample index only for samples_per_frame > 1, VolumeDepth / ColorChannel only with media — 36 B per sample of
+    // a plain batch (the kernels touch those words under exactly these conditions; path_words_ok() replaces the buffers when a batch needs more).
+    // The records of round 1's stage kernels come with ensure_legacy_buffers()
+    const bool want_sidx = P.samples_per_frame > 1u, want_media = !c->volumes.empty() || c->dsc.atm_on;
+    const size_t kRecords = 2, kWords = 1u + (want_sidx ? 1u : 0u) + (want_media ? 2u : 0u);
     size_t stride = ((size_t)samples + 63) & ~(size_t)63;
     HIPCHK(c, hipMalloc(&c->ps_block, stride * (16 * kRecords + 4 * kWords)));
     float4* rb = (float4*)c->ps_block;
@@ -310,7 +314,10 @@ int alloc_path_buffers(vpt_ctx* c, uint32_t frames, uint32_t resident) {
     s.capacity = cap;
     s.ACC = rb; s.M = rb + stride;
     uint32_t* wb = (uint32_t*)(rb + stride * kRecords);
-    s.maniso = (float*)wb; s.sidx = wb + stride; s.vdepth = wb + stride * 2; s.cchan = (int32_t*)(wb + stride * 3);
+    s.maniso = (float*)wb; wb += stride;
+    if (want_sidx) { s.sidx = wb; wb += stride; }
+    if (want_media) { s.vdepth = wb; s.cchan = (int32_t*)(wb + stride); }
+    c->ps_has_sidx = want_sidx; c->ps_has_media = want_media;
     // streams written by chunked appends hold up to one unwritten chunk tail per wave that appended to them: at most
     // 256 entries per 64 items processed, and never more than one per resident wave of the largest persistent grid.  A launch
     // appends in chunks only when its queue holds >= kFusedExactBelow (fused kernel) / kAppendExactBelow (streams) entries, holes
@@ -432,8 +439,13 @@ uint32_t resident_frames_for(const vpt_ctx* c, uint32_t frames) {
 // library chose itself (vpt_config.frames_in_flight == 0) is halved and tried again when the device runs out of memory after all
 // (another process, fragmentation) — frames_in_flight then drops to what was obtained and the caller renders in smaller batches;
 // an explicit size fails as it is and the context keeps the buffers it had.
+// Do the per-sample word arrays allocated cover what the next batch touches (samples_per_frame / media may have changed since)?
+bool path_words_ok(const vpt_ctx* c) {
+    const bool want_sidx = c->P.samples_per_frame > 1u, want_media = !c->volumes.empty() || c->dsc.atm_on;
+    return (!want_sidx || c->ps_has_sidx) && (!want_media || c->ps_has_media);
+}
 int ensure_path_buffers(vpt_ctx* c, uint32_t want) {
-    if (want <= c->frames_alloc && resident_frames_for(c, want) <= c->resident_alloc) return VPT_OK;
+    if (want <= c->frames_alloc && resident_frames_for(c, want) <= c->resident_alloc && path_words_ok(c)) return VPT_OK;
     const uint32_t old = std::max(c->frames_alloc, 1u), old_res = std::max(c->resident_alloc, 1u);
     uint32_t tryf = std::max(want, old);
     while (true) {
@@ -1068,6 +1080,8 @@ void sync_lane(vpt_ctx* c, vpt_ctx* L) {
     L->primary_blocks = c->primary_blocks; L->whole_blocks = c->whole_blocks; L->lab_whole_frames = c->lab_whole_frames; L->lab_whole_sched = c->lab_whole_sched;
     L->image = c->image;
     L->state_gen = c->state_gen;   // the owner's generation invalidates the lane's captured batch too
+    // (vpt_set_params drained every lane before samples_per_frame changed: nothing of this lane is in flight when its per-sample words are replaced)
+    if (!path_words_ok(L)) (void)alloc_path_buffers(L, 1, 1);
 }
 void destroy_lane(vpt_ctx* L) {
     if (!L) return;
@@ -1604,7 +1618,7 @@ int next_batch(vpt_ctx* c, uint32_t left, uint32_t* nf) {
     const uint64_t frames_needed = ((uint64_t)c->params.max_samples + c->params.samples_per_frame - 1) / c->params.samples_per_frame;
     const uint64_t disp_left = frames_needed * S2 - c->dispatch_count;
     uint32_t n = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(left, c->frames_in_flight), disp_left);
-    if (n > c->frames_alloc || resident_frames_for(c, n) > c->resident_alloc) {   // the buffers grow to the largest batch asked for; nothing may be in flight while they are replaced
+    if (n > c->frames_alloc || resident_frames_for(c, n) > c->resident_alloc || !path_words_ok(c)) {   // the buffers grow to the largest batch asked for (and to the words it touches); nothing may be in flight while they are replaced
         int rc = drain(c);
         if (rc) return rc;
         if ((rc = ensure_path_buffers(c, n))) return rc;
