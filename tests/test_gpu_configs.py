@@ -31,7 +31,7 @@ def test_config3_atrium_exact_at_320x180(vpt, oracle, atrium, pipeline):
     assert 0.95 * 250_000 <= atrium.triangle_count() <= 1.05 * 250_000   # 250 k +- 5 %
     P = vpt.default_params(max_depth=8)
     ref = oracle_image(oracle, atrium, 320, 180, P, 2)
-    g = vpt.PathTracer(320, 180, pipeline=pipeline); g.set_scene(atrium); g.set_params(P); g.render(2)
+    g = vpt.PathTracer(320, 180, pipeline=pipeline, build_flags=4 if pipeline == 2 else 0); g.set_scene(atrium); g.set_params(P); g.render(2)
     img = g.radiance(); st = g.stats(); g.close()
     assert np.array_equal(img, ref)
     assert st["bvh_node_bytes"] == 64
@@ -48,7 +48,7 @@ def test_fog_in_the_atrium_exact_at_320x180(vpt, oracle, atrium, pipeline):
     P = vpt.default_params(max_depth=8)
     o = oracle.Oracle(atrium, 320, 180); o.set_params(P); o.set_volumes([fog]); o.render(2)
     ref = o.radiance(); o.close()
-    g = vpt.PathTracer(320, 180, pipeline=pipeline); g.set_scene(atrium); g.set_params(P); g.set_volumes([fog]); g.render(2)
+    g = vpt.PathTracer(320, 180, pipeline=pipeline, build_flags=4 if pipeline == 2 else 0); g.set_scene(atrium); g.set_params(P); g.set_volumes([fog]); g.render(2)
     img = g.radiance(); st = g.stats(); g.close()
     assert np.array_equal(img, ref)
     assert (st["kernel_launches"]["bounce"] > 0) == (pipeline == 1) and (st["kernel_launches"]["join"] > 0) == (pipeline != 1)
@@ -59,11 +59,11 @@ def test_config5_glass_bust_exact_at_320x180_depth32(vpt, oracle, bust, pipeline
     if pipeline == 3 and not vpt.has_lab(): pytest.skip("VPT_PIPELINE_STAGED_R1 (round 1's stage kernels) lives in the laboratory build: VPT_LAB=1")
     P = vpt.default_params(max_depth=32)
     ref = oracle_image(oracle, bust, 320, 180, P, 2)
-    g = vpt.PathTracer(320, 180, pipeline=pipeline); g.set_scene(bust); g.set_params(P); g.render(2)
+    g = vpt.PathTracer(320, 180, pipeline=pipeline, build_flags=4 if pipeline == 2 else 0); g.set_scene(bust); g.set_params(P); g.render(2)
     img = g.radiance(); g.close()
     assert np.array_equal(img, ref)
     out8_ref, _ = oracle.postprocess(ref, vpt.default_post_params())      # config 5 names bloom + tonemap defaults
-    g = vpt.PathTracer(320, 180, pipeline=pipeline); g.set_scene(bust); g.set_params(P); g.render(2)
+    g = vpt.PathTracer(320, 180, pipeline=pipeline, build_flags=4 if pipeline == 2 else 0); g.set_scene(bust); g.set_params(P); g.render(2)
     assert np.array_equal(g.postprocess(), out8_ref); g.close()
 
 
@@ -71,7 +71,7 @@ def test_config3_atrium_1080p_pipelines_and_shards_agree(vpt, atrium):
     P = vpt.default_params(max_depth=8)
     imgs = []
     for pipeline in (2, 1, 3, 4, 0) if vpt.has_lab() else (2, 1, 4, 0):     # staged, fused, round 1's stage kernels (laboratory build), staged + class sort, AUTO
-        g = vpt.PathTracer(1920, 1080, pipeline=pipeline, frames_in_flight=4); g.set_scene(atrium); g.set_params(P); g.render(4 if pipeline else 20)
+        g = vpt.PathTracer(1920, 1080, pipeline=pipeline, frames_in_flight=4, build_flags=4 if pipeline == 2 else 0); g.set_scene(atrium); g.set_params(P); g.render(4 if pipeline else 20)
         if pipeline == 0:
             g.reset(); g.render(4)       # after the tuning batches
         imgs.append(g.radiance()); g.close()

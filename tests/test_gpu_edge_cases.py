@@ -23,7 +23,7 @@ def both(vpt, oracle, sc, w, h, P, frames, **kw):
 @pytest.mark.parametrize("w,h", [(1, 1), (1, 7), (5, 3), (2, 2), (63, 65), (257, 3)])
 @pytest.mark.parametrize("pipeline", [1, 2])
 def test_tiny_and_ragged_image_sizes(vpt, oracle, scenes, w, h, pipeline):
-    img, ref, out8, ref8 = both(vpt, oracle, scenes("cornell_box"), w, h, vpt.default_params(max_depth=5), 3, pipeline=pipeline)
+    img, ref, out8, ref8 = both(vpt, oracle, scenes("cornell_box"), w, h, vpt.default_params(max_depth=5), 3, pipeline=pipeline, build_flags=4 if pipeline == 2 else 0)
     assert_parity(img, ref)
     assert np.array_equal(out8, ref8)       # bloom chain stops when a mip would fall below 2 px (PostProcessor.cpp:136-157)
 

@@ -131,7 +131,7 @@ def test_both_pipelines_match_the_oracle(vpt, oracle, scenes, name, pipeline):
     sc = copy.deepcopy(scenes(name))
     sc.env = vpt.scenes.sun_sky_env(64, 32, seed=4, sun_peak=80.0)
     p = vpt.default_params(max_depth=10, samples_per_frame=2)
-    img, ref, st, ctr = render_both(vpt, oracle, sc, 144, 81, p, 3, pipeline=pipeline)
+    img, ref, st, ctr = render_both(vpt, oracle, sc, 144, 81, p, 3, pipeline=pipeline, build_flags=4 if pipeline == 2 else 0)
     assert_parity(img, ref)
     assert st["closest_rays"] == ctr["closest"]
     launched = st["kernel_launches"]
@@ -146,7 +146,7 @@ def test_split_screen_dispatch(vpt, oracle, scenes, S, w, h, pipeline):
     sc = scenes("cornell_box")
     p = vpt.default_params(max_depth=4, screen_chunk_count=S, samples_per_frame=2)
     o = oracle.Oracle(sc, w, h); o.set_params(p)
-    g = vpt.PathTracer(w, h, pipeline=pipeline, frames_in_flight=5); g.set_scene(sc); g.set_params(p)
+    g = vpt.PathTracer(w, h, pipeline=pipeline, frames_in_flight=5, build_flags=4 if pipeline == 2 else 0); g.set_scene(sc); g.set_params(p)
     for n in (1, 2, S * S - 3 if S > 2 else 1, S * S + 2, 7):
         o.render(n); g.render(n)
         assert np.array_equal(g.radiance(), o.radiance()), n

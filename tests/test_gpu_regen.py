@@ -36,7 +36,7 @@ def test_regenerated_batches_equal_the_oracle(vpt, oracle, scenes, name, pipelin
         expect = K if name != "cornell_box" else (1 if pipeline == 0 else frames)
         if pipeline == 1: expect = frames
         assert st["resident_frames"] == expect and st["frames_allocated"] == frames and st["samples"] == w * h * frames
-        if expect == K and K < frames: assert st["kernel_launches"]["primary"] > 1   # the camera-ray launch + refills
+        if name != "cornell_box" and pipeline != 1 and K < frames: assert st["kernel_launches"]["primary"] > 1   # the camera-ray launch + refills
         assert np.array_equal(g.radiance(), ref), (name, pipeline, K)
         g.close()
 

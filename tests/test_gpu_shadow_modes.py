@@ -36,7 +36,7 @@ def test_trace_ray_shadow_mode_equals_the_oracle(vpt, oracle, scenes, name, dept
     w, h, frames = 128, 72, 3
     p = no_rq(vpt, max_depth=depth)
     ref, ctr = oracle_image(oracle, sc, w, h, p, frames)
-    g = vpt.PathTracer(w, h, pipeline=pipeline)
+    g = vpt.PathTracer(w, h, pipeline=pipeline, build_flags=4 if pipeline == 2 else 0)
     g.set_scene(sc); g.set_params(p); g.render(frames)
     img, st = g.radiance(), g.stats()
     g.close()
@@ -75,7 +75,7 @@ def test_sky_rays_longer_than_1000_units_miss_in_trace_ray_mode(vpt, oracle):
         ref, _ = oracle_image(oracle, sc, w, h, params, frames)
         means.append(float(ref[h * 3 // 4, :, :3].mean()))   # rows that see the floor
         for pipeline in (1, 2):   # four triangles ride in LDS: the fused per-bounce kernel; and the stream kernels forced on the same tree in memory
-            g = vpt.PathTracer(w, h, pipeline=pipeline)
+            g = vpt.PathTracer(w, h, pipeline=pipeline, build_flags=4 if pipeline == 2 else 0)
             g.set_scene(sc); g.set_params(params); g.render(frames)
             assert np.array_equal(g.radiance(), ref), pipeline
             g.close()
@@ -93,7 +93,7 @@ def test_distance_query_in_trace_ray_mode_with_fog(vpt, oracle, scenes, pipeline
         w, h, frames = 96, 54, 2
         p = no_rq(vpt, max_depth=5)
         ref, _ = oracle_image(oracle, sc, w, h, p, frames, [fog])
-        g = vpt.PathTracer(w, h, pipeline=pipeline)
+        g = vpt.PathTracer(w, h, pipeline=pipeline, build_flags=4 if pipeline == 2 else 0)
         g.set_scene(sc); g.set_params(p); g.set_volumes([fog]); g.render(frames)
         assert np.array_equal(g.radiance(), ref), (name, pipeline)
         g.close()

@@ -15,6 +15,10 @@ int bounce_blocks_per_cu(bool lds_scene, const DeviceScene& sc, bool plain = fal
 void launch_whole(hipStream_t s, uint32_t blocks, bool count, const DeviceScene& sc, const RenderParams& P, const PathState& ps, Counters* ctr, uint32_t n_slots,
                   uint32_t dispatch_base, bool plain, uint32_t static_rounds, uint32_t chunk_tiles);
 int whole_blocks_per_cu(const DeviceScene& sc, bool plain);
+// the rest of a streams batch in one launch (kernels_path.hip k_finish): every path of queue[parity] run to its end
+void launch_finish(hipStream_t s, uint32_t blocks, bool count, const DeviceScene& sc, const RenderParams& P, const PathState& ps, const StreamState& ss, const uint32_t* queue,
+                   StreamCounters* sctr, Counters* ctr, uint32_t parity);
+int finish_blocks_per_cu(const DeviceScene& sc);
 void launch_raygen(hipStream_t s, const RenderParams& P, const PathState& ps, uint32_t* queue, Counters* ctr, uint32_t n_slots, uint32_t dispatch_base);
 void launch_prepare(hipStream_t s, Counters* ctr, uint32_t parity);
 void launch_fold(hipStream_t s, Counters* ctr);

@@ -536,6 +536,83 @@ __global__ __launch_bounds__(kTraverseBlock, 3) void k_bounce(DeviceScene sc, Re
     }
 }
 
+// ------------------------------------------------------------------ the rest of a batch in one launch (streams pipeline, short queues)
+// A bounce of the streams pipeline is seven dependent launches.  On a queue of 10^5 paths each of them is bounded below by launch latency and by
+// the tail of its persistent grid, not by throughput: a 1-frame batch of the atrium spent 4.9 ms in 56 such launches against 1.4 ms per frame
+// inside a 226-frame batch, the glass bust (depth 32: 224 launches) 11.8 ms against 0.68 (profiles/r05_latency.json).  k_finish takes what is left of
+// a batch once its queue is short — one path per lane, records read from the streams at the queue's parity — and runs every path to its END:
+// closest hit, miss / closest-hit shader, the <= 2 shadow queries, contribution, roulette, next bounce, exactly as k_bounce does per bounce
+// (the same shade_core and connect code on the same values in the same order: bit-identical to the streams' stages and to the oracle), with
+// the per-lane traversal loops of traverse.hpp on the tree in memory.  Per path-bounce that is about half the streams' rate on long queues —
+// which is why only the tail of a batch goes here: the host decides (vpt_api.hip BatchState::finish_at).  No media, no regeneration.
+template <bool COUNT>
+__global__ __launch_bounds__(kTraverseBlock, 3) void k_finish(DeviceScene sc, RenderParams P, PathState ps, StreamState ss, const uint32_t* queue, StreamCounters* sctr,
+                                                             Counters* ctr, uint32_t parity) {
+    sc.all_plain = 0u;   // (strict_hits is read at run time, as in k_bounce on a tree in memory)
+    const bool rq = (P.flags & VPT_FLAG_RAY_QUERIES) != 0u;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const TravStack stack = make_stack(smem, sc.stack_overflow);
+    const uint32_t n = sctr->queue_len[parity].v;
+    TravStats st, sst; st.nodes = 0; st.tris = 0; sst.nodes = 0; sst.tris = 0;
+    unsigned long long t_paths = 0ull, t_rays = 0ull;   // per lane: closest-hit rays, shadow rays
+    for (uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += gridDim.x * blockDim.x) {
+        const uint32_t slot = queue[idx];
+        if (slot == kHole) continue;
+        const float4 a = ss.RA[parity][idx], b = ss.RB[parity][idx], t = ss.RT[parity][idx];
+        ShadeIn in_;
+        in_.rng = __float_as_uint(a.w);
+        in_.porg = xyz(a); in_.pdir = xyz(b);
+        const uint32_t dw = __float_as_uint(b.w);
+        in_.depth = dw & 0x7fffffffu; in_.in_medium = (dw >> 31) != 0u;
+        in_.thr_prev = xyz(t); in_.prev_pdf = t.w;
+        in_.vdepth = 0u; in_.cchan = -1; in_.vol_index = -1; in_.vol_t = 0.0f; in_.atm_comp = -1;
+        V3 light_prev = xyz(ss.RL[parity][idx]);
+        while (true) {
+            HitRec hr;
+            const bool hit = trace_any<false, COUNT>(sc, nullptr, nullptr, in_.porg, normalize(in_.pdir), 0.01f, 100000.0f, stack, hr, st);
+            in_.h = make_float4(hit ? hr.t : -1.0f, hr.u, hr.v, __uint_as_float(hr.gid));
+            in_.inst = hr.inst;
+            t_paths++;
+            ShadeOut o;
+            shade_core<false>(sc, P, ps, slot, in_, o);
+            // connect, inline (RayGen.slang:92-102), as k_bounce
+            V3 E = o.emitted;
+            if (o.want_sky) { if (sky_visible<false, COUNT>(sc, nullptr, nullptr, o.sky_o, o.sky_d, stack, sst, rq)) E = E + o.csky; t_rays++; }
+            if (o.want_light) { if (light_visible<false, COUNT>(sc, nullptr, nullptr, o.light_o, o.light_d, o.light_gid, stack, sst)) E = E + o.clight; t_rays++; }
+            V3 contrib = E * in_.thr_prev;
+            if (o.cflags & kCF_Clamp) {
+                float lum = dot(contrib, v3(0.212671f, 0.715160f, 0.072169f));
+                contrib = contrib * (P.max_luminance / max_(lum, P.max_luminance));
+            }
+            V3 light = light_prev + contrib;
+            if (o.terminated) {  // end of a sample: NaN/Inf guard, frame sum (RayGen.slang:116-128)
+                const bool ok = !isinf_(light.x) && !isinf_(light.y) && !isinf_(light.z) && !isnan_(light.x) && !isnan_(light.y) && !isnan_(light.z);
+                if (P.samples_per_frame == 1) ps.ACC[slot] = ok ? f4(v3s(0.0f) + light, 0.0f) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                else if (ok) { float4 acc = ps.ACC[slot]; ps.ACC[slot] = f4(xyz(acc) + light, 0.0f); }
+                light = v3s(0.0f);   // the pixel's next sample of the frame starts from pathLight = 0
+            }
+            if (!o.alive) break;
+            in_.rng = o.rng; in_.porg = o.new_o; in_.pdir = o.new_d; in_.depth = o.new_depth; in_.in_medium = o.in_medium;
+            in_.thr_prev = o.thr; in_.prev_pdf = o.new_pdf;
+            light_prev = light;
+        }
+    }
+    // wave totals -> the running statistics
+    for (int off = 32; off > 0; off >>= 1) { t_paths += __shfl_down(t_paths, off); t_rays += __shfl_down(t_rays, off); }
+    if (lane_id() == 0u) {
+        if (t_paths) atomicAdd(&ctr->stat_closest, t_paths);
+        if (t_rays) atomicAdd(&ctr->stat_shadow, t_rays);
+    }
+    if (COUNT) {
+        atomicAdd(&ctr->stat_nodes, (unsigned long long)st.nodes);
+        atomicAdd(&ctr->stat_tris, (unsigned long long)st.tris);
+        atomicAdd(&ctr->stat_shadow_nodes, (unsigned long long)sst.nodes);
+        atomicAdd(&ctr->stat_shadow_tris, (unsigned long long)sst.tris);
+    }
+}
+// Behind k_finish nothing of the batch is alive: the queue words say so (the guarded resolve and the host read them).
+__global__ void k_finish_done(StreamCounters* sctr, uint32_t parity) { sctr->alive[parity].v = 0u; sctr->queue_len[parity].v = 0u; }
+
 // ------------------------------------------------------------------ whole paths in one launch
 // The reference's RayGen invocation IS a whole path: one thread runs the bounce loop of its pixel's sample to the end
 // (RayGen.slang:66-114).  k_whole is that loop on persistent waves, for scenes whose BVH rides in LDS and which have no media:
@@ -1043,11 +1120,10 @@ void launch_bounce(hipStream_t s, uint32_t blocks, bool lds_scene, bool count, b
     } else if (lds_scene) {
         if (count) { if (first) VPT_LAUNCH_BOUNCE(true, true, true); else VPT_LAUNCH_BOUNCE(true, true, false); }
         else { if (first) VPT_LAUNCH_BOUNCE(true, false, true); else VPT_LAUNCH_BOUNCE(true, false, false); }
-    } else {   // a tree in memory: the hit rule is read at run time (above)
-#define VPT_LAUNCH_MEM(C, F) hipLaunchKernelGGL((k_bounce<false, C, F, false, false>), g, b, lds, s, sc, P, ps, ss, queue, queue_next, ctr, parity, n_slots, dispatch_base, k3)
-        if (count) { if (first) VPT_LAUNCH_MEM(true, true); else VPT_LAUNCH_MEM(true, false); }
-        else { if (first) VPT_LAUNCH_MEM(false, true); else VPT_LAUNCH_MEM(false, false); }
-#undef VPT_LAUNCH_MEM
+    } else {   // a tree in memory: the hit rule is read at run time (above), and the visit counters always run (two adds per visit in a kernel
+               // that is the slow side of an A/B anyway: one instantiation per bounce kind instead of four)
+        if (first) hipLaunchKernelGGL((k_bounce<false, true, true, false, false>), g, b, lds, s, sc, P, ps, ss, queue, queue_next, ctr, parity, n_slots, dispatch_base, k3);
+        else hipLaunchKernelGGL((k_bounce<false, true, false, false, false>), g, b, lds, s, sc, P, ps, ss, queue, queue_next, ctr, parity, n_slots, dispatch_base, k3);
     }
 #undef VPT_LAUNCH_MEDIA
 #undef VPT_LAUNCH_BOUNCE
@@ -1064,6 +1140,18 @@ void launch_whole(hipStream_t s, uint32_t blocks, bool count, const DeviceScene&
     else if (count) VPT_LW(true, false, false);
     else VPT_LW(false, false, false);
 #undef VPT_LW
+}
+void launch_finish(hipStream_t s, uint32_t blocks, bool count, const DeviceScene& sc, const RenderParams& P, const PathState& ps, const StreamState& ss, const uint32_t* queue,
+                   StreamCounters* sctr, Counters* ctr, uint32_t parity) {
+    const size_t lds = traverse_lds_bytes(sc, false);
+    (void)count;   // one instantiation: the visit counters always run (the tail of a batch; vpt_stats reports them only when count_traversal asked)
+    hipLaunchKernelGGL((k_finish<true>), dim3(blocks), dim3(kTraverseBlock), lds, s, sc, P, ps, ss, queue, sctr, ctr, parity);
+    hipLaunchKernelGGL(k_finish_done, dim3(1), dim3(1), 0, s, sctr, parity);
+}
+int finish_blocks_per_cu(const DeviceScene& sc) {
+    int nb = 0;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_finish<true>, kTraverseBlock, traverse_lds_bytes(sc, false));
+    return nb > 0 ? nb : 1;
 }
 int whole_blocks_per_cu(const DeviceScene& sc, bool plain) {
     int nb = 0;
@@ -1083,7 +1171,7 @@ int bounce_blocks_per_cu(bool lds_scene, const DeviceScene& sc, bool plain) {
         return nb > 0 ? nb : 1;
     }
     if (lds_scene) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_bounce<true, false, false, false, false>, kTraverseBlock, lds);
-    else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_bounce<false, false, false, false, false>, kTraverseBlock, lds);
+    else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_bounce<false, true, false, false, false>, kTraverseBlock, lds);
     return nb > 0 ? nb : 1;
 }
 #if VPT_LAB

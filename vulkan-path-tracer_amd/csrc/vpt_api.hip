@@ -21,6 +21,16 @@ using namespace vpt;
 constexpr uint64_t kBytesPerPath = 380;          // core slot records 68 + stream records ~290 (slack included) + queues 8 + image share
 constexpr uint32_t kMaxFramesInFlight = 2048;   // frames of one batch (a 1/8 shard of 1080p holds ~448M paths at 1728 frames)
 constexpr uint64_t kResidentPaths = 448ull << 20;   // samples of a batch by default (see check_render_size)
+// The rest of a streams batch goes to k_finish (kernels_path.hip) — one launch instead of seven per bounce —
+//  * after kFinishAfterBounces bounces when the batch is small from the start (a frame or two per call: its launches never fill the chip for long), and
+//  * as soon as the host sees fewer than kFinishBelowPaths paths alive in a large one (the last of depth-32 paths: 20 bounce-sets on nearly empty queues).
+#ifndef VPT_FINISH_AFTER   // (-D overrides: the A/B builds of tests/tools/ab_variants.sh)
+#define VPT_FINISH_AFTER 2
+#endif
+#ifndef VPT_FINISH_BELOW
+#define VPT_FINISH_BELOW (1u << 18)
+#endif
+constexpr uint32_t kFinishSmallBatchPaths = 6u << 20, kFinishAfterBounces = VPT_FINISH_AFTER, kFinishBelowPaths = VPT_FINISH_BELOW;
 
 // One wavefront batch in progress: what render_batch's stages hand to each other (and what an asynchronous batch leaves behind for
 // the call that finishes it).
@@ -30,6 +40,8 @@ struct BatchState {
     bool fused = false, stream = false, media_stream = false, sorted = false, overlap = false, count = false;
     bool whole = false;     // the whole batch is ONE launch of k_whole (kernels_path.hip): no bounces follow
     bool regen = false;     // only n_first of the batch's n_slots samples start with the camera-ray launch; refills start the rest (kernels_stream.hip k_refill_plan)
+    uint32_t finish_at = 0; // streams: once this many bounces have run, ONE launch of k_finish runs what is left of the batch to its end (0: never)
+    bool finished = false;  // ... and it has been enqueued: no bounce follows
     uint32_t parity = 0, k3 = 0;
     bool join_pending = false;
     uint64_t iter = 0, iter_cap = 0, min_bounces = 0;
@@ -159,7 +171,7 @@ struct vpt_ctx {
     uint32_t media_frames = 0;   // frames a media batch on the streams can hold (ensure_media_buffers)
     uint32_t class_present = 0x1fu;   // shade classes some instance of the scene belongs to (bit kShadeMiss always set): the others get no launch
     uint32_t stream_slack = 0;   // entries a stream may hold beyond its true count: unwritten chunk tails (vote.hpp WaveAppender)
-    int shade_stream_blocks = 768, shadow_blocks = 2048;
+    int shade_stream_blocks = 768, shadow_blocks = 2048, finish_blocks = 768;
     std::vector<vpt_volume> volumes;       // homogeneous box volumes (vpt_set_volumes)
     vpt_volume* d_volumes = nullptr;
     std::vector<DensityGrid> grids;        // device pointers inside (vpt_add_density_grid)
@@ -739,7 +751,9 @@ int batch_begin(vpt_ctx* c, uint32_t frames, uint32_t dispatch_base, BatchState&
     // Two streams: the shadow-ray kernels and the join of bounce k run beside the extend of bounce k + 1 (which needs only the ray
     // queue shade k wrote), so the tail of one persistent traversal kernel is filled by the next one's first blocks.  Off while
     // kernels are timed or visits counted (one kernel at a time then) and in the sorted pipeline.
-    b.overlap = b.stream && !b.sorted && !c->cfg.profile && !b.count && !b.media_stream && !c->capturing;
+    b.overlap = b.stream && !b.sorted && !c->cfg.profile && !b.count && !b.media_stream && !c->capturing && !c->owner;   // (a lane's batch stays on its one stream: the lanes overlap each other)
+    const bool finisher = !(c->cfg.build_flags & VPT_BUILD_STREAMS_ONLY);
+    if (finisher && b.stream && !b.media_stream && !b.regen && n_slots <= kFinishSmallBatchPaths) b.finish_at = kFinishAfterBounces;
     if (n_slots == 0) return VPT_OK;
     HIPCHK(c, hipMemsetAsync(c->ctr, 0, offsetof(Counters, stat_closest), s));  // queue words only, stat_* keep running
     if (b.whole) {  // the batch's paths from camera ray to their end in one launch; no queue is written, alive3[] stays 0 for the resolve's guard
@@ -801,6 +815,13 @@ int batch_bounces(vpt_ctx* c, BatchState& b, uint32_t bounces) {
             TIMED(c, VPT_K_SHADOW, launch_trace_shadow(s, (uint32_t)c->shadow_blocks, true, count, c->dsc, c->ss, c->ctr, c->sctr, c->vote_param, (c->P.flags & VPT_FLAG_RAY_QUERIES) ? 1u : 0u));
             TIMED(c, VPT_K_JOIN, launch_media_tail(s, (uint32_t)c->media_tail_blocks, c->dsc, c->P, c->ps, c->ss, c->ms, c->queue[parity], c->queue[parity ^ 1u], c->ctr, c->sctr, parity));
             parity ^= 1u;
+            continue;
+        }
+        if (b.stream && b.finished) continue;   // k_finish has been enqueued: nothing is alive behind it
+        if (b.stream && b.finish_at != 0u && b.iter > b.finish_at) {   // (b.iter counts this bounce): the rest of the batch in one launch
+            if (b.join_pending) { HIPCHK(c, hipStreamWaitEvent(s, c->ev_join, 0)); b.join_pending = false; }   // pathLight of the queue's entries is final behind the previous join
+            TIMED(c, VPT_K_BOUNCE, launch_finish(s, (uint32_t)c->finish_blocks, count, c->dsc, c->P, c->ps, c->ss, c->queue[parity], c->sctr, c->ctr, parity));
+            b.finished = true;
             continue;
         }
         if (b.stream) {   // stream pipeline: extend -> classify -> shade per class (streams out) -> sky rays, light rays -> join
@@ -894,10 +915,11 @@ int batch_check(vpt_ctx* c, BatchState& b, uint32_t* alive) {
     collect_timing(c);
     const Counters& h = c->h_ctr->ctr;
     update_ray_stats(c);
-    c->stats.nodes_visited = h.stat_nodes;
-    c->stats.tris_tested = h.stat_tris;
-    c->stats.shadow_nodes_visited = h.stat_shadow_nodes;
-    c->stats.shadow_tris_tested = h.stat_shadow_tris;
+    const bool counted = c->cfg.count_traversal != 0;   // (the finisher and the fused kernel on a tree in memory always count: reported only when asked for, so the figures are never partial)
+    c->stats.nodes_visited = counted ? h.stat_nodes : 0;
+    c->stats.tris_tested = counted ? h.stat_tris : 0;
+    c->stats.shadow_nodes_visited = counted ? h.stat_shadow_nodes : 0;
+    c->stats.shadow_tris_tested = counted ? h.stat_shadow_tris : 0;
     uint32_t n = b.fused ? h.alive3[b.k3] : h.ray_count[b.parity];
     if (b.stream) {
         n = c->h_ctr->alive[0];
@@ -920,6 +942,7 @@ int batch_finish(vpt_ctx* c, BatchState& b, bool resolve_enqueued) {
         int rc = batch_check(c, b, &n);
         if (rc) return rc;
         if (n == 0) break;
+        if (!(c->cfg.build_flags & VPT_BUILD_STREAMS_ONLY) && b.stream && !b.media_stream && !b.regen && !b.finished && b.finish_at == 0u && n < kFinishBelowPaths) b.finish_at = (uint32_t)b.iter;   // few paths left: the next launch finishes them
         rc = batch_bounces(c, b, b.regen ? 8u : 4u);   // (a regenerating batch runs many more launches than max_depth: fewer host round trips)
         if (rc) return rc;
     }
@@ -964,7 +987,7 @@ int drain(vpt_ctx* c) {
     for (vpt_ctx* L : c->lanes)
         if (L) {
             HIPCHK(c, hipStreamSynchronize(L->stream));
-            if (L->last_fixed_valid && L->h_ctr->ctr.alive3[L->last_fixed.k3] != 0u) return fail(c, VPT_ERR_DEVICE, "internal: a path outlived a fixed-schedule batch");
+            if (L->last_fixed_valid && (L->last_fixed.stream ? L->h_ctr->alive[0] : L->h_ctr->ctr.alive3[L->last_fixed.k3]) != 0u) return fail(c, VPT_ERR_DEVICE, "internal: a path outlived a fixed-schedule batch");
             L->last_fixed_valid = false;
             for (int k = 0; k < VPT_KERNEL_COUNT; k++) { c->stats.kernel_launches[k] += L->stats.kernel_launches[k]; L->stats.kernel_launches[k] = 0; }
             c->stats.graph_launches += L->stats.graph_launches; L->stats.graph_launches = 0;
@@ -1062,7 +1085,7 @@ vpt_ctx* get_lane(vpt_ctx* c, int k) {
     L->P = c->P;
     bool ok = init_ctx_resources(L) == VPT_OK && alloc_path_buffers(L, 1, 1) == VPT_OK;
     if (ok) {
-        const size_t bytes = stack_overflow_bytes((uint32_t)std::max(std::max(c->primary_blocks_general, c->primary_blocks_plain), c->whole_blocks));
+        const size_t bytes = stack_overflow_bytes((uint32_t)std::max(std::max(std::max(c->primary_blocks_general, c->primary_blocks_plain), c->whole_blocks), c->max_blocks));   // (the stream kernels' grids included)
         ok = hipMalloc(&L->lane_spill, bytes) == hipSuccess && hipMemset(L->lane_spill, 0x7f, bytes) == hipSuccess;   // (kSpillPatternByte: vpt_get_stats counts what was spilled)
         L->stack_overflow_words = (uint32_t)(bytes / 4);
     }
@@ -1078,6 +1101,8 @@ void sync_lane(vpt_ctx* c, vpt_ctx* L) {
     L->params = c->params;
     L->lds_scene = c->lds_scene; L->scene_plain = c->scene_plain; L->depth_bounded = c->depth_bounded; L->has_scene = true;
     L->primary_blocks = c->primary_blocks; L->whole_blocks = c->whole_blocks; L->lab_whole_frames = c->lab_whole_frames; L->lab_whole_sched = c->lab_whole_sched;
+    L->vote_blocks = c->vote_blocks; L->shadow_blocks = c->shadow_blocks; L->shade_stream_blocks = c->shade_stream_blocks; L->join_blocks = c->join_blocks; L->finish_blocks = c->finish_blocks;
+    L->max_blocks = c->max_blocks; L->vote_param = c->vote_param; L->class_present = c->class_present; L->stack_overflow2 = (uint32_t*)L->lane_spill;   // (a lane's batches run on one stream: no second region in use)
     L->image = c->image;
     L->state_gen = c->state_gen;   // the owner's generation invalidates the lane's captured batch too
     // (vpt_set_params drained every lane before samples_per_frame changed: nothing of this lane is in flight when its per-sample words are replaced)
@@ -1386,12 +1411,13 @@ int vpt_set_scene(vpt_ctx* c, const vpt_scene_desc* sd) {
     c->primary_blocks = std::max(c->primary_blocks_general, c->primary_blocks_plain);   // (sizes the spill regions below; update_depth_bounded picks the grid)
     c->whole_blocks = c->lds_scene ? std::max(whole_blocks_per_cu(D, false), whole_blocks_per_cu(D, true)) * c->cu_count : 0;
     c->shade_stream_blocks = shade_stream_blocks_per_cu() * c->cu_count;
+    c->finish_blocks = finish_blocks_per_cu(D) * c->cu_count;
     c->shade_media_blocks = shade_media_blocks_per_cu() * c->cu_count;
     c->media_tail_blocks = media_tail_blocks_per_cu() * c->cu_count;
     c->shadow_blocks = trace_shadow_blocks_per_cu() * c->cu_count;
     c->vote_blocks = std::min(trace_blocks_per_cu(VPT_TRACE_VOTE, false), trace_blocks_per_cu(VPT_TRACE_VOTE, true)) * c->cu_count;
     {   // per-thread overflow region of the traversal stacks, for the largest persistent grid launched
-        c->max_blocks = std::max(std::max(std::max(std::max(c->trav_blocks, c->shade_blocks), std::max(c->primary_blocks, c->whole_blocks)), c->vote_blocks), std::max(c->shade_stream_blocks, c->shadow_blocks));
+        c->max_blocks = std::max(std::max(std::max(std::max(c->trav_blocks, c->shade_blocks), std::max(c->primary_blocks, c->whole_blocks)), c->vote_blocks), std::max(std::max(c->shade_stream_blocks, c->finish_blocks), c->shadow_blocks));
         void* d = nullptr;
         // two regions: the shadow kernels of bounce k run on the second stream beside the extend kernel of bounce k + 1, and a
         // spill slot is addressed by (block, thread) alone, so concurrent grids must not share one region (round 2 did)
@@ -1681,19 +1707,22 @@ int vpt_render_async(vpt_ctx* c, uint32_t dispatches, int* done, uint64_t* ticke
         // a fixed schedule: every path has ended after `bounds` bounces, whatever the random numbers say
         // ... or the batch is ONE launch that runs every path to its end (k_whole), whatever max_depth is
         const bool whole = whole_applies(c, nf);
-        const bool fixed = whole || (c->depth_bounded && !vol && bounds <= VPT_ASYNC_MAX_BOUNCES && nf <= c->resident_alloc);   // (a regenerating batch has no fixed length)
-        const uint32_t enq = (uint32_t)std::min<uint64_t>(bounds, VPT_ASYNC_MAX_BOUNCES);
-        const uint32_t base = (uint32_t)c->dispatch_count;
         const bool fused_auto = (whole || c->cfg.pipeline == VPT_PIPELINE_FUSED || (c->cfg.pipeline == VPT_PIPELINE_AUTO && c->lds_scene)) && !vol;
+        const bool streams_pipe = !vol && !fused_auto && (c->cfg.pipeline == VPT_PIPELINE_AUTO || c->cfg.pipeline == VPT_PIPELINE_STAGED || c->cfg.pipeline == VPT_PIPELINE_STAGED_SORTED);
+        // a small batch of the streams pipeline ends in ONE launch that runs every path to its end (k_finish): a fixed schedule whatever max_depth is
+        const bool stream_finish = streams_pipe && !(c->cfg.build_flags & VPT_BUILD_STREAMS_ONLY) && nf <= c->resident_alloc && (uint64_t)nf * c->P.shard_pixels <= kFinishSmallBatchPaths;
+        const bool fixed = whole || stream_finish || (c->depth_bounded && !vol && bounds <= VPT_ASYNC_MAX_BOUNCES && nf <= c->resident_alloc);   // (a regenerating batch has no fixed length)
+        const uint32_t enq = stream_finish ? kFinishAfterBounces + 1u : (uint32_t)std::min<uint64_t>(bounds, VPT_ASYNC_MAX_BOUNCES);
+        const uint32_t base = (uint32_t)c->dispatch_count;
         const bool plain_launches = c->cfg.profile || c->cfg.count_traversal || c->P.split != 1u;
-        // the streams pipeline's fixed batch (a frame per call on a scene whose BVH lives in memory: ~7 launches per bounce, every one of them short)
-        // is replayed from a captured graph too — on one stream, without lanes
-        const bool stream_fixed = fixed && !fused_auto && !vol && (c->cfg.pipeline == VPT_PIPELINE_AUTO || c->cfg.pipeline == VPT_PIPELINE_STAGED);
+        // the streams pipeline's fixed batch (a frame per call on a scene whose BVH lives in memory: seven launches per bounce, every one of them short)
+        // goes over the lanes and is replayed from a captured graph too — each lane's batch on ONE stream
+        const bool stream_fixed = fixed && streams_pipe && c->cfg.pipeline != VPT_PIPELINE_STAGED_SORTED;
         if (c->graph_streak_gen == c->state_gen) c->graph_streak++; else { c->graph_streak = 0; c->graph_streak_gen = c->state_gen; }
         // the fused pipeline's fixed 1-frame batch goes to the next lane (vpt_ctx::lanes); asked for again with nothing changed since the
         // last two calls it is replayed from the lane's captured graph
         vpt_ctx* X = c;
-        if (fixed && fused_auto && !plain_launches && nf == 1u) {
+        if (fixed && (fused_auto || stream_fixed) && !plain_launches && nf == 1u) {
             const uint32_t max_lanes = std::max(1u, std::min(c->lab_lanes, 3u));
             vpt_ctx* idle = nullptr;
             uint32_t have = 1;
@@ -1968,7 +1997,7 @@ int vpt_get_stats(vpt_ctx* c, vpt_stats* out) {
     s.bvh_node_bytes = c->lds_scene ? sizeof(BvhNodeWide) : sizeof(BvhNode); s.bvh_tri_bytes = sizeof(BvhTri);
     s.emissive_mesh_count = (uint32_t)c->emissive.size(); s.emissive_triangle_count = c->emissive_tris;
     s.frames_in_flight = c->frames_in_flight; s.shard_pixels = c->P.shard_pixels;
-    s.build_flags = (c->sbvh ? VPT_BUILD_SBVH : 0u) | (c->cfg.build_flags & VPT_BUILD_GENERAL_KERNELS);
+    s.build_flags = (c->sbvh ? VPT_BUILD_SBVH : 0u) | (c->cfg.build_flags & (VPT_BUILD_GENERAL_KERNELS | VPT_BUILD_STREAMS_ONLY));
     s.frames_allocated = c->frames_alloc; s.resident_frames = c->resident_alloc;
     s.set_scene_ms = c->set_scene_ms; s.bvh_build_ms = c->bvh_build_ms;
     // what the traversal kernels have written into their spill regions: counted when something has run since the last count (the scan reads
