@@ -92,7 +92,7 @@ def parse():
     ap.add_argument("--workload", default="cornell_1080p_d8", choices=sorted(WORKLOADS), help="headline workload (the default is BASELINE's metric config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-workloads", action="store_true", help="skip the atrium / atrium 4K / glass-bust blocks")
-    ap.add_argument("--extra-steps", type=int, default=6, help="timed steps of each extra workload")
+    ap.add_argument("--extra-steps", type=int, default=4, help="timed steps of each extra workload (a step of a regenerating context is a batch of 4 x 226 frames at 1080p)")
     ap.add_argument("--frames-in-flight", type=int, default=0, help="frames per step per GPU (0 = backend default, ~448M resident paths)")
     ap.add_argument("--pipeline", type=int, default=0, help="vpt_config.pipeline (0 AUTO)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the oracle sample")
@@ -303,7 +303,11 @@ def timed_run(vpt, sharding, R, name, scene, pipeline, frames_in_flight, steps, 
             rccl.update({"nranks": R.world, "rank": R.rank, "transport": "host-staged through the torch process group (VPT_BENCH_DEVICE test hook: RCCL refuses two ranks on one device)"})
         comm.close()
     out = {"value": round(samples / dt / 1e6, 3), "unit": "Msamples/s", "scaling": scaling, "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 4),
-           "frames_per_step_per_gpu": F, "paths_in_flight_per_gpu": st["shard_pixels"] * F, "timed_samples_per_pixel": round(samples / (wl["w"] * wl["h"]), 1),
+           "frames_per_step_per_gpu": F, "resident_frames_per_gpu": st["resident_frames"],
+           # paths whose records live in HBM at a time: the whole batch, or (regeneration by refill) resident_frames of it; a whole-path context
+           # (resident_frames 1: one frame of records allocated, none used) keeps its paths in registers — 3 waves per SIMD of them
+           "paths_in_flight_per_gpu": st["shard_pixels"] * min(F, st["resident_frames"]) if st["resident_frames"] > 1 else "registers (whole-path launch)",
+           "timed_samples_per_pixel": round(samples / (wl["w"] * wl["h"]), 1),
            "batches_per_gpu": batches if len(set(batches)) > 1 else "%d x %d frames" % (len(batches), batches[0]),
            "mrays_per_s": round((closest + shadow) / dt / 1e6, 2), "rays_per_sample": round((closest + shadow) / max(samples, 1), 3),
            "set_scene_s": round(t_scene, 3), "bvh_build_ms": round(st.get("bvh_build_ms", 0.0), 1), "set_scene_ms": round(st.get("set_scene_ms", 0.0), 1),
@@ -496,7 +500,7 @@ def main():
                 continue
             sc2 = load_scene(vpt, other)
             modes = ("weak",) if world == 1 else ("weak", "strong")
-            runs = {m: timed_run(vpt, sharding, R, other, sc2, 0, 0, args.extra_steps, 3, m) for m in modes}
+            runs = {m: timed_run(vpt, sharding, R, other, sc2, 0, 0, args.extra_steps, 2, m) for m in modes}
             if rank == 0:
                 w = dict(runs["weak"])
                 if world > 1:

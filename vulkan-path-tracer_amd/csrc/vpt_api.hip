@@ -50,6 +50,7 @@ struct BatchState {
 struct HostCounters {
     Counters ctr;
     uint32_t alive[2], queue_len[2];
+    uint32_t refill_next;   // regenerating batches: samples started so far (StreamCounters::refill_next)
 };
 constexpr int kTickets = 16;
 
@@ -102,6 +103,7 @@ struct vpt_ctx {
     RenderParams P{};
     uint32_t frames_in_flight = 1;   // largest batch the context will render at once (the cap; vpt_config.frames_in_flight)
     uint32_t frames_cap = 0;     // upper bound of frames_in_flight after an out-of-memory failure of a size the library chose itself
+    uint32_t long_factor = 4;    // batch_cap(): contexts that keep only part (or none) of a batch's paths resident take batches this many times frames_in_flight
     uint32_t frames_alloc = 0;   // frames of SAMPLES the slot-addressed buffers hold now: they grow to the largest batch actually requested (ensure_path_buffers)
     uint32_t resident_alloc = 0; // frames of PATHS the queues and stream records hold (<= frames_alloc; less when paths are regenerated)
     bool ps_has_sidx = false, ps_has_media = false;   // the per-sample words only some batches touch are allocated only for them: sample index (samples_per_frame > 1), VolumeDepth / ColorChannel (media)
@@ -439,12 +441,26 @@ bool regen_allowed(const vpt_ctx* c) {
     if (c->cfg.pipeline == VPT_PIPELINE_STAGED || c->cfg.pipeline == VPT_PIPELINE_STAGED_SORTED) return true;   // the stream kernels, whatever the scene's size
     return c->cfg.pipeline == VPT_PIPELINE_AUTO && !c->lds_scene;
 }
+// Default schedule of a context that regenerates (profiles/r05_frames_sweep.json, 1080p): batches of 4 x frames_in_flight frames with HALF of
+// frames_in_flight frames of paths resident — 904 / 113 frames: 126 GB instead of 142 GB for 226 / 226, glass bust (depth 32) 3272 against 3088
+// Msamples/s (the tail of a batch, ~max_depth bounce-sets on emptying queues, is paid once per 1.9 G samples instead of once per 469 M), atrium
+// 1477 against 1485.  vpt_config.resident_frames != 0: as asked (a value >= the batch keeps every sample resident).
 uint32_t resident_frames_for(const vpt_ctx* c, uint32_t frames) {
     if (whole_without_records(c, frames)) return 1u;   // (one frame of records stays: what the context would need for a per-bounce batch of one frame)
     if (!regen_allowed(c)) return frames;
     uint64_t k = c->cfg.resident_frames;
-    if (k == 0) k = frames;   // 0: every sample resident (the fastest schedule; regeneration is the caller's trade of a little throughput for memory: profiles/r05_frames_sweep.json)
+    if (k == 0) k = c->cfg.frames_in_flight != 0 ? frames : std::max(1u, c->frames_in_flight / 2u);   // (an explicit batch size without an explicit residency: all resident, as before)
     return (uint32_t)std::min<uint64_t>(frames, k);
+}
+// The largest batch this context renders at once.  frames_in_flight is what fits with EVERY sample resident (380 B per sample; or what the caller
+// asked for).  A context whose batches keep half of that many frames of paths resident (regeneration by refill: 36 B per sample + 290 B per
+// resident path) — or none at all (whole-path launches: 36 B per sample) — takes batches long_factor (4) times as long, in less memory.
+uint32_t batch_cap(const vpt_ctx* c) {
+    const uint32_t F = c->frames_in_flight;
+    if (c->cfg.frames_in_flight != 0 || c->cfg.resident_frames != 0 || !c->has_scene) return F;
+    const uint64_t by_slots = ((1ull << 31) - 1ull) / std::max<uint64_t>(1, c->P.shard_pixels);
+    const uint32_t cap = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>((uint64_t)F * c->long_factor, kMaxFramesInFlight), by_slots));
+    return (regen_allowed(c) || whole_policy(c, cap)) ? cap : F;
 }
 
 // Grows the buffers so that a batch of `want` frames (<= frames_in_flight) fits; the caller has drained the streams.  A size the
@@ -472,6 +488,7 @@ int ensure_path_buffers(vpt_ctx* c, uint32_t want) {
             c->err = keep;
             return rc;
         }
+        if (tryf > c->frames_in_flight && c->long_factor > 1u) c->long_factor /= 2u;   // a long batch did not fit: shorter long batches from now on
         tryf = std::max(tryf / 2, old);
         c->frames_cap = tryf;
         c->frames_in_flight = std::min(c->frames_in_flight, tryf);
@@ -889,6 +906,7 @@ int batch_resolve(vpt_ctx* c, BatchState& b) {
     if (b.stream) {  // the exact number of live paths, and the queue length (holes included), which must fit the queue allocation
         HIPCHK(c, hipMemcpyAsync(&c->h_ctr->alive[0], &c->sctr->alive[b.parity].v, 4, hipMemcpyDeviceToHost, s));
         HIPCHK(c, hipMemcpyAsync(&c->h_ctr->queue_len[0], &c->sctr->queue_len[b.parity].v, 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipMemcpyAsync(&c->h_ctr->refill_next, &c->sctr->refill_next, 4, hipMemcpyDeviceToHost, s));
     }
     return VPT_OK;
 }
@@ -942,7 +960,8 @@ int batch_finish(vpt_ctx* c, BatchState& b, bool resolve_enqueued) {
         int rc = batch_check(c, b, &n);
         if (rc) return rc;
         if (n == 0) break;
-        if (!(c->cfg.build_flags & VPT_BUILD_STREAMS_ONLY) && b.stream && !b.media_stream && !b.regen && !b.finished && b.finish_at == 0u && n < kFinishBelowPaths) b.finish_at = (uint32_t)b.iter;   // few paths left: the next launch finishes them
+        // few paths left — and, in a regenerating batch, no sample left to start: the next launch finishes them
+        if (!(c->cfg.build_flags & VPT_BUILD_STREAMS_ONLY) && b.stream && !b.media_stream && (!b.regen || c->h_ctr->refill_next >= b.n_slots) && !b.finished && b.finish_at == 0u && n < kFinishBelowPaths) b.finish_at = (uint32_t)b.iter;
         rc = batch_bounces(c, b, b.regen ? 8u : 4u);   // (a regenerating batch runs many more launches than max_depth: fewer host round trips)
         if (rc) return rc;
     }
@@ -1643,7 +1662,7 @@ int next_batch(vpt_ctx* c, uint32_t left, uint32_t* nf) {
     const uint64_t S2 = (uint64_t)c->params.screen_chunk_count * c->params.screen_chunk_count;
     const uint64_t frames_needed = ((uint64_t)c->params.max_samples + c->params.samples_per_frame - 1) / c->params.samples_per_frame;
     const uint64_t disp_left = frames_needed * S2 - c->dispatch_count;
-    uint32_t n = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(left, c->frames_in_flight), disp_left);
+    uint32_t n = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(left, batch_cap(c)), disp_left);
     if (n > c->frames_alloc || resident_frames_for(c, n) > c->resident_alloc || !path_words_ok(c)) {   // the buffers grow to the largest batch asked for (and to the words it touches); nothing may be in flight while they are replaced
         int rc = drain(c);
         if (rc) return rc;
@@ -1996,7 +2015,7 @@ int vpt_get_stats(vpt_ctx* c, vpt_stats* out) {
     s.bvh_nodes = c->dsc.node_count; s.bvh_triangles = c->dsc.tri_count;
     s.bvh_node_bytes = c->lds_scene ? sizeof(BvhNodeWide) : sizeof(BvhNode); s.bvh_tri_bytes = sizeof(BvhTri);
     s.emissive_mesh_count = (uint32_t)c->emissive.size(); s.emissive_triangle_count = c->emissive_tris;
-    s.frames_in_flight = c->frames_in_flight; s.shard_pixels = c->P.shard_pixels;
+    s.frames_in_flight = batch_cap(c); s.shard_pixels = c->P.shard_pixels;   // (the largest batch the context renders at once with its current scene and parameters)
     s.build_flags = (c->sbvh ? VPT_BUILD_SBVH : 0u) | (c->cfg.build_flags & (VPT_BUILD_GENERAL_KERNELS | VPT_BUILD_STREAMS_ONLY));
     s.frames_allocated = c->frames_alloc; s.resident_frames = c->resident_alloc;
     s.set_scene_ms = c->set_scene_ms; s.bvh_build_ms = c->bvh_build_ms;
