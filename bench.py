@@ -384,12 +384,18 @@ def roofline_for(name, prof):
     kernels = prof["kernels"]
     dom = max(kernels, key=lambda k: kernels[k]["share"])
     k = kernels[dom]
-    pmc = load_json(os.path.join(ROOT, "profiles", "traffic.json")).get(name, {})   # written from rocprofv3 --pmc passes (profiles/README.md)
+    pmc_all = load_json(os.path.join(ROOT, "profiles", "traffic.json"))   # written from rocprofv3 --pmc passes (profiles/README.md)
+    pmc = pmc_all.get(name, {})
     entry = pmc.get(dom, {})
-    # the counters belong to the build they were collected on: an entry whose recorded mean launch time is not within 5 % of
-    # this run's is a different kernel (or another clock) and is NOT copied into the line
+    # the counters belong to the build they were collected on: copied only when traffic.json carries the id of THIS build's sources
+    # (vulkan-path-tracer_amd/_build.py source_id: kernels, headers, flags) and the recorded mean launch time is within 4 % of this run's own (boxes of this pool differ by ~3 %; round 4's rule was 5 % on the time alone)
+    try:
+        source_id = importlib.import_module("vulkan-path-tracer_amd._build").source_id()
+    except Exception:
+        source_id = None
+    same_build = source_id is not None and pmc_all.get("_source_id") == source_id
     pmc_ms = entry.get("mean_duration_us", 0.0) / 1e3
-    stale = bool(entry) and not (0.95 <= pmc_ms / max(k["avg_ms"], 1e-9) <= 1.05)
+    stale = bool(entry) and not (same_build and 0.96 <= pmc_ms / max(k["avg_ms"], 1e-9) <= 1.04)
     if stale:
         entry = {}
     traffic = entry.get("hbm_bytes_per_launch")
@@ -406,8 +412,9 @@ def roofline_for(name, prof):
         bound = "valu" if lds_scene or dom in ("extend", "connect", "shadow", "shade") else "hbm"
     return {"bound": bound, "kernel": dom, "achieved": k["records_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(k["records_GBs"] / HBM_PEAK_GBS, 5),
             "traffic": traffic, "traffic_frac_of_hbm_peak": round(traffic_frac, 4) if traffic_frac else None, "valu_busy": valu_busy, "avg_launch_ms": k["avg_ms"],
-            "pmc": {"source": "profiles/traffic.json", "recorded_avg_launch_ms": round(pmc_ms, 5) if pmc_ms else None, "stale": stale,
-                    "rule": "copied only when the recorded mean launch time is within 5 % of this run's"},
+            "pmc": {"source": "profiles/traffic.json", "recorded_avg_launch_ms": round(pmc_ms, 5) if pmc_ms else None, "stale": stale, "source_id": source_id,
+                    "recorded_source_id": pmc_all.get("_source_id"), "kernel_names": entry.get("kernel_names"),
+                    "rule": "copied only when traffic.json was collected on this build (source_id of kernels + headers + flags) and its mean launch time is within 4 % of this run's (box-to-box spread ~3 %)"},
             # the roof that actually binds these kernels (SURVEY 8d's secondary figure): VALU lane throughput.  frac = share of issue
             # cycles with a VALU instruction (VALUBusy) x share of its 64 lanes that are active; the peak is 256 CUs x 4 SIMDs x 16
             # lanes x 2.4 GHz lane-operations per second, of which the 157 TFLOP/s fp32 figure counts 4 flops each (packed FMA)

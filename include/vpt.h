@@ -210,7 +210,7 @@ typedef struct vpt_config {
  * (every texture 1x1 and a black environment: k_whole<PLAIN>, k_bounce<PLAIN>, kernels_path.hip).  Images are identical; this is the A/B switch of that choice. */
 #define VPT_BUILD_GENERAL_KERNELS 2u
 /* Streams pipeline: never hand the rest of a batch to the one-launch finisher (kernels_path.hip k_finish), i.e. run every bounce of every batch
- * through the stream stages.  By default a small batch (<= 6M samples: a frame or two per call) goes there after two bounces and a large one once
+ * through the stream stages.  By default a small batch (<= 6M samples: a frame or two per call) goes there after three bounces and a large one once
  * the host sees fewer than 262,144 paths alive: seven dependent launches per bounce on a short queue cost more than the finisher's slower
  * per-lane traversal.  Images are identical; this is the A/B switch of that choice. */
 #define VPT_BUILD_STREAMS_ONLY 4u

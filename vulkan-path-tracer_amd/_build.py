@@ -32,6 +32,17 @@ def hipcc():
     raise RuntimeError("hipcc not found")
 
 
+def source_id():
+    """sha256 (16 hex digits) over everything the library is compiled from: kernel sources, headers, this file's flags.  profiles/traffic.json carries the
+    id of the build its rocprofv3 counters were collected on; bench.py copies an entry only when it equals the current one."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(SOURCES) + sorted(HEADERS):
+        h.update(open(os.path.join(CSRC, f), "rb").read())
+    h.update(repr((FLAGS, sorted(EXTRA_FLAGS.items()))).encode())
+    return h.hexdigest()[:16]
+
+
 def needs_build(lab=False):
     lib = LIB_LAB if lab else LIB
     if not os.path.exists(lib):

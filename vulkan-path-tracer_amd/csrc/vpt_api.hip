@@ -22,10 +22,10 @@ constexpr uint64_t kBytesPerPath = 380;          // core slot records 68 + strea
 constexpr uint32_t kMaxFramesInFlight = 2048;   // frames of one batch (a 1/8 shard of 1080p holds ~448M paths at 1728 frames)
 constexpr uint64_t kResidentPaths = 448ull << 20;   // samples of a batch by default (see check_render_size)
 // The rest of a streams batch goes to k_finish (kernels_path.hip) — one launch instead of seven per bounce —
-//  * after kFinishAfterBounces bounces when the batch is small from the start (a frame or two per call: its launches never fill the chip for long), and
+//  * after kFinishAfterBounces (3) bounces when the batch is small from the start (a frame or two per call: its launches never fill the chip for long), and
 //  * as soon as the host sees fewer than kFinishBelowPaths paths alive in a large one (the last of depth-32 paths: 20 bounce-sets on nearly empty queues).
 #ifndef VPT_FINISH_AFTER   // (-D overrides: the A/B builds of tests/tools/ab_variants.sh)
-#define VPT_FINISH_AFTER 2
+#define VPT_FINISH_AFTER 3
 #endif
 #ifndef VPT_FINISH_BELOW
 #define VPT_FINISH_BELOW (1u << 18)
