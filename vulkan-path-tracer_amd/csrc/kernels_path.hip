@@ -613,6 +613,136 @@ __global__ __launch_bounds__(kTraverseBlock, 3) void k_finish(DeviceScene sc, Re
 // Behind k_finish nothing of the batch is alive: the queue words say so (the guarded resolve and the host read them).
 __global__ void k_finish_done(StreamCounters* sctr, uint32_t parity) { sctr->alive[parity].v = 0u; sctr->queue_len[parity].v = 0u; }
 
+// ------------------------------------------------------------------ vote-scheduled traversal of the tree in LDS (k_whole)
+// The per-lane loops of traverse.hpp make a wave run the node branch AND the leaf branch of every iteration as soon as its lanes stand at
+// different places of their trees — on the Cornell box a ray needs 1.9 node visits and 1.4 triangle tests, in no particular order.  These are
+// the same searches with the wave-level vote of the stream kernels (vote.hpp): every iteration the lanes that are in the call execute ONE kind of
+// step — an inner-node step (fp32 node from LDS, four slab tests, nearest-first order / slot order) or a one-triangle step — chosen by ballot, and
+// a lane that wants the other kind waits a turn.  A ray's own sequence of visits, tests and interval updates is exactly that of
+// trace_closest_pass / trace_occluded_pass (the state machine is per ray; only the interleaving changes), so hits, visibility and the visit
+// counters are identical.  Lanes outside the call (no ray, no shadow ray) are simply not part of the ballots.  The validating (STRICT)
+// instantiations keep the per-lane loops.
+// MEASURED AND NOT TAKEN (round 5, same box, alternating, three rounds: profiles/r05_whole_vote_ab.json): Cornell 1080p 8277-8281 Msamples/s with it
+// against 8376-8378 with the per-lane loops (-1.2 %), images and ray statistics identical; 168 VGPRs either way, 16 instead of 36 B of scratch.
+// The tree is twelve triangles under three nodes: a lane's two or three steps are over before a vote per step can pay for itself, and what
+// idles the lanes of this kernel (47 of 64 per VALU instruction) is the shader's own branching, not the searches.  Built only with
+// -DVPT_WHOLE_VOTE=1 (tests/tools/build_variant.py).
+#ifndef VPT_WHOLE_VOTE
+#define VPT_WHOLE_VOTE 0
+#endif
+constexpr int kWalkDone = 0x7fffffff;
+__device__ __forceinline__ int walk_pop(TravStack& stack) { return stack.sp ? (int)stack.pop() : kWalkDone; }
+template <bool COUNT>
+__device__ __forceinline__ bool lds_closest_vote(const LdsSceneSrc& src, V3 o, V3 d, float tmin, float tmax, TravStack stack, HitRec& best, TravStats& st) {
+    best.t = tmax; best.u = 0.0f; best.v = 0.0f; best.prim = 0xffffffffu; best.inst = 0xffffffffu; best.gid = 0xffffffffu; best.slot = 0;
+    bool found = false;
+    const RaySlab slab = make_slab(o, d);
+    stack.sp = 0;
+    int cur = 0;   // root is inner node 0
+    while (true) {
+        const bool at_node = cur >= 0 && cur != kWalkDone, at_leaf = cur < 0;
+        const uint32_t nn = (uint32_t)__popcll(__ballot(at_node)), nl = (uint32_t)__popcll(__ballot(at_leaf));
+        if (nn + nl == 0u) break;
+        const bool node_wins = 4u * nn > kVoteWeight4 * nl;   // a node step retires about twice the work of a triangle step
+        if (node_wins & at_node) {
+            NodeDataWide n;
+            src.node(cur, n);
+            if (COUNT) st.nodes++;
+            float t0, t1, t2, t3;
+            node_entries(n, slab, tmin, best.t, t0, t1, t2, t3);
+            int c0 = n.c0, c1 = n.c1, c2 = n.c2, c3 = n.c3;
+            cswap(t0, c0, t1, c1); cswap(t2, c2, t3, c3); cswap(t0, c0, t2, c2); cswap(t1, c1, t3, c3); cswap(t1, c1, t2, c2);
+            if (t0 < kMissT) {  // nearest child next, the others pushed far -> near
+                if (t3 < kMissT) stack.push((uint32_t)c3);
+                if (t2 < kMissT) stack.push((uint32_t)c2);
+                if (t1 < kMissT) stack.push((uint32_t)c1);
+                cur = c0;
+            } else cur = walk_pop(stack);
+        }
+        if (!node_wins & at_leaf) {   // ONE triangle of the lane's leaf
+            const uint32_t enc = (uint32_t)(~cur);
+            const int first = (int)(enc >> 3);
+            const uint32_t more = enc & 7u;
+            float4 a, b, c;
+            src.tri(first, a, b, c);
+            if (COUNT) st.tris++;
+            float t, u, v;
+            const bool hit = ray_triangle_flat(o, d, vptfp::v3(a.x, a.y, a.z), vptfp::v3(a.w, b.x, b.y), vptfp::v3(b.z, b.w, c.x), tmin, tmax, t, u, v);
+            const uint32_t gid = __float_as_uint(c.w);
+            if (hit & (!found | (t < best.t) | ((t == best.t) & (gid < best.gid)))) {
+                best.t = t; best.u = u; best.v = v; best.prim = __float_as_uint(c.y); best.inst = __float_as_uint(c.z); best.gid = gid;
+                found = true;
+            }
+            if (more) cur = ~(int)((((uint32_t)first + 1u) << 3) | (more - 1u));
+            else cur = walk_pop(stack);
+        }
+    }
+    return found;
+}
+// any-hit: LIGHT = false: occluded <=> some triangle is hit in (tmin, tmax); LIGHT = true: something beats the sampled triangle's hit at t_e (traverse.hpp)
+template <bool COUNT, bool LIGHT>
+__device__ __forceinline__ bool lds_occluded_vote(const LdsSceneSrc& src, V3 o, V3 d, float tmin, float tmax, float t_e, uint32_t expect, TravStack stack, TravStats& st) {
+    const float tlimit = LIGHT ? t_e : tmax;
+    const RaySlab slab = make_slab(o, d);
+    stack.sp = 0;
+    int cur = 0;
+    bool occluded = false;
+    while (true) {
+        const bool at_node = cur >= 0 && cur != kWalkDone, at_leaf = cur < 0;
+        const uint32_t nn = (uint32_t)__popcll(__ballot(at_node)), nl = (uint32_t)__popcll(__ballot(at_leaf));
+        if (nn + nl == 0u) break;
+        const bool node_wins = 4u * nn > kVoteWeight4 * nl;
+        if (node_wins & at_node) {
+            NodeDataWide n;
+            src.node(cur, n);
+            if (COUNT) st.nodes++;
+            float t0, t1, t2, t3;
+            node_entries(n, slab, tmin, tlimit, t0, t1, t2, t3);
+            int next = kWalkDone;   // order is irrelevant for an any-hit search: hit children in slot order
+            if (t3 < kMissT) next = n.c3;
+            if (t2 < kMissT) { if (next != kWalkDone) stack.push((uint32_t)next); next = n.c2; }
+            if (t1 < kMissT) { if (next != kWalkDone) stack.push((uint32_t)next); next = n.c1; }
+            if (t0 < kMissT) { if (next != kWalkDone) stack.push((uint32_t)next); next = n.c0; }
+            cur = next != kWalkDone ? next : walk_pop(stack);
+        }
+        if (!node_wins & at_leaf) {
+            const uint32_t enc = (uint32_t)(~cur);
+            const int first = (int)(enc >> 3);
+            const uint32_t more = enc & 7u;
+            float4 a, b, c;
+            src.tri(first, a, b, c);
+            if (COUNT) st.tris++;
+            float t, u, v;
+            const bool hit = ray_triangle_flat(o, d, vptfp::v3(a.x, a.y, a.z), vptfp::v3(a.w, b.x, b.y), vptfp::v3(b.z, b.w, c.x), tmin, tmax, t, u, v);
+            const uint32_t gid = __float_as_uint(c.w);
+            if (hit & (!LIGHT | (t < t_e) | ((t == t_e) & (gid < expect)))) { occluded = true; cur = kWalkDone; }
+            else if (more) cur = ~(int)((((uint32_t)first + 1u) << 3) | (more - 1u));
+            else cur = walk_pop(stack);
+        }
+    }
+    return occluded;
+}
+// sky_visible / light_visible of k_whole's non-validating instantiations (the interval and direction rules of sky_visible above)
+template <bool COUNT>
+__device__ __forceinline__ bool sky_visible_vote(const float4* lds_nodes, const float4* lds_tris, V3 o, V3 d, const TravStack& stack, TravStats& st, bool rq) {
+    const float tmin = rq ? 0.0001f : 0.00001f, tmax = rq ? 1000000.0f : 1000.0f;
+    if (!rq) d = normalize(d);
+    LdsSceneSrc src{lds_nodes, lds_tris, false};
+    return !lds_occluded_vote<COUNT, false>(src, o, d, tmin, tmax, 0.0f, 0u, stack, st);
+}
+template <bool COUNT>
+__device__ __forceinline__ bool light_visible_vote(const DeviceScene& sc, const float4* lds_nodes, const float4* lds_tris, V3 o, V3 d, uint32_t gid, const TravStack& stack, TravStats& st) {
+    const uint32_t slot = sc.tri_slot_of_gid[gid];
+    if (slot == 0xffffffffu) return false;  // the sampled light triangle is a sliver: nothing can hit it
+    LdsSceneSrc src{lds_nodes, lds_tris, false};
+    float4 a, b, c;
+    src.tri((int)slot, a, b, c);   // traverse.hpp closest_is: the sampled triangle by its own record first, then the search for anything that beats it
+    if (COUNT) st.tris++;
+    float t_e, u, v;
+    if (!vptfp::ray_triangle(o, d, vptfp::v3(a.x, a.y, a.z), vptfp::v3(a.w, b.x, b.y), vptfp::v3(b.z, b.w, c.x), 0.0001f, 1000000.0f, &t_e, &u, &v)) return false;
+    return !lds_occluded_vote<COUNT, true>(src, o, d, 0.0001f, 1000000.0f, t_e, gid, stack, st);
+}
+
 // ------------------------------------------------------------------ whole paths in one launch
 // The reference's RayGen invocation IS a whole path: one thread runs the bounce loop of its pixel's sample to the end
 // (RayGen.slang:66-114).  k_whole is that loop on persistent waves, for scenes whose BVH rides in LDS and which have no media:
@@ -706,12 +836,19 @@ __global__ __launch_bounds__(kTraverseBlock, 3) void k_whole(DeviceScene sc, Ren
                 const V3 light_prev = first ? v3s(0.0f) : xyz(ps.ACC[slot]);
                 // connect, inline (RayGen.slang:92-102)
                 V3 E = o.emitted;
+                constexpr bool kVote = VPT_WHOLE_VOTE != 0 && !STRICT;   // vote-scheduled searches on the tree in LDS (above); the validating instantiations keep the per-lane loops
                 if (o.want_sky) {
-                    if (sky_visible<true, COUNT>(sc, lds_nodes, lds_tris, o.sky_o, o.sky_d, stack, sst, rq)) E = E + o.csky;
+                    bool vis;
+                    if constexpr (kVote) vis = sky_visible_vote<COUNT>(lds_nodes, lds_tris, o.sky_o, o.sky_d, stack, sst, rq);
+                    else vis = sky_visible<true, COUNT>(sc, lds_nodes, lds_tris, o.sky_o, o.sky_d, stack, sst, rq);
+                    if (vis) E = E + o.csky;
                     nrays++;
                 }
                 if (o.want_light) {
-                    if (light_visible<true, COUNT>(sc, lds_nodes, lds_tris, o.light_o, o.light_d, o.light_gid, stack, sst)) E = E + o.clight;
+                    bool vis;
+                    if constexpr (kVote) vis = light_visible_vote<COUNT>(sc, lds_nodes, lds_tris, o.light_o, o.light_d, o.light_gid, stack, sst);
+                    else vis = light_visible<true, COUNT>(sc, lds_nodes, lds_tris, o.light_o, o.light_d, o.light_gid, stack, sst);
+                    if (vis) E = E + o.clight;
                     nrays++;
                 }
                 const V3 light = whole_finish(P, ps, slot, E, in_.thr_prev, light_prev, o);
@@ -773,7 +910,10 @@ __global__ __launch_bounds__(kTraverseBlock, 3) void k_whole(DeviceScene sc, Ren
         {
             HitRec hr;
             bool hit = false;
-            if (has_ray) hit = trace_any<true, COUNT>(sc, lds_nodes, lds_tris, porg, normalize(pdir), 0.01f, 100000.0f, stack, hr, st);
+            if (has_ray) {
+                if constexpr (VPT_WHOLE_VOTE != 0 && !STRICT) { LdsSceneSrc src{lds_nodes, lds_tris, false}; hit = lds_closest_vote<COUNT>(src, porg, normalize(pdir), 0.01f, 100000.0f, stack, hr, st); }
+                else hit = trace_any<true, COUNT>(sc, lds_nodes, lds_tris, porg, normalize(pdir), 0.01f, 100000.0f, stack, hr, st);
+            }
             const unsigned long long mh = __ballot(has_ray && hit);
             if (has_ray && hit) {
                 const uint32_t q = (hit_head + hit_count + lanes_below(mh)) & 127u;
