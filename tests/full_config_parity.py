@@ -30,7 +30,9 @@ P = vpt.default_params(max_depth=depth, max_samples=spp)
 if cfg.endswith("_strict"):
     P.flags |= abi.FLAG_LOCAL_HITS
 t = time.time()
-g = vpt.PathTracer(W, H); g.set_scene(sc); g.set_params(P); g.render(spp)
+g = vpt.PathTracer(W, H); t_create = time.time() - t
+g.set_scene(sc); g.set_params(P); t_scene = time.time() - t - t_create
+g.render(spp); t_render = time.time() - t - t_create - t_scene   # incl. growing the path buffers to the batch size (hipMalloc of tens of GB) on the first batch
 img = g.radiance(); st = g.stats()
 out8 = g.postprocess() if cfg == "config5" else None
 g.close()
@@ -45,7 +47,8 @@ res = {"config": "%s %dx%d, %d spp, depth %d, base seed 1%s" % (what, W, H, spp,
        "samples": int(st["samples"]), "bit_exact": bool(np.array_equal(img, ref)),
        "differing_pixels": diff, "rel_l2": rel, "tolerance_rel_l2": 1e-4, "closest_rays_gpu": int(st["closest_rays"]), "closest_rays_oracle": int(ctr["closest"]),
        "pipeline_kernels": {k: int(v) for k, v in st["kernel_launches"].items() if v},
-       "gpu_seconds": round(tg, 3), "oracle_seconds": round(to, 1), "oracle_threads": os.cpu_count(), "mean_radiance": float(ref[..., :3].mean())}
+       "gpu_seconds": round(tg, 3), "gpu_seconds_split": {"create": round(t_create, 3), "set_scene_and_params": round(t_scene, 3), "render_incl_buffer_growth": round(t_render, 3), "read_back_stats_post_close": round(tg - t_create - t_scene - t_render, 3)},
+       "batch_frames": int(st["frames_in_flight"]), "resident_frames": int(st["resident_frames"]), "oracle_seconds": round(to, 1), "oracle_threads": os.cpu_count(), "mean_radiance": float(ref[..., :3].mean())}
 if out8 is not None:
     ref8, _ = O.postprocess(ref, vpt.default_post_params())
     res["post_rgba8_differing_bytes"] = int((out8 != ref8).sum())

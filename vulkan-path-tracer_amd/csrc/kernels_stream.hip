@@ -235,7 +235,10 @@ __global__ __launch_bounds__(256, 3) void k_shade_stream(DeviceScene sc, RenderP
 }
 
 // ------------------------------------------------------------------ join
-constexpr int kJoinUnroll = 4;
+#ifndef VPT_JOIN_UNROLL   // (-D override: tests/tools/build_variant.py)
+#define VPT_JOIN_UNROLL 4
+#endif
+constexpr int kJoinUnroll = VPT_JOIN_UNROLL;
 __global__ __launch_bounds__(256) void k_join(RenderParams P, PathState ps, StreamState ss, const StreamCounters* sctr, const uint32_t* queue, const uint32_t* queue_next,
                                               uint32_t parity) {
     const uint32_t n = sctr->pend_len.v;
