@@ -26,8 +26,11 @@ around every launch on its own stream) and with traversal counters, which feed
   roofline     — for the kernel with the largest share of GPU time (the headline's is the whole-path launch k_whole,
                  timed under "primary"): `bound` says what limits it ("valu" for the Cornell kernels: VALU issue
                  saturated in profiles/, their BVH rides in LDS; "hbm" only where the bytes really cross HBM).  `achieved` = bytes that MUST cross HBM per launch (path records, queue
-                 words, frame sums) / mean launch duration, so frac <= 1 by construction; `traffic` = the PMC
-                 measurement (profiles/traffic.json); `algorithmic_GBs` is SURVEY §8d's figure (records + scene
+                 words, frame sums) / mean launch duration, so frac <= 1 by construction; `traffic`, `valu_busy` and the lane
+                 use of the headline's kernel are MEASURED BY THIS RUN at N = 1 (live_pmc: three short child runs of this script
+                 under `rocprofv3 --pmc`, one counter group each; `roofline.pmc` says so and keeps the committed file's figures
+                 beside them), for the headline and for every extra workload's dominant kernel; where rocprofv3 is unavailable they
+                 come from profiles/traffic.json under its source-id rule; `algorithmic_GBs` is SURVEY §8d's figure (records + scene
                  gathers + measured BVH visits), which on an LDS/L2-resident scene exceeds what HBM moves and is
                  therefore reported beside the fraction, not as it.
   workloads    — the scenes whose traversal touches memory, BASELINE configs 3, 4 and 5 at their own resolution and
@@ -100,6 +103,8 @@ def parse():
                     help="weak (default): every rank renders `steps` batches of its own default size (~448M resident paths), so work grows with N; "
                          "strong: the FIXED job steps x strong_frames whole frames (Cornell: 8 x 129 = config 2's 1024-spp job) is split over the ranks")
     ap.add_argument("--no-latency", action="store_true", help="skip the per-frame latency block (the reference's per-frame call pattern)")
+    ap.add_argument("--no-live-pmc", action="store_true", help="do not spawn the rocprofv3 --pmc passes behind roofline.traffic / valu_busy (then they come from profiles/traffic.json under its staleness rule)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # live_pmc's child runs: the timed loop only, no line
     return ap.parse_args()
 
 
@@ -379,8 +384,75 @@ def frame_latency(vpt, name, scene, params, device, frames=30):
     return out
 
 
-def roofline_for(name, prof):
-    """The roofline object of the bench line, for the kernel with the largest share of GPU time."""
+# stage name of bench.py's kernel table -> the kernels rocprofv3 lists for it (the counting instantiations of kernel_profile's traversal pass are not the timed ones)
+def stage_of_kernel(kernel_name):
+    import re
+    m = re.search(r"<([^>]*)>", kernel_name)
+    a = [x.strip() for x in m.group(1).split(",")] if m else []
+    if "k_whole" in kernel_name:        # <COUNT, STRICT, PLAIN>
+        return None if a and a[0] == "true" else "primary"
+    if "k_bounce" in kernel_name:       # <LDS_SCENE, COUNT, FIRST, ...>
+        if len(a) >= 2 and a[1] == "true":
+            return None
+        return "primary" if len(a) >= 3 and a[2] == "true" else "bounce"
+    for key, st in (("k_trace_vote", "extend"), ("k_shade_stream", "shade"), ("k_trace_shadow", "shadow"), ("k_join", "join"), ("k_resolve", "resolve"),
+                    ("k_finish<", "bounce"), ("k_refill_stream", "primary"), ("k_raygen_stream", "primary")):
+        if key in kernel_name:
+            return st
+    return None
+
+
+def live_pmc(name, stage, pipeline, frames_in_flight):
+    """roofline.traffic / valu_busy measured in THIS run: three short rocprofv3 --pmc passes (FETCH_SIZE; WRITE_SIZE; the VALU counters — separate
+    passes, never combined with a trace) over `python bench.py --workload <name> --steps 2 --warmup 1 --pmc-child` (the timed loop of this script and nothing else), the counters of the stage's kernels averaged per launch.  The corrections are profiles/summarize_bench_r05.py's: HBM-side bytes =
+    (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (KiB units, the fetch counter doubled per MI355X_MICROARCH.md's gfx950 note), VALU busy =
+    SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x GRBM_GUI_ACTIVE / 8) capped at 1, lanes = SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU.
+    Returns (entry, info); entry is None when rocprofv3 is missing or a pass fails (info says why) and the caller falls back to profiles/traffic.json."""
+    import csv, glob, shutil, subprocess, tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None, {"error": "rocprofv3 not found"}
+    if any(k.startswith("ROCPROF") or k.startswith("ROCP_") for k in os.environ):
+        return None, {"error": "already running under a profiler"}
+    passes = (("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]), ("valu", ["SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "GRBM_GUI_ACTIVE"]))
+    child = [sys.executable, os.path.abspath(__file__), "--workload", name, "--steps", "2", "--warmup", "1", "--pipeline", str(pipeline), "--frames-in-flight", str(frames_in_flight),
+             "--no-cpu-baseline", "--no-extra-workloads", "--no-latency", "--no-live-pmc", "--pmc-child"]
+    tmp = tempfile.mkdtemp(prefix="vpt_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    acc, cnt, names, t0 = {}, {}, set(), time.perf_counter()
+    try:
+        for tag, counters in passes:
+            cmd = [exe, "--pmc"] + counters + ["--output-format", "csv", "-d", os.path.join(tmp, tag), "-o", tag, "--"] + child
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=240)
+            files = glob.glob(os.path.join(tmp, tag, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, {"error": "pass %s: rc %d, %d counter file(s)" % (tag, r.returncode, len(files)), "tail": r.stdout.decode(errors="replace")[-300:]}
+            for f in files:
+                for row in csv.DictReader(open(f)):
+                    if stage_of_kernel(row["Kernel_Name"]) == stage:
+                        c = row["Counter_Name"]
+                        acc[c] = acc.get(c, 0.0) + float(row["Counter_Value"]); cnt[c] = cnt.get(c, 0) + 1
+                        names.add(row["Kernel_Name"].split("(")[0])
+    except Exception as e:   # a timeout, an unreadable file: the line still goes out, with the committed counters
+        return None, {"error": "%s: %s" % (type(e).__name__, e)}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    need = ("FETCH_SIZE", "WRITE_SIZE", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "GRBM_GUI_ACTIVE")
+    if any(cnt.get(c, 0) == 0 for c in need):
+        return None, {"error": "no %s launches in the passes" % stage, "counters_seen": sorted(cnt)}
+    per = lambda c: acc[c] / cnt[c]
+    fetch, write = per("FETCH_SIZE") * 1024.0, per("WRITE_SIZE") * 1024.0
+    busy = per("SQ_ACTIVE_INST_VALU") * 4.0 / (1024.0 * per("GRBM_GUI_ACTIVE") / 8.0)
+    entry = {"hbm_bytes_per_launch": 2.0 * fetch + write, "fetch_bytes_raw": fetch, "write_bytes": write, "valu_busy": round(min(busy, 1.0), 3), "valu_busy_raw": round(busy, 3),
+             "lanes_per_valu_instr": round(acc["SQ_THREAD_CYCLES_VALU"] / acc["SQ_ACTIVE_INST_VALU"], 1), "kernel_names": sorted(names)}
+    info = {"source": "live: rocprofv3 --pmc passes spawned by this run (FETCH_SIZE | WRITE_SIZE | SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU GRBM_GUI_ACTIVE), `%s` launches averaged" % stage,
+            "launches_per_pass": cnt["FETCH_SIZE"], "seconds": round(time.perf_counter() - t0, 1),
+            "corrections": "bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024; valu_busy = min(1, SQ_ACTIVE_INST_VALU x 4 / (1024 x GRBM_GUI_ACTIVE / 8)); lanes = SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU"}
+    return entry, info
+
+
+def roofline_for(name, prof, live=None):
+    """The roofline object of the bench line, for the kernel with the largest share of GPU time.  live = (entry, info) of live_pmc for that kernel."""
     kernels = prof["kernels"]
     dom = max(kernels, key=lambda k: kernels[k]["share"])
     k = kernels[dom]
@@ -398,6 +470,17 @@ def roofline_for(name, prof):
     stale = bool(entry) and not (same_build and 0.96 <= pmc_ms / max(k["avg_ms"], 1e-9) <= 1.04)
     if stale:
         entry = {}
+    file_entry = entry
+    pmc_note = {"source": "profiles/traffic.json", "recorded_avg_launch_ms": round(pmc_ms, 5) if pmc_ms else None, "stale": stale, "source_id": source_id,
+                "recorded_source_id": pmc_all.get("_source_id"), "kernel_names": entry.get("kernel_names"),
+                "rule": "copied only when traffic.json was collected on this build (source_id of kernels + headers + flags) and its mean launch time is within 4 % of this run's (box-to-box spread ~3 %)"}
+    if live is not None and live[0] is not None:
+        # measured by this run: traffic, VALU busy and lane use come from the live passes; the operation-mix figures (a separate seven-counter pass) stay the committed file's
+        entry = dict(file_entry, **live[0])
+        pmc_note = dict(live[1], source_id=source_id, kernel_names=live[0]["kernel_names"],
+                        committed_file={"traffic": file_entry.get("hbm_bytes_per_launch"), "valu_busy": file_entry.get("valu_busy"), "lanes_per_valu_instr": file_entry.get("lanes_per_valu_instr"), "stale": stale})
+    elif live is not None:
+        pmc_note["live_failed"] = live[1]
     traffic = entry.get("hbm_bytes_per_launch")
     valu_busy = entry.get("valu_busy")
     lanes = entry.get("lanes_per_valu_instr")
@@ -412,9 +495,7 @@ def roofline_for(name, prof):
         bound = "valu" if lds_scene or dom in ("extend", "connect", "shadow", "shade") else "hbm"
     return {"bound": bound, "kernel": dom, "achieved": k["records_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(k["records_GBs"] / HBM_PEAK_GBS, 5),
             "traffic": traffic, "traffic_frac_of_hbm_peak": round(traffic_frac, 4) if traffic_frac else None, "valu_busy": valu_busy, "avg_launch_ms": k["avg_ms"],
-            "pmc": {"source": "profiles/traffic.json", "recorded_avg_launch_ms": round(pmc_ms, 5) if pmc_ms else None, "stale": stale, "source_id": source_id,
-                    "recorded_source_id": pmc_all.get("_source_id"), "kernel_names": entry.get("kernel_names"),
-                    "rule": "copied only when traffic.json was collected on this build (source_id of kernels + headers + flags) and its mean launch time is within 4 % of this run's (box-to-box spread ~3 %)"},
+            "pmc": pmc_note,
             # the roof that actually binds these kernels (SURVEY 8d's secondary figure): VALU lane throughput.  frac = share of issue
             # cycles with a VALU instruction (VALUBusy) x share of its 64 lanes that are active; the peak is 256 CUs x 4 SIMDs x 16
             # lanes x 2.4 GHz lane-operations per second, of which the 157 TFLOP/s fp32 figure counts 4 flops each (packed FMA)
@@ -475,10 +556,15 @@ def main():
     params = vpt.default_params(max_depth=wl["depth"], base_seed=BASE_SEED, max_samples=0x7fffffff)
 
     head = timed_run(vpt, sharding, R, name, scene, args.pipeline, args.frames_in_flight, args.steps, args.warmup, args.scaling)
+    if args.pmc_child:
+        return
 
     line = None
     if rank == 0:
         prof = kernel_profile(vpt, name, scene, local_rank, rank, world, args.pipeline, args.frames_in_flight, 4)
+        live = None
+        if world == 1 and not args.no_live_pmc:   # the dominant kernel's counters, measured here and now (three short child runs of this script under rocprofv3 --pmc)
+            live = live_pmc(name, max(prof["kernels"], key=lambda k: prof["kernels"][k]["share"]), args.pipeline, args.frames_in_flight)
         line = {
             "metric": "Msamples/s at %dx%d" % (wl["w"], wl["h"]), "value": head["value"], "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
@@ -492,7 +578,7 @@ def main():
                        "partition": "rows y % N == rank, one ncclGather at the end", "base_seed": BASE_SEED, "pipeline": prof["pipeline"]},
             "mrays_per_s": head["mrays_per_s"],
             "set_scene": {"wall_s": head["set_scene_s"], "bvh_build_ms": head["bvh_build_ms"], "set_scene_ms": head["set_scene_ms"]},
-            "roofline": roofline_for(name, prof),
+            "roofline": roofline_for(name, prof, live),
         }
         if "post_ms_in_timed_region" in head:
             line["post_ms_in_timed_region"] = head["post_ms_in_timed_region"]
@@ -517,7 +603,10 @@ def main():
                     wl2 = WORKLOADS[other]
                     w["latency"] = frame_latency(vpt, other, sc2, vpt.default_params(max_depth=wl2["depth"], base_seed=BASE_SEED, max_samples=0x7fffffff), local_rank, frames=10)
                     w["latency"]["batch_ms_per_frame"] = round(wl2["w"] * wl2["h"] / (w["value"] * 1e3), 4)   # what a frame costs inside a full batch: the floor
-                r = roofline_for(other, w)
+                live2 = None
+                if world == 1 and not args.no_live_pmc:
+                    live2 = live_pmc(other, max(w["kernels"], key=lambda k: w["kernels"][k]["share"]), 0, 0)
+                r = roofline_for(other, w, live2)
                 w["roofline"] = {k: r[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_frac_of_hbm_peak", "valu_busy", "avg_launch_ms", "algorithmic_GBs", "algorithmic_frac_of_hbm_peak", "pmc", "valu")}
                 extra[other] = w
             del sc2

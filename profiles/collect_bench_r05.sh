@@ -6,7 +6,7 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_bench
 rm -rf $OUT; mkdir -p $OUT
-BENCH="python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-extra-workloads --no-latency"
+BENCH="python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-extra-workloads --no-latency --no-live-pmc"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- $BENCH > $OUT/kt.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o fetch -- $BENCH > $OUT/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -o write -- $BENCH > $OUT/write.log 2>&1

@@ -20,7 +20,7 @@ def run_bench(args, extra_env=None, timeout=600):
     return r, (json.loads(lines[-1]) if lines else None)
 
 
-QUICK = ["--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-extra-workloads", "--no-latency", "--frames-in-flight", "2"]
+QUICK = ["--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-extra-workloads", "--no-latency", "--no-live-pmc", "--frames-in-flight", "2"]
 
 
 def test_gpus_2_without_a_launcher_runs_two_ranks():
@@ -64,3 +64,21 @@ def test_the_4k_and_post_workloads_as_headline():
     r, line = run_bench(["--workload", "glass_bust_1080p_d32"] + QUICK)
     assert r.returncode == 0, r.stderr[-2000:]
     assert line["config"]["post_in_timed_region"] is True and line["post_ms_in_timed_region"] > 0
+
+
+def test_headline_counters_are_measured_by_the_run_itself():
+    """roofline.traffic / valu_busy at N = 1: bench.py spawns its own rocprofv3 --pmc passes (live_pmc) instead of copying profiles/traffic.json;
+    the committed file's figures stay beside them."""
+    import shutil
+    if shutil.which("rocprofv3") is None and not os.path.exists("/opt/rocm/bin/rocprofv3"):
+        pytest.skip("no rocprofv3 on this box")
+    r, line = run_bench(["--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-extra-workloads", "--no-latency", "--frames-in-flight", "16"], timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    roof = line["roofline"]
+    assert roof["pmc"]["source"].startswith("live"), roof["pmc"]
+    assert roof["kernel"] == "primary" and any("k_whole" in k for k in roof["pmc"]["kernel_names"])
+    assert roof["traffic"] > 0 and 0.0 < roof["valu_busy"] <= 1.0
+    # the whole-path launch writes a 16-byte frame sum per sample and parks a share of the later hits: within a factor of the records it must move
+    assert 0.5 < roof["traffic"] / roof["record_bytes_per_launch"] < 8.0, (roof["traffic"], roof["record_bytes_per_launch"])
+    assert 32.0 < roof["valu"]["active_lanes_of_64"] <= 64.0
+    assert "committed_file" in roof["pmc"]

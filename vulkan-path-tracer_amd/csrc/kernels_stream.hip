@@ -94,8 +94,11 @@ __global__ __launch_bounds__(256) void k_classify(const uint32_t* queue, const u
 }
 
 // ------------------------------------------------------------------ shade
+#ifndef VPT_SHADE_MIN_BLOCKS
+#define VPT_SHADE_MIN_BLOCKS 3   // blocks of four waves per CU the register allocation aims at (168 registers per lane); 2 and 4 measured: profiles/r05_shade_occupancy_ab.log
+#endif
 template <int CLS>
-__global__ __launch_bounds__(256, 3) void k_shade_stream(DeviceScene sc, RenderParams P, PathState ps, StreamState ss, const uint32_t* queue, const uint32_t* order,
+__global__ __launch_bounds__(256, VPT_SHADE_MIN_BLOCKS) void k_shade_stream(DeviceScene sc, RenderParams P, PathState ps, StreamState ss, const uint32_t* queue, const uint32_t* order,
                                                          uint32_t* queue_next, Counters* ctr, StreamCounters* sctr, uint32_t parity, uint32_t cls) {
     const uint32_t n = sctr->class_len[cls].v;    // this class's queue: dense, written by k_classify
     const uint32_t active = sctr->class_active[cls];   // min(waves of the grid, ceil(n / 64))

@@ -470,10 +470,13 @@ __device__ inline void emissive_tri_compute(const DeviceScene& sc, const Emissiv
 }
 
 // SampleEmissiveTriangle, :348-422 (1+1+2 draws; none if there is no emissive mesh)
-__device__ inline void sample_emissive(const DeviceScene& sc, Rng& r, V3 pos, V3& to_light, V4& cpdf, uint32_t& gid) {
+// (results are built in locals and assigned once at the end: with stores to the callers' cpdf on two paths the optimiser merges them into one store through a
+// selected ADDRESS, which keeps cpdf in scratch memory)
+__device__ inline void sample_emissive(const DeviceScene& sc, Rng& r, V3 pos, V3& to_light_out, V4& cpdf_out, uint32_t& gid) {
     gid = 0xffffffffu;
     uint32_t n = sc.emissive_count;
-    if (n == 0) { to_light = v3s(0.0f); cpdf = v4(0.0f, 0.0f, 0.0f, 0.0f); return; }
+    V3 to_light = v3s(0.0f); V4 cpdf = v4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (n == 0) { to_light_out = to_light; cpdf_out = cpdf; return; }
     uint32_t mi = (uint32_t)floor_(r.uf() * (float)n);
     mi = mi < n - 1 ? mi : n - 1;
     const LightSampler ls = sc.lights[mi];
@@ -503,6 +506,7 @@ __device__ inline void sample_emissive(const DeviceScene& sc, Rng& r, V3 pos, V3
         V4 te = tex_finish(k);
         cpdf.x = ls.emissive_color[0] * te.x; cpdf.y = ls.emissive_color[1] * te.y; cpdf.z = ls.emissive_color[2] * te.z;
     }
+    to_light_out = to_light; cpdf_out = cpdf;
 }
 
 // Camera ray + AA jitter + DOF, RayGen.slang:35-50 (4 draws, the DOF pair always drawn).
