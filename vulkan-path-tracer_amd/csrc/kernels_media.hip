@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void k_media_scatter(DeviceScene sc, PathState
 __global__ __launch_bounds__(256, 3) void k_shade_media(DeviceScene sc, RenderParams P, PathState ps, StreamState ss, MediaState ms, const uint32_t* queue, Counters* ctr,
                                                         StreamCounters* sctr, uint32_t parity) {
     const uint32_t n = sctr->class_len[0].v, active = sctr->class_active[0];
-    const uint32_t gw = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const uint32_t gw = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
     if (gw >= active) return;
     const bool exact = sctr->class_exact[0] != 0u;
     WaveAppender a_sky, a_light;
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256, 3) void k_shade_media(DeviceScene sc, RenderPa
 __global__ __launch_bounds__(256, 3) void k_media_tail(DeviceScene sc, RenderParams P, PathState ps, StreamState ss, MediaState ms, const uint32_t* queue, uint32_t* queue_next,
                                                        Counters* ctr, StreamCounters* sctr, uint32_t parity) {
     const uint32_t n = sctr->class_len[0].v, active = sctr->class_active[1];
-    const uint32_t gw = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const uint32_t gw = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
     if (gw >= active) return;
     const bool exact = sctr->class_exact[0] != 0u;
     WaveAppender a_next;

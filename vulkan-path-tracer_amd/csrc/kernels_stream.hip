@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256, VPT_SHADE_MIN_BLOCKS) void k_shade_stream(Devi
                                                          uint32_t* queue_next, Counters* ctr, StreamCounters* sctr, uint32_t parity, uint32_t cls) {
     const uint32_t n = sctr->class_len[cls].v;    // this class's queue: dense, written by k_classify
     const uint32_t active = sctr->class_active[cls];   // min(waves of the grid, ceil(n / 64))
-    const uint32_t gw = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const uint32_t gw = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));   // (said to be uniform: what derives from it — the appenders, the cursor — then lives in scalar registers)
     if (gw >= active) return;                     // this wave owns no chunk of any stream and takes no work
     const uint32_t chunk = fetch_chunk(n);
     WaveAppender a_next, a_pend, a_sky, a_light;
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256, VPT_SHADE_MIN_BLOCKS) void k_shade_stream(Devi
     constexpr bool kRegroup = CLS == kShadeAny;
     __shared__ uint32_t r_q[4][128], r_m[4][128];
     __shared__ float4 r_h[4][128];
-    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     uint32_t hit_head = 0u, hit_count = 0u, miss_head = 0u, miss_count = 0u;   // wave-uniform
     uint32_t pos = gw * 64u, end = pos + 64u;      // the wave's static first 64 entries, then chunks through the cursor
     bool done = false;
