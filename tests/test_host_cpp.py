@@ -18,7 +18,10 @@ LUTS = os.path.join(ROOT, "vulkan-path-tracer_amd", "assets", "lookup_tables.bin
 @pytest.fixture(scope="module")
 def cli(vpt):
     vpt.load_library()  # libvpt_hip.so must exist to link against
-    subprocess.check_call(["make", "-C", HOST, "vpt_render"], stdout=subprocess.DEVNULL)
+    import fcntl
+    with open(os.path.join(HOST, ".build.lock"), "w") as lock:   # pytest-xdist workers share the tree: one make at a time (a second one would relink the binary under a running test)
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        subprocess.check_call(["make", "-C", HOST, "vpt_render"], stdout=subprocess.DEVNULL)
     return CLI
 
 

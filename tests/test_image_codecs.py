@@ -35,7 +35,10 @@ FIXTURES = sorted(glob.glob(os.path.join(IMAGES, "*.png")) + glob.glob(os.path.j
 def cli():
     host = os.path.join(ROOT, "vulkan-path-tracer_amd", "host")
     vpt.build(force=False)
-    subprocess.check_call(["make", "-C", host, "vpt_render"], stdout=subprocess.DEVNULL)
+    import fcntl
+    with open(os.path.join(host, ".build.lock"), "w") as lock:   # one make at a time across pytest-xdist workers (tests/test_host_cpp.py builds the same binary)
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        subprocess.check_call(["make", "-C", host, "vpt_render"], stdout=subprocess.DEVNULL)
     return os.path.join(host, "vpt_render")
 
 
