@@ -402,9 +402,9 @@ def stage_of_kernel(kernel_name):
     return None
 
 
-def live_pmc(name, stage, pipeline, frames_in_flight):
+def live_pmc(name, stage, pipeline, frames_in_flight, steps=2):
     """roofline.traffic / valu_busy measured in THIS run: three short rocprofv3 --pmc passes (FETCH_SIZE; WRITE_SIZE; the VALU counters — separate
-    passes, never combined with a trace) over `python bench.py --workload <name> --steps 2 --warmup 1 --pmc-child` (the timed loop of this script and nothing else), the counters of the stage's kernels averaged per launch.  The corrections are profiles/summarize_bench_r05.py's: HBM-side bytes =
+    passes, never combined with a trace) over `python bench.py --workload <name> --steps 2|4 --warmup 1 --pmc-child` (the timed loop of this script and nothing else), the counters of the stage's kernels averaged per launch.  The corrections are profiles/summarize_bench_r05.py's: HBM-side bytes =
     (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (KiB units, the fetch counter doubled per MI355X_MICROARCH.md's gfx950 note), VALU busy =
     SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x GRBM_GUI_ACTIVE / 8) capped at 1, lanes = SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU.
     Returns (entry, info); entry is None when rocprofv3 is missing or a pass fails (info says why) and the caller falls back to profiles/traffic.json."""
@@ -415,7 +415,7 @@ def live_pmc(name, stage, pipeline, frames_in_flight):
     if any(k.startswith("ROCPROF") or k.startswith("ROCP_") for k in os.environ):
         return None, {"error": "already running under a profiler"}
     passes = (("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]), ("valu", ["SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "GRBM_GUI_ACTIVE"]))
-    child = [sys.executable, os.path.abspath(__file__), "--workload", name, "--steps", "2", "--warmup", "1", "--pipeline", str(pipeline), "--frames-in-flight", str(frames_in_flight),
+    child = [sys.executable, os.path.abspath(__file__), "--workload", name, "--steps", str(steps), "--warmup", "1", "--pipeline", str(pipeline), "--frames-in-flight", str(frames_in_flight),
              "--no-cpu-baseline", "--no-extra-workloads", "--no-latency", "--no-live-pmc", "--pmc-child"]
     tmp = tempfile.mkdtemp(prefix="vpt_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp")
@@ -564,7 +564,7 @@ def main():
         prof = kernel_profile(vpt, name, scene, local_rank, rank, world, args.pipeline, args.frames_in_flight, 4)
         live = None
         if world == 1 and not args.no_live_pmc:   # the dominant kernel's counters, measured here and now (three short child runs of this script under rocprofv3 --pmc)
-            live = live_pmc(name, max(prof["kernels"], key=lambda k: prof["kernels"][k]["share"]), args.pipeline, args.frames_in_flight)
+            live = live_pmc(name, max(prof["kernels"], key=lambda k: prof["kernels"][k]["share"]), args.pipeline, args.frames_in_flight, steps=4)   # (1 + 4 launches of the whole-path kernel per pass)
         line = {
             "metric": "Msamples/s at %dx%d" % (wl["w"], wl["h"]), "value": head["value"], "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
