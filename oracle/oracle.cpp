@@ -19,7 +19,8 @@
 // against the only reference-produced numbers in the tree: Assets/LookupTables/*.bin (generated
 // by the reference's own Material/Sampler code; tests/test_oracle_kat.py reproduces table cells
 // by Monte Carlo through THIS file's BSDF functions), the PCG known answers derived from
-// Sampler.slang:4-9, and furnace-mode energy conservation.  Beyond reference-produced numbers, the
+// Sampler.slang:4-9, and furnace-mode energy conservation; every numeric constant of the hot-path shaders is
+// audited against this file and the product's sources (tests/test_reference_constants.py).  Beyond reference-produced numbers, the
 // algorithmic content is held against INDEPENDENT float64 restatements written from the Slang
 // sources, not from this file: the refraction tables' cells (tests/test_oracle_lut_fp64.py),
 // EvaluateBSDF and the VNDF / SampleBSDF draws (tests/test_oracle_bsdf_fp64.py), the bloom chain and
