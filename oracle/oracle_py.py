@@ -15,8 +15,13 @@ def build(force=False):
     so = os.path.join(_HERE, "liboracle.so")
     src = os.path.join(_HERE, "oracle.cpp")
     deps = [src, os.path.join(_HERE, "..", "include", "vpt.h"), os.path.join(_HERE, "..", "include", "vpt_fp32.h")]
-    if force or not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
-        subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
+    stale = lambda: not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps)
+    if force or stale():
+        import fcntl
+        with open(os.path.join(_HERE, ".build.lock"), "w") as lock:   # one builder at a time (pytest-xdist workers share the tree): the others find the library built
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            if force or stale():
+                subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
     return so
 
 

@@ -56,6 +56,16 @@ def build(force=False, verbose=False, lab=False):
     lib = LIB_LAB if lab else LIB
     if not force and not needs_build(lab):
         return lib
+    import fcntl
+    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    with open(os.path.join(HERE, "build", ".lock"), "w") as lock:   # one builder at a time (pytest-xdist workers, a bench beside a test run): the others find the library built
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and not needs_build(lab):
+            return lib
+        return _build_locked(lib, force, verbose, lab)
+
+
+def _build_locked(lib, force, verbose, lab):
     objs = []
     procs = []
     objdir = os.path.join(HERE, "build", "lab" if lab else "product")
