@@ -402,6 +402,9 @@ def stage_of_kernel(kernel_name):
     return None
 
 
+_LIVE_PMC_OFF = ""   # set by the first failed pass: later workloads do not try again
+
+
 def live_pmc(name, stage, pipeline, frames_in_flight, steps=2):
     """roofline.traffic / valu_busy measured in THIS run: three short rocprofv3 --pmc passes (FETCH_SIZE; WRITE_SIZE; the VALU counters — separate
     passes, never combined with a trace) over `python bench.py --workload <name> --steps 2|4 --warmup 1 --pmc-child` (the timed loop of this script and nothing else), the counters of the stage's kernels averaged per launch.  The corrections are profiles/summarize_bench_r05.py's: HBM-side bytes =
@@ -409,6 +412,9 @@ def live_pmc(name, stage, pipeline, frames_in_flight, steps=2):
     SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x GRBM_GUI_ACTIVE / 8) capped at 1, lanes = SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU.
     Returns (entry, info); entry is None when rocprofv3 is missing or a pass fails (info says why) and the caller falls back to profiles/traffic.json."""
     import csv, glob, shutil, subprocess, tempfile
+    global _LIVE_PMC_OFF
+    if _LIVE_PMC_OFF:   # a pass of an earlier workload failed or timed out: the line must still go out within minutes
+        return None, {"error": "skipped after an earlier failure: " + _LIVE_PMC_OFF}
     exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if exe is None:
         return None, {"error": "rocprofv3 not found"}
@@ -423,9 +429,10 @@ def live_pmc(name, stage, pipeline, frames_in_flight, steps=2):
     try:
         for tag, counters in passes:
             cmd = [exe, "--pmc"] + counters + ["--output-format", "csv", "-d", os.path.join(tmp, tag), "-o", tag, "--"] + child
-            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=240)
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=150)
             files = glob.glob(os.path.join(tmp, tag, "**", "*counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
+                _LIVE_PMC_OFF = "pass %s of %s: rc %d, %d counter file(s)" % (tag, name, r.returncode, len(files))
                 return None, {"error": "pass %s: rc %d, %d counter file(s)" % (tag, r.returncode, len(files)), "tail": r.stdout.decode(errors="replace")[-300:]}
             for f in files:
                 for row in csv.DictReader(open(f)):
@@ -434,6 +441,7 @@ def live_pmc(name, stage, pipeline, frames_in_flight, steps=2):
                         acc[c] = acc.get(c, 0.0) + float(row["Counter_Value"]); cnt[c] = cnt.get(c, 0) + 1
                         names.add(row["Kernel_Name"].split("(")[0])
     except Exception as e:   # a timeout, an unreadable file: the line still goes out, with the committed counters
+        _LIVE_PMC_OFF = "%s in the passes of %s" % (type(e).__name__, name)
         return None, {"error": "%s: %s" % (type(e).__name__, e)}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)

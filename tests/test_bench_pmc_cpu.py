@@ -81,6 +81,9 @@ def test_live_pmc_reports_why_it_fell_back(bench, fake_rocprof, monkeypatch):
     entry, info = bench.live_pmc("cornell_1080p_d8", "primary", 0, 0)
     assert entry is None and "pass write" in info["error"]
     monkeypatch.delenv("FAKE_FAIL")
+    entry, info = bench.live_pmc("atrium_1080p_d8", "shade", 0, 0)      # after a failed pass the other workloads do not try again (the line must go out within minutes)
+    assert entry is None and "skipped after an earlier failure" in info["error"]
+    monkeypatch.setattr(bench, "_LIVE_PMC_OFF", "")
     entry, info = bench.live_pmc("cornell_1080p_d8", "shade", 0, 0)     # no launch of that stage in the passes
     assert entry is None and "no shade launches" in info["error"]
     monkeypatch.setenv("ROCPROFILER_SOMETHING", "1")                    # already under a profiler: never nest
