@@ -339,7 +339,7 @@ def kernel_profile(vpt, name, scene, device, rank, world, pipeline, frames_in_fl
         pp.render(F)
     st = pp.stats(); pp.close()
     whole = st["kernel_launches"]["bounce"] == 0 and st["kernel_launches"]["extend"] == 0
-    used = 5 if whole else 1 if st["kernel_launches"]["bounce"] > 0 else 2    # the pipeline AUTO settled on: count with the same one
+    used = 5 if whole else 2 if st["kernel_launches"]["extend"] > 0 else 1    # the pipeline AUTO settled on: count with the same one ("bounce" launches alone do not say fused: the streams' one-launch finisher k_finish is timed under that name)
     tc = traversal_counts(vpt, name, scene, params, device, rank, world, used if pipeline == 0 else pipeline, min(F, 4))
     kernels = kernel_table(st, tc)
     return {"pipeline": "whole paths (one launch per batch)" if whole else "fused" if used == 1 else ("staged (streams)" if st["kernel_launches"]["join"] > 0 else "staged (round-1 kernels)"), "bvh": {"nodes": st["bvh_nodes"], "triangles": st["bvh_triangles"], "node_bytes": st["bvh_node_bytes"], "tri_bytes": st["bvh_tri_bytes"]},
