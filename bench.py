@@ -185,11 +185,14 @@ def kernel_table(st, tc):
     the part of them that is unique per path (records / queue words / frame sums) and therefore has to cross HBM."""
     n0 = st["samples"]
     whole = st["kernel_launches"]["bounce"] == 0 and st["kernel_launches"]["extend"] == 0 and st["kernel_launches"]["primary"] > 0   # one whole-path launch per batch (k_whole)
-    fused0 = st["kernel_launches"]["bounce"] > 0 or st["kernel_launches"]["extend"] == 0   # bounce 0 ran in the fused primary kernel
     streams = st["kernel_launches"]["join"] > 0                                            # staged pipeline on compact streams
-    n_later = st["closest_rays"] - (n0 if fused0 else 0)
+    # bounce 0 ran in the fused primary kernel.  NOT on the streams: there "bounce" is the one-launch finisher (k_finish, timed under VPT_K_BOUNCE),
+    # which round 5's table mistook for fused bounces and so priced the raygen launch and the finisher with the fused kernels' units (non-physical rates)
+    fused0 = not streams and (st["kernel_launches"]["bounce"] > 0 or st["kernel_launches"]["extend"] == 0)
+    fin_paths, fin_closest, fin_shadow = st.get("finish_paths", 0), st.get("finish_closest_rays", 0), st.get("finish_shadow_rays", 0)
+    n_later = st["closest_rays"] - (n0 if fused0 else 0) - (fin_closest if streams else 0)   # closest-hit rays of the stream stages
     hits0, alive0, rays0 = st["primary_hits"], st["primary_survivors"], st["primary_shadow_rays"]
-    later_rays = st["shadow_rays"] - rays0
+    later_rays = st["shadow_rays"] - rays0 - (fin_shadow if streams else 0)
     alive_later = max(n_later - alive0, 0) if fused0 else max(st["closest_rays"] - n0, 0)
     node_b = st["bvh_node_bytes"]
     trav = tc["nodes_per_closest_ray"] * node_b + tc["tris_per_closest_ray"] * TRI_BYTES
@@ -213,6 +216,10 @@ def kernel_table(st, tc):
         units["shade"] = (n_later, rec + SHADE_SCENE, rec)
         units["shadow"] = (later_rays, SHADOW_RAY + strav, SHADOW_RAY)
         units["join"] = (pend, JOIN_FIXED + (CONNECT_FINAL * fin) / max(pend, 1), JOIN_FIXED + (CONNECT_FINAL * fin) / max(pend, 1))
+        # k_finish: the unit is a PATH-BOUNCE it ran (one closest-hit ray each).  Records cross HBM once per path taken over (queue word + RA, RB, RT, RL in,
+        # the frame sum out); per bounce the scene gathers and the BVH visits of its closest-hit ray and its share of the shadow rays
+        fin_rec = (4 + 64 + CONNECT_FINAL) * fin_paths / max(fin_closest, 1)
+        units["bounce"] = (fin_closest, fin_rec + SHADE_SCENE + trav + strav * fin_shadow / max(fin_closest, 1), fin_rec)
     else:
         units["shade"] = (n_later, SHADE_IN + SHADE_SCENE + (SHADE_ALIVE_OUT * alive_later + SHADE_PENDING_OUT * pend + SHADE_RAY_OUT * later_rays) / max(n_later, 1),
                           SHADE_IN + (SHADE_ALIVE_OUT * alive_later + SHADE_PENDING_OUT * pend + SHADE_RAY_OUT * later_rays) / max(n_later, 1))

@@ -184,8 +184,13 @@ typedef struct vpt_config {
                                 * frame (~0.8 GB at 1080p) and the buffers grow to the largest batch a vpt_render / vpt_render_async call actually asks for
                                 * (min(dispatches, cap) frames, 380 B per path; vpt_stats.frames_allocated) — an interactive host that renders a frame per
                                 * call never holds more than that one frame.  Contexts whose batches run as whole-path launches (VPT_PIPELINE_WHOLE, or AUTO
-                                * where it applies) keep their paths in registers and allocate 48 B per sample + the records of one frame
-                                * (vpt_stats.resident_frames == 1): 22.6 GB instead of 149 GB for 226 frames at 1080p */
+                                * where it applies) keep their paths in registers and allocate 36 B per sample + the records of one frame
+                                * (vpt_stats.resident_frames == 1).
+                                * DEFAULT SCHEDULE (this field 0 AND resident_frames 0): a context that regenerates paths (see resident_frames) or runs whole-path
+                                * launches takes batches of 4 x F frames, F being the cap above (904 frames at 1080p), with F / 2 frames of paths resident
+                                * (113; none for whole-path launches): 126 GB on a 1080p scene whose BVH lives in memory (profiles/r05_frames_sweep.json).
+                                * To CAP THE MEMORY of a drop-in host set this field: e.g. frames_in_flight = 64, resident_frames = 16 holds
+                                * 64 x pixels x 36 B + 16 x pixels x 290 B = 14.4 GB at 1080p (INTEGRATION.md "Device memory"). */
     uint32_t profile;    /* 1 = bracket every kernel launch with hipEvents (vpt_get_stats kernel times) */
     uint32_t count_traversal; /* 1 = count BVH node/triangle visits (slower; for the roofline's algorithmic bytes) */
     uint32_t pipeline;   /* VPT_PIPELINE_* */
@@ -195,10 +200,12 @@ typedef struct vpt_config {
      * next ray queue is REFILLED with the batch's next unstarted samples — a contiguous run of sample ids, i.e. a block of coherent camera
      * rays appended behind the survivors (seeds depend on pixel and frame only, a sample's result lands in its own slot of the frame sums
      * and the running mean is applied in frame order when the batch has finished) — so every launch works on ~K x pixels paths until the
-     * samples run out: ~290 B per resident path + 48 B per sample instead of 380 B per sample.  Applies to the streams pipeline (scenes whose
+     * samples run out: ~290 B per resident path + 36 B per sample instead of 380 B per sample.  Applies to the streams pipeline (scenes whose
      * BVH lives in memory; VPT_PIPELINE_AUTO / _STAGED / _STAGED_SORTED).  Whole-path launches (scenes that ride in LDS) hold no path records
      * at all, whatever this says; the fused per-bounce kernels, media batches, split-screen dispatch and VPT_PIPELINE_STAGED_R1 keep every
-     * sample resident.  0 (default) or a value >= the batch size: every sample resident.  Measured trade: profiles/r05_frames_sweep.json
+     * sample resident.  0 (default): with frames_in_flight == 0 too, batches of 4 x F frames keep F / 2 frames of paths resident (the default schedule
+     * described at frames_in_flight); with an explicit frames_in_flight, every sample resident.  A value >= the batch size: every sample resident.
+     * Measured trade: profiles/r05_frames_sweep.json
      * (DESIGN.md section 4 "Path regeneration").  Images do not depend on it, bit for bit.  Reference loop being unrolled: RayGen.slang:28-33,116-159. */
     uint32_t resident_frames;
 } vpt_config;
@@ -271,7 +278,8 @@ typedef struct vpt_stats {
     uint32_t bvh_tri_bytes;
     uint32_t emissive_mesh_count;
     uint32_t emissive_triangle_count;
-    uint32_t frames_in_flight;
+    uint32_t frames_in_flight; /* the largest batch this context renders at once, in frames: NOT an echo of vpt_config.frames_in_flight — on the default
+                                * schedule it is 4 x that cap (see vpt_config.frames_in_flight) */
     uint32_t shard_pixels;
     uint32_t bvh8_nodes;       /* laboratory build: eight-wide nodes of the BVH8 experiment (0 in the product library) */
     uint32_t build_flags;      /* VPT_BUILD_* the scene's BVH was built with */
@@ -286,6 +294,11 @@ typedef struct vpt_stats {
     uint64_t stack_spills[2];
     double set_scene_ms;       /* wall time of the last vpt_set_scene (validation, BVH build, uploads, derived tables) */
     double bvh_build_ms;       /* of which: the host-side BVH build (bvh_build.cpp; the reference builds BLAS / TLAS on the device, PathTracer.cpp:484-505) */
+    /* Streams pipeline, the one-launch finisher (kernels_path.hip k_finish, timed under VPT_K_BOUNCE): paths it took over from the streams, and the
+     * closest-hit / shadow rays it traced — both also counted in closest_rays / shadow_rays above. */
+    uint64_t finish_paths;
+    uint64_t finish_closest_rays;
+    uint64_t finish_shadow_rays;
 } vpt_stats;
 
 typedef struct vpt_ctx vpt_ctx;

@@ -61,9 +61,20 @@ def test_the_4k_and_post_workloads_as_headline():
     assert r.returncode == 0, r.stderr[-2000:]
     assert line["metric"] == "Msamples/s at 3840x2160" and line["config"]["width"] == 3840 and line["n_gpus"] == 1
     assert line["config"]["pipeline"] == "staged (streams)" and line["set_scene"]["bvh_build_ms"] > 0
+    assert_physical_kernel_table(line)
     r, line = run_bench(["--workload", "glass_bust_1080p_d32"] + QUICK)
     assert r.returncode == 0, r.stderr[-2000:]
     assert line["config"]["post_in_timed_region"] is True and line["post_ms_in_timed_region"] > 0
+    # 2-frame batches at depth 32: the streams hand the rest of a batch to the one-launch finisher (k_finish, timed under "bounce"), which must be priced
+    # with ITS units — paths taken over, path-bounces run — not with the fused per-bounce kernels' (round 5: 138 x the HBM peak in this row)
+    assert "bounce" in line["roofline"]["kernels"] and line["roofline"]["kernels"]["bounce"]["units_per_launch"] > 0
+    assert_physical_kernel_table(line)
+
+
+def assert_physical_kernel_table(line):
+    """No row of the per-kernel table may claim more bytes across HBM than HBM can move: records_GBs counts only what MUST cross (path records, queue words, frame sums)."""
+    for name, k in line["roofline"]["kernels"].items():
+        assert 0 < k["records_GBs"] <= 8000.0, (name, k)
 
 
 def test_headline_counters_are_measured_by_the_run_itself():

@@ -28,4 +28,5 @@ for src, p in procs:
 os.makedirs(os.path.join(ROOT, "variants"), exist_ok=True)
 lib = os.path.join(ROOT, "variants", name + ".so")
 subprocess.check_call([B.hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs + ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib", "-Wl,--strip-all"])
+open(lib + ".id", "w").write(B.source_id(["-DVPT_LAB=0"] + defs) + "\n")   # not the product's id: counters collected on this build are never attributed to the product
 print(lib)

@@ -11,7 +11,7 @@ B = importlib.import_module("vulkan-path-tracer_amd._build")
 CSRC = os.path.join(ROOT, "vulkan-path-tracer_amd", "csrc")
 # the kernels of the BASELINE configs (bench.py's workloads): demangled-name fragments
 MAIN = ("k_whole<false, false, true>", "k_whole<false, false, false>", "k_shade_stream<-1>", "k_trace_vote<false, false, false, true, false, false, false, true>",
-        "k_trace_shadow<true, false, true, false, true>", "k_trace_shadow<false, false, true, false, true>", "k_join", "k_refill_stream", "k_raygen_stream", "k_finish<true>", "k_resolve",
+        "k_trace_shadow<true, false, true, false, true>", "k_trace_shadow<false, false, true, false, true>", "k_join", "k_refill_stream", "k_raygen_stream", "k_finish<false, false>", "k_resolve",
         "k_post_final<true, true>", "k_bloom_down<true>", "k_bloom_tail<true>", "k_bloom_up_chain", "k_bloom_down_chain")
 
 

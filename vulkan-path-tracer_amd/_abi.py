@@ -180,6 +180,7 @@ class Stats(C.Structure):
         ("frames_in_flight", C.c_uint32), ("shard_pixels", C.c_uint32), ("bvh8_nodes", C.c_uint32), ("build_flags", C.c_uint32),
         ("frames_allocated", C.c_uint32), ("resident_frames", C.c_uint32), ("reserved0", C.c_uint32), ("graph_launches", C.c_uint32), ("stack_spills", C.c_uint64 * 2),
         ("set_scene_ms", C.c_double), ("bvh_build_ms", C.c_double),
+        ("finish_paths", C.c_uint64), ("finish_closest_rays", C.c_uint64), ("finish_shadow_rays", C.c_uint64),
     ]
 
 

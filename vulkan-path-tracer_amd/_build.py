@@ -32,14 +32,15 @@ def hipcc():
     raise RuntimeError("hipcc not found")
 
 
-def source_id():
-    """sha256 (16 hex digits) over everything the library is compiled from: kernel sources, headers, this file's flags.  profiles/traffic.json carries the
-    id of the build its rocprofv3 counters were collected on; bench.py copies an entry only when it equals the current one."""
+def source_id(defines=("-DVPT_LAB=0",)):
+    """sha256 (16 hex digits) over everything the library is compiled from: kernel sources, headers, this file's flags and the build's -D list
+    (the product's is -DVPT_LAB=0; the laboratory build and tests/tools/build_variant.py pass theirs, so a variant never carries the product's id).
+    profiles/traffic.json carries the id of the build its rocprofv3 counters were collected on; bench.py copies an entry only when it equals the current one."""
     import hashlib
     h = hashlib.sha256()
     for f in sorted(SOURCES) + sorted(HEADERS):
         h.update(open(os.path.join(CSRC, f), "rb").read())
-    h.update(repr((FLAGS, sorted(EXTRA_FLAGS.items()))).encode())
+    h.update(repr((FLAGS, sorted(EXTRA_FLAGS.items()), sorted(defines))).encode())
     return h.hexdigest()[:16]
 
 

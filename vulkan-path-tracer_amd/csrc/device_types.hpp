@@ -288,6 +288,7 @@ struct StreamCounters {
     HotWord alive[2];       // exact number of live paths in queue[p]: what the host and the resolve guard look at
     HotWord pend_len, sky_len, light_len;                // stream lengths, holes included
     HotWord extend_head, shade_head, sky_head, light_head;  // dynamic work cursors (work beyond each wave's static first 64 entries)
+    HotWord finish_head;    // k_finish's cursor (0 between launches: k_finish_done resets it)
     // per shade class (filled by the extend stage's retire step, laid out by k_prepare_classes)
     HotWord class_len[kShadeClasses];    // class queue lengths (dense: the classify step writes no holes)
     HotWord class_head[kShadeClasses];   // shade work cursors
@@ -331,6 +332,7 @@ struct Counters {
     unsigned long long stat_nodes, stat_tris;                // extend kernel (count_traversal builds only)
     unsigned long long stat_shadow_nodes, stat_shadow_tris;  // connect kernel
     unsigned long long stat_primary_hits, stat_primary_alive, stat_primary_rays;  // bounce 0: hits, survivors, shadow rays
+    unsigned long long stat_finish_paths, stat_finish_closest, stat_finish_shadow;  // k_finish (streams pipeline): paths taken over, closest-hit rays, shadow rays (both also in stat_closest / stat_shadow)
 };
 
 }  // namespace vpt

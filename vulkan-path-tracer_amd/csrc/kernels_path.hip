@@ -540,78 +540,220 @@ __global__ __launch_bounds__(kTraverseBlock, 3) void k_bounce(DeviceScene sc, Re
 // A bounce of the streams pipeline is seven dependent launches.  On a queue of 10^5 paths each of them is bounded below by launch latency and by
 // the tail of its persistent grid, not by throughput: a 1-frame batch of the atrium spent 4.9 ms in 56 such launches against 1.4 ms per frame
 // inside a 226-frame batch, the glass bust (depth 32: 224 launches) 11.8 ms against 0.68 (profiles/r05_latency.json).  k_finish takes what is left of
-// a batch once its queue is short — one path per lane, records read from the streams at the queue's parity — and runs every path to its END:
-// closest hit, miss / closest-hit shader, the <= 2 shadow queries, contribution, roulette, next bounce, exactly as k_bounce does per bounce
-// (the same shade_core and connect code on the same values in the same order: bit-identical to the streams' stages and to the oracle), with
-// the per-lane traversal loops of traverse.hpp on the tree in memory.  Per path-bounce that is about half the streams' rate on long queues —
-// which is why only the tail of a batch goes here: the host decides (vpt_api.hip BatchState::finish_at).  No media, no regeneration.
+// a batch once its queue is short and runs every path to its END: closest hit, miss / closest-hit shader, the <= 2 shadow queries, contribution,
+// roulette, next bounce, exactly as k_bounce does per bounce (the same shade_core and connect code on the same values in the same order:
+// bit-identical to the streams' stages and to the oracle).  No media, no regeneration of camera paths.
+// Round 6: persistent waves.  A lane owns ONE path (records read from the streams at the queue's parity) and keeps it in registers from
+// bounce to bounce; a lane whose path has ended takes the next entry of the queue (every wave starts on its own 64 entries, further chunks
+// through sctr->finish_head), so a wave works on full lanes until the queue runs dry instead of idling behind its longest path (round 5:
+// 10 % lane use, profiles/r05_bust_p2_summary.md).  The three searches of a bounce run on the tree in memory with the wave-level vote of the
+// stream kernels (vote.hpp: ONE kind of step per iteration — node step or triangle step — for the lanes that want it) instead of the per-lane
+// loops of traverse.hpp; a ray's own sequence of visits, tests and interval updates is unchanged, so hits and visibility are identical.
+// STRICT (VPT_FLAG_LOCAL_HITS) keeps the validating per-lane loops.
+struct VoteRay {   // one search of a lane
+    int cur, sp;
+    float best_t, bu, bv;
+    uint32_t bslot, bgid;
+};
+// closest hit (tmin < t < tmax; ties -> smaller global id) of the lanes with `active`; every lane of the wave calls
 template <bool COUNT>
+__device__ __forceinline__ bool mem_closest_vote(const BvhNode* nodes, const BvhTri* tris, const TreeTop& top, const LaneStack& S, bool active, V3 o, V3 d, float tmin, float tmax,
+                                                 HitRec& best, TravStats& st) {
+    VoteRay r; r.cur = active ? 0 : kLaneDone; r.sp = 0; r.best_t = tmax; r.bu = 0.0f; r.bv = 0.0f; r.bslot = 0xffffffffu; r.bgid = 0xffffffffu;
+    const V3 inv = safe_inverse(d);
+    while (true) {
+        const bool busy = r.cur < kLaneDone, at_node = busy && r.cur >= 0, at_leaf = busy && r.cur < 0;
+        const uint32_t nn = (uint32_t)__popcll(__ballot(at_node)), nl = (uint32_t)__popcll(__ballot(at_leaf));
+        if (nn + nl == 0u) break;
+        const bool node_wins = 4u * nn > kVoteWeight4 * nl;
+        if (node_wins & at_node) {
+            if (COUNT) st.nodes++;
+            vote_node_step<false, false, false>(nodes, top, S, r.cur, r.sp, o, inv, tmin, r.best_t);
+        }
+        if (!node_wins & at_leaf) {
+            if (COUNT) { st.tris++; vote_tri_step_closest<false, false>(tris, S, r.cur, r.sp, o, d, tmin, tmax, r.best_t, r.bu, r.bv, r.bslot, r.bgid); }   // (the counting build: one triangle per step, the count is what the ray needs)
+            else vote_tri2_step_closest(tris, S, r.cur, r.sp, o, d, tmin, tmax, r.best_t, r.bu, r.bv, r.bslot, r.bgid);
+        }
+    }
+    const bool found = r.bslot != 0xffffffffu;
+    best.t = r.best_t; best.u = r.bu; best.v = r.bv; best.prim = 0xffffffffu; best.inst = 0xffffffffu; best.gid = 0xffffffffu; best.slot = 0;
+    if (found) { best.prim = tris[r.bslot].prim; best.inst = tris[r.bslot].inst; best.gid = r.bgid; best.slot = (int)r.bslot; }
+    return found;
+}
+// any-hit: is some triangle hit with t < tlim, or t == tlim and a smaller global id than `expect` (traverse.hpp trace_occluded_pass)?
+template <bool COUNT>
+__device__ __forceinline__ bool mem_occluded_vote(const BvhNode* nodes, const BvhTri* tris, const TreeTop& top, const LaneStack& S, bool active, V3 o, V3 d, float tmin, float tmax,
+                                                  float tlim, uint32_t expect, TravStats& st) {
+    int cur = active ? 0 : kLaneDone, sp = 0;
+    bool occluded = false;
+    const V3 inv = safe_inverse(d);
+    while (true) {
+        const bool busy = cur < kLaneDone, at_node = busy && cur >= 0, at_leaf = busy && cur < 0;
+        const uint32_t nn = (uint32_t)__popcll(__ballot(at_node)), nl = (uint32_t)__popcll(__ballot(at_leaf));
+        if (nn + nl == 0u) break;
+        const bool node_wins = 4u * nn > kVoteWeight4 * nl;
+        if (node_wins & at_node) {
+            if (COUNT) st.nodes++;
+            vote_node_step<true>(nodes, top, S, cur, sp, o, inv, tmin, tlim);
+        }
+        if (!node_wins & at_leaf) {
+            if (COUNT) { st.tris++; if (vote_tri_step_any<false>(tris, S, cur, sp, o, d, tmin, tmax, tlim, expect)) occluded = true; }
+            else if (vote_tri2_step_any(tris, S, cur, sp, o, d, tmin, tmax, tlim, expect)) occluded = true;
+        }
+    }
+    return occluded;
+}
+template <bool COUNT, bool STRICT>
 __global__ __launch_bounds__(kTraverseBlock, 3) void k_finish(DeviceScene sc, RenderParams P, PathState ps, StreamState ss, const uint32_t* queue, StreamCounters* sctr,
                                                              Counters* ctr, uint32_t parity) {
-    sc.all_plain = 0u;   // (strict_hits is read at run time, as in k_bounce on a tree in memory)
+    sc.all_plain = 0u; sc.strict_hits = STRICT ? 1u : 0u;
     const bool rq = (P.flags & VPT_FLAG_RAY_QUERIES) != 0u;
     extern __shared__ __align__(16) unsigned char smem[];
-    const TravStack stack = make_stack(smem, sc.stack_overflow);
+    const TravStack stack = make_stack(smem, sc.stack_overflow);     // STRICT: the per-lane loops
+    const LaneStack S = make_lane_stack(smem, sc.stack_overflow);     // the same LDS rows and spill region, as the vote steps address them
+    const BvhNode* const nodes = sc.nodes;
+    const BvhTri* const tris = sc.tris;
+    const TreeTop top = stage_tree_top(smem, nodes, sc.node_count, !STRICT);   // the any-hit searches read the top of the tree from LDS (vote.hpp)
     const uint32_t n = sctr->queue_len[parity].v;
     TravStats st, sst; st.nodes = 0; st.tris = 0; sst.nodes = 0; sst.tris = 0;
-    unsigned long long t_paths = 0ull, t_rays = 0ull;   // per lane: closest-hit rays, shadow rays
-    for (uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += gridDim.x * blockDim.x) {
-        const uint32_t slot = queue[idx];
-        if (slot == kHole) continue;
-        const float4 a = ss.RA[parity][idx], b = ss.RB[parity][idx], t = ss.RT[parity][idx];
+    uint32_t w_paths = 0u, w_rays = 0u, w_taken = 0u;   // wave totals (uniform): closest-hit rays, shadow rays, paths taken over
+    // the wave's cursor into the queue, wave-uniform by construction (kernels_trace.hip k_trace_vote)
+    const uint32_t n_static = gridDim.x * (kTraverseBlock / 64u) * 64u;
+    uint32_t w_next = __builtin_amdgcn_readfirstlane((blockIdx.x * (kTraverseBlock / 64u) + (threadIdx.x >> 6)) * 64u), w_end = w_next + 64u < n ? w_next + 64u : n;
+    if (w_next >= n) { w_next = 0u; w_end = 0u; }
+    bool exhausted = false;
+    // the lane's path between two bounces
+    bool has_path = false;
+    uint32_t slot = 0u, rng_s = 0u, depth = 0u;
+    bool in_medium = false;
+    V3 porg = v3s(0.0f), pdir = v3s(0.0f), thr = v3s(1.0f), lightp = v3s(0.0f);
+    float pdf = 1.0f;
+    for (;;) {
+        // ---- refill: free lanes take the next queue entries (a second pass when the wave's chunk ran out half-way)
+        if (!exhausted) {
+#pragma unroll 1
+            for (int pass = 0; pass < 2; pass++) {
+                const unsigned long long m_free = __ballot(!has_path);
+                if (m_free == 0ull) break;
+                if (w_next >= w_end) {
+                    if (n_static >= n) exhausted = true;
+                    else {
+                        uint32_t base = 0u;
+                        if (lane_id() == 0u) base = atomicAdd(&sctr->finish_head.v, 64u);
+                        base = n_static + __builtin_amdgcn_readfirstlane(base);
+                        if (base >= n) exhausted = true;
+                        else { w_next = base; w_end = base + 64u < n ? base + 64u : n; }
+                    }
+                }
+                if (exhausted) break;
+                const uint32_t idx = w_next + lanes_below(m_free);
+                bool took = false;
+                if (!has_path && idx < w_end) {
+                    slot = queue[idx];
+                    if (slot != kHole) {   // a hole: the tail of some wave's last chunk of the queue (vote.hpp WaveAppender)
+                        const float4 a = ss.RA[parity][idx], b = ss.RB[parity][idx], t = ss.RT[parity][idx];
+                        rng_s = __float_as_uint(a.w); porg = xyz(a); pdir = xyz(b);
+                        const uint32_t dw = __float_as_uint(b.w);
+                        depth = dw & 0x7fffffffu; in_medium = (dw >> 31) != 0u;
+                        thr = xyz(t); pdf = t.w;
+                        lightp = xyz(ss.RL[parity][idx]);
+                        has_path = true; took = true;
+                    }
+                }
+                w_taken += (uint32_t)__popcll(__ballot(took));
+                const uint32_t want = (uint32_t)__popcll(m_free), left = w_end - w_next;
+                w_next += want < left ? want : left;
+            }
+        }
+        if (__ballot(has_path) == 0ull) {
+            if (exhausted) break;
+            continue;
+        }
+        // ---- one bounce of every lane's path
+        HitRec hr;
+        bool hit = false;
+        if constexpr (STRICT) { if (has_path) hit = trace_any<false, COUNT>(sc, nullptr, nullptr, porg, normalize(pdir), 0.01f, 100000.0f, stack, hr, st); }
+        else hit = mem_closest_vote<COUNT>(nodes, tris, top, S, has_path, porg, normalize(pdir), 0.01f, 100000.0f, hr, st);
+        w_paths += (uint32_t)__popcll(__ballot(has_path));
         ShadeIn in_;
-        in_.rng = __float_as_uint(a.w);
-        in_.porg = xyz(a); in_.pdir = xyz(b);
-        const uint32_t dw = __float_as_uint(b.w);
-        in_.depth = dw & 0x7fffffffu; in_.in_medium = (dw >> 31) != 0u;
-        in_.thr_prev = xyz(t); in_.prev_pdf = t.w;
-        in_.vdepth = 0u; in_.cchan = -1; in_.vol_index = -1; in_.vol_t = 0.0f; in_.atm_comp = -1;
-        V3 light_prev = xyz(ss.RL[parity][idx]);
-        while (true) {
-            HitRec hr;
-            const bool hit = trace_any<false, COUNT>(sc, nullptr, nullptr, in_.porg, normalize(in_.pdir), 0.01f, 100000.0f, stack, hr, st);
+        ShadeOut o;
+        o.want_sky = false; o.want_light = false;
+        if (has_path) {
+            in_.rng = rng_s; in_.porg = porg; in_.pdir = pdir; in_.depth = depth; in_.in_medium = in_medium; in_.thr_prev = thr; in_.prev_pdf = pdf;
+            in_.vdepth = 0u; in_.cchan = -1; in_.vol_index = -1; in_.vol_t = 0.0f; in_.atm_comp = -1;
             in_.h = make_float4(hit ? hr.t : -1.0f, hr.u, hr.v, __uint_as_float(hr.gid));
             in_.inst = hr.inst;
-            t_paths++;
-            ShadeOut o;
             shade_core<false>(sc, P, ps, slot, in_, o);
-            // connect, inline (RayGen.slang:92-102), as k_bounce
+        }
+        // connect, inline (RayGen.slang:92-102), as k_bounce
+        const bool q_sky = has_path && o.want_sky, q_light = has_path && o.want_light;
+        bool vis_sky = false, vis_light = false;
+        if constexpr (STRICT) {
+            if (q_sky) vis_sky = sky_visible<false, COUNT>(sc, nullptr, nullptr, o.sky_o, o.sky_d, stack, sst, rq);
+            if (q_light) vis_light = light_visible<false, COUNT>(sc, nullptr, nullptr, o.light_o, o.light_d, o.light_gid, stack, sst);
+        } else {
+            if (__ballot(q_sky) != 0ull) {   // RTCommon.slang:52-63 (USE_RAY_QUERIES) or :64-84 (sky_visible above)
+                const float tmin = rq ? 0.0001f : 0.00001f, tmax = rq ? 1000000.0f : 1000.0f;
+                const V3 sd = rq ? o.sky_d : normalize(o.sky_d);
+                vis_sky = !mem_occluded_vote<COUNT>(nodes, tris, top, S, q_sky, o.sky_o, sd, tmin, tmax, tmax, 0xffffffffu, sst);
+            }
+            if (__ballot(q_light) != 0ull) {   // traverse.hpp closest_is: the sampled triangle by its own record first, then the search for anything that beats it
+                bool search = false;
+                float t_e = 0.0f;
+                if (q_light) {
+                    const uint32_t lslot = sc.tri_slot_of_gid[o.light_gid];
+                    if (lslot != 0xffffffffu) {   // 0xffffffff: the sampled light triangle is a sliver, nothing can hit it
+                        const float4* q = reinterpret_cast<const float4*>(tris + lslot);
+                        const float4 ta = q[0], tb = q[1], tc = q[2];
+                        if (COUNT) sst.tris++;
+                        float u, v;
+                        search = vptfp::ray_triangle(o.light_o, o.light_d, vptfp::v3(ta.x, ta.y, ta.z), vptfp::v3(ta.w, tb.x, tb.y), vptfp::v3(tb.z, tb.w, tc.x), 0.0001f, 1000000.0f, &t_e, &u, &v);
+                    }
+                }
+                const bool occ = mem_occluded_vote<COUNT>(nodes, tris, top, S, search, o.light_o, o.light_d, 0.0001f, 1000000.0f, t_e, o.light_gid, sst);
+                vis_light = search && !occ;
+            }
+        }
+        w_rays += (uint32_t)__popcll(__ballot(q_sky)) + (uint32_t)__popcll(__ballot(q_light));
+        if (has_path) {
             V3 E = o.emitted;
-            if (o.want_sky) { if (sky_visible<false, COUNT>(sc, nullptr, nullptr, o.sky_o, o.sky_d, stack, sst, rq)) E = E + o.csky; t_rays++; }
-            if (o.want_light) { if (light_visible<false, COUNT>(sc, nullptr, nullptr, o.light_o, o.light_d, o.light_gid, stack, sst)) E = E + o.clight; t_rays++; }
+            if (q_sky && vis_sky) E = E + o.csky;
+            if (q_light && vis_light) E = E + o.clight;
             V3 contrib = E * in_.thr_prev;
             if (o.cflags & kCF_Clamp) {
                 float lum = dot(contrib, v3(0.212671f, 0.715160f, 0.072169f));
                 contrib = contrib * (P.max_luminance / max_(lum, P.max_luminance));
             }
-            V3 light = light_prev + contrib;
+            V3 light = lightp + contrib;
             if (o.terminated) {  // end of a sample: NaN/Inf guard, frame sum (RayGen.slang:116-128)
                 const bool ok = !isinf_(light.x) && !isinf_(light.y) && !isinf_(light.z) && !isnan_(light.x) && !isnan_(light.y) && !isnan_(light.z);
                 if (P.samples_per_frame == 1) ps.ACC[slot] = ok ? f4(v3s(0.0f) + light, 0.0f) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                 else if (ok) { float4 acc = ps.ACC[slot]; ps.ACC[slot] = f4(xyz(acc) + light, 0.0f); }
                 light = v3s(0.0f);   // the pixel's next sample of the frame starts from pathLight = 0
             }
-            if (!o.alive) break;
-            in_.rng = o.rng; in_.porg = o.new_o; in_.pdir = o.new_d; in_.depth = o.new_depth; in_.in_medium = o.in_medium;
-            in_.thr_prev = o.thr; in_.prev_pdf = o.new_pdf;
-            light_prev = light;
+            if (o.alive) { rng_s = o.rng; porg = o.new_o; pdir = o.new_d; depth = o.new_depth; in_medium = o.in_medium; thr = o.thr; pdf = o.new_pdf; lightp = light; }
+            else has_path = false;
         }
     }
     // wave totals -> the running statistics
-    for (int off = 32; off > 0; off >>= 1) { t_paths += __shfl_down(t_paths, off); t_rays += __shfl_down(t_rays, off); }
     if (lane_id() == 0u) {
-        if (t_paths) atomicAdd(&ctr->stat_closest, t_paths);
-        if (t_rays) atomicAdd(&ctr->stat_shadow, t_rays);
+        if (w_paths) { atomicAdd(&ctr->stat_closest, (unsigned long long)w_paths); atomicAdd(&ctr->stat_finish_closest, (unsigned long long)w_paths); }
+        if (w_rays) { atomicAdd(&ctr->stat_shadow, (unsigned long long)w_rays); atomicAdd(&ctr->stat_finish_shadow, (unsigned long long)w_rays); }
+        if (w_taken) atomicAdd(&ctr->stat_finish_paths, (unsigned long long)w_taken);
     }
     if (COUNT) {
-        atomicAdd(&ctr->stat_nodes, (unsigned long long)st.nodes);
-        atomicAdd(&ctr->stat_tris, (unsigned long long)st.tris);
-        atomicAdd(&ctr->stat_shadow_nodes, (unsigned long long)sst.nodes);
-        atomicAdd(&ctr->stat_shadow_tris, (unsigned long long)sst.tris);
+        uint32_t a0 = st.nodes, a1 = st.tris, a2 = sst.nodes, a3 = sst.tris;
+        for (int off = 32; off > 0; off >>= 1) { a0 += __shfl_down(a0, off); a1 += __shfl_down(a1, off); a2 += __shfl_down(a2, off); a3 += __shfl_down(a3, off); }
+        if (lane_id() == 0u) {
+            atomicAdd(&ctr->stat_nodes, (unsigned long long)a0);
+            atomicAdd(&ctr->stat_tris, (unsigned long long)a1);
+            atomicAdd(&ctr->stat_shadow_nodes, (unsigned long long)a2);
+            atomicAdd(&ctr->stat_shadow_tris, (unsigned long long)a3);
+        }
     }
 }
 // Behind k_finish nothing of the batch is alive: the queue words say so (the guarded resolve and the host read them).
-__global__ void k_finish_done(StreamCounters* sctr, uint32_t parity) { sctr->alive[parity].v = 0u; sctr->queue_len[parity].v = 0u; }
+__global__ void k_finish_done(StreamCounters* sctr, uint32_t parity) { sctr->alive[parity].v = 0u; sctr->queue_len[parity].v = 0u; sctr->finish_head.v = 0u; }
 
 // ------------------------------------------------------------------ vote-scheduled traversal of the tree in LDS (k_whole)
 // The per-lane loops of traverse.hpp make a wave run the node branch AND the leaf branch of every iteration as soon as its lanes stand at
@@ -629,6 +771,9 @@ __global__ void k_finish_done(StreamCounters* sctr, uint32_t parity) { sctr->ali
 // -DVPT_WHOLE_VOTE=1 (tests/tools/build_variant.py).
 #ifndef VPT_WHOLE_VOTE
 #define VPT_WHOLE_VOTE 0
+#endif
+#ifndef VPT_DIAG_NO_LIGHT_SEARCH
+#define VPT_DIAG_NO_LIGHT_SEARCH 0
 #endif
 constexpr int kWalkDone = 0x7fffffff;
 __device__ __forceinline__ int walk_pop(TravStack& stack) { return stack.sp ? (int)stack.pop() : kWalkDone; }
@@ -846,8 +991,12 @@ __global__ __launch_bounds__(kTraverseBlock, 3) void k_whole(DeviceScene sc, Ren
                 }
                 if (o.want_light) {
                     bool vis;
+#if VPT_DIAG_NO_LIGHT_SEARCH   // measuring build only (tests/tools/build_variant.py): what the kernel costs WITHOUT its light-identity searches (wrong images)
+                    vis = true;
+#else
                     if constexpr (kVote) vis = light_visible_vote<COUNT>(sc, lds_nodes, lds_tris, o.light_o, o.light_d, o.light_gid, stack, sst);
                     else vis = light_visible<true, COUNT>(sc, lds_nodes, lds_tris, o.light_o, o.light_d, o.light_gid, stack, sst);
+#endif
                     if (vis) E = E + o.clight;
                     nrays++;
                 }
@@ -1283,14 +1432,19 @@ void launch_whole(hipStream_t s, uint32_t blocks, bool count, const DeviceScene&
 }
 void launch_finish(hipStream_t s, uint32_t blocks, bool count, const DeviceScene& sc, const RenderParams& P, const PathState& ps, const StreamState& ss, const uint32_t* queue,
                    StreamCounters* sctr, Counters* ctr, uint32_t parity) {
-    const size_t lds = traverse_lds_bytes(sc, false);
-    (void)count;   // one instantiation: the visit counters always run (the tail of a batch; vpt_stats reports them only when count_traversal asked)
-    hipLaunchKernelGGL((k_finish<true>), dim3(blocks), dim3(kTraverseBlock), lds, s, sc, P, ps, ss, queue, sctr, ctr, parity);
+    const size_t lds = kVoteLdsBytes;   // traversal stacks + the LDS copy of the tree top (vote.hpp)
+    const dim3 g(blocks), b(kTraverseBlock);
+    if (sc.strict_hits) { if (count) hipLaunchKernelGGL((k_finish<true, true>), g, b, lds, s, sc, P, ps, ss, queue, sctr, ctr, parity); else hipLaunchKernelGGL((k_finish<false, true>), g, b, lds, s, sc, P, ps, ss, queue, sctr, ctr, parity); }
+    else if (count) hipLaunchKernelGGL((k_finish<true, false>), g, b, lds, s, sc, P, ps, ss, queue, sctr, ctr, parity);
+    else hipLaunchKernelGGL((k_finish<false, false>), g, b, lds, s, sc, P, ps, ss, queue, sctr, ctr, parity);
     hipLaunchKernelGGL(k_finish_done, dim3(1), dim3(1), 0, s, sctr, parity);
 }
 int finish_blocks_per_cu(const DeviceScene& sc) {
-    int nb = 0;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_finish<true>, kTraverseBlock, traverse_lds_bytes(sc, false));
+    (void)sc;
+    int a = 0, b = 0;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_finish<false, false>, kTraverseBlock, kVoteLdsBytes);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_finish<false, true>, kTraverseBlock, kVoteLdsBytes);
+    const int nb = a < b ? a : b;
     return nb > 0 ? nb : 1;
 }
 int whole_blocks_per_cu(const DeviceScene& sc, bool plain) {

@@ -305,7 +305,7 @@ int check_render_size(vpt_ctx* c, uint32_t width, uint32_t height, uint32_t* fra
 }
 
 // Buffers for batches of up to `frames` frames of this shard of which `resident` frames of paths are in flight at a time (the caller
-// has drained the streams): slot-addressed records (frame sum, medium, per-sample words: 48 B per SAMPLE of the batch) and the queues
+// has drained the streams): slot-addressed records (frame sum, medium, per-sample words: 36 B per SAMPLE of the batch) and the queues
 // and stream records (~290 B per RESIDENT path).
 int alloc_path_buffers(vpt_ctx* c, uint32_t frames, uint32_t resident) {
     free_path_buffers(c);
@@ -423,7 +423,7 @@ bool whole_policy(const vpt_ctx* c, uint32_t frames) {
     if (!whole_possible(c)) return false;
     return c->cfg.pipeline == VPT_PIPELINE_WHOLE || (c->cfg.pipeline == VPT_PIPELINE_AUTO && frames <= c->lab_whole_frames);
 }
-// Does a batch of `frames` frames need only its per-sample buffers (48 B per sample: frame sum, medium state), not the ~290 B of records per
+// Does a batch of `frames` frames need only its per-sample buffers (36 B per sample: frame sum, medium state), not the ~290 B of records per
 // resident path?  A whole-path launch keeps its paths in registers (vpt_config.resident_frames means nothing to it: no path of it is resident in memory).
 bool whole_without_records(const vpt_ctx* c, uint32_t frames) { return whole_policy(c, frames); }
 bool whole_applies(const vpt_ctx* c, uint32_t frames) { return whole_policy(c, frames) && frames <= c->frames_alloc; }
@@ -477,7 +477,9 @@ int ensure_path_buffers(vpt_ctx* c, uint32_t want) {
     const uint32_t old = std::max(c->frames_alloc, 1u), old_res = std::max(c->resident_alloc, 1u);
     uint32_t tryf = std::max(want, old);
     while (true) {
-        int rc = alloc_path_buffers(c, tryf, std::max(resident_frames_for(c, tryf), std::min(old_res, tryf)));
+        // (a long batch — tryf beyond frames_in_flight — is sized for resident_frames_for(tryf) resident frames: keeping a larger old residency there would exceed the budget F was chosen for)
+        const uint32_t keep_res = tryf > c->frames_in_flight ? resident_frames_for(c, tryf) : std::max(resident_frames_for(c, tryf), std::min(old_res, tryf));
+        int rc = alloc_path_buffers(c, tryf, keep_res);
         if (rc == VPT_OK) break;
         std::string keep = c->err;
         free_path_buffers(c);
@@ -914,15 +916,17 @@ int batch_resolve(vpt_ctx* c, BatchState& b) {
 // The device-side ray statistics are running totals per lane (Counters::stat_*), copied to pinned memory behind every resolve.
 void update_ray_stats(vpt_ctx* c) {
     vpt_ctx* root = c->owner ? c->owner : c;
-    unsigned long long v[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     auto add = [&](const vpt_ctx* x) {
         const Counters& h = x->h_ctr->ctr;
         v[0] += h.stat_closest; v[1] += h.stat_shadow; v[2] += h.stat_connect; v[3] += h.stat_primary_hits; v[4] += h.stat_primary_alive; v[5] += h.stat_primary_rays;
+        v[6] += h.stat_finish_paths; v[7] += h.stat_finish_closest; v[8] += h.stat_finish_shadow;
     };
     add(root);
     for (vpt_ctx* L : root->lanes) if (L) add(L);
     root->stats.closest_rays = v[0]; root->stats.shadow_rays = v[1]; root->stats.connect_paths = v[2];
     root->stats.primary_hits = v[3]; root->stats.primary_survivors = v[4]; root->stats.primary_shadow_rays = v[5];
+    root->stats.finish_paths = v[6]; root->stats.finish_closest_rays = v[7]; root->stats.finish_shadow_rays = v[8];
 }
 
 // Host synchronisation: statistics, overflow checks, *alive = paths of the batch still in flight.
@@ -1114,7 +1118,7 @@ vpt_ctx* get_lane(vpt_ctx* c, int k) {
     return L;
 }
 // What a lane borrows from its owner, refreshed before every use: scene tables, parameters, camera, the accumulation image.
-void sync_lane(vpt_ctx* c, vpt_ctx* L) {
+int sync_lane(vpt_ctx* c, vpt_ctx* L) {
     L->P = c->P; L->P.dispatch_base_dev = nullptr;
     L->dsc = c->dsc; L->dsc.stack_overflow = (uint32_t*)L->lane_spill;
     L->params = c->params;
@@ -1123,9 +1127,15 @@ void sync_lane(vpt_ctx* c, vpt_ctx* L) {
     L->vote_blocks = c->vote_blocks; L->shadow_blocks = c->shadow_blocks; L->shade_stream_blocks = c->shade_stream_blocks; L->join_blocks = c->join_blocks; L->finish_blocks = c->finish_blocks;
     L->max_blocks = c->max_blocks; L->vote_param = c->vote_param; L->class_present = c->class_present; L->stack_overflow2 = (uint32_t*)L->lane_spill;   // (a lane's batches run on one stream: no second region in use)
     L->image = c->image;
-    L->state_gen = c->state_gen;   // the owner's generation invalidates the lane's captured batch too
     // (vpt_set_params drained every lane before samples_per_frame changed: nothing of this lane is in flight when its per-sample words are replaced)
-    if (!path_words_ok(L)) (void)alloc_path_buffers(L, 1, 1);
+    // New buffers first — free_path_buffers() bumps the lane's own generation — and the owner's generation assigned BEHIND that: a lane left one
+    // generation ahead of its owner would, after one more vpt_set_camera / vpt_set_params on the owner, find its stale captured batch "current" again.
+    if (!path_words_ok(L)) {
+        destroy_graph(L);   // the captured batch holds the old buffers' addresses
+        if (alloc_path_buffers(L, 1, 1) != VPT_OK) { L->buffers_ok = false; c->err = L->err.empty() ? "lane: out of memory" : L->err; return VPT_ERR_OUT_OF_MEMORY; }
+    }
+    L->state_gen = c->state_gen;   // the owner's generation invalidates the lane's captured batch too
+    return VPT_OK;
 }
 void destroy_lane(vpt_ctx* L) {
     if (!L) return;
@@ -1758,7 +1768,7 @@ int vpt_render_async(vpt_ctx* c, uint32_t dispatches, int* done, uint64_t* ticke
                 idle = k == 0u ? c : c->lanes[k - 1];
             }
             X = idle;
-            if (X != c) sync_lane(c, X);
+            if (X != c) { const int rc_lane = sync_lane(c, X); if (rc_lane != VPT_OK) return rc_lane; }
         }
         // a batch on the main lane behind pipelined frames: their resolves come first (frame order), and the records it overwrites are the main lane's own
         if (X == c && c->order_lane && c->order_lane != c) HIPCHK(c, hipStreamWaitEvent(c->stream, c->order_lane->ev_resolved, 0));
@@ -2062,6 +2072,7 @@ int vpt_trace_rays(vpt_ctx* c, const vpt_ray* rays, uint32_t n, vpt_hit* hits) {
     int rc = VPT_OK;
     if (hipMemcpy(dr, rays, (size_t)n * sizeof(vpt_ray), hipMemcpyHostToDevice) != hipSuccess) rc = VPT_ERR_DEVICE;
     if (!rc) {
+        c->spill_dirty = true;   // a traversal kernel runs: vpt_get_stats recounts the spill regions
         launch_trace_rays(c->stream, (uint32_t)c->max_blocks, c->dsc, dr, n, dh);
         if (hipStreamSynchronize(c->stream) != hipSuccess || hipGetLastError() != hipSuccess) rc = VPT_ERR_DEVICE;
     }
@@ -2251,6 +2262,7 @@ int vpt_lab_trace(vpt_ctx* c, uint32_t variant, uint32_t any_hit, const uint32_t
         c->stats.bvh8_nodes = (uint32_t)n8.size();
     }
     const uint32_t n = c->lab_n;
+    c->spill_dirty = true;   // traversal kernels run: vpt_get_stats recounts the spill regions
     if (order) HIPCHK(c, hipMemcpy(c->lab_order, order, (size_t)n * 4, hipMemcpyHostToDevice));
     TraceArgs a{};
     a.ro = c->lab_ro; a.rd = c->lab_rd; a.order = order ? c->lab_order : nullptr; a.hit = c->lab_hit; a.hinst = c->lab_hinst;

@@ -20,10 +20,11 @@ PathTracer PathTracer::New(int device) {
     pt.m_Env.assign(4, 0.0f);  // black 1x1 environment until SetEnvironmentMap (the reference's default .hdr is not redistributable)
     return pt;
 }
-PathTracer PathTracer::New(int device, uint32_t shardRank, uint32_t shardCount) {
+PathTracer PathTracer::New(int device, uint32_t shardRank, uint32_t shardCount, uint32_t framesInFlight, uint32_t residentFrames) {
     if (shardCount == 0 || shardRank >= shardCount) throw std::runtime_error("PathTracer::New: shardRank must be < shardCount");
     PathTracer pt = New(device);
     pt.m_ShardRank = shardRank; pt.m_ShardCount = shardCount;
+    pt.m_FramesInFlight = framesInFlight; pt.m_ResidentFrames = residentFrames;
     return pt;
 }
 void PathTracer::GatherShards(const std::vector<PathTracer*>& shards, uint32_t root) {
@@ -37,6 +38,7 @@ void PathTracer::GatherShards(const std::vector<PathTracer*>& shards, uint32_t r
 void PathTracer::Swap(PathTracer& o) noexcept {
     using std::swap;
     swap(m_Device, o.m_Device); swap(m_ShardRank, o.m_ShardRank); swap(m_ShardCount, o.m_ShardCount); swap(m_Ctx, o.m_Ctx);
+    swap(m_FramesInFlight, o.m_FramesInFlight); swap(m_ResidentFrames, o.m_ResidentFrames);
     swap(m_Params, o.m_Params); swap(m_Width, o.m_Width); swap(m_Height, o.m_Height);
     swap(m_SamplesAccumulated, o.m_SamplesAccumulated); swap(m_DispatchCount, o.m_DispatchCount);
     swap(m_TotalVertexCount, o.m_TotalVertexCount); swap(m_TotalIndexCount, o.m_TotalIndexCount);
@@ -92,6 +94,7 @@ void PathTracer::SetScene(const SceneAsset& sceneIn) {
     if (m_Width == 0) { m_Width = w; m_Height = h; }  // unless ResizeImage already chose a size
     if (!m_Ctx) {
         vpt_config cfg{}; cfg.device = m_Device; cfg.width = m_Width; cfg.height = m_Height; cfg.shard_rank = m_ShardRank; cfg.shard_count = m_ShardCount;
+        cfg.frames_in_flight = m_FramesInFlight; cfg.resident_frames = m_ResidentFrames;
         int err = 0;
         m_Ctx = vpt_create(&cfg, &err);
         if (!m_Ctx) throw std::runtime_error("vpt_create failed (" + std::to_string(err) + "): no usable HIP device; this backend has no CPU fallback");

@@ -41,7 +41,9 @@ public:
     // reference's interleaved split-screen partition, RayGen.slang:16-25, along one axis).  GatherShards() is the one
     // collective of the path: every shard's rows go to shards[root] over xGMI (vpt_multi_gather_shards), after which
     // shards[root].GetOutputImage() / PostProcessor see the whole image — bit-identical to a single-device render.
-    [[nodiscard]] static PathTracer New(int device, uint32_t shardRank, uint32_t shardCount);
+    // framesInFlight / residentFrames: vpt_config.frames_in_flight / resident_frames — the device-memory cap of an offline host (0, 0 = the library's
+    // default schedule: 126 GB on a 1080p scene whose BVH lives in memory; 64, 16 = 14.4 GB; INTEGRATION.md "Device memory").  Images do not depend on them.
+    [[nodiscard]] static PathTracer New(int device, uint32_t shardRank, uint32_t shardCount, uint32_t framesInFlight = 0, uint32_t residentFrames = 0);
     static void GatherShards(const std::vector<PathTracer*>& shards, uint32_t root = 0);
     [[nodiscard]] uint32_t GetShardRank() const { return m_ShardRank; }
     [[nodiscard]] uint32_t GetShardCount() const { return m_ShardCount; }
@@ -121,7 +123,10 @@ public:
     [[nodiscard]] float GetOzonePeak() const { return m_Atmosphere.ozone_peak; }
     [[nodiscard]] Vec3 GetSunColor() const { return Vec3(m_Atmosphere.sun_color[0], m_Atmosphere.sun_color[1], m_Atmosphere.sun_color[2]); }
     // GetOutputImageView() (PathTracer.h:112) is a Vulkan image view upstream; here GetOutputImage() returns the RGBA32F host copy.
-    // ReloadShaders() (PathTracer.h:185) has no counterpart: feature toggles are flag bits, nothing is recompiled.
+    // ReloadShaders (PathTracer.h:92, called from Editor.cpp:437 behind the "Reload Shaders" button): upstream recompiles the Slang sources and rebuilds
+    // the ray-tracing pipeline.  Here every kernel is compiled into libvpt_hip.so and feature toggles are flag bits, so there is nothing to
+    // reload: a callable no-op that keeps the accumulated image (upstream's reload does not reset it either), so an unmodified Editor.cpp links.
+    void ReloadShaders() {}
     void SetCameraViewInverse(const Mat4& view);
     void SetCameraProjectionInverse(const Mat4& projection);
     void SetMaxSamplesAccumulated(uint32_t v) { m_Params.max_samples = v; Push(false); }
@@ -181,6 +186,7 @@ private:
 
     int m_Device = 0;
     uint32_t m_ShardRank = 0, m_ShardCount = 1;
+    uint32_t m_FramesInFlight = 0, m_ResidentFrames = 0;
     vpt_ctx* m_Ctx = nullptr;
     vpt_params m_Params{};
     uint32_t m_Width = 0, m_Height = 0;

@@ -21,6 +21,8 @@ public:
     // an interop / swapchain image as `rgba8Device`.  Returns the ticket to hand to PathTracer::Wait.
     uint64_t PostProcessAsync(void* rgba8Device = nullptr);
     [[nodiscard]] const void* GetOutputImageView() const;
+    // ReloadShaders (PostProcessor.h:31, Editor.cpp:438): the bloom / tonemap kernels live in libvpt_hip.so — a callable no-op (see PathTracer::ReloadShaders)
+    void ReloadShaders() {}
     void SetTonemappingData(const TonemappingData& data) { m_Tonemap = data; }
     void SetBloomData(const BloomData& data) { m_Bloom = data; }
     [[nodiscard]] const std::vector<uint8_t>& GetOutputImage() const { return m_Output; }  // RGBA8 UNORM
