@@ -28,6 +28,8 @@ extern "C" {
                             * of both in flight together; bits 16-21 = slots at leaves that make such an iteration carry the triangle step (0: 32) */
 #define VPT_TRACE_PAIR 4u  /* closest hit only: every lane keeps TWO rays in its registers and serves, in a step of the voted kind, whichever of them wants it
                             * (kernels_trace.hip k_trace_pair).  param: low byte = idle rays (of 128 per wave) that trigger a fetch (0: 48) */
+#define VPT_TRACE_VOTE4S 5u /* the vote kernel on the SPLIT-ORDER four-wide tree — hit children visited in the order the node's binary splits give for the
+                             * ray's direction octant (three table bits, a three-exchange butterfly) instead of sorted by entry distance (vote.hpp vote_node4s_step; built on first use) */
 int vpt_lab_set_rays(vpt_ctx* ctx, const vpt_ray* rays_host, uint32_t n);
 /* Measurement hook on the scheduling of pipelined 1-frame batches (vpt_render_async; tests/tools/latency_probe.py): images never depend on it.
  *   VPT_LAB_LANES       lanes consecutive frames are dealt to (1-3; default 3: a frame takes the first lane whose previous frame is resolved)

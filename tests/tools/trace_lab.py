@@ -24,7 +24,7 @@ os.environ.setdefault("VPT_LAB", "1")   # a laboratory tool: loads libvpt_hip_la
 vpt = importlib.import_module("vulkan-path-tracer_amd")
 
 W, H = 1920, 1080
-BASE, VOTE, VOTE8, POOL, PAIR = 0, 1, 2, 3, 4
+BASE, VOTE, VOTE8, POOL, PAIR, VOTE4S = 0, 1, 2, 3, 4, 5
 
 
 def world_triangles(sc):
@@ -182,6 +182,9 @@ def main():
             if os.environ.get("LAB_PK") == "1":   # packed plane arithmetic in the node step (bit 18) against the product instantiation, alternating
                 plan = [(VOTE, 256 + 16), (VOTE, (256 + 16) | (1 << 18))] * 3
                 cull_mode = True
+            if os.environ.get("LAB_SPLIT4") == "1":   # the split-order four-wide tree (no distance sort in the node step; closest hit) against the product kernel, alternating, visits of both
+                plan = [(VOTE, 256 + 16), (VOTE4S, 256 + 16)] * 3   # (any-hit sets: the plain node step on the split-order tree — what its pair-wise collapse costs a search that ignores the order)
+                cull_mode = True
             if os.environ.get("LAB_POOL") == "1":   # ray slots in LDS (k_trace_pool, closest hit) against the product instantiation: param bits as in include/vpt.h VPT_TRACE_POOL
                 if any_hit:
                     continue
@@ -195,7 +198,7 @@ def main():
                     ref = hits
                 same = bool(np.array_equal(hits["t"], ref["t"]) and np.array_equal(hits["u"], ref["u"]) and np.array_equal(hits["v"], ref["v"]) and
                             np.array_equal(hits["primitive"], ref["primitive"]) and np.array_equal(hits["instance"], ref["instance"]))
-                r = {"scene": which, "set": name, "rays": len(rays), "any_hit": any_hit, "order": oname, "variant": ["base", "vote", "vote_bvh8", "pool", "pair"][variant], "param": param,
+                r = {"scene": which, "set": name, "rays": len(rays), "any_hit": any_hit, "order": oname, "variant": ["base", "vote", "vote_bvh8", "pool", "pair", "vote_split4"][variant], "param": param,
                      "ms": round(ms, 4), "grays_per_s": round(len(rays) / ms / 1e6, 3), "equal_to_reference": same,
                      "hit_fraction": round(float((ref["t"] > 0).mean()), 4)}
                 if vis:

@@ -33,6 +33,11 @@ static void entries(const BvhNode& n, const Slab& r, float tmin, float tlimit, f
     }
 }
 
+static BvhNode clean4s(BvhNode n) {   // the split-order tree keeps its order tables in the mantissas of step_x / step_y
+    uint32_t b; memcpy(&b, &n.step_x, 4); b &= 0x7f800000u; memcpy(&n.step_x, &b, 4);
+    memcpy(&b, &n.step_y, 4); b &= 0x7f800000u; memcpy(&n.step_y, &b, 4);
+    return n;
+}
 struct Policy {
     const char* name;
     int stash;          // leaves a lane may set aside while it goes on with inner nodes (0: the product)
@@ -44,6 +49,7 @@ struct Policy {
     int pair;           // 1 (with pool 128): lane i owns slots i and i + 64 — two rays in its registers — and serves at most one of them per step
     int pool;           // ray slots per wave (64: a ray lives in a lane's registers, the product).  More: rays live in LDS slots and a step runs on
                         // up to 64 of the slots that want it (lanes are workers, not owners)
+    int split_order = 0;   // 1: the split-order tree (bvh_build.hpp BvhBuildOptions::nodes4s): hit children in the order the binary splits give for the ray's octant, no distance sort
 };
 
 struct Lane {
@@ -64,10 +70,15 @@ int main(int argc, char** argv) {
         for (const BvhTri& t : tris) if (!vptfp::triangle_degenerate(vptfp::v3(t.e1[0], t.e1[1], t.e1[2]), vptfp::v3(t.e2[0], t.e2[1], t.e2[2]))) keep.push_back(t);
         tris.swap(keep);
     }
-    std::vector<BvhNode> nodes; std::vector<BvhNodeWide> wide; std::vector<BvhTri> leaf; int depth = 0;
-    build_bvh(tris, nodes, wide, leaf, &depth, nullptr, false);
+    std::vector<BvhNode> nodes, nodes4s; std::vector<BvhNodeWide> wide; std::vector<BvhTri> leaf; int depth = 0;
+    // builder study (round 6): SIM_BINS = SAH bins per axis (16: the product), SIM_SBVH=1 = spatial splits, SIM_STUDY=1 = only the product policy and the split-order one
+    BvhBuildOptions opt; double sah = 0.0;
+    opt.bins = getenv("SIM_BINS") ? atoi(getenv("SIM_BINS")) : 16; opt.spatial_splits = getenv("SIM_SBVH") && atoi(getenv("SIM_SBVH")) != 0;
+    opt.nodes4s = &nodes4s; opt.sah_cost = &sah;
+    build_bvh_ex(tris, nodes, wide, leaf, &depth, opt);
+    const bool study = getenv("SIM_STUDY") && atoi(getenv("SIM_STUDY")) != 0;
     const size_t nrays = rays.size() / 10;
-    printf("%s: %zu rays, %zu triangles, %zu nodes, depth %d\n", argv[3], nrays, leaf.size(), nodes.size(), depth);
+    printf("%s: %zu rays, %zu triangles, %zu nodes (split-order tree: %zu), depth %d, bins %d, sbvh %d, SAH cost %.3f\n", argv[3], nrays, leaf.size(), nodes.size(), nodes4s.size(), depth, opt.bins, (int)opt.spatial_splits, sah);
     const int node_cost = any ? 133 : 155, tri_cost = any ? 91 : 97, fetch_cost = 148;
     const Policy policies[] = {
         {"product (vote 2.0, fetch at 24)", 0, 8, 24, 0, 0, false, 1, 0, 64},
@@ -95,10 +106,17 @@ int main(int argc, char** argv) {
         {"pool 192, fetch at 64", 0, 8, 64, 20, 20, false, 1, 0, 192},
         {"two rays per lane (registers), fetch at 48", 0, 8, 48, 28, 28, false, 1, 1, 128},
         {"two rays per lane, 2 triangles per step", 0, 8, 48, 28, 98, false, 2, 1, 128},
+        // round 6: the split-order tree.  Its node step drops the five-exchange sorting network (25 VALU) and the four miss selects, and adds three table
+        // tests (6), one mask of the two step words (2) and the three-exchange butterfly on the child codes (8 v_cndmask): 155 - 29 + 16 = 142 by the count, 134 if the
+        // hit masks are permuted on the scalar unit
+        {"split order, 2 triangles per step", 0, 8, 24, -13, 70, false, 2, 0, 64, 1},
+        {"split order (scalar masks), 2 tri", 0, 8, 24, -21, 70, false, 2, 0, 64, 1},
     };
     std::vector<float> ref_t(nrays); std::vector<int> ref_g(nrays);
     for (size_t pi = 0; pi < sizeof(policies) / sizeof(policies[0]); pi++) {
         const Policy& P = policies[pi];
+        if (study && !(pi == 0 || pi == 11 || P.split_order)) continue;
+        if (P.split_order && any) continue;   // (an any-hit search has no order)
         std::vector<Lane> L((size_t)P.pool);
         const int pool = P.pool;
         size_t next = 0; bool exhausted = false;
@@ -173,9 +191,20 @@ int main(int argc, char** argv) {
                     if (!take[li]) continue;
                     if (++served > 64) break;
                     visits++;
-                    float t[4]; entries(nodes[l.cur], l.s, l.tmin, l.best, t);
-                    int c[4] = {nodes[l.cur].child[0], nodes[l.cur].child[1], nodes[l.cur].child[2], nodes[l.cur].child[3]};
-                    if (any) {
+                    const BvhNode nd = P.split_order ? clean4s(nodes4s[l.cur]) : nodes[l.cur];
+                    float t[4]; entries(nd, l.s, l.tmin, l.best, t);
+                    int c[4] = {nd.child[0], nd.child[1], nd.child[2], nd.child[3]};
+                    if (P.split_order) {   // vote.hpp vote_node4s_step
+                        uint32_t bx, by; memcpy(&bx, &nodes4s[l.cur].step_x, 4); memcpy(&by, &nodes4s[l.cur].step_y, 4);
+                        const uint32_t oct = (uint32_t)l.s.nx | (uint32_t)l.s.ny << 1 | (uint32_t)l.s.nz << 2;
+                        if ((bx >> oct) & 1u) { std::swap(t[0], t[1]); std::swap(c[0], c[1]); }
+                        if ((bx >> (8 + oct)) & 1u) { std::swap(t[2], t[3]); std::swap(c[2], c[3]); }
+                        if ((by >> oct) & 1u) { std::swap(t[0], t[2]); std::swap(c[0], c[2]); std::swap(t[1], t[3]); std::swap(c[1], c[3]); }
+                        int first = -1;
+                        for (int k = 0; k < 4; k++) if (t[k] < kMiss) { first = k; break; }
+                        if (first < 0) pop_or_done(l);
+                        else { for (int k = 3; k > first; k--) if (t[k] < kMiss) l.st.push_back(c[k]); l.cur = c[first]; }
+                    } else if (any) {
                         int nxt = kIdle;
                         for (int k = 3; k >= 0; k--) if (t[k] < kMiss) { if (nxt != kIdle) l.st.push_back(nxt); nxt = c[k]; }
                         if (nxt != kIdle) l.cur = nxt; else pop_or_done(l);

@@ -96,10 +96,18 @@ def main():
                            "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "tools", "vote_sim.cpp"),
                            os.path.join(ROOT, "vulkan-path-tracer_amd", "csrc", "bvh_build.cpp"), "-o", exe, "-lpthread"])
     tris.tofile(os.path.join(tmp, "tris.bin"))
+    # SIM_CONFIGS="bins=16;bins=32;sbvh=1;bins=32,sbvh=1": the builder study (round 6) — every stream under each builder setting, product policy + split-order policy only
+    configs = [c for c in os.environ.get("SIM_CONFIGS", "").split(";") if c]
     for nm, (kind, r) in streams.items():
         r.tofile(os.path.join(tmp, nm + ".bin"))
         print("==== %s (%d rays)" % (nm, len(r)), flush=True)
-        subprocess.check_call([exe, os.path.join(tmp, "tris.bin"), os.path.join(tmp, nm + ".bin"), kind])
+        if not configs:
+            subprocess.check_call([exe, os.path.join(tmp, "tris.bin"), os.path.join(tmp, nm + ".bin"), kind])
+        for cfg in configs:
+            kv = dict(x.split("=") for x in cfg.split(","))
+            env = dict(os.environ, SIM_STUDY="1", SIM_BINS=kv.get("bins", "16"), SIM_SBVH=kv.get("sbvh", "0"))
+            print("-- builder: %s" % cfg, flush=True)
+            subprocess.check_call([exe, os.path.join(tmp, "tris.bin"), os.path.join(tmp, nm + ".bin"), kind], env=env)
 
 
 if __name__ == "__main__":

@@ -16,7 +16,7 @@ namespace vpt {
 
 namespace {
 constexpr int kLeafSize = 4;
-constexpr int kBins = 16;
+constexpr int kMaxBins = 32;   // (the product builds with 16 bins, BvhBuildOptions::bins; 32 is the builder study's other setting: profiles/r06_builder_study.md)
 constexpr int kMaxDepth = 30;  // < kStackDepth (32)
 constexpr float kNodeCost = 0.7f;  // one two-box node test relative to one triangle test
 
@@ -46,6 +46,7 @@ struct Builder {
     std::vector<Ref> refs;
     std::vector<TmpNode> nodes;
     bool parallel = true;
+    int bins = 16;
 
     int build(int first, int count, int depth) { return build(first, count, depth, nodes); }
     static void append_shifted(std::vector<TmpNode>& out, const std::vector<TmpNode>& sub) {
@@ -67,19 +68,19 @@ struct Builder {
             for (int a = 0; a < 3; a++) {
                 float ext = cb.hi[a] - cb.lo[a];
                 if (!(ext > 0.0f)) continue;
-                Box bb[kBins]; int bc[kBins];
-                for (int k = 0; k < kBins; k++) { bb[k].reset(); bc[k] = 0; }
-                float scale = (float)kBins / ext;
+                Box bb[kMaxBins]; int bc[kMaxBins];
+                for (int k = 0; k < bins; k++) { bb[k].reset(); bc[k] = 0; }
+                float scale = (float)bins / ext;
                 for (int i = first; i < first + count; i++) {
                     int k = (int)((refs[i].c[a] - cb.lo[a]) * scale);
-                    k = k < 0 ? 0 : (k >= kBins ? kBins - 1 : k);
+                    k = k < 0 ? 0 : (k >= bins ? bins - 1 : k);
                     bb[k].grow(refs[i].b); bc[k]++;
                 }
-                float la[kBins]; int lc[kBins];
+                float la[kMaxBins]; int lc[kMaxBins];
                 Box acc; acc.reset(); int cnt = 0;
-                for (int k = 0; k < kBins - 1; k++) { acc.grow(bb[k]); cnt += bc[k]; la[k] = acc.half_area(); lc[k] = cnt; }
+                for (int k = 0; k < bins - 1; k++) { acc.grow(bb[k]); cnt += bc[k]; la[k] = acc.half_area(); lc[k] = cnt; }
                 acc.reset(); cnt = 0;
-                for (int k = kBins - 1; k > 0; k--) {
+                for (int k = bins - 1; k > 0; k--) {
                     acc.grow(bb[k]); cnt += bc[k];
                     if (lc[k - 1] == 0 || cnt == 0) continue;
                     float cost = la[k - 1] * (float)lc[k - 1] + acc.half_area() * (float)cnt;
@@ -95,11 +96,11 @@ struct Builder {
         int mid;
         if (best_axis >= 0) {
             int a = best_axis;
-            float ext = cb.hi[a] - cb.lo[a], scale = (float)kBins / ext, lo = cb.lo[a];
+            float ext = cb.hi[a] - cb.lo[a], scale = (float)bins / ext, lo = cb.lo[a];
             int bin = best_bin;
             auto it = std::stable_partition(refs.begin() + first, refs.begin() + first + count, [&](const Ref& r) {
                 int k = (int)((r.c[a] - lo) * scale);
-                k = k < 0 ? 0 : (k >= kBins ? kBins - 1 : k);
+                k = k < 0 ? 0 : (k >= bins ? bins - 1 : k);
                 return k < bin;
             });
             mid = (int)(it - refs.begin());
@@ -192,19 +193,19 @@ struct Builder {
             for (int a = 0; a < 3; a++) {
                 float ext = cb.hi[a] - cb.lo[a];
                 if (!(ext > 0.0f)) continue;
-                Box bb[kBins]; int bc[kBins];
-                for (int k = 0; k < kBins; k++) { bb[k].reset(); bc[k] = 0; }
-                float scale = (float)kBins / ext;
+                Box bb[kMaxBins]; int bc[kMaxBins];
+                for (int k = 0; k < bins; k++) { bb[k].reset(); bc[k] = 0; }
+                float scale = (float)bins / ext;
                 for (const Ref& x : r) {
                     int k = (int)((x.c[a] - cb.lo[a]) * scale);
-                    k = k < 0 ? 0 : (k >= kBins ? kBins - 1 : k);
+                    k = k < 0 ? 0 : (k >= bins ? bins - 1 : k);
                     bb[k].grow(x.b); bc[k]++;
                 }
-                Box lb[kBins]; int lc[kBins];
+                Box lb[kMaxBins]; int lc[kMaxBins];
                 Box acc; acc.reset(); int cnt = 0;
-                for (int k = 0; k < kBins - 1; k++) { acc.grow(bb[k]); cnt += bc[k]; lb[k] = acc; lc[k] = cnt; }
+                for (int k = 0; k < bins - 1; k++) { acc.grow(bb[k]); cnt += bc[k]; lb[k] = acc; lc[k] = cnt; }
                 acc.reset(); cnt = 0;
-                for (int k = kBins - 1; k > 0; k--) {
+                for (int k = bins - 1; k > 0; k--) {
                     acc.grow(bb[k]); cnt += bc[k];
                     if (lc[k - 1] == 0 || cnt == 0) continue;
                     float cost = lb[k - 1].half_area() * (float)lc[k - 1] + acc.half_area() * (float)cnt;
@@ -222,12 +223,12 @@ struct Builder {
             for (int a = 0; a < 3; a++) {
                 const double lo = nb.lo[a], ext = (double)nb.hi[a] - lo;
                 if (!(ext > 0.0)) continue;
-                Box bb[kBins]; int enter[kBins], leave[kBins];
-                for (int k = 0; k < kBins; k++) { bb[k].reset(); enter[k] = leave[k] = 0; }
-                const double scale = kBins / ext;
+                Box bb[kMaxBins]; int enter[kMaxBins], leave[kMaxBins];
+                for (int k = 0; k < bins; k++) { bb[k].reset(); enter[k] = leave[k] = 0; }
+                const double scale = bins / ext;
                 for (const Ref& x : r) {
                     int k0 = (int)(((double)x.b.lo[a] - lo) * scale), k1 = (int)(((double)x.b.hi[a] - lo) * scale);
-                    k0 = k0 < 0 ? 0 : (k0 >= kBins ? kBins - 1 : k0); k1 = k1 < k0 ? k0 : (k1 >= kBins ? kBins - 1 : k1);
+                    k0 = k0 < 0 ? 0 : (k0 >= bins ? bins - 1 : k0); k1 = k1 < k0 ? k0 : (k1 >= bins ? bins - 1 : k1);
                     enter[k0]++; leave[k1]++;
                     if (k0 == k1) { bb[k0].grow(x.b); continue; }
                     for (int k = k0; k <= k1; k++) {
@@ -235,11 +236,11 @@ struct Builder {
                         if (clip_bounds(x.tri, a, lo + k / scale, lo + (k + 1) / scale, x.b, part)) bb[k].grow(part);
                     }
                 }
-                float la[kBins]; int lc[kBins];
+                float la[kMaxBins]; int lc[kMaxBins];
                 Box acc; acc.reset(); int cnt = 0;
-                for (int k = 0; k < kBins - 1; k++) { acc.grow(bb[k]); cnt += enter[k]; la[k] = acc.half_area(); lc[k] = cnt; }
+                for (int k = 0; k < bins - 1; k++) { acc.grow(bb[k]); cnt += enter[k]; la[k] = acc.half_area(); lc[k] = cnt; }
                 acc.reset(); cnt = 0;
-                for (int k = kBins - 1; k > 0; k--) {
+                for (int k = bins - 1; k > 0; k--) {
                     acc.grow(bb[k]); cnt += leave[k];
                     if (lc[k - 1] == 0 || cnt == 0) continue;
                     float cost = la[k - 1] * (float)lc[k - 1] + acc.half_area() * (float)cnt;
@@ -272,10 +273,10 @@ struct Builder {
         if (L.empty() && R.empty()) {
             if (o_axis >= 0) {
                 const int a = o_axis;
-                const float ext = cb.hi[a] - cb.lo[a], scale = (float)kBins / ext, lo = cb.lo[a];
+                const float ext = cb.hi[a] - cb.lo[a], scale = (float)bins / ext, lo = cb.lo[a];
                 for (const Ref& x : r) {
                     int k = (int)((x.c[a] - lo) * scale);
-                    k = k < 0 ? 0 : (k >= kBins ? kBins - 1 : k);
+                    k = k < 0 ? 0 : (k >= bins ? bins - 1 : k);
                     (k < o_bin ? L : R).push_back(x);
                 }
             }
@@ -303,9 +304,19 @@ inline int32_t leaf_code(int first, int count) { return ~(int32_t)(((uint32_t)fi
 
 void build_bvh(const std::vector<BvhTri>& tris_in, std::vector<BvhNode>& nodes_out, std::vector<BvhNodeWide>& wide_out, std::vector<BvhTri>& tris_out, int* depth_out,
                std::vector<BvhNode8>* nodes8_out, bool spatial_splits, bool parallel) {
+    BvhBuildOptions opt; opt.spatial_splits = spatial_splits; opt.parallel = parallel; opt.nodes8 = nodes8_out;
+    build_bvh_ex(tris_in, nodes_out, wide_out, tris_out, depth_out, opt);
+}
+void build_bvh_ex(const std::vector<BvhTri>& tris_in, std::vector<BvhNode>& nodes_out, std::vector<BvhNodeWide>& wide_out, std::vector<BvhTri>& tris_out, int* depth_out,
+                  const BvhBuildOptions& opt) {
+    std::vector<BvhNode8>* const nodes8_out = opt.nodes8;
+    const bool spatial_splits = opt.spatial_splits;
     nodes_out.clear(); wide_out.clear(); tris_out.clear();
+    if (opt.nodes4s) opt.nodes4s->clear();
+    if (opt.sah_cost) *opt.sah_cost = 0.0;
     Builder b;
-    b.parallel = parallel;
+    b.parallel = opt.parallel;
+    b.bins = opt.bins < 2 ? 2 : (opt.bins > kMaxBins ? kMaxBins : opt.bins);
     b.refs.resize(tris_in.size());
     float maxabs = 0.0f;
     for (size_t i = 0; i < tris_in.size(); i++) {
@@ -335,6 +346,7 @@ void build_bvh(const std::vector<BvhTri>& tris_in, std::vector<BvhNode>& nodes_o
     };
     if (tris_in.empty()) {
         nodes_out.push_back(empty_node()); wide_out.push_back(empty_wide());
+        if (opt.nodes4s) opt.nodes4s->push_back(empty_node());
         if (depth_out) *depth_out = 0;
         return;
     }
@@ -426,27 +438,101 @@ void build_bvh(const std::vector<BvhTri>& tris_in, std::vector<BvhNode>& nodes_o
         }
     }
     if (depth_out) *depth_out = max_depth;
-    {   // The top of the tree first, in breadth-first order: nodes 0 .. kBvhTopNodes-1 are the ones the traversal kernels keep in LDS
-        // (vote.hpp LaneStack / kernels_trace.hip: every ray visits them, and a node fetched from LDS costs the vector L1 nothing);
-        // the rest keep their depth-first order (subtrees contiguous).  A pure renumbering: boxes, children and leaves are unchanged.
-        const size_t n = nodes_out.size();
+    // The top of the tree first, in breadth-first order: nodes 0 .. kBvhTopNodes-1 are the ones the traversal kernels keep in LDS
+    // (vote.hpp LaneStack / kernels_trace.hip: every ray visits them, and a node fetched from LDS costs the vector L1 nothing);
+    // the rest keep their depth-first order (subtrees contiguous).  A pure renumbering: boxes, children and leaves are unchanged.
+    auto top_first = [&](std::vector<BvhNode>& nv, std::vector<BvhNodeWide>* wv) {
+        const size_t n = nv.size();
         std::vector<int> order; order.reserve(n);
         std::vector<char> taken(n, 0);
         order.push_back(0); taken[0] = 1;
         for (size_t head = 0; head < order.size() && order.size() < (size_t)kBvhTopNodes; head++)
             for (int k = 0; k < 4 && order.size() < (size_t)kBvhTopNodes; k++) {
-                const int c = nodes_out[order[head]].child[k];
+                const int c = nv[order[head]].child[k];
                 if (c >= 0 && !taken[c]) { taken[c] = 1; order.push_back(c); }
             }
         for (size_t i = 0; i < n; i++) if (!taken[i]) order.push_back((int)i);
         std::vector<int> new_index(n);
         for (size_t i = 0; i < n; i++) new_index[order[i]] = (int)i;
-        std::vector<BvhNode> nn(n); std::vector<BvhNodeWide> nw(n);
+        std::vector<BvhNode> nn(n); std::vector<BvhNodeWide> nw(wv ? n : 0);
         for (size_t i = 0; i < n; i++) {
-            nn[i] = nodes_out[order[i]]; nw[i] = wide_out[order[i]];
-            for (int k = 0; k < 4; k++) if (nn[i].child[k] >= 0) { nn[i].child[k] = new_index[nn[i].child[k]]; nw[i].child[k] = nn[i].child[k]; }
+            nn[i] = nv[order[i]]; if (wv) nw[i] = (*wv)[order[i]];
+            for (int k = 0; k < 4; k++) if (nn[i].child[k] >= 0) { nn[i].child[k] = new_index[nn[i].child[k]]; if (wv) nw[i].child[k] = nn[i].child[k]; }
         }
-        nodes_out.swap(nn); wide_out.swap(nw);
+        nv.swap(nn); if (wv) wv->swap(nw);
+    };
+    top_first(nodes_out, &wide_out);
+    if (opt.sah_cost) {
+        double cost = 0.0;
+        for (const TmpNode& t : b.nodes) cost += (t.left >= 0 ? (double)kNodeCost : (double)t.count) * (double)t.b.half_area();
+        const double ra = (double)b.nodes[0].b.half_area();
+        *opt.sah_cost = ra > 0.0 ? cost / ra : 0.0;
+    }
+    if (opt.nodes4s) {
+        // ---- the split-order tree: slots 0,1 = the left child's children (or the left child itself in slot 0 when it is a leaf), slots 2,3 = the
+        // right child's.  For every pair the axis along which its two centres differ most decides the order: a ray whose direction is negative
+        // along it meets the pair in reverse.  Tables: bit `oct` (= negx | negy << 1 | negz << 2) of byte 0 / byte 1 of step_x's mantissa for the
+        // left / right pair, of byte 0 of step_y's mantissa for the two pairs themselves.
+        std::vector<BvhNode>& out = *opt.nodes4s;
+        std::vector<BvhNodeWide> dummy_w;
+        auto centre = [&](int t, int a) { return 0.5f * (b.nodes[t].b.lo[a] + b.nodes[t].b.hi[a]); };
+        auto order_table = [&](int ta, int tb) -> uint32_t {   // bit oct = 1: tb comes first
+            if (ta < 0 || tb < 0) return 0u;
+            int axis = 0; float best = -1.0f;
+            for (int a = 0; a < 3; a++) { const float d = std::fabs(centre(ta, a) - centre(tb, a)); if (d > best) { best = d; axis = a; } }
+            const bool a_low = centre(ta, axis) <= centre(tb, axis);
+            uint32_t tab = 0u;
+            for (uint32_t oct = 0; oct < 8; oct++) { const bool neg = ((oct >> axis) & 1u) != 0u; if (neg == a_low) tab |= 1u << oct; }
+            return tab;
+        };
+        struct Item4 { int tmp; int out; };
+        std::vector<Item4> work4;
+        out.push_back(empty_node()); dummy_w.push_back(empty_wide());
+        if (b.nodes[0].left < 0) {
+            put_boxes(out[0], dummy_w[0], &b.nodes[0].b, 1);
+            out[0].child[0] = leaf_code(b.nodes[0].first, b.nodes[0].count);
+        } else work4.push_back({0, 0});
+        while (!work4.empty()) {
+            const Item4 it = work4.back(); work4.pop_back();
+            const int L = b.nodes[it.tmp].left, R = b.nodes[it.tmp].right;
+            int kid[4] = {-1, -1, -1, -1};
+            if (b.nodes[L].left >= 0) { kid[0] = b.nodes[L].left; kid[1] = b.nodes[L].right; } else kid[0] = L;
+            if (b.nodes[R].left >= 0) { kid[2] = b.nodes[R].left; kid[3] = b.nodes[R].right; } else kid[2] = R;
+            // put_boxes takes a dense list: unused slots are written as inverted boxes afterwards
+            Box boxes[4]; int map[4]; int nk = 0;
+            for (int k = 0; k < 4; k++) if (kid[k] >= 0) { boxes[nk] = b.nodes[kid[k]].b; map[nk] = k; nk++; }
+            BvhNode dense = empty_node(); BvhNodeWide dw = empty_wide();
+            put_boxes(dense, dw, boxes, nk);
+            BvhNode n = empty_node();
+            for (int a = 0; a < 3; a++) { n.origin[a] = dense.origin[a]; }
+            n.step_x = dense.step_x; n.step_y = dense.step_y; n.step_z = dense.step_z;
+            for (int a = 0; a < 3; a++) {
+                uint32_t wl = 0xffffffffu, wh = 0u;
+                for (int j = 0; j < nk; j++) {
+                    const int k = map[j];
+                    wl = (wl & ~(0xffu << (8 * k))) | (((dense.lo[a] >> (8 * j)) & 0xffu) << (8 * k));
+                    wh = (wh & ~(0xffu << (8 * k))) | (((dense.hi[a] >> (8 * j)) & 0xffu) << (8 * k));
+                }
+                n.lo[a] = wl; n.hi[a] = wh;
+            }
+            const uint32_t tabL = order_table(kid[0], kid[1]), tabR = order_table(kid[2], kid[3]), tabT = order_table(L, R);
+            uint32_t bx, by; std::memcpy(&bx, &n.step_x, 4); std::memcpy(&by, &n.step_y, 4);
+            bx |= tabL | (tabR << 8); by |= tabT;
+            std::memcpy(&n.step_x, &bx, 4); std::memcpy(&n.step_y, &by, 4);
+            out[it.out] = n;
+            for (int k = 0; k < 4; k++) {
+                if (kid[k] < 0) continue;
+                const TmpNode& c = b.nodes[kid[k]];
+                if (c.left < 0) out[it.out].child[k] = leaf_code(c.first, c.count);
+                else {
+                    const int idx = (int)out.size();
+                    out.push_back(empty_node());
+                    out[it.out].child[k] = idx;
+                    work4.push_back({kid[k], idx});
+                }
+            }
+        }
+        top_first(out, nullptr);
     }
     if (!nodes8_out) return;
 

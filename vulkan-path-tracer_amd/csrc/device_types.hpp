@@ -147,6 +147,7 @@ struct DeviceScene {
     const BvhNode* nodes;
     const BvhNodeWide* nodes_wide;  // non-null only for LDS-resident scenes
     const BvhNode8* nodes8;         // eight-wide tree over the SAME leaf-ordered triangles (trace lab only; nullptr unless built)
+    const BvhNode* nodes4s;         // split-order four-wide tree over the same triangles (trace lab VPT_TRACE_VOTE4S only; nullptr unless built)
     const BvhTri* tris;
     uint32_t node_count, tri_count;
     const vpt_vertex* vertices;

@@ -91,14 +91,16 @@ __global__ __launch_bounds__(kTraverseBlock, 8) void k_trace_base(DeviceScene sc
 // STRICT (VPT_FLAG_LOCAL_HITS, traverse.hpp trace_closest_strict / trace_occluded_strict): a closest-hit winner is validated when its
 // ray retires and the ray is traced again without that triangle if the hit was not local to it; an any-hit stop is validated on the spot.
 // CULL (closest-hit, four-wide tree): stale stack entries are dropped at the pop (vote.hpp LaneStack::pop_or_done_cull).
-template <bool ANY, bool COUNT, bool WIDE8, bool TUNED, bool STRICT = false, bool CULL = false, bool PK = false, bool TRI2 = false>
+template <bool ANY, bool COUNT, bool WIDE8, bool TUNED, bool STRICT = false, bool CULL = false, bool PK = false, bool TRI2 = false, bool SPLIT4 = false>
 __global__ __launch_bounds__(kTraverseBlock, 8) void k_trace_vote(DeviceScene sc, TraceArgs a, Counters* ctr) {
+    static_assert(!SPLIT4 || (!WIDE8 && !CULL && !STRICT && !PK), "the split-order tree is an experiment on the four-wide node (any-hit searches ignore its order tables)");
     static_assert(!(TRI2 && STRICT), "the two-triangle steps have no validating form: VPT_FLAG_LOCAL_HITS keeps the one-triangle step");
     extern __shared__ __align__(16) unsigned char smem[];
     const LaneStack S = make_lane_stack(smem, sc.stack_overflow);
-    const BvhNode* const nodes = sc.nodes;
+    const BvhNode* const nodes = SPLIT4 ? sc.nodes4s : sc.nodes;
     const BvhTri* const tris = sc.tris;
     const TreeTop top = stage_tree_top(smem, nodes, sc.node_count, ANY && !WIDE8 && (TUNED || ((a.param >> 16) & 1u) == 0u));   // any-hit only (vote.hpp vote_node_step); lab: bit 16 switches it off
+    uint32_t oct = 0u;   // SPLIT4: the ray's direction octant
     const uint32_t n = a.n_dev ? *a.n_dev : a.n;
     const uint32_t chunk = fetch_chunk(n);
     const uint32_t fetch_at = TUNED ? kVoteFetchAt : (a.param & 0xffu) ? (a.param & 0xffu) : 16u;  // idle lanes that trigger a fetch step (64: only when all are idle)
@@ -142,6 +144,8 @@ __global__ __launch_bounds__(kTraverseBlock, 8) void k_trace_vote(DeviceScene sc
             if (node_wins & at_node) {  // ---- inner-node step
                 if (COUNT) st_nodes++;
                 if (WIDE8) vote_node8_step(sc.nodes8, S, cur, sp, o, inv, a.tmin, best_t);
+                else if (SPLIT4 && ANY) vote_node_step<true, true, false, LaneStack, false, true>(nodes, top, S, cur, sp, o, inv, a.tmin, best_t);
+                else if (SPLIT4) vote_node4s_step(nodes, S, cur, sp, o, inv, oct, a.tmin, best_t);
                 else vote_node_step<ANY, ANY, CULL, LaneStack, PK>(nodes, top, S, cur, sp, o, inv, a.tmin, best_t);
             }
             VPT_MARK("tri");
@@ -205,6 +209,7 @@ __global__ __launch_bounds__(kTraverseBlock, 8) void k_trace_vote(DeviceScene sc
                     d = xyz4(ld_stream(&a.rd[rid]));
                     if (a.normalize_dir) d = vptfp::normalize(d);  // RayGen.slang:70
                     inv = safe_inverse(d);
+                    if (SPLIT4) oct = (inv.x < 0.0f ? 1u : 0u) | (inv.y < 0.0f ? 2u : 0u) | (inv.z < 0.0f ? 4u : 0u);
                     best_t = a.tmax; bslot = 0xffffffffu; bgid = 0xffffffffu;
                     ex0 = 0xffffffffu; ex1 = 0xffffffffu; validated = false;
                     sp = 0; cur = 0;  // root
@@ -668,6 +673,10 @@ int trace_blocks_per_cu(uint32_t variant, bool any) {
         else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_base<false, false>, kTraverseBlock, lds_lab);
         return nb > 0 ? nb : 1;
     }
+    if (variant == VPT_TRACE_VOTE4S) {
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_vote<false, false, false, true, false, false, false, true, true>, kTraverseBlock, lds_lab);
+        return nb > 0 ? nb : 1;
+    }
     if (variant == VPT_TRACE_VOTE8) {
         if (any) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_vote<true, false, true, false>, kTraverseBlock, lds_lab);
         else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_vote<false, false, true, false>, kTraverseBlock, lds_lab);
@@ -714,6 +723,14 @@ void launch_trace(hipStream_t s, uint32_t blocks, uint32_t variant, bool any, bo
                        else { if (count) hipLaunchKernelGGL((K<false, true>), g, b, lds, s, sc, a, ctr); else hipLaunchKernelGGL((K<false, false>), g, b, lds, s, sc, a, ctr); } } while (0)
 #define VPT_LV(W, T) do { if (any) { if (count) hipLaunchKernelGGL((k_trace_vote<true, true, W, T>), g, b, lds, s, sc, a, ctr); else hipLaunchKernelGGL((k_trace_vote<true, false, W, T>), g, b, lds, s, sc, a, ctr); } \
                           else { if (count) hipLaunchKernelGGL((k_trace_vote<false, true, W, T>), g, b, lds, s, sc, a, ctr); else hipLaunchKernelGGL((k_trace_vote<false, false, W, T>), g, b, lds, s, sc, a, ctr); } } while (0)
+        if (variant == VPT_TRACE_VOTE4S) {   // product vote parameters, two triangles per step; the counting form one.  Any-hit: the plain node step on the split-order tree (its order tables masked off)
+            if (any) {
+                if (count) hipLaunchKernelGGL((k_trace_vote<true, true, false, true, false, false, false, false, true>), g, b, lds, s, sc, a, ctr);
+                else hipLaunchKernelGGL((k_trace_vote<true, false, false, true, false, false, false, true, true>), g, b, lds, s, sc, a, ctr);
+            } else if (count) hipLaunchKernelGGL((k_trace_vote<false, true, false, true, false, false, false, false, true>), g, b, lds, s, sc, a, ctr);
+            else hipLaunchKernelGGL((k_trace_vote<false, false, false, true, false, false, false, true, true>), g, b, lds, s, sc, a, ctr);
+            return;
+        }
         if (variant == VPT_TRACE_BASE) { VPT_LT(k_trace_base); return; }
         if (variant == VPT_TRACE_VOTE8) { VPT_LV(true, false); return; }
         if (!sc.strict_hits) {

@@ -106,11 +106,13 @@ __device__ __forceinline__ TreeTop stage_tree_top(unsigned char* smem, const Bvh
 // USE_TOP: only the any-hit kernels use the LDS tree top.  Measured (atrium / glass bust, bench kernel means): shadow stage 4.46 -> 3.94 ms
 // and 0.318 -> 0.311 ms with it — those kernels are L1-bound with VALU issue to spare (VALUBusy 82-85 %); the closest-hit extend kernel,
 // VALU-saturated, pays for the six instructions of the address select: 6.37 -> 6.71 ms and 1.12 -> 1.19 ms, so it keeps the plain load.
-template <bool ANY, bool USE_TOP = ANY, bool CULL = false, class STK = LaneStack, bool PK = false>
+// MASKED: the node comes from the split-order tree, whose step_x / step_y carry order tables in their mantissas (vote_node4s_step below): two v_and.
+template <bool ANY, bool USE_TOP = ANY, bool CULL = false, class STK = LaneStack, bool PK = false, bool MASKED = false>
 __device__ __forceinline__ void vote_node_step(const BvhNode* nodes, const TreeTop& top, const STK& S, int& cur, int& sp, V3 o, V3 inv, float tmin, float tlimit) {
     const uint4* p = (USE_TOP && cur < top.count) ? top.lds + cur * 4 : reinterpret_cast<const uint4*>(nodes + cur);
     NodeData n;
-    unpack_node(p[0], p[1], p[2], p[3], n);
+    if (MASKED) { uint4 a = p[0], c = p[2]; a.w &= 0x7f800000u; c.z &= 0x7f800000u; unpack_node(a, p[1], c, p[3], n); }
+    else unpack_node(p[0], p[1], p[2], p[3], n);
     RaySlab slab; slab.o = o; slab.inv = inv;
     slab.negx = inv.x < 0.0f; slab.negy = inv.y < 0.0f; slab.negz = inv.z < 0.0f;
     float t0, t1, t2, t3;
@@ -141,6 +143,39 @@ __device__ __forceinline__ void vote_node_step(const BvhNode* nodes, const TreeT
             if (CULL) S.pop_or_done_cull(sp, cur, tlimit); else S.pop_or_done(sp, cur);
         }
     }
+}
+// ---- split-order experiment (trace lab VPT_TRACE_VOTE4S, closest hit): one visit of a four-wide node of the split-order tree
+// (bvh_build.hpp BvhBuildOptions::nodes4s).  The four slab tests as above, but instead of sorting the entry distances (five compare-exchanges
+// on distance + child code, 25 VALU) the hit children are visited in the order the node's binary splits give for the ray's direction octant:
+// three table bits (bit `oct` of two bytes in step_x's mantissa, of one in step_y's) drive a three-exchange butterfly on the child codes and
+// the hit flags.  A closest-hit result does not depend on the order (ties in t go to the smaller global id); the order only decides how soon
+// best_t shrinks.  oct = negx | negy << 1 | negz << 2, kept per ray by the caller.
+__device__ __forceinline__ void vote_node4s_step(const BvhNode* nodes, const LaneStack& S, int& cur, int& sp, V3 o, V3 inv, uint32_t oct, float tmin, float tlimit) {
+    const uint4* p = reinterpret_cast<const uint4*>(nodes + cur);
+    const uint4 w0 = p[0], w1 = p[1], w2 = p[2], w3 = p[3];
+    NodeData n;
+    unpack_node(make_uint4(w0.x, w0.y, w0.z, w0.w & 0x7f800000u), w1, make_uint4(w2.x, w2.y, w2.z & 0x7f800000u, w2.w), w3, n);
+    RaySlab slab; slab.o = o; slab.inv = inv;
+    slab.negx = inv.x < 0.0f; slab.negy = inv.y < 0.0f; slab.negz = inv.z < 0.0f;
+    float t0, t1, t2, t3;
+    node_entries(n, slab, tmin, tlimit, t0, t1, t2, t3);
+    bool h0 = t0 < kMissT, h1 = t1 < kMissT, h2 = t2 < kMissT, h3 = t3 < kMissT;
+    int c0 = n.c0, c1 = n.c1, c2 = n.c2, c3 = n.c3;
+    const bool swl = ((w0.w >> oct) & 1u) != 0u, swr = ((w0.w >> (oct + 8u)) & 1u) != 0u, swt = ((w2.z >> oct) & 1u) != 0u;
+#define VPT_SWAPI(C, A, B) { const int t_ = (C) ? B : A; B = (C) ? A : B; A = t_; }
+#define VPT_SWAPB(C, A, B) { const bool t_ = (C) ? B : A; B = (C) ? A : B; A = t_; }
+    VPT_SWAPI(swl, c0, c1) VPT_SWAPB(swl, h0, h1)
+    VPT_SWAPI(swr, c2, c3) VPT_SWAPB(swr, h2, h3)
+    VPT_SWAPI(swt, c0, c2) VPT_SWAPB(swt, h0, h2)
+    VPT_SWAPI(swt, c1, c3) VPT_SWAPB(swt, h1, h3)
+#undef VPT_SWAPI
+#undef VPT_SWAPB
+    if (!(h0 | h1 | h2 | h3)) { S.pop_or_done(sp, cur); return; }
+    // every hit child except the first is pushed, last first
+    if (h3 & (h0 | h1 | h2)) S.push(sp, c3);
+    if (h2 & (h0 | h1)) S.push(sp, c2);
+    if (h1 & h0) S.push(sp, c1);
+    cur = h0 ? c0 : h1 ? c1 : h2 ? c2 : c3;
 }
 // ---- BVH8 experiment: one visit of an eight-wide node (device_types.hpp BvhNode8).  Eight slab tests on the shared grid, then
 // the hit children in OCTANT order — slot XOR (sign bits of the ray direction), ascending — instead of a distance sort: the

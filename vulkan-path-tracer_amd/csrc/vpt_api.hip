@@ -1347,7 +1347,7 @@ int vpt_set_scene(vpt_ctx* c, const vpt_scene_desc* sd) {
     const auto t_bvh0 = std::chrono::steady_clock::now();
     build_bvh(tris, nodes, wide, leaf_tris, &depth, nullptr, c->sbvh);
     c->bvh_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_bvh0).count();
-    c->bvh_input = tris; c->dsc.nodes8 = nullptr;
+    c->bvh_input = tris; c->dsc.nodes8 = nullptr; c->dsc.nodes4s = nullptr;
     c->bvh_depth = (uint32_t)depth;
     // ---- textures
     c->tex_1x1.clear();
@@ -2246,13 +2246,20 @@ int vpt_lab_set_rays(vpt_ctx* c, const vpt_ray* rays, uint32_t n) {
 }
 int vpt_lab_trace(vpt_ctx* c, uint32_t variant, uint32_t any_hit, const uint32_t* order, uint32_t param, uint32_t reps, vpt_hit* hits, float* best_ms,
                   uint64_t* visits) {
-    if (!c || variant > VPT_TRACE_PAIR || reps == 0) return VPT_ERR_INVALID_ARGUMENT;
+    if (!c || variant > VPT_TRACE_VOTE4S || reps == 0) return VPT_ERR_INVALID_ARGUMENT;
     if ((variant == VPT_TRACE_POOL || variant == VPT_TRACE_PAIR) && any_hit) return fail(c, VPT_ERR_UNSUPPORTED, "VPT_TRACE_POOL / _PAIR are closest-hit variants");
     if (!c->has_scene) return fail(c, VPT_ERR_NO_SCENE, "no scene");
     if (c->lds_scene) return fail(c, VPT_ERR_UNSUPPORTED, "the trace lab runs on scenes whose BVH lives in memory");
     if (c->lab_n == 0) return fail(c, VPT_ERR_INVALID_ARGUMENT, "vpt_lab_trace before vpt_lab_set_rays");
     HIPCHK(c, hipSetDevice(c->cfg.device));
     { int rd = drain(c); if (rd) return rd; }
+    if (variant == VPT_TRACE_VOTE4S && !c->dsc.nodes4s) {   // split-order experiment: the same binary tree collapsed pair-wise with order tables, over the same leaf-ordered triangles
+        std::vector<BvhNode> n4, n4s; std::vector<BvhNodeWide> w4; std::vector<BvhTri> lt; int d = 0;
+        BvhBuildOptions opt; opt.spatial_splits = c->sbvh; opt.nodes4s = &n4s;
+        build_bvh_ex(c->bvh_input, n4, w4, lt, &d, opt);
+        int rc4 = upload(c, n4s, &c->dsc.nodes4s);
+        if (rc4) return rc4;
+    }
     if (variant == VPT_TRACE_VOTE8 && !c->dsc.nodes8) {   // BVH8 experiment: the same binary tree collapsed eight-wide, over the same leaf-ordered triangles
         std::vector<BvhNode> n4; std::vector<BvhNodeWide> w4; std::vector<BvhTri> lt; std::vector<BvhNode8> n8; int d = 0;
         build_bvh(c->bvh_input, n4, w4, lt, &d, &n8, c->sbvh);
