@@ -58,6 +58,16 @@ def test_gloo_world2_gather_assemble(tmp_path, w, h):
     assert np.array_equal(img, full)
 
 
+@pytest.mark.parametrize("world,w,h", [(4, 12, 10), (8, 8, 16), (8, 8, 19)])
+def test_gloo_world4_and_8_gather_assemble(tmp_path, world, w, h):
+    """The node's own shape: 4 and 8 ranks (one per GPU of an MI355X node), an even split (16 rows / 8) and ragged ones (10 / 4, 19 / 8:
+    the first ranks own one row more, every shard is padded to rank 0's size for the gather)."""
+    out = str(tmp_path / "img.npy")
+    mp.spawn(_worker, args=(world, _free_port(), w, h, out), nprocs=world, join=True)
+    img, full = np.load(out)
+    assert np.array_equal(img, full)
+
+
 def test_shard_arithmetic():
     import importlib
     sys.path.insert(0, ROOT)

@@ -41,7 +41,8 @@ def test_rccl_communicator_world1(vpt, scenes):
     g.close()
 
 
-@pytest.mark.parametrize("world,root,h", [(2, 0, 54), (3, 2, 55)])
+# world 8: the node's shape — 1080 rows (135 per rank) and 2160 rows (270 per rank) of a narrow image, and a ragged height (1083 = 8 x 135 + 3: ranks 0-2 own 136 rows)
+@pytest.mark.parametrize("world,root,h", [(2, 0, 54), (3, 2, 55), (8, 0, 1080), (8, 5, 2160), (8, 0, 1083)])
 def test_library_gather_at_world_n_through_a_stub_rccl(vpt, scenes, tmp_path, world, root, h):
     """The C++ gather path itself — vpt_comm_init, vpt_comm_gather_shards (padding, root-only receive buffer, offset r * count per
     rank), the row re-interleave on the root, post-processing of the assembled image — at world > 1: `world` PROCESSES on this box's
@@ -53,7 +54,7 @@ def test_library_gather_at_world_n_through_a_stub_rccl(vpt, scenes, tmp_path, wo
     subprocess.check_call(["/opt/rocm/bin/hipcc", "-shared", "-fPIC", "-O2", "-o", stub, os.path.join(ROOT, "tests", "tools", "rccl_stub.cpp")])
     sc = scenes("cornell_box_glass")
     P = vpt.default_params(max_depth=5)
-    w, frames = 80, 2
+    w, frames = (80, 2) if h < 1000 else (16, 1)
     ref = render_whole(vpt, sc, w, h, P, frames)
     g = vpt.PathTracer(w, h); g.set_scene(sc); g.set_params(P); g.render(frames); ref8 = g.postprocess(); g.close()
     env = dict(os.environ, LD_PRELOAD=stub, VPT_RCCL_STUB_DIR=str(tmp_path))
@@ -151,6 +152,22 @@ def test_bench_two_ranks_on_one_device():
     line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["value"] > 0 and line["scaling"] == "weak" and line["config"]["workload"] == "cornell_1080p_d8"
     assert line["roofline"]["frac"] <= 1.0 and line["roofline"]["bound"] in ("valu", "hbm")
+
+
+def test_bench_gpus_8_dry_run_on_one_device():
+    """`bench.py --gpus 8` as the driver launches it on a node, on this box's one device through the one-device hook (eight processes share the GPU, the gather is host-staged):
+    the emitted line must say 8 ranks, the communicator must report 8, and weak mode must keep the per-rank frame count of the N = 1 run."""
+    env = dict(os.environ, VPT_BENCH_DEVICE="0", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "1", "--frames-in-flight", "2", "--no-cpu-baseline", "--no-extra-workloads", "--no-latency", "--no-live-pmc"]
+    p = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=1500)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 8 and line["scaling"] == "weak" and line["value"] > 0
+    assert line["rccl"]["nranks"] == 8
+    assert line["config"]["frames_per_step_per_gpu"] == 2 and line["config"]["workload"] == "cornell_1080p_d8"
+    # whole-job samples of the timed region: 8 ranks x 2 frames x 135 rows each = 2 whole 1080p frames per step... weak mode renders frames_per_step_per_gpu frames of the rank's rows
+    assert abs(line["value"] * line["ms_per_step"] * 1e-3 * 1e6 - 2 * 1920 * 1080) < 1e-3 * 2 * 1920 * 1080 * 8
 
 
 def test_bench_strong_scaling_splits_a_fixed_job():

@@ -111,12 +111,14 @@ int main(int argc, char** argv) {
         // hit masks are permuted on the scalar unit
         {"split order, 2 triangles per step", 0, 8, 24, -13, 70, false, 2, 0, 64, 1},
         {"split order (scalar masks), 2 tri", 0, 8, 24, -21, 70, false, 2, 0, 64, 1},
+        // the pair-wise collapse alone (children = the two children's children), nearest-first by entry distance as in the product, any-hit in slot order
+        {"pair-wise collapse, 2 tri per step", 0, 8, 24, 0, 70, false, 2, 0, 64, 2},
     };
     std::vector<float> ref_t(nrays); std::vector<int> ref_g(nrays);
     for (size_t pi = 0; pi < sizeof(policies) / sizeof(policies[0]); pi++) {
         const Policy& P = policies[pi];
         if (study && !(pi == 0 || pi == 11 || P.split_order)) continue;
-        if (P.split_order && any) continue;   // (an any-hit search has no order)
+        if (P.split_order == 1 && any) continue;   // (an any-hit search has no order)
         std::vector<Lane> L((size_t)P.pool);
         const int pool = P.pool;
         size_t next = 0; bool exhausted = false;
@@ -194,7 +196,7 @@ int main(int argc, char** argv) {
                     const BvhNode nd = P.split_order ? clean4s(nodes4s[l.cur]) : nodes[l.cur];
                     float t[4]; entries(nd, l.s, l.tmin, l.best, t);
                     int c[4] = {nd.child[0], nd.child[1], nd.child[2], nd.child[3]};
-                    if (P.split_order) {   // vote.hpp vote_node4s_step
+                    if (P.split_order == 1) {   // vote.hpp vote_node4s_step
                         uint32_t bx, by; memcpy(&bx, &nodes4s[l.cur].step_x, 4); memcpy(&by, &nodes4s[l.cur].step_y, 4);
                         const uint32_t oct = (uint32_t)l.s.nx | (uint32_t)l.s.ny << 1 | (uint32_t)l.s.nz << 2;
                         if ((bx >> oct) & 1u) { std::swap(t[0], t[1]); std::swap(c[0], c[1]); }

@@ -413,14 +413,22 @@ void build_bvh_ex(const std::vector<BvhTri>& tris_in, std::vector<BvhNode>& node
         Item it = work.back(); work.pop_back();
         max_depth = std::max(max_depth, it.depth);
         int kids[4]; int nk = 0;
-        kids[nk++] = b.nodes[it.tmp].left; kids[nk++] = b.nodes[it.tmp].right;
-        while (nk < 4) {
-            int best = -1; float ba = -1.0f;
-            for (int k = 0; k < nk; k++)
-                if (b.nodes[kids[k]].left >= 0) { float a = b.nodes[kids[k]].b.half_area(); if (a > ba) { ba = a; best = k; } }
-            if (best < 0) break;
-            int t = kids[best];
-            kids[best] = b.nodes[t].left; kids[nk++] = b.nodes[t].right;
+        if (opt.pairwise) {   // the two children's children (a leaf child stays as it is): two binary levels per four-wide node, always
+            const int lr[2] = {b.nodes[it.tmp].left, b.nodes[it.tmp].right};
+            for (int side = 0; side < 2; side++) {
+                if (b.nodes[lr[side]].left >= 0) { kids[nk++] = b.nodes[lr[side]].left; kids[nk++] = b.nodes[lr[side]].right; }
+                else kids[nk++] = lr[side];
+            }
+        } else {
+            kids[nk++] = b.nodes[it.tmp].left; kids[nk++] = b.nodes[it.tmp].right;
+            while (nk < 4) {
+                int best = -1; float ba = -1.0f;
+                for (int k = 0; k < nk; k++)
+                    if (b.nodes[kids[k]].left >= 0) { float a = b.nodes[kids[k]].b.half_area(); if (a > ba) { ba = a; best = k; } }
+                if (best < 0) break;
+                int t = kids[best];
+                kids[best] = b.nodes[t].left; kids[nk++] = b.nodes[t].right;
+            }
         }
         Box boxes[4];
         for (int k = 0; k < nk; k++) boxes[k] = b.nodes[kids[k]].b;

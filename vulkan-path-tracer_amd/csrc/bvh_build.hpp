@@ -4,6 +4,9 @@
 
 #include "device_types.hpp"
 
+#ifndef VPT_BVH_PAIRWISE
+#define VPT_BVH_PAIRWISE 0
+#endif
 namespace vpt {
 // tris_in: world-space triangles in instance-major order (gid = index). Produces 128 B four-wide nodes
 // (root = node 0) and the triangles permuted into leaf order.
@@ -14,6 +17,9 @@ void build_bvh(const std::vector<BvhTri>& tris_in, std::vector<BvhNode>& nodes_o
 struct BvhBuildOptions {
     bool spatial_splits = false, parallel = true;
     int bins = 16;                                // SAH bins per axis (16: the product; at most 32)
+    // How the binary tree is collapsed four-wide.  false: a node adopts grandchildren largest box first (up to three levels of the binary tree in one node);
+    // true: always the two children's children ("pair-wise").  Same triangles, same leaves; only which inner boxes share a node changes.
+    bool pairwise = VPT_BVH_PAIRWISE;
     std::vector<BvhNode8>* nodes8 = nullptr;      // the eight-wide tree of the BVH8 experiment
     // "split-order" four-wide tree (trace lab VPT_TRACE_VOTE4S): the binary tree collapsed so that slots 0,1 hold the left child's children
     // and slots 2,3 the right child's, with three 8-bit tables (one bit per ray-direction octant) in the mantissas of step_x / step_y that say

@@ -603,8 +603,11 @@ __device__ __forceinline__ bool mem_occluded_vote(const BvhNode* nodes, const Bv
     }
     return occluded;
 }
+#ifndef VPT_FINISH_MIN_BLOCKS   // (-D override: the A/B builds of tests/tools/ab_variants.sh)
+#define VPT_FINISH_MIN_BLOCKS 3
+#endif
 template <bool COUNT, bool STRICT>
-__global__ __launch_bounds__(kTraverseBlock, 3) void k_finish(DeviceScene sc, RenderParams P, PathState ps, StreamState ss, const uint32_t* queue, StreamCounters* sctr,
+__global__ __launch_bounds__(kTraverseBlock, VPT_FINISH_MIN_BLOCKS) void k_finish(DeviceScene sc, RenderParams P, PathState ps, StreamState ss, const uint32_t* queue, StreamCounters* sctr,
                                                              Counters* ctr, uint32_t parity) {
     sc.all_plain = 0u; sc.strict_hits = STRICT ? 1u : 0u;
     const bool rq = (P.flags & VPT_FLAG_RAY_QUERIES) != 0u;

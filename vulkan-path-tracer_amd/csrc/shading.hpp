@@ -442,6 +442,9 @@ __device__ inline void sample_env(const DeviceScene& sc, const RenderParams& P, 
     else { px = ei % w; py = ei / w; }
     float u = ((float)px + x1) / (float)w;
     float sp, cp; sincos_(u * (2.0f * VPT_PI) - VPT_PI, &sp, &cp);
+    // (Measured and not kept, round 6: the two cosines below depend on the texel ROW alone; a per-row table of them, filled on the device by these very
+    // expressions, made the shade stage 1.2 % SLOWER on the atrium and the bust — the stage waits on its gathers, and the table adds a dependent one:
+    // profiles/r06_envrows_pairwise_ab.log.)
     float step = VPT_PI / (float)h;
     float theta0 = (float)py * step;
     float ct = cos_(theta0) * (1.0f - x2) + cos_(theta0 + step) * x2;
