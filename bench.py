@@ -68,7 +68,7 @@ WORKLOADS = {
 }
 EXTRA_WORKLOADS = ("atrium_1080p_d8", "atrium_4k_d8", "glass_bust_1080p_d32")
 
-# Algorithmic bytes per unit for each stage (DESIGN.md §6): state words actually read/written per path or
+# Algorithmic bytes per unit for each stage (DESIGN.md §5, §8): state words actually read/written per path or
 # ray by the algorithm with this build's struct sizes; BVH node/triangle visits are measured, not assumed.
 TRI_BYTES = 48   # triangle record; the node size comes from vpt_stats (64 B quantised BVH4, 128 B fp32 when the BVH rides in LDS)
 EXTEND_FIXED = 4 + 24 + 20          # queue id, origin+direction in, hit record out

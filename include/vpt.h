@@ -206,11 +206,11 @@ typedef struct vpt_config {
      * sample resident.  0 (default): with frames_in_flight == 0 too, batches of 4 x F frames keep F / 2 frames of paths resident (the default schedule
      * described at frames_in_flight); with an explicit frames_in_flight, every sample resident.  A value >= the batch size: every sample resident.
      * Measured trade: profiles/r05_frames_sweep.json
-     * (DESIGN.md section 4 "Path regeneration").  Images do not depend on it, bit for bit.  Reference loop being unrolled: RayGen.slang:28-33,116-159. */
+     * (DESIGN.md §3 "Regeneration by refill").  Images do not depend on it, bit for bit.  Reference loop being unrolled: RayGen.slang:28-33,116-159. */
     uint32_t resident_frames;
 } vpt_config;
 
-/* Spatial splits in the BVH builder (bvh_build.hpp): identical images, pays on scenes of uneven triangle sizes only.
+/* Spatial splits in the BVH builder (bvh_build.hpp): identical images, pays on scenes of uneven triangle sizes only (profiles/REJECTED.md).
  * Per context, never read from the environment: two contexts of one process cannot silently build different trees. */
 #define VPT_BUILD_SBVH 1u
 /* Keep the general instantiation of the whole-path / fused per-bounce kernels even when the scene qualifies for the class-specialised one
@@ -218,8 +218,8 @@ typedef struct vpt_config {
 #define VPT_BUILD_GENERAL_KERNELS 2u
 /* Streams pipeline: never hand the rest of a batch to the one-launch finisher (kernels_path.hip k_finish), i.e. run every bounce of every batch
  * through the stream stages.  By default a small batch (<= 6M samples: a frame or two per call) goes there after three bounces and a large one once
- * the host sees fewer than 262,144 paths alive: seven dependent launches per bounce on a short queue cost more than the finisher's slower
- * per-lane traversal.  Images are identical; this is the A/B switch of that choice. */
+ * the host sees fewer than 262,144 paths alive: seven dependent launches per bounce on a short queue cost more than the finisher's one launch of
+ * persistent waves.  Images are identical; this is the A/B switch of that choice. */
 #define VPT_BUILD_STREAMS_ONLY 4u
 
 /* AUTO = WHOLE where it applies (BVH in LDS, no media, one sample per pixel and frame), FUSED for the other scenes whose BVH fits in LDS next to
@@ -229,7 +229,7 @@ typedef struct vpt_config {
 #define VPT_PIPELINE_STAGED 2u  /* extend -> shade -> connect with compacted queues; traversal on the vote-scheduled persistent kernels */
 #define VPT_PIPELINE_STAGED_SORTED 4u /* STAGED with the shade queue sorted by material class (miss | plain | textured | glass | emissive),
                                        * one shade launch per class, the miss and plain ones specialised.  Bit-identical; measured
-                                       * 10-14 % SLOWER than STAGED on the BASELINE scenes, so AUTO never picks it */
+                                       * 10-14 % SLOWER than STAGED on the BASELINE scenes (profiles/REJECTED.md), so AUTO never picks it */
 #define VPT_PIPELINE_WHOLE 5u  /* ONE launch per batch: persistent waves run every path from its camera ray to its end, a lane whose path has ended takes
                                * the batch's next sample (kernels_path.hip k_whole; the reference's own shape: one RayGen thread = one whole path).
                                * For scenes whose BVH rides in LDS, no media, samples_per_frame == 1, every sample resident — VPT_ERR_UNSUPPORTED
@@ -503,7 +503,7 @@ int vpt_trace_rays(vpt_ctx* ctx, const vpt_ray* rays_host, uint32_t n, vpt_hit* 
  * per pass); here it is one caller-chosen value, so a table is reproducible.  Application.cpp:41,54,67 use
  * sizes 64x64x32 (reflect) and 128x128x32 (refract) with 10'000'000 samples.
  * out_host receives size_x*size_y*size_z floats, x fastest.  Needs no context (runs on `device`).
- * Known disagreement with the shipped tables (DESIGN.md section 5, tests/test_oracle_lut_fp64.py): in the grazing near-mirror corner of
+ * Known disagreement with the shipped tables (DESIGN.md §6, tests/test_oracle_lut_fp64.py): in the grazing near-mirror corner of
  * the two refraction tables (rows y <= 4 with x <= 31, and layer z = 0) this generator — like a float64 evaluation of the same
  * algorithm — gives 0.896 where Assets/LookupTables/RefractionLookup*.bin hold 0.819.  Everywhere else the generated tables match the
  * shipped ones within Monte-Carlo error.  Rendering is unaffected: the integrator consumes whichever tables vpt_set_scene is given. */

@@ -3,7 +3,7 @@
  * NOT part of the drop-in boundary (include/vpt.h) and NOT in the product library: libvpt_hip.so exports none of these symbols.  They exist in
  * libvpt_hip_lab.so, the same sources compiled with -DVPT_LAB=1 (python -m "vulkan-path-tracer_amd._build" --lab; VPT_LAB=1 in the environment makes
  * the Python shim load it), together with every kernel variant that was built, measured against the product kernels and found slower
- * (the baseline traversal loop, the eight-wide tree, stale-entry culling, packed fp32 node arithmetic, ray-slot pools, two
+ * (profiles/REJECTED.md: the baseline traversal loop, the eight-wide tree, stale-entry culling, packed fp32 node arithmetic, ray-slot pools, two
  * rays per lane, round 1's stage kernels = VPT_PIPELINE_STAGED_R1).  tests/tools/trace_lab.py, latency_probe.py, whole_*.py drive them.
  * Images never depend on anything here. */
 #ifndef VPT_LAB_H

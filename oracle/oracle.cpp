@@ -30,7 +30,7 @@
 // The second restatement covers textures, environment importance sampling (alias map included), the medium inside a glass
 // mesh, homogeneous box volumes with all three phase functions and the atmosphere; density grids are outside it.  BVH traversal, scene import and the
 // elementary fp32 functions live in the Vulkan driver / VulkanHelper / Slang: parity for those
-// is UNPINNED (see DESIGN.md); they follow include/vpt_fp32.h on both sides.
+// is UNPINNED (see DESIGN.md §6); they follow include/vpt_fp32.h on both sides.
 //
 // Structure is deliberately the reference's: one scalar "megakernel" per pixel with a simple
 // median-split BVH (or brute force) — nothing here is shared with the HIP wavefront design.
@@ -284,7 +284,7 @@ bool closest_hit_impl(const Oracle& o, V3 org, V3 dir, float tmin, float tmax, H
 // the shadow miss shader, on the NORMALISED direction with TMin 1e-5, TMax 1000; "intersects" = payload.Depth stayed 0 = some triangle was hit.
 // Nothing on that path writes payload.TriangleIdx / InstanceIdx (the closest-hit shader is skipped, MissShadow leaves them alone), so the
 // callers' light-identity compare reads an UNDEFINED word upstream.  Pinned here as "never equal to a sampled light": an emissive-mesh NEE
-// sample is never visible in this mode (its random draws still happen).  DESIGN.md section 5.
+// sample is never visible in this mode (its random draws still happen).  DESIGN.md §6.
 bool does_ray_intersect(const Oracle& o, V3 org, V3 dir, uint32_t& tri, uint32_t& inst, Counters* c) {
     tri = 0; inst = 0;
     Hit h;

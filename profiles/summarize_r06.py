@@ -63,14 +63,14 @@ if any("TA_TA_BUSY_sum" in acc[s] for s in acc):
     for s, (calls, tot) in sorted(dur.items(), key=lambda kv: -kv[1][1]):
         a = acc[s]
         div = lambda x, y: x / y if y else float("nan")
+        have_flops = "SQ_INSTS_VALU_FMA_F32" in a     # (before the lookups below: `a` is a defaultdict)  the fp32-mix / instruction-cache passes are collected for the headline bench only: say so instead of printing zeros
+        have_ic = "SQC_ICACHE_REQ" in a
         fp = a["SQ_INSTS_VALU_ADD_F32"] + a["SQ_INSTS_VALU_MUL_F32"] + a["SQ_INSTS_VALU_FMA_F32"] + a["SQ_INSTS_VALU_TRANS_F32"]
         flop = (a["SQ_INSTS_VALU_ADD_F32"] + a["SQ_INSTS_VALU_MUL_F32"] + a["SQ_INSTS_VALU_TRANS_F32"] + 2 * a["SQ_INSTS_VALU_FMA_F32"]) * 64 * rows[s]["lane_use"]
         tfl = div(flop, tot / 1e9) / 1e12
         rows[s].update({"ta_busy": div(a["TA_TA_BUSY_sum"], 32 * a["GRBM_GUI_ACTIVE"]), "fp32_tflops": tfl,
                         "l1_accesses_per_vmem_rd": div(a["TCP_TOTAL_CACHE_ACCESSES_sum"], a["SQ_INSTS_VMEM_RD"]), "icache_hit": div(a["SQC_ICACHE_HITS"], a["SQC_ICACHE_REQ"])})
         rows[s]["l1_accesses_per_clk_per_cu"] = div(a["TCP_TOTAL_CACHE_ACCESSES_sum"], 256 * (tot / 1e9) * 2.4e9)
-        have_flops = "SQ_INSTS_VALU_FMA_F32" in a     # the fp32-mix / instruction-cache passes are collected for the headline bench only: say so instead of printing zeros
-        have_ic = "SQC_ICACHE_REQ" in a
         nc = "not collected"
         lines.append("| %s | %.0f %% | %.2f | %.1f | %.0f %% | %s | %s | %s | %s | %.2f |" % (
             s, 100 * rows[s]["ta_busy"], rows[s]["l1_accesses_per_clk_per_cu"], rows[s]["l1_accesses_per_vmem_rd"], 100 * div(a["TCP_PENDING_STALL_CYCLES_sum"], a["TCP_GATE_EN1_sum"]),

@@ -48,6 +48,7 @@ res = {"config": "%s %dx%d, %d spp, depth %d, base seed 1%s" % (what, W, H, spp,
        "differing_pixels": diff, "rel_l2": rel, "tolerance_rel_l2": 1e-4, "closest_rays_gpu": int(st["closest_rays"]), "closest_rays_oracle": int(ctr["closest"]),
        "pipeline_kernels": {k: int(v) for k, v in st["kernel_launches"].items() if v},
        "gpu_seconds": round(tg, 3), "gpu_seconds_split": {"create": round(t_create, 3), "set_scene_and_params": round(t_scene, 3), "render_incl_buffer_growth": round(t_render, 3), "read_back_stats_post_close": round(tg - t_create - t_scene - t_render, 3)},
+       "source_id": importlib.import_module("vulkan-path-tracer_amd._build").source_id(), "finish_paths": int(st.get("finish_paths", 0)),
        "batch_frames": int(st["frames_in_flight"]), "resident_frames": int(st["resident_frames"]), "oracle_seconds": round(to, 1), "oracle_threads": os.cpu_count(), "mean_radiance": float(ref[..., :3].mean())}
 if out8 is not None:
     ref8, _ = O.postprocess(ref, vpt.default_post_params())

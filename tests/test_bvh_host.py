@@ -58,7 +58,7 @@ def test_spatial_splits_keep_the_hits_and_cut_the_visits(vpt, oracle, tmp_path):
     """The builder's spatial splits (bvh_build.hpp spatial_splits; vpt_config.build_flags = VPT_BUILD_SBVH in the library, the environment variable VPT_SBVH=1 in this host tool): triangles crossing a
     split plane are referenced from both children with the bounds of their clipped parts.  On the host restatement of the device
     traversal every ray still returns the brute-force hit, and on a scene of uneven triangle sizes (the Viking room) the tree is
-    cheaper to walk; on the uniformly tessellated BASELINE scenes it changes < 1 % (why it is off by default)."""
+    cheaper to walk; on the uniformly tessellated BASELINE scenes it changes < 1 % (why it is off by default, profiles/REJECTED.md)."""
     exe = build_tool(tmp_path)
     sc = vpt.scenes.Scene.load(os.path.join(ROOT, "tests", "golden", "viking_room.npz"))
     o = oracle.Oracle(sc, 8, 8); tris = o.triangles(); o.close()

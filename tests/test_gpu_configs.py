@@ -119,7 +119,7 @@ def test_config4_atrium_4k_matches_the_oracle_on_crops(vpt, oracle, atrium):
 
 def test_config3_known_grazing_samples_with_strict_hits(vpt, oracle):
     """Four (pixel, frame) samples of round 1's full-size run on the 284,880-triangle variant (detail=1.0) in which fp32 gave a grazing ray a hit outside the
-    triangle's own box (DESIGN.md section 5).  With VPT_FLAG_LOCAL_HITS the HIP traversal and the oracle (whatever its
+    triangle's own box (DESIGN.md §6).  With VPT_FLAG_LOCAL_HITS the HIP traversal and the oracle (whatever its
     acceleration structure) agree on them bit for bit; frame k alone is frame 0 of a run whose base seed is 1 + k."""
     from importlib import import_module
     abi = import_module("vulkan-path-tracer_amd._abi")

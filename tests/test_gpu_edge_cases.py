@@ -84,7 +84,7 @@ def test_rays_from_far_outside_the_scene(vpt, oracle, scenes, far):
     the build-time padding does not — the traversal must still find every hit the shared triangle test accepts.
     (Holds up to ~1e3 scene radii.  At 3e4 radii about 0.1 % of the rays differ from brute force: there one ulp of the
     ray origin is larger than the triangles, and no fixed box padding can follow what the fp32 triangle test accepts;
-    the integrator never starts a ray that far from the geometry it can hit: DESIGN.md section 5.)"""
+    the integrator never starts a ray that far from the geometry it can hit: DESIGN.md §6.)"""
     sc = scenes("viking_room")
     rng = np.random.default_rng(11)
     n = 40000

@@ -1,0 +1,125 @@
+"""The DEVICE compile of the shared leaf header (include/vpt_fp32.h) against its HOST compile, bit for bit.
+
+HIP images equal oracle images because both sides compile ONE definition of the leaf arithmetic (sin / cos / pow / log / acos / atan2, normalize, refract,
+Moeller-Trumbore, texel addressing ...).  tests/test_fp32_contract.py holds the host compile of that header against float64; until round 6 the device compile
+was checked only transitively, through whole renders.  Here tests/tools/fp32_device_eval.hip (built with the product's compiler flags) evaluates the
+header's functions on the GPU on large random input sets, edge values included, and every result must carry the bits the host compile (the oracle's
+orc_fp32_eval / orc_leaf_eval) produces — NaNs compared as NaNs of any payload."""
+import importlib
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def tool(tmp_path_factory):
+    B = importlib.import_module("vulkan-path-tracer_amd._build")
+    exe = str(tmp_path_factory.mktemp("fp32dev") / "fp32_device_eval")
+    flags = [f for f in B.FLAGS if f != "-fPIC"] + ["-fno-slp-vectorize"]   # (the traversal files' extra flag: values cannot depend on it either)
+    subprocess.check_call([B.hipcc()] + flags + [os.path.join(ROOT, "tests", "tools", "fp32_device_eval.hip"), "-o", exe])
+    return exe
+
+
+def same_bits(a, b):
+    a, b = np.ascontiguousarray(a, np.float32), np.ascontiguousarray(b, np.float32)
+    nan = np.isnan(a) & np.isnan(b)
+    return bool(np.all((a.view(np.uint32) == b.view(np.uint32)) | nan))
+
+
+def run_elem(tool, tmp_path, fn, x, y):
+    x = np.ascontiguousarray(x, np.float32); y = np.ascontiguousarray(y, np.float32)
+    x.tofile(str(tmp_path / "x.bin")); y.tofile(str(tmp_path / "y.bin"))
+    subprocess.check_call([tool, "elem", str(fn), str(x.size), str(tmp_path / "x.bin"), str(tmp_path / "y.bin"), str(tmp_path / "o.bin")])
+    return np.fromfile(str(tmp_path / "o.bin"), np.float32)
+
+
+EDGE = np.array([0.0, -0.0, 1.0, -1.0, 0.5, -0.5, 2.0, 1e-30, -1e-30, 1e30, 3.4e38, np.inf, -np.inf, np.nan, 1e-45, 0.99999994, 1.0000001, 3.14159274, 6.28318548, 1.57079637], np.float32)
+
+
+@pytest.mark.parametrize("name,code,lo,hi", [("sin", 0, -50.0, 50.0), ("cos", 1, -50.0, 50.0), ("log", 2, 0.0, 1e6), ("exp", 3, -90.0, 90.0), ("asin", 4, -1.0, 1.0), ("acos", 5, -1.0, 1.0)])
+def test_unary_elementary_functions_device_equals_host(tool, oracle, tmp_path, name, code, lo, hi):
+    rng = np.random.RandomState(code + 1)
+    x = np.concatenate([(rng.rand(1 << 20) * (hi - lo) + lo).astype(np.float32), (rng.randn(1 << 16) * 1e-3).astype(np.float32), EDGE])
+    dev = run_elem(tool, tmp_path, code, x, x)
+    assert same_bits(dev, oracle.fp32_eval(name, x)), name
+
+
+def test_atan2_pow_sqrt_division_and_the_unit_float_device_equals_host(tool, oracle, tmp_path):
+    rng = np.random.RandomState(7)
+    y = np.concatenate([(rng.rand(1 << 20) * 8 - 4).astype(np.float32), np.repeat(EDGE, len(EDGE))])
+    x = np.concatenate([(rng.rand(1 << 20) * 8 - 4).astype(np.float32), np.tile(EDGE, len(EDGE))])
+    assert same_bits(run_elem(tool, tmp_path, 6, y, x), oracle.fp32_eval("atan2", y, x))
+    b = np.concatenate([(rng.rand(1 << 20) * 6).astype(np.float32), np.repeat(EDGE, 6)])
+    e = np.concatenate([rng.choice(np.array([2.0, 0.5, 2.2, 1 / 2.2, 5.0, 0.0, 1.0, 3.7], np.float32), 1 << 20), np.tile(np.array([2.0, 0.5, 2.2, 0.0, -1.0, 7.0], np.float32), len(EDGE))])
+    assert same_bits(run_elem(tool, tmp_path, 7, b, e), oracle.fp32_eval("pow", b, e))
+    # IEEE operations the contract relies on being correctly rounded on both sides: sqrt and division (numpy float32 = the host's IEEE operations)
+    p = np.abs(x) * np.float32(1e3)
+    assert same_bits(run_elem(tool, tmp_path, 8, p, p), np.sqrt(p))
+    with np.errstate(all="ignore"):
+        assert same_bits(run_elem(tool, tmp_path, 9, y, x), y / x)
+    # PCG hash -> unit float (the random stream): the input words travel as float bit patterns
+    w = rng.randint(0, 1 << 32, 1 << 18, dtype=np.uint64).astype(np.uint32)
+    L = oracle.lib()
+    ref = np.array([L.orc_uniform_float(L.orc_pcg_hash(int(v))) for v in w[:20000]], np.float32)
+    assert same_bits(run_elem(tool, tmp_path, 10, w.view(np.float32), w.view(np.float32))[:20000], ref)
+
+
+def run_leaf(tool, tmp_path, oracle, name, rows):
+    code, nin, nout = oracle._LEAF[name]
+    rows = np.ascontiguousarray(rows, np.float32).reshape(-1, nin)
+    rows.tofile(str(tmp_path / "in.bin"))
+    subprocess.check_call([tool, "leaf", str(code), str(len(rows)), str(nin), str(nout), str(tmp_path / "in.bin"), str(tmp_path / "o.bin")])
+    return np.fromfile(str(tmp_path / "o.bin"), np.float32).reshape(-1, nout), oracle.leaf_eval(name, rows)
+
+
+def test_ray_triangle_and_hit_is_local_device_equal_host(tool, oracle, tmp_path):
+    rng = np.random.RandomState(21)
+    n = 1 << 19
+    v0 = rng.randn(n, 3) * 3; e1 = rng.randn(n, 3); e2 = rng.randn(n, 3)
+    bary = rng.rand(n, 2) * 1.4 - 0.2                                   # inside, on the edges' neighbourhood, outside
+    target = v0 + e1 * bary[:, :1] + e2 * bary[:, 1:]
+    o = target + rng.randn(n, 3) * np.where(rng.rand(n, 1) < 0.3, 0.01, 5.0)   # 30 % of the rays start very close: grazing and near-plane cases
+    d = target - o; d /= np.maximum(np.linalg.norm(d, axis=1, keepdims=True), 1e-12)
+    d[: n // 8] = rng.randn(n // 8, 3)                                   # unnormalised and unrelated directions too
+    e2[n // 8: n // 8 + 2000] = e1[n // 8: n // 8 + 2000]               # exact slivers: det is a rounding residue
+    rows = np.concatenate([o, d, v0, e1, e2, np.full((n, 1), 1e-4), np.full((n, 1), 1e6)], axis=1)
+    dev, host = run_leaf(tool, tmp_path, oracle, "ray_triangle", rows)
+    assert np.array_equal(dev[:, 0], host[:, 0])
+    hit = host[:, 0] == 1.0
+    assert hit.sum() > n // 4 and (~hit).sum() > n // 8
+    assert same_bits(dev[hit], host[hit])                                # t, u, v of every accepted hit carry the same bits (a rejected one's outputs are unspecified)
+    t = np.where(hit, host[:, 1], 1.0)
+    rows2 = np.concatenate([o, d, v0, e1, e2, t[:, None]], axis=1)
+    dev, host = run_leaf(tool, tmp_path, oracle, "hit_is_local", rows2)
+    assert np.array_equal(dev, host)
+    dev, host = run_leaf(tool, tmp_path, oracle, "triangle_degenerate", np.concatenate([e1, e2], axis=1))
+    assert np.array_equal(dev, host) and host.sum() >= 2000
+
+
+def test_vector_and_texel_leaves_device_equal_host(tool, oracle, tmp_path):
+    rng = np.random.RandomState(33)
+    n = 1 << 18
+    a = rng.randn(n, 3); b = rng.randn(n, 3); b /= np.linalg.norm(b, axis=1, keepdims=True)
+    for name, rows in (("normalize", a * rng.choice([1e-20, 1.0, 1e15], (n, 1))), ("reflect", np.concatenate([a, b], axis=1)),
+                       ("refract", np.concatenate([a / np.linalg.norm(a, axis=1, keepdims=True), b, rng.choice([1.0 / 1.5, 1.5, 1.0, 1.33], (n, 1))], axis=1)),
+                       ("smoothstep", np.concatenate([rng.rand(n, 1), rng.rand(n, 1) + 1.0, rng.rand(n, 1) * 3 - 0.5], axis=1))):
+        dev, host = run_leaf(tool, tmp_path, oracle, name, rows)
+        assert same_bits(dev, host), name
+    u = np.concatenate([rng.rand(n) * 40 - 20, rng.rand(n) * 1e6 - 5e5, [0.0, 1.0, -1.0, 0.5, 1e9, -1e9]])
+    for repeat in (0.0, 1.0):
+        for size in (1, 2, 7, 1024, 4096):
+            rows = np.stack([u, np.full_like(u, size), np.full_like(u, repeat)], axis=1)
+            dev, host = run_leaf(tool, tmp_path, oracle, "texel_coords", rows)
+            assert same_bits(dev, host), (repeat, size)
+    dev, host = run_leaf(tool, tmp_path, oracle, "lut_layer", np.stack([rng.rand(n) * 40 - 4, np.full(n, 32.0)], axis=1))
+    assert np.array_equal(dev, host)
+    c = np.concatenate([rng.rand(n) * 1.4 - 0.2, [0.0, 1.0, 0.5, np.nan, np.inf, -np.inf]])
+    dev, host = run_leaf(tool, tmp_path, oracle, "unorm8", c[:, None])
+    assert np.array_equal(dev, host)
+    dev, host = run_leaf(tool, tmp_path, oracle, "unorm8_to_float", np.arange(256.0)[:, None])
+    assert same_bits(dev, host)

@@ -1,4 +1,4 @@
-"""tests/tools/vote_sim (the host model of one wave of the vote-scheduled traversal kernels): every scheduling policy it prices must
+"""tests/tools/vote_sim (the host model of one wave of the vote-scheduled traversal kernels, profiles/NOTEBOOK_r1_r5.md section 4): every scheduling policy it prices must
 return the hits of the product's policy — it walks the PRODUCT tree (csrc/bvh_build.cpp) with the device's quantised slab test restated — and the product
 policy's lane use must stay where the counters put the kernels (roughly half of the 64 lanes), or the tool no longer gauges anything.  CPU only."""
 import os

@@ -26,8 +26,8 @@ _build = __import__("importlib").import_module("vulkan-path-tracer_amd._build")
 FLAGS = _build.FLAGS + ([] if os.environ.get("VPT_NO_FILE_FLAGS") else _build.EXTRA_FLAGS.get("kernels_trace.hip", [])) + os.environ.get("VPT_EXTRA_FLAGS", "").split()
 
 KERNELS = {  # label -> (source file, regex on the mangled name)
-    "k_trace_vote<closest> (extend)": ("kernels_trace.hip", r"_ZN3vpt12k_trace_voteILb0ELb0ELb0E(?:Lb1E(?:Lb0E){0,3}(?:Lb1E)?)?EEv"),
-    "k_trace_vote<closest, lab parameters>": ("kernels_trace.hip", r"_ZN3vpt12k_trace_voteILb0ELb0ELb0ELb0E(?:Lb0E){0,3}EEv"),
+    "k_trace_vote<closest> (extend)": ("kernels_trace.hip", r"_ZN3vpt12k_trace_voteILb0ELb0ELb0E(?:Lb1E(?:Lb0E){0,3}(?:Lb1E)?(?:Lb0E)?)?EEv"),
+    "k_trace_vote<closest, lab parameters>": ("kernels_trace.hip", r"_ZN3vpt12k_trace_voteILb0ELb0ELb0ELb0E(?:Lb0E){0,5}EEv"),
     "k_trace_shadow<sky>": ("kernels_trace.hip", r"_ZN3vpt14k_trace_shadowILb0ELb0E(?:Lb1E(?:Lb0E(?:Lb1E)?)?)?EEv"),
     "k_trace_shadow<light>": ("kernels_trace.hip", r"_ZN3vpt14k_trace_shadowILb1ELb0E(?:Lb1E(?:Lb0E(?:Lb1E)?)?)?EEv"),
 }

@@ -10,7 +10,7 @@ sys.path.insert(0, ROOT)
 B = importlib.import_module("vulkan-path-tracer_amd._build")
 CSRC = os.path.join(ROOT, "vulkan-path-tracer_amd", "csrc")
 # the kernels of the BASELINE configs (bench.py's workloads): demangled-name fragments
-MAIN = ("k_whole<false, false, true>", "k_whole<false, false, false>", "k_shade_stream<-1>", "k_trace_vote<false, false, false, true, false, false, false, true>",
+MAIN = ("k_whole<false, false, true>", "k_whole<false, false, false>", "k_shade_stream<-1>", "k_trace_vote<false, false, false, true, false, false, false, true, false>",
         "k_trace_shadow<true, false, true, false, true>", "k_trace_shadow<false, false, true, false, true>", "k_join", "k_refill_stream", "k_raygen_stream", "k_finish<false, false>", "k_resolve",
         "k_post_final<true, true>", "k_bloom_down<true>", "k_bloom_tail<true>", "k_bloom_up_chain", "k_bloom_down_chain")
 

@@ -1,4 +1,4 @@
-// device_types.hpp — HBM data layout of the wavefront backend (see DESIGN.md §3).
+// device_types.hpp — HBM data layout of the wavefront backend (see DESIGN.md §4).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -36,7 +36,7 @@ static_assert(sizeof(BvhNode) == 64, "node is 64 B");
 // traversal kernels copy into LDS (4 KB per block next to the 14 KB of stacks: 8 blocks per CU still fit the 160 KB).
 constexpr int kBvhTopNodes = 64;
 
-// Eight-wide variant of the quantised node (96 B, 6 x dwordx4) for the BVH8 experiment: same grid
+// Eight-wide variant of the quantised node (96 B, 6 x dwordx4) for the BVH8 experiment (profiles/REJECTED.md): same grid
 // quantisation, eight child boxes, children placed in slots by OCTANT — bit a of a slot index says on which side of the node's
 // centre the child lies along axis a — so that a ray can visit the hit children in the fixed order slot XOR (sign bits of its
 // direction) instead of sorting entry distances.  Unused slots hold the inverted box and a harmless leaf code.

@@ -655,7 +655,7 @@ __global__ __launch_bounds__(kTraverseBlock, 8) void k_trace_shadow(DeviceScene 
 // The PRODUCT library holds four instantiations of k_trace_vote (closest hit: default, counting, validating, validating + counting — the
 // pipeline always runs the compile-time vote parameters) and eight of k_trace_shadow.  Everything else — the baseline loop, the eight-wide
 // tree, culling, packed arithmetic, ray pools, ray pairs, the one-triangle step for the A/B, run-time vote parameters, any-hit k_trace_vote —
-// was measured slower and lives in the LABORATORY build only (-DVPT_LAB=1: libvpt_hip_lab.so, include/vpt_lab.h, tests/tools/trace_lab.py).
+// was measured slower (profiles/REJECTED.md) and lives in the LABORATORY build only (-DVPT_LAB=1: libvpt_hip_lab.so, include/vpt_lab.h, tests/tools/trace_lab.py).
 int trace_blocks_per_cu(uint32_t variant, bool any) {
     int nb = 0;
 #if VPT_LAB
