@@ -180,7 +180,7 @@ typedef struct vpt_config {
     uint32_t shard_rank; /* this context renders rows y with y % shard_count == shard_rank */
     uint32_t shard_count;/* 1 = whole image */
     uint32_t frames_in_flight; /* largest batch (frames per wavefront batch) the context will hold; 0 = ~448M paths (226 frames at 1080p), never more than 60 % of
-                                * the free device memory, at most 2048 frames.  This is a CAP, not an allocation: vpt_create allocates the path records of ONE
+                                * the free device memory, at most 8192 frames.  This is a CAP, not an allocation: vpt_create allocates the path records of ONE
                                 * frame (~0.8 GB at 1080p) and the buffers grow to the largest batch a vpt_render / vpt_render_async call actually asks for
                                 * (min(dispatches, cap) frames, 380 B per path; vpt_stats.frames_allocated) — an interactive host that renders a frame per
                                 * call never holds more than that one frame.  Contexts whose batches run as whole-path launches (VPT_PIPELINE_WHOLE, or AUTO

@@ -91,7 +91,7 @@ def test_ray_triangle_and_hit_is_local_device_equal_host(tool, oracle, tmp_path)
     dev, host = run_leaf(tool, tmp_path, oracle, "ray_triangle", rows)
     assert np.array_equal(dev[:, 0], host[:, 0])
     hit = host[:, 0] == 1.0
-    assert hit.sum() > n // 4 and (~hit).sum() > n // 8
+    assert hit.sum() > n // 8 and (~hit).sum() > n // 8   # (the input set exercises both outcomes: ~23 % hits)
     assert same_bits(dev[hit], host[hit])                                # t, u, v of every accepted hit carry the same bits (a rejected one's outputs are unspecified)
     t = np.where(hit, host[:, 1], 1.0)
     rows2 = np.concatenate([o, d, v0, e1, e2, t[:, None]], axis=1)

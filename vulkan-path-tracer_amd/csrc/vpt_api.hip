@@ -19,7 +19,9 @@
 using namespace vpt;
 
 constexpr uint64_t kBytesPerPath = 380;          // core slot records 68 + stream records ~290 (slack included) + queues 8 + image share
-constexpr uint32_t kMaxFramesInFlight = 2048;   // frames of one batch (a 1/8 shard of 1080p holds ~448M paths at 1728 frames)
+constexpr uint32_t kMaxFramesInFlight = 8192;   // frames of one batch.  A 1/8 shard of 1080p holds ~448M paths at 1728 frames and its default batch is four times that
+                                                // (6912 frames = 1.79 G samples, what a whole 1080p image renders per batch at 904 frames): with round 5's bound of 2048 a rank of an 8-GPU
+                                                // job rendered 3.5 x shorter batches than a 1-GPU job, i.e. bench.py's "weak" scaling did not keep the per-rank work fixed
 constexpr uint64_t kResidentPaths = 448ull << 20;   // samples of a batch by default (see check_render_size)
 // The rest of a streams batch goes to k_finish (kernels_path.hip) — one launch instead of seven per bounce —
 //  * after kFinishAfterBounces (3) bounces when the batch is small from the start (a frame or two per call: its launches never fill the chip for long), and
