@@ -543,12 +543,6 @@ __global__ __launch_bounds__(kTraverseBlock, 5) void k_trace_pair(DeviceScene sc
 // looks for anything that beats it (traverse.hpp closest_is).
 // TRI2: up to two triangles of a leaf per triangle step (vote.hpp vote_tri2_step_any: -3 ... -6 % on atrium and bust shadow rays, profiles/r04_trace_lab_tri2_*.json); the
 // product instantiation only — the counting and the validating ones keep the one-triangle step, so the visit statistics stay what a ray needs.
-// OCCLUDER CACHE (VPT_SHADOW_CACHE, the TRI2 product instantiations only): a lane remembers the triangle that stopped its last search and tests a new ray
-// against it before descending — an any-hit search may stop at ANY triangle that satisfies the predicate, so finding one without the tree is the same
-// answer.  Rays a lane takes one after the other are neighbours in the stream, i.e. mostly neighbours in the image.
-#ifndef VPT_SHADOW_CACHE
-#define VPT_SHADOW_CACHE 0
-#endif
 template <bool LIGHT, bool COUNT, bool TUNED, bool STRICT = false, bool TRI2 = false>
 __global__ __launch_bounds__(kTraverseBlock, 8) void k_trace_shadow(DeviceScene sc, const float4* RO, const float4* RD, unsigned char* vis, const uint32_t* n_dev,
                                                                   uint32_t* head, Counters* ctr, uint32_t param, uint32_t ray_queries) {
@@ -576,8 +570,6 @@ __global__ __launch_bounds__(kTraverseBlock, 8) void k_trace_shadow(DeviceScene 
     V3 o = vptfp::v3(0.0f, 0.0f, 0.0f), d = o, inv = o;
     float tlim = tmax;
     uint32_t st_nodes = 0u, st_tris = 0u;
-    constexpr bool kCache = VPT_SHADOW_CACHE != 0 && TRI2 && !STRICT && !COUNT;
-    uint32_t cslot = 0xffffffffu;   // kCache: leaf slot of the triangle that stopped this lane's last search
     while (true) {   // fetch steps outside, node / triangle steps in the inner loop, one kind per iteration (kernels_trace.hip k_trace_vote)
         while (true) {
             VPT_MARK("vote");
@@ -595,7 +587,7 @@ __global__ __launch_bounds__(kTraverseBlock, 8) void k_trace_shadow(DeviceScene 
             VPT_MARK("tri");
             if (!node_wins & at_leaf) {
                 if (COUNT) st_tris++;
-                if (TRI2) { if (vote_tri2_step_any(tris, S, cur, sp, o, d, tmin, tmax, tlim, expect, kCache ? &cslot : nullptr)) visible = false; }
+                if (TRI2) { if (vote_tri2_step_any(tris, S, cur, sp, o, d, tmin, tmax, tlim, expect)) visible = false; }
                 else if (vote_tri_step_any<STRICT>(tris, S, cur, sp, o, d, tmin, tmax, tlim, expect)) visible = false;
             }
         }
@@ -643,15 +635,6 @@ __global__ __launch_bounds__(kTraverseBlock, 8) void k_trace_shadow(DeviceScene 
                             // it hits nothing at all — then this becomes a plain occlusion query; otherwise the sample is not visible
                             if (rd.w != 0.0f) { tlim = tmax; expect = 0xffffffffu; }
                             else { visible = false; cur = kLaneDone; }
-                        }
-                    }
-                    if (kCache) {
-                        if (cur == 0 && cslot != 0xffffffffu) {   // the last occluder first
-                            const float4* q = reinterpret_cast<const float4*>(tris + cslot);
-                            const float4 ta = q[0], tb = q[1], tc = q[2];
-                            float t, u, v;
-                            const bool hit = ray_triangle_flat(o, d, vptfp::v3(ta.x, ta.y, ta.z), vptfp::v3(ta.w, tb.x, tb.y), vptfp::v3(tb.z, tb.w, tc.x), tmin, tmax, t, u, v);
-                            if (hit & ((t < tlim) | ((t == tlim) & (__float_as_uint(tc.w) < expect)))) { visible = false; cur = kLaneDone; }
                         }
                     }
                 }

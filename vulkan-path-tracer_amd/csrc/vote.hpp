@@ -293,9 +293,7 @@ __device__ __forceinline__ void vote_tri2_step_closest(const BvhTri* tris, const
     if (more >= 2u) cur = ~(int)((((uint32_t)first + 2u) << 3) | (more - 2u));
     else S.pop_or_done(sp, cur);
 }
-// `stopper` (optional): receives the leaf slot of the triangle that stopped the search (the occluder cache of k_trace_shadow)
-__device__ __forceinline__ bool vote_tri2_step_any(const BvhTri* tris, const LaneStack& S, int& cur, int& sp, V3 o, V3 d, float tmin, float tmax, float tlim, uint32_t expect,
-                                                   uint32_t* stopper = nullptr) {
+__device__ __forceinline__ bool vote_tri2_step_any(const BvhTri* tris, const LaneStack& S, int& cur, int& sp, V3 o, V3 d, float tmin, float tmax, float tlim, uint32_t expect) {
     const uint32_t enc = (uint32_t)(~cur);
     const int first = (int)(enc >> 3);
     const uint32_t more = enc & 7u;
@@ -305,12 +303,11 @@ __device__ __forceinline__ bool vote_tri2_step_any(const BvhTri* tris, const Lan
     float t, u, v;
     bool hit = ray_triangle_flat(o, d, vptfp::v3(ta.x, ta.y, ta.z), vptfp::v3(ta.w, tb.x, tb.y), vptfp::v3(tb.z, tb.w, tc.x), tmin, tmax, t, u, v);
     bool stop = hit & ((t < tlim) | ((t == tlim) & (__float_as_uint(tc.w) < expect)));
-    const bool stop0 = stop;
     if (more) {
         hit = ray_triangle_flat(o, d, vptfp::v3(ua.x, ua.y, ua.z), vptfp::v3(ua.w, ub.x, ub.y), vptfp::v3(ub.z, ub.w, uc.x), tmin, tmax, t, u, v);
         stop = stop | (hit & ((t < tlim) | ((t == tlim) & (__float_as_uint(uc.w) < expect))));
     }
-    if (stop) { if (stopper) *stopper = (uint32_t)first + (stop0 ? 0u : 1u); cur = kLaneDone; return true; }
+    if (stop) { cur = kLaneDone; return true; }
     if (more >= 2u) cur = ~(int)((((uint32_t)first + 2u) << 3) | (more - 2u));
     else S.pop_or_done(sp, cur);
     return false;
