@@ -922,24 +922,18 @@ __device__ __forceinline__ V3 whole_finish(const RenderParams& P, const PathStat
 // without an atomic, and the tiles behind them `chunk_tiles` at a time through ctr->extend_head (the host picks both: vpt_api.hip whole_schedule).
 // (Measured and not kept: one-wave blocks, which leave the CU as soon as THEIR paths have ended and so let the next frame's launch in earlier —
 // a 1-frame launch at 1080p 542 us against 509 us, and slower with two or three frames in flight too: profiles/r04_whole_lanes.json.)
-// MEM (round 6 experiment, VPT_PIPELINE_WHOLE forced on a scene whose BVH lives in memory): the same loop with the searches on the tree in memory —
-// the wave-level vote of the stream kernels (mem_closest_vote / mem_occluded_vote above; the validating instantiation keeps per-lane loops), every lane of
-// the wave in the call.  A frame per call then costs ONE launch instead of three bounces of seven stream launches + the finisher.
-template <bool COUNT, bool STRICT, bool PLAIN, bool MEM = false>
+template <bool COUNT, bool STRICT, bool PLAIN>
 __global__ __launch_bounds__(kTraverseBlock, 3) void k_whole(DeviceScene sc, RenderParams P, PathState ps, Counters* ctr, uint32_t n_slots, uint32_t dispatch_base,
                                                             uint32_t static_rounds, uint32_t chunk_tiles) {
-    static_assert(!(MEM && PLAIN), "the class-specialised instantiation is for scenes that ride in LDS");
     sc.strict_hits = STRICT ? 1u : 0u;
     if (PLAIN) { sc.all_plain = 1u; sc.env_black = 1u; } else sc.all_plain = 0u;
     if (P.dispatch_base_dev) dispatch_base = *P.dispatch_base_dev;   // a replayed graph: the batch's first dispatch index lives in device memory
     const bool rq = (P.flags & VPT_FLAG_RAY_QUERIES) != 0u;
     extern __shared__ __align__(16) unsigned char smem[];
     const TravStack stack = make_stack(smem, sc.stack_overflow);
-    const LaneStack S = make_lane_stack(smem, sc.stack_overflow);   // MEM: the same rows as the vote steps address them
-    TreeTop top0; top0.lds = nullptr; top0.count = 0;               // MEM: no LDS copy of the tree top (the rings take the LDS)
     float4* lds_nodes = reinterpret_cast<float4*>(smem + kStackDepth * kTraverseBlock * 4);
     float4* lds_tris = lds_nodes + sc.node_count * 8;
-    if constexpr (!MEM) stage_scene<true>(sc, lds_nodes, lds_tris);
+    stage_scene<true>(sc, lds_nodes, lds_tris);
     constexpr uint32_t kWaves = kTraverseBlock / 64u;
     __shared__ uint32_t r_slot[kWaves][128], r_prim[kWaves][128], r_inst[kWaves][128];
     __shared__ float r_t[kWaves][128], r_u[kWaves][128], r_v[kWaves][128];
@@ -970,68 +964,6 @@ __global__ __launch_bounds__(kTraverseBlock, 3) void k_whole(DeviceScene sc, Ren
             const bool valid = lane_id() < cnt;
             uint32_t nrays = 0u;
             bool first = false, alive = false;
-            if constexpr (MEM) {
-                ShadeIn in_;
-                ShadeOut o;
-                o.want_sky = false; o.want_light = false;
-                V3 light_prev = v3s(0.0f);
-                if (valid) {
-                    const uint32_t q = (hit_head + lane_id()) & 127u;
-                    const float4 a = r_ra[wave][q], b = r_rb[wave][q], t = r_rt[wave][q];
-                    slot = r_slot[wave][q];
-                    in_.rng = __float_as_uint(a.w);
-                    in_.porg = xyz(a); in_.pdir = xyz(b);
-                    const uint32_t dw = __float_as_uint(b.w);
-                    in_.depth = dw & 0x7fffffffu; in_.in_medium = (dw >> 31) != 0u;
-                    in_.thr_prev = xyz(t); in_.prev_pdf = t.w;
-                    in_.vdepth = 0u; in_.cchan = -1; in_.vol_index = -1; in_.vol_t = 0.0f; in_.atm_comp = -1;
-                    in_.h = make_float4(r_t[wave][q], r_u[wave][q], r_v[wave][q], __uint_as_float(r_prim[wave][q]));
-                    in_.inst = r_inst[wave][q];
-                    first = in_.depth == 0u;
-                    shade_core<false, (int)kShadeTextured>(sc, P, ps, slot, in_, o);
-                    light_prev = first ? v3s(0.0f) : xyz(ps.ACC[slot]);
-                }
-                const bool q_sky = valid && o.want_sky, q_light = valid && o.want_light;
-                bool vis_sky = false, vis_light = false;
-                if constexpr (STRICT) {
-                    if (q_sky) vis_sky = sky_visible<false, COUNT>(sc, nullptr, nullptr, o.sky_o, o.sky_d, stack, sst, rq);
-                    if (q_light) vis_light = light_visible<false, COUNT>(sc, nullptr, nullptr, o.light_o, o.light_d, o.light_gid, stack, sst);
-                } else {
-                    if (__ballot(q_sky) != 0ull) {
-                        const float tmin = rq ? 0.0001f : 0.00001f, tmax = rq ? 1000000.0f : 1000.0f;
-                        const V3 sd = rq ? o.sky_d : normalize(o.sky_d);
-                        vis_sky = !mem_occluded_vote<COUNT>(sc.nodes, sc.tris, top0, S, q_sky, o.sky_o, sd, tmin, tmax, tmax, 0xffffffffu, sst);
-                    }
-                    if (__ballot(q_light) != 0ull) {   // traverse.hpp closest_is
-                        bool search = false;
-                        float t_e = 0.0f;
-                        if (q_light) {
-                            const uint32_t lslot = sc.tri_slot_of_gid[o.light_gid];
-                            if (lslot != 0xffffffffu) {
-                                const float4* qq = reinterpret_cast<const float4*>(sc.tris + lslot);
-                                const float4 ta = qq[0], tb = qq[1], tc = qq[2];
-                                if (COUNT) sst.tris++;
-                                float u, v;
-                                search = vptfp::ray_triangle(o.light_o, o.light_d, vptfp::v3(ta.x, ta.y, ta.z), vptfp::v3(ta.w, tb.x, tb.y), vptfp::v3(tb.z, tb.w, tc.x), 0.0001f, 1000000.0f, &t_e, &u, &v);
-                            }
-                        }
-                        const bool occ = mem_occluded_vote<COUNT>(sc.nodes, sc.tris, top0, S, search, o.light_o, o.light_d, 0.0001f, 1000000.0f, t_e, o.light_gid, sst);
-                        vis_light = search && !occ;
-                    }
-                }
-                nrays = (q_sky ? 1u : 0u) + (q_light ? 1u : 0u);
-                if (valid) {
-                    V3 E = o.emitted;
-                    if (q_sky && vis_sky) E = E + o.csky;
-                    if (q_light && vis_light) E = E + o.clight;
-                    const V3 light = whole_finish(P, ps, slot, E, in_.thr_prev, light_prev, o);
-                    alive = o.alive;
-                    if (alive) {
-                        has_ray = true;
-                        rng_s = o.rng; porg = o.new_o; pdir = o.new_d; depth = o.new_depth; in_medium = o.in_medium; thr = o.thr; pdf = o.new_pdf; lightp = light;
-                    }
-                }
-            } else
             if (valid) {
                 const uint32_t q = (hit_head + lane_id()) & 127u;
                 ShadeIn in_;
@@ -1130,10 +1062,8 @@ __global__ __launch_bounds__(kTraverseBlock, 3) void k_whole(DeviceScene sc, Ren
         {
             HitRec hr;
             bool hit = false;
-            if constexpr (MEM && !STRICT) hit = mem_closest_vote<COUNT>(sc.nodes, sc.tris, top0, S, has_ray, porg, normalize(pdir), 0.01f, 100000.0f, hr, st);
-            else if (has_ray) {
-                if constexpr (MEM) hit = trace_any<false, COUNT>(sc, nullptr, nullptr, porg, normalize(pdir), 0.01f, 100000.0f, stack, hr, st);
-                else if constexpr (VPT_WHOLE_VOTE != 0 && !STRICT) { LdsSceneSrc src{lds_nodes, lds_tris, false}; hit = lds_closest_vote<COUNT>(src, porg, normalize(pdir), 0.01f, 100000.0f, stack, hr, st); }
+            if (has_ray) {
+                if constexpr (VPT_WHOLE_VOTE != 0 && !STRICT) { LdsSceneSrc src{lds_nodes, lds_tris, false}; hit = lds_closest_vote<COUNT>(src, porg, normalize(pdir), 0.01f, 100000.0f, stack, hr, st); }
                 else hit = trace_any<true, COUNT>(sc, lds_nodes, lds_tris, porg, normalize(pdir), 0.01f, 100000.0f, stack, hr, st);
             }
             const unsigned long long mh = __ballot(has_ray && hit);
@@ -1494,17 +1424,8 @@ void launch_bounce(hipStream_t s, uint32_t blocks, bool lds_scene, bool count, b
 // Whole paths in one launch (k_whole): LDS-resident scenes without media, one sample per pixel and frame.
 void launch_whole(hipStream_t s, uint32_t blocks, bool count, const DeviceScene& sc, const RenderParams& P, const PathState& ps, Counters* ctr, uint32_t n_slots,
                   uint32_t dispatch_base, bool plain, uint32_t static_rounds, uint32_t chunk_tiles) {
-    const bool mem = sc.nodes_wide == nullptr;   // the BVH lives in memory: the MEM instantiations (stacks only in dynamic LDS)
-    const size_t lds = traverse_lds_bytes(sc, !mem);
+    const size_t lds = traverse_lds_bytes(sc, true);
     const dim3 g(blocks), b(kTraverseBlock);
-    if (mem) {
-#define VPT_LWM(C, S) hipLaunchKernelGGL((k_whole<C, S, false, true>), g, b, lds, s, sc, P, ps, ctr, n_slots, dispatch_base, static_rounds, chunk_tiles)
-        if (sc.strict_hits) { if (count) VPT_LWM(true, true); else VPT_LWM(false, true); }
-        else if (count) VPT_LWM(true, false);
-        else VPT_LWM(false, false);
-#undef VPT_LWM
-        return;
-    }
 #define VPT_LW(C, S, PL) hipLaunchKernelGGL((k_whole<C, S, PL>), g, b, lds, s, sc, P, ps, ctr, n_slots, dispatch_base, static_rounds, chunk_tiles)
     if (plain && !count && !sc.strict_hits && sc.env_black) VPT_LW(false, false, true);
     else if (sc.strict_hits) { if (count) VPT_LW(true, true, false); else VPT_LW(false, true, false); }
@@ -1531,13 +1452,6 @@ int finish_blocks_per_cu(const DeviceScene& sc) {
 }
 int whole_blocks_per_cu(const DeviceScene& sc, bool plain) {
     int nb = 0;
-    if (sc.nodes_wide == nullptr) {   // the BVH lives in memory
-        int a = 0, b = 0;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_whole<false, false, false, true>, kTraverseBlock, traverse_lds_bytes(sc, false));
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_whole<false, true, false, true>, kTraverseBlock, traverse_lds_bytes(sc, false));
-        nb = a < b ? a : b;
-        return nb > 0 ? nb : 1;
-    }
     const size_t lds = traverse_lds_bytes(sc, true);
     if (plain) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_whole<false, false, true>, kTraverseBlock, lds);
     else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_whole<false, false, false>, kTraverseBlock, lds);

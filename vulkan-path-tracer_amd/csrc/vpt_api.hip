@@ -416,15 +416,14 @@ int alloc_render_buffers(vpt_ctx* c) {
 
 // One launch per batch (kernels_path.hip k_whole): the scene rides in LDS, no media, one sample per pixel and frame.
 // VPT_PIPELINE_WHOLE asks for it; AUTO takes it wherever it applies (lab_whole_frames bounds the batch size, for the A/B).
-// (round 6: a scene whose BVH lives in memory qualifies too — k_whole<MEM> — but only when VPT_PIPELINE_WHOLE asks for it: AUTO keeps the streams there)
 bool whole_possible(const vpt_ctx* c) {
     const bool vol = !c->volumes.empty() || c->dsc.atm_on;
-    return c->has_scene && c->whole_blocks > 0 && !vol && c->P.samples_per_frame == 1u;
+    return c->has_scene && c->lds_scene && c->whole_blocks > 0 && !vol && c->P.samples_per_frame == 1u;
 }
 // ... as far as scene, parameters and configuration go (the buffers are the callers' business)
 bool whole_policy(const vpt_ctx* c, uint32_t frames) {
     if (!whole_possible(c)) return false;
-    return c->cfg.pipeline == VPT_PIPELINE_WHOLE || (c->cfg.pipeline == VPT_PIPELINE_AUTO && c->lds_scene && frames <= c->lab_whole_frames);
+    return c->cfg.pipeline == VPT_PIPELINE_WHOLE || (c->cfg.pipeline == VPT_PIPELINE_AUTO && frames <= c->lab_whole_frames);
 }
 // Does a batch of `frames` frames need only its per-sample buffers (36 B per sample: frame sum, medium state), not the ~290 B of records per
 // resident path?  A whole-path launch keeps its paths in registers (vpt_config.resident_frames means nothing to it: no path of it is resident in memory).
@@ -1441,7 +1440,7 @@ int vpt_set_scene(vpt_ctx* c, const vpt_scene_desc* sd) {
     c->primary_blocks_general = bounce_blocks_per_cu(c->lds_scene, D, false) * c->cu_count;
     c->primary_blocks_plain = bounce_blocks_per_cu(c->lds_scene, D, true) * c->cu_count;
     c->primary_blocks = std::max(c->primary_blocks_general, c->primary_blocks_plain);   // (sizes the spill regions below; update_depth_bounded picks the grid)
-    c->whole_blocks = std::max(whole_blocks_per_cu(D, false), c->lds_scene ? whole_blocks_per_cu(D, true) : 0) * c->cu_count;
+    c->whole_blocks = c->lds_scene ? std::max(whole_blocks_per_cu(D, false), whole_blocks_per_cu(D, true)) * c->cu_count : 0;
     c->shade_stream_blocks = shade_stream_blocks_per_cu() * c->cu_count;
     c->finish_blocks = finish_blocks_per_cu(D) * c->cu_count;
     c->shade_media_blocks = shade_media_blocks_per_cu() * c->cu_count;
