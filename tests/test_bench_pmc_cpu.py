@@ -103,3 +103,22 @@ def test_roofline_prefers_the_live_entry_and_keeps_the_files_figures(bench):
     failed = (None, {"error": "rocprofv3 not found"})
     r2 = bench.roofline_for("cornell_1080p_d8", prof, failed)
     assert r2["pmc"]["source"] == "profiles/traffic.json" and r2["pmc"]["live_failed"]["error"] == "rocprofv3 not found"
+
+
+def test_kernel_table_prices_the_finisher_with_its_own_units(bench):
+    """A streams batch whose tail ran in the one-launch finisher (k_finish, timed under "bounce"): round 5's table took the finisher's launches for fused
+    bounces and priced the raygen launch and the finisher with the fused kernels' units — 138 x the HBM peak on the driver's glass-bust block.  The finisher's
+    unit is a path-bounce it ran, its records cross HBM once per path taken over, and the stream stages count only the rays they traced."""
+    K = ("primary", "extend", "shade", "connect", "bounce", "resolve", "bloom", "tonemap", "shadow", "join")
+    launches = dict.fromkeys(K, 0); ms = dict.fromkeys(K, 0.0)
+    launches.update(primary=25, extend=24, shade=24, shadow=48, join=24, bounce=1, resolve=4)
+    ms.update(primary=20.0, extend=140.0, shade=150.0, shadow=60.0, join=40.0, bounce=1.75, resolve=4.0)
+    st = {"samples": 1_874_534_400, "closest_rays": 6_085_799_731, "shadow_rays": 2_031_925_852, "connect_paths": 1_900_000_000, "primary_hits": 0, "primary_survivors": 0, "primary_shadow_rays": 0,
+          "finish_paths": 41_893, "finish_closest_rays": 294_015, "finish_shadow_rays": 98_000, "bvh_node_bytes": 64, "frames_in_flight": 904, "kernel_launches": launches, "kernel_ms": ms}
+    tc = {"nodes_per_closest_ray": 9.0, "tris_per_closest_ray": 2.0, "nodes_per_shadow_ray": 10.0, "tris_per_shadow_ray": 3.0}
+    t = bench.kernel_table(st, tc)
+    assert set(t) == {"primary", "extend", "shade", "shadow", "join", "bounce", "resolve"}
+    assert t["bounce"]["units_per_launch"] == 294_015 and t["bounce"]["record_bytes_per_unit"] < 100.0
+    assert t["primary"]["record_bytes_per_unit"] == 68.0                      # the raygen launch of the streams, not the fused bounce 0
+    assert abs(t["extend"]["units_per_launch"] - (6_085_799_731 - 294_015) / 24) < 1.0
+    assert all(0 < k["records_GBs"] <= 8000.0 for k in t.values()), {n: k["records_GBs"] for n, k in t.items()}
